@@ -1,0 +1,228 @@
+"""ctypes harness for oracle/liboracle_photo_icp.so -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
+product package rgbd360_amd never does (it fails loudly when its HIP library is missing instead).
+PARITY UNPINNED (see photo_icp_ref.cpp header): the reference has no golden vectors for this path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle_photo_icp.so")
+
+PHOTO_CONSISTENCY, DEPTH_CONSISTENCY, PHOTO_DEPTH = 0, 1, 2
+PLANES = {"gray_src": 0, "gray_trg": 1, "depth_src": 2, "depth_trg": 3, "gx": 4, "gy": 5, "dgx": 6, "dgy": 7}
+
+
+class Params(C.Structure):
+    _fields_ = [("n_pyr", C.c_int), ("min_depth", C.c_float), ("max_depth", C.c_float), ("sigma_photo", C.c_float),
+                ("sigma_depth", C.c_float), ("thres_sal_photo", C.c_float), ("thres_sal_depth", C.c_float),
+                ("max_iters", C.c_int), ("tol_residual", C.c_float), ("tol_update", C.c_float), ("mask_seams", C.c_int),
+                ("math_mode", C.c_int), ("reduce_mode", C.c_int)]
+
+
+class Result(C.Structure):
+    _fields_ = [("status", C.c_int), ("iters", C.c_int * 8), ("sso", C.c_float), ("err_final", C.c_double),
+                ("rms_photo", C.c_double), ("rms_depth", C.c_double), ("hessian", C.c_float * 36),
+                ("gradient", C.c_float * 6)]
+
+
+class Trace(C.Structure):
+    _fields_ = [("level", C.c_int), ("it", C.c_int), ("accepted", C.c_int), ("error", C.c_double),
+                ("new_error", C.c_double), ("pose", C.c_float * 16), ("update", C.c_float * 6), ("n_valid", C.c_long)]
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "photo_icp_ref.cpp")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle_photo_icp.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        L.oracle_create.restype = C.c_void_p
+        L.oracle_create.argtypes = [C.POINTER(Params)]
+        L.oracle_destroy.argtypes = [C.c_void_p]
+        L.oracle_set_modes.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        for f in (L.oracle_set_target, L.oracle_set_source):
+            f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int]
+        L.oracle_align360.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(Result)]
+        L.oracle_trace_len.argtypes = [C.c_void_p]
+        L.oracle_trace_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(Trace)]
+        L.oracle_level_dims.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.oracle_get_plane.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.oracle_prepare_level.argtypes = [C.c_void_p, C.c_int]
+        L.oracle_get_lut.argtypes = [C.c_void_p, C.c_void_p]
+        L.oracle_error.restype = C.c_double
+        L.oracle_error.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long)]
+        L.oracle_hessgrad.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.POINTER(C.c_long)]
+        L.oracle_gn_step.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_forced_iters.restype = C.c_double
+        L.oracle_forced_iters.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.oracle_warp_indices.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.oracle_asinf_poly.restype = C.c_float
+        L.oracle_asinf_poly.argtypes = [C.c_float]
+        L.oracle_atan2f_poly.restype = C.c_float
+        L.oracle_atan2f_poly.argtypes = [C.c_float, C.c_float]
+        L.oracle_round_half_away.restype = C.c_float
+        L.oracle_round_half_away.argtypes = [C.c_float]
+        L.oracle_weight_huber.restype = C.c_float
+        L.oracle_weight_huber.argtypes = [C.c_float, C.c_float]
+        L.oracle_rank6.argtypes = [C.c_void_p]
+        L.oracle_inverse6.argtypes = [C.c_void_p, C.c_void_p]
+        L.oracle_se3_pseudo_exp.argtypes = [C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def default_params(**kw) -> Params:
+    p = Params()
+    lib().oracle_default_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def pose_to_cm(T) -> np.ndarray:
+    """4x4 (row-major numpy) -> 16 floats column-major (Eigen layout at the ABI)."""
+    return np.ascontiguousarray(np.asarray(T, dtype=np.float32).reshape(4, 4).T.reshape(16))
+
+
+def pose_from_cm(v) -> np.ndarray:
+    return np.asarray(v, dtype=np.float32).reshape(4, 4).T.copy()
+
+
+class Oracle:
+    """Mirror of the RegisterPhotoICP call sequence (RPI.h:480-516, 4519) on the CPU restatement."""
+
+    def __init__(self, **params):
+        self.params = default_params(**params)
+        self.h = C.c_void_p(lib().oracle_create(C.byref(self.params)))
+        self.result = Result()
+
+    def close(self):
+        if self.h:
+            lib().oracle_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_modes(self, math_mode: int, reduce_mode: int):
+        lib().oracle_set_modes(self.h, math_mode, reduce_mode)
+
+    def _set(self, fn, rgb, depth):
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        assert rgb.ndim == 3 and rgb.shape[2] == 3
+        if depth.dtype == np.uint16:
+            d, dt = np.ascontiguousarray(depth), 0
+        else:
+            d, dt = np.ascontiguousarray(depth, dtype=np.float32), 1
+        rows, cols = d.shape
+        fn(self.h, _ptr(rgb), rgb.strides[0], _ptr(d), d.strides[0], dt, rows, cols)
+
+    def set_target(self, rgb, depth):
+        self._set(lib().oracle_set_target, rgb, depth)
+
+    def set_source(self, rgb, depth):
+        self._set(lib().oracle_set_source, rgb, depth)
+
+    def align360(self, guess=None, method=PHOTO_CONSISTENCY):
+        g = pose_to_cm(np.eye(4) if guess is None else guess)
+        out = np.zeros(16, dtype=np.float32)
+        st = lib().oracle_align360(self.h, _ptr(g), method, _ptr(out), C.byref(self.result))
+        return st, pose_from_cm(out)
+
+    def trace(self):
+        n = lib().oracle_trace_len(self.h)
+        out = []
+        for i in range(n):
+            t = Trace()
+            lib().oracle_trace_get(self.h, i, C.byref(t))
+            out.append(dict(level=t.level, it=t.it, accepted=t.accepted, error=t.error, new_error=t.new_error,
+                            pose=pose_from_cm(list(t.pose)), update=np.array(list(t.update), dtype=np.float32),
+                            n_valid=t.n_valid))
+        return out
+
+    def level_dims(self, level):
+        r, c = C.c_int(), C.c_int()
+        if lib().oracle_level_dims(self.h, level, C.byref(r), C.byref(c)) != 0:
+            raise IndexError(level)
+        return r.value, c.value
+
+    def plane(self, which: str, level: int) -> np.ndarray:
+        r, c = self.level_dims(level)
+        out = np.empty((r, c), dtype=np.float32)
+        if lib().oracle_get_plane(self.h, PLANES[which], level, _ptr(out)) != 0:
+            raise KeyError(which)
+        return out
+
+    def prepare_level(self, level):
+        lib().oracle_prepare_level(self.h, level)
+
+    def lut(self, level) -> np.ndarray:
+        self.prepare_level(level)
+        r, c = self.level_dims(level)
+        out = np.empty((r * c, 3), dtype=np.float32)
+        lib().oracle_get_lut(self.h, _ptr(out))
+        return out
+
+    def error(self, level, pose, method):
+        e2, n = C.c_double(), C.c_long()
+        rms = lib().oracle_error(self.h, level, _ptr(pose_to_cm(pose)), method, C.byref(e2), C.byref(n))
+        return rms, e2.value, n.value
+
+    def hessgrad(self, level, pose, method):
+        H = np.zeros(36, np.float32)
+        g = np.zeros(6, np.float32)
+        Hd = np.zeros(36, np.float64)
+        gd = np.zeros(6, np.float64)
+        nv = C.c_long()
+        lib().oracle_hessgrad(self.h, level, _ptr(pose_to_cm(pose)), method, _ptr(H), _ptr(g), _ptr(Hd), _ptr(gd),
+                              C.byref(nv))
+        return H.reshape(6, 6).T.copy(), g, Hd.reshape(6, 6).T.copy(), gd, nv.value
+
+    def forced_iters(self, level, pose, method, n_iters):
+        out = np.zeros(16, np.float32)
+        e = lib().oracle_forced_iters(self.h, level, _ptr(pose_to_cm(pose)), method, n_iters, _ptr(out))
+        return e, pose_from_cm(out)
+
+    def warp_indices(self, level, pose) -> np.ndarray:
+        r, c = self.level_dims(level)
+        out = np.empty((r * c, 2), dtype=np.int32)
+        lib().oracle_warp_indices(self.h, level, _ptr(pose_to_cm(pose)), _ptr(out))
+        return out
+
+
+def gn_step(H, g, lam, pose):
+    Hc = np.ascontiguousarray(np.asarray(H, np.float32).reshape(6, 6).T.reshape(36))
+    gc = np.ascontiguousarray(np.asarray(g, np.float32))
+    out = np.zeros(16, np.float32)
+    upd = np.zeros(6, np.float32)
+    st = lib().oracle_gn_step(_ptr(Hc), _ptr(gc), float(lam), _ptr(pose_to_cm(pose)), _ptr(out), _ptr(upd))
+    return st, pose_from_cm(out), upd
+
+
+def num_threads() -> int:
+    return int(lib().oracle_num_threads())

@@ -1,0 +1,1008 @@
+// =====================================================================================
+//  oracle/photo_icp_ref.cpp  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+//
+//  CPU restatement of the dense spherical RGB-D alignment path of EduFdez/rgbd360
+//  (RegisterPhotoICP::setTargetFrame / setSourceFrame / alignFrames360 and what they
+//  call).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+//  load this library; the product (rgbd360_amd/) never does.
+//
+//  PARITY UNPINNED: the reference ships no tests, golden vectors or recorded poses for
+//  this path and cannot be compiled here (it needs MRPT, OpenCV,
+//  PCL, Eigen, Boost, none of which is installed).  This file therefore follows the
+//  reference source line by line; every function cites the lines it restates
+//  ("RPI.h" = /root/reference/include/RegisterPhotoICP.h).  Arithmetic that the
+//  reference delegates to third-party libraries is restated from their published
+//  algorithms and marked THIRD-PARTY below:
+//     OpenCV 2.4  cvtColor(CV_RGB2GRAY) on 8U, Mat::convertTo, pyrDown (5x5 binomial)
+//     Eigen 3     fixed-size products, Matrix<float,6,6>::inverse() (partial-pivot LU)
+//     MRPT 1.x    Eigen plugin rank() (ColPivHouseholderQR), CPose3D::exp(.,pseudo=true)
+//
+//  Float semantics: the reference is built by GCC -O3 -mtune=native (top CMakeLists.txt
+//  :77), i.e. x86-64 baseline SSE2: no FMA contraction.  Build this file with
+//  -ffp-contract=off and without fast-math (oracle/Makefile does).
+//
+//  Two switches exist purely for checking the HIP path:
+//    math_mode   0 = libm asinf/atan2f/roundf (reference-faithful)
+//                1 = the branch-free polynomial asinf/atan2f the device kernels use
+//                    (same operations in the same order => warped pixel indices of the
+//                    HIP path can be compared bit-for-bit)
+//    reduce_mode 0 = float32 accumulators for H,g like RPI.h:3117-3195 (OpenMP chunking)
+//                1 = float64 accumulation of the same float32 per-pixel rows (the
+//                    comparison target for the GPU's f32-lane / f64-block reduction)
+// =====================================================================================
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace {
+
+// Miscellaneous.h:43-45 -- truncated literal, type double.
+constexpr double kPI = 3.14159265359;
+// RPI.h:40
+constexpr float kInvalidPoint = -10000.f;
+
+enum { METHOD_PHOTO = 0, METHOD_DEPTH = 1, METHOD_PHOTO_DEPTH = 2 };  // RPI.h:194
+
+struct Params {
+    int   n_pyr;            // RPI.h:204 nPyrLevels(4)
+    float min_depth;        // RPI.h:202 (0.3)
+    float max_depth;        // RPI.h:203 (6.0)
+    float sigma_photo;      // RPI.h:208 stdDevPhoto = 6/255
+    float sigma_depth;      // RPI.h:211 stdDevDepth = 0.2
+    float thres_sal_photo;  // RPI.h:218 (0.01)
+    float thres_sal_depth;  // RPI.h:219 (0.01)
+    int   max_iters;        // RPI.h:4593 (10)
+    float tol_residual;     // RPI.h:4594 (1e-3)
+    float tol_update;       // RPI.h:4595 (1e-4)
+    int   mask_seams;       // RPI.h:4538-4549 (1)
+    int   math_mode;
+    int   reduce_mode;
+};
+
+struct Image {
+    int rows = 0, cols = 0;
+    std::vector<float> d;
+    void alloc(int r, int c) { rows = r; cols = c; d.assign((size_t)r * c, 0.f); }
+    float& at(int r, int c) { return d[(size_t)r * cols + c]; }
+    float at(int r, int c) const { return d[(size_t)r * cols + c]; }
+};
+
+struct IterTrace {          // one record per error evaluation inside alignFrames360
+    int level, it, accepted;
+    double error, new_error;
+    float pose[16];
+    float update[6];
+    long  n_valid;
+};
+
+struct Result {
+    int    status;          // 0 ok, 1 ill-posed, 2 no valid pixels
+    int    iters[8];
+    float  sso;
+    double err_final, rms_photo, rms_depth;
+    float  hessian[36];     // column-major
+    float  gradient[6];
+};
+
+struct Ctx {
+    Params p;
+    std::vector<Image> graySrc, grayTrg, depthSrc, depthTrg, gTrgGx, gTrgGy, dTrgGx, dTrgGy;
+    std::vector<float> lut;         // xyz AoS, 3 floats / pixel (Eigen::Vector3f)
+    int lut_level = -1;
+    float H[36], g[6];              // column-major 6x6, like Eigen
+    double H64[36], g64[6];         // same sums accumulated in double (diagnostics)
+    float sso = 0.f;
+    long  n_visible = 0;
+    double last_err2 = 0, last_err2_photo = 0, last_err2_depth = 0;
+    long  last_nvalid = 0, last_nvalid_photo = 0, last_nvalid_depth = 0;
+    std::vector<IterTrace> trace;
+    bool keep_intermediates = true;  // allocate J arrays per call like RPI.h:2761-2767
+};
+
+// ------------------------------------------------------------------------------------
+// Scalar helpers
+// ------------------------------------------------------------------------------------
+
+// RPI.h:545-554 weightHuber<T>, T = float on this path.
+inline float weightHuber(float error, float regularization) {
+    float error_abs = fabsf(error);
+    if (error_abs < regularization) return 1.f;
+    float weight = sqrtf(2 * regularization * error_abs - regularization * regularization) / error_abs;
+    return weight;
+}
+
+// C round(): half away from zero.  Written with exact float ops so that the device can
+// use the identical sequence.
+inline float round_half_away(float x) {
+    float t = truncf(x);
+    float f = fabsf(x - t);           // exact
+    if (f >= 0.5f) t += copysignf(1.f, x);
+    return t;
+}
+
+// Polynomial asinf / atan2f used by the device kernels (math_mode 1).  Pure float32
+// +,-,*,/,sqrt,fma: IEEE-exact on both x86 and gfx950, hence bit-identical results.
+inline float asinf_poly(float x) {
+    const float c0 = 0.16666672764720836f, c1 = 0.07498809174564633f, c2 = 0.0450107002296682f,
+                c3 = 0.02649427585795898f, c4 = 0.03820645371719902f;
+    float ax = fabsf(x);
+    bool  big = ax >= 0.5f;
+    float z = big ? (1.f - ax) * 0.5f : ax * ax;
+    float s = big ? sqrtf(z) : ax;
+    float p = fmaf(z, c4, c3);
+    p = fmaf(z, p, c2);
+    p = fmaf(z, p, c1);
+    p = fmaf(z, p, c0);
+    float r = fmaf(s * z, p, s);                       // asin(s)
+    if (big) r = 1.57079637f - 2.f * r;                // pi/2 - 2 asin(sqrt((1-|x|)/2))
+    return copysignf(r, x);
+}
+
+inline float atan2f_poly(float y, float x) {
+    const float q0 = -0.3333333195069166f, q1 = 0.19999765993465415f, q2 = -0.14279110844310372f,
+                q3 = 0.11037993832882714f, q4 = -0.08673169371217875f, q5 = 0.06284358078457526f,
+                q6 = -0.03627014369584507f, q7 = 0.01375026672953864f, q8 = -0.00244702708829393f;
+    float ay = fabsf(y), ax = fabsf(x);
+    float mx = fmaxf(ay, ax), mn = fminf(ay, ax);
+    float t = (mx == 0.f) ? 0.f : mn / mx;
+    float s = t * t;
+    float p = fmaf(s, q8, q7);
+    p = fmaf(s, p, q6);
+    p = fmaf(s, p, q5);
+    p = fmaf(s, p, q4);
+    p = fmaf(s, p, q3);
+    p = fmaf(s, p, q2);
+    p = fmaf(s, p, q1);
+    p = fmaf(s, p, q0);
+    float a = fmaf(t * s, p, t);                       // atan(t), t in [0,1]
+    if (ay > ax) a = 1.57079637f - a;
+    if (std::signbit(x)) a = 3.14159274f - a;
+    return copysignf(a, y);
+}
+
+// ------------------------------------------------------------------------------------
+// THIRD-PARTY restatements (OpenCV)
+// ------------------------------------------------------------------------------------
+
+// cv::cvtColor(CV_RGB2GRAY) for CV_8UC3 (OpenCV 2.4 RGB2Gray<uchar>: fixed point, shift 14,
+// coefficients R 4899 / G 9617 / B 1868, rounding term 1<<13), followed by
+// Mat::convertTo(CV_32FC1, 1./255) (cvtScale_<uchar,float,float>: float(src)*float(scale)).
+// Call sites RPI.h:485-486, 502-503.
+void rgb_to_gray_f32(const uint8_t* rgb, size_t step, int rows, int cols, Image& out) {
+    out.alloc(rows, cols);
+    const float scale = (float)(1. / 255);
+    for (int r = 0; r < rows; ++r) {
+        const uint8_t* row = rgb + (size_t)r * step;
+        for (int c = 0; c < cols; ++c) {
+            int v = (4899 * row[3 * c] + 9617 * row[3 * c + 1] + 1868 * row[3 * c + 2] + 8192) >> 14;
+            out.at(r, c) = (float)v * scale;
+        }
+    }
+}
+
+inline int reflect101(int i, int n) {           // cv::BORDER_REFLECT_101
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) {
+        if (i < 0) i = -i;
+        else i = 2 * n - 2 - i;
+    }
+    return i;
+}
+
+// cv::pyrDown on CV_32FC1 with explicit dsize (cols/2, rows/2)  (RPI.h:303).
+// OpenCV 2.4 pyrDown_<FltCast<float,8>>: horizontal 1-4-6-4-1 into row buffers,
+// vertical 1-4-6-4-1, one multiply by 1/256.  Source index 2*x+k, BORDER_REFLECT_101.
+void pyr_down_f32(const Image& src, Image& dst) {
+    const int dr = src.rows / 2, dc = src.cols / 2;
+    dst.alloc(dr, dc);
+    std::vector<float> hbuf((size_t)src.rows * dc);
+    for (int r = 0; r < src.rows; ++r)
+        for (int x = 0; x < dc; ++x) {
+            int c0 = reflect101(2 * x - 2, src.cols), c1 = reflect101(2 * x - 1, src.cols), c2 = 2 * x,
+                c3 = reflect101(2 * x + 1, src.cols), c4 = reflect101(2 * x + 2, src.cols);
+            hbuf[(size_t)r * dc + x] =
+                src.at(r, c2) * 6 + (src.at(r, c1) + src.at(r, c3)) * 4 + src.at(r, c0) + src.at(r, c4);
+        }
+    for (int y = 0; y < dr; ++y) {
+        int r0 = reflect101(2 * y - 2, src.rows), r1 = reflect101(2 * y - 1, src.rows), r2 = 2 * y,
+            r3 = reflect101(2 * y + 1, src.rows), r4 = reflect101(2 * y + 2, src.rows);
+        for (int x = 0; x < dc; ++x) {
+            float v = hbuf[(size_t)r2 * dc + x] * 6 + (hbuf[(size_t)r1 * dc + x] + hbuf[(size_t)r3 * dc + x]) * 4 +
+                      hbuf[(size_t)r0 * dc + x] + hbuf[(size_t)r4 * dc + x];
+            dst.at(y, x) = v * (1.f / 256.f);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// RPI.h:292-308 buildPyramid
+// ------------------------------------------------------------------------------------
+void buildPyramid(const Image& img, std::vector<Image>& pyr, int nLevels) {
+    pyr.resize(nLevels);
+    pyr[0] = img;
+    for (int level = 1; level < nLevels; ++level) pyr_down_f32(pyr[level - 1], pyr[level]);
+}
+
+// RPI.h:312-354 buildPyramidRange.  depth_type 0: CV_16U millimetres -> convertTo(CV_32FC1, 0.001)
+// (float(src)*float(0.001)); depth_type 1: already float metres.
+void buildPyramidRange(const void* depth, size_t step, int depth_type, int rows, int cols, const Params& p,
+                       std::vector<Image>& pyr) {
+    pyr.resize(p.n_pyr);
+    pyr[0].alloc(rows, cols);
+    for (int r = 0; r < rows; ++r) {
+        if (depth_type == 0) {
+            const uint16_t* row = (const uint16_t*)((const uint8_t*)depth + (size_t)r * step);
+            for (int c = 0; c < cols; ++c) pyr[0].at(r, c) = (float)row[c] * 0.001f;
+        } else {
+            const float* row = (const float*)((const uint8_t*)depth + (size_t)r * step);
+            for (int c = 0; c < cols; ++c) pyr[0].at(r, c) = row[c];
+        }
+    }
+    for (int level = 1; level < p.n_pyr; ++level) {
+        const Image& prev = pyr[level - 1];
+        Image& cur = pyr[level];
+        cur.alloc(prev.rows / 2, prev.cols / 2);
+#pragma omp parallel for
+        for (int r = 0; r < cur.rows * 2; r += 2)          // reference iterates r < prev.rows; identical for even sizes,
+            for (int c = 0; c < cur.cols * 2; c += 2) {     // and it would write out of bounds for odd ones.
+                float avDepth = 0.f;
+                unsigned nValidPixels = 0;
+                for (int i = 0; i < 2; ++i)
+                    for (int j = 0; j < 2; ++j) {
+                        float z = prev.at(r + i, c + j);
+                        if (z > p.min_depth && z < p.max_depth) {
+                            avDepth += z;
+                            ++nValidPixels;
+                        }
+                    }
+                if (nValidPixels > 0) cur.at(r / 2, c / 2) = avDepth / nValidPixels;
+            }
+    }
+}
+
+// RPI.h:365-398 calcGradientXY
+void calcGradientXY(const Image& src, Image& gradX, Image& gradY) {
+    gradX.alloc(src.rows, src.cols);
+    gradY.alloc(src.rows, src.cols);
+#pragma omp parallel for
+    for (int r = 1; r < src.rows - 1; ++r)
+        for (int c = 1; c < src.cols - 1; ++c) {
+            const float v = src.at(r, c);
+            if ((v > src.at(r, c + 1) && v < src.at(r, c - 1)) || (v < src.at(r, c + 1) && v > src.at(r, c - 1)))
+                gradX.at(r, c) = 2.f / (1 / (src.at(r, c + 1) - v) + 1 / (v - src.at(r, c - 1)));
+            if ((v > src.at(r + 1, c) && v < src.at(r - 1, c)) || (v < src.at(r + 1, c) && v > src.at(r - 1, c)))
+                gradY.at(r, c) = 2.f / (1 / (src.at(r + 1, c) - v) + 1 / (v - src.at(r - 1, c)));
+        }
+}
+
+// RPI.h:4538-4549 seam mask: 2-px-wide bands at c = s*(nCols/8)-1, s = 1..7
+void maskSeams(Image& img) {
+    int width_sensor = img.cols / 8;
+    for (int s = 1; s < 8; ++s)
+        for (int r = 0; r < img.rows; ++r)
+            for (int k = 0; k < 2; ++k) {
+                int c = s * width_sensor - 1 + k;
+                if (c >= 0 && c < img.cols) img.at(r, c) = 0.f;
+            }
+}
+
+// RPI.h:4554-4587 LUT of 3-D points of the source sphere
+void buildLUT(Ctx& ctx, int level) {
+    const Image& depth = ctx.depthSrc[level];
+    const int nRows = depth.rows, nCols = depth.cols;
+    ctx.lut.assign((size_t)nRows * nCols * 3, 0.f);
+    const float angle_res = 2 * kPI / nCols;
+    std::vector<float> v_sinTheta(nCols), v_cosTheta(nCols);
+    for (int c = 0; c < nCols; ++c) {
+        float theta = c * angle_res;
+        v_sinTheta[c] = sinf(theta);
+        v_cosTheta[c] = cosf(theta);
+    }
+    const float half_nRows = 0.5 * nRows - 0.5;
+    for (int r = 0; r < nRows; ++r) {
+        float phi = (half_nRows - r) * angle_res;
+        float sin_phi = sinf(phi), cos_phi = cosf(phi);
+        for (int c = 0; c < nCols; ++c) {
+            size_t i = (size_t)r * nCols + c;
+            float depth1 = depth.at(r, c);
+            if (ctx.p.min_depth < depth1 && depth1 < ctx.p.max_depth) {
+                ctx.lut[3 * i + 0] = depth1 * sin_phi;
+                ctx.lut[3 * i + 1] = -depth1 * cos_phi * v_sinTheta[c];
+                ctx.lut[3 * i + 2] = -depth1 * cos_phi * v_cosTheta[c];
+            } else
+                ctx.lut[3 * i + 0] = kInvalidPoint;
+        }
+    }
+    ctx.lut_level = level;
+}
+
+// Shared per-pixel front end of RPI.h:2663-2684 and 2959-2989.
+struct Warp {
+    float X, Y, Z, dist, dist_inv;
+    int r, c;
+    bool visible;
+};
+
+struct PoseRT {
+    float R[9];  // row-major R[i*3+j]
+    float t[3];
+};
+inline PoseRT split_pose(const float* pose /*col-major 4x4*/) {
+    PoseRT o;
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) o.R[i * 3 + j] = pose[j * 4 + i];
+        o.t[i] = pose[12 + i];
+    }
+    return o;
+}
+
+inline Warp warp_pixel(const PoseRT& T, const float* p, int nRows, int nCols, float half_nRows, float angle_res_inv,
+                       int math_mode) {
+    Warp w;
+    // Eigen fixed-size product rotation*LUT + translation: ((a0*b0 + a1*b1) + a2*b2) + t
+    w.X = ((T.R[0] * p[0] + T.R[1] * p[1]) + T.R[2] * p[2]) + T.t[0];
+    w.Y = ((T.R[3] * p[0] + T.R[4] * p[1]) + T.R[5] * p[2]) + T.t[1];
+    w.Z = ((T.R[6] * p[0] + T.R[7] * p[1]) + T.R[8] * p[2]) + T.t[2];
+    w.dist = sqrtf((w.X * w.X + w.Y * w.Y) + w.Z * w.Z);  // Eigen norm()
+    w.dist_inv = 1.f / w.dist;
+    float phi_trg, theta_trg;
+    if (math_mode == 0) {
+        phi_trg = asinf(w.X * w.dist_inv);
+        theta_trg = (float)((double)atan2f(w.Y, w.Z) + kPI);  // float + double PI, stored to float
+    } else {
+        phi_trg = asinf_poly(w.X * w.dist_inv);
+        theta_trg = (float)((double)atan2f_poly(w.Y, w.Z) + kPI);
+    }
+    float fr = half_nRows - phi_trg * angle_res_inv;
+    float fc = theta_trg * angle_res_inv;
+    if (math_mode == 0) {
+        w.r = (int)roundf(fr);
+        w.c = (int)roundf(fc);
+    } else {
+        w.r = (int)round_half_away(fr);
+        w.c = (int)round_half_away(fc);
+    }
+    w.visible = (w.r >= 0 && w.r < nRows) && w.c < nCols;  // RPI.h:2684 (c==nCols dropped, not wrapped)
+    if (w.visible && w.c < 0) w.visible = false;           // cannot occur (theta_trg >= 0); guards the index
+    return w;
+}
+
+// ------------------------------------------------------------------------------------
+// RPI.h:2545-2739 errorPhotoICP_sphere
+// ------------------------------------------------------------------------------------
+double errorPhotoICP_sphere(Ctx& ctx, int level, const float* pose, int method) {
+    double error2 = 0.0, error2_photo = 0.0, error2_depth = 0.0;
+    long numValidPts = 0, nPhoto = 0, nDepth = 0;
+    const Image& graySrc = ctx.graySrc[level];
+    const int nRows = graySrc.rows, nCols = graySrc.cols;
+    const float angle_res = 2 * kPI / nCols;
+    const float angle_res_inv = 1 / angle_res;
+    const float half_nRows = 0.5 * nRows - 0.5;
+    const float stdDevPhoto = ctx.p.sigma_photo, stdDevDepth = ctx.p.sigma_depth;
+    const double stdDevPhoto_inv = 1. / stdDevPhoto;
+    const PoseRT T = split_pose(pose);
+    const Image &grayTrg = ctx.grayTrg[level], &depthTrg = ctx.depthTrg[level];
+    const Image &gx = ctx.gTrgGx[level], &gy = ctx.gTrgGy[level], &dgx = ctx.dTrgGx[level], &dgy = ctx.dTrgGy[level];
+    const float thrI = ctx.p.thres_sal_photo, thrD = ctx.p.thres_sal_depth;
+    const long n = (long)nRows * nCols;
+    const int mm = ctx.p.math_mode;
+
+#pragma omp parallel for reduction(+ : error2, error2_photo, error2_depth, numValidPts, nPhoto, nDepth)
+    for (long i = 0; i < n; ++i) {
+        const float* p = &ctx.lut[3 * i];
+        if (p[0] == kInvalidPoint) continue;
+        Warp w = warp_pixel(T, p, nRows, nCols, half_nRows, angle_res_inv, mm);
+        if (!w.visible) continue;
+        if (method == METHOD_PHOTO || method == METHOD_PHOTO_DEPTH) {
+            if (fabsf(gx.at(w.r, w.c)) < thrI && fabsf(gy.at(w.r, w.c)) < thrI) continue;
+            float pixel1 = graySrc.d[i];
+            float pixel2 = grayTrg.at(w.r, w.c);
+            float photoDiff = pixel2 - pixel1;
+            double weight_photo = weightHuber(photoDiff, stdDevPhoto) * stdDevPhoto_inv;  // float * double
+            float weightedErrorPhoto = weight_photo * photoDiff;
+            error2 += weightedErrorPhoto * weightedErrorPhoto;
+            error2_photo += weightedErrorPhoto * weightedErrorPhoto;
+            ++numValidPts;
+            ++nPhoto;
+        }
+        if (method == METHOD_DEPTH || method == METHOD_PHOTO_DEPTH) {
+            float depth2 = depthTrg.at(w.r, w.c);
+            if (std::isfinite(depth2)) {
+                if (fabsf(dgx.at(w.r, w.c)) < thrD && fabsf(dgy.at(w.r, w.c)) < thrD) continue;
+                float depthDiff = depth2 - w.dist;
+                float stdDev_depth1 = stdDevDepth * depth2;
+                double weight_depth = weightHuber(depthDiff, stdDev_depth1) / stdDev_depth1;  // float/float -> double
+                float weightedErrorDepth = weight_depth * depthDiff;
+                error2 += weightedErrorDepth * weightedErrorDepth;
+                error2_depth += weightedErrorDepth * weightedErrorDepth;
+                ++numValidPts;
+                ++nDepth;
+            }
+        }
+    }
+    ctx.last_err2 = error2;
+    ctx.last_nvalid = numValidPts;
+    ctx.last_err2_photo = error2_photo;
+    ctx.last_err2_depth = error2_depth;
+    ctx.last_nvalid_photo = nPhoto;
+    ctx.last_nvalid_depth = nDepth;
+    // RPI.h:2737 prints "error2 ... numValidPts ..." on every call: silenced.
+    return sqrt(error2 / numValidPts);
+}
+
+// ------------------------------------------------------------------------------------
+// RPI.h:2745-3228 calcHessGrad_sphere
+// ------------------------------------------------------------------------------------
+void calcHessGrad_sphere(Ctx& ctx, int level, const float* pose, int method) {
+    const Image& graySrc = ctx.graySrc[level];
+    const int nRows = graySrc.rows, nCols = graySrc.cols;
+    const long imgSize = (long)nRows * nCols;
+    const float angle_res = 2 * kPI / nCols;
+    const float angle_res_inv = 1 / angle_res;
+    const float half_nRows = 0.5 * nRows - 0.5;
+
+    // RPI.h:2761-2767: per-call intermediates (Eigen::MatrixXf is column-major: 6 planes of imgSize)
+    std::vector<float> jacobiansPhoto((size_t)imgSize * 6), jacobiansDepth((size_t)imgSize * 6);
+    std::vector<float> residualsPhoto(imgSize, 0.f), residualsDepth(imgSize, 0.f);
+    std::vector<int> validPixelsPhoto(imgSize, 0), validPixelsDepth(imgSize, 0);
+    std::vector<float> invDepthBuffer(imgSize, 0.f);  // allocated+zeroed by the reference, unused on this path
+    (void)invDepthBuffer;
+
+    const PoseRT T = split_pose(pose);
+    const float stdDevPhoto = ctx.p.sigma_photo, stdDevDepth = ctx.p.sigma_depth;
+    const float stdDevPhoto_inv = 1. / stdDevPhoto;
+    const Image &grayTrg = ctx.grayTrg[level], &depthTrg = ctx.depthTrg[level];
+    const Image &gx = ctx.gTrgGx[level], &gy = ctx.gTrgGy[level], &dgx = ctx.dTrgGx[level], &dgy = ctx.dTrgGy[level];
+    const float thrI = ctx.p.thres_sal_photo, thrD = ctx.p.thres_sal_depth;
+    const int mm = ctx.p.math_mode;
+    long numVisiblePixels = 0;
+
+#pragma omp parallel for reduction(+ : numVisiblePixels)
+    for (long i = 0; i < imgSize; ++i) {
+        const float* p = &ctx.lut[3 * i];
+        if (p[0] == kInvalidPoint) continue;
+        Warp w = warp_pixel(T, p, nRows, nCols, half_nRows, angle_res_inv, mm);
+        if (!w.visible) continue;
+        ++numVisiblePixels;
+        const float X = w.X, Y = w.Y, Z = w.Z, dist_inv = w.dist_inv;
+
+        // jacobianT36 = [ I | -skew(p') ]  (RPI.h:2994-2996, Miscellaneous.h:88-98)
+        // -skew(p') = [ 0  Z -Y ; -Z 0  X ; Y -X 0 ]
+        // jacobianProj23 (RPI.h:3000-3016)
+        float z_inv = 1.f / Z;
+        float z_inv2 = z_inv * z_inv;
+        float D_atan_theta = 1.f / (1 + Y * Y * z_inv2) * angle_res_inv;
+        float a1 = D_atan_theta * z_inv;
+        float a2 = -Y * z_inv2 * D_atan_theta;
+        float dist_inv2 = dist_inv * dist_inv;
+        float x_dist_inv2 = X * dist_inv2;
+        float D_asin = 1.f / sqrtf(1 - X * x_dist_inv2) * angle_res_inv;
+        float b0 = -D_asin * dist_inv * (1 - X * x_dist_inv2);
+        float b1 = D_asin * (x_dist_inv2 * Y * dist_inv);
+        float b2 = D_asin * (x_dist_inv2 * Z * dist_inv);
+        // jacobianWarpRt = jacobianProj23 * jacobianT36 (RPI.h:3026); Eigen coefficient products
+        // ((a0*b0 + a1*b1) + a2*b2) with the structural zeros dropped (adding +-0 is exact).
+        float Jw0[6] = {0.f, a1, a2, a1 * (-Z) + a2 * Y, a2 * (-X), a1 * X};
+        float Jw1[6] = {b0, b1, b2, b1 * (-Z) + b2 * Y, b0 * Z + b2 * (-X), b0 * (-Y) + b1 * X};
+
+        if (method == METHOD_PHOTO || method == METHOD_PHOTO_DEPTH) {
+            float tgx = gx.at(w.r, w.c), tgy = gy.at(w.r, w.c);
+            if (fabsf(tgx) < thrI && fabsf(tgy) < thrI) continue;
+            float pixel1 = graySrc.d[i];
+            float pixel2 = grayTrg.at(w.r, w.c);
+            float photoDiff = pixel2 - pixel1;
+            float weight_photo = weightHuber(photoDiff, stdDevPhoto) * stdDevPhoto_inv;
+            float weightedErrorPhoto = weight_photo * photoDiff;
+            // jacobianPhoto = weight_photo * target_imgGradient * jacobianWarpRt, evaluated left to right
+            float wgx = weight_photo * tgx, wgy = weight_photo * tgy;
+            for (int j = 0; j < 6; ++j) jacobiansPhoto[(size_t)j * imgSize + i] = wgx * Jw0[j] + wgy * Jw1[j];
+            residualsPhoto[i] = weightedErrorPhoto;
+            validPixelsPhoto[i] = 1;
+        }
+        if (method == METHOD_DEPTH || method == METHOD_PHOTO_DEPTH) {
+            float depth2 = depthTrg.at(w.r, w.c);
+            if (std::isfinite(depth2)) {
+                float tdx = dgx.at(w.r, w.c), tdy = dgy.at(w.r, w.c);
+                if (fabsf(tdx) < thrD && fabsf(tdy) < thrD) continue;
+                float depthDiff = depth2 - w.dist;
+                float stdDev_depth1 = stdDevDepth * depth2;
+                float weight_depth = weightHuber(depthDiff, stdDev_depth1) / stdDev_depth1;
+                float weightedErrorDepth = weight_depth * depthDiff;
+                // jacobianDepthSrc = p'/dist ; (p'/dist) * jacobianT36
+                float n0 = X * dist_inv, n1 = Y * dist_inv, n2 = Z * dist_inv;
+                float nJ[6] = {n0, n1, n2, n1 * (-Z) + n2 * Y, n0 * Z + n2 * (-X), n0 * (-Y) + n1 * X};
+                for (int j = 0; j < 6; ++j)
+                    jacobiansDepth[(size_t)j * imgSize + i] = weight_depth * ((tdx * Jw0[j] + tdy * Jw1[j]) - nJ[j]);
+                residualsDepth[i] = weightedErrorDepth;
+                validPixelsDepth[i] = 1;
+            }
+        }
+    }
+
+    // RPI.h:3117-3195: 21 + 6 scalar reductions, float accumulators (reduce_mode 0) or double (1).
+    float hf[21] = {0}, gf[6] = {0};
+    double hd[21] = {0}, gd[6] = {0};
+    auto reduce_rows = [&](const std::vector<float>& J, const std::vector<float>& res, const std::vector<int>& valid) {
+        double H0[21] = {0}, G0[6] = {0};
+#pragma omp parallel
+        {
+            float lh[21] = {0}, lg[6] = {0};
+            double lhd[21] = {0}, lgd[6] = {0};
+#pragma omp for schedule(static) nowait
+            for (long i = 0; i < imgSize; ++i)
+                if (valid[i]) {
+                    float Ji[6];
+                    for (int j = 0; j < 6; ++j) Ji[j] = J[(size_t)j * imgSize + i];
+                    int k = 0;
+                    for (int a = 0; a < 6; ++a)
+                        for (int b = a; b < 6; ++b, ++k) {
+                            float prod = Ji[a] * Ji[b];
+                            lh[k] += prod;
+                            lhd[k] += (double)prod;
+                        }
+                    for (int a = 0; a < 6; ++a) {
+                        float prod = Ji[a] * res[i];
+                        lg[a] += prod;
+                        lgd[a] += (double)prod;
+                    }
+                }
+#pragma omp critical
+            {
+                for (int k = 0; k < 21; ++k) { hf[k] += lh[k]; H0[k] += lhd[k]; }
+                for (int a = 0; a < 6; ++a) { gf[a] += lg[a]; G0[a] += lgd[a]; }
+            }
+        }
+        for (int k = 0; k < 21; ++k) hd[k] += H0[k];
+        for (int a = 0; a < 6; ++a) gd[a] += G0[a];
+    };
+    if (method == METHOD_PHOTO || method == METHOD_PHOTO_DEPTH) reduce_rows(jacobiansPhoto, residualsPhoto, validPixelsPhoto);
+    if (method == METHOD_DEPTH || method == METHOD_PHOTO_DEPTH) reduce_rows(jacobiansDepth, residualsDepth, validPixelsDepth);
+
+    int k = 0;
+    for (int a = 0; a < 6; ++a)
+        for (int b = a; b < 6; ++b, ++k) {
+            float v = ctx.p.reduce_mode == 0 ? hf[k] : (float)hd[k];
+            ctx.H[b * 6 + a] = ctx.H[a * 6 + b] = v;
+            ctx.H64[b * 6 + a] = ctx.H64[a * 6 + b] = hd[k];
+        }
+    for (int a = 0; a < 6; ++a) {
+        ctx.g[a] = ctx.p.reduce_mode == 0 ? gf[a] : (float)gd[a];
+        ctx.g64[a] = gd[a];
+    }
+    ctx.n_visible = numVisiblePixels;
+    ctx.sso = (float)numVisiblePixels / imgSize;  // RPI.h:3226
+}
+
+// ------------------------------------------------------------------------------------
+// THIRD-PARTY restatements (Eigen / MRPT) for the 6x6 step
+// ------------------------------------------------------------------------------------
+
+// MRPT 1.x Eigen plugin rank(): ColPivHouseholderQR(m).rank() with Eigen's default threshold
+// epsilon * diagonalSize; a pivot counts if |R_ii| > |maxpivot| * threshold.  (RPI.h:4682)
+int rank6_colpiv_qr(const float* Mcm /*col-major 6x6*/) {
+    float A[6][6];
+    for (int r = 0; r < 6; ++r)
+        for (int c = 0; c < 6; ++c) A[r][c] = Mcm[c * 6 + r];
+    float colNormsSq[6];
+    for (int c = 0; c < 6; ++c) {
+        float s = 0;
+        for (int r = 0; r < 6; ++r) s += A[r][c] * A[r][c];
+        colNormsSq[c] = s;
+    }
+    float maxNormSq = *std::max_element(colNormsSq, colNormsSq + 6);
+    const float eps = 1.1920929e-07f;
+    float threshold_helper = maxNormSq * (eps * eps) / 6.f;  // Eigen 3.2: maxCoeff * abs2(eps) / rows
+    int nonzero_pivots = 6;
+    float maxpivot = 0.f;
+    float diag[6] = {0};
+    for (int k = 0; k < 6; ++k) {
+        int best = k;
+        float bestv = -1.f;
+        for (int c = k; c < 6; ++c) {
+            float s = 0;
+            for (int r = k; r < 6; ++r) s += A[r][c] * A[r][c];  // recompute exactly
+            if (s > bestv) { bestv = s; best = c; }
+        }
+        if (bestv < threshold_helper * (float)(6 - k)) { nonzero_pivots = k; break; }
+        if (best != k)
+            for (int r = 0; r < 6; ++r) std::swap(A[r][k], A[r][best]);
+        // Householder on column k, rows k..5
+        float tailSq = 0;
+        for (int r = k + 1; r < 6; ++r) tailSq += A[r][k] * A[r][k];
+        float c0 = A[k][k], beta, tau;
+        float v[6] = {0};
+        if (tailSq == 0.f) {
+            tau = 0.f;
+            beta = c0;
+        } else {
+            beta = sqrtf(c0 * c0 + tailSq);
+            if (c0 >= 0.f) beta = -beta;
+            for (int r = k + 1; r < 6; ++r) v[r] = A[r][k] / (c0 - beta);
+            tau = (beta - c0) / beta;
+        }
+        v[k] = 1.f;
+        for (int c = k + 1; c < 6; ++c) {
+            float dot = 0;
+            for (int r = k; r < 6; ++r) dot += v[r] * A[r][c];
+            dot *= tau;
+            for (int r = k; r < 6; ++r) A[r][c] -= dot * v[r];
+        }
+        A[k][k] = beta;
+        for (int r = k + 1; r < 6; ++r) A[r][k] = 0.f;
+        diag[k] = beta;
+        if (fabsf(beta) > maxpivot) maxpivot = fabsf(beta);
+    }
+    float thr = maxpivot * (eps * 6.f);
+    int rank = 0;
+    for (int k = 0; k < nonzero_pivots; ++k) rank += (fabsf(diag[k]) > thr);
+    return rank;
+}
+
+// Eigen Matrix<float,6,6>::inverse(): PartialPivLU, then solve against identity. (RPI.h:4693)
+bool inverse6_partial_piv_lu(const float* Mcm, float* inv_cm) {
+    float LU[6][6];
+    int perm[6];
+    for (int r = 0; r < 6; ++r) {
+        perm[r] = r;
+        for (int c = 0; c < 6; ++c) LU[r][c] = Mcm[c * 6 + r];
+    }
+    for (int k = 0; k < 6; ++k) {
+        int piv = k;
+        float best = fabsf(LU[k][k]);
+        for (int r = k + 1; r < 6; ++r)
+            if (fabsf(LU[r][k]) > best) { best = fabsf(LU[r][k]); piv = r; }
+        if (best == 0.f) return false;
+        if (piv != k) {
+            for (int c = 0; c < 6; ++c) std::swap(LU[k][c], LU[piv][c]);
+            std::swap(perm[k], perm[piv]);
+        }
+        for (int r = k + 1; r < 6; ++r) {
+            LU[r][k] /= LU[k][k];
+            for (int c = k + 1; c < 6; ++c) LU[r][c] -= LU[r][k] * LU[k][c];
+        }
+    }
+    for (int col = 0; col < 6; ++col) {
+        float y[6];
+        for (int r = 0; r < 6; ++r) {  // forward: L y = P e_col
+            float s = (perm[r] == col) ? 1.f : 0.f;
+            for (int c = 0; c < r; ++c) s -= LU[r][c] * y[c];
+            y[r] = s;
+        }
+        for (int r = 5; r >= 0; --r) {  // backward: U x = y
+            float s = y[r];
+            for (int c = r + 1; c < 6; ++c) s -= LU[r][c] * y[c];
+            y[r] = s / LU[r][r];
+        }
+        for (int r = 0; r < 6; ++r) inv_cm[col * 6 + r] = y[r];
+    }
+    return true;
+}
+
+// MRPT 1.x CPose3D::exp(v, pseudo_exponential = true)  (SE_traits<3>::pseudo_exp): translation copied
+// verbatim from v[0..2], rotation = Rodrigues(v[3..5]) = I + sin(a)/a W + (1-cos(a))/a^2 W^2. (RPI.h:4697)
+void se3_pseudo_exp(const double* v, double* M /*col-major 4x4*/) {
+    const double wx = v[3], wy = v[4], wz = v[5];
+    const double angle = sqrt(wx * wx + wy * wy + wz * wz);
+    double R[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    if (angle >= 128 * 2.220446049250313e-16) {
+        const double W[3][3] = {{0, -wz, wy}, {wz, 0, -wx}, {-wy, wx, 0}};
+        double W2[3][3];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double s = 0;
+                for (int k = 0; k < 3; ++k) s += W[i][k] * W[k][j];
+                W2[i][j] = s;
+            }
+        const double a = sin(angle) / angle, b = (1 - cos(angle)) / (angle * angle);
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) R[i][j] += a * W[i][j] + b * W2[i][j];
+    }
+    for (int k = 0; k < 16; ++k) M[k] = 0;
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) M[j * 4 + i] = R[i][j];
+        M[12 + i] = v[i];
+    }
+    M[15] = 1;
+}
+
+inline void mat4_mul_f32(const float* A, const float* B, float* C) {  // col-major, Eigen coefficient order
+    for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 4; ++r)
+            C[c * 4 + r] = ((A[0 * 4 + r] * B[c * 4 + 0] + A[1 * 4 + r] * B[c * 4 + 1]) + A[2 * 4 + r] * B[c * 4 + 2]) +
+                           A[3 * 4 + r] * B[c * 4 + 3];
+}
+
+// One Gauss-Newton step from (H, g) at pose: returns 0 ok / 1 ill-posed. RPI.h:4682-4697.
+int gn_step(const float* H, const float* g, float lambda, const float* pose, float* pose_tmp, float* update) {
+    float M[36];
+    for (int k = 0; k < 36; ++k) M[k] = H[k];
+    for (int i = 0; i < 6; ++i) M[i * 6 + i] = H[i * 6 + i] + lambda * H[i * 6 + i];
+    if (rank6_colpiv_qr(M) != 6) return 1;
+    float inv[36];
+    if (!inverse6_partial_piv_lu(H, inv)) return 1;
+    for (int r = 0; r < 6; ++r) {  // update = (-H^-1) * g
+        float s = 0.f;
+        for (int c = 0; c < 6; ++c) s += (-inv[c * 6 + r]) * g[c];
+        update[r] = s;
+    }
+    double ud[6], E[16];
+    for (int i = 0; i < 6; ++i) ud[i] = (double)update[i];
+    se3_pseudo_exp(ud, E);
+    float Ef[16];
+    for (int k = 0; k < 16; ++k) Ef[k] = (float)E[k];
+    mat4_mul_f32(Ef, pose, pose_tmp);
+    return 0;
+}
+
+void prepare_level(Ctx& ctx, int level) {
+    // RPI.h:4538-4549 (idempotent; the reference re-applies it on every call)
+    if (ctx.p.mask_seams) {
+        maskSeams(ctx.gTrgGx[level]);
+        maskSeams(ctx.gTrgGy[level]);
+        maskSeams(ctx.dTrgGx[level]);
+        maskSeams(ctx.dTrgGy[level]);
+    }
+    buildLUT(ctx, level);
+}
+
+// RPI.h:4519-4784 alignFrames360, occlusion == 0
+int alignFrames360(Ctx& ctx, const float* pose_guess, int method, float* pose_out, Result* res) {
+    ctx.trace.clear();
+    memset(res, 0, sizeof(*res));
+    float pose_estim[16], pose_estim_temp[16];
+    memcpy(pose_estim, pose_guess, sizeof(pose_estim));
+    double error = 0;
+    memset(ctx.H, 0, sizeof(ctx.H));
+    memset(ctx.g, 0, sizeof(ctx.g));
+    for (int level = ctx.p.n_pyr - 1; level >= 0; --level) {
+        prepare_level(ctx, level);
+        float lambda = 1.f;  // double lambda = 1e0 converted to float by Eigen's scalar*matrix
+        const double step = 5;
+        int it = 0;
+        const int maxIters = ctx.p.max_iters;
+        const double tol_residual = ctx.p.tol_residual, tol_update = ctx.p.tol_update;
+        float update_pose[6] = {1, 1, 1, 1, 1, 1};
+        error = errorPhotoICP_sphere(ctx, level, pose_estim, method);
+        if (ctx.last_nvalid == 0) {
+            memcpy(pose_out, pose_estim, sizeof(pose_estim));
+            res->status = 2;
+            return 2;
+        }
+        {
+            IterTrace t{};
+            t.level = level; t.it = -1; t.accepted = 1; t.error = error; t.new_error = error; t.n_valid = ctx.last_nvalid;
+            memcpy(t.pose, pose_estim, sizeof(t.pose));
+            ctx.trace.push_back(t);
+        }
+        double diff_error = error;
+        auto unorm = [&]() {
+            float s = 0;
+            for (int i = 0; i < 6; ++i) s += update_pose[i] * update_pose[i];
+            return sqrtf(s);
+        };
+        while (it < maxIters && unorm() > tol_update && diff_error > tol_residual) {
+            calcHessGrad_sphere(ctx, level, pose_estim, method);
+            if (gn_step(ctx.H, ctx.g, lambda, pose_estim, pose_estim_temp, update_pose) != 0) {
+                memcpy(pose_out, pose_estim, sizeof(pose_estim));  // relPose = pose_estim; avResidual = 0; return
+                res->status = 1;
+                for (int k = 0; k < 36; ++k) res->hessian[k] = ctx.H[k];
+                for (int k = 0; k < 6; ++k) res->gradient[k] = ctx.g[k];
+                res->sso = ctx.sso;
+                return 1;
+            }
+            double new_error = errorPhotoICP_sphere(ctx, level, pose_estim_temp, method);
+            diff_error = error - new_error;
+            IterTrace t{};
+            t.level = level; t.it = it; t.error = error; t.new_error = new_error; t.n_valid = ctx.last_nvalid;
+            memcpy(t.pose, pose_estim_temp, sizeof(t.pose));
+            memcpy(t.update, update_pose, sizeof(t.update));
+            if (diff_error > tol_residual) {
+                lambda /= step;
+                memcpy(pose_estim, pose_estim_temp, sizeof(pose_estim));
+                error = new_error;
+                it = it + 1;
+                t.accepted = 1;
+            }
+            ctx.trace.push_back(t);
+        }
+        res->iters[level] = it;
+    }
+    memcpy(pose_out, pose_estim, sizeof(pose_estim));
+    // The reference never writes avPhotoResidual/avDepthResidual on this path;
+    // defined here as the photo / depth RMS of the error pass at the returned pose.
+    double e = errorPhotoICP_sphere(ctx, 0, pose_estim, method);
+    res->err_final = e;
+    res->rms_photo = ctx.last_nvalid_photo ? sqrt(ctx.last_err2_photo / ctx.last_nvalid_photo) : 0.0;
+    res->rms_depth = ctx.last_nvalid_depth ? sqrt(ctx.last_err2_depth / ctx.last_nvalid_depth) : 0.0;
+    res->sso = ctx.sso;
+    for (int k = 0; k < 36; ++k) res->hessian[k] = ctx.H[k];
+    for (int k = 0; k < 6; ++k) res->gradient[k] = ctx.g[k];
+    res->status = 0;
+    return 0;
+}
+
+void set_frame(Ctx& ctx, bool target, const uint8_t* rgb, size_t rgb_step, const void* depth, size_t d_step,
+               int depth_type, int rows, int cols) {
+    Image gray;
+    rgb_to_gray_f32(rgb, rgb_step, rows, cols, gray);
+    if (target) {  // RPI.h:498-516
+        buildPyramid(gray, ctx.grayTrg, ctx.p.n_pyr);
+        buildPyramidRange(depth, d_step, depth_type, rows, cols, ctx.p, ctx.depthTrg);
+        // RPI.h:429-477 buildGradientPyramids
+        ctx.gTrgGx.resize(ctx.p.n_pyr); ctx.gTrgGy.resize(ctx.p.n_pyr);
+        ctx.dTrgGx.resize(ctx.p.n_pyr); ctx.dTrgGy.resize(ctx.p.n_pyr);
+        for (int l = 0; l < ctx.p.n_pyr; ++l) {
+            calcGradientXY(ctx.grayTrg[l], ctx.gTrgGx[l], ctx.gTrgGy[l]);
+            calcGradientXY(ctx.depthTrg[l], ctx.dTrgGx[l], ctx.dTrgGy[l]);
+        }
+    } else {  // RPI.h:480-494 (the colour pyramid is visualisation-only and omitted)
+        buildPyramid(gray, ctx.graySrc, ctx.p.n_pyr);
+        buildPyramidRange(depth, d_step, depth_type, rows, cols, ctx.p, ctx.depthSrc);
+    }
+    ctx.lut_level = -1;
+}
+
+}  // namespace
+
+// ======================================================================================
+// C interface for the Python harness (ctypes)
+// ======================================================================================
+extern "C" {
+
+typedef Params oracle_params;
+typedef Result oracle_result;
+typedef IterTrace oracle_trace;
+
+void oracle_default_params(oracle_params* p) {
+    p->n_pyr = 4;
+    p->min_depth = 0.3f;
+    p->max_depth = 6.0f;
+    p->sigma_photo = (float)(6. / 255);
+    p->sigma_depth = (float)0.2;
+    p->thres_sal_photo = 0.01f;
+    p->thres_sal_depth = 0.01f;
+    p->max_iters = 10;
+    p->tol_residual = 1e-3f;
+    p->tol_update = 1e-4f;
+    p->mask_seams = 1;
+    p->math_mode = 0;
+    p->reduce_mode = 0;
+}
+
+void* oracle_create(const oracle_params* p) {
+    Ctx* c = new Ctx();
+    c->p = *p;
+    return c;
+}
+void oracle_destroy(void* h) { delete (Ctx*)h; }
+void oracle_set_modes(void* h, int math_mode, int reduce_mode) {
+    ((Ctx*)h)->p.math_mode = math_mode;
+    ((Ctx*)h)->p.reduce_mode = reduce_mode;
+}
+
+void oracle_set_target(void* h, const uint8_t* rgb, size_t rgb_step, const void* depth, size_t d_step, int depth_type,
+                       int rows, int cols) {
+    set_frame(*(Ctx*)h, true, rgb, rgb_step, depth, d_step, depth_type, rows, cols);
+}
+void oracle_set_source(void* h, const uint8_t* rgb, size_t rgb_step, const void* depth, size_t d_step, int depth_type,
+                       int rows, int cols) {
+    set_frame(*(Ctx*)h, false, rgb, rgb_step, depth, d_step, depth_type, rows, cols);
+}
+
+int oracle_align360(void* h, const float* guess, int method, float* pose_out, oracle_result* res) {
+    return alignFrames360(*(Ctx*)h, guess, method, pose_out, res);
+}
+
+int oracle_trace_len(void* h) { return (int)((Ctx*)h)->trace.size(); }
+void oracle_trace_get(void* h, int i, oracle_trace* out) { *out = ((Ctx*)h)->trace[i]; }
+
+// which: 0 graySrc 1 grayTrg 2 depthSrc 3 depthTrg 4 gx 5 gy 6 dgx 7 dgy
+int oracle_level_dims(void* h, int level, int* rows, int* cols) {
+    Ctx& c = *(Ctx*)h;
+    if (level < 0 || level >= (int)c.grayTrg.size()) return -1;
+    *rows = c.grayTrg[level].rows;
+    *cols = c.grayTrg[level].cols;
+    return 0;
+}
+int oracle_get_plane(void* h, int which, int level, float* out) {
+    Ctx& c = *(Ctx*)h;
+    std::vector<Image>* v[8] = {&c.graySrc, &c.grayTrg, &c.depthSrc, &c.depthTrg, &c.gTrgGx, &c.gTrgGy, &c.dTrgGx, &c.dTrgGy};
+    if (which < 0 || which > 7 || level < 0 || level >= (int)v[which]->size()) return -1;
+    const Image& im = (*v[which])[level];
+    memcpy(out, im.d.data(), im.d.size() * sizeof(float));
+    return 0;
+}
+// Applies the seam mask and builds the LUT of `level` (what alignFrames360 does on entering a level).
+void oracle_prepare_level(void* h, int level) { prepare_level(*(Ctx*)h, level); }
+int oracle_get_lut(void* h, float* out_xyz) {
+    Ctx& c = *(Ctx*)h;
+    memcpy(out_xyz, c.lut.data(), c.lut.size() * sizeof(float));
+    return (int)(c.lut.size() / 3);
+}
+// Error pass at `pose` on a prepared level. Returns rms; outputs raw sums.
+double oracle_error(void* h, int level, const float* pose, int method, double* err2, long* n_valid) {
+    Ctx& c = *(Ctx*)h;
+    if (c.lut_level != level) prepare_level(c, level);
+    double e = errorPhotoICP_sphere(c, level, pose, method);
+    if (err2) *err2 = c.last_err2;
+    if (n_valid) *n_valid = c.last_nvalid;
+    return e;
+}
+// H,g pass at `pose` on a prepared level.
+void oracle_hessgrad(void* h, int level, const float* pose, int method, float* H36, float* g6, double* H36d, double* g6d,
+                     long* n_visible) {
+    Ctx& c = *(Ctx*)h;
+    if (c.lut_level != level) prepare_level(c, level);
+    calcHessGrad_sphere(c, level, pose, method);
+    if (H36) memcpy(H36, c.H, sizeof(c.H));
+    if (g6) memcpy(g6, c.g, sizeof(c.g));
+    if (H36d) memcpy(H36d, c.H64, sizeof(c.H64));
+    if (g6d) memcpy(g6d, c.g64, sizeof(c.g64));
+    if (n_visible) *n_visible = c.n_visible;
+}
+// One GN step from given H,g: returns 0 / 1 (ill-posed).
+int oracle_gn_step(const float* H36, const float* g6, float lambda, const float* pose, float* pose_tmp, float* update6) {
+    return gn_step(H36, g6, lambda, pose, pose_tmp, update6);
+}
+// Forced schedule used for the CPU baseline timing: n_iters x { H,g pass; solve; error pass },
+// step applied regardless of the accept rule.  Returns the last error.
+double oracle_forced_iters(void* h, int level, const float* pose0, int method, int n_iters, float* pose_out) {
+    Ctx& c = *(Ctx*)h;
+    if (c.lut_level != level) prepare_level(c, level);
+    float pose[16], tmp[16], upd[6];
+    memcpy(pose, pose0, sizeof(pose));
+    double e = 0;
+    for (int k = 0; k < n_iters; ++k) {
+        calcHessGrad_sphere(c, level, pose, method);
+        if (gn_step(c.H, c.g, 1.f, pose, tmp, upd) != 0) break;
+        e = errorPhotoICP_sphere(c, level, tmp, method);
+        memcpy(pose, tmp, sizeof(pose));
+    }
+    if (pose_out) memcpy(pose_out, pose, sizeof(pose));
+    return e;
+}
+// Per-pixel warp indices for a prepared level (index parity checks): out_rc[2*i] = r', [2*i+1] = c', -1 if skipped.
+void oracle_warp_indices(void* h, int level, const float* pose, int* out_rc) {
+    Ctx& c = *(Ctx*)h;
+    if (c.lut_level != level) prepare_level(c, level);
+    const int nRows = c.graySrc[level].rows, nCols = c.graySrc[level].cols;
+    const float angle_res = 2 * kPI / nCols;
+    const float angle_res_inv = 1 / angle_res;
+    const float half_nRows = 0.5 * nRows - 0.5;
+    PoseRT T = split_pose(pose);
+    const long n = (long)nRows * nCols;
+#pragma omp parallel for
+    for (long i = 0; i < n; ++i) {
+        out_rc[2 * i] = out_rc[2 * i + 1] = -1;
+        const float* p = &c.lut[3 * i];
+        if (p[0] == kInvalidPoint) continue;
+        Warp w = warp_pixel(T, p, nRows, nCols, half_nRows, angle_res_inv, c.p.math_mode);
+        if (!w.visible) continue;
+        out_rc[2 * i] = w.r;
+        out_rc[2 * i + 1] = w.c;
+    }
+}
+// Scalar probes for unit tests.
+float oracle_asinf_poly(float x) { return asinf_poly(x); }
+float oracle_atan2f_poly(float y, float x) { return atan2f_poly(y, x); }
+float oracle_round_half_away(float x) { return round_half_away(x); }
+float oracle_weight_huber(float e, float k) { return weightHuber(e, k); }
+int oracle_rank6(const float* M) { return rank6_colpiv_qr(M); }
+int oracle_inverse6(const float* M, float* inv) { return inverse6_partial_piv_lu(M, inv) ? 0 : 1; }
+void oracle_se3_pseudo_exp(const double* v, double* M) { se3_pseudo_exp(v, M); }
+int oracle_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+}  // extern "C"

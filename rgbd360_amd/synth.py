@@ -1,0 +1,165 @@
+"""Deterministic synthetic spherical RGB-D frames.
+
+An axis-aligned box room (x up in [-1.5, 1.5], y in [-3, 3], z in [-4, 4]) is rendered into
+full-sphere equirectangular panoramas with the reference's pixel<->ray convention
+(RegisterPhotoICP.h:4567-4582): row r <-> phi = (H/2 - 0.5 - r) * 2pi/W, column c <-> theta = c * 2pi/W,
+ray = (sin phi, -cos phi sin theta, -cos phi cos theta).  Output matches what Frame360 hands to
+RegisterPhotoICP (Frame360.h:104-111, 394): RGB uint8 HxWx3 and range uint16 millimetres (0 = invalid).
+
+This is input generation only (no alignment arithmetic); both the HIP path and the CPU oracle consume
+the same arrays.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+ROOM_LO = np.array([-1.5, -3.0, -4.0])
+ROOM_HI = np.array([1.5, 3.0, 4.0])
+CAM_A = np.array([0.1, -0.2, 0.3])
+MIN_DEPTH, MAX_DEPTH = 0.3, 6.0
+
+_WAVELENGTHS = np.array([0.15, 0.22, 0.33, 0.6, 1.1, 2.3])  # metres
+_AMPS = np.array([0.10, 0.10, 0.09, 0.08, 0.07, 0.06])
+
+
+def rodrigues(axis: np.ndarray, angle: float) -> np.ndarray:
+    a = np.asarray(axis, dtype=np.float64)
+    a = a / np.linalg.norm(a)
+    K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    return np.eye(3) + math.sin(angle) * K + (1 - math.cos(angle)) * (K @ K)
+
+
+def make_pose(R: np.ndarray, t: np.ndarray) -> np.ndarray:
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = t
+    return T
+
+
+def _wall_params(seed: int):
+    rng = np.random.default_rng(seed)
+    K = len(_WAVELENGTHS)
+    alpha = rng.uniform(0, math.pi, size=(6, K))
+    phase = rng.uniform(0, 2 * math.pi, size=(6, K))
+    jitter = rng.uniform(0.9, 1.1, size=(6, K))
+    freq = 1.0 / (_WAVELENGTHS[None, :] * jitter)
+    lattice = rng.uniform(-1.0, 1.0, size=(6, 48, 48))
+    chroma = rng.uniform(-1.0, 1.0, size=(6, 2, K))
+    return alpha, phase, freq, lattice, chroma
+
+
+def render(T_wc: np.ndarray, width: int, height: int | None = None, seed: int = 1234, depth_f32: bool = False):
+    """Render the room from camera-to-world pose T_wc.  Returns (rgb uint8 HxWx3, depth uint16 mm HxW),
+    or float32 metres for the depth when depth_f32 (RegisterPhotoICP.h:318-319 accepts both)."""
+    W = int(width)
+    H = int(height) if height is not None else W // 2
+    alpha, phase, freq, lattice, chroma = _wall_params(seed)
+    res = 2 * math.pi / W
+    phi = (H / 2 - 0.5 - np.arange(H, dtype=np.float64)) * res
+    theta = np.arange(W, dtype=np.float64) * res
+    sp, cp = np.sin(phi)[:, None], np.cos(phi)[:, None]
+    st, ct = np.sin(theta)[None, :], np.cos(theta)[None, :]
+    ray_c = np.stack([np.broadcast_to(sp, (H, W)), -cp * st, -cp * ct], axis=-1)  # HxWx3
+    R, o = T_wc[:3, :3], T_wc[:3, 3]
+    ray_w = ray_c @ R.T
+    with np.errstate(divide="ignore", invalid="ignore"):
+        bound = np.where(ray_w > 0, ROOM_HI, ROOM_LO)
+        tk = (bound - o) / ray_w
+        tk = np.where(np.abs(ray_w) < 1e-12, np.inf, tk)
+    axis = np.argmin(tk, axis=-1)
+    t = np.take_along_axis(tk, axis[..., None], axis=-1)[..., 0]
+    P = o + t[..., None] * ray_w
+    side = (np.take_along_axis(ray_w, axis[..., None], axis=-1)[..., 0] > 0).astype(np.int64)
+    wall = axis * 2 + side
+    # wall-plane coordinates: the two axes other than `axis`
+    ua = np.where(axis == 0, 1, 0)
+    va = np.where(axis == 2, 1, 2)
+    u = np.take_along_axis(P, ua[..., None], axis=-1)[..., 0]
+    v = np.take_along_axis(P, va[..., None], axis=-1)[..., 0]
+
+    tex = np.full((H, W), 0.5)
+    c1 = np.zeros((H, W))
+    c2 = np.zeros((H, W))
+    for k in range(len(_WAVELENGTHS)):
+        a = alpha[wall, k]
+        s = np.sin(2 * math.pi * freq[wall, k] * (u * np.cos(a) + v * np.sin(a)) + phase[wall, k])
+        tex += _AMPS[k] * s
+        c1 += 0.02 * chroma[wall, 0, k] * s
+        c2 += 0.02 * chroma[wall, 1, k] * s
+    # seeded lattice (value) noise, 0.3 m cells, smoothstep-interpolated
+    gu, gv = (u + 6.0) / 0.3, (v + 6.0) / 0.3
+    iu, iv = np.floor(gu).astype(np.int64), np.floor(gv).astype(np.int64)
+    fu, fv = gu - iu, gv - iv
+    fu, fv = fu * fu * (3 - 2 * fu), fv * fv * (3 - 2 * fv)
+    iu0, iv0 = np.clip(iu, 0, 46), np.clip(iv, 0, 46)
+    n00 = lattice[wall, iu0, iv0]
+    n10 = lattice[wall, iu0 + 1, iv0]
+    n01 = lattice[wall, iu0, iv0 + 1]
+    n11 = lattice[wall, iu0 + 1, iv0 + 1]
+    tex += 0.08 * ((n00 * (1 - fu) + n10 * fu) * (1 - fv) + (n01 * (1 - fu) + n11 * fu) * fv)
+
+    rgb = np.stack([tex + c1, tex, tex + c2], axis=-1)
+    rgb = np.clip(np.rint(rgb * 255.0), 0, 255).astype(np.uint8)
+    valid = (t > MIN_DEPTH) & (t < MAX_DEPTH)
+    if depth_f32:
+        depth = np.where(valid, t, 0.0).astype(np.float32)
+    else:
+        depth = np.where(valid, np.rint(t * 1000.0), 0).astype(np.uint16)
+    return np.ascontiguousarray(rgb), np.ascontiguousarray(depth)
+
+
+def default_motion(seed: int = 1234, trans: float = 0.06, rot_deg: float = 2.0) -> np.ndarray:
+    """Camera-B-in-camera-A motion: `trans` metres and `rot_deg` degrees about seeded random axes."""
+    rng = np.random.default_rng(seed + 7919)
+    ax = rng.normal(size=3)
+    td = rng.normal(size=3)
+    td = td / np.linalg.norm(td) * trans
+    return make_pose(rodrigues(ax, math.radians(rot_deg)), td)
+
+
+def make_pair(width: int, height: int | None = None, seed: int = 1234, trans: float = 0.06, rot_deg: float = 2.0,
+              depth_f32: bool = False):
+    """Target frame A, source frame B and the ground-truth relPose (source points -> target frame,
+    p_trg = R p_src + t; RegisterPhotoICP.h:2663) as a 4x4 float64."""
+    T_wA = make_pose(np.eye(3), CAM_A)
+    M = default_motion(seed, trans, rot_deg)
+    T_wB = T_wA @ M
+    rgbA, dA = render(T_wA, width, height, seed, depth_f32)
+    rgbB, dB = render(T_wB, width, height, seed, depth_f32)
+    T_rel = np.linalg.inv(T_wA) @ T_wB
+    return (rgbA, dA), (rgbB, dB), T_rel
+
+
+def trajectory_pose(k: int, seed: int = 1234) -> np.ndarray:
+    """Frame k of a smooth closed trajectory (config 4: pair i = frames i, i+1): a 0.6 m-radius loop in the
+    y-z plane with ~6 cm steps, 2 degrees of yaw about the up axis per frame and a small seeded wobble."""
+    rng = np.random.default_rng(seed + 104729)
+    ph = rng.uniform(0, 2 * math.pi, size=3)
+    n_loop = 63.0
+    a = 2 * math.pi * k / n_loop
+    pos = np.array([0.15 * math.sin(0.5 * a + ph[0]), 0.6 * math.cos(a), 0.6 * math.sin(a)])
+    Rm = rodrigues(np.array([1.0, 0, 0]), math.radians(2.0) * k) @ rodrigues(
+        np.array([0, math.cos(ph[1]), math.sin(ph[1])]), math.radians(1.5) * math.sin(0.7 * a + ph[2]))
+    return make_pose(Rm, pos)
+
+
+def make_sequence_pair(i: int, width: int, height: int | None = None, seed: int = 1234):
+    """Pair i of the odometry-like sequence: target = frame i, source = frame i+1."""
+    T_wA, T_wB = trajectory_pose(i, seed), trajectory_pose(i + 1, seed)
+    rgbA, dA = render(T_wA, width, height, seed)
+    rgbB, dB = render(T_wB, width, height, seed)
+    return (rgbA, dA), (rgbB, dB), np.linalg.inv(T_wA) @ T_wB
+
+
+def pose_error(Ta: np.ndarray, Tb: np.ndarray):
+    """(rotation angle of Ra Rb^T in rad, ||ta - tb|| in m) -- SURVEY.md §8d metric (iii)."""
+    Ta = np.asarray(Ta, dtype=np.float64).reshape(4, 4)
+    Tb = np.asarray(Tb, dtype=np.float64).reshape(4, 4)
+    Rd = Ta[:3, :3] @ Tb[:3, :3].T
+    c = max(-1.0, min(1.0, (np.trace(Rd) - 1) / 2))
+    # asin form is accurate for tiny angles
+    s = 0.5 * math.sqrt((Rd[2, 1] - Rd[1, 2]) ** 2 + (Rd[0, 2] - Rd[2, 0]) ** 2 + (Rd[1, 0] - Rd[0, 1]) ** 2)
+    ang = math.atan2(s, c)
+    return ang, float(np.linalg.norm(Ta[:3, 3] - Tb[:3, 3]))
