@@ -1,0 +1,160 @@
+/*
+ * rgbd360_hip.h -- C ABI of the MI355X (gfx950) dense spherical RGB-D alignment library.
+ *
+ * Drop-in boundary for ONE path of EduFdez/rgbd360: RegisterPhotoICP's spherical alignment
+ * (setTargetFrame / setSourceFrame / alignFrames360 and the per-pixel passes they call) plus the
+ * adjacent Frame360 per-pixel stages.  Everything is plain C: opaque context, POD structs, raw
+ * pointers and sizes.  File:line citations are relative to the reference tree; "RPI.h" is
+ * include/RegisterPhotoICP.h.
+ *
+ * Conventions
+ *   - 4x4 poses and the 6x6 Hessian are COLUMN-MAJOR float arrays (Eigen's default layout, which
+ *     is what Eigen::Matrix4f::data() of the reference's relPose/hessian hands over).
+ *   - relPose maps source-frame points into the target frame: p_trg = R p_src + t (RPI.h:2663).
+ *   - Images are row-major with an explicit byte stride (cv::Mat::step).  rgb is 8UC3, depth is
+ *     16UC1 millimetres (depth_type 0; Frame360.h:394) or 32FC1 metres (depth_type 1; RPI.h:318).
+ *   - Host image pointers are copied before the call returns; the caller keeps ownership
+ *     (the reference aliases cv::Mat buffers, RPI.h:296,319, and never frees caller memory).
+ *   - A context is stateful and not re-entrant, like a RegisterPhotoICP object (one per thread).
+ *   - Every function returns 0 on success, a positive rgbd360 status (below) for algorithmic
+ *     outcomes and a negative value for HIP/argument errors; rgbd360_last_error() has the text.
+ *   - There is NO CPU fallback: without a usable HIP device rgbd360_create fails.
+ */
+#ifndef RGBD360_HIP_H
+#define RGBD360_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rgbd360_ctx rgbd360_ctx;
+
+/* costFuncType, RPI.h:194 */
+enum { RGBD360_PHOTO_CONSISTENCY = 0, RGBD360_DEPTH_CONSISTENCY = 1, RGBD360_PHOTO_DEPTH = 2 };
+
+/* status codes */
+enum {
+    RGBD360_OK = 0,
+    RGBD360_ILL_POSED = 1,      /* rank(H + lambda diag H) != 6, RPI.h:4682-4690: pose_out = last accepted pose */
+    RGBD360_NO_VALID_PIXELS = 2 /* the error pass found no residual (the reference would divide by zero) */
+};
+
+/* Replaces the constructor defaults + setters of RegisterPhotoICP (RPI.h:201-221, 224-269) and the
+ * loop constants of alignFrames360 (RPI.h:4593-4595). */
+typedef struct {
+    int   n_pyr;            /* setNumPyr, default 4 */
+    float min_depth;        /* setMinDepth, 0.3 m */
+    float max_depth;        /* setMaxDepth, 6.0 m */
+    float sigma_photo;      /* setGrayVariance (sets the std-dev, RPI.h:242-245), 6/255 */
+    float sigma_depth;      /* setDepthVariance (std-dev, RPI.h:248-251), 0.2 */
+    float thres_sal_photo;  /* thresSaliencyIntensity, 0.01 */
+    float thres_sal_depth;  /* thresSaliencyDepth, 0.01 */
+    int   max_iters;        /* 10 */
+    float tol_residual;     /* 1e-3 */
+    float tol_update;       /* 1e-4 */
+    int   mask_seams;       /* 1: zero the gradient bands at the 8-sensor seams (RPI.h:4538-4549) */
+    int   device;           /* HIP device ordinal */
+} rgbd360_params;
+
+/* What callers read from a RegisterPhotoICP after alignFrames360: getHessian()/getGradient()
+ * (RPI.h:279-288), SSO, avPhotoResidual/avDepthResidual (RPI.h:180-189), num_iterations (RPI.h:177). */
+typedef struct {
+    int    status;
+    int    iters[8];        /* accepted Gauss-Newton iterations per pyramid level (index = level) */
+    float  sso;             /* visible pixels / image size at level 0 (RPI.h:3226) */
+    double err_final;       /* RMS residual of the error pass at pose_out, level 0 */
+    double rms_photo;       /* photo / depth RMS of that pass (the reference leaves these unset on this path) */
+    double rms_depth;
+    float  hessian[36];     /* column-major 6x6: H of the last calcHessGrad_sphere the reference would have run */
+    float  gradient[6];
+} rgbd360_result;
+
+void rgbd360_default_params(rgbd360_params* p);
+
+/* RegisterPhotoICP::RegisterPhotoICP() (RPI.h:201) */
+int  rgbd360_create(const rgbd360_params* p, rgbd360_ctx** out);
+void rgbd360_destroy(rgbd360_ctx* ctx);
+const char* rgbd360_last_error(rgbd360_ctx* ctx);
+
+/* RegisterPhotoICP::setTargetFrame(cv::Mat& rgb, cv::Mat& depth) (RPI.h:498-516): gray conversion,
+ * gray + depth pyramids, gradient pyramids.  Host pointers. */
+int rgbd360_set_target(rgbd360_ctx* ctx, const uint8_t* rgb, size_t rgb_step, const void* depth, size_t depth_step,
+                       int depth_type, int rows, int cols);
+/* RegisterPhotoICP::setSourceFrame (RPI.h:480-494) + the per-level LUT of 3-D points (RPI.h:4554-4587). */
+int rgbd360_set_source(rgbd360_ctx* ctx, const uint8_t* rgb, size_t rgb_step, const void* depth, size_t depth_step,
+                       int depth_type, int rows, int cols);
+/* Same, images already resident in device memory (HBM) on the context's device. */
+int rgbd360_set_target_dev(rgbd360_ctx* ctx, const uint8_t* rgb_dev, size_t rgb_step, const void* depth_dev,
+                           size_t depth_step, int depth_type, int rows, int cols);
+int rgbd360_set_source_dev(rgbd360_ctx* ctx, const uint8_t* rgb_dev, size_t rgb_step, const void* depth_dev,
+                           size_t depth_step, int depth_type, int rows, int cols);
+/* Odometry reuse: the previous source frame becomes the target without re-uploading
+ * (OdometryRGBD360.cpp:189-190 re-sets both frames every step). Builds the target gradients on device. */
+int rgbd360_promote_source_to_target(rgbd360_ctx* ctx);
+
+/* RegisterPhotoICP::alignFrames360(pose_guess, method, occlusion) (RPI.h:4519-4784) + getOptimalPose().
+ * occlusion must be 0 (Occ1/Occ2 are SURVEY.md §8f items). */
+int rgbd360_align360(rgbd360_ctx* ctx, const float guess[16], int method, int occlusion, float pose_out[16],
+                     rgbd360_result* res);
+
+/* ---- stage-level entry points (parity tests and measurement) ------------------------------------------------ */
+
+/* Pyramid planes as float32 rows x cols (level dims via rgbd360_level_dims).
+ * which: 0 graySrc 1 grayTrg 2 depthSrc 3 depthTrg 4 grayTrgGradX 5 grayTrgGradY 6 depthTrgGradX 7 depthTrgGradY
+ * (the public pyramid vectors of RPI.h:198-199).  Gradients already carry the seam mask. */
+int rgbd360_level_dims(rgbd360_ctx* ctx, int level, int* rows, int* cols);
+int rgbd360_get_plane(rgbd360_ctx* ctx, int which, int level, float* host_out);
+/* LUT_xyz_sphere of a level (RPI.h:4554-4587) as n x 3 floats; invalid points have x = -10000. */
+int rgbd360_get_lut(rgbd360_ctx* ctx, int level, float* host_out_xyz);
+
+/* One fused per-pixel pass at `pose` on `level`: errorPhotoICP_sphere (RPI.h:2545) and calcHessGrad_sphere
+ * (RPI.h:2745) evaluated at the same pose.  Any output pointer may be NULL.
+ * err2 / n_valid: sum of squared weighted residuals and their count (RPI.h:2707-2729), split photo / depth in
+ * err2_split[2], n_split[2].  H (column-major) and g from float64 block partials of float32 rows. */
+int rgbd360_eval(rgbd360_ctx* ctx, int level, const float pose[16], int method, double* err2, long long* n_valid,
+                 double err2_split[2], long long n_split[2], float H[36], float g[6], double H64[36], double g64[6],
+                 long long* n_visible);
+/* Warped target pixel of every source pixel of `level` under `pose`: out[2i] = r', out[2i+1] = c', -1 if the
+ * pixel is invalid or leaves the image (RPI.h:2663-2684).  Host output, n x 2 int32. */
+int rgbd360_warp_indices(rgbd360_ctx* ctx, int level, const float pose[16], int32_t* host_out_rc);
+/* One Gauss-Newton step on the device from the H,g of the preceding rgbd360_eval... exposed for tests:
+ * pose_tmp = exp(-H^-1 g) * pose (RPI.h:4682-4697).  Returns RGBD360_ILL_POSED when the rank test fails. */
+int rgbd360_gn_step(rgbd360_ctx* ctx, const float H[36], const float g[6], float lambda, const float pose[16],
+                    float pose_tmp[16], float update[6]);
+
+/* Forced schedule for throughput measurement: n_iters Gauss-Newton iterations on `level`
+ * starting at pose0, every step applied regardless of the accept rule, no host round trip.  One iteration =
+ * one fused pass + one solve launch.  Enqueued on the context's stream; *elapsed_ms (may be NULL) is the HIP
+ * event time around the n_iters iterations. */
+int rgbd360_forced_iters(rgbd360_ctx* ctx, int level, const float pose0[16], int method, int n_iters,
+                         float pose_out[16], double* last_rms, float* elapsed_ms);
+/* Average duration in microseconds of `reps` back-to-back launches of the fused per-pixel kernel alone
+ * (HIP events on the stream the kernel is launched on). want_hg = 0 times the error-only variant. */
+int rgbd360_time_eval_kernel(rgbd360_ctx* ctx, int level, const float pose[16], int method, int want_hg, int reps,
+                             float* avg_us);
+
+/* The HIP stream all work of this context is enqueued on (hipStream_t as void*). */
+void* rgbd360_stream(rgbd360_ctx* ctx);
+int   rgbd360_sync(rgbd360_ctx* ctx);
+/* Number of HIP devices visible; does not create a context. */
+int   rgbd360_device_count(void);
+
+/* ---- Frame360 per-pixel stages ------------------------------------------------------------------------------ */
+
+/* Spherical point cloud from a range panorama.
+ * convention 0: Frame360::buildSphereCloud_fromImage (Frame360.h:555-612): depth u16 mm, phi offset 31.5 deg,
+ *               xyz = d (sin phi, -cos phi sin theta, -cos phi cos theta), NaN where depth == 0.
+ * convention 1: Frame360_stereo::buildSphereCloud (Frame360_stereo.h:454-512): depth f32 m valid in (0,15),
+ *               phi = (row+166) step - pi/2, theta = col step - pi, xyz = d (sin theta cos phi, sin phi, cos theta cos phi).
+ * convention 2: full-sphere RegisterPhotoICP convention (RPI.h:4567-4582) with depth_type as in set_source.
+ * Output: xyz as rows*cols x 3 float32 (host).  */
+int rgbd360_sphere_cloud(rgbd360_ctx* ctx, const void* depth, size_t depth_step, int depth_type, int rows, int cols,
+                         int convention, float* host_out_xyz);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RGBD360_HIP_H */

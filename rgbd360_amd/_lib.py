@@ -1,0 +1,72 @@
+"""ctypes binding of include/rgbd360_hip.h.  Loading fails loudly: there is no CPU fallback."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librgbd360_hip.so")
+
+# Every symbol include/rgbd360_hip.h declares (checked by tests/test_abi.py against the header text).
+SYMBOLS = [
+    "rgbd360_default_params", "rgbd360_create", "rgbd360_destroy", "rgbd360_last_error", "rgbd360_set_target",
+    "rgbd360_set_source", "rgbd360_set_target_dev", "rgbd360_set_source_dev", "rgbd360_promote_source_to_target",
+    "rgbd360_align360", "rgbd360_level_dims", "rgbd360_get_plane", "rgbd360_get_lut", "rgbd360_eval",
+    "rgbd360_warp_indices", "rgbd360_gn_step", "rgbd360_forced_iters", "rgbd360_time_eval_kernel", "rgbd360_stream",
+    "rgbd360_sync", "rgbd360_device_count", "rgbd360_sphere_cloud",
+]
+
+
+class Params(C.Structure):
+    _fields_ = [("n_pyr", C.c_int), ("min_depth", C.c_float), ("max_depth", C.c_float), ("sigma_photo", C.c_float),
+                ("sigma_depth", C.c_float), ("thres_sal_photo", C.c_float), ("thres_sal_depth", C.c_float),
+                ("max_iters", C.c_int), ("tol_residual", C.c_float), ("tol_update", C.c_float), ("mask_seams", C.c_int),
+                ("device", C.c_int)]
+
+
+class Result(C.Structure):
+    _fields_ = [("status", C.c_int), ("iters", C.c_int * 8), ("sso", C.c_float), ("err_final", C.c_double),
+                ("rms_photo", C.c_double), ("rms_depth", C.c_double), ("hessian", C.c_float * 36),
+                ("gradient", C.c_float * 6)]
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Returns the loaded HIP library or raises; never substitutes another implementation."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(rgbd360_amd has no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, f32p = C.c_void_p, C.c_int, C.c_void_p
+    L.rgbd360_default_params.argtypes = [C.POINTER(Params)]
+    L.rgbd360_default_params.restype = None
+    L.rgbd360_create.argtypes = [C.POINTER(Params), C.POINTER(vp)]
+    L.rgbd360_destroy.argtypes = [vp]
+    L.rgbd360_destroy.restype = None
+    L.rgbd360_last_error.argtypes = [vp]
+    L.rgbd360_last_error.restype = C.c_char_p
+    for f in (L.rgbd360_set_target, L.rgbd360_set_source, L.rgbd360_set_target_dev, L.rgbd360_set_source_dev):
+        f.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, i32, i32, i32]
+    L.rgbd360_promote_source_to_target.argtypes = [vp]
+    L.rgbd360_align360.argtypes = [vp, f32p, i32, i32, f32p, C.POINTER(Result)]
+    L.rgbd360_level_dims.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
+    L.rgbd360_get_plane.argtypes = [vp, i32, i32, f32p]
+    L.rgbd360_get_lut.argtypes = [vp, i32, f32p]
+    L.rgbd360_eval.argtypes = [vp, i32, f32p, i32, C.POINTER(C.c_double), C.POINTER(C.c_longlong), vp, vp, vp, vp, vp, vp,
+                               C.POINTER(C.c_longlong)]
+    L.rgbd360_warp_indices.argtypes = [vp, i32, f32p, vp]
+    L.rgbd360_gn_step.argtypes = [vp, f32p, f32p, C.c_float, f32p, f32p, f32p]
+    L.rgbd360_forced_iters.argtypes = [vp, i32, f32p, i32, i32, f32p, C.POINTER(C.c_double), C.POINTER(C.c_float)]
+    L.rgbd360_time_eval_kernel.argtypes = [vp, i32, f32p, i32, i32, i32, C.POINTER(C.c_float)]
+    L.rgbd360_stream.argtypes = [vp]
+    L.rgbd360_stream.restype = vp
+    L.rgbd360_sync.argtypes = [vp]
+    L.rgbd360_device_count.argtypes = []
+    L.rgbd360_sphere_cloud.argtypes = [vp, vp, C.c_size_t, i32, i32, i32, i32, f32p]
+    _lib = L
+    return L

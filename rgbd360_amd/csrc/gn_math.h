@@ -1,0 +1,195 @@
+// gn_math.h -- the serial tail of one Gauss-Newton iteration (6x6 rank test, 6x6 inverse, SE(3) pseudo-exp,
+// pose composition), written once for host and device.  Restates what RegisterPhotoICP::alignFrames360 does at
+// RPI.h:4682-4697 through Eigen / MRPT:
+//   (hessian + lambda*getDiagonalMatrix(hessian)).rank()   MRPT Eigen plugin = ColPivHouseholderQR::rank()
+//   update_pose = -hessian.inverse() * gradient            Eigen fixed 6x6 inverse = PartialPivLU
+//   CPose3D::exp(update, pseudo_exponential = true)        t verbatim, R = Rodrigues(w), float64
+//   pose_estim_temp = exp(...).cast<float>() * pose_estim  float32 4x4 product
+// All matrices are column-major like Eigen.
+#pragma once
+
+#if defined(__HIPCC__)
+#define GN_HD __host__ __device__
+#else
+#define GN_HD
+#endif
+
+#include <math.h>
+
+namespace gn {
+
+constexpr float kEpsF = 1.1920929e-07f;
+
+// Number of pivots of a column-pivoted Householder QR of the 6x6 matrix M whose magnitude exceeds
+// |max pivot| * (epsilon * 6)  (Eigen's default threshold for ColPivHouseholderQR::rank()).
+GN_HD inline int rank6(const float* M) {
+    float A[6][6];
+    for (int r = 0; r < 6; ++r)
+        for (int c = 0; c < 6; ++c) A[r][c] = M[c * 6 + r];
+    float maxColSq = 0.f;
+    for (int c = 0; c < 6; ++c) {
+        float s = 0.f;
+        for (int r = 0; r < 6; ++r) s += A[r][c] * A[r][c];
+        maxColSq = s > maxColSq ? s : maxColSq;
+    }
+    const float threshold_helper = maxColSq * (kEpsF * kEpsF) / 6.f;
+    float pivots[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float maxpivot = 0.f;
+    int nonzero = 6;
+    for (int k = 0; k < 6; ++k) {
+        int best = k;
+        float bestSq = -1.f;
+        for (int c = k; c < 6; ++c) {
+            float s = 0.f;
+            for (int r = k; r < 6; ++r) s += A[r][c] * A[r][c];
+            if (s > bestSq) {
+                bestSq = s;
+                best = c;
+            }
+        }
+        if (bestSq < threshold_helper * (float)(6 - k)) {
+            nonzero = k;
+            break;
+        }
+        if (best != k)
+            for (int r = 0; r < 6; ++r) {
+                float tmp = A[r][k];
+                A[r][k] = A[r][best];
+                A[r][best] = tmp;
+            }
+        float tailSq = 0.f;
+        for (int r = k + 1; r < 6; ++r) tailSq += A[r][k] * A[r][k];
+        const float c0 = A[k][k];
+        float beta, tau;
+        float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (tailSq == 0.f) {
+            tau = 0.f;
+            beta = c0;
+        } else {
+            beta = sqrtf(c0 * c0 + tailSq);
+            if (c0 >= 0.f) beta = -beta;
+            for (int r = k + 1; r < 6; ++r) v[r] = A[r][k] / (c0 - beta);
+            tau = (beta - c0) / beta;
+        }
+        v[k] = 1.f;
+        for (int c = k + 1; c < 6; ++c) {
+            float dot = 0.f;
+            for (int r = k; r < 6; ++r) dot += v[r] * A[r][c];
+            dot *= tau;
+            for (int r = k; r < 6; ++r) A[r][c] -= dot * v[r];
+        }
+        A[k][k] = beta;
+        pivots[k] = beta;
+        const float ab = fabsf(beta);
+        maxpivot = ab > maxpivot ? ab : maxpivot;
+    }
+    const float thr = maxpivot * (kEpsF * 6.f);
+    int rank = 0;
+    for (int k = 0; k < nonzero; ++k) rank += (fabsf(pivots[k]) > thr) ? 1 : 0;
+    return rank;
+}
+
+// inv = M^-1 through LU with partial pivoting, column by column against the identity.
+GN_HD inline bool inverse6(const float* M, float* inv) {
+    float LU[6][6];
+    int perm[6];
+    for (int r = 0; r < 6; ++r) {
+        perm[r] = r;
+        for (int c = 0; c < 6; ++c) LU[r][c] = M[c * 6 + r];
+    }
+    for (int k = 0; k < 6; ++k) {
+        int piv = k;
+        float best = fabsf(LU[k][k]);
+        for (int r = k + 1; r < 6; ++r) {
+            const float a = fabsf(LU[r][k]);
+            if (a > best) {
+                best = a;
+                piv = r;
+            }
+        }
+        if (best == 0.f) return false;
+        if (piv != k) {
+            for (int c = 0; c < 6; ++c) {
+                float tmp = LU[k][c];
+                LU[k][c] = LU[piv][c];
+                LU[piv][c] = tmp;
+            }
+            int tp = perm[k];
+            perm[k] = perm[piv];
+            perm[piv] = tp;
+        }
+        for (int r = k + 1; r < 6; ++r) {
+            LU[r][k] /= LU[k][k];
+            for (int c = k + 1; c < 6; ++c) LU[r][c] -= LU[r][k] * LU[k][c];
+        }
+    }
+    for (int col = 0; col < 6; ++col) {
+        float y[6];
+        for (int r = 0; r < 6; ++r) {
+            float s = (perm[r] == col) ? 1.f : 0.f;
+            for (int c = 0; c < r; ++c) s -= LU[r][c] * y[c];
+            y[r] = s;
+        }
+        for (int r = 5; r >= 0; --r) {
+            float s = y[r];
+            for (int c = r + 1; c < 6; ++c) s -= LU[r][c] * y[c];
+            y[r] = s / LU[r][r];
+        }
+        for (int r = 0; r < 6; ++r) inv[col * 6 + r] = y[r];
+    }
+    return true;
+}
+
+// E = [ Rodrigues(v[3..5])  v[0..2] ; 0 0 0 1 ], float64, column-major.
+GN_HD inline void se3_pseudo_exp(const double* v, double* E) {
+    const double wx = v[3], wy = v[4], wz = v[5];
+    const double angle = sqrt(wx * wx + wy * wy + wz * wz);
+    double R[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    if (angle >= 128 * 2.220446049250313e-16) {
+        const double W[3][3] = {{0, -wz, wy}, {wz, 0, -wx}, {-wy, wx, 0}};
+        const double a = sin(angle) / angle, b = (1 - cos(angle)) / (angle * angle);
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                double w2 = 0;
+                for (int k = 0; k < 3; ++k) w2 += W[i][k] * W[k][j];
+                R[i][j] += a * W[i][j] + b * w2;
+            }
+    }
+    for (int k = 0; k < 16; ++k) E[k] = 0;
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) E[j * 4 + i] = R[i][j];
+        E[12 + i] = v[i];
+    }
+    E[15] = 1;
+}
+
+GN_HD inline void mat4_mul(const float* A, const float* B, float* C) {
+    for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 4; ++r)
+            C[c * 4 + r] = ((A[0 * 4 + r] * B[c * 4 + 0] + A[1 * 4 + r] * B[c * 4 + 1]) + A[2 * 4 + r] * B[c * 4 + 2]) +
+                           A[3 * 4 + r] * B[c * 4 + 3];
+}
+
+// One step: returns 0, or 1 when the rank test of (H + lambda diag H) fails.
+GN_HD inline int step(const float* H, const float* g, float lambda, const float* pose, float* pose_tmp, float* update) {
+    float M[36];
+    for (int k = 0; k < 36; ++k) M[k] = H[k];
+    for (int i = 0; i < 6; ++i) M[i * 6 + i] = H[i * 6 + i] + lambda * H[i * 6 + i];
+    if (rank6(M) != 6) return 1;
+    float inv[36];
+    if (!inverse6(H, inv)) return 1;
+    for (int r = 0; r < 6; ++r) {
+        float s = 0.f;
+        for (int c = 0; c < 6; ++c) s += (-inv[c * 6 + r]) * g[c];
+        update[r] = s;
+    }
+    double ud[6], E[16];
+    for (int i = 0; i < 6; ++i) ud[i] = (double)update[i];
+    se3_pseudo_exp(ud, E);
+    float Ef[16];
+    for (int k = 0; k < 16; ++k) Ef[k] = (float)E[k];
+    mat4_mul(Ef, pose, pose_tmp);
+    return 0;
+}
+
+}  // namespace gn

@@ -1,0 +1,642 @@
+// photo_icp_kernels.h -- gfx950 (MI355X, wave64) device code of the dense spherical alignment path.
+//
+// Kernels and the reference loops they replace ("RPI.h" = include/RegisterPhotoICP.h of EduFdez/rgbd360):
+//   k_gray_u8            cv::cvtColor(CV_RGB2GRAY)+convertTo(1/255)            RPI.h:485-486, 502-503
+//   k_depth_to_f32       convertTo(CV_32FC1, 0.001)                             RPI.h:316-319
+//   k_pyrdown_gray       buildPyramid -> cv::pyrDown                            RPI.h:292-308
+//   k_pyrdown_depth      buildPyramidRange                                      RPI.h:312-354
+//   k_gradient_rec       calcGradientXY + seam mask, writes {v,gx,gy} records   RPI.h:365-398, 4538-4549
+//   k_src_rec            LUT_xyz_sphere build, writes {x,y,z,Isrc} records      RPI.h:4554-4587
+//   k_eval<METHOD,HG>    errorPhotoICP_sphere + calcHessGrad_sphere, fused      RPI.h:2545-2739, 2745-3228
+//   k_solve              reductions' tail + the serial part of alignFrames360   RPI.h:4599-4722
+//
+// This translation unit is compiled with -ffp-contract=off: the warp front end (rotation, norm, asin, atan2,
+// rounding) must produce the same float32 values as the CPU oracle so that the nearest-neighbour target pixel
+// is identical; contraction is re-enabled locally (clang fp contract) for the Jacobian / normal-equation part,
+// whose values only need to agree to float32 rounding.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "gn_math.h"
+
+namespace r360 {
+
+constexpr float  kInvalidPoint = -10000.f;      // RPI.h:40
+constexpr double kPI = 3.14159265359;           // Miscellaneous.h:44 (truncated literal, double)
+constexpr int    kEvalThreads = 256;
+constexpr int    kNumPartials = 32;             // doubles per block partial
+// partial slots
+enum { P_H = 0 /*21*/, P_G = 21 /*6*/, P_E2P = 27, P_E2D = 28, P_NP = 29, P_ND = 30, P_NVIS = 31 };
+
+struct F3 {
+    float a, b, c;
+};
+
+struct LevelDev {
+    int rows, cols, n;
+    float half_nRows;        // 0.5*nRows - 0.5
+    float angle_res_inv;     // 1 / float(2*PI/nCols)
+    const float4* src;       // {x, y, z, Isrc} per source pixel; x == -10000 marks an invalid point
+    const F3* trgP;          // {Itrg, gradX, gradY} per target pixel
+    const F3* trgD;          // {Dtrg, dgradX, dgradY} per target pixel
+};
+
+struct EvalConsts {
+    float  sigma_photo, sigma_depth, thr_photo, thr_depth;
+    float  sigma_photo_inv_f;   // float(1./stdDevPhoto)   RPI.h:2774
+    double sigma_photo_inv_d;   // 1./stdDevPhoto          RPI.h:2561
+};
+
+// Device-resident state of one alignment (one per context).  Poses/H column-major.
+struct GNState {
+    float  pose[16];     // accepted pose of the current level
+    float  cand[16];     // pose the next / last fused pass is evaluated at
+    float  H[36], g[6];  // normal equations at `pose`
+    float  Hused[36], gused[6];  // those of the last Gauss-Newton step actually taken (= reference `hessian`)
+    float  update[6];
+    double lambda;
+    double error, new_error, diff_error;
+    double tot[kNumPartials];        // reduced partials of the last pass
+    double acc_e2p, acc_e2d;         // error sums at the accepted pose
+    long long acc_np, acc_nd, acc_nvis, used_nvis, used_npix;
+    int    it, done, status, first, n_evals, pad;
+};
+
+struct SolveCfg {
+    int    mode;          // 0 Gauss-Newton logic, 1 reduce only
+    int    forced;        // apply every step, never terminate
+    int    max_iters;
+    int    n_pixels;
+    double tol_residual, tol_update;
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// scalar helpers (bit-for-bit counterparts of the oracle's math_mode 1)
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float weight_huber(float error, float k) {   // RPI.h:545-554
+    float ea = fabsf(error);
+    if (ea < k) return 1.f;
+    return sqrtf(2 * k * ea - k * k) / ea;
+}
+
+__device__ __forceinline__ float round_half_away(float x) {             // C round()
+    float t = truncf(x);
+    float f = fabsf(x - t);
+    if (f >= 0.5f) t += copysignf(1.f, x);
+    return t;
+}
+
+__device__ __forceinline__ float asinf_poly(float x) {
+    const float c0 = 0.16666672764720836f, c1 = 0.07498809174564633f, c2 = 0.0450107002296682f,
+                c3 = 0.02649427585795898f, c4 = 0.03820645371719902f;
+    float ax = fabsf(x);
+    bool big = ax >= 0.5f;
+    float z = big ? (1.f - ax) * 0.5f : ax * ax;
+    float s = big ? sqrtf(z) : ax;
+    float p = fmaf(z, c4, c3);
+    p = fmaf(z, p, c2);
+    p = fmaf(z, p, c1);
+    p = fmaf(z, p, c0);
+    float r = fmaf(s * z, p, s);
+    if (big) r = 1.57079637f - 2.f * r;
+    return copysignf(r, x);
+}
+
+__device__ __forceinline__ float atan2f_poly(float y, float x) {
+    const float q0 = -0.3333333195069166f, q1 = 0.19999765993465415f, q2 = -0.14279110844310372f,
+                q3 = 0.11037993832882714f, q4 = -0.08673169371217875f, q5 = 0.06284358078457526f,
+                q6 = -0.03627014369584507f, q7 = 0.01375026672953864f, q8 = -0.00244702708829393f;
+    float ay = fabsf(y), ax = fabsf(x);
+    float mx = fmaxf(ay, ax), mn = fminf(ay, ax);
+    float t = (mx == 0.f) ? 0.f : mn / mx;
+    float s = t * t;
+    float p = fmaf(s, q8, q7);
+    p = fmaf(s, p, q6);
+    p = fmaf(s, p, q5);
+    p = fmaf(s, p, q4);
+    p = fmaf(s, p, q3);
+    p = fmaf(s, p, q2);
+    p = fmaf(s, p, q1);
+    p = fmaf(s, p, q0);
+    float a = fmaf(t * s, p, t);
+    if (ay > ax) a = 1.57079637f - a;
+    if (__builtin_signbit(x)) a = 3.14159274f - a;
+    return copysignf(a, y);
+}
+
+struct PoseRT {
+    float r00, r01, r02, r10, r11, r12, r20, r21, r22, tx, ty, tz;
+};
+__device__ __forceinline__ PoseRT load_pose(const float* P) {   // column-major 4x4
+    PoseRT T;
+    T.r00 = P[0]; T.r10 = P[1]; T.r20 = P[2];
+    T.r01 = P[4]; T.r11 = P[5]; T.r21 = P[6];
+    T.r02 = P[8]; T.r12 = P[9]; T.r22 = P[10];
+    T.tx = P[12]; T.ty = P[13]; T.tz = P[14];
+    return T;
+}
+
+// Shared front end of RPI.h:2663-2684 / 2959-2989.  Returns the target pixel index or -1.
+__device__ __forceinline__ int warp_pixel(const PoseRT& T, float px, float py, float pz, const LevelDev& lv, float& X,
+                                          float& Y, float& Z, float& dist, float& dist_inv, int& tr, int& tc) {
+    X = ((T.r00 * px + T.r01 * py) + T.r02 * pz) + T.tx;
+    Y = ((T.r10 * px + T.r11 * py) + T.r12 * pz) + T.ty;
+    Z = ((T.r20 * px + T.r21 * py) + T.r22 * pz) + T.tz;
+    dist = sqrtf((X * X + Y * Y) + Z * Z);
+    dist_inv = 1.f / dist;
+    float phi_trg = asinf_poly(X * dist_inv);
+    float theta_trg = (float)((double)atan2f_poly(Y, Z) + kPI);
+    tr = (int)round_half_away(lv.half_nRows - phi_trg * lv.angle_res_inv);
+    tc = (int)round_half_away(theta_trg * lv.angle_res_inv);
+    bool vis = (tr >= 0 && tr < lv.rows) && (tc < lv.cols) && (tc >= 0);
+    return vis ? tr * lv.cols + tc : -1;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// wave64 sum: DPP inside a 16-lane row, ds_bpermute across the four rows.  Every lane ends with the total.
+// ---------------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dpp_f<0xB1>(v);    // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E>(v);    // quad_perm [2,3,0,1]
+    v += dpp_f<0x141>(v);   // row_half_mirror
+    v += dpp_f<0x140>(v);   // row_mirror
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_eval: one fused pass over the source pixels of a level at pose st->cand.
+//   METHOD: 0 photo, 1 depth, 2 photo+depth.  HG: also accumulate the 21+6 normal-equation terms.
+// Work split: block b owns the contiguous pixel span [cb*chunk, (cb+1)*chunk) (cb = XCD-aware remap of b so
+// that neighbouring spans, which gather neighbouring target rows, share an XCD L2); its 256 lanes sweep the
+// span in coalesced 256-pixel steps (16 B/lane source records), accumulate in float32 registers, then reduce
+// wave (DPP) -> block (LDS) and store 32 float64 partials.  No atomics: the final sum order is fixed.
+// ---------------------------------------------------------------------------------------------------------
+template <int METHOD, bool HG>
+__global__ __launch_bounds__(kEvalThreads) void k_eval(LevelDev lv, EvalConsts ec, const GNState* __restrict__ st,
+                                                        double* __restrict__ partials, int chunk) {
+    if (st->done) return;
+    const int nb = gridDim.x;
+    const int b = blockIdx.x;
+    const int cb = ((nb & 7) == 0) ? (b & 7) * (nb >> 3) + (b >> 3) : b;
+    const PoseRT T = load_pose(st->cand);
+
+    float acc[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) acc[k] = 0.f;
+    double e2p = 0.0, e2d = 0.0;
+    int nP = 0, nD = 0, nVis = 0;
+
+    const int base = cb * chunk;
+    const int end = min(base + chunk, lv.n);
+    for (int i = base + (int)threadIdx.x; i < end; i += kEvalThreads) {
+        const float4 s = lv.src[i];
+        if (s.x == kInvalidPoint) continue;
+        float X, Y, Z, dist, dist_inv;
+        int tr, tc;
+        const int ti = warp_pixel(T, s.x, s.y, s.z, lv, X, Y, Z, dist, dist_inv, tr, tc);
+        if (ti < 0) continue;
+        ++nVis;
+        F3 tp, td;
+        if (METHOD != 1) tp = lv.trgP[ti];
+        if (METHOD != 0) td = lv.trgD[ti];
+
+        // projection Jacobian rows (RPI.h:3000-3026); only needed when a residual survives, but cheap enough
+        float Jw0[6], Jw1[6];
+        if (HG) {
+#pragma clang fp contract(fast)
+            float z_inv = 1.f / Z;
+            float z_inv2 = z_inv * z_inv;
+            float D_atan_theta = 1.f / (1 + Y * Y * z_inv2) * lv.angle_res_inv;
+            float a1 = D_atan_theta * z_inv;
+            float a2 = -Y * z_inv2 * D_atan_theta;
+            float dist_inv2 = dist_inv * dist_inv;
+            float x_dist_inv2 = X * dist_inv2;
+            float D_asin = 1.f / sqrtf(1 - X * x_dist_inv2) * lv.angle_res_inv;
+            float b0 = -D_asin * dist_inv * (1 - X * x_dist_inv2);
+            float b1 = D_asin * (x_dist_inv2 * Y * dist_inv);
+            float b2 = D_asin * (x_dist_inv2 * Z * dist_inv);
+            Jw0[0] = 0.f; Jw0[1] = a1; Jw0[2] = a2;
+            Jw0[3] = a2 * Y - a1 * Z; Jw0[4] = -a2 * X; Jw0[5] = a1 * X;
+            Jw1[0] = b0; Jw1[1] = b1; Jw1[2] = b2;
+            Jw1[3] = b2 * Y - b1 * Z; Jw1[4] = b0 * Z - b2 * X; Jw1[5] = b1 * X - b0 * Y;
+        }
+
+        bool skip_depth = false;
+        if (METHOD != 1) {
+            const float tgx = tp.b, tgy = tp.c;
+            if (fabsf(tgx) < ec.thr_photo && fabsf(tgy) < ec.thr_photo) {
+                skip_depth = true;     // `continue` at RPI.h:2690 / 3039 also skips the depth term
+            } else {
+                const float photoDiff = tp.a - s.w;
+                const float wh = weight_huber(photoDiff, ec.sigma_photo);
+                // error pass: double weight (RPI.h:2559-2562, 2697-2698)
+                const double wpd = (double)wh * ec.sigma_photo_inv_d;
+                const float werr = (float)(wpd * (double)photoDiff);
+                e2p += (double)(werr * werr);
+                ++nP;
+                if (HG) {
+#pragma clang fp contract(fast)
+                    // H,g pass: float weight (RPI.h:2772-2775, 3047-3052)
+                    const float wpf = wh * ec.sigma_photo_inv_f;
+                    const float res = wpf * photoDiff;
+                    const float wgx = wpf * tgx, wgy = wpf * tgy;
+                    float J[6];
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) J[j] = wgx * Jw0[j] + wgy * Jw1[j];
+                    int k = 0;
+#pragma unroll
+                    for (int a = 0; a < 6; ++a)
+#pragma unroll
+                        for (int bb = a; bb < 6; ++bb, ++k) acc[k] += J[a] * J[bb];
+#pragma unroll
+                    for (int a = 0; a < 6; ++a) acc[21 + a] += J[a] * res;
+                }
+            }
+        }
+        if (METHOD != 0 && !skip_depth) {
+            const float depth2 = td.a;
+            if (isfinite(depth2)) {
+                const float tdx = td.b, tdy = td.c;
+                if (!(fabsf(tdx) < ec.thr_depth && fabsf(tdy) < ec.thr_depth)) {
+                    const float depthDiff = depth2 - dist;
+                    const float sd = ec.sigma_depth * depth2;
+                    const float wd = weight_huber(depthDiff, sd) / sd;
+                    const float werr = wd * depthDiff;   // == float(double(wd)*depthDiff): the product is exact in double
+                    e2d += (double)(werr * werr);
+                    ++nD;
+                    if (HG) {
+#pragma clang fp contract(fast)
+                        const float n0 = X * dist_inv, n1 = Y * dist_inv, n2 = Z * dist_inv;
+                        float nJ[6] = {n0, n1, n2, n2 * Y - n1 * Z, n0 * Z - n2 * X, n1 * X - n0 * Y};
+                        float J[6];
+#pragma unroll
+                        for (int j = 0; j < 6; ++j) J[j] = wd * ((tdx * Jw0[j] + tdy * Jw1[j]) - nJ[j]);
+                        int k = 0;
+#pragma unroll
+                        for (int a = 0; a < 6; ++a)
+#pragma unroll
+                            for (int bb = a; bb < 6; ++bb, ++k) acc[k] += J[a] * J[bb];
+#pragma unroll
+                        for (int a = 0; a < 6; ++a) acc[21 + a] += J[a] * werr;
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- reduction: lanes -> wave (f32 DPP) -> block (f64 via LDS) -> one partial row per block ----
+    __shared__ double red[kEvalThreads / 64][kNumPartials];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (HG) {
+#pragma unroll
+        for (int k = 0; k < 27; ++k) {
+            float v = wave_sum(acc[k]);
+            if (lane == 0) red[wave][k] = (double)v;
+        }
+    } else if (lane < 27) {
+        red[wave][lane] = 0.0;
+    }
+    {
+        double v;
+        v = wave_sum_d(e2p);          if (lane == 0) red[wave][P_E2P] = v;
+        v = wave_sum_d(e2d);          if (lane == 0) red[wave][P_E2D] = v;
+        v = wave_sum_d((double)nP);   if (lane == 0) red[wave][P_NP] = v;
+        v = wave_sum_d((double)nD);   if (lane == 0) red[wave][P_ND] = v;
+        v = wave_sum_d((double)nVis); if (lane == 0) red[wave][P_NVIS] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kNumPartials) {
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < kEvalThreads / 64; ++w) v += red[w][threadIdx.x];
+        partials[(size_t)b * kNumPartials + threadIdx.x] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_level_init: entering a pyramid level (RPI.h:4590-4604): it = 0, update = (1,..,1), lambda = 1, the first
+// pass is evaluated at the incoming pose.  use_pose != 0 loads `pose` (first level / stage calls).
+// ---------------------------------------------------------------------------------------------------------
+struct Pose16 {
+    float v[16];
+};
+__global__ void k_level_init(GNState* st, Pose16 pose, int use_pose, int reset_all) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (reset_all) {
+        for (int k = 0; k < 36; ++k) st->H[k] = st->Hused[k] = 0.f;
+        for (int k = 0; k < 6; ++k) st->g[k] = st->gused[k] = 0.f;
+        st->status = 0;
+        st->n_evals = 0;
+        st->acc_e2p = st->acc_e2d = 0.0;
+        st->acc_np = st->acc_nd = st->acc_nvis = st->used_nvis = st->used_npix = 0;
+    }
+    if (use_pose)
+        for (int k = 0; k < 16; ++k) st->pose[k] = pose.v[k];
+    for (int k = 0; k < 16; ++k) st->cand[k] = st->pose[k];
+    for (int k = 0; k < 6; ++k) st->update[k] = 1.f;
+    st->lambda = 1.0;
+    st->it = 0;
+    st->first = 1;
+    st->done = (st->status != 0) ? 1 : 0;
+    st->error = st->new_error = st->diff_error = 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_solve: one block.  (1) fixed-order float64 reduction of the block partials; (2) the serial part of one
+// loop trip of alignFrames360 (accept test, termination test, rank test, GN step, pose composition).
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kSolveThreads = 1024;
+__global__ __launch_bounds__(kSolveThreads) void k_solve(GNState* st, const double* __restrict__ partials, int nb,
+                                                          SolveCfg cfg) {
+    if (cfg.mode == 0 && st->done) return;
+    __shared__ double red[kSolveThreads / kNumPartials][kNumPartials];
+    const int v = threadIdx.x % kNumPartials, q = threadIdx.x / kNumPartials;
+    constexpr int Q = kSolveThreads / kNumPartials;
+    double s = 0.0;
+    for (int b = q; b < nb; b += Q) s += partials[(size_t)b * kNumPartials + v];
+    red[q][v] = s;
+    __syncthreads();
+    if (threadIdx.x < kNumPartials) {
+        double t = 0.0;
+        for (int k = 0; k < Q; ++k) t += red[k][threadIdx.x];
+        st->tot[threadIdx.x] = t;
+        red[0][threadIdx.x] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    st->n_evals += 1;
+    const double* tot = red[0];
+    // normal equations at the evaluated pose (float like the reference's `hessian` / `gradient`)
+    float Hc[36], gc[6];
+    {
+        int k = 0;
+        for (int a = 0; a < 6; ++a)
+            for (int b = a; b < 6; ++b, ++k) Hc[b * 6 + a] = Hc[a * 6 + b] = (float)tot[P_H + k];
+        for (int a = 0; a < 6; ++a) gc[a] = (float)tot[P_G + a];
+    }
+    const double err2 = tot[P_E2P] + tot[P_E2D];
+    const double nvalid = tot[P_NP] + tot[P_ND];
+    const double new_error = sqrt(err2 / nvalid);   // RPI.h:2738
+    st->new_error = new_error;
+    if (cfg.mode == 1) {
+        for (int k = 0; k < 36; ++k) st->H[k] = Hc[k];
+        for (int k = 0; k < 6; ++k) st->g[k] = gc[k];
+        return;
+    }
+    bool take = false;
+    if (st->first) {
+        st->first = 0;
+        if (nvalid == 0.0) {
+            st->status = 2;
+            st->done = 1;
+            return;
+        }
+        st->error = new_error;           // RPI.h:4599
+        st->diff_error = new_error;      // RPI.h:4605
+        take = true;                     // cand == pose
+    } else {
+        const double diff = st->error - new_error;   // RPI.h:4713
+        st->diff_error = diff;
+        if (cfg.forced || diff > cfg.tol_residual) {  // RPI.h:4715-4722
+            st->lambda = st->lambda / 5.0;
+            for (int k = 0; k < 16; ++k) st->pose[k] = st->cand[k];
+            st->error = new_error;
+            st->it += 1;
+            take = true;
+        }
+    }
+    if (take) {
+        for (int k = 0; k < 36; ++k) st->H[k] = Hc[k];
+        for (int k = 0; k < 6; ++k) st->g[k] = gc[k];
+        st->acc_e2p = tot[P_E2P];
+        st->acc_e2d = tot[P_E2D];
+        st->acc_np = (long long)tot[P_NP];
+        st->acc_nd = (long long)tot[P_ND];
+        st->acc_nvis = (long long)tot[P_NVIS];
+    }
+    // while(it < maxIters && update_pose.norm() > tol_update && diff_error > tol_residual)   RPI.h:4611
+    float un = 0.f;
+    for (int k = 0; k < 6; ++k) un += st->update[k] * st->update[k];
+    un = sqrtf(un);
+    const bool go = cfg.forced || (st->it < cfg.max_iters && (double)un > cfg.tol_update && st->diff_error > cfg.tol_residual);
+    if (!go) {
+        st->done = 1;
+        return;
+    }
+    // calcHessGrad_sphere(pose_estim) is what st->H/g hold; record them as "used" (reference `hessian`, `SSO`)
+    for (int k = 0; k < 36; ++k) st->Hused[k] = st->H[k];
+    for (int k = 0; k < 6; ++k) st->gused[k] = st->g[k];
+    st->used_nvis = st->acc_nvis;
+    st->used_npix = cfg.n_pixels;
+    float upd[6], cand[16];
+    if (gn::step(st->H, st->g, (float)st->lambda, st->pose, cand, upd) != 0) {   // RPI.h:4682-4697
+        st->status = 1;
+        st->done = 1;
+        return;
+    }
+    for (int k = 0; k < 6; ++k) st->update[k] = upd[k];
+    for (int k = 0; k < 16; ++k) st->cand[k] = cand[k];
+}
+
+// Standalone GN step for tests: one thread.
+struct GnIO {
+    float H[36], g[6], pose[16], pose_tmp[16], update[6];
+    float lambda;
+    int status;
+};
+__global__ void k_gn_step(GnIO* io) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) io->status = gn::step(io->H, io->g, io->lambda, io->pose, io->pose_tmp, io->update);
+}
+
+// Warp indices of every source pixel (parity diagnostics).
+__global__ void k_warp_indices(LevelDev lv, Pose16 pose, int32_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= lv.n) return;
+    const PoseRT T = load_pose(pose.v);
+    const float4 s = lv.src[i];
+    int r = -1, c = -1;
+    if (s.x != kInvalidPoint) {
+        float X, Y, Z, d, di;
+        int tr, tc;
+        if (warp_pixel(T, s.x, s.y, s.z, lv, X, Y, Z, d, di, tr, tc) >= 0) {
+            r = tr;
+            c = tc;
+        }
+    }
+    out[2 * i] = r;
+    out[2 * i + 1] = c;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// frame preparation
+// ---------------------------------------------------------------------------------------------------------
+// cv::cvtColor(CV_RGB2GRAY) on 8UC3 (fixed point, shift 14) then convertTo(CV_32FC1, 1./255).
+__global__ void k_gray_u8(const uint8_t* __restrict__ rgb, size_t step, int rows, int cols, float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (c >= cols || r >= rows) return;
+    const uint8_t* p = rgb + (size_t)r * step + 3 * c;
+    const int v = (4899 * p[0] + 9617 * p[1] + 1868 * p[2] + 8192) >> 14;
+    out[(size_t)r * cols + c] = (float)v * (float)(1. / 255);
+}
+
+__global__ void k_depth_to_f32(const void* __restrict__ depth, size_t step, int depth_type, int rows, int cols,
+                               float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (c >= cols || r >= rows) return;
+    const uint8_t* row = (const uint8_t*)depth + (size_t)r * step;
+    float v;
+    if (depth_type == 0) v = (float)((const uint16_t*)row)[c] * 0.001f;
+    else v = ((const float*)row)[c];
+    out[(size_t)r * cols + c] = v;
+}
+
+__device__ __forceinline__ int reflect101(int i, int n) {
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = (i < 0) ? -i : 2 * n - 2 - i;
+    return i;
+}
+
+// cv::pyrDown, CV_32FC1, dsize (cols/2, rows/2), BORDER_REFLECT_101; horizontal pass first, then vertical,
+// one scale by 1/256 -- same operation order as the oracle.
+__global__ void k_pyrdown_gray(const float* __restrict__ src, int srows, int scols, float* __restrict__ dst, int drows,
+                               int dcols) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= dcols || y >= drows) return;
+    int cc[5], rr[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        cc[k] = reflect101(2 * x - 2 + k, scols);
+        rr[k] = reflect101(2 * y - 2 + k, srows);
+    }
+    float h[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const float* row = src + (size_t)rr[k] * scols;
+        h[k] = row[cc[2]] * 6 + (row[cc[1]] + row[cc[3]]) * 4 + row[cc[0]] + row[cc[4]];
+    }
+    const float v = h[2] * 6 + (h[1] + h[3]) * 4 + h[0] + h[4];
+    dst[(size_t)y * dcols + x] = v * (1.f / 256.f);
+}
+
+// buildPyramidRange level step: mean of the in-range pixels of each 2x2 block, else 0.
+__global__ void k_pyrdown_depth(const float* __restrict__ src, int scols, float* __restrict__ dst, int drows, int dcols,
+                                float min_depth, float max_depth) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= dcols || y >= drows) return;
+    float av = 0.f;
+    unsigned n = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float z = src[(size_t)(2 * y + i) * scols + 2 * x + j];
+            if (z > min_depth && z < max_depth) {
+                av += z;
+                ++n;
+            }
+        }
+    dst[(size_t)y * dcols + x] = n > 0 ? av / n : 0.f;
+}
+
+// calcGradientXY on one plane + seam mask; writes the interleaved {value, gradX, gradY} gather record.
+__global__ void k_gradient_rec(const float* __restrict__ src, int rows, int cols, int seam_width, F3* __restrict__ rec) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (c >= cols || r >= rows) return;
+    const float v = src[(size_t)r * cols + c];
+    float gx = 0.f, gy = 0.f;
+    if (r >= 1 && r < rows - 1 && c >= 1 && c < cols - 1) {
+        const float xm = src[(size_t)r * cols + c - 1], xp = src[(size_t)r * cols + c + 1];
+        const float ym = src[(size_t)(r - 1) * cols + c], yp = src[(size_t)(r + 1) * cols + c];
+        if ((v > xp && v < xm) || (v < xp && v > xm)) gx = 2.f / (1 / (xp - v) + 1 / (v - xm));
+        if ((v > yp && v < ym) || (v < yp && v > ym)) gy = 2.f / (1 / (yp - v) + 1 / (v - ym));
+    }
+    if (seam_width > 0) {   // columns s*w-1 and s*w, s = 1..7
+        const int s0 = (c + 1) / seam_width, s1 = c / seam_width;
+        const bool on = ((c + 1) % seam_width == 0 && s0 >= 1 && s0 <= 7) || (c % seam_width == 0 && s1 >= 1 && s1 <= 7);
+        if (on) gx = gy = 0.f;
+    }
+    F3 o;
+    o.a = v; o.b = gx; o.c = gy;
+    rec[(size_t)r * cols + c] = o;
+}
+
+// LUT_xyz_sphere + source intensity -> {x,y,z,I}.  sin/cos tables come from the host's libm (same values as
+// the CPU path: RPI.h:4559-4571 evaluates them once per column / row).
+__global__ void k_src_rec(const float* __restrict__ depth, const float* __restrict__ gray, int rows, int cols,
+                          const float* __restrict__ sin_theta, const float* __restrict__ cos_theta,
+                          const float* __restrict__ sin_phi, const float* __restrict__ cos_phi, float min_depth,
+                          float max_depth, float4* __restrict__ rec) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (c >= cols || r >= rows) return;
+    const size_t i = (size_t)r * cols + c;
+    const float d = depth[i];
+    float4 o;
+    o.w = gray[i];
+    if (min_depth < d && d < max_depth) {
+        o.x = d * sin_phi[r];
+        o.y = -d * cos_phi[r] * sin_theta[c];
+        o.z = -d * cos_phi[r] * cos_theta[c];
+    } else {
+        o.x = kInvalidPoint;
+        o.y = 0.f;
+        o.z = 0.f;
+    }
+    rec[i] = o;
+}
+
+// Frame360 sphere clouds (Frame360.h:555-612, Frame360_stereo.h:454-512) and the RegisterPhotoICP convention.
+__global__ void k_sphere_cloud(const void* __restrict__ depth, size_t step, int depth_type, int rows, int cols,
+                               int convention, const float* __restrict__ sin_theta, const float* __restrict__ cos_theta,
+                               const float* __restrict__ sin_phi, const float* __restrict__ cos_phi,
+                               float* __restrict__ xyz) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y;
+    if (c >= cols || r >= rows) return;
+    const uint8_t* row = (const uint8_t*)depth + (size_t)r * step;
+    float d;
+    if (depth_type == 0) d = 0.001f * (float)((const uint16_t*)row)[c];
+    else d = ((const float*)row)[c];
+    const float qnan = __builtin_nanf("");
+    float x = qnan, y = qnan, z = qnan;
+    if (convention == 0) {
+        if (d != 0) {
+            x = sin_phi[r] * d;
+            y = -cos_phi[r] * sin_theta[c] * d;
+            z = -cos_phi[r] * cos_theta[c] * d;
+        }
+    } else if (convention == 1) {
+        if (d > 0.f && d < 15.f) {
+            x = sin_theta[c] * cos_phi[r] * d;
+            y = sin_phi[r] * d;
+            z = cos_theta[c] * cos_phi[r] * d;
+        }
+    } else {
+        if (d != 0) {
+            x = d * sin_phi[r];
+            y = -d * cos_phi[r] * sin_theta[c];
+            z = -d * cos_phi[r] * cos_theta[c];
+        }
+    }
+    float* o = xyz + 3 * ((size_t)r * cols + c);
+    o[0] = x; o[1] = y; o[2] = z;
+}
+
+}  // namespace r360

@@ -1,0 +1,654 @@
+// rgbd360_api.hip -- host side of the C ABI declared in include/rgbd360_hip.h.
+//
+// Mirrors the call protocol of RegisterPhotoICP (RPI.h:201-288 setters, 480-516 frame setup, 4519-4784
+// alignFrames360): frames are converted to device-resident pyramids once; an alignment is a sequence of
+// {fused per-pixel pass, solve} launches per pyramid level on one HIP stream, with the Gauss-Newton state
+// (poses, H, g, error, iteration counters) living in device memory.  The host only polls a "level done" flag.
+// There is no CPU fallback anywhere in this file.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rgbd360_hip.h"
+#include "photo_icp_kernels.h"
+
+using namespace r360;
+
+namespace {
+
+struct Level {
+    int rows = 0, cols = 0, n = 0;
+    float half_nRows = 0.f, angle_res_inv = 0.f;
+    float *graySrc = nullptr, *depthSrc = nullptr, *grayTrg = nullptr, *depthTrg = nullptr;
+    float4* srcRec = nullptr;
+    F3 *trgP = nullptr, *trgD = nullptr;
+    float *sinT = nullptr, *cosT = nullptr, *sinP = nullptr, *cosP = nullptr;
+    int nblocks = 0, chunk = 0;
+};
+
+}  // namespace
+
+struct rgbd360_ctx {
+    rgbd360_params p;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<Level> levels;
+    int rows = 0, cols = 0;
+    bool have_src = false, have_trg = false;
+    GNState* d_state = nullptr;
+    GNState* h_state = nullptr;   // pinned
+    double* d_partials = nullptr;
+    GnIO* d_gnio = nullptr;
+    uint8_t* d_stage_rgb = nullptr;
+    uint8_t* d_stage_depth = nullptr;
+    size_t stage_rgb_bytes = 0, stage_depth_bytes = 0;
+    int poll_chunk = 2;           // {pass, solve} pairs enqueued between two polls of the done flag
+    std::string err;
+};
+
+namespace {
+
+#define HIPC(ctx, expr)                                                                                   \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess) {                                                                           \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                               \
+            return -(int)e_ - 1000;                                                                       \
+        }                                                                                                 \
+    } while (0)
+
+int fail(rgbd360_ctx* ctx, int code, const char* msg) {
+    ctx->err = msg;
+    return code;
+}
+
+void free_levels(rgbd360_ctx* ctx) {
+    for (Level& L : ctx->levels) {
+        hipFree(L.graySrc); hipFree(L.depthSrc); hipFree(L.grayTrg); hipFree(L.depthTrg);
+        hipFree(L.srcRec); hipFree(L.trgP); hipFree(L.trgD);
+        hipFree(L.sinT); hipFree(L.cosT); hipFree(L.sinP); hipFree(L.cosP);
+    }
+    ctx->levels.clear();
+    ctx->rows = ctx->cols = 0;
+    ctx->have_src = ctx->have_trg = false;
+}
+
+int ensure_levels(rgbd360_ctx* ctx, int rows, int cols) {
+    if (ctx->rows == rows && ctx->cols == cols && !ctx->levels.empty()) return 0;
+    if (rows < 2 || cols < 8) return fail(ctx, -1, "image too small");
+    if ((rows >> (ctx->p.n_pyr - 1)) < 2 || (cols >> (ctx->p.n_pyr - 1)) < 8)
+        return fail(ctx, -1, "too many pyramid levels for this image size (coarsest level must be >= 2 x 8)");
+    if ((long long)rows * cols >= (1ll << 30)) return fail(ctx, -1, "image too large");
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    free_levels(ctx);
+    ctx->levels.resize(ctx->p.n_pyr);
+    int r = rows, c = cols;
+    int max_blocks = 0;
+    for (int l = 0; l < ctx->p.n_pyr; ++l) {
+        Level& L = ctx->levels[l];
+        L.rows = r; L.cols = c; L.n = r * c;
+        const float angle_res = 2 * kPI / c;        // RPI.h:2554
+        L.angle_res_inv = 1 / angle_res;            // RPI.h:2555
+        L.half_nRows = 0.5 * r - 0.5;               // RPI.h:2557
+        const size_t nb = (size_t)L.n * sizeof(float);
+        HIPC(ctx, hipMalloc(&L.graySrc, nb)); HIPC(ctx, hipMalloc(&L.depthSrc, nb));
+        HIPC(ctx, hipMalloc(&L.grayTrg, nb)); HIPC(ctx, hipMalloc(&L.depthTrg, nb));
+        HIPC(ctx, hipMalloc(&L.srcRec, (size_t)L.n * sizeof(float4)));
+        HIPC(ctx, hipMalloc(&L.trgP, (size_t)L.n * sizeof(F3)));
+        HIPC(ctx, hipMalloc(&L.trgD, (size_t)L.n * sizeof(F3)));
+        HIPC(ctx, hipMalloc(&L.sinT, c * sizeof(float))); HIPC(ctx, hipMalloc(&L.cosT, c * sizeof(float)));
+        HIPC(ctx, hipMalloc(&L.sinP, r * sizeof(float))); HIPC(ctx, hipMalloc(&L.cosP, r * sizeof(float)));
+        // RPI.h:4556-4571: per-column / per-row sin, cos of float arguments (host libm, once per size)
+        std::vector<float> st(c), ct(c), sp(r), cp(r);
+        for (int j = 0; j < c; ++j) {
+            float theta = j * angle_res;
+            st[j] = sinf(theta);
+            ct[j] = cosf(theta);
+        }
+        for (int i = 0; i < r; ++i) {
+            float phi = (L.half_nRows - i) * angle_res;
+            sp[i] = sinf(phi);
+            cp[i] = cosf(phi);
+        }
+        HIPC(ctx, hipMemcpy(L.sinT, st.data(), c * sizeof(float), hipMemcpyHostToDevice));
+        HIPC(ctx, hipMemcpy(L.cosT, ct.data(), c * sizeof(float), hipMemcpyHostToDevice));
+        HIPC(ctx, hipMemcpy(L.sinP, sp.data(), r * sizeof(float), hipMemcpyHostToDevice));
+        HIPC(ctx, hipMemcpy(L.cosP, cp.data(), r * sizeof(float), hipMemcpyHostToDevice));
+        // work split of the fused pass: <= 1024 blocks, contiguous spans that are multiples of 256 pixels
+        int chunk = (L.n + 1023) / 1024;
+        chunk = ((chunk + kEvalThreads - 1) / kEvalThreads) * kEvalThreads;
+        L.chunk = chunk;
+        L.nblocks = (L.n + chunk - 1) / chunk;
+        if (L.nblocks > max_blocks) max_blocks = L.nblocks;
+        r /= 2; c /= 2;
+    }
+    hipFree(ctx->d_partials);
+    ctx->d_partials = nullptr;
+    HIPC(ctx, hipMalloc(&ctx->d_partials, (size_t)max_blocks * kNumPartials * sizeof(double)));
+    ctx->rows = rows; ctx->cols = cols;
+    return 0;
+}
+
+LevelDev level_dev(const Level& L) {
+    LevelDev d;
+    d.rows = L.rows; d.cols = L.cols; d.n = L.n;
+    d.half_nRows = L.half_nRows; d.angle_res_inv = L.angle_res_inv;
+    d.src = L.srcRec; d.trgP = L.trgP; d.trgD = L.trgD;
+    return d;
+}
+
+EvalConsts eval_consts(const rgbd360_params& p) {
+    EvalConsts e;
+    e.sigma_photo = p.sigma_photo; e.sigma_depth = p.sigma_depth;
+    e.thr_photo = p.thres_sal_photo; e.thr_depth = p.thres_sal_depth;
+    e.sigma_photo_inv_f = 1. / p.sigma_photo;
+    e.sigma_photo_inv_d = 1. / p.sigma_photo;
+    return e;
+}
+
+dim3 grid2d(int rows, int cols, int bx = 256) { return dim3((cols + bx - 1) / bx, rows, 1); }
+
+void launch_eval(rgbd360_ctx* ctx, int level, int method, bool hg) {
+    const Level& L = ctx->levels[level];
+    const LevelDev lv = level_dev(L);
+    const EvalConsts ec = eval_consts(ctx->p);
+    dim3 g(L.nblocks), b(kEvalThreads);
+#define LAUNCH(M, HG) hipLaunchKernelGGL((k_eval<M, HG>), g, b, 0, ctx->stream, lv, ec, ctx->d_state, ctx->d_partials, L.chunk)
+    if (hg) {
+        if (method == 0) LAUNCH(0, true);
+        else if (method == 1) LAUNCH(1, true);
+        else LAUNCH(2, true);
+    } else {
+        if (method == 0) LAUNCH(0, false);
+        else if (method == 1) LAUNCH(1, false);
+        else LAUNCH(2, false);
+    }
+#undef LAUNCH
+}
+
+void launch_solve(rgbd360_ctx* ctx, int level, int mode, int forced) {
+    const Level& L = ctx->levels[level];
+    SolveCfg cfg;
+    cfg.mode = mode; cfg.forced = forced; cfg.max_iters = ctx->p.max_iters; cfg.n_pixels = L.n;
+    cfg.tol_residual = ctx->p.tol_residual; cfg.tol_update = ctx->p.tol_update;
+    hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), 0, ctx->stream, ctx->d_state, ctx->d_partials, L.nblocks, cfg);
+}
+
+void launch_level_init(rgbd360_ctx* ctx, const float* pose, int reset_all) {
+    Pose16 P;
+    if (pose) memcpy(P.v, pose, sizeof(P.v));
+    else memset(P.v, 0, sizeof(P.v));
+    hipLaunchKernelGGL(k_level_init, dim3(1), dim3(64), 0, ctx->stream, ctx->d_state, P, pose ? 1 : 0, reset_all);
+}
+
+int read_state(rgbd360_ctx* ctx) {
+    HIPC(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(GNState), hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int check_args(rgbd360_ctx* ctx, int level, int method) {
+    if (!ctx) return -1;
+    if (!ctx->have_src || !ctx->have_trg) return fail(ctx, -2, "set_target and set_source must be called first");
+    if (level < 0 || level >= (int)ctx->levels.size()) return fail(ctx, -3, "bad pyramid level");
+    if (method < 0 || method > 2) return fail(ctx, -4, "bad method");
+    return 0;
+}
+
+int set_frame(rgbd360_ctx* ctx, bool target, const uint8_t* rgb, size_t rgb_step, const void* depth, size_t d_step,
+              int depth_type, int rows, int cols, bool on_device) {
+    if (!ctx) return -1;
+    if (!rgb || !depth) return fail(ctx, -1, "null image pointer");
+    if (depth_type != 0 && depth_type != 1) return fail(ctx, -1, "depth_type must be 0 (u16 mm) or 1 (f32 m)");
+    if (ctx->levels.size() && (rows != ctx->rows || cols != ctx->cols) && (target ? ctx->have_src : ctx->have_trg)) {
+        // the other frame has different dimensions: both must be set again (the reference would read out of bounds)
+        if (target) ctx->have_src = false; else ctx->have_trg = false;
+    }
+    int rc = ensure_levels(ctx, rows, cols);
+    if (rc) return rc;
+    const size_t dpx = depth_type == 0 ? 2 : 4;
+    const uint8_t* d_rgb = rgb;
+    const void* d_depth = depth;
+    size_t s_rgb = rgb_step, s_depth = d_step;
+    if (!on_device) {
+        const size_t need_rgb = (size_t)rows * cols * 3, need_d = (size_t)rows * cols * dpx;
+        if (ctx->stage_rgb_bytes < need_rgb) {
+            hipFree(ctx->d_stage_rgb);
+            HIPC(ctx, hipMalloc(&ctx->d_stage_rgb, need_rgb));
+            ctx->stage_rgb_bytes = need_rgb;
+        }
+        if (ctx->stage_depth_bytes < need_d) {
+            hipFree(ctx->d_stage_depth);
+            HIPC(ctx, hipMalloc(&ctx->d_stage_depth, need_d));
+            ctx->stage_depth_bytes = need_d;
+        }
+        HIPC(ctx, hipMemcpy2DAsync(ctx->d_stage_rgb, (size_t)cols * 3, rgb, rgb_step, (size_t)cols * 3, rows,
+                                   hipMemcpyHostToDevice, ctx->stream));
+        HIPC(ctx, hipMemcpy2DAsync(ctx->d_stage_depth, (size_t)cols * dpx, depth, d_step, (size_t)cols * dpx, rows,
+                                   hipMemcpyHostToDevice, ctx->stream));
+        d_rgb = ctx->d_stage_rgb; d_depth = ctx->d_stage_depth;
+        s_rgb = (size_t)cols * 3; s_depth = (size_t)cols * dpx;
+    }
+    Level& L0 = ctx->levels[0];
+    float* gray0 = target ? L0.grayTrg : L0.graySrc;
+    float* dep0 = target ? L0.depthTrg : L0.depthSrc;
+    hipLaunchKernelGGL(k_gray_u8, grid2d(rows, cols), dim3(256), 0, ctx->stream, d_rgb, s_rgb, rows, cols, gray0);
+    hipLaunchKernelGGL(k_depth_to_f32, grid2d(rows, cols), dim3(256), 0, ctx->stream, d_depth, s_depth, depth_type, rows,
+                       cols, dep0);
+    for (int l = 1; l < ctx->p.n_pyr; ++l) {
+        Level &P = ctx->levels[l - 1], &C = ctx->levels[l];
+        hipLaunchKernelGGL(k_pyrdown_gray, grid2d(C.rows, C.cols), dim3(256), 0, ctx->stream,
+                           target ? P.grayTrg : P.graySrc, P.rows, P.cols, target ? C.grayTrg : C.graySrc, C.rows, C.cols);
+        hipLaunchKernelGGL(k_pyrdown_depth, grid2d(C.rows, C.cols), dim3(256), 0, ctx->stream,
+                           target ? P.depthTrg : P.depthSrc, P.cols, target ? C.depthTrg : C.depthSrc, C.rows, C.cols,
+                           ctx->p.min_depth, ctx->p.max_depth);
+    }
+    for (int l = 0; l < ctx->p.n_pyr; ++l) {
+        Level& L = ctx->levels[l];
+        if (target) {
+            const int seam = ctx->p.mask_seams ? L.cols / 8 : 0;
+            hipLaunchKernelGGL(k_gradient_rec, grid2d(L.rows, L.cols), dim3(256), 0, ctx->stream, L.grayTrg, L.rows, L.cols,
+                               seam, L.trgP);
+            hipLaunchKernelGGL(k_gradient_rec, grid2d(L.rows, L.cols), dim3(256), 0, ctx->stream, L.depthTrg, L.rows,
+                               L.cols, seam, L.trgD);
+        } else {
+            hipLaunchKernelGGL(k_src_rec, grid2d(L.rows, L.cols), dim3(256), 0, ctx->stream, L.depthSrc, L.graySrc, L.rows,
+                               L.cols, L.sinT, L.cosT, L.sinP, L.cosP, ctx->p.min_depth, ctx->p.max_depth, L.srcRec);
+        }
+    }
+    HIPC(ctx, hipGetLastError());
+    if (!on_device) HIPC(ctx, hipStreamSynchronize(ctx->stream));   // host buffers may be reused by the caller
+    if (target) ctx->have_trg = true; else ctx->have_src = true;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+void rgbd360_default_params(rgbd360_params* p) {
+    p->n_pyr = 4;
+    p->min_depth = 0.3f;
+    p->max_depth = 6.0f;
+    p->sigma_photo = (float)(6. / 255);
+    p->sigma_depth = (float)0.2;
+    p->thres_sal_photo = 0.01f;
+    p->thres_sal_depth = 0.01f;
+    p->max_iters = 10;
+    p->tol_residual = 1e-3f;
+    p->tol_update = 1e-4f;
+    p->mask_seams = 1;
+    p->device = 0;
+}
+
+int rgbd360_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int rgbd360_create(const rgbd360_params* p, rgbd360_ctx** out) {
+    if (!p || !out) return -1;
+    *out = nullptr;
+    if (p->n_pyr < 1 || p->n_pyr > 8) return -1;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return -100;   // no HIP device: no fallback
+    if (p->device < 0 || p->device >= ndev) return -101;
+    if (hipSetDevice(p->device) != hipSuccess) return -102;
+    rgbd360_ctx* ctx = new rgbd360_ctx();
+    ctx->p = *p;
+    bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreate(&ctx->ev0) == hipSuccess && hipEventCreate(&ctx->ev1) == hipSuccess &&
+              hipMalloc(&ctx->d_state, sizeof(GNState)) == hipSuccess &&
+              hipMemset(ctx->d_state, 0, sizeof(GNState)) == hipSuccess &&
+              hipMalloc(&ctx->d_gnio, sizeof(GnIO)) == hipSuccess &&
+              hipHostMalloc((void**)&ctx->h_state, sizeof(GNState), hipHostMallocDefault) == hipSuccess;
+    if (!ok) {
+        rgbd360_destroy(ctx);
+        return -103;
+    }
+    *out = ctx;
+    return 0;
+}
+
+void rgbd360_destroy(rgbd360_ctx* ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->p.device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    free_levels(ctx);
+    hipFree(ctx->d_state); hipFree(ctx->d_partials); hipFree(ctx->d_gnio);
+    hipFree(ctx->d_stage_rgb); hipFree(ctx->d_stage_depth);
+    if (ctx->h_state) hipHostFree(ctx->h_state);
+    if (ctx->ev0) hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) hipEventDestroy(ctx->ev1);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* rgbd360_last_error(rgbd360_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+void* rgbd360_stream(rgbd360_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+int rgbd360_sync(rgbd360_ctx* ctx) {
+    if (!ctx) return -1;
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int rgbd360_set_target(rgbd360_ctx* ctx, const uint8_t* rgb, size_t rgb_step, const void* depth, size_t depth_step,
+                       int depth_type, int rows, int cols) {
+    if (ctx) hipSetDevice(ctx->p.device);
+    return set_frame(ctx, true, rgb, rgb_step, depth, depth_step, depth_type, rows, cols, false);
+}
+int rgbd360_set_source(rgbd360_ctx* ctx, const uint8_t* rgb, size_t rgb_step, const void* depth, size_t depth_step,
+                       int depth_type, int rows, int cols) {
+    if (ctx) hipSetDevice(ctx->p.device);
+    return set_frame(ctx, false, rgb, rgb_step, depth, depth_step, depth_type, rows, cols, false);
+}
+int rgbd360_set_target_dev(rgbd360_ctx* ctx, const uint8_t* rgb, size_t rgb_step, const void* depth, size_t depth_step,
+                           int depth_type, int rows, int cols) {
+    if (ctx) hipSetDevice(ctx->p.device);
+    return set_frame(ctx, true, rgb, rgb_step, depth, depth_step, depth_type, rows, cols, true);
+}
+int rgbd360_set_source_dev(rgbd360_ctx* ctx, const uint8_t* rgb, size_t rgb_step, const void* depth, size_t depth_step,
+                           int depth_type, int rows, int cols) {
+    if (ctx) hipSetDevice(ctx->p.device);
+    return set_frame(ctx, false, rgb, rgb_step, depth, depth_step, depth_type, rows, cols, true);
+}
+
+int rgbd360_promote_source_to_target(rgbd360_ctx* ctx) {
+    if (!ctx) return -1;
+    if (!ctx->have_src) return fail(ctx, -2, "no source frame to promote");
+    hipSetDevice(ctx->p.device);
+    for (Level& L : ctx->levels) {
+        std::swap(L.graySrc, L.grayTrg);
+        std::swap(L.depthSrc, L.depthTrg);
+        const int seam = ctx->p.mask_seams ? L.cols / 8 : 0;
+        hipLaunchKernelGGL(k_gradient_rec, grid2d(L.rows, L.cols), dim3(256), 0, ctx->stream, L.grayTrg, L.rows, L.cols, seam,
+                           L.trgP);
+        hipLaunchKernelGGL(k_gradient_rec, grid2d(L.rows, L.cols), dim3(256), 0, ctx->stream, L.depthTrg, L.rows, L.cols,
+                           seam, L.trgD);
+    }
+    HIPC(ctx, hipGetLastError());
+    ctx->have_trg = true;
+    ctx->have_src = false;
+    return 0;
+}
+
+int rgbd360_align360(rgbd360_ctx* ctx, const float guess[16], int method, int occlusion, float pose_out[16],
+                     rgbd360_result* res) {
+    int rc = check_args(ctx, 0, method);
+    if (rc) return rc;
+    if (occlusion != 0) return fail(ctx, -5, "occlusion modes 1/2 are not implemented (SURVEY.md 8f)");
+    if (!guess || !pose_out) return fail(ctx, -1, "null pose pointer");
+    hipSetDevice(ctx->p.device);
+    rgbd360_result R;
+    memset(&R, 0, sizeof(R));
+    for (int level = ctx->p.n_pyr - 1; level >= 0; --level) {
+        const bool top = (level == ctx->p.n_pyr - 1);
+        launch_level_init(ctx, top ? guess : nullptr, top ? 1 : 0);
+        int guard = 0;
+        for (;;) {
+            for (int k = 0; k < ctx->poll_chunk; ++k) {
+                launch_eval(ctx, level, method, true);
+                launch_solve(ctx, level, 0, 0);
+            }
+            HIPC(ctx, hipGetLastError());
+            rc = read_state(ctx);
+            if (rc) return rc;
+            if (ctx->h_state->done) break;
+            if (++guard > ctx->p.max_iters + 4) return fail(ctx, -6, "alignment loop did not terminate");
+        }
+        R.iters[level] = ctx->h_state->it;
+        if (ctx->h_state->status != 0) break;
+    }
+    const GNState& S = *ctx->h_state;
+    memcpy(pose_out, S.pose, sizeof(float) * 16);
+    R.status = S.status;
+    memcpy(R.hessian, S.Hused, sizeof(R.hessian));
+    memcpy(R.gradient, S.gused, sizeof(R.gradient));
+    R.sso = S.used_npix ? (float)S.used_nvis / (float)S.used_npix : 0.f;
+    const double nv = (double)(S.acc_np + S.acc_nd);
+    R.err_final = nv > 0 ? sqrt((S.acc_e2p + S.acc_e2d) / nv) : 0.0;
+    R.rms_photo = S.acc_np > 0 ? sqrt(S.acc_e2p / (double)S.acc_np) : 0.0;
+    R.rms_depth = S.acc_nd > 0 ? sqrt(S.acc_e2d / (double)S.acc_nd) : 0.0;
+    if (res) *res = R;
+    return R.status;
+}
+
+int rgbd360_level_dims(rgbd360_ctx* ctx, int level, int* rows, int* cols) {
+    if (!ctx || level < 0 || level >= (int)ctx->levels.size()) return -3;
+    *rows = ctx->levels[level].rows;
+    *cols = ctx->levels[level].cols;
+    return 0;
+}
+
+int rgbd360_get_plane(rgbd360_ctx* ctx, int which, int level, float* host_out) {
+    if (!ctx || !host_out) return -1;
+    if (level < 0 || level >= (int)ctx->levels.size()) return fail(ctx, -3, "bad pyramid level");
+    hipSetDevice(ctx->p.device);
+    const Level& L = ctx->levels[level];
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    if (which >= 0 && which <= 3) {
+        const float* src = which == 0 ? L.graySrc : which == 1 ? L.grayTrg : which == 2 ? L.depthSrc : L.depthTrg;
+        HIPC(ctx, hipMemcpy(host_out, src, (size_t)L.n * sizeof(float), hipMemcpyDeviceToHost));
+        return 0;
+    }
+    if (which >= 4 && which <= 7) {
+        std::vector<F3> tmp(L.n);
+        HIPC(ctx, hipMemcpy(tmp.data(), which < 6 ? L.trgP : L.trgD, (size_t)L.n * sizeof(F3), hipMemcpyDeviceToHost));
+        const bool x = (which == 4 || which == 6);
+        for (int i = 0; i < L.n; ++i) host_out[i] = x ? tmp[i].b : tmp[i].c;
+        return 0;
+    }
+    return fail(ctx, -4, "bad plane id");
+}
+
+int rgbd360_get_lut(rgbd360_ctx* ctx, int level, float* host_out_xyz) {
+    if (!ctx || !host_out_xyz) return -1;
+    if (level < 0 || level >= (int)ctx->levels.size()) return fail(ctx, -3, "bad pyramid level");
+    if (!ctx->have_src) return fail(ctx, -2, "no source frame");
+    hipSetDevice(ctx->p.device);
+    const Level& L = ctx->levels[level];
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<float4> tmp(L.n);
+    HIPC(ctx, hipMemcpy(tmp.data(), L.srcRec, (size_t)L.n * sizeof(float4), hipMemcpyDeviceToHost));
+    for (int i = 0; i < L.n; ++i) {
+        host_out_xyz[3 * i] = tmp[i].x;
+        host_out_xyz[3 * i + 1] = tmp[i].y;
+        host_out_xyz[3 * i + 2] = tmp[i].z;
+    }
+    return 0;
+}
+
+int rgbd360_eval(rgbd360_ctx* ctx, int level, const float pose[16], int method, double* err2, long long* n_valid,
+                 double err2_split[2], long long n_split[2], float H[36], float g[6], double H64[36], double g64[6],
+                 long long* n_visible) {
+    int rc = check_args(ctx, level, method);
+    if (rc) return rc;
+    if (!pose) return fail(ctx, -1, "null pose pointer");
+    hipSetDevice(ctx->p.device);
+    launch_level_init(ctx, pose, 1);
+    launch_eval(ctx, level, method, true);
+    launch_solve(ctx, level, 1, 0);
+    HIPC(ctx, hipGetLastError());
+    rc = read_state(ctx);
+    if (rc) return rc;
+    const GNState& S = *ctx->h_state;
+    if (err2) *err2 = S.tot[P_E2P] + S.tot[P_E2D];
+    if (n_valid) *n_valid = (long long)(S.tot[P_NP] + S.tot[P_ND]);
+    if (err2_split) { err2_split[0] = S.tot[P_E2P]; err2_split[1] = S.tot[P_E2D]; }
+    if (n_split) { n_split[0] = (long long)S.tot[P_NP]; n_split[1] = (long long)S.tot[P_ND]; }
+    if (H) memcpy(H, S.H, sizeof(float) * 36);
+    if (g) memcpy(g, S.g, sizeof(float) * 6);
+    if (H64 || g64) {
+        int k = 0;
+        for (int a = 0; a < 6; ++a)
+            for (int b = a; b < 6; ++b, ++k)
+                if (H64) H64[b * 6 + a] = H64[a * 6 + b] = S.tot[P_H + k];
+        if (g64)
+            for (int a = 0; a < 6; ++a) g64[a] = S.tot[P_G + a];
+    }
+    if (n_visible) *n_visible = (long long)S.tot[P_NVIS];
+    return 0;
+}
+
+int rgbd360_warp_indices(rgbd360_ctx* ctx, int level, const float pose[16], int32_t* host_out_rc) {
+    if (!ctx || !pose || !host_out_rc) return -1;
+    if (level < 0 || level >= (int)ctx->levels.size()) return fail(ctx, -3, "bad pyramid level");
+    if (!ctx->have_src) return fail(ctx, -2, "no source frame");
+    hipSetDevice(ctx->p.device);
+    const Level& L = ctx->levels[level];
+    int32_t* d_out = nullptr;
+    HIPC(ctx, hipMalloc(&d_out, (size_t)L.n * 2 * sizeof(int32_t)));
+    Pose16 P;
+    memcpy(P.v, pose, sizeof(P.v));
+    hipLaunchKernelGGL(k_warp_indices, dim3((L.n + 255) / 256), dim3(256), 0, ctx->stream, level_dev(L), P, d_out);
+    hipError_t e = hipMemcpyAsync(host_out_rc, d_out, (size_t)L.n * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipFree(d_out);
+    HIPC(ctx, e);
+    return 0;
+}
+
+int rgbd360_gn_step(rgbd360_ctx* ctx, const float H[36], const float g[6], float lambda, const float pose[16],
+                    float pose_tmp[16], float update[6]) {
+    if (!ctx || !H || !g || !pose) return -1;
+    hipSetDevice(ctx->p.device);
+    GnIO io;
+    memcpy(io.H, H, sizeof(io.H));
+    memcpy(io.g, g, sizeof(io.g));
+    memcpy(io.pose, pose, sizeof(io.pose));
+    io.lambda = lambda;
+    io.status = -1;
+    HIPC(ctx, hipMemcpyAsync(ctx->d_gnio, &io, sizeof(io), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_gn_step, dim3(1), dim3(64), 0, ctx->stream, ctx->d_gnio);
+    HIPC(ctx, hipMemcpyAsync(&io, ctx->d_gnio, sizeof(io), hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    if (pose_tmp) memcpy(pose_tmp, io.pose_tmp, sizeof(io.pose_tmp));
+    if (update) memcpy(update, io.update, sizeof(io.update));
+    return io.status;
+}
+
+int rgbd360_forced_iters(rgbd360_ctx* ctx, int level, const float pose0[16], int method, int n_iters, float pose_out[16],
+                         double* last_rms, float* elapsed_ms) {
+    int rc = check_args(ctx, level, method);
+    if (rc) return rc;
+    if (!pose0 || n_iters < 1) return fail(ctx, -1, "bad arguments");
+    hipSetDevice(ctx->p.device);
+    launch_level_init(ctx, pose0, 1);
+    HIPC(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    for (int k = 0; k < n_iters; ++k) {
+        launch_eval(ctx, level, method, true);
+        launch_solve(ctx, level, 0, 1);
+    }
+    HIPC(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    HIPC(ctx, hipGetLastError());
+    rc = read_state(ctx);
+    if (rc) return rc;
+    if (elapsed_ms) HIPC(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
+    if (pose_out) memcpy(pose_out, ctx->h_state->pose, sizeof(float) * 16);
+    if (last_rms) *last_rms = ctx->h_state->error;
+    return ctx->h_state->status;
+}
+
+int rgbd360_time_eval_kernel(rgbd360_ctx* ctx, int level, const float pose[16], int method, int want_hg, int reps,
+                             float* avg_us) {
+    int rc = check_args(ctx, level, method);
+    if (rc) return rc;
+    if (!pose || reps < 1 || !avg_us) return fail(ctx, -1, "bad arguments");
+    hipSetDevice(ctx->p.device);
+    launch_level_init(ctx, pose, 1);
+    launch_eval(ctx, level, method, want_hg != 0);   // warm-up
+    HIPC(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    for (int k = 0; k < reps; ++k) launch_eval(ctx, level, method, want_hg != 0);
+    HIPC(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    HIPC(ctx, hipGetLastError());
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0.f;
+    HIPC(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *avg_us = ms * 1000.f / reps;
+    return 0;
+}
+
+int rgbd360_sphere_cloud(rgbd360_ctx* ctx, const void* depth, size_t depth_step, int depth_type, int rows, int cols,
+                         int convention, float* host_out_xyz) {
+    if (!ctx || !depth || !host_out_xyz) return -1;
+    if (rows < 1 || cols < 1 || convention < 0 || convention > 2 || (depth_type != 0 && depth_type != 1))
+        return fail(ctx, -1, "bad arguments");
+    hipSetDevice(ctx->p.device);
+    std::vector<float> st(cols), ct(cols), sp(rows), cp(rows);
+    if (convention == 0) {          // Frame360.h:562-585
+        const float angle_pixel(cols / (2 * kPI));
+        const float angle_pixel_inv(1 / angle_pixel);
+        const float offset_phi = kPI * 31.5 / 180;
+        for (int r = 0; r < rows; ++r) {
+            float phi_i = offset_phi - r * angle_pixel_inv;
+            sp[r] = sinf(phi_i);
+            cp[r] = cosf(phi_i);
+        }
+        for (int c = 0; c < cols; ++c) {
+            float theta_i = c * angle_pixel_inv;
+            st[c] = sinf(theta_i);
+            ct[c] = cosf(theta_i);
+        }
+    } else if (convention == 1) {   // Frame360_stereo.h:470-490
+        const float step_theta = 2 * kPI / cols;
+        const float step_phi = step_theta;
+        const int start_phi = 166;
+        for (int r = 0; r < rows; ++r) {
+            float phi = (r + start_phi) * step_phi - kPI / 2;
+            cp[r] = cosf(phi);
+            sp[r] = sinf(phi);
+        }
+        for (int c = 0; c < cols; ++c) {
+            float theta = c * step_theta - kPI;
+            st[c] = sinf(theta);
+            ct[c] = cosf(theta);
+        }
+    } else {                        // RPI.h:4556-4571
+        const float angle_res = 2 * kPI / cols;
+        const float half_nRows = 0.5 * rows - 0.5;
+        for (int c = 0; c < cols; ++c) {
+            float theta = c * angle_res;
+            st[c] = sinf(theta);
+            ct[c] = cosf(theta);
+        }
+        for (int r = 0; r < rows; ++r) {
+            float phi = (half_nRows - r) * angle_res;
+            sp[r] = sinf(phi);
+            cp[r] = cosf(phi);
+        }
+    }
+    const size_t dpx = depth_type == 0 ? 2 : 4;
+    float *d_tab = nullptr, *d_xyz = nullptr;
+    uint8_t* d_depth = nullptr;
+    const size_t ntab = (size_t)2 * cols + 2 * rows;
+    hipError_t e = hipMalloc(&d_tab, ntab * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&d_xyz, (size_t)rows * cols * 3 * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(&d_depth, (size_t)rows * cols * dpx);
+    if (e == hipSuccess) {
+        std::vector<float> tab;
+        tab.insert(tab.end(), st.begin(), st.end());
+        tab.insert(tab.end(), ct.begin(), ct.end());
+        tab.insert(tab.end(), sp.begin(), sp.end());
+        tab.insert(tab.end(), cp.begin(), cp.end());
+        e = hipMemcpy(d_tab, tab.data(), ntab * sizeof(float), hipMemcpyHostToDevice);
+    }
+    if (e == hipSuccess)
+        e = hipMemcpy2D(d_depth, (size_t)cols * dpx, depth, depth_step, (size_t)cols * dpx, rows, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_sphere_cloud, grid2d(rows, cols), dim3(256), 0, ctx->stream, d_depth, (size_t)cols * dpx,
+                           depth_type, rows, cols, convention, d_tab, d_tab + cols, d_tab + 2 * cols, d_tab + 2 * cols + rows,
+                           d_xyz);
+        e = hipStreamSynchronize(ctx->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(host_out_xyz, d_xyz, (size_t)rows * cols * 3 * sizeof(float), hipMemcpyDeviceToHost);
+    hipFree(d_tab); hipFree(d_xyz); hipFree(d_depth);
+    HIPC(ctx, e);
+    return 0;
+}
+
+}  // extern "C"

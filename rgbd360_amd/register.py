@@ -1,0 +1,278 @@
+"""Host-side mirror of the reference's RegisterPhotoICP interface for the spherical path, over the C ABI.
+
+Method names, argument meaning and error behaviour follow include/RegisterPhotoICP.h ("RPI.h") of
+EduFdez/rgbd360 so that callers such as OdometryRGBD360.cpp:189-193 read the same:
+
+    align360 = RegisterPhotoICP(); align360.setNumPyr(5); align360.useSaliency(False)
+    align360.setTargetFrame(rgb1, depth1); align360.setSourceFrame(rgb2, depth2)
+    align360.alignFrames360(guess, RegisterPhotoICP.PHOTO_DEPTH)
+    pose = align360.getOptimalPose()
+
+All arithmetic runs in the HIP library (rgbd360_amd/lib/librgbd360_hip.so); there is no CPU path here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def pose_to_cm(T) -> np.ndarray:
+    """4x4 numpy (row-major) -> 16 floats column-major, Eigen's layout at the ABI."""
+    return np.ascontiguousarray(np.asarray(T, dtype=np.float32).reshape(4, 4).T.reshape(16))
+
+
+def pose_from_cm(v) -> np.ndarray:
+    return np.asarray(v, dtype=np.float32).reshape(4, 4).T.copy()
+
+
+class Rgbd360Error(RuntimeError):
+    pass
+
+
+class RegisterPhotoICP:
+    # costFuncType, RPI.h:194
+    PHOTO_CONSISTENCY, DEPTH_CONSISTENCY, PHOTO_DEPTH = 0, 1, 2
+
+    def __init__(self, device: int = 0):
+        self._L = _lib.load()
+        self._p = _lib.Params()
+        self._L.rgbd360_default_params(C.byref(self._p))   # RPI.h:201-221
+        self._p.device = device
+        self._h = None
+        self._res = _lib.Result()
+        self._pose = np.eye(4, dtype=np.float32)
+        # public fields of the reference (RPI.h:177-189)
+        self.SSO = 0.0
+        self.avResidual = 0.0
+        self.avPhotoResidual = 0.0
+        self.avDepthResidual = 0.0
+        self.num_iterations = []
+        self.status = 0
+
+    # ---- setters (RPI.h:224-269); they must precede the first frame, like the reference's constructor-time state
+    def _dirty(self):
+        if self._h is not None:
+            self._L.rgbd360_destroy(self._h)
+            self._h = None
+
+    @property
+    def nPyrLevels(self) -> int:
+        return self._p.n_pyr
+
+    def setNumPyr(self, Npyr: int):
+        self._p.n_pyr = int(Npyr)
+        self._dirty()
+
+    def setMinDepth(self, minD: float):
+        self._p.min_depth = float(minD)
+        self._dirty()
+
+    def setMaxDepth(self, maxD: float):
+        self._p.max_depth = float(maxD)
+        self._dirty()
+
+    def setGrayVariance(self, stdDev: float):     # sets the std-dev despite its name (RPI.h:242-245)
+        self._p.sigma_photo = float(stdDev)
+        self._dirty()
+
+    def setDepthVariance(self, stdDev: float):    # RPI.h:248-251
+        self._p.sigma_depth = float(stdDev)
+        self._dirty()
+
+    def useSaliency(self, flag: bool):
+        # bUseSalientPixels only selects calcGradientXY_saliency's index list, which the spherical passes
+        # never read (their saliency branch is commented out, RPI.h:2568-2642); accepted and ignored.
+        self._use_saliency = bool(flag)
+
+    def setVisualization(self, viz: bool):
+        if viz:
+            raise Rgbd360Error("visualisation windows are not part of the MI355X path")
+
+    def setMaskSeams(self, flag: bool):
+        self._p.mask_seams = 1 if flag else 0
+        self._dirty()
+
+    # ---- lifecycle
+    def _ctx(self):
+        if self._h is None:
+            h = C.c_void_p()
+            rc = self._L.rgbd360_create(C.byref(self._p), C.byref(h))
+            if rc != 0:
+                raise Rgbd360Error(f"rgbd360_create failed ({rc}): no usable HIP device; there is no CPU fallback")
+            self._h = h
+        return self._h
+
+    def close(self):
+        self._dirty()
+
+    def __del__(self):
+        try:
+            self._dirty()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, allow=(0,)):
+        if rc not in allow:
+            msg = self._L.rgbd360_last_error(self._h).decode() if self._h else ""
+            raise Rgbd360Error(f"rgbd360 call failed ({rc}): {msg}")
+        return rc
+
+    # ---- frames (RPI.h:480-516)
+    def _set(self, fn, imgRGB, imgDepth):
+        rgb = np.asarray(imgRGB)
+        if rgb.dtype != np.uint8 or rgb.ndim != 3 or rgb.shape[2] != 3:
+            raise Rgbd360Error("imgRGB must be HxWx3 uint8 (CV_8UC3)")
+        if rgb.strides[2] != 1 or rgb.strides[1] != 3:
+            rgb = np.ascontiguousarray(rgb)
+        d = np.asarray(imgDepth)
+        if d.dtype == np.uint16:
+            dt = 0
+        elif d.dtype == np.float32:
+            dt = 1
+        else:
+            raise Rgbd360Error("imgDepth must be uint16 millimetres (CV_16UC1) or float32 metres (CV_32FC1)")
+        if d.ndim != 2 or d.shape != rgb.shape[:2]:
+            raise Rgbd360Error("imgDepth must be HxW and match imgRGB")
+        if d.strides[1] != d.itemsize:
+            d = np.ascontiguousarray(d)
+        self._check(fn(self._ctx(), _ptr(rgb), rgb.strides[0], _ptr(d), d.strides[0], dt, d.shape[0], d.shape[1]))
+
+    def setTargetFrame(self, imgRGB, imgDepth):
+        self._set(self._L.rgbd360_set_target, imgRGB, imgDepth)
+
+    def setSourceFrame(self, imgRGB, imgDepth):
+        self._set(self._L.rgbd360_set_source, imgRGB, imgDepth)
+
+    def setTargetFrameDev(self, rgb_ptr: int, rgb_step: int, depth_ptr: int, depth_step: int, depth_type: int, rows: int,
+                          cols: int):
+        """Images already in HBM on this context's device (raw device pointers)."""
+        self._check(self._L.rgbd360_set_target_dev(self._ctx(), C.c_void_p(rgb_ptr), rgb_step, C.c_void_p(depth_ptr),
+                                                   depth_step, depth_type, rows, cols))
+
+    def setSourceFrameDev(self, rgb_ptr: int, rgb_step: int, depth_ptr: int, depth_step: int, depth_type: int, rows: int,
+                          cols: int):
+        self._check(self._L.rgbd360_set_source_dev(self._ctx(), C.c_void_p(rgb_ptr), rgb_step, C.c_void_p(depth_ptr),
+                                                   depth_step, depth_type, rows, cols))
+
+    def promoteSourceToTarget(self):
+        self._check(self._L.rgbd360_promote_source_to_target(self._ctx()))
+
+    # ---- alignment (RPI.h:4519-4784)
+    def alignFrames360(self, pose_guess=None, method: int = 0, occlusion: int = 0):
+        g = pose_to_cm(np.eye(4) if pose_guess is None else pose_guess)
+        out = np.zeros(16, dtype=np.float32)
+        rc = self._L.rgbd360_align360(self._ctx(), _ptr(g), int(method), int(occlusion), _ptr(out), C.byref(self._res))
+        self._check(rc, allow=(0, 1, 2))
+        self.status = rc
+        self._pose = pose_from_cm(out)
+        r = self._res
+        self.SSO = float(r.sso)
+        self.avResidual = 0.0 if rc == 1 else float(r.err_final)     # ill-posed: avResidual = 0 (RPI.h:4688)
+        self.avPhotoResidual = float(r.rms_photo)
+        self.avDepthResidual = float(r.rms_depth)
+        self.num_iterations = [int(r.iters[l]) for l in range(self._p.n_pyr)]
+        return rc
+
+    def getOptimalPose(self) -> np.ndarray:       # RPI.h:273
+        return self._pose.copy()
+
+    def getHessian(self) -> np.ndarray:           # RPI.h:279
+        return np.asarray(list(self._res.hessian), dtype=np.float32).reshape(6, 6).T.copy()
+
+    def getGradient(self) -> np.ndarray:          # RPI.h:285
+        return np.asarray(list(self._res.gradient), dtype=np.float32)
+
+    # ---- stage-level access (tests / measurement)
+    def level_dims(self, level: int):
+        r, c = C.c_int(), C.c_int()
+        self._check(self._L.rgbd360_level_dims(self._ctx(), level, C.byref(r), C.byref(c)))
+        return r.value, c.value
+
+    _PLANES = {"gray_src": 0, "gray_trg": 1, "depth_src": 2, "depth_trg": 3, "gx": 4, "gy": 5, "dgx": 6, "dgy": 7}
+
+    def plane(self, which: str, level: int) -> np.ndarray:
+        r, c = self.level_dims(level)
+        out = np.empty((r, c), dtype=np.float32)
+        self._check(self._L.rgbd360_get_plane(self._ctx(), self._PLANES[which], level, _ptr(out)))
+        return out
+
+    def lut(self, level: int) -> np.ndarray:
+        r, c = self.level_dims(level)
+        out = np.empty((r * c, 3), dtype=np.float32)
+        self._check(self._L.rgbd360_get_lut(self._ctx(), level, _ptr(out)))
+        return out
+
+    def eval(self, level: int, pose, method: int):
+        p = pose_to_cm(pose)
+        e2, nv, nvis = C.c_double(), C.c_longlong(), C.c_longlong()
+        e2s = np.zeros(2, np.float64)
+        ns = np.zeros(2, np.int64)
+        H = np.zeros(36, np.float32)
+        g = np.zeros(6, np.float32)
+        Hd = np.zeros(36, np.float64)
+        gd = np.zeros(6, np.float64)
+        self._check(self._L.rgbd360_eval(self._ctx(), level, _ptr(p), method, C.byref(e2), C.byref(nv), _ptr(e2s), _ptr(ns),
+                                         _ptr(H), _ptr(g), _ptr(Hd), _ptr(gd), C.byref(nvis)))
+        return dict(err2=e2.value, n_valid=nv.value, err2_split=e2s, n_split=ns, H=H.reshape(6, 6).T.copy(), g=g,
+                    H64=Hd.reshape(6, 6).T.copy(), g64=gd, n_visible=nvis.value)
+
+    def warp_indices(self, level: int, pose) -> np.ndarray:
+        r, c = self.level_dims(level)
+        out = np.empty((r * c, 2), dtype=np.int32)
+        self._check(self._L.rgbd360_warp_indices(self._ctx(), level, _ptr(pose_to_cm(pose)), _ptr(out)))
+        return out
+
+    def gn_step(self, H, g, lam: float, pose):
+        Hc = np.ascontiguousarray(np.asarray(H, np.float32).reshape(6, 6).T.reshape(36))
+        gc = np.ascontiguousarray(np.asarray(g, np.float32))
+        out = np.zeros(16, np.float32)
+        upd = np.zeros(6, np.float32)
+        rc = self._L.rgbd360_gn_step(self._ctx(), _ptr(Hc), _ptr(gc), float(lam), _ptr(pose_to_cm(pose)), _ptr(out),
+                                     _ptr(upd))
+        self._check(rc, allow=(0, 1))
+        return rc, pose_from_cm(out), upd
+
+    def forced_iters(self, level: int, pose0, method: int, n_iters: int):
+        out = np.zeros(16, np.float32)
+        rms, ms = C.c_double(), C.c_float()
+        rc = self._L.rgbd360_forced_iters(self._ctx(), level, _ptr(pose_to_cm(pose0)), method, n_iters, _ptr(out),
+                                          C.byref(rms), C.byref(ms))
+        self._check(rc, allow=(0, 1, 2))
+        return dict(status=rc, pose=pose_from_cm(out), rms=rms.value, elapsed_ms=ms.value)
+
+    def time_eval_kernel(self, level: int, pose, method: int, want_hg: bool = True, reps: int = 20) -> float:
+        us = C.c_float()
+        self._check(self._L.rgbd360_time_eval_kernel(self._ctx(), level, _ptr(pose_to_cm(pose)), method, int(want_hg), reps,
+                                                     C.byref(us)))
+        return float(us.value)
+
+    def sync(self):
+        self._check(self._L.rgbd360_sync(self._ctx()))
+
+    def sphere_cloud(self, depth, convention: int = 2) -> np.ndarray:
+        d = np.ascontiguousarray(depth)
+        dt = 0 if d.dtype == np.uint16 else 1
+        if dt == 1:
+            d = np.ascontiguousarray(d, dtype=np.float32)
+        out = np.empty((d.shape[0] * d.shape[1], 3), dtype=np.float32)
+        self._check(self._L.rgbd360_sphere_cloud(self._ctx(), _ptr(d), d.strides[0], dt, d.shape[0], d.shape[1], convention,
+                                                 _ptr(out)))
+        return out
+
+
+def Register(frame_trg, frame_src, pose: np.ndarray, method: int = RegisterPhotoICP.PHOTO_DEPTH, reg=None) -> bool:
+    """The north-star convenience shape `Register(Frame360&, Frame360&, Matrix4f&) -> bool`: frames are any objects
+    with `sphereRGB` / `sphereDepth` (Frame360.h:104-111); `pose` is the initial guess and is overwritten in place."""
+    r = reg or RegisterPhotoICP()
+    r.setTargetFrame(frame_trg.sphereRGB, frame_trg.sphereDepth)
+    r.setSourceFrame(frame_src.sphereRGB, frame_src.sphereDepth)
+    rc = r.alignFrames360(pose, method)
+    pose[...] = r.getOptimalPose()
+    return rc == 0

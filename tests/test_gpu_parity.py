@@ -1,0 +1,216 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star): integer / index work bit-exact; float32 planes bit-exact (same operation order);
+normal equations within float32 rounding of the float64-accumulated oracle; final SE(3) pose within
+1e-4 rad / 1e-3 m of the oracle.
+"""
+import numpy as np
+import pytest
+
+from rgbd360_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+ROT_TOL, TRANS_TOL = 1e-4, 1e-3     # north_star pose tolerance (rad, m)
+HG_RTOL = 2e-5                      # H,g: float32 rows, FMA vs mul+add rounding, float64 accumulation on both sides
+
+
+def _mk(hip_lib, n_pyr=3, **kw):
+    from rgbd360_amd.register import RegisterPhotoICP
+    r = RegisterPhotoICP()
+    r.setNumPyr(n_pyr)
+    for k, v in kw.items():
+        getattr(r, k)(v)
+    return r
+
+
+def _pair_ctx(hip_lib, oracle_mod, pair, n_pyr=3, math_mode=1):
+    (rgbA, dA), (rgbB, dB), T = pair
+    reg = _mk(hip_lib, n_pyr)
+    reg.setTargetFrame(rgbA, dA)
+    reg.setSourceFrame(rgbB, dB)
+    ora = oracle_mod.Oracle(n_pyr=n_pyr, math_mode=math_mode, reduce_mode=1)
+    ora.set_target(rgbA, dA)
+    ora.set_source(rgbB, dB)
+    return reg, ora, T
+
+
+def _poses(T_gt):
+    rng = np.random.default_rng(5)
+    out = [np.eye(4), np.asarray(T_gt)]
+    for _ in range(2):
+        out.append(synth.make_pose(synth.rodrigues(rng.normal(size=3), 0.05), rng.normal(size=3) * 0.05))
+    return out
+
+
+def test_planes_bit_exact(hip_lib, oracle_mod, small_pair):
+    reg, ora, _ = _pair_ctx(hip_lib, oracle_mod, small_pair)
+    for level in range(3):
+        ora.prepare_level(level)      # applies the seam mask like alignFrames360 does on entering a level
+        for name in ("gray_src", "gray_trg", "depth_src", "depth_trg", "gx", "gy", "dgx", "dgy"):
+            a, b = reg.plane(name, level), ora.plane(name, level)
+            assert a.shape == b.shape
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (name, level, np.abs(a - b).max())
+        la, lb = reg.lut(level), ora.lut(level)
+        valid = lb[:, 0] != -10000
+        assert np.array_equal(la[:, 0] != -10000, valid)
+        assert np.array_equal(la[valid].view(np.uint32), lb[valid].view(np.uint32)), level
+
+
+def test_warp_indices_bit_exact(hip_lib, oracle_mod, small_pair):
+    reg, ora, T = _pair_ctx(hip_lib, oracle_mod, small_pair)
+    for level in range(3):
+        for pose in _poses(T):
+            a, b = reg.warp_indices(level, pose), ora.warp_indices(level, pose)
+            assert np.array_equal(a, b), (level, int((a != b).any(axis=1).sum()))
+
+
+@pytest.mark.parametrize("method", [0, 1, 2])
+def test_eval_parity(hip_lib, oracle_mod, small_pair, method):
+    reg, ora, T = _pair_ctx(hip_lib, oracle_mod, small_pair)
+    for level in range(3):
+        for pose in _poses(T):
+            e = reg.eval(level, pose, method)
+            rms, err2, nvalid = ora.error(level, pose, method)
+            H, g, Hd, gd, nvis = ora.hessgrad(level, pose, method)
+            assert e["n_valid"] == nvalid            # integer work: exact
+            assert e["n_visible"] == nvis
+            assert abs(e["err2"] - err2) <= 1e-11 * max(1.0, abs(err2)), (e["err2"], err2)
+            scale_h = np.abs(Hd).max()
+            assert np.abs(e["H64"] - Hd).max() <= HG_RTOL * scale_h
+            assert np.abs(e["g64"] - gd).max() <= HG_RTOL * max(np.abs(gd).max(), 1e-3 * np.sqrt(scale_h))
+            assert np.allclose(e["H"], e["H64"].astype(np.float32))
+
+
+def test_gn_step_matches_oracle(hip_lib, oracle_mod, small_pair):
+    reg, ora, T = _pair_ctx(hip_lib, oracle_mod, small_pair)
+    H, g, Hd, gd, _ = ora.hessgrad(1, np.eye(4), 2)
+    st_o, pose_o, upd_o = oracle_mod.gn_step(H, g, 1.0, np.eye(4))
+    st_d, pose_d, upd_d = reg.gn_step(H, g, 1.0, np.eye(4))
+    assert st_o == st_d == 0
+    assert np.allclose(upd_d, upd_o, rtol=1e-5, atol=1e-8)
+    assert np.allclose(pose_d, pose_o, rtol=0, atol=1e-7)
+    # rank-deficient system: both report ILL-POSED (RPI.h:4682-4690)
+    Hbad = H.copy()
+    Hbad[:, 5] = Hbad[:, 4]
+    Hbad[5, :] = Hbad[4, :]
+    assert oracle_mod.gn_step(Hbad, g, 1.0, np.eye(4))[0] == 1
+    assert reg.gn_step(Hbad, g, 1.0, np.eye(4))[0] == 1
+
+
+@pytest.mark.parametrize("method", [0, 1, 2])
+def test_align_small_matches_oracle(hip_lib, oracle_mod, small_pair, method):
+    reg, ora, T = _pair_ctx(hip_lib, oracle_mod, small_pair)
+    rc = reg.alignFrames360(np.eye(4), method)
+    st, pose_ref = ora.align360(np.eye(4), method)
+    assert rc == st == 0
+    assert reg.num_iterations == list(ora.result.iters)[:3]     # same accept / reject sequence
+    rot, trans = synth.pose_error(reg.getOptimalPose(), pose_ref)
+    assert rot <= 1e-6 and trans <= 1e-6, (rot, trans)
+    assert abs(reg.avResidual - ora.result.err_final) <= 1e-9 * max(1.0, ora.result.err_final)
+    assert np.allclose(reg.getHessian(), np.asarray(list(ora.result.hessian)).reshape(6, 6).T, rtol=1e-4,
+                       atol=1e-4 * np.abs(reg.getHessian()).max())
+    assert abs(reg.SSO - ora.result.sso) < 1e-6
+    # and against the reference-faithful libm oracle: the north-star tolerance
+    ora.set_modes(0, 0)
+    st, pose_libm = ora.align360(np.eye(4), method)
+    rot, trans = synth.pose_error(reg.getOptimalPose(), pose_libm)
+    assert rot <= ROT_TOL and trans <= TRANS_TOL, (rot, trans)
+
+
+def test_forced_schedule_matches_oracle(hip_lib, oracle_mod, small_pair):
+    reg, ora, T = _pair_ctx(hip_lib, oracle_mod, small_pair)
+    n = 4
+    out = reg.forced_iters(0, np.eye(4), 2, n + 1)      # n+1 fused passes apply n steps
+    e_ref, pose_ref = ora.forced_iters(0, np.eye(4), 2, n)
+    rot, trans = synth.pose_error(out["pose"], pose_ref)
+    assert rot <= 1e-6 and trans <= 1e-6, (rot, trans)
+    assert abs(out["rms"] - e_ref) <= 1e-6
+
+
+def test_float_depth_and_strided_inputs(hip_lib, oracle_mod):
+    (rgbA, dA), (rgbB, dB), T = synth.make_pair(256, 128, seed=77, depth_f32=True)
+    # row-padded (strided) host images, like a cv::Mat ROI
+    padA = np.zeros((128, 300, 3), np.uint8)
+    padA[:, :256] = rgbA
+    padD = np.zeros((128, 290), np.float32)
+    padD[:, :256] = dA
+    reg = _mk(hip_lib, 3)
+    reg.setTargetFrame(padA[:, :256], padD[:, :256])
+    reg.setSourceFrame(rgbB, dB)
+    ora = oracle_mod.Oracle(n_pyr=3, math_mode=1, reduce_mode=1)
+    ora.set_target(rgbA, dA)
+    ora.set_source(rgbB, dB)
+    assert np.array_equal(reg.plane("depth_trg", 0), ora.plane("depth_trg", 0))
+    assert np.array_equal(reg.plane("gray_trg", 1), ora.plane("gray_trg", 1))
+    rc = reg.alignFrames360(np.eye(4), 2)
+    st, pose_ref = ora.align360(np.eye(4), 2)
+    assert rc == st == 0
+    rot, trans = synth.pose_error(reg.getOptimalPose(), pose_ref)
+    assert rot <= 1e-6 and trans <= 1e-6
+
+
+def test_no_valid_pixels_and_errors(hip_lib, oracle_mod, small_pair):
+    (rgbA, dA), (rgbB, dB), T = small_pair
+    reg = _mk(hip_lib, 3)
+    reg.setTargetFrame(rgbA, dA)
+    reg.setSourceFrame(rgbB, np.zeros_like(dB))          # every source depth invalid
+    assert reg.alignFrames360(np.eye(4), 2) == 2         # RGBD360_NO_VALID_PIXELS
+    assert np.allclose(reg.getOptimalPose(), np.eye(4))
+    from rgbd360_amd.register import Rgbd360Error
+    with pytest.raises(Rgbd360Error):
+        reg.alignFrames360(np.eye(4), 2, occlusion=1)
+    fresh = _mk(hip_lib, 3)
+    fresh.setTargetFrame(rgbA, dA)
+    with pytest.raises(Rgbd360Error):                    # source frame missing
+        fresh.alignFrames360(np.eye(4), 0)
+
+
+def test_identity_pair_stays_at_identity(hip_lib, oracle_mod, small_pair):
+    (rgbA, dA), _, _ = small_pair
+    reg = _mk(hip_lib, 3)
+    reg.setTargetFrame(rgbA, dA)
+    reg.setSourceFrame(rgbA, dA)
+    rc = reg.alignFrames360(np.eye(4), 2)
+    assert rc == 0
+    rot, trans = synth.pose_error(reg.getOptimalPose(), np.eye(4))
+    assert rot < 1e-5 and trans < 1e-5
+
+
+def test_promote_source_to_target(hip_lib, oracle_mod, small_pair):
+    (rgbA, dA), (rgbB, dB), T = small_pair
+    reg = _mk(hip_lib, 3)
+    reg.setTargetFrame(rgbA, dA)
+    reg.setSourceFrame(rgbB, dB)
+    reg.promoteSourceToTarget()                          # B becomes the target
+    reg.setSourceFrame(rgbA, dA)
+    ref = _mk(hip_lib, 3)
+    ref.setTargetFrame(rgbB, dB)
+    ref.setSourceFrame(rgbA, dA)
+    for name in ("gray_trg", "depth_trg", "gx", "dgy"):
+        assert np.array_equal(reg.plane(name, 1), ref.plane(name, 1))
+    assert reg.alignFrames360(np.eye(4), 2) == ref.alignFrames360(np.eye(4), 2) == 0
+    assert np.array_equal(reg.getOptimalPose(), ref.getOptimalPose())
+
+
+@pytest.mark.parametrize("method", [0, 2])
+def test_full_size_2048x1024(hip_lib, oracle_mod, method):
+    """BASELINE.json configs 2/3 at full size: GPU vs oracle pose, and both vs ground truth."""
+    pair = synth.make_pair(2048, 1024, seed=1234)
+    reg, ora, T = _pair_ctx(hip_lib, oracle_mod, pair, n_pyr=4)
+    rc = reg.alignFrames360(np.eye(4), method)
+    st, pose_ref = ora.align360(np.eye(4), method)
+    assert rc == st == 0
+    rot, trans = synth.pose_error(reg.getOptimalPose(), pose_ref)
+    assert rot <= ROT_TOL and trans <= TRANS_TOL, (rot, trans)
+    rot_gt, trans_gt = synth.pose_error(reg.getOptimalPose(), T)
+    assert rot_gt < 5e-4 and trans_gt < 2e-3, (rot_gt, trans_gt)
+    # size-independent property: re-running is bitwise reproducible (fixed-order reductions, no atomics)
+    pose1 = reg.getOptimalPose()
+    reg.alignFrames360(np.eye(4), method)
+    assert np.array_equal(pose1, reg.getOptimalPose())
+    # counts at full size are exact against the oracle
+    e = reg.eval(0, pose_ref, method)
+    _, err2, nvalid = ora.error(0, pose_ref, method)
+    assert e["n_valid"] == nvalid
+    assert abs(e["err2"] - err2) <= 1e-11 * err2
