@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- Gauss-Newton iterations/sec of the dense spherical alignment hot path on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches this file
+with torch.distributed.run, one rank per GPU (RCCL).  Rank 0 prints ONE JSON line.
+
+Step      = one level-0 Gauss-Newton iteration of RegisterPhotoICP::alignFrames360 on one 2048x1024 synthetic
+            spherical pair (BASELINE.json configs[1]: photometric-only), in the forced schedule of BASELINE.md §2
+            (accept rule evaluated, step applied regardless): one fused warp+residual+Jacobian pass over every
+            source pixel + the 6x6 solve / pose update launch.  Frames are resident in HBM before the timed region.
+N > 1     = every rank aligns its own independent pair (weak scaling) and the solved poses are all-gathered
+            (RCCL) inside the timed region.
+roofline  = algorithmic bytes of the fused kernel (28 B/px photo, 40 B/px photo+depth, LUT variant)
+            / its average launch duration measured with HIP events on the library's own stream.
+cpu_baseline = the CPU oracle (restatement of the reference algorithm, OpenMP) on the same workload, bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_COPY_GBS = 6290.0          # measured float4 copy (same guide)
+BYTES_PER_PX = {0: 28, 1: 28, 2: 40}   # LUT variant: 16 B source record + 12 B (24 B) gathered target records
+METHOD_NAMES = {0: "PHOTO_CONSISTENCY", 1: "DEPTH_CONSISTENCY", 2: "PHOTO_DEPTH"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--width", type=int, default=2048)
+    ap.add_argument("--height", type=int, default=1024)
+    ap.add_argument("--method", type=int, default=0, help="0 photo (configs[1]), 2 photo+depth (configs[2])")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    n_gpus = max(args.gpus, 1)
+    if world != n_gpus and world > 1:
+        n_gpus = world
+
+    import torch
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback in the product path)"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from rgbd360_amd import synth
+    from rgbd360_amd.register import RegisterPhotoICP
+
+    W, H, method = args.width, args.height, args.method
+    n_px = W * H
+    t_gen = time.time()
+    (rgbA, dA), (rgbB, dB), T_gt = synth.make_pair(W, H, seed=1234 + rank)
+    t_gen = time.time() - t_gen
+
+    reg = RegisterPhotoICP(device=local_rank)
+    reg.setNumPyr(4)
+    reg.setTargetFrame(rgbA, dA)
+    reg.setSourceFrame(rgbB, dB)
+    reg.sync()
+
+    # full coarse-to-fine alignment once (natural accept/reject schedule): pose + the level-0 starting pose
+    t0 = time.time()
+    rc = reg.alignFrames360(np.eye(4), method)
+    t_align = time.time() - t0
+    t0 = time.time()
+    rc = reg.alignFrames360(np.eye(4), method)
+    t_align = min(t_align, time.time() - t0)
+    pose_gpu = reg.getOptimalPose()
+    iters_nat = list(reg.num_iterations)
+    start_pose = np.eye(4)     # forced schedule starts from the identity guess at level 0
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warmup, then EXACTLY K steps ------------------------------------------------------------------------
+    reg.forced_iters(0, start_pose, method, max(args.warmup, 1))
+    sync_all()
+    t0 = time.perf_counter()
+    out = reg.forced_iters(0, start_pose, method, args.steps)
+    poses = None
+    if dist is not None:
+        mine = torch.from_numpy(out["pose"].reshape(16).copy()).cuda()
+        gathered = torch.empty(world * 16, dtype=torch.float32, device="cuda")
+        dist.all_gather_into_tensor(gathered, mine)      # RCCL over xGMI: the path's one exchange step
+        poses = gathered
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        assert poses is not None and bool(torch.isfinite(poses).all())
+
+    value = n_gpus * args.steps / elapsed
+    result = {
+        "metric": "Gauss-Newton iters/sec on 2048x1024 spherical pair; SE(3) err vs CPU ref",
+        "value": value,
+        "unit": "GN iterations/s",
+        "n_gpus": n_gpus,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": ("configs[1]: single %dx%d synthetic sphere pair per GPU, %s RegisterPhotoICP, level-0 forced "
+                         "Gauss-Newton iterations (1 fused pass + 1 solve launch each)" % (W, H, METHOD_NAMES[method])),
+            "width": W, "height": H, "method": METHOD_NAMES[method], "n_pyr": 4,
+            "pairs_per_gpu": 1, "parallelism": "independent pairs per GPU, RCCL all-gather of poses" if world > 1 else "1 GPU",
+        },
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel: HIP events on the library's stream -----------------------------
+        kernel_us = reg.time_eval_kernel(0, pose_gpu, method, True, 50)
+        alg_bytes = BYTES_PER_PX[method] * n_px
+        achieved = alg_bytes / (kernel_us * 1e-6) / 1e9
+        traffic = None
+        tr_path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tr_path):
+            try:
+                tr = json.load(open(tr_path))
+                key = "%dx%d_%s" % (W, H, METHOD_NAMES[method])
+                traffic = tr.get(key, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result["roofline"] = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "kernel": "k_eval<%d,true>" % method, "kernel_avg_us": kernel_us,
+            "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_pixel": BYTES_PER_PX[method],
+            "frac_of_measured_copy_peak": achieved / HBM_COPY_GBS,
+        }
+        # same kernel in photo+depth mode (configs[2]) for reference
+        other = 2 if method == 0 else 0
+        k2 = reg.time_eval_kernel(0, pose_gpu, other, True, 50)
+        result["roofline_other_method"] = {
+            "method": METHOD_NAMES[other], "kernel_avg_us": k2,
+            "achieved": BYTES_PER_PX[other] * n_px / (k2 * 1e-6) / 1e9,
+            "frac": BYTES_PER_PX[other] * n_px / (k2 * 1e-6) / 1e9 / HBM_PEAK_GBS,
+        }
+        result["alignment"] = {"full_pyramid_ms": t_align * 1e3, "iters_per_level": iters_nat, "status": rc,
+                               "pose_err_vs_ground_truth": dict(zip(("rot_rad", "trans_m"), synth.pose_error(pose_gpu, T_gt)))}
+        result["setup_s"] = {"render_pair": t_gen}
+
+        # ---- CPU baseline: the oracle on this host's cores, bounded sample (rank 0, N = 1 only) ---------------
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            from oracle import oracle as O
+            ora = O.Oracle(n_pyr=4, math_mode=0, reduce_mode=0)      # reference-faithful modes
+            ora.set_target(rgbA, dA)
+            ora.set_source(rgbB, dB)
+            st, pose_cpu = ora.align360(np.eye(4), method)
+            rot, trans = synth.pose_error(pose_gpu, pose_cpu)
+            result["alignment"]["pose_err_vs_cpu_ref"] = {"rot_rad": rot, "trans_m": trans}
+            result["alignment"]["cpu_iters_per_level"] = list(ora.result.iters)[:4]
+            ora.forced_iters(0, np.eye(4), method, 2)       # warm
+            t0 = time.perf_counter()
+            ora.forced_iters(0, np.eye(4), method, 4)
+            per_it = (time.perf_counter() - t0) / 4
+            n_cpu = int(max(8, min(2000, args.cpu_seconds / max(per_it, 1e-6))))
+            t0 = time.perf_counter()
+            ora.forced_iters(0, np.eye(4), method, n_cpu)
+            dt = time.perf_counter() - t0
+            result["cpu_baseline"] = {
+                "value": n_cpu / dt, "unit": "GN iterations/s", "cores": O.num_threads(), "kind": "port",
+                "sample": "%d level-0 forced GN iterations (H,g pass + solve + error pass, reference structure with its "
+                          "per-call Jacobian arrays) on the same %dx%d %s pair, %.1f s" % (n_cpu, W, H, METHOD_NAMES[method], dt),
+                "host_cpus": os.cpu_count(),
+            }
+        print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

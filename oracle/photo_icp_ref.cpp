@@ -127,14 +127,15 @@ inline float round_half_away(float x) {
     return t;
 }
 
-// Polynomial asinf / atan2f used by the device kernels (math_mode 1).  Pure float32
-// +,-,*,/,sqrt,fma: IEEE-exact on both x86 and gfx950, hence bit-identical results.
+// Device arithmetic (math_mode 1): the operation sequence of rgbd360_amd/csrc/photo_icp_kernels.h warp_pixel.
+// Pure float32 fma / mul / add / correctly rounded sqrt and reciprocal: IEEE-exact on x86 and gfx950 alike, hence
+// bit-identical results (the device's sqrt_rn / rcp_rn are checked against IEEE by its own self-test).
 inline float asinf_poly(float x) {
     const float c0 = 0.16666672764720836f, c1 = 0.07498809174564633f, c2 = 0.0450107002296682f,
                 c3 = 0.02649427585795898f, c4 = 0.03820645371719902f;
     float ax = fabsf(x);
     bool  big = ax >= 0.5f;
-    float z = big ? (1.f - ax) * 0.5f : ax * ax;
+    float z = fmaxf(big ? (1.f - ax) * 0.5f : ax * ax, 0.f);
     float s = big ? sqrtf(z) : ax;
     float p = fmaf(z, c4, c3);
     p = fmaf(z, p, c2);
@@ -145,13 +146,10 @@ inline float asinf_poly(float x) {
     return copysignf(r, x);
 }
 
-inline float atan2f_poly(float y, float x) {
+inline float atan2f_poly_t(float y, float x, float ay, float ax, float t) {
     const float q0 = -0.3333333195069166f, q1 = 0.19999765993465415f, q2 = -0.14279110844310372f,
                 q3 = 0.11037993832882714f, q4 = -0.08673169371217875f, q5 = 0.06284358078457526f,
                 q6 = -0.03627014369584507f, q7 = 0.01375026672953864f, q8 = -0.00244702708829393f;
-    float ay = fabsf(y), ax = fabsf(x);
-    float mx = fmaxf(ay, ax), mn = fminf(ay, ax);
-    float t = (mx == 0.f) ? 0.f : mn / mx;
     float s = t * t;
     float p = fmaf(s, q8, q7);
     p = fmaf(s, p, q6);
@@ -166,6 +164,12 @@ inline float atan2f_poly(float y, float x) {
     if (std::signbit(x)) a = 3.14159274f - a;
     return copysignf(a, y);
 }
+inline float atan2f_poly(float y, float x) {
+    float ay = fabsf(y), ax = fabsf(x);
+    float mx = fmaxf(fmaxf(ay, ax), 1e-30f), mn = fminf(ay, ax);
+    return atan2f_poly_t(y, x, ay, ax, mn * (1.f / mx));
+}
+inline int round_index(float x) { return (int)floorf(x + 0.5f); }
 
 // ------------------------------------------------------------------------------------
 // THIRD-PARTY restatements (OpenCV)
@@ -346,31 +350,36 @@ inline PoseRT split_pose(const float* pose /*col-major 4x4*/) {
 inline Warp warp_pixel(const PoseRT& T, const float* p, int nRows, int nCols, float half_nRows, float angle_res_inv,
                        int math_mode) {
     Warp w;
-    // Eigen fixed-size product rotation*LUT + translation: ((a0*b0 + a1*b1) + a2*b2) + t
-    w.X = ((T.R[0] * p[0] + T.R[1] * p[1]) + T.R[2] * p[2]) + T.t[0];
-    w.Y = ((T.R[3] * p[0] + T.R[4] * p[1]) + T.R[5] * p[2]) + T.t[1];
-    w.Z = ((T.R[6] * p[0] + T.R[7] * p[1]) + T.R[8] * p[2]) + T.t[2];
-    w.dist = sqrtf((w.X * w.X + w.Y * w.Y) + w.Z * w.Z);  // Eigen norm()
-    w.dist_inv = 1.f / w.dist;
-    float phi_trg, theta_trg;
     if (math_mode == 0) {
-        phi_trg = asinf(w.X * w.dist_inv);
-        theta_trg = (float)((double)atan2f(w.Y, w.Z) + kPI);  // float + double PI, stored to float
+        // Eigen fixed-size product rotation*LUT + translation: ((a0*b0 + a1*b1) + a2*b2) + t
+        w.X = ((T.R[0] * p[0] + T.R[1] * p[1]) + T.R[2] * p[2]) + T.t[0];
+        w.Y = ((T.R[3] * p[0] + T.R[4] * p[1]) + T.R[5] * p[2]) + T.t[1];
+        w.Z = ((T.R[6] * p[0] + T.R[7] * p[1]) + T.R[8] * p[2]) + T.t[2];
+        w.dist = sqrtf((w.X * w.X + w.Y * w.Y) + w.Z * w.Z);  // Eigen norm()
+        w.dist_inv = 1.f / w.dist;
+        float phi_trg = asinf(w.X * w.dist_inv);
+        float theta_trg = (float)((double)atan2f(w.Y, w.Z) + kPI);  // float + double PI, stored to float
+        w.r = (int)roundf(half_nRows - phi_trg * angle_res_inv);
+        w.c = (int)roundf(theta_trg * angle_res_inv);
+        w.visible = (w.r >= 0 && w.r < nRows) && w.c < nCols;  // RPI.h:2684 (c==nCols dropped, not wrapped)
+        if (w.visible && w.c < 0) w.visible = false;           // cannot occur (theta_trg >= 0); guards the index
     } else {
-        phi_trg = asinf_poly(w.X * w.dist_inv);
-        theta_trg = (float)((double)atan2f_poly(w.Y, w.Z) + kPI);
+        // device arithmetic: same IEEE operations in the same order as photo_icp_kernels.h warp_pixel
+        w.X = fmaf(T.R[2], p[2], fmaf(T.R[1], p[1], fmaf(T.R[0], p[0], T.t[0])));
+        w.Y = fmaf(T.R[5], p[2], fmaf(T.R[4], p[1], fmaf(T.R[3], p[0], T.t[1])));
+        w.Z = fmaf(T.R[8], p[2], fmaf(T.R[7], p[1], fmaf(T.R[6], p[0], T.t[2])));
+        w.dist = sqrtf(fmaf(w.Z, w.Z, fmaf(w.Y, w.Y, w.X * w.X)));
+        const float ay = fabsf(w.Y), az = fabsf(w.Z);
+        const float mx = fmaxf(fmaxf(ay, az), 1e-30f), mn = fminf(ay, az);
+        const float r = 1.f / (w.dist * mx);
+        w.dist_inv = r * mx;
+        const float t = mn * (r * w.dist);
+        const float phi_trg = asinf_poly(w.X * w.dist_inv);
+        const float theta_trg = (float)((double)atan2f_poly_t(w.Y, w.Z, ay, az, t) + kPI);
+        w.r = round_index(half_nRows - phi_trg * angle_res_inv);
+        w.c = round_index(theta_trg * angle_res_inv);
+        w.visible = ((unsigned)w.r < (unsigned)nRows) && ((unsigned)w.c < (unsigned)nCols);
     }
-    float fr = half_nRows - phi_trg * angle_res_inv;
-    float fc = theta_trg * angle_res_inv;
-    if (math_mode == 0) {
-        w.r = (int)roundf(fr);
-        w.c = (int)roundf(fc);
-    } else {
-        w.r = (int)round_half_away(fr);
-        w.c = (int)round_half_away(fc);
-    }
-    w.visible = (w.r >= 0 && w.r < nRows) && w.c < nCols;  // RPI.h:2684 (c==nCols dropped, not wrapped)
-    if (w.visible && w.c < 0) w.visible = false;           // cannot occur (theta_trg >= 0); guards the index
     return w;
 }
 
@@ -993,6 +1002,7 @@ void oracle_warp_indices(void* h, int level, const float* pose, int* out_rc) {
 float oracle_asinf_poly(float x) { return asinf_poly(x); }
 float oracle_atan2f_poly(float y, float x) { return atan2f_poly(y, x); }
 float oracle_round_half_away(float x) { return round_half_away(x); }
+int oracle_round_index(float x) { return round_index(x); }
 float oracle_weight_huber(float e, float k) { return weightHuber(e, k); }
 int oracle_rank6(const float* M) { return rank6_colpiv_qr(M); }
 int oracle_inverse6(const float* M, float* inv) { return inverse6_partial_piv_lu(M, inv) ? 0 : 1; }

@@ -17,7 +17,10 @@ LIB = os.path.join(_HERE, "lib", "librgbd360_hip.so")
 
 # -ffp-contract=off: the warp front end must round exactly like the CPU oracle (see photo_icp_kernels.h);
 # contraction is re-enabled per block where it is harmless.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unused-value"]
+# -fno-slp-vectorize: packed f32 math is not faster than scalar on gfx950 (tools/ubench/valu_rate.hip) and the
+# packing costs ~50 v_mov per pixel in the fused kernel.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-slp-vectorize",
+         "-Wno-unused-value"]
 
 
 def hipcc() -> str:

@@ -50,8 +50,10 @@ struct EvalConsts {
 
 // Device-resident state of one alignment (one per context).  Poses/H column-major.
 struct GNState {
+    float  cand[16];     // pose the next / last fused pass is evaluated at (first: read by every k_eval block)
+    int    done;         // level finished (or status != 0): later launches of this level exit immediately
+    int    it, status, first, n_evals, pad0, pad1, pad2;
     float  pose[16];     // accepted pose of the current level
-    float  cand[16];     // pose the next / last fused pass is evaluated at
     float  H[36], g[6];  // normal equations at `pose`
     float  Hused[36], gused[6];  // those of the last Gauss-Newton step actually taken (= reference `hessian`)
     float  update[6];
@@ -60,7 +62,6 @@ struct GNState {
     double tot[kNumPartials];        // reduced partials of the last pass
     double acc_e2p, acc_e2d;         // error sums at the accepted pose
     long long acc_np, acc_nd, acc_nvis, used_nvis, used_npix;
-    int    it, done, status, first, n_evals, pad;
 };
 
 struct SolveCfg {
@@ -72,28 +73,50 @@ struct SolveCfg {
 };
 
 // ---------------------------------------------------------------------------------------------------------
-// scalar helpers (bit-for-bit counterparts of the oracle's math_mode 1)
+// scalar helpers.  The warp front end below is the *device arithmetic definition* of the pixel warp: a fixed
+// sequence of IEEE-754 basic operations (fma, mul, add, correctly rounded sqrt and reciprocal) that the CPU oracle
+// repeats operation for operation in its math_mode 1, so warped pixel indices agree bit for bit.
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float weight_huber(float error, float k) {   // RPI.h:545-554
+__device__ __forceinline__ float weight_huber(float error, float k) {   // RPI.h:545-554 (IEEE form, tests only)
     float ea = fabsf(error);
     if (ea < k) return 1.f;
     return sqrtf(2 * k * ea - k * k) / ea;
 }
 
-__device__ __forceinline__ float round_half_away(float x) {             // C round()
-    float t = truncf(x);
-    float f = fabsf(x - t);
-    if (f >= 0.5f) t += copysignf(1.f, x);
-    return t;
+// Correctly rounded sqrt for normal, finite x >= 0 (and x == 0): hardware estimate (<= 1 ulp) corrected with two
+// exact fma residuals -- the core of the compiler's own IEEE expansion without its denormal / special-class
+// handling, which inputs on this path never need.  rgbd360_selftest_math compares it with sqrtf over the range.
+__device__ __forceinline__ float sqrt_rn(float x) {
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float sm = __builtin_bit_cast(float, __builtin_bit_cast(int, s) - 1);
+    const float sp = __builtin_bit_cast(float, __builtin_bit_cast(int, s) + 1);
+    const float rm = fmaf(-sm, s, x);
+    const float rp = fmaf(-sp, s, x);
+    s = (rm <= 0.f) ? sm : s;
+    s = (rp > 0.f) ? sp : s;
+    return s;
 }
+// Correctly rounded 1/x for normal finite x: hardware estimate + Newton step + one residual correction.
+__device__ __forceinline__ float rcp_rn(float x) {
+    float r = __builtin_amdgcn_rcpf(x);
+    float e = fmaf(-x, r, 1.f);
+    r = fmaf(e, r, r);
+    e = fmaf(-x, r, 1.f);
+    r = fmaf(e, r, r);
+    return r;
+}
+
+// round-half-up to the nearest integer; equals C round() except at x = 0.49999997 and exact negative ties, which
+// cannot change a visible pixel index (negative rows / columns are dropped).
+__device__ __forceinline__ int round_index(float x) { return (int)floorf(x + 0.5f); }
 
 __device__ __forceinline__ float asinf_poly(float x) {
     const float c0 = 0.16666672764720836f, c1 = 0.07498809174564633f, c2 = 0.0450107002296682f,
                 c3 = 0.02649427585795898f, c4 = 0.03820645371719902f;
     float ax = fabsf(x);
     bool big = ax >= 0.5f;
-    float z = big ? (1.f - ax) * 0.5f : ax * ax;
-    float s = big ? sqrtf(z) : ax;
+    float z = fmaxf(big ? (1.f - ax) * 0.5f : ax * ax, 0.f);   // |x| may exceed 1 by an ulp
+    float s = big ? sqrt_rn(z) : ax;
     float p = fmaf(z, c4, c3);
     p = fmaf(z, p, c2);
     p = fmaf(z, p, c1);
@@ -103,13 +126,11 @@ __device__ __forceinline__ float asinf_poly(float x) {
     return copysignf(r, x);
 }
 
-__device__ __forceinline__ float atan2f_poly(float y, float x) {
+// atan2(y, x) with t = min(|y|,|x|) / max(|y|,|x|) supplied by the caller (it shares one reciprocal with 1/dist).
+__device__ __forceinline__ float atan2f_poly_t(float y, float x, float ay, float ax, float t) {
     const float q0 = -0.3333333195069166f, q1 = 0.19999765993465415f, q2 = -0.14279110844310372f,
                 q3 = 0.11037993832882714f, q4 = -0.08673169371217875f, q5 = 0.06284358078457526f,
                 q6 = -0.03627014369584507f, q7 = 0.01375026672953864f, q8 = -0.00244702708829393f;
-    float ay = fabsf(y), ax = fabsf(x);
-    float mx = fmaxf(ay, ax), mn = fminf(ay, ax);
-    float t = (mx == 0.f) ? 0.f : mn / mx;
     float s = t * t;
     float p = fmaf(s, q8, q7);
     p = fmaf(s, p, q6);
@@ -138,40 +159,42 @@ __device__ __forceinline__ PoseRT load_pose(const float* P) {   // column-major 
 }
 
 // Shared front end of RPI.h:2663-2684 / 2959-2989.  Returns the target pixel index or -1.
+// One correctly rounded sqrt and ONE correctly rounded reciprocal serve both angles:
+//   r = 1/(dist*mx),  1/dist = r*mx,  1/mx = r*dist      (mx = max(|Y|,|Z|, 1e-30))
 __device__ __forceinline__ int warp_pixel(const PoseRT& T, float px, float py, float pz, const LevelDev& lv, float& X,
-                                          float& Y, float& Z, float& dist, float& dist_inv, int& tr, int& tc) {
-    X = ((T.r00 * px + T.r01 * py) + T.r02 * pz) + T.tx;
-    Y = ((T.r10 * px + T.r11 * py) + T.r12 * pz) + T.ty;
-    Z = ((T.r20 * px + T.r21 * py) + T.r22 * pz) + T.tz;
-    dist = sqrtf((X * X + Y * Y) + Z * Z);
-    dist_inv = 1.f / dist;
-    float phi_trg = asinf_poly(X * dist_inv);
-    float theta_trg = (float)((double)atan2f_poly(Y, Z) + kPI);
-    tr = (int)round_half_away(lv.half_nRows - phi_trg * lv.angle_res_inv);
-    tc = (int)round_half_away(theta_trg * lv.angle_res_inv);
-    bool vis = (tr >= 0 && tr < lv.rows) && (tc < lv.cols) && (tc >= 0);
-    return vis ? tr * lv.cols + tc : -1;
+                                          float& Y, float& Z, float& dist, float& dist_inv) {
+    X = fmaf(T.r02, pz, fmaf(T.r01, py, fmaf(T.r00, px, T.tx)));
+    Y = fmaf(T.r12, pz, fmaf(T.r11, py, fmaf(T.r10, px, T.ty)));
+    Z = fmaf(T.r22, pz, fmaf(T.r21, py, fmaf(T.r20, px, T.tz)));
+    dist = sqrt_rn(fmaf(Z, Z, fmaf(Y, Y, X * X)));
+    const float ay = fabsf(Y), az = fabsf(Z);
+    const float mx = fmaxf(fmaxf(ay, az), 1e-30f), mn = fminf(ay, az);
+    const float r = rcp_rn(dist * mx);
+    dist_inv = r * mx;
+    const float t = mn * (r * dist);
+    const float phi_trg = asinf_poly(X * dist_inv);
+    const float theta_trg = (float)((double)atan2f_poly_t(Y, Z, ay, az, t) + kPI);
+    const int tr = round_index(lv.half_nRows - phi_trg * lv.angle_res_inv);
+    const int tc = round_index(theta_trg * lv.angle_res_inv);
+    const bool vis = ((unsigned)tr < (unsigned)lv.rows) && ((unsigned)tc < (unsigned)lv.cols);
+    return vis ? (int)__umul24(tr, lv.cols) + tc : -1;
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // wave64 sum: DPP inside a 16-lane row, ds_bpermute across the four rows.  Every lane ends with the total.
 // ---------------------------------------------------------------------------------------------------------
-template <int CTRL>
+template <int CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ float dpp_f(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, true));
 }
-__device__ __forceinline__ float wave_sum(float v) {
-    v += dpp_f<0xB1>(v);    // quad_perm [1,0,3,2]
-    v += dpp_f<0x4E>(v);    // quad_perm [2,3,0,1]
-    v += dpp_f<0x141>(v);   // row_half_mirror
-    v += dpp_f<0x140>(v);   // row_mirror
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
-}
-__device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
+// Sum over the 64 lanes; the total is valid in lane 63 only (rows 0-2 hold partial sums).
+__device__ __forceinline__ float wave_sum63(float v) {
+    v += dpp_f<0xB1>(v);          // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E>(v);          // quad_perm [2,3,0,1]
+    v += dpp_f<0x141>(v);         // row_half_mirror
+    v += dpp_f<0x140>(v);         // row_mirror: every lane of a row holds the row sum
+    v += dpp_f<0x142, 0xA>(v);    // row_bcast:15 -> rows 1,3 += previous row
+    v += dpp_f<0x143, 0xC>(v);    // row_bcast:31 -> rows 2,3 += row 1 (which holds rows 0+1)
     return v;
 }
 
@@ -182,7 +205,128 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 // that neighbouring spans, which gather neighbouring target rows, share an XCD L2); its 256 lanes sweep the
 // span in coalesced 256-pixel steps (16 B/lane source records), accumulate in float32 registers, then reduce
 // wave (DPP) -> block (LDS) and store 32 float64 partials.  No atomics: the final sum order is fixed.
+//
+// The pixel body is branch-free: the reference's `continue`s (invalid point, not visible, non-salient) become
+// predicates that zero the pixel's contribution, so every load is unconditional (the gather index of a skipped
+// pixel is clamped to 0) and the compiler can issue the next source record and both gathers early instead of
+// serialising four dependent memory round trips behind divergent branches.
 // ---------------------------------------------------------------------------------------------------------
+struct EvalAcc {
+    float acc[27];       // 21 upper-triangle terms of H, 6 of g
+    float e2p, e2d;      // per-lane float32 partial sums of squared weighted residuals
+    int   nP, nD, nVis;  // wave-uniform counts (scalar registers: popcount of the predicate ballots)
+};
+
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ int ballot_count(bool p) { return __builtin_popcountll(__ballot(p)); }
+
+// weightHuber (RPI.h:545-554) with the hardware sqrt / rcp approximations (1 ulp): weights are float32 data,
+// not index work.
+__device__ __forceinline__ float weight_huber_fast(float error, float k) {
+    const float ea = fabsf(error);
+    const float w = fast_sqrt(2 * k * ea - k * k) * fast_rcp(ea);
+    return ea < k ? 1.f : w;
+}
+
+// acc += [J | res]^T-products of one residual row J = (j3, p' x j3): jacobianT36 = [I | -skew(p')] makes the last
+// three entries of every Jacobian row the cross product of p' with the first three (RPI.h:2994-2996, 3026).
+__device__ __forceinline__ void accumulate_row(EvalAcc& A, float jx, float jy, float jz, float X, float Y, float Z,
+                                               float res) {
+#pragma clang fp contract(fast)
+    float J[6];
+    J[0] = jx; J[1] = jy; J[2] = jz;
+    J[3] = Y * jz - Z * jy;
+    J[4] = Z * jx - X * jz;
+    J[5] = X * jy - Y * jx;
+    int k = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = a; b < 6; ++b, ++k) A.acc[k] += J[a] * J[b];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) A.acc[21 + a] += J[a] * res;
+}
+
+template <int METHOD, bool HG>
+__device__ __forceinline__ void eval_pixel(const float4 s, const bool in_range, const PoseRT& T, const LevelDev& lv,
+                                           const EvalConsts& ec, EvalAcc& A) {
+    float X, Y, Z, dist, dist_inv;
+    int ti = warp_pixel(T, s.x, s.y, s.z, lv, X, Y, Z, dist, dist_inv);
+    const bool vis = in_range && (s.x != kInvalidPoint) && (ti >= 0);
+    ti = vis ? ti : 0;
+    F3 tp, td;
+    if (METHOD != 1) tp = lv.trgP[ti];     // unconditional gathers: issued as soon as the index is known
+    if (METHOD != 0) td = lv.trgD[ti];
+    A.nVis += ballot_count(vis);
+    // keep each gather one 12-byte load: without this the compiler splits it and sinks the intensity / depth
+    // dword under the saliency branch, adding a dependent memory round trip per pixel
+    if (METHOD != 1) asm volatile("" : "+v"(tp.a), "+v"(tp.b), "+v"(tp.c));
+    if (METHOD != 0) asm volatile("" : "+v"(td.a), "+v"(td.b), "+v"(td.c));
+
+    // rows of jacobianProj23 (RPI.h:3000-3016); float32 data: hardware rcp / rsq
+    float a1 = 0.f, a2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
+    if (HG) {
+#pragma clang fp contract(fast)
+        const float z_inv = fast_rcp(Z);
+        const float z_inv2 = z_inv * z_inv;
+        const float D_atan_theta = fast_rcp(1 + Y * Y * z_inv2) * lv.angle_res_inv;
+        a1 = D_atan_theta * z_inv;
+        a2 = -Y * z_inv2 * D_atan_theta;
+        const float x_dist_inv2 = X * (dist_inv * dist_inv);
+        const float one_m = 1 - X * x_dist_inv2;
+        const float D_asin = fast_rsq(one_m) * lv.angle_res_inv;
+        b0 = -D_asin * dist_inv * one_m;
+        const float c = D_asin * x_dist_inv2 * dist_inv;
+        b1 = c * Y;
+        b2 = c * Z;
+    }
+
+    bool photo_skip = false;   // `continue` at RPI.h:2690 / 3039 also skips the depth term of the pixel
+    if (METHOD != 1) {
+        const float tgx = tp.b, tgy = tp.c;
+        const bool nonsal = fabsf(tgx) < ec.thr_photo && fabsf(tgy) < ec.thr_photo;
+        photo_skip = nonsal;
+        const bool ok = vis && !nonsal;
+        A.nP += ballot_count(ok);
+        const float photoDiff = tp.a - s.w;    // outside the branch: keeps the gather one unconditional 12-byte load
+        if (ok) {
+#pragma clang fp contract(fast)
+            const float wpf = weight_huber_fast(photoDiff, ec.sigma_photo) * ec.sigma_photo_inv_f;
+            const float res = wpf * photoDiff;
+            A.e2p += res * res;
+            if (HG) {
+                const float wgx = wpf * tgx, wgy = wpf * tgy;
+                // (w * grad) * jacobianProj23
+                accumulate_row(A, wgy * b0, wgx * a1 + wgy * b1, wgx * a2 + wgy * b2, X, Y, Z, res);
+            }
+        }
+    }
+    if (METHOD != 0) {
+        const float depth2 = td.a;
+        const float tdx = td.b, tdy = td.c;
+        const bool nonsal = fabsf(tdx) < ec.thr_depth && fabsf(tdy) < ec.thr_depth;
+        const bool ok = vis && !photo_skip && isfinite(depth2) && !nonsal;
+        A.nD += ballot_count(ok);
+        const float depthDiff = depth2 - dist;
+        if (ok) {
+#pragma clang fp contract(fast)
+            const float sd = ec.sigma_depth * depth2;
+            const float wd = weight_huber_fast(depthDiff, sd) * fast_rcp(sd);
+            const float res = wd * depthDiff;
+            A.e2d += res * res;
+            if (HG) {
+                // wd * (dgrad * jacobianProj23 - p'/dist)   (RPI.h:3080-3083)
+                const float kx = wd * (tdy * b0 - X * dist_inv);
+                const float ky = wd * ((tdx * a1 + tdy * b1) - Y * dist_inv);
+                const float kz = wd * ((tdx * a2 + tdy * b2) - Z * dist_inv);
+                accumulate_row(A, kx, ky, kz, X, Y, Z, res);
+            }
+        }
+    }
+}
+
 template <int METHOD, bool HG>
 __global__ __launch_bounds__(kEvalThreads) void k_eval(LevelDev lv, EvalConsts ec, const GNState* __restrict__ st,
                                                         double* __restrict__ partials, int chunk) {
@@ -192,129 +336,46 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval(LevelDev lv, EvalConsts e
     const int cb = ((nb & 7) == 0) ? (b & 7) * (nb >> 3) + (b >> 3) : b;
     const PoseRT T = load_pose(st->cand);
 
-    float acc[27];
+    EvalAcc A;
 #pragma unroll
-    for (int k = 0; k < 27; ++k) acc[k] = 0.f;
-    double e2p = 0.0, e2d = 0.0;
-    int nP = 0, nD = 0, nVis = 0;
+    for (int k = 0; k < 27; ++k) A.acc[k] = 0.f;
+    A.e2p = A.e2d = 0.f;
+    A.nP = A.nD = A.nVis = 0;
 
     const int base = cb * chunk;
     const int end = min(base + chunk, lv.n);
-    for (int i = base + (int)threadIdx.x; i < end; i += kEvalThreads) {
-        const float4 s = lv.src[i];
-        if (s.x == kInvalidPoint) continue;
-        float X, Y, Z, dist, dist_inv;
-        int tr, tc;
-        const int ti = warp_pixel(T, s.x, s.y, s.z, lv, X, Y, Z, dist, dist_inv, tr, tc);
-        if (ti < 0) continue;
-        ++nVis;
-        F3 tp, td;
-        if (METHOD != 1) tp = lv.trgP[ti];
-        if (METHOD != 0) td = lv.trgD[ti];
-
-        // projection Jacobian rows (RPI.h:3000-3026); only needed when a residual survives, but cheap enough
-        float Jw0[6], Jw1[6];
-        if (HG) {
-#pragma clang fp contract(fast)
-            float z_inv = 1.f / Z;
-            float z_inv2 = z_inv * z_inv;
-            float D_atan_theta = 1.f / (1 + Y * Y * z_inv2) * lv.angle_res_inv;
-            float a1 = D_atan_theta * z_inv;
-            float a2 = -Y * z_inv2 * D_atan_theta;
-            float dist_inv2 = dist_inv * dist_inv;
-            float x_dist_inv2 = X * dist_inv2;
-            float D_asin = 1.f / sqrtf(1 - X * x_dist_inv2) * lv.angle_res_inv;
-            float b0 = -D_asin * dist_inv * (1 - X * x_dist_inv2);
-            float b1 = D_asin * (x_dist_inv2 * Y * dist_inv);
-            float b2 = D_asin * (x_dist_inv2 * Z * dist_inv);
-            Jw0[0] = 0.f; Jw0[1] = a1; Jw0[2] = a2;
-            Jw0[3] = a2 * Y - a1 * Z; Jw0[4] = -a2 * X; Jw0[5] = a1 * X;
-            Jw1[0] = b0; Jw1[1] = b1; Jw1[2] = b2;
-            Jw1[3] = b2 * Y - b1 * Z; Jw1[4] = b0 * Z - b2 * X; Jw1[5] = b1 * X - b0 * Y;
-        }
-
-        bool skip_depth = false;
-        if (METHOD != 1) {
-            const float tgx = tp.b, tgy = tp.c;
-            if (fabsf(tgx) < ec.thr_photo && fabsf(tgy) < ec.thr_photo) {
-                skip_depth = true;     // `continue` at RPI.h:2690 / 3039 also skips the depth term
-            } else {
-                const float photoDiff = tp.a - s.w;
-                const float wh = weight_huber(photoDiff, ec.sigma_photo);
-                // error pass: double weight (RPI.h:2559-2562, 2697-2698)
-                const double wpd = (double)wh * ec.sigma_photo_inv_d;
-                const float werr = (float)(wpd * (double)photoDiff);
-                e2p += (double)(werr * werr);
-                ++nP;
-                if (HG) {
-#pragma clang fp contract(fast)
-                    // H,g pass: float weight (RPI.h:2772-2775, 3047-3052)
-                    const float wpf = wh * ec.sigma_photo_inv_f;
-                    const float res = wpf * photoDiff;
-                    const float wgx = wpf * tgx, wgy = wpf * tgy;
-                    float J[6];
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) J[j] = wgx * Jw0[j] + wgy * Jw1[j];
-                    int k = 0;
-#pragma unroll
-                    for (int a = 0; a < 6; ++a)
-#pragma unroll
-                        for (int bb = a; bb < 6; ++bb, ++k) acc[k] += J[a] * J[bb];
-#pragma unroll
-                    for (int a = 0; a < 6; ++a) acc[21 + a] += J[a] * res;
-                }
-            }
-        }
-        if (METHOD != 0 && !skip_depth) {
-            const float depth2 = td.a;
-            if (isfinite(depth2)) {
-                const float tdx = td.b, tdy = td.c;
-                if (!(fabsf(tdx) < ec.thr_depth && fabsf(tdy) < ec.thr_depth)) {
-                    const float depthDiff = depth2 - dist;
-                    const float sd = ec.sigma_depth * depth2;
-                    const float wd = weight_huber(depthDiff, sd) / sd;
-                    const float werr = wd * depthDiff;   // == float(double(wd)*depthDiff): the product is exact in double
-                    e2d += (double)(werr * werr);
-                    ++nD;
-                    if (HG) {
-#pragma clang fp contract(fast)
-                        const float n0 = X * dist_inv, n1 = Y * dist_inv, n2 = Z * dist_inv;
-                        float nJ[6] = {n0, n1, n2, n2 * Y - n1 * Z, n0 * Z - n2 * X, n1 * X - n0 * Y};
-                        float J[6];
-#pragma unroll
-                        for (int j = 0; j < 6; ++j) J[j] = wd * ((tdx * Jw0[j] + tdy * Jw1[j]) - nJ[j]);
-                        int k = 0;
-#pragma unroll
-                        for (int a = 0; a < 6; ++a)
-#pragma unroll
-                            for (int bb = a; bb < 6; ++bb, ++k) acc[k] += J[a] * J[bb];
-#pragma unroll
-                        for (int a = 0; a < 6; ++a) acc[21 + a] += J[a] * werr;
-                    }
-                }
-            }
-        }
+    const int last = lv.n - 1;
+    int i = base + (int)threadIdx.x;
+    float4 s_cur = lv.src[min(i, last)];
+    // wave-uniform trip count (every lane stays active: the ballots below count whole waves); lanes past the end of
+    // the span process a clamped record with in_range = false
+    for (int i0 = base; i0 < end; i0 += kEvalThreads, i += kEvalThreads) {
+        const float4 s_next = lv.src[min(i + kEvalThreads, last)];   // in flight during this pixel's arithmetic
+        eval_pixel<METHOD, HG>(s_cur, i < end, T, lv, ec, A);
+        s_cur = s_next;
     }
 
-    // ---- reduction: lanes -> wave (f32 DPP) -> block (f64 via LDS) -> one partial row per block ----
+    // ---- reduction: lanes -> wave (f32 DPP, total in lane 63) -> block (f64 via LDS) -> one partial row ----
     __shared__ double red[kEvalThreads / 64][kNumPartials];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (HG) {
 #pragma unroll
         for (int k = 0; k < 27; ++k) {
-            float v = wave_sum(acc[k]);
-            if (lane == 0) red[wave][k] = (double)v;
+            const float v = wave_sum63(A.acc[k]);
+            if (lane == 63) red[wave][k] = (double)v;
         }
     } else if (lane < 27) {
         red[wave][lane] = 0.0;
     }
     {
-        double v;
-        v = wave_sum_d(e2p);          if (lane == 0) red[wave][P_E2P] = v;
-        v = wave_sum_d(e2d);          if (lane == 0) red[wave][P_E2D] = v;
-        v = wave_sum_d((double)nP);   if (lane == 0) red[wave][P_NP] = v;
-        v = wave_sum_d((double)nD);   if (lane == 0) red[wave][P_ND] = v;
-        v = wave_sum_d((double)nVis); if (lane == 0) red[wave][P_NVIS] = v;
+        const float vp = wave_sum63(A.e2p), vd = wave_sum63(A.e2d);
+        if (lane == 63) {
+            red[wave][P_E2P] = (double)vp;
+            red[wave][P_E2D] = (double)vd;
+            red[wave][P_NP] = (double)A.nP;
+            red[wave][P_ND] = (double)A.nD;
+            red[wave][P_NVIS] = (double)A.nVis;
+        }
     }
     __syncthreads();
     if (threadIdx.x < kNumPartials) {
@@ -469,14 +530,29 @@ __global__ void k_warp_indices(LevelDev lv, Pose16 pose, int32_t* __restrict__ o
     int r = -1, c = -1;
     if (s.x != kInvalidPoint) {
         float X, Y, Z, d, di;
-        int tr, tc;
-        if (warp_pixel(T, s.x, s.y, s.z, lv, X, Y, Z, d, di, tr, tc) >= 0) {
-            r = tr;
-            c = tc;
+        const int ti = warp_pixel(T, s.x, s.y, s.z, lv, X, Y, Z, d, di);
+        if (ti >= 0) {
+            r = ti / lv.cols;
+            c = ti - r * lv.cols;
         }
     }
     out[2 * i] = r;
     out[2 * i + 1] = c;
+}
+
+// Self-test of sqrt_rn / rcp_rn against the compiler's IEEE sqrtf and 1.f/x over a bit-pattern range.
+__global__ void k_selftest_math(unsigned first_bits, unsigned count, unsigned long long* __restrict__ mismatches) {
+    const unsigned stride = gridDim.x * blockDim.x;
+    unsigned bad_s = 0, bad_r = 0;
+    for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += stride) {
+        const float x = __builtin_bit_cast(float, first_bits + k);
+        const float s0 = sqrtf(x), s1 = sqrt_rn(x);
+        const float r0 = 1.f / x, r1 = rcp_rn(x);
+        bad_s += (__builtin_bit_cast(unsigned, s0) != __builtin_bit_cast(unsigned, s1));
+        bad_r += (__builtin_bit_cast(unsigned, r0) != __builtin_bit_cast(unsigned, r1));
+    }
+    if (bad_s) atomicAdd(&mismatches[0], (unsigned long long)bad_s);
+    if (bad_r) atomicAdd(&mismatches[1], (unsigned long long)bad_r);
 }
 
 // ---------------------------------------------------------------------------------------------------------

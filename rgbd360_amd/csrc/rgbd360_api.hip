@@ -82,7 +82,8 @@ int ensure_levels(rgbd360_ctx* ctx, int rows, int cols) {
     if (rows < 2 || cols < 8) return fail(ctx, -1, "image too small");
     if ((rows >> (ctx->p.n_pyr - 1)) < 2 || (cols >> (ctx->p.n_pyr - 1)) < 8)
         return fail(ctx, -1, "too many pyramid levels for this image size (coarsest level must be >= 2 x 8)");
-    if ((long long)rows * cols >= (1ll << 30)) return fail(ctx, -1, "image too large");
+    if ((long long)rows * cols >= (1ll << 24) || rows >= (1 << 15) || cols >= (1 << 15))
+        return fail(ctx, -1, "image too large (the fused pass uses 24-bit index arithmetic: < 16 Mpx)");
     HIPC(ctx, hipStreamSynchronize(ctx->stream));
     free_levels(ctx);
     ctx->levels.resize(ctx->p.n_pyr);
@@ -570,6 +571,22 @@ int rgbd360_time_eval_kernel(rgbd360_ctx* ctx, int level, const float pose[16], 
     float ms = 0.f;
     HIPC(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     *avg_us = ms * 1000.f / reps;
+    return 0;
+}
+
+int rgbd360_selftest_math(rgbd360_ctx* ctx, uint32_t first_bits, uint32_t count, unsigned long long mismatches[2]) {
+    if (!ctx || !mismatches) return -1;
+    hipSetDevice(ctx->p.device);
+    unsigned long long* d = nullptr;
+    HIPC(ctx, hipMalloc(&d, 2 * sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(d, 0, 2 * sizeof(unsigned long long), ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_selftest_math, dim3(2048), dim3(256), 0, ctx->stream, first_bits, count, d);
+        e = hipMemcpyAsync(mismatches, d, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipFree(d);
+    HIPC(ctx, e);
     return 0;
 }
 

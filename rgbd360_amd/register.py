@@ -253,6 +253,11 @@ class RegisterPhotoICP:
                                                      C.byref(us)))
         return float(us.value)
 
+    def selftest_math(self, first_bits: int, count: int):
+        out = np.zeros(2, dtype=np.uint64)
+        self._check(self._L.rgbd360_selftest_math(self._ctx(), first_bits, count, _ptr(out)))
+        return int(out[0]), int(out[1])
+
     def sync(self):
         self._check(self._L.rgbd360_sync(self._ctx()))
 

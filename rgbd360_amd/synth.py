@@ -50,18 +50,31 @@ def _wall_params(seed: int):
     return alpha, phase, freq, lattice, chroma
 
 
-def render(T_wc: np.ndarray, width: int, height: int | None = None, seed: int = 1234, depth_f32: bool = False):
+def render(T_wc: np.ndarray, width: int, height: int | None = None, seed: int = 1234, depth_f32: bool = False,
+           strip: int = 32):
     """Render the room from camera-to-world pose T_wc.  Returns (rgb uint8 HxWx3, depth uint16 mm HxW),
-    or float32 metres for the depth when depth_f32 (RegisterPhotoICP.h:318-319 accepts both)."""
+    or float32 metres for the depth when depth_f32 (RegisterPhotoICP.h:318-319 accepts both).
+    Rows are processed in strips so temporaries stay cache-sized; the result does not depend on `strip`."""
     W = int(width)
     H = int(height) if height is not None else W // 2
-    alpha, phase, freq, lattice, chroma = _wall_params(seed)
+    params = _wall_params(seed)
+    rgb = np.empty((H, W, 3), dtype=np.uint8)
+    depth = np.empty((H, W), dtype=np.float32 if depth_f32 else np.uint16)
+    for r0 in range(0, H, strip):
+        r1 = min(H, r0 + strip)
+        _render_rows(T_wc, W, H, r0, r1, params, depth_f32, rgb[r0:r1], depth[r0:r1])
+    return rgb, depth
+
+
+def _render_rows(T_wc, W, H, r0, r1, params, depth_f32, rgb_out, depth_out):
+    alpha, phase, freq, lattice, chroma = params
+    n = r1 - r0
     res = 2 * math.pi / W
-    phi = (H / 2 - 0.5 - np.arange(H, dtype=np.float64)) * res
+    phi = (H / 2 - 0.5 - np.arange(r0, r1, dtype=np.float64)) * res
     theta = np.arange(W, dtype=np.float64) * res
     sp, cp = np.sin(phi)[:, None], np.cos(phi)[:, None]
     st, ct = np.sin(theta)[None, :], np.cos(theta)[None, :]
-    ray_c = np.stack([np.broadcast_to(sp, (H, W)), -cp * st, -cp * ct], axis=-1)  # HxWx3
+    ray_c = np.stack([np.broadcast_to(sp, (n, W)), -cp * st, -cp * ct], axis=-1)  # n x W x 3
     R, o = T_wc[:3, :3], T_wc[:3, 3]
     ray_w = ray_c @ R.T
     with np.errstate(divide="ignore", invalid="ignore"):
@@ -79,9 +92,9 @@ def render(T_wc: np.ndarray, width: int, height: int | None = None, seed: int = 
     u = np.take_along_axis(P, ua[..., None], axis=-1)[..., 0]
     v = np.take_along_axis(P, va[..., None], axis=-1)[..., 0]
 
-    tex = np.full((H, W), 0.5)
-    c1 = np.zeros((H, W))
-    c2 = np.zeros((H, W))
+    tex = np.full((n, W), 0.5)
+    c1 = np.zeros((n, W))
+    c2 = np.zeros((n, W))
     for k in range(len(_WAVELENGTHS)):
         a = alpha[wall, k]
         s = np.sin(2 * math.pi * freq[wall, k] * (u * np.cos(a) + v * np.sin(a)) + phase[wall, k])
@@ -100,14 +113,13 @@ def render(T_wc: np.ndarray, width: int, height: int | None = None, seed: int = 
     n11 = lattice[wall, iu0 + 1, iv0 + 1]
     tex += 0.08 * ((n00 * (1 - fu) + n10 * fu) * (1 - fv) + (n01 * (1 - fu) + n11 * fu) * fv)
 
-    rgb = np.stack([tex + c1, tex, tex + c2], axis=-1)
-    rgb = np.clip(np.rint(rgb * 255.0), 0, 255).astype(np.uint8)
+    col = np.stack([tex + c1, tex, tex + c2], axis=-1)
+    rgb_out[...] = np.clip(np.rint(col * 255.0), 0, 255).astype(np.uint8)
     valid = (t > MIN_DEPTH) & (t < MAX_DEPTH)
     if depth_f32:
-        depth = np.where(valid, t, 0.0).astype(np.float32)
+        depth_out[...] = np.where(valid, t, 0.0).astype(np.float32)
     else:
-        depth = np.where(valid, np.rint(t * 1000.0), 0).astype(np.uint16)
-    return np.ascontiguousarray(rgb), np.ascontiguousarray(depth)
+        depth_out[...] = np.where(valid, np.rint(t * 1000.0), 0).astype(np.uint16)
 
 
 def default_motion(seed: int = 1234, trans: float = 0.06, rot_deg: float = 2.0) -> np.ndarray:
