@@ -136,10 +136,15 @@ int rgbd360_forced_iters(rgbd360_ctx* ctx, int level, const float pose0[16], int
 int rgbd360_time_eval_kernel(rgbd360_ctx* ctx, int level, const float pose[16], int method, int want_hg, int reps,
                              float* avg_us);
 
+/* Same for the solve launch (mode 0: reduction + Gauss-Newton step, forced; mode 1: reduction only), re-using the
+ * partials of the last pass. */
+int rgbd360_time_solve_kernel(rgbd360_ctx* ctx, int level, int mode, int reps, float* avg_us);
+
 /* Device self-test of the correctly rounded sqrt / reciprocal sequences the warp front end uses: compares them
  * with the compiler's IEEE sqrtf and 1.f/x for the `count` float bit patterns starting at `first_bits`;
- * mismatches[0] = sqrt, mismatches[1] = reciprocal. */
-int rgbd360_selftest_math(rgbd360_ctx* ctx, uint32_t first_bits, uint32_t count, unsigned long long mismatches[2]);
+ * mismatches[0] = sqrt, mismatches[1] = reciprocal, mismatches[2] = the round-half-up float->int conversion
+ * against floor((double)x + 0.5) for |x| < 1e9 (both signs). */
+int rgbd360_selftest_math(rgbd360_ctx* ctx, uint32_t first_bits, uint32_t count, unsigned long long mismatches[3]);
 
 /* The HIP stream all work of this context is enqueued on (hipStream_t as void*). */
 void* rgbd360_stream(rgbd360_ctx* ctx);

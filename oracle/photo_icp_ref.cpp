@@ -169,7 +169,7 @@ inline float atan2f_poly(float y, float x) {
     float mx = fmaxf(fmaxf(ay, ax), 1e-30f), mn = fminf(ay, ax);
     return atan2f_poly_t(y, x, ay, ax, mn * (1.f / mx));
 }
-inline int round_index(float x) { return (int)floorf(x + 0.5f); }
+inline int round_index(float x) { return (int)floor((double)x + 0.5); }   // v_cvt_rpi_i32_f32: exact sum, then floor
 
 // ------------------------------------------------------------------------------------
 // THIRD-PARTY restatements (OpenCV)
@@ -376,7 +376,7 @@ inline Warp warp_pixel(const PoseRT& T, const float* p, int nRows, int nCols, fl
         const float t = mn * (r * w.dist);
         const float phi_trg = asinf_poly(w.X * w.dist_inv);
         const float theta_trg = (float)((double)atan2f_poly_t(w.Y, w.Z, ay, az, t) + kPI);
-        w.r = round_index(half_nRows - phi_trg * angle_res_inv);
+        w.r = round_index(fmaf(-phi_trg, angle_res_inv, half_nRows));
         w.c = round_index(theta_trg * angle_res_inv);
         w.visible = ((unsigned)w.r < (unsigned)nRows) && ((unsigned)w.c < (unsigned)nCols);
     }

@@ -13,7 +13,7 @@ SYMBOLS = [
     "rgbd360_set_source", "rgbd360_set_target_dev", "rgbd360_set_source_dev", "rgbd360_promote_source_to_target",
     "rgbd360_align360", "rgbd360_level_dims", "rgbd360_get_plane", "rgbd360_get_lut", "rgbd360_eval",
     "rgbd360_warp_indices", "rgbd360_gn_step", "rgbd360_forced_iters", "rgbd360_time_eval_kernel", "rgbd360_stream",
-    "rgbd360_sync", "rgbd360_device_count", "rgbd360_sphere_cloud", "rgbd360_selftest_math",
+    "rgbd360_sync", "rgbd360_device_count", "rgbd360_sphere_cloud", "rgbd360_selftest_math", "rgbd360_time_solve_kernel",
 ]
 
 
@@ -67,6 +67,7 @@ def load() -> C.CDLL:
     L.rgbd360_stream.restype = vp
     L.rgbd360_sync.argtypes = [vp]
     L.rgbd360_device_count.argtypes = []
+    L.rgbd360_time_solve_kernel.argtypes = [vp, i32, i32, i32, C.POINTER(C.c_float)]
     L.rgbd360_selftest_math.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
     L.rgbd360_sphere_cloud.argtypes = [vp, vp, C.c_size_t, i32, i32, i32, i32, f32p]
     _lib = L

@@ -140,6 +140,43 @@ GN_HD inline bool inverse6(const float* M, float* inv) {
     return true;
 }
 
+// sin(a)/a and (1-cos(a))/a^2 in float64.  On the device small angles (every Gauss-Newton update is one) use the
+// Maclaurin series to full double accuracy instead of the library's argument-reduction sin/cos; the result is cast
+// to float32 by the caller (RPI.h:4697), far above any difference in the last double bits.
+GN_HD inline void sinc_cosc(double angle, double& a, double& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (angle < 0.5) {
+        const double x2 = angle * angle;
+        // sin(x)/x = sum (-1)^k x^2k/(2k+1)!,  (1-cos x)/x^2 = sum (-1)^k x^2k/(2k+2)!   (k <= 9: x^18 < 4e-6^... 1e-22 rel)
+        double sa = 1.0 / 121645100408832000.0;      // 1/19!
+        sa = -sa * x2 + 1.0 / 355687428096000.0;     // 1/17!
+        sa = -sa * x2 + 1.0 / 1307674368000.0;       // 1/15!
+        sa = -sa * x2 + 1.0 / 6227020800.0;          // 1/13!
+        sa = -sa * x2 + 1.0 / 39916800.0;            // 1/11!
+        sa = -sa * x2 + 1.0 / 362880.0;              // 1/9!
+        sa = -sa * x2 + 1.0 / 5040.0;                // 1/7!
+        sa = -sa * x2 + 1.0 / 120.0;                 // 1/5!
+        sa = -sa * x2 + 1.0 / 6.0;                   // 1/3!
+        sa = -sa * x2 + 1.0;
+        double cb = 1.0 / 2432902008176640000.0;     // 1/20!
+        cb = -cb * x2 + 1.0 / 6402373705728000.0;    // 1/18!
+        cb = -cb * x2 + 1.0 / 20922789888000.0;      // 1/16!
+        cb = -cb * x2 + 1.0 / 87178291200.0;         // 1/14!
+        cb = -cb * x2 + 1.0 / 479001600.0;           // 1/12!
+        cb = -cb * x2 + 1.0 / 3628800.0;             // 1/10!
+        cb = -cb * x2 + 1.0 / 40320.0;               // 1/8!
+        cb = -cb * x2 + 1.0 / 720.0;                 // 1/6!
+        cb = -cb * x2 + 1.0 / 24.0;                  // 1/4!
+        cb = -cb * x2 + 0.5;
+        a = sa;
+        b = cb;
+        return;
+    }
+#endif
+    a = sin(angle) / angle;
+    b = (1 - cos(angle)) / (angle * angle);
+}
+
 // E = [ Rodrigues(v[3..5])  v[0..2] ; 0 0 0 1 ], float64, column-major.
 GN_HD inline void se3_pseudo_exp(const double* v, double* E) {
     const double wx = v[3], wy = v[4], wz = v[5];
@@ -147,7 +184,8 @@ GN_HD inline void se3_pseudo_exp(const double* v, double* E) {
     double R[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
     if (angle >= 128 * 2.220446049250313e-16) {
         const double W[3][3] = {{0, -wz, wy}, {wz, 0, -wx}, {-wy, wx, 0}};
-        const double a = sin(angle) / angle, b = (1 - cos(angle)) / (angle * angle);
+        double a, b;
+        sinc_cosc(angle, a, b);
         for (int i = 0; i < 3; ++i)
             for (int j = 0; j < 3; ++j) {
                 double w2 = 0;

@@ -24,7 +24,7 @@ namespace r360 {
 
 constexpr float  kInvalidPoint = -10000.f;      // RPI.h:40
 constexpr double kPI = 3.14159265359;           // Miscellaneous.h:44 (truncated literal, double)
-constexpr int    kEvalThreads = 256;
+constexpr int    kEvalThreads = 512;
 constexpr int    kNumPartials = 32;             // doubles per block partial
 // partial slots
 enum { P_H = 0 /*21*/, P_G = 21 /*6*/, P_E2P = 27, P_E2D = 28, P_NP = 29, P_ND = 30, P_NVIS = 31 };
@@ -106,9 +106,14 @@ __device__ __forceinline__ float rcp_rn(float x) {
     return r;
 }
 
-// round-half-up to the nearest integer; equals C round() except at x = 0.49999997 and exact negative ties, which
-// cannot change a visible pixel index (negative rows / columns are dropped).
-__device__ __forceinline__ int round_index(float x) { return (int)floorf(x + 0.5f); }
+// round-half-up to the nearest integer, floor(x + 0.5) with the sum taken exactly: one v_cvt_rpi_i32_f32.  Equals
+// C round() except at exact negative ties, which cannot change a visible pixel index (negative rows / columns are
+// dropped).  rgbd360_selftest_math checks the instruction against floor((double)x + 0.5) over the index range.
+__device__ __forceinline__ int round_index(float x) {
+    int r;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
 
 __device__ __forceinline__ float asinf_poly(float x) {
     const float c0 = 0.16666672764720836f, c1 = 0.07498809174564633f, c2 = 0.0450107002296682f,
@@ -174,7 +179,7 @@ __device__ __forceinline__ int warp_pixel(const PoseRT& T, float px, float py, f
     const float t = mn * (r * dist);
     const float phi_trg = asinf_poly(X * dist_inv);
     const float theta_trg = (float)((double)atan2f_poly_t(Y, Z, ay, az, t) + kPI);
-    const int tr = round_index(lv.half_nRows - phi_trg * lv.angle_res_inv);
+    const int tr = round_index(fmaf(-phi_trg, lv.angle_res_inv, lv.half_nRows));
     const int tc = round_index(theta_trg * lv.angle_res_inv);
     const bool vis = ((unsigned)tr < (unsigned)lv.rows) && ((unsigned)tc < (unsigned)lv.cols);
     return vis ? (int)__umul24(tr, lv.cols) + tc : -1;
@@ -249,21 +254,40 @@ __device__ __forceinline__ void accumulate_row(EvalAcc& A, float jx, float jy, f
     for (int a = 0; a < 6; ++a) A.acc[21 + a] += J[a] * res;
 }
 
+// The pixel body is split in two stages so that the loop can be software-pipelined:
+//   warp_stage    source record -> warped point, target index, both gathers ISSUED
+//   consume_stage gathered records -> residuals, Jacobian rows, normal-equation terms
+// k_eval runs warp_stage of pixel i+1 before consume_stage of pixel i: the gather latency of one pixel hides behind
+// the arithmetic of its neighbour instead of stalling the wave.
+struct PixW {
+    float X, Y, Z, dist, dist_inv, isrc;
+    bool  vis;
+    F3    tp, td;
+};
+
+template <int METHOD>
+__device__ __forceinline__ void warp_stage(const float4 s, const bool in_range, const PoseRT& T, const LevelDev& lv,
+                                           PixW& w) {
+    int ti = warp_pixel(T, s.x, s.y, s.z, lv, w.X, w.Y, w.Z, w.dist, w.dist_inv);
+    w.vis = in_range && (s.x != kInvalidPoint) && (ti >= 0);
+    w.isrc = s.w;
+    // tie the copy of the source intensity to the end of the warp arithmetic: scheduled earlier it would sit in
+    // front of the whole stage and wait for the youngest load (vmcnt(0)) instead of the one this stage needs
+    asm volatile("" : "+v"(w.isrc), "+v"(w.dist));
+    ti = w.vis ? ti : 0;
+    if (METHOD != 1) w.tp = lv.trgP[ti];     // unconditional gathers: issued as soon as the index is known
+    if (METHOD != 0) w.td = lv.trgD[ti];
+}
+
 template <int METHOD, bool HG>
-__device__ __forceinline__ void eval_pixel(const float4 s, const bool in_range, const PoseRT& T, const LevelDev& lv,
-                                           const EvalConsts& ec, EvalAcc& A) {
-    float X, Y, Z, dist, dist_inv;
-    int ti = warp_pixel(T, s.x, s.y, s.z, lv, X, Y, Z, dist, dist_inv);
-    const bool vis = in_range && (s.x != kInvalidPoint) && (ti >= 0);
-    ti = vis ? ti : 0;
-    F3 tp, td;
-    if (METHOD != 1) tp = lv.trgP[ti];     // unconditional gathers: issued as soon as the index is known
-    if (METHOD != 0) td = lv.trgD[ti];
-    A.nVis += ballot_count(vis);
+__device__ __forceinline__ void consume_stage(PixW& w, const LevelDev& lv, const EvalConsts& ec, EvalAcc& A) {
     // keep each gather one 12-byte load: without this the compiler splits it and sinks the intensity / depth
     // dword under the saliency branch, adding a dependent memory round trip per pixel
-    if (METHOD != 1) asm volatile("" : "+v"(tp.a), "+v"(tp.b), "+v"(tp.c));
-    if (METHOD != 0) asm volatile("" : "+v"(td.a), "+v"(td.b), "+v"(td.c));
+    if (METHOD != 1) asm volatile("" : "+v"(w.tp.a), "+v"(w.tp.b), "+v"(w.tp.c));
+    if (METHOD != 0) asm volatile("" : "+v"(w.td.a), "+v"(w.td.b), "+v"(w.td.c));
+    const float X = w.X, Y = w.Y, Z = w.Z, dist_inv = w.dist_inv;
+    const bool vis = w.vis;
+    A.nVis += ballot_count(vis);
 
     // rows of jacobianProj23 (RPI.h:3000-3016); float32 data: hardware rcp / rsq
     float a1 = 0.f, a2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
@@ -285,14 +309,14 @@ __device__ __forceinline__ void eval_pixel(const float4 s, const bool in_range, 
 
     bool photo_skip = false;   // `continue` at RPI.h:2690 / 3039 also skips the depth term of the pixel
     if (METHOD != 1) {
-        const float tgx = tp.b, tgy = tp.c;
+        const float tgx = w.tp.b, tgy = w.tp.c;
         const bool nonsal = fabsf(tgx) < ec.thr_photo && fabsf(tgy) < ec.thr_photo;
         photo_skip = nonsal;
         const bool ok = vis && !nonsal;
         A.nP += ballot_count(ok);
-        const float photoDiff = tp.a - s.w;    // outside the branch: keeps the gather one unconditional 12-byte load
         if (ok) {
 #pragma clang fp contract(fast)
+            const float photoDiff = w.tp.a - w.isrc;
             const float wpf = weight_huber_fast(photoDiff, ec.sigma_photo) * ec.sigma_photo_inv_f;
             const float res = wpf * photoDiff;
             A.e2p += res * res;
@@ -304,14 +328,14 @@ __device__ __forceinline__ void eval_pixel(const float4 s, const bool in_range, 
         }
     }
     if (METHOD != 0) {
-        const float depth2 = td.a;
-        const float tdx = td.b, tdy = td.c;
+        const float depth2 = w.td.a;
+        const float tdx = w.td.b, tdy = w.td.c;
         const bool nonsal = fabsf(tdx) < ec.thr_depth && fabsf(tdy) < ec.thr_depth;
         const bool ok = vis && !photo_skip && isfinite(depth2) && !nonsal;
         A.nD += ballot_count(ok);
-        const float depthDiff = depth2 - dist;
         if (ok) {
 #pragma clang fp contract(fast)
+            const float depthDiff = depth2 - w.dist;
             const float sd = ec.sigma_depth * depth2;
             const float wd = weight_huber_fast(depthDiff, sd) * fast_rcp(sd);
             const float res = wd * depthDiff;
@@ -330,10 +354,17 @@ __device__ __forceinline__ void eval_pixel(const float4 s, const bool in_range, 
 template <int METHOD, bool HG>
 __global__ __launch_bounds__(kEvalThreads) void k_eval(LevelDev lv, EvalConsts ec, const GNState* __restrict__ st,
                                                         double* __restrict__ partials, int chunk) {
-    if (st->done) return;
     const int nb = gridDim.x;
     const int b = blockIdx.x;
     const int cb = ((nb & 7) == 0) ? (b & 7) * (nb >> 3) + (b >> 3) : b;
+    const int base = cb * chunk;
+    const int end = min(base + chunk, lv.n);
+    const int last = lv.n - 1;
+    int i = base + (int)threadIdx.x;
+    // the first two source records do not depend on the state: issue them before the scalar loads of done / pose
+    float4 sA = lv.src[min(i, last)];
+    float4 sB = lv.src[min(i + kEvalThreads, last)];
+    if (st->done) return;
     const PoseRT T = load_pose(st->cand);
 
     EvalAcc A;
@@ -342,17 +373,31 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval(LevelDev lv, EvalConsts e
     A.e2p = A.e2d = 0.f;
     A.nP = A.nD = A.nVis = 0;
 
-    const int base = cb * chunk;
-    const int end = min(base + chunk, lv.n);
-    const int last = lv.n - 1;
-    int i = base + (int)threadIdx.x;
-    float4 s_cur = lv.src[min(i, last)];
-    // wave-uniform trip count (every lane stays active: the ballots below count whole waves); lanes past the end of
-    // the span process a clamped record with in_range = false
-    for (int i0 = base; i0 < end; i0 += kEvalThreads, i += kEvalThreads) {
-        const float4 s_next = lv.src[min(i + kEvalThreads, last)];   // in flight during this pixel's arithmetic
-        eval_pixel<METHOD, HG>(s_cur, i < end, T, lv, ec, A);
-        s_cur = s_next;
+    // Wave-uniform trip count (every lane stays active: the ballots count whole waves); lanes past the end of the
+    // span process a clamped record with in_range = false.  The loop is unrolled by two with ping-pong register
+    // sets (wA / wB) so that no register copy forces an early wait: while the arithmetic of step k runs, the gathers
+    // of step k+1 and the source record of step k+2 are in flight.
+    const int n_steps = (end - base + kEvalThreads - 1) / kEvalThreads;
+    PixW wA, wB;
+    warp_stage<METHOD>(sA, i < end, T, lv, wA);
+    sA = lv.src[min(i + 2 * kEvalThreads, last)];
+    int k = 0;
+    // steady state: straight-line body (no control-flow joins, so the compiler's waits are counted, not vmcnt(0))
+    for (; k + 2 < n_steps; k += 2, i += 2 * kEvalThreads) {
+        warp_stage<METHOD>(sB, (i + kEvalThreads) < end, T, lv, wB);
+        sB = lv.src[min(i + 3 * kEvalThreads, last)];
+        consume_stage<METHOD, HG>(wA, lv, ec, A);
+        warp_stage<METHOD>(sA, (i + 2 * kEvalThreads) < end, T, lv, wA);
+        sA = lv.src[min(i + 4 * kEvalThreads, last)];
+        consume_stage<METHOD, HG>(wB, lv, ec, A);
+    }
+    // tail: one or two steps left, wA holds step k
+    if (k + 1 < n_steps) {
+        warp_stage<METHOD>(sB, (i + kEvalThreads) < end, T, lv, wB);
+        consume_stage<METHOD, HG>(wA, lv, ec, A);
+        consume_stage<METHOD, HG>(wB, lv, ec, A);
+    } else {
+        consume_stage<METHOD, HG>(wA, lv, ec, A);
     }
 
     // ---- reduction: lanes -> wave (f32 DPP, total in lane 63) -> block (f64 via LDS) -> one partial row ----
@@ -415,100 +460,311 @@ __global__ void k_level_init(GNState* st, Pose16 pose, int use_pose, int reset_a
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Lane-parallel 6x6 kernels for k_solve: matrix columns live on lanes, rows in registers with compile-time
+// indices (no scratch memory).  They perform the same float32 operations in the same order as gn::inverse6 /
+// gn::rank6 (gn_math.h), which the tests compare against through k_gn_step and the CPU oracle.
+// ---------------------------------------------------------------------------------------------------------
+// Broadcast of one lane's value to the whole wave through a scalar register (v_readlane_b32): the lane index is
+// wave-uniform everywhere below, so no LDS crossbar (ds_bpermute) round trip is needed.
+__device__ __forceinline__ float bcast(float v, int lane_uniform) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane_uniform));
+}
+
+// Lanes 0-5 hold the columns of M, lanes 6-11 the columns of the identity; returns false when a pivot is zero.
+// On return lanes 6-11 hold the columns of M^-1 in x[0..5].
+__device__ __forceinline__ bool lu_inverse6_lanes(const float* M /*LDS, column-major*/, int lane, float x[6]) {
+    float a[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) a[r] = lane < 6 ? M[lane * 6 + r] : ((lane - 6) == r ? 1.f : 0.f);
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        float ck[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) ck[r] = bcast(a[r], k);
+        int piv = k;
+        float best = fabsf(ck[k]);
+#pragma unroll
+        for (int r = k + 1; r < 6; ++r) {
+            const float v = fabsf(ck[r]);
+            if (v > best) {
+                best = v;
+                piv = r;
+            }
+        }
+        if (best == 0.f) ok = false;
+#pragma unroll
+        for (int r = k + 1; r < 6; ++r)
+            if (piv == r) {
+                float t = a[k]; a[k] = a[r]; a[r] = t;
+                t = ck[k]; ck[k] = ck[r]; ck[r] = t;
+            }
+#pragma unroll
+        for (int r = k + 1; r < 6; ++r) {
+            const float l = ck[r] / ck[k];
+            if (lane > k) a[r] -= l * a[k];
+        }
+    }
+    // back substitution on the right-hand-side lanes: U[r][c] is row r of lane c
+#pragma unroll
+    for (int r = 5; r >= 0; --r) {
+        float sacc = a[r];
+#pragma unroll
+        for (int c = r + 1; c < 6; ++c) sacc -= bcast(a[r], c) * x[c];
+        x[r] = sacc / bcast(a[r], r);
+    }
+    return ok;
+}
+
+// Rank of the 6x6 matrix whose columns sit on lanes 0-5 (column-pivoted Householder QR, Eigen thresholds).
+__device__ __forceinline__ int qr_rank6_lanes(const float* M /*LDS, column-major*/, int lane) {
+    const int col = lane < 6 ? lane : 5;
+    float a[6];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) a[r] = M[col * 6 + r];
+    float sq = 0.f;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) sq += a[r] * a[r];
+    float maxColSq = 0.f;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        const float v = bcast(sq, c);
+        maxColSq = v > maxColSq ? v : maxColSq;
+    }
+    const float threshold_helper = maxColSq * (gn::kEpsF * gn::kEpsF) / 6.f;
+    float pivots[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float maxpivot = 0.f;
+    int nonzero = 6;
+    bool stopped = false;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        float sk = 0.f;
+#pragma unroll
+        for (int r = k; r < 6; ++r) sk += a[r] * a[r];
+        int best = k;
+        float bestSq = -1.f;
+#pragma unroll
+        for (int c = k; c < 6; ++c) {
+            const float v = bcast(sk, c);
+            if (v > bestSq) {
+                bestSq = v;
+                best = c;
+            }
+        }
+        if (!stopped && bestSq < threshold_helper * (float)(6 - k)) {
+            nonzero = k;
+            stopped = true;
+        }
+        if (!stopped) {
+            // swap columns k and best
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                const float from_best = bcast(a[r], best), from_k = bcast(a[r], k);
+                a[r] = (lane == k) ? from_best : ((lane == best) ? from_k : a[r]);
+            }
+            float ck[6];
+#pragma unroll
+            for (int r = 0; r < 6; ++r) ck[r] = bcast(a[r], k);
+            float tailSq = 0.f;
+#pragma unroll
+            for (int r = k + 1; r < 6; ++r) tailSq += ck[r] * ck[r];
+            const float c0 = ck[k];
+            float beta, tau;
+            float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (tailSq == 0.f) {
+                tau = 0.f;
+                beta = c0;
+            } else {
+                beta = sqrtf(c0 * c0 + tailSq);
+                if (c0 >= 0.f) beta = -beta;
+#pragma unroll
+                for (int r = k + 1; r < 6; ++r) v[r] = ck[r] / (c0 - beta);
+                tau = (beta - c0) / beta;
+            }
+            v[k] = 1.f;
+            float dot = 0.f;
+#pragma unroll
+            for (int r = k; r < 6; ++r) dot += v[r] * a[r];
+            dot *= tau;
+            if (lane > k) {
+#pragma unroll
+                for (int r = k; r < 6; ++r) a[r] -= dot * v[r];
+            }
+            pivots[k] = beta;
+            const float ab = fabsf(beta);
+            maxpivot = ab > maxpivot ? ab : maxpivot;
+        }
+    }
+    const float thr = maxpivot * (gn::kEpsF * 6.f);
+    int rank = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) rank += (k < nonzero && fabsf(pivots[k]) > thr) ? 1 : 0;
+    return rank;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // k_solve: one block.  (1) fixed-order float64 reduction of the block partials; (2) the serial part of one
-// loop trip of alignFrames360 (accept test, termination test, rank test, GN step, pose composition).
+// loop trip of alignFrames360 (accept test, termination test, rank test, GN step, pose composition), with
+// the rank test and the 6x6 inverse on two waves side by side.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kSolveThreads = 1024;
-__global__ __launch_bounds__(kSolveThreads) void k_solve(GNState* st, const double* __restrict__ partials, int nb,
+__global__ __launch_bounds__(kSolveThreads) void k_solve(GNState* st_g, const double* __restrict__ partials, int nb,
                                                           SolveCfg cfg) {
-    if (cfg.mode == 0 && st->done) return;
+    // The state is staged through LDS: one coalesced read while the partials are being reduced, one coalesced
+    // write-back at the end; the single-lane bookkeeping below then never waits on global memory.
+    __shared__ GNState sst;
     __shared__ double red[kSolveThreads / kNumPartials][kNumPartials];
-    const int v = threadIdx.x % kNumPartials, q = threadIdx.x / kNumPartials;
+    __shared__ float shH[36], shM[36], shg[6], shInv[36], shUpd[6], shE[16];
+    __shared__ int shGo, shRank, shLuOk;
+    constexpr int kStateWords = sizeof(GNState) / 4;
+    static_assert(sizeof(GNState) % 4 == 0 && kStateWords <= kSolveThreads, "GNState staging");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < kStateWords) reinterpret_cast<int*>(&sst)[tid] = reinterpret_cast<const int*>(st_g)[tid];
+    const int v = tid % kNumPartials, q = tid / kNumPartials;
     constexpr int Q = kSolveThreads / kNumPartials;
+    // rows q, q+Q, q+2Q, ... of the partial table: all loads of a batch are issued before the first add (one
+    // memory round trip per 16 rows instead of one per row); the summation order stays fixed.
     double s = 0.0;
-    for (int b = q; b < nb; b += Q) s += partials[(size_t)b * kNumPartials + v];
+    for (int b0 = q; b0 < nb; b0 += 16 * Q) {
+        double tmp[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int b = b0 + j * Q;
+            tmp[j] = b < nb ? partials[(size_t)b * kNumPartials + v] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s += tmp[j];
+    }
     red[q][v] = s;
     __syncthreads();
-    if (threadIdx.x < kNumPartials) {
+    if (cfg.mode == 0 && sst.done) return;      // uniform: the level already finished
+    if (tid < kNumPartials) {
         double t = 0.0;
-        for (int k = 0; k < Q; ++k) t += red[k][threadIdx.x];
-        st->tot[threadIdx.x] = t;
-        red[0][threadIdx.x] = t;
+#pragma unroll
+        for (int k = 0; k < Q; ++k) t += red[k][tid];
+        sst.tot[tid] = t;
     }
     __syncthreads();
-    if (threadIdx.x != 0) return;
-    st->n_evals += 1;
-    const double* tot = red[0];
-    // normal equations at the evaluated pose (float like the reference's `hessian` / `gradient`)
-    float Hc[36], gc[6];
-    {
+    GNState* st = &sst;
+    const double* tot = sst.tot;
+    if (tid == 0) {
+        st->n_evals += 1;
+        // normal equations at the evaluated pose (float like the reference's `hessian` / `gradient`)
         int k = 0;
+#pragma unroll
         for (int a = 0; a < 6; ++a)
-            for (int b = a; b < 6; ++b, ++k) Hc[b * 6 + a] = Hc[a * 6 + b] = (float)tot[P_H + k];
-        for (int a = 0; a < 6; ++a) gc[a] = (float)tot[P_G + a];
-    }
-    const double err2 = tot[P_E2P] + tot[P_E2D];
-    const double nvalid = tot[P_NP] + tot[P_ND];
-    const double new_error = sqrt(err2 / nvalid);   // RPI.h:2738
-    st->new_error = new_error;
-    if (cfg.mode == 1) {
-        for (int k = 0; k < 36; ++k) st->H[k] = Hc[k];
-        for (int k = 0; k < 6; ++k) st->g[k] = gc[k];
-        return;
-    }
-    bool take = false;
-    if (st->first) {
-        st->first = 0;
-        if (nvalid == 0.0) {
-            st->status = 2;
-            st->done = 1;
-            return;
+#pragma unroll
+            for (int b = a; b < 6; ++b, ++k) shH[b * 6 + a] = shH[a * 6 + b] = (float)tot[P_H + k];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) shg[a] = (float)tot[P_G + a];
+        const double err2 = tot[P_E2P] + tot[P_E2D];
+        const double nvalid = tot[P_NP] + tot[P_ND];
+        const double new_error = sqrt(err2 / nvalid);   // RPI.h:2738
+        st->new_error = new_error;
+        int go = 0;
+        if (cfg.mode == 1) {
+            for (int i = 0; i < 36; ++i) st->H[i] = shH[i];
+            for (int i = 0; i < 6; ++i) st->g[i] = shg[i];
+        } else {
+            bool take = false, stop = false;
+            if (st->first) {
+                st->first = 0;
+                if (nvalid == 0.0) {
+                    st->status = 2;
+                    st->done = 1;
+                    stop = true;
+                } else {
+                    st->error = new_error;           // RPI.h:4599
+                    st->diff_error = new_error;      // RPI.h:4605
+                    take = true;                     // cand == pose
+                }
+            } else {
+                const double diff = st->error - new_error;   // RPI.h:4713
+                st->diff_error = diff;
+                if (cfg.forced || diff > cfg.tol_residual) {  // RPI.h:4715-4722
+                    st->lambda = st->lambda / 5.0;
+                    for (int i = 0; i < 16; ++i) st->pose[i] = st->cand[i];
+                    st->error = new_error;
+                    st->it += 1;
+                    take = true;
+                }
+            }
+            if (take) {
+                for (int i = 0; i < 36; ++i) st->H[i] = shH[i];
+                for (int i = 0; i < 6; ++i) st->g[i] = shg[i];
+                st->acc_e2p = tot[P_E2P];
+                st->acc_e2d = tot[P_E2D];
+                st->acc_np = (long long)tot[P_NP];
+                st->acc_nd = (long long)tot[P_ND];
+                st->acc_nvis = (long long)tot[P_NVIS];
+            }
+            if (!stop) {
+                // while(it < maxIters && update_pose.norm() > tol_update && diff_error > tol_residual)   RPI.h:4611
+                float un = 0.f;
+                for (int i = 0; i < 6; ++i) un += st->update[i] * st->update[i];
+                un = sqrtf(un);
+                go = cfg.forced || (st->it < cfg.max_iters && (double)un > cfg.tol_update && st->diff_error > cfg.tol_residual);
+                if (!go) st->done = 1;
+            }
+            if (go) {
+                // a step is only ever computed right after its pose was taken, so st->H/g == shH/shg here;
+                // record them as "used" (what the reference's `hessian` / `SSO` members hold afterwards)
+                for (int i = 0; i < 36; ++i) st->Hused[i] = shH[i];
+                for (int i = 0; i < 6; ++i) st->gused[i] = shg[i];
+                st->used_nvis = st->acc_nvis;
+                st->used_npix = cfg.n_pixels;
+                const float lam = (float)st->lambda;
+                for (int i = 0; i < 36; ++i) shM[i] = shH[i];
+                for (int i = 0; i < 6; ++i) shM[i * 6 + i] = shH[i * 6 + i] + lam * shH[i * 6 + i];   // RPI.h:4682
+            }
         }
-        st->error = new_error;           // RPI.h:4599
-        st->diff_error = new_error;      // RPI.h:4605
-        take = true;                     // cand == pose
-    } else {
-        const double diff = st->error - new_error;   // RPI.h:4713
-        st->diff_error = diff;
-        if (cfg.forced || diff > cfg.tol_residual) {  // RPI.h:4715-4722
-            st->lambda = st->lambda / 5.0;
-            for (int k = 0; k < 16; ++k) st->pose[k] = st->cand[k];
-            st->error = new_error;
-            st->it += 1;
-            take = true;
+        shGo = go;
+    }
+    __syncthreads();
+    if (shGo) {
+        if (wave == 0) {
+            float x[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const bool ok = lu_inverse6_lanes(shH, lane, x);     // hessian.inverse()   RPI.h:4693
+            if (lane >= 6 && lane < 12) {
+#pragma unroll
+                for (int r = 0; r < 6; ++r) shInv[(lane - 6) * 6 + r] = x[r];
+            }
+            if (lane == 0) shLuOk = ok ? 1 : 0;
+        } else if (wave == 1) {
+            const int rk = qr_rank6_lanes(shM, lane);             // (H + lambda diag H).rank()   RPI.h:4682
+            if (lane == 0) shRank = rk;
         }
+        __syncthreads();
+        const bool ill = (shRank != 6) || !shLuOk;
+        if (tid < 6 && !ill) {    // update_pose = (-H^-1) * g, row tid, summed in column order
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) acc += (-shInv[c * 6 + tid]) * shg[c];
+            shUpd[tid] = acc;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            if (ill) {
+                st->status = 1;      // "The problem is ILL-POSED": relPose = pose_estim, return   RPI.h:4684-4689
+                st->done = 1;
+            } else {
+                double ud[6], E[16];
+                for (int i = 0; i < 6; ++i) ud[i] = (double)shUpd[i];
+                gn::se3_pseudo_exp(ud, E);       // CPose3D::exp(update, true)   RPI.h:4697
+                for (int i = 0; i < 16; ++i) shE[i] = (float)E[i];
+                for (int i = 0; i < 6; ++i) st->update[i] = shUpd[i];
+            }
+        }
+        __syncthreads();
+        if (tid < 16 && !ill) {   // pose_estim_temp = exp(...).cast<float>() * pose_estim
+            const int c = tid >> 2, r = tid & 3;
+            const float* P = sst.pose;
+            sst.cand[tid] = ((shE[0 * 4 + r] * P[c * 4 + 0] + shE[1 * 4 + r] * P[c * 4 + 1]) + shE[2 * 4 + r] * P[c * 4 + 2]) +
+                            shE[3 * 4 + r] * P[c * 4 + 3];
+        }
+        __syncthreads();
     }
-    if (take) {
-        for (int k = 0; k < 36; ++k) st->H[k] = Hc[k];
-        for (int k = 0; k < 6; ++k) st->g[k] = gc[k];
-        st->acc_e2p = tot[P_E2P];
-        st->acc_e2d = tot[P_E2D];
-        st->acc_np = (long long)tot[P_NP];
-        st->acc_nd = (long long)tot[P_ND];
-        st->acc_nvis = (long long)tot[P_NVIS];
-    }
-    // while(it < maxIters && update_pose.norm() > tol_update && diff_error > tol_residual)   RPI.h:4611
-    float un = 0.f;
-    for (int k = 0; k < 6; ++k) un += st->update[k] * st->update[k];
-    un = sqrtf(un);
-    const bool go = cfg.forced || (st->it < cfg.max_iters && (double)un > cfg.tol_update && st->diff_error > cfg.tol_residual);
-    if (!go) {
-        st->done = 1;
-        return;
-    }
-    // calcHessGrad_sphere(pose_estim) is what st->H/g hold; record them as "used" (reference `hessian`, `SSO`)
-    for (int k = 0; k < 36; ++k) st->Hused[k] = st->H[k];
-    for (int k = 0; k < 6; ++k) st->gused[k] = st->g[k];
-    st->used_nvis = st->acc_nvis;
-    st->used_npix = cfg.n_pixels;
-    float upd[6], cand[16];
-    if (gn::step(st->H, st->g, (float)st->lambda, st->pose, cand, upd) != 0) {   // RPI.h:4682-4697
-        st->status = 1;
-        st->done = 1;
-        return;
-    }
-    for (int k = 0; k < 6; ++k) st->update[k] = upd[k];
-    for (int k = 0; k < 16; ++k) st->cand[k] = cand[k];
+    if (tid < kStateWords) reinterpret_cast<int*>(st_g)[tid] = reinterpret_cast<const int*>(&sst)[tid];
 }
 
 // Standalone GN step for tests: one thread.
@@ -540,19 +796,25 @@ __global__ void k_warp_indices(LevelDev lv, Pose16 pose, int32_t* __restrict__ o
     out[2 * i + 1] = c;
 }
 
-// Self-test of sqrt_rn / rcp_rn against the compiler's IEEE sqrtf and 1.f/x over a bit-pattern range.
+// Self-test of sqrt_rn / rcp_rn against the compiler's IEEE sqrtf and 1.f/x, and of round_index against
+// floor((double)x + 0.5), over a bit-pattern range.
 __global__ void k_selftest_math(unsigned first_bits, unsigned count, unsigned long long* __restrict__ mismatches) {
     const unsigned stride = gridDim.x * blockDim.x;
-    unsigned bad_s = 0, bad_r = 0;
+    unsigned bad_s = 0, bad_r = 0, bad_i = 0;
     for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += stride) {
         const float x = __builtin_bit_cast(float, first_bits + k);
         const float s0 = sqrtf(x), s1 = sqrt_rn(x);
         const float r0 = 1.f / x, r1 = rcp_rn(x);
         bad_s += (__builtin_bit_cast(unsigned, s0) != __builtin_bit_cast(unsigned, s1));
         bad_r += (__builtin_bit_cast(unsigned, r0) != __builtin_bit_cast(unsigned, r1));
+        if (fabsf(x) < 1.0e9f) {
+            bad_i += (round_index(x) != (int)floor((double)x + 0.5));
+            bad_i += (round_index(-x) != (int)floor((double)(-x) + 0.5));
+        }
     }
     if (bad_s) atomicAdd(&mismatches[0], (unsigned long long)bad_s);
     if (bad_r) atomicAdd(&mismatches[1], (unsigned long long)bad_r);
+    if (bad_i) atomicAdd(&mismatches[2], (unsigned long long)bad_i);
 }
 
 // ---------------------------------------------------------------------------------------------------------

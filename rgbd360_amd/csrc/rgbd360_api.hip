@@ -9,6 +9,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -47,6 +48,7 @@ struct rgbd360_ctx {
     uint8_t* d_stage_depth = nullptr;
     size_t stage_rgb_bytes = 0, stage_depth_bytes = 0;
     int poll_chunk = 2;           // {pass, solve} pairs enqueued between two polls of the done flag
+    int max_eval_blocks = 512;    // grid cap of the fused pass (tuning knob: RGBD360_EVAL_BLOCKS)
     std::string err;
 };
 
@@ -119,8 +121,8 @@ int ensure_levels(rgbd360_ctx* ctx, int rows, int cols) {
         HIPC(ctx, hipMemcpy(L.cosT, ct.data(), c * sizeof(float), hipMemcpyHostToDevice));
         HIPC(ctx, hipMemcpy(L.sinP, sp.data(), r * sizeof(float), hipMemcpyHostToDevice));
         HIPC(ctx, hipMemcpy(L.cosP, cp.data(), r * sizeof(float), hipMemcpyHostToDevice));
-        // work split of the fused pass: <= 1024 blocks, contiguous spans that are multiples of 256 pixels
-        int chunk = (L.n + 1023) / 1024;
+        // work split of the fused pass: <= max_eval_blocks blocks, contiguous spans that are multiples of 256 pixels
+        int chunk = (L.n + ctx->max_eval_blocks - 1) / ctx->max_eval_blocks;
         chunk = ((chunk + kEvalThreads - 1) / kEvalThreads) * kEvalThreads;
         L.chunk = chunk;
         L.nblocks = (L.n + chunk - 1) / chunk;
@@ -302,6 +304,14 @@ int rgbd360_create(const rgbd360_params* p, rgbd360_ctx** out) {
     if (hipSetDevice(p->device) != hipSuccess) return -102;
     rgbd360_ctx* ctx = new rgbd360_ctx();
     ctx->p = *p;
+    if (const char* e = getenv("RGBD360_EVAL_BLOCKS")) {
+        const int v = atoi(e);
+        if (v >= 8 && v <= 8192) ctx->max_eval_blocks = v;
+    }
+    if (const char* e = getenv("RGBD360_POLL_CHUNK")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 16) ctx->poll_chunk = v;
+    }
     bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreate(&ctx->ev0) == hipSuccess && hipEventCreate(&ctx->ev1) == hipSuccess &&
               hipMalloc(&ctx->d_state, sizeof(GNState)) == hipSuccess &&
@@ -574,15 +584,32 @@ int rgbd360_time_eval_kernel(rgbd360_ctx* ctx, int level, const float pose[16], 
     return 0;
 }
 
-int rgbd360_selftest_math(rgbd360_ctx* ctx, uint32_t first_bits, uint32_t count, unsigned long long mismatches[2]) {
+int rgbd360_time_solve_kernel(rgbd360_ctx* ctx, int level, int mode, int reps, float* avg_us) {
+    int rc = check_args(ctx, level, 0);
+    if (rc) return rc;
+    if (reps < 1 || !avg_us) return fail(ctx, -1, "bad arguments");
+    hipSetDevice(ctx->p.device);
+    launch_solve(ctx, level, mode, 1);   // warm-up (partials of the last pass)
+    HIPC(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    for (int k = 0; k < reps; ++k) launch_solve(ctx, level, mode, 1);
+    HIPC(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    HIPC(ctx, hipGetLastError());
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0.f;
+    HIPC(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *avg_us = ms * 1000.f / reps;
+    return 0;
+}
+
+int rgbd360_selftest_math(rgbd360_ctx* ctx, uint32_t first_bits, uint32_t count, unsigned long long mismatches[3]) {
     if (!ctx || !mismatches) return -1;
     hipSetDevice(ctx->p.device);
     unsigned long long* d = nullptr;
-    HIPC(ctx, hipMalloc(&d, 2 * sizeof(unsigned long long)));
-    hipError_t e = hipMemsetAsync(d, 0, 2 * sizeof(unsigned long long), ctx->stream);
+    HIPC(ctx, hipMalloc(&d, 3 * sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(d, 0, 3 * sizeof(unsigned long long), ctx->stream);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_selftest_math, dim3(2048), dim3(256), 0, ctx->stream, first_bits, count, d);
-        e = hipMemcpyAsync(mismatches, d, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
+        e = hipMemcpyAsync(mismatches, d, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     hipFree(d);

@@ -253,10 +253,15 @@ class RegisterPhotoICP:
                                                      C.byref(us)))
         return float(us.value)
 
+    def time_solve_kernel(self, level: int, mode: int = 0, reps: int = 20) -> float:
+        us = C.c_float()
+        self._check(self._L.rgbd360_time_solve_kernel(self._ctx(), level, mode, reps, C.byref(us)))
+        return float(us.value)
+
     def selftest_math(self, first_bits: int, count: int):
-        out = np.zeros(2, dtype=np.uint64)
+        out = np.zeros(3, dtype=np.uint64)
         self._check(self._L.rgbd360_selftest_math(self._ctx(), first_bits, count, _ptr(out)))
-        return int(out[0]), int(out[1])
+        return int(out[0]), int(out[1]), int(out[2])
 
     def sync(self):
         self._check(self._L.rgbd360_sync(self._ctx()))

@@ -46,11 +46,12 @@ def _poses(T_gt):
 
 def test_device_sqrt_and_reciprocal_are_correctly_rounded(hip_lib):
     """The warp front end relies on sqrt_rn / rcp_rn being IEEE correctly rounded (that is what makes the CPU oracle's
-    sqrtf and 1.f/x bit-identical).  Exhaustive over every float in [2^-60, 2^60] (1.0e9 values)."""
+    sqrtf and 1.f/x bit-identical), and on v_cvt_rpi_i32_f32 being floor(x + 0.5) with an exact sum.
+    Exhaustive over every float in [2^-60, 2^60] (1.0e9 values; the rounding check covers |x| < 1e9, both signs)."""
     reg = _mk(hip_lib, 3)
     first, last = 0x21800000, 0x5D800000
-    bad_sqrt, bad_rcp = reg.selftest_math(first, last - first)
-    assert bad_sqrt == 0 and bad_rcp == 0, (bad_sqrt, bad_rcp)
+    bad_sqrt, bad_rcp, bad_round = reg.selftest_math(first, last - first)
+    assert bad_sqrt == 0 and bad_rcp == 0 and bad_round == 0, (bad_sqrt, bad_rcp, bad_round)
 
 
 def test_planes_bit_exact(hip_lib, oracle_mod, small_pair):

@@ -19,6 +19,8 @@ for method, bpp in ((0, 28), (2, 40)):
     out = reg.forced_iters(0, np.eye(4), method, 200)
     out = reg.forced_iters(0, np.eye(4), method, 200)
     print("method %d forced: %.2f us/iter" % (method, out["elapsed_ms"]*1e3/200))
+reg.forced_iters(0, np.eye(4), 2, 3)
+print("solve kernel: full %.2f us, reduce-only %.2f us" % (reg.time_solve_kernel(0, 0, 50), reg.time_solve_kernel(0, 1, 50)))
 for lvl in (1, 2, 3):
     us = reg.time_eval_kernel(lvl, pose, 2, True, 50)
     print("level %d eval: %.2f us" % (lvl, us))
