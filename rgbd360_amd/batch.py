@@ -1,0 +1,75 @@
+"""Batches of independent frame-pair alignments sharded over the GPUs of one node.
+
+Unit of work = one frame pair (each alignment is a closed problem).  An odometry sequence of n_pairs pairs
+(pair i = frames i, i+1; OdometryRGBD360.cpp:141-297) is cut into contiguous chunks, one per rank, so that inside
+a chunk frame i+1's pyramids are reused as the next pair's target (`promoteSourceToTarget`); one frame is rendered
+twice at each chunk boundary.  The data path has no collective; the solved 4x4 poses (+ status / iteration counts)
+are exchanged once at the end with an all-gather (RCCL over xGMI on GPUs, gloo in the CPU tests): 16 floats per pair,
+latency-bound, not bandwidth-bound.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def shard_range(n_items: int, rank: int, world: int):
+    """Contiguous, balanced partition: the first (n_items % world) ranks get one extra item."""
+    base, extra = divmod(n_items, world)
+    lo = rank * base + min(rank, extra)
+    hi = lo + base + (1 if rank < extra else 0)
+    return lo, hi
+
+
+def align_sequence(reg, get_frame, lo: int, hi: int, method: int, guess=None):
+    """Aligns pairs lo..hi-1 of a sequence on one context.  get_frame(k) -> (rgb uint8 HxWx3, depth).
+    Returns (poses [n,4,4] float32, status [n] int32, iters [n, n_pyr] int32)."""
+    n = hi - lo
+    poses = np.zeros((n, 4, 4), np.float32)
+    status = np.zeros(n, np.int32)
+    iters = np.zeros((n, reg.nPyrLevels), np.int32)
+    if n == 0:
+        return poses, status, iters
+    rgb, d = get_frame(lo)
+    reg.setTargetFrame(rgb, d)
+    for j in range(n):
+        rgb, d = get_frame(lo + j + 1)
+        reg.setSourceFrame(rgb, d)
+        status[j] = reg.alignFrames360(np.eye(4) if guess is None else guess, method)
+        poses[j] = reg.getOptimalPose()
+        iters[j] = reg.num_iterations
+        if j + 1 < n:
+            reg.promoteSourceToTarget()       # frame lo+j+1 becomes the next pair's target without re-upload
+    return poses, status, iters
+
+
+def gather_poses(local_poses: np.ndarray, n_total: int, dist=None, device=None):
+    """All-gather of the per-rank pose blocks into the full [n_total,4,4] array on every rank."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        assert local_poses.shape[0] == n_total
+        return local_poses.copy()
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    max_chunk = (n_total + world - 1) // world
+    buf = torch.zeros(max_chunk * 16, dtype=torch.float32, device=device)
+    lo, hi = shard_range(n_total, rank, world)
+    assert local_poses.shape[0] == hi - lo
+    if hi > lo:
+        buf[: (hi - lo) * 16] = torch.from_numpy(np.ascontiguousarray(local_poses, np.float32).reshape(-1)).to(buf.device)
+    out = torch.empty(world * max_chunk * 16, dtype=torch.float32, device=device)
+    dist.all_gather_into_tensor(out, buf)
+    out = out.cpu().numpy().reshape(world, max_chunk, 4, 4)
+    full = np.zeros((n_total, 4, 4), np.float32)
+    for r in range(world):
+        a, b = shard_range(n_total, r, world)
+        full[a:b] = out[r, : b - a]
+    return full
+
+
+def compose_trajectory(rel_poses: np.ndarray, first=None) -> np.ndarray:
+    """currentPose *= rel (OdometryRGBD360.cpp:257): serial prefix product on the host, float64."""
+    T = np.eye(4) if first is None else np.asarray(first, np.float64)
+    out = [T.copy()]
+    for P in rel_poses:
+        T = T @ np.asarray(P, np.float64)
+        out.append(T.copy())
+    return np.stack(out)

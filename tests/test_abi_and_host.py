@@ -1,0 +1,104 @@
+"""CPU tests of the boundary: the C-ABI library loads and exports every declared symbol; host-side logic."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    from rgbd360_amd import build
+    path = build.build()          # hipcc cross-compiles for gfx950 without a GPU
+    return C.CDLL(path)
+
+
+def declared_symbols():
+    names = set()
+    for fn in os.listdir(os.path.join(ROOT, "include")):
+        if fn.endswith(".h"):
+            txt = open(os.path.join(ROOT, "include", fn)).read()
+            txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+            names |= set(re.findall(r"\b(rgbd360_[a-z0-9_]+)\s*\(", txt))
+    return sorted(names)
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    from rgbd360_amd import _lib
+    decl = declared_symbols()
+    assert len(decl) >= 20
+    missing = [s for s in decl if not hasattr(built_lib, s)]
+    assert not missing, missing
+    assert sorted(_lib.SYMBOLS) == decl      # the ctypes binding covers the whole header and nothing else
+
+
+def test_no_torch_types_in_the_abi():
+    txt = open(os.path.join(ROOT, "include", "rgbd360_hip.h")).read()
+    assert 'extern "C"' in txt
+    code = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)          # declarations only, comments stripped
+    for banned in ("torch", "at::", "std::", "Tensor", "hipStream_t", "template"):
+        assert banned not in code, banned
+
+
+def test_default_params_match_reference_defaults(built_lib):
+    from rgbd360_amd import _lib
+    L = _lib.load()
+    p = _lib.Params()
+    L.rgbd360_default_params(C.byref(p))
+    # RegisterPhotoICP.h:201-221, 4593-4595
+    assert (p.n_pyr, p.max_iters, p.mask_seams) == (4, 10, 1)
+    assert p.min_depth == np.float32(0.3) and p.max_depth == np.float32(6.0)
+    assert p.sigma_photo == np.float32(6.0 / 255) and p.sigma_depth == np.float32(0.2)
+    assert p.thres_sal_photo == np.float32(0.01) and p.thres_sal_depth == np.float32(0.01)
+    assert p.tol_residual == np.float32(1e-3) and p.tol_update == np.float32(1e-4)
+
+
+def test_product_path_fails_loudly_without_a_gpu(built_lib):
+    """No CPU fallback: on a machine without a HIP device context creation must fail, not degrade."""
+    from rgbd360_amd import _lib
+    from rgbd360_amd.register import RegisterPhotoICP, Rgbd360Error
+    L = _lib.load()
+    if L.rgbd360_device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    reg = RegisterPhotoICP()
+    rgb = np.zeros((32, 64, 3), np.uint8)
+    d = np.zeros((32, 64), np.uint16)
+    with pytest.raises(Rgbd360Error):
+        reg.setTargetFrame(rgb, d)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "rgbd360_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".h", ".hip", ".cpp", ".hpp")):
+                txt = open(os.path.join(dirpath, fn), errors="ignore").read()
+                assert "oracle" not in txt.replace("CPU oracle", "").replace("the oracle", "").replace("oracle's", ""), \
+                    os.path.join(dirpath, fn)
+
+
+def test_host_argument_validation():
+    from rgbd360_amd.register import RegisterPhotoICP, Rgbd360Error
+    reg = RegisterPhotoICP()
+    with pytest.raises(Rgbd360Error):
+        reg.setTargetFrame(np.zeros((8, 8), np.uint8), np.zeros((8, 8), np.uint16))          # not HxWx3
+    with pytest.raises(Rgbd360Error):
+        reg.setTargetFrame(np.zeros((8, 8, 3), np.uint8), np.zeros((8, 8), np.float64))       # bad depth dtype
+    with pytest.raises(Rgbd360Error):
+        reg.setTargetFrame(np.zeros((8, 8, 3), np.uint8), np.zeros((4, 8), np.uint16))        # size mismatch
+    with pytest.raises(Rgbd360Error):
+        reg.setVisualization(True)
+    assert reg.nPyrLevels == 4
+    reg.setNumPyr(5)
+    assert reg.nPyrLevels == 5
+
+
+def test_pose_layout_helpers():
+    from rgbd360_amd.register import pose_from_cm, pose_to_cm
+    T = np.arange(16, dtype=np.float32).reshape(4, 4)
+    cm = pose_to_cm(T)
+    assert cm[12] == T[0, 3] and cm[1] == T[1, 0]       # column-major like Eigen::Matrix4f::data()
+    assert np.array_equal(pose_from_cm(cm), T)

@@ -225,3 +225,29 @@ def test_full_size_2048x1024(hip_lib, oracle_mod, method):
     _, err2, nvalid = ora.error(0, pose_ref, method)
     assert e["n_valid"] == nvalid
     assert abs(e["err2"] - err2) <= ERR2_RTOL * err2
+
+
+def test_sequence_batch_matches_pairwise_alignment(hip_lib, oracle_mod):
+    """BASELINE.json config 4 in miniature: a chunk of an odometry sequence aligned with frame reuse
+    (promoteSourceToTarget) gives the same poses as aligning every pair from scratch, and as the oracle."""
+    from rgbd360_amd.batch import align_sequence, compose_trajectory
+    frames = {k: synth.render(synth.trajectory_pose(k, 7), 256, 128, 7) for k in range(4)}
+    reg = _mk(hip_lib, 3)
+    poses, status, iters = align_sequence(reg, lambda k: frames[k], 0, 3, 2)
+    assert (status == 0).all()
+    for j in range(3):
+        fresh = _mk(hip_lib, 3)
+        fresh.setTargetFrame(*frames[j])
+        fresh.setSourceFrame(*frames[j + 1])
+        assert fresh.alignFrames360(np.eye(4), 2) == 0
+        assert np.array_equal(fresh.getOptimalPose(), poses[j])
+        ora = oracle_mod.Oracle(n_pyr=3, math_mode=1, reduce_mode=1)
+        ora.set_target(*frames[j])
+        ora.set_source(*frames[j + 1])
+        st, pose_ref = ora.align360(np.eye(4), 2)
+        rot, trans = synth.pose_error(poses[j], pose_ref)
+        assert st == 0 and rot <= 1e-6 and trans <= 1e-6
+        T_gt = np.linalg.inv(synth.trajectory_pose(j, 7)) @ synth.trajectory_pose(j + 1, 7)
+        rot, trans = synth.pose_error(poses[j], T_gt)
+        assert rot < 5e-3 and trans < 1e-2, (j, rot, trans)       # 256x128 resolution limit
+    assert compose_trajectory(poses).shape == (4, 4, 4)
