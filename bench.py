@@ -177,18 +177,29 @@ def main():
             rot, trans = synth.pose_error(pose_gpu, pose_cpu)
             result["alignment"]["pose_err_vs_cpu_ref"] = {"rot_rad": rot, "trans_m": trans}
             result["alignment"]["cpu_iters_per_level"] = list(ora.result.iters)[:4]
-            ora.forced_iters(0, np.eye(4), method, 2)       # warm
-            t0 = time.perf_counter()
-            ora.forced_iters(0, np.eye(4), method, 4)
-            per_it = (time.perf_counter() - t0) / 4
-            n_cpu = int(max(8, min(2000, args.cpu_seconds / max(per_it, 1e-6))))
+            # thread count: the reference uses every OpenMP thread; on many-core hosts that is not the fastest
+            # setting for this memory-bound loop, so the baseline is quoted at the best of a short sweep
+            max_thr = O.num_threads()
+            cands = sorted({t for t in (8, 16, 32, 64, 128, max_thr) if t <= max_thr})
+            best_thr, best_per_it = max_thr, None
+            for thr in cands:
+                O.set_num_threads(thr)
+                ora.forced_iters(0, np.eye(4), method, 1)       # warm
+                t0 = time.perf_counter()
+                ora.forced_iters(0, np.eye(4), method, 3)
+                per_it = (time.perf_counter() - t0) / 3
+                if best_per_it is None or per_it < best_per_it:
+                    best_thr, best_per_it = thr, per_it
+            O.set_num_threads(best_thr)
+            n_cpu = int(max(8, min(5000, args.cpu_seconds / max(best_per_it, 1e-6))))
             t0 = time.perf_counter()
             ora.forced_iters(0, np.eye(4), method, n_cpu)
             dt = time.perf_counter() - t0
             result["cpu_baseline"] = {
-                "value": n_cpu / dt, "unit": "GN iterations/s", "cores": O.num_threads(), "kind": "port",
+                "value": n_cpu / dt, "unit": "GN iterations/s", "cores": best_thr, "kind": "port",
                 "sample": "%d level-0 forced GN iterations (H,g pass + solve + error pass, reference structure with its "
-                          "per-call Jacobian arrays) on the same %dx%d %s pair, %.1f s" % (n_cpu, W, H, METHOD_NAMES[method], dt),
+                          "per-call Jacobian arrays) on the same %dx%d %s pair, %.1f s, best of OpenMP thread counts %s"
+                          % (n_cpu, W, H, METHOD_NAMES[method], dt, cands),
                 "host_cpus": os.cpu_count(),
             }
         print(json.dumps(result), flush=True)

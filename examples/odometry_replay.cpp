@@ -1,0 +1,74 @@
+// odometry_replay.cpp -- replays the call sequence of Registration/OdometryRGBD360.cpp:141-297 of the reference
+// (per frame: set target / set source / alignFrames360(PHOTO_DEPTH) / accumulate currentPose) through the C++
+// adapter, on frames read from raw files written by tools/dump_sequence.py:
+//     frame_%03d.rgb  (H*W*3 uint8)   frame_%03d.depth (H*W uint16 mm)
+// Build:  g++ -std=c++17 -O2 -Iinclude examples/odometry_replay.cpp -Lrgbd360_amd/lib -lrgbd360_hip
+//             -Wl,-rpath,$PWD/rgbd360_amd/lib -o odometry_replay
+// Usage:  odometry_replay <dir> <n_frames> <width> <height>
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "rgbd360/RegisterPhotoICP.hpp"
+
+struct Frame {   // the two members of Frame360 the dense path reads (Frame360.h:104-111)
+    std::vector<uint8_t> rgb;
+    std::vector<uint16_t> depth;
+    int rows, cols;
+    rgbd360::ImageView sphereRGB, sphereDepth;
+    bool load(const std::string& dir, int k, int w, int h) {
+        rows = h; cols = w;
+        char name[512];
+        rgb.resize((size_t)w * h * 3);
+        depth.resize((size_t)w * h);
+        snprintf(name, sizeof(name), "%s/frame_%03d.rgb", dir.c_str(), k);
+        std::ifstream f1(name, std::ios::binary);
+        if (!f1.read((char*)rgb.data(), rgb.size())) return false;
+        snprintf(name, sizeof(name), "%s/frame_%03d.depth", dir.c_str(), k);
+        std::ifstream f2(name, std::ios::binary);
+        if (!f2.read((char*)depth.data(), depth.size() * 2)) return false;
+        sphereRGB = {rgb.data(), h, w, (size_t)w * 3, rgbd360::ImageView::U8C3};
+        sphereDepth = {depth.data(), h, w, (size_t)w * 2, rgbd360::ImageView::U16C1};
+        return true;
+    }
+};
+
+static rgbd360::Mat4f mul(const rgbd360::Mat4f& A, const rgbd360::Mat4f& B) {
+    rgbd360::Mat4f C{};
+    for (int c = 0; c < 4; ++c)
+        for (int r = 0; r < 4; ++r) {
+            float s = 0;
+            for (int k = 0; k < 4; ++k) s += A(r, k) * B(k, c);
+            C(r, c) = s;
+        }
+    return C;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 5) {
+        fprintf(stderr, "usage: %s <dir> <n_frames> <width> <height>\n", argv[0]);
+        return 2;
+    }
+    const std::string dir = argv[1];
+    const int n = atoi(argv[2]), w = atoi(argv[3]), h = atoi(argv[4]);
+    rgbd360::RegisterPhotoICP align360;      // OdometryRGBD360.cpp:91-95
+    align360.setNumPyr(4);
+    align360.useSaliency(false);
+    rgbd360::Mat4f currentPose = rgbd360::Mat4f::Identity();
+    Frame frame1, frame2;
+    if (!frame1.load(dir, 0, w, h)) return 3;
+    for (int k = 1; k < n; ++k) {
+        if (!frame2.load(dir, k, w, h)) return 3;
+        align360.setTargetFrame(frame1.sphereRGB, frame1.sphereDepth);                          // :189
+        align360.setSourceFrame(frame2.sphereRGB, frame2.sphereDepth);                          // :190
+        align360.alignFrames360(rgbd360::Mat4f::Identity(), rgbd360::RegisterPhotoICP::PHOTO_DEPTH);   // :192
+        const rgbd360::Mat4f rel = align360.getOptimalPose();                                   // :193
+        currentPose = mul(currentPose, rel);                                                    // :257
+        printf("pair %d status %d sso %.4f rel_t %.5f %.5f %.5f pose_t %.5f %.5f %.5f\n", k - 1, align360.status(), align360.SSO,
+               rel(0, 3), rel(1, 3), rel(2, 3), currentPose(0, 3), currentPose(1, 3), currentPose(2, 3));
+        std::swap(frame1, frame2);
+    }
+    return 0;
+}

@@ -1,0 +1,176 @@
+// RegisterPhotoICP.hpp -- C++ adapter over the C ABI (include/rgbd360_hip.h) with the public surface of the
+// reference's RegisterPhotoICP for the spherical path (include/RegisterPhotoICP.h "RPI.h" of EduFdez/rgbd360):
+// same method names, argument meaning and error behaviour, so call sites such as OdometryRGBD360.cpp:189-193,
+// OdometryKeyFrame360.cpp:244-253, LoopClosure360.h:306-321 compile against it unchanged apart from the include.
+//
+// The adapter is header-only and depends on nothing but the C ABI.  When Eigen / OpenCV headers are present
+// (they are not in the build container) the overloads taking Eigen::Matrix4f / cv::Mat are enabled as well;
+// otherwise the POD Mat4f / ImageView types below are used.
+#pragma once
+
+#include <array>
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../rgbd360_hip.h"
+
+#if defined(__has_include)
+#if __has_include(<Eigen/Core>)
+#include <Eigen/Core>
+#define RGBD360_HAVE_EIGEN 1
+#endif
+#if __has_include(<opencv2/core/core.hpp>)
+#include <opencv2/core/core.hpp>
+#define RGBD360_HAVE_OPENCV 1
+#endif
+#endif
+
+namespace rgbd360 {
+
+// Column-major 4x4 / 6x6 PODs: the memory layout of Eigen::Matrix4f and Eigen::Matrix<float,6,6>.
+struct Mat4f {
+    float m[16];
+    static Mat4f Identity() {
+        Mat4f I{};
+        I.m[0] = I.m[5] = I.m[10] = I.m[15] = 1.f;
+        return I;
+    }
+    float& operator()(int r, int c) { return m[c * 4 + r]; }
+    float operator()(int r, int c) const { return m[c * 4 + r]; }
+};
+struct Mat6f {
+    float m[36];
+    float operator()(int r, int c) const { return m[c * 6 + r]; }
+};
+
+// What the path needs from a cv::Mat: data pointer, size, row stride, element type.
+struct ImageView {
+    const void* data = nullptr;
+    int rows = 0, cols = 0;
+    size_t step = 0;
+    enum Type { U8C3, U16C1, F32C1 } type = U8C3;
+};
+
+class RegisterPhotoICP {
+   public:
+    enum costFuncType { PHOTO_CONSISTENCY, DEPTH_CONSISTENCY, PHOTO_DEPTH };   // RPI.h:194
+
+    // public fields of the reference (RPI.h:177-189)
+    float SSO = 0.f;
+    float avResidual = 0.f;
+    double avPhotoResidual = 0.0, avDepthResidual = 0.0;
+    int nPyrLevels = 4;
+
+    RegisterPhotoICP() { rgbd360_default_params(&p_); }            // RPI.h:201-221
+    ~RegisterPhotoICP() { reset(); }
+    RegisterPhotoICP(const RegisterPhotoICP&) = delete;
+    RegisterPhotoICP& operator=(const RegisterPhotoICP&) = delete;
+
+    // RPI.h:224-269.  Like the reference these are meant to be called before the frames are set.
+    void setNumPyr(int Npyr) { nPyrLevels = p_.n_pyr = Npyr; reset(); }
+    void setMinDepth(float minD) { p_.min_depth = minD; reset(); }
+    void setMaxDepth(float maxD) { p_.max_depth = maxD; reset(); }
+    void setGrayVariance(float stdDev) { p_.sigma_photo = stdDev; reset(); }     // sets the std-dev (RPI.h:242-245)
+    void setDepthVariance(float stdDev) { p_.sigma_depth = stdDev; reset(); }
+    void useSaliency(bool) {}             // only feeds code the spherical passes have commented out (RPI.h:2568-2642)
+    void setVisualization(bool viz) {
+        if (viz) throw std::runtime_error("rgbd360: visualisation is not part of the MI355X path");
+    }
+    void setDevice(int device) { p_.device = device; reset(); }
+
+    // RPI.h:498-516 / 480-494
+    void setTargetFrame(const ImageView& rgb, const ImageView& depth) { set(true, rgb, depth); }
+    void setSourceFrame(const ImageView& rgb, const ImageView& depth) { set(false, rgb, depth); }
+
+    // RPI.h:4519-4784.  void like the reference; `status()` tells ill-posed (1) / no valid pixels (2).
+    void alignFrames360(const Mat4f& pose_guess = Mat4f::Identity(), costFuncType method = PHOTO_CONSISTENCY,
+                        int occlusion = 0) {
+        rgbd360_result r;
+        const int rc = rgbd360_align360(ctx(), pose_guess.m, (int)method, occlusion, relPose_.m, &r);
+        if (rc < 0) throw std::runtime_error(std::string("rgbd360_align360: ") + rgbd360_last_error(ctx_));
+        status_ = rc;
+        std::memcpy(hessian_.m, r.hessian, sizeof(hessian_.m));
+        std::memcpy(gradient_.data(), r.gradient, sizeof(float) * 6);
+        SSO = r.sso;
+        avResidual = rc == RGBD360_ILL_POSED ? 0.f : (float)r.err_final;      // RPI.h:4688
+        avPhotoResidual = r.rms_photo;
+        avDepthResidual = r.rms_depth;
+        num_iterations_.assign(r.iters, r.iters + p_.n_pyr);
+    }
+
+    Mat4f getOptimalPose() const { return relPose_; }          // RPI.h:273
+    Mat6f getHessian() const { return hessian_; }              // RPI.h:279
+    std::array<float, 6> getGradient() const { return gradient_; }
+    const std::vector<int>& numIterations() const { return num_iterations_; }
+    int status() const { return status_; }
+
+#ifdef RGBD360_HAVE_OPENCV
+    void setTargetFrame(cv::Mat& imgRGB, cv::Mat& imgDepth) { set(true, view(imgRGB), view(imgDepth)); }
+    void setSourceFrame(cv::Mat& imgRGB, cv::Mat& imgDepth) { set(false, view(imgRGB), view(imgDepth)); }
+    static ImageView view(const cv::Mat& m) {
+        ImageView v;
+        v.data = m.data; v.rows = m.rows; v.cols = m.cols; v.step = m.step;
+        v.type = m.type() == CV_8UC3 ? ImageView::U8C3 : (m.type() == CV_16UC1 ? ImageView::U16C1 : ImageView::F32C1);
+        return v;
+    }
+#endif
+#ifdef RGBD360_HAVE_EIGEN
+    void alignFrames360(const Eigen::Matrix4f pose_guess, costFuncType method = PHOTO_CONSISTENCY, int occlusion = 0) {
+        Mat4f g;
+        std::memcpy(g.m, pose_guess.data(), sizeof(g.m));
+        alignFrames360(g, method, occlusion);
+    }
+    Eigen::Matrix4f getOptimalPoseEigen() const { return Eigen::Map<const Eigen::Matrix4f>(relPose_.m); }
+    Eigen::Matrix<float, 6, 6> getHessianEigen() const { return Eigen::Map<const Eigen::Matrix<float, 6, 6>>(hessian_.m); }
+#endif
+
+   private:
+    rgbd360_params p_;
+    rgbd360_ctx* ctx_ = nullptr;
+    Mat4f relPose_ = Mat4f::Identity();
+    Mat6f hessian_{};
+    std::array<float, 6> gradient_{};
+    std::vector<int> num_iterations_;
+    int status_ = 0;
+
+    void reset() {
+        if (ctx_) rgbd360_destroy(ctx_);
+        ctx_ = nullptr;
+    }
+    rgbd360_ctx* ctx() {
+        if (!ctx_) {
+            const int rc = rgbd360_create(&p_, &ctx_);
+            if (rc != 0) throw std::runtime_error("rgbd360_create failed (" + std::to_string(rc) + "): no usable HIP device; there is no CPU fallback");
+        }
+        return ctx_;
+    }
+    void set(bool target, const ImageView& rgb, const ImageView& depth) {
+        if (rgb.type != ImageView::U8C3) throw std::invalid_argument("rgbd360: imgRGB must be CV_8UC3");
+        if (depth.type == ImageView::U8C3) throw std::invalid_argument("rgbd360: imgDepth must be CV_16UC1 (mm) or CV_32FC1 (m)");
+        if (rgb.rows != depth.rows || rgb.cols != depth.cols) throw std::invalid_argument("rgbd360: rgb / depth size mismatch");
+        const int dt = depth.type == ImageView::U16C1 ? 0 : 1;
+        const int rc = (target ? rgbd360_set_target : rgbd360_set_source)(ctx(), (const uint8_t*)rgb.data, rgb.step, depth.data,
+                                                                         depth.step, dt, rgb.rows, rgb.cols);
+        if (rc != 0) throw std::runtime_error(std::string("rgbd360_set_frame: ") + rgbd360_last_error(ctx_));
+    }
+};
+
+// The literal north-star shape `bool Register(Frame360&, Frame360&, Eigen::Matrix4f&)`: FrameLike is anything with
+// public `sphereRGB` / `sphereDepth` image members (Frame360.h:104-111); `pose` carries the initial guess in and the
+// solved relative pose out.
+template <class FrameLike, class ToView>
+bool Register(FrameLike& trg, FrameLike& src, Mat4f& pose, ToView to_view,
+              RegisterPhotoICP::costFuncType method = RegisterPhotoICP::PHOTO_DEPTH, RegisterPhotoICP* reg = nullptr) {
+    RegisterPhotoICP local;
+    RegisterPhotoICP& r = reg ? *reg : local;
+    r.setTargetFrame(to_view(trg.sphereRGB), to_view(trg.sphereDepth));
+    r.setSourceFrame(to_view(src.sphereRGB), to_view(src.sphereDepth));
+    r.alignFrames360(pose, method);
+    pose = r.getOptimalPose();
+    return r.status() == 0;
+}
+
+}  // namespace rgbd360

@@ -226,3 +226,7 @@ def gn_step(H, g, lam, pose):
 
 def num_threads() -> int:
     return int(lib().oracle_num_threads())
+
+
+def set_num_threads(n: int) -> None:
+    lib().oracle_set_num_threads(int(n))

@@ -1007,6 +1007,13 @@ float oracle_weight_huber(float e, float k) { return weightHuber(e, k); }
 int oracle_rank6(const float* M) { return rank6_colpiv_qr(M); }
 int oracle_inverse6(const float* M, float* inv) { return inverse6_partial_piv_lu(M, inv) ? 0 : 1; }
 void oracle_se3_pseudo_exp(const double* v, double* M) { se3_pseudo_exp(v, M); }
+void oracle_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
 int oracle_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): bench + rocprofv3 kernel trace of the same command + PMC passes.
+# usage: bash tools/collect_profiles.sh <tag>
+TAG=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+cd $R
+python bench.py > $OUT/bench.json 2> $OUT/bench.err
+cd /tmp; export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline > $OUT/trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/tools/prof_eval.py 2048 1024 10 > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/tools/prof_eval.py 2048 1024 10 > $OUT/pmc_write.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_sq -- python3 $R/tools/prof_eval.py 2048 1024 10 > $OUT/pmc_sq.log 2>&1
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_tcc -- python3 $R/tools/prof_eval.py 2048 1024 10 > $OUT/pmc_tcc.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_4k -- python3 $R/tools/prof_eval.py 4096 2048 10 > $OUT/pmc_fetch_4k.log 2>&1
+cd $R
+cat $OUT/bench.json
+python3 tools/trace_gaps.py $OUT/trace
+for d in pmc_fetch pmc_write pmc_sq pmc_tcc pmc_fetch_4k; do echo "== $d"; cat $OUT/$d.log | grep "avg us"; python3 tools/pmc_summary.py $OUT/$d; done
