@@ -164,6 +164,45 @@ int   rgbd360_device_count(void);
 int rgbd360_sphere_cloud(rgbd360_ctx* ctx, const void* depth, size_t depth_step, int depth_type, int rows, int cols,
                          int convention, float* host_out_xyz);
 
+/* Normal map of an organised cloud (rows*cols x 3 float32, NaN = invalid): pcl::IntegralImageNormalEstimation with
+ * AVERAGE_3D_GRADIENT, setMaxDepthChangeFactor(max_depth_change_factor), setNormalSmoothingSize(normal_smoothing_size),
+ * setDepthDependentSmoothing(true), as configured at Frame360.h:949-957 (0.02, 8) and Frame360_stereo.h:854-862
+ * (0.05, 8).  depth_mode 0 uses the z coordinate as "depth" like PCL, 1 the range |p| (full spheres).
+ * normals_out: rows*cols x 3, NaN where PCL leaves the normal undefined; normals point towards the origin. */
+int rgbd360_normals(rgbd360_ctx* ctx, const float* xyz, int rows, int cols, float max_depth_change_factor,
+                    float normal_smoothing_size, int depth_mode, float* normals_out);
+/* The chamfer (1 / 1.4) distance-to-depth-discontinuity map that drives the smoothing window (diagnostics). */
+int rgbd360_distance_map(rgbd360_ctx* ctx, const float* xyz, int rows, int cols, float max_depth_change_factor,
+                         int depth_mode, float* dist_out);
+
+/* One planar region: n . x + d = 0 with n towards the origin, curvature = lambda_min / trace(cov). */
+typedef struct {
+    float centroid[3];
+    float normal[3];
+    float d;
+    float curvature;
+    int   count;        /* inliers */
+    int   root;         /* smallest pixel index of the region = its label */
+} rgbd360_plane;
+
+/* Planar regions of an organised cloud with normals: pcl::OrganizedMultiPlaneSegmentation::segment as configured at
+ * Frame360.h:958-977 (min_inliers 80, angular 0.0398 rad, distance 0.02) / Frame360_stereo.h:863-882 (40, 0.05, 0.05):
+ * PlaneCoefficientComparator (depth-dependent distance threshold) + organised connected components + per-region
+ * centroid / covariance / smallest eigenvector / curvature (the values Frame360.h:984-996 copies into
+ * mrpt::pbmap::Plane).  labels_out (may be NULL): per pixel the region's root pixel index, -1 for non-finite points.
+ * Planes are returned in PCL's order (by first pixel), at most max_planes. */
+int rgbd360_plane_fit(rgbd360_ctx* ctx, const float* xyz, const float* normals, int rows, int cols, int min_inliers,
+                      float angular_threshold, float distance_threshold, float max_curvature, int depth_mode,
+                      int32_t* labels_out, rgbd360_plane* planes_out, int max_planes, int* n_planes_out);
+
+/* Range panorama -> sphere cloud -> normals -> planar regions in one call (cloud and normals stay on the device
+ * between the stages); xyz_out / normals_out / labels_out may be NULL. */
+int rgbd360_frame_planes(rgbd360_ctx* ctx, const void* depth, size_t depth_step, int depth_type, int rows, int cols,
+                         int convention, float max_depth_change_factor, float normal_smoothing_size, int min_inliers,
+                         float angular_threshold, float distance_threshold, float max_curvature, int depth_mode,
+                         float* xyz_out, float* normals_out, int32_t* labels_out, rgbd360_plane* planes_out, int max_planes,
+                         int* n_planes_out);
+
 #ifdef __cplusplus
 }
 #endif

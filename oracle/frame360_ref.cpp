@@ -1,0 +1,285 @@
+// =====================================================================================
+//  oracle/frame360_ref.cpp  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+//
+//  CPU restatement of the two PCL algorithms Frame360 runs on its organised cloud before handing planes to
+//  mrpt::pbmap:
+//    Frame360.h:949-977, Frame360_stereo.h:854-882
+//      pcl::IntegralImageNormalEstimation  AVERAGE_3D_GRADIENT, maxDepthChangeFactor 0.02 / 0.05,
+//                                          normalSmoothingSize 8, depth-dependent smoothing
+//      pcl::OrganizedMultiPlaneSegmentation minInliers 80 / 40, angular 0.0398 / 0.05 rad, distance 0.02 / 0.05
+//
+//  PARITY UNPINNED / THIRD-PARTY: PCL (>= 1.7, version not pinned by the reference's CMakeLists.txt:19) is not in the
+//  reference tree and not installed; the algorithms are restated from PCL 1.7's published sources
+//  (features/integral_image_normal.hpp computeFeature / computeFeatureFull / computePointNormal,
+//   segmentation/organized_multi_plane_segmentation.hpp segment, plane_coefficient_comparator.h compare,
+//   organized_connected_component_segmentation.hpp).  Deliberate differences, shared with the HIP path:
+//    * window sums are taken directly in double (PCL: double integral images) -- same values up to rounding;
+//    * region moments are accumulated in double (PCL 1.7 uses float accumulators);
+//    * segmentAndRefine's boundary refinement step and everything mrpt::pbmap does afterwards (hulls, areas,
+//      colours, merging; Frame360.h:984-1075) are not part of this stage;
+//    * depth_mode 1 replaces PCL's use of the z coordinate as "depth" by the range |p|, which is what makes the
+//      depth-dependent thresholds meaningful on a full sphere (depth_mode 0 is PCL-faithful);
+//    * the chamfer distance map ignores PCL's row-wrap reads in the first/last column (those columns lie in the
+//      border band that is set to NaN anyway).
+// =====================================================================================
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <numeric>
+#include <vector>
+
+namespace {
+
+inline bool finite3(const float* p) { return std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]); }
+inline float depth_of(const float* p, int depth_mode) {
+    return depth_mode == 0 ? p[2] : sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+}
+
+// integral_image_normal.hpp computeFeature: depth-change map + two-pass chamfer (1 / 1.4) distance map
+void distance_map(const float* xyz, int rows, int cols, float max_depth_change_factor, int depth_mode, std::vector<float>& dist) {
+    const size_t n = (size_t)rows * cols;
+    std::vector<unsigned char> change(n, 255);
+    for (int ri = 0; ri < rows - 1; ++ri)
+        for (int ci = 0; ci < cols - 1; ++ci) {
+            const size_t index = (size_t)ri * cols + ci;
+            const float depth = depth_of(xyz + 3 * index, depth_mode);
+            const float depthR = depth_of(xyz + 3 * (index + 1), depth_mode);
+            const float depthD = depth_of(xyz + 3 * (index + cols), depth_mode);
+            const float ddc = max_depth_change_factor * (fabsf(depth) + 1.0f) * 2.0f;
+            if (fabs(depth - depthR) > ddc || !std::isfinite(depth) || !std::isfinite(depthR)) {
+                change[index] = 0;
+                change[index + 1] = 0;
+            }
+            if (fabs(depth - depthD) > ddc || !std::isfinite(depth) || !std::isfinite(depthD)) {
+                change[index] = 0;
+                change[index + cols] = 0;
+            }
+        }
+    dist.resize(n);
+    for (size_t i = 0; i < n; ++i) dist[i] = change[i] == 0 ? 0.0f : (float)(cols + rows);
+    for (int ri = 1; ri < rows; ++ri)
+        for (int ci = 1; ci < cols - 1; ++ci) {
+            float* cur = &dist[(size_t)ri * cols];
+            const float* prev = cur - cols;
+            const float upLeft = prev[ci - 1] + 1.4f, up = prev[ci] + 1.0f, upRight = prev[ci + 1] + 1.4f, left = cur[ci - 1] + 1.0f;
+            const float minValue = std::min(std::min(upLeft, up), std::min(left, upRight));
+            if (minValue < cur[ci]) cur[ci] = minValue;
+        }
+    for (int ri = rows - 2; ri >= 0; --ri)
+        for (int ci = cols - 2; ci >= 1; --ci) {
+            float* cur = &dist[(size_t)ri * cols];
+            const float* next = cur + cols;
+            const float lowerLeft = next[ci - 1] + 1.4f, lower = next[ci] + 1.0f, lowerRight = next[ci + 1] + 1.4f, right = cur[ci + 1] + 1.0f;
+            const float minValue = std::min(std::min(lowerLeft, lower), std::min(right, lowerRight));
+            if (minValue < cur[ci]) cur[ci] = minValue;
+        }
+}
+
+}  // namespace
+
+extern "C" {
+
+// Truncated chamfer distance map exactly as above (exposed so the device's map can be compared on its own).
+void oracle_f360_distance_map(const float* xyz, int rows, int cols, float max_depth_change_factor, int depth_mode, float* out) {
+    std::vector<float> d;
+    distance_map(xyz, rows, cols, max_depth_change_factor, depth_mode, d);
+    memcpy(out, d.data(), d.size() * sizeof(float));
+}
+
+// IntegralImageNormalEstimation, AVERAGE_3D_GRADIENT, depth-dependent smoothing, BORDER_POLICY_IGNORE.
+// normals: n x 3, NaN where PCL leaves the normal undefined.  window_out (optional): the rect size used, 0 if none.
+void oracle_f360_normals(const float* xyz, int rows, int cols, float max_depth_change_factor, float normal_smoothing_size,
+                         int depth_mode, float* normals, int* window_out) {
+    const size_t n = (size_t)rows * cols;
+    const float qnan = std::numeric_limits<float>::quiet_NaN();
+    for (size_t i = 0; i < 3 * n; ++i) normals[i] = qnan;
+    if (window_out) memset(window_out, 0, n * sizeof(int));
+    std::vector<float> dist;
+    distance_map(xyz, rows, cols, max_depth_change_factor, depth_mode, dist);
+    // initAverage3DGradientMethod: central differences, zero on the image border
+    std::vector<float> dx(3 * n, 0.f), dy(3 * n, 0.f);
+    for (int r = 1; r < rows - 1; ++r)
+        for (int c = 1; c < cols - 1; ++c) {
+            const size_t i = (size_t)r * cols + c;
+            for (int k = 0; k < 3; ++k) {
+                dx[3 * i + k] = xyz[3 * (i + 1) + k] - xyz[3 * (i - 1) + k];
+                dy[3 * i + k] = xyz[3 * (i + cols) + k] - xyz[3 * (i - cols) + k];
+            }
+        }
+    const int border = (int)normal_smoothing_size;
+#pragma omp parallel for
+    for (int ri = border; ri < rows - border; ++ri)
+        for (int ci = border; ci < cols - border; ++ci) {
+            const size_t index = (size_t)ri * cols + ci;
+            const float depth = depth_of(xyz + 3 * index, depth_mode);
+            if (!std::isfinite(depth)) continue;
+            const float smoothing = std::min(dist[index], normal_smoothing_size + depth / 10.0f);
+            if (!(smoothing > 2.0f)) continue;
+            const int rect = (int)smoothing;                 // setRectSize(rect, rect)
+            const int x0 = ci - rect / 2, y0 = ri - rect / 2;
+            double gx[3] = {0, 0, 0}, gy[3] = {0, 0, 0};
+            unsigned count_x = 0, count_y = 0;
+            for (int y = y0; y < y0 + rect; ++y)
+                for (int x = x0; x < x0 + rect; ++x) {
+                    if (x < 0 || y < 0 || x >= cols || y >= rows) continue;
+                    const size_t j = (size_t)y * cols + x;
+                    if (finite3(&dx[3 * j])) {
+                        ++count_x;
+                        for (int k = 0; k < 3; ++k) gx[k] += dx[3 * j + k];
+                    }
+                    if (finite3(&dy[3 * j])) {
+                        ++count_y;
+                        for (int k = 0; k < 3; ++k) gy[k] += dy[3 * j + k];
+                    }
+                }
+            if (window_out) window_out[index] = rect;
+            if (count_x == 0 || count_y == 0) continue;
+            double nv[3] = {gy[1] * gx[2] - gy[2] * gx[1], gy[2] * gx[0] - gy[0] * gx[2], gy[0] * gx[1] - gy[1] * gx[0]};   // gradient_y x gradient_x
+            const double len2 = nv[0] * nv[0] + nv[1] * nv[1] + nv[2] * nv[2];
+            if (len2 == 0.0) continue;
+            const double inv = 1.0 / sqrt(len2);
+            float nx = (float)(nv[0] * inv), ny = (float)(nv[1] * inv), nz = (float)(nv[2] * inv);
+            // flipNormalTowardsViewpoint, viewpoint (0,0,0)
+            const float* p = xyz + 3 * index;
+            if ((-p[0]) * nx + (-p[1]) * ny + (-p[2]) * nz < 0) {
+                nx = -nx; ny = -ny; nz = -nz;
+            }
+            normals[3 * index] = nx; normals[3 * index + 1] = ny; normals[3 * index + 2] = nz;
+        }
+}
+
+struct oracle_plane {
+    float centroid[3];
+    float normal[3];
+    float d;            // n . x + d = 0
+    float curvature;    // lambda_min / trace(cov)
+    int   count;
+    int   root;         // smallest pixel index of the region (PCL's label order)
+};
+
+// smallest eigenpair of a symmetric 3x3 (cyclic Jacobi, double)
+static void smallest_eigen(const double C[3][3], double& eval, double evec[3]) {
+    double A[3][3], V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    memcpy(A, C, sizeof(A));
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+        if (off < 1e-300) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (fabs(A[p][q]) < 1e-300) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2 * A[p][q]);
+                const double t = (theta >= 0 ? 1 : -1) / (fabs(theta) + sqrt(theta * theta + 1));
+                const double c = 1 / sqrt(t * t + 1), s = t * c;
+                for (int k = 0; k < 3; ++k) {
+                    const double akp = A[k][p], akq = A[k][q];
+                    A[k][p] = c * akp - s * akq;
+                    A[k][q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double apk = A[p][k], aqk = A[q][k];
+                    A[p][k] = c * apk - s * aqk;
+                    A[q][k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - s * vkq;
+                    V[k][q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    int m = 0;
+    for (int k = 1; k < 3; ++k)
+        if (A[k][k] < A[m][m]) m = k;
+    eval = A[m][m];
+    for (int k = 0; k < 3; ++k) evec[k] = V[k][m];
+}
+
+// OrganizedMultiPlaneSegmentation::segment.  labels: n int32 (root pixel index of the region, -1 for non-finite
+// points).  Returns the number of planes written (<= max_planes), in PCL's order (by first pixel).
+int oracle_f360_plane_segment(const float* xyz, const float* normals, int rows, int cols, int min_inliers, float angular_threshold,
+                              float distance_threshold, float max_curvature, int depth_mode, int* labels, oracle_plane* planes,
+                              int max_planes) {
+    const size_t n = (size_t)rows * cols;
+    std::vector<float> plane_d(n);
+    for (size_t i = 0; i < n; ++i)
+        plane_d[i] = xyz[3 * i] * normals[3 * i] + xyz[3 * i + 1] * normals[3 * i + 1] + xyz[3 * i + 2] * normals[3 * i + 2];
+    const float cos_thr = cosf(angular_threshold);
+    auto compare = [&](size_t a, size_t b) {          // PlaneCoefficientComparator::compare, depth-dependent threshold
+        const float z = depth_of(xyz + 3 * a, depth_mode);
+        const float thr = distance_threshold * z * z;
+        const float dot = normals[3 * a] * normals[3 * b] + normals[3 * a + 1] * normals[3 * b + 1] + normals[3 * a + 2] * normals[3 * b + 2];
+        return (fabs(plane_d[a] - plane_d[b]) < thr) && (dot > cos_thr);
+    };
+    std::vector<int> parent(n);
+    auto find = [&](int x) {
+        while (parent[x] != x) {
+            parent[x] = parent[parent[x]];
+            x = parent[x];
+        }
+        return x;
+    };
+    for (size_t i = 0; i < n; ++i) parent[i] = finite3(xyz + 3 * i) ? (int)i : -1;
+    for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < cols; ++c) {
+            const size_t i = (size_t)r * cols + c;
+            if (parent[i] < 0) continue;
+            if (c > 0 && parent[i - 1] >= 0 && compare(i, i - 1)) {
+                int a = find((int)i), b = find((int)(i - 1));
+                if (a != b) parent[std::max(a, b)] = std::min(a, b);
+            }
+            if (r > 0 && parent[i - cols] >= 0 && compare(i, i - cols)) {
+                int a = find((int)i), b = find((int)(i - cols));
+                if (a != b) parent[std::max(a, b)] = std::min(a, b);
+            }
+        }
+    std::vector<int> count(n, 0);
+    for (size_t i = 0; i < n; ++i) {
+        labels[i] = parent[i] < 0 ? -1 : find((int)i);
+        if (labels[i] >= 0) ++count[labels[i]];
+    }
+    int n_planes = 0;
+    std::vector<int> roots;
+    for (size_t i = 0; i < n; ++i)
+        if (labels[i] == (int)i && count[i] > min_inliers) roots.push_back((int)i);
+    std::vector<int> slot(n, -1);
+    for (size_t k = 0; k < roots.size(); ++k) slot[roots[k]] = (int)k;
+    std::vector<double> mom(roots.size() * 9, 0.0);
+    for (size_t i = 0; i < n; ++i) {
+        if (labels[i] < 0 || slot[labels[i]] < 0) continue;
+        double* m = &mom[(size_t)slot[labels[i]] * 9];
+        const double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+        m[0] += x; m[1] += y; m[2] += z;
+        m[3] += x * x; m[4] += x * y; m[5] += x * z; m[6] += y * y; m[7] += y * z; m[8] += z * z;
+    }
+    for (size_t k = 0; k < roots.size() && n_planes < max_planes; ++k) {
+        const double* m = &mom[k * 9];
+        const double N = count[roots[k]];
+        const double cx = m[0] / N, cy = m[1] / N, cz = m[2] / N;
+        const double C[3][3] = {{m[3] / N - cx * cx, m[4] / N - cx * cy, m[5] / N - cx * cz},
+                                {m[4] / N - cx * cy, m[6] / N - cy * cy, m[7] / N - cy * cz},
+                                {m[5] / N - cx * cz, m[7] / N - cy * cz, m[8] / N - cz * cz}};
+        double ev, v[3];
+        smallest_eigen(C, ev, v);
+        double d = -(v[0] * cx + v[1] * cy + v[2] * cz);
+        // orient towards the viewpoint (origin): vp - centroid
+        if ((-cx) * v[0] + (-cy) * v[1] + (-cz) * v[2] < 0) {
+            v[0] = -v[0]; v[1] = -v[1]; v[2] = -v[2];
+            d = -(v[0] * cx + v[1] * cy + v[2] * cz);
+        }
+        const double tr = C[0][0] + C[1][1] + C[2][2];
+        const double curvature = tr != 0 ? fabs(ev / tr) : 0;
+        if (!(curvature < max_curvature)) continue;
+        oracle_plane& P = planes[n_planes++];
+        P.centroid[0] = (float)cx; P.centroid[1] = (float)cy; P.centroid[2] = (float)cz;
+        P.normal[0] = (float)v[0]; P.normal[1] = (float)v[1]; P.normal[2] = (float)v[2];
+        P.d = (float)d;
+        P.curvature = (float)curvature;
+        P.count = count[roots[k]];
+        P.root = roots[k];
+    }
+    return n_planes;
+}
+
+}  // extern "C"

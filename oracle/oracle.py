@@ -38,8 +38,8 @@ class Trace(C.Structure):
 
 
 def build(force: bool = False) -> str:
-    src = os.path.join(_HERE, "photo_icp_ref.cpp")
-    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, "photo_icp_ref.cpp"), os.path.join(_HERE, "frame360_ref.cpp")]
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle_photo_icp.so"], stdout=subprocess.DEVNULL)
     return _LIB_PATH
 
@@ -222,6 +222,63 @@ def gn_step(H, g, lam, pose):
     upd = np.zeros(6, np.float32)
     st = lib().oracle_gn_step(_ptr(Hc), _ptr(gc), float(lam), _ptr(pose_to_cm(pose)), _ptr(out), _ptr(upd))
     return st, pose_from_cm(out), upd
+
+
+def sphere_cloud(depth: np.ndarray, convention: int) -> np.ndarray:
+    d = np.ascontiguousarray(depth)
+    dt = 0 if d.dtype == np.uint16 else 1
+    if dt == 1:
+        d = np.ascontiguousarray(d, dtype=np.float32)
+    out = np.empty((d.shape[0] * d.shape[1], 3), dtype=np.float32)
+    f = lib().oracle_sphere_cloud
+    f.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    f.restype = None
+    f(_ptr(d), d.strides[0], dt, d.shape[0], d.shape[1], convention, _ptr(out))
+    return out
+
+
+class OraclePlane(C.Structure):
+    _fields_ = [("centroid", C.c_float * 3), ("normal", C.c_float * 3), ("d", C.c_float), ("curvature", C.c_float),
+                ("count", C.c_int), ("root", C.c_int)]
+
+
+def f360_distance_map(xyz, rows, cols, max_depth_change_factor=0.05, depth_mode=1):
+    xyz = np.ascontiguousarray(xyz, np.float32).reshape(rows * cols, 3)
+    out = np.empty((rows, cols), np.float32)
+    f = lib().oracle_f360_distance_map
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_int, C.c_void_p]
+    f.restype = None
+    f(_ptr(xyz), rows, cols, max_depth_change_factor, depth_mode, _ptr(out))
+    return out
+
+
+def f360_normals(xyz, rows, cols, max_depth_change_factor=0.05, normal_smoothing_size=8.0, depth_mode=1):
+    xyz = np.ascontiguousarray(xyz, np.float32).reshape(rows * cols, 3)
+    out = np.empty_like(xyz)
+    win = np.empty(rows * cols, np.int32)
+    f = lib().oracle_f360_normals
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
+    f.restype = None
+    f(_ptr(xyz), rows, cols, max_depth_change_factor, normal_smoothing_size, depth_mode, _ptr(out), _ptr(win))
+    return out, win.reshape(rows, cols)
+
+
+def f360_plane_segment(xyz, normals, rows, cols, min_inliers=40, angular_threshold=0.05, distance_threshold=0.05,
+                       max_curvature=0.001, depth_mode=1, max_planes=256):
+    xyz = np.ascontiguousarray(xyz, np.float32).reshape(rows * cols, 3)
+    normals = np.ascontiguousarray(normals, np.float32).reshape(rows * cols, 3)
+    labels = np.empty(rows * cols, np.int32)
+    arr = (OraclePlane * max_planes)()
+    f = lib().oracle_f360_plane_segment
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_void_p,
+                  C.c_void_p, C.c_int]
+    f.restype = C.c_int
+    n = f(_ptr(xyz), _ptr(normals), rows, cols, min_inliers, angular_threshold, distance_threshold, max_curvature, depth_mode,
+          _ptr(labels), C.cast(arr, C.c_void_p), max_planes)
+    planes = [dict(centroid=np.array(list(arr[i].centroid), np.float32), normal=np.array(list(arr[i].normal), np.float32),
+                   d=float(arr[i].d), curvature=float(arr[i].curvature), count=int(arr[i].count), root=int(arr[i].root))
+              for i in range(n)]
+    return labels.reshape(rows, cols), planes
 
 
 def num_threads() -> int:

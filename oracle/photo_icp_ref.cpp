@@ -35,6 +35,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <vector>
 #include <algorithm>
 #ifdef _OPENMP
@@ -998,6 +999,61 @@ void oracle_warp_indices(void* h, int level, const float* pose, int* out_rc) {
         out_rc[2 * i + 1] = w.c;
     }
 }
+// ------------------------------------------------------------------------------------
+// Frame360 sphere clouds.  xyz out: rows*cols x 3, NaN where the reference writes NaN.
+//   convention 0: Frame360::buildSphereCloud_fromImage        Frame360.h:555-612   (u16 mm, phi offset 31.5 deg)
+//   convention 1: Frame360_stereo::buildSphereCloud           Frame360_stereo.h:454-512 (f32 m, valid in (0,15))
+//   convention 2: the RegisterPhotoICP LUT convention          RPI.h:4556-4582 without the depth band
+// ------------------------------------------------------------------------------------
+void oracle_sphere_cloud(const void* depth, size_t step, int depth_type, int rows, int cols, int convention, float* xyz) {
+    const float qnan = std::numeric_limits<float>::quiet_NaN();
+    for (int r = 0; r < rows; ++r) {
+        const uint8_t* row = (const uint8_t*)depth + (size_t)r * step;
+        for (int c = 0; c < cols; ++c) {
+            float* o = xyz + 3 * ((size_t)r * cols + c);
+            o[0] = o[1] = o[2] = qnan;
+            if (convention == 0) {
+                const float angle_pixel(cols / (2 * kPI));
+                const float angle_pixel_inv(1 / angle_pixel);
+                const float offset_phi = kPI * 31.5 / 180;
+                const float phi_i = offset_phi - r * angle_pixel_inv;
+                const float sin_phi = sinf(phi_i), cos_phi = cosf(phi_i);   // float arguments -> float overloads (SURVEY.md 3.4 gotcha 2)
+                const float theta_i = c * angle_pixel_inv;
+                const float d = 0.001f * ((const uint16_t*)row)[c];
+                if (d != 0) {
+                    o[0] = sin_phi * d;
+                    o[1] = -cos_phi * sinf(theta_i) * d;
+                    o[2] = -cos_phi * cosf(theta_i) * d;
+                }
+            } else if (convention == 1) {
+                const float step_theta = 2 * kPI / cols;
+                const float step_phi = step_theta;
+                const int start_phi = 166;
+                const float phi = (r + start_phi) * step_phi - kPI / 2;
+                const float cos_phi = cosf(phi), sin_phi = sinf(phi);
+                const float d = ((const float*)row)[c];
+                if (d > 0.f && d < 15.f) {
+                    const float theta = c * step_theta - kPI;
+                    o[0] = sinf(theta) * cos_phi * d;
+                    o[1] = sin_phi * d;
+                    o[2] = cosf(theta) * cos_phi * d;
+                }
+            } else {
+                const float angle_res = 2 * kPI / cols;
+                const float half_nRows = 0.5 * rows - 0.5;
+                const float theta = c * angle_res;
+                const float phi = (half_nRows - r) * angle_res;
+                const float d = depth_type == 0 ? (float)((const uint16_t*)row)[c] * 0.001f : ((const float*)row)[c];
+                if (d != 0) {
+                    o[0] = d * sinf(phi);
+                    o[1] = -d * cosf(phi) * sinf(theta);
+                    o[2] = -d * cosf(phi) * cosf(theta);
+                }
+            }
+        }
+    }
+}
+
 // Scalar probes for unit tests.
 float oracle_asinf_poly(float x) { return asinf_poly(x); }
 float oracle_atan2f_poly(float y, float x) { return atan2f_poly(y, x); }

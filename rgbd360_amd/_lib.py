@@ -13,7 +13,8 @@ SYMBOLS = [
     "rgbd360_set_source", "rgbd360_set_target_dev", "rgbd360_set_source_dev", "rgbd360_promote_source_to_target",
     "rgbd360_align360", "rgbd360_level_dims", "rgbd360_get_plane", "rgbd360_get_lut", "rgbd360_eval",
     "rgbd360_warp_indices", "rgbd360_gn_step", "rgbd360_forced_iters", "rgbd360_time_eval_kernel", "rgbd360_stream",
-    "rgbd360_sync", "rgbd360_device_count", "rgbd360_sphere_cloud", "rgbd360_selftest_math", "rgbd360_time_solve_kernel",
+    "rgbd360_sync", "rgbd360_device_count", "rgbd360_sphere_cloud", "rgbd360_selftest_math", "rgbd360_time_solve_kernel", "rgbd360_normals", "rgbd360_distance_map",
+    "rgbd360_plane_fit", "rgbd360_frame_planes",
 ]
 
 
@@ -28,6 +29,11 @@ class Result(C.Structure):
     _fields_ = [("status", C.c_int), ("iters", C.c_int * 8), ("sso", C.c_float), ("err_final", C.c_double),
                 ("rms_photo", C.c_double), ("rms_depth", C.c_double), ("hessian", C.c_float * 36),
                 ("gradient", C.c_float * 6)]
+
+
+class Plane(C.Structure):
+    _fields_ = [("centroid", C.c_float * 3), ("normal", C.c_float * 3), ("d", C.c_float), ("curvature", C.c_float),
+                ("count", C.c_int), ("root", C.c_int)]
 
 
 _lib = None
@@ -68,6 +74,11 @@ def load() -> C.CDLL:
     L.rgbd360_sync.argtypes = [vp]
     L.rgbd360_device_count.argtypes = []
     L.rgbd360_time_solve_kernel.argtypes = [vp, i32, i32, i32, C.POINTER(C.c_float)]
+    L.rgbd360_normals.argtypes = [vp, vp, i32, i32, C.c_float, C.c_float, i32, vp]
+    L.rgbd360_distance_map.argtypes = [vp, vp, i32, i32, C.c_float, i32, vp]
+    L.rgbd360_plane_fit.argtypes = [vp, vp, vp, i32, i32, i32, C.c_float, C.c_float, C.c_float, i32, vp, vp, i32, C.POINTER(i32)]
+    L.rgbd360_frame_planes.argtypes = [vp, vp, C.c_size_t, i32, i32, i32, i32, C.c_float, C.c_float, i32, C.c_float, C.c_float, C.c_float,
+                                       i32, vp, vp, vp, vp, i32, C.POINTER(i32)]
     L.rgbd360_selftest_math.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
     L.rgbd360_sphere_cloud.argtypes = [vp, vp, C.c_size_t, i32, i32, i32, i32, f32p]
     _lib = L

@@ -1,0 +1,269 @@
+// frame360_kernels.h -- gfx950 kernels for the per-pixel Frame360 stages next to the alignment path
+// (SURVEY.md rows a14 / a15): the normal map and the planar-region segmentation + inlier moments that
+// Frame360::getPlanesSensor / Frame360_stereo::getPlanesStereo obtain from PCL
+// (Frame360.h:949-977, Frame360_stereo.h:854-882):
+//   pcl::IntegralImageNormalEstimation (AVERAGE_3D_GRADIENT, depth-dependent smoothing)
+//   pcl::OrganizedMultiPlaneSegmentation (PlaneCoefficientComparator + organised connected components + PCA fit)
+// PCL is third-party and unpinned (not in the reference tree); the algorithms follow PCL 1.7's published sources and
+// the CPU restatement in oracle/frame360_ref.cpp documents the shared, deliberate differences (direct window sums,
+// double moments, no boundary refinement, optional range-as-depth mode for full spheres).
+//
+//   k_f360_edges      depth-change map (computeFeature)                      1 B/px out
+//   k_f360_hdist      per-row distance to the nearest depth-change pixel     1 B/px
+//   k_f360_dist       chamfer (1 / 1.4) distance map, truncated at kF360R    4 B/px
+//   k_f360_diff       central differences DX, DY (initAverage3DGradientMethod) 32 B/px
+//   k_f360_normals    window-averaged gradients -> normal, flipped to the viewpoint
+//   k_f360_ccl_init / _merge / _compress   label-equivalence connected components (union-find, atomicMin)
+//   k_f360_count / _assign / _moments      region sizes, compaction of the large regions, 9 moments per region
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace f360 {
+
+constexpr int kF360R = 12;          // truncation radius of the distance map (>= smoothing_size + max depth / 10)
+constexpr float kBig = 1.0e9f;
+
+__device__ __forceinline__ bool finite3(float x, float y, float z) { return isfinite(x) && isfinite(y) && isfinite(z); }
+__device__ __forceinline__ float depth_of(const float* p, int depth_mode) {
+    return depth_mode == 0 ? p[2] : sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+}
+
+// pair test of computeFeature: `a` is the pixel the loop visits, `b` its right / lower neighbour
+__device__ __forceinline__ bool depth_break(float da, float db, float factor) {
+    const float ddc = factor * (fabsf(da) + 1.0f) * 2.0f;
+    return (fabsf(da - db) > ddc) || !isfinite(da) || !isfinite(db);
+}
+
+__global__ void k_f360_edges(const float* __restrict__ xyz, int rows, int cols, float factor, int depth_mode,
+                             uint8_t* __restrict__ change) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    if (c >= cols || r >= rows) return;
+    const size_t i = (size_t)r * cols + c;
+    const float d = depth_of(xyz + 3 * i, depth_mode);
+    bool edge = false;
+    if (r < rows - 1 && c < cols - 1) {       // visited as `index`
+        edge |= depth_break(d, depth_of(xyz + 3 * (i + 1), depth_mode), factor);
+        edge |= depth_break(d, depth_of(xyz + 3 * (i + cols), depth_mode), factor);
+    }
+    if (c >= 1 && r < rows - 1)               // right neighbour of (r, c-1)   (c-1 < cols-1 always)
+        edge |= depth_break(depth_of(xyz + 3 * (i - 1), depth_mode), d, factor);
+    if (r >= 1 && c < cols - 1)               // lower neighbour of (r-1, c)
+        edge |= depth_break(depth_of(xyz + 3 * (i - cols), depth_mode), d, factor);
+    change[i] = edge ? 0 : 255;
+}
+
+__global__ void k_f360_hdist(const uint8_t* __restrict__ change, int rows, int cols, uint8_t* __restrict__ hd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    if (c >= cols || r >= rows) return;
+    const uint8_t* row = change + (size_t)r * cols;
+    int best = 255;
+    for (int k = 0; k <= kF360R; ++k) {
+        const bool l = (c - k >= 0) && row[c - k] == 0, rr = (c + k < cols) && row[c + k] == 0;
+        if (l || rr) {
+            best = k;
+            break;
+        }
+    }
+    hd[(size_t)r * cols + c] = (uint8_t)best;
+}
+
+// chamfer distance with weights 1 (straight) / 1.4 (diagonal): max + 0.4 min, min over the rows within the radius of the
+// nearest depth-change pixel of each row (for a fixed row offset the metric grows with |dx|)
+__global__ void k_f360_dist(const uint8_t* __restrict__ hd, int rows, int cols, float* __restrict__ dist) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    if (c >= cols || r >= rows) return;
+    float best = (float)(cols + rows);
+    for (int dy = -kF360R; dy <= kF360R; ++dy) {
+        const int rr = r + dy;
+        if (rr < 0 || rr >= rows) continue;
+        const int dx = hd[(size_t)rr * cols + c];
+        if (dx == 255) continue;
+        const int ady = dy < 0 ? -dy : dy;
+        const int mn = dx < ady ? dx : ady, mx = dx < ady ? ady : dx;
+        const float v = (float)mn * 1.4f + (float)(mx - mn);
+        best = v < best ? v : best;
+    }
+    dist[(size_t)r * cols + c] = best;
+}
+
+// DX = p(r, c+1) - p(r, c-1), DY = p(r+1, c) - p(r-1, c), zero on the image border; .w = 1 when all three finite
+__global__ void k_f360_diff(const float* __restrict__ xyz, int rows, int cols, float4* __restrict__ dx, float4* __restrict__ dy) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    if (c >= cols || r >= rows) return;
+    const size_t i = (size_t)r * cols + c;
+    float4 gx = make_float4(0.f, 0.f, 0.f, 1.f), gy = gx;
+    if (r >= 1 && r < rows - 1 && c >= 1 && c < cols - 1) {
+        const float *pl = xyz + 3 * (i - 1), *pr = xyz + 3 * (i + 1), *pu = xyz + 3 * (i - cols), *pd = xyz + 3 * (i + cols);
+        gx.x = pr[0] - pl[0]; gx.y = pr[1] - pl[1]; gx.z = pr[2] - pl[2];
+        gy.x = pd[0] - pu[0]; gy.y = pd[1] - pu[1]; gy.z = pd[2] - pu[2];
+        gx.w = finite3(gx.x, gx.y, gx.z) ? 1.f : 0.f;
+        gy.w = finite3(gy.x, gy.y, gy.z) ? 1.f : 0.f;
+    }
+    dx[i] = gx;
+    dy[i] = gy;
+}
+
+__global__ void k_f360_normals(const float* __restrict__ xyz, const float* __restrict__ dist, const float4* __restrict__ dx,
+                               const float4* __restrict__ dy, int rows, int cols, float smoothing_size, int depth_mode,
+                               float* __restrict__ normals, int* __restrict__ window) {
+    const int ci = blockIdx.x * blockDim.x + threadIdx.x, ri = blockIdx.y;
+    if (ci >= cols || ri >= rows) return;
+    const size_t index = (size_t)ri * cols + ci;
+    const float qnan = __builtin_nanf("");
+    float nx = qnan, ny = qnan, nz = qnan;
+    int rect = 0;
+    const int border = (int)smoothing_size;
+    if (ri >= border && ri < rows - border && ci >= border && ci < cols - border) {
+        const float* p = xyz + 3 * index;
+        const float depth = depth_of(p, depth_mode);
+        if (isfinite(depth)) {
+            const float smoothing = fminf(dist[index], smoothing_size + depth / 10.0f);
+            if (smoothing > 2.0f) {
+                rect = (int)smoothing;
+                const int x0 = ci - rect / 2, y0 = ri - rect / 2;
+                float gx0 = 0.f, gx1 = 0.f, gx2 = 0.f, gy0 = 0.f, gy1 = 0.f, gy2 = 0.f, cx = 0.f, cy = 0.f;
+                for (int y = y0; y < y0 + rect; ++y)
+                    for (int x = x0; x < x0 + rect; ++x) {
+                        const size_t j = (size_t)y * cols + x;      // inside the image: the border band is >= rect/2 wide
+                        const float4 a = dx[j], b = dy[j];
+                        if (a.w != 0.f) { gx0 += a.x; gx1 += a.y; gx2 += a.z; cx += 1.f; }
+                        if (b.w != 0.f) { gy0 += b.x; gy1 += b.y; gy2 += b.z; cy += 1.f; }
+                    }
+                if (cx > 0.f && cy > 0.f) {
+                    const float v0 = gy1 * gx2 - gy2 * gx1, v1 = gy2 * gx0 - gy0 * gx2, v2 = gy0 * gx1 - gy1 * gx0;   // gradient_y x gradient_x
+                    const float len2 = v0 * v0 + v1 * v1 + v2 * v2;
+                    if (len2 != 0.f) {
+                        const float inv = 1.f / sqrtf(len2);
+                        nx = v0 * inv; ny = v1 * inv; nz = v2 * inv;
+                        if ((-p[0]) * nx + (-p[1]) * ny + (-p[2]) * nz < 0.f) {    // flipNormalTowardsViewpoint, vp = origin
+                            nx = -nx; ny = -ny; nz = -nz;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    normals[3 * index] = nx; normals[3 * index + 1] = ny; normals[3 * index + 2] = nz;
+    if (window) window[index] = rect;
+}
+
+// ---- organised connected components with PlaneCoefficientComparator -------------------------------------------
+__global__ void k_f360_ccl_init(const float* __restrict__ xyz, const float* __restrict__ normals, int n, float* __restrict__ plane_d,
+                                int* __restrict__ label) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *p = xyz + 3 * (size_t)i, *q = normals + 3 * (size_t)i;
+    plane_d[i] = p[0] * q[0] + p[1] * q[1] + p[2] * q[2];
+    label[i] = finite3(p[0], p[1], p[2]) ? i : -1;
+}
+
+__device__ __forceinline__ int uf_find(const int* label, int x) {
+    int p = label[x];
+    while (p != x) {
+        x = p;
+        p = label[x];
+    }
+    return x;
+}
+__device__ __forceinline__ void uf_union(int* label, int a, int b) {
+    for (;;) {
+        a = uf_find(label, a);
+        b = uf_find(label, b);
+        if (a == b) return;
+        if (a < b) {
+            const int t = a; a = b; b = t;
+        }
+        const int old = atomicMin(&label[a], b);     // a > b: hang the larger root under the smaller
+        if (old == a) return;
+        a = old;                                     // somebody re-rooted `a` meanwhile: retry from there
+    }
+}
+
+__global__ void k_f360_ccl_merge(const float* __restrict__ xyz, const float* __restrict__ normals, const float* __restrict__ plane_d,
+                                 int rows, int cols, float cos_thr, float dist_thr, int depth_mode, int* __restrict__ label) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    if (c >= cols || r >= rows) return;
+    const int i = r * cols + c;
+    if (label[i] < 0) return;
+    const float* p = xyz + 3 * (size_t)i;
+    const float* n = normals + 3 * (size_t)i;
+    const float z = depth_of(p, depth_mode);
+    const float thr = dist_thr * z * z;                          // depth-dependent distance threshold
+    const float pd = plane_d[i];
+    const int nb[2] = {c > 0 ? i - 1 : -1, r > 0 ? i - cols : -1};
+    for (int k = 0; k < 2; ++k) {
+        const int j = nb[k];
+        if (j < 0 || label[j] < 0) continue;
+        const float* m = normals + 3 * (size_t)j;
+        const float dot = n[0] * m[0] + n[1] * m[1] + n[2] * m[2];
+        if ((fabsf(pd - plane_d[j]) < thr) && (dot > cos_thr)) uf_union(label, i, j);
+    }
+}
+
+__global__ void k_f360_ccl_compress(int n, int* __restrict__ label) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (label[i] >= 0) label[i] = uf_find(label, i);
+}
+
+// region sizes; a wave whose active lanes share one label adds once
+__global__ void k_f360_count(const int* __restrict__ label, int n, int* __restrict__ count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int l = i < n ? label[i] : -1;
+    const int first = __builtin_amdgcn_readfirstlane(l);
+    const unsigned long long same = __ballot(l == first);
+    if (same == __ballot(true)) {
+        if (first >= 0 && (threadIdx.x & 63) == 0) atomicAdd(&count[first], (int)__builtin_popcountll(same));
+    } else if (l >= 0) {
+        atomicAdd(&count[l], 1);
+    }
+}
+
+// compaction: roots of regions with more than min_inliers points get a slot (order fixed later on the host)
+__global__ void k_f360_assign(const int* __restrict__ label, const int* __restrict__ count, int n, int min_inliers, int max_slots,
+                              int* __restrict__ slot_of_root, int* __restrict__ root_of_slot, int* __restrict__ n_slots) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (label[i] == i && count[i] > min_inliers) {
+        const int s = atomicAdd(n_slots, 1);
+        if (s < max_slots) {
+            slot_of_root[i] = s;
+            root_of_slot[s] = i;
+        }
+    }
+}
+
+// 9 raw moments per selected region, float64 atomics; wave-uniform labels are reduced in the wave first
+__global__ void k_f360_moments(const float* __restrict__ xyz, const int* __restrict__ label, const int* __restrict__ slot_of_root, int n,
+                               double* __restrict__ mom) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int s = -1;
+    double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (i < n) {
+        const int l = label[i];
+        if (l >= 0) s = slot_of_root[l];
+        if (s >= 0) {
+            const double x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
+            v[0] = x; v[1] = y; v[2] = z;
+            v[3] = x * x; v[4] = x * y; v[5] = x * z; v[6] = y * y; v[7] = y * z; v[8] = z * z;
+        }
+    }
+    const int first = __builtin_amdgcn_readfirstlane(s);
+    const bool uniform = __ballot(s == first) == __ballot(true);
+    if (uniform) {
+        if (first < 0) return;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            double t = v[k];
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) t += __shfl_xor(t, m);
+            if ((threadIdx.x & 63) == 0) atomicAdd(&mom[(size_t)first * 9 + k], t);
+        }
+    } else if (s >= 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) atomicAdd(&mom[(size_t)s * 9 + k], v[k]);
+    }
+}
+
+}  // namespace f360

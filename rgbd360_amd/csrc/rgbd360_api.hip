@@ -7,6 +7,7 @@
 // There is no CPU fallback anywhere in this file.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -16,6 +17,7 @@
 
 #include "../../include/rgbd360_hip.h"
 #include "photo_icp_kernels.h"
+#include "frame360_kernels.h"
 
 using namespace r360;
 
@@ -48,6 +50,13 @@ struct rgbd360_ctx {
     uint8_t* d_stage_depth = nullptr;
     size_t stage_rgb_bytes = 0, stage_depth_bytes = 0;
     int poll_chunk = 2;           // {pass, solve} pairs enqueued between two polls of the done flag
+    // Frame360 stage scratch (normals / plane segmentation), grown on demand
+    size_t f360_n = 0;
+    float *f_xyz = nullptr, *f_normals = nullptr, *f_dist = nullptr, *f_plane_d = nullptr;
+    float4 *f_dx = nullptr, *f_dy = nullptr;
+    uint8_t *f_change = nullptr, *f_hd = nullptr;
+    int *f_label = nullptr, *f_count = nullptr, *f_slot_of_root = nullptr, *f_root_of_slot = nullptr, *f_nslots = nullptr, *f_window = nullptr;
+    double* f_mom = nullptr;
     int max_eval_blocks = 512;    // grid cap of the fused pass (tuning knob: RGBD360_EVAL_BLOCKS)
     std::string err;
 };
@@ -333,6 +342,9 @@ void rgbd360_destroy(rgbd360_ctx* ctx) {
     free_levels(ctx);
     hipFree(ctx->d_state); hipFree(ctx->d_partials); hipFree(ctx->d_gnio);
     hipFree(ctx->d_stage_rgb); hipFree(ctx->d_stage_depth);
+    hipFree(ctx->f_xyz); hipFree(ctx->f_normals); hipFree(ctx->f_dist); hipFree(ctx->f_plane_d); hipFree(ctx->f_dx); hipFree(ctx->f_dy);
+    hipFree(ctx->f_change); hipFree(ctx->f_hd); hipFree(ctx->f_label); hipFree(ctx->f_count); hipFree(ctx->f_slot_of_root);
+    hipFree(ctx->f_root_of_slot); hipFree(ctx->f_nslots); hipFree(ctx->f_window); hipFree(ctx->f_mom);
     if (ctx->h_state) hipHostFree(ctx->h_state);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
@@ -696,3 +708,235 @@ int rgbd360_sphere_cloud(rgbd360_ctx* ctx, const void* depth, size_t depth_step,
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------
+// Frame360 stages: normal map (row a14) and planar regions + inlier moments (row a15)
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int kF360MaxSlots = 4096;
+
+int f360_ensure(rgbd360_ctx* ctx, size_t n) {
+    if (ctx->f360_n >= n) return 0;
+    hipFree(ctx->f_xyz); hipFree(ctx->f_normals); hipFree(ctx->f_dist); hipFree(ctx->f_plane_d); hipFree(ctx->f_dx); hipFree(ctx->f_dy);
+    hipFree(ctx->f_change); hipFree(ctx->f_hd); hipFree(ctx->f_label); hipFree(ctx->f_count); hipFree(ctx->f_slot_of_root);
+    hipFree(ctx->f_root_of_slot); hipFree(ctx->f_nslots); hipFree(ctx->f_window); hipFree(ctx->f_mom);
+    ctx->f360_n = 0;
+    HIPC(ctx, hipMalloc(&ctx->f_xyz, n * 3 * sizeof(float)));
+    HIPC(ctx, hipMalloc(&ctx->f_normals, n * 3 * sizeof(float)));
+    HIPC(ctx, hipMalloc(&ctx->f_dist, n * sizeof(float)));
+    HIPC(ctx, hipMalloc(&ctx->f_plane_d, n * sizeof(float)));
+    HIPC(ctx, hipMalloc(&ctx->f_dx, n * sizeof(float4)));
+    HIPC(ctx, hipMalloc(&ctx->f_dy, n * sizeof(float4)));
+    HIPC(ctx, hipMalloc(&ctx->f_change, n));
+    HIPC(ctx, hipMalloc(&ctx->f_hd, n));
+    HIPC(ctx, hipMalloc(&ctx->f_label, n * sizeof(int)));
+    HIPC(ctx, hipMalloc(&ctx->f_count, n * sizeof(int)));
+    HIPC(ctx, hipMalloc(&ctx->f_slot_of_root, n * sizeof(int)));
+    HIPC(ctx, hipMalloc(&ctx->f_window, n * sizeof(int)));
+    HIPC(ctx, hipMalloc(&ctx->f_root_of_slot, kF360MaxSlots * sizeof(int)));
+    HIPC(ctx, hipMalloc(&ctx->f_nslots, sizeof(int)));
+    HIPC(ctx, hipMalloc(&ctx->f_mom, (size_t)kF360MaxSlots * 9 * sizeof(double)));
+    ctx->f360_n = n;
+    return 0;
+}
+
+// normals of the organised cloud in ctx->f_xyz -> ctx->f_normals (device)
+int f360_normals_dev(rgbd360_ctx* ctx, int rows, int cols, float max_depth_change_factor, float smoothing_size, int depth_mode) {
+    using namespace f360;
+    if (smoothing_size < 1.f || smoothing_size + 2.5f > (float)kF360R)
+        return fail(ctx, -1, "normal_smoothing_size out of range (the distance map is truncated at 12 px)");
+    const dim3 g = grid2d(rows, cols), b(256);
+    hipLaunchKernelGGL(k_f360_edges, g, b, 0, ctx->stream, ctx->f_xyz, rows, cols, max_depth_change_factor, depth_mode, ctx->f_change);
+    hipLaunchKernelGGL(k_f360_hdist, g, b, 0, ctx->stream, ctx->f_change, rows, cols, ctx->f_hd);
+    hipLaunchKernelGGL(k_f360_dist, g, b, 0, ctx->stream, ctx->f_hd, rows, cols, ctx->f_dist);
+    hipLaunchKernelGGL(k_f360_diff, g, b, 0, ctx->stream, ctx->f_xyz, rows, cols, ctx->f_dx, ctx->f_dy);
+    hipLaunchKernelGGL(k_f360_normals, g, b, 0, ctx->stream, ctx->f_xyz, ctx->f_dist, ctx->f_dx, ctx->f_dy, rows, cols, smoothing_size,
+                       depth_mode, ctx->f_normals, ctx->f_window);
+    HIPC(ctx, hipGetLastError());
+    return 0;
+}
+
+// smallest eigenpair of a symmetric 3x3 (cyclic Jacobi, float64) -- pcl::eigen33's role
+void smallest_eigen3(const double C[3][3], double& eval, double evec[3]) {
+    double A[3][3], V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    memcpy(A, C, sizeof(A));
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        if (fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]) < 1e-300) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (fabs(A[p][q]) < 1e-300) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2 * A[p][q]);
+                const double t = (theta >= 0 ? 1 : -1) / (fabs(theta) + sqrt(theta * theta + 1));
+                const double c = 1 / sqrt(t * t + 1), sn = t * c;
+                for (int k = 0; k < 3; ++k) {
+                    const double akp = A[k][p], akq = A[k][q];
+                    A[k][p] = c * akp - sn * akq;
+                    A[k][q] = sn * akp + c * akq;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double apk = A[p][k], aqk = A[q][k];
+                    A[p][k] = c * apk - sn * aqk;
+                    A[q][k] = sn * apk + c * aqk;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - sn * vkq;
+                    V[k][q] = sn * vkp + c * vkq;
+                }
+            }
+    }
+    int m = 0;
+    for (int k = 1; k < 3; ++k)
+        if (A[k][k] < A[m][m]) m = k;
+    eval = A[m][m];
+    for (int k = 0; k < 3; ++k) evec[k] = V[k][m];
+}
+
+// regions of (ctx->f_xyz, ctx->f_normals) -> labels (device ctx->f_label) + plane list (host)
+int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float angular_threshold, float distance_threshold,
+                    float max_curvature, int depth_mode, rgbd360_plane* planes, int max_planes, int* n_planes) {
+    using namespace f360;
+    const int n = rows * cols;
+    const dim3 g1((n + 255) / 256), b(256);
+    HIPC(ctx, hipMemsetAsync(ctx->f_count, 0, (size_t)n * sizeof(int), ctx->stream));
+    HIPC(ctx, hipMemsetAsync(ctx->f_slot_of_root, 0xFF, (size_t)n * sizeof(int), ctx->stream));
+    HIPC(ctx, hipMemsetAsync(ctx->f_nslots, 0, sizeof(int), ctx->stream));
+    HIPC(ctx, hipMemsetAsync(ctx->f_mom, 0, (size_t)kF360MaxSlots * 9 * sizeof(double), ctx->stream));
+    hipLaunchKernelGGL(k_f360_ccl_init, g1, b, 0, ctx->stream, ctx->f_xyz, ctx->f_normals, n, ctx->f_plane_d, ctx->f_label);
+    hipLaunchKernelGGL(k_f360_ccl_merge, grid2d(rows, cols), b, 0, ctx->stream, ctx->f_xyz, ctx->f_normals, ctx->f_plane_d, rows, cols,
+                       cosf(angular_threshold), distance_threshold, depth_mode, ctx->f_label);
+    hipLaunchKernelGGL(k_f360_ccl_compress, g1, b, 0, ctx->stream, n, ctx->f_label);
+    hipLaunchKernelGGL(k_f360_count, g1, b, 0, ctx->stream, ctx->f_label, n, ctx->f_count);
+    hipLaunchKernelGGL(k_f360_assign, g1, b, 0, ctx->stream, ctx->f_label, ctx->f_count, n, min_inliers, kF360MaxSlots,
+                       ctx->f_slot_of_root, ctx->f_root_of_slot, ctx->f_nslots);
+    hipLaunchKernelGGL(k_f360_moments, g1, b, 0, ctx->stream, ctx->f_xyz, ctx->f_label, ctx->f_slot_of_root, n, ctx->f_mom);
+    HIPC(ctx, hipGetLastError());
+    int nslots = 0;
+    HIPC(ctx, hipMemcpyAsync(&nslots, ctx->f_nslots, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    if (nslots > kF360MaxSlots) return fail(ctx, -7, "more than 4096 regions exceed min_inliers");
+    std::vector<int> roots(nslots), counts(nslots);
+    std::vector<double> mom((size_t)nslots * 9);
+    if (nslots > 0) {
+        HIPC(ctx, hipMemcpy(roots.data(), ctx->f_root_of_slot, nslots * sizeof(int), hipMemcpyDeviceToHost));
+        HIPC(ctx, hipMemcpy(mom.data(), ctx->f_mom, (size_t)nslots * 9 * sizeof(double), hipMemcpyDeviceToHost));
+        for (int s = 0; s < nslots; ++s)
+            HIPC(ctx, hipMemcpy(&counts[s], ctx->f_count + roots[s], sizeof(int), hipMemcpyDeviceToHost));
+    }
+    std::vector<int> order(nslots);
+    for (int s = 0; s < nslots; ++s) order[s] = s;
+    std::sort(order.begin(), order.end(), [&](int a, int c) { return roots[a] < roots[c]; });   // PCL's order: by first pixel
+    int np = 0;
+    for (int oi = 0; oi < nslots && np < max_planes; ++oi) {
+        const int s = order[oi];
+        const double* m = &mom[(size_t)s * 9];
+        const double N = counts[s];
+        const double cx = m[0] / N, cy = m[1] / N, cz = m[2] / N;
+        const double C[3][3] = {{m[3] / N - cx * cx, m[4] / N - cx * cy, m[5] / N - cx * cz},
+                                {m[4] / N - cx * cy, m[6] / N - cy * cy, m[7] / N - cy * cz},
+                                {m[5] / N - cx * cz, m[7] / N - cy * cz, m[8] / N - cz * cz}};
+        double ev, v[3];
+        smallest_eigen3(C, ev, v);
+        double d = -(v[0] * cx + v[1] * cy + v[2] * cz);
+        if ((-cx) * v[0] + (-cy) * v[1] + (-cz) * v[2] < 0) {     // orient towards the viewpoint (origin)
+            v[0] = -v[0]; v[1] = -v[1]; v[2] = -v[2];
+            d = -(v[0] * cx + v[1] * cy + v[2] * cz);
+        }
+        const double tr = C[0][0] + C[1][1] + C[2][2];
+        const double curvature = tr != 0 ? fabs(ev / tr) : 0;
+        if (!(curvature < max_curvature)) continue;
+        rgbd360_plane& P = planes[np++];
+        P.centroid[0] = (float)cx; P.centroid[1] = (float)cy; P.centroid[2] = (float)cz;
+        P.normal[0] = (float)v[0]; P.normal[1] = (float)v[1]; P.normal[2] = (float)v[2];
+        P.d = (float)d;
+        P.curvature = (float)curvature;
+        P.count = counts[s];
+        P.root = roots[s];
+    }
+    *n_planes = np;
+    return 0;
+}
+}  // namespace
+
+extern "C" int rgbd360_normals(rgbd360_ctx* ctx, const float* xyz, int rows, int cols, float max_depth_change_factor,
+                               float normal_smoothing_size, int depth_mode, float* normals_out) {
+    if (!ctx || !xyz || !normals_out) return -1;
+    if (rows < 3 || cols < 3 || (long long)rows * cols >= (1ll << 30)) return fail(ctx, -1, "bad image size");
+    hipSetDevice(ctx->p.device);
+    const size_t n = (size_t)rows * cols;
+    int rc = f360_ensure(ctx, n);
+    if (rc) return rc;
+    HIPC(ctx, hipMemcpyAsync(ctx->f_xyz, xyz, n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    rc = f360_normals_dev(ctx, rows, cols, max_depth_change_factor, normal_smoothing_size, depth_mode);
+    if (rc) return rc;
+    HIPC(ctx, hipMemcpyAsync(normals_out, ctx->f_normals, n * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" int rgbd360_distance_map(rgbd360_ctx* ctx, const float* xyz, int rows, int cols, float max_depth_change_factor,
+                                    int depth_mode, float* dist_out) {
+    if (!ctx || !xyz || !dist_out) return -1;
+    if (rows < 3 || cols < 3 || (long long)rows * cols >= (1ll << 30)) return fail(ctx, -1, "bad image size");
+    hipSetDevice(ctx->p.device);
+    const size_t n = (size_t)rows * cols;
+    int rc = f360_ensure(ctx, n);
+    if (rc) return rc;
+    HIPC(ctx, hipMemcpyAsync(ctx->f_xyz, xyz, n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    const dim3 g = grid2d(rows, cols), b(256);
+    hipLaunchKernelGGL(f360::k_f360_edges, g, b, 0, ctx->stream, ctx->f_xyz, rows, cols, max_depth_change_factor, depth_mode, ctx->f_change);
+    hipLaunchKernelGGL(f360::k_f360_hdist, g, b, 0, ctx->stream, ctx->f_change, rows, cols, ctx->f_hd);
+    hipLaunchKernelGGL(f360::k_f360_dist, g, b, 0, ctx->stream, ctx->f_hd, rows, cols, ctx->f_dist);
+    HIPC(ctx, hipGetLastError());
+    HIPC(ctx, hipMemcpyAsync(dist_out, ctx->f_dist, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" int rgbd360_plane_fit(rgbd360_ctx* ctx, const float* xyz, const float* normals, int rows, int cols, int min_inliers,
+                                 float angular_threshold, float distance_threshold, float max_curvature, int depth_mode,
+                                 int32_t* labels_out, rgbd360_plane* planes_out, int max_planes, int* n_planes_out) {
+    if (!ctx || !xyz || !normals || !planes_out || !n_planes_out || max_planes < 1) return -1;
+    if (rows < 2 || cols < 2 || (long long)rows * cols >= (1ll << 30)) return fail(ctx, -1, "bad image size");
+    hipSetDevice(ctx->p.device);
+    const size_t n = (size_t)rows * cols;
+    int rc = f360_ensure(ctx, n);
+    if (rc) return rc;
+    HIPC(ctx, hipMemcpyAsync(ctx->f_xyz, xyz, n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    HIPC(ctx, hipMemcpyAsync(ctx->f_normals, normals, n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    rc = f360_planes_dev(ctx, rows, cols, min_inliers, angular_threshold, distance_threshold, max_curvature, depth_mode, planes_out,
+                         max_planes, n_planes_out);
+    if (rc) return rc;
+    if (labels_out) HIPC(ctx, hipMemcpy(labels_out, ctx->f_label, n * sizeof(int), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int rgbd360_frame_planes(rgbd360_ctx* ctx, const void* depth, size_t depth_step, int depth_type, int rows, int cols,
+                                    int convention, float max_depth_change_factor, float normal_smoothing_size, int min_inliers,
+                                    float angular_threshold, float distance_threshold, float max_curvature, int depth_mode,
+                                    float* xyz_out, float* normals_out, int32_t* labels_out, rgbd360_plane* planes_out,
+                                    int max_planes, int* n_planes_out) {
+    if (!ctx || !depth || !planes_out || !n_planes_out || max_planes < 1) return -1;
+    if (rows < 3 || cols < 3 || (long long)rows * cols >= (1ll << 30)) return fail(ctx, -1, "bad image size");
+    const size_t n = (size_t)rows * cols;
+    int rc = f360_ensure(ctx, n);
+    if (rc) return rc;
+    // cloud on the device (the host copy of rgbd360_sphere_cloud is only made when asked for)
+    std::vector<float> tmp;
+    float* host_xyz = xyz_out;
+    if (!host_xyz) {
+        tmp.resize(n * 3);
+        host_xyz = tmp.data();
+    }
+    rc = rgbd360_sphere_cloud(ctx, depth, depth_step, depth_type, rows, cols, convention, host_xyz);
+    if (rc) return rc;
+    HIPC(ctx, hipMemcpyAsync(ctx->f_xyz, host_xyz, n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    rc = f360_normals_dev(ctx, rows, cols, max_depth_change_factor, normal_smoothing_size, depth_mode);
+    if (rc) return rc;
+    rc = f360_planes_dev(ctx, rows, cols, min_inliers, angular_threshold, distance_threshold, max_curvature, depth_mode, planes_out,
+                         max_planes, n_planes_out);
+    if (rc) return rc;
+    if (normals_out) HIPC(ctx, hipMemcpy(normals_out, ctx->f_normals, n * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    if (labels_out) HIPC(ctx, hipMemcpy(labels_out, ctx->f_label, n * sizeof(int), hipMemcpyDeviceToHost));
+    return 0;
+}

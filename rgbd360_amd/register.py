@@ -277,6 +277,66 @@ class RegisterPhotoICP:
         return out
 
 
+def _planes_to_dicts(arr, n):
+    return [dict(centroid=np.array(list(arr[i].centroid), np.float32), normal=np.array(list(arr[i].normal), np.float32),
+                 d=float(arr[i].d), curvature=float(arr[i].curvature), count=int(arr[i].count), root=int(arr[i].root))
+            for i in range(n)]
+
+
+class Frame360Stages:
+    """The per-pixel Frame360 stages on the device: buildSphereCloud (Frame360.h:555-612), the PCL normal map and planar
+    region extraction of getPlanesSensor / getPlanesStereo (Frame360.h:949-996, Frame360_stereo.h:854-900).  Defaults are
+    the reference's settings for the spherical (stereo) variant."""
+
+    def __init__(self, reg: RegisterPhotoICP | None = None):
+        self._reg = reg or RegisterPhotoICP()
+        self._L = self._reg._L
+
+    def normals(self, xyz, rows, cols, max_depth_change_factor=0.05, normal_smoothing_size=8.0, depth_mode=1):
+        xyz = np.ascontiguousarray(xyz, np.float32).reshape(rows * cols, 3)
+        out = np.empty_like(xyz)
+        self._reg._check(self._L.rgbd360_normals(self._reg._ctx(), _ptr(xyz), rows, cols, max_depth_change_factor,
+                                                 normal_smoothing_size, depth_mode, _ptr(out)))
+        return out
+
+    def distance_map(self, xyz, rows, cols, max_depth_change_factor=0.05, depth_mode=1):
+        xyz = np.ascontiguousarray(xyz, np.float32).reshape(rows * cols, 3)
+        out = np.empty((rows, cols), np.float32)
+        self._reg._check(self._L.rgbd360_distance_map(self._reg._ctx(), _ptr(xyz), rows, cols, max_depth_change_factor, depth_mode,
+                                                      _ptr(out)))
+        return out
+
+    def plane_fit(self, xyz, normals, rows, cols, min_inliers=40, angular_threshold=0.05, distance_threshold=0.05,
+                  max_curvature=0.001, depth_mode=1, max_planes=256):
+        xyz = np.ascontiguousarray(xyz, np.float32).reshape(rows * cols, 3)
+        normals = np.ascontiguousarray(normals, np.float32).reshape(rows * cols, 3)
+        labels = np.empty(rows * cols, np.int32)
+        arr = (_lib.Plane * max_planes)()
+        n = C.c_int()
+        self._reg._check(self._L.rgbd360_plane_fit(self._reg._ctx(), _ptr(xyz), _ptr(normals), rows, cols, min_inliers,
+                                                   angular_threshold, distance_threshold, max_curvature, depth_mode, _ptr(labels),
+                                                   C.cast(arr, C.c_void_p), max_planes, C.byref(n)))
+        return labels.reshape(rows, cols), _planes_to_dicts(arr, n.value)
+
+    def frame_planes(self, depth, convention=2, max_depth_change_factor=0.05, normal_smoothing_size=8.0, min_inliers=40,
+                     angular_threshold=0.05, distance_threshold=0.05, max_curvature=0.001, depth_mode=1, max_planes=256):
+        d = np.ascontiguousarray(depth)
+        dt = 0 if d.dtype == np.uint16 else 1
+        if dt == 1:
+            d = np.ascontiguousarray(d, np.float32)
+        rows, cols = d.shape
+        xyz = np.empty((rows * cols, 3), np.float32)
+        nrm = np.empty((rows * cols, 3), np.float32)
+        labels = np.empty(rows * cols, np.int32)
+        arr = (_lib.Plane * max_planes)()
+        n = C.c_int()
+        self._reg._check(self._L.rgbd360_frame_planes(self._reg._ctx(), _ptr(d), d.strides[0], dt, rows, cols, convention,
+                                                      max_depth_change_factor, normal_smoothing_size, min_inliers, angular_threshold,
+                                                      distance_threshold, max_curvature, depth_mode, _ptr(xyz), _ptr(nrm), _ptr(labels),
+                                                      C.cast(arr, C.c_void_p), max_planes, C.byref(n)))
+        return dict(xyz=xyz, normals=nrm, labels=labels.reshape(rows, cols), planes=_planes_to_dicts(arr, n.value))
+
+
 def Register(frame_trg, frame_src, pose: np.ndarray, method: int = RegisterPhotoICP.PHOTO_DEPTH, reg=None) -> bool:
     """The north-star convenience shape `Register(Frame360&, Frame360&, Matrix4f&) -> bool`: frames are any objects
     with `sphereRGB` / `sphereDepth` (Frame360.h:104-111); `pose` is the initial guess and is overwritten in place."""

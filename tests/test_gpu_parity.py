@@ -251,3 +251,92 @@ def test_sequence_batch_matches_pairwise_alignment(hip_lib, oracle_mod):
         rot, trans = synth.pose_error(poses[j], T_gt)
         assert rot < 5e-3 and trans < 1e-2, (j, rot, trans)       # 256x128 resolution limit
     assert compose_trajectory(poses).shape == (4, 4, 4)
+
+
+@pytest.mark.parametrize("convention", [0, 1, 2])
+def test_sphere_cloud_bit_exact(hip_lib, oracle_mod, convention):
+    """SURVEY.md row a13: Frame360::buildSphereCloud_fromImage / Frame360_stereo::buildSphereCloud / LUT convention."""
+    (rgbA, dA), _, _ = synth.make_pair(256, 128, seed=11, depth_f32=(convention == 1))
+    d = dA.copy()
+    d[10:20, 30:50] = 0                       # a hole: NaN points
+    if convention == 1:
+        d[40:44, 5:9] = 20.0                  # beyond the 15 m cut of the stereo variant
+    reg = _mk(hip_lib, 3)
+    got = reg.sphere_cloud(d, convention)
+    ref = oracle_mod.sphere_cloud(d, convention)
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    assert np.isnan(ref).any() and not np.isnan(ref).all()
+    ok = ~np.isnan(ref)
+    assert np.array_equal(got[ok].view(np.uint32), ref[ok].view(np.uint32))
+
+
+# ---- Frame360 stages: rows a14 (normal map) and a15 (planar regions + inlier moments) ---------------------------------
+def _room_cloud(oracle_mod, W=512, H=256, seed=5):
+    (rgbA, dA), _, _ = synth.make_pair(W, H, seed=seed)
+    d = dA.copy()
+    d[60:90, 200:230] = 0                      # a hole (NaN points, depth discontinuity all around)
+    d[150:170, 300:340] = (d[150:170, 300:340] * 0.7).astype(np.uint16)     # a box in front of the wall: depth steps
+    return oracle_mod.sphere_cloud(d, 2), d, H, W
+
+
+@pytest.mark.parametrize("depth_mode", [0, 1])
+def test_normal_map_matches_oracle(hip_lib, oracle_mod, depth_mode):
+    from rgbd360_amd.register import Frame360Stages
+    xyz, d, H, W = _room_cloud(oracle_mod)
+    st = Frame360Stages(_mk(hip_lib, 3))
+    dist_ref = oracle_mod.f360_distance_map(xyz, H, W, 0.05, depth_mode)
+    dist = st.distance_map(xyz, H, W, 0.05, depth_mode)
+    near = dist_ref < 10.0                      # the device map is exact below its truncation radius
+    assert np.array_equal(dist_ref == 0, dist == 0)
+    assert np.abs(dist[near] - dist_ref[near]).max() < 1e-5
+    assert (dist[~near] >= 10.0 - 1e-5).all()
+    nrm = st.normals(xyz, H, W, 0.05, 8.0, depth_mode)
+    ref, win = oracle_mod.f360_normals(xyz, H, W, 0.05, 8.0, depth_mode)
+    assert np.array_equal(np.isnan(nrm[:, 0]), np.isnan(ref[:, 0]))
+    ok = ~np.isnan(ref[:, 0])
+    assert ok.mean() > 0.3
+    assert np.abs(nrm[ok] - ref[ok]).max() < 2e-4      # float32 window sums vs the oracle's double sums
+    assert np.allclose(np.linalg.norm(nrm[ok], axis=1), 1.0, atol=1e-5)
+    assert ((nrm[ok] * xyz[ok]).sum(1) <= 1e-4).all()  # flipped towards the viewpoint (origin)
+
+
+@pytest.mark.parametrize("depth_mode,ang", [(1, 0.05), (1, 0.03), (0, 0.0398)])
+def test_plane_regions_match_oracle(hip_lib, oracle_mod, depth_mode, ang):
+    """Same normals in, same partition out (labels are the regions' smallest pixel index on both sides), moments and
+    plane parameters equal to float32 rounding."""
+    from rgbd360_amd.register import Frame360Stages
+    xyz, d, H, W = _room_cloud(oracle_mod)
+    nrm, _ = oracle_mod.f360_normals(xyz, H, W, 0.05, 8.0, depth_mode)
+    st = Frame360Stages(_mk(hip_lib, 3))
+    labels, planes = st.plane_fit(xyz, nrm, H, W, 40, ang, 0.05, 0.001, depth_mode)
+    labels_ref, planes_ref = oracle_mod.f360_plane_segment(xyz, nrm, H, W, 40, ang, 0.05, 0.001, depth_mode)
+    assert np.array_equal(labels, labels_ref)                       # integer / index work: exact
+    assert [p["root"] for p in planes] == [p["root"] for p in planes_ref]
+    assert [p["count"] for p in planes] == [p["count"] for p in planes_ref]
+    for a, b in zip(planes, planes_ref):
+        assert np.allclose(a["centroid"], b["centroid"], atol=1e-5)
+        assert abs(a["curvature"] - b["curvature"]) < 1e-6
+        if b["curvature"] > 1e-9:        # (collinear one-column regions have a degenerate normal direction)
+            assert abs(abs(np.dot(a["normal"], b["normal"])) - 1) < 1e-5 and abs(a["d"] - b["d"]) < 1e-4
+
+
+def test_frame_planes_recovers_the_room_walls(hip_lib, oracle_mod):
+    """Functional known answer for the chained device pipeline (range image -> cloud -> normals -> regions): the six walls
+    of the synthetic room come out within 1 degree / 1 cm (SURVEY.md 8c bar for the PCL-based rows)."""
+    from rgbd360_amd.register import Frame360Stages
+    (rgbA, dA), _, _ = synth.make_pair(512, 256, seed=5)
+    out = Frame360Stages(_mk(hip_lib, 3)).frame_planes(dA, convention=2, angular_threshold=0.03)
+    big = [p for p in out["planes"] if p["count"] > 1000]
+    cam = synth.CAM_A
+    truth = []           # (normal towards the camera, distance) of every wall, camera at CAM_A with identity orientation
+    for ax in range(3):
+        for sgn, bound in ((-1.0, synth.ROOM_HI[ax]), (1.0, synth.ROOM_LO[ax])):
+            n = np.zeros(3)
+            n[ax] = sgn
+            truth.append((n, abs(bound - cam[ax])))
+    found = 0
+    for n_true, dist in truth:
+        hits = [p for p in big if np.dot(p["normal"], n_true) > np.cos(np.radians(1.0)) and abs(p["d"] - dist) < 0.01]
+        found += bool(hits)
+    assert found == 6, [(p["count"], p["normal"], p["d"]) for p in big]
+    assert out["labels"].shape == (256, 512) and np.isfinite(out["normals"]).any()

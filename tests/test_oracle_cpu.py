@@ -222,3 +222,36 @@ def test_no_valid_pixels_status(oracle_mod, small_pair):
     ora.set_source(rgbB, np.zeros_like(dB))
     st, pose = ora.align360(np.eye(4), 2)
     assert st == 2 and np.allclose(pose, np.eye(4))
+
+
+def test_frame360_oracle_recovers_the_room_walls(oracle_mod):
+    """Rows a14/a15 (PCL restatement): on the synthetic room the segmented planes are the six walls within 1 degree / 1 cm."""
+    W, H = 512, 256
+    (rgbA, dA), _, _ = synth.make_pair(W, H, seed=5)
+    xyz = oracle_mod.sphere_cloud(dA, 2)
+    assert np.allclose(np.linalg.norm(xyz, axis=1), dA.ravel() * 1e-3, atol=1e-5)
+    nrm, win = oracle_mod.f360_normals(xyz, H, W, 0.05, 8.0, 1)
+    ok = np.isfinite(nrm[:, 0])
+    assert ok.mean() > 0.8 and np.allclose(np.linalg.norm(nrm[ok], axis=1), 1, atol=1e-5)
+    labels, planes = oracle_mod.f360_plane_segment(xyz, nrm, H, W, 40, 0.03, 0.05, 0.001, 1)
+    big = [p for p in planes if p["count"] > 1000]
+    cam = synth.CAM_A
+    for ax in range(3):
+        for sgn, bound in ((-1.0, synth.ROOM_HI[ax]), (1.0, synth.ROOM_LO[ax])):
+            n = np.zeros(3)
+            n[ax] = sgn
+            hits = [p for p in big if np.dot(p["normal"], n) > np.cos(np.radians(1.0)) and abs(p["d"] - abs(bound - cam[ax])) < 0.01]
+            assert hits, (ax, sgn)
+    # labels are region roots: the smallest pixel index of each region
+    for p in big:
+        assert labels.ravel()[p["root"]] == p["root"] and (labels == p["root"]).sum() == p["count"]
+
+
+def test_frame360_distance_map_is_a_chamfer_transform(oracle_mod):
+    xyz = np.zeros((40 * 60, 3), np.float32)
+    xyz[:, 2] = 2.0
+    img = xyz.reshape(40, 60, 3)
+    img[20, 30, 2] = 3.0                    # one depth spike -> depth-change pixels around it
+    d = oracle_mod.f360_distance_map(xyz, 40, 60, 0.05, 0)
+    assert d[20, 30] == 0 and d[20, 31] == 0 and d[21, 30] == 0
+    assert d[20, 36] == pytest.approx(5.0) and d[26, 36] == pytest.approx(5 * 1.4 + 0.0, abs=1e-5)
