@@ -71,13 +71,18 @@ def test_product_path_fails_loudly_without_a_gpu(built_lib):
 
 
 def test_product_package_never_imports_the_oracle():
+    """The oracle is a checker only: no import, include, link or dlopen of anything under oracle/ from the product."""
     pkg = os.path.join(ROOT, "rgbd360_amd")
+    banned = [r"^\s*(from|import)\s+oracle\b", r"import_module\([^)]*oracle", r"#\s*include[^\n]*oracle", r"liboracle",
+              r"oracle_[a-z0-9_]+\s*\(", r"CDLL\([^)]*oracle"]
     for dirpath, _, files in os.walk(pkg):
         for fn in files:
             if fn.endswith((".py", ".h", ".hip", ".cpp", ".hpp")):
                 txt = open(os.path.join(dirpath, fn), errors="ignore").read()
-                assert "oracle" not in txt.replace("CPU oracle", "").replace("the oracle", "").replace("oracle's", ""), \
-                    os.path.join(dirpath, fn)
+                for pat in banned:
+                    assert not re.search(pat, txt, flags=re.M), (os.path.join(dirpath, fn), pat)
+    # and the build of the product does not mention the oracle's sources
+    assert "oracle" not in open(os.path.join(pkg, "build.py")).read()
 
 
 def test_host_argument_validation():
