@@ -81,8 +81,9 @@ def test_product_package_never_imports_the_oracle():
                 txt = open(os.path.join(dirpath, fn), errors="ignore").read()
                 for pat in banned:
                     assert not re.search(pat, txt, flags=re.M), (os.path.join(dirpath, fn), pat)
-    # and the build of the product does not mention the oracle's sources
-    assert "oracle" not in open(os.path.join(pkg, "build.py")).read()
+    # and the build of the product does not compile or link the oracle's sources
+    code = "\n".join(l for l in open(os.path.join(pkg, "build.py")).read().splitlines() if not l.lstrip().startswith("#"))
+    assert "oracle" not in code
 
 
 def test_host_argument_validation():
