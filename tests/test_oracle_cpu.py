@@ -254,4 +254,5 @@ def test_frame360_distance_map_is_a_chamfer_transform(oracle_mod):
     img[20, 30, 2] = 3.0                    # one depth spike -> depth-change pixels around it
     d = oracle_mod.f360_distance_map(xyz, 40, 60, 0.05, 0)
     assert d[20, 30] == 0 and d[20, 31] == 0 and d[21, 30] == 0
-    assert d[20, 36] == pytest.approx(5.0) and d[26, 36] == pytest.approx(5 * 1.4 + 0.0, abs=1e-5)
+    # the depth-change set is the plus shape around the spike; (25,36) is 5 diagonal steps from (20,31)
+    assert d[20, 36] == pytest.approx(5.0) and d[25, 36] == pytest.approx(5 * 1.4, abs=1e-5) and d[26, 36] == pytest.approx(8.0, abs=1e-5)
