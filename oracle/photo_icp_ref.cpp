@@ -131,27 +131,11 @@ inline float round_half_away(float x) {
 // Device arithmetic (math_mode 1): the operation sequence of rgbd360_amd/csrc/photo_icp_kernels.h warp_pixel.
 // Pure float32 fma / mul / add / correctly rounded sqrt and reciprocal: IEEE-exact on x86 and gfx950 alike, hence
 // bit-identical results (the device's sqrt_rn / rcp_rn are checked against IEEE by its own self-test).
-inline float asinf_poly(float x) {
-    const float c0 = 0.16666672764720836f, c1 = 0.07498809174564633f, c2 = 0.0450107002296682f,
-                c3 = 0.02649427585795898f, c4 = 0.03820645371719902f;
-    float ax = fabsf(x);
-    bool  big = ax >= 0.5f;
-    float z = fmaxf(big ? (1.f - ax) * 0.5f : ax * ax, 0.f);
-    float s = big ? sqrtf(z) : ax;
-    float p = fmaf(z, c4, c3);
-    p = fmaf(z, p, c2);
-    p = fmaf(z, p, c1);
-    p = fmaf(z, p, c0);
-    float r = fmaf(s * z, p, s);                       // asin(s)
-    if (big) r = 1.57079637f - 2.f * r;                // pi/2 - 2 asin(sqrt((1-|x|)/2))
-    return copysignf(r, x);
-}
-
-inline float atan2f_poly_t(float y, float x, float ay, float ax, float t) {
+inline float atan_unit(float t) {     // atan(t), t in [0,1]: odd minimax polynomial
     const float q0 = -0.3333333195069166f, q1 = 0.19999765993465415f, q2 = -0.14279110844310372f,
                 q3 = 0.11037993832882714f, q4 = -0.08673169371217875f, q5 = 0.06284358078457526f,
                 q6 = -0.03627014369584507f, q7 = 0.01375026672953864f, q8 = -0.00244702708829393f;
-    float s = t * t;
+    const float s = t * t;
     float p = fmaf(s, q8, q7);
     p = fmaf(s, p, q6);
     p = fmaf(s, p, q5);
@@ -160,16 +144,21 @@ inline float atan2f_poly_t(float y, float x, float ay, float ax, float t) {
     p = fmaf(s, p, q2);
     p = fmaf(s, p, q1);
     p = fmaf(s, p, q0);
-    float a = fmaf(t * s, p, t);                       // atan(t), t in [0,1]
+    return fmaf(t * s, p, t);
+}
+inline float atan2_from_t(float y, float x, float ay, float ax, float t) {
+    float a = atan_unit(t);
     if (ay > ax) a = 1.57079637f - a;
     if (std::signbit(x)) a = 3.14159274f - a;
     return copysignf(a, y);
 }
+// Stand-alone forms of the device's angle functions (unit tests): asin(x) = atan2(x, sqrt(1 - x^2)).
 inline float atan2f_poly(float y, float x) {
-    float ay = fabsf(y), ax = fabsf(x);
-    float mx = fmaxf(fmaxf(ay, ax), 1e-30f), mn = fminf(ay, ax);
-    return atan2f_poly_t(y, x, ay, ax, mn * (1.f / mx));
+    const float ay = fabsf(y), ax = fabsf(x);
+    const float mx = fmaxf(fmaxf(ay, ax), 1e-9f), mn = fminf(ay, ax);
+    return atan2_from_t(y, x, ay, ax, mn * (1.f / mx));
 }
+inline float asinf_poly(float x) { return atan2f_poly(x, sqrtf(fmaxf(fmaf(-x, x, 1.f), 0.f))); }
 inline int round_index(float x) { return (int)floor((double)x + 0.5); }   // v_cvt_rpi_i32_f32: exact sum, then floor
 
 // ------------------------------------------------------------------------------------
@@ -369,14 +358,21 @@ inline Warp warp_pixel(const PoseRT& T, const float* p, int nRows, int nCols, fl
         w.X = fmaf(T.R[2], p[2], fmaf(T.R[1], p[1], fmaf(T.R[0], p[0], T.t[0])));
         w.Y = fmaf(T.R[5], p[2], fmaf(T.R[4], p[1], fmaf(T.R[3], p[0], T.t[1])));
         w.Z = fmaf(T.R[8], p[2], fmaf(T.R[7], p[1], fmaf(T.R[6], p[0], T.t[2])));
-        w.dist = sqrtf(fmaf(w.Z, w.Z, fmaf(w.Y, w.Y, w.X * w.X)));
-        const float ay = fabsf(w.Y), az = fabsf(w.Z);
-        const float mx = fmaxf(fmaxf(ay, az), 1e-30f), mn = fminf(ay, az);
-        const float r = 1.f / (w.dist * mx);
-        w.dist_inv = r * mx;
-        const float t = mn * (r * w.dist);
-        const float phi_trg = asinf_poly(w.X * w.dist_inv);
-        const float theta_trg = (float)((double)atan2f_poly_t(w.Y, w.Z, ay, az, t) + kPI);
+        const float rho2 = fmaf(w.Z, w.Z, w.Y * w.Y);
+        const float d2 = fmaf(w.X, w.X, rho2);
+        w.dist = sqrtf(d2);
+        w.dist_inv = 1.f / w.dist;
+        const float rho = sqrtf(rho2);
+        const float ax = fabsf(w.X), ay = fabsf(w.Y), az = fabsf(w.Z);
+        const float mxp = fmaxf(fmaxf(ax, rho), 1e-9f), mnp = fminf(ax, rho);
+        const float mxt = fmaxf(fmaxf(ay, az), 1e-9f), mnt = fminf(ay, az);
+        const float r = 1.f / (mxp * mxt);
+        const float tp = mnp * (r * mxt);
+        const float tt = mnt * (r * mxp);
+        float phi_trg = atan_unit(tp);
+        if (ax > rho) phi_trg = 1.57079637f - phi_trg;
+        phi_trg = copysignf(phi_trg, w.X);
+        const float theta_trg = (float)((double)atan2_from_t(w.Y, w.Z, ay, az, tt) + kPI);
         w.r = round_index(fmaf(-phi_trg, angle_res_inv, half_nRows));
         w.c = round_index(theta_trg * angle_res_inv);
         w.visible = ((unsigned)w.r < (unsigned)nRows) && ((unsigned)w.c < (unsigned)nCols);

@@ -62,6 +62,7 @@ struct GNState {
     double tot[kNumPartials];        // reduced partials of the last pass
     double acc_e2p, acc_e2d;         // error sums at the accepted pose
     long long acc_np, acc_nd, acc_nvis, used_nvis, used_npix;
+    unsigned long long stamps[8];    // diagnostic build only (RGBD360_SOLVE_STAMPS): 100 MHz timestamps of k_solve phases
 };
 
 struct SolveCfg {
@@ -115,28 +116,12 @@ __device__ __forceinline__ int round_index(float x) {
     return r;
 }
 
-__device__ __forceinline__ float asinf_poly(float x) {
-    const float c0 = 0.16666672764720836f, c1 = 0.07498809174564633f, c2 = 0.0450107002296682f,
-                c3 = 0.02649427585795898f, c4 = 0.03820645371719902f;
-    float ax = fabsf(x);
-    bool big = ax >= 0.5f;
-    float z = fmaxf(big ? (1.f - ax) * 0.5f : ax * ax, 0.f);   // |x| may exceed 1 by an ulp
-    float s = big ? sqrt_rn(z) : ax;
-    float p = fmaf(z, c4, c3);
-    p = fmaf(z, p, c2);
-    p = fmaf(z, p, c1);
-    p = fmaf(z, p, c0);
-    float r = fmaf(s * z, p, s);
-    if (big) r = 1.57079637f - 2.f * r;
-    return copysignf(r, x);
-}
-
-// atan2(y, x) with t = min(|y|,|x|) / max(|y|,|x|) supplied by the caller (it shares one reciprocal with 1/dist).
-__device__ __forceinline__ float atan2f_poly_t(float y, float x, float ay, float ax, float t) {
+// atan(t) for t in [0, 1(+ulps)]: odd minimax polynomial, 9 coefficients, relative error 1.3e-8.
+__device__ __forceinline__ float atan_unit(float t) {
     const float q0 = -0.3333333195069166f, q1 = 0.19999765993465415f, q2 = -0.14279110844310372f,
                 q3 = 0.11037993832882714f, q4 = -0.08673169371217875f, q5 = 0.06284358078457526f,
                 q6 = -0.03627014369584507f, q7 = 0.01375026672953864f, q8 = -0.00244702708829393f;
-    float s = t * t;
+    const float s = t * t;
     float p = fmaf(s, q8, q7);
     p = fmaf(s, p, q6);
     p = fmaf(s, p, q5);
@@ -145,7 +130,11 @@ __device__ __forceinline__ float atan2f_poly_t(float y, float x, float ay, float
     p = fmaf(s, p, q2);
     p = fmaf(s, p, q1);
     p = fmaf(s, p, q0);
-    float a = fmaf(t * s, p, t);
+    return fmaf(t * s, p, t);
+}
+// atan2(y, x) from t = min(|y|,|x|) / max(|y|,|x|) supplied by the caller (both angles share one reciprocal).
+__device__ __forceinline__ float atan2_from_t(float y, float x, float ay, float ax, float t) {
+    float a = atan_unit(t);
     if (ay > ax) a = 1.57079637f - a;
     if (__builtin_signbit(x)) a = 3.14159274f - a;
     return copysignf(a, y);
@@ -164,21 +153,30 @@ __device__ __forceinline__ PoseRT load_pose(const float* P) {   // column-major 
 }
 
 // Shared front end of RPI.h:2663-2684 / 2959-2989.  Returns the target pixel index or -1.
-// One correctly rounded sqrt and ONE correctly rounded reciprocal serve both angles:
-//   r = 1/(dist*mx),  1/dist = r*mx,  1/mx = r*dist      (mx = max(|Y|,|Z|, 1e-30))
+// Device arithmetic definition (the oracle's math_mode 1 repeats it operation for operation):
+//   p' = R p + t with fused multiply-adds;  rho^2 = Y^2 + Z^2,  d^2 = X^2 + rho^2
+//   phi   = atan2(X, rho)      (= asin(X/d) of the reference, RPI.h:2676)      rho = correctly rounded sqrt
+//   theta = atan2(Y, Z) + PI   (RPI.h:2677-2678)
+//   both quotients min/max come from ONE correctly rounded reciprocal r = 1 / (mx_phi * mx_theta)
+// Every step is an IEEE-754 basic operation, so x86 and gfx950 agree bit for bit on the pixel index.
 __device__ __forceinline__ int warp_pixel(const PoseRT& T, float px, float py, float pz, const LevelDev& lv, float& X,
-                                          float& Y, float& Z, float& dist, float& dist_inv) {
+                                          float& Y, float& Z, float& rho2, float& d2) {
     X = fmaf(T.r02, pz, fmaf(T.r01, py, fmaf(T.r00, px, T.tx)));
     Y = fmaf(T.r12, pz, fmaf(T.r11, py, fmaf(T.r10, px, T.ty)));
     Z = fmaf(T.r22, pz, fmaf(T.r21, py, fmaf(T.r20, px, T.tz)));
-    dist = sqrt_rn(fmaf(Z, Z, fmaf(Y, Y, X * X)));
-    const float ay = fabsf(Y), az = fabsf(Z);
-    const float mx = fmaxf(fmaxf(ay, az), 1e-30f), mn = fminf(ay, az);
-    const float r = rcp_rn(dist * mx);
-    dist_inv = r * mx;
-    const float t = mn * (r * dist);
-    const float phi_trg = asinf_poly(X * dist_inv);
-    const float theta_trg = (float)((double)atan2f_poly_t(Y, Z, ay, az, t) + kPI);
+    rho2 = fmaf(Z, Z, Y * Y);
+    d2 = fmaf(X, X, rho2);
+    const float rho = sqrt_rn(rho2);
+    const float ax = fabsf(X), ay = fabsf(Y), az = fabsf(Z);
+    const float mxp = fmaxf(fmaxf(ax, rho), 1e-9f), mnp = fminf(ax, rho);
+    const float mxt = fmaxf(fmaxf(ay, az), 1e-9f), mnt = fminf(ay, az);
+    const float r = rcp_rn(mxp * mxt);
+    const float tp = mnp * (r * mxt);
+    const float tt = mnt * (r * mxp);
+    float phi_trg = atan_unit(tp);
+    if (ax > rho) phi_trg = 1.57079637f - phi_trg;
+    phi_trg = copysignf(phi_trg, X);
+    const float theta_trg = (float)((double)atan2_from_t(Y, Z, ay, az, tt) + kPI);
     const int tr = round_index(fmaf(-phi_trg, lv.angle_res_inv, lv.half_nRows));
     const int tc = round_index(theta_trg * lv.angle_res_inv);
     const bool vis = ((unsigned)tr < (unsigned)lv.rows) && ((unsigned)tc < (unsigned)lv.cols);
@@ -231,7 +229,8 @@ __device__ __forceinline__ int ballot_count(bool p) { return __builtin_popcountl
 // not index work.
 __device__ __forceinline__ float weight_huber_fast(float error, float k) {
     const float ea = fabsf(error);
-    const float w = fast_sqrt(2 * k * ea - k * k) * fast_rcp(ea);
+    const float q = 2 * k * ea - k * k;
+    const float w = q * fast_rsq(q * ea * ea);       // sqrt(q) / |e| with one transcendental
     return ea < k ? 1.f : w;
 }
 
@@ -260,7 +259,7 @@ __device__ __forceinline__ void accumulate_row(EvalAcc& A, float jx, float jy, f
 // k_eval runs warp_stage of pixel i+1 before consume_stage of pixel i: the gather latency of one pixel hides behind
 // the arithmetic of its neighbour instead of stalling the wave.
 struct PixW {
-    float X, Y, Z, dist, dist_inv, isrc;
+    float X, Y, Z, rho2, d2, isrc;
     bool  vis;
     F3    tp, td;
 };
@@ -268,12 +267,12 @@ struct PixW {
 template <int METHOD>
 __device__ __forceinline__ void warp_stage(const float4 s, const bool in_range, const PoseRT& T, const LevelDev& lv,
                                            PixW& w) {
-    int ti = warp_pixel(T, s.x, s.y, s.z, lv, w.X, w.Y, w.Z, w.dist, w.dist_inv);
+    int ti = warp_pixel(T, s.x, s.y, s.z, lv, w.X, w.Y, w.Z, w.rho2, w.d2);
     w.vis = in_range && (s.x != kInvalidPoint) && (ti >= 0);
     w.isrc = s.w;
     // tie the copy of the source intensity to the end of the warp arithmetic: scheduled earlier it would sit in
     // front of the whole stage and wait for the youngest load (vmcnt(0)) instead of the one this stage needs
-    asm volatile("" : "+v"(w.isrc), "+v"(w.dist));
+    asm volatile("" : "+v"(w.isrc), "+v"(w.d2));
     ti = w.vis ? ti : 0;
     if (METHOD != 1) w.tp = lv.trgP[ti];     // unconditional gathers: issued as soon as the index is known
     if (METHOD != 0) w.td = lv.trgD[ti];
@@ -285,24 +284,26 @@ __device__ __forceinline__ void consume_stage(PixW& w, const LevelDev& lv, const
     // dword under the saliency branch, adding a dependent memory round trip per pixel
     if (METHOD != 1) asm volatile("" : "+v"(w.tp.a), "+v"(w.tp.b), "+v"(w.tp.c));
     if (METHOD != 0) asm volatile("" : "+v"(w.td.a), "+v"(w.td.b), "+v"(w.td.c));
-    const float X = w.X, Y = w.Y, Z = w.Z, dist_inv = w.dist_inv;
+    const float X = w.X, Y = w.Y, Z = w.Z;
     const bool vis = w.vis;
     A.nVis += ballot_count(vis);
 
-    // rows of jacobianProj23 (RPI.h:3000-3016); float32 data: hardware rcp / rsq
+    // rows of jacobianProj23 (RPI.h:3000-3016) in terms of rho^2 = Y^2+Z^2 and d^2 = |p'|^2 (k = angle_res_inv):
+    //   d c'/d(y,z) = k (Z, -Y) / rho^2
+    //   d r'/d(x,y,z) = k (-rho^2, X Y, X Z) / (rho d^2)
+    // (algebraically what the reference writes with 1/z, 1/(1+y^2/z^2), 1/sqrt(1-x^2/d^2)); float32 data, so the
+    // hardware reciprocal / reciprocal square root are used.
     float a1 = 0.f, a2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
+    const float dist_inv = fast_rsq(w.d2);
     if (HG) {
 #pragma clang fp contract(fast)
-        const float z_inv = fast_rcp(Z);
-        const float z_inv2 = z_inv * z_inv;
-        const float D_atan_theta = fast_rcp(1 + Y * Y * z_inv2) * lv.angle_res_inv;
-        a1 = D_atan_theta * z_inv;
-        a2 = -Y * z_inv2 * D_atan_theta;
-        const float x_dist_inv2 = X * (dist_inv * dist_inv);
-        const float one_m = 1 - X * x_dist_inv2;
-        const float D_asin = fast_rsq(one_m) * lv.angle_res_inv;
-        b0 = -D_asin * dist_inv * one_m;
-        const float c = D_asin * x_dist_inv2 * dist_inv;
+        const float inv_rho = fast_rsq(w.rho2);
+        const float k_rho2 = lv.angle_res_inv * (inv_rho * inv_rho);
+        a1 = k_rho2 * Z;
+        a2 = -k_rho2 * Y;
+        const float k_d2 = lv.angle_res_inv * (dist_inv * dist_inv);
+        b0 = -k_d2 * (w.rho2 * inv_rho);
+        const float c = k_d2 * inv_rho * X;
         b1 = c * Y;
         b2 = c * Z;
     }
@@ -335,7 +336,9 @@ __device__ __forceinline__ void consume_stage(PixW& w, const LevelDev& lv, const
         A.nD += ballot_count(ok);
         if (ok) {
 #pragma clang fp contract(fast)
-            const float depthDiff = depth2 - w.dist;
+            float dist = w.d2 * dist_inv;                               // |p'|: rsq estimate + one Newton step (< 1 ulp)
+            dist = fmaf(0.5f * dist_inv, fmaf(-dist, dist, w.d2), dist);
+            const float depthDiff = depth2 - dist;
             const float sd = ec.sigma_depth * depth2;
             const float wd = weight_huber_fast(depthDiff, sd) * fast_rcp(sd);
             const float res = wd * depthDiff;
@@ -499,6 +502,7 @@ __device__ __forceinline__ bool lu_inverse6_lanes(const float* M /*LDS, column-m
                 float t = a[k]; a[k] = a[r]; a[r] = t;
                 t = ck[k]; ck[k] = ck[r]; ck[r] = t;
             }
+        // the five quotients are independent: their correctly rounded division sequences interleave
 #pragma unroll
         for (int r = k + 1; r < 6; ++r) {
             const float l = ck[r] / ck[k];
@@ -614,11 +618,17 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(GNState* st_g, const do
     // write-back at the end; the single-lane bookkeeping below then never waits on global memory.
     __shared__ GNState sst;
     __shared__ double red[kSolveThreads / kNumPartials][kNumPartials];
-    __shared__ float shH[36], shM[36], shg[6], shInv[36], shUpd[6], shE[16];
+    __shared__ float shH[36], shM[36], shg[6], shInv[36], shE[16];
     __shared__ int shGo, shRank, shLuOk;
     constexpr int kStateWords = sizeof(GNState) / 4;
     static_assert(sizeof(GNState) % 4 == 0 && kStateWords <= kSolveThreads, "GNState staging");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef RGBD360_SOLVE_STAMPS
+    unsigned long long stamp0 = __builtin_amdgcn_s_memrealtime(), stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define STAMP(i) if (tid == 0) stamp[i] = __builtin_amdgcn_s_memrealtime() - stamp0
+#else
+#define STAMP(i)
+#endif
     if (tid < kStateWords) reinterpret_cast<int*>(&sst)[tid] = reinterpret_cast<const int*>(st_g)[tid];
     const int v = tid % kNumPartials, q = tid / kNumPartials;
     constexpr int Q = kSolveThreads / kNumPartials;
@@ -637,6 +647,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(GNState* st_g, const do
     }
     red[q][v] = s;
     __syncthreads();
+    STAMP(0);
     if (cfg.mode == 0 && sst.done) return;      // uniform: the level already finished
     if (tid < kNumPartials) {
         double t = 0.0;
@@ -647,79 +658,94 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(GNState* st_g, const do
     __syncthreads();
     GNState* st = &sst;
     const double* tot = sst.tot;
-    if (tid == 0) {
-        st->n_evals += 1;
-        // normal equations at the evaluated pose (float like the reference's `hessian` / `gradient`)
-        int k = 0;
-#pragma unroll
-        for (int a = 0; a < 6; ++a)
-#pragma unroll
-            for (int b = a; b < 6; ++b, ++k) shH[b * 6 + a] = shH[a * 6 + b] = (float)tot[P_H + k];
-#pragma unroll
-        for (int a = 0; a < 6; ++a) shg[a] = (float)tot[P_G + a];
-        const double err2 = tot[P_E2P] + tot[P_E2D];
-        const double nvalid = tot[P_NP] + tot[P_ND];
-        const double new_error = sqrt(err2 / nvalid);   // RPI.h:2738
-        st->new_error = new_error;
-        int go = 0;
-        if (cfg.mode == 1) {
-            for (int i = 0; i < 36; ++i) st->H[i] = shH[i];
-            for (int i = 0; i < 6; ++i) st->g[i] = shg[i];
-        } else {
-            bool take = false, stop = false;
-            if (st->first) {
-                st->first = 0;
-                if (nvalid == 0.0) {
-                    st->status = 2;
-                    st->done = 1;
-                    stop = true;
-                } else {
-                    st->error = new_error;           // RPI.h:4599
-                    st->diff_error = new_error;      // RPI.h:4605
-                    take = true;                     // cand == pose
-                }
+    // ---- bookkeeping on wave 0: lane 0 takes the scalar decisions, lanes 0-41 move the 36 + 6 matrix entries ----
+    if (wave == 0) {
+        // normal equations at the evaluated pose (float like the reference's `hessian` / `gradient`): lane l < 36 owns
+        // H(r,c), r = l/6, c = l%6 (upper-triangle slot a*(13-a)/2 + (b-a)); lanes 36-41 own g
+        float hval = 0.f;
+        if (lane < 36) {
+            const int r = lane / 6, c = lane - 6 * r;
+            const int aa = r < c ? r : c, bb = r < c ? c : r;
+            hval = (float)tot[P_H + (aa * (13 - aa)) / 2 + (bb - aa)];
+        } else if (lane < 42) {
+            hval = (float)tot[P_G + lane - 36];
+        }
+        int take = 0, go = 0;
+        if (lane == 0) {
+            st->n_evals += 1;
+            const double err2 = tot[P_E2P] + tot[P_E2D];
+            const double nvalid = tot[P_NP] + tot[P_ND];
+            const double new_error = sqrt(err2 / nvalid);   // RPI.h:2738
+            st->new_error = new_error;
+            if (cfg.mode == 1) {
+                take = 1;
             } else {
-                const double diff = st->error - new_error;   // RPI.h:4713
-                st->diff_error = diff;
-                if (cfg.forced || diff > cfg.tol_residual) {  // RPI.h:4715-4722
-                    st->lambda = st->lambda / 5.0;
-                    for (int i = 0; i < 16; ++i) st->pose[i] = st->cand[i];
-                    st->error = new_error;
-                    st->it += 1;
-                    take = true;
+                bool stop = false;
+                if (st->first) {
+                    st->first = 0;
+                    if (nvalid == 0.0) {
+                        st->status = 2;
+                        st->done = 1;
+                        stop = true;
+                    } else {
+                        st->error = new_error;           // RPI.h:4599
+                        st->diff_error = new_error;      // RPI.h:4605
+                        take = 1;                        // cand == pose
+                    }
+                } else {
+                    const double diff = st->error - new_error;   // RPI.h:4713
+                    st->diff_error = diff;
+                    if (cfg.forced || diff > cfg.tol_residual) {  // RPI.h:4715-4722
+                        st->lambda = st->lambda / 5.0;
+                        st->error = new_error;
+                        st->it += 1;
+                        take = 2;                        // 2: also promote cand -> pose
+                    }
+                }
+                if (take) {
+                    st->acc_e2p = tot[P_E2P];
+                    st->acc_e2d = tot[P_E2D];
+                    st->acc_np = (long long)tot[P_NP];
+                    st->acc_nd = (long long)tot[P_ND];
+                    st->acc_nvis = (long long)tot[P_NVIS];
+                }
+                if (!stop) {
+                    // while(it < maxIters && update_pose.norm() > tol_update && diff_error > tol_residual)   RPI.h:4611
+                    float un = 0.f;
+                    for (int i = 0; i < 6; ++i) un += st->update[i] * st->update[i];
+                    un = sqrtf(un);
+                    go = cfg.forced || (st->it < cfg.max_iters && (double)un > cfg.tol_update && st->diff_error > cfg.tol_residual);
+                    if (!go) st->done = 1;
+                }
+                if (go) {
+                    st->used_nvis = st->acc_nvis;
+                    st->used_npix = cfg.n_pixels;
                 }
             }
-            if (take) {
-                for (int i = 0; i < 36; ++i) st->H[i] = shH[i];
-                for (int i = 0; i < 6; ++i) st->g[i] = shg[i];
-                st->acc_e2p = tot[P_E2P];
-                st->acc_e2d = tot[P_E2D];
-                st->acc_np = (long long)tot[P_NP];
-                st->acc_nd = (long long)tot[P_ND];
-                st->acc_nvis = (long long)tot[P_NVIS];
-            }
-            if (!stop) {
-                // while(it < maxIters && update_pose.norm() > tol_update && diff_error > tol_residual)   RPI.h:4611
-                float un = 0.f;
-                for (int i = 0; i < 6; ++i) un += st->update[i] * st->update[i];
-                un = sqrtf(un);
-                go = cfg.forced || (st->it < cfg.max_iters && (double)un > cfg.tol_update && st->diff_error > cfg.tol_residual);
-                if (!go) st->done = 1;
-            }
-            if (go) {
-                // a step is only ever computed right after its pose was taken, so st->H/g == shH/shg here;
-                // record them as "used" (what the reference's `hessian` / `SSO` members hold afterwards)
-                for (int i = 0; i < 36; ++i) st->Hused[i] = shH[i];
-                for (int i = 0; i < 6; ++i) st->gused[i] = shg[i];
-                st->used_nvis = st->acc_nvis;
-                st->used_npix = cfg.n_pixels;
-                const float lam = (float)st->lambda;
-                for (int i = 0; i < 36; ++i) shM[i] = shH[i];
-                for (int i = 0; i < 6; ++i) shM[i * 6 + i] = shH[i * 6 + i] + lam * shH[i * 6 + i];   // RPI.h:4682
+            shGo = go;
+        }
+        take = __builtin_amdgcn_readfirstlane(take);
+        go = __builtin_amdgcn_readfirstlane(go);
+        if (take == 2 && lane < 16) st->pose[lane] = st->cand[lane];
+        if (take) {
+            if (lane < 36) st->H[lane] = hval;
+            else if (lane < 42) st->g[lane - 36] = hval;
+        }
+        if (go) {
+            // a step is only ever computed right after its pose was taken, so hval is H / g at `pose`;
+            // record them as "used" (what the reference's `hessian` / `SSO` members hold afterwards)
+            const float lam = (float)st->lambda;
+            if (lane < 36) {
+                st->Hused[lane] = hval;
+                shH[lane] = hval;
+                shM[lane] = (lane % 7 == 0) ? hval + lam * hval : hval;      // H + lambda diag(H)   RPI.h:4682
+            } else if (lane < 42) {
+                st->gused[lane - 36] = hval;
+                shg[lane - 36] = hval;
             }
         }
-        shGo = go;
     }
+    STAMP(1);
     __syncthreads();
     if (shGo) {
         if (wave == 0) {
@@ -735,26 +761,47 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(GNState* st_g, const do
             if (lane == 0) shRank = rk;
         }
         __syncthreads();
+        STAMP(2);
         const bool ill = (shRank != 6) || !shLuOk;
-        if (tid < 6 && !ill) {    // update_pose = (-H^-1) * g, row tid, summed in column order
-            float acc = 0.f;
-#pragma unroll
-            for (int c = 0; c < 6; ++c) acc += (-shInv[c * 6 + tid]) * shg[c];
-            shUpd[tid] = acc;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            if (ill) {
+        if (ill) {
+            if (tid == 0) {
                 st->status = 1;      // "The problem is ILL-POSED": relPose = pose_estim, return   RPI.h:4684-4689
                 st->done = 1;
-            } else {
-                double ud[6], E[16];
-                for (int i = 0; i < 6; ++i) ud[i] = (double)shUpd[i];
-                gn::se3_pseudo_exp(ud, E);       // CPose3D::exp(update, true)   RPI.h:4697
-                for (int i = 0; i < 16; ++i) shE[i] = (float)E[i];
-                for (int i = 0; i < 6; ++i) st->update[i] = shUpd[i];
+            }
+        } else if (wave == 0) {
+            // update_pose = (-H^-1) * g, row `lane`, summed in column order
+            float upd = 0.f;
+            if (lane < 6) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) upd += (-shInv[c * 6 + lane]) * shg[c];
+                st->update[lane] = upd;
+            }
+            // CPose3D::exp(update, true) (RPI.h:4697): every lane evaluates the two scalar coefficients, lane 4*j+i
+            // assembles element (i,j) of the 4x4
+            const double ux = (double)bcast(upd, 0), uy = (double)bcast(upd, 1), uz = (double)bcast(upd, 2);
+            const double wx = (double)bcast(upd, 3), wy = (double)bcast(upd, 4), wz = (double)bcast(upd, 5);
+            const double angle = sqrt(wx * wx + wy * wy + wz * wz);
+            double ca = 0.0, cb = 0.0;
+            const bool rot = angle >= 128 * 2.220446049250313e-16;
+            if (rot) gn::sinc_cosc(angle, ca, cb);
+            if (lane < 16) {
+                const int i = lane & 3, j = lane >> 2;
+                double e = (i == j) ? 1.0 : 0.0;
+                if (i < 3 && j < 3) {
+                    if (rot) {
+                        const double W[3][3] = {{0, -wz, wy}, {wz, 0, -wx}, {-wy, wx, 0}};
+                        double w2 = 0;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) w2 += W[i][k] * W[k][j];
+                        e += ca * W[i][j] + cb * w2;
+                    }
+                } else if (j == 3 && i < 3) {
+                    e = i == 0 ? ux : (i == 1 ? uy : uz);
+                }
+                shE[lane] = (float)e;
             }
         }
+        STAMP(3);
         __syncthreads();
         if (tid < 16 && !ill) {   // pose_estim_temp = exp(...).cast<float>() * pose_estim
             const int c = tid >> 2, r = tid & 3;
@@ -764,7 +811,15 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(GNState* st_g, const do
         }
         __syncthreads();
     }
+#ifdef RGBD360_SOLVE_STAMPS
+    if (tid == 0) {
+        stamp[4] = __builtin_amdgcn_s_memrealtime() - stamp0;
+        for (int i = 0; i < 8; ++i) sst.stamps[i] = stamp[i];
+    }
+    __syncthreads();
+#endif
     if (tid < kStateWords) reinterpret_cast<int*>(st_g)[tid] = reinterpret_cast<const int*>(&sst)[tid];
+#undef STAMP
 }
 
 // Standalone GN step for tests: one thread.

