@@ -52,7 +52,9 @@ struct EvalConsts {
 struct GNState {
     float  cand[16];     // pose the next / last fused pass is evaluated at (first: read by every k_eval block)
     int    done;         // level finished (or status != 0): later launches of this level exit immediately
-    int    it, status, first, n_evals, pad0, pad1, pad2;
+    int    level_active; // pyramid level being optimised; launches tagged with another level are no-ops
+    int    it, status, first, n_evals, pad1, pad2;
+    int    iters[8];     // accepted iterations per level (num_iterations, RPI.h:177)
     float  pose[16];     // accepted pose of the current level
     float  H[36], g[6];  // normal equations at `pose`
     float  Hused[36], gused[6];  // those of the last Gauss-Newton step actually taken (= reference `hessian`)
@@ -66,6 +68,7 @@ struct GNState {
 };
 
 struct SolveCfg {
+    int    level;         // pyramid level this launch belongs to
     int    mode;          // 0 Gauss-Newton logic, 1 reduce only
     int    forced;        // apply every step, never terminate
     int    max_iters;
@@ -356,7 +359,7 @@ __device__ __forceinline__ void consume_stage(PixW& w, const LevelDev& lv, const
 
 template <int METHOD, bool HG>
 __global__ __launch_bounds__(kEvalThreads) void k_eval(LevelDev lv, EvalConsts ec, const GNState* __restrict__ st,
-                                                        double* __restrict__ partials, int chunk) {
+                                                        double* __restrict__ partials, int chunk, int level) {
     const int nb = gridDim.x;
     const int b = blockIdx.x;
     const int cb = ((nb & 7) == 0) ? (b & 7) * (nb >> 3) + (b >> 3) : b;
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval(LevelDev lv, EvalConsts e
     // the first two source records do not depend on the state: issue them before the scalar loads of done / pose
     float4 sA = lv.src[min(i, last)];
     float4 sB = lv.src[min(i + kEvalThreads, last)];
-    if (st->done) return;
+    if (st->done || st->level_active != level) return;     // speculatively enqueued launch of a finished / later level
     const PoseRT T = load_pose(st->cand);
 
     EvalAcc A;
@@ -441,16 +444,21 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval(LevelDev lv, EvalConsts e
 struct Pose16 {
     float v[16];
 };
-__global__ void k_level_init(GNState* st, Pose16 pose, int use_pose, int reset_all) {
+__global__ void k_level_init(GNState* st, Pose16 pose, int use_pose, int reset_all, int level) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (reset_all) {
         for (int k = 0; k < 36; ++k) st->H[k] = st->Hused[k] = 0.f;
         for (int k = 0; k < 6; ++k) st->g[k] = st->gused[k] = 0.f;
+        for (int k = 0; k < 8; ++k) st->iters[k] = 0;
         st->status = 0;
         st->n_evals = 0;
         st->acc_e2p = st->acc_e2d = 0.0;
         st->acc_np = st->acc_nd = st->acc_nvis = st->used_nvis = st->used_npix = 0;
+    } else {
+        // entered speculatively right behind the previous level's launches: only proceed if that level really finished
+        if (st->status != 0 || !st->done || st->level_active != level + 1) return;
     }
+    st->level_active = level;
     if (use_pose)
         for (int k = 0; k < 16; ++k) st->pose[k] = pose.v[k];
     for (int k = 0; k < 16; ++k) st->cand[k] = st->pose[k];
@@ -458,7 +466,7 @@ __global__ void k_level_init(GNState* st, Pose16 pose, int use_pose, int reset_a
     st->lambda = 1.0;
     st->it = 0;
     st->first = 1;
-    st->done = (st->status != 0) ? 1 : 0;
+    st->done = 0;
     st->error = st->new_error = st->diff_error = 0.0;
 }
 
@@ -648,7 +656,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(GNState* st_g, const do
     red[q][v] = s;
     __syncthreads();
     STAMP(0);
-    if (cfg.mode == 0 && sst.done) return;      // uniform: the level already finished
+    if (cfg.mode == 0 && (sst.done || sst.level_active != cfg.level)) return;      // uniform: finished / other level
     if (tid < kNumPartials) {
         double t = 0.0;
 #pragma unroll
@@ -699,6 +707,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(GNState* st_g, const do
                         st->lambda = st->lambda / 5.0;
                         st->error = new_error;
                         st->it += 1;
+                        st->iters[cfg.level & 7] = st->it;
                         take = 2;                        // 2: also promote cand -> pose
                     }
                 }

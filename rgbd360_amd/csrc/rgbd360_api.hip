@@ -49,7 +49,8 @@ struct rgbd360_ctx {
     uint8_t* d_stage_rgb = nullptr;
     uint8_t* d_stage_depth = nullptr;
     size_t stage_rgb_bytes = 0, stage_depth_bytes = 0;
-    int poll_chunk = 2;           // {pass, solve} pairs enqueued between two polls of the done flag
+    int poll_chunk = 3;           // {pass, solve} pairs per level enqueued ahead of the device
+    int first_chunk_top = 8;      // ... and for the first visit of the coarsest level (cheap passes, most iterations)
     // Frame360 stage scratch (normals / plane segmentation), grown on demand
     size_t f360_n = 0;
     float *f_xyz = nullptr, *f_normals = nullptr, *f_dist = nullptr, *f_plane_d = nullptr;
@@ -169,7 +170,7 @@ void launch_eval(rgbd360_ctx* ctx, int level, int method, bool hg) {
     const LevelDev lv = level_dev(L);
     const EvalConsts ec = eval_consts(ctx->p);
     dim3 g(L.nblocks), b(kEvalThreads);
-#define LAUNCH(M, HG) hipLaunchKernelGGL((k_eval<M, HG>), g, b, 0, ctx->stream, lv, ec, ctx->d_state, ctx->d_partials, L.chunk)
+#define LAUNCH(M, HG) hipLaunchKernelGGL((k_eval<M, HG>), g, b, 0, ctx->stream, lv, ec, ctx->d_state, ctx->d_partials, L.chunk, level)
     if (hg) {
         if (method == 0) LAUNCH(0, true);
         else if (method == 1) LAUNCH(1, true);
@@ -185,16 +186,16 @@ void launch_eval(rgbd360_ctx* ctx, int level, int method, bool hg) {
 void launch_solve(rgbd360_ctx* ctx, int level, int mode, int forced) {
     const Level& L = ctx->levels[level];
     SolveCfg cfg;
-    cfg.mode = mode; cfg.forced = forced; cfg.max_iters = ctx->p.max_iters; cfg.n_pixels = L.n;
+    cfg.level = level; cfg.mode = mode; cfg.forced = forced; cfg.max_iters = ctx->p.max_iters; cfg.n_pixels = L.n;
     cfg.tol_residual = ctx->p.tol_residual; cfg.tol_update = ctx->p.tol_update;
     hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), 0, ctx->stream, ctx->d_state, ctx->d_partials, L.nblocks, cfg);
 }
 
-void launch_level_init(rgbd360_ctx* ctx, const float* pose, int reset_all) {
+void launch_level_init(rgbd360_ctx* ctx, int level, const float* pose, int reset_all) {
     Pose16 P;
     if (pose) memcpy(P.v, pose, sizeof(P.v));
     else memset(P.v, 0, sizeof(P.v));
-    hipLaunchKernelGGL(k_level_init, dim3(1), dim3(64), 0, ctx->stream, ctx->d_state, P, pose ? 1 : 0, reset_all);
+    hipLaunchKernelGGL(k_level_init, dim3(1), dim3(64), 0, ctx->stream, ctx->d_state, P, pose ? 1 : 0, reset_all, level);
 }
 
 int read_state(rgbd360_ctx* ctx) {
@@ -321,6 +322,10 @@ int rgbd360_create(const rgbd360_params* p, rgbd360_ctx** out) {
         const int v = atoi(e);
         if (v >= 1 && v <= 16) ctx->poll_chunk = v;
     }
+    if (const char* e = getenv("RGBD360_FIRST_CHUNK")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 16) ctx->first_chunk_top = v;
+    }
     bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreate(&ctx->ev0) == hipSuccess && hipEventCreate(&ctx->ev1) == hipSuccess &&
               hipMalloc(&ctx->d_state, sizeof(GNState)) == hipSuccess &&
@@ -409,24 +414,34 @@ int rgbd360_align360(rgbd360_ctx* ctx, const float guess[16], int method, int oc
     hipSetDevice(ctx->p.device);
     rgbd360_result R;
     memset(&R, 0, sizeof(R));
-    for (int level = ctx->p.n_pyr - 1; level >= 0; --level) {
-        const bool top = (level == ctx->p.n_pyr - 1);
-        launch_level_init(ctx, top ? guess : nullptr, top ? 1 : 0);
-        int guard = 0;
-        for (;;) {
-            for (int k = 0; k < ctx->poll_chunk; ++k) {
+    // The whole coarse-to-fine schedule is enqueued ahead of the device: every launch carries its level and turns into
+    // a no-op unless that level is the active, unfinished one (k_level_init of level l only fires once level l+1 has
+    // finished).  In the common case -- each level converges within its first chunk -- the host synchronises ONCE per
+    // alignment; a level that needs more passes gets another chunk, followed again by the finer levels.
+    const int top = ctx->p.n_pyr - 1;
+    int pending = top;           // coarsest level not known to be finished
+    bool pending_started = false;
+    for (int round = 0;; ++round) {
+        for (int level = pending; level >= 0; --level) {
+            if (!(level == pending && pending_started)) launch_level_init(ctx, level, level == top ? guess : nullptr, level == top ? 1 : 0);
+            const int n_pairs = (level == top && !pending_started) ? ctx->first_chunk_top : ctx->poll_chunk;
+            for (int k = 0; k < n_pairs; ++k) {
                 launch_eval(ctx, level, method, true);
                 launch_solve(ctx, level, 0, 0);
             }
-            HIPC(ctx, hipGetLastError());
-            rc = read_state(ctx);
-            if (rc) return rc;
-            if (ctx->h_state->done) break;
-            if (++guard > ctx->p.max_iters + 4) return fail(ctx, -6, "alignment loop did not terminate");
         }
-        R.iters[level] = ctx->h_state->it;
-        if (ctx->h_state->status != 0) break;
+        HIPC(ctx, hipGetLastError());
+        rc = read_state(ctx);
+        if (rc) return rc;
+        const GNState& S = *ctx->h_state;
+        if (S.status != 0) break;
+        if (S.level_active == 0 && S.done) break;
+        if (S.done) return fail(ctx, -6, "alignment schedule stalled between levels");
+        pending = S.level_active;
+        pending_started = true;
+        if (round > (ctx->p.max_iters + 4) * ctx->p.n_pyr) return fail(ctx, -6, "alignment loop did not terminate");
     }
+    for (int l = 0; l < ctx->p.n_pyr && l < 8; ++l) R.iters[l] = ctx->h_state->iters[l];
     const GNState& S = *ctx->h_state;
     memcpy(pose_out, S.pose, sizeof(float) * 16);
     R.status = S.status;
@@ -493,7 +508,7 @@ int rgbd360_eval(rgbd360_ctx* ctx, int level, const float pose[16], int method, 
     if (rc) return rc;
     if (!pose) return fail(ctx, -1, "null pose pointer");
     hipSetDevice(ctx->p.device);
-    launch_level_init(ctx, pose, 1);
+    launch_level_init(ctx, level, pose, 1);
     launch_eval(ctx, level, method, true);
     launch_solve(ctx, level, 1, 0);
     HIPC(ctx, hipGetLastError());
@@ -561,7 +576,7 @@ int rgbd360_forced_iters(rgbd360_ctx* ctx, int level, const float pose0[16], int
     if (rc) return rc;
     if (!pose0 || n_iters < 1) return fail(ctx, -1, "bad arguments");
     hipSetDevice(ctx->p.device);
-    launch_level_init(ctx, pose0, 1);
+    launch_level_init(ctx, level, pose0, 1);
     HIPC(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     for (int k = 0; k < n_iters; ++k) {
         launch_eval(ctx, level, method, true);
@@ -583,7 +598,7 @@ int rgbd360_time_eval_kernel(rgbd360_ctx* ctx, int level, const float pose[16], 
     if (rc) return rc;
     if (!pose || reps < 1 || !avg_us) return fail(ctx, -1, "bad arguments");
     hipSetDevice(ctx->p.device);
-    launch_level_init(ctx, pose, 1);
+    launch_level_init(ctx, level, pose, 1);
     launch_eval(ctx, level, method, want_hg != 0);   // warm-up
     HIPC(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     for (int k = 0; k < reps; ++k) launch_eval(ctx, level, method, want_hg != 0);

@@ -1,1 +1,1 @@
-for nb in 512 1024; do echo "== RGBD360_EVAL_BLOCKS=$nb"; RGBD360_EVAL_BLOCKS=$nb python tools/quick_perf.py | grep -E "hg 1|forced|full align|level 3"; done
+for pc in 1 2 3 4 6; do echo "== RGBD360_POLL_CHUNK=$pc"; RGBD360_POLL_CHUNK=$pc python tools/quick_perf.py | grep -E "full align"; done
