@@ -1,0 +1,34 @@
+"""BASELINE.json configs[0] (plumbing, CPU only): the reference's own sample frames through the restated .bin reader,
+the restated spherical stitcher and the CPU oracle.  Runs only where /root/reference is mounted (the build container);
+the GPU box never sees the reference.  Expected values: tests/golden/config1_samples.json (tools/config1_samples.py --write)."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SAMPLES = "/root/reference/samples/sphere_images_1.bin"
+
+
+@pytest.mark.skipif(not os.path.exists(SAMPLES), reason="reference samples are only present in the build container")
+def test_sample_pair_stitches_and_aligns_like_the_committed_record():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import config1_samples as c1
+    from rgbd360_amd import synth
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "config1_samples.json")))
+    out, pano = c1.run()
+    assert out["sensor_image_shape"] == [240, 320, 3] and out["panorama_shape"] == [320, 1920, 3]
+    assert out["crc32"] == gold["crc32"]                       # byte-exact stitched panoramas
+    assert all(f > 0.5 for f in out["valid_depth_fraction"])
+    for name in ("PHOTO_CONSISTENCY", "PHOTO_DEPTH"):
+        assert out[name]["status"] == gold[name]["status"] == 0
+        assert out[name]["iters"] == gold[name]["iters"]
+        rot, trans = synth.pose_error(np.array(out[name]["pose"]), np.array(gold[name]["pose"]))
+        assert rot < 1e-6 and trans < 1e-6
+    # sanity of the recovered motion between frames 1 and 10 of the sample sequence: a hand-held rig moved by a few
+    # decimetres, rotated by about a degree
+    T = np.array(out["PHOTO_DEPTH"]["pose"])
+    rot, trans = synth.pose_error(T, np.eye(4))
+    assert 0.05 < trans < 0.6 and rot < 0.1
