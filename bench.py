@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--method", type=int, default=0, help="0 photo (configs[1]), 2 photo+depth (configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-4k", action="store_true", help="skip the extra 4096x2048 (configs[4]) kernel measurement")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -166,6 +167,25 @@ def main():
         result["alignment"] = {"full_pyramid_ms": t_align * 1e3, "iters_per_level": iters_nat, "status": rc,
                                "pose_err_vs_ground_truth": dict(zip(("rot_rad", "trans_m"), synth.pose_error(pose_gpu, T_gt)))}
         result["setup_s"] = {"render_pair": t_gen}
+
+        # ---- the same kernel at 4096x2048 (BASELINE.json configs[4]: working set beyond the 256 MiB Infinity Cache) ----
+        if n_gpus == 1 and not args.no_4k:
+            (a4, d4), (b4, e4), _ = synth.make_pair(4096, 2048, seed=1234)
+            reg4 = RegisterPhotoICP(device=local_rank)
+            reg4.setNumPyr(5)
+            reg4.setTargetFrame(a4, d4)
+            reg4.setSourceFrame(b4, e4)
+            reg4.alignFrames360(np.eye(4), 2)
+            p4 = reg4.getOptimalPose()
+            result["roofline_4096x2048"] = {}
+            for m in (0, 2):
+                us = reg4.time_eval_kernel(0, p4, m, True, 30)
+                ach = BYTES_PER_PX[m] * 4096 * 2048 / (us * 1e-6) / 1e9
+                it = reg4.forced_iters(0, np.eye(4), m, 100)
+                result["roofline_4096x2048"][METHOD_NAMES[m]] = {
+                    "kernel_avg_us": us, "achieved": ach, "frac": ach / HBM_PEAK_GBS, "frac_of_measured_copy_peak": ach / HBM_COPY_GBS,
+                    "gn_iterations_per_s": 100 / (it["elapsed_ms"] * 1e-3)}
+            reg4.close()
 
         # ---- CPU baseline: the oracle on this host's cores, bounded sample (rank 0, N = 1 only) ---------------
         if n_gpus == 1 and not args.no_cpu_baseline:

@@ -24,7 +24,7 @@ namespace r360 {
 
 constexpr float  kInvalidPoint = -10000.f;      // RPI.h:40
 constexpr double kPI = 3.14159265359;           // Miscellaneous.h:44 (truncated literal, double)
-constexpr int    kEvalThreads = 512;
+constexpr int    kEvalThreads = 1024;
 constexpr int    kNumPartials = 32;             // doubles per block partial
 // partial slots
 enum { P_H = 0 /*21*/, P_G = 21 /*6*/, P_E2P = 27, P_E2D = 28, P_NP = 29, P_ND = 30, P_NVIS = 31 };
@@ -208,8 +208,8 @@ __device__ __forceinline__ float wave_sum63(float v) {
 // k_eval: one fused pass over the source pixels of a level at pose st->cand.
 //   METHOD: 0 photo, 1 depth, 2 photo+depth.  HG: also accumulate the 21+6 normal-equation terms.
 // Work split: block b owns the contiguous pixel span [cb*chunk, (cb+1)*chunk) (cb = XCD-aware remap of b so
-// that neighbouring spans, which gather neighbouring target rows, share an XCD L2); its 256 lanes sweep the
-// span in coalesced 256-pixel steps (16 B/lane source records), accumulate in float32 registers, then reduce
+// that neighbouring spans, which gather neighbouring target rows, share an XCD L2); its 1024 lanes sweep the
+// span in coalesced 1024-pixel steps (16 B/lane source records), accumulate in float32 registers, then reduce
 // wave (DPP) -> block (LDS) and store 32 float64 partials.  No atomics: the final sum order is fixed.
 //
 // The pixel body is branch-free: the reference's `continue`s (invalid point, not visible, non-salient) become

@@ -58,7 +58,7 @@ struct rgbd360_ctx {
     uint8_t *f_change = nullptr, *f_hd = nullptr;
     int *f_label = nullptr, *f_count = nullptr, *f_slot_of_root = nullptr, *f_root_of_slot = nullptr, *f_nslots = nullptr, *f_window = nullptr;
     double* f_mom = nullptr;
-    int max_eval_blocks = 512;    // grid cap of the fused pass (tuning knob: RGBD360_EVAL_BLOCKS)
+    int max_eval_blocks = 256;    // grid cap of the fused pass (tuning knob: RGBD360_EVAL_BLOCKS)
     std::string err;
 };
 

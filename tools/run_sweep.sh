@@ -1,1 +1,1 @@
-for pc in 1 2 3 4 6; do echo "== RGBD360_POLL_CHUNK=$pc"; RGBD360_POLL_CHUNK=$pc python tools/quick_perf.py | grep -E "full align"; done
+for nb in 64 128 256 512; do echo "== 1024-thread blocks, RGBD360_EVAL_BLOCKS=$nb"; RGBD360_EVAL_BLOCKS=$nb python tools/quick_perf.py | grep -E "hg 1|forced|full"; done
