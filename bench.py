@@ -37,8 +37,8 @@ METHOD_NAMES = {0: "PHOTO_CONSISTENCY", 1: "DEPTH_CONSISTENCY", 2: "PHOTO_DEPTH"
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--method", type=int, default=0, help="0 photo (configs[1]), 2 photo+depth (configs[2])")
@@ -56,13 +56,22 @@ def main():
 
     import torch
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback in the product path)"
+    # Development aid for 1-GPU boxes: BENCH_SHARE_DEVICE=1 puts every rank on device 0 and uses gloo for the exchange
+    # (RCCL refuses two ranks on one GPU).  The driver never sets it: one rank per GPU, backend nccl (= RCCL).
+    share = os.environ.get("BENCH_SHARE_DEVICE") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    xdev = "cpu" if share else "cuda"       # where the exchanged tensors live
 
     from rgbd360_amd import synth
     from rgbd360_amd.register import RegisterPhotoICP
@@ -102,14 +111,14 @@ def main():
     out = reg.forced_iters(0, start_pose, method, args.steps)
     poses = None
     if dist is not None:
-        mine = torch.from_numpy(out["pose"].reshape(16).copy()).cuda()
-        gathered = torch.empty(world * 16, dtype=torch.float32, device="cuda")
+        mine = torch.from_numpy(out["pose"].reshape(16).copy()).to(xdev)
+        gathered = torch.empty(world * 16, dtype=torch.float32, device=xdev)
         dist.all_gather_into_tensor(gathered, mine)      # RCCL over xGMI: the path's one exchange step
         poses = gathered
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
         assert poses is not None and bool(torch.isfinite(poses).all())

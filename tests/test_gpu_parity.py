@@ -341,3 +341,57 @@ def test_frame_planes_recovers_the_room_walls(hip_lib, oracle_mod):
         found += bool(hits)
     assert found == 6, [(p["count"], p["normal"], p["d"]) for p in big]
     assert out["labels"].shape == (256, 512) and np.isfinite(out["normals"]).any()
+
+
+@pytest.mark.parametrize("W,H,n_pyr", [(480, 80, 3), (250, 101, 3), (1000, 37, 2)])
+def test_ragged_sizes_match_oracle(hip_lib, oracle_mod, W, H, n_pyr):
+    """Sizes that are neither powers of two nor multiples of the block span (the real rig gives 1920x320): odd rows and
+    columns through the pyramids, partially filled last step of the fused pass, seam columns at cols/8."""
+    pair = synth.make_pair(W, H, seed=21)
+    reg, ora, T = _pair_ctx(hip_lib, oracle_mod, pair, n_pyr=n_pyr)
+    for level in range(n_pyr):
+        ora.prepare_level(level)
+        assert reg.level_dims(level) == ora.level_dims(level)
+        for name in ("gray_src", "depth_trg", "gx", "dgy"):
+            assert np.array_equal(reg.plane(name, level), ora.plane(name, level)), (name, level)
+        assert np.array_equal(reg.warp_indices(level, T), ora.warp_indices(level, T))
+        e = reg.eval(level, T, 2)
+        _, err2, nvalid = ora.error(level, T, 2)
+        H_, g_, Hd, gd, nvis = ora.hessgrad(level, T, 2)
+        assert e["n_valid"] == nvalid and e["n_visible"] == nvis
+        assert abs(e["err2"] - err2) <= ERR2_RTOL * max(1.0, err2)
+        assert np.abs(e["H64"] - Hd).max() <= HG_RTOL * np.abs(Hd).max()
+    rc = reg.alignFrames360(np.eye(4), 2)
+    st, pose_ref = ora.align360(np.eye(4), 2)
+    assert rc == st
+    rot, trans = synth.pose_error(reg.getOptimalPose(), pose_ref)
+    assert rot <= POSE_TOL_DEV and trans <= POSE_TOL_DEV
+    assert reg.num_iterations == list(ora.result.iters)[:n_pyr]
+
+
+def test_non_default_parameters_match_oracle(hip_lib, oracle_mod, small_pair):
+    """The setters of RPI.h:224-269 reach the kernels: depth band, standard deviations, no seam mask, 2 levels."""
+    (rgbA, dA), (rgbB, dB), T = small_pair
+    from rgbd360_amd.register import RegisterPhotoICP
+    reg = RegisterPhotoICP()
+    reg.setNumPyr(2); reg.setMinDepth(1.6); reg.setMaxDepth(4.5); reg.setGrayVariance(3.0 / 255); reg.setDepthVariance(0.1)
+    reg.setMaskSeams(False)
+    reg.setTargetFrame(rgbA, dA)
+    reg.setSourceFrame(rgbB, dB)
+    ora = oracle_mod.Oracle(n_pyr=2, min_depth=1.6, max_depth=4.5, sigma_photo=3.0 / 255, sigma_depth=0.1, mask_seams=0,
+                            math_mode=1, reduce_mode=1)
+    ora.set_target(rgbA, dA)
+    ora.set_source(rgbB, dB)
+    for level in range(2):
+        ora.prepare_level(level)
+        assert np.array_equal(reg.plane("gx", level), ora.plane("gx", level))          # unmasked seams
+        assert np.array_equal(reg.plane("depth_src", level), ora.plane("depth_src", level))
+        la, lb = reg.lut(level), ora.lut(level)
+        assert np.array_equal(la[:, 0] != -10000, lb[:, 0] != -10000) and (lb[:, 0] == -10000).any()
+    e = reg.eval(0, T, 2)
+    _, err2, nvalid = ora.error(0, T, 2)
+    assert e["n_valid"] == nvalid and abs(e["err2"] - err2) <= ERR2_RTOL * err2
+    rc = reg.alignFrames360(np.eye(4), 2)
+    st, pose_ref = ora.align360(np.eye(4), 2)
+    rot, trans = synth.pose_error(reg.getOptimalPose(), pose_ref)
+    assert rc == st == 0 and rot <= POSE_TOL_DEV and trans <= POSE_TOL_DEV
