@@ -203,6 +203,21 @@ int rgbd360_frame_planes(rgbd360_ctx* ctx, const void* depth, size_t depth_step,
                          float* xyz_out, float* normals_out, int32_t* labels_out, rgbd360_plane* planes_out, int max_planes,
                          int* n_planes_out);
 
+/* ---- Frame360 input side (the two steps before the path) ------------------------------------------------------- */
+
+/* Frame360::loadFrame (Frame360.h:231-266): reads one `sphere_images_%d.bin` (Boost binary archive of 8 x {RGB 8UC3,
+ * depth 16UC1 mm} cv::Mat records).  Host-only.  rgb_out: 8*rows*cols*3 bytes, depth_out: 8*rows*cols uint16; pass
+ * NULL buffers to query rows / cols first.  Returns 0, -2 cannot open, -3 truncated, -4 unexpected record. */
+int rgbd360_load_frame_bin(const char* path, uint8_t* rgb_out, uint16_t* depth_out, int* rows, int* cols);
+
+/* Frame360::stitchSphericalImage (Frame360.h:386-405, stitchImage :1099-1148): the 8 sensor images (contiguous
+ * [8][sensor_rows][sensor_cols][3] uint8 and [8][sensor_rows][sensor_cols] uint16 mm, host) -> panorama of
+ * W = sensor_rows*8 columns and H = int(W*0.5*60/180) rows (sphere_rgb_out H*W*3, sphere_depth_out H*W range in mm).
+ * Rt_inv: 8 column-major 4x4 (Calib360::Rt_inv), K = {fx, fy, cx, cy} (Calib360.h:74-77). */
+int rgbd360_stitch_sphere(rgbd360_ctx* ctx, const uint8_t* rgb8, const uint16_t* depth8, int sensor_rows, int sensor_cols,
+                          const float Rt_inv[128], const float K[4], uint8_t* sphere_rgb_out, uint16_t* sphere_depth_out,
+                          int* out_rows, int* out_cols);
+
 #ifdef __cplusplus
 }
 #endif

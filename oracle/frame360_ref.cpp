@@ -282,4 +282,49 @@ int oracle_f360_plane_segment(const float* xyz, const float* normals, int rows, 
     return n_planes;
 }
 
+
+// ------------------------------------------------------------------------------------
+// Frame360::stitchSphericalImage / stitchImage (Frame360.h:386-405, 1099-1148): the step right before the alignment
+// path.  rgb[s]: sensor_rows x sensor_cols x 3 uint8, depth[s]: uint16 mm; Rt_inv: 8 column-major
+// 4x4 (Calib360::Rt_inv, Calib360.h:129); K = {fx, fy, cx, cy} (Calib360.h:74-77).  Outputs: H x W x 3 and H x W with
+// W = sensor_rows*8, H = int(W*0.5*60/180), zero where no sensor pixel projects.
+// ------------------------------------------------------------------------------------
+void oracle_stitch_sphere(const uint8_t* const* rgb, const uint16_t* const* depth, int sensor_rows, int sensor_cols,
+                          const float* Rt_inv, const float* K, uint8_t* sphereRGB, uint16_t* sphereDepth) {
+    const double PI = 3.14159265359;
+    const int W = sensor_rows * 8;
+    const int H = (int)(W * 0.5 * 60.0 / 180);
+    memset(sphereRGB, 0, (size_t)H * W * 3);
+    memset(sphereDepth, 0, (size_t)H * W * sizeof(uint16_t));
+    for (int sensor_id = 0; sensor_id < 8; ++sensor_id) {
+        const float* M = Rt_inv + 16 * sensor_id;
+        const int size_w = sensor_cols, size_h = sensor_rows;
+        const float offsetPhi = H / 2 - 0.5;
+        const float offsetTheta = -sensor_rows * 15 / 2 + 0.5;
+        const float angle_pixel = 2 * PI / W;
+        for (int row_phi = 0; row_phi < H; ++row_phi) {
+            const float phi_i = (offsetPhi - row_phi) * angle_pixel;
+            const float v0 = sinf(phi_i);
+            const float cos_phi = cosf(phi_i);
+            const int init_col_sphere = (7 - sensor_id) * size_h, end_col_sphere = (8 - sensor_id) * size_h;
+            for (int col_theta = init_col_sphere; col_theta < end_col_sphere; ++col_theta) {
+                const float theta_i = (col_theta + offsetTheta) * angle_pixel;
+                const float v1 = cos_phi * sinf(theta_i);
+                const float v2 = cos_phi * cosf(theta_i);
+                float p[3];
+                for (int i = 0; i < 3; ++i) p[i] = ((M[0 * 4 + i] * v0 + M[1 * 4 + i] * v1) + M[2 * 4 + i] * v2) + M[3 * 4 + i];
+                const float u = K[0] * p[0] / p[2] + K[2];
+                const float v = K[1] * p[1] / p[2] + K[3];
+                if (u >= 0 && u < size_w && v >= 0 && v < size_h) {
+                    const int ui = (int)u, vi = (int)v;
+                    const size_t o = (size_t)row_phi * W + col_theta, in = (size_t)vi * size_w + ui;
+                    for (int k = 0; k < 3; ++k) sphereRGB[3 * o + k] = rgb[sensor_id][3 * in + k];
+                    sphereDepth[o] = depth[sensor_id][in] * sqrt(1 + pow((u - K[2]) / K[0], 2) + pow((v - K[3]) / K[1], 2));
+                }
+            }
+        }
+    }
+}
+
 }  // extern "C"
+

@@ -281,6 +281,26 @@ def f360_plane_segment(xyz, normals, rows, cols, min_inliers=40, angular_thresho
     return labels.reshape(rows, cols), planes
 
 
+def stitch_sphere(rgb8, depth8, Rt_inv, K=(262.5, 262.5, 159.5, 119.5)):
+    """Frame360::stitchSphericalImage restated (oracle/frame360_ref.cpp).  Rt_inv: [8,4,4] row-major numpy."""
+    rgb8 = np.ascontiguousarray(rgb8, np.uint8)
+    depth8 = np.ascontiguousarray(depth8, np.uint16)
+    _, rows, cols, _ = rgb8.shape
+    W = rows * 8
+    H = int(W * 0.5 * 60.0 / 180)
+    M = np.ascontiguousarray(np.asarray(Rt_inv, np.float32).transpose(0, 2, 1).reshape(8 * 16))
+    Kc = np.asarray(K, np.float32)
+    out_rgb = np.empty((H, W, 3), np.uint8)
+    out_d = np.empty((H, W), np.uint16)
+    rp = (C.c_void_p * 8)(*[rgb8[s].ctypes.data for s in range(8)])
+    dp = (C.c_void_p * 8)(*[depth8[s].ctypes.data for s in range(8)])
+    f = lib().oracle_stitch_sphere
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    f.restype = None
+    f(rp, dp, rows, cols, _ptr(M), _ptr(Kc), _ptr(out_rgb), _ptr(out_d))
+    return out_rgb, out_d
+
+
 def num_threads() -> int:
     return int(lib().oracle_num_threads())
 

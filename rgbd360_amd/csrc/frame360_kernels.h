@@ -266,4 +266,42 @@ __global__ void k_f360_moments(const float* __restrict__ xyz, const int* __restr
     }
 }
 
+// Frame360::stitchImage (Frame360.h:1099-1148): one thread per panorama pixel; the sensor is fixed by the column band.
+// sin/cos tables of the row / column angles come from the host's libm (the reference evaluates them per row / pixel).
+struct StitchArgs {
+    float Rt_inv[8][16];     // column-major 4x4 per sensor
+    float fx, fy, cx, cy;
+    int   sensor_rows, sensor_cols, W, H;
+};
+__global__ void k_stitch_sphere(StitchArgs a, const uint8_t* __restrict__ rgb /*[8][rows][cols][3]*/,
+                                const uint16_t* __restrict__ depth /*[8][rows][cols]*/, const float* __restrict__ sin_phi,
+                                const float* __restrict__ cos_phi, const float* __restrict__ sin_theta,
+                                const float* __restrict__ cos_theta, uint8_t* __restrict__ sphereRGB, uint16_t* __restrict__ sphereDepth) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x, row = blockIdx.y;
+    if (col >= a.W || row >= a.H) return;
+    const int sensor = 7 - col / a.sensor_rows;
+    const float* M = a.Rt_inv[sensor];
+    const float v0 = sin_phi[row];
+    const float v1 = cos_phi[row] * sin_theta[col];
+    const float v2 = cos_phi[row] * cos_theta[col];
+    float p[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) p[i] = ((M[0 * 4 + i] * v0 + M[1 * 4 + i] * v1) + M[2 * 4 + i] * v2) + M[3 * 4 + i];
+    const float u = a.fx * p[0] / p[2] + a.cx;
+    const float v = a.fy * p[1] / p[2] + a.cy;
+    const size_t o = (size_t)row * a.W + col;
+    uint8_t r = 0, g = 0, b = 0;
+    uint16_t d = 0;
+    if (u >= 0 && u < a.sensor_cols && v >= 0 && v < a.sensor_rows) {
+        const int ui = (int)u, vi = (int)v;
+        const size_t in = ((size_t)sensor * a.sensor_rows + vi) * a.sensor_cols + ui;
+        r = rgb[3 * in]; g = rgb[3 * in + 1]; b = rgb[3 * in + 2];
+        // range = depth * sqrt(1 + x^2 + y^2) in double, truncated to unsigned short (Frame360.h:1141)
+        const double xn = (double)((u - a.cx) / a.fx), yn = (double)((v - a.cy) / a.fy);
+        d = (uint16_t)((double)depth[in] * sqrt(1 + xn * xn + yn * yn));
+    }
+    sphereRGB[3 * o] = r; sphereRGB[3 * o + 1] = g; sphereRGB[3 * o + 2] = b;
+    sphereDepth[o] = d;
+}
+
 }  // namespace f360

@@ -963,3 +963,89 @@ extern "C" int rgbd360_frame_planes(rgbd360_ctx* ctx, const void* depth, size_t 
     if (labels_out) HIPC(ctx, hipMemcpy(labels_out, ctx->f_label, n * sizeof(int), hipMemcpyDeviceToHost));
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Frame360 input side: the .bin reader and the spherical stitcher, i.e. the two steps between
+// the sensor rig's raw frames and rgbd360_set_target / _source.
+// ---------------------------------------------------------------------------------------------------------
+extern "C" int rgbd360_load_frame_bin(const char* path, uint8_t* rgb_out, uint16_t* depth_out, int* rows, int* cols) {
+    // Frame360::loadFrame (Frame360.h:231-266): boost::archive::binary_iarchive of 8 x {cv::Mat rgb 8UC3, cv::Mat depth
+    // 16UC1} + a timestamp Mat; every Mat = int32 cols, int32 rows, uint64 elemSize, uint64 cvType, raw bytes
+    // (cvmat_serialization.h:23-36) behind the archive's 45-byte header.
+    if (!path || !rows || !cols) return -1;
+    FILE* f = fopen(path, "rb");
+    if (!f) return -2;
+    int rc = 0;
+    if (fseek(f, 45, SEEK_SET) != 0) rc = -3;
+    for (int m = 0; m < 16 && rc == 0; ++m) {
+        int32_t c = 0, r = 0;
+        uint64_t elem = 0, type = 0;
+        if (fread(&c, 4, 1, f) != 1 || fread(&r, 4, 1, f) != 1 || fread(&elem, 8, 1, f) != 1 || fread(&type, 8, 1, f) != 1) { rc = -3; break; }
+        const bool is_rgb = (m % 2) == 0;
+        if (c <= 0 || r <= 0 || c > 8192 || r > 8192 || elem != (is_rgb ? 3u : 2u) || type != (is_rgb ? 16u : 2u)) { rc = -4; break; }   // CV_8UC3 = 16, CV_16UC1 = 2
+        if (m == 0) { *rows = r; *cols = c; }
+        else if (r != *rows || c != *cols) { rc = -4; break; }
+        const size_t bytes = (size_t)c * r * elem;
+        void* dst = is_rgb ? (void*)(rgb_out ? rgb_out + (size_t)(m / 2) * bytes : nullptr)
+                           : (void*)(depth_out ? depth_out + (size_t)(m / 2) * (bytes / 2) : nullptr);
+        if (dst) {
+            if (fread(dst, 1, bytes, f) != bytes) rc = -3;
+        } else if (fseek(f, (long)bytes, SEEK_CUR) != 0) rc = -3;
+    }
+    fclose(f);
+    return rc;
+}
+
+extern "C" int rgbd360_stitch_sphere(rgbd360_ctx* ctx, const uint8_t* rgb8, const uint16_t* depth8, int sensor_rows, int sensor_cols,
+                                     const float Rt_inv[128], const float K[4], uint8_t* sphere_rgb_out, uint16_t* sphere_depth_out,
+                                     int* out_rows, int* out_cols) {
+    if (!ctx || !rgb8 || !depth8 || !Rt_inv || !K || !sphere_rgb_out || !sphere_depth_out) return -1;
+    if (sensor_rows < 1 || sensor_cols < 1 || sensor_rows > 4096 || sensor_cols > 4096) return fail(ctx, -1, "bad sensor image size");
+    hipSetDevice(ctx->p.device);
+    f360::StitchArgs a;
+    memcpy(a.Rt_inv, Rt_inv, sizeof(a.Rt_inv));
+    a.fx = K[0]; a.fy = K[1]; a.cx = K[2]; a.cy = K[3];
+    a.sensor_rows = sensor_rows; a.sensor_cols = sensor_cols;
+    a.W = sensor_rows * 8;                               // Frame360.h:391
+    a.H = (int)(a.W * 0.5 * 60.0 / 180);                 // Frame360.h:392
+    if (out_rows) *out_rows = a.H;
+    if (out_cols) *out_cols = a.W;
+    const float offsetPhi = a.H / 2 - 0.5;               // Frame360.h:1104-1106
+    const float offsetTheta = -sensor_rows * 15 / 2 + 0.5;
+    const float angle_pixel = 2 * kPI / a.W;
+    std::vector<float> tab((size_t)2 * a.H + 2 * a.W);
+    for (int r = 0; r < a.H; ++r) {
+        const float phi_i = (offsetPhi - r) * angle_pixel;
+        tab[r] = sinf(phi_i);
+        tab[a.H + r] = cosf(phi_i);
+    }
+    for (int c = 0; c < a.W; ++c) {
+        const float theta_i = (c + offsetTheta) * angle_pixel;
+        tab[2 * a.H + c] = sinf(theta_i);
+        tab[2 * a.H + a.W + c] = cosf(theta_i);
+    }
+    const size_t n_in = (size_t)8 * sensor_rows * sensor_cols, n_out = (size_t)a.H * a.W;
+    uint8_t *d_rgb = nullptr, *d_out_rgb = nullptr;
+    uint16_t *d_depth = nullptr, *d_out_depth = nullptr;
+    float* d_tab = nullptr;
+    hipError_t e = hipMalloc(&d_rgb, n_in * 3);
+    if (e == hipSuccess) e = hipMalloc(&d_depth, n_in * 2);
+    if (e == hipSuccess) e = hipMalloc(&d_out_rgb, n_out * 3);
+    if (e == hipSuccess) e = hipMalloc(&d_out_depth, n_out * 2);
+    if (e == hipSuccess) e = hipMalloc(&d_tab, tab.size() * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_rgb, rgb8, n_in * 3, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_depth, depth8, n_in * 2, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(f360::k_stitch_sphere, grid2d(a.H, a.W), dim3(256), 0, ctx->stream, a, d_rgb, d_depth, d_tab, d_tab + a.H,
+                           d_tab + 2 * a.H, d_tab + 2 * a.H + a.W, d_out_rgb, d_out_depth);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(sphere_rgb_out, d_out_rgb, n_out * 3, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(sphere_depth_out, d_out_depth, n_out * 2, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipFree(d_rgb); hipFree(d_depth); hipFree(d_out_rgb); hipFree(d_out_depth); hipFree(d_tab);
+    HIPC(ctx, e);
+    return 0;
+}
+

@@ -337,6 +337,42 @@ class Frame360Stages:
         return dict(xyz=xyz, normals=nrm, labels=labels.reshape(rows, cols), planes=_planes_to_dicts(arr, n.value))
 
 
+QVGA_K = (262.5, 262.5, 159.5, 119.5)       # Calib360.h:74-77 (fx, fy, cx, cy)
+
+
+def load_frame_bin(path: str):
+    """Frame360::loadFrame: -> (rgb [8,rows,cols,3] uint8, depth [8,rows,cols] uint16 mm).  Host-only, no GPU needed."""
+    L = _lib.load()
+    r, c = C.c_int(), C.c_int()
+    rc = L.rgbd360_load_frame_bin(path.encode(), None, None, C.byref(r), C.byref(c))
+    if rc != 0:
+        raise Rgbd360Error(f"rgbd360_load_frame_bin({path}) failed ({rc})")
+    rgb = np.empty((8, r.value, c.value, 3), np.uint8)
+    depth = np.empty((8, r.value, c.value), np.uint16)
+    rc = L.rgbd360_load_frame_bin(path.encode(), _ptr(rgb), _ptr(depth), C.byref(r), C.byref(c))
+    if rc != 0:
+        raise Rgbd360Error(f"rgbd360_load_frame_bin({path}) failed ({rc})")
+    return rgb, depth
+
+
+def stitch_sphere(reg: RegisterPhotoICP, rgb8, depth8, Rt_inv, K=QVGA_K):
+    """Frame360::stitchSphericalImage on the device.  Rt_inv: [8,4,4] (row-major numpy)."""
+    rgb8 = np.ascontiguousarray(rgb8, np.uint8)
+    depth8 = np.ascontiguousarray(depth8, np.uint16)
+    _, rows, cols, _ = rgb8.shape
+    W = rows * 8
+    H = int(W * 0.5 * 60.0 / 180)
+    M = np.ascontiguousarray(np.asarray(Rt_inv, np.float32).transpose(0, 2, 1).reshape(8 * 16))    # column-major per sensor
+    Kc = np.asarray(K, np.float32)
+    out_rgb = np.empty((H, W, 3), np.uint8)
+    out_d = np.empty((H, W), np.uint16)
+    r, c = C.c_int(), C.c_int()
+    reg._check(reg._L.rgbd360_stitch_sphere(reg._ctx(), _ptr(rgb8), _ptr(depth8), rows, cols, _ptr(M), _ptr(Kc), _ptr(out_rgb),
+                                            _ptr(out_d), C.byref(r), C.byref(c)))
+    assert (r.value, c.value) == (H, W)
+    return out_rgb, out_d
+
+
 def Register(frame_trg, frame_src, pose: np.ndarray, method: int = RegisterPhotoICP.PHOTO_DEPTH, reg=None) -> bool:
     """The north-star convenience shape `Register(Frame360&, Frame360&, Matrix4f&) -> bool`: frames are any objects
     with `sphereRGB` / `sphereDepth` (Frame360.h:104-111); `pose` is the initial guess and is overwritten in place."""

@@ -108,3 +108,28 @@ def test_pose_layout_helpers():
     cm = pose_to_cm(T)
     assert cm[12] == T[0, 3] and cm[1] == T[1, 0]       # column-major like Eigen::Matrix4f::data()
     assert np.array_equal(pose_from_cm(cm), T)
+
+
+def test_bin_loader_reads_the_boost_archive_layout(tmp_path):
+    """rgbd360_load_frame_bin (host-only) on a file written in the layout of Frame360::serialize / cvmat_serialization.h."""
+    import struct
+    from rgbd360_amd.register import Rgbd360Error, load_frame_bin
+    rng = np.random.default_rng(0)
+    rows, cols = 12, 16
+    rgb = rng.integers(0, 256, size=(8, rows, cols, 3), dtype=np.uint8)
+    dep = rng.integers(0, 5000, size=(8, rows, cols)).astype(np.uint16)
+    path = tmp_path / "sphere_images_0.bin"
+    with open(path, "wb") as f:
+        f.write(b"\x16\x00\x00\x00\x00\x00\x00\x00serialization::archive" + b"\x00" * 15)     # 45-byte archive header
+        for s in range(8):
+            f.write(struct.pack("<iiQQ", cols, rows, 3, 16) + rgb[s].tobytes())
+            f.write(struct.pack("<iiQQ", cols, rows, 2, 2) + dep[s].tobytes())
+        f.write(struct.pack("<iiQQ", 0, 0, 0, 0))                                                  # empty timestamp Mat
+    a, b = load_frame_bin(str(path))
+    assert np.array_equal(a, rgb) and np.array_equal(b, dep)
+    with pytest.raises(Rgbd360Error):
+        load_frame_bin(str(tmp_path / "missing.bin"))
+    bad = tmp_path / "bad.bin"
+    bad.write_bytes(open(path, "rb").read()[:500])
+    with pytest.raises(Rgbd360Error):
+        load_frame_bin(str(bad))

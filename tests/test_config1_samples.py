@@ -20,7 +20,13 @@ def test_sample_pair_stitches_and_aligns_like_the_committed_record():
     gold = json.load(open(os.path.join(ROOT, "tests", "golden", "config1_samples.json")))
     out, pano = c1.run()
     assert out["sensor_image_shape"] == [240, 320, 3] and out["panorama_shape"] == [320, 1920, 3]
-    assert out["crc32"] == gold["crc32"]                       # byte-exact stitched panoramas
+    assert out["crc32"] == gold["crc32"]                       # byte-exact stitched panoramas (C++ oracle stitcher)
+    assert max(out["numpy_vs_cpp_stitch_mismatching_pixels"]) <= 30      # the independent numpy stitcher agrees (of 614,400 px)
+    # the product's host-side .bin reader returns the same 8 x (rgb, depth) as the test-side parser
+    from rgbd360_amd.register import load_frame_bin
+    rgb8, d8 = load_frame_bin(SAMPLES)
+    fr = c1.load_frame(SAMPLES)
+    assert all(np.array_equal(rgb8[s], fr[s][0]) and np.array_equal(d8[s], fr[s][1]) for s in range(8))
     assert all(f > 0.5 for f in out["valid_depth_fraction"])
     for name in ("PHOTO_CONSISTENCY", "PHOTO_DEPTH"):
         assert out[name]["status"] == gold[name]["status"] == 0

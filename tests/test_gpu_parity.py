@@ -395,3 +395,29 @@ def test_non_default_parameters_match_oracle(hip_lib, oracle_mod, small_pair):
     st, pose_ref = ora.align360(np.eye(4), 2)
     rot, trans = synth.pose_error(reg.getOptimalPose(), pose_ref)
     assert rc == st == 0 and rot <= POSE_TOL_DEV and trans <= POSE_TOL_DEV
+
+
+def _fake_rig(seed=3, rows=60, cols=80):
+    """8 random sensor images + rig-like extrinsics (45-degree steps about the up axis, small offsets)."""
+    rng = np.random.default_rng(seed)
+    rgb8 = rng.integers(0, 256, size=(8, rows, cols, 3), dtype=np.uint8)
+    d8 = rng.integers(400, 6000, size=(8, rows, cols)).astype(np.uint16)
+    d8[:, :5, :7] = 0
+    Rt = []
+    for s in range(8):
+        R = synth.rodrigues([1.0, 0.0, 0.0], np.radians(45.0 * s + rng.uniform(-1, 1)))
+        Rt.append(np.linalg.inv(synth.make_pose(R, rng.normal(size=3) * 0.03)).astype(np.float32))
+    K = (rows * 262.5 / 240, rows * 262.5 / 240, cols / 2 - 0.5, rows / 2 - 0.5)
+    return rgb8, d8, np.stack(Rt), K
+
+
+def test_stitch_sphere_bit_exact(hip_lib, oracle_mod):
+    """SURVEY.md 8f rank 2: Frame360::stitchSphericalImage on the device equals the CPU restatement byte for byte."""
+    from rgbd360_amd.register import stitch_sphere
+    rgb8, d8, Rt, K = _fake_rig()
+    reg = _mk(hip_lib, 3)
+    a, b = stitch_sphere(reg, rgb8, d8, Rt, K)
+    a_ref, b_ref = oracle_mod.stitch_sphere(rgb8, d8, Rt, K)
+    assert a.shape == (int(60 * 8 * 0.5 * 60.0 / 180), 480, 3)
+    assert (b_ref > 0).mean() > 0.3
+    assert np.array_equal(a, a_ref) and np.array_equal(b, b_ref)

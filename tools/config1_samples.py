@@ -103,13 +103,20 @@ def crc(a):
 
 
 def run():
+    """Panoramas from the C++ oracle stitcher (oracle/frame360_ref.cpp); the numpy stitcher above is an independent
+    second restatement whose disagreement (numpy float32 sin/cos vs libm: a handful of boundary pixels) is reported."""
     from oracle import oracle as O
     Rt_inv = load_extrinsics()
-    pano = []
+    pano, mismatch = [], []
     for idx in (1, 10):
         frames = load_frame(os.path.join(REF, "samples", "sphere_images_%d.bin" % idx))
-        pano.append(stitch(frames, Rt_inv))
-    out = {"sensor_image_shape": list(frames[0][0].shape), "panorama_shape": list(pano[0][0].shape),
+        rgb8 = np.stack([f[0] for f in frames])
+        d8 = np.stack([f[1] for f in frames])
+        a, b = O.stitch_sphere(rgb8, d8, np.stack(Rt_inv))
+        a2, b2 = stitch(frames, Rt_inv)
+        mismatch.append(int((a != a2).any(-1).sum() + (b != b2).sum()))
+        pano.append((a, b))
+    out = {"numpy_vs_cpp_stitch_mismatching_pixels": mismatch,"sensor_image_shape": list(frames[0][0].shape), "panorama_shape": list(pano[0][0].shape),
            "crc32": {"rgb_1": crc(pano[0][0]), "depth_1": crc(pano[0][1]), "rgb_10": crc(pano[1][0]), "depth_10": crc(pano[1][1])},
            "valid_depth_fraction": [float((p[1] > 0).mean()) for p in pano]}
     for method, name in ((0, "PHOTO_CONSISTENCY"), (2, "PHOTO_DEPTH")):
