@@ -205,6 +205,70 @@ __device__ __forceinline__ float wave_sum63(float v) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Wave reduction of 32 values at once ("halving" butterfly): every step pairs lanes and, instead of reducing each value
+// in every lane, lets the two partners keep complementary halves of the value list, so the number of live registers
+// halves per step: 32 -> 16 (v_permlane32_swap) -> 8 (v_permlane16_swap) -> 4 (quads {0,1}|{2,3}, DPP row_ror:8 with
+// bank masks) -> 2 (quad parity, DPP row_shl/shr:4) -> full sums inside each quad (quad_perm).  64 VALU operations
+// instead of 32 x 6 = 192.  On return lane (row r, quad b, any q) holds in out[j], j = 0,1, the wave total of value
+//     j + 2*(b & 1) + 4*(b >> 1) + 8*(r & 1) + 16*(r >> 1).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float add_ror8_banks01(float dst, float src) {    // dst (quads 0,1) = src + src[lane+8 within row]
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3" : "+v"(dst) : "v"(src));
+    return dst;
+}
+__device__ __forceinline__ float add_ror8_banks23(float dst, float src) {    // dst (quads 2,3) = src + src[lane-8 within row]
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc" : "+v"(dst) : "v"(src));
+    return dst;
+}
+__device__ __forceinline__ float add_shl4_even_quads(float dst, float src) { // dst (quads 0,2) = src + src[lane+4]
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5" : "+v"(dst) : "v"(src));
+    return dst;
+}
+__device__ __forceinline__ float add_shr4_odd_quads(float dst, float src) {  // dst (quads 1,3) = src + src[lane-4]
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xa" : "+v"(dst) : "v"(src));
+    return dst;
+}
+// The swaps are written as inline asm: with ROCm 7.2's hipcc the __builtin_amdgcn_permlane{16,32}_swap builtins
+// lose their second result when both results feed one add (the add reads the first register twice;
+// tools/ubench/reduce_test2.hip reproduces it).  s_nop 1 covers the VALU-write -> permlane-read hazard.
+__device__ __forceinline__ float swap32_add(float a, float b) {   // lanes 0-31: sum of a's halves, lanes 32-63: of b's
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ float swap16_add(float a, float b) {   // even rows: a's row pair, odd rows: b's row pair
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ void wave_reduce32(const float v[32], float out[2]) {
+    float u[16], t[8], w[4], r[2];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) u[j] = swap32_add(v[j], v[j + 16]);   // lanes 0-31 keep v[j], lanes 32-63 keep v[j+16]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = swap16_add(u[j], u[j + 8]);     // even rows keep u[j], odd rows keep u[j+8]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {       // quads 0,1 keep t[j], quads 2,3 keep t[j+4]
+        float d = 0.f;
+        d = add_ror8_banks01(d, t[j]);
+        d = add_ror8_banks23(d, t[j + 4]);
+        w[j] = d;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {       // even quads keep w[j], odd quads keep w[j+2]
+        float d = 0.f;
+        d = add_shl4_even_quads(d, w[j]);
+        d = add_shr4_odd_quads(d, w[j + 2]);
+        r[j] = d;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {       // the four lanes of a quad hold partial sums of the same value
+        float x = r[j];
+        x += dpp_f<0xB1>(x);
+        x += dpp_f<0x4E>(x);
+        out[j] = x;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // k_eval: one fused pass over the source pixels of a level at pose st->cand.
 //   METHOD: 0 photo, 1 depth, 2 photo+depth.  HG: also accumulate the 21+6 normal-equation terms.
 // Work split: block b owns the contiguous pixel span [cb*chunk, (cb+1)*chunk) (cb = XCD-aware remap of b so
@@ -406,23 +470,24 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval(LevelDev lv, EvalConsts e
         consume_stage<METHOD, HG>(wA, lv, ec, A);
     }
 
-    // ---- reduction: lanes -> wave (f32 DPP, total in lane 63) -> block (f64 via LDS) -> one partial row ----
+    // ---- reduction: lanes -> wave (halving butterfly, f32) -> block (f64 via LDS) -> one partial row ----
     __shared__ double red[kEvalThreads / 64][kNumPartials];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (HG) {
-#pragma unroll
-        for (int k = 0; k < 27; ++k) {
-            const float v = wave_sum63(A.acc[k]);
-            if (lane == 63) red[wave][k] = (double)v;
-        }
-    } else if (lane < 27) {
-        red[wave][lane] = 0.0;
-    }
     {
-        const float vp = wave_sum63(A.e2p), vd = wave_sum63(A.e2d);
+        float v[32], out[2];
+#pragma unroll
+        for (int k = 0; k < 27; ++k) v[k] = HG ? A.acc[k] : 0.f;
+        v[P_E2P] = A.e2p;
+        v[P_E2D] = A.e2d;
+        v[P_NP] = v[P_ND] = v[P_NVIS] = 0.f;        // the counts are wave-uniform scalars, stored below
+        wave_reduce32(v, out);
+        if ((lane & 3) == 0) {
+            const int row = lane >> 4, quad = (lane >> 2) & 3;
+            const int idx = 2 * (quad & 1) + 4 * (quad >> 1) + 8 * (row & 1) + 16 * (row >> 1);
+            if (idx + 0 < P_NP) red[wave][idx + 0] = (double)out[0];
+            if (idx + 1 < P_NP) red[wave][idx + 1] = (double)out[1];
+        }
         if (lane == 63) {
-            red[wave][P_E2P] = (double)vp;
-            red[wave][P_E2D] = (double)vd;
             red[wave][P_NP] = (double)A.nP;
             red[wave][P_ND] = (double)A.nD;
             red[wave][P_NVIS] = (double)A.nVis;
