@@ -372,9 +372,10 @@ inline Warp warp_pixel(const PoseRT& T, const float* p, int nRows, int nCols, fl
         float phi_trg = atan_unit(tp);
         if (ax > rho) phi_trg = 1.57079637f - phi_trg;
         phi_trg = copysignf(phi_trg, w.X);
-        const float theta_trg = (float)((double)atan2_from_t(w.Y, w.Z, ay, az, tt) + kPI);
-        w.r = round_index(fmaf(-phi_trg, angle_res_inv, half_nRows));
-        w.c = round_index(theta_trg * angle_res_inv);
+        const float theta = atan2_from_t(w.Y, w.Z, ay, az, tt);
+        const float pi_k = (float)(kPI * (double)angle_res_inv);      // the +PI of RPI.h:2677 folded into the column scaling
+        w.r = round_index(fmaf(phi_trg, -angle_res_inv, half_nRows));
+        w.c = round_index(fmaf(theta, angle_res_inv, pi_k));
         w.visible = ((unsigned)w.r < (unsigned)nRows) && ((unsigned)w.c < (unsigned)nCols);
     }
     return w;

@@ -37,6 +37,7 @@ struct LevelDev {
     int rows, cols, n;
     float half_nRows;        // 0.5*nRows - 0.5
     float angle_res_inv;     // 1 / float(2*PI/nCols)
+    float pi_k;              // float(PI * angle_res_inv): the +PI of theta_trg (RPI.h:2677) folded into the column scaling
     const float4* src;       // {x, y, z, Isrc} per source pixel; x == -10000 marks an invalid point
     const F3* trgP;          // {Itrg, gradX, gradY} per target pixel
     const F3* trgD;          // {Dtrg, dgradX, dgradY} per target pixel
@@ -155,23 +156,32 @@ __device__ __forceinline__ PoseRT load_pose(const float* P) {   // column-major 
     return T;
 }
 
-// Shared front end of RPI.h:2663-2684 / 2959-2989.  Returns the target pixel index or -1.
+// Shared front end of RPI.h:2663-2684 / 2959-2989.  Returns the target pixel index (valid only when `vis`).
 // Device arithmetic definition (the oracle's math_mode 1 repeats it operation for operation):
 //   p' = R p + t with fused multiply-adds;  rho^2 = Y^2 + Z^2,  d^2 = X^2 + rho^2
 //   phi   = atan2(X, rho)      (= asin(X/d) of the reference, RPI.h:2676)      rho = correctly rounded sqrt
-//   theta = atan2(Y, Z) + PI   (RPI.h:2677-2678)
+//   theta = atan2(Y, Z);  column = round(theta * k + PI*k)   (RPI.h:2677-2680 with the +PI folded into the scaling)
 //   both quotients min/max come from ONE correctly rounded reciprocal r = 1 / (mx_phi * mx_theta)
 // Every step is an IEEE-754 basic operation, so x86 and gfx950 agree bit for bit on the pixel index.
-__device__ __forceinline__ int warp_pixel(const PoseRT& T, float px, float py, float pz, const LevelDev& lv, float& X,
-                                          float& Y, float& Z, float& rho2, float& d2) {
-    X = fmaf(T.r02, pz, fmaf(T.r01, py, fmaf(T.r00, px, T.tx)));
-    Y = fmaf(T.r12, pz, fmaf(T.r11, py, fmaf(T.r10, px, T.ty)));
-    Z = fmaf(T.r22, pz, fmaf(T.r21, py, fmaf(T.r20, px, T.tz)));
+struct WarpConsts {        // per-lane copies (VGPRs) of the wave-uniform addends: a VOP3 fma reads one scalar only
+    float tx, ty, tz, half_nRows, pi_k;
+};
+__device__ __forceinline__ WarpConsts make_warp_consts(const PoseRT& T, const LevelDev& lv) {
+    WarpConsts c = {T.tx, T.ty, T.tz, lv.half_nRows, lv.pi_k};
+    asm volatile("" : "+v"(c.tx), "+v"(c.ty), "+v"(c.tz), "+v"(c.half_nRows), "+v"(c.pi_k));
+    return c;
+}
+__device__ __forceinline__ unsigned warp_pixel(const PoseRT& T, const WarpConsts& wc, float px, float py, float pz,
+                                               const LevelDev& lv, float& X, float& Y, float& Z, float& rho2, float& d2,
+                                               bool& vis) {
+    X = fmaf(T.r02, pz, fmaf(T.r01, py, fmaf(T.r00, px, wc.tx)));
+    Y = fmaf(T.r12, pz, fmaf(T.r11, py, fmaf(T.r10, px, wc.ty)));
+    Z = fmaf(T.r22, pz, fmaf(T.r21, py, fmaf(T.r20, px, wc.tz)));
     rho2 = fmaf(Z, Z, Y * Y);
     d2 = fmaf(X, X, rho2);
     const float rho = sqrt_rn(rho2);
     const float ax = fabsf(X), ay = fabsf(Y), az = fabsf(Z);
-    const float mxp = fmaxf(fmaxf(ax, rho), 1e-9f), mnp = fminf(ax, rho);
+    const float mxp = fmaxf(fmaxf(ax, rho), 1e-9f), mnp = __builtin_amdgcn_fmed3f(ax, rho, 0.f);   // min of two non-negatives
     const float mxt = fmaxf(fmaxf(ay, az), 1e-9f), mnt = fminf(ay, az);
     const float r = rcp_rn(mxp * mxt);
     const float tp = mnp * (r * mxt);
@@ -179,11 +189,11 @@ __device__ __forceinline__ int warp_pixel(const PoseRT& T, float px, float py, f
     float phi_trg = atan_unit(tp);
     if (ax > rho) phi_trg = 1.57079637f - phi_trg;
     phi_trg = copysignf(phi_trg, X);
-    const float theta_trg = (float)((double)atan2_from_t(Y, Z, ay, az, tt) + kPI);
-    const int tr = round_index(fmaf(-phi_trg, lv.angle_res_inv, lv.half_nRows));
-    const int tc = round_index(theta_trg * lv.angle_res_inv);
-    const bool vis = ((unsigned)tr < (unsigned)lv.rows) && ((unsigned)tc < (unsigned)lv.cols);
-    return vis ? (int)__umul24(tr, lv.cols) + tc : -1;
+    const float theta = atan2_from_t(Y, Z, ay, az, tt);
+    const int tr = round_index(fmaf(phi_trg, -lv.angle_res_inv, wc.half_nRows));
+    const int tc = round_index(fmaf(theta, lv.angle_res_inv, wc.pi_k));
+    vis = ((unsigned)tr < (unsigned)lv.rows) && ((unsigned)tc < (unsigned)lv.cols);
+    return __umul24(tr, lv.cols) + (unsigned)tc;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -326,22 +336,25 @@ __device__ __forceinline__ void accumulate_row(EvalAcc& A, float jx, float jy, f
 // k_eval runs warp_stage of pixel i+1 before consume_stage of pixel i: the gather latency of one pixel hides behind
 // the arithmetic of its neighbour instead of stalling the wave.
 struct PixW {
-    float X, Y, Z, rho2, d2, isrc;
-    bool  vis;
+    float X, Y, Z, rho2, d2s, isrc;   // d2s = |p'|^2 with the sign bit carrying "not visible" (saves a flag register)
     F3    tp, td;
 };
 
 template <int METHOD>
-__device__ __forceinline__ void warp_stage(const float4 s, const bool in_range, const PoseRT& T, const LevelDev& lv,
-                                           PixW& w) {
-    int ti = warp_pixel(T, s.x, s.y, s.z, lv, w.X, w.Y, w.Z, w.rho2, w.d2);
-    w.vis = in_range && (s.x != kInvalidPoint) && (ti >= 0);
+__device__ __forceinline__ void warp_stage(const float4 s, const bool in_range, const PoseRT& T, const WarpConsts& wc,
+                                           const LevelDev& lv, PixW& w) {
+    bool vis;
+    float d2;
+    unsigned ti = warp_pixel(T, wc, s.x, s.y, s.z, lv, w.X, w.Y, w.Z, w.rho2, d2, vis);
+    vis = vis && in_range && (s.x != kInvalidPoint);
+    w.d2s = vis ? d2 : -d2;
     w.isrc = s.w;
     // tie the copy of the source intensity to the end of the warp arithmetic: scheduled earlier it would sit in
     // front of the whole stage and wait for the youngest load (vmcnt(0)) instead of the one this stage needs
-    asm volatile("" : "+v"(w.isrc), "+v"(w.d2));
-    ti = w.vis ? ti : 0;
-    if (METHOD != 1) w.tp = lv.trgP[ti];     // unconditional gathers: issued as soon as the index is known
+    asm volatile("" : "+v"(w.isrc), "+v"(w.d2s));
+    ti = vis ? ti : 0u;
+    // unconditional gathers, issued as soon as the index is known
+    if (METHOD != 1) w.tp = lv.trgP[ti];
     if (METHOD != 0) w.td = lv.trgD[ti];
 }
 
@@ -352,7 +365,8 @@ __device__ __forceinline__ void consume_stage(PixW& w, const LevelDev& lv, const
     if (METHOD != 1) asm volatile("" : "+v"(w.tp.a), "+v"(w.tp.b), "+v"(w.tp.c));
     if (METHOD != 0) asm volatile("" : "+v"(w.td.a), "+v"(w.td.b), "+v"(w.td.c));
     const float X = w.X, Y = w.Y, Z = w.Z;
-    const bool vis = w.vis;
+    const bool vis = w.d2s > 0.f;
+    const float d2 = fabsf(w.d2s);
     A.nVis += ballot_count(vis);
 
     // rows of jacobianProj23 (RPI.h:3000-3016) in terms of rho^2 = Y^2+Z^2 and d^2 = |p'|^2 (k = angle_res_inv):
@@ -361,7 +375,7 @@ __device__ __forceinline__ void consume_stage(PixW& w, const LevelDev& lv, const
     // (algebraically what the reference writes with 1/z, 1/(1+y^2/z^2), 1/sqrt(1-x^2/d^2)); float32 data, so the
     // hardware reciprocal / reciprocal square root are used.
     float a1 = 0.f, a2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
-    const float dist_inv = fast_rsq(w.d2);
+    const float dist_inv = fast_rsq(d2);
     if (HG) {
 #pragma clang fp contract(fast)
         const float inv_rho = fast_rsq(w.rho2);
@@ -403,8 +417,8 @@ __device__ __forceinline__ void consume_stage(PixW& w, const LevelDev& lv, const
         A.nD += ballot_count(ok);
         if (ok) {
 #pragma clang fp contract(fast)
-            float dist = w.d2 * dist_inv;                               // |p'|: rsq estimate + one Newton step (< 1 ulp)
-            dist = fmaf(0.5f * dist_inv, fmaf(-dist, dist, w.d2), dist);
+            float dist = d2 * dist_inv;                                 // |p'|: rsq estimate + one Newton step (< 1 ulp)
+            dist = fmaf(0.5f * dist_inv, fmaf(-dist, dist, d2), dist);
             const float depthDiff = depth2 - dist;
             const float sd = ec.sigma_depth * depth2;
             const float wd = weight_huber_fast(depthDiff, sd) * fast_rcp(sd);
@@ -436,6 +450,7 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval(LevelDev lv, EvalConsts e
     float4 sB = lv.src[min(i + kEvalThreads, last)];
     if (st->done || st->level_active != level) return;     // speculatively enqueued launch of a finished / later level
     const PoseRT T = load_pose(st->cand);
+    const WarpConsts wc = make_warp_consts(T, lv);
 
     EvalAcc A;
 #pragma unroll
@@ -449,21 +464,21 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval(LevelDev lv, EvalConsts e
     // of step k+1 and the source record of step k+2 are in flight.
     const int n_steps = (end - base + kEvalThreads - 1) / kEvalThreads;
     PixW wA, wB;
-    warp_stage<METHOD>(sA, i < end, T, lv, wA);
+    warp_stage<METHOD>(sA, i < end, T, wc, lv, wA);
     sA = lv.src[min(i + 2 * kEvalThreads, last)];
     int k = 0;
     // steady state: straight-line body (no control-flow joins, so the compiler's waits are counted, not vmcnt(0))
     for (; k + 2 < n_steps; k += 2, i += 2 * kEvalThreads) {
-        warp_stage<METHOD>(sB, (i + kEvalThreads) < end, T, lv, wB);
+        warp_stage<METHOD>(sB, (i + kEvalThreads) < end, T, wc, lv, wB);
         sB = lv.src[min(i + 3 * kEvalThreads, last)];
         consume_stage<METHOD, HG>(wA, lv, ec, A);
-        warp_stage<METHOD>(sA, (i + 2 * kEvalThreads) < end, T, lv, wA);
+        warp_stage<METHOD>(sA, (i + 2 * kEvalThreads) < end, T, wc, lv, wA);
         sA = lv.src[min(i + 4 * kEvalThreads, last)];
         consume_stage<METHOD, HG>(wB, lv, ec, A);
     }
     // tail: one or two steps left, wA holds step k
     if (k + 1 < n_steps) {
-        warp_stage<METHOD>(sB, (i + kEvalThreads) < end, T, lv, wB);
+        warp_stage<METHOD>(sB, (i + kEvalThreads) < end, T, wc, lv, wB);
         consume_stage<METHOD, HG>(wA, lv, ec, A);
         consume_stage<METHOD, HG>(wB, lv, ec, A);
     } else {
@@ -914,11 +929,13 @@ __global__ void k_warp_indices(LevelDev lv, Pose16 pose, int32_t* __restrict__ o
     const float4 s = lv.src[i];
     int r = -1, c = -1;
     if (s.x != kInvalidPoint) {
-        float X, Y, Z, d, di;
-        const int ti = warp_pixel(T, s.x, s.y, s.z, lv, X, Y, Z, d, di);
-        if (ti >= 0) {
-            r = ti / lv.cols;
-            c = ti - r * lv.cols;
+        float X, Y, Z, rho2, d2;
+        bool vis;
+        const WarpConsts wc = {T.tx, T.ty, T.tz, lv.half_nRows, lv.pi_k};
+        const unsigned ti = warp_pixel(T, wc, s.x, s.y, s.z, lv, X, Y, Z, rho2, d2, vis);
+        if (vis) {
+            r = (int)(ti / (unsigned)lv.cols);
+            c = (int)ti - r * lv.cols;
         }
     }
     out[2 * i] = r;

@@ -150,6 +150,7 @@ LevelDev level_dev(const Level& L) {
     LevelDev d;
     d.rows = L.rows; d.cols = L.cols; d.n = L.n;
     d.half_nRows = L.half_nRows; d.angle_res_inv = L.angle_res_inv;
+    d.pi_k = (float)(kPI * (double)L.angle_res_inv);
     d.src = L.srcRec; d.trgP = L.trgP; d.trgD = L.trgD;
     return d;
 }
