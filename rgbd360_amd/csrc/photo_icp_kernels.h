@@ -438,6 +438,13 @@ __device__ __forceinline__ void consume_stage(PixW& w, const LevelDev& lv, const
 template <int METHOD, bool HG>
 __global__ __launch_bounds__(kEvalThreads) void k_eval(LevelDev lv, EvalConsts ec, const GNState* __restrict__ st,
                                                         double* __restrict__ partials, int chunk, int level) {
+#ifdef RGBD360_EVAL_STAMPS
+    const unsigned long long es0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long es[6] = {0, 0, 0, 0, 0, 0};
+#define ESTAMP(i) es[i] = __builtin_amdgcn_s_memrealtime() - es0
+#else
+#define ESTAMP(i)
+#endif
     const int nb = gridDim.x;
     const int b = blockIdx.x;
     const int cb = ((nb & 7) == 0) ? (b & 7) * (nb >> 3) + (b >> 3) : b;
@@ -451,6 +458,7 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval(LevelDev lv, EvalConsts e
     if (st->done || st->level_active != level) return;     // speculatively enqueued launch of a finished / later level
     const PoseRT T = load_pose(st->cand);
     const WarpConsts wc = make_warp_consts(T, lv);
+    ESTAMP(0);
 
     EvalAcc A;
 #pragma unroll
@@ -465,6 +473,7 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval(LevelDev lv, EvalConsts e
     const int n_steps = (end - base + kEvalThreads - 1) / kEvalThreads;
     PixW wA, wB;
     warp_stage<METHOD>(sA, i < end, T, wc, lv, wA);
+    ESTAMP(1);
     sA = lv.src[min(i + 2 * kEvalThreads, last)];
     int k = 0;
     // steady state: straight-line body (no control-flow joins, so the compiler's waits are counted, not vmcnt(0))
@@ -485,6 +494,7 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval(LevelDev lv, EvalConsts e
         consume_stage<METHOD, HG>(wA, lv, ec, A);
     }
 
+    ESTAMP(2);
     // ---- reduction: lanes -> wave (halving butterfly, f32) -> block (f64 via LDS) -> one partial row ----
     __shared__ double red[kEvalThreads / 64][kNumPartials];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -508,6 +518,7 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval(LevelDev lv, EvalConsts e
             red[wave][P_NVIS] = (double)A.nVis;
         }
     }
+    ESTAMP(3);
     __syncthreads();
     if (threadIdx.x < kNumPartials) {
         double v = 0.0;
@@ -515,6 +526,29 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval(LevelDev lv, EvalConsts e
         for (int w = 0; w < kEvalThreads / 64; ++w) v += red[w][threadIdx.x];
         partials[(size_t)b * kNumPartials + threadIdx.x] = v;
     }
+#ifdef RGBD360_EVAL_STAMPS
+    ESTAMP(4);
+    if (threadIdx.x == 0 && (b == 0 || b == nb - 1)) {      // diagnostic rows behind the partial table
+        double* o = partials + (size_t)(nb + (b == 0 ? 0 : 1)) * kNumPartials;
+        for (int k = 0; k < 5; ++k) o[k] = (double)es[k];
+        o[5] = (double)es0;
+        }
+    if (threadIdx.x == 0) {     // per-block (start, end) of the last launch: rows nb+8 ...
+        double* pb = partials + (size_t)(nb + 8) * kNumPartials + 2 * b;
+        pb[0] = (double)es0;
+        pb[1] = (double)(es0 + es[4]);
+    }
+    if (threadIdx.x == 0 && b == 0) {
+        {       // history of (start, end) of block 0 over consecutive launches: rows nb+2 ...
+            unsigned long long* cnt = reinterpret_cast<unsigned long long*>(partials + (size_t)(nb + 2) * kNumPartials);
+            const unsigned long long slot = atomicAdd(cnt, 1ull) % 60;
+            double* h = partials + (size_t)(nb + 3) * kNumPartials + 2 * slot;
+            h[0] = (double)es0;
+            h[1] = (double)(es0 + es[4]);
+        }
+    }
+#endif
+#undef ESTAMP
 }
 
 // ---------------------------------------------------------------------------------------------------------

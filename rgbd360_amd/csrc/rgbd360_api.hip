@@ -141,7 +141,7 @@ int ensure_levels(rgbd360_ctx* ctx, int rows, int cols) {
     }
     hipFree(ctx->d_partials);
     ctx->d_partials = nullptr;
-    HIPC(ctx, hipMalloc(&ctx->d_partials, (size_t)max_blocks * kNumPartials * sizeof(double)));
+    HIPC(ctx, hipMalloc(&ctx->d_partials, (size_t)(max_blocks + 8 + max_blocks / 16 + 2) * kNumPartials * sizeof(double)));   // + diagnostic rows
     ctx->rows = rows; ctx->cols = cols;
     return 0;
 }
@@ -626,6 +626,32 @@ int rgbd360_time_solve_kernel(rgbd360_ctx* ctx, int level, int mode, int reps, f
     float ms = 0.f;
     HIPC(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     *avg_us = ms * 1000.f / reps;
+    return 0;
+}
+
+int rgbd360_debug_eval_stamps(rgbd360_ctx* ctx, int level, double out[12]) {
+    if (!ctx || !out || level < 0 || level >= (int)ctx->levels.size()) return -1;
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    const int nb = ctx->levels[level].nblocks;
+    HIPC(ctx, hipMemcpy(out, ctx->d_partials + (size_t)nb * kNumPartials, 6 * sizeof(double), hipMemcpyDeviceToHost));
+    HIPC(ctx, hipMemcpy(out + 6, ctx->d_partials + (size_t)(nb + 1) * kNumPartials, 6 * sizeof(double), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int rgbd360_debug_eval_blocks(rgbd360_ctx* ctx, int level, double* out /*2*nblocks*/) {
+    if (!ctx || !out || level < 0 || level >= (int)ctx->levels.size()) return -1;
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    const int nb = ctx->levels[level].nblocks;
+    HIPC(ctx, hipMemcpy(out, ctx->d_partials + (size_t)(nb + 8) * kNumPartials, 2 * nb * sizeof(double), hipMemcpyDeviceToHost));
+    return nb;
+}
+
+int rgbd360_debug_eval_history(rgbd360_ctx* ctx, int level, int reset, double out[120]) {
+    if (!ctx || level < 0 || level >= (int)ctx->levels.size()) return -1;
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    const int nb = ctx->levels[level].nblocks;
+    if (reset) HIPC(ctx, hipMemset(ctx->d_partials + (size_t)(nb + 2) * kNumPartials, 0, 5 * kNumPartials * sizeof(double)));
+    if (out) HIPC(ctx, hipMemcpy(out, ctx->d_partials + (size_t)(nb + 3) * kNumPartials, 120 * sizeof(double), hipMemcpyDeviceToHost));
     return 0;
 }
 
