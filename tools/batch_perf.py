@@ -1,0 +1,24 @@
+"""Config-4 style throughput on one GPU: n consecutive pairs of the synthetic odometry sequence, frames uploaded from host
+memory, frame reuse inside the chunk.  python tools/batch_perf.py [n_pairs] [W] [H]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from rgbd360_amd import synth
+from rgbd360_amd.batch import align_sequence
+from rgbd360_amd.register import RegisterPhotoICP
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+W = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
+H = int(sys.argv[3]) if len(sys.argv) > 3 else W // 2
+t0 = time.time()
+frames = [synth.render(synth.trajectory_pose(k, 7), W, H, 7) for k in range(n + 1)]
+print("rendered %d frames in %.1f s" % (n + 1, time.time() - t0))
+reg = RegisterPhotoICP(); reg.setNumPyr(4)
+align_sequence(reg, lambda k: frames[k], 0, 2, 2)          # warm
+for method, name in ((2, "PHOTO_DEPTH"), (0, "PHOTO_CONSISTENCY")):
+    t0 = time.perf_counter()
+    poses, status, iters = align_sequence(reg, lambda k: frames[k], 0, n, method)
+    dt = time.perf_counter() - t0
+    errs = [synth.pose_error(poses[j], np.linalg.inv(synth.trajectory_pose(j, 7)) @ synth.trajectory_pose(j + 1, 7)) for j in range(n)]
+    print("%s: %d pairs in %.2f ms -> %.0f alignments/s (%.3f ms/pair incl. H2D upload + pyramids of one new frame); status ok %d/%d; "
+          "mean iters/level %s; max pose err vs ground truth %.2e rad %.2e m" % (name, n, dt * 1e3, n / dt, dt * 1e3 / n, int((status == 0).sum()), n,
+          np.round(iters.mean(0), 2).tolist(), max(e[0] for e in errs), max(e[1] for e in errs)))
