@@ -106,6 +106,13 @@ def main():
 
     # ---- warmup, then EXACTLY K steps ------------------------------------------------------------------------
     reg.forced_iters(0, start_pose, method, max(args.warmup, 1))
+    if dist is not None:
+        # warm the exchange too: the first RCCL all-gather builds channels / loads kernels, which must not be timed
+        w_in = torch.zeros(16, dtype=torch.float32, device=xdev)
+        w_out = torch.empty(world * 16, dtype=torch.float32, device=xdev)
+        dist.all_gather_into_tensor(w_out, w_in)
+        w_t = torch.zeros(1, dtype=torch.float64, device=xdev)
+        dist.all_reduce(w_t, op=dist.ReduceOp.MAX)
     sync_all()
     t0 = time.perf_counter()
     out = reg.forced_iters(0, start_pose, method, args.steps)

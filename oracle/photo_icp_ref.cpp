@@ -444,6 +444,33 @@ double errorPhotoICP_sphere(Ctx& ctx, int level, const float* pose, int method) 
     return sqrt(error2 / numValidPts);
 }
 
+// jacobianWarpRt = jacobianProj23 * jacobianT36 of RPI.h:2994-3026: d(c', r') / d(delta) for the left perturbation
+// exp(delta) * T, delta = [t; w], evaluated at the transformed point p' = (X, Y, Z).
+inline void warp_jacobian(float X, float Y, float Z, float dist_inv, float angle_res_inv, float Jw0[6], float Jw1[6]) {
+    // jacobianT36 = [ I | -skew(p') ]  (RPI.h:2994-2996, Miscellaneous.h:88-98)
+    // -skew(p') = [ 0  Z -Y ; -Z 0  X ; Y -X 0 ]
+    // jacobianProj23 (RPI.h:3000-3016)
+    float z_inv = 1.f / Z;
+    float z_inv2 = z_inv * z_inv;
+    float D_atan_theta = 1.f / (1 + Y * Y * z_inv2) * angle_res_inv;
+    float a1 = D_atan_theta * z_inv;
+    float a2 = -Y * z_inv2 * D_atan_theta;
+    float dist_inv2 = dist_inv * dist_inv;
+    float x_dist_inv2 = X * dist_inv2;
+    float D_asin = 1.f / sqrtf(1 - X * x_dist_inv2) * angle_res_inv;
+    float b0 = -D_asin * dist_inv * (1 - X * x_dist_inv2);
+    float b1 = D_asin * (x_dist_inv2 * Y * dist_inv);
+    float b2 = D_asin * (x_dist_inv2 * Z * dist_inv);
+    // jacobianWarpRt = jacobianProj23 * jacobianT36 (RPI.h:3026); Eigen coefficient products
+    // ((a0*b0 + a1*b1) + a2*b2) with the structural zeros dropped (adding +-0 is exact).
+    const float r0[6] = {0.f, a1, a2, a1 * (-Z) + a2 * Y, a2 * (-X), a1 * X};
+    const float r1[6] = {b0, b1, b2, b1 * (-Z) + b2 * Y, b0 * Z + b2 * (-X), b0 * (-Y) + b1 * X};
+    for (int j = 0; j < 6; ++j) {
+        Jw0[j] = r0[j];
+        Jw1[j] = r1[j];
+    }
+}
+
 // ------------------------------------------------------------------------------------
 // RPI.h:2745-3228 calcHessGrad_sphere
 // ------------------------------------------------------------------------------------
@@ -480,24 +507,8 @@ void calcHessGrad_sphere(Ctx& ctx, int level, const float* pose, int method) {
         ++numVisiblePixels;
         const float X = w.X, Y = w.Y, Z = w.Z, dist_inv = w.dist_inv;
 
-        // jacobianT36 = [ I | -skew(p') ]  (RPI.h:2994-2996, Miscellaneous.h:88-98)
-        // -skew(p') = [ 0  Z -Y ; -Z 0  X ; Y -X 0 ]
-        // jacobianProj23 (RPI.h:3000-3016)
-        float z_inv = 1.f / Z;
-        float z_inv2 = z_inv * z_inv;
-        float D_atan_theta = 1.f / (1 + Y * Y * z_inv2) * angle_res_inv;
-        float a1 = D_atan_theta * z_inv;
-        float a2 = -Y * z_inv2 * D_atan_theta;
-        float dist_inv2 = dist_inv * dist_inv;
-        float x_dist_inv2 = X * dist_inv2;
-        float D_asin = 1.f / sqrtf(1 - X * x_dist_inv2) * angle_res_inv;
-        float b0 = -D_asin * dist_inv * (1 - X * x_dist_inv2);
-        float b1 = D_asin * (x_dist_inv2 * Y * dist_inv);
-        float b2 = D_asin * (x_dist_inv2 * Z * dist_inv);
-        // jacobianWarpRt = jacobianProj23 * jacobianT36 (RPI.h:3026); Eigen coefficient products
-        // ((a0*b0 + a1*b1) + a2*b2) with the structural zeros dropped (adding +-0 is exact).
-        float Jw0[6] = {0.f, a1, a2, a1 * (-Z) + a2 * Y, a2 * (-X), a1 * X};
-        float Jw1[6] = {b0, b1, b2, b1 * (-Z) + b2 * Y, b0 * Z + b2 * (-X), b0 * (-Y) + b1 * X};
+        float Jw0[6], Jw1[6];
+        warp_jacobian(X, Y, Z, dist_inv, angle_res_inv, Jw0, Jw1);
 
         if (method == METHOD_PHOTO || method == METHOD_PHOTO_DEPTH) {
             float tgx = gx.at(w.r, w.c), tgy = gy.at(w.r, w.c);
@@ -1049,6 +1060,14 @@ void oracle_sphere_cloud(const void* depth, size_t step, int depth_type, int row
             }
         }
     }
+}
+
+// Analytic warp Jacobian at a transformed point (finite-difference tests): rows d c'/d delta, d r'/d delta.
+void oracle_warp_jacobian(const float* p, int nCols, float* Jw0, float* Jw1) {
+    const float angle_res = 2 * kPI / nCols;
+    const float angle_res_inv = 1 / angle_res;
+    const float dist = sqrtf((p[0] * p[0] + p[1] * p[1]) + p[2] * p[2]);
+    warp_jacobian(p[0], p[1], p[2], 1.f / dist, angle_res_inv, Jw0, Jw1);
 }
 
 // Scalar probes for unit tests.

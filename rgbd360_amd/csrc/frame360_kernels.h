@@ -22,7 +22,6 @@
 namespace f360 {
 
 constexpr int kF360R = 12;          // truncation radius of the distance map (>= smoothing_size + max depth / 10)
-constexpr float kBig = 1.0e9f;
 
 __device__ __forceinline__ bool finite3(float x, float y, float z) { return isfinite(x) && isfinite(y) && isfinite(z); }
 __device__ __forceinline__ float depth_of(const float* p, int depth_mode) {

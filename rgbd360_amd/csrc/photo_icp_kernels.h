@@ -82,12 +82,6 @@ struct SolveCfg {
 // sequence of IEEE-754 basic operations (fma, mul, add, correctly rounded sqrt and reciprocal) that the CPU oracle
 // repeats operation for operation in its math_mode 1, so warped pixel indices agree bit for bit.
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float weight_huber(float error, float k) {   // RPI.h:545-554 (IEEE form, tests only)
-    float ea = fabsf(error);
-    if (ea < k) return 1.f;
-    return sqrtf(2 * k * ea - k * k) / ea;
-}
-
 // Correctly rounded sqrt for normal, finite x >= 0 (and x == 0): hardware estimate (<= 1 ulp) corrected with two
 // exact fma residuals -- the core of the compiler's own IEEE expansion without its denormal / special-class
 // handling, which inputs on this path never need.  rgbd360_selftest_math compares it with sqrtf over the range.
@@ -197,23 +191,12 @@ __device__ __forceinline__ unsigned warp_pixel(const PoseRT& T, const WarpConsts
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// wave64 sum: DPP inside a 16-lane row, ds_bpermute across the four rows.  Every lane ends with the total.
+// DPP move helper (quad_perm / row modes) used by the wave reduction below.
 // ---------------------------------------------------------------------------------------------------------
 template <int CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ float dpp_f(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, true));
 }
-// Sum over the 64 lanes; the total is valid in lane 63 only (rows 0-2 hold partial sums).
-__device__ __forceinline__ float wave_sum63(float v) {
-    v += dpp_f<0xB1>(v);          // quad_perm [1,0,3,2]
-    v += dpp_f<0x4E>(v);          // quad_perm [2,3,0,1]
-    v += dpp_f<0x141>(v);         // row_half_mirror
-    v += dpp_f<0x140>(v);         // row_mirror: every lane of a row holds the row sum
-    v += dpp_f<0x142, 0xA>(v);    // row_bcast:15 -> rows 1,3 += previous row
-    v += dpp_f<0x143, 0xC>(v);    // row_bcast:31 -> rows 2,3 += row 1 (which holds rows 0+1)
-    return v;
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // Wave reduction of 32 values at once ("halving" butterfly): every step pairs lanes and, instead of reducing each value
 // in every lane, lets the two partners keep complementary halves of the value list, so the number of live registers
@@ -299,7 +282,6 @@ struct EvalAcc {
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
-__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ int ballot_count(bool p) { return __builtin_popcountll(__ballot(p)); }
 
 // weightHuber (RPI.h:545-554) with the hardware sqrt / rcp approximations (1 ulp): weights are float32 data,

@@ -256,3 +256,40 @@ def test_frame360_distance_map_is_a_chamfer_transform(oracle_mod):
     assert d[20, 30] == 0 and d[20, 31] == 0 and d[21, 30] == 0
     # the depth-change set is the plus shape around the spike; (25,36) is 5 diagonal steps from (20,31)
     assert d[20, 36] == pytest.approx(5.0) and d[25, 36] == pytest.approx(5 * 1.4, abs=1e-5) and d[26, 36] == pytest.approx(8.0, abs=1e-5)
+
+
+def test_analytic_warp_jacobian_matches_finite_differences(oracle_mod):
+    """The restated jacobianProj23 * jacobianT36 (RPI.h:2994-3026) is the derivative of the continuous spherical
+    projection (c', r') = (theta' k, h - phi' k) under the left perturbation exp(delta) * p' (hard parts)."""
+    import ctypes as C
+    from scipy.linalg import expm
+    L = oracle_mod.lib()
+    L.oracle_warp_jacobian.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.oracle_warp_jacobian.restype = None
+    nCols = 2048
+    k = nCols / (2 * 3.14159265359)
+    rng = np.random.default_rng(4)
+
+    def project(p):
+        d = np.linalg.norm(p)
+        return np.array([(np.arctan2(p[1], p[2]) + np.pi) * k, -np.arcsin(p[0] / d) * k])      # (c', r' - h)
+
+    for _ in range(20):
+        p = rng.normal(size=3) * 2.0
+        if abs(p[2]) < 0.2 or np.hypot(p[1], p[2]) < 0.3:
+            continue
+        pf = p.astype(np.float32)
+        Jw0 = np.zeros(6, np.float32)
+        Jw1 = np.zeros(6, np.float32)
+        L.oracle_warp_jacobian(pf.ctypes.data_as(C.c_void_p), nCols, Jw0.ctypes.data_as(C.c_void_p), Jw1.ctypes.data_as(C.c_void_p))
+        J = np.stack([Jw0, Jw1]).astype(np.float64)
+        Jfd = np.zeros((2, 6))
+        eps = 1e-6
+        for j in range(6):
+            dlt = np.zeros(6)
+            dlt[j] = eps
+            W = np.array([[0, -dlt[5], dlt[4]], [dlt[5], 0, -dlt[3]], [-dlt[4], dlt[3], 0]])
+            pp = expm(W) @ pf.astype(np.float64) + dlt[:3]
+            pm = expm(-W) @ pf.astype(np.float64) - dlt[:3]
+            Jfd[:, j] = (project(pp) - project(pm)) / (2 * eps)
+        assert np.allclose(J, Jfd, rtol=2e-4, atol=2e-3 * np.abs(Jfd).max()), (p, J, Jfd)
