@@ -100,6 +100,13 @@ int rgbd360_promote_source_to_target(rgbd360_ctx* ctx);
 int rgbd360_align360(rgbd360_ctx* ctx, const float guess[16], int method, int occlusion, float pose_out[16],
                      rgbd360_result* res);
 
+/* The same alignment split in two, so that several contexts (one per frame pair, each on its own HIP stream) can be in
+ * flight on one GPU at once: _begin enqueues the coarse-to-fine schedule and returns without waiting; _finish waits,
+ * tops the schedule up if a level needed more iterations than were enqueued, and returns what rgbd360_align360 returns.
+ * Coarse-level launches of different pairs then overlap on the device (they fill only a fraction of the CUs). */
+int rgbd360_align360_begin(rgbd360_ctx* ctx, const float guess[16], int method, int occlusion);
+int rgbd360_align360_finish(rgbd360_ctx* ctx, float pose_out[16], rgbd360_result* res);
+
 /* ---- stage-level entry points (parity tests and measurement) ------------------------------------------------ */
 
 /* Pyramid planes as float32 rows x cols (level dims via rgbd360_level_dims).

@@ -42,6 +42,37 @@ def align_sequence(reg, get_frame, lo: int, hi: int, method: int, guess=None):
     return poses, status, iters
 
 
+def align_sequence_concurrent(regs, get_frame, lo: int, hi: int, method: int, guess=None):
+    """Same result as align_sequence, with len(regs) contexts (each on its own HIP stream) working on interleaved
+    sub-chunks at once: in every step each context's alignment is enqueued (`alignFrames360_begin`) before any is waited
+    for, so the coarse-level launches of different pairs overlap on the GPU."""
+    n = hi - lo
+    k = max(1, min(len(regs), n))
+    n_pyr = regs[0].nPyrLevels
+    poses = np.zeros((n, 4, 4), np.float32)
+    status = np.zeros(n, np.int32)
+    iters = np.zeros((n, n_pyr), np.int32)
+    spans = [shard_range(n, c, k) for c in range(k)]          # context c owns pairs lo+a .. lo+b-1 (contiguous: frame reuse)
+    for c, (a, b) in enumerate(spans):
+        if b > a:
+            regs[c].setTargetFrame(*get_frame(lo + a))
+    steps = max((b - a) for a, b in spans) if n else 0
+    g = np.eye(4) if guess is None else guess
+    for s in range(steps):
+        live = [c for c, (a, b) in enumerate(spans) if a + s < b]
+        for c in live:
+            regs[c].setSourceFrame(*get_frame(lo + spans[c][0] + s + 1))
+            regs[c].alignFrames360_begin(g, method)
+        for c in live:
+            j = spans[c][0] + s
+            status[j] = regs[c].alignFrames360_finish()
+            poses[j] = regs[c].getOptimalPose()
+            iters[j] = regs[c].num_iterations
+            if j + 1 < spans[c][1]:
+                regs[c].promoteSourceToTarget()
+    return poses, status, iters
+
+
 def gather_poses(local_poses: np.ndarray, n_total: int, dist=None, device=None):
     """All-gather of the per-rank pose blocks into the full [n_total,4,4] array on every rank."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:

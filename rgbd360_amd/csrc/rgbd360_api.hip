@@ -58,6 +58,9 @@ struct rgbd360_ctx {
     uint8_t *f_change = nullptr, *f_hd = nullptr;
     int *f_label = nullptr, *f_count = nullptr, *f_slot_of_root = nullptr, *f_root_of_slot = nullptr, *f_nslots = nullptr, *f_window = nullptr;
     double* f_mom = nullptr;
+    float al_guess[16] = {0};     // alignment in flight (rgbd360_align360_begin / _finish)
+    int al_method = 0;
+    bool al_active = false;
     int max_eval_blocks = 256;    // grid cap of the fused pass (tuning knob: RGBD360_EVAL_BLOCKS)
     std::string err;
 };
@@ -406,44 +409,58 @@ int rgbd360_promote_source_to_target(rgbd360_ctx* ctx) {
     return 0;
 }
 
-int rgbd360_align360(rgbd360_ctx* ctx, const float guess[16], int method, int occlusion, float pose_out[16],
-                     rgbd360_result* res) {
+// The whole coarse-to-fine schedule is enqueued ahead of the device: every launch carries its level and turns into a
+// no-op unless that level is the active, unfinished one (k_level_init of level l only fires once level l+1 has
+// finished).  In the common case -- each level converges within its first chunk -- the host synchronises ONCE per
+// alignment; a level that needs more passes gets another chunk, followed again by the finer levels.
+static void enqueue_schedule(rgbd360_ctx* ctx, int pending, bool pending_started) {
+    const int top = ctx->p.n_pyr - 1;
+    for (int level = pending; level >= 0; --level) {
+        if (!(level == pending && pending_started))
+            launch_level_init(ctx, level, level == top ? ctx->al_guess : nullptr, level == top ? 1 : 0);
+        const int n_pairs = (level == top && !pending_started) ? ctx->first_chunk_top : ctx->poll_chunk;
+        for (int k = 0; k < n_pairs; ++k) {
+            launch_eval(ctx, level, ctx->al_method, true);
+            launch_solve(ctx, level, 0, 0);
+        }
+    }
+}
+
+int rgbd360_align360_begin(rgbd360_ctx* ctx, const float guess[16], int method, int occlusion) {
     int rc = check_args(ctx, 0, method);
     if (rc) return rc;
     if (occlusion != 0) return fail(ctx, -5, "occlusion modes 1/2 are not implemented (SURVEY.md 8f)");
-    if (!guess || !pose_out) return fail(ctx, -1, "null pose pointer");
+    if (!guess) return fail(ctx, -1, "null pose pointer");
     hipSetDevice(ctx->p.device);
-    rgbd360_result R;
-    memset(&R, 0, sizeof(R));
-    // The whole coarse-to-fine schedule is enqueued ahead of the device: every launch carries its level and turns into
-    // a no-op unless that level is the active, unfinished one (k_level_init of level l only fires once level l+1 has
-    // finished).  In the common case -- each level converges within its first chunk -- the host synchronises ONCE per
-    // alignment; a level that needs more passes gets another chunk, followed again by the finer levels.
-    const int top = ctx->p.n_pyr - 1;
-    int pending = top;           // coarsest level not known to be finished
-    bool pending_started = false;
+    memcpy(ctx->al_guess, guess, sizeof(ctx->al_guess));
+    ctx->al_method = method;
+    ctx->al_active = true;
+    enqueue_schedule(ctx, ctx->p.n_pyr - 1, false);
+    HIPC(ctx, hipGetLastError());
+    HIPC(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(GNState), hipMemcpyDeviceToHost, ctx->stream));
+    return 0;
+}
+
+int rgbd360_align360_finish(rgbd360_ctx* ctx, float pose_out[16], rgbd360_result* res) {
+    if (!ctx || !pose_out) return -1;
+    if (!ctx->al_active) return fail(ctx, -2, "rgbd360_align360_begin was not called");
+    hipSetDevice(ctx->p.device);
+    ctx->al_active = false;
     for (int round = 0;; ++round) {
-        for (int level = pending; level >= 0; --level) {
-            if (!(level == pending && pending_started)) launch_level_init(ctx, level, level == top ? guess : nullptr, level == top ? 1 : 0);
-            const int n_pairs = (level == top && !pending_started) ? ctx->first_chunk_top : ctx->poll_chunk;
-            for (int k = 0; k < n_pairs; ++k) {
-                launch_eval(ctx, level, method, true);
-                launch_solve(ctx, level, 0, 0);
-            }
-        }
-        HIPC(ctx, hipGetLastError());
-        rc = read_state(ctx);
-        if (rc) return rc;
+        HIPC(ctx, hipStreamSynchronize(ctx->stream));      // the state copy of begin / the previous round has landed
         const GNState& S = *ctx->h_state;
         if (S.status != 0) break;
         if (S.level_active == 0 && S.done) break;
         if (S.done) return fail(ctx, -6, "alignment schedule stalled between levels");
-        pending = S.level_active;
-        pending_started = true;
         if (round > (ctx->p.max_iters + 4) * ctx->p.n_pyr) return fail(ctx, -6, "alignment loop did not terminate");
+        enqueue_schedule(ctx, S.level_active, true);         // the stalled level gets another chunk, then the finer ones
+        HIPC(ctx, hipGetLastError());
+        HIPC(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(GNState), hipMemcpyDeviceToHost, ctx->stream));
     }
-    for (int l = 0; l < ctx->p.n_pyr && l < 8; ++l) R.iters[l] = ctx->h_state->iters[l];
+    rgbd360_result R;
+    memset(&R, 0, sizeof(R));
     const GNState& S = *ctx->h_state;
+    for (int l = 0; l < ctx->p.n_pyr && l < 8; ++l) R.iters[l] = S.iters[l];
     memcpy(pose_out, S.pose, sizeof(float) * 16);
     R.status = S.status;
     memcpy(R.hessian, S.Hused, sizeof(R.hessian));
@@ -455,6 +472,14 @@ int rgbd360_align360(rgbd360_ctx* ctx, const float guess[16], int method, int oc
     R.rms_depth = S.acc_nd > 0 ? sqrt(S.acc_e2d / (double)S.acc_nd) : 0.0;
     if (res) *res = R;
     return R.status;
+}
+
+int rgbd360_align360(rgbd360_ctx* ctx, const float guess[16], int method, int occlusion, float pose_out[16],
+                     rgbd360_result* res) {
+    if (!pose_out) return ctx ? fail(ctx, -1, "null pose pointer") : -1;
+    const int rc = rgbd360_align360_begin(ctx, guess, method, occlusion);
+    if (rc) return rc;
+    return rgbd360_align360_finish(ctx, pose_out, res);
 }
 
 int rgbd360_level_dims(rgbd360_ctx* ctx, int level, int* rows, int* cols) {

@@ -421,3 +421,20 @@ def test_stitch_sphere_bit_exact(hip_lib, oracle_mod):
     assert a.shape == (int(60 * 8 * 0.5 * 60.0 / 180), 480, 3)
     assert (b_ref > 0).mean() > 0.3
     assert np.array_equal(a, a_ref) and np.array_equal(b, b_ref)
+
+
+def test_concurrent_contexts_give_identical_poses(hip_lib):
+    """rgbd360_align360_begin / _finish: several alignments in flight on one GPU (one context and stream per pair)
+    produce exactly the poses of the one-at-a-time schedule."""
+    from rgbd360_amd.batch import align_sequence, align_sequence_concurrent
+    frames = {k: synth.render(synth.trajectory_pose(k, 7), 256, 128, 7) for k in range(6)}
+    poses, status, iters = align_sequence(_mk(hip_lib, 3), lambda k: frames[k], 0, 5, 2)
+    regs = [_mk(hip_lib, 3) for _ in range(3)]
+    p2, s2, i2 = align_sequence_concurrent(regs, lambda k: frames[k], 0, 5, 2)
+    assert np.array_equal(poses, p2) and np.array_equal(status, s2) and np.array_equal(iters, i2)
+    # begin without finish, then a fresh begin: the context recovers
+    r = regs[0]
+    r.setTargetFrame(*frames[0]); r.setSourceFrame(*frames[1])
+    r.alignFrames360_begin(np.eye(4), 2)
+    assert r.alignFrames360_finish() == 0
+    assert np.array_equal(r.getOptimalPose(), poses[0])

@@ -4,7 +4,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from rgbd360_amd import synth
-from rgbd360_amd.batch import align_sequence
+from rgbd360_amd.batch import align_sequence, align_sequence_concurrent
 from rgbd360_amd.register import RegisterPhotoICP
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 W = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
@@ -18,7 +18,19 @@ for method, name in ((2, "PHOTO_DEPTH"), (0, "PHOTO_CONSISTENCY")):
     t0 = time.perf_counter()
     poses, status, iters = align_sequence(reg, lambda k: frames[k], 0, n, method)
     dt = time.perf_counter() - t0
+    if method == 2:
+        ref_poses = poses.copy()
     errs = [synth.pose_error(poses[j], np.linalg.inv(synth.trajectory_pose(j, 7)) @ synth.trajectory_pose(j + 1, 7)) for j in range(n)]
     print("%s: %d pairs in %.2f ms -> %.0f alignments/s (%.3f ms/pair incl. H2D upload + pyramids of one new frame); status ok %d/%d; "
           "mean iters/level %s; max pose err vs ground truth %.2e rad %.2e m" % (name, n, dt * 1e3, n / dt, dt * 1e3 / n, int((status == 0).sum()), n,
           np.round(iters.mean(0), 2).tolist(), max(e[0] for e in errs), max(e[1] for e in errs)))
+
+for k in (2, 4, 8):
+    regs = []
+    for _ in range(k):
+        r = RegisterPhotoICP(); r.setNumPyr(4); regs.append(r)
+    align_sequence_concurrent(regs, lambda i: frames[i], 0, min(n, 2 * k), 2)      # warm
+    t0 = time.perf_counter()
+    p2, st2, it2 = align_sequence_concurrent(regs, lambda i: frames[i], 0, n, 2)
+    dt = time.perf_counter() - t0
+    print("PHOTO_DEPTH, %d contexts in flight: %d pairs in %.2f ms -> %.0f alignments/s; identical poses: %s" % (k, n, dt * 1e3, n / dt, bool(np.array_equal(p2, ref_poses))))
