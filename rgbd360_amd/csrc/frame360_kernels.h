@@ -206,62 +206,133 @@ __global__ void k_f360_ccl_compress(int n, int* __restrict__ label) {
     if (label[i] >= 0) label[i] = uf_find(label, i);
 }
 
-// region sizes; a wave whose active lanes share one label adds once
-__global__ void k_f360_count(const int* __restrict__ label, int n, int* __restrict__ count) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int l = i < n ? label[i] : -1;
-    const int first = __builtin_amdgcn_readfirstlane(l);
-    const unsigned long long same = __ballot(l == first);
-    if (same == __ballot(true)) {
-        if (first >= 0 && (threadIdx.x & 63) == 0) atomicAdd(&count[first], (int)__builtin_popcountll(same));
-    } else if (l >= 0) {
-        atomicAdd(&count[l], 1);
+// ---- region sizes and moments: block-aggregated, integer, order-independent ------------------------------------------
+// A planar wall owns hundreds of thousands of pixels, so adding per pixel (or even per wave) into one global counter
+// serialises on that address.  Each 1024-thread block therefore sweeps 4096 consecutive pixels, aggregates per label
+// in a small LDS hash (wave-uniform labels -- the common case -- are first reduced inside the wave), and only then
+// issues one global atomic per (block, label, value).  All sums are integers (counts; moments in 2^-24 fixed point):
+// integer addition is associative, so the results are bitwise reproducible whatever the arrival order.
+constexpr int kAggThreads = 1024;
+constexpr int kAggPerThread = 4;
+constexpr int kAggHash = 64;
+constexpr double kMomScale = 16777216.0;      // 2^24 units per m (linear terms) / per m^2 (quadratic terms)
+
+__device__ __forceinline__ long long wave_sum_ll(long long v) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+// find-or-insert `key` (>= 0) in the block's LDS hash; returns the entry index or -1 when the table is full
+__device__ __forceinline__ int agg_slot(int* keys, int key) {
+    int h = (int)(((unsigned)key * 2654435761u) >> 26) & (kAggHash - 1);
+    for (int probe = 0; probe < kAggHash; ++probe) {
+        const int old = atomicCAS(&keys[h], -1, key);
+        if (old == -1 || old == key) return h;
+        h = (h + 1) & (kAggHash - 1);
+    }
+    return -1;
+}
+
+template <int NV>
+__device__ __forceinline__ void agg_add(int* keys, unsigned long long (*vals)[NV], unsigned long long* global_table, int key,
+                                        const long long v[NV], bool active) {
+    const int first = __builtin_amdgcn_readfirstlane(active ? key : -2);
+    const bool uniform = __ballot((active ? key : -2) == first) == __ballot(true);
+    if (uniform) {
+        if (first < 0) return;                                  // whole wave inactive
+        long long t[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) t[k] = wave_sum_ll(v[k]);
+        if ((threadIdx.x & 63) == 0) {
+            const int e = agg_slot(keys, first);
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                if (e >= 0) atomicAdd(&vals[e][k], (unsigned long long)t[k]);
+                else atomicAdd(&global_table[(size_t)first * NV + k], (unsigned long long)t[k]);
+            }
+        }
+    } else if (active) {
+        const int e = agg_slot(keys, key);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            if (e >= 0) atomicAdd(&vals[e][k], (unsigned long long)v[k]);
+            else atomicAdd(&global_table[(size_t)key * NV + k], (unsigned long long)v[k]);
+        }
     }
 }
 
+// count[root] = number of pixels of the region (as unsigned 64-bit)
+__global__ __launch_bounds__(kAggThreads) void k_f360_count(const int* __restrict__ label, int n, unsigned long long* __restrict__ count) {
+    __shared__ int keys[kAggHash];
+    __shared__ unsigned long long vals[kAggHash][1];
+    if (threadIdx.x < kAggHash) {
+        keys[threadIdx.x] = -1;
+        vals[threadIdx.x][0] = 0ull;
+    }
+    __syncthreads();
+    const int base = blockIdx.x * kAggThreads * kAggPerThread;
+#pragma unroll
+    for (int j = 0; j < kAggPerThread; ++j) {
+        const int i = base + j * kAggThreads + (int)threadIdx.x;
+        const int l = i < n ? label[i] : -1;
+        const long long one[1] = {1};
+        agg_add<1>(keys, vals, count, l, one, l >= 0);
+    }
+    __syncthreads();
+    if (threadIdx.x < kAggHash && keys[threadIdx.x] >= 0) atomicAdd(&count[keys[threadIdx.x]], vals[threadIdx.x][0]);
+}
+
 // compaction: roots of regions with more than min_inliers points get a slot (order fixed later on the host)
-__global__ void k_f360_assign(const int* __restrict__ label, const int* __restrict__ count, int n, int min_inliers, int max_slots,
-                              int* __restrict__ slot_of_root, int* __restrict__ root_of_slot, int* __restrict__ n_slots) {
+__global__ void k_f360_assign(const int* __restrict__ label, const unsigned long long* __restrict__ count, int n, int min_inliers,
+                              int max_slots, int* __restrict__ slot_of_root, int* __restrict__ root_of_slot, int* __restrict__ count_of_slot,
+                              int* __restrict__ n_slots) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    if (label[i] == i && count[i] > min_inliers) {
+    if (label[i] == i && count[i] > (unsigned long long)min_inliers) {
         const int s = atomicAdd(n_slots, 1);
         if (s < max_slots) {
             slot_of_root[i] = s;
             root_of_slot[s] = i;
+            count_of_slot[s] = (int)count[i];
         }
     }
 }
 
-// 9 raw moments per selected region, float64 atomics; wave-uniform labels are reduced in the wave first
-__global__ void k_f360_moments(const float* __restrict__ xyz, const int* __restrict__ label, const int* __restrict__ slot_of_root, int n,
-                               double* __restrict__ mom) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int s = -1;
-    double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (i < n) {
-        const int l = label[i];
-        if (l >= 0) s = slot_of_root[l];
-        if (s >= 0) {
-            const double x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
-            v[0] = x; v[1] = y; v[2] = z;
-            v[3] = x * x; v[4] = x * y; v[5] = x * z; v[6] = y * y; v[7] = y * z; v[8] = z * z;
-        }
+// 9 raw moments per selected region (sum x, y, z, xx, xy, xz, yy, yz, zz) in 2^-24 fixed point, two's complement in u64
+__global__ __launch_bounds__(kAggThreads) void k_f360_moments(const float* __restrict__ xyz, const int* __restrict__ label,
+                                                             const int* __restrict__ slot_of_root, int n,
+                                                             unsigned long long* __restrict__ mom) {
+    __shared__ int keys[kAggHash];
+    __shared__ unsigned long long vals[kAggHash][9];
+    if (threadIdx.x < kAggHash) {
+        keys[threadIdx.x] = -1;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) vals[threadIdx.x][k] = 0ull;
     }
-    const int first = __builtin_amdgcn_readfirstlane(s);
-    const bool uniform = __ballot(s == first) == __ballot(true);
-    if (uniform) {
-        if (first < 0) return;
+    __syncthreads();
+    const int base = blockIdx.x * kAggThreads * kAggPerThread;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            double t = v[k];
-#pragma unroll
-            for (int m = 1; m < 64; m <<= 1) t += __shfl_xor(t, m);
-            if ((threadIdx.x & 63) == 0) atomicAdd(&mom[(size_t)first * 9 + k], t);
+    for (int j = 0; j < kAggPerThread; ++j) {
+        const int i = base + j * kAggThreads + (int)threadIdx.x;
+        int s = -1;
+        long long v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (i < n) {
+            const int l = label[i];
+            if (l >= 0) s = slot_of_root[l];
+            if (s >= 0) {
+                const double x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
+                v[0] = __double2ll_rn(x * kMomScale); v[1] = __double2ll_rn(y * kMomScale); v[2] = __double2ll_rn(z * kMomScale);
+                v[3] = __double2ll_rn(x * x * kMomScale); v[4] = __double2ll_rn(x * y * kMomScale); v[5] = __double2ll_rn(x * z * kMomScale);
+                v[6] = __double2ll_rn(y * y * kMomScale); v[7] = __double2ll_rn(y * z * kMomScale); v[8] = __double2ll_rn(z * z * kMomScale);
+            }
         }
-    } else if (s >= 0) {
+        agg_add<9>(keys, vals, mom, s, v, s >= 0);
+    }
+    __syncthreads();
+    if (threadIdx.x < kAggHash && keys[threadIdx.x] >= 0) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) atomicAdd(&mom[(size_t)s * 9 + k], v[k]);
+        for (int k = 0; k < 9; ++k) atomicAdd(&mom[(size_t)keys[threadIdx.x] * 9 + k], vals[threadIdx.x][k]);
     }
 }
 

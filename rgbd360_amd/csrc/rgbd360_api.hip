@@ -56,8 +56,12 @@ struct rgbd360_ctx {
     float *f_xyz = nullptr, *f_normals = nullptr, *f_dist = nullptr, *f_plane_d = nullptr;
     float4 *f_dx = nullptr, *f_dy = nullptr;
     uint8_t *f_change = nullptr, *f_hd = nullptr;
-    int *f_label = nullptr, *f_count = nullptr, *f_slot_of_root = nullptr, *f_root_of_slot = nullptr, *f_nslots = nullptr, *f_window = nullptr;
-    double* f_mom = nullptr;
+    int *f_label = nullptr, *f_slot_of_root = nullptr, *f_root_of_slot = nullptr, *f_nslots = nullptr, *f_window = nullptr;
+    unsigned long long *f_count = nullptr, *f_mom = nullptr;
+    int* f_count_of_slot = nullptr;
+    float* f_tab = nullptr;
+    size_t f_tab_n = 0;
+    uint8_t* f_depth_raw = nullptr;
     float al_guess[16] = {0};     // alignment in flight (rgbd360_align360_begin / _finish)
     int al_method = 0;
     bool al_active = false;
@@ -354,6 +358,7 @@ void rgbd360_destroy(rgbd360_ctx* ctx) {
     hipFree(ctx->f_xyz); hipFree(ctx->f_normals); hipFree(ctx->f_dist); hipFree(ctx->f_plane_d); hipFree(ctx->f_dx); hipFree(ctx->f_dy);
     hipFree(ctx->f_change); hipFree(ctx->f_hd); hipFree(ctx->f_label); hipFree(ctx->f_count); hipFree(ctx->f_slot_of_root);
     hipFree(ctx->f_root_of_slot); hipFree(ctx->f_nslots); hipFree(ctx->f_window); hipFree(ctx->f_mom);
+    hipFree(ctx->f_count_of_slot); hipFree(ctx->f_depth_raw);
     if (ctx->h_state) hipHostFree(ctx->h_state);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
@@ -704,84 +709,6 @@ int rgbd360_selftest_math(rgbd360_ctx* ctx, uint32_t first_bits, uint32_t count,
     return 0;
 }
 
-int rgbd360_sphere_cloud(rgbd360_ctx* ctx, const void* depth, size_t depth_step, int depth_type, int rows, int cols,
-                         int convention, float* host_out_xyz) {
-    if (!ctx || !depth || !host_out_xyz) return -1;
-    if (rows < 1 || cols < 1 || convention < 0 || convention > 2 || (depth_type != 0 && depth_type != 1))
-        return fail(ctx, -1, "bad arguments");
-    hipSetDevice(ctx->p.device);
-    std::vector<float> st(cols), ct(cols), sp(rows), cp(rows);
-    if (convention == 0) {          // Frame360.h:562-585
-        const float angle_pixel(cols / (2 * kPI));
-        const float angle_pixel_inv(1 / angle_pixel);
-        const float offset_phi = kPI * 31.5 / 180;
-        for (int r = 0; r < rows; ++r) {
-            float phi_i = offset_phi - r * angle_pixel_inv;
-            sp[r] = sinf(phi_i);
-            cp[r] = cosf(phi_i);
-        }
-        for (int c = 0; c < cols; ++c) {
-            float theta_i = c * angle_pixel_inv;
-            st[c] = sinf(theta_i);
-            ct[c] = cosf(theta_i);
-        }
-    } else if (convention == 1) {   // Frame360_stereo.h:470-490
-        const float step_theta = 2 * kPI / cols;
-        const float step_phi = step_theta;
-        const int start_phi = 166;
-        for (int r = 0; r < rows; ++r) {
-            float phi = (r + start_phi) * step_phi - kPI / 2;
-            cp[r] = cosf(phi);
-            sp[r] = sinf(phi);
-        }
-        for (int c = 0; c < cols; ++c) {
-            float theta = c * step_theta - kPI;
-            st[c] = sinf(theta);
-            ct[c] = cosf(theta);
-        }
-    } else {                        // RPI.h:4556-4571
-        const float angle_res = 2 * kPI / cols;
-        const float half_nRows = 0.5 * rows - 0.5;
-        for (int c = 0; c < cols; ++c) {
-            float theta = c * angle_res;
-            st[c] = sinf(theta);
-            ct[c] = cosf(theta);
-        }
-        for (int r = 0; r < rows; ++r) {
-            float phi = (half_nRows - r) * angle_res;
-            sp[r] = sinf(phi);
-            cp[r] = cosf(phi);
-        }
-    }
-    const size_t dpx = depth_type == 0 ? 2 : 4;
-    float *d_tab = nullptr, *d_xyz = nullptr;
-    uint8_t* d_depth = nullptr;
-    const size_t ntab = (size_t)2 * cols + 2 * rows;
-    hipError_t e = hipMalloc(&d_tab, ntab * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc(&d_xyz, (size_t)rows * cols * 3 * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc(&d_depth, (size_t)rows * cols * dpx);
-    if (e == hipSuccess) {
-        std::vector<float> tab;
-        tab.insert(tab.end(), st.begin(), st.end());
-        tab.insert(tab.end(), ct.begin(), ct.end());
-        tab.insert(tab.end(), sp.begin(), sp.end());
-        tab.insert(tab.end(), cp.begin(), cp.end());
-        e = hipMemcpy(d_tab, tab.data(), ntab * sizeof(float), hipMemcpyHostToDevice);
-    }
-    if (e == hipSuccess)
-        e = hipMemcpy2D(d_depth, (size_t)cols * dpx, depth, depth_step, (size_t)cols * dpx, rows, hipMemcpyHostToDevice);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_sphere_cloud, grid2d(rows, cols), dim3(256), 0, ctx->stream, d_depth, (size_t)cols * dpx,
-                           depth_type, rows, cols, convention, d_tab, d_tab + cols, d_tab + 2 * cols, d_tab + 2 * cols + rows,
-                           d_xyz);
-        e = hipStreamSynchronize(ctx->stream);
-    }
-    if (e == hipSuccess) e = hipMemcpy(host_out_xyz, d_xyz, (size_t)rows * cols * 3 * sizeof(float), hipMemcpyDeviceToHost);
-    hipFree(d_tab); hipFree(d_xyz); hipFree(d_depth);
-    HIPC(ctx, e);
-    return 0;
-}
-
 }  // extern "C"
 
 // ---------------------------------------------------------------------------------------------------------
@@ -795,6 +722,7 @@ int f360_ensure(rgbd360_ctx* ctx, size_t n) {
     hipFree(ctx->f_xyz); hipFree(ctx->f_normals); hipFree(ctx->f_dist); hipFree(ctx->f_plane_d); hipFree(ctx->f_dx); hipFree(ctx->f_dy);
     hipFree(ctx->f_change); hipFree(ctx->f_hd); hipFree(ctx->f_label); hipFree(ctx->f_count); hipFree(ctx->f_slot_of_root);
     hipFree(ctx->f_root_of_slot); hipFree(ctx->f_nslots); hipFree(ctx->f_window); hipFree(ctx->f_mom);
+    hipFree(ctx->f_count_of_slot); hipFree(ctx->f_depth_raw);
     ctx->f360_n = 0;
     HIPC(ctx, hipMalloc(&ctx->f_xyz, n * 3 * sizeof(float)));
     HIPC(ctx, hipMalloc(&ctx->f_normals, n * 3 * sizeof(float)));
@@ -805,12 +733,14 @@ int f360_ensure(rgbd360_ctx* ctx, size_t n) {
     HIPC(ctx, hipMalloc(&ctx->f_change, n));
     HIPC(ctx, hipMalloc(&ctx->f_hd, n));
     HIPC(ctx, hipMalloc(&ctx->f_label, n * sizeof(int)));
-    HIPC(ctx, hipMalloc(&ctx->f_count, n * sizeof(int)));
+    HIPC(ctx, hipMalloc(&ctx->f_count, n * sizeof(unsigned long long)));
     HIPC(ctx, hipMalloc(&ctx->f_slot_of_root, n * sizeof(int)));
     HIPC(ctx, hipMalloc(&ctx->f_window, n * sizeof(int)));
     HIPC(ctx, hipMalloc(&ctx->f_root_of_slot, kF360MaxSlots * sizeof(int)));
     HIPC(ctx, hipMalloc(&ctx->f_nslots, sizeof(int)));
-    HIPC(ctx, hipMalloc(&ctx->f_mom, (size_t)kF360MaxSlots * 9 * sizeof(double)));
+    HIPC(ctx, hipMalloc(&ctx->f_mom, (size_t)kF360MaxSlots * 9 * sizeof(unsigned long long)));
+    HIPC(ctx, hipMalloc(&ctx->f_count_of_slot, kF360MaxSlots * sizeof(int)));
+    HIPC(ctx, hipMalloc(&ctx->f_depth_raw, n * 4));
     ctx->f360_n = n;
     return 0;
 }
@@ -873,18 +803,19 @@ int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float
     using namespace f360;
     const int n = rows * cols;
     const dim3 g1((n + 255) / 256), b(256);
-    HIPC(ctx, hipMemsetAsync(ctx->f_count, 0, (size_t)n * sizeof(int), ctx->stream));
+    HIPC(ctx, hipMemsetAsync(ctx->f_count, 0, (size_t)n * sizeof(unsigned long long), ctx->stream));
     HIPC(ctx, hipMemsetAsync(ctx->f_slot_of_root, 0xFF, (size_t)n * sizeof(int), ctx->stream));
     HIPC(ctx, hipMemsetAsync(ctx->f_nslots, 0, sizeof(int), ctx->stream));
-    HIPC(ctx, hipMemsetAsync(ctx->f_mom, 0, (size_t)kF360MaxSlots * 9 * sizeof(double), ctx->stream));
+    HIPC(ctx, hipMemsetAsync(ctx->f_mom, 0, (size_t)kF360MaxSlots * 9 * sizeof(unsigned long long), ctx->stream));
     hipLaunchKernelGGL(k_f360_ccl_init, g1, b, 0, ctx->stream, ctx->f_xyz, ctx->f_normals, n, ctx->f_plane_d, ctx->f_label);
     hipLaunchKernelGGL(k_f360_ccl_merge, grid2d(rows, cols), b, 0, ctx->stream, ctx->f_xyz, ctx->f_normals, ctx->f_plane_d, rows, cols,
                        cosf(angular_threshold), distance_threshold, depth_mode, ctx->f_label);
     hipLaunchKernelGGL(k_f360_ccl_compress, g1, b, 0, ctx->stream, n, ctx->f_label);
-    hipLaunchKernelGGL(k_f360_count, g1, b, 0, ctx->stream, ctx->f_label, n, ctx->f_count);
+    const dim3 gagg((n + kAggThreads * kAggPerThread - 1) / (kAggThreads * kAggPerThread)), bagg(kAggThreads);
+    hipLaunchKernelGGL(k_f360_count, gagg, bagg, 0, ctx->stream, ctx->f_label, n, ctx->f_count);
     hipLaunchKernelGGL(k_f360_assign, g1, b, 0, ctx->stream, ctx->f_label, ctx->f_count, n, min_inliers, kF360MaxSlots,
-                       ctx->f_slot_of_root, ctx->f_root_of_slot, ctx->f_nslots);
-    hipLaunchKernelGGL(k_f360_moments, g1, b, 0, ctx->stream, ctx->f_xyz, ctx->f_label, ctx->f_slot_of_root, n, ctx->f_mom);
+                       ctx->f_slot_of_root, ctx->f_root_of_slot, ctx->f_count_of_slot, ctx->f_nslots);
+    hipLaunchKernelGGL(k_f360_moments, gagg, bagg, 0, ctx->stream, ctx->f_xyz, ctx->f_label, ctx->f_slot_of_root, n, ctx->f_mom);
     HIPC(ctx, hipGetLastError());
     int nslots = 0;
     HIPC(ctx, hipMemcpyAsync(&nslots, ctx->f_nslots, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -893,10 +824,11 @@ int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float
     std::vector<int> roots(nslots), counts(nslots);
     std::vector<double> mom((size_t)nslots * 9);
     if (nslots > 0) {
+        std::vector<unsigned long long> raw((size_t)nslots * 9);
         HIPC(ctx, hipMemcpy(roots.data(), ctx->f_root_of_slot, nslots * sizeof(int), hipMemcpyDeviceToHost));
-        HIPC(ctx, hipMemcpy(mom.data(), ctx->f_mom, (size_t)nslots * 9 * sizeof(double), hipMemcpyDeviceToHost));
-        for (int s = 0; s < nslots; ++s)
-            HIPC(ctx, hipMemcpy(&counts[s], ctx->f_count + roots[s], sizeof(int), hipMemcpyDeviceToHost));
+        HIPC(ctx, hipMemcpy(raw.data(), ctx->f_mom, raw.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (size_t k = 0; k < raw.size(); ++k) mom[k] = (double)(long long)raw[k] / kMomScale;     // fixed point -> metres
+        HIPC(ctx, hipMemcpy(counts.data(), ctx->f_count_of_slot, nslots * sizeof(int), hipMemcpyDeviceToHost));
     }
     std::vector<int> order(nslots);
     for (int s = 0; s < nslots; ++s) order[s] = s;
@@ -931,7 +863,93 @@ int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float
     *n_planes = np;
     return 0;
 }
+// organised cloud of one spherical depth image -> ctx->f_xyz (device); the per-row/column sin/cos tables follow the
+// reference's float expressions and are computed on the host (rows + cols values)
+int sphere_cloud_dev(rgbd360_ctx* ctx, const void* depth, size_t depth_step, int depth_type, int rows, int cols, int convention) {
+    if (convention < 0 || convention > 2 || (depth_type != 0 && depth_type != 1)) return fail(ctx, -1, "bad arguments");
+    std::vector<float> st(cols), ct(cols), sp(rows), cp(rows);
+    if (convention == 0) {          // Frame360.h:562-585
+        const float angle_pixel(cols / (2 * kPI));
+        const float angle_pixel_inv(1 / angle_pixel);
+        const float offset_phi = kPI * 31.5 / 180;
+        for (int r = 0; r < rows; ++r) {
+            float phi_i = offset_phi - r * angle_pixel_inv;
+            sp[r] = sinf(phi_i);
+            cp[r] = cosf(phi_i);
+        }
+        for (int c = 0; c < cols; ++c) {
+            float theta_i = c * angle_pixel_inv;
+            st[c] = sinf(theta_i);
+            ct[c] = cosf(theta_i);
+        }
+    } else if (convention == 1) {   // Frame360_stereo.h:470-490
+        const float step_theta = 2 * kPI / cols;
+        const float step_phi = step_theta;
+        const int start_phi = 166;
+        for (int r = 0; r < rows; ++r) {
+            float phi = (r + start_phi) * step_phi - kPI / 2;
+            cp[r] = cosf(phi);
+            sp[r] = sinf(phi);
+        }
+        for (int c = 0; c < cols; ++c) {
+            float theta = c * step_theta - kPI;
+            st[c] = sinf(theta);
+            ct[c] = cosf(theta);
+        }
+    } else {                        // RPI.h:4556-4571
+        const float angle_res = 2 * kPI / cols;
+        const float half_nRows = 0.5 * rows - 0.5;
+        for (int c = 0; c < cols; ++c) {
+            float theta = c * angle_res;
+            st[c] = sinf(theta);
+            ct[c] = cosf(theta);
+        }
+        for (int r = 0; r < rows; ++r) {
+            float phi = (half_nRows - r) * angle_res;
+            sp[r] = sinf(phi);
+            cp[r] = cosf(phi);
+        }
+    }
+    const size_t dpx = depth_type == 0 ? 2 : 4;
+    const size_t ntab = (size_t)2 * cols + 2 * rows;
+    if (ctx->f_tab_n < ntab) {
+        hipFree(ctx->f_tab);
+        ctx->f_tab = nullptr;
+        ctx->f_tab_n = 0;
+        HIPC(ctx, hipMalloc(&ctx->f_tab, ntab * sizeof(float)));
+        ctx->f_tab_n = ntab;
+    }
+    std::vector<float> tab;
+    tab.insert(tab.end(), st.begin(), st.end());
+    tab.insert(tab.end(), ct.begin(), ct.end());
+    tab.insert(tab.end(), sp.begin(), sp.end());
+    tab.insert(tab.end(), cp.begin(), cp.end());
+    HIPC(ctx, hipMemcpyAsync(ctx->f_tab, tab.data(), ntab * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    HIPC(ctx, hipMemcpy2DAsync(ctx->f_depth_raw, (size_t)cols * dpx, depth, depth_step, (size_t)cols * dpx, rows, hipMemcpyHostToDevice,
+                               ctx->stream));
+    float* d_tab = ctx->f_tab;
+    hipLaunchKernelGGL(k_sphere_cloud, grid2d(rows, cols), dim3(256), 0, ctx->stream, ctx->f_depth_raw, (size_t)cols * dpx, depth_type,
+                       rows, cols, convention, d_tab, d_tab + cols, d_tab + 2 * cols, d_tab + 2 * cols + rows, ctx->f_xyz);
+    HIPC(ctx, hipGetLastError());
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));      // `tab` (pageable) must outlive the copy
+    return 0;
+}
 }  // namespace
+
+extern "C" int rgbd360_sphere_cloud(rgbd360_ctx* ctx, const void* depth, size_t depth_step, int depth_type, int rows, int cols,
+                         int convention, float* host_out_xyz) {
+    if (!ctx || !depth || !host_out_xyz) return -1;
+    if (rows < 1 || cols < 1 || (long long)rows * cols >= (1ll << 30)) return fail(ctx, -1, "bad image size");
+    hipSetDevice(ctx->p.device);
+    const size_t n = (size_t)rows * cols;
+    int rc = f360_ensure(ctx, n);
+    if (rc) return rc;
+    rc = sphere_cloud_dev(ctx, depth, depth_step, depth_type, rows, cols, convention);
+    if (rc) return rc;
+    HIPC(ctx, hipMemcpyAsync(host_out_xyz, ctx->f_xyz, n * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
 
 extern "C" int rgbd360_normals(rgbd360_ctx* ctx, const float* xyz, int rows, int cols, float max_depth_change_factor,
                                float normal_smoothing_size, int depth_mode, float* normals_out) {
@@ -993,19 +1011,14 @@ extern "C" int rgbd360_frame_planes(rgbd360_ctx* ctx, const void* depth, size_t 
                                     int max_planes, int* n_planes_out) {
     if (!ctx || !depth || !planes_out || !n_planes_out || max_planes < 1) return -1;
     if (rows < 3 || cols < 3 || (long long)rows * cols >= (1ll << 30)) return fail(ctx, -1, "bad image size");
+    hipSetDevice(ctx->p.device);
     const size_t n = (size_t)rows * cols;
     int rc = f360_ensure(ctx, n);
     if (rc) return rc;
-    // cloud on the device (the host copy of rgbd360_sphere_cloud is only made when asked for)
-    std::vector<float> tmp;
-    float* host_xyz = xyz_out;
-    if (!host_xyz) {
-        tmp.resize(n * 3);
-        host_xyz = tmp.data();
-    }
-    rc = rgbd360_sphere_cloud(ctx, depth, depth_step, depth_type, rows, cols, convention, host_xyz);
+    // the cloud stays on the device; a host copy is only made when asked for
+    rc = sphere_cloud_dev(ctx, depth, depth_step, depth_type, rows, cols, convention);
     if (rc) return rc;
-    HIPC(ctx, hipMemcpyAsync(ctx->f_xyz, host_xyz, n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    if (xyz_out) HIPC(ctx, hipMemcpyAsync(xyz_out, ctx->f_xyz, n * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     rc = f360_normals_dev(ctx, rows, cols, max_depth_change_factor, normal_smoothing_size, depth_mode);
     if (rc) return rc;
     rc = f360_planes_dev(ctx, rows, cols, min_inliers, angular_threshold, distance_threshold, max_curvature, depth_mode, planes_out,
