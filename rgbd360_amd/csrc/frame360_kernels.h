@@ -13,7 +13,7 @@
 //   k_f360_dist       chamfer (1 / 1.4) distance map, truncated at kF360R    4 B/px
 //   k_f360_diff       central differences DX, DY (initAverage3DGradientMethod) 32 B/px
 //   k_f360_normals    window-averaged gradients -> normal, flipped to the viewpoint
-//   k_f360_ccl_init / _merge / _compress   label-equivalence connected components (union-find, atomicMin)
+//   k_f360_ccl_rows / _merge / _compress   connected components: row runs by scan, vertical joins by union-find (atomicMin)
 //   k_f360_count / _assign / _moments      region sizes, compaction of the large regions, 9 moments per region
 #pragma once
 #include <hip/hip_runtime.h>
@@ -148,13 +148,61 @@ __global__ void k_f360_normals(const float* __restrict__ xyz, const float* __res
 }
 
 // ---- organised connected components with PlaneCoefficientComparator -------------------------------------------
-__global__ void k_f360_ccl_init(const float* __restrict__ xyz, const float* __restrict__ normals, int n, float* __restrict__ plane_d,
-                                int* __restrict__ label) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// PlaneCoefficientComparator::compare(i, j) as the segmentation calls it: i = the pixel visited, j = its left / upper
+// neighbour; the distance threshold scales with the depth of i.  plane_d = p . n in the reference's float order.
+__device__ __forceinline__ float plane_dot(const float* __restrict__ xyz, const float* __restrict__ normals, int i) {
     const float *p = xyz + 3 * (size_t)i, *q = normals + 3 * (size_t)i;
-    plane_d[i] = p[0] * q[0] + p[1] * q[1] + p[2] * q[2];
-    label[i] = finite3(p[0], p[1], p[2]) ? i : -1;
+    return p[0] * q[0] + p[1] * q[1] + p[2] * q[2];
+}
+__device__ __forceinline__ bool plane_link(const float* __restrict__ xyz, const float* __restrict__ normals, int i, int j, float cos_thr,
+                                           float dist_thr, int depth_mode) {
+    const float *p = xyz + 3 * (size_t)i, *q = xyz + 3 * (size_t)j;
+    if (!finite3(p[0], p[1], p[2]) || !finite3(q[0], q[1], q[2])) return false;
+    const float* n = normals + 3 * (size_t)i;
+    const float* m = normals + 3 * (size_t)j;
+    const float z = depth_of(p, depth_mode);
+    const float thr = dist_thr * z * z;                          // depth-dependent distance threshold
+    const float dot = n[0] * m[0] + n[1] * m[1] + n[2] * m[2];
+    return (fabsf(plane_dot(xyz, normals, i) - plane_dot(xyz, normals, j)) < thr) && (dot > cos_thr);
+}
+
+// Pass 1, one block per image row: every pixel is labelled with the first pixel of its horizontal run of linked
+// pixels (an inclusive max-scan of "column where a run starts"), so pass 2 only has to join runs vertically.
+constexpr int kCclRowThreads = 256;
+__global__ __launch_bounds__(kCclRowThreads) void k_f360_ccl_rows(const float* __restrict__ xyz, const float* __restrict__ normals, int rows,
+                                                                 int cols, float cos_thr, float dist_thr, int depth_mode,
+                                                                 int* __restrict__ label, uint8_t* __restrict__ link_left) {
+    __shared__ int wave_last[kCclRowThreads / 64];
+    __shared__ int carry_s;
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int carry = -1;
+    for (int c0 = 0; c0 < cols; c0 += kCclRowThreads) {
+        const int c = c0 + tid;
+        const int i = r * cols + c;
+        bool valid = false, link = false;
+        if (c < cols) {
+            const float* p = xyz + 3 * (size_t)i;
+            valid = finite3(p[0], p[1], p[2]);
+            link = c > 0 && valid && plane_link(xyz, normals, i, i - 1, cos_thr, dist_thr, depth_mode);
+        }
+        int v = (c < cols && !link) ? c : -1;                    // a run starts here
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(v, o);
+            if (lane >= o) v = t > v ? t : v;
+        }
+        if (lane == 63) wave_last[w] = v;
+        __syncthreads();
+        int start = v > carry ? v : carry;
+        for (int k = 0; k < w; ++k) start = wave_last[k] > start ? wave_last[k] : start;
+        if (c < cols) {
+            label[i] = valid ? r * cols + start : -1;
+            link_left[i] = link ? 1 : 0;
+        }
+        if (tid == kCclRowThreads - 1) carry_s = start;
+        __syncthreads();
+        carry = carry_s;
+    }
 }
 
 __device__ __forceinline__ int uf_find(const int* label, int x) {
@@ -179,25 +227,16 @@ __device__ __forceinline__ void uf_union(int* label, int a, int b) {
     }
 }
 
-__global__ void k_f360_ccl_merge(const float* __restrict__ xyz, const float* __restrict__ normals, const float* __restrict__ plane_d,
+// Pass 2: join a pixel's run with the run of its upper neighbour.  The join is skipped where the pixel to the left
+// already made it (same two runs), which leaves about one union per pair of overlapping runs.
+__global__ void k_f360_ccl_merge(const float* __restrict__ xyz, const float* __restrict__ normals, const uint8_t* __restrict__ link_left,
                                  int rows, int cols, float cos_thr, float dist_thr, int depth_mode, int* __restrict__ label) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
-    if (c >= cols || r >= rows) return;
-    const int i = r * cols + c;
-    if (label[i] < 0) return;
-    const float* p = xyz + 3 * (size_t)i;
-    const float* n = normals + 3 * (size_t)i;
-    const float z = depth_of(p, depth_mode);
-    const float thr = dist_thr * z * z;                          // depth-dependent distance threshold
-    const float pd = plane_d[i];
-    const int nb[2] = {c > 0 ? i - 1 : -1, r > 0 ? i - cols : -1};
-    for (int k = 0; k < 2; ++k) {
-        const int j = nb[k];
-        if (j < 0 || label[j] < 0) continue;
-        const float* m = normals + 3 * (size_t)j;
-        const float dot = n[0] * m[0] + n[1] * m[1] + n[2] * m[2];
-        if ((fabsf(pd - plane_d[j]) < thr) && (dot > cos_thr)) uf_union(label, i, j);
-    }
+    if (c >= cols || r >= rows || r == 0) return;
+    const int i = r * cols + c, up = i - cols;
+    if (!plane_link(xyz, normals, i, up, cos_thr, dist_thr, depth_mode)) return;
+    if (c > 0 && link_left[i] && link_left[up] && plane_link(xyz, normals, i - 1, up - 1, cos_thr, dist_thr, depth_mode)) return;
+    uf_union(label, i, up);
 }
 
 __global__ void k_f360_ccl_compress(int n, int* __restrict__ label) {

@@ -53,7 +53,7 @@ struct rgbd360_ctx {
     int first_chunk_top = 8;      // ... and for the first visit of the coarsest level (cheap passes, most iterations)
     // Frame360 stage scratch (normals / plane segmentation), grown on demand
     size_t f360_n = 0;
-    float *f_xyz = nullptr, *f_normals = nullptr, *f_dist = nullptr, *f_plane_d = nullptr;
+    float *f_xyz = nullptr, *f_normals = nullptr, *f_dist = nullptr;
     float4 *f_dx = nullptr, *f_dy = nullptr;
     uint8_t *f_change = nullptr, *f_hd = nullptr;
     int *f_label = nullptr, *f_slot_of_root = nullptr, *f_root_of_slot = nullptr, *f_nslots = nullptr, *f_window = nullptr;
@@ -355,7 +355,7 @@ void rgbd360_destroy(rgbd360_ctx* ctx) {
     free_levels(ctx);
     hipFree(ctx->d_state); hipFree(ctx->d_partials); hipFree(ctx->d_gnio);
     hipFree(ctx->d_stage_rgb); hipFree(ctx->d_stage_depth);
-    hipFree(ctx->f_xyz); hipFree(ctx->f_normals); hipFree(ctx->f_dist); hipFree(ctx->f_plane_d); hipFree(ctx->f_dx); hipFree(ctx->f_dy);
+    hipFree(ctx->f_xyz); hipFree(ctx->f_normals); hipFree(ctx->f_dist); hipFree(ctx->f_dx); hipFree(ctx->f_dy);
     hipFree(ctx->f_change); hipFree(ctx->f_hd); hipFree(ctx->f_label); hipFree(ctx->f_count); hipFree(ctx->f_slot_of_root);
     hipFree(ctx->f_root_of_slot); hipFree(ctx->f_nslots); hipFree(ctx->f_window); hipFree(ctx->f_mom);
     hipFree(ctx->f_count_of_slot); hipFree(ctx->f_depth_raw);
@@ -719,7 +719,7 @@ constexpr int kF360MaxSlots = 4096;
 
 int f360_ensure(rgbd360_ctx* ctx, size_t n) {
     if (ctx->f360_n >= n) return 0;
-    hipFree(ctx->f_xyz); hipFree(ctx->f_normals); hipFree(ctx->f_dist); hipFree(ctx->f_plane_d); hipFree(ctx->f_dx); hipFree(ctx->f_dy);
+    hipFree(ctx->f_xyz); hipFree(ctx->f_normals); hipFree(ctx->f_dist); hipFree(ctx->f_dx); hipFree(ctx->f_dy);
     hipFree(ctx->f_change); hipFree(ctx->f_hd); hipFree(ctx->f_label); hipFree(ctx->f_count); hipFree(ctx->f_slot_of_root);
     hipFree(ctx->f_root_of_slot); hipFree(ctx->f_nslots); hipFree(ctx->f_window); hipFree(ctx->f_mom);
     hipFree(ctx->f_count_of_slot); hipFree(ctx->f_depth_raw);
@@ -727,7 +727,6 @@ int f360_ensure(rgbd360_ctx* ctx, size_t n) {
     HIPC(ctx, hipMalloc(&ctx->f_xyz, n * 3 * sizeof(float)));
     HIPC(ctx, hipMalloc(&ctx->f_normals, n * 3 * sizeof(float)));
     HIPC(ctx, hipMalloc(&ctx->f_dist, n * sizeof(float)));
-    HIPC(ctx, hipMalloc(&ctx->f_plane_d, n * sizeof(float)));
     HIPC(ctx, hipMalloc(&ctx->f_dx, n * sizeof(float4)));
     HIPC(ctx, hipMalloc(&ctx->f_dy, n * sizeof(float4)));
     HIPC(ctx, hipMalloc(&ctx->f_change, n));
@@ -807,8 +806,9 @@ int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float
     HIPC(ctx, hipMemsetAsync(ctx->f_slot_of_root, 0xFF, (size_t)n * sizeof(int), ctx->stream));
     HIPC(ctx, hipMemsetAsync(ctx->f_nslots, 0, sizeof(int), ctx->stream));
     HIPC(ctx, hipMemsetAsync(ctx->f_mom, 0, (size_t)kF360MaxSlots * 9 * sizeof(unsigned long long), ctx->stream));
-    hipLaunchKernelGGL(k_f360_ccl_init, g1, b, 0, ctx->stream, ctx->f_xyz, ctx->f_normals, n, ctx->f_plane_d, ctx->f_label);
-    hipLaunchKernelGGL(k_f360_ccl_merge, grid2d(rows, cols), b, 0, ctx->stream, ctx->f_xyz, ctx->f_normals, ctx->f_plane_d, rows, cols,
+    hipLaunchKernelGGL(k_f360_ccl_rows, dim3(rows), dim3(kCclRowThreads), 0, ctx->stream, ctx->f_xyz, ctx->f_normals, rows, cols,
+                       cosf(angular_threshold), distance_threshold, depth_mode, ctx->f_label, ctx->f_change);
+    hipLaunchKernelGGL(k_f360_ccl_merge, grid2d(rows, cols), b, 0, ctx->stream, ctx->f_xyz, ctx->f_normals, ctx->f_change, rows, cols,
                        cosf(angular_threshold), distance_threshold, depth_mode, ctx->f_label);
     hipLaunchKernelGGL(k_f360_ccl_compress, g1, b, 0, ctx->stream, n, ctx->f_label);
     const dim3 gagg((n + kAggThreads * kAggPerThread - 1) / (kAggThreads * kAggPerThread)), bagg(kAggThreads);
