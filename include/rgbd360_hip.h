@@ -96,7 +96,10 @@ int rgbd360_set_source_dev(rgbd360_ctx* ctx, const uint8_t* rgb_dev, size_t rgb_
 int rgbd360_promote_source_to_target(rgbd360_ctx* ctx);
 
 /* RegisterPhotoICP::alignFrames360(pose_guess, method, occlusion) (RPI.h:4519-4784) + getOptimalPose().
- * occlusion must be 0 (Occ1/Occ2 are SURVEY.md §8f items). */
+ * occlusion 0 = regular registration, 1 / 2 = the z-buffer variants errorPhotoICP_sphereOcc1/2 + calcHessGrad_sphereOcc1/2
+ * (RPI.h:3232-4249) with the sequential semantics of the reference source (its OpenMP build races on the z-buffer; see
+ * DESIGN.md).  occlusion 1 needs method PHOTO_DEPTH: with one modality the reference's error is 0/0 and it returns the
+ * guess (status RGBD360_NO_VALID_PIXELS here). */
 int rgbd360_align360(rgbd360_ctx* ctx, const float guess[16], int method, int occlusion, float pose_out[16],
                      rgbd360_result* res);
 
@@ -124,6 +127,12 @@ int rgbd360_get_lut(rgbd360_ctx* ctx, int level, float* host_out_xyz);
 int rgbd360_eval(rgbd360_ctx* ctx, int level, const float pose[16], int method, double* err2, long long* n_valid,
                  double err2_split[2], long long n_split[2], float H[36], float g[6], double H64[36], double g64[6],
                  long long* n_visible);
+/* The same pass in the occlusion-aware variants (occlusion 1: RPI.h:3232-3716, 2: RPI.h:3720-4249; 0 = rgbd360_eval).
+ * n_split[] are the reference's nValidPhotoPts / nValidDepthPts (occlusion 2: both = nValidDepthPts), the error of
+ * the alignment loop is sqrt(err2_split[0]/n_split[0]) + sqrt(err2_split[1]/n_split[1]). */
+int rgbd360_eval_occ(rgbd360_ctx* ctx, int level, const float pose[16], int method, int occlusion, double* err2,
+                     long long* n_valid, double err2_split[2], long long n_split[2], float H[36], float g[6], double H64[36],
+                     double g64[6], long long* n_visible);
 /* Warped target pixel of every source pixel of `level` under `pose`: out[2i] = r', out[2i+1] = c', -1 if the
  * pixel is invalid or leaves the image (RPI.h:2663-2684).  Host output, n x 2 int32. */
 int rgbd360_warp_indices(rgbd360_ctx* ctx, int level, const float pose[16], int32_t* host_out_rc);

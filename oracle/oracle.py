@@ -60,6 +60,11 @@ def lib():
         for f in (L.oracle_set_target, L.oracle_set_source):
             f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int]
         L.oracle_align360.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(Result)]
+        L.oracle_align360_occ.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(Result)]
+        L.oracle_error_occ.restype = C.c_double
+        L.oracle_error_occ.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.oracle_hessgrad_occ.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.POINTER(C.c_long)]
         L.oracle_trace_len.argtypes = [C.c_void_p]
         L.oracle_trace_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(Trace)]
         L.oracle_level_dims.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -148,11 +153,30 @@ class Oracle:
     def set_source(self, rgb, depth):
         self._set(lib().oracle_set_source, rgb, depth)
 
-    def align360(self, guess=None, method=PHOTO_CONSISTENCY):
+    def align360(self, guess=None, method=PHOTO_CONSISTENCY, occlusion=0):
         g = pose_to_cm(np.eye(4) if guess is None else guess)
         out = np.zeros(16, dtype=np.float32)
-        st = lib().oracle_align360(self.h, _ptr(g), method, _ptr(out), C.byref(self.result))
+        if occlusion:
+            st = lib().oracle_align360_occ(self.h, _ptr(g), method, occlusion, _ptr(out), C.byref(self.result))
+        else:
+            st = lib().oracle_align360(self.h, _ptr(g), method, _ptr(out), C.byref(self.result))
         return st, pose_from_cm(out)
+
+    def error_occ(self, level, pose, method, occlusion):
+        """Occlusion-mode error pass -> (avPhoto + avDepth, sum photo, sum depth, n photo, n depth)."""
+        sums = np.zeros(4, np.float64)
+        e = lib().oracle_error_occ(self.h, level, _ptr(pose_to_cm(pose)), method, occlusion, _ptr(sums))
+        return e, sums[0], sums[1], int(sums[2]), int(sums[3])
+
+    def hessgrad_occ(self, level, pose, method, occlusion):
+        H = np.zeros(36, np.float32)
+        g = np.zeros(6, np.float32)
+        Hd = np.zeros(36, np.float64)
+        gd = np.zeros(6, np.float64)
+        nv = C.c_long()
+        lib().oracle_hessgrad_occ(self.h, level, _ptr(pose_to_cm(pose)), method, occlusion, _ptr(H), _ptr(g), _ptr(Hd),
+                                  _ptr(gd), C.byref(nv))
+        return H.reshape(6, 6).T.copy(), g, Hd.reshape(6, 6).T.copy(), gd, nv.value
 
     def trace(self):
         n = lib().oracle_trace_len(self.h)

@@ -599,6 +599,258 @@ void calcHessGrad_sphere(Ctx& ctx, int level, const float* pose, int method) {
 }
 
 // ------------------------------------------------------------------------------------
+// Occlusion-aware variants.  The reference runs their pixel loops under `#pragma omp parallel
+// for` while the loop bodies read and write shared z-buffers / per-target rows without synchronisation, so the OpenMP
+// build's results depend on thread timing.  What is restated here is the SEQUENTIAL semantics of the same source
+// (ENABLE_OPENMP 0): pixels visited in index order.  RPI.h:4525 hard-codes thresDepthOutliers = 0.3.
+// ------------------------------------------------------------------------------------
+constexpr float kThresDepthOutliers = 0.3f;
+
+struct OccSums {
+    double photo = 0, depth = 0;    // sums of the squared weighted residuals
+    long nPhoto = 0, nDepth = 0;
+};
+
+// RPI.h:3232-3367 errorPhotoICP_sphereOcc1: residuals and z-buffer indexed by the TARGET pixel; a closer (or equal)
+// source pixel overwrites the residual, the counters count every write.  Returns avPhotoResidual + avDepthResidual
+// (NaN when one of the two modalities is unused: 0/0 -- the reference's behaviour for PHOTO / DEPTH only).
+double errorPhotoICP_sphereOcc1(Ctx& ctx, int level, const float* pose, int method, OccSums* out) {
+    const Image& graySrc = ctx.graySrc[level];
+    const int nRows = graySrc.rows, nCols = graySrc.cols;
+    const long imgSize = (long)nRows * nCols;
+    std::vector<float> residualsPhoto(imgSize, 0.f), residualsDepth(imgSize, 0.f), invDepthBuffer(imgSize, 0.f);
+    const float angle_res = 2 * kPI / nCols;
+    const float angle_res_inv = 1 / angle_res;
+    const float half_nRows = 0.5 * nRows - 0.5;
+    const float stdDevPhoto = ctx.p.sigma_photo, stdDevDepth = ctx.p.sigma_depth;
+    const double stdDevPhoto_inv = 1. / stdDevPhoto;
+    const PoseRT T = split_pose(pose);
+    const Image &grayTrg = ctx.grayTrg[level], &depthTrg = ctx.depthTrg[level];
+    const Image &gx = ctx.gTrgGx[level], &gy = ctx.gTrgGy[level], &dgx = ctx.dTrgGx[level], &dgy = ctx.dTrgGy[level];
+    const float thrI = ctx.p.thres_sal_photo, thrD = ctx.p.thres_sal_depth;
+    long nValidPhotoPts = 0, nValidDepthPts = 0;
+    for (long i = 0; i < imgSize; ++i) {
+        const float* p = &ctx.lut[3 * i];
+        if (p[0] == kInvalidPoint) continue;
+        Warp w = warp_pixel(T, p, nRows, nCols, half_nRows, angle_res_inv, ctx.p.math_mode);
+        if (!w.visible) continue;
+        const long ii = (long)w.r * nCols + w.c;
+        if (invDepthBuffer[ii] > 0 && w.dist_inv < invDepthBuffer[ii]) continue;   // RPI.h:3297-3299
+        invDepthBuffer[ii] = w.dist_inv;
+        if (method == METHOD_PHOTO || method == METHOD_PHOTO_DEPTH) {
+            if (fabsf(gx.at(w.r, w.c)) < thrI && fabsf(gy.at(w.r, w.c)) < thrI) continue;
+            float photoDiff = grayTrg.at(w.r, w.c) - graySrc.d[i];
+            double weight_photo = weightHuber(photoDiff, stdDevPhoto) * stdDevPhoto_inv;
+            float weightedErrorPhoto = weight_photo * photoDiff;
+            residualsPhoto[ii] = weightedErrorPhoto * weightedErrorPhoto;
+            ++nValidPhotoPts;
+        }
+        if (method == METHOD_DEPTH || method == METHOD_PHOTO_DEPTH) {
+            float depth2 = depthTrg.at(w.r, w.c);
+            if (std::isfinite(depth2)) {
+                if (fabsf(dgx.at(w.r, w.c)) < thrD && fabsf(dgy.at(w.r, w.c)) < thrD) continue;
+                float depthDiff = depth2 - w.dist;
+                float stdDev_depth1 = stdDevDepth * depth2;
+                double weight_depth = weightHuber(depthDiff, stdDev_depth1) / stdDev_depth1;
+                float weightedErrorDepth = weight_depth * depthDiff;
+                residualsDepth[ii] = weightedErrorDepth * weightedErrorDepth;
+                ++nValidDepthPts;
+            }
+        }
+    }
+    double PhotoResidual = 0.0, DepthResidual = 0.0;
+    for (long i = 0; i < imgSize; ++i) {
+        PhotoResidual += residualsPhoto[i];
+        DepthResidual += residualsDepth[i];
+    }
+    if (out) { out->photo = PhotoResidual; out->depth = DepthResidual; out->nPhoto = nValidPhotoPts; out->nDepth = nValidDepthPts; }
+    ctx.last_err2_photo = PhotoResidual; ctx.last_err2_depth = DepthResidual;
+    ctx.last_nvalid_photo = nValidPhotoPts; ctx.last_nvalid_depth = nValidDepthPts;
+    ctx.last_nvalid = nValidPhotoPts + nValidDepthPts;
+    return sqrt(PhotoResidual / nValidPhotoPts) + sqrt(DepthResidual / nValidDepthPts);    // RPI.h:3358-3366
+}
+
+// RPI.h:3720-3856 errorPhotoICP_sphereOcc2: depth-outlier gate, z-buffer by TARGET pixel, residuals by SOURCE pixel
+// (an accepted pixel is not retracted when a closer one arrives later); both averages divide by nValidDepthPts, which
+// counts the accepted pixels before any saliency test.
+double errorPhotoICP_sphereOcc2(Ctx& ctx, int level, const float* pose, int method, OccSums* out) {
+    const Image& graySrc = ctx.graySrc[level];
+    const int nRows = graySrc.rows, nCols = graySrc.cols;
+    const long imgSize = (long)nRows * nCols;
+    std::vector<float> residualsPhoto(imgSize, 0.f), residualsDepth(imgSize, 0.f), invDepthBuffer(imgSize, 0.f);
+    const float angle_res = 2 * kPI / nCols;
+    const float angle_res_inv = 1 / angle_res;
+    const float half_nRows = 0.5 * nRows - 0.5;
+    const float stdDevPhoto = ctx.p.sigma_photo, stdDevDepth = ctx.p.sigma_depth;
+    const double stdDevPhoto_inv = 1. / stdDevPhoto;
+    const PoseRT T = split_pose(pose);
+    const Image &grayTrg = ctx.grayTrg[level], &depthTrg = ctx.depthTrg[level];
+    const Image &gx = ctx.gTrgGx[level], &gy = ctx.gTrgGy[level], &dgx = ctx.dTrgGx[level], &dgy = ctx.dTrgGy[level];
+    const float thrI = ctx.p.thres_sal_photo, thrD = ctx.p.thres_sal_depth;
+    long nValidDepthPts = 0;
+    for (long i = 0; i < imgSize; ++i) {
+        const float* p = &ctx.lut[3 * i];
+        if (p[0] == kInvalidPoint) continue;
+        Warp w = warp_pixel(T, p, nRows, nCols, half_nRows, angle_res_inv, ctx.p.math_mode);
+        if (!w.visible) continue;
+        float depth2 = depthTrg.at(w.r, w.c);
+        float depthDiff = depth2 - w.dist;
+        if (fabsf(depthDiff) > kThresDepthOutliers) continue;                      // RPI.h:3788-3791
+        const long ii = (long)w.r * nCols + w.c;
+        if (invDepthBuffer[ii] > 0 && w.dist_inv < invDepthBuffer[ii]) continue;   // RPI.h:3794-3796
+        invDepthBuffer[ii] = w.dist_inv;
+        ++nValidDepthPts;
+        if (method == METHOD_PHOTO || method == METHOD_PHOTO_DEPTH) {
+            if (fabsf(gx.at(w.r, w.c)) < thrI && fabsf(gy.at(w.r, w.c)) < thrI) continue;
+            float photoDiff = grayTrg.at(w.r, w.c) - graySrc.d[i];
+            double weight_photo = weightHuber(photoDiff, stdDevPhoto) * stdDevPhoto_inv;
+            float weightedErrorPhoto = weight_photo * photoDiff;
+            residualsPhoto[i] = weightedErrorPhoto * weightedErrorPhoto;
+        }
+        if (method == METHOD_DEPTH || method == METHOD_PHOTO_DEPTH) {
+            if (std::isfinite(depth2)) {
+                if (fabsf(dgx.at(w.r, w.c)) < thrD && fabsf(dgy.at(w.r, w.c)) < thrD) continue;
+                float stdDev_depth1 = stdDevDepth * depth2;
+                double weight_depth = weightHuber(depthDiff, stdDev_depth1) / stdDev_depth1;
+                float weightedErrorDepth = weight_depth * depthDiff;
+                residualsDepth[i] = weightedErrorDepth * weightedErrorDepth;
+            }
+        }
+    }
+    double PhotoResidual = 0.0, DepthResidual = 0.0;
+    for (long i = 0; i < imgSize; ++i) {
+        PhotoResidual += residualsPhoto[i];
+        DepthResidual += residualsDepth[i];
+    }
+    if (out) { out->photo = PhotoResidual; out->depth = DepthResidual; out->nPhoto = nValidDepthPts; out->nDepth = nValidDepthPts; }
+    ctx.last_err2_photo = PhotoResidual; ctx.last_err2_depth = DepthResidual;
+    ctx.last_nvalid_photo = nValidDepthPts; ctx.last_nvalid_depth = nValidDepthPts;
+    ctx.last_nvalid = nValidDepthPts;
+    return sqrt(PhotoResidual / nValidDepthPts) + sqrt(DepthResidual / nValidDepthPts);     // RPI.h:3848-3855
+}
+
+// RPI.h:3373-3716 calcHessGrad_sphereOcc1 (occ == 1) and RPI.h:3861-4249 calcHessGrad_sphereOcc2 (occ == 2).
+//  Occ1: the z-buffer is indexed by the SOURCE pixel (RPI.h:3473-3475), every pixel is visited once, so nothing is ever
+//        rejected; rows are stored per source pixel.  Unlike the plain pass the rows are stored in one trailing block
+//        (RPI.h:3575-3600), which a `continue` of the depth saliency test skips: a pixel whose depth gradient is not
+//        salient loses its photometric row as well.
+//  Occ2: depth-outlier gate, then rows are stored per TARGET pixel without a depth test (RPI.h:4096-4120): the pixel
+//        visited last wins.  numVisiblePixels counts the distinct target pixels (RPI.h:3981-3982).
+void calcHessGrad_sphereOcc(Ctx& ctx, int level, const float* pose, int method, int occ) {
+    const Image& graySrc = ctx.graySrc[level];
+    const int nRows = graySrc.rows, nCols = graySrc.cols;
+    const long imgSize = (long)nRows * nCols;
+    const float angle_res = 2 * kPI / nCols;
+    const float angle_res_inv = 1 / angle_res;
+    const float half_nRows = 0.5 * nRows - 0.5;
+    std::vector<float> jacobiansPhoto((size_t)imgSize * 6), jacobiansDepth((size_t)imgSize * 6);
+    std::vector<float> residualsPhoto(imgSize, 0.f), residualsDepth(imgSize, 0.f);
+    std::vector<int> validPixelsPhoto(imgSize, 0), validPixelsDepth(imgSize, 0);
+    std::vector<float> invDepthBuffer(imgSize, 0.f);
+    const PoseRT T = split_pose(pose);
+    const float stdDevPhoto = ctx.p.sigma_photo, stdDevDepth = ctx.p.sigma_depth;
+    const float stdDevPhoto_inv = 1. / stdDevPhoto;
+    const Image &grayTrg = ctx.grayTrg[level], &depthTrg = ctx.depthTrg[level];
+    const Image &gx = ctx.gTrgGx[level], &gy = ctx.gTrgGy[level], &dgx = ctx.dTrgGx[level], &dgy = ctx.dTrgGy[level];
+    const float thrI = ctx.p.thres_sal_photo, thrD = ctx.p.thres_sal_depth;
+    long numVisiblePixels = 0;
+    for (long i = 0; i < imgSize; ++i) {
+        const float* p = &ctx.lut[3 * i];
+        if (p[0] == kInvalidPoint) continue;
+        Warp w = warp_pixel(T, p, nRows, nCols, half_nRows, angle_res_inv, ctx.p.math_mode);
+        if (!w.visible) continue;
+        long row;       // where this pixel's rows are stored
+        if (occ == 1) {
+            if (invDepthBuffer[i] > 0 && w.dist_inv < invDepthBuffer[i]) continue;     // never true: one visit per i
+            invDepthBuffer[i] = w.dist_inv;
+            ++numVisiblePixels;
+            row = i;
+        } else {
+            float depthDiff0 = depthTrg.at(w.r, w.c) - w.dist;
+            if (fabsf(depthDiff0) > kThresDepthOutliers) continue;                     // RPI.h:3968-3979
+            const long ii = (long)w.r * nCols + w.c;
+            if (invDepthBuffer[ii] == 0) ++numVisiblePixels;
+            invDepthBuffer[ii] = w.dist_inv;
+            row = ii;
+        }
+        const float X = w.X, Y = w.Y, Z = w.Z, dist_inv = w.dist_inv;
+        float Jw0[6], Jw1[6];
+        warp_jacobian(X, Y, Z, dist_inv, angle_res_inv, Jw0, Jw1);
+        float jacobianPhoto[6] = {0, 0, 0, 0, 0, 0}, jacobianDepth[6] = {0, 0, 0, 0, 0, 0};
+        float weightedErrorPhoto = 0.f, weightedErrorDepth = 0.f, depth2 = 0.f;
+        if (method == METHOD_PHOTO || method == METHOD_PHOTO_DEPTH) {
+            float tgx = gx.at(w.r, w.c), tgy = gy.at(w.r, w.c);
+            if (fabsf(tgx) < thrI && fabsf(tgy) < thrI) continue;
+            float photoDiff = grayTrg.at(w.r, w.c) - graySrc.d[i];
+            float weight_photo = weightHuber(photoDiff, stdDevPhoto) * stdDevPhoto_inv;
+            weightedErrorPhoto = weight_photo * photoDiff;
+            float wgx = weight_photo * tgx, wgy = weight_photo * tgy;
+            for (int j = 0; j < 6; ++j) jacobianPhoto[j] = wgx * Jw0[j] + wgy * Jw1[j];
+        }
+        if (method == METHOD_DEPTH || method == METHOD_PHOTO_DEPTH) {
+            depth2 = depthTrg.at(w.r, w.c);
+            if (std::isfinite(depth2)) {
+                float tdx = dgx.at(w.r, w.c), tdy = dgy.at(w.r, w.c);
+                if (fabsf(tdx) < thrD && fabsf(tdy) < thrD) continue;      // also skips the trailing store of the photo row
+                float depthDiff = depth2 - w.dist;
+                float stdDev_depth1 = stdDevDepth * depth2;
+                float weight_depth = weightHuber(depthDiff, stdDev_depth1) / stdDev_depth1;
+                weightedErrorDepth = weight_depth * depthDiff;
+                float n0 = X * dist_inv, n1 = Y * dist_inv, n2 = Z * dist_inv;
+                float nJ[6] = {n0, n1, n2, n1 * (-Z) + n2 * Y, n0 * Z + n2 * (-X), n0 * (-Y) + n1 * X};
+                for (int j = 0; j < 6; ++j) jacobianDepth[j] = weight_depth * ((tdx * Jw0[j] + tdy * Jw1[j]) - nJ[j]);
+            }
+        }
+        if (method == METHOD_PHOTO || method == METHOD_PHOTO_DEPTH) {
+            for (int j = 0; j < 6; ++j) jacobiansPhoto[(size_t)j * imgSize + row] = jacobianPhoto[j];
+            residualsPhoto[row] = weightedErrorPhoto;
+            validPixelsPhoto[row] = 1;
+        }
+        if ((method == METHOD_DEPTH || method == METHOD_PHOTO_DEPTH) && std::isfinite(depth2)) {
+            for (int j = 0; j < 6; ++j) jacobiansDepth[(size_t)j * imgSize + row] = jacobianDepth[j];
+            residualsDepth[row] = weightedErrorDepth;
+            validPixelsDepth[row] = 1;
+        }
+    }
+    float hf[21] = {0}, gf[6] = {0};
+    double hd[21] = {0}, gd[6] = {0};
+    auto reduce_rows = [&](const std::vector<float>& J, const std::vector<float>& res, const std::vector<int>& valid) {
+        for (long i = 0; i < imgSize; ++i)
+            if (valid[i]) {
+                float Ji[6];
+                for (int j = 0; j < 6; ++j) Ji[j] = J[(size_t)j * imgSize + i];
+                int k = 0;
+                for (int a = 0; a < 6; ++a)
+                    for (int b = a; b < 6; ++b, ++k) {
+                        float prod = Ji[a] * Ji[b];
+                        hf[k] += prod;
+                        hd[k] += (double)prod;
+                    }
+                for (int a = 0; a < 6; ++a) {
+                    float prod = Ji[a] * res[i];
+                    gf[a] += prod;
+                    gd[a] += (double)prod;
+                }
+            }
+    };
+    if (method == METHOD_PHOTO || method == METHOD_PHOTO_DEPTH) reduce_rows(jacobiansPhoto, residualsPhoto, validPixelsPhoto);
+    if (method == METHOD_DEPTH || method == METHOD_PHOTO_DEPTH) reduce_rows(jacobiansDepth, residualsDepth, validPixelsDepth);
+    int k = 0;
+    for (int a = 0; a < 6; ++a)
+        for (int b = a; b < 6; ++b, ++k) {
+            float v = ctx.p.reduce_mode == 0 ? hf[k] : (float)hd[k];
+            ctx.H[b * 6 + a] = ctx.H[a * 6 + b] = v;
+            ctx.H64[b * 6 + a] = ctx.H64[a * 6 + b] = hd[k];
+        }
+    for (int a = 0; a < 6; ++a) {
+        ctx.g[a] = ctx.p.reduce_mode == 0 ? gf[a] : (float)gd[a];
+        ctx.g64[a] = gd[a];
+    }
+    ctx.n_visible = numVisiblePixels;
+    ctx.sso = (float)numVisiblePixels / imgSize;
+}
+
+// ------------------------------------------------------------------------------------
 // THIRD-PARTY restatements (Eigen / MRPT) for the 6x6 step
 // ------------------------------------------------------------------------------------
 
@@ -770,8 +1022,18 @@ void prepare_level(Ctx& ctx, int level) {
     buildLUT(ctx, level);
 }
 
-// RPI.h:4519-4784 alignFrames360, occlusion == 0
-int alignFrames360(Ctx& ctx, const float* pose_guess, int method, float* pose_out, Result* res) {
+// RPI.h:4519-4784 alignFrames360; occlusion 0 / 1 / 2 selects the error and H,g functions (RPI.h:4597-4603, 4616-4622,
+// 4701-4707)
+int alignFrames360(Ctx& ctx, const float* pose_guess, int method, float* pose_out, Result* res, int occlusion = 0) {
+    auto error_fn = [&](int level, const float* pose) -> double {
+        if (occlusion == 1) return errorPhotoICP_sphereOcc1(ctx, level, pose, method, nullptr);
+        if (occlusion == 2) return errorPhotoICP_sphereOcc2(ctx, level, pose, method, nullptr);
+        return errorPhotoICP_sphere(ctx, level, pose, method);
+    };
+    auto hessgrad_fn = [&](int level, const float* pose) {
+        if (occlusion == 0) calcHessGrad_sphere(ctx, level, pose, method);
+        else calcHessGrad_sphereOcc(ctx, level, pose, method, occlusion);
+    };
     ctx.trace.clear();
     memset(res, 0, sizeof(*res));
     float pose_estim[16], pose_estim_temp[16];
@@ -787,8 +1049,8 @@ int alignFrames360(Ctx& ctx, const float* pose_guess, int method, float* pose_ou
         const int maxIters = ctx.p.max_iters;
         const double tol_residual = ctx.p.tol_residual, tol_update = ctx.p.tol_update;
         float update_pose[6] = {1, 1, 1, 1, 1, 1};
-        error = errorPhotoICP_sphere(ctx, level, pose_estim, method);
-        if (ctx.last_nvalid == 0) {
+        error = error_fn(level, pose_estim);
+        if (ctx.last_nvalid == 0 || error != error) {      // no residuals (occlusion modes: NaN from an unused modality)
             memcpy(pose_out, pose_estim, sizeof(pose_estim));
             res->status = 2;
             return 2;
@@ -806,7 +1068,7 @@ int alignFrames360(Ctx& ctx, const float* pose_guess, int method, float* pose_ou
             return sqrtf(s);
         };
         while (it < maxIters && unorm() > tol_update && diff_error > tol_residual) {
-            calcHessGrad_sphere(ctx, level, pose_estim, method);
+            hessgrad_fn(level, pose_estim);
             if (gn_step(ctx.H, ctx.g, lambda, pose_estim, pose_estim_temp, update_pose) != 0) {
                 memcpy(pose_out, pose_estim, sizeof(pose_estim));  // relPose = pose_estim; avResidual = 0; return
                 res->status = 1;
@@ -815,7 +1077,7 @@ int alignFrames360(Ctx& ctx, const float* pose_guess, int method, float* pose_ou
                 res->sso = ctx.sso;
                 return 1;
             }
-            double new_error = errorPhotoICP_sphere(ctx, level, pose_estim_temp, method);
+            double new_error = error_fn(level, pose_estim_temp);
             diff_error = error - new_error;
             IterTrace t{};
             t.level = level; t.it = it; t.error = error; t.new_error = new_error; t.n_valid = ctx.last_nvalid;
@@ -835,7 +1097,7 @@ int alignFrames360(Ctx& ctx, const float* pose_guess, int method, float* pose_ou
     memcpy(pose_out, pose_estim, sizeof(pose_estim));
     // The reference never writes avPhotoResidual/avDepthResidual on this path;
     // defined here as the photo / depth RMS of the error pass at the returned pose.
-    double e = errorPhotoICP_sphere(ctx, 0, pose_estim, method);
+    double e = error_fn(0, pose_estim);
     res->err_final = e;
     res->rms_photo = ctx.last_nvalid_photo ? sqrt(ctx.last_err2_photo / ctx.last_nvalid_photo) : 0.0;
     res->rms_depth = ctx.last_nvalid_depth ? sqrt(ctx.last_err2_depth / ctx.last_nvalid_depth) : 0.0;
@@ -916,6 +1178,30 @@ void oracle_set_source(void* h, const uint8_t* rgb, size_t rgb_step, const void*
 
 int oracle_align360(void* h, const float* guess, int method, float* pose_out, oracle_result* res) {
     return alignFrames360(*(Ctx*)h, guess, method, pose_out, res);
+}
+
+int oracle_align360_occ(void* h, const float* guess, int method, int occlusion, float* pose_out, oracle_result* res) {
+    return alignFrames360(*(Ctx*)h, guess, method, pose_out, res, occlusion);
+}
+// Occlusion-mode error pass: sums[4] = {sum photo, sum depth, n photo, n depth}; returns avPhoto + avDepth.
+double oracle_error_occ(void* h, int level, const float* pose, int method, int occlusion, double* sums) {
+    Ctx& c = *(Ctx*)h;
+    if (c.lut_level != level) prepare_level(c, level);
+    OccSums o;
+    double e = occlusion == 1 ? errorPhotoICP_sphereOcc1(c, level, pose, method, &o) : errorPhotoICP_sphereOcc2(c, level, pose, method, &o);
+    if (sums) { sums[0] = o.photo; sums[1] = o.depth; sums[2] = (double)o.nPhoto; sums[3] = (double)o.nDepth; }
+    return e;
+}
+void oracle_hessgrad_occ(void* h, int level, const float* pose, int method, int occlusion, float* H36, float* g6, double* H36d,
+                         double* g6d, long* n_visible) {
+    Ctx& c = *(Ctx*)h;
+    if (c.lut_level != level) prepare_level(c, level);
+    calcHessGrad_sphereOcc(c, level, pose, method, occlusion);
+    if (H36) memcpy(H36, c.H, sizeof(c.H));
+    if (g6) memcpy(g6, c.g, sizeof(c.g));
+    if (H36d) memcpy(H36d, c.H64, sizeof(c.H64));
+    if (g6d) memcpy(g6d, c.g64, sizeof(c.g64));
+    if (n_visible) *n_visible = c.n_visible;
 }
 
 int oracle_trace_len(void* h) { return (int)((Ctx*)h)->trace.size(); }

@@ -74,6 +74,7 @@ struct SolveCfg {
     int    forced;        // apply every step, never terminate
     int    max_iters;
     int    n_pixels;
+    int    occ;           // 0: error = sqrt(sum / n) (RPI.h:2738); 1/2: avPhotoResidual + avDepthResidual (RPI.h:3358-3366, 3848-3855)
     double tol_residual, tol_update;
 };
 
@@ -779,7 +780,8 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(GNState* st_g, const do
             st->n_evals += 1;
             const double err2 = tot[P_E2P] + tot[P_E2D];
             const double nvalid = tot[P_NP] + tot[P_ND];
-            const double new_error = sqrt(err2 / nvalid);   // RPI.h:2738
+            const double new_error = cfg.occ == 0 ? sqrt(err2 / nvalid)      // RPI.h:2738
+                                                  : sqrt(tot[P_E2P] / tot[P_NP]) + sqrt(tot[P_E2D] / tot[P_ND]);
             st->new_error = new_error;
             if (cfg.mode == 1) {
                 take = 1;
@@ -787,7 +789,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(GNState* st_g, const do
                 bool stop = false;
                 if (st->first) {
                     st->first = 0;
-                    if (nvalid == 0.0) {
+                    if (nvalid == 0.0 || new_error != new_error) {      // no residuals (occlusion modes: 0/0 of an unused modality)
                         st->status = 2;
                         st->done = 1;
                         stop = true;

@@ -17,6 +17,7 @@
 
 #include "../../include/rgbd360_hip.h"
 #include "photo_icp_kernels.h"
+#include "occlusion_kernels.h"
 #include "frame360_kernels.h"
 
 using namespace r360;
@@ -65,6 +66,10 @@ struct rgbd360_ctx {
     float al_guess[16] = {0};     // alignment in flight (rgbd360_align360_begin / _finish)
     int al_method = 0;
     bool al_active = false;
+    int al_occ = 0;
+    int *occ_head = nullptr, *occ_next = nullptr;      // occlusion modes: per-target candidate lists
+    float* occ_dinv = nullptr;
+    size_t occ_n = 0;
     int max_eval_blocks = 256;    // grid cap of the fused pass (tuning knob: RGBD360_EVAL_BLOCKS)
     std::string err;
 };
@@ -173,11 +178,44 @@ EvalConsts eval_consts(const rgbd360_params& p) {
 
 dim3 grid2d(int rows, int cols, int bx = 256) { return dim3((cols + bx - 1) / bx, rows, 1); }
 
-void launch_eval(rgbd360_ctx* ctx, int level, int method, bool hg) {
+int occ_ensure(rgbd360_ctx* ctx) {
+    const size_t n = ctx->levels.empty() ? 0 : (size_t)ctx->levels[0].n;
+    if (ctx->occ_n >= n && n > 0) return 0;
+    hipFree(ctx->occ_head); hipFree(ctx->occ_next); hipFree(ctx->occ_dinv);
+    ctx->occ_head = ctx->occ_next = nullptr;
+    ctx->occ_dinv = nullptr;
+    ctx->occ_n = 0;
+    HIPC(ctx, hipMalloc(&ctx->occ_head, n * sizeof(int)));
+    HIPC(ctx, hipMalloc(&ctx->occ_next, n * sizeof(int)));
+    HIPC(ctx, hipMalloc(&ctx->occ_dinv, n * sizeof(float)));
+    ctx->occ_n = n;
+    return 0;
+}
+
+void launch_eval(rgbd360_ctx* ctx, int level, int method, bool hg, int occ = 0) {
     const Level& L = ctx->levels[level];
     const LevelDev lv = level_dev(L);
     const EvalConsts ec = eval_consts(ctx->p);
     dim3 g(L.nblocks), b(kEvalThreads);
+    if (occ != 0) {
+        // per-target candidate lists at the pose under evaluation, then the occlusion-aware fused pass
+        hipMemsetAsync(ctx->occ_head, 0xFF, (size_t)L.n * sizeof(int), ctx->stream);
+        const dim3 gb((L.n + 255) / 256), bb(256);
+        if (occ == 1) hipLaunchKernelGGL((k_occ_build<1>), gb, bb, 0, ctx->stream, lv, ctx->d_state, level, ctx->occ_head, ctx->occ_next, ctx->occ_dinv);
+        else hipLaunchKernelGGL((k_occ_build<2>), gb, bb, 0, ctx->stream, lv, ctx->d_state, level, ctx->occ_head, ctx->occ_next, ctx->occ_dinv);
+#define LAUNCH_OCC(M, O) hipLaunchKernelGGL((k_eval_occ<M, O>), g, b, 0, ctx->stream, lv, ec, ctx->d_state, ctx->d_partials, L.chunk, level, ctx->occ_head, ctx->occ_next, ctx->occ_dinv)
+        if (occ == 1) {
+            if (method == 0) LAUNCH_OCC(0, 1);
+            else if (method == 1) LAUNCH_OCC(1, 1);
+            else LAUNCH_OCC(2, 1);
+        } else {
+            if (method == 0) LAUNCH_OCC(0, 2);
+            else if (method == 1) LAUNCH_OCC(1, 2);
+            else LAUNCH_OCC(2, 2);
+        }
+#undef LAUNCH_OCC
+        return;
+    }
 #define LAUNCH(M, HG) hipLaunchKernelGGL((k_eval<M, HG>), g, b, 0, ctx->stream, lv, ec, ctx->d_state, ctx->d_partials, L.chunk, level)
     if (hg) {
         if (method == 0) LAUNCH(0, true);
@@ -191,10 +229,11 @@ void launch_eval(rgbd360_ctx* ctx, int level, int method, bool hg) {
 #undef LAUNCH
 }
 
-void launch_solve(rgbd360_ctx* ctx, int level, int mode, int forced) {
+void launch_solve(rgbd360_ctx* ctx, int level, int mode, int forced, int occ = 0) {
     const Level& L = ctx->levels[level];
     SolveCfg cfg;
     cfg.level = level; cfg.mode = mode; cfg.forced = forced; cfg.max_iters = ctx->p.max_iters; cfg.n_pixels = L.n;
+    cfg.occ = occ;
     cfg.tol_residual = ctx->p.tol_residual; cfg.tol_update = ctx->p.tol_update;
     hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), 0, ctx->stream, ctx->d_state, ctx->d_partials, L.nblocks, cfg);
 }
@@ -359,6 +398,7 @@ void rgbd360_destroy(rgbd360_ctx* ctx) {
     hipFree(ctx->f_change); hipFree(ctx->f_hd); hipFree(ctx->f_label); hipFree(ctx->f_count); hipFree(ctx->f_slot_of_root);
     hipFree(ctx->f_root_of_slot); hipFree(ctx->f_nslots); hipFree(ctx->f_window); hipFree(ctx->f_mom);
     hipFree(ctx->f_count_of_slot); hipFree(ctx->f_depth_raw);
+    hipFree(ctx->occ_head); hipFree(ctx->occ_next); hipFree(ctx->occ_dinv);
     if (ctx->h_state) hipHostFree(ctx->h_state);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
@@ -425,8 +465,8 @@ static void enqueue_schedule(rgbd360_ctx* ctx, int pending, bool pending_started
             launch_level_init(ctx, level, level == top ? ctx->al_guess : nullptr, level == top ? 1 : 0);
         const int n_pairs = (level == top && !pending_started) ? ctx->first_chunk_top : ctx->poll_chunk;
         for (int k = 0; k < n_pairs; ++k) {
-            launch_eval(ctx, level, ctx->al_method, true);
-            launch_solve(ctx, level, 0, 0);
+            launch_eval(ctx, level, ctx->al_method, true, ctx->al_occ);
+            launch_solve(ctx, level, 0, 0, ctx->al_occ);
         }
     }
 }
@@ -434,9 +474,11 @@ static void enqueue_schedule(rgbd360_ctx* ctx, int pending, bool pending_started
 int rgbd360_align360_begin(rgbd360_ctx* ctx, const float guess[16], int method, int occlusion) {
     int rc = check_args(ctx, 0, method);
     if (rc) return rc;
-    if (occlusion != 0) return fail(ctx, -5, "occlusion modes 1/2 are not implemented (SURVEY.md 8f)");
+    if (occlusion < 0 || occlusion > 2) return fail(ctx, -5, "occlusion must be 0, 1 or 2");
     if (!guess) return fail(ctx, -1, "null pose pointer");
     hipSetDevice(ctx->p.device);
+    if (occlusion != 0 && (rc = occ_ensure(ctx)) != 0) return rc;
+    ctx->al_occ = occlusion;
     memcpy(ctx->al_guess, guess, sizeof(ctx->al_guess));
     ctx->al_method = method;
     ctx->al_active = true;
@@ -473,6 +515,8 @@ int rgbd360_align360_finish(rgbd360_ctx* ctx, float pose_out[16], rgbd360_result
     R.sso = S.used_npix ? (float)S.used_nvis / (float)S.used_npix : 0.f;
     const double nv = (double)(S.acc_np + S.acc_nd);
     R.err_final = nv > 0 ? sqrt((S.acc_e2p + S.acc_e2d) / nv) : 0.0;
+    if (ctx->al_occ != 0)       // avPhotoResidual + avDepthResidual (RPI.h:3358-3366, 3848-3855)
+        R.err_final = (S.acc_np > 0 ? sqrt(S.acc_e2p / (double)S.acc_np) : 0.0) + (S.acc_nd > 0 ? sqrt(S.acc_e2d / (double)S.acc_nd) : 0.0);
     R.rms_photo = S.acc_np > 0 ? sqrt(S.acc_e2p / (double)S.acc_np) : 0.0;
     R.rms_depth = S.acc_nd > 0 ? sqrt(S.acc_e2d / (double)S.acc_nd) : 0.0;
     if (res) *res = R;
@@ -535,13 +579,21 @@ int rgbd360_get_lut(rgbd360_ctx* ctx, int level, float* host_out_xyz) {
 int rgbd360_eval(rgbd360_ctx* ctx, int level, const float pose[16], int method, double* err2, long long* n_valid,
                  double err2_split[2], long long n_split[2], float H[36], float g[6], double H64[36], double g64[6],
                  long long* n_visible) {
+    return rgbd360_eval_occ(ctx, level, pose, method, 0, err2, n_valid, err2_split, n_split, H, g, H64, g64, n_visible);
+}
+
+int rgbd360_eval_occ(rgbd360_ctx* ctx, int level, const float pose[16], int method, int occlusion, double* err2,
+                     long long* n_valid, double err2_split[2], long long n_split[2], float H[36], float g[6], double H64[36],
+                     double g64[6], long long* n_visible) {
     int rc = check_args(ctx, level, method);
     if (rc) return rc;
     if (!pose) return fail(ctx, -1, "null pose pointer");
+    if (occlusion < 0 || occlusion > 2) return fail(ctx, -5, "occlusion must be 0, 1 or 2");
     hipSetDevice(ctx->p.device);
+    if (occlusion != 0 && (rc = occ_ensure(ctx)) != 0) return rc;
     launch_level_init(ctx, level, pose, 1);
-    launch_eval(ctx, level, method, true);
-    launch_solve(ctx, level, 1, 0);
+    launch_eval(ctx, level, method, true, occlusion);
+    launch_solve(ctx, level, 1, 0, occlusion);
     HIPC(ctx, hipGetLastError());
     rc = read_state(ctx);
     if (rc) return rc;

@@ -217,7 +217,7 @@ class RegisterPhotoICP:
         self._check(self._L.rgbd360_get_lut(self._ctx(), level, _ptr(out)))
         return out
 
-    def eval(self, level: int, pose, method: int):
+    def eval(self, level: int, pose, method: int, occlusion: int = 0):
         p = pose_to_cm(pose)
         e2, nv, nvis = C.c_double(), C.c_longlong(), C.c_longlong()
         e2s = np.zeros(2, np.float64)
@@ -226,8 +226,8 @@ class RegisterPhotoICP:
         g = np.zeros(6, np.float32)
         Hd = np.zeros(36, np.float64)
         gd = np.zeros(6, np.float64)
-        self._check(self._L.rgbd360_eval(self._ctx(), level, _ptr(p), method, C.byref(e2), C.byref(nv), _ptr(e2s), _ptr(ns),
-                                         _ptr(H), _ptr(g), _ptr(Hd), _ptr(gd), C.byref(nvis)))
+        self._check(self._L.rgbd360_eval_occ(self._ctx(), level, _ptr(p), method, int(occlusion), C.byref(e2), C.byref(nv),
+                                             _ptr(e2s), _ptr(ns), _ptr(H), _ptr(g), _ptr(Hd), _ptr(gd), C.byref(nvis)))
         return dict(err2=e2.value, n_valid=nv.value, err2_split=e2s, n_split=ns, H=H.reshape(6, 6).T.copy(), g=g,
                     H64=Hd.reshape(6, 6).T.copy(), g64=gd, n_visible=nvis.value)
 

@@ -175,3 +175,25 @@ def pose_error(Ta: np.ndarray, Tb: np.ndarray):
     s = 0.5 * math.sqrt((Rd[2, 1] - Rd[1, 2]) ** 2 + (Rd[0, 2] - Rd[2, 0]) ** 2 + (Rd[1, 0] - Rd[0, 1]) ** 2)
     ang = math.atan2(s, c)
     return ang, float(np.linalg.norm(Ta[:3, 3] - Tb[:3, 3]))
+
+
+def add_occluder(pair):
+    """The box room is convex, so no surface hides another.  A near 'billboard' pasted into both frames (2 columns
+    apart) makes source pixels of different depth land on the same target pixel once a pose moves them: real z-buffer
+    conflicts for the occlusion-aware passes (RegisterPhotoICP.h:3232-4249)."""
+    (rgbA, dA), (rgbB, dB), T = pair
+    rgbA, dA, rgbB, dB = rgbA.copy(), dA.copy(), rgbB.copy(), dB.copy()
+    H, W = dA.shape
+    for (rgb, d, c0) in ((rgbA, dA, W // 3), (rgbB, dB, W // 3 + 2)):
+        r0, r1, c1 = H // 3, 2 * H // 3, c0 + W // 8
+        d[r0:r1, c0:c1] = 1200 if d.dtype == np.uint16 else 1.2
+        rgb[r0:r1, c0:c1] = (np.indices((r1 - r0, c1 - c0)).sum(axis=0)[..., None] * 9 % 256).astype(np.uint8)
+    return (rgbA, dA), (rgbB, dB), T
+
+
+def occlusion_test_poses(T_gt):
+    rng = np.random.default_rng(11)
+    out = [np.eye(4), np.asarray(T_gt)]
+    out.append(make_pose(rodrigues(rng.normal(size=3), 0.03), np.array([0.0, 0.25, 0.1])))    # large sideways step
+    out.append(make_pose(np.eye(3), np.array([0.0, 0.0, -0.4])))                                # moving away: compression
+    return out

@@ -65,6 +65,24 @@ def main():
             H, g, Hd, gd, nvis = ora.hessgrad(1, T, method)
             out["runs"]["math%d/method%d" % (math_mode, method)]["at_gt_level1"] = {
                 "rms": e[0], "err2": e[1], "n_valid": e[2], "n_visible": nvis, "H64": Hd.tolist(), "g64": gd.tolist()}
+    # occlusion-aware variants (sequential semantics of RPI.h:3232-4249) on the same pair with a pasted occluder
+    (orgbA, odA), (orgbB, odB), _ = synth.add_occluder(((rgbA, dA), (rgbB, dB), T))
+    occ = O.Oracle(n_pyr=3, math_mode=0, reduce_mode=1)
+    occ.set_target(orgbA, odA)
+    occ.set_source(orgbB, odB)
+    out["occlusion"] = {}
+    probe_pose = synth.occlusion_test_poses(T)[2]
+    for math_mode in (0, 1):
+        occ.set_modes(math_mode, 1)
+        for occlusion, method in ((1, 2), (2, 0), (2, 1), (2, 2)):
+            st, pose = occ.align360(np.eye(4), method, occlusion)
+            rec = {"status": st, "iters": list(occ.result.iters)[:3], "pose": pose.astype(np.float64).tolist(),
+                   "err_final": occ.result.err_final, "sso": float(occ.result.sso)}
+            e = occ.error_occ(1, probe_pose, method, occlusion)
+            H, g, Hd, gd, nvis = occ.hessgrad_occ(1, probe_pose, method, occlusion)
+            rec["at_probe_level1"] = {"error": e[0], "sum_photo": e[1], "sum_depth": e[2], "n_photo": e[3], "n_depth": e[4],
+                                      "n_visible": nvis, "H64": Hd.tolist(), "g64": gd.tolist()}
+            out["occlusion"]["math%d/occ%d/method%d" % (math_mode, occlusion, method)] = rec
     with open(os.path.join(HERE, "oracle_256x128.json"), "w") as f:
         json.dump(out, f, indent=1)
     print("wrote", os.listdir(HERE))

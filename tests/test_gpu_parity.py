@@ -171,7 +171,8 @@ def test_no_valid_pixels_and_errors(hip_lib, oracle_mod, small_pair):
     assert np.allclose(reg.getOptimalPose(), np.eye(4))
     from rgbd360_amd.register import Rgbd360Error
     with pytest.raises(Rgbd360Error):
-        reg.alignFrames360(np.eye(4), 2, occlusion=1)
+        reg.alignFrames360(np.eye(4), 2, occlusion=3)   # only 0, 1, 2 exist (RPI.h:4517)
+    assert reg.alignFrames360(np.eye(4), 2, occlusion=1) == 2
     fresh = _mk(hip_lib, 3)
     fresh.setTargetFrame(rgbA, dA)
     with pytest.raises(Rgbd360Error):                    # source frame missing
@@ -438,3 +439,105 @@ def test_concurrent_contexts_give_identical_poses(hip_lib):
     r.alignFrames360_begin(np.eye(4), 2)
     assert r.alignFrames360_finish() == 0
     assert np.array_equal(r.getOptimalPose(), poses[0])
+
+
+# ---- occlusion-aware variants (RPI.h:3232-4249, sequential semantics) ---------------------------
+_occluder_pair = synth.add_occluder
+_occ_poses = synth.occlusion_test_poses
+
+
+@pytest.mark.parametrize("occlusion", [1, 2])
+@pytest.mark.parametrize("method", [0, 1, 2])
+def test_eval_occlusion_parity(hip_lib, oracle_mod, small_pair, method, occlusion):
+    reg, ora, T = _pair_ctx(hip_lib, oracle_mod, _occluder_pair(small_pair))
+    conflicts = 0
+    for level in range(3):
+        for pose in _occ_poses(T):
+            e = reg.eval(level, pose, method, occlusion)
+            _, sp, sd, n_p, n_d = ora.error_occ(level, pose, method, occlusion)
+            H, g, Hd, gd, nvis = ora.hessgrad_occ(level, pose, method, occlusion)
+            assert list(e["n_split"]) == [n_p, n_d], (level, list(e["n_split"]), n_p, n_d)     # integer work: exact
+            assert e["n_visible"] == nvis
+            assert abs(e["err2_split"][0] - sp) <= ERR2_RTOL * max(1.0, abs(sp)), (e["err2_split"], sp)
+            assert abs(e["err2_split"][1] - sd) <= ERR2_RTOL * max(1.0, abs(sd)), (e["err2_split"], sd)
+            scale_h = max(np.abs(Hd).max(), 1e-30)
+            assert np.abs(e["H64"] - Hd).max() <= HG_RTOL * scale_h
+            assert np.abs(e["g64"] - gd).max() <= HG_RTOL * max(np.abs(gd).max(), 1e-3 * np.sqrt(scale_h))
+            # the variants must actually differ from the plain pass somewhere, or the test proves nothing
+            plain = reg.eval(level, pose, method, 0)
+            conflicts += int(plain["n_visible"] != e["n_visible"]) + int(list(plain["n_split"]) != list(e["n_split"]))
+    assert conflicts > 0
+
+
+@pytest.mark.parametrize("occlusion,method", [(1, 2), (2, 0), (2, 1), (2, 2)])
+def test_align_occlusion_matches_oracle(hip_lib, oracle_mod, small_pair, occlusion, method):
+    reg, ora, T = _pair_ctx(hip_lib, oracle_mod, _occluder_pair(small_pair))
+    rc = reg.alignFrames360(np.eye(4), method, occlusion)
+    st, pose_ref = ora.align360(np.eye(4), method, occlusion)
+    assert rc == st == 0
+    assert reg.num_iterations == list(ora.result.iters)[:3]
+    rot, trans = synth.pose_error(reg.getOptimalPose(), pose_ref)
+    assert rot <= POSE_TOL_DEV and trans <= POSE_TOL_DEV, (rot, trans)
+    assert abs(reg.avResidual - ora.result.err_final) <= 1e-5 * max(1.0, ora.result.err_final)
+    assert abs(reg.SSO - ora.result.sso) < 1e-6
+    # the alignment still lands near the true motion (the billboard is a moving outlier for the room)
+    rot, trans = synth.pose_error(reg.getOptimalPose(), T)
+    assert rot < 0.02 and trans < 0.05, (rot, trans)
+
+
+def test_occlusion1_single_modality_returns_guess(hip_lib, oracle_mod, small_pair):
+    """errorPhotoICP_sphereOcc1 adds avPhotoResidual + avDepthResidual: with PHOTO (or DEPTH) only, the unused term is
+    0/0, the error is NaN and the reference's loop never runs -- the guess comes back."""
+    reg, ora, T = _pair_ctx(hip_lib, oracle_mod, small_pair)
+    guess = synth.make_pose(synth.rodrigues(np.array([0.0, 0.0, 1.0]), 0.01), np.array([0.01, 0.0, 0.0]))
+    rc = reg.alignFrames360(guess, 0, 1)
+    st, pose_ref = ora.align360(guess, 0, 1)
+    assert rc == st == 2
+    assert np.allclose(reg.getOptimalPose(), guess.astype(np.float32)) and np.allclose(pose_ref, guess.astype(np.float32))
+    assert reg.num_iterations == [0, 0, 0]
+
+
+# ---- the HIP path against the committed golden fixtures (tests/golden/, device-arithmetic entries) -------------------
+def _golden():
+    import json
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    z = np.load(os.path.join(here, "golden", "pair_256x128.npz"))
+    return z, json.load(open(os.path.join(here, "golden", "oracle_256x128.json")))
+
+
+@pytest.mark.parametrize("method", [0, 1, 2])
+def test_hip_matches_golden_fixture(hip_lib, method):
+    z, j = _golden()
+    ref = j["runs"]["math1/method%d" % method]
+    reg = _mk(hip_lib, 3)
+    reg.setTargetFrame(z["rgbA"], z["dA"])
+    reg.setSourceFrame(z["rgbB"], z["dB"])
+    rc = reg.alignFrames360(np.eye(4), method)
+    assert rc == ref["status"] and reg.num_iterations == ref["iters"]
+    rot, trans = synth.pose_error(reg.getOptimalPose(), np.array(ref["pose"]))
+    assert rot <= POSE_TOL_DEV and trans <= POSE_TOL_DEV
+    assert abs(reg.SSO - ref["sso"]) < 1e-6
+    g = ref["at_gt_level1"]
+    e = reg.eval(1, z["T_gt"], method)
+    assert e["n_valid"] == g["n_valid"] and e["n_visible"] == g["n_visible"]
+    assert abs(e["err2"] - g["err2"]) <= ERR2_RTOL * max(1.0, g["err2"])
+    assert np.abs(e["H64"] - np.array(g["H64"])).max() <= HG_RTOL * np.abs(np.array(g["H64"])).max()
+
+
+@pytest.mark.parametrize("occlusion,method", [(1, 2), (2, 0), (2, 1), (2, 2)])
+def test_hip_occlusion_matches_golden_fixture(hip_lib, occlusion, method):
+    z, j = _golden()
+    ref = j["occlusion"]["math1/occ%d/method%d" % (occlusion, method)]
+    (rgbA, dA), (rgbB, dB), T = synth.add_occluder(((z["rgbA"], z["dA"]), (z["rgbB"], z["dB"]), z["T_gt"]))
+    reg = _mk(hip_lib, 3)
+    reg.setTargetFrame(rgbA, dA)
+    reg.setSourceFrame(rgbB, dB)
+    rc = reg.alignFrames360(np.eye(4), method, occlusion)
+    assert rc == ref["status"] and reg.num_iterations == ref["iters"]
+    rot, trans = synth.pose_error(reg.getOptimalPose(), np.array(ref["pose"]))
+    assert rot <= POSE_TOL_DEV and trans <= POSE_TOL_DEV
+    g = ref["at_probe_level1"]
+    e = reg.eval(1, synth.occlusion_test_poses(T)[2], method, occlusion)
+    assert list(e["n_split"]) == [g["n_photo"], g["n_depth"]] and e["n_visible"] == g["n_visible"]
+    assert np.abs(e["H64"] - np.array(g["H64"])).max() <= HG_RTOL * np.abs(np.array(g["H64"])).max()

@@ -293,3 +293,84 @@ def test_analytic_warp_jacobian_matches_finite_differences(oracle_mod):
             pm = expm(-W) @ pf.astype(np.float64) - dlt[:3]
             Jfd[:, j] = (project(pp) - project(pm)) / (2 * eps)
         assert np.allclose(J, Jfd, rtol=2e-4, atol=2e-3 * np.abs(Jfd).max()), (p, J, Jfd)
+
+
+# ---- occlusion-aware variants (sequential semantics of RPI.h:3232-4249) ---------------------------------------------
+@pytest.mark.parametrize("math_mode", [0, 1])
+@pytest.mark.parametrize("occlusion,method", [(1, 2), (2, 0), (2, 1), (2, 2)])
+def test_oracle_occlusion_matches_golden(golden, oracle_mod, math_mode, occlusion, method):
+    z, j = golden
+    ref = j["occlusion"]["math%d/occ%d/method%d" % (math_mode, occlusion, method)]
+    (rgbA, dA), (rgbB, dB), T = synth.add_occluder(((z["rgbA"], z["dA"]), (z["rgbB"], z["dB"]), z["T_gt"]))
+    ora = oracle_mod.Oracle(n_pyr=3, math_mode=math_mode, reduce_mode=1)
+    ora.set_target(rgbA, dA)
+    ora.set_source(rgbB, dB)
+    st, pose = ora.align360(np.eye(4), method, occlusion)
+    assert st == ref["status"] and list(ora.result.iters)[:3] == ref["iters"]
+    rot, trans = synth.pose_error(pose, np.array(ref["pose"]))
+    assert rot < 1e-6 and trans < 1e-6
+    assert abs(ora.result.err_final - ref["err_final"]) < 1e-9
+    probe = synth.occlusion_test_poses(T)[2]
+    e = ora.error_occ(1, probe, method, occlusion)
+    g = ref["at_probe_level1"]
+    assert (e[3], e[4]) == (g["n_photo"], g["n_depth"])
+    assert abs(e[1] - g["sum_photo"]) <= 1e-9 * max(1.0, g["sum_photo"]) and abs(e[2] - g["sum_depth"]) <= 1e-9 * max(1.0, g["sum_depth"])
+    H, gg, Hd, gd, nvis = ora.hessgrad_occ(1, probe, method, occlusion)
+    assert nvis == g["n_visible"]
+    assert np.allclose(Hd, np.array(g["H64"]), rtol=1e-9)
+
+
+def test_occlusion_invariants(oracle_mod, small_pair):
+    """Relations between the occlusion passes and the plain pass that follow from the reference source alone."""
+    (rgbA, dA), (rgbB, dB), T = synth.add_occluder(small_pair)
+    ora = oracle_mod.Oracle(n_pyr=3, math_mode=0, reduce_mode=1)
+    ora.set_target(rgbA, dA)
+    ora.set_source(rgbB, dB)
+    for pose in synth.occlusion_test_poses(T):
+        # Occ1's H,g pass indexes its z-buffer by the source pixel, so it rejects nothing (RPI.h:3473-3475); for PHOTO only
+        # the trailing store is reached by exactly the pixels the plain pass keeps: identical normal equations
+        H1, g1, Hd1, gd1, nv1 = ora.hessgrad_occ(1, pose, 0, 1)
+        H0, g0, Hd0, gd0, nv0 = ora.hessgrad(1, pose, 0)
+        assert nv1 == nv0
+        assert np.allclose(Hd1, Hd0, rtol=1e-12) and np.allclose(gd1, gd0, rtol=1e-10, atol=1e-9)
+        # with PHOTO_DEPTH a non-salient depth gradient also drops the photometric row (RPI.h:3575-3600): H can only lose
+        Hd1b = ora.hessgrad_occ(1, pose, 2, 1)[2]
+        Hd0b = ora.hessgrad(1, pose, 2)[2]
+        assert np.all(np.diag(Hd1b) <= np.diag(Hd0b) * (1 + 1e-12))
+        # Occ1 error: a target pixel holds one residual, so the sums cannot exceed the plain ones; the counters count
+        # every z-buffer update, so they lie between the number of distinct targets and the plain counts
+        rms0, err2_0, n0 = ora.error(1, pose, 2)
+        e1 = ora.error_occ(1, pose, 2, 1)
+        assert e1[1] + e1[2] <= err2_0 * (1 + 1e-12) and e1[3] + e1[4] <= n0
+        # Occ2: the gate only removes pixels; distinct targets <= accepted pixels <= visible pixels
+        e2 = ora.error_occ(1, pose, 2, 2)
+        nv2 = ora.hessgrad_occ(1, pose, 2, 2)[4]
+        assert nv2 <= e2[3] == e2[4] <= nv0
+    # single modality under Occ1: avPhoto + avDepth has a 0/0 term -> NaN, no iteration, guess returned
+    st, pose = ora.align360(np.eye(4), 0, 1)
+    assert st == 2 and np.allclose(pose, np.eye(4)) and list(ora.result.iters)[:3] == [0, 0, 0]
+
+
+def test_occlusion_zbuffer_known_answer(oracle_mod):
+    """Hand-checkable case: two flat frames 2 m away, the source carrying a near patch that a sideways pose moves in
+    front of far pixels.  Every number below follows from counting pixels."""
+    W, H = 64, 32
+    rgb = np.zeros((H, W, 3), np.uint8)
+    rgb[..., :] = (np.arange(W)[None, :, None] * 4) % 256            # horizontal ramp: salient everywhere inside
+    d_far = np.full((H, W), 2000, np.uint16)
+    ora = oracle_mod.Oracle(n_pyr=1, math_mode=0, reduce_mode=1, mask_seams=0)
+    ora.set_target(rgb, d_far)
+    ora.set_source(rgb, d_far)
+    e_plain = ora.error(0, np.eye(4), 2)
+    e1 = ora.error_occ(0, np.eye(4), 2, 1)
+    e2 = ora.error_occ(0, np.eye(4), 2, 2)
+    # identity pose, identical frames: one source pixel per target pixel, nothing gated, nothing occluded
+    assert e1[3] + e1[4] == e_plain[2]
+    assert e2[3] == e2[4] == ora.hessgrad(0, np.eye(4), 2)[4] == ora.hessgrad_occ(0, np.eye(4), 2, 2)[4]
+    # a source whose left half is 1 m closer: under Occ2 every pixel of that half fails |Dtrg - dist| <= 0.3
+    d_src = d_far.copy()
+    d_src[:, : W // 2] = 1000
+    ora.set_source(rgb, d_src)
+    e2 = ora.error_occ(0, np.eye(4), 2, 2)
+    assert e2[3] == H * W // 2
+    assert ora.hessgrad_occ(0, np.eye(4), 2, 2)[4] == H * W // 2
