@@ -110,6 +110,18 @@ int rgbd360_align360(rgbd360_ctx* ctx, const float guess[16], int method, int oc
 int rgbd360_align360_begin(rgbd360_ctx* ctx, const float guess[16], int method, int occlusion);
 int rgbd360_align360_finish(rgbd360_ctx* ctx, float pose_out[16], rgbd360_result* res);
 
+/* A sequence of n_frames frames = n_frames-1 consecutive pairs (pair j: frame j = target, frame j+1 = source), the way
+ * OdometryRGBD360.cpp:141-297 walks a sequence; SURVEY.md 8b/8e's batch entry for ONE GPU (multi-GPU = one process per GPU,
+ * each calling this on its contiguous shard; see rgbd360_amd/batch.py).  rgb[k] / depth[k]: host images as in
+ * rgbd360_set_target.  The pairs are split into n_inflight (1..16) contiguous sub-chunks that run concurrently, each on its
+ * own context and stream (created once and owned by `ctx`); inside a sub-chunk every frame is uploaded once.  guess (NULL =
+ * identity) is the initial pose of every pair.  poses_out: (n_frames-1) x 16 floats column-major; results_out (may be NULL):
+ * n_frames-1 records whose .status carries the per-pair outcome (0 / ILL_POSED / NO_VALID_PIXELS).  Returns 0, or the first
+ * negative error. */
+int rgbd360_align360_batch(rgbd360_ctx* ctx, int n_frames, const uint8_t* const* rgb, size_t rgb_step, const void* const* depth,
+                           size_t depth_step, int depth_type, int rows, int cols, const float guess[16], int method,
+                           int occlusion, int n_inflight, float* poses_out, rgbd360_result* results_out);
+
 /* ---- stage-level entry points (parity tests and measurement) ------------------------------------------------ */
 
 /* Pyramid planes as float32 rows x cols (level dims via rgbd360_level_dims).

@@ -66,6 +66,7 @@ struct rgbd360_ctx {
     float al_guess[16] = {0};     // alignment in flight (rgbd360_align360_begin / _finish)
     int al_method = 0;
     bool al_active = false;
+    std::vector<rgbd360_ctx*> siblings;                // extra contexts of rgbd360_align360_batch (owned)
     int al_occ = 0;
     int *occ_head = nullptr, *occ_next = nullptr;      // occlusion modes: per-target candidate lists
     float* occ_dinv = nullptr;
@@ -390,6 +391,8 @@ int rgbd360_create(const rgbd360_params* p, rgbd360_ctx** out) {
 void rgbd360_destroy(rgbd360_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->p.device);
+    for (rgbd360_ctx* sib : ctx->siblings) rgbd360_destroy(sib);
+    ctx->siblings.clear();
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     free_levels(ctx);
     hipFree(ctx->d_state); hipFree(ctx->d_partials); hipFree(ctx->d_gnio);
@@ -529,6 +532,79 @@ int rgbd360_align360(rgbd360_ctx* ctx, const float guess[16], int method, int oc
     const int rc = rgbd360_align360_begin(ctx, guess, method, occlusion);
     if (rc) return rc;
     return rgbd360_align360_finish(ctx, pose_out, res);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// A sequence of consecutive pairs on one GPU (SURVEY.md 8b rgbd360_align360_batch, 8e): pair j = (frame j, frame j+1),
+// frame j = target, frame j+1 = source, as OdometryRGBD360.cpp:141-297 walks a sequence.  The pairs are cut into
+// n_inflight contiguous sub-chunks, one context (own HIP stream) each; inside a sub-chunk frame j+1 is uploaded once and
+// promoted from source to target; in every step all live contexts are enqueued before any is waited for.
+// ---------------------------------------------------------------------------------------------------------
+int rgbd360_align360_batch(rgbd360_ctx* ctx, int n_frames, const uint8_t* const* rgb, size_t rgb_step, const void* const* depth,
+                           size_t depth_step, int depth_type, int rows, int cols, const float guess[16], int method,
+                           int occlusion, int n_inflight, float* poses_out, rgbd360_result* results_out) {
+    if (!ctx) return -1;
+    if (!rgb || !depth || !poses_out) return fail(ctx, -1, "null pointer");
+    if (n_frames < 1) return fail(ctx, -1, "n_frames must be >= 1");
+    if (n_inflight < 1 || n_inflight > 16) return fail(ctx, -1, "n_inflight must be in 1..16");
+    if (method < 0 || method > 2) return fail(ctx, -4, "bad method");
+    if (occlusion < 0 || occlusion > 2) return fail(ctx, -5, "occlusion must be 0, 1 or 2");
+    const int n = n_frames - 1;
+    if (n == 0) return 0;
+    for (int k = 0; k < n_frames; ++k)
+        if (!rgb[k] || !depth[k]) return fail(ctx, -1, "null frame pointer");
+    static const float kIdentity[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    const float* g = guess ? guess : kIdentity;
+    const int k_ctx = std::min(n_inflight, n);
+    while ((int)ctx->siblings.size() < k_ctx - 1) {
+        rgbd360_ctx* sib = nullptr;
+        const int rc = rgbd360_create(&ctx->p, &sib);
+        if (rc) return fail(ctx, rc, "cannot create a sibling context");
+        ctx->siblings.push_back(sib);
+    }
+    std::vector<rgbd360_ctx*> cs(k_ctx);
+    cs[0] = ctx;
+    for (int c = 1; c < k_ctx; ++c) cs[c] = ctx->siblings[c - 1];
+    // contiguous balanced spans [a, b) of pairs per context
+    std::vector<int> a(k_ctx), b(k_ctx);
+    int steps = 0;
+    for (int c = 0; c < k_ctx; ++c) {
+        const int base = n / k_ctx, extra = n % k_ctx;
+        a[c] = c * base + std::min(c, extra);
+        b[c] = a[c] + base + (c < extra ? 1 : 0);
+        steps = std::max(steps, b[c] - a[c]);
+    }
+    auto propagate = [&](rgbd360_ctx* from, int rc) { return from == ctx ? rc : fail(ctx, rc, from->err.c_str()); };
+    for (int c = 0; c < k_ctx; ++c) {
+        const int rc = rgbd360_set_target(cs[c], rgb[a[c]], rgb_step, depth[a[c]], depth_step, depth_type, rows, cols);
+        if (rc) return propagate(cs[c], rc);
+    }
+    for (int s = 0; s < steps; ++s) {
+        for (int c = 0; c < k_ctx; ++c) {
+            if (a[c] + s >= b[c]) continue;
+            const int f = a[c] + s + 1;
+            int rc = rgbd360_set_source(cs[c], rgb[f], rgb_step, depth[f], depth_step, depth_type, rows, cols);
+            if (!rc) rc = rgbd360_align360_begin(cs[c], g, method, occlusion);
+            if (rc) {
+                for (int d = 0; d < c; ++d)          // drain what is already in flight
+                    if (cs[d]->al_active) { float tmp[16]; rgbd360_align360_finish(cs[d], tmp, nullptr); }
+                return propagate(cs[c], rc);
+            }
+        }
+        int first_err = 0;
+        rgbd360_ctx* err_ctx = nullptr;
+        for (int c = 0; c < k_ctx; ++c) {
+            if (a[c] + s >= b[c]) continue;
+            const int j = a[c] + s;
+            rgbd360_result R;
+            int rc = rgbd360_align360_finish(cs[c], poses_out + (size_t)16 * j, &R);
+            if (results_out) results_out[j] = R;
+            if (rc >= 0 && j + 1 < b[c]) rc = std::min(0, rgbd360_promote_source_to_target(cs[c]));
+            if (rc < 0 && !first_err) { first_err = rc; err_ctx = cs[c]; }
+        }
+        if (first_err) return propagate(err_ctx, first_err);
+    }
+    return 0;
 }
 
 int rgbd360_level_dims(rgbd360_ctx* ctx, int level, int* rows, int* cols) {

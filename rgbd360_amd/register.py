@@ -188,6 +188,39 @@ class RegisterPhotoICP:
         self.num_iterations = [int(r.iters[l]) for l in range(self._p.n_pyr)]
         return rc
 
+    def alignSequence(self, frames, method: int = 0, occlusion: int = 0, pose_guess=None, n_inflight: int = 2):
+        """rgbd360_align360_batch: the len(frames)-1 consecutive pairs of a sequence (frame j = target, j+1 = source) on this
+        context's GPU, n_inflight sub-chunks in flight.  frames: list of (rgb HxWx3 uint8, depth HxW uint16 mm | float32 m).
+        Returns (poses [n,4,4] float32, status [n] int32, iters [n, n_pyr] int32)."""
+        from ._lib import Result
+        n = len(frames) - 1
+        poses = np.zeros((max(n, 0), 4, 4), np.float32)
+        status = np.zeros(max(n, 0), np.int32)
+        iters = np.zeros((max(n, 0), self._p.n_pyr), np.int32)
+        if n <= 0:
+            return poses, status, iters
+        rgbs = [np.ascontiguousarray(f[0], np.uint8) for f in frames]
+        deps = [np.ascontiguousarray(f[1]) for f in frames]
+        shape, dtype = deps[0].shape, deps[0].dtype
+        if dtype not in (np.uint16, np.float32):
+            raise Rgbd360Error("imgDepth must be uint16 millimetres (CV_16UC1) or float32 metres (CV_32FC1)")
+        for r, d in zip(rgbs, deps):
+            if r.shape != shape + (3,) or d.shape != shape or d.dtype != dtype:
+                raise Rgbd360Error("all frames of a sequence must share one size and depth type")
+        rgb_ptrs = (C.c_void_p * len(frames))(*[r.ctypes.data for r in rgbs])
+        dep_ptrs = (C.c_void_p * len(frames))(*[d.ctypes.data for d in deps])
+        out = np.zeros(n * 16, np.float32)
+        res = (Result * n)()
+        g = None if pose_guess is None else _ptr(pose_to_cm(pose_guess))
+        self._check(self._L.rgbd360_align360_batch(self._ctx(), len(frames), rgb_ptrs, shape[1] * 3, dep_ptrs,
+                                                   shape[1] * dtype.itemsize, 0 if dtype == np.uint16 else 1, shape[0], shape[1],
+                                                   g, int(method), int(occlusion), int(n_inflight), _ptr(out), res))
+        for j in range(n):
+            poses[j] = pose_from_cm(out[16 * j:16 * j + 16])
+            status[j] = res[j].status
+            iters[j] = [int(res[j].iters[l]) for l in range(self._p.n_pyr)]
+        return poses, status, iters
+
     def getOptimalPose(self) -> np.ndarray:       # RPI.h:273
         return self._pose.copy()
 

@@ -441,6 +441,28 @@ def test_concurrent_contexts_give_identical_poses(hip_lib):
     assert np.array_equal(r.getOptimalPose(), poses[0])
 
 
+def test_native_batch_entry_equals_pairwise_alignment(hip_lib):
+    """rgbd360_align360_batch (one C call for a whole sequence) returns exactly the poses of the pair-by-pair schedule,
+    for 1, 2 and 3 sub-chunks in flight, and for an occlusion mode."""
+    from rgbd360_amd.batch import align_sequence
+    frames = [synth.render(synth.trajectory_pose(k, 7), 256, 128, 7) for k in range(6)]
+    poses, status, iters = align_sequence(_mk(hip_lib, 3), lambda k: frames[k], 0, 5, 2)
+    reg = _mk(hip_lib, 3)
+    for k in (1, 2, 3):
+        p2, s2, i2 = reg.alignSequence(frames, method=2, n_inflight=k)
+        assert np.array_equal(poses, p2) and np.array_equal(status, s2) and np.array_equal(iters, i2), k
+    p3, s3, i3 = reg.alignSequence(frames, method=2, occlusion=2, n_inflight=2)
+    one = _mk(hip_lib, 3)
+    one.setTargetFrame(*frames[2]); one.setSourceFrame(*frames[3])
+    assert one.alignFrames360(np.eye(4), 2, 2) == s3[2]
+    assert np.array_equal(one.getOptimalPose(), p3[2])
+    # degenerate inputs
+    assert reg.alignSequence(frames[:1])[0].shape == (0, 4, 4)
+    from rgbd360_amd.register import Rgbd360Error
+    with pytest.raises(Rgbd360Error):
+        reg.alignSequence(frames, n_inflight=0)
+
+
 # ---- occlusion-aware variants (SURVEY.md 8f rank 1; RPI.h:3232-4249, sequential semantics) ---------------------------
 _occluder_pair = synth.add_occluder
 _occ_poses = synth.occlusion_test_poses

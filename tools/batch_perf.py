@@ -34,3 +34,12 @@ for k in (2, 4, 8):
     p2, st2, it2 = align_sequence_concurrent(regs, lambda i: frames[i], 0, n, 2)
     dt = time.perf_counter() - t0
     print("PHOTO_DEPTH, %d contexts in flight: %d pairs in %.2f ms -> %.0f alignments/s; identical poses: %s" % (k, n, dt * 1e3, n / dt, bool(np.array_equal(p2, ref_poses))))
+
+# the same through ONE C call (rgbd360_align360_batch): no Python between the pairs
+reg2 = RegisterPhotoICP(); reg2.setNumPyr(4)
+for k in (1, 2, 4):
+    reg2.alignSequence(frames[: 2 * k + 1], method=2, n_inflight=k)      # warm (creates the sibling contexts)
+    t0 = time.perf_counter()
+    p3, st3, it3 = reg2.alignSequence(frames, method=2, n_inflight=k)
+    dt = time.perf_counter() - t0
+    print("PHOTO_DEPTH, rgbd360_align360_batch n_inflight=%d: %d pairs in %.2f ms -> %.0f alignments/s; identical poses: %s" % (k, n, dt * 1e3, n / dt, bool(np.array_equal(p3, ref_poses))))
