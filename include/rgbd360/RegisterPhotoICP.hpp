@@ -80,6 +80,15 @@ class RegisterPhotoICP {
         if (viz) throw std::runtime_error("rgbd360: visualisation is not part of the MI355X path");
     }
     void setDevice(int device) { p_.device = device; reset(); }
+    // RPI.h:254-257 (pinhole single-sensor use).  The seam mask of the spherical panorama (RPI.h:4538-4549) does not apply
+    // to a sensor image: alignFrames() needs setMaskSeams(false), which the reference gets implicitly by never running
+    // alignFrames360 on such an object.
+    void setCameraMatrix(float fx, float fy, float ox, float oy) {
+        cam_[0] = fx; cam_[1] = fy; cam_[2] = ox; cam_[3] = oy;
+        have_cam_ = true;
+        if (ctx_ && rgbd360_set_camera(ctx_, fx, fy, ox, oy) != 0) throw std::runtime_error(std::string("rgbd360_set_camera: ") + rgbd360_last_error(ctx_));
+    }
+    void setMaskSeams(bool on) { p_.mask_seams = on ? 1 : 0; reset(); }
 
     // RPI.h:498-516 / 480-494
     void setTargetFrame(const ImageView& rgb, const ImageView& depth) { set(true, rgb, depth); }
@@ -96,6 +105,20 @@ class RegisterPhotoICP {
         std::memcpy(gradient_.data(), r.gradient, sizeof(float) * 6);
         SSO = r.sso;
         avResidual = rc == RGBD360_ILL_POSED ? 0.f : (float)r.err_final;      // RPI.h:4688
+        avPhotoResidual = r.rms_photo;
+        avDepthResidual = r.rms_depth;
+        num_iterations_.assign(r.iters, r.iters + p_.n_pyr);
+    }
+
+    // RPI.h:4254-4512: pinhole single-sensor alignment (Levenberg-Marquardt), occlusion 0.
+    void alignFrames(const Mat4f& pose_guess = Mat4f::Identity(), costFuncType method = PHOTO_CONSISTENCY, int occlusion = 0) {
+        rgbd360_result r;
+        const int rc = rgbd360_align_pinhole(ctx(), pose_guess.m, (int)method, occlusion, relPose_.m, &r);
+        if (rc < 0) throw std::runtime_error(std::string("rgbd360_align_pinhole: ") + rgbd360_last_error(ctx_));
+        status_ = rc;
+        std::memcpy(hessian_.m, r.hessian, sizeof(hessian_.m));
+        std::memcpy(gradient_.data(), r.gradient, sizeof(float) * 6);
+        avResidual = (float)r.err_final;
         avPhotoResidual = r.rms_photo;
         avDepthResidual = r.rms_depth;
         num_iterations_.assign(r.iters, r.iters + p_.n_pyr);
@@ -118,6 +141,12 @@ class RegisterPhotoICP {
     }
 #endif
 #ifdef RGBD360_HAVE_EIGEN
+    void setCameraMatrix(Eigen::Matrix3f& camMat) { setCameraMatrix(camMat(0, 0), camMat(1, 1), camMat(0, 2), camMat(1, 2)); }
+    void alignFrames(const Eigen::Matrix4f pose_guess, costFuncType method = PHOTO_CONSISTENCY, int occlusion = 0) {
+        Mat4f g;
+        std::memcpy(g.m, pose_guess.data(), sizeof(g.m));
+        alignFrames(g, method, occlusion);
+    }
     void alignFrames360(const Eigen::Matrix4f pose_guess, costFuncType method = PHOTO_CONSISTENCY, int occlusion = 0) {
         Mat4f g;
         std::memcpy(g.m, pose_guess.data(), sizeof(g.m));
@@ -135,6 +164,8 @@ class RegisterPhotoICP {
     std::array<float, 6> gradient_{};
     std::vector<int> num_iterations_;
     int status_ = 0;
+    float cam_[4] = {0.f, 0.f, 0.f, 0.f};
+    bool have_cam_ = false;
 
     void reset() {
         if (ctx_) rgbd360_destroy(ctx_);
@@ -144,6 +175,7 @@ class RegisterPhotoICP {
         if (!ctx_) {
             const int rc = rgbd360_create(&p_, &ctx_);
             if (rc != 0) throw std::runtime_error("rgbd360_create failed (" + std::to_string(rc) + "): no usable HIP device; there is no CPU fallback");
+            if (have_cam_) rgbd360_set_camera(ctx_, cam_[0], cam_[1], cam_[2], cam_[3]);
         }
         return ctx_;
     }

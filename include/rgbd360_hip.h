@@ -231,6 +231,26 @@ int rgbd360_frame_planes(rgbd360_ctx* ctx, const void* depth, size_t depth_step,
                          float* xyz_out, float* normals_out, int32_t* labels_out, rgbd360_plane* planes_out, int max_planes,
                          int* n_planes_out);
 
+/* ---- pinhole single-sensor alignment ------------------------------------------------------ */
+
+/* RegisterPhotoICP::setCameraMatrix (RPI.h:254-257): fx, fy, ox, oy of the full-resolution sensor image; the pyramid
+ * levels scale them by 2^-level (RPI.h:571-575). */
+int rgbd360_set_camera(rgbd360_ctx* ctx, float fx, float fy, float ox, float oy);
+/* RegisterPhotoICP::alignFrames(pose_guess, method, occlusion) (RPI.h:4254-4512): coarse-to-fine alignment of two
+ * pinhole RGB-D images (the frames given to rgbd360_set_target / _source of a context created with mask_seams = 0) with
+ * the reference's Levenberg-Marquardt schedule (lambda 0.01, x10 / /10, 10 iterations, tolerances 1e-4 hard-coded at
+ * RPI.h:4303-4308), errorPhotoICP (RPI.h:560-748) and calcHessGrad (RPI.h:754-1104), CPose3D::exp (full exponential).
+ * The per-pixel passes run on the device, the damping loop on the host.  occlusion must be 0.  Reference quirks kept:
+ * the error divides both residual sums by the number of depth-valid pixels, so PHOTO_CONSISTENCY alone gives NaN and the
+ * guess comes back (status RGBD360_NO_VALID_PIXELS); the error pass applies no saliency test while the H,g pass does. */
+int rgbd360_align_pinhole(rgbd360_ctx* ctx, const float guess[16], int method, int occlusion, float pose_out[16],
+                          rgbd360_result* res);
+/* One fused pinhole pass at `pose` (stage-level, for parity tests): error sums / counts of errorPhotoICP and H, g of
+ * calcHessGrad; n_rows = Jacobian rows that entered the normal equations. */
+int rgbd360_eval_pinhole(rgbd360_ctx* ctx, int level, const float pose[16], int method, double err2_split[2],
+                         long long n_split[2], float H[36], float g[6], double H64[36], double g64[6], long long* n_rows);
+int rgbd360_warp_indices_pinhole(rgbd360_ctx* ctx, int level, const float pose[16], int32_t* host_out_rc);
+
 /* ---- Frame360 input side (the two steps before the path) ------------------------------------------------------- */
 
 /* Frame360::loadFrame (Frame360.h:231-266): reads one `sphere_images_%d.bin` (Boost binary archive of 8 x {RGB 8UC3,

@@ -65,6 +65,15 @@ def lib():
         L.oracle_error_occ.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.oracle_hessgrad_occ.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.POINTER(C.c_long)]
+        L.oracle_set_camera.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float]
+        L.oracle_align_pinhole.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(Result)]
+        L.oracle_error_pinhole.restype = C.c_double
+        L.oracle_error_pinhole.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.oracle_hessgrad_pinhole.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.POINTER(C.c_long)]
+        L.oracle_get_lut_pinhole.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.oracle_se3_exp.argtypes = [C.c_void_p, C.c_void_p]
+        L.oracle_warp_indices_pinhole.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.oracle_trace_len.argtypes = [C.c_void_p]
         L.oracle_trace_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(Trace)]
         L.oracle_level_dims.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -162,6 +171,43 @@ class Oracle:
             st = lib().oracle_align360(self.h, _ptr(g), method, _ptr(out), C.byref(self.result))
         return st, pose_from_cm(out)
 
+    # ---- pinhole single-sensor path (RPI.h:4254-4512)
+    def set_camera(self, fx, fy, ox, oy):
+        lib().oracle_set_camera(self.h, fx, fy, ox, oy)
+
+    def align_pinhole(self, guess=None, method=PHOTO_DEPTH):
+        g = pose_to_cm(np.eye(4) if guess is None else guess)
+        out = np.zeros(16, dtype=np.float32)
+        st = lib().oracle_align_pinhole(self.h, _ptr(g), method, _ptr(out), C.byref(self.result))
+        return st, pose_from_cm(out)
+
+    def error_pinhole(self, level, pose, method):
+        sums = np.zeros(4, np.float64)
+        e = lib().oracle_error_pinhole(self.h, level, _ptr(pose_to_cm(pose)), method, _ptr(sums))
+        return e, sums[0], sums[1], int(sums[2]), int(sums[3])
+
+    def hessgrad_pinhole(self, level, pose, method):
+        H = np.zeros(36, np.float32)
+        g = np.zeros(6, np.float32)
+        Hd = np.zeros(36, np.float64)
+        gd = np.zeros(6, np.float64)
+        nv = C.c_long()
+        lib().oracle_hessgrad_pinhole(self.h, level, _ptr(pose_to_cm(pose)), method, _ptr(H), _ptr(g), _ptr(Hd), _ptr(gd),
+                                      C.byref(nv))
+        return H.reshape(6, 6).T.copy(), g, Hd.reshape(6, 6).T.copy(), gd, nv.value
+
+    def lut_pinhole(self, level) -> np.ndarray:
+        r, c = self.level_dims(level)
+        out = np.empty((r * c, 3), dtype=np.float32)
+        lib().oracle_get_lut_pinhole(self.h, level, _ptr(out))
+        return out
+
+    def warp_indices_pinhole(self, level, pose) -> np.ndarray:
+        r, c = self.level_dims(level)
+        out = np.empty((r * c, 2), dtype=np.int32)
+        lib().oracle_warp_indices_pinhole(self.h, level, _ptr(pose_to_cm(pose)), _ptr(out))
+        return out
+
     def error_occ(self, level, pose, method, occlusion):
         """Occlusion-mode error pass -> (avPhoto + avDepth, sum photo, sum depth, n photo, n depth)."""
         sums = np.zeros(4, np.float64)
@@ -237,6 +283,13 @@ class Oracle:
         out = np.empty((r * c, 2), dtype=np.int32)
         lib().oracle_warp_indices(self.h, level, _ptr(pose_to_cm(pose)), _ptr(out))
         return out
+
+
+def se3_exp(v) -> np.ndarray:
+    """CPose3D::exp(v, pseudo_exponential=false) restatement: 4x4 float64."""
+    out = np.zeros(16, np.float64)
+    lib().oracle_se3_exp(_ptr(np.ascontiguousarray(v, np.float64)), _ptr(out))
+    return out.reshape(4, 4).T.copy()
 
 
 def gn_step(H, g, lam, pose):

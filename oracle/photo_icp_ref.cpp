@@ -105,6 +105,8 @@ struct Ctx {
     long  last_nvalid = 0, last_nvalid_photo = 0, last_nvalid_depth = 0;
     std::vector<IterTrace> trace;
     bool keep_intermediates = true;  // allocate J arrays per call like RPI.h:2761-2767
+    float cam[4] = {0, 0, 0, 0};     // cameraMatrix(0,0), (1,1), (0,2), (1,2)   RPI.h:89, 254-257
+    bool have_cam = false;
 };
 
 // ------------------------------------------------------------------------------------
@@ -989,6 +991,252 @@ inline void mat4_mul_f32(const float* A, const float* B, float* C) {  // col-maj
                            A[3 * 4 + r] * B[c * 4 + 3];
 }
 
+// ====================================================================================
+// Pinhole single-sensor path: alignFrames RPI.h:4254-4512 with errorPhotoICP RPI.h:560-748 and
+// calcHessGrad RPI.h:754-1104 (occlusion 0, bUseSalientPixels false = the constructor default RPI.h:205).
+// ====================================================================================
+struct PinholeK {
+    float fx, fy, ox, oy;
+};
+inline PinholeK level_intrinsics(const Ctx& ctx, int level) {   // RPI.h:571-575
+    const float scaleFactor = 1.0 / pow(2, level);
+    return {ctx.cam[0] * scaleFactor, ctx.cam[1] * scaleFactor, ctx.cam[2] * scaleFactor, ctx.cam[3] * scaleFactor};
+}
+
+// RPI.h:4277-4300: LUT of the source sensor's 3-D points; z is written for every pixel, x = INVALID marks bad depth
+void buildLUT_pinhole(Ctx& ctx, int level) {
+    const Image& depth = ctx.depthSrc[level];
+    const int nRows = depth.rows, nCols = depth.cols;
+    ctx.lut.assign((size_t)nRows * nCols * 3, 0.f);
+    const PinholeK K = level_intrinsics(ctx, level);
+    const float inv_fx = 1. / K.fx, inv_fy = 1. / K.fy;
+    for (int r = 0; r < nRows; ++r)
+        for (int c = 0; c < nCols; ++c) {
+            const size_t i = (size_t)r * nCols + c;
+            float* P = &ctx.lut[3 * i];
+            P[2] = depth.at(r, c);
+            if (ctx.p.min_depth < P[2] && P[2] < ctx.p.max_depth) {
+                P[0] = (c - K.ox) * P[2] * inv_fx;
+                P[1] = (r - K.oy) * P[2] * inv_fy;
+            } else
+                P[0] = kInvalidPoint;
+        }
+    ctx.lut_level = 1000 + level;
+}
+
+struct WarpPin {
+    float X, Y, Z, inv_z;
+    int r, c;
+    bool visible;
+};
+inline WarpPin warp_pinhole(const PoseRT& T, const float* p, int nRows, int nCols, const PinholeK& K, int math_mode) {
+    WarpPin w;
+    float tr, tc;
+    if (math_mode == 0) {       // RPI.h:701-708
+        w.X = ((T.R[0] * p[0] + T.R[1] * p[1]) + T.R[2] * p[2]) + T.t[0];
+        w.Y = ((T.R[3] * p[0] + T.R[4] * p[1]) + T.R[5] * p[2]) + T.t[1];
+        w.Z = ((T.R[6] * p[0] + T.R[7] * p[1]) + T.R[8] * p[2]) + T.t[2];
+        w.inv_z = 1.0 / w.Z;
+        tc = (w.X * K.fx) * w.inv_z + K.ox;
+        tr = (w.Y * K.fy) * w.inv_z + K.oy;
+        if (!std::isfinite(tr) || !std::isfinite(tc)) { w.visible = false; w.r = w.c = -1; return w; }   // (int)round(inf) is UB in C++
+        w.r = (int)roundf(tr);
+        w.c = (int)roundf(tc);
+    } else {                    // device arithmetic (occlusion-free pinhole kernels): fma rotation, fma projection, round half up
+        w.X = fmaf(T.R[2], p[2], fmaf(T.R[1], p[1], fmaf(T.R[0], p[0], T.t[0])));
+        w.Y = fmaf(T.R[5], p[2], fmaf(T.R[4], p[1], fmaf(T.R[3], p[0], T.t[1])));
+        w.Z = fmaf(T.R[8], p[2], fmaf(T.R[7], p[1], fmaf(T.R[6], p[0], T.t[2])));
+        w.inv_z = 1.f / w.Z;
+        tc = fmaf(w.X * K.fx, w.inv_z, K.ox);
+        tr = fmaf(w.Y * K.fy, w.inv_z, K.oy);
+        if (!(fabsf(tr) < 1e9f) || !(fabsf(tc) < 1e9f)) { w.visible = false; w.r = w.c = -1; return w; }
+        w.r = round_index(tr);
+        w.c = round_index(tc);
+    }
+    w.visible = (w.r >= 0 && w.r < nRows) && (w.c >= 0 && w.c < nCols);
+    return w;
+}
+
+// RPI.h:560-748 errorPhotoICP (else-branch :693-739: every valid LUT point, NO saliency test).  Both averages divide by
+// nValidDepthPts (RPI.h:742-743): with PHOTO_CONSISTENCY alone the result is inf + NaN = NaN.
+double errorPhotoICP(Ctx& ctx, int level, const float* pose, int method) {
+    double PhotoResidual = 0.0, DepthResidual = 0.0;
+    long nValidPhotoPts = 0, nValidDepthPts = 0;
+    const Image& graySrc = ctx.graySrc[level];
+    const int nRows = graySrc.rows, nCols = graySrc.cols;
+    const PinholeK K = level_intrinsics(ctx, level);
+    const float stdDevPhoto = ctx.p.sigma_photo, stdDevDepth = ctx.p.sigma_depth;
+    const float stdDevPhoto_inv = 1. / stdDevPhoto;
+    const PoseRT T = split_pose(pose);
+    const Image &grayTrg = ctx.grayTrg[level], &depthTrg = ctx.depthTrg[level];
+    const long n = (long)nRows * nCols;
+#pragma omp parallel for reduction(+ : PhotoResidual, DepthResidual, nValidPhotoPts, nValidDepthPts)
+    for (long i = 0; i < n; ++i) {
+        const float* p = &ctx.lut[3 * i];
+        if (p[0] == kInvalidPoint) continue;
+        const WarpPin w = warp_pinhole(T, p, nRows, nCols, K, ctx.p.math_mode);
+        if (!w.visible) continue;
+        if (method == METHOD_PHOTO || method == METHOD_PHOTO_DEPTH) {
+            float photoDiff = grayTrg.at(w.r, w.c) - graySrc.d[i];
+            float weight_photo = weightHuber(photoDiff, stdDevPhoto) * stdDevPhoto_inv;
+            float weightedErrorPhoto = weight_photo * photoDiff;
+            PhotoResidual += weightedErrorPhoto * weightedErrorPhoto;
+            ++nValidPhotoPts;
+        }
+        if (method == METHOD_DEPTH || method == METHOD_PHOTO_DEPTH) {
+            float depth2 = depthTrg.at(w.r, w.c);
+            if (std::isfinite(depth2)) {
+                float depth1 = w.Z;
+                float depthDiff = depth2 - depth1;
+                float stdDev_depth1 = stdDevDepth * depth1;
+                float weight_depth = weightHuber(depthDiff, stdDev_depth1) / stdDev_depth1;
+                float weightedErrorDepth = weight_depth * depthDiff;
+                DepthResidual += weightedErrorDepth * weightedErrorDepth;
+                ++nValidDepthPts;
+            }
+        }
+    }
+    ctx.last_err2_photo = PhotoResidual; ctx.last_err2_depth = DepthResidual;
+    ctx.last_nvalid_photo = nValidPhotoPts; ctx.last_nvalid_depth = nValidDepthPts;
+    ctx.last_nvalid = nValidPhotoPts + nValidDepthPts;
+    return sqrt(PhotoResidual / nValidDepthPts) + sqrt(DepthResidual / nValidDepthPts);
+}
+
+// RPI.h:754-1104 calcHessGrad: H += J^T J, g += J^T r per pixel (float, under `omp critical`: summation order = arrival
+// order; reduce_mode 0 restates the index order, reduce_mode 1 accumulates the same float products in double).
+void calcHessGrad(Ctx& ctx, int level, const float* pose, int method) {
+    const Image& graySrc = ctx.graySrc[level];
+    const int nRows = graySrc.rows, nCols = graySrc.cols;
+    const long imgSize = (long)nRows * nCols;
+    const PinholeK K = level_intrinsics(ctx, level);
+    const float fx = K.fx, fy = K.fy;
+    const float stdDevPhoto = ctx.p.sigma_photo, stdDevDepth = ctx.p.sigma_depth;
+    const float stdDevPhoto_inv = 1. / stdDevPhoto;
+    const PoseRT T = split_pose(pose);
+    const Image &grayTrg = ctx.grayTrg[level], &depthTrg = ctx.depthTrg[level];
+    const Image &gx = ctx.gTrgGx[level], &gy = ctx.gTrgGy[level], &dgx = ctx.dTrgGx[level], &dgy = ctx.dTrgGy[level];
+    const float thrI = ctx.p.thres_sal_photo, thrD = ctx.p.thres_sal_depth;
+    float Hf[36] = {0}, gf[6] = {0};
+    double Hd[36] = {0}, gd[6] = {0};
+    long rows_used = 0;
+    auto add_row = [&](const float* J, float res) {
+        for (int a = 0; a < 6; ++a) {
+            for (int b = 0; b < 6; ++b) {
+                const float prod = J[a] * J[b];
+                Hf[b * 6 + a] += prod;
+                Hd[b * 6 + a] += (double)prod;
+            }
+            const float pr = J[a] * res;
+            gf[a] += pr;
+            gd[a] += (double)pr;
+        }
+        ++rows_used;
+    };
+    for (long i = 0; i < imgSize; ++i) {
+        const float* p = &ctx.lut[3 * i];
+        if (p[0] == kInvalidPoint) continue;
+        const WarpPin w = warp_pinhole(T, p, nRows, nCols, K, ctx.p.math_mode);
+        if (!w.visible) continue;
+        const float X = w.X, Y = w.Y, inv_transformedPz = w.inv_z;
+        // jacobianWarpRt RPI.h:876-893
+        float Jw0[6], Jw1[6];
+        Jw0[0] = fx * inv_transformedPz;
+        Jw1[0] = 0;
+        Jw0[1] = 0;
+        Jw1[1] = fy * inv_transformedPz;
+        const float inv_transformedPz_2 = inv_transformedPz * inv_transformedPz;
+        Jw0[2] = -fx * X * inv_transformedPz_2;
+        Jw1[2] = -fy * Y * inv_transformedPz_2;
+        Jw0[3] = -fx * Y * X * inv_transformedPz_2;
+        Jw1[3] = -fy * (1 + Y * Y * inv_transformedPz_2);
+        Jw0[4] = fx * (1 + X * X * inv_transformedPz_2);
+        Jw1[4] = fy * X * Y * inv_transformedPz_2;
+        Jw0[5] = -fx * Y * inv_transformedPz;
+        Jw1[5] = fy * X * inv_transformedPz;
+        float jacobianPhoto[6] = {0, 0, 0, 0, 0, 0}, jacobianDepth[6] = {0, 0, 0, 0, 0, 0};
+        float weightedErrorPhoto = 0.f, weightedErrorDepth = 0.f;
+        float depth2 = std::numeric_limits<float>::quiet_NaN();   // the reference leaves it uninitialised for PHOTO only; see note below
+        if (method == METHOD_PHOTO || method == METHOD_PHOTO_DEPTH) {
+            const float tgx = gx.at(w.r, w.c), tgy = gy.at(w.r, w.c);
+            if (fabsf(tgx) < thrI && fabsf(tgy) < thrI) continue;
+            float photoDiff = grayTrg.at(w.r, w.c) - graySrc.d[i];
+            float weight_photo = weightHuber(photoDiff, stdDevPhoto) * stdDevPhoto_inv;
+            weightedErrorPhoto = weight_photo * photoDiff;
+            const float wgx = weight_photo * tgx, wgy = weight_photo * tgy;
+            for (int j = 0; j < 6; ++j) jacobianPhoto[j] = wgx * Jw0[j] + wgy * Jw1[j];
+        }
+        if (method == METHOD_DEPTH || method == METHOD_PHOTO_DEPTH) {
+            const float tdx = dgx.at(w.r, w.c), tdy = dgy.at(w.r, w.c);
+            if (fabsf(tdx) < thrD && fabsf(tdy) < thrD) continue;       // RPI.h:929-930: before the finite test, skips the photo row too
+            depth2 = depthTrg.at(w.r, w.c);
+            if (std::isfinite(depth2)) {
+                float depthDiff = depth2 - w.Z;
+                float stdDev_depth1 = stdDevDepth * w.Z;
+                float weight_depth = weightHuber(depthDiff, stdDev_depth1) / stdDev_depth1;
+                weightedErrorDepth = weight_depth * depthDiff;
+                const float jacobianRt_z[6] = {0, 0, 1, Y, -X, 0};
+                for (int j = 0; j < 6; ++j) jacobianDepth[j] = weight_depth * ((tdx * Jw0[j] + tdy * Jw1[j]) - jacobianRt_z[j]);
+            }
+        }
+        if (method == METHOD_PHOTO || method == METHOD_PHOTO_DEPTH) add_row(jacobianPhoto, weightedErrorPhoto);
+        if ((method == METHOD_DEPTH || method == METHOD_PHOTO_DEPTH) && std::isfinite(depth2)) add_row(jacobianDepth, weightedErrorDepth);
+    }
+    for (int k = 0; k < 36; ++k) {
+        ctx.H[k] = ctx.p.reduce_mode == 0 ? Hf[k] : (float)Hd[k];
+        ctx.H64[k] = Hd[k];
+    }
+    for (int a = 0; a < 6; ++a) {
+        ctx.g[a] = ctx.p.reduce_mode == 0 ? gf[a] : (float)gd[a];
+        ctx.g64[a] = gd[a];
+    }
+    ctx.n_visible = rows_used;
+    ctx.sso = 0.f;
+}
+
+// THIRD-PARTY (MRPT 1.x CPose3D::exp(mu, pseudo_exponential = false), RPI.h:4358, 4391): the SE(3) exponential with
+// the translation coupled through V(w): t = u + B (w x u) + C (w x (w x u)); small-angle series below theta^2 < 1e-8 /
+// 1e-6 as in MRPT's (TooN-derived) implementation.
+void se3_exp(const double* v, double* M /*col-major 4x4*/) {
+    const double ux = v[0], uy = v[1], uz = v[2], wx = v[3], wy = v[4], wz = v[5];
+    const double theta_sq = wx * wx + wy * wy + wz * wz;
+    const double theta = sqrt(theta_sq);
+    const double cx = wy * uz - wz * uy, cy = wz * ux - wx * uz, cz = wx * uy - wy * ux;      // w x u
+    double A, B, tx, ty, tz;
+    if (theta_sq < 1e-8) {
+        A = 1.0 - theta_sq / 6.0;
+        B = 0.5;
+        tx = ux + 0.5 * cx; ty = uy + 0.5 * cy; tz = uz + 0.5 * cz;
+    } else {
+        double C;
+        if (theta_sq < 1e-6) {
+            C = (1.0 / 6.0) * (1.0 - theta_sq / 20.0);
+            A = 1.0 - theta_sq * C;
+            B = 0.5 - 0.25 * (1.0 / 6.0) * theta_sq;
+        } else {
+            const double inv_theta = 1.0 / theta;
+            A = sin(theta) * inv_theta;
+            B = (1 - cos(theta)) * (inv_theta * inv_theta);
+            C = (1 - A) * (inv_theta * inv_theta);
+        }
+        const double dx = wy * cz - wz * cy, dy = wz * cx - wx * cz, dz = wx * cy - wy * cx;  // w x (w x u)
+        tx = ux + B * cx + C * dx; ty = uy + B * cy + C * dy; tz = uz + B * cz + C * dz;
+    }
+    // rodrigues_so3_exp(w, A, B)
+    const double wx2 = wx * wx, wy2 = wy * wy, wz2 = wz * wz;
+    double R[3][3];
+    R[0][0] = 1.0 - B * (wy2 + wz2);
+    R[1][1] = 1.0 - B * (wx2 + wz2);
+    R[2][2] = 1.0 - B * (wx2 + wy2);
+    { const double a = A * wz, b = B * (wx * wy); R[0][1] = b - a; R[1][0] = b + a; }
+    { const double a = A * wy, b = B * (wx * wz); R[0][2] = b + a; R[2][0] = b - a; }
+    { const double a = A * wx, b = B * (wy * wz); R[1][2] = b - a; R[2][1] = b + a; }
+    for (int k = 0; k < 16; ++k) M[k] = 0;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) M[j * 4 + i] = R[i][j];
+    M[12] = tx; M[13] = ty; M[14] = tz;
+    M[15] = 1;
+}
+
 // One Gauss-Newton step from (H, g) at pose: returns 0 ok / 1 ill-posed. RPI.h:4682-4697.
 int gn_step(const float* H, const float* g, float lambda, const float* pose, float* pose_tmp, float* update) {
     float M[36];
@@ -1108,6 +1356,133 @@ int alignFrames360(Ctx& ctx, const float* pose_guess, int method, float* pose_ou
     return 0;
 }
 
+// RPI.h:4254-4512 alignFrames (pinhole, Levenberg-Marquardt damping, occlusion 0).
+int alignFrames(Ctx& ctx, const float* pose_guess, int method, float* pose_out, Result* res) {
+    ctx.trace.clear();
+    memset(res, 0, sizeof(*res));
+    float pose_estim[16], pose_estim_temp[16];
+    memcpy(pose_estim, pose_guess, sizeof(pose_estim));
+    memset(ctx.H, 0, sizeof(ctx.H));
+    memset(ctx.g, 0, sizeof(ctx.g));
+    double last_eval = 0, last_eval_photo = 0, last_eval_depth = 0;       // avResidual & co as the members hold them
+    double avResidual_temp = 0, avPhoto_temp = 0, avDepth_temp = 0;
+    bool any_iteration = false;
+    double final_error = 0;
+    auto eval = [&](int level, const float* pose) {
+        const double e = errorPhotoICP(ctx, level, pose, method);
+        last_eval = e;
+        last_eval_photo = sqrt(ctx.last_err2_photo / ctx.last_nvalid_depth);
+        last_eval_depth = sqrt(ctx.last_err2_depth / ctx.last_nvalid_depth);
+        return e;
+    };
+    auto lm_update = [&](float lambda_or_neg, float* update_pose) -> bool {     // lambda < 0: plain -H^-1 g (RPI.h:4355)
+        float M[36];
+        for (int k = 0; k < 36; ++k) M[k] = ctx.H[k];
+        if (lambda_or_neg >= 0)
+            for (int i = 0; i < 6; ++i) M[i * 6 + i] = ctx.H[i * 6 + i] + lambda_or_neg * ctx.H[i * 6 + i];
+        float inv[36];
+        if (!inverse6_partial_piv_lu(M, inv)) return false;
+        for (int r = 0; r < 6; ++r) {
+            float s = 0.f;
+            for (int c = 0; c < 6; ++c) s += (-inv[c * 6 + r]) * ctx.g[c];
+            update_pose[r] = s;
+        }
+        double ud[6], E[16];
+        for (int i = 0; i < 6; ++i) ud[i] = (double)update_pose[i];
+        se3_exp(ud, E);
+        float Ef[16];
+        for (int k = 0; k < 16; ++k) Ef[k] = (float)E[k];
+        mat4_mul_f32(Ef, pose_estim, pose_estim_temp);
+        return true;
+    };
+    for (int level = ctx.p.n_pyr - 1; level >= 0; --level) {
+        buildLUT_pinhole(ctx, level);
+        float lambda = 0.01f;            // double lambda = 0.01, used as float scalar by Eigen
+        const double step = 10;
+        const unsigned LM_maxIters = 1;
+        int it = 0;
+        const int maxIters = 10;
+        const double tol_residual = 1e-4, tol_update = 1e-4;
+        float update_pose[6] = {1, 1, 1, 1, 1, 1};
+        double error = eval(level, pose_estim), new_error;
+        double diff_error = error;
+        {
+            IterTrace t{};
+            t.level = level; t.it = -1; t.accepted = 1; t.error = error; t.new_error = error; t.n_valid = ctx.last_nvalid;
+            memcpy(t.pose, pose_estim, sizeof(t.pose));
+            ctx.trace.push_back(t);
+        }
+        auto unorm = [&]() {
+            float s = 0;
+            for (int i = 0; i < 6; ++i) s += update_pose[i] * update_pose[i];
+            return sqrtf(s);
+        };
+        while (it < maxIters && unorm() > tol_update && diff_error > tol_residual) {
+            any_iteration = true;
+            avResidual_temp = last_eval; avPhoto_temp = last_eval_photo; avDepth_temp = last_eval_depth;
+            calcHessGrad(ctx, level, pose_estim, method);
+            float M[36];
+            for (int k = 0; k < 36; ++k) M[k] = ctx.H[k];
+            for (int i = 0; i < 6; ++i) M[i * 6 + i] = ctx.H[i * 6 + i] + lambda * ctx.H[i * 6 + i];
+            if (rank6_colpiv_qr(M) != 6 || !lm_update(-1.f, update_pose)) {
+                memcpy(pose_out, pose_estim, sizeof(pose_estim));      // relPose = pose_estim; return
+                res->status = 1;
+                for (int k = 0; k < 36; ++k) res->hessian[k] = ctx.H[k];
+                for (int k = 0; k < 6; ++k) res->gradient[k] = ctx.g[k];
+                return 1;
+            }
+            new_error = eval(level, pose_estim_temp);
+            diff_error = error - new_error;
+            IterTrace t{};
+            t.level = level; t.it = it; t.error = error; t.new_error = new_error; t.n_valid = ctx.last_nvalid;
+            memcpy(t.pose, pose_estim_temp, sizeof(t.pose));
+            memcpy(t.update, update_pose, sizeof(t.update));
+            if (diff_error > 0) {
+                lambda /= step;
+                memcpy(pose_estim, pose_estim_temp, sizeof(pose_estim));
+                error = new_error;
+                it = it + 1;
+                t.accepted = 1;
+                ctx.trace.push_back(t);
+            } else {
+                ctx.trace.push_back(t);
+                unsigned LM_it = 0;
+                while (LM_it < LM_maxIters && diff_error < 0) {
+                    lambda = lambda * step;
+                    if (!lm_update(lambda, update_pose)) break;        // singular damped system: Eigen would return inf/NaN
+                    new_error = eval(level, pose_estim_temp);
+                    diff_error = error - new_error;
+                    IterTrace t2{};
+                    t2.level = level; t2.it = it; t2.error = error; t2.new_error = new_error; t2.n_valid = ctx.last_nvalid;
+                    memcpy(t2.pose, pose_estim_temp, sizeof(t2.pose));
+                    memcpy(t2.update, update_pose, sizeof(t2.update));
+                    if (diff_error > 0) {
+                        memcpy(pose_estim, pose_estim_temp, sizeof(pose_estim));
+                        error = new_error;
+                        it = it + 1;
+                        t2.accepted = 1;
+                    } else
+                        LM_it = LM_it + 1;
+                    ctx.trace.push_back(t2);
+                }
+            }
+        }
+        res->iters[level] = it;
+        final_error = error;
+    }
+    memcpy(pose_out, pose_estim, sizeof(pose_estim));
+    // RPI.h:4507-4509: avResidual = avResidual_temp (the value at the top of the last loop trip; the reference leaves it
+    // uninitialised when no trip ran -- defined here as the last evaluated error)
+    res->err_final = any_iteration ? avResidual_temp : last_eval;
+    res->rms_photo = any_iteration ? avPhoto_temp : last_eval_photo;
+    res->rms_depth = any_iteration ? avDepth_temp : last_eval_depth;
+    res->sso = 0.f;
+    for (int k = 0; k < 36; ++k) res->hessian[k] = ctx.H[k];
+    for (int k = 0; k < 6; ++k) res->gradient[k] = ctx.g[k];
+    res->status = (final_error != final_error) ? 2 : 0;       // NaN error (no depth-valid pixel): nothing was optimised
+    return res->status;
+}
+
 void set_frame(Ctx& ctx, bool target, const uint8_t* rgb, size_t rgb_step, const void* depth, size_t d_step,
                int depth_type, int rows, int cols) {
     Image gray;
@@ -1202,6 +1577,57 @@ void oracle_hessgrad_occ(void* h, int level, const float* pose, int method, int 
     if (H36d) memcpy(H36d, c.H64, sizeof(c.H64));
     if (g6d) memcpy(g6d, c.g64, sizeof(c.g64));
     if (n_visible) *n_visible = c.n_visible;
+}
+
+// ---- pinhole single-sensor path ----
+void oracle_set_camera(void* h, float fx, float fy, float ox, float oy) {
+    Ctx& c = *(Ctx*)h;
+    c.cam[0] = fx; c.cam[1] = fy; c.cam[2] = ox; c.cam[3] = oy;
+    c.have_cam = true;
+}
+int oracle_align_pinhole(void* h, const float* guess, int method, float* pose_out, oracle_result* res) {
+    return alignFrames(*(Ctx*)h, guess, method, pose_out, res);
+}
+// sums[4] = {sum photo, sum depth, n photo, n depth}; returns avPhoto + avDepth (both / n depth)
+double oracle_error_pinhole(void* h, int level, const float* pose, int method, double* sums) {
+    Ctx& c = *(Ctx*)h;
+    if (c.lut_level != 1000 + level) buildLUT_pinhole(c, level);
+    const double e = errorPhotoICP(c, level, pose, method);
+    if (sums) { sums[0] = c.last_err2_photo; sums[1] = c.last_err2_depth; sums[2] = (double)c.last_nvalid_photo; sums[3] = (double)c.last_nvalid_depth; }
+    return e;
+}
+void oracle_hessgrad_pinhole(void* h, int level, const float* pose, int method, float* H36, float* g6, double* H36d, double* g6d,
+                             long* n_rows) {
+    Ctx& c = *(Ctx*)h;
+    if (c.lut_level != 1000 + level) buildLUT_pinhole(c, level);
+    calcHessGrad(c, level, pose, method);
+    if (H36) memcpy(H36, c.H, sizeof(c.H));
+    if (g6) memcpy(g6, c.g, sizeof(c.g));
+    if (H36d) memcpy(H36d, c.H64, sizeof(c.H64));
+    if (g6d) memcpy(g6d, c.g64, sizeof(c.g64));
+    if (n_rows) *n_rows = c.n_visible;
+}
+int oracle_get_lut_pinhole(void* h, int level, float* out_xyz) {
+    Ctx& c = *(Ctx*)h;
+    buildLUT_pinhole(c, level);
+    memcpy(out_xyz, c.lut.data(), c.lut.size() * sizeof(float));
+    return (int)(c.lut.size() / 3);
+}
+void oracle_se3_exp(const double* v, double* M) { se3_exp(v, M); }
+// Per-pixel pinhole warp indices of a level: out_rc[2*i] = r', [2*i+1] = c', -1 if skipped.
+void oracle_warp_indices_pinhole(void* h, int level, const float* pose, int* out_rc) {
+    Ctx& c = *(Ctx*)h;
+    if (c.lut_level != 1000 + level) buildLUT_pinhole(c, level);
+    const int nRows = c.graySrc[level].rows, nCols = c.graySrc[level].cols;
+    const PinholeK K = level_intrinsics(c, level);
+    const PoseRT T = split_pose(pose);
+    for (long i = 0; i < (long)nRows * nCols; ++i) {
+        out_rc[2 * i] = out_rc[2 * i + 1] = -1;
+        const float* p = &c.lut[3 * i];
+        if (p[0] == kInvalidPoint) continue;
+        const WarpPin w = warp_pinhole(T, p, nRows, nCols, K, c.p.math_mode);
+        if (w.visible) { out_rc[2 * i] = w.r; out_rc[2 * i + 1] = w.c; }
+    }
 }
 
 int oracle_trace_len(void* h) { return (int)((Ctx*)h)->trace.size(); }

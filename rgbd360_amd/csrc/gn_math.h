@@ -201,6 +201,45 @@ GN_HD inline void se3_pseudo_exp(const double* v, double* E) {
     E[15] = 1;
 }
 
+// THIRD-PARTY (MRPT 1.x CPose3D::exp(v, pseudo_exponential = false), RPI.h:4358, 4391): full SE(3) exponential,
+// t = u + B (w x u) + C (w x (w x u)), small-angle series below theta^2 < 1e-8 / 1e-6.  Column-major 4x4 out.
+GN_HD inline void se3_exp(const double* v, double* E) {
+    const double ux = v[0], uy = v[1], uz = v[2], wx = v[3], wy = v[4], wz = v[5];
+    const double theta_sq = wx * wx + wy * wy + wz * wz;
+    const double theta = sqrt(theta_sq);
+    const double cx = wy * uz - wz * uy, cy = wz * ux - wx * uz, cz = wx * uy - wy * ux;
+    double A, B, tx, ty, tz;
+    if (theta_sq < 1e-8) {
+        A = 1.0 - theta_sq / 6.0;
+        B = 0.5;
+        tx = ux + 0.5 * cx; ty = uy + 0.5 * cy; tz = uz + 0.5 * cz;
+    } else {
+        double C;
+        if (theta_sq < 1e-6) {
+            C = (1.0 / 6.0) * (1.0 - theta_sq / 20.0);
+            A = 1.0 - theta_sq * C;
+            B = 0.5 - 0.25 * (1.0 / 6.0) * theta_sq;
+        } else {
+            const double inv_theta = 1.0 / theta;
+            A = sin(theta) * inv_theta;
+            B = (1 - cos(theta)) * (inv_theta * inv_theta);
+            C = (1 - A) * (inv_theta * inv_theta);
+        }
+        const double dx = wy * cz - wz * cy, dy = wz * cx - wx * cz, dz = wx * cy - wy * cx;
+        tx = ux + B * cx + C * dx; ty = uy + B * cy + C * dy; tz = uz + B * cz + C * dz;
+    }
+    const double wx2 = wx * wx, wy2 = wy * wy, wz2 = wz * wz;
+    for (int k = 0; k < 16; ++k) E[k] = 0.0;
+    E[0] = 1.0 - B * (wy2 + wz2);
+    E[5] = 1.0 - B * (wx2 + wz2);
+    E[10] = 1.0 - B * (wx2 + wy2);
+    { const double a = A * wz, b = B * (wx * wy); E[4] = b - a; E[1] = b + a; }      // R(0,1), R(1,0)
+    { const double a = A * wy, b = B * (wx * wz); E[8] = b + a; E[2] = b - a; }      // R(0,2), R(2,0)
+    { const double a = A * wx, b = B * (wy * wz); E[9] = b - a; E[6] = b + a; }      // R(1,2), R(2,1)
+    E[12] = tx; E[13] = ty; E[14] = tz;
+    E[15] = 1.0;
+}
+
 GN_HD inline void mat4_mul(const float* A, const float* B, float* C) {
     for (int c = 0; c < 4; ++c)
         for (int r = 0; r < 4; ++r)

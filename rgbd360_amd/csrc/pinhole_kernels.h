@@ -1,0 +1,174 @@
+// Pinhole single-sensor alignment: RegisterPhotoICP::alignFrames RPI.h:4254-4512 with
+// errorPhotoICP RPI.h:560-748 and calcHessGrad RPI.h:754-1104 (occlusion 0, bUseSalientPixels false).
+//
+// The sensor images are small (320x240 per Asus sensor of the rig), so these passes are launch- and latency-bound, not
+// bandwidth-bound; the kernels are the plain form of k_eval (no software pipelining), one fused pass producing
+//   * the error sums of errorPhotoICP (every visible pixel, NO saliency test; both averages / nValidDepthPts), and
+//   * the normal equations of calcHessGrad (saliency-gated rows; a flat depth gradient drops the photometric row too)
+// at one pose, in k_eval's partial-row layout so that k_solve's reduction mode is shared.  The Levenberg-Marquardt
+// driver runs on the host (one state read-back per evaluation).
+#pragma once
+#include "photo_icp_kernels.h"
+
+namespace r360 {
+
+struct PinK {
+    float fx, fy, ox, oy;     // intrinsics of the pyramid level (RPI.h:571-575)
+};
+
+// RPI.h:4277-4300: source record {x, y, z, Isrc}; x = -10000 marks a depth outside (min_depth, max_depth)
+__global__ void k_src_rec_pinhole(const float* __restrict__ depth, const float* __restrict__ gray, int rows, int cols, PinK K,
+                                  float inv_fx, float inv_fy, float min_depth, float max_depth, float4* __restrict__ rec) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    if (c >= cols || r >= rows) return;
+    const size_t i = (size_t)r * cols + c;
+    const float z = depth[i];
+    float4 o;
+    o.z = z;
+    o.w = gray[i];
+    if (min_depth < z && z < max_depth) {
+        o.x = ((float)c - K.ox) * z * inv_fx;
+        o.y = ((float)r - K.oy) * z * inv_fy;
+    } else {
+        o.x = kInvalidPoint;
+        o.y = 0.f;
+    }
+    rec[i] = o;
+}
+
+// Device arithmetic definition of the pinhole warp (the oracle's math_mode 1 repeats it): fma rotation, correctly rounded
+// 1/Z, column = round(fma(X fx, 1/Z, ox)), row = round(fma(Y fy, 1/Z, oy)), round = floor(x + 0.5).
+__device__ __forceinline__ unsigned warp_pinhole(const PoseRT& T, float px, float py, float pz, const PinK& K, int rows, int cols,
+                                                 float& X, float& Y, float& Z, float& inv_z, bool& vis) {
+    X = fmaf(T.r02, pz, fmaf(T.r01, py, fmaf(T.r00, px, T.tx)));
+    Y = fmaf(T.r12, pz, fmaf(T.r11, py, fmaf(T.r10, px, T.ty)));
+    Z = fmaf(T.r22, pz, fmaf(T.r21, py, fmaf(T.r20, px, T.tz)));
+    inv_z = rcp_rn(Z);
+    const float tc = fmaf(X * K.fx, inv_z, K.ox);
+    const float tr = fmaf(Y * K.fy, inv_z, K.oy);
+    const bool sane = (fabsf(tr) < 1e9f) && (fabsf(tc) < 1e9f);
+    const int ri = round_index(sane ? tr : -1.f), ci = round_index(sane ? tc : -1.f);
+    vis = sane && ((unsigned)ri < (unsigned)rows) && ((unsigned)ci < (unsigned)cols);
+    return (unsigned)(ri * cols + ci);
+}
+
+template <int METHOD>
+__global__ __launch_bounds__(kEvalThreads) void k_eval_pinhole(LevelDev lv, PinK K, EvalConsts ec, const GNState* __restrict__ st,
+                                                                double* __restrict__ partials, int chunk, int level) {
+    const int b = blockIdx.x;
+    const int base = b * chunk;
+    const int end = min(base + chunk, lv.n);
+    if (st->done || st->level_active != level) return;
+    const PoseRT T = load_pose(st->cand);
+
+    EvalAcc A;
+#pragma unroll
+    for (int k = 0; k < 27; ++k) A.acc[k] = 0.f;
+    A.e2p = A.e2d = 0.f;
+    A.nP = A.nD = A.nVis = 0;
+
+    const int n_steps = (end - base + kEvalThreads - 1) / kEvalThreads;      // wave-uniform: the ballots count whole waves
+    for (int k = 0; k < n_steps; ++k) {
+        const int i = base + k * kEvalThreads + (int)threadIdx.x;
+        const bool in_range = i < end;
+        const float4 s = lv.src[in_range ? i : lv.n - 1];
+        float X, Y, Z, iz;
+        bool vis;
+        unsigned ti = warp_pinhole(T, s.x, s.y, s.z, K, lv.rows, lv.cols, X, Y, Z, iz, vis);
+        vis = vis && in_range && (s.x != kInvalidPoint);
+        ti = vis ? ti : 0u;
+        F3 tp = {0.f, 0.f, 0.f}, td = {0.f, 0.f, 0.f};
+        if (METHOD != 1) tp = lv.trgP[ti];
+        if (METHOD != 0) td = lv.trgD[ti];
+        const float depth2 = td.a;
+        const bool sal_p = !(fabsf(tp.b) < ec.thr_photo && fabsf(tp.c) < ec.thr_photo);
+        const bool sal_d = !(fabsf(td.b) < ec.thr_depth && fabsf(td.c) < ec.thr_depth);
+        const float iz2 = iz * iz;
+
+        if (METHOD != 1) {
+            A.nP += ballot_count(vis);                                            // errorPhotoICP: no saliency test (RPI.h:712-721)
+            const bool row_on = vis && sal_p && (METHOD == 0 || sal_d);           // calcHessGrad: RPI.h:906-907, 929-930
+            A.nVis += ballot_count(row_on);
+            if (vis) {
+#pragma clang fp contract(fast)
+                const float photoDiff = tp.a - s.w;
+                const float wpf = weight_huber_fast(photoDiff, ec.sigma_photo) * ec.sigma_photo_inv_f;
+                const float res = wpf * photoDiff;
+                A.e2p += res * res;
+                if (row_on) {
+                    const float wgx = wpf * tp.b * K.fx, wgy = wpf * tp.c * K.fy;
+                    accumulate_row(A, wgx * iz, wgy * iz, -(wgx * X + wgy * Y) * iz2, X, Y, Z, res);
+                }
+            }
+        }
+        if (METHOD != 0) {
+            const bool err_on = vis && isfinite(depth2);                          // RPI.h:722-735
+            A.nD += ballot_count(err_on);
+            const bool row_on = err_on && sal_d && (METHOD == 1 || sal_p);
+            A.nVis += ballot_count(row_on);
+            if (err_on) {
+#pragma clang fp contract(fast)
+                const float depthDiff = depth2 - Z;
+                const float sd = ec.sigma_depth * Z;
+                const float wd = weight_huber_fast(depthDiff, sd) * fast_rcp(sd);
+                const float res = wd * depthDiff;
+                A.e2d += res * res;
+                if (row_on) {
+                    const float gx = td.b * K.fx, gy = td.c * K.fy;
+                    accumulate_row(A, wd * (gx * iz), wd * (gy * iz), wd * (-(gx * X + gy * Y) * iz2 - 1.f), X, Y, Z, res);
+                }
+            }
+        }
+    }
+
+    __shared__ double red[kEvalThreads / 64][kNumPartials];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    {
+        float v[32], out[2];
+#pragma unroll
+        for (int k = 0; k < 27; ++k) v[k] = A.acc[k];
+        v[P_E2P] = A.e2p;
+        v[P_E2D] = A.e2d;
+        v[P_NP] = v[P_ND] = v[P_NVIS] = 0.f;
+        wave_reduce32(v, out);
+        if ((lane & 3) == 0) {
+            const int row = lane >> 4, quad = (lane >> 2) & 3;
+            const int idx = 2 * (quad & 1) + 4 * (quad >> 1) + 8 * (row & 1) + 16 * (row >> 1);
+            if (idx + 0 < P_NP) red[wave][idx + 0] = (double)out[0];
+            if (idx + 1 < P_NP) red[wave][idx + 1] = (double)out[1];
+        }
+        if (lane == 63) {
+            red[wave][P_NP] = (double)A.nP;
+            red[wave][P_ND] = (double)A.nD;
+            red[wave][P_NVIS] = (double)A.nVis;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < kNumPartials) {
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < kEvalThreads / 64; ++w) v += red[w][threadIdx.x];
+        partials[(size_t)b * kNumPartials + threadIdx.x] = v;
+    }
+}
+
+__global__ void k_warp_indices_pinhole(LevelDev lv, PinK K, Pose16 pose, int32_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= lv.n) return;
+    const PoseRT T = load_pose(pose.v);
+    const float4 s = lv.src[i];
+    int r = -1, c = -1;
+    if (s.x != kInvalidPoint) {
+        float X, Y, Z, iz;
+        bool vis;
+        const unsigned ti = warp_pinhole(T, s.x, s.y, s.z, K, lv.rows, lv.cols, X, Y, Z, iz, vis);
+        if (vis) {
+            r = (int)(ti / (unsigned)lv.cols);
+            c = (int)ti - r * lv.cols;
+        }
+    }
+    out[2 * i] = r;
+    out[2 * i + 1] = c;
+}
+
+}  // namespace r360

@@ -18,6 +18,7 @@
 #include "../../include/rgbd360_hip.h"
 #include "photo_icp_kernels.h"
 #include "occlusion_kernels.h"
+#include "pinhole_kernels.h"
 #include "frame360_kernels.h"
 
 using namespace r360;
@@ -29,6 +30,7 @@ struct Level {
     float half_nRows = 0.f, angle_res_inv = 0.f;
     float *graySrc = nullptr, *depthSrc = nullptr, *grayTrg = nullptr, *depthTrg = nullptr;
     float4* srcRec = nullptr;
+    float4* srcRecPin = nullptr;     // pinhole LUT record of the source (built per alignment, RPI.h:4277-4300)
     F3 *trgP = nullptr, *trgD = nullptr;
     float *sinT = nullptr, *cosT = nullptr, *sinP = nullptr, *cosP = nullptr;
     int nblocks = 0, chunk = 0;
@@ -68,6 +70,8 @@ struct rgbd360_ctx {
     bool al_active = false;
     std::vector<rgbd360_ctx*> siblings;                // extra contexts of rgbd360_align360_batch (owned)
     int al_occ = 0;
+    float cam[4] = {0.f, 0.f, 0.f, 0.f};               // cameraMatrix(0,0), (1,1), (0,2), (1,2)   RPI.h:89, 254-257
+    bool have_cam = false;
     int *occ_head = nullptr, *occ_next = nullptr;      // occlusion modes: per-target candidate lists
     float* occ_dinv = nullptr;
     size_t occ_n = 0;
@@ -94,7 +98,7 @@ int fail(rgbd360_ctx* ctx, int code, const char* msg) {
 void free_levels(rgbd360_ctx* ctx) {
     for (Level& L : ctx->levels) {
         hipFree(L.graySrc); hipFree(L.depthSrc); hipFree(L.grayTrg); hipFree(L.depthTrg);
-        hipFree(L.srcRec); hipFree(L.trgP); hipFree(L.trgD);
+        hipFree(L.srcRec); hipFree(L.srcRecPin); hipFree(L.trgP); hipFree(L.trgD);
         hipFree(L.sinT); hipFree(L.cosT); hipFree(L.sinP); hipFree(L.cosP);
     }
     ctx->levels.clear();
@@ -838,6 +842,250 @@ int rgbd360_selftest_math(rgbd360_ctx* ctx, uint32_t first_bits, uint32_t count,
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------
+// Pinhole single-sensor alignment: RegisterPhotoICP::alignFrames, RPI.h:4254-4512.
+// Per-pixel passes on the device (pinhole_kernels.h), Levenberg-Marquardt driver on the host.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+PinK pin_level_K(const rgbd360_ctx* ctx, int level) {         // RPI.h:571-575
+    const float scaleFactor = 1.0 / pow(2, level);
+    return {ctx->cam[0] * scaleFactor, ctx->cam[1] * scaleFactor, ctx->cam[2] * scaleFactor, ctx->cam[3] * scaleFactor};
+}
+
+int pin_check(rgbd360_ctx* ctx, int level, int method) {
+    int rc = check_args(ctx, level, method);
+    if (rc) return rc;
+    if (!ctx->have_cam) return fail(ctx, -2, "rgbd360_set_camera was not called");
+    if (ctx->p.mask_seams) return fail(ctx, -5, "pinhole alignment needs params.mask_seams = 0 (the seam mask belongs to the spherical panorama)");
+    return 0;
+}
+
+int pin_prepare_level(rgbd360_ctx* ctx, int level) {
+    Level& L = ctx->levels[level];
+    if (!L.srcRecPin) HIPC(ctx, hipMalloc(&L.srcRecPin, (size_t)L.n * sizeof(float4)));
+    const PinK K = pin_level_K(ctx, level);
+    const float inv_fx = 1. / K.fx, inv_fy = 1. / K.fy;
+    hipLaunchKernelGGL(k_src_rec_pinhole, grid2d(L.rows, L.cols), dim3(256), 0, ctx->stream, L.depthSrc, L.graySrc, L.rows, L.cols, K,
+                       inv_fx, inv_fy, ctx->p.min_depth, ctx->p.max_depth, L.srcRecPin);
+    HIPC(ctx, hipGetLastError());
+    return 0;
+}
+
+LevelDev pin_level_dev(const Level& L) {
+    LevelDev d = level_dev(L);
+    d.src = L.srcRecPin;
+    return d;
+}
+
+// one fused pass at `pose`; the reduced sums land in ctx->h_state->tot
+int pin_eval(rgbd360_ctx* ctx, int level, const float* pose, int method) {
+    const Level& L = ctx->levels[level];
+    const LevelDev lv = pin_level_dev(L);
+    const PinK K = pin_level_K(ctx, level);
+    const EvalConsts ec = eval_consts(ctx->p);
+    launch_level_init(ctx, level, pose, 1);
+    const dim3 g(L.nblocks), b(kEvalThreads);
+    if (method == 0) hipLaunchKernelGGL((k_eval_pinhole<0>), g, b, 0, ctx->stream, lv, K, ec, ctx->d_state, ctx->d_partials, L.chunk, level);
+    else if (method == 1) hipLaunchKernelGGL((k_eval_pinhole<1>), g, b, 0, ctx->stream, lv, K, ec, ctx->d_state, ctx->d_partials, L.chunk, level);
+    else hipLaunchKernelGGL((k_eval_pinhole<2>), g, b, 0, ctx->stream, lv, K, ec, ctx->d_state, ctx->d_partials, L.chunk, level);
+    launch_solve(ctx, level, 1, 0);
+    HIPC(ctx, hipGetLastError());
+    return read_state(ctx);
+}
+
+struct PinSums {
+    double e2p, e2d, np, nd, rows;
+    float H[36], g[6];
+    double error() const { return sqrt(e2p / nd) + sqrt(e2d / nd); }     // RPI.h:742-744: both averages / nValidDepthPts
+};
+PinSums pin_sums(const GNState& S) {
+    PinSums o;
+    o.e2p = S.tot[P_E2P]; o.e2d = S.tot[P_E2D]; o.np = S.tot[P_NP]; o.nd = S.tot[P_ND]; o.rows = S.tot[P_NVIS];
+    int k = 0;
+    for (int a = 0; a < 6; ++a)
+        for (int b = a; b < 6; ++b, ++k) o.H[b * 6 + a] = o.H[a * 6 + b] = (float)S.tot[P_H + k];
+    for (int a = 0; a < 6; ++a) o.g[a] = (float)S.tot[P_G + a];
+    return o;
+}
+
+// update = -(H [+ lambda diag H])^-1 g ; pose_tmp = exp(update) * pose   (RPI.h:4355-4358, 4389-4391)
+bool pin_lm_update(const float* H, const float* g, float lambda_or_neg, const float* pose, float* pose_tmp, float* update) {
+    float M[36], inv[36];
+    for (int k = 0; k < 36; ++k) M[k] = H[k];
+    if (lambda_or_neg >= 0.f)
+        for (int i = 0; i < 6; ++i) M[i * 6 + i] = H[i * 6 + i] + lambda_or_neg * H[i * 6 + i];
+    if (!gn::inverse6(M, inv)) return false;
+    for (int r = 0; r < 6; ++r) {
+        float s = 0.f;
+        for (int c = 0; c < 6; ++c) s += (-inv[c * 6 + r]) * g[c];
+        update[r] = s;
+    }
+    double ud[6], E[16];
+    for (int i = 0; i < 6; ++i) ud[i] = (double)update[i];
+    gn::se3_exp(ud, E);
+    float Ef[16];
+    for (int k = 0; k < 16; ++k) Ef[k] = (float)E[k];
+    gn::mat4_mul(Ef, pose, pose_tmp);
+    return true;
+}
+}  // namespace
+
+extern "C" int rgbd360_set_camera(rgbd360_ctx* ctx, float fx, float fy, float ox, float oy) {
+    if (!ctx) return -1;
+    if (!(fx > 0.f) || !(fy > 0.f)) return fail(ctx, -1, "focal lengths must be positive");
+    ctx->cam[0] = fx; ctx->cam[1] = fy; ctx->cam[2] = ox; ctx->cam[3] = oy;
+    ctx->have_cam = true;
+    return 0;
+}
+
+extern "C" int rgbd360_eval_pinhole(rgbd360_ctx* ctx, int level, const float pose[16], int method, double err2_split[2],
+                                    long long n_split[2], float H[36], float g[6], double H64[36], double g64[6], long long* n_rows) {
+    int rc = pin_check(ctx, level, method);
+    if (rc) return rc;
+    if (!pose) return fail(ctx, -1, "null pose pointer");
+    hipSetDevice(ctx->p.device);
+    if ((rc = pin_prepare_level(ctx, level)) != 0) return rc;
+    if ((rc = pin_eval(ctx, level, pose, method)) != 0) return rc;
+    const GNState& S = *ctx->h_state;
+    const PinSums P = pin_sums(S);
+    if (err2_split) { err2_split[0] = P.e2p; err2_split[1] = P.e2d; }
+    if (n_split) { n_split[0] = (long long)P.np; n_split[1] = (long long)P.nd; }
+    if (H) memcpy(H, P.H, sizeof(P.H));
+    if (g) memcpy(g, P.g, sizeof(P.g));
+    if (H64 || g64) {
+        int k = 0;
+        for (int a = 0; a < 6; ++a)
+            for (int b = a; b < 6; ++b, ++k)
+                if (H64) H64[b * 6 + a] = H64[a * 6 + b] = S.tot[P_H + k];
+        if (g64)
+            for (int a = 0; a < 6; ++a) g64[a] = S.tot[P_G + a];
+    }
+    if (n_rows) *n_rows = (long long)P.rows;
+    return 0;
+}
+
+extern "C" int rgbd360_warp_indices_pinhole(rgbd360_ctx* ctx, int level, const float pose[16], int32_t* host_out_rc) {
+    int rc = pin_check(ctx, level, 0);
+    if (rc) return rc;
+    if (!pose || !host_out_rc) return fail(ctx, -1, "null pointer");
+    hipSetDevice(ctx->p.device);
+    if ((rc = pin_prepare_level(ctx, level)) != 0) return rc;
+    const Level& L = ctx->levels[level];
+    int32_t* d_out = nullptr;
+    HIPC(ctx, hipMalloc(&d_out, (size_t)L.n * 2 * sizeof(int32_t)));
+    Pose16 P;
+    memcpy(P.v, pose, sizeof(P.v));
+    hipLaunchKernelGGL(k_warp_indices_pinhole, dim3((L.n + 255) / 256), dim3(256), 0, ctx->stream, pin_level_dev(L), pin_level_K(ctx, level),
+                       P, d_out);
+    hipError_t e = hipMemcpyAsync(host_out_rc, d_out, (size_t)L.n * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipFree(d_out);
+    HIPC(ctx, e);
+    return 0;
+}
+
+extern "C" int rgbd360_align_pinhole(rgbd360_ctx* ctx, const float guess[16], int method, int occlusion, float pose_out[16],
+                                     rgbd360_result* res) {
+    int rc = pin_check(ctx, 0, method);
+    if (rc) return rc;
+    if (!guess || !pose_out) return fail(ctx, -1, "null pose pointer");
+    if (occlusion != 0) return fail(ctx, -5, "the pinhole path implements occlusion 0 only");
+    hipSetDevice(ctx->p.device);
+    rgbd360_result R;
+    memset(&R, 0, sizeof(R));
+    float pose_estim[16], pose_estim_temp[16];
+    memcpy(pose_estim, guess, sizeof(pose_estim));
+    float H[36] = {0}, g[6] = {0};
+    double last_eval = 0, last_photo = 0, last_depth = 0, temp_eval = 0, temp_photo = 0, temp_depth = 0, final_error = 0;
+    bool any_iteration = false;
+    int status = 0;
+    PinSums P;
+    auto eval = [&](int level, const float* pose, double& out) -> int {
+        const int e = pin_eval(ctx, level, pose, method);
+        if (e) return e;
+        P = pin_sums(*ctx->h_state);
+        out = P.error();
+        last_eval = out;
+        last_photo = sqrt(P.e2p / P.nd);
+        last_depth = sqrt(P.e2d / P.nd);
+        return 0;
+    };
+    for (int level = ctx->p.n_pyr - 1; level >= 0 && status == 0; --level) {
+        if ((rc = pin_prepare_level(ctx, level)) != 0) return rc;
+        float lambda = 0.01f;                 // RPI.h:4303 (double 0.01 used as a float scalar by Eigen)
+        const double step = 10;
+        const unsigned LM_maxIters = 1;
+        int it = 0;
+        const int maxIters = 10;              // RPI.h:4306-4308: the pinhole driver hard-codes its own limits
+        const double tol_residual = 1e-4, tol_update = 1e-4;
+        float update_pose[6] = {1, 1, 1, 1, 1, 1};
+        double error = 0, new_error = 0;
+        if ((rc = eval(level, pose_estim, error)) != 0) return rc;
+        double diff_error = error;
+        // the first pass doubles as the H,g pass of the first trip (same pose)
+        PinSums at_pose = P;
+        auto unorm = [&]() {
+            float s2 = 0;
+            for (int i = 0; i < 6; ++i) s2 += update_pose[i] * update_pose[i];
+            return sqrtf(s2);
+        };
+        while (it < maxIters && unorm() > tol_update && diff_error > tol_residual) {
+            any_iteration = true;
+            temp_eval = last_eval; temp_photo = last_photo; temp_depth = last_depth;
+            memcpy(H, at_pose.H, sizeof(H));          // calcHessGrad(pose_estim): the fused pass at pose_estim
+            memcpy(g, at_pose.g, sizeof(g));
+            float M[36];
+            for (int k = 0; k < 36; ++k) M[k] = H[k];
+            for (int i = 0; i < 6; ++i) M[i * 6 + i] = H[i * 6 + i] + lambda * H[i * 6 + i];
+            if (gn::rank6(M) != 6 || !pin_lm_update(H, g, -1.f, pose_estim, pose_estim_temp, update_pose)) {
+                status = 1;                            // "The problem is ILL-POSED": relPose = pose_estim, return   RPI.h:4346-4353
+                break;
+            }
+            PinSums cand;
+            if ((rc = eval(level, pose_estim_temp, new_error)) != 0) return rc;
+            cand = P;
+            diff_error = error - new_error;
+            if (diff_error > 0) {
+                lambda /= step;
+                memcpy(pose_estim, pose_estim_temp, sizeof(pose_estim));
+                error = new_error;
+                it = it + 1;
+                at_pose = cand;
+            } else {
+                unsigned LM_it = 0;
+                while (LM_it < LM_maxIters && diff_error < 0) {
+                    lambda = lambda * step;
+                    if (!pin_lm_update(H, g, lambda, pose_estim, pose_estim_temp, update_pose)) break;
+                    if ((rc = eval(level, pose_estim_temp, new_error)) != 0) return rc;
+                    cand = P;
+                    diff_error = error - new_error;
+                    if (diff_error > 0) {
+                        memcpy(pose_estim, pose_estim_temp, sizeof(pose_estim));
+                        error = new_error;
+                        it = it + 1;
+                        at_pose = cand;
+                    } else
+                        LM_it = LM_it + 1;
+                }
+            }
+        }
+        if (status == 1) break;
+        R.iters[level & 7] = it;
+        final_error = error;
+    }
+    memcpy(pose_out, pose_estim, sizeof(pose_estim));
+    if (status == 0 && final_error != final_error) status = 2;      // NaN: no depth-valid pixel (or PHOTO only: x / nValidDepthPts)
+    R.status = status;
+    R.err_final = any_iteration ? temp_eval : last_eval;             // avResidual = avResidual_temp   RPI.h:4507-4509
+    R.rms_photo = any_iteration ? temp_photo : last_photo;
+    R.rms_depth = any_iteration ? temp_depth : last_depth;
+    if (status == 1) R.err_final = 0.0;
+    memcpy(R.hessian, H, sizeof(H));
+    memcpy(R.gradient, g, sizeof(g));
+    if (res) *res = R;
+    return status;
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // Frame360 stages: normal map (row a14) and planar regions + inlier moments (row a15)

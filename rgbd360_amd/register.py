@@ -107,6 +107,8 @@ class RegisterPhotoICP:
             if rc != 0:
                 raise Rgbd360Error(f"rgbd360_create failed ({rc}): no usable HIP device; there is no CPU fallback")
             self._h = h
+            if getattr(self, "_cam", None) is not None:          # the camera matrix survives the setters that recreate the context
+                self._check(self._L.rgbd360_set_camera(self._h, *self._cam))
         return self._h
 
     def close(self):
@@ -187,6 +189,50 @@ class RegisterPhotoICP:
         self.avDepthResidual = float(r.rms_depth)
         self.num_iterations = [int(r.iters[l]) for l in range(self._p.n_pyr)]
         return rc
+
+    # ---- pinhole single-sensor path (RPI.h:254-257, 4254-4512)
+    def setCameraMatrix(self, camMat):
+        """3x3 intrinsic matrix (or (fx, fy, ox, oy)) of the full-resolution sensor image."""
+        K = np.asarray(camMat, np.float64)
+        fx, fy, ox, oy = (K[0, 0], K[1, 1], K[0, 2], K[1, 2]) if K.shape == (3, 3) else K.reshape(4)
+        self._cam = (float(fx), float(fy), float(ox), float(oy))
+        if self._h is not None:
+            self._check(self._L.rgbd360_set_camera(self._h, *self._cam))
+
+    def alignFrames(self, pose_guess=None, method: int = 0, occlusion: int = 0):
+        g = pose_to_cm(np.eye(4) if pose_guess is None else pose_guess)
+        out = np.zeros(16, dtype=np.float32)
+        rc = self._L.rgbd360_align_pinhole(self._ctx(), _ptr(g), int(method), int(occlusion), _ptr(out), C.byref(self._res))
+        self._check(rc, allow=(0, 1, 2))
+        self.status = rc
+        self._pose = pose_from_cm(out)
+        r = self._res
+        self.SSO = 0.0
+        self.avResidual = float(r.err_final)
+        self.avPhotoResidual = float(r.rms_photo)
+        self.avDepthResidual = float(r.rms_depth)
+        self.num_iterations = [int(r.iters[l]) for l in range(self._p.n_pyr)]
+        return rc
+
+    def eval_pinhole(self, level: int, pose, method: int):
+        p = pose_to_cm(pose)
+        nrows = C.c_longlong()
+        e2s = np.zeros(2, np.float64)
+        ns = np.zeros(2, np.int64)
+        H = np.zeros(36, np.float32)
+        g = np.zeros(6, np.float32)
+        Hd = np.zeros(36, np.float64)
+        gd = np.zeros(6, np.float64)
+        self._check(self._L.rgbd360_eval_pinhole(self._ctx(), level, _ptr(p), method, _ptr(e2s), _ptr(ns), _ptr(H), _ptr(g),
+                                                 _ptr(Hd), _ptr(gd), C.byref(nrows)))
+        return dict(err2_split=e2s, n_split=ns, H=H.reshape(6, 6).T.copy(), g=g, H64=Hd.reshape(6, 6).T.copy(), g64=gd,
+                    n_rows=nrows.value)
+
+    def warp_indices_pinhole(self, level: int, pose) -> np.ndarray:
+        r, c = self.level_dims(level)
+        out = np.empty((r * c, 2), dtype=np.int32)
+        self._check(self._L.rgbd360_warp_indices_pinhole(self._ctx(), level, _ptr(pose_to_cm(pose)), _ptr(out)))
+        return out
 
     def alignSequence(self, frames, method: int = 0, occlusion: int = 0, pose_guess=None, n_inflight: int = 2):
         """rgbd360_align360_batch: the len(frames)-1 consecutive pairs of a sequence (frame j = target, j+1 = source) on this

@@ -66,15 +66,33 @@ def render(T_wc: np.ndarray, width: int, height: int | None = None, seed: int = 
     return rgb, depth
 
 
-def _render_rows(T_wc, W, H, r0, r1, params, depth_f32, rgb_out, depth_out):
+def _render_rows(T_wc, W, H, r0, r1, params, depth_f32, rgb_out, depth_out, pinhole=None):
     alpha, phase, freq, lattice, chroma = params
     n = r1 - r0
+    if pinhole is not None:
+        _shade(T_wc, _pinhole_rays(W, r0, r1, pinhole), n, W, params, depth_f32, rgb_out, depth_out)
+        return
     res = 2 * math.pi / W
     phi = (H / 2 - 0.5 - np.arange(r0, r1, dtype=np.float64)) * res
     theta = np.arange(W, dtype=np.float64) * res
     sp, cp = np.sin(phi)[:, None], np.cos(phi)[:, None]
     st, ct = np.sin(theta)[None, :], np.cos(theta)[None, :]
     ray_c = np.stack([np.broadcast_to(sp, (n, W)), -cp * st, -cp * ct], axis=-1)  # n x W x 3
+    _shade(T_wc, ray_c, n, W, params, depth_f32, rgb_out, depth_out)
+
+
+def _pinhole_rays(W, r0, r1, K):
+    """Camera-frame rays of a pinhole sensor (x right, y down, z forward), NOT normalised: z = 1, so the ray parameter of
+    a hit is the z-depth the sensor stores (Frame360 sensor images, RegisterPhotoICP.h:4277-4300)."""
+    fx, fy, ox, oy = K
+    cc = (np.arange(W, dtype=np.float64) - ox) / fx
+    rr = (np.arange(r0, r1, dtype=np.float64) - oy) / fy
+    n = r1 - r0
+    return np.stack([np.broadcast_to(cc[None, :], (n, W)), np.broadcast_to(rr[:, None], (n, W)), np.ones((n, W))], axis=-1)
+
+
+def _shade(T_wc, ray_c, n, W, params, depth_f32, rgb_out, depth_out):
+    alpha, phase, freq, lattice, chroma = params
     R, o = T_wc[:3, :3], T_wc[:3, 3]
     ray_w = ray_c @ R.T
     with np.errstate(divide="ignore", invalid="ignore"):
@@ -197,3 +215,37 @@ def occlusion_test_poses(T_gt):
     out.append(make_pose(rodrigues(rng.normal(size=3), 0.03), np.array([0.0, 0.25, 0.1])))    # large sideways step
     out.append(make_pose(np.eye(3), np.array([0.0, 0.0, -0.4])))                                # moving away: compression
     return out
+
+
+# ---- pinhole single-sensor frames (RegisterPhotoICP::alignFrames) ----------------------------------
+def pinhole_intrinsics(width: int, height: int):
+    """The rig's sensor model as RegisterRGBD360.h:357-365 builds it: f = 525 * width / 640, principal point at the centre."""
+    f = 525.0 * width / 640.0
+    return (f, f, width / 2 - 0.5, height / 2 - 0.5)
+
+
+def render_pinhole(T_wc: np.ndarray, width: int, height: int, seed: int = 1234, depth_f32: bool = False, K=None, strip: int = 32):
+    """The room through a pinhole sensor at camera-to-world pose T_wc: (rgb uint8 HxWx3, z-depth uint16 mm | float32 m)."""
+    K = pinhole_intrinsics(width, height) if K is None else K
+    params = _wall_params(seed)
+    rgb = np.empty((height, width, 3), dtype=np.uint8)
+    depth = np.empty((height, width), dtype=np.float32 if depth_f32 else np.uint16)
+    for r0 in range(0, height, strip):
+        r1 = min(height, r0 + strip)
+        _render_rows(T_wc, width, height, r0, r1, params, depth_f32, rgb[r0:r1], depth[r0:r1], pinhole=K)
+    return rgb, depth
+
+
+def make_pinhole_pair(width: int = 320, height: int = 240, seed: int = 1234, trans: float = 0.03, rot_deg: float = 1.0,
+                      depth_f32: bool = False):
+    """Target sensor frame A, source frame B, ground-truth relPose (p_trg = R p_src + t) and the intrinsics."""
+    # the sensor looks towards a vertical corner of the room (two walls + floor/ceiling bands in view: well conditioned);
+    # image "down" = room -x (x is up)
+    R0 = np.array([[0.0, -1.0, 0.0], [-1.0, 0.0, 0.0], [0.0, 0.0, -1.0]])      # columns: camera x, y, z axes in the world
+    T_wA = make_pose(R0 @ rodrigues(np.array([0.0, 1.0, 0.0]), 0.75), CAM_A + np.array([0.0, -1.0, -1.5]))
+    M = default_motion(seed, trans, rot_deg)
+    T_wB = T_wA @ M
+    K = pinhole_intrinsics(width, height)
+    rgbA, dA = render_pinhole(T_wA, width, height, seed, depth_f32, K)
+    rgbB, dB = render_pinhole(T_wB, width, height, seed, depth_f32, K)
+    return (rgbA, dA), (rgbB, dB), np.linalg.inv(T_wA) @ T_wB, K

@@ -83,6 +83,26 @@ def main():
             rec["at_probe_level1"] = {"error": e[0], "sum_photo": e[1], "sum_depth": e[2], "n_photo": e[3], "n_depth": e[4],
                                       "n_visible": nvis, "H64": Hd.tolist(), "g64": gd.tolist()}
             out["occlusion"]["math%d/occ%d/method%d" % (math_mode, occlusion, method)] = rec
+    # pinhole single-sensor path (RPI.h:4254-4512) on a seeded 320x240 sensor pair (inputs regenerated from the seed in the
+    # tests: synth.make_pinhole_pair(320, 240, seed=77); their CRC32 is recorded here)
+    (prgbA, pdA), (prgbB, pdB), pT, pK = synth.make_pinhole_pair(320, 240, seed=77)
+    out["pinhole"] = {"K": list(pK), "T_gt": pT.tolist(), "crc32_inputs": [crc(prgbA), crc(pdA), crc(prgbB), crc(pdB)], "runs": {}}
+    pin = O.Oracle(n_pyr=3, math_mode=0, reduce_mode=1, mask_seams=0)
+    pin.set_camera(*pK)
+    pin.set_target(prgbA, pdA)
+    pin.set_source(prgbB, pdB)
+    for math_mode in (0, 1):
+        pin.set_modes(math_mode, 1)
+        for method in (0, 1, 2):
+            st, pose = pin.align_pinhole(np.eye(4), method)
+            rec = {"status": st, "iters": list(pin.result.iters)[:3], "pose": pose.astype(np.float64).tolist(),
+                   "err_final": None if pin.result.err_final != pin.result.err_final else pin.result.err_final,
+                   "trace": [{"level": t["level"], "it": t["it"], "accepted": t["accepted"], "n_valid": t["n_valid"]} for t in pin.trace()]}
+            e = pin.error_pinhole(1, pT, method)
+            H, g, Hd, gd, nrows = pin.hessgrad_pinhole(1, pT, method)
+            rec["at_gt_level1"] = {"sum_photo": e[1], "sum_depth": e[2], "n_photo": e[3], "n_depth": e[4], "n_rows": nrows,
+                                   "H64": Hd.tolist(), "g64": gd.tolist()}
+            out["pinhole"]["runs"]["math%d/method%d" % (math_mode, method)] = rec
     with open(os.path.join(HERE, "oracle_256x128.json"), "w") as f:
         json.dump(out, f, indent=1)
     print("wrote", os.listdir(HERE))

@@ -563,3 +563,101 @@ def test_hip_occlusion_matches_golden_fixture(hip_lib, occlusion, method):
     e = reg.eval(1, synth.occlusion_test_poses(T)[2], method, occlusion)
     assert list(e["n_split"]) == [g["n_photo"], g["n_depth"]] and e["n_visible"] == g["n_visible"]
     assert np.abs(e["H64"] - np.array(g["H64"])).max() <= HG_RTOL * np.abs(np.array(g["H64"])).max()
+
+
+# ---- pinhole single-sensor alignment (RPI.h:4254-4512) -------------------------------------------
+def _pinhole_ctx(hip_lib, oracle_mod, math_mode=1, depth_f32=False):
+    (rgbA, dA), (rgbB, dB), T, K = synth.make_pinhole_pair(320, 240, seed=77, depth_f32=depth_f32)
+    reg = _mk(hip_lib, 3, setMaskSeams=False)
+    reg.setCameraMatrix(K)
+    reg.setTargetFrame(rgbA, dA)
+    reg.setSourceFrame(rgbB, dB)
+    ora = oracle_mod.Oracle(n_pyr=3, math_mode=math_mode, reduce_mode=1, mask_seams=0)
+    ora.set_camera(*K)
+    ora.set_target(rgbA, dA)
+    ora.set_source(rgbB, dB)
+    return reg, ora, T
+
+
+def test_pinhole_warp_indices_bit_exact(hip_lib, oracle_mod):
+    reg, ora, T = _pinhole_ctx(hip_lib, oracle_mod)
+    for level in range(3):
+        for pose in _poses(T):
+            a, b = reg.warp_indices_pinhole(level, pose), ora.warp_indices_pinhole(level, pose)
+            assert (b[:, 0] >= 0).mean() > 0.5
+            assert np.array_equal(a, b), (level, int((a != b).any(axis=1).sum()))
+
+
+@pytest.mark.parametrize("method", [0, 1, 2])
+def test_pinhole_eval_parity(hip_lib, oracle_mod, method):
+    reg, ora, T = _pinhole_ctx(hip_lib, oracle_mod)
+    for level in range(3):
+        for pose in _poses(T):
+            e = reg.eval_pinhole(level, pose, method)
+            _, sp, sd, n_p, n_d = ora.error_pinhole(level, pose, method)
+            H, g, Hd, gd, nrows = ora.hessgrad_pinhole(level, pose, method)
+            assert list(e["n_split"]) == [n_p, n_d] and e["n_rows"] == nrows           # integer work: exact
+            assert abs(e["err2_split"][0] - sp) <= ERR2_RTOL * max(1.0, abs(sp))
+            assert abs(e["err2_split"][1] - sd) <= ERR2_RTOL * max(1.0, abs(sd))
+            scale_h = np.abs(Hd).max()
+            assert np.abs(e["H64"] - Hd).max() <= HG_RTOL * scale_h
+            assert np.abs(e["g64"] - gd).max() <= HG_RTOL * max(np.abs(gd).max(), 1e-3 * np.sqrt(scale_h))
+
+
+@pytest.mark.parametrize("method,depth_f32", [(0, False), (1, False), (2, False), (2, True)])
+def test_pinhole_align_matches_oracle(hip_lib, oracle_mod, method, depth_f32):
+    reg, ora, T = _pinhole_ctx(hip_lib, oracle_mod, depth_f32=depth_f32)
+    rc = reg.alignFrames(np.eye(4), method)
+    st, pose_ref = ora.align_pinhole(np.eye(4), method)
+    assert rc == st
+    assert rc == (2 if method == 0 else 0)          # PHOTO only: x / nValidDepthPts = NaN in the reference, guess returned
+    assert reg.num_iterations == list(ora.result.iters)[:3]
+    rot, trans = synth.pose_error(reg.getOptimalPose(), pose_ref)
+    assert rot <= POSE_TOL_DEV and trans <= POSE_TOL_DEV, (rot, trans)
+    if method != 0:
+        assert abs(reg.avResidual - ora.result.err_final) <= 1e-5 * max(1.0, ora.result.err_final)
+        assert np.allclose(reg.getHessian(), np.asarray(list(ora.result.hessian)).reshape(6, 6).T, rtol=1e-4,
+                           atol=1e-4 * np.abs(reg.getHessian()).max())
+        # and against the reference-faithful libm / roundf oracle: the north-star tolerance
+        ora0 = oracle_mod.Oracle(n_pyr=3, math_mode=0, reduce_mode=0, mask_seams=0)
+        (rgbA, dA), (rgbB, dB), _, K = synth.make_pinhole_pair(320, 240, seed=77, depth_f32=depth_f32)
+        ora0.set_camera(*K); ora0.set_target(rgbA, dA); ora0.set_source(rgbB, dB)
+        st0, pose0 = ora0.align_pinhole(np.eye(4), method)
+        assert st0 == 0
+        rot, trans = synth.pose_error(reg.getOptimalPose(), pose0)
+        assert rot <= ROT_TOL and trans <= TRANS_TOL, (rot, trans)
+
+
+def test_pinhole_argument_errors(hip_lib):
+    from rgbd360_amd.register import Rgbd360Error
+    (rgbA, dA), (rgbB, dB), T, K = synth.make_pinhole_pair(320, 240, seed=77)
+    reg = _mk(hip_lib, 3, setMaskSeams=False)
+    reg.setTargetFrame(rgbA, dA); reg.setSourceFrame(rgbB, dB)
+    with pytest.raises(Rgbd360Error):
+        reg.alignFrames(np.eye(4), 2)                 # no camera matrix yet
+    reg.setCameraMatrix(np.array([[K[0], 0, K[2]], [0, K[1], K[3]], [0, 0, 1]]))
+    with pytest.raises(Rgbd360Error):
+        reg.alignFrames(np.eye(4), 2, occlusion=1)
+    assert reg.alignFrames(np.eye(4), 2) == 0
+    seams = _mk(hip_lib, 3)                           # default params mask the panorama seams: refused for a pinhole image
+    seams.setCameraMatrix(K); seams.setTargetFrame(rgbA, dA); seams.setSourceFrame(rgbB, dB)
+    with pytest.raises(Rgbd360Error):
+        seams.alignFrames(np.eye(4), 2)
+
+
+@pytest.mark.parametrize("method", [1, 2])
+def test_hip_pinhole_matches_golden_fixture(hip_lib, method):
+    z, j = _golden()
+    G = j["pinhole"]
+    ref = G["runs"]["math1/method%d" % method]
+    (rgbA, dA), (rgbB, dB), T, K = synth.make_pinhole_pair(320, 240, seed=77)
+    reg = _mk(hip_lib, 3, setMaskSeams=False)
+    reg.setCameraMatrix(K); reg.setTargetFrame(rgbA, dA); reg.setSourceFrame(rgbB, dB)
+    rc = reg.alignFrames(np.eye(4), method)
+    assert rc == ref["status"] and reg.num_iterations == ref["iters"]
+    rot, trans = synth.pose_error(reg.getOptimalPose(), np.array(ref["pose"]))
+    assert rot <= POSE_TOL_DEV and trans <= POSE_TOL_DEV
+    g = ref["at_gt_level1"]
+    e = reg.eval_pinhole(1, T, method)
+    assert list(e["n_split"]) == [g["n_photo"], g["n_depth"]] and e["n_rows"] == g["n_rows"]
+    assert np.abs(e["H64"] - np.array(g["H64"])).max() <= HG_RTOL * np.abs(np.array(g["H64"])).max()

@@ -374,3 +374,84 @@ def test_occlusion_zbuffer_known_answer(oracle_mod):
     e2 = ora.error_occ(0, np.eye(4), 2, 2)
     assert e2[3] == H * W // 2
     assert ora.hessgrad_occ(0, np.eye(4), 2, 2)[4] == H * W // 2
+
+
+# ---- pinhole single-sensor path (RPI.h:4254-4512) ------------------------------------------------------------------------
+def test_se3_exp_matches_matrix_exponential(oracle_mod):
+    """CPose3D::exp(., false) restatement against scipy's expm of the 4x4 twist, through all three branches of the
+    small-angle series (theta^2 < 1e-8, < 1e-6, general)."""
+    import scipy.linalg
+    rng = np.random.default_rng(3)
+    for scale in (1.0, 3e-3, 5e-4, 1e-5, 0.0):
+        v = rng.normal(size=6) * np.array([0.3, 0.3, 0.3, scale, scale, scale])
+        X = np.zeros((4, 4))
+        X[:3, :3] = np.array([[0, -v[5], v[4]], [v[5], 0, -v[3]], [-v[4], v[3], 0]])
+        X[:3, 3] = v[:3]
+        # below theta^2 = 1e-8 MRPT truncates the translation coupling after the first-order term: error ~ theta^2 |u| / 6
+        tol = 1e-13 if (v[3:] ** 2).sum() >= 1e-8 else 1e-10
+        assert np.abs(oracle_mod.se3_exp(v) - scipy.linalg.expm(X)).max() < tol
+
+
+def test_pinhole_lut_and_projection_roundtrip(oracle_mod):
+    """Known answer: back-projecting the source depth with K and re-projecting with the identity pose lands every valid
+    pixel on itself (RPI.h:4277-4300 against :701-708)."""
+    (rgbA, dA), (rgbB, dB), T, K = synth.make_pinhole_pair(160, 120, seed=5)
+    for mm in (0, 1):
+        ora = oracle_mod.Oracle(n_pyr=2, math_mode=mm, reduce_mode=1, mask_seams=0)
+        ora.set_camera(*K); ora.set_target(rgbA, dA); ora.set_source(rgbB, dB)
+        for level in (0, 1):
+            rows, cols = ora.level_dims(level)
+            idx = ora.warp_indices_pinhole(level, np.eye(4))
+            rr, cc = np.divmod(np.arange(rows * cols), cols)
+            valid = ora.lut_pinhole(level)[:, 0] != -10000
+            assert valid.mean() > 0.9
+            assert np.array_equal(idx[valid, 0], rr[valid]) and np.array_equal(idx[valid, 1], cc[valid])
+            lut = ora.lut_pinhole(level)
+            z = ora.plane("depth_src", level).reshape(-1)
+            assert np.array_equal(lut[:, 2], z)
+            s = 2.0 ** -level
+            assert np.allclose(lut[valid, 0], (cc[valid] - K[2] * s) * z[valid] / (K[0] * s), rtol=1e-5, atol=1e-6)
+
+
+def test_pinhole_alignment_improves_on_the_guess(oracle_mod):
+    """Functional: PHOTO_DEPTH moves the identity guess towards the rendered motion; PHOTO only reproduces the reference's
+    NaN (both averages are divided by nValidDepthPts, RPI.h:742-743) and returns the guess."""
+    (rgbA, dA), (rgbB, dB), T, K = synth.make_pinhole_pair(320, 240, seed=77)
+    ora = oracle_mod.Oracle(n_pyr=3, mask_seams=0)
+    ora.set_camera(*K); ora.set_target(rgbA, dA); ora.set_source(rgbB, dB)
+    st, pose = ora.align_pinhole(np.eye(4), 2)
+    r0, t0 = synth.pose_error(np.eye(4), T)
+    r1, t1 = synth.pose_error(pose, T)
+    assert st == 0 and sum(list(ora.result.iters)[:3]) >= 2
+    assert t1 < 0.6 * t0 and r1 < 0.6 * r0, (r0, t0, r1, t1)
+    st, pose = ora.align_pinhole(np.eye(4), 0)
+    assert st == 2 and np.allclose(pose, np.eye(4))
+    # the cost the driver minimises is far lower at the rendered motion than at the guess, on every level
+    for level in range(3):
+        assert ora.error_pinhole(level, T, 2)[0] < 0.4 * ora.error_pinhole(level, np.eye(4), 2)[0]
+
+
+@pytest.mark.parametrize("math_mode", [0, 1])
+@pytest.mark.parametrize("method", [0, 1, 2])
+def test_oracle_pinhole_matches_golden(golden, oracle_mod, math_mode, method):
+    import zlib
+    _, j = golden
+    G = j["pinhole"]
+    (rgbA, dA), (rgbB, dB), T, K = synth.make_pinhole_pair(320, 240, seed=77)
+    crc = lambda a: zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF
+    assert [crc(rgbA), crc(dA), crc(rgbB), crc(dB)] == G["crc32_inputs"]          # the generator reproduces the recorded inputs
+    ref = G["runs"]["math%d/method%d" % (math_mode, method)]
+    ora = oracle_mod.Oracle(n_pyr=3, math_mode=math_mode, reduce_mode=1, mask_seams=0)
+    ora.set_camera(*K); ora.set_target(rgbA, dA); ora.set_source(rgbB, dB)
+    st, pose = ora.align_pinhole(np.eye(4), method)
+    assert st == ref["status"] and list(ora.result.iters)[:3] == ref["iters"]
+    rot, trans = synth.pose_error(pose, np.array(ref["pose"]))
+    assert rot < 1e-6 and trans < 1e-6
+    tr = ora.trace()
+    assert [(t["level"], t["it"], t["accepted"], t["n_valid"]) for t in tr] == [(t["level"], t["it"], t["accepted"], t["n_valid"]) for t in ref["trace"]]
+    g = ref["at_gt_level1"]
+    e = ora.error_pinhole(1, T, method)
+    assert (e[3], e[4]) == (g["n_photo"], g["n_depth"])
+    assert abs(e[1] - g["sum_photo"]) <= 1e-9 * max(1.0, g["sum_photo"]) and abs(e[2] - g["sum_depth"]) <= 1e-9 * max(1.0, g["sum_depth"])
+    H, gg, Hd, gd, nrows = ora.hessgrad_pinhole(1, T, method)
+    assert nrows == g["n_rows"] and np.allclose(Hd, np.array(g["H64"]), rtol=1e-9)
