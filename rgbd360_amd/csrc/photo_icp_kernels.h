@@ -166,9 +166,9 @@ __device__ __forceinline__ WarpConsts make_warp_consts(const PoseRT& T, const Le
     asm volatile("" : "+v"(c.tx), "+v"(c.ty), "+v"(c.tz), "+v"(c.half_nRows), "+v"(c.pi_k));
     return c;
 }
-__device__ __forceinline__ unsigned warp_pixel(const PoseRT& T, const WarpConsts& wc, float px, float py, float pz,
-                                               const LevelDev& lv, float& X, float& Y, float& Z, float& rho2, float& d2,
-                                               bool& vis) {
+__device__ __forceinline__ void warp_pixel_rc(const PoseRT& T, const WarpConsts& wc, float px, float py, float pz,
+                                              const LevelDev& lv, float& X, float& Y, float& Z, float& rho2, float& d2,
+                                              int& tr, int& tc, bool& vis) {
     X = fmaf(T.r02, pz, fmaf(T.r01, py, fmaf(T.r00, px, wc.tx)));
     Y = fmaf(T.r12, pz, fmaf(T.r11, py, fmaf(T.r10, px, wc.ty)));
     Z = fmaf(T.r22, pz, fmaf(T.r21, py, fmaf(T.r20, px, wc.tz)));
@@ -185,9 +185,15 @@ __device__ __forceinline__ unsigned warp_pixel(const PoseRT& T, const WarpConsts
     if (ax > rho) phi_trg = 1.57079637f - phi_trg;
     phi_trg = copysignf(phi_trg, X);
     const float theta = atan2_from_t(Y, Z, ay, az, tt);
-    const int tr = round_index(fmaf(phi_trg, -lv.angle_res_inv, wc.half_nRows));
-    const int tc = round_index(fmaf(theta, lv.angle_res_inv, wc.pi_k));
+    tr = round_index(fmaf(phi_trg, -lv.angle_res_inv, wc.half_nRows));
+    tc = round_index(fmaf(theta, lv.angle_res_inv, wc.pi_k));
     vis = ((unsigned)tr < (unsigned)lv.rows) && ((unsigned)tc < (unsigned)lv.cols);
+}
+__device__ __forceinline__ unsigned warp_pixel(const PoseRT& T, const WarpConsts& wc, float px, float py, float pz,
+                                               const LevelDev& lv, float& X, float& Y, float& Z, float& rho2, float& d2,
+                                               bool& vis) {
+    int tr, tc;
+    warp_pixel_rc(T, wc, px, py, pz, lv, X, Y, Z, rho2, d2, tr, tc, vis);
     return __umul24(tr, lv.cols) + (unsigned)tc;
 }
 
@@ -275,6 +281,32 @@ __device__ __forceinline__ void wave_reduce32(const float v[32], float out[2]) {
 // pixel is clamped to 0) and the compiler can issue the next source record and both gathers early instead of
 // serialising four dependent memory round trips behind divergent branches.
 // ---------------------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------------------
+// Buffer-addressed loads for the fused pass: a 128-bit resource descriptor in SGPRs + a 32-bit byte offset per lane
+// replaces 64-bit per-lane address arithmetic (v_mad_u64_u32 / v_lshl_add_u64), and the hardware range check (offsets
+// past num_records return 0) replaces the index clamps: a lane past the end of its span, or a pixel warped outside
+// the image, may issue its load with whatever offset it has -- the value is never used and the load cannot fault.
+// ---------------------------------------------------------------------------------------------------------
+typedef float float3v __attribute__((ext_vector_type(3)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+// (whole-vector casts: with ROCm 7.2's hipcc __builtin_bit_cast(float, v.y) of an ext-vector ELEMENT reads element 0)
+__device__ __forceinline__ float4 buf_load_f4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    const float4v w = (float4v)__builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+    return make_float4(w.x, w.y, w.z, w.w);
+}
+__device__ __forceinline__ F3 buf_load_f3(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    const float3v w = (float3v)__builtin_amdgcn_raw_buffer_load_b96(r, (int)byte_off, 0, 0);
+    F3 o = {w.x, w.y, w.z};
+    return o;
+}
+struct EvalBufs {
+    __amdgpu_buffer_rsrc_t src, trgP, trgD;
+    unsigned row_bytes;      // cols * 12
+};
+
 struct EvalAcc {
     float acc[27];       // 21 upper-triangle terms of H, 6 of g
     float e2p, e2d;      // per-lane float32 partial sums of squared weighted residuals
@@ -289,7 +321,7 @@ __device__ __forceinline__ int ballot_count(bool p) { return __builtin_popcountl
 // not index work.
 __device__ __forceinline__ float weight_huber_fast(float error, float k) {
     const float ea = fabsf(error);
-    const float q = 2 * k * ea - k * k;
+    const float q = fmaf(2 * k, ea, -(k * k));
     const float w = q * fast_rsq(q * ea * ea);       // sqrt(q) / |e| with one transcendental
     return ea < k ? 1.f : w;
 }
@@ -325,20 +357,22 @@ struct PixW {
 
 template <int METHOD>
 __device__ __forceinline__ void warp_stage(const float4 s, const bool in_range, const PoseRT& T, const WarpConsts& wc,
-                                           const LevelDev& lv, PixW& w) {
+                                           const LevelDev& lv, const EvalBufs& bufs, PixW& w) {
     bool vis;
     float d2;
-    unsigned ti = warp_pixel(T, wc, s.x, s.y, s.z, lv, w.X, w.Y, w.Z, w.rho2, d2, vis);
+    int tr, tc;
+    warp_pixel_rc(T, wc, s.x, s.y, s.z, lv, w.X, w.Y, w.Z, w.rho2, d2, tr, tc, vis);
     vis = vis && in_range && (s.x != kInvalidPoint);
     w.d2s = vis ? d2 : -d2;
     w.isrc = s.w;
     // tie the copy of the source intensity to the end of the warp arithmetic: scheduled earlier it would sit in
     // front of the whole stage and wait for the youngest load (vmcnt(0)) instead of the one this stage needs
     asm volatile("" : "+v"(w.isrc), "+v"(w.d2s));
-    ti = vis ? ti : 0u;
-    // unconditional gathers, issued as soon as the index is known
-    if (METHOD != 1) w.tp = lv.trgP[ti];
-    if (METHOD != 0) w.td = lv.trgD[ti];
+    // unconditional gathers, issued as soon as the index is known; an invisible pixel's offset is arbitrary but
+    // range-checked by the buffer descriptor
+    const unsigned off = __umul24(tr, bufs.row_bytes) + __umul24(tc, 12u);      // byte offset of the 12-byte target record
+    if (METHOD != 1) w.tp = buf_load_f3(bufs.trgP, off);
+    if (METHOD != 0) w.td = buf_load_f3(bufs.trgD, off);
 }
 
 template <int METHOD, bool HG>
@@ -356,20 +390,15 @@ __device__ __forceinline__ void consume_stage(PixW& w, const LevelDev& lv, const
     //   d c'/d(y,z) = k (Z, -Y) / rho^2
     //   d r'/d(x,y,z) = k (-rho^2, X Y, X Z) / (rho d^2)
     // (algebraically what the reference writes with 1/z, 1/(1+y^2/z^2), 1/sqrt(1-x^2/d^2)); float32 data, so the
-    // hardware reciprocal / reciprocal square root are used.
-    float a1 = 0.f, a2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
+    // hardware reciprocal square roots are used.  A weighted gradient (gx, gy) times this 2x3 matrix is, with
+    // u = gx k / rho^2 and v = gy k / (rho d^2):   ( -v rho^2,  v X Y + u Z,  v X Z - u Y ).
+    float k_rho2 = 0.f, k_d2r = 0.f;
     const float dist_inv = fast_rsq(d2);
     if (HG) {
 #pragma clang fp contract(fast)
         const float inv_rho = fast_rsq(w.rho2);
-        const float k_rho2 = lv.angle_res_inv * (inv_rho * inv_rho);
-        a1 = k_rho2 * Z;
-        a2 = -k_rho2 * Y;
-        const float k_d2 = lv.angle_res_inv * (dist_inv * dist_inv);
-        b0 = -k_d2 * (w.rho2 * inv_rho);
-        const float c = k_d2 * inv_rho * X;
-        b1 = c * Y;
-        b2 = c * Z;
+        k_rho2 = lv.angle_res_inv * (inv_rho * inv_rho);
+        k_d2r = (lv.angle_res_inv * (dist_inv * dist_inv)) * inv_rho;
     }
 
     bool photo_skip = false;   // `continue` at RPI.h:2690 / 3039 also skips the depth term of the pixel
@@ -386,9 +415,10 @@ __device__ __forceinline__ void consume_stage(PixW& w, const LevelDev& lv, const
             const float res = wpf * photoDiff;
             A.e2p += res * res;
             if (HG) {
-                const float wgx = wpf * tgx, wgy = wpf * tgy;
                 // (w * grad) * jacobianProj23
-                accumulate_row(A, wgy * b0, wgx * a1 + wgy * b1, wgx * a2 + wgy * b2, X, Y, Z, res);
+                const float u = (wpf * tgx) * k_rho2, v = (wpf * tgy) * k_d2r;
+                const float vX = v * X;
+                accumulate_row(A, -v * w.rho2, vX * Y + u * Z, vX * Z - u * Y, X, Y, Z, res);
             }
         }
     }
@@ -409,10 +439,9 @@ __device__ __forceinline__ void consume_stage(PixW& w, const LevelDev& lv, const
             A.e2d += res * res;
             if (HG) {
                 // wd * (dgrad * jacobianProj23 - p'/dist)   (RPI.h:3080-3083)
-                const float kx = wd * (tdy * b0 - X * dist_inv);
-                const float ky = wd * ((tdx * a1 + tdy * b1) - Y * dist_inv);
-                const float kz = wd * ((tdx * a2 + tdy * b2) - Z * dist_inv);
-                accumulate_row(A, kx, ky, kz, X, Y, Z, res);
+                const float u = (wd * tdx) * k_rho2, v = (wd * tdy) * k_d2r;
+                const float vX = v * X, sdi = wd * dist_inv;
+                accumulate_row(A, -v * w.rho2 - sdi * X, (vX * Y + u * Z) - sdi * Y, (vX * Z - u * Y) - sdi * Z, X, Y, Z, res);
             }
         }
     }
@@ -433,11 +462,15 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval(LevelDev lv, EvalConsts e
     const int cb = ((nb & 7) == 0) ? (b & 7) * (nb >> 3) + (b >> 3) : b;
     const int base = cb * chunk;
     const int end = min(base + chunk, lv.n);
-    const int last = lv.n - 1;
+    EvalBufs bufs;
+    bufs.src = make_rsrc(lv.src, (unsigned)lv.n * 16u);
+    bufs.trgP = make_rsrc(lv.trgP, (unsigned)lv.n * 12u);
+    bufs.trgD = make_rsrc(lv.trgD, (unsigned)lv.n * 12u);
+    bufs.row_bytes = (unsigned)lv.cols * 12u;
     int i = base + (int)threadIdx.x;
     // the first two source records do not depend on the state: issue them before the scalar loads of done / pose
-    float4 sA = lv.src[min(i, last)];
-    float4 sB = lv.src[min(i + kEvalThreads, last)];
+    float4 sA = buf_load_f4(bufs.src, (unsigned)i << 4);
+    float4 sB = buf_load_f4(bufs.src, (unsigned)(i + kEvalThreads) << 4);
     if (st->done || st->level_active != level) return;     // speculatively enqueued launch of a finished / later level
     const PoseRT T = load_pose(st->cand);
     const WarpConsts wc = make_warp_consts(T, lv);
@@ -455,22 +488,22 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval(LevelDev lv, EvalConsts e
     // of step k+1 and the source record of step k+2 are in flight.
     const int n_steps = (end - base + kEvalThreads - 1) / kEvalThreads;
     PixW wA, wB;
-    warp_stage<METHOD>(sA, i < end, T, wc, lv, wA);
+    warp_stage<METHOD>(sA, i < end, T, wc, lv, bufs, wA);
     ESTAMP(1);
-    sA = lv.src[min(i + 2 * kEvalThreads, last)];
+    sA = buf_load_f4(bufs.src, (unsigned)(i + 2 * kEvalThreads) << 4);
     int k = 0;
     // steady state: straight-line body (no control-flow joins, so the compiler's waits are counted, not vmcnt(0))
     for (; k + 2 < n_steps; k += 2, i += 2 * kEvalThreads) {
-        warp_stage<METHOD>(sB, (i + kEvalThreads) < end, T, wc, lv, wB);
-        sB = lv.src[min(i + 3 * kEvalThreads, last)];
+        warp_stage<METHOD>(sB, (i + kEvalThreads) < end, T, wc, lv, bufs, wB);
+        sB = buf_load_f4(bufs.src, (unsigned)(i + 3 * kEvalThreads) << 4);
         consume_stage<METHOD, HG>(wA, lv, ec, A);
-        warp_stage<METHOD>(sA, (i + 2 * kEvalThreads) < end, T, wc, lv, wA);
-        sA = lv.src[min(i + 4 * kEvalThreads, last)];
+        warp_stage<METHOD>(sA, (i + 2 * kEvalThreads) < end, T, wc, lv, bufs, wA);
+        sA = buf_load_f4(bufs.src, (unsigned)(i + 4 * kEvalThreads) << 4);
         consume_stage<METHOD, HG>(wB, lv, ec, A);
     }
     // tail: one or two steps left, wA holds step k
     if (k + 1 < n_steps) {
-        warp_stage<METHOD>(sB, (i + kEvalThreads) < end, T, wc, lv, wB);
+        warp_stage<METHOD>(sB, (i + kEvalThreads) < end, T, wc, lv, bufs, wB);
         consume_stage<METHOD, HG>(wA, lv, ec, A);
         consume_stage<METHOD, HG>(wB, lv, ec, A);
     } else {
