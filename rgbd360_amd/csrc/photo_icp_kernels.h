@@ -83,27 +83,24 @@ struct SolveCfg {
 // sequence of IEEE-754 basic operations (fma, mul, add, correctly rounded sqrt and reciprocal) that the CPU oracle
 // repeats operation for operation in its math_mode 1, so warped pixel indices agree bit for bit.
 // ---------------------------------------------------------------------------------------------------------
-// Correctly rounded sqrt for normal, finite x >= 0 (and x == 0): hardware estimate (<= 1 ulp) corrected with two
-// exact fma residuals -- the core of the compiler's own IEEE expansion without its denormal / special-class
-// handling, which inputs on this path never need.  rgbd360_selftest_math compares it with sqrtf over the range.
+// Correctly rounded sqrt for x == 0 and normal finite x in [2^-60, 2^60]: reciprocal-square-root estimate (<= 1 ulp) and
+// ONE coupled Newton step, s = x y, s += (x - s s) (y / 2), with the residual taken exactly by an fma.  Proven by
+// exhaustion, not by analysis: rgbd360_selftest_math (and tools/ubench/rn_variants.hip) compare it with the compiler's IEEE
+// sqrtf for every float of that range -- 0 mismatches on gfx950.  (The first version corrected the hardware sqrt with two
+// +-1 ulp residual tests: 9 instructions instead of 6.)
 __device__ __forceinline__ float sqrt_rn(float x) {
-    float s = __builtin_amdgcn_sqrtf(x);
-    const float sm = __builtin_bit_cast(float, __builtin_bit_cast(int, s) - 1);
-    const float sp = __builtin_bit_cast(float, __builtin_bit_cast(int, s) + 1);
-    const float rm = fmaf(-sm, s, x);
-    const float rp = fmaf(-sp, s, x);
-    s = (rm <= 0.f) ? sm : s;
-    s = (rp > 0.f) ? sp : s;
-    return s;
+    const float y = __builtin_amdgcn_rsqf(fmaxf(x, 1.17549435e-38f));      // the clamp only matters for x == 0: s = 0 * y = 0
+    const float s = x * y;
+    const float h = 0.5f * y;
+    const float r = fmaf(-s, s, x);
+    return fmaf(r, h, s);
 }
-// Correctly rounded 1/x for normal finite x: hardware estimate + Newton step + one residual correction.
+// Correctly rounded 1/x for normal finite |x| in [2^-60, 2^60]: hardware estimate (<= 1 ulp) + one Newton step with an exact
+// fma residual; exhaustively equal to the IEEE quotient 1.f / x on gfx950 (same self-test).
 __device__ __forceinline__ float rcp_rn(float x) {
-    float r = __builtin_amdgcn_rcpf(x);
-    float e = fmaf(-x, r, 1.f);
-    r = fmaf(e, r, r);
-    e = fmaf(-x, r, 1.f);
-    r = fmaf(e, r, r);
-    return r;
+    const float r = __builtin_amdgcn_rcpf(x);
+    const float e = fmaf(-x, r, 1.f);
+    return fmaf(e, r, r);
 }
 
 // round-half-up to the nearest integer, floor(x + 0.5) with the sum taken exactly: one v_cvt_rpi_i32_f32.  Equals
@@ -447,9 +444,13 @@ __device__ __forceinline__ void consume_stage(PixW& w, const LevelDev& lv, const
     }
 }
 
+// Argument order: the scalars the first instructions need (state pointer for the gate / pose loads, source base and span for
+// the first record loads) lead the list so that the kernarg preload (build flag -amdgpu-kernarg-preload-count) delivers
+// them in SGPRs at wave start; the structs follow and are fetched while those first loads are in flight.
 template <int METHOD, bool HG>
-__global__ __launch_bounds__(kEvalThreads) void k_eval(LevelDev lv, EvalConsts ec, const GNState* __restrict__ st,
-                                                        double* __restrict__ partials, int chunk, int level) {
+__global__ __launch_bounds__(kEvalThreads) void k_eval(const GNState* __restrict__ st, const float4* __restrict__ src0, int n_px,
+                                                        int chunk, int level, int nb_arg, double* __restrict__ partials,
+                                                        LevelDev lv, EvalConsts ec) {
 #ifdef RGBD360_EVAL_STAMPS
     const unsigned long long es0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long es[6] = {0, 0, 0, 0, 0, 0};
@@ -457,13 +458,13 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval(LevelDev lv, EvalConsts e
 #else
 #define ESTAMP(i)
 #endif
-    const int nb = gridDim.x;
+    const int nb = nb_arg;
     const int b = blockIdx.x;
     const int cb = ((nb & 7) == 0) ? (b & 7) * (nb >> 3) + (b >> 3) : b;
     const int base = cb * chunk;
-    const int end = min(base + chunk, lv.n);
+    const int end = min(base + chunk, n_px);
     EvalBufs bufs;
-    bufs.src = make_rsrc(lv.src, (unsigned)lv.n * 16u);
+    bufs.src = make_rsrc(src0, (unsigned)n_px * 16u);
     bufs.trgP = make_rsrc(lv.trgP, (unsigned)lv.n * 12u);
     bufs.trgD = make_rsrc(lv.trgD, (unsigned)lv.n * 12u);
     bufs.row_bytes = (unsigned)lv.cols * 12u;
@@ -471,7 +472,11 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval(LevelDev lv, EvalConsts e
     // the first two source records do not depend on the state: issue them before the scalar loads of done / pose
     float4 sA = buf_load_f4(bufs.src, (unsigned)i << 4);
     float4 sB = buf_load_f4(bufs.src, (unsigned)(i + kEvalThreads) << 4);
-    if (st->done || st->level_active != level) return;     // speculatively enqueued launch of a finished / later level
+    // gate and pose are fetched in ONE batch of scalar loads, in parallel with the two record loads above.  The gate is
+    // only TESTED after the first warp stage: an early-exit branch up here makes the compiler sink every load behind it
+    // (one dependent memory round trip per sunk batch, ~1 us each); the asm statement that ends warp_stage cannot be moved
+    // across the branch, so this order survives.  A no-op launch (finished / other level) costs one warp stage.
+    const int2 gate = *reinterpret_cast<const int2*>(&st->done);            // {done, level_active}
     const PoseRT T = load_pose(st->cand);
     const WarpConsts wc = make_warp_consts(T, lv);
     ESTAMP(0);
@@ -489,6 +494,8 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval(LevelDev lv, EvalConsts e
     const int n_steps = (end - base + kEvalThreads - 1) / kEvalThreads;
     PixW wA, wB;
     warp_stage<METHOD>(sA, i < end, T, wc, lv, bufs, wA);
+    asm volatile("" ::: "memory");                   // the loads issued so far stay above the gate
+    if (gate.x | (gate.y != level)) return;          // speculatively enqueued launch of a finished / later level
     ESTAMP(1);
     sA = buf_load_f4(bufs.src, (unsigned)(i + 2 * kEvalThreads) << 4);
     int k = 0;
@@ -998,12 +1005,15 @@ __global__ void k_warp_indices(LevelDev lv, Pose16 pose, int32_t* __restrict__ o
 __global__ void k_selftest_math(unsigned first_bits, unsigned count, unsigned long long* __restrict__ mismatches) {
     const unsigned stride = gridDim.x * blockDim.x;
     unsigned bad_s = 0, bad_r = 0, bad_i = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) bad_s += (__builtin_bit_cast(unsigned, sqrt_rn(0.f)) != 0u);      // rho = 0 on the polar axis
     for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += stride) {
         const float x = __builtin_bit_cast(float, first_bits + k);
         const float s0 = sqrtf(x), s1 = sqrt_rn(x);
         const float r0 = 1.f / x, r1 = rcp_rn(x);
+        const float q0 = 1.f / -x, q1 = rcp_rn(-x);          // the pinhole warp takes 1 / Z of either sign
         bad_s += (__builtin_bit_cast(unsigned, s0) != __builtin_bit_cast(unsigned, s1));
         bad_r += (__builtin_bit_cast(unsigned, r0) != __builtin_bit_cast(unsigned, r1));
+        bad_r += (__builtin_bit_cast(unsigned, q0) != __builtin_bit_cast(unsigned, q1));
         if (fabsf(x) < 1.0e9f) {
             bad_i += (round_index(x) != (int)floor((double)x + 0.5));
             bad_i += (round_index(-x) != (int)floor((double)(-x) + 0.5));

@@ -221,7 +221,7 @@ void launch_eval(rgbd360_ctx* ctx, int level, int method, bool hg, int occ = 0) 
 #undef LAUNCH_OCC
         return;
     }
-#define LAUNCH(M, HG) hipLaunchKernelGGL((k_eval<M, HG>), g, b, 0, ctx->stream, lv, ec, ctx->d_state, ctx->d_partials, L.chunk, level)
+#define LAUNCH(M, HG) hipLaunchKernelGGL((k_eval<M, HG>), g, b, 0, ctx->stream, ctx->d_state, lv.src, lv.n, L.chunk, level, L.nblocks, ctx->d_partials, lv, ec)
     if (hg) {
         if (method == 0) LAUNCH(0, true);
         else if (method == 1) LAUNCH(1, true);
