@@ -57,7 +57,6 @@ struct rgbd360_ctx {
     // Frame360 stage scratch (normals / plane segmentation), grown on demand
     size_t f360_n = 0;
     float *f_xyz = nullptr, *f_normals = nullptr, *f_dist = nullptr;
-    float4 *f_dx = nullptr, *f_dy = nullptr;
     uint8_t *f_change = nullptr, *f_hd = nullptr;
     int *f_label = nullptr, *f_slot_of_root = nullptr, *f_root_of_slot = nullptr, *f_nslots = nullptr, *f_window = nullptr;
     unsigned long long *f_count = nullptr, *f_mom = nullptr;
@@ -401,7 +400,7 @@ void rgbd360_destroy(rgbd360_ctx* ctx) {
     free_levels(ctx);
     hipFree(ctx->d_state); hipFree(ctx->d_partials); hipFree(ctx->d_gnio);
     hipFree(ctx->d_stage_rgb); hipFree(ctx->d_stage_depth);
-    hipFree(ctx->f_xyz); hipFree(ctx->f_normals); hipFree(ctx->f_dist); hipFree(ctx->f_dx); hipFree(ctx->f_dy);
+    hipFree(ctx->f_xyz); hipFree(ctx->f_normals); hipFree(ctx->f_dist);
     hipFree(ctx->f_change); hipFree(ctx->f_hd); hipFree(ctx->f_label); hipFree(ctx->f_count); hipFree(ctx->f_slot_of_root);
     hipFree(ctx->f_root_of_slot); hipFree(ctx->f_nslots); hipFree(ctx->f_window); hipFree(ctx->f_mom);
     hipFree(ctx->f_count_of_slot); hipFree(ctx->f_depth_raw);
@@ -1095,7 +1094,7 @@ constexpr int kF360MaxSlots = 4096;
 
 int f360_ensure(rgbd360_ctx* ctx, size_t n) {
     if (ctx->f360_n >= n) return 0;
-    hipFree(ctx->f_xyz); hipFree(ctx->f_normals); hipFree(ctx->f_dist); hipFree(ctx->f_dx); hipFree(ctx->f_dy);
+    hipFree(ctx->f_xyz); hipFree(ctx->f_normals); hipFree(ctx->f_dist);
     hipFree(ctx->f_change); hipFree(ctx->f_hd); hipFree(ctx->f_label); hipFree(ctx->f_count); hipFree(ctx->f_slot_of_root);
     hipFree(ctx->f_root_of_slot); hipFree(ctx->f_nslots); hipFree(ctx->f_window); hipFree(ctx->f_mom);
     hipFree(ctx->f_count_of_slot); hipFree(ctx->f_depth_raw);
@@ -1103,8 +1102,6 @@ int f360_ensure(rgbd360_ctx* ctx, size_t n) {
     HIPC(ctx, hipMalloc(&ctx->f_xyz, n * 3 * sizeof(float)));
     HIPC(ctx, hipMalloc(&ctx->f_normals, n * 3 * sizeof(float)));
     HIPC(ctx, hipMalloc(&ctx->f_dist, n * sizeof(float)));
-    HIPC(ctx, hipMalloc(&ctx->f_dx, n * sizeof(float4)));
-    HIPC(ctx, hipMalloc(&ctx->f_dy, n * sizeof(float4)));
     HIPC(ctx, hipMalloc(&ctx->f_change, n));
     HIPC(ctx, hipMalloc(&ctx->f_hd, n));
     HIPC(ctx, hipMalloc(&ctx->f_label, n * sizeof(int)));
@@ -1129,8 +1126,8 @@ int f360_normals_dev(rgbd360_ctx* ctx, int rows, int cols, float max_depth_chang
     hipLaunchKernelGGL(k_f360_edges, g, b, 0, ctx->stream, ctx->f_xyz, rows, cols, max_depth_change_factor, depth_mode, ctx->f_change);
     hipLaunchKernelGGL(k_f360_hdist, g, b, 0, ctx->stream, ctx->f_change, rows, cols, ctx->f_hd);
     hipLaunchKernelGGL(k_f360_dist, g, b, 0, ctx->stream, ctx->f_hd, rows, cols, ctx->f_dist);
-    hipLaunchKernelGGL(k_f360_diff, g, b, 0, ctx->stream, ctx->f_xyz, rows, cols, ctx->f_dx, ctx->f_dy);
-    hipLaunchKernelGGL(k_f360_normals, g, b, 0, ctx->stream, ctx->f_xyz, ctx->f_dist, ctx->f_dx, ctx->f_dy, rows, cols, smoothing_size,
+    const dim3 gt((cols + kNT_W - 1) / kNT_W, (rows + kNT_H - 1) / kNT_H);
+    hipLaunchKernelGGL(k_f360_normals_tiled, gt, dim3(kNT_THREADS), 0, ctx->stream, ctx->f_xyz, ctx->f_dist, rows, cols, smoothing_size,
                        depth_mode, ctx->f_normals, ctx->f_window);
     HIPC(ctx, hipGetLastError());
     return 0;
