@@ -54,6 +54,7 @@ struct rgbd360_ctx {
     size_t stage_rgb_bytes = 0, stage_depth_bytes = 0;
     int poll_chunk = 3;           // {pass, solve} pairs per level enqueued ahead of the device
     int first_chunk_top = 8;      // ... and for the first visit of the coarsest level (cheap passes, most iterations)
+    int chunk_level0 = 3;         // ... and for the finest level (most expensive passes; a second chunk costs a host round trip)
     // Frame360 stage scratch (normals / plane segmentation), grown on demand
     size_t f360_n = 0;
     float *f_xyz = nullptr, *f_normals = nullptr, *f_dist = nullptr;
@@ -377,6 +378,10 @@ int rgbd360_create(const rgbd360_params* p, rgbd360_ctx** out) {
         const int v = atoi(e);
         if (v >= 1 && v <= 16) ctx->first_chunk_top = v;
     }
+    if (const char* e = getenv("RGBD360_L0_CHUNK")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 16) ctx->chunk_level0 = v;
+    }
     bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreate(&ctx->ev0) == hipSuccess && hipEventCreate(&ctx->ev1) == hipSuccess &&
               hipMalloc(&ctx->d_state, sizeof(GNState)) == hipSuccess &&
@@ -469,7 +474,7 @@ static void enqueue_schedule(rgbd360_ctx* ctx, int pending, bool pending_started
     for (int level = pending; level >= 0; --level) {
         if (!(level == pending && pending_started))
             launch_level_init(ctx, level, level == top ? ctx->al_guess : nullptr, level == top ? 1 : 0);
-        const int n_pairs = (level == top && !pending_started) ? ctx->first_chunk_top : ctx->poll_chunk;
+        const int n_pairs = (level == top && !pending_started) ? ctx->first_chunk_top : (level == 0 ? ctx->chunk_level0 : ctx->poll_chunk);
         for (int k = 0; k < n_pairs; ++k) {
             launch_eval(ctx, level, ctx->al_method, true, ctx->al_occ);
             launch_solve(ctx, level, 0, 0, ctx->al_occ);
