@@ -34,6 +34,13 @@ BYTES_PER_PX = {0: 28, 1: 28, 2: 40}   # LUT variant: 16 B source record + 12 B 
 METHOD_NAMES = {0: "PHOTO_CONSISTENCY", 1: "DEPTH_CONSISTENCY", 2: "PHOTO_DEPTH"}
 
 
+def avg_kernel_us(reg, level, pose, method, reps, batches=5):
+    """Average launch duration of the fused kernel (HIP events on the library's stream around `reps` back-to-back launches);
+    the median of `batches` such averages, so that one disturbed batch (another process touching the device) cannot skew it."""
+    vals = sorted(reg.time_eval_kernel(level, pose, method, True, reps) for _ in range(batches))
+    return vals[len(vals) // 2], vals
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,7 +161,7 @@ def main():
 
     if rank == 0:
         # ---- roofline of the dominant kernel: HIP events on the library's stream -----------------------------
-        kernel_us = reg.time_eval_kernel(0, pose_gpu, method, True, 50)
+        kernel_us, kernel_batches = avg_kernel_us(reg, 0, pose_gpu, method, 50)
         alg_bytes = BYTES_PER_PX[method] * n_px
         achieved = alg_bytes / (kernel_us * 1e-6) / 1e9
         traffic = None
@@ -168,13 +175,13 @@ def main():
                 traffic = None
         result["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "kernel": "k_eval<%d,true>" % method, "kernel_avg_us": kernel_us,
+            "traffic": traffic, "kernel": "k_eval<%d,true>" % method, "kernel_avg_us": kernel_us, "kernel_avg_us_batches": kernel_batches,
             "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_pixel": BYTES_PER_PX[method],
             "frac_of_measured_copy_peak": achieved / HBM_COPY_GBS,
         }
         # same kernel in photo+depth mode (configs[2]) for reference
         other = 2 if method == 0 else 0
-        k2 = reg.time_eval_kernel(0, pose_gpu, other, True, 50)
+        k2, _ = avg_kernel_us(reg, 0, pose_gpu, other, 50)
         result["roofline_other_method"] = {
             "method": METHOD_NAMES[other], "kernel_avg_us": k2,
             "achieved": BYTES_PER_PX[other] * n_px / (k2 * 1e-6) / 1e9,
@@ -195,7 +202,7 @@ def main():
             p4 = reg4.getOptimalPose()
             result["roofline_4096x2048"] = {}
             for m in (0, 2):
-                us = reg4.time_eval_kernel(0, p4, m, True, 30)
+                us, _ = avg_kernel_us(reg4, 0, p4, m, 30)
                 ach = BYTES_PER_PX[m] * 4096 * 2048 / (us * 1e-6) / 1e9
                 it = reg4.forced_iters(0, np.eye(4), m, 100)
                 result["roofline_4096x2048"][METHOD_NAMES[m]] = {
