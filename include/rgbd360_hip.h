@@ -121,6 +121,11 @@ int rgbd360_align360_finish(rgbd360_ctx* ctx, float pose_out[16], rgbd360_result
 int rgbd360_align360_batch(rgbd360_ctx* ctx, int n_frames, const uint8_t* const* rgb, size_t rgb_step, const void* const* depth,
                            size_t depth_step, int depth_type, int rows, int cols, const float guess[16], int method,
                            int occlusion, int n_inflight, float* poses_out, rgbd360_result* results_out);
+/* The same with every rgb[k] / depth[k] already in HBM on the context's device (as rgbd360_set_target_dev): no PCIe traffic
+ * inside the call; poses_out / results_out stay host arrays. */
+int rgbd360_align360_batch_dev(rgbd360_ctx* ctx, int n_frames, const uint8_t* const* rgb, size_t rgb_step, const void* const* depth,
+                               size_t depth_step, int depth_type, int rows, int cols, const float guess[16], int method,
+                               int occlusion, int n_inflight, float* poses_out, rgbd360_result* results_out);
 
 /* ---- stage-level entry points (parity tests and measurement) ------------------------------------------------ */
 

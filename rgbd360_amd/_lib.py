@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "librgbd360_hip.so")
 SYMBOLS = [
     "rgbd360_default_params", "rgbd360_create", "rgbd360_destroy", "rgbd360_last_error", "rgbd360_set_target",
     "rgbd360_set_source", "rgbd360_set_target_dev", "rgbd360_set_source_dev", "rgbd360_promote_source_to_target",
-    "rgbd360_align360", "rgbd360_align360_begin", "rgbd360_align360_finish", "rgbd360_align360_batch", "rgbd360_level_dims", "rgbd360_get_plane", "rgbd360_get_lut", "rgbd360_eval", "rgbd360_eval_occ",
+    "rgbd360_align360", "rgbd360_align360_begin", "rgbd360_align360_finish", "rgbd360_align360_batch", "rgbd360_align360_batch_dev", "rgbd360_level_dims", "rgbd360_get_plane", "rgbd360_get_lut", "rgbd360_eval", "rgbd360_eval_occ",
     "rgbd360_warp_indices", "rgbd360_gn_step", "rgbd360_forced_iters", "rgbd360_time_eval_kernel", "rgbd360_stream",
     "rgbd360_sync", "rgbd360_device_count", "rgbd360_sphere_cloud", "rgbd360_selftest_math", "rgbd360_time_solve_kernel", "rgbd360_normals", "rgbd360_distance_map",
     "rgbd360_plane_fit", "rgbd360_frame_planes", "rgbd360_load_frame_bin", "rgbd360_stitch_sphere",
@@ -64,6 +64,7 @@ def load() -> C.CDLL:
     L.rgbd360_align360_begin.argtypes = [vp, f32p, i32, i32]
     L.rgbd360_align360_finish.argtypes = [vp, f32p, C.POINTER(Result)]
     L.rgbd360_align360_batch.argtypes = [vp, i32, vp, C.c_size_t, vp, C.c_size_t, i32, i32, i32, f32p, i32, i32, i32, f32p, vp]
+    L.rgbd360_align360_batch_dev.argtypes = L.rgbd360_align360_batch.argtypes
     L.rgbd360_level_dims.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32)]
     L.rgbd360_get_plane.argtypes = [vp, i32, i32, f32p]
     L.rgbd360_get_lut.argtypes = [vp, i32, f32p]

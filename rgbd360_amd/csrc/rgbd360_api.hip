@@ -548,9 +548,9 @@ int rgbd360_align360(rgbd360_ctx* ctx, const float guess[16], int method, int oc
 // n_inflight contiguous sub-chunks, one context (own HIP stream) each; inside a sub-chunk frame j+1 is uploaded once and
 // promoted from source to target; in every step all live contexts are enqueued before any is waited for.
 // ---------------------------------------------------------------------------------------------------------
-int rgbd360_align360_batch(rgbd360_ctx* ctx, int n_frames, const uint8_t* const* rgb, size_t rgb_step, const void* const* depth,
-                           size_t depth_step, int depth_type, int rows, int cols, const float guess[16], int method,
-                           int occlusion, int n_inflight, float* poses_out, rgbd360_result* results_out) {
+static int align360_batch_impl(rgbd360_ctx* ctx, int n_frames, const uint8_t* const* rgb, size_t rgb_step, const void* const* depth,
+                               size_t depth_step, int depth_type, int rows, int cols, const float guess[16], int method,
+                               int occlusion, int n_inflight, float* poses_out, rgbd360_result* results_out, bool on_device) {
     if (!ctx) return -1;
     if (!rgb || !depth || !poses_out) return fail(ctx, -1, "null pointer");
     if (n_frames < 1) return fail(ctx, -1, "n_frames must be >= 1");
@@ -584,14 +584,14 @@ int rgbd360_align360_batch(rgbd360_ctx* ctx, int n_frames, const uint8_t* const*
     }
     auto propagate = [&](rgbd360_ctx* from, int rc) { return from == ctx ? rc : fail(ctx, rc, from->err.c_str()); };
     for (int c = 0; c < k_ctx; ++c) {
-        const int rc = rgbd360_set_target(cs[c], rgb[a[c]], rgb_step, depth[a[c]], depth_step, depth_type, rows, cols);
+        const int rc = set_frame(cs[c], true, rgb[a[c]], rgb_step, depth[a[c]], depth_step, depth_type, rows, cols, on_device);
         if (rc) return propagate(cs[c], rc);
     }
     for (int s = 0; s < steps; ++s) {
         for (int c = 0; c < k_ctx; ++c) {
             if (a[c] + s >= b[c]) continue;
             const int f = a[c] + s + 1;
-            int rc = rgbd360_set_source(cs[c], rgb[f], rgb_step, depth[f], depth_step, depth_type, rows, cols);
+            int rc = set_frame(cs[c], false, rgb[f], rgb_step, depth[f], depth_step, depth_type, rows, cols, on_device);
             if (!rc) rc = rgbd360_align360_begin(cs[c], g, method, occlusion);
             if (rc) {
                 for (int d = 0; d < c; ++d)          // drain what is already in flight
@@ -613,6 +613,19 @@ int rgbd360_align360_batch(rgbd360_ctx* ctx, int n_frames, const uint8_t* const*
         if (first_err) return propagate(err_ctx, first_err);
     }
     return 0;
+}
+
+int rgbd360_align360_batch(rgbd360_ctx* ctx, int n_frames, const uint8_t* const* rgb, size_t rgb_step, const void* const* depth,
+                           size_t depth_step, int depth_type, int rows, int cols, const float guess[16], int method,
+                           int occlusion, int n_inflight, float* poses_out, rgbd360_result* results_out) {
+    return align360_batch_impl(ctx, n_frames, rgb, rgb_step, depth, depth_step, depth_type, rows, cols, guess, method, occlusion,
+                               n_inflight, poses_out, results_out, false);
+}
+int rgbd360_align360_batch_dev(rgbd360_ctx* ctx, int n_frames, const uint8_t* const* rgb, size_t rgb_step, const void* const* depth,
+                               size_t depth_step, int depth_type, int rows, int cols, const float guess[16], int method,
+                               int occlusion, int n_inflight, float* poses_out, rgbd360_result* results_out) {
+    return align360_batch_impl(ctx, n_frames, rgb, rgb_step, depth, depth_step, depth_type, rows, cols, guess, method, occlusion,
+                               n_inflight, poses_out, results_out, true);
 }
 
 int rgbd360_level_dims(rgbd360_ctx* ctx, int level, int* rows, int* cols) {

@@ -267,6 +267,33 @@ class RegisterPhotoICP:
             iters[j] = [int(res[j].iters[l]) for l in range(self._p.n_pyr)]
         return poses, status, iters
 
+    def alignSequenceDev(self, rgb_ptrs, depth_ptrs, rows: int, cols: int, depth_type: int, method: int = 0, occlusion: int = 0,
+                         pose_guess=None, n_inflight: int = 2, rgb_step: int = 0, depth_step: int = 0):
+        """rgbd360_align360_batch_dev: like alignSequence with every frame already in HBM on this context's device.
+        rgb_ptrs / depth_ptrs: raw device pointers (e.g. torch_tensor.data_ptr()), row-major, steps in bytes (0 = packed)."""
+        from ._lib import Result
+        n = len(rgb_ptrs) - 1
+        poses = np.zeros((max(n, 0), 4, 4), np.float32)
+        status = np.zeros(max(n, 0), np.int32)
+        iters = np.zeros((max(n, 0), self._p.n_pyr), np.int32)
+        if n <= 0:
+            return poses, status, iters
+        if len(depth_ptrs) != len(rgb_ptrs):
+            raise Rgbd360Error("rgb_ptrs and depth_ptrs must have the same length")
+        rp = (C.c_void_p * len(rgb_ptrs))(*[int(x) for x in rgb_ptrs])
+        dp = (C.c_void_p * len(depth_ptrs))(*[int(x) for x in depth_ptrs])
+        out = np.zeros(n * 16, np.float32)
+        res = (Result * n)()
+        g = None if pose_guess is None else _ptr(pose_to_cm(pose_guess))
+        self._check(self._L.rgbd360_align360_batch_dev(self._ctx(), len(rgb_ptrs), rp, rgb_step or cols * 3, dp,
+                                                       depth_step or cols * (2 if depth_type == 0 else 4), int(depth_type), rows, cols,
+                                                       g, int(method), int(occlusion), int(n_inflight), _ptr(out), res))
+        for j in range(n):
+            poses[j] = pose_from_cm(out[16 * j:16 * j + 16])
+            status[j] = res[j].status
+            iters[j] = [int(res[j].iters[l]) for l in range(self._p.n_pyr)]
+        return poses, status, iters
+
     def getOptimalPose(self) -> np.ndarray:       # RPI.h:273
         return self._pose.copy()
 

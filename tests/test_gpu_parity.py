@@ -459,6 +459,25 @@ def test_native_batch_entry_equals_pairwise_alignment(hip_lib):
     one.setTargetFrame(*frames[2]); one.setSourceFrame(*frames[3])
     assert one.alignFrames360(np.eye(4), 2, 2) == s3[2]
     assert np.array_equal(one.getOptimalPose(), p3[2])
+    # frames already in HBM (device pointers from the same HIP runtime the library links): the same poses, no PCIe traffic in the call
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+
+    def to_device(a):
+        a = np.ascontiguousarray(a)
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), a.nbytes) == 0
+        assert hip.hipMemcpy(p, a.ctypes.data_as(C.c_void_p), a.nbytes, 1) == 0      # hipMemcpyHostToDevice
+        return p.value
+    rgb_d = [to_device(f[0]) for f in frames]
+    dep_d = [to_device(f[1]) for f in frames]
+    p4, s4, i4 = reg.alignSequenceDev(rgb_d, dep_d, 128, 256, 0, method=2, n_inflight=2)
+    for q in rgb_d + dep_d:
+        hip.hipFree(C.c_void_p(q))
+    assert np.array_equal(poses, p4) and np.array_equal(status, s4) and np.array_equal(iters, i4)
     # degenerate inputs
     assert reg.alignSequence(frames[:1])[0].shape == (0, 4, 4)
     from rgbd360_amd.register import Rgbd360Error

@@ -43,3 +43,26 @@ for k in (1, 2, 4):
     p3, st3, it3 = reg2.alignSequence(frames, method=2, n_inflight=k)
     dt = time.perf_counter() - t0
     print("PHOTO_DEPTH, rgbd360_align360_batch n_inflight=%d: %d pairs in %.2f ms -> %.0f alignments/s; identical poses: %s" % (k, n, dt * 1e3, n / dt, bool(np.array_equal(p3, ref_poses))))
+
+# frames resident in HBM (rgbd360_align360_batch_dev): the compute-side rate of the sequence path
+import ctypes as C
+hip = C.CDLL("libamdhip64.so")
+hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+
+
+def to_device(a):
+    a = np.ascontiguousarray(a)
+    p = C.c_void_p()
+    assert hip.hipMalloc(C.byref(p), a.nbytes) == 0 and hip.hipMemcpy(p, a.ctypes.data_as(C.c_void_p), a.nbytes, 1) == 0
+    return p.value
+
+
+rgb_d = [to_device(f[0]) for f in frames]
+dep_d = [to_device(f[1]) for f in frames]
+for k in (1, 2, 4):
+    reg2.alignSequenceDev(rgb_d, dep_d, H, W, 0, method=2, n_inflight=k)
+    t0 = time.perf_counter()
+    p4, st4, it4 = reg2.alignSequenceDev(rgb_d, dep_d, H, W, 0, method=2, n_inflight=k)
+    dt = time.perf_counter() - t0
+    print("PHOTO_DEPTH, rgbd360_align360_batch_dev n_inflight=%d: %d pairs in %.2f ms -> %.0f alignments/s; identical poses: %s" % (k, n, dt * 1e3, n / dt, bool(np.array_equal(p4, ref_poses))))
