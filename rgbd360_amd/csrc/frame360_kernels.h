@@ -306,6 +306,8 @@ constexpr int kAggThreads = 1024;
 constexpr int kAggPerThread = 4;
 constexpr int kAggHash = 64;
 constexpr double kMomScale = 16777216.0;      // 2^24 units per m (linear terms) / per m^2 (quadratic terms)
+constexpr int kMomReplicas = 16;              // copies of the global moment table (block b adds into copy b % 16): a wall is hit by
+                                              // every block it spans, and same-address global atomics serialise; the host adds the copies
 
 __device__ __forceinline__ long long wave_sum_ll(long long v) {
 #pragma unroll
@@ -392,37 +394,64 @@ __global__ void k_f360_assign(const int* __restrict__ label, const unsigned long
 // 9 raw moments per selected region (sum x, y, z, xx, xy, xz, yy, yz, zz) in 2^-24 fixed point, two's complement in u64
 __global__ __launch_bounds__(kAggThreads) void k_f360_moments(const float* __restrict__ xyz, const int* __restrict__ label,
                                                              const int* __restrict__ slot_of_root, int n,
-                                                             unsigned long long* __restrict__ mom) {
+                                                             unsigned long long* __restrict__ mom, int max_slots) {
     __shared__ int keys[kAggHash];
     __shared__ unsigned long long vals[kAggHash][9];
+    unsigned long long* mom_rep = mom + (size_t)(blockIdx.x % kMomReplicas) * max_slots * 9;
     if (threadIdx.x < kAggHash) {
         keys[threadIdx.x] = -1;
 #pragma unroll
         for (int k = 0; k < 9; ++k) vals[threadIdx.x][k] = 0ull;
     }
     __syncthreads();
-    const int base = blockIdx.x * kAggThreads * kAggPerThread;
+    // each thread owns kAggPerThread CONSECUTIVE pixels: inside a plane they share one slot, so their moments are summed in
+    // registers and the wave reduction + LDS insert runs once per 4 pixels (the cross-lane shuffles are what this kernel
+    // spends its time on).  A wave in which some thread straddles a region boundary takes the pixel-by-pixel path.
+    const int i0 = (blockIdx.x * kAggThreads + (int)threadIdx.x) * kAggPerThread;
+    int sl[kAggPerThread];
+    int key = -1;
+    bool mixed = false;
 #pragma unroll
     for (int j = 0; j < kAggPerThread; ++j) {
-        const int i = base + j * kAggThreads + (int)threadIdx.x;
-        int s = -1;
-        long long v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const int i = i0 + j;
+        int sj = -1;
         if (i < n) {
             const int l = label[i];
-            if (l >= 0) s = slot_of_root[l];
-            if (s >= 0) {
-                const double x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
-                v[0] = __double2ll_rn(x * kMomScale); v[1] = __double2ll_rn(y * kMomScale); v[2] = __double2ll_rn(z * kMomScale);
-                v[3] = __double2ll_rn(x * x * kMomScale); v[4] = __double2ll_rn(x * y * kMomScale); v[5] = __double2ll_rn(x * z * kMomScale);
-                v[6] = __double2ll_rn(y * y * kMomScale); v[7] = __double2ll_rn(y * z * kMomScale); v[8] = __double2ll_rn(z * z * kMomScale);
-            }
+            if (l >= 0) sj = slot_of_root[l];
         }
-        agg_add<9>(keys, vals, mom, s, v, s >= 0);
+        sl[j] = sj;
+        if (sj >= 0) {
+            if (key < 0) key = sj;
+            else if (sj != key) mixed = true;
+        }
+    }
+    // round-to-nearest-even double -> int64 for |v| < 2^51 by the 1.5 * 2^52 trick (one add + one integer subtract instead of
+    // the ~20-instruction conversion sequence; nine of these per pixel dominated the kernel)
+    auto d2ll = [](double v) -> long long { return __double_as_longlong(v + 6755399441055744.0) - 0x4338000000000000LL; };
+    auto moments_of = [&](int i, long long v[9]) {
+        const double x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
+        v[0] += d2ll(x * kMomScale); v[1] += d2ll(y * kMomScale); v[2] += d2ll(z * kMomScale);
+        v[3] += d2ll(x * x * kMomScale); v[4] += d2ll(x * y * kMomScale); v[5] += d2ll(x * z * kMomScale);
+        v[6] += d2ll(y * y * kMomScale); v[7] += d2ll(y * z * kMomScale); v[8] += d2ll(z * z * kMomScale);
+    };
+    if (__ballot(mixed) == 0ull) {
+        long long v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < kAggPerThread; ++j)
+            if (sl[j] >= 0) moments_of(i0 + j, v);
+        agg_add<9>(keys, vals, mom_rep, key, v, key >= 0);
+    } else {
+#pragma unroll
+        for (int j = 0; j < kAggPerThread; ++j) {
+            long long v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            if (sl[j] >= 0) moments_of(i0 + j, v);
+            agg_add<9>(keys, vals, mom_rep, sl[j], v, sl[j] >= 0);
+        }
     }
     __syncthreads();
     if (threadIdx.x < kAggHash && keys[threadIdx.x] >= 0) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) atomicAdd(&mom[(size_t)keys[threadIdx.x] * 9 + k], vals[threadIdx.x][k]);
+        for (int k = 0; k < 9; ++k) atomicAdd(&mom_rep[(size_t)keys[threadIdx.x] * 9 + k], vals[threadIdx.x][k]);
     }
 }
 

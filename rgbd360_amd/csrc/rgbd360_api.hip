@@ -1128,7 +1128,7 @@ int f360_ensure(rgbd360_ctx* ctx, size_t n) {
     HIPC(ctx, hipMalloc(&ctx->f_window, n * sizeof(int)));
     HIPC(ctx, hipMalloc(&ctx->f_root_of_slot, kF360MaxSlots * sizeof(int)));
     HIPC(ctx, hipMalloc(&ctx->f_nslots, sizeof(int)));
-    HIPC(ctx, hipMalloc(&ctx->f_mom, (size_t)kF360MaxSlots * 9 * sizeof(unsigned long long)));
+    HIPC(ctx, hipMalloc(&ctx->f_mom, (size_t)f360::kMomReplicas * kF360MaxSlots * 9 * sizeof(unsigned long long)));
     HIPC(ctx, hipMalloc(&ctx->f_count_of_slot, kF360MaxSlots * sizeof(int)));
     HIPC(ctx, hipMalloc(&ctx->f_depth_raw, n * 4));
     ctx->f360_n = n;
@@ -1196,7 +1196,7 @@ int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float
     HIPC(ctx, hipMemsetAsync(ctx->f_count, 0, (size_t)n * sizeof(unsigned long long), ctx->stream));
     HIPC(ctx, hipMemsetAsync(ctx->f_slot_of_root, 0xFF, (size_t)n * sizeof(int), ctx->stream));
     HIPC(ctx, hipMemsetAsync(ctx->f_nslots, 0, sizeof(int), ctx->stream));
-    HIPC(ctx, hipMemsetAsync(ctx->f_mom, 0, (size_t)kF360MaxSlots * 9 * sizeof(unsigned long long), ctx->stream));
+    HIPC(ctx, hipMemsetAsync(ctx->f_mom, 0, (size_t)f360::kMomReplicas * kF360MaxSlots * 9 * sizeof(unsigned long long), ctx->stream));
     hipLaunchKernelGGL(k_f360_ccl_rows, dim3(rows), dim3(kCclRowThreads), 0, ctx->stream, ctx->f_xyz, ctx->f_normals, rows, cols,
                        cosf(angular_threshold), distance_threshold, depth_mode, ctx->f_label, ctx->f_change);
     hipLaunchKernelGGL(k_f360_ccl_merge, grid2d(rows, cols), b, 0, ctx->stream, ctx->f_xyz, ctx->f_normals, ctx->f_change, rows, cols,
@@ -1206,7 +1206,7 @@ int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float
     hipLaunchKernelGGL(k_f360_count, gagg, bagg, 0, ctx->stream, ctx->f_label, n, ctx->f_count);
     hipLaunchKernelGGL(k_f360_assign, g1, b, 0, ctx->stream, ctx->f_label, ctx->f_count, n, min_inliers, kF360MaxSlots,
                        ctx->f_slot_of_root, ctx->f_root_of_slot, ctx->f_count_of_slot, ctx->f_nslots);
-    hipLaunchKernelGGL(k_f360_moments, gagg, bagg, 0, ctx->stream, ctx->f_xyz, ctx->f_label, ctx->f_slot_of_root, n, ctx->f_mom);
+    hipLaunchKernelGGL(k_f360_moments, gagg, bagg, 0, ctx->stream, ctx->f_xyz, ctx->f_label, ctx->f_slot_of_root, n, ctx->f_mom, kF360MaxSlots);
     HIPC(ctx, hipGetLastError());
     int nslots = 0;
     HIPC(ctx, hipMemcpyAsync(&nslots, ctx->f_nslots, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -1215,9 +1215,13 @@ int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float
     std::vector<int> roots(nslots), counts(nslots);
     std::vector<double> mom((size_t)nslots * 9);
     if (nslots > 0) {
-        std::vector<unsigned long long> raw((size_t)nslots * 9);
+        std::vector<unsigned long long> raw((size_t)nslots * 9, 0ull), rep((size_t)nslots * 9);
         HIPC(ctx, hipMemcpy(roots.data(), ctx->f_root_of_slot, nslots * sizeof(int), hipMemcpyDeviceToHost));
-        HIPC(ctx, hipMemcpy(raw.data(), ctx->f_mom, raw.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (int r = 0; r < f360::kMomReplicas; ++r) {         // integer sums: the order of the copies does not matter
+            HIPC(ctx, hipMemcpy(rep.data(), ctx->f_mom + (size_t)r * kF360MaxSlots * 9, rep.size() * sizeof(unsigned long long),
+                                hipMemcpyDeviceToHost));
+            for (size_t k = 0; k < raw.size(); ++k) raw[k] += rep[k];
+        }
         for (size_t k = 0; k < raw.size(); ++k) mom[k] = (double)(long long)raw[k] / kMomScale;     // fixed point -> metres
         HIPC(ctx, hipMemcpy(counts.data(), ctx->f_count_of_slot, nslots * sizeof(int), hipMemcpyDeviceToHost));
     }
