@@ -11,7 +11,7 @@
 //   k_f360_edges      depth-change map (computeFeature)                      1 B/px out
 //   k_f360_hdist      per-row distance to the nearest depth-change pixel     1 B/px
 //   k_f360_dist       chamfer (1 / 1.4) distance map, truncated at kF360R    4 B/px
-//   k_f360_normals_tiled  central differences + window-averaged gradients out of an LDS tile -> normal, flipped to the viewpoint
+//   k_f360_normals_tiled  central differences + per-tile integral images in LDS -> window-averaged gradients -> normal
 //   k_f360_ccl_rows / _merge / _compress   connected components: row runs by scan, vertical joins by union-find (atomicMin)
 //   k_f360_count / _assign / _moments      region sizes, compaction of the large regions, 9 moments per region
 #pragma once
@@ -85,23 +85,38 @@ __global__ void k_f360_dist(const uint8_t* __restrict__ hd, int rows, int cols, 
     dist[(size_t)r * cols + c] = best;
 }
 
-// Normal map, LDS-tiled: one block owns a 64 x 16 tile of normals.  The xyz tile (halo 7) is staged in LDS, the central
-// differences DX = p(r, c+1) - p(r, c-1), DY = p(r+1, c) - p(r-1, c) (initAverage3DGradientMethod; zero on the image border) of
-// the tile + halo 6 are formed from it ONCE and stored back as seven planes (DX xyz, DY xyz, packed validity; non-finite
-// differences stored as 0 and not counted), and every pixel then sums its rect x rect window out of LDS, rows outer, columns
-// inner.  Global traffic: 12 B/px in (+ halo), 12 B/px out.  (The first version was two kernels: differences written as 2 x 16 B/px
-// and a per-pixel gather of 2 x 16 B x rect^2 through L1 -- 270 us at 2048x1024 against 112 us now, bit-identical results.)
-constexpr int kNT_W = 64, kNT_H = 16, kNT_HALO = 6;
-constexpr int kNT_EW = kNT_W + 2 * kNT_HALO, kNT_EH = kNT_H + 2 * kNT_HALO;            // 76 x 28 entries of differences
-constexpr int kNT_XW = kNT_EW + 2, kNT_XH = kNT_EH + 2;                                // 78 x 30 points (one more ring)
-constexpr int kNT_PLANE = ((kNT_EW * kNT_EH + 63) / 64) * 64;                          // plane pitch, multiple of 64 dwords
+// Normal map from per-tile integral images in LDS (what pcl::IntegralImageNormalEstimation does globally, in double):
+// one block owns a 32 x 16 tile of normals.
+//   1. the xyz tile (halo 7) is staged in LDS;
+//   2. the central differences DX = p(r, c+1) - p(r, c-1), DY = p(r+1, c) - p(r-1, c) (initAverage3DGradientMethod; zero on
+//      the image border) of the tile + halo 6 are formed from it ONCE (registers);
+//   3. they overwrite the point tile as six float64 planes + one int32 plane of packed validity counts (non-finite differences
+//      enter as 0 and are not counted), laid out with a zero row / column in front;
+//   4. inclusive prefix sums along the rows, then along the columns, turn the seven planes into summed-area tables;
+//   5. every pixel obtains its rect x rect window sums from four corners per plane (28 LDS reads whatever the window size).
+// float64 tables keep the corner differences exact to ~1e-16 of the tile sum, like PCL's double integral images (the
+// oracle sums its windows in double too): the normals are BIT-IDENTICAL to the oracle's.  History at 2048x1024: two kernels with
+// per-pixel gathers through L1 270 us -> direct float32 window sums out of an LDS tile 112 us (1.8e-7 off the oracle) ->
+// integral images 88 us.
+constexpr int kNT_W = 32, kNT_H = 16, kNT_HALO = 6;       // 32 x 16: the tables take 71 KB, two blocks share a CU's 160 KB
+constexpr int kNT_EW = kNT_W + 2 * kNT_HALO, kNT_EH = kNT_H + 2 * kNT_HALO;            // 44 x 28 entries of differences
+constexpr int kNT_XW = kNT_EW + 2, kNT_XH = kNT_EH + 2;                                // 46 x 30 points (one more ring)
+constexpr int kNT_SW = kNT_EW + 3, kNT_SH = kNT_EH + 1;                                // table: zero column / row in front; odd pitch 47
+                                                                                       // (row scans: lane stride 47 doubles = all banks)
+constexpr int kNT_SPLANE = kNT_SW * kNT_SH;                                            // 47 x 29 entries per plane
 constexpr int kNT_THREADS = 256;
+constexpr int kNT_BX = 11, kNT_BY = 14;                                                // scan batch lengths
+static_assert(kNT_EW % kNT_BX == 0 && kNT_EH % kNT_BY == 0, "scan batches");
 static_assert(kNT_HALO * 2 >= kF360R, "window offsets span -rect/2 .. rect-rect/2-1 with rect <= kF360R");
+static_assert(6 * kNT_SPLANE * 8 + kNT_SPLANE * 4 <= 160 * 1024, "tables must fit the CU's LDS");
+static_assert(3 * kNT_XW * kNT_XH * 4 <= 6 * kNT_SPLANE * 8, "the point tile is staged inside the table storage");
 
 __global__ __launch_bounds__(kNT_THREADS) void k_f360_normals_tiled(const float* __restrict__ xyz, const float* __restrict__ dist,
                                                                    int rows, int cols, float smoothing_size, int depth_mode,
                                                                    float* __restrict__ normals, int* __restrict__ window) {
-    __shared__ float lds[7 * kNT_PLANE];              // phase 1: xyz tile (3 x 78 x 30 floats), phase 2: the seven planes
+    __shared__ double sat[6 * kNT_SPLANE];            // phase 1 also holds the xyz tile (3 x 46 x 30 floats)
+    __shared__ int satc[kNT_SPLANE];
+    float* pts = reinterpret_cast<float*>(sat);
     const int tid = threadIdx.x;
     const int c0 = blockIdx.x * kNT_W, r0 = blockIdx.y * kNT_H;
     // ---- phase 1: points of the tile + halo 7 (outside the image: NaN, never used by a pixel that produces a normal) ----
@@ -114,77 +129,168 @@ __global__ __launch_bounds__(kNT_THREADS) void k_f360_normals_tiled(const float*
             const float* p = xyz + 3 * ((size_t)r * cols + c);
             x = p[0]; y = p[1]; z = p[2];
         }
-        lds[3 * e] = x; lds[3 * e + 1] = y; lds[3 * e + 2] = z;
+        pts[3 * e] = x; pts[3 * e + 1] = y; pts[3 * e + 2] = z;
     }
     __syncthreads();
-    // ---- phase 2: differences of the tile + halo 6 into registers (PCL's initAverage3DGradientMethod) ----
+    // ---- phase 2: differences of the tile + halo 6 into registers ----
     constexpr int kPer = (kNT_EW * kNT_EH + kNT_THREADS - 1) / kNT_THREADS;
-    float d[kPer][7];
+    float d[kPer][6];
+    int fl[kPer];
 #pragma unroll
     for (int j = 0; j < kPer; ++j) {
         const int e = tid + j * kNT_THREADS;
-        float gx0 = 0.f, gx1 = 0.f, gx2 = 0.f, gy0 = 0.f, gy1 = 0.f, gy2 = 0.f, fl = 257.f;      // border of the image: valid zeros
+        float gx0 = 0.f, gx1 = 0.f, gx2 = 0.f, gy0 = 0.f, gy1 = 0.f, gy2 = 0.f;
+        int f = 257;                                  // border of the image: valid zeros for both differences
         if (e < kNT_EW * kNT_EH) {
             const int ey = e / kNT_EW, ex = e - ey * kNT_EW;
             const int r = r0 - kNT_HALO + ey, c = c0 - kNT_HALO + ex;
             if (r >= 1 && r < rows - 1 && c >= 1 && c < cols - 1) {
-                const float* pc = lds + 3 * ((ey + 1) * kNT_XW + (ex + 1));
+                const float* pc = pts + 3 * ((ey + 1) * kNT_XW + (ex + 1));
                 const float *pl = pc - 3, *pr = pc + 3, *pu = pc - 3 * kNT_XW, *pd = pc + 3 * kNT_XW;
                 gx0 = pr[0] - pl[0]; gx1 = pr[1] - pl[1]; gx2 = pr[2] - pl[2];
                 gy0 = pd[0] - pu[0]; gy1 = pd[1] - pu[1]; gy2 = pd[2] - pu[2];
                 const bool vx = finite3(gx0, gx1, gx2), vy = finite3(gy0, gy1, gy2);
                 if (!vx) gx0 = gx1 = gx2 = 0.f;
                 if (!vy) gy0 = gy1 = gy2 = 0.f;
-                fl = (vx ? 1.f : 0.f) + (vy ? 256.f : 0.f);
+                f = (vx ? 1 : 0) + (vy ? 256 : 0);
             }
         }
-        d[j][0] = gx0; d[j][1] = gx1; d[j][2] = gx2; d[j][3] = gy0; d[j][4] = gy1; d[j][5] = gy2; d[j][6] = fl;
+        d[j][0] = gx0; d[j][1] = gx1; d[j][2] = gx2; d[j][3] = gy0; d[j][4] = gy1; d[j][5] = gy2;
+        fl[j] = f;
     }
     __syncthreads();
-    // ---- phase 3: the seven planes overwrite the point tile ----
+    // ---- phase 3: the planes overwrite the point tile; entry (ex, ey) lives at table position (ex + 1, ey + 1) ----
+    for (int e = tid; e < kNT_SPLANE; e += kNT_THREADS) {         // zero row 0 and column 0 (and the unused pad columns)
+        const int sy = e / kNT_SW, sx = e - sy * kNT_SW;
+        if (sy == 0 || sx == 0 || sx > kNT_EW) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) sat[k * kNT_SPLANE + e] = 0.0;
+            satc[e] = 0;
+        }
+    }
 #pragma unroll
     for (int j = 0; j < kPer; ++j) {
         const int e = tid + j * kNT_THREADS;
         if (e < kNT_EW * kNT_EH) {
+            const int ey = e / kNT_EW, ex = e - ey * kNT_EW;
+            const int t = (ey + 1) * kNT_SW + (ex + 1);
 #pragma unroll
-            for (int k = 0; k < 7; ++k) lds[k * kNT_PLANE + e] = d[j][k];
+            for (int k = 0; k < 6; ++k) sat[k * kNT_SPLANE + t] = (double)d[j][k];
+            satc[t] = fl[j];
         }
     }
     __syncthreads();
-    // ---- phase 4: window sums; thread (tx, ty) handles column tx of rows ty, ty + 4, ty + 8, ty + 12 ----
-    const int tx = tid & (kNT_W - 1), ty = tid >> 6;
+    // this thread's output pixels: their point and distance-map value are fetched now, so that the global round trip runs
+    // under the scans
+    const int tx = tid % kNT_W, ty = tid / kNT_W;
+    constexpr int kRowsPerThread = kNT_H / (kNT_THREADS / kNT_W);
+    float ppx[kRowsPerThread], ppy[kRowsPerThread], ppz[kRowsPerThread], pdist[kRowsPerThread];
+#pragma unroll
+    for (int q = 0; q < kRowsPerThread; ++q) {
+        const int ci = c0 + tx, ri = r0 + ty + q * (kNT_THREADS / kNT_W);
+        ppx[q] = ppy[q] = ppz[q] = qnan;
+        pdist[q] = 0.f;
+        if (ci < cols && ri < rows) {
+            const size_t index = (size_t)ri * cols + ci;
+            ppx[q] = xyz[3 * index]; ppy[q] = xyz[3 * index + 1]; ppz[q] = xyz[3 * index + 2];
+            pdist[q] = dist[index];
+        }
+    }
+    // ---- phase 4: summed-area tables.  Rows: one thread per (plane, row); columns: one thread per (plane, column).  The
+    //      scans run in batches (all reads of a batch issued, then the adds, then the writes): with one block per CU there
+    //      is little else to hide an LDS round trip behind. ----
+    for (int t = tid; t < 7 * kNT_EH; t += kNT_THREADS) {
+        const int pl = t / kNT_EH, row = t - pl * kNT_EH + 1;
+        if (pl < 6) {
+            double* p = sat + pl * kNT_SPLANE + row * kNT_SW;
+            double acc = 0.0;
+            for (int x0 = 1; x0 <= kNT_EW; x0 += kNT_BX) {
+                double v[kNT_BX];
+#pragma unroll
+                for (int k = 0; k < kNT_BX; ++k) v[k] = p[x0 + k];
+#pragma unroll
+                for (int k = 0; k < kNT_BX; ++k) { acc += v[k]; v[k] = acc; }
+#pragma unroll
+                for (int k = 0; k < kNT_BX; ++k) p[x0 + k] = v[k];
+            }
+        } else {
+            int* p = satc + row * kNT_SW;
+            int acc = 0;
+            for (int x0 = 1; x0 <= kNT_EW; x0 += kNT_BX) {
+                int v[kNT_BX];
+#pragma unroll
+                for (int k = 0; k < kNT_BX; ++k) v[k] = p[x0 + k];
+#pragma unroll
+                for (int k = 0; k < kNT_BX; ++k) { acc += v[k]; v[k] = acc; }
+#pragma unroll
+                for (int k = 0; k < kNT_BX; ++k) p[x0 + k] = v[k];
+            }
+        }
+    }
+    __syncthreads();
+    for (int t = tid; t < 7 * kNT_EW; t += kNT_THREADS) {
+        const int pl = t / kNT_EW, col = t - pl * kNT_EW + 1;
+        if (pl < 6) {
+            double* p = sat + pl * kNT_SPLANE + col;
+            double acc = 0.0;
+            for (int y0 = 1; y0 <= kNT_EH; y0 += kNT_BY) {
+                double v[kNT_BY];
+#pragma unroll
+                for (int k = 0; k < kNT_BY; ++k) v[k] = p[(y0 + k) * kNT_SW];
+#pragma unroll
+                for (int k = 0; k < kNT_BY; ++k) { acc += v[k]; v[k] = acc; }
+#pragma unroll
+                for (int k = 0; k < kNT_BY; ++k) p[(y0 + k) * kNT_SW] = v[k];
+            }
+        } else {
+            int* p = satc + col;
+            int acc = 0;
+            for (int y0 = 1; y0 <= kNT_EH; y0 += kNT_BY) {
+                int v[kNT_BY];
+#pragma unroll
+                for (int k = 0; k < kNT_BY; ++k) v[k] = p[(y0 + k) * kNT_SW];
+#pragma unroll
+                for (int k = 0; k < kNT_BY; ++k) { acc += v[k]; v[k] = acc; }
+#pragma unroll
+                for (int k = 0; k < kNT_BY; ++k) p[(y0 + k) * kNT_SW] = v[k];
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 5: four corners per plane; thread (tx, ty) handles column tx of rows ty, ty + 8 ----
     const int border = (int)smoothing_size;
-    for (int ly = ty; ly < kNT_H; ly += kNT_THREADS / kNT_W) {
+#pragma unroll
+    for (int q = 0; q < kRowsPerThread; ++q) {
+        const int ly = ty + q * (kNT_THREADS / kNT_W);
         const int ci = c0 + tx, ri = r0 + ly;
         if (ci >= cols || ri >= rows) continue;
         const size_t index = (size_t)ri * cols + ci;
         float nx = qnan, ny = qnan, nz = qnan;
         int rect = 0;
         if (ri >= border && ri < rows - border && ci >= border && ci < cols - border) {
-            const float* p = xyz + 3 * index;
-            const float px = p[0], py = p[1], pz = p[2];
+            const float px = ppx[q], py = ppy[q], pz = ppz[q];
             const float depth = depth_mode == 0 ? pz : sqrtf(px * px + py * py + pz * pz);
             if (isfinite(depth)) {
-                const float smoothing = fminf(dist[index], smoothing_size + depth / 10.0f);
+                const float smoothing = fminf(pdist[q], smoothing_size + depth / 10.0f);
                 if (smoothing > 2.0f) {
                     rect = (int)smoothing;
+                    // window = entries [ex0, ex0 + rect) x [ey0, ey0 + rect); table corners are one position further (zero front)
                     const int ex0 = tx + kNT_HALO - rect / 2, ey0 = ly + kNT_HALO - rect / 2;
-                    float gx0 = 0.f, gx1 = 0.f, gx2 = 0.f, gy0 = 0.f, gy1 = 0.f, gy2 = 0.f, cnt = 0.f;
-                    for (int y = 0; y < rect; ++y) {
-                        const float* row = lds + (ey0 + y) * kNT_EW + ex0;
-                        for (int x = 0; x < rect; ++x) {
-                            gx0 += row[x]; gx1 += row[kNT_PLANE + x]; gx2 += row[2 * kNT_PLANE + x];
-                            gy0 += row[3 * kNT_PLANE + x]; gy1 += row[4 * kNT_PLANE + x]; gy2 += row[5 * kNT_PLANE + x];
-                            cnt += row[6 * kNT_PLANE + x];
-                        }
+                    const int a = ey0 * kNT_SW + ex0, b = a + rect, c = a + rect * kNT_SW, dd = c + rect;
+                    double g[6];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) {
+                        const double* t = sat + k * kNT_SPLANE;
+                        g[k] = (t[dd] - t[b]) - (t[c] - t[a]);
                     }
-                    const int icnt = (int)cnt;                       // exact: <= 144 * 257
+                    const int icnt = (satc[dd] - satc[b]) - (satc[c] - satc[a]);
                     if ((icnt & 255) > 0 && (icnt >> 8) > 0) {
-                        const float v0 = gy1 * gx2 - gy2 * gx1, v1 = gy2 * gx0 - gy0 * gx2, v2 = gy0 * gx1 - gy1 * gx0;
-                        const float len2 = v0 * v0 + v1 * v1 + v2 * v2;
-                        if (len2 != 0.f) {
-                            const float inv = 1.f / sqrtf(len2);
-                            nx = v0 * inv; ny = v1 * inv; nz = v2 * inv;
+                        // gradient_y x gradient_x in double, like the sums
+                        const double v0 = g[4] * g[2] - g[5] * g[1], v1 = g[5] * g[0] - g[3] * g[2], v2 = g[3] * g[1] - g[4] * g[0];
+                        const double len2 = v0 * v0 + v1 * v1 + v2 * v2;
+                        if (len2 != 0.0) {
+                            const double inv = 1.0 / sqrt(len2);
+                            nx = (float)(v0 * inv); ny = (float)(v1 * inv); nz = (float)(v2 * inv);
                             if ((-px) * nx + (-py) * ny + (-pz) * nz < 0.f) {
                                 nx = -nx; ny = -ny; nz = -nz;
                             }

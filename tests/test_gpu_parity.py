@@ -300,7 +300,9 @@ def test_normal_map_matches_oracle(hip_lib, oracle_mod, depth_mode):
     assert np.array_equal(np.isnan(nrm[:, 0]), np.isnan(ref[:, 0]))
     ok = ~np.isnan(ref[:, 0])
     assert ok.mean() > 0.3
-    assert np.abs(nrm[ok] - ref[ok]).max() < 2e-4      # float32 window sums vs the oracle's double sums
+    # per-tile integral images in float64 vs the oracle's float64 window sums: identical up to a rare 1-ulp rounding flip
+    assert np.abs(nrm[ok] - ref[ok]).max() <= 1.2e-7
+    assert (nrm[ok] == ref[ok]).mean() > 0.9999
     assert np.allclose(np.linalg.norm(nrm[ok], axis=1), 1.0, atol=1e-5)
     assert ((nrm[ok] * xyz[ok]).sum(1) <= 1e-4).all()  # flipped towards the viewpoint (origin)
 
