@@ -647,10 +647,12 @@ __device__ __forceinline__ bool lu_inverse6_lanes(const float* M /*LDS, column-m
                 float t = a[k]; a[k] = a[r]; a[r] = t;
                 t = ck[k]; ck[k] = ck[r]; ck[r] = t;
             }
-        // the five quotients are independent: their correctly rounded division sequences interleave
+        // multipliers l = c_r / c_k through ONE exact reciprocal per step (the five IEEE division sequences were the longest
+        // dependent chain of the kernel); l differs from the quotient by at most one rounding
+        const float rk = rcp_rn(ck[k]);
 #pragma unroll
         for (int r = k + 1; r < 6; ++r) {
-            const float l = ck[r] / ck[k];
+            const float l = ck[r] * rk;
             if (lane > k) a[r] -= l * a[k];
         }
     }
@@ -660,7 +662,7 @@ __device__ __forceinline__ bool lu_inverse6_lanes(const float* M /*LDS, column-m
         float sacc = a[r];
 #pragma unroll
         for (int c = r + 1; c < 6; ++c) sacc -= bcast(a[r], c) * x[c];
-        x[r] = sacc / bcast(a[r], r);
+        x[r] = sacc * rcp_rn(bcast(a[r], r));
     }
     return ok;
 }
@@ -763,7 +765,7 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(GNState* st_g, const do
     // write-back at the end; the single-lane bookkeeping below then never waits on global memory.
     __shared__ GNState sst;
     __shared__ double red[kSolveThreads / kNumPartials][kNumPartials];
-    __shared__ float shH[36], shM[36], shg[6], shInv[36], shE[16];
+    __shared__ float shH[36], shM[36], shInv[36], shE[16], shCand[16], shUpd[6];
     __shared__ int shGo, shRank, shLuOk;
     constexpr int kStateWords = sizeof(GNState) / 4;
     static_assert(sizeof(GNState) % 4 == 0 && kStateWords <= kSolveThreads, "GNState staging");
@@ -800,9 +802,77 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(GNState* st_g, const do
         for (int k = 0; k < Q; ++k) t += red[k][tid];
         sst.tot[tid] = t;
     }
+    // the damping the rank test will use, read while nobody writes the staged state (wave 0 updates first / lambda below)
+    const float lam_spec = (float)(sst.first ? sst.lambda : sst.lambda / 5.0);
     __syncthreads();
     GNState* st = &sst;
     const double* tot = sst.tot;
+    // ---- waves 1 and 2 start the 6x6 work speculatively, in parallel with the bookkeeping of wave 0: a step is only ever
+    //      computed from the H of THIS pass (go implies take, see below), and the damping of the rank test is known from the
+    //      state before the decision: lambda on the first pass of a level, lambda / 5 after an accepted step (a rejected
+    //      step ends the level, so its result is simply dropped).  RPI.h:4682, 4693, 4718 ----
+    if (cfg.mode == 0 && (wave == 1 || wave == 2)) {
+        float hval = 0.f;
+        if (lane < 36) {
+            const int r = lane / 6, c = lane - 6 * r;
+            const int aa = r < c ? r : c, bb = r < c ? c : r;
+            hval = (float)tot[P_H + (aa * (13 - aa)) / 2 + (bb - aa)];
+        }
+        if (wave == 1) {
+            if (lane < 36) shH[lane] = hval;
+            float x[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const bool ok = lu_inverse6_lanes(shH, lane, x);     // hessian.inverse()   RPI.h:4693
+            if (lane >= 6 && lane < 12) {
+#pragma unroll
+                for (int r = 0; r < 6; ++r) shInv[(lane - 6) * 6 + r] = x[r];
+            }
+            if (lane == 0) shLuOk = ok ? 1 : 0;
+            // update_pose = (-H^-1) * g, row `lane`, summed in column order; kept aside until wave 0 has decided (its test
+            // of the loop condition still reads the previous update)
+            float upd = 0.f;
+            if (lane < 6) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) upd += (-shInv[c * 6 + lane]) * (float)tot[P_G + c];
+                shUpd[lane] = upd;
+            }
+            // CPose3D::exp(update, true) (RPI.h:4697): every lane evaluates the two scalar coefficients, lane 4*j+i
+            // assembles element (i,j) of the 4x4
+            const double ux = (double)bcast(upd, 0), uy = (double)bcast(upd, 1), uz = (double)bcast(upd, 2);
+            const double wx = (double)bcast(upd, 3), wy = (double)bcast(upd, 4), wz = (double)bcast(upd, 5);
+            const double angle = sqrt(wx * wx + wy * wy + wz * wz);
+            double ca = 0.0, cb = 0.0;
+            const bool rot = angle >= 128 * 2.220446049250313e-16;
+            if (rot) gn::sinc_cosc(angle, ca, cb);
+            if (lane < 16) {
+                const int i = lane & 3, j = lane >> 2;
+                double e = (i == j) ? 1.0 : 0.0;
+                if (i < 3 && j < 3) {
+                    if (rot) {
+                        const double W[3][3] = {{0, -wz, wy}, {wz, 0, -wx}, {-wy, wx, 0}};
+                        double w2 = 0;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) w2 += W[i][k] * W[k][j];
+                        e += ca * W[i][j] + cb * w2;
+                    }
+                } else if (j == 3 && i < 3) {
+                    e = i == 0 ? ux : (i == 1 ? uy : uz);
+                }
+                shE[lane] = (float)e;
+            }
+            // pose_estim_temp = exp(...).cast<float>() * pose_estim: whenever a step is taken the pose it starts from is the
+            // candidate of this pass (accepted: pose := cand; first pass of a level: cand == pose)
+            if (lane < 16) {
+                const int c = lane >> 2, r = lane & 3;
+                const float* P = sst.cand;
+                shCand[lane] = ((shE[0 * 4 + r] * P[c * 4 + 0] + shE[1 * 4 + r] * P[c * 4 + 1]) + shE[2 * 4 + r] * P[c * 4 + 2]) +
+                               shE[3 * 4 + r] * P[c * 4 + 3];
+            }
+        } else {
+            if (lane < 36) shM[lane] = (lane % 7 == 0) ? hval + lam_spec * hval : hval;      // H + lambda diag(H)   RPI.h:4682
+            const int rk = qr_rank6_lanes(shM, lane);             // (H + lambda diag H).rank()   RPI.h:4682
+            if (lane == 0) shRank = rk;
+        }
+    }
     // ---- bookkeeping on wave 0: lane 0 takes the scalar decisions, lanes 0-41 move the 36 + 6 matrix entries ----
     if (wave == 0) {
         // normal equations at the evaluated pose (float like the reference's `hessian` / `gradient`): lane l < 36 owns
@@ -881,33 +951,16 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(GNState* st_g, const do
         if (go) {
             // a step is only ever computed right after its pose was taken, so hval is H / g at `pose`;
             // record them as "used" (what the reference's `hessian` / `SSO` members hold afterwards)
-            const float lam = (float)st->lambda;
             if (lane < 36) {
                 st->Hused[lane] = hval;
-                shH[lane] = hval;
-                shM[lane] = (lane % 7 == 0) ? hval + lam * hval : hval;      // H + lambda diag(H)   RPI.h:4682
             } else if (lane < 42) {
                 st->gused[lane - 36] = hval;
-                shg[lane - 36] = hval;
             }
         }
     }
     STAMP(1);
-    __syncthreads();
+    __syncthreads();            // bookkeeping (wave 0), inverse (wave 1) and rank (wave 2) are all done
     if (shGo) {
-        if (wave == 0) {
-            float x[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            const bool ok = lu_inverse6_lanes(shH, lane, x);     // hessian.inverse()   RPI.h:4693
-            if (lane >= 6 && lane < 12) {
-#pragma unroll
-                for (int r = 0; r < 6; ++r) shInv[(lane - 6) * 6 + r] = x[r];
-            }
-            if (lane == 0) shLuOk = ok ? 1 : 0;
-        } else if (wave == 1) {
-            const int rk = qr_rank6_lanes(shM, lane);             // (H + lambda diag H).rank()   RPI.h:4682
-            if (lane == 0) shRank = rk;
-        }
-        __syncthreads();
         STAMP(2);
         const bool ill = (shRank != 6) || !shLuOk;
         if (ill) {
@@ -915,47 +968,11 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(GNState* st_g, const do
                 st->status = 1;      // "The problem is ILL-POSED": relPose = pose_estim, return   RPI.h:4684-4689
                 st->done = 1;
             }
-        } else if (wave == 0) {
-            // update_pose = (-H^-1) * g, row `lane`, summed in column order
-            float upd = 0.f;
-            if (lane < 6) {
-#pragma unroll
-                for (int c = 0; c < 6; ++c) upd += (-shInv[c * 6 + lane]) * shg[c];
-                st->update[lane] = upd;
-            }
-            // CPose3D::exp(update, true) (RPI.h:4697): every lane evaluates the two scalar coefficients, lane 4*j+i
-            // assembles element (i,j) of the 4x4
-            const double ux = (double)bcast(upd, 0), uy = (double)bcast(upd, 1), uz = (double)bcast(upd, 2);
-            const double wx = (double)bcast(upd, 3), wy = (double)bcast(upd, 4), wz = (double)bcast(upd, 5);
-            const double angle = sqrt(wx * wx + wy * wy + wz * wz);
-            double ca = 0.0, cb = 0.0;
-            const bool rot = angle >= 128 * 2.220446049250313e-16;
-            if (rot) gn::sinc_cosc(angle, ca, cb);
-            if (lane < 16) {
-                const int i = lane & 3, j = lane >> 2;
-                double e = (i == j) ? 1.0 : 0.0;
-                if (i < 3 && j < 3) {
-                    if (rot) {
-                        const double W[3][3] = {{0, -wz, wy}, {wz, 0, -wx}, {-wy, wx, 0}};
-                        double w2 = 0;
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) w2 += W[i][k] * W[k][j];
-                        e += ca * W[i][j] + cb * w2;
-                    }
-                } else if (j == 3 && i < 3) {
-                    e = i == 0 ? ux : (i == 1 ? uy : uz);
-                }
-                shE[lane] = (float)e;
-            }
+        } else if (tid < 16) {
+            sst.cand[tid] = shCand[tid];
+            if (tid < 6) sst.update[tid] = shUpd[tid];
         }
         STAMP(3);
-        __syncthreads();
-        if (tid < 16 && !ill) {   // pose_estim_temp = exp(...).cast<float>() * pose_estim
-            const int c = tid >> 2, r = tid & 3;
-            const float* P = sst.pose;
-            sst.cand[tid] = ((shE[0 * 4 + r] * P[c * 4 + 0] + shE[1 * 4 + r] * P[c * 4 + 1]) + shE[2 * 4 + r] * P[c * 4 + 2]) +
-                            shE[3 * 4 + r] * P[c * 4 + 3];
-        }
         __syncthreads();
     }
 #ifdef RGBD360_SOLVE_STAMPS
