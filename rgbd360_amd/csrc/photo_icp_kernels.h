@@ -707,11 +707,13 @@ __device__ __forceinline__ int qr_rank6_lanes(const float* M /*LDS, column-major
             stopped = true;
         }
         if (!stopped) {
-            // swap columns k and best
+            // swap columns k and best (wave-uniform test: usually nothing to swap)
+            if (best != k) {
 #pragma unroll
-            for (int r = 0; r < 6; ++r) {
-                const float from_best = bcast(a[r], best), from_k = bcast(a[r], k);
-                a[r] = (lane == k) ? from_best : ((lane == best) ? from_k : a[r]);
+                for (int r = 0; r < 6; ++r) {
+                    const float from_best = bcast(a[r], best), from_k = bcast(a[r], k);
+                    a[r] = (lane == k) ? from_best : ((lane == best) ? from_k : a[r]);
+                }
             }
             float ck[6];
 #pragma unroll
@@ -726,11 +728,14 @@ __device__ __forceinline__ int qr_rank6_lanes(const float* M /*LDS, column-major
                 tau = 0.f;
                 beta = c0;
             } else {
-                beta = sqrtf(c0 * c0 + tailSq);
+                // exact sqrt / reciprocals in 6 / 3 instructions (sqrt_rn, rcp_rn); the quotients become products with an exact
+                // reciprocal (one extra rounding each, far below the rank thresholds)
+                beta = sqrt_rn(c0 * c0 + tailSq);
                 if (c0 >= 0.f) beta = -beta;
+                const float rden = rcp_rn(c0 - beta);
 #pragma unroll
-                for (int r = k + 1; r < 6; ++r) v[r] = ck[r] / (c0 - beta);
-                tau = (beta - c0) / beta;
+                for (int r = k + 1; r < 6; ++r) v[r] = ck[r] * rden;
+                tau = (beta - c0) * rcp_rn(beta);
             }
             v[k] = 1.f;
             float dot = 0.f;
