@@ -980,6 +980,23 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(GNState* st_g, const do
         STAMP(3);
         __syncthreads();
     }
+    // A level that has just finished hands over to the next finer one right here (RPI.h:4590-4604: it = 0, update = (1,..,1),
+    // lambda = 1, first pass at the pose reached so far): the next launch in the queue, tagged with that level, finds it
+    // active -- no separate initialisation launch between levels.
+    if (cfg.mode == 0 && !cfg.forced && cfg.level > 0 && sst.done && sst.status == 0) {      // uniform
+        __syncthreads();
+        if (tid < 16) sst.cand[tid] = sst.pose[tid];
+        if (tid < 6) sst.update[tid] = 1.f;
+        if (tid == 0) {
+            sst.level_active = cfg.level - 1;
+            sst.lambda = 1.0;
+            sst.it = 0;
+            sst.first = 1;
+            sst.done = 0;
+            sst.error = sst.new_error = sst.diff_error = 0.0;
+        }
+        __syncthreads();
+    }
 #ifdef RGBD360_SOLVE_STAMPS
     if (tid == 0) {
         stamp[4] = __builtin_amdgcn_s_memrealtime() - stamp0;

@@ -472,8 +472,8 @@ int rgbd360_promote_source_to_target(rgbd360_ctx* ctx) {
 static void enqueue_schedule(rgbd360_ctx* ctx, int pending, bool pending_started) {
     const int top = ctx->p.n_pyr - 1;
     for (int level = pending; level >= 0; --level) {
-        if (!(level == pending && pending_started))
-            launch_level_init(ctx, level, level == top ? ctx->al_guess : nullptr, level == top ? 1 : 0);
+        if (level == top && !pending_started)        // the finer levels are entered by k_solve itself when a level finishes
+            launch_level_init(ctx, level, ctx->al_guess, 1);
         const int n_pairs = (level == top && !pending_started) ? ctx->first_chunk_top : (level == 0 ? ctx->chunk_level0 : ctx->poll_chunk);
         for (int k = 0; k < n_pairs; ++k) {
             launch_eval(ctx, level, ctx->al_method, true, ctx->al_occ);
