@@ -853,11 +853,23 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(GNState* st_g, const do
                 double e = (i == j) ? 1.0 : 0.0;
                 if (i < 3 && j < 3) {
                     if (rot) {
-                        const double W[3][3] = {{0, -wz, wy}, {wz, 0, -wx}, {-wy, wx, 0}};
-                        double w2 = 0;
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) w2 += W[i][k] * W[k][j];
-                        e += ca * W[i][j] + cb * w2;
+                        // W = skew(w), W2 = W W, element (i, j), written with selects: a W[i][k] lookup with a per-lane index puts
+                        // the matrix into scratch memory (the only scratch use of the whole library).  Off the diagonal
+                        // W2_ij = w_i w_j and W_ij = -/+ w_k (k the third index); on it W2_ii = -(w_a^2) - (w_b^2), added in the
+                        // order of the matrix product.
+                        const double wi = i == 0 ? wx : (i == 1 ? wy : wz), wj = j == 0 ? wx : (j == 1 ? wy : wz);
+                        const int kk = 3 - i - j;
+                        const double wk = kk == 0 ? wx : (kk == 1 ? wy : wz);
+                        double Wij, W2ij;
+                        if (i == j) {
+                            Wij = 0.0;
+                            const double first = i == 2 ? wy : wz, second = i == 0 ? wy : wx;      // k ascending, k != i
+                            W2ij = (0.0 - first * first) - second * second;
+                        } else {
+                            Wij = ((j - i + 3) % 3 == 1) ? -wk : wk;
+                            W2ij = wi * wj;
+                        }
+                        e += ca * Wij + cb * W2ij;
                     }
                 } else if (j == 3 && i < 3) {
                     e = i == 0 ? ux : (i == 1 ? uy : uz);

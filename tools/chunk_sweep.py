@@ -19,7 +19,7 @@ t0 = time.perf_counter()
 p, s, it = reg.alignSequence(frames, method=2, n_inflight=2)
 print("sequence %%.0f alignments/s, mean iters %%s" %% (8 / (time.perf_counter() - t0), it.mean(0).round(2).tolist()))
 ''' % ROOT
-for l0, poll, first in ((3, 3, 8), (6, 3, 8), (8, 3, 8), (8, 4, 8), (5, 3, 6), (8, 2, 6)):
+for l0, poll, first in ((3, 3, 8), (3, 3, 4), (3, 3, 3), (4, 3, 4), (3, 2, 3), (4, 4, 4), (3, 3, 6)):
     env = dict(os.environ, RGBD360_L0_CHUNK=str(l0), RGBD360_POLL_CHUNK=str(poll), RGBD360_FIRST_CHUNK=str(first))
     r = subprocess.run([sys.executable, "-c", CHILD], capture_output=True, text=True, env=env)
     print("L0 %d poll %d first %d | %s" % (l0, poll, first, r.stdout.strip() or r.stderr.strip()[-300:]))
