@@ -232,6 +232,42 @@ def test_full_size_2048x1024(hip_lib, oracle_mod, method):
     assert abs(e["err2"] - err2) <= ERR2_RTOL * err2
 
 
+def test_full_size_4096x2048_with_planes(hip_lib, oracle_mod):
+    """BASELINE.json configs[4] at full size: 4096x2048 photo+depth alignment (5 levels) against the oracle -- identical
+    iteration counts, exact pixel counts, pose within the device tolerance -- plus the Frame360 stages on the same frame:
+    cloud and region labels bit-exact, normal map equal to the oracle's."""
+    pair = synth.make_pair(4096, 2048, seed=1234)
+    reg, ora, T = _pair_ctx(hip_lib, oracle_mod, pair, n_pyr=5)
+    rc = reg.alignFrames360(np.eye(4), 2)
+    st, pose_ref = ora.align360(np.eye(4), 2)
+    assert rc == st == 0
+    assert reg.num_iterations == list(ora.result.iters)[:5]
+    rot, trans = synth.pose_error(reg.getOptimalPose(), pose_ref)
+    assert rot <= POSE_TOL_DEV and trans <= POSE_TOL_DEV, (rot, trans)
+    rot_gt, trans_gt = synth.pose_error(reg.getOptimalPose(), T)
+    assert rot_gt < 2e-4 and trans_gt < 1e-3, (rot_gt, trans_gt)
+    e = reg.eval(0, pose_ref, 2)
+    _, err2, nvalid = ora.error(0, pose_ref, 2)
+    H, g, Hd, gd, nvis = ora.hessgrad(0, pose_ref, 2)
+    assert e["n_valid"] == nvalid and e["n_visible"] == nvis
+    assert abs(e["err2"] - err2) <= ERR2_RTOL * err2
+    assert np.abs(e["H64"] - Hd).max() <= HG_RTOL * np.abs(Hd).max()
+    # Frame360 stages on the target frame
+    from rgbd360_amd.register import Frame360Stages
+    (rgbA, dA) = pair[0]
+    st360 = Frame360Stages(reg)
+    out = st360.frame_planes(dA, convention=2, angular_threshold=0.03)
+    xyz = oracle_mod.sphere_cloud(dA, 2)
+    assert np.array_equal(np.nan_to_num(xyz), np.nan_to_num(out["xyz"]))
+    nrm, _ = oracle_mod.f360_normals(xyz, 2048, 4096, 0.05, 8.0, 1)
+    ok = ~np.isnan(nrm[:, 0])
+    assert np.array_equal(np.isnan(out["normals"][:, 0]), ~ok)
+    assert np.abs(out["normals"][ok] - nrm[ok]).max() <= 1.2e-7 and (out["normals"][ok] == nrm[ok]).mean() > 0.9999
+    labels, planes = oracle_mod.f360_plane_segment(xyz, out["normals"], 2048, 4096, 40, 0.03, 0.05, 0.001, 1)
+    assert np.array_equal(np.asarray(out["labels"]).reshape(-1), np.asarray(labels).reshape(-1))
+    assert len(out["planes"]) == len(planes) >= 6
+
+
 def test_sequence_batch_matches_pairwise_alignment(hip_lib, oracle_mod):
     """BASELINE.json config 4 in miniature: a chunk of an odometry sequence aligned with frame reuse
     (promoteSourceToTarget) gives the same poses as aligning every pair from scratch, and as the oracle."""
