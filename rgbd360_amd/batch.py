@@ -73,6 +73,16 @@ def align_sequence_concurrent(regs, get_frame, lo: int, hi: int, method: int, gu
     return poses, status, iters
 
 
+def align_sequence_native(reg, get_frame, lo: int, hi: int, method: int, guess=None, n_inflight: int = 2, occlusion: int = 0):
+    """Same result as align_sequence through ONE call of the C ABI (rgbd360_align360_batch): the frames lo..hi of the chunk
+    are handed over together, the library walks them with n_inflight contexts in flight and no Python between the pairs."""
+    n = hi - lo
+    if n <= 0:
+        return np.zeros((0, 4, 4), np.float32), np.zeros(0, np.int32), np.zeros((0, reg.nPyrLevels), np.int32)
+    frames = [get_frame(k) for k in range(lo, hi + 1)]
+    return reg.alignSequence(frames, method=method, occlusion=occlusion, pose_guess=guess, n_inflight=n_inflight)
+
+
 def gather_poses(local_poses: np.ndarray, n_total: int, dist=None, device=None):
     """All-gather of the per-rank pose blocks into the full [n_total,4,4] array on every rank."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:

@@ -492,6 +492,9 @@ def test_native_batch_entry_equals_pairwise_alignment(hip_lib):
     for k in (1, 2, 3):
         p2, s2, i2 = reg.alignSequence(frames, method=2, n_inflight=k)
         assert np.array_equal(poses, p2) and np.array_equal(status, s2) and np.array_equal(iters, i2), k
+    from rgbd360_amd.batch import align_sequence_native
+    pn, sn, inn = align_sequence_native(reg, lambda k: frames[k], 1, 4, 2, n_inflight=2)
+    assert np.array_equal(pn, poses[1:4]) and np.array_equal(sn, status[1:4]) and np.array_equal(inn, iters[1:4])
     p3, s3, i3 = reg.alignSequence(frames, method=2, occlusion=2, n_inflight=2)
     one = _mk(hip_lib, 3)
     one.setTargetFrame(*frames[2]); one.setSourceFrame(*frames[3])
