@@ -208,3 +208,119 @@ def error_and_hg(fr, level, pose, method, sigma_p=F(6.0 / 255), sigma_d=F(0.2), 
         H += np.einsum("ni,nj->ij", J[ok], J[ok], dtype=np.float64)
         g += J[ok].astype(np.float64).T @ werr[ok].astype(np.float64)
     return err2, nvalid, H, g, int(vis.sum())
+
+
+# ---- occlusion-aware error passes (sequential semantics of RPI.h:3232-3367 and 3720-3856) -----------------------------
+def _prefix_maxima(target, key, order_index):
+    """For candidates landing on `target` pixels, visited in `order_index` order: flag those whose key is >= every earlier
+    key on the same target (the ones that pass `if (buf > 0 && key < buf) continue; buf = key`), and flag the final owner of
+    each target's buffer (the last flagged one)."""
+    order = np.lexsort((order_index, target))
+    t, k = target[order], key[order]
+    pm = np.ones(len(order), bool)
+    owner = np.zeros(len(order), bool)
+    start = 0
+    n = len(order)
+    bounds = np.nonzero(np.diff(t))[0] + 1
+    for end in list(bounds) + [n]:
+        if end - start == 1:
+            owner[start] = True
+        else:
+            run = np.maximum.accumulate(k[start:end])
+            prev = np.concatenate(([F(0)], run[:-1]))
+            pm[start:end] = k[start:end] >= prev
+            owner[start + np.nonzero(pm[start:end])[0][-1]] = True
+        start = end
+    out_pm = np.zeros(n, bool); out_owner = np.zeros(n, bool)
+    out_pm[order] = pm; out_owner[order] = owner
+    return out_pm, out_owner
+
+
+def occ_error(fr, level, pose, method, occ, sigma_p=F(6.0 / 255), sigma_d=F(0.2), thr_p=F(0.01), thr_d=F(0.01),
+              thr_outlier=F(0.3)):
+    """(sum photo, sum depth, n photo, n depth) of errorPhotoICP_sphereOcc1 (occ = 1) / ...Occ2 (occ = 2)."""
+    w = warp(fr, level, pose)
+    idx = np.nonzero(w["vis"])[0]
+    r, c = w["r"][idx], w["c"][idx]
+    dist, dinv = w["dist"][idx], w["dist_inv"][idx]
+    d2 = fr.dep_t[level][r, c]
+    if occ == 2:                                   # depth-outlier gate before the z-buffer (RPI.h:3788-3791)
+        with np.errstate(invalid="ignore"):
+            keep = ~(np.abs((d2 - dist).astype(F)) > thr_outlier)
+        idx, r, c, dist, dinv, d2 = idx[keep], r[keep], c[keep], dist[keep], dinv[keep], d2[keep]
+    target = r * w["cols"] + c
+    pm, owner = _prefix_maxima(target, dinv, idx)
+    gx, gy = fr.gx[level][r, c], fr.gy[level][r, c]
+    sal_p = ~((np.abs(gx) < thr_p) & (np.abs(gy) < thr_p))
+    dgx, dgy = fr.dgx[level][r, c], fr.dgy[level][r, c]
+    sal_d = ~((np.abs(dgx) < thr_d) & (np.abs(dgy) < thr_d))
+    diff_p = (fr.gray_t[level][r, c] - fr.gray_s[level].ravel()[idx]).astype(F)
+    wp = (huber(diff_p, sigma_p).astype(np.float64) * (1.0 / np.float64(sigma_p)) * diff_p.astype(np.float64)).astype(F)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        diff_d = (d2 - dist).astype(F)
+        sd = (sigma_d * d2).astype(F)
+        wd = ((huber(diff_d, sd).astype(np.float64) / sd.astype(np.float64)) * diff_d.astype(np.float64)).astype(F)
+    use_p = method in (0, 2)
+    use_d = method in (1, 2)
+    ok_p = sal_p if use_p else np.zeros(len(idx), bool)
+    ok_d = np.isfinite(d2) & sal_d & (sal_p if method == 2 else True) if use_d else np.zeros(len(idx), bool)
+    sq = lambda v: (v * v).astype(F).astype(np.float64)
+    if occ == 1:        # residual per TARGET: the owner's; counters: every prefix maximum
+        return (float(sq(wp[owner & ok_p]).sum()), float(sq(wd[owner & ok_d]).sum()), int((pm & ok_p).sum()), int((pm & ok_d).sum()))
+    n = int(pm.sum())   # occ 2: residual per SOURCE pixel, never retracted; both averages over the accepted pixels
+    return (float(sq(wp[pm & ok_p]).sum()), float(sq(wd[pm & ok_d]).sum()), n, n)
+
+
+def occ2_visible(fr, level, pose, thr_outlier=F(0.3)):
+    """numVisiblePixels of calcHessGrad_sphereOcc2: distinct target pixels hit by a gated source pixel (RPI.h:3981-3982)."""
+    w = warp(fr, level, pose)
+    idx = np.nonzero(w["vis"])[0]
+    r, c = w["r"][idx], w["c"][idx]
+    with np.errstate(invalid="ignore"):
+        keep = ~(np.abs((fr.dep_t[level][r, c] - w["dist"][idx]).astype(F)) > thr_outlier)
+    return len(np.unique((r * w["cols"] + c)[keep]))
+
+
+# ---- pinhole single-sensor error pass (RPI.h:560-748, else-branch) --------------------------------------------------------
+def pinhole_error(fr, level, pose, K, method, sigma_p=F(6.0 / 255), sigma_d=F(0.2)):
+    """(sum photo, sum depth, n photo, n depth): every valid, visible source pixel, no saliency test."""
+    d = fr.dep_s[level]
+    rows, cols = d.shape
+    s = F(1.0 / 2 ** level)
+    fx, fy, ox, oy = (F(K[0]) * s, F(K[1]) * s, F(K[2]) * s, F(K[3]) * s)
+    valid = ((fr.dmin < d) & (d < fr.dmax)).ravel()
+    cc, rr = np.meshgrid(np.arange(cols).astype(F), np.arange(rows).astype(F))
+    z = d.ravel()
+    x = ((cc.ravel() - ox) * z * F(1.0 / np.float64(fx))).astype(F)
+    y = ((rr.ravel() - oy) * z * F(1.0 / np.float64(fy))).astype(F)
+    R = np.asarray(pose, F)[:3, :3]
+    t = np.asarray(pose, F)[:3, 3]
+    X = ((R[0, 0] * x + R[0, 1] * y) + R[0, 2] * z) + t[0]
+    Y = ((R[1, 0] * x + R[1, 1] * y) + R[1, 2] * z) + t[1]
+    Z = ((R[2, 0] * x + R[2, 1] * y) + R[2, 2] * z) + t[2]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        iz = (1.0 / Z.astype(np.float64)).astype(F)
+        tc = ((X * fx) * iz + ox).astype(F)
+        tr = ((Y * fy) * iz + oy).astype(F)
+        rnd = lambda v: np.where(np.isfinite(v), np.sign(v) * np.floor(np.abs(v.astype(np.float64)) + 0.5), -1).astype(np.int64)
+        ri, ci = rnd(tr), rnd(tc)
+    vis = valid & (ri >= 0) & (ri < rows) & (ci >= 0) & (ci < cols)
+    idx = np.nonzero(vis)[0]
+    r, c = ri[idx], ci[idx]
+    sq = lambda v: (v * v).astype(F).astype(np.float64)
+    sp = sd_ = 0.0
+    n_p = n_d = 0
+    if method in (0, 2):
+        diff = (fr.gray_t[level][r, c] - fr.gray_s[level].ravel()[idx]).astype(F)
+        we = ((huber(diff, sigma_p) * F(1.0 / np.float64(sigma_p))).astype(F) * diff).astype(F)
+        sp, n_p = float(sq(we).sum()), len(idx)
+    if method in (1, 2):
+        d2 = fr.dep_t[level][r, c]
+        fin = np.isfinite(d2)
+        depth1 = Z[idx]
+        with np.errstate(invalid="ignore", divide="ignore"):
+            diff = (d2 - depth1).astype(F)
+            sdev = (sigma_d * depth1).astype(F)
+            we = ((huber(diff, sdev) / sdev).astype(F) * diff).astype(F)
+        sd_, n_d = float(sq(we[fin]).sum()), int(fin.sum())
+    return sp, sd_, n_p, n_d

@@ -1,6 +1,7 @@
 """CPU tests of the oracle (no GPU): golden fixtures, an independent numpy restatement, analytic known answers."""
 import json
 import os
+import sys
 import zlib
 
 import numpy as np
@@ -455,3 +456,51 @@ def test_oracle_pinhole_matches_golden(golden, oracle_mod, math_mode, method):
     assert abs(e[1] - g["sum_photo"]) <= 1e-9 * max(1.0, g["sum_photo"]) and abs(e[2] - g["sum_depth"]) <= 1e-9 * max(1.0, g["sum_depth"])
     H, gg, Hd, gd, nrows = ora.hessgrad_pinhole(1, T, method)
     assert nrows == g["n_rows"] and np.allclose(Hd, np.array(g["H64"]), rtol=1e-9)
+
+
+@pytest.mark.parametrize("occlusion", [1, 2])
+def test_numpy_restatement_agrees_on_occlusion_passes(oracle_mod, occlusion):
+    """The occlusion error passes against the independent numpy restatement (group-by-target prefix maxima instead of a
+    z-buffer swept in pixel order)."""
+    sys.path.insert(0, HERE)
+    import np_restatement as NP
+    (rgbA, dA), (rgbB, dB), T = synth.add_occluder(synth.make_pair(128, 64, seed=99))
+    ora = oracle_mod.Oracle(n_pyr=2, reduce_mode=1)
+    ora.set_target(rgbA, dA)
+    ora.set_source(rgbB, dB)
+    fr = NP.Frames(rgbA, dA, rgbB, dB, n_pyr=2)
+    conflicts = 0
+    for level in range(2):
+        for pose in synth.occlusion_test_poses(T):
+            for method in (0, 1, 2):
+                _, sp, sd, n_p, n_d = ora.error_occ(level, pose, method, occlusion)
+                a, b, c, d = NP.occ_error(fr, level, pose, method, occlusion)
+                if method in (0, 2):
+                    assert abs(c - n_p) <= max(3, 2e-3 * n_p), (level, method, c, n_p)
+                    assert abs(a - sp) <= 5e-3 * max(sp, 1.0)
+                if method in (1, 2):
+                    assert abs(d - n_d) <= max(3, 2e-3 * n_d), (level, method, d, n_d)
+                    assert abs(b - sd) <= 5e-3 * max(sd, 1.0)
+            if occlusion == 2:
+                nv = ora.hessgrad_occ(level, pose, 2, 2)[4]
+                assert abs(NP.occ2_visible(fr, level, pose) - nv) <= 3
+                conflicts += int(nv != ora.hessgrad(level, pose, 2)[4])
+            else:
+                conflicts += int(ora.error_occ(level, pose, 2, 1)[3] != ora.error(level, pose, 0)[2])
+    assert conflicts > 0            # the scene does exercise the z-buffer
+
+
+def test_numpy_restatement_agrees_on_pinhole_error(oracle_mod):
+    sys.path.insert(0, HERE)
+    import np_restatement as NP
+    (rgbA, dA), (rgbB, dB), T, K = synth.make_pinhole_pair(160, 120, seed=5)
+    ora = oracle_mod.Oracle(n_pyr=2, reduce_mode=1, mask_seams=0)
+    ora.set_camera(*K); ora.set_target(rgbA, dA); ora.set_source(rgbB, dB)
+    fr = NP.Frames(rgbA, dA, rgbB, dB, n_pyr=2, mask=False)
+    for level in range(2):
+        for pose in (np.eye(4), T):
+            for method in (0, 1, 2):
+                _, sp, sd, n_p, n_d = ora.error_pinhole(level, pose, method)
+                a, b, c, d = NP.pinhole_error(fr, level, pose, K, method)
+                assert abs(c - n_p) <= max(3, 2e-3 * n_p) and abs(d - n_d) <= max(3, 2e-3 * n_d), (level, method, c, n_p, d, n_d)
+                assert abs(a - sp) <= 5e-3 * max(sp, 1.0) and abs(b - sd) <= 5e-3 * max(sd, 1.0)
