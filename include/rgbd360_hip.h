@@ -2,8 +2,9 @@
  * rgbd360_hip.h -- C ABI of the MI355X (gfx950) dense spherical RGB-D alignment library.
  *
  * Drop-in boundary for ONE path of EduFdez/rgbd360: RegisterPhotoICP's spherical alignment
- * (setTargetFrame / setSourceFrame / alignFrames360 and the per-pixel passes they call) plus the
- * adjacent Frame360 per-pixel stages.  Everything is plain C: opaque context, POD structs, raw
+ * (setTargetFrame / setSourceFrame / alignFrames360 with its three occlusion modes and the per-pixel passes they
+ * call), the pinhole single-sensor alignFrames, and the adjacent Frame360 per-pixel stages (frame file reader,
+ * 8-sensor spherical stitching, sphere cloud, normal map, planar regions).  Everything is plain C: opaque context, POD structs, raw
  * pointers and sizes.  File:line citations are relative to the reference tree; "RPI.h" is
  * include/RegisterPhotoICP.h.
  *
@@ -65,7 +66,8 @@ typedef struct {
     int    status;
     int    iters[8];        /* accepted Gauss-Newton iterations per pyramid level (index = level) */
     float  sso;             /* visible pixels / image size at level 0 (RPI.h:3226) */
-    double err_final;       /* RMS residual of the error pass at pose_out, level 0 */
+    double err_final;       /* RMS residual of the error pass at pose_out, level 0 (occlusion 1 / 2 and the pinhole path:
+                               avPhotoResidual + avDepthResidual, as their error functions define it) */
     double rms_photo;       /* photo / depth RMS of that pass (the reference leaves these unset on this path) */
     double rms_depth;
     float  hessian[36];     /* column-major 6x6: H of the last calcHessGrad_sphere the reference would have run */
