@@ -724,3 +724,40 @@ def test_hip_pinhole_matches_golden_fixture(hip_lib, method):
     e = reg.eval_pinhole(1, T, method)
     assert list(e["n_split"]) == [g["n_photo"], g["n_depth"]] and e["n_rows"] == g["n_rows"]
     assert np.abs(e["H64"] - np.array(g["H64"])).max() <= HG_RTOL * np.abs(np.array(g["H64"])).max()
+
+
+@pytest.mark.parametrize("method", [0, 2])
+def test_control_flow_matches_oracle_over_many_scenarios(hip_lib, oracle_mod, method):
+    """The device-resident Gauss-Newton state machine (accept / reject, termination tests, level hand-over, speculative solve)
+    against the oracle's restatement of alignFrames360 on pairs that exercise different paths: tiny and large motions, wrong
+    initial guesses, iteration caps of 1 / 2 / 10, loose and tight tolerances, 2 to 4 pyramid levels."""
+    from rgbd360_amd.register import RegisterPhotoICP
+    rng = np.random.default_rng(2024 + method)
+    checked = set()
+    for case in range(14):
+        trans = float(rng.choice([0.0, 0.01, 0.05, 0.12, 0.3]))
+        rot_deg = float(rng.choice([0.0, 0.5, 2.0, 5.0]))
+        n_pyr = int(rng.choice([2, 3, 4]))
+        max_iters = int(rng.choice([1, 2, 10]))
+        tol_res = float(rng.choice([1e-3, 1e-5, 5e-2]))
+        pair = synth.make_pair(192, 96, seed=500 + case, trans=trans, rot_deg=rot_deg)
+        (rgbA, dA), (rgbB, dB), T = pair
+        guess = np.eye(4) if case % 3 else synth.make_pose(synth.rodrigues(rng.normal(size=3), 0.02), rng.normal(size=3) * 0.03)
+        reg = RegisterPhotoICP()
+        reg.setNumPyr(n_pyr)
+        reg._p.max_iters = max_iters
+        reg._p.tol_residual = tol_res
+        reg.setTargetFrame(rgbA, dA)
+        reg.setSourceFrame(rgbB, dB)
+        ora = oracle_mod.Oracle(n_pyr=n_pyr, max_iters=max_iters, tol_residual=tol_res, math_mode=1, reduce_mode=1)
+        ora.set_target(rgbA, dA)
+        ora.set_source(rgbB, dB)
+        rc = reg.alignFrames360(guess, method)
+        st, pose_ref = ora.align360(guess, method)
+        ctx = (case, trans, rot_deg, n_pyr, max_iters, tol_res)
+        assert rc == st, ctx
+        assert reg.num_iterations == list(ora.result.iters)[:n_pyr], (ctx, reg.num_iterations, list(ora.result.iters)[:n_pyr])
+        rot, trans_e = synth.pose_error(reg.getOptimalPose(), pose_ref)
+        assert rot <= 2e-5 and trans_e <= 2e-5, (ctx, rot, trans_e)       # several accepted steps: rounding differences add up
+        checked.add((rc, tuple(min(i, 3) for i in reg.num_iterations)))
+    assert len(checked) >= 5          # the scenarios did take different paths through the loop
