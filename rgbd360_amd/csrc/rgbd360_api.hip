@@ -1260,7 +1260,8 @@ int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float
 }
 // organised cloud of one spherical depth image -> ctx->f_xyz (device); the per-row/column sin/cos tables follow the
 // reference's float expressions and are computed on the host (rows + cols values)
-int sphere_cloud_dev(rgbd360_ctx* ctx, const void* depth, size_t depth_step, int depth_type, int rows, int cols, int convention) {
+int sphere_cloud_dev(rgbd360_ctx* ctx, const void* depth, size_t depth_step, int depth_type, int rows, int cols, int convention,
+                     bool depth_on_device = false) {
     if (convention < 0 || convention > 2 || (depth_type != 0 && depth_type != 1)) return fail(ctx, -1, "bad arguments");
     std::vector<float> st(cols), ct(cols), sp(rows), cp(rows);
     if (convention == 0) {          // Frame360.h:562-585
@@ -1320,8 +1321,8 @@ int sphere_cloud_dev(rgbd360_ctx* ctx, const void* depth, size_t depth_step, int
     tab.insert(tab.end(), sp.begin(), sp.end());
     tab.insert(tab.end(), cp.begin(), cp.end());
     HIPC(ctx, hipMemcpyAsync(ctx->f_tab, tab.data(), ntab * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    HIPC(ctx, hipMemcpy2DAsync(ctx->f_depth_raw, (size_t)cols * dpx, depth, depth_step, (size_t)cols * dpx, rows, hipMemcpyHostToDevice,
-                               ctx->stream));
+    HIPC(ctx, hipMemcpy2DAsync(ctx->f_depth_raw, (size_t)cols * dpx, depth, depth_step, (size_t)cols * dpx, rows,
+                               depth_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
     float* d_tab = ctx->f_tab;
     hipLaunchKernelGGL(k_sphere_cloud, grid2d(rows, cols), dim3(256), 0, ctx->stream, ctx->f_depth_raw, (size_t)cols * dpx, depth_type,
                        rows, cols, convention, d_tab, d_tab + cols, d_tab + 2 * cols, d_tab + 2 * cols + rows, ctx->f_xyz);
@@ -1399,11 +1400,11 @@ extern "C" int rgbd360_plane_fit(rgbd360_ctx* ctx, const float* xyz, const float
     return 0;
 }
 
-extern "C" int rgbd360_frame_planes(rgbd360_ctx* ctx, const void* depth, size_t depth_step, int depth_type, int rows, int cols,
-                                    int convention, float max_depth_change_factor, float normal_smoothing_size, int min_inliers,
-                                    float angular_threshold, float distance_threshold, float max_curvature, int depth_mode,
-                                    float* xyz_out, float* normals_out, int32_t* labels_out, rgbd360_plane* planes_out,
-                                    int max_planes, int* n_planes_out) {
+static int frame_planes_impl(rgbd360_ctx* ctx, const void* depth, size_t depth_step, int depth_type, int rows, int cols,
+                             int convention, float max_depth_change_factor, float normal_smoothing_size, int min_inliers,
+                             float angular_threshold, float distance_threshold, float max_curvature, int depth_mode,
+                             float* xyz_out, float* normals_out, int32_t* labels_out, rgbd360_plane* planes_out,
+                             int max_planes, int* n_planes_out, bool depth_on_device) {
     if (!ctx || !depth || !planes_out || !n_planes_out || max_planes < 1) return -1;
     if (rows < 3 || cols < 3 || (long long)rows * cols >= (1ll << 30)) return fail(ctx, -1, "bad image size");
     hipSetDevice(ctx->p.device);
@@ -1411,7 +1412,7 @@ extern "C" int rgbd360_frame_planes(rgbd360_ctx* ctx, const void* depth, size_t 
     int rc = f360_ensure(ctx, n);
     if (rc) return rc;
     // the cloud stays on the device; a host copy is only made when asked for
-    rc = sphere_cloud_dev(ctx, depth, depth_step, depth_type, rows, cols, convention);
+    rc = sphere_cloud_dev(ctx, depth, depth_step, depth_type, rows, cols, convention, depth_on_device);
     if (rc) return rc;
     if (xyz_out) HIPC(ctx, hipMemcpyAsync(xyz_out, ctx->f_xyz, n * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     rc = f360_normals_dev(ctx, rows, cols, max_depth_change_factor, normal_smoothing_size, depth_mode);
@@ -1421,6 +1422,31 @@ extern "C" int rgbd360_frame_planes(rgbd360_ctx* ctx, const void* depth, size_t 
     if (rc) return rc;
     if (normals_out) HIPC(ctx, hipMemcpy(normals_out, ctx->f_normals, n * 3 * sizeof(float), hipMemcpyDeviceToHost));
     if (labels_out) HIPC(ctx, hipMemcpy(labels_out, ctx->f_label, n * sizeof(int), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int rgbd360_frame_planes(rgbd360_ctx* ctx, const void* depth, size_t depth_step, int depth_type, int rows, int cols,
+                                    int convention, float max_depth_change_factor, float normal_smoothing_size, int min_inliers,
+                                    float angular_threshold, float distance_threshold, float max_curvature, int depth_mode,
+                                    float* xyz_out, float* normals_out, int32_t* labels_out, rgbd360_plane* planes_out,
+                                    int max_planes, int* n_planes_out) {
+    return frame_planes_impl(ctx, depth, depth_step, depth_type, rows, cols, convention, max_depth_change_factor, normal_smoothing_size,
+                             min_inliers, angular_threshold, distance_threshold, max_curvature, depth_mode, xyz_out, normals_out,
+                             labels_out, planes_out, max_planes, n_planes_out, false);
+}
+
+extern "C" int rgbd360_frame_planes_dev(rgbd360_ctx* ctx, const void* depth_dev, size_t depth_step, int depth_type, int rows, int cols,
+                                        int convention, float max_depth_change_factor, float normal_smoothing_size, int min_inliers,
+                                        float angular_threshold, float distance_threshold, float max_curvature, int depth_mode,
+                                        rgbd360_plane* planes_out, int max_planes, int* n_planes_out, const float** xyz_dev,
+                                        const float** normals_dev, const int32_t** labels_dev) {
+    const int rc = frame_planes_impl(ctx, depth_dev, depth_step, depth_type, rows, cols, convention, max_depth_change_factor,
+                                     normal_smoothing_size, min_inliers, angular_threshold, distance_threshold, max_curvature, depth_mode,
+                                     nullptr, nullptr, nullptr, planes_out, max_planes, n_planes_out, true);
+    if (rc) return rc;
+    if (xyz_dev) *xyz_dev = ctx->f_xyz;
+    if (normals_dev) *normals_dev = ctx->f_normals;
+    if (labels_dev) *labels_dev = ctx->f_label;
     return 0;
 }
 

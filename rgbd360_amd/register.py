@@ -451,6 +451,22 @@ class Frame360Stages:
         return dict(xyz=xyz, normals=nrm, labels=labels.reshape(rows, cols), planes=_planes_to_dicts(arr, n.value))
 
 
+    def frame_planes_dev(self, depth_ptr: int, rows: int, cols: int, depth_type: int = 0, convention=2, max_depth_change_factor=0.05,
+                         normal_smoothing_size=8.0, min_inliers=40, angular_threshold=0.05, distance_threshold=0.05,
+                         max_curvature=0.001, depth_mode=1, max_planes=256, depth_step: int = 0):
+        """rgbd360_frame_planes_dev: depth image already in HBM (raw device pointer), maps stay on the device.
+        Returns dict(planes=[...], xyz_ptr, normals_ptr, labels_ptr) -- device pointers valid until the next Frame360 call."""
+        arr = (_lib.Plane * max_planes)()
+        n = C.c_int()
+        px, pn, pl = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        step = depth_step or cols * (2 if depth_type == 0 else 4)
+        self._reg._check(self._L.rgbd360_frame_planes_dev(self._reg._ctx(), C.c_void_p(depth_ptr), step, depth_type, rows, cols, convention,
+                                                          max_depth_change_factor, normal_smoothing_size, min_inliers, angular_threshold,
+                                                          distance_threshold, max_curvature, depth_mode, C.cast(arr, C.c_void_p), max_planes,
+                                                          C.byref(n), C.byref(px), C.byref(pn), C.byref(pl)))
+        return dict(planes=_planes_to_dicts(arr, n.value), xyz_ptr=px.value, normals_ptr=pn.value, labels_ptr=pl.value)
+
+
 QVGA_K = (262.5, 262.5, 159.5, 119.5)       # Calib360.h:74-77 (fx, fy, cx, cy)
 
 

@@ -761,3 +761,29 @@ def test_control_flow_matches_oracle_over_many_scenarios(hip_lib, oracle_mod, me
         assert rot <= 2e-5 and trans_e <= 2e-5, (ctx, rot, trans_e)       # several accepted steps: rounding differences add up
         checked.add((rc, tuple(min(i, 3) for i in reg.num_iterations)))
     assert len(checked) >= 5          # the scenarios did take different paths through the loop
+
+
+def test_frame_planes_dev_equals_host_variant(hip_lib):
+    """rgbd360_frame_planes_dev (depth in HBM, maps left in HBM) returns the plane list of the host-buffer entry point, and its
+    device maps hold the same bytes."""
+    import ctypes as C
+    from rgbd360_amd.register import RegisterPhotoICP, Frame360Stages
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+    (rgbA, dA), _, _ = synth.make_pair(256, 128, seed=5)
+    st = Frame360Stages(RegisterPhotoICP())
+    ref = st.frame_planes(dA, convention=2, angular_threshold=0.03)
+    p = C.c_void_p()
+    assert hip.hipMalloc(C.byref(p), dA.nbytes) == 0 and hip.hipMemcpy(p, dA.ctypes.data_as(C.c_void_p), dA.nbytes, 1) == 0
+    out = st.frame_planes_dev(p.value, 128, 256, 0, convention=2, angular_threshold=0.03)
+    assert [(q["count"], q["root"]) for q in out["planes"]] == [(q["count"], q["root"]) for q in ref["planes"]]
+    assert all(np.allclose(a["normal"], b["normal"]) and abs(a["d"] - b["d"]) < 1e-6 for a, b in zip(out["planes"], ref["planes"]))
+    labels = np.empty(128 * 256, np.int32)
+    nrm = np.empty((128 * 256, 3), np.float32)
+    assert hip.hipMemcpy(labels.ctypes.data_as(C.c_void_p), C.c_void_p(out["labels_ptr"]), labels.nbytes, 2) == 0     # DeviceToHost
+    assert hip.hipMemcpy(nrm.ctypes.data_as(C.c_void_p), C.c_void_p(out["normals_ptr"]), nrm.nbytes, 2) == 0
+    hip.hipFree(p)
+    assert np.array_equal(labels, np.asarray(ref["labels"]).reshape(-1))
+    assert np.array_equal(np.nan_to_num(nrm), np.nan_to_num(ref["normals"]))
