@@ -1459,6 +1459,11 @@ extern "C" int rgbd360_load_frame_bin(const char* path, uint8_t* rgb_out, uint16
     // 16UC1} + a timestamp Mat; every Mat = int32 cols, int32 rows, uint64 elemSize, uint64 cvType, raw bytes
     // (cvmat_serialization.h:23-36) behind the archive's 45-byte header.
     if (!path || !rows || !cols) return -1;
+    // with output buffers the caller states the size they were allocated for (the values of the size query); a file whose
+    // records do not have exactly that size is refused instead of being read into them
+    const bool have_buffers = rgb_out || depth_out;
+    const int want_rows = *rows, want_cols = *cols;
+    if (have_buffers && (want_rows <= 0 || want_cols <= 0)) return -1;
     FILE* f = fopen(path, "rb");
     if (!f) return -2;
     int rc = 0;
@@ -1469,6 +1474,7 @@ extern "C" int rgbd360_load_frame_bin(const char* path, uint8_t* rgb_out, uint16
         if (fread(&c, 4, 1, f) != 1 || fread(&r, 4, 1, f) != 1 || fread(&elem, 8, 1, f) != 1 || fread(&type, 8, 1, f) != 1) { rc = -3; break; }
         const bool is_rgb = (m % 2) == 0;
         if (c <= 0 || r <= 0 || c > 8192 || r > 8192 || elem != (is_rgb ? 3u : 2u) || type != (is_rgb ? 16u : 2u)) { rc = -4; break; }   // CV_8UC3 = 16, CV_16UC1 = 2
+        if (have_buffers && (r != want_rows || c != want_cols)) { rc = -4; break; }
         if (m == 0) { *rows = r; *cols = c; }
         else if (r != *rows || c != *cols) { rc = -4; break; }
         const size_t bytes = (size_t)c * r * elem;

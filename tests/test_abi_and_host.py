@@ -133,3 +133,19 @@ def test_bin_loader_reads_the_boost_archive_layout(tmp_path):
     bad.write_bytes(open(path, "rb").read()[:500])
     with pytest.raises(Rgbd360Error):
         load_frame_bin(str(bad))
+    # buffers sized for another image size are never written: the call is refused
+    import ctypes as C
+    from rgbd360_amd import _lib
+    L = _lib.load()
+    small_rgb = np.zeros((8, 4, 4, 3), np.uint8)
+    small_dep = np.zeros((8, 4, 4), np.uint16)
+    r, c = C.c_int(4), C.c_int(4)
+    rc = L.rgbd360_load_frame_bin(str(path).encode(), small_rgb.ctypes.data_as(C.c_void_p), small_dep.ctypes.data_as(C.c_void_p),
+                                  C.byref(r), C.byref(c))
+    assert rc == -4 and not small_rgb.any() and not small_dep.any()
+    # absurd record headers (negative / huge sizes, wrong element type) are rejected before anything is read
+    for hdr in (struct.pack("<iiQQ", -1, rows, 3, 16), struct.pack("<iiQQ", 100000, rows, 3, 16), struct.pack("<iiQQ", cols, rows, 4, 24)):
+        evil = tmp_path / "evil.bin"
+        evil.write_bytes(b"\x00" * 45 + hdr + b"\x00" * 64)
+        with pytest.raises(Rgbd360Error):
+            load_frame_bin(str(evil))
