@@ -1133,11 +1133,8 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 
 // cv::pyrDown, CV_32FC1, dsize (cols/2, rows/2), BORDER_REFLECT_101; horizontal pass first, then vertical,
 // one scale by 1/256 -- same operation order as the oracle.
-__global__ void k_pyrdown_gray(const float* __restrict__ src, int srows, int scols, float* __restrict__ dst, int drows,
-                               int dcols) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
-    if (x >= dcols || y >= drows) return;
+__device__ __forceinline__ void pyrdown_gray_px(const float* __restrict__ src, int srows, int scols, float* __restrict__ dst,
+                                                int dcols, int x, int y) {
     int cc[5], rr[5];
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
@@ -1155,11 +1152,8 @@ __global__ void k_pyrdown_gray(const float* __restrict__ src, int srows, int sco
 }
 
 // buildPyramidRange level step: mean of the in-range pixels of each 2x2 block, else 0.
-__global__ void k_pyrdown_depth(const float* __restrict__ src, int scols, float* __restrict__ dst, int drows, int dcols,
-                                float min_depth, float max_depth) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
-    if (x >= dcols || y >= drows) return;
+__device__ __forceinline__ void pyrdown_depth_px(const float* __restrict__ src, int scols, float* __restrict__ dst, int dcols,
+                                                 float min_depth, float max_depth, int x, int y) {
     float av = 0.f;
     unsigned n = 0;
 #pragma unroll
@@ -1175,11 +1169,21 @@ __global__ void k_pyrdown_depth(const float* __restrict__ src, int scols, float*
     dst[(size_t)y * dcols + x] = n > 0 ? av / n : 0.f;
 }
 
+// One pyramid step of BOTH planes of a frame in one launch (blockIdx.z = 0: intensity, 5x5 binomial; 1: depth, valid mean):
+// the frame set-up is a chain of small kernels, so its cost is the number of launches, not their bytes.
+__global__ void k_pyrdown_pair(const float* __restrict__ gray_src, const float* __restrict__ depth_src, int srows, int scols,
+                               float* __restrict__ gray_dst, float* __restrict__ depth_dst, int drows, int dcols, float min_depth,
+                               float max_depth) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= dcols || y >= drows) return;
+    if (blockIdx.z == 0) pyrdown_gray_px(gray_src, srows, scols, gray_dst, dcols, x, y);
+    else pyrdown_depth_px(depth_src, scols, depth_dst, dcols, min_depth, max_depth, x, y);
+}
+
 // calcGradientXY on one plane + seam mask; writes the interleaved {value, gradX, gradY} gather record.
-__global__ void k_gradient_rec(const float* __restrict__ src, int rows, int cols, int seam_width, F3* __restrict__ rec) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    const int r = blockIdx.y;
-    if (c >= cols || r >= rows) return;
+__device__ __forceinline__ void gradient_rec_px(const float* __restrict__ src, int rows, int cols, int seam_width,
+                                                F3* __restrict__ rec, int r, int c) {
     const float v = src[(size_t)r * cols + c];
     float gx = 0.f, gy = 0.f;
     if (r >= 1 && r < rows - 1 && c >= 1 && c < cols - 1) {
@@ -1198,15 +1202,31 @@ __global__ void k_gradient_rec(const float* __restrict__ src, int rows, int cols
     rec[(size_t)r * cols + c] = o;
 }
 
+// All gradient records of a target frame (every level, intensity and depth) in ONE launch: a job table in the kernel
+// arguments, 256-pixel blocks numbered across the jobs.
+constexpr int kMaxJobs = 16;
+struct GradJobs {
+    const float* src[kMaxJobs];
+    F3*          rec[kMaxJobs];
+    int rows[kMaxJobs], cols[kMaxJobs], seam[kMaxJobs], first_block[kMaxJobs + 1];
+    int n;
+};
+__global__ void k_gradient_rec_multi(GradJobs jobs) {
+    int j = 0;
+    while (j + 1 < jobs.n && (int)blockIdx.x >= jobs.first_block[j + 1]) ++j;
+    const int p = ((int)blockIdx.x - jobs.first_block[j]) * (int)blockDim.x + (int)threadIdx.x;
+    const int cols = jobs.cols[j], rows = jobs.rows[j];
+    if (p >= rows * cols) return;
+    const int r = p / cols, c = p - r * cols;
+    gradient_rec_px(jobs.src[j], rows, cols, jobs.seam[j], jobs.rec[j], r, c);
+}
+
 // LUT_xyz_sphere + source intensity -> {x,y,z,I}.  sin/cos tables come from the host's libm (same values as
 // the CPU path: RPI.h:4559-4571 evaluates them once per column / row).
-__global__ void k_src_rec(const float* __restrict__ depth, const float* __restrict__ gray, int rows, int cols,
-                          const float* __restrict__ sin_theta, const float* __restrict__ cos_theta,
-                          const float* __restrict__ sin_phi, const float* __restrict__ cos_phi, float min_depth,
-                          float max_depth, float4* __restrict__ rec) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    const int r = blockIdx.y;
-    if (c >= cols || r >= rows) return;
+__device__ __forceinline__ void src_rec_px(const float* __restrict__ depth, const float* __restrict__ gray, int cols,
+                                           const float* __restrict__ sin_theta, const float* __restrict__ cos_theta,
+                                           const float* __restrict__ sin_phi, const float* __restrict__ cos_phi, float min_depth,
+                                           float max_depth, float4* __restrict__ rec, int r, int c) {
     const size_t i = (size_t)r * cols + c;
     const float d = depth[i];
     float4 o;
@@ -1221,6 +1241,23 @@ __global__ void k_src_rec(const float* __restrict__ depth, const float* __restri
         o.z = 0.f;
     }
     rec[i] = o;
+}
+struct SrcJobs {
+    const float *depth[8], *gray[8], *sin_theta[8], *cos_theta[8], *sin_phi[8], *cos_phi[8];
+    float4* rec[8];
+    int rows[8], cols[8], first_block[9];
+    int n;
+    float min_depth, max_depth;
+};
+__global__ void k_src_rec_multi(SrcJobs jobs) {
+    int j = 0;
+    while (j + 1 < jobs.n && (int)blockIdx.x >= jobs.first_block[j + 1]) ++j;
+    const int p = ((int)blockIdx.x - jobs.first_block[j]) * (int)blockDim.x + (int)threadIdx.x;
+    const int cols = jobs.cols[j], rows = jobs.rows[j];
+    if (p >= rows * cols) return;
+    const int r = p / cols, c = p - r * cols;
+    src_rec_px(jobs.depth[j], jobs.gray[j], cols, jobs.sin_theta[j], jobs.cos_theta[j], jobs.sin_phi[j], jobs.cos_phi[j],
+               jobs.min_depth, jobs.max_depth, jobs.rec[j], r, c);
 }
 
 // Frame360 sphere clouds (Frame360.h:555-612, Frame360_stereo.h:454-512) and the RegisterPhotoICP convention.

@@ -264,6 +264,47 @@ int check_args(rgbd360_ctx* ctx, int level, int method) {
     return 0;
 }
 
+// every gradient record of the target frame (all levels x {intensity, depth}) in one launch
+void launch_gradient_recs(rgbd360_ctx* ctx) {
+    GradJobs jobs;
+    int nb = 0, n = 0;
+    for (int l = 0; l < ctx->p.n_pyr; ++l) {
+        const Level& L = ctx->levels[l];
+        const int seam = ctx->p.mask_seams ? L.cols / 8 : 0;
+        for (int k = 0; k < 2; ++k) {
+            jobs.src[n] = k == 0 ? L.grayTrg : L.depthTrg;
+            jobs.rec[n] = k == 0 ? L.trgP : L.trgD;
+            jobs.rows[n] = L.rows; jobs.cols[n] = L.cols; jobs.seam[n] = seam;
+            jobs.first_block[n] = nb;
+            nb += (L.n + 255) / 256;
+            ++n;
+        }
+    }
+    jobs.first_block[n] = nb;
+    jobs.n = n;
+    hipLaunchKernelGGL(k_gradient_rec_multi, dim3(nb), dim3(256), 0, ctx->stream, jobs);
+}
+
+// every source record (LUT point + intensity) of the source frame in one launch
+void launch_src_recs(rgbd360_ctx* ctx) {
+    SrcJobs jobs;
+    int nb = 0, n = 0;
+    for (int l = 0; l < ctx->p.n_pyr; ++l) {
+        const Level& L = ctx->levels[l];
+        jobs.depth[n] = L.depthSrc; jobs.gray[n] = L.graySrc;
+        jobs.sin_theta[n] = L.sinT; jobs.cos_theta[n] = L.cosT; jobs.sin_phi[n] = L.sinP; jobs.cos_phi[n] = L.cosP;
+        jobs.rec[n] = L.srcRec;
+        jobs.rows[n] = L.rows; jobs.cols[n] = L.cols;
+        jobs.first_block[n] = nb;
+        nb += (L.n + 255) / 256;
+        ++n;
+    }
+    jobs.first_block[n] = nb;
+    jobs.n = n;
+    jobs.min_depth = ctx->p.min_depth; jobs.max_depth = ctx->p.max_depth;
+    hipLaunchKernelGGL(k_src_rec_multi, dim3(nb), dim3(256), 0, ctx->stream, jobs);
+}
+
 int set_frame(rgbd360_ctx* ctx, bool target, const uint8_t* rgb, size_t rgb_step, const void* depth, size_t d_step,
               int depth_type, int rows, int cols, bool on_device) {
     if (!ctx) return -1;
@@ -306,25 +347,14 @@ int set_frame(rgbd360_ctx* ctx, bool target, const uint8_t* rgb, size_t rgb_step
                        cols, dep0);
     for (int l = 1; l < ctx->p.n_pyr; ++l) {
         Level &P = ctx->levels[l - 1], &C = ctx->levels[l];
-        hipLaunchKernelGGL(k_pyrdown_gray, grid2d(C.rows, C.cols), dim3(256), 0, ctx->stream,
-                           target ? P.grayTrg : P.graySrc, P.rows, P.cols, target ? C.grayTrg : C.graySrc, C.rows, C.cols);
-        hipLaunchKernelGGL(k_pyrdown_depth, grid2d(C.rows, C.cols), dim3(256), 0, ctx->stream,
-                           target ? P.depthTrg : P.depthSrc, P.cols, target ? C.depthTrg : C.depthSrc, C.rows, C.cols,
-                           ctx->p.min_depth, ctx->p.max_depth);
+        dim3 g = grid2d(C.rows, C.cols);
+        g.z = 2;                                        // intensity and depth step in one launch
+        hipLaunchKernelGGL(k_pyrdown_pair, g, dim3(256), 0, ctx->stream, target ? P.grayTrg : P.graySrc,
+                           target ? P.depthTrg : P.depthSrc, P.rows, P.cols, target ? C.grayTrg : C.graySrc,
+                           target ? C.depthTrg : C.depthSrc, C.rows, C.cols, ctx->p.min_depth, ctx->p.max_depth);
     }
-    for (int l = 0; l < ctx->p.n_pyr; ++l) {
-        Level& L = ctx->levels[l];
-        if (target) {
-            const int seam = ctx->p.mask_seams ? L.cols / 8 : 0;
-            hipLaunchKernelGGL(k_gradient_rec, grid2d(L.rows, L.cols), dim3(256), 0, ctx->stream, L.grayTrg, L.rows, L.cols,
-                               seam, L.trgP);
-            hipLaunchKernelGGL(k_gradient_rec, grid2d(L.rows, L.cols), dim3(256), 0, ctx->stream, L.depthTrg, L.rows,
-                               L.cols, seam, L.trgD);
-        } else {
-            hipLaunchKernelGGL(k_src_rec, grid2d(L.rows, L.cols), dim3(256), 0, ctx->stream, L.depthSrc, L.graySrc, L.rows,
-                               L.cols, L.sinT, L.cosT, L.sinP, L.cosP, ctx->p.min_depth, ctx->p.max_depth, L.srcRec);
-        }
-    }
+    if (target) launch_gradient_recs(ctx);
+    else launch_src_recs(ctx);
     HIPC(ctx, hipGetLastError());
     if (!on_device) HIPC(ctx, hipStreamSynchronize(ctx->stream));   // host buffers may be reused by the caller
     if (target) ctx->have_trg = true; else ctx->have_src = true;
@@ -453,12 +483,8 @@ int rgbd360_promote_source_to_target(rgbd360_ctx* ctx) {
     for (Level& L : ctx->levels) {
         std::swap(L.graySrc, L.grayTrg);
         std::swap(L.depthSrc, L.depthTrg);
-        const int seam = ctx->p.mask_seams ? L.cols / 8 : 0;
-        hipLaunchKernelGGL(k_gradient_rec, grid2d(L.rows, L.cols), dim3(256), 0, ctx->stream, L.grayTrg, L.rows, L.cols, seam,
-                           L.trgP);
-        hipLaunchKernelGGL(k_gradient_rec, grid2d(L.rows, L.cols), dim3(256), 0, ctx->stream, L.depthTrg, L.rows, L.cols,
-                           seam, L.trgD);
     }
+    launch_gradient_recs(ctx);
     HIPC(ctx, hipGetLastError());
     ctx->have_trg = true;
     ctx->have_src = false;
