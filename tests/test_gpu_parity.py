@@ -787,3 +787,24 @@ def test_frame_planes_dev_equals_host_variant(hip_lib):
     hip.hipFree(p)
     assert np.array_equal(labels, np.asarray(ref["labels"]).reshape(-1))
     assert np.array_equal(np.nan_to_num(nrm), np.nan_to_num(ref["normals"]))
+
+
+def test_eight_pyramid_levels(hip_lib, oracle_mod):
+    """The deepest pyramid the ABI allows (n_pyr = 8, job tables of the batched set-up kernels full): planes bit-exact on every
+    level, alignment identical to the oracle's."""
+    pair = synth.make_pair(1024, 512, seed=21)
+    reg, ora, T = _pair_ctx(hip_lib, oracle_mod, pair, n_pyr=8)
+    for level in range(8):
+        ora.prepare_level(level)
+        for name in ("gray_src", "gray_trg", "depth_src", "depth_trg", "gx", "gy", "dgx", "dgy"):
+            a, b = reg.plane(name, level), ora.plane(name, level)
+            assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32)), (name, level)
+        la, lb = reg.lut(level), ora.lut(level)
+        valid = lb[:, 0] != -10000
+        assert np.array_equal(la[:, 0] != -10000, valid) and np.array_equal(la[valid].view(np.uint32), lb[valid].view(np.uint32))
+    rc = reg.alignFrames360(np.eye(4), 2)
+    st, pose_ref = ora.align360(np.eye(4), 2)
+    assert rc == st
+    assert reg.num_iterations == list(ora.result.iters)[:8]
+    rot, trans = synth.pose_error(reg.getOptimalPose(), pose_ref)
+    assert rot <= 2e-5 and trans <= 2e-5, (rot, trans)
