@@ -1081,9 +1081,8 @@ __global__ void k_selftest_math(unsigned first_bits, unsigned count, unsigned lo
 // cv::cvtColor(CV_RGB2GRAY) on 8UC3 (fixed point, shift 14) then convertTo(CV_32FC1, 1./255).
 // Four pixels per thread: 12 bytes in as three dwords, 16 bytes out as one float4 (a byte-per-lane version ran at 1.4 TB/s).
 // The vector path needs 4-byte aligned rows (base and step); otherwise, and for the last columns, bytes are read one by one.
-__global__ void k_gray_u8(const uint8_t* __restrict__ rgb, size_t step, int rows, int cols, float* __restrict__ out) {
-    const int c4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    const int r = blockIdx.y;
+__device__ __forceinline__ void gray_u8_x4(const uint8_t* __restrict__ rgb, size_t step, int rows, int cols, float* __restrict__ out,
+                                           int c4, int r) {
     if (c4 >= cols || r >= rows) return;
     const uint8_t* p = rgb + (size_t)r * step + 3 * (size_t)c4;
     float* o = out + (size_t)r * cols + c4;
@@ -1103,10 +1102,8 @@ __global__ void k_gray_u8(const uint8_t* __restrict__ rgb, size_t step, int rows
     }
 }
 
-__global__ void k_depth_to_f32(const void* __restrict__ depth, size_t step, int depth_type, int rows, int cols,
-                               float* __restrict__ out) {
-    const int c4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    const int r = blockIdx.y;
+__device__ __forceinline__ void depth_to_f32_x4(const void* __restrict__ depth, size_t step, int depth_type, int rows, int cols,
+                                                float* __restrict__ out, int c4, int r) {
     if (c4 >= cols || r >= rows) return;
     const uint8_t* row = (const uint8_t*)depth + (size_t)r * step;
     float* o = out + (size_t)r * cols + c4;
@@ -1123,6 +1120,16 @@ __global__ void k_depth_to_f32(const void* __restrict__ depth, size_t step, int 
         const float* p = (const float*)row + c4;
         for (int j = 0; j < 4 && c4 + j < cols; ++j) o[j] = p[j];
     }
+}
+
+// Level 0 of a frame in one launch: blockIdx.z = 0 converts the colour image (cv::cvtColor + convertTo, RPI.h:485-486),
+// 1 the depth image (RPI.h:316-319).
+__global__ void k_convert_pair(const uint8_t* __restrict__ rgb, size_t rgb_step, const void* __restrict__ depth, size_t depth_step,
+                               int depth_type, int rows, int cols, float* __restrict__ gray_out, float* __restrict__ depth_out) {
+    const int c4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int r = blockIdx.y;
+    if (blockIdx.z == 0) gray_u8_x4(rgb, rgb_step, rows, cols, gray_out, c4, r);
+    else depth_to_f32_x4(depth, depth_step, depth_type, rows, cols, depth_out, c4, r);
 }
 
 __device__ __forceinline__ int reflect101(int i, int n) {

@@ -342,9 +342,11 @@ int set_frame(rgbd360_ctx* ctx, bool target, const uint8_t* rgb, size_t rgb_step
     Level& L0 = ctx->levels[0];
     float* gray0 = target ? L0.grayTrg : L0.graySrc;
     float* dep0 = target ? L0.depthTrg : L0.depthSrc;
-    hipLaunchKernelGGL(k_gray_u8, grid2d(rows, (cols + 3) / 4), dim3(256), 0, ctx->stream, d_rgb, s_rgb, rows, cols, gray0);
-    hipLaunchKernelGGL(k_depth_to_f32, grid2d(rows, (cols + 3) / 4), dim3(256), 0, ctx->stream, d_depth, s_depth, depth_type, rows,
-                       cols, dep0);
+    {
+        dim3 g = grid2d(rows, (cols + 3) / 4);
+        g.z = 2;                                        // colour -> intensity and depth -> metres in one launch
+        hipLaunchKernelGGL(k_convert_pair, g, dim3(256), 0, ctx->stream, d_rgb, s_rgb, d_depth, s_depth, depth_type, rows, cols, gray0, dep0);
+    }
     for (int l = 1; l < ctx->p.n_pyr; ++l) {
         Level &P = ctx->levels[l - 1], &C = ctx->levels[l];
         dim3 g = grid2d(C.rows, C.cols);
