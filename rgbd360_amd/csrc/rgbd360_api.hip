@@ -306,7 +306,7 @@ void launch_src_recs(rgbd360_ctx* ctx) {
 }
 
 int set_frame(rgbd360_ctx* ctx, bool target, const uint8_t* rgb, size_t rgb_step, const void* depth, size_t d_step,
-              int depth_type, int rows, int cols, bool on_device) {
+              int depth_type, int rows, int cols, bool on_device, bool wait_for_upload = true) {
     if (!ctx) return -1;
     if (!rgb || !depth) return fail(ctx, -1, "null image pointer");
     if (depth_type != 0 && depth_type != 1) return fail(ctx, -1, "depth_type must be 0 (u16 mm) or 1 (f32 m)");
@@ -358,7 +358,8 @@ int set_frame(rgbd360_ctx* ctx, bool target, const uint8_t* rgb, size_t rgb_step
     if (target) launch_gradient_recs(ctx);
     else launch_src_recs(ctx);
     HIPC(ctx, hipGetLastError());
-    if (!on_device) HIPC(ctx, hipStreamSynchronize(ctx->stream));   // host buffers may be reused by the caller
+    // host buffers may be reused by the caller once a set_* call returns; the sequence entry owns them until it returns
+    if (!on_device && wait_for_upload) HIPC(ctx, hipStreamSynchronize(ctx->stream));
     if (target) ctx->have_trg = true; else ctx->have_src = true;
     return 0;
 }
@@ -611,34 +612,34 @@ static int align360_batch_impl(rgbd360_ctx* ctx, int n_frames, const uint8_t* co
         steps = std::max(steps, b[c] - a[c]);
     }
     auto propagate = [&](rgbd360_ctx* from, int rc) { return from == ctx ? rc : fail(ctx, rc, from->err.c_str()); };
+    auto drain = [&]() {
+        for (int d = 0; d < k_ctx; ++d)
+            if (cs[d]->al_active) { float tmp[16]; rgbd360_align360_finish(cs[d], tmp, nullptr); }
+        for (int d = 0; d < k_ctx; ++d) hipStreamSynchronize(cs[d]->stream);      // no upload may outlive the caller's buffers
+    };
     for (int c = 0; c < k_ctx; ++c) {
-        const int rc = set_frame(cs[c], true, rgb[a[c]], rgb_step, depth[a[c]], depth_step, depth_type, rows, cols, on_device);
-        if (rc) return propagate(cs[c], rc);
+        const int rc = set_frame(cs[c], true, rgb[a[c]], rgb_step, depth[a[c]], depth_step, depth_type, rows, cols, on_device, false);
+        if (rc) { drain(); return propagate(cs[c], rc); }
     }
-    for (int s = 0; s < steps; ++s) {
+    // Rolling pipeline: context c collects pair s-1, then immediately gets the upload + frame set-up + schedule of pair s;
+    // while the host waits for one context the other k_ctx-1 keep the copy engine and the CUs busy.
+    for (int s = 0; s <= steps; ++s) {
         for (int c = 0; c < k_ctx; ++c) {
-            if (a[c] + s >= b[c]) continue;
-            const int f = a[c] + s + 1;
-            int rc = set_frame(cs[c], false, rgb[f], rgb_step, depth[f], depth_step, depth_type, rows, cols, on_device);
-            if (!rc) rc = rgbd360_align360_begin(cs[c], g, method, occlusion);
-            if (rc) {
-                for (int d = 0; d < c; ++d)          // drain what is already in flight
-                    if (cs[d]->al_active) { float tmp[16]; rgbd360_align360_finish(cs[d], tmp, nullptr); }
-                return propagate(cs[c], rc);
+            int rc = 0;
+            if (s > 0 && a[c] + s - 1 < b[c]) {
+                const int j = a[c] + s - 1;
+                rgbd360_result R;
+                rc = rgbd360_align360_finish(cs[c], poses_out + (size_t)16 * j, &R);
+                if (results_out) results_out[j] = R;
+                if (rc >= 0) rc = j + 1 < b[c] ? std::min(0, rgbd360_promote_source_to_target(cs[c])) : 0;
             }
+            if (!rc && a[c] + s < b[c]) {
+                const int f = a[c] + s + 1;
+                rc = set_frame(cs[c], false, rgb[f], rgb_step, depth[f], depth_step, depth_type, rows, cols, on_device, false);
+                if (!rc) rc = rgbd360_align360_begin(cs[c], g, method, occlusion);
+            }
+            if (rc) { drain(); return propagate(cs[c], rc); }
         }
-        int first_err = 0;
-        rgbd360_ctx* err_ctx = nullptr;
-        for (int c = 0; c < k_ctx; ++c) {
-            if (a[c] + s >= b[c]) continue;
-            const int j = a[c] + s;
-            rgbd360_result R;
-            int rc = rgbd360_align360_finish(cs[c], poses_out + (size_t)16 * j, &R);
-            if (results_out) results_out[j] = R;
-            if (rc >= 0 && j + 1 < b[c]) rc = std::min(0, rgbd360_promote_source_to_target(cs[c]));
-            if (rc < 0 && !first_err) { first_err = rc; err_ctx = cs[c]; }
-        }
-        if (first_err) return propagate(err_ctx, first_err);
     }
     return 0;
 }

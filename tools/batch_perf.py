@@ -37,7 +37,7 @@ for k in (2, 4, 8):
 
 # the same through ONE C call (rgbd360_align360_batch): no Python between the pairs
 reg2 = RegisterPhotoICP(); reg2.setNumPyr(4)
-for k in (1, 2, 4):
+for k in (1, 2, 4, 8):
     reg2.alignSequence(frames[: 2 * k + 1], method=2, n_inflight=k)      # warm (creates the sibling contexts)
     t0 = time.perf_counter()
     p3, st3, it3 = reg2.alignSequence(frames, method=2, n_inflight=k)
@@ -66,3 +66,34 @@ for k in (1, 2, 4):
     p4, st4, it4 = reg2.alignSequenceDev(rgb_d, dep_d, H, W, 0, method=2, n_inflight=k)
     dt = time.perf_counter() - t0
     print("PHOTO_DEPTH, rgbd360_align360_batch_dev n_inflight=%d: %d pairs in %.2f ms -> %.0f alignments/s; identical poses: %s" % (k, n, dt * 1e3, n / dt, bool(np.array_equal(p4, ref_poses))))
+
+# host frames in PINNED memory (hipHostMalloc): the uploads become real asynchronous DMA that overlaps the other contexts' kernels
+hip.hipHostMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint]
+
+
+def pinned_copy(a):
+    a = np.ascontiguousarray(a)
+    p = C.c_void_p()
+    assert hip.hipHostMalloc(C.byref(p), a.nbytes, 0) == 0
+    out = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(a.nbytes,)).view(a.dtype).reshape(a.shape)
+    out[...] = a
+    return out
+
+
+frames_p = [(pinned_copy(f[0]), pinned_copy(f[1])) for f in frames]
+for k in (1, 2, 4, 8):
+    reg2.alignSequence(frames_p[: 2 * k + 1], method=2, n_inflight=k)
+    t0 = time.perf_counter()
+    p5, st5, it5 = reg2.alignSequence(frames_p, method=2, n_inflight=k)
+    dt = time.perf_counter() - t0
+    print("PHOTO_DEPTH, rgbd360_align360_batch PINNED host frames n_inflight=%d: %d pairs in %.2f ms -> %.0f alignments/s; identical poses: %s" % (k, n, dt * 1e3, n / dt, bool(np.array_equal(p5, ref_poses))))
+frames_p16 = [(f[0], pinned_copy(np.round(f[1] * 1000.0).astype(np.uint16))) for f in frames_p]
+for k in (2, 4):
+    try:
+        reg2.alignSequence(frames_p16[: 2 * k + 1], method=2, n_inflight=k)
+        t0 = time.perf_counter()
+        p6, st6, it6 = reg2.alignSequence(frames_p16, method=2, n_inflight=k)
+        dt = time.perf_counter() - t0
+        print("PHOTO_DEPTH, PINNED host frames, uint16 mm depth, n_inflight=%d: %d pairs in %.2f ms -> %.0f alignments/s; mean iters/level %s; status ok %d" % (k, n, dt * 1e3, n / dt, np.round(it6.mean(0), 2).tolist(), int((st6 == 0).sum())))
+    except Exception as ex:
+        print("u16 pinned run failed:", ex)
