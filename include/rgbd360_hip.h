@@ -116,9 +116,9 @@ int rgbd360_align360_finish(rgbd360_ctx* ctx, float pose_out[16], rgbd360_result
  * OdometryRGBD360.cpp:141-297 walks a sequence; SURVEY.md 8b/8e's batch entry for ONE GPU (multi-GPU = one process per GPU,
  * each calling this on its contiguous shard; see rgbd360_amd/batch.py).  rgb[k] / depth[k]: host images as in
  * rgbd360_set_target.  The pairs are split into n_inflight (1..16) contiguous sub-chunks that run concurrently, each on its
- * own context and stream (created once and owned by `ctx`); inside a sub-chunk every frame is uploaded once, asynchronously:
- * the host images must stay unchanged until the call returns, and the upload of one sub-chunk's next frame overlaps the
- * other sub-chunks' kernels (4 in flight keep both the copy engine and the CUs busy).  guess (NULL =
+ * own context, stream and host thread (created by and owned by `ctx`); inside a sub-chunk every frame is uploaded once, one
+ * frame ahead of its alignment on a copy stream: the host images must stay unchanged until the call returns.  3 in flight
+ * keep the copy engine and the CUs busy.  guess (NULL =
  * identity) is the initial pose of every pair.  poses_out: (n_frames-1) x 16 floats column-major; results_out (may be NULL):
  * n_frames-1 records whose .status carries the per-pair outcome (0 / ILL_POSED / NO_VALID_PIXELS).  Returns 0, or the first
  * negative error. */

@@ -20,7 +20,7 @@ LIB = os.path.join(_HERE, "lib", "librgbd360_hip.so")
 # contraction is re-enabled per block where it is harmless.
 # -fno-slp-vectorize: packed f32 math is not faster than scalar on gfx950 (tools/ubench/valu_rate.hip) and the
 # packing costs ~50 v_mov per pixel in the fused kernel.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-slp-vectorize",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", "-fno-slp-vectorize",
          "-mllvm", "-amdgpu-kernarg-preload-count=16",     # leading scalar kernel arguments arrive in SGPRs (gfx940+): no s_load round trip before the state load
          "-Wno-unused-value"]
 

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rgbd360_hip.h"
@@ -49,9 +50,13 @@ struct rgbd360_ctx {
     GNState* h_state = nullptr;   // pinned
     double* d_partials = nullptr;
     GnIO* d_gnio = nullptr;
-    uint8_t* d_stage_rgb = nullptr;
-    uint8_t* d_stage_depth = nullptr;
-    size_t stage_rgb_bytes = 0, stage_depth_bytes = 0;
+    // upload staging: slot 0 serves the single-frame entries (copies on `stream`); the sequence entry alternates both slots,
+    // copying on `up_stream` one frame ahead of the alignment (up_ev: upload landed, conv_ev: slot consumed)
+    uint8_t* d_stage_rgb[2] = {nullptr, nullptr};
+    uint8_t* d_stage_depth[2] = {nullptr, nullptr};
+    size_t stage_rgb_bytes[2] = {0, 0}, stage_depth_bytes[2] = {0, 0};
+    hipStream_t up_stream = nullptr;
+    hipEvent_t up_ev[2] = {nullptr, nullptr}, conv_ev[2] = {nullptr, nullptr};
     int poll_chunk = 3;           // {pass, solve} pairs per level enqueued ahead of the device
     int first_chunk_top = 8;      // ... and for the first visit of the coarsest level (cheap passes, most iterations)
     int chunk_level0 = 3;         // ... and for the finest level (most expensive passes; a second chunk costs a host round trip)
@@ -305,10 +310,49 @@ void launch_src_recs(rgbd360_ctx* ctx) {
     hipLaunchKernelGGL(k_src_rec_multi, dim3(nb), dim3(256), 0, ctx->stream, jobs);
 }
 
+static int ensure_stage(rgbd360_ctx* ctx, int slot, size_t need_rgb, size_t need_d) {
+    if (ctx->stage_rgb_bytes[slot] < need_rgb) {
+        hipFree(ctx->d_stage_rgb[slot]);
+        ctx->d_stage_rgb[slot] = nullptr; ctx->stage_rgb_bytes[slot] = 0;
+        HIPC(ctx, hipMalloc(&ctx->d_stage_rgb[slot], need_rgb));
+        ctx->stage_rgb_bytes[slot] = need_rgb;
+    }
+    if (ctx->stage_depth_bytes[slot] < need_d) {
+        hipFree(ctx->d_stage_depth[slot]);
+        ctx->d_stage_depth[slot] = nullptr; ctx->stage_depth_bytes[slot] = 0;
+        HIPC(ctx, hipMalloc(&ctx->d_stage_depth[slot], need_d));
+        ctx->stage_depth_bytes[slot] = need_d;
+    }
+    return 0;
+}
+
+// Sequence path: copy one host frame into staging slot `slot` on the context's upload stream, ahead of its use.
+static int upload_stage(rgbd360_ctx* ctx, int slot, const uint8_t* rgb, size_t rgb_step, const void* depth, size_t d_step,
+                        int depth_type, int rows, int cols) {
+    const size_t dpx = depth_type == 0 ? 2 : 4;
+    if (!ctx->up_stream) {
+        HIPC(ctx, hipStreamCreateWithFlags(&ctx->up_stream, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k) {
+            HIPC(ctx, hipEventCreateWithFlags(&ctx->up_ev[k], hipEventDisableTiming));
+            HIPC(ctx, hipEventCreateWithFlags(&ctx->conv_ev[k], hipEventDisableTiming));
+        }
+    }
+    int rc = ensure_stage(ctx, slot, (size_t)rows * cols * 3, (size_t)rows * cols * dpx);
+    if (rc) return rc;
+    HIPC(ctx, hipStreamWaitEvent(ctx->up_stream, ctx->conv_ev[slot], 0));      // the slot's previous frame has been converted
+    HIPC(ctx, hipMemcpy2DAsync(ctx->d_stage_rgb[slot], (size_t)cols * 3, rgb, rgb_step, (size_t)cols * 3, rows,
+                               hipMemcpyHostToDevice, ctx->up_stream));
+    HIPC(ctx, hipMemcpy2DAsync(ctx->d_stage_depth[slot], (size_t)cols * dpx, depth, d_step, (size_t)cols * dpx, rows,
+                               hipMemcpyHostToDevice, ctx->up_stream));
+    HIPC(ctx, hipEventRecord(ctx->up_ev[slot], ctx->up_stream));
+    return 0;
+}
+
+// staged_slot >= 0: the frame was put into that staging slot by upload_stage (rgb / depth are then unused).
 int set_frame(rgbd360_ctx* ctx, bool target, const uint8_t* rgb, size_t rgb_step, const void* depth, size_t d_step,
-              int depth_type, int rows, int cols, bool on_device, bool wait_for_upload = true) {
+              int depth_type, int rows, int cols, bool on_device, bool wait_for_upload = true, int staged_slot = -1) {
     if (!ctx) return -1;
-    if (!rgb || !depth) return fail(ctx, -1, "null image pointer");
+    if (staged_slot < 0 && (!rgb || !depth)) return fail(ctx, -1, "null image pointer");
     if (depth_type != 0 && depth_type != 1) return fail(ctx, -1, "depth_type must be 0 (u16 mm) or 1 (f32 m)");
     if (ctx->levels.size() && (rows != ctx->rows || cols != ctx->cols) && (target ? ctx->have_src : ctx->have_trg)) {
         // the other frame has different dimensions: both must be set again (the reference would read out of bounds)
@@ -320,23 +364,18 @@ int set_frame(rgbd360_ctx* ctx, bool target, const uint8_t* rgb, size_t rgb_step
     const uint8_t* d_rgb = rgb;
     const void* d_depth = depth;
     size_t s_rgb = rgb_step, s_depth = d_step;
-    if (!on_device) {
-        const size_t need_rgb = (size_t)rows * cols * 3, need_d = (size_t)rows * cols * dpx;
-        if (ctx->stage_rgb_bytes < need_rgb) {
-            hipFree(ctx->d_stage_rgb);
-            HIPC(ctx, hipMalloc(&ctx->d_stage_rgb, need_rgb));
-            ctx->stage_rgb_bytes = need_rgb;
-        }
-        if (ctx->stage_depth_bytes < need_d) {
-            hipFree(ctx->d_stage_depth);
-            HIPC(ctx, hipMalloc(&ctx->d_stage_depth, need_d));
-            ctx->stage_depth_bytes = need_d;
-        }
-        HIPC(ctx, hipMemcpy2DAsync(ctx->d_stage_rgb, (size_t)cols * 3, rgb, rgb_step, (size_t)cols * 3, rows,
+    if (staged_slot >= 0) {
+        HIPC(ctx, hipStreamWaitEvent(ctx->stream, ctx->up_ev[staged_slot], 0));
+        d_rgb = ctx->d_stage_rgb[staged_slot]; d_depth = ctx->d_stage_depth[staged_slot];
+        s_rgb = (size_t)cols * 3; s_depth = (size_t)cols * dpx;
+    } else if (!on_device) {
+        rc = ensure_stage(ctx, 0, (size_t)rows * cols * 3, (size_t)rows * cols * dpx);
+        if (rc) return rc;
+        HIPC(ctx, hipMemcpy2DAsync(ctx->d_stage_rgb[0], (size_t)cols * 3, rgb, rgb_step, (size_t)cols * 3, rows,
                                    hipMemcpyHostToDevice, ctx->stream));
-        HIPC(ctx, hipMemcpy2DAsync(ctx->d_stage_depth, (size_t)cols * dpx, depth, d_step, (size_t)cols * dpx, rows,
+        HIPC(ctx, hipMemcpy2DAsync(ctx->d_stage_depth[0], (size_t)cols * dpx, depth, d_step, (size_t)cols * dpx, rows,
                                    hipMemcpyHostToDevice, ctx->stream));
-        d_rgb = ctx->d_stage_rgb; d_depth = ctx->d_stage_depth;
+        d_rgb = ctx->d_stage_rgb[0]; d_depth = ctx->d_stage_depth[0];
         s_rgb = (size_t)cols * 3; s_depth = (size_t)cols * dpx;
     }
     Level& L0 = ctx->levels[0];
@@ -346,6 +385,7 @@ int set_frame(rgbd360_ctx* ctx, bool target, const uint8_t* rgb, size_t rgb_step
         dim3 g = grid2d(rows, (cols + 3) / 4);
         g.z = 2;                                        // colour -> intensity and depth -> metres in one launch
         hipLaunchKernelGGL(k_convert_pair, g, dim3(256), 0, ctx->stream, d_rgb, s_rgb, d_depth, s_depth, depth_type, rows, cols, gray0, dep0);
+        if (staged_slot >= 0) HIPC(ctx, hipEventRecord(ctx->conv_ev[staged_slot], ctx->stream));
     }
     for (int l = 1; l < ctx->p.n_pyr; ++l) {
         Level &P = ctx->levels[l - 1], &C = ctx->levels[l];
@@ -359,7 +399,7 @@ int set_frame(rgbd360_ctx* ctx, bool target, const uint8_t* rgb, size_t rgb_step
     else launch_src_recs(ctx);
     HIPC(ctx, hipGetLastError());
     // host buffers may be reused by the caller once a set_* call returns; the sequence entry owns them until it returns
-    if (!on_device && wait_for_upload) HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    if (!on_device && staged_slot < 0 && wait_for_upload) HIPC(ctx, hipStreamSynchronize(ctx->stream));
     if (target) ctx->have_trg = true; else ctx->have_src = true;
     return 0;
 }
@@ -437,7 +477,12 @@ void rgbd360_destroy(rgbd360_ctx* ctx) {
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     free_levels(ctx);
     hipFree(ctx->d_state); hipFree(ctx->d_partials); hipFree(ctx->d_gnio);
-    hipFree(ctx->d_stage_rgb); hipFree(ctx->d_stage_depth);
+    for (int k = 0; k < 2; ++k) {
+        hipFree(ctx->d_stage_rgb[k]); hipFree(ctx->d_stage_depth[k]);
+        if (ctx->up_ev[k]) hipEventDestroy(ctx->up_ev[k]);
+        if (ctx->conv_ev[k]) hipEventDestroy(ctx->conv_ev[k]);
+    }
+    if (ctx->up_stream) { hipStreamSynchronize(ctx->up_stream); hipStreamDestroy(ctx->up_stream); }
     hipFree(ctx->f_xyz); hipFree(ctx->f_normals); hipFree(ctx->f_dist);
     hipFree(ctx->f_change); hipFree(ctx->f_hd); hipFree(ctx->f_label); hipFree(ctx->f_count); hipFree(ctx->f_slot_of_root);
     hipFree(ctx->f_root_of_slot); hipFree(ctx->f_nslots); hipFree(ctx->f_window); hipFree(ctx->f_mom);
@@ -604,43 +649,55 @@ static int align360_batch_impl(rgbd360_ctx* ctx, int n_frames, const uint8_t* co
     for (int c = 1; c < k_ctx; ++c) cs[c] = ctx->siblings[c - 1];
     // contiguous balanced spans [a, b) of pairs per context
     std::vector<int> a(k_ctx), b(k_ctx);
-    int steps = 0;
     for (int c = 0; c < k_ctx; ++c) {
         const int base = n / k_ctx, extra = n % k_ctx;
         a[c] = c * base + std::min(c, extra);
         b[c] = a[c] + base + (c < extra ? 1 : 0);
-        steps = std::max(steps, b[c] - a[c]);
     }
-    auto propagate = [&](rgbd360_ctx* from, int rc) { return from == ctx ? rc : fail(ctx, rc, from->err.c_str()); };
-    auto drain = [&]() {
-        for (int d = 0; d < k_ctx; ++d)
-            if (cs[d]->al_active) { float tmp[16]; rgbd360_align360_finish(cs[d], tmp, nullptr); }
-        for (int d = 0; d < k_ctx; ++d) hipStreamSynchronize(cs[d]->stream);      // no upload may outlive the caller's buffers
-    };
-    for (int c = 0; c < k_ctx; ++c) {
-        const int rc = set_frame(cs[c], true, rgb[a[c]], rgb_step, depth[a[c]], depth_step, depth_type, rows, cols, on_device, false);
-        if (rc) { drain(); return propagate(cs[c], rc); }
-    }
-    // Rolling pipeline: context c collects pair s-1, then immediately gets the upload + frame set-up + schedule of pair s;
-    // while the host waits for one context the other k_ctx-1 keep the copy engine and the CUs busy.
-    for (int s = 0; s <= steps; ++s) {
-        for (int c = 0; c < k_ctx; ++c) {
-            int rc = 0;
-            if (s > 0 && a[c] + s - 1 < b[c]) {
-                const int j = a[c] + s - 1;
-                rgbd360_result R;
-                rc = rgbd360_align360_finish(cs[c], poses_out + (size_t)16 * j, &R);
-                if (results_out) results_out[j] = R;
-                if (rc >= 0) rc = j + 1 < b[c] ? std::min(0, rgbd360_promote_source_to_target(cs[c])) : 0;
-            }
-            if (!rc && a[c] + s < b[c]) {
-                const int f = a[c] + s + 1;
-                rc = set_frame(cs[c], false, rgb[f], rgb_step, depth[f], depth_step, depth_type, rows, cols, on_device, false);
-                if (!rc) rc = rgbd360_align360_begin(cs[c], g, method, occlusion);
-            }
-            if (rc) { drain(); return propagate(cs[c], rc); }
+    // One host thread per sub-chunk: a 4-level alignment is ~65 dependent launches, so a single enqueueing thread (≈2.7 us
+    // per launch) caps a GPU at ≈5.7 k alignments/s however many contexts are in flight.  The sub-chunks share nothing
+    // (own context, stream, buffers, error string; disjoint output slots), so each walks its pairs on its own thread:
+    // upload (asynchronous, waited for only by the pair's own finish) -> frame set-up -> schedule -> finish -> promote.
+    std::vector<int> rcs(k_ctx, 0);
+    auto run_chunk = [&](int c) {
+        rgbd360_ctx* cc = cs[c];
+        hipSetDevice(cc->p.device);
+        int rc = 0;
+        if (on_device) {
+            rc = set_frame(cc, true, rgb[a[c]], rgb_step, depth[a[c]], depth_step, depth_type, rows, cols, true);
+        } else {        // frame f of this sub-chunk travels through staging slot (f - a) & 1, one frame ahead of the alignment
+            rc = upload_stage(cc, 0, rgb[a[c]], rgb_step, depth[a[c]], depth_step, depth_type, rows, cols);
+            if (!rc) rc = upload_stage(cc, 1, rgb[a[c] + 1], rgb_step, depth[a[c] + 1], depth_step, depth_type, rows, cols);
+            if (!rc) rc = set_frame(cc, true, nullptr, 0, nullptr, 0, depth_type, rows, cols, false, false, 0);
         }
+        for (int j = a[c]; !rc && j < b[c]; ++j) {
+            if (on_device) {
+                rc = set_frame(cc, false, rgb[j + 1], rgb_step, depth[j + 1], depth_step, depth_type, rows, cols, true);
+            } else {
+                rc = set_frame(cc, false, nullptr, 0, nullptr, 0, depth_type, rows, cols, false, false, (j + 1 - a[c]) & 1);
+                if (!rc && j + 2 <= b[c])       // the next source frame is copied while this pair is being aligned
+                    rc = upload_stage(cc, (j + 2 - a[c]) & 1, rgb[j + 2], rgb_step, depth[j + 2], depth_step, depth_type, rows, cols);
+            }
+            if (!rc) rc = rgbd360_align360_begin(cc, g, method, occlusion);
+            if (rc) break;
+            rgbd360_result R;
+            rc = rgbd360_align360_finish(cc, poses_out + (size_t)16 * j, &R);      // >= 0: the pair's outcome, kept in R.status
+            if (results_out) results_out[j] = R;
+            if (rc >= 0) rc = j + 1 < b[c] ? std::min(0, rgbd360_promote_source_to_target(cc)) : 0;
+        }
+        if (cc->up_stream) hipStreamSynchronize(cc->up_stream);      // no upload may outlive the caller's buffers
+        if (rc) hipStreamSynchronize(cc->stream);
+        rcs[c] = rc;
+    };
+    {
+        std::vector<std::thread> workers;
+        workers.reserve(k_ctx - 1);
+        for (int c = 1; c < k_ctx; ++c) workers.emplace_back(run_chunk, c);
+        run_chunk(0);
+        for (std::thread& w : workers) w.join();
     }
+    for (int c = 0; c < k_ctx; ++c)
+        if (rcs[c]) return cs[c] == ctx ? rcs[c] : fail(ctx, rcs[c], cs[c]->err.c_str());
     return 0;
 }
 

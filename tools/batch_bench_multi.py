@@ -28,7 +28,7 @@ if world > 1:
     dist.barrier()
 torch.cuda.synchronize() if world > 1 else None
 t0 = time.perf_counter()
-poses, status, iters = align_sequence_native(reg, lambda k: frames[k], lo, hi, 2, n_inflight=4)
+poses, status, iters = align_sequence_native(reg, lambda k: frames[k], lo, hi, 2, n_inflight=3)
 full = gather_poses(poses, n_pairs, dist if world > 1 else None, device=torch.device("cuda", local) if (world > 1 and not shared) else None)
 dt = time.perf_counter() - t0
 if world > 1:

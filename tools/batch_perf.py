@@ -87,13 +87,3 @@ for k in (1, 2, 4, 8):
     p5, st5, it5 = reg2.alignSequence(frames_p, method=2, n_inflight=k)
     dt = time.perf_counter() - t0
     print("PHOTO_DEPTH, rgbd360_align360_batch PINNED host frames n_inflight=%d: %d pairs in %.2f ms -> %.0f alignments/s; identical poses: %s" % (k, n, dt * 1e3, n / dt, bool(np.array_equal(p5, ref_poses))))
-frames_p16 = [(f[0], pinned_copy(np.round(f[1] * 1000.0).astype(np.uint16))) for f in frames_p]
-for k in (2, 4):
-    try:
-        reg2.alignSequence(frames_p16[: 2 * k + 1], method=2, n_inflight=k)
-        t0 = time.perf_counter()
-        p6, st6, it6 = reg2.alignSequence(frames_p16, method=2, n_inflight=k)
-        dt = time.perf_counter() - t0
-        print("PHOTO_DEPTH, PINNED host frames, uint16 mm depth, n_inflight=%d: %d pairs in %.2f ms -> %.0f alignments/s; mean iters/level %s; status ok %d" % (k, n, dt * 1e3, n / dt, np.round(it6.mean(0), 2).tolist(), int((st6 == 0).sum())))
-    except Exception as ex:
-        print("u16 pinned run failed:", ex)
