@@ -526,6 +526,42 @@ def test_native_batch_entry_equals_pairwise_alignment(hip_lib):
         reg.alignSequence(frames, n_inflight=0)
 
 
+@pytest.mark.gpu
+def test_native_batch_threads_blank_frame_and_odd_spans(hip_lib):
+    """The threaded sequence entry with a frame that has no valid depth in the middle (the pair that has it as source ends
+    NO_VALID_PIXELS, the others are unaffected), uneven sub-chunk spans, more sub-chunks than pairs, float depth and row-padded host images."""
+    from rgbd360_amd.batch import align_sequence
+    frames = [synth.render(synth.trajectory_pose(k, 11), 256, 128, 11) for k in range(8)]
+    frames[4] = (frames[4][0], np.zeros_like(frames[4][1]))
+    poses, status, iters = align_sequence(_mk(hip_lib, 3), lambda k: frames[k], 0, 7, 2)
+    assert status[3] != 0 and (np.delete(status, [3]) == 0).all()      # a blank TARGET still aligns photometrically
+    reg = _mk(hip_lib, 3)
+    for k in (1, 2, 3, 5, 7, 12):
+        p2, s2, i2 = reg.alignSequence(frames, method=2, n_inflight=k)
+        assert np.array_equal(poses, p2) and np.array_equal(status, s2) and np.array_equal(iters, i2), k
+    # float32 metres + row-padded views (cv::Mat ROI style): steps are taken from the first frame, so pad all alike
+    def padded(f):
+        rgb = np.zeros((128, 300, 3), np.uint8); rgb[:, :256] = f[0]
+        d = np.zeros((128, 290), np.float32); d[:, :256] = f[1].astype(np.float32) * np.float32(0.001)
+        return rgb, d
+    pads = [padded(f) for f in frames]
+    import ctypes as C
+    from rgbd360_amd._lib import Result
+    n = len(frames) - 1
+    rgb_ptrs = (C.c_void_p * len(frames))(*[q[0].ctypes.data for q in pads])
+    dep_ptrs = (C.c_void_p * len(frames))(*[q[1].ctypes.data for q in pads])
+    out = np.zeros(n * 16, np.float32)
+    res = (Result * n)()
+    rc = reg._L.rgbd360_align360_batch(reg._ctx(), len(frames), rgb_ptrs, 300 * 3, dep_ptrs, 290 * 4, 1, 128, 256, None, 2, 0, 3,
+                                       out.ctypes.data_as(C.POINTER(C.c_float)), res)
+    assert rc == 0
+    f32 = [(f[0], f[1].astype(np.float32) * np.float32(0.001)) for f in frames]
+    p3, s3, i3 = align_sequence(_mk(hip_lib, 3), lambda k: f32[k], 0, 7, 2)
+    for j in range(n):
+        assert res[j].status == s3[j]
+        assert np.array_equal(out[16 * j:16 * j + 16].reshape(4, 4).T, p3[j]), j
+
+
 # ---- occlusion-aware variants (SURVEY.md 8f rank 1; RPI.h:3232-4249, sequential semantics) ---------------------------
 _occluder_pair = synth.add_occluder
 _occ_poses = synth.occlusion_test_poses
