@@ -4,7 +4,8 @@
 //     frame_%03d.rgb  (H*W*3 uint8)   frame_%03d.depth (H*W uint16 mm)
 // Build:  g++ -std=c++17 -O2 -Iinclude examples/odometry_replay.cpp -Lrgbd360_amd/lib -lrgbd360_hip
 //             -Wl,-rpath,$PWD/rgbd360_amd/lib -o odometry_replay
-// Usage:  odometry_replay <dir> <n_frames> <width> <height>
+// Usage:  odometry_replay <dir> <n_frames> <width> <height> [--sequence]
+//         --sequence: all frames are loaded first and the frame loop runs inside the library (alignSequence)
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -48,7 +49,7 @@ static rgbd360::Mat4f mul(const rgbd360::Mat4f& A, const rgbd360::Mat4f& B) {
 
 int main(int argc, char** argv) {
     if (argc < 5) {
-        fprintf(stderr, "usage: %s <dir> <n_frames> <width> <height>\n", argv[0]);
+        fprintf(stderr, "usage: %s <dir> <n_frames> <width> <height> [--sequence]\n", argv[0]);
         return 2;
     }
     const std::string dir = argv[1];
@@ -57,6 +58,24 @@ int main(int argc, char** argv) {
     align360.setNumPyr(4);
     align360.useSaliency(false);
     rgbd360::Mat4f currentPose = rgbd360::Mat4f::Identity();
+    if (argc > 5 && std::string(argv[5]) == "--sequence") {
+        std::vector<Frame> frames(n);
+        std::vector<rgbd360::ImageView> rgb, depth;
+        for (int k = 0; k < n; ++k) {
+            if (!frames[k].load(dir, k, w, h)) return 3;
+            rgb.push_back(frames[k].sphereRGB);
+            depth.push_back(frames[k].sphereDepth);
+        }
+        std::vector<rgbd360_result> res;
+        const std::vector<rgbd360::Mat4f> rels = align360.alignSequence(rgb, depth, rgbd360::RegisterPhotoICP::PHOTO_DEPTH, 0, 3,
+                                                                        rgbd360::Mat4f::Identity(), &res);
+        for (size_t j = 0; j < rels.size(); ++j) {
+            currentPose = mul(currentPose, rels[j]);
+            printf("pair %zu status %d sso %.4f rel_t %.5f %.5f %.5f pose_t %.5f %.5f %.5f\n", j, res[j].status, res[j].sso,
+                   rels[j](0, 3), rels[j](1, 3), rels[j](2, 3), currentPose(0, 3), currentPose(1, 3), currentPose(2, 3));
+        }
+        return 0;
+    }
     Frame frame1, frame2;
     if (!frame1.load(dir, 0, w, h)) return 3;
     for (int k = 1; k < n; ++k) {

@@ -124,6 +124,36 @@ class RegisterPhotoICP {
         num_iterations_.assign(r.iters, r.iters + p_.n_pyr);
     }
 
+    // The frame loop of OdometryRGBD360.cpp:141-297 as one call (rgbd360_align360_batch): pair j aligns frame j+1 (source)
+    // to frame j (target); every frame is uploaded once, n_inflight sub-sequences run concurrently on the GPU.  All
+    // frames must share one size and depth type, and stay untouched until the call returns.  Returns the relative poses;
+    // statuses (0 / ILL_POSED / NO_VALID_PIXELS per pair) and full records through the optional outputs.
+    std::vector<Mat4f> alignSequence(const std::vector<ImageView>& rgb, const std::vector<ImageView>& depth,
+                                     costFuncType method = PHOTO_DEPTH, int occlusion = 0, int n_inflight = 3,
+                                     const Mat4f& pose_guess = Mat4f::Identity(), std::vector<rgbd360_result>* results = nullptr) {
+        if (rgb.size() != depth.size()) throw std::invalid_argument("rgbd360: rgb / depth sequence length mismatch");
+        const size_t n_frames = rgb.size();
+        std::vector<Mat4f> poses(n_frames > 0 ? n_frames - 1 : 0, Mat4f::Identity());
+        if (results) results->assign(poses.size(), rgbd360_result{});
+        if (poses.empty()) return poses;
+        std::vector<const uint8_t*> prgb(n_frames);
+        std::vector<const void*> pdepth(n_frames);
+        for (size_t k = 0; k < n_frames; ++k) {
+            if (rgb[k].type != ImageView::U8C3 || depth[k].type == ImageView::U8C3 || depth[k].type != depth[0].type ||
+                rgb[k].rows != rgb[0].rows || rgb[k].cols != rgb[0].cols || depth[k].rows != rgb[0].rows || depth[k].cols != rgb[0].cols ||
+                rgb[k].step != rgb[0].step || depth[k].step != depth[0].step)
+                throw std::invalid_argument("rgbd360: all frames of a sequence must share one size, step and depth type");
+            prgb[k] = (const uint8_t*)rgb[k].data;
+            pdepth[k] = depth[k].data;
+        }
+        static_assert(sizeof(Mat4f) == 16 * sizeof(float), "Mat4f must be 16 packed floats");
+        const int rc = rgbd360_align360_batch(ctx(), (int)n_frames, prgb.data(), rgb[0].step, pdepth.data(), depth[0].step,
+                                              depth[0].type == ImageView::U16C1 ? 0 : 1, rgb[0].rows, rgb[0].cols, pose_guess.m,
+                                              (int)method, occlusion, n_inflight, poses[0].m, results ? results->data() : nullptr);
+        if (rc < 0) throw std::runtime_error(std::string("rgbd360_align360_batch: ") + rgbd360_last_error(ctx_));
+        return poses;
+    }
+
     Mat4f getOptimalPose() const { return relPose_; }          // RPI.h:273
     Mat6f getHessian() const { return hessian_; }              // RPI.h:279
     std::array<float, 6> getGradient() const { return gradient_; }

@@ -44,3 +44,8 @@ def test_odometry_replay_matches_python_host(tmp_path, hip_lib):
     for j, r in enumerate(rows):
         rel_t = np.array([float(x) for x in r[7:10]])
         assert np.allclose(rel_t, poses[j][:3, 3], atol=2e-5)
+    # the frame loop inside the library (RegisterPhotoICP::alignSequence -> rgbd360_align360_batch): the same lines
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "dump_sequence.py"), str(seq), "6", "256", "128"])
+    pairwise = subprocess.check_output([exe, str(seq), "6", "256", "128"], text=True)
+    batched = subprocess.check_output([exe, str(seq), "6", "256", "128", "--sequence"], text=True)
+    assert len(pairwise.strip().splitlines()) == 5 and pairwise == batched
