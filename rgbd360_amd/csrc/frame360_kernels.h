@@ -8,9 +8,9 @@
 // the CPU restatement in oracle/frame360_ref.cpp documents the shared, deliberate differences (direct window sums,
 // double moments, no boundary refinement, optional range-as-depth mode for full spheres).
 //
-//   k_f360_edges      depth-change map (computeFeature)                      1 B/px out
-//   k_f360_hdist      per-row distance to the nearest depth-change pixel     1 B/px
-//   k_f360_dist       chamfer (1 / 1.4) distance map, truncated at kF360R    4 B/px
+//   k_f360_edge_bits  depth-change map (computeFeature) as a bit mask        1 bit/px out
+//   k_f360_distmap    per-row distance to the nearest depth-change pixel + chamfer (1 / 1.4) distance map, truncated at
+//                     kF360R                                                  4 B/px out
 //   k_f360_normals_tiled  central differences + per-tile integral images in LDS -> window-averaged gradients -> normal
 //   k_f360_ccl_rows / _merge / _compress   connected components: row runs by scan, vertical joins by union-find (atomicMin)
 //   k_f360_count / _assign / _moments      region sizes, compaction of the large regions, 9 moments per region
@@ -33,56 +33,126 @@ __device__ __forceinline__ bool depth_break(float da, float db, float factor) {
     return (fabsf(da - db) > ddc) || !isfinite(da) || !isfinite(db);
 }
 
-__global__ void k_f360_edges(const float* __restrict__ xyz, int rows, int cols, float factor, int depth_mode,
-                             uint8_t* __restrict__ change) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
-    if (c >= cols || r >= rows) return;
-    const size_t i = (size_t)r * cols + c;
-    const float d = depth_of(xyz + 3 * i, depth_mode);
-    bool edge = false;
-    if (r < rows - 1 && c < cols - 1) {       // visited as `index`
-        edge |= depth_break(d, depth_of(xyz + 3 * (i + 1), depth_mode), factor);
-        edge |= depth_break(d, depth_of(xyz + 3 * (i + cols), depth_mode), factor);
-    }
-    if (c >= 1 && r < rows - 1)               // right neighbour of (r, c-1)   (c-1 < cols-1 always)
-        edge |= depth_break(depth_of(xyz + 3 * (i - 1), depth_mode), d, factor);
-    if (r >= 1 && c < cols - 1)               // lower neighbour of (r-1, c)
-        edge |= depth_break(depth_of(xyz + 3 * (i - cols), depth_mode), d, factor);
-    change[i] = edge ? 0 : 255;
-}
-
-__global__ void k_f360_hdist(const uint8_t* __restrict__ change, int rows, int cols, uint8_t* __restrict__ hd) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
-    if (c >= cols || r >= rows) return;
-    const uint8_t* row = change + (size_t)r * cols;
-    int best = 255;
-    for (int k = 0; k <= kF360R; ++k) {
-        const bool l = (c - k >= 0) && row[c - k] == 0, rr = (c + k < cols) && row[c + k] == 0;
-        if (l || rr) {
-            best = k;
-            break;
+// Depth-change map as a BIT mask (bit c & 63 of word [r * pitch + c / 64] = pixel (r, c) lies on a depth change; bits past
+// the last column are 0).  One block owns 256 columns x 8 rows; the depths of the tile + a one-pixel ring are computed once
+// into LDS (1.26 per pixel instead of 5), the 64 decisions of a wave row leave through one ballot.
+// History at 2048x1024: byte map + per-row distance + chamfer map as three per-pixel kernels 19.5 + 21 + 27 us.
+constexpr int kEdgeTW = 256, kEdgeTH = 8;
+__global__ __launch_bounds__(kEdgeTW) void k_f360_edge_bits(const float* __restrict__ xyz, int rows, int cols, float factor, int depth_mode,
+                                                           int pitch_words, unsigned long long* __restrict__ bits) {
+    __shared__ float dep[kEdgeTH + 2][kEdgeTW + 2];
+    const int t = threadIdx.x;
+    const int c0 = blockIdx.x * kEdgeTW, r0 = blockIdx.y * kEdgeTH;
+    {   // all loads of the thread are issued before the first depth is formed (one memory round trip per block, not eleven)
+        constexpr int kN = (kEdgeTH + 2) * (kEdgeTW + 2), kTrips = (kN + kEdgeTW - 1) / kEdgeTW;
+        float px[kTrips], py[kTrips], pz[kTrips];
+        bool inb[kTrips];
+#pragma unroll
+        for (int k = 0; k < kTrips; ++k) {
+            const int e = t + k * kEdgeTW;
+            const int ey = e / (kEdgeTW + 2), ex = e - ey * (kEdgeTW + 2);
+            const int r = r0 - 1 + ey, c = c0 - 1 + ex;
+            inb[k] = e < kN && r >= 0 && r < rows && c >= 0 && c < cols;
+            const float* p = xyz + 3 * (inb[k] ? (size_t)r * cols + c : (size_t)0);
+            px[k] = p[0]; py[k] = p[1]; pz[k] = p[2];
+        }
+        float* flat = &dep[0][0];
+#pragma unroll
+        for (int k = 0; k < kTrips; ++k) {
+            const int e = t + k * kEdgeTW;
+            const float pt[3] = {px[k], py[k], pz[k]};
+            if (e < kN) flat[e] = inb[k] ? depth_of(pt, depth_mode) : 0.f;
         }
     }
-    hd[(size_t)r * cols + c] = (uint8_t)best;
+    __syncthreads();
+    const int c = c0 + t;
+#pragma unroll
+    for (int y = 0; y < kEdgeTH; ++y) {
+        const int r = r0 + y;
+        bool edge = false;
+        if (c < cols && r < rows) {
+            const float d = dep[y + 1][t + 1];
+            if (r < rows - 1 && c < cols - 1) {       // visited as `index`
+                edge |= depth_break(d, dep[y + 1][t + 2], factor);
+                edge |= depth_break(d, dep[y + 2][t + 1], factor);
+            }
+            if (c >= 1 && r < rows - 1)               // right neighbour of (r, c-1)   (c-1 < cols-1 always)
+                edge |= depth_break(dep[y + 1][t], d, factor);
+            if (r >= 1 && c < cols - 1)               // lower neighbour of (r-1, c)
+                edge |= depth_break(dep[y][t + 1], d, factor);
+        }
+        const unsigned long long m = __ballot(edge);
+        const int w = (c0 >> 6) + (t >> 6);
+        if ((t & 63) == 0 && r < rows && w < pitch_words) bits[(size_t)r * pitch_words + w] = m;
+    }
 }
 
-// chamfer distance with weights 1 (straight) / 1.4 (diagonal): max + 0.4 min, min over the rows within the radius of the
-// nearest depth-change pixel of each row (for a fixed row offset the metric grows with |dx|)
-__global__ void k_f360_dist(const uint8_t* __restrict__ hd, int rows, int cols, float* __restrict__ dist) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
-    if (c >= cols || r >= rows) return;
-    float best = (float)(cols + rows);
-    for (int dy = -kF360R; dy <= kF360R; ++dy) {
-        const int rr = r + dy;
-        if (rr < 0 || rr >= rows) continue;
-        const int dx = hd[(size_t)rr * cols + c];
-        if (dx == 255) continue;
-        const int ady = dy < 0 ? -dy : dy;
+// Chamfer (1 / 1.4) distance to the nearest depth-change pixel, truncated at kF360R, from the bit mask: one block owns
+// 64 columns x 32 rows.  (1) the three mask words around the tile's word column of the 56 rows within the radius go to
+// LDS; (2) the per-row distance to the nearest set bit within +-kF360R comes from a 25-bit window (count-leading /
+// count-trailing zeros instead of a 13-step search); (3) every pixel takes max + 0.4 min over the 25 rows around it (for
+// a fixed row offset the metric grows with |dx|, so the nearest change pixel of each row suffices); the 13 x 14 possible
+// values come from a table in LDS (one read + one min per candidate instead of nine VALU operations: the kernel was
+// VALU-bound on the 25 candidates per pixel).
+constexpr int kDistTW = 64, kDistTH = 32, kDistThreads = 256;
+constexpr int kDistRows = kDistTH + 2 * kF360R;
+__global__ __launch_bounds__(kDistThreads) void k_f360_distmap(const unsigned long long* __restrict__ bits, int rows, int cols, int pitch_words,
+                                                              float* __restrict__ dist) {
+    __shared__ unsigned long long words[kDistRows][3];
+    __shared__ uint8_t hd[kDistRows][kDistTW];              // 4 * min(row distance, kF360R + 1): a byte offset into a LUT row
+    __shared__ float lut[kF360R + 1][16];                    // lut[|dy|][dx]: chamfer value; dx = kF360R + 1: no change pixel in that row
+    const int t = threadIdx.x;
+    const int w = blockIdx.x, r0 = blockIdx.y * kDistTH;
+    const float far = (float)(cols + rows);
+    if (t < kDistRows * 3) {
+        const int y = t / 3, k = t - 3 * y;
+        const int r = r0 - kF360R + y, ww = w - 1 + k;
+        words[y][k] = (r >= 0 && r < rows && ww >= 0 && ww < pitch_words) ? bits[(size_t)r * pitch_words + ww] : 0ull;
+    }
+    if (t < (kF360R + 1) * 16) {
+        const int ady = t >> 4, dx = t & 15;
         const int mn = dx < ady ? dx : ady, mx = dx < ady ? ady : dx;
         const float v = (float)mn * 1.4f + (float)(mx - mn);
-        best = v < best ? v : best;
+        lut[ady][dx] = (dx <= kF360R && v < far) ? v : far;
     }
-    dist[(size_t)r * cols + c] = best;
+    __syncthreads();
+    const int b = t & 63;
+    for (int y = t >> 6; y < kDistRows; y += kDistThreads / 64) {
+        const unsigned long long lo = words[y][0], mid = words[y][1], hi = words[y][2];
+        const int s = 64 - kF360R + b;                      // first bit of the window in the 192-bit row lo | mid | hi
+        unsigned long long x;
+        if (s < 64) x = (lo >> s) | (mid << (64 - s));      // s >= 52
+        else x = (s == 64) ? mid : ((mid >> (s - 64)) | (hi << (128 - s)));
+        const unsigned win = (unsigned)x & ((1u << (2 * kF360R + 1)) - 1u);     // bit kF360R = the pixel itself
+        const unsigned left = win & ((1u << (kF360R + 1)) - 1u), right = win >> kF360R;
+        int best = kF360R + 1;
+        if (left) best = kF360R - (31 - __clz((int)left));
+        if (right) {
+            const int dr = __ffs((int)right) - 1;
+            best = dr < best ? dr : best;
+        }
+        hd[y][b] = (uint8_t)(best * 4);
+    }
+    __syncthreads();
+    const int c = w * 64 + b;
+    const int g = t >> 6;                                  // rows g*8 .. g*8+7 of the tile
+    constexpr int kPer = kDistTH / (kDistThreads / 64);
+    int col[kPer + 2 * kF360R];
+#pragma unroll
+    for (int k = 0; k < kPer + 2 * kF360R; ++k) col[k] = hd[g * kPer + k][b];
+    const char* lut_bytes = reinterpret_cast<const char*>(&lut[0][0]);
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const int r = r0 + g * kPer + j;
+        float best = far;
+#pragma unroll
+        for (int dy = -kF360R; dy <= kF360R; ++dy) {       // rows outside the image hold "none" (their mask words are 0)
+            const int ady = dy < 0 ? -dy : dy;
+            const float v = *reinterpret_cast<const float*>(lut_bytes + ady * 64 + col[j + kF360R + dy]);
+            best = v < best ? v : best;
+        }
+        if (r < rows && c < cols) dist[(size_t)r * cols + c] = best;
+    }
 }
 
 // Normal map from per-tile integral images in LDS (what pcl::IntegralImageNormalEstimation does globally, in double):

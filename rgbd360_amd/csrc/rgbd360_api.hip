@@ -1207,7 +1207,7 @@ int f360_ensure(rgbd360_ctx* ctx, size_t n) {
     HIPC(ctx, hipMalloc(&ctx->f_normals, n * 3 * sizeof(float)));
     HIPC(ctx, hipMalloc(&ctx->f_dist, n * sizeof(float)));
     HIPC(ctx, hipMalloc(&ctx->f_change, n));
-    HIPC(ctx, hipMalloc(&ctx->f_hd, n));
+    HIPC(ctx, hipMalloc(&ctx->f_hd, 3 * n + 64));      // depth-change bit mask: rows x ceil(cols / 64) words <= n/8 + 8 rows bytes, cols >= 3
     HIPC(ctx, hipMalloc(&ctx->f_label, n * sizeof(int)));
     HIPC(ctx, hipMalloc(&ctx->f_count, n * sizeof(unsigned long long)));
     HIPC(ctx, hipMalloc(&ctx->f_slot_of_root, n * sizeof(int)));
@@ -1221,15 +1221,23 @@ int f360_ensure(rgbd360_ctx* ctx, size_t n) {
     return 0;
 }
 
+// distance to the nearest depth change of the organised cloud in ctx->f_xyz -> ctx->f_dist (device); f_hd holds the bit mask
+static void launch_distance_map(rgbd360_ctx* ctx, int rows, int cols, float max_depth_change_factor, int depth_mode) {
+    using namespace f360;
+    const int pitch = (cols + 63) / 64;
+    unsigned long long* bits = reinterpret_cast<unsigned long long*>(ctx->f_hd);
+    hipLaunchKernelGGL(k_f360_edge_bits, dim3((cols + kEdgeTW - 1) / kEdgeTW, (rows + kEdgeTH - 1) / kEdgeTH), dim3(kEdgeTW), 0, ctx->stream,
+                       ctx->f_xyz, rows, cols, max_depth_change_factor, depth_mode, pitch, bits);
+    hipLaunchKernelGGL(k_f360_distmap, dim3(pitch, (rows + kDistTH - 1) / kDistTH), dim3(kDistThreads), 0, ctx->stream, bits, rows, cols,
+                       pitch, ctx->f_dist);
+}
+
 // normals of the organised cloud in ctx->f_xyz -> ctx->f_normals (device)
 int f360_normals_dev(rgbd360_ctx* ctx, int rows, int cols, float max_depth_change_factor, float smoothing_size, int depth_mode) {
     using namespace f360;
     if (smoothing_size < 1.f || smoothing_size + 2.5f > (float)kF360R)
         return fail(ctx, -1, "normal_smoothing_size out of range (the distance map is truncated at 12 px)");
-    const dim3 g = grid2d(rows, cols), b(256);
-    hipLaunchKernelGGL(k_f360_edges, g, b, 0, ctx->stream, ctx->f_xyz, rows, cols, max_depth_change_factor, depth_mode, ctx->f_change);
-    hipLaunchKernelGGL(k_f360_hdist, g, b, 0, ctx->stream, ctx->f_change, rows, cols, ctx->f_hd);
-    hipLaunchKernelGGL(k_f360_dist, g, b, 0, ctx->stream, ctx->f_hd, rows, cols, ctx->f_dist);
+    launch_distance_map(ctx, rows, cols, max_depth_change_factor, depth_mode);
     const dim3 gt((cols + kNT_W - 1) / kNT_W, (rows + kNT_H - 1) / kNT_H);
     hipLaunchKernelGGL(k_f360_normals_tiled, gt, dim3(kNT_THREADS), 0, ctx->stream, ctx->f_xyz, ctx->f_dist, rows, cols, smoothing_size,
                        depth_mode, ctx->f_normals, ctx->f_window);
@@ -1458,10 +1466,7 @@ extern "C" int rgbd360_distance_map(rgbd360_ctx* ctx, const float* xyz, int rows
     int rc = f360_ensure(ctx, n);
     if (rc) return rc;
     HIPC(ctx, hipMemcpyAsync(ctx->f_xyz, xyz, n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    const dim3 g = grid2d(rows, cols), b(256);
-    hipLaunchKernelGGL(f360::k_f360_edges, g, b, 0, ctx->stream, ctx->f_xyz, rows, cols, max_depth_change_factor, depth_mode, ctx->f_change);
-    hipLaunchKernelGGL(f360::k_f360_hdist, g, b, 0, ctx->stream, ctx->f_change, rows, cols, ctx->f_hd);
-    hipLaunchKernelGGL(f360::k_f360_dist, g, b, 0, ctx->stream, ctx->f_hd, rows, cols, ctx->f_dist);
+    launch_distance_map(ctx, rows, cols, max_depth_change_factor, depth_mode);
     HIPC(ctx, hipGetLastError());
     HIPC(ctx, hipMemcpyAsync(dist_out, ctx->f_dist, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIPC(ctx, hipStreamSynchronize(ctx->stream));

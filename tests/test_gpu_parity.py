@@ -343,6 +343,38 @@ def test_normal_map_matches_oracle(hip_lib, oracle_mod, depth_mode):
     assert ((nrm[ok] * xyz[ok]).sum(1) <= 1e-4).all()  # flipped towards the viewpoint (origin)
 
 
+@pytest.mark.parametrize("H,W", [(37, 250), (70, 65), (33, 129), (9, 3), (64, 64), (41, 700)])
+@pytest.mark.parametrize("depth_mode", [0, 1])
+def test_distance_map_ragged_sizes(hip_lib, oracle_mod, H, W, depth_mode):
+    """The bit-mask distance map on widths that are not a multiple of the 64-pixel mask word / the 256 x 8 and 64 x 32 tiles:
+    blocky depth steps, NaN holes, changes right at the image border."""
+    from rgbd360_amd.register import Frame360Stages
+    rng = np.random.default_rng(H * 1000 + W + depth_mode)
+    z = np.full((H, W), 2.0, np.float32)
+    for _ in range(6):
+        r, c = rng.integers(0, H), rng.integers(0, W)
+        z[r:r + rng.integers(1, 12), c:c + rng.integers(1, 40)] += np.float32(rng.uniform(0.5, 2.0))
+    z[:, W - 1] += 1.5 * (rng.random(H) < 0.3)            # steps in the last column / row
+    z[H - 1, :] += 1.5 * (rng.random(W) < 0.3)
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    xyz = np.stack([(xx - W / 2) * z / 200, (yy - H / 2) * z / 200, z], -1).reshape(-1, 3).astype(np.float32)
+    holes = rng.random(H * W) < 0.002
+    xyz[holes] = np.nan
+    st = Frame360Stages(_mk(hip_lib, 2))
+    dist_ref = oracle_mod.f360_distance_map(xyz, H, W, 0.05, depth_mode)
+    dist = st.distance_map(xyz, H, W, 0.05, depth_mode)
+    assert np.array_equal(dist_ref == 0, dist == 0) and (dist_ref == 0).any()
+    # PCL's two passes never update the first / last column, the first row (forward) and the last row (backward): those
+    # pixels keep rows + cols unless they are depth changes themselves (they never get a normal); inside, both are the chamfer metric
+    inner = np.zeros((H, W), bool)
+    inner[1:H - 1, 1:W - 1] = True
+    dist, dist_ref = np.asarray(dist).reshape(H, W), np.asarray(dist_ref).reshape(H, W)
+    near = (dist_ref < 10.0) & inner
+    assert near.any()
+    assert np.abs(dist[near] - dist_ref[near]).max() < 1e-5      # the oracle accumulates 1 / 1.4 steps, the device multiplies
+    assert (dist[inner & ~near] >= 10.0 - 1e-5).all()
+
+
 @pytest.mark.parametrize("depth_mode,ang", [(1, 0.05), (1, 0.03), (0, 0.0398)])
 def test_plane_regions_match_oracle(hip_lib, oracle_mod, depth_mode, ang):
     """Same normals in, same partition out (labels are the regions' smallest pixel index on both sides), moments and
