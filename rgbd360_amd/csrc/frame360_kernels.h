@@ -393,83 +393,227 @@ __device__ __forceinline__ bool plane_link(const float* __restrict__ xyz, const 
     return (fabsf(plane_dot(xyz, normals, i) - plane_dot(xyz, normals, j)) < thr) && (dot > cos_thr);
 }
 
-// Pass 1, one block per image row: every pixel is labelled with the first pixel of its horizontal run of linked
-// pixels (an inclusive max-scan of "column where a run starts"), so pass 2 only has to join runs vertically.
-constexpr int kCclRowThreads = 256;
-__global__ __launch_bounds__(kCclRowThreads) void k_f360_ccl_rows(const float* __restrict__ xyz, const float* __restrict__ normals, int rows,
-                                                                 int cols, float cos_thr, float dist_thr, int depth_mode,
-                                                                 int* __restrict__ label, uint8_t* __restrict__ link_left) {
-    __shared__ int wave_last[kCclRowThreads / 64];
-    __shared__ int carry_s;
-    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    int carry = -1;
-    for (int c0 = 0; c0 < cols; c0 += kCclRowThreads) {
-        const int c = c0 + tid;
-        const int i = r * cols + c;
-        bool valid = false, link = false;
-        if (c < cols) {
-            const float* p = xyz + 3 * (size_t)i;
-            valid = finite3(p[0], p[1], p[2]);
-            link = c > 0 && valid && plane_link(xyz, normals, i, i - 1, cos_thr, dist_thr, depth_mode);
-        }
-        int v = (c < cols && !link) ? c : -1;                    // a run starts here
+// Pass 1, per pixel: the two comparisons the segmentation makes at pixel i (against its left and its upper neighbour) as
+// flag bits -- bit 0: the point is finite, bit 1: linked to the left neighbour, bit 2: linked to the upper neighbour.
+// One block owns 256 columns x 4 rows; the per-pixel plane record (normal, p . n, distance threshold) of the tile + the
+// row above + the column to the left is formed once in LDS (1.25 per pixel; the per-pixel kernels before it evaluated
+// plane_link's 2 x 24 B gathers three to five times per pixel), all loads of a thread are issued up front.
+constexpr int kLinkTW = 256, kLinkTH = 4;
+__global__ __launch_bounds__(kLinkTW) void k_f360_link_flags(const float* __restrict__ xyz, const float* __restrict__ normals, int rows,
+                                                            int cols, float cos_thr, float dist_thr, int depth_mode,
+                                                            uint8_t* __restrict__ flags) {
+    __shared__ float4 rec[kLinkTH + 1][kLinkTW + 1];       // normal.xyz, p . n
+    __shared__ float thr[kLinkTH + 1][kLinkTW + 1];        // dist_thr * depth^2 (the threshold when this pixel is the visiting one)
+    __shared__ uint8_t ok[kLinkTH + 1][kLinkTW + 1];       // finite point
+    const int t = threadIdx.x;
+    const int c0 = blockIdx.x * kLinkTW, r0 = blockIdx.y * kLinkTH;
+    {
+        constexpr int kN = (kLinkTH + 1) * (kLinkTW + 1), kTrips = (kN + kLinkTW - 1) / kLinkTW;
+        float p[kTrips][3], q[kTrips][3];
+        bool inb[kTrips];
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(v, o);
-            if (lane >= o) v = t > v ? t : v;
+        for (int k = 0; k < kTrips; ++k) {
+            const int e = t + k * kLinkTW;
+            const int ey = e / (kLinkTW + 1), ex = e - ey * (kLinkTW + 1);
+            const int r = r0 - 1 + ey, c = c0 - 1 + ex;
+            inb[k] = e < kN && r >= 0 && r < rows && c >= 0 && c < cols;
+            const size_t i = inb[k] ? (size_t)r * cols + c : (size_t)0;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                p[k][d] = xyz[3 * i + d];
+                q[k][d] = normals[3 * i + d];
+            }
         }
-        if (lane == 63) wave_last[w] = v;
-        __syncthreads();
-        int start = v > carry ? v : carry;
-        for (int k = 0; k < w; ++k) start = wave_last[k] > start ? wave_last[k] : start;
-        if (c < cols) {
-            label[i] = valid ? r * cols + start : -1;
-            link_left[i] = link ? 1 : 0;
+#pragma unroll
+        for (int k = 0; k < kTrips; ++k) {
+            const int e = t + k * kLinkTW;
+            if (e < kN) {
+                const int ey = e / (kLinkTW + 1), ex = e - ey * (kLinkTW + 1);
+                const bool fin = inb[k] && finite3(p[k][0], p[k][1], p[k][2]);
+                const float z = depth_of(p[k], depth_mode);
+                rec[ey][ex] = make_float4(q[k][0], q[k][1], q[k][2], p[k][0] * q[k][0] + p[k][1] * q[k][1] + p[k][2] * q[k][2]);
+                thr[ey][ex] = dist_thr * z * z;
+                ok[ey][ex] = fin ? 1 : 0;
+            }
         }
-        if (tid == kCclRowThreads - 1) carry_s = start;
-        __syncthreads();
-        carry = carry_s;
+    }
+    __syncthreads();
+    const int c = c0 + t;
+    if (c >= cols) return;
+#pragma unroll
+    for (int y = 0; y < kLinkTH; ++y) {
+        const int r = r0 + y;
+        if (r >= rows) break;
+        const float4 me = rec[y + 1][t + 1];
+        const float th = thr[y + 1][t + 1];
+        const bool fin = ok[y + 1][t + 1] != 0;
+        auto linked = [&](int yy, int xx) {
+            const float4 o = rec[yy][xx];
+            const float dot = me.x * o.x + me.y * o.y + me.z * o.z;
+            return fin && ok[yy][xx] != 0 && (fabsf(me.w - o.w) < th) && (dot > cos_thr);
+        };
+        const bool left = c > 0 && linked(y + 1, t), up = r > 0 && linked(y, t + 1);
+        flags[(size_t)r * cols + c] = (uint8_t)((fin ? 1 : 0) | (left ? 2 : 0) | (up ? 4 : 0));
     }
 }
 
-__device__ __forceinline__ int uf_find(const int* label, int x) {
+// Pass 2, one wave per image row, flags only: every pixel is labelled with the first pixel of its horizontal run of linked
+// pixels (an inclusive max-scan of "column where a run starts"; a lane owns 4 consecutive pixels), so pass 3 only has to
+// join runs vertically.  Invalid pixels get -1.
+constexpr int kRunRowsPerBlock = 4;
+__global__ __launch_bounds__(64 * kRunRowsPerBlock) void k_f360_ccl_runs(const uint8_t* __restrict__ flags, int rows, int cols,
+                                                                        int* __restrict__ label) {
+    const int lane = threadIdx.x & 63, r = blockIdx.x * kRunRowsPerBlock + (threadIdx.x >> 6);
+    if (r >= rows) return;                                   // whole waves leave; no block-level synchronisation below
+    const uint8_t* f = flags + (size_t)r * cols;
+    int* L = label + (size_t)r * cols;
+    int carry = -1;
+    for (int c0 = 0; c0 < cols; c0 += 256) {
+        const int c = c0 + 4 * lane;
+        int v[4];
+        bool valid[4];
+        int m = -1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int cc = c + k;
+            const int fl = cc < cols ? f[cc] : 0;
+            valid[k] = (fl & 1) != 0;
+            if (cc < cols && !(fl & 2)) m = cc;              // a run starts here
+            v[k] = m;
+        }
+        int s = m;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int tt = __shfl_up(s, o);
+            if (lane >= o) s = tt > s ? tt : s;
+        }
+        int prev = __shfl_up(s, 1);
+        prev = lane == 0 ? carry : (prev > carry ? prev : carry);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int cc = c + k;
+            const int start = v[k] > prev ? v[k] : prev;
+            if (cc < cols) L[cc] = valid[k] ? r * cols + start : -1;
+        }
+        const int last = __shfl(s, 63);
+        carry = last > carry ? last : carry;
+    }
+}
+
+// Parents always have the smaller index (uf_union hangs the larger root under the smaller), so a cell only ever decreases
+// and any ancestor is a valid parent: the walk re-points every node it passes at its grandparent (path splitting, by
+// atomicMin so that it commutes with the unions).  Without it a wall's runs form a chain as long as the wall is tall.
+#ifdef F360_DEBUG_COUNTERS
+__device__ unsigned long long g_dbg[8];
+#endif
+__device__ __forceinline__ int uf_find(int* label, int x) {
     int p = label[x];
+#ifdef F360_DEBUG_COUNTERS
+    unsigned long long hops = 0;
+#endif
     while (p != x) {
+#ifdef F360_DEBUG_COUNTERS
+        atomicAdd(&g_dbg[1], 1ull);
+        atomicMax(&g_dbg[3], ++hops);
+#endif
+        const int g = label[p];
+        if (g != p) atomicMin(&label[x], g);
         x = p;
-        p = label[x];
+        p = g;
     }
     return x;
 }
 __device__ __forceinline__ void uf_union(int* label, int a, int b) {
     for (;;) {
-        a = uf_find(label, a);
-        b = uf_find(label, b);
+        // both walks advance together: the two loads of a step are in flight at the same time (a join is a chain of dependent
+        // L2 round trips and nothing else)
+        int pa = label[a], pb = label[b];
+        while (pa != a || pb != b) {
+            int ga = pa, gb = pb;
+            if (pa != a) ga = label[pa];
+            if (pb != b) gb = label[pb];
+            if (pa != a && ga != pa) atomicMin(&label[a], ga);
+            if (pb != b && gb != pb) atomicMin(&label[b], gb);
+            a = pa; pa = ga;
+            b = pb; pb = gb;
+        }
         if (a == b) return;
         if (a < b) {
             const int t = a; a = b; b = t;
         }
         const int old = atomicMin(&label[a], b);     // a > b: hang the larger root under the smaller
+#ifdef F360_DEBUG_COUNTERS
+        atomicAdd(&g_dbg[2], 1ull);
+#endif
         if (old == a) return;
         a = old;                                     // somebody re-rooted `a` meanwhile: retry from there
     }
 }
 
-// Pass 2: join a pixel's run with the run of its upper neighbour.  The join is skipped where the pixel to the left
-// already made it (same two runs), which leaves about one union per pair of overlapping runs.
-__global__ void k_f360_ccl_merge(const float* __restrict__ xyz, const float* __restrict__ normals, const uint8_t* __restrict__ link_left,
-                                 int rows, int cols, float cos_thr, float dist_thr, int depth_mode, int* __restrict__ label) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
-    if (c >= cols || r >= rows || r == 0) return;
-    const int i = r * cols + c, up = i - cols;
-    if (!plane_link(xyz, normals, i, up, cos_thr, dist_thr, depth_mode)) return;
-    if (c > 0 && link_left[i] && link_left[up] && plane_link(xyz, normals, i - 1, up - 1, cos_thr, dist_thr, depth_mode)) return;
-    uf_union(label, i, up);
+// Pass 3: join a pixel's run with the run of its upper neighbour (flags only).  The join is skipped where the pixel to the
+// left already made it (same two runs), which leaves about one union per pair of overlapping runs.
+//
+// The joins are made bottom-up in a binary hierarchy over the rows: the boundary above row r belongs to level ctz(r), and a
+// level only starts when the levels below it are complete, so a join always connects two finished blocks of 2^level rows.
+// Launched all at once instead, a wall's thousand runs hook onto each other in one step (run r under run r-1 under ...),
+// and whoever comes late walks the whole chain one dependent L2 round trip at a time: 8 k joins cost 70-90 us at
+// 2048x1024 through a single 75-86 hop walk.  Levels 0..3 (bands of 16 rows) share one launch, levels 4 and 5 get one each, the sparse rest (every 64th row) one together.
+// fl: flags of (r, c); fl_up: of (r-1, c); fl_left: of (r, c-1)
+__device__ __forceinline__ void ccl_join_up(int cols, int* __restrict__ label, int r, int c, int fl, int fl_up, int fl_left) {
+    if (!(fl & 4)) return;
+    if (c > 0 && (fl & 2) && (fl_up & 2) && (fl_left & 4)) return;
+    const int i = r * cols + c;
+    uf_union(label, i, i - cols);
 }
 
-__global__ void k_f360_ccl_compress(int n, int* __restrict__ label) {
+constexpr int kBandRows = 16, kBandLevels = 4, kBandCols = 256, kBandGroups = 4;
+__global__ __launch_bounds__(kBandCols * kBandGroups) void k_f360_ccl_merge_band(const uint8_t* __restrict__ flags, int rows, int cols,
+                                                                                int* __restrict__ label) {
+    __shared__ uint8_t tile[kBandRows][kBandCols + 4];        // flags of the band; column 0 = the column left of the block
+    const int tx = threadIdx.x & (kBandCols - 1), g = threadIdx.x / kBandCols;
+    const int c0 = blockIdx.x * kBandCols, r0 = blockIdx.y * kBandRows;
+    for (int e = threadIdx.x; e < kBandRows * (kBandCols + 1); e += kBandCols * kBandGroups) {
+        const int y = e / (kBandCols + 1), x = e - y * (kBandCols + 1);
+        const int r = r0 + y, c = c0 - 1 + x;
+        tile[y][x] = (r < rows && c >= 0 && c < cols) ? flags[(size_t)r * cols + c] : 0;
+    }
+    __syncthreads();
+    const int c = c0 + tx;
+#pragma unroll
+    for (int level = 0; level < kBandLevels; ++level) {
+        // the rows of this level: y = 2^level (2 m + 1); row group g takes every kBandGroups-th of them
+        for (int m = g; (1 << level) * (2 * m + 1) < kBandRows; m += kBandGroups) {
+            const int y = (1 << level) * (2 * m + 1);
+            if (c < cols && r0 + y < rows) ccl_join_up(cols, label, r0 + y, c, tile[y][tx + 1], tile[y - 1][tx + 1], tile[y][tx]);
+        }
+        __syncthreads();        // the block's own joins of this level are issued before the next level starts (other column
+                                // blocks of the band may run ahead: that costs depth, not correctness)
+    }
+}
+
+// one level >= kBandLevels: rows r = 2^level * (2 m + 1); all_above: every multiple of 2^level (the sparse top of the hierarchy
+// in one launch: at most rows / 2^level boundaries hook at once)
+__global__ void k_f360_ccl_merge_level(const uint8_t* __restrict__ flags, int rows, int cols, int* __restrict__ label, int level, int all_above) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = all_above ? (1 << level) * ((int)blockIdx.y + 1) : (1 << level) * (2 * (int)blockIdx.y + 1);
+    if (c >= cols || r >= rows) return;
+    const size_t i = (size_t)r * cols + c;
+    const int fl = flags[i];
+    if (!(fl & 4)) return;
+    ccl_join_up(cols, label, r, c, fl, flags[i - cols], c > 0 ? flags[i - 1] : 0);
+}
+
+// Pass 4: only the first pixel of a run can be (or become) a root, and every other pixel still points at the first pixel of
+// its run: the pointer chase runs over the run starts only (a few per cent of the pixels); their region counters are
+// cleared on the way (no memset of the 8 B/px table).
+__global__ void k_f360_ccl_roots(const uint8_t* __restrict__ flags, int n, int* __restrict__ label, unsigned long long* __restrict__ count) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    if (label[i] >= 0) label[i] = uf_find(label, i);
+    const int fl = flags[i];
+    if ((fl & 1) && !(fl & 2)) {
+        label[i] = uf_find(label, i);
+        count[i] = 0ull;
+    }
 }
 
 // ---- region sizes and moments: block-aggregated, integer, order-independent ------------------------------------------
@@ -479,7 +623,7 @@ __global__ void k_f360_ccl_compress(int n, int* __restrict__ label) {
 // issues one global atomic per (block, label, value).  All sums are integers (counts; moments in 2^-24 fixed point):
 // integer addition is associative, so the results are bitwise reproducible whatever the arrival order.
 constexpr int kAggThreads = 1024;
-constexpr int kAggPerThread = 4;
+constexpr int kMomPerThread = 8;
 constexpr int kAggHash = 64;
 constexpr double kMomScale = 16777216.0;      // 2^24 units per m (linear terms) / per m^2 (quadratic terms)
 constexpr int kMomReplicas = 16;              // copies of the global moment table (block b adds into copy b % 16): a wall is hit by
@@ -530,25 +674,82 @@ __device__ __forceinline__ void agg_add(int* keys, unsigned long long (*vals)[NV
     }
 }
 
-// count[root] = number of pixels of the region (as unsigned 64-bit)
-__global__ __launch_bounds__(kAggThreads) void k_f360_count(const int* __restrict__ label, int n, unsigned long long* __restrict__ count) {
-    __shared__ int keys[kAggHash];
-    __shared__ unsigned long long vals[kAggHash][1];
-    if (threadIdx.x < kAggHash) {
+// Pass 5: every remaining pixel takes the root of its run start (exactly one hop), and the region sizes are counted on the
+// way: count[root] = number of pixels of the region (unsigned 64-bit).  A block sweeps kCntPerThread x 1024 consecutive
+// pixels; wave-uniform labels (the common case) are accumulated in a wave-scalar (key, count) pair that is only flushed to
+// the block's LDS hash when the key changes, the hash goes to global memory once per (block, label).
+constexpr int kCntPerThread = 8;
+constexpr int kCntHashBits = 8, kCntHash = 1 << kCntHashBits;
+__device__ __forceinline__ int cnt_slot(int* keys, int key) {
+    int h = (int)(((unsigned)key * 2654435761u) >> (32 - kCntHashBits));
+    for (int probe = 0; probe < 8; ++probe) {           // bounded: where every pixel is its own region (no normal) the table is
+                                                        // full at once and the adds go straight to their own global counters
+        const int old = atomicCAS(&keys[h], -1, key);
+        if (old == -1 || old == key) return h;
+        h = (h + 1) & (kCntHash - 1);
+    }
+    return -1;
+}
+__global__ __launch_bounds__(kAggThreads) void k_f360_finish_count(const uint8_t* __restrict__ flags, int n, int* __restrict__ label,
+                                                                  unsigned long long* __restrict__ count) {
+    __shared__ int keys[kCntHash];
+    __shared__ unsigned int vals[kCntHash];
+    if (threadIdx.x < kCntHash) {
         keys[threadIdx.x] = -1;
-        vals[threadIdx.x][0] = 0ull;
+        vals[threadIdx.x] = 0u;
     }
     __syncthreads();
-    const int base = blockIdx.x * kAggThreads * kAggPerThread;
+    auto add = [&](int key, unsigned int cnt) {
+        const int e = cnt_slot(keys, key);
+        if (e >= 0) atomicAdd(&vals[e], cnt);
+        else atomicAdd(&count[key], (unsigned long long)cnt);
+    };
+    const int base = blockIdx.x * kAggThreads * kCntPerThread;
+    const bool lane0 = (threadIdx.x & 63) == 0;
+    // three batched rounds of loads (flags, labels, the run starts' labels) instead of a dependent triple per pixel
+    int fl[kCntPerThread], lab[kCntPerThread];
 #pragma unroll
-    for (int j = 0; j < kAggPerThread; ++j) {
+    for (int j = 0; j < kCntPerThread; ++j) {
         const int i = base + j * kAggThreads + (int)threadIdx.x;
-        const int l = i < n ? label[i] : -1;
-        const long long one[1] = {1};
-        agg_add<1>(keys, vals, count, l, one, l >= 0);
+        fl[j] = i < n ? flags[i] : 0;
     }
+#pragma unroll
+    for (int j = 0; j < kCntPerThread; ++j) {
+        const int i = base + j * kAggThreads + (int)threadIdx.x;
+        lab[j] = (fl[j] & 1) ? label[i] : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < kCntPerThread; ++j)
+        if ((fl[j] & 3) == 3) lab[j] = label[lab[j]];      // not a run start: its label is its run start, whose label is the root by now
+#pragma unroll
+    for (int j = 0; j < kCntPerThread; ++j) {
+        const int i = base + j * kAggThreads + (int)threadIdx.x;
+        if ((fl[j] & 3) == 3) label[i] = lab[j];
+    }
+    int pend_key = -1;
+    unsigned int pend_cnt = 0;
+#pragma unroll
+    for (int j = 0; j < kCntPerThread; ++j) {
+        const int l = lab[j];
+        const int first = __builtin_amdgcn_readfirstlane(l);
+        const unsigned long long same = __ballot(l == first);
+        if (same == __ballot(true)) {
+            if (first >= 0) {
+                const unsigned int c64 = (unsigned int)__popcll(same);
+                if (first == pend_key) pend_cnt += c64;
+                else {
+                    if (pend_cnt && lane0) add(pend_key, pend_cnt);
+                    pend_key = first;
+                    pend_cnt = c64;
+                }
+            }
+        } else if (l >= 0) {
+            add(l, 1u);
+        }
+    }
+    if (pend_cnt && lane0) add(pend_key, pend_cnt);
     __syncthreads();
-    if (threadIdx.x < kAggHash && keys[threadIdx.x] >= 0) atomicAdd(&count[keys[threadIdx.x]], vals[threadIdx.x][0]);
+    if (threadIdx.x < kCntHash && keys[threadIdx.x] >= 0) atomicAdd(&count[keys[threadIdx.x]], (unsigned long long)vals[threadIdx.x]);
 }
 
 // compaction: roots of regions with more than min_inliers points get a slot (order fixed later on the host)
@@ -557,14 +758,17 @@ __global__ void k_f360_assign(const int* __restrict__ label, const unsigned long
                               int* __restrict__ n_slots) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    if (label[i] == i && count[i] > (unsigned long long)min_inliers) {
+    if (label[i] != i) return;               // slot_of_root is only ever read at roots: no memset of the table
+    int slot = -1;
+    if (count[i] > (unsigned long long)min_inliers) {
         const int s = atomicAdd(n_slots, 1);
         if (s < max_slots) {
-            slot_of_root[i] = s;
+            slot = s;
             root_of_slot[s] = i;
             count_of_slot[s] = (int)count[i];
         }
     }
+    slot_of_root[i] = slot;
 }
 
 // 9 raw moments per selected region (sum x, y, z, xx, xy, xz, yy, yz, zz) in 2^-24 fixed point, two's complement in u64
@@ -580,49 +784,72 @@ __global__ __launch_bounds__(kAggThreads) void k_f360_moments(const float* __res
         for (int k = 0; k < 9; ++k) vals[threadIdx.x][k] = 0ull;
     }
     __syncthreads();
-    // each thread owns kAggPerThread CONSECUTIVE pixels: inside a plane they share one slot, so their moments are summed in
-    // registers and the wave reduction + LDS insert runs once per 4 pixels (the cross-lane shuffles are what this kernel
-    // spends its time on).  A wave in which some thread straddles a region boundary takes the pixel-by-pixel path.
-    const int i0 = (blockIdx.x * kAggThreads + (int)threadIdx.x) * kAggPerThread;
-    int sl[kAggPerThread];
+    // a wave owns kMomPerThread * 64 CONSECUTIVE pixels, lane-interleaved (coalesced rows of 64); inside a plane all of them share
+    // one slot, so every thread sums its pixels in registers and the wave reduction + LDS insert runs once per 512 pixels and
+    // region (the cross-lane shuffles are what this kernel used to spend its time on).  Loads are issued in three batched rounds
+    // (labels, slots, points).
+    const int wave_base = (blockIdx.x * (kAggThreads / 64) + ((int)threadIdx.x >> 6)) * (kMomPerThread * 64) + ((int)threadIdx.x & 63);
+    int sl[kMomPerThread];
+#pragma unroll
+    for (int j = 0; j < kMomPerThread; ++j) {
+        const int i = wave_base + j * 64;
+        sl[j] = i < n ? label[i] : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < kMomPerThread; ++j)
+        if (sl[j] >= 0) sl[j] = slot_of_root[sl[j]];
+    float px[kMomPerThread], py[kMomPerThread], pz[kMomPerThread];
     int key = -1;
     bool mixed = false;
 #pragma unroll
-    for (int j = 0; j < kAggPerThread; ++j) {
-        const int i = i0 + j;
-        int sj = -1;
-        if (i < n) {
-            const int l = label[i];
-            if (l >= 0) sj = slot_of_root[l];
-        }
-        sl[j] = sj;
-        if (sj >= 0) {
-            if (key < 0) key = sj;
-            else if (sj != key) mixed = true;
+    for (int j = 0; j < kMomPerThread; ++j) {
+        const size_t i = (size_t)(wave_base + j * 64);
+        px[j] = py[j] = pz[j] = 0.f;
+        if (sl[j] >= 0) {
+            px[j] = xyz[3 * i]; py[j] = xyz[3 * i + 1]; pz[j] = xyz[3 * i + 2];
+            if (key < 0) key = sl[j];
+            else if (sl[j] != key) mixed = true;
         }
     }
     // round-to-nearest-even double -> int64 for |v| < 2^51 by the 1.5 * 2^52 trick (one add + one integer subtract instead of
     // the ~20-instruction conversion sequence; nine of these per pixel dominated the kernel)
     auto d2ll = [](double v) -> long long { return __double_as_longlong(v + 6755399441055744.0) - 0x4338000000000000LL; };
-    auto moments_of = [&](int i, long long v[9]) {
-        const double x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
+    auto moments_of = [&](int j, long long v[9]) {
+        const double x = px[j], y = py[j], z = pz[j];
         v[0] += d2ll(x * kMomScale); v[1] += d2ll(y * kMomScale); v[2] += d2ll(z * kMomScale);
         v[3] += d2ll(x * x * kMomScale); v[4] += d2ll(x * y * kMomScale); v[5] += d2ll(x * z * kMomScale);
         v[6] += d2ll(y * y * kMomScale); v[7] += d2ll(y * z * kMomScale); v[8] += d2ll(z * z * kMomScale);
     };
-    if (__ballot(mixed) == 0ull) {
-        long long v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto lane_add = [&](int k, const long long t[9]) {            // one lane on its own (a thread that sees a second region)
+        const int e = agg_slot(keys, k);
 #pragma unroll
-        for (int j = 0; j < kAggPerThread; ++j)
-            if (sl[j] >= 0) moments_of(i0 + j, v);
-        agg_add<9>(keys, vals, mom_rep, key, v, key >= 0);
-    } else {
-#pragma unroll
-        for (int j = 0; j < kAggPerThread; ++j) {
-            long long v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-            if (sl[j] >= 0) moments_of(i0 + j, v);
-            agg_add<9>(keys, vals, mom_rep, sl[j], v, sl[j] >= 0);
+        for (int q = 0; q < 9; ++q) {
+            if (e >= 0) atomicAdd(&vals[e][q], (unsigned long long)t[q]);
+            else atomicAdd(&mom_rep[(size_t)k * 9 + q], (unsigned long long)t[q]);
         }
+    };
+    long long v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < kMomPerThread; ++j) {
+        if (sl[j] < 0) continue;
+        if (sl[j] == key) moments_of(j, v);
+        else {
+            long long t[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            moments_of(j, t);
+            lane_add(sl[j], t);
+        }
+    }
+    (void)mixed;
+    // one wave reduction per distinct region among the lanes (one or two almost everywhere)
+    unsigned long long todo = __ballot(key >= 0);
+    while (todo) {
+        const int k = __shfl(key, __ffsll((long long)todo) - 1);
+        const bool mine = key == k;
+        long long t[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) t[q] = wave_sum_ll(mine ? v[q] : 0ll);
+        if ((threadIdx.x & 63) == 0) lane_add(k, t);
+        todo &= ~__ballot(mine);
     }
     __syncthreads();
     if (threadIdx.x < kAggHash && keys[threadIdx.x] >= 0) {

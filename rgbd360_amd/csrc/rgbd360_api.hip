@@ -1287,20 +1287,47 @@ int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float
     using namespace f360;
     const int n = rows * cols;
     const dim3 g1((n + 255) / 256), b(256);
-    HIPC(ctx, hipMemsetAsync(ctx->f_count, 0, (size_t)n * sizeof(unsigned long long), ctx->stream));
-    HIPC(ctx, hipMemsetAsync(ctx->f_slot_of_root, 0xFF, (size_t)n * sizeof(int), ctx->stream));
     HIPC(ctx, hipMemsetAsync(ctx->f_nslots, 0, sizeof(int), ctx->stream));
     HIPC(ctx, hipMemsetAsync(ctx->f_mom, 0, (size_t)f360::kMomReplicas * kF360MaxSlots * 9 * sizeof(unsigned long long), ctx->stream));
-    hipLaunchKernelGGL(k_f360_ccl_rows, dim3(rows), dim3(kCclRowThreads), 0, ctx->stream, ctx->f_xyz, ctx->f_normals, rows, cols,
-                       cosf(angular_threshold), distance_threshold, depth_mode, ctx->f_label, ctx->f_change);
-    hipLaunchKernelGGL(k_f360_ccl_merge, grid2d(rows, cols), b, 0, ctx->stream, ctx->f_xyz, ctx->f_normals, ctx->f_change, rows, cols,
-                       cosf(angular_threshold), distance_threshold, depth_mode, ctx->f_label);
-    hipLaunchKernelGGL(k_f360_ccl_compress, g1, b, 0, ctx->stream, n, ctx->f_label);
-    const dim3 gagg((n + kAggThreads * kAggPerThread - 1) / (kAggThreads * kAggPerThread)), bagg(kAggThreads);
-    hipLaunchKernelGGL(k_f360_count, gagg, bagg, 0, ctx->stream, ctx->f_label, n, ctx->f_count);
+    uint8_t* flags = ctx->f_change;
+    hipLaunchKernelGGL(k_f360_link_flags, dim3((cols + kLinkTW - 1) / kLinkTW, (rows + kLinkTH - 1) / kLinkTH), dim3(kLinkTW), 0, ctx->stream,
+                       ctx->f_xyz, ctx->f_normals, rows, cols, cosf(angular_threshold), distance_threshold, depth_mode, flags);
+    hipLaunchKernelGGL(k_f360_ccl_runs, dim3((rows + kRunRowsPerBlock - 1) / kRunRowsPerBlock), dim3(64 * kRunRowsPerBlock), 0, ctx->stream,
+                       flags, rows, cols, ctx->f_label);
+    hipLaunchKernelGGL(k_f360_ccl_merge_band, dim3((cols + kBandCols - 1) / kBandCols, (rows + kBandRows - 1) / kBandRows),
+                       dim3(kBandCols * kBandGroups), 0, ctx->stream, flags, rows, cols, ctx->f_label);
+    constexpr int kTopLevel = kBandLevels + 2;
+    for (int level = kBandLevels; level <= kTopLevel && (1 << level) < rows; ++level) {
+        const bool all_above = level == kTopLevel;
+        const int n_rows = all_above ? (rows - 1) / (1 << level) : (rows - 1 - (1 << level)) / (2 << level) + 1;
+        hipLaunchKernelGGL(k_f360_ccl_merge_level, dim3((cols + 255) / 256, n_rows), dim3(256), 0, ctx->stream, flags, rows, cols,
+                           ctx->f_label, level, all_above ? 1 : 0);
+    }
+#ifdef F360_DEBUG_COUNTERS
+    {
+        unsigned long long h[8];
+        hipStreamSynchronize(ctx->stream);
+        hipMemcpyFromSymbol(h, HIP_SYMBOL(f360::g_dbg), sizeof(h));
+        fprintf(stderr, "[f360 dbg] after merge: unions %llu find-hops %llu atomicMin %llu longest walk %llu\n", h[0], h[1], h[2], h[3]);
+    }
+#endif
+    hipLaunchKernelGGL(k_f360_ccl_roots, g1, b, 0, ctx->stream, flags, n, ctx->f_label, ctx->f_count);
+#ifdef F360_DEBUG_COUNTERS
+    {
+        unsigned long long h[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        hipStreamSynchronize(ctx->stream);
+        hipMemcpyFromSymbol(h, HIP_SYMBOL(f360::g_dbg), sizeof(h));
+        fprintf(stderr, "[f360 dbg] after roots: find-hops %llu (cumulative) longest walk %llu\n", h[1], h[3]);
+        hipMemcpyToSymbol(HIP_SYMBOL(f360::g_dbg), z, sizeof(z));
+    }
+#endif
+    hipLaunchKernelGGL(k_f360_finish_count, dim3((n + kAggThreads * kCntPerThread - 1) / (kAggThreads * kCntPerThread)), dim3(kAggThreads), 0,
+                       ctx->stream, flags, n, ctx->f_label, ctx->f_count);
+    const dim3 bagg(kAggThreads);
     hipLaunchKernelGGL(k_f360_assign, g1, b, 0, ctx->stream, ctx->f_label, ctx->f_count, n, min_inliers, kF360MaxSlots,
                        ctx->f_slot_of_root, ctx->f_root_of_slot, ctx->f_count_of_slot, ctx->f_nslots);
-    hipLaunchKernelGGL(k_f360_moments, gagg, bagg, 0, ctx->stream, ctx->f_xyz, ctx->f_label, ctx->f_slot_of_root, n, ctx->f_mom, kF360MaxSlots);
+    const dim3 gmom((n + kAggThreads * kMomPerThread - 1) / (kAggThreads * kMomPerThread));
+    hipLaunchKernelGGL(k_f360_moments, gmom, bagg, 0, ctx->stream, ctx->f_xyz, ctx->f_label, ctx->f_slot_of_root, n, ctx->f_mom, kF360MaxSlots);
     HIPC(ctx, hipGetLastError());
     int nslots = 0;
     HIPC(ctx, hipMemcpyAsync(&nslots, ctx->f_nslots, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
