@@ -191,15 +191,24 @@ __global__ __launch_bounds__(kNT_THREADS) void k_f360_normals_tiled(const float*
     const int c0 = blockIdx.x * kNT_W, r0 = blockIdx.y * kNT_H;
     // ---- phase 1: points of the tile + halo 7 (outside the image: NaN, never used by a pixel that produces a normal) ----
     const float qnan = __builtin_nanf("");
-    for (int e = tid; e < kNT_XW * kNT_XH; e += kNT_THREADS) {
-        const int ey = e / kNT_XW, ex = e - ey * kNT_XW;
-        const int r = r0 - kNT_HALO - 1 + ey, c = c0 - kNT_HALO - 1 + ex;
-        float x = qnan, y = qnan, z = qnan;
-        if (r >= 0 && r < rows && c >= 0 && c < cols) {
-            const float* p = xyz + 3 * ((size_t)r * cols + c);
-            x = p[0]; y = p[1]; z = p[2];
+    {   // float by float (a tile row is 138 contiguous floats of the cloud), every load of the thread issued before the first
+        // LDS store: the block waits for ONE memory round trip here, not one per sweep of the loop
+        constexpr int kRowF = 3 * kNT_XW, kNF = kRowF * kNT_XH, kTrips = (kNF + kNT_THREADS - 1) / kNT_THREADS;
+        float v[kTrips];
+#pragma unroll
+        for (int k = 0; k < kTrips; ++k) {
+            const int e = tid + k * kNT_THREADS;
+            const int ey = e / kRowF, ef = e - ey * kRowF;
+            const int r = r0 - kNT_HALO - 1 + ey, c = c0 - kNT_HALO - 1 + ef / 3;
+            const bool in = e < kNF && r >= 0 && r < rows && c >= 0 && c < cols;
+            const float t = xyz[in ? 3 * ((size_t)r * cols + (c0 - kNT_HALO - 1)) + ef : (size_t)0];
+            v[k] = in ? t : qnan;
         }
-        pts[3 * e] = x; pts[3 * e + 1] = y; pts[3 * e + 2] = z;
+#pragma unroll
+        for (int k = 0; k < kTrips; ++k) {
+            const int e = tid + k * kNT_THREADS;
+            if (e < kNF) pts[e] = v[k];
+        }
     }
     __syncthreads();
     // ---- phase 2: differences of the tile + halo 6 into registers ----
