@@ -867,6 +867,17 @@ __global__ __launch_bounds__(kAggThreads) void k_f360_moments(const float* __res
     }
 }
 
+// the 16 copies of the moment table -> copy 0 (integer sums: any order), so that the host fetches n_slots x 9 values once
+__global__ void k_f360_mom_reduce(unsigned long long* __restrict__ mom, const int* __restrict__ n_slots, int max_slots) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ns = *n_slots < max_slots ? *n_slots : max_slots;
+    if (i >= ns * 9) return;
+    unsigned long long acc = mom[i];
+#pragma unroll
+    for (int r = 1; r < kMomReplicas; ++r) acc += mom[(size_t)r * max_slots * 9 + i];
+    mom[i] = acc;
+}
+
 // Frame360::stitchImage (Frame360.h:1099-1148): one thread per panorama pixel; the sensor is fixed by the column band.
 // sin/cos tables of the row / column angles come from the host's libm (the reference evaluates them per row / pixel).
 struct StitchArgs {

@@ -1268,6 +1268,61 @@ __global__ void k_src_rec_multi(SrcJobs jobs) {
 }
 
 // Frame360 sphere clouds (Frame360.h:555-612, Frame360_stereo.h:454-512) and the RegisterPhotoICP convention.
+__device__ __forceinline__ void sphere_point(int convention, float d, float sp, float cp, float st, float ct, float& x, float& y, float& z) {
+    const float qnan = __builtin_nanf("");
+    x = qnan; y = qnan; z = qnan;
+    if (convention == 0) {
+        if (d != 0) {
+            x = sp * d;
+            y = -cp * st * d;
+            z = -cp * ct * d;
+        }
+    } else if (convention == 1) {
+        if (d > 0.f && d < 15.f) {
+            x = st * cp * d;
+            y = sp * d;
+            z = ct * cp * d;
+        }
+    } else {
+        if (d != 0) {
+            x = d * sp;
+            y = -d * cp * st;
+            z = -d * cp * ct;
+        }
+    }
+}
+
+// A thread owns 4 consecutive pixels of a row: 12 consecutive floats of the cloud leave as three 16-byte stores (12-byte
+// strided dword stores before).  Needs cols % 4 == 0 and 16-byte aligned rows; k_sphere_cloud is the general form.
+__global__ void k_sphere_cloud_x4(const void* __restrict__ depth, size_t step, int depth_type, int rows, int cols,
+                                  int convention, const float* __restrict__ sin_theta, const float* __restrict__ cos_theta,
+                                  const float* __restrict__ sin_phi, const float* __restrict__ cos_phi,
+                                  float* __restrict__ xyz) {
+    const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int r = blockIdx.y;
+    if (c >= cols || r >= rows) return;
+    const uint8_t* row = (const uint8_t*)depth + (size_t)r * step;
+    float d[4];
+    if (depth_type == 0) {
+        const uint2 w = *reinterpret_cast<const uint2*>((const uint16_t*)row + c);
+        d[0] = 0.001f * (float)(w.x & 0xFFFFu); d[1] = 0.001f * (float)(w.x >> 16);
+        d[2] = 0.001f * (float)(w.y & 0xFFFFu); d[3] = 0.001f * (float)(w.y >> 16);
+    } else {
+        const float4 w = *reinterpret_cast<const float4*>((const float*)row + c);
+        d[0] = w.x; d[1] = w.y; d[2] = w.z; d[3] = w.w;
+    }
+    const float4 st4 = *reinterpret_cast<const float4*>(sin_theta + c), ct4 = *reinterpret_cast<const float4*>(cos_theta + c);
+    const float st[4] = {st4.x, st4.y, st4.z, st4.w}, ct[4] = {ct4.x, ct4.y, ct4.z, ct4.w};
+    const float sp = sin_phi[r], cp = cos_phi[r];
+    float o[12];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sphere_point(convention, d[k], sp, cp, st[k], ct[k], o[3 * k], o[3 * k + 1], o[3 * k + 2]);
+    float4* out = reinterpret_cast<float4*>(xyz + 3 * ((size_t)r * cols + c));
+    out[0] = make_float4(o[0], o[1], o[2], o[3]);
+    out[1] = make_float4(o[4], o[5], o[6], o[7]);
+    out[2] = make_float4(o[8], o[9], o[10], o[11]);
+}
+
 __global__ void k_sphere_cloud(const void* __restrict__ depth, size_t step, int depth_type, int rows, int cols,
                                int convention, const float* __restrict__ sin_theta, const float* __restrict__ cos_theta,
                                const float* __restrict__ sin_phi, const float* __restrict__ cos_phi,
@@ -1279,27 +1334,8 @@ __global__ void k_sphere_cloud(const void* __restrict__ depth, size_t step, int 
     float d;
     if (depth_type == 0) d = 0.001f * (float)((const uint16_t*)row)[c];
     else d = ((const float*)row)[c];
-    const float qnan = __builtin_nanf("");
-    float x = qnan, y = qnan, z = qnan;
-    if (convention == 0) {
-        if (d != 0) {
-            x = sin_phi[r] * d;
-            y = -cos_phi[r] * sin_theta[c] * d;
-            z = -cos_phi[r] * cos_theta[c] * d;
-        }
-    } else if (convention == 1) {
-        if (d > 0.f && d < 15.f) {
-            x = sin_theta[c] * cos_phi[r] * d;
-            y = sin_phi[r] * d;
-            z = cos_theta[c] * cos_phi[r] * d;
-        }
-    } else {
-        if (d != 0) {
-            x = d * sin_phi[r];
-            y = -d * cos_phi[r] * sin_theta[c];
-            z = -d * cos_phi[r] * cos_theta[c];
-        }
-    }
+    float x, y, z;
+    sphere_point(convention, d, sin_phi[r], cos_phi[r], sin_theta[c], cos_theta[c], x, y, z);
     float* o = xyz + 3 * ((size_t)r * cols + c);
     o[0] = x; o[1] = y; o[2] = z;
 }

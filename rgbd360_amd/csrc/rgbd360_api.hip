@@ -69,6 +69,7 @@ struct rgbd360_ctx {
     int* f_count_of_slot = nullptr;
     float* f_tab = nullptr;
     size_t f_tab_n = 0;
+    int f_tab_rows = 0, f_tab_cols = 0, f_tab_conv = -1;      // what the resident angle tables were built for
     uint8_t* f_depth_raw = nullptr;
     float al_guess[16] = {0};     // alignment in flight (rgbd360_align360_begin / _finish)
     int al_method = 0;
@@ -1328,6 +1329,7 @@ int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float
                        ctx->f_slot_of_root, ctx->f_root_of_slot, ctx->f_count_of_slot, ctx->f_nslots);
     const dim3 gmom((n + kAggThreads * kMomPerThread - 1) / (kAggThreads * kMomPerThread));
     hipLaunchKernelGGL(k_f360_moments, gmom, bagg, 0, ctx->stream, ctx->f_xyz, ctx->f_label, ctx->f_slot_of_root, n, ctx->f_mom, kF360MaxSlots);
+    hipLaunchKernelGGL(k_f360_mom_reduce, dim3((kF360MaxSlots * 9 + 255) / 256), dim3(256), 0, ctx->stream, ctx->f_mom, ctx->f_nslots, kF360MaxSlots);
     HIPC(ctx, hipGetLastError());
     int nslots = 0;
     HIPC(ctx, hipMemcpyAsync(&nslots, ctx->f_nslots, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -1336,15 +1338,12 @@ int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float
     std::vector<int> roots(nslots), counts(nslots);
     std::vector<double> mom((size_t)nslots * 9);
     if (nslots > 0) {
-        std::vector<unsigned long long> raw((size_t)nslots * 9, 0ull), rep((size_t)nslots * 9);
-        HIPC(ctx, hipMemcpy(roots.data(), ctx->f_root_of_slot, nslots * sizeof(int), hipMemcpyDeviceToHost));
-        for (int r = 0; r < f360::kMomReplicas; ++r) {         // integer sums: the order of the copies does not matter
-            HIPC(ctx, hipMemcpy(rep.data(), ctx->f_mom + (size_t)r * kF360MaxSlots * 9, rep.size() * sizeof(unsigned long long),
-                                hipMemcpyDeviceToHost));
-            for (size_t k = 0; k < raw.size(); ++k) raw[k] += rep[k];
-        }
+        std::vector<unsigned long long> raw((size_t)nslots * 9, 0ull);
+        HIPC(ctx, hipMemcpyAsync(roots.data(), ctx->f_root_of_slot, nslots * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIPC(ctx, hipMemcpyAsync(raw.data(), ctx->f_mom, raw.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+        HIPC(ctx, hipMemcpyAsync(counts.data(), ctx->f_count_of_slot, nslots * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIPC(ctx, hipStreamSynchronize(ctx->stream));
         for (size_t k = 0; k < raw.size(); ++k) mom[k] = (double)(long long)raw[k] / kMomScale;     // fixed point -> metres
-        HIPC(ctx, hipMemcpy(counts.data(), ctx->f_count_of_slot, nslots * sizeof(int), hipMemcpyDeviceToHost));
     }
     std::vector<int> order(nslots);
     for (int s = 0; s < nslots; ++s) order[s] = s;
@@ -1384,8 +1383,10 @@ int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float
 int sphere_cloud_dev(rgbd360_ctx* ctx, const void* depth, size_t depth_step, int depth_type, int rows, int cols, int convention,
                      bool depth_on_device = false) {
     if (convention < 0 || convention > 2 || (depth_type != 0 && depth_type != 1)) return fail(ctx, -1, "bad arguments");
+    const bool tables_resident = ctx->f_tab && ctx->f_tab_rows == rows && ctx->f_tab_cols == cols && ctx->f_tab_conv == convention;
     std::vector<float> st(cols), ct(cols), sp(rows), cp(rows);
-    if (convention == 0) {          // Frame360.h:562-585
+    if (tables_resident) {          // the angle tables of this geometry are already on the device
+    } else if (convention == 0) {   // Frame360.h:562-585
         const float angle_pixel(cols / (2 * kPI));
         const float angle_pixel_inv(1 / angle_pixel);
         const float offset_phi = kPI * 31.5 / 180;
@@ -1428,27 +1429,44 @@ int sphere_cloud_dev(rgbd360_ctx* ctx, const void* depth, size_t depth_step, int
         }
     }
     const size_t dpx = depth_type == 0 ? 2 : 4;
-    const size_t ntab = (size_t)2 * cols + 2 * rows;
-    if (ctx->f_tab_n < ntab) {
-        hipFree(ctx->f_tab);
-        ctx->f_tab = nullptr;
-        ctx->f_tab_n = 0;
-        HIPC(ctx, hipMalloc(&ctx->f_tab, ntab * sizeof(float)));
-        ctx->f_tab_n = ntab;
+    if (!tables_resident) {
+        const size_t ntab = (size_t)2 * cols + 2 * rows;
+        if (ctx->f_tab_n < ntab) {
+            hipFree(ctx->f_tab);
+            ctx->f_tab = nullptr;
+            ctx->f_tab_n = 0;
+            HIPC(ctx, hipMalloc(&ctx->f_tab, ntab * sizeof(float)));
+            ctx->f_tab_n = ntab;
+        }
+        std::vector<float> tab;
+        tab.insert(tab.end(), st.begin(), st.end());
+        tab.insert(tab.end(), ct.begin(), ct.end());
+        tab.insert(tab.end(), sp.begin(), sp.end());
+        tab.insert(tab.end(), cp.begin(), cp.end());
+        ctx->f_tab_conv = -1;
+        HIPC(ctx, hipMemcpyAsync(ctx->f_tab, tab.data(), ntab * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        HIPC(ctx, hipStreamSynchronize(ctx->stream));      // `tab` (pageable) must outlive the copy
+        ctx->f_tab_rows = rows; ctx->f_tab_cols = cols; ctx->f_tab_conv = convention;
     }
-    std::vector<float> tab;
-    tab.insert(tab.end(), st.begin(), st.end());
-    tab.insert(tab.end(), ct.begin(), ct.end());
-    tab.insert(tab.end(), sp.begin(), sp.end());
-    tab.insert(tab.end(), cp.begin(), cp.end());
-    HIPC(ctx, hipMemcpyAsync(ctx->f_tab, tab.data(), ntab * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    HIPC(ctx, hipMemcpy2DAsync(ctx->f_depth_raw, (size_t)cols * dpx, depth, depth_step, (size_t)cols * dpx, rows,
-                               depth_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+    const void* d_depth = depth;
+    size_t d_step = depth_step;
+    if (!depth_on_device) {
+        HIPC(ctx, hipMemcpy2DAsync(ctx->f_depth_raw, (size_t)cols * dpx, depth, depth_step, (size_t)cols * dpx, rows, hipMemcpyHostToDevice,
+                                   ctx->stream));
+        d_depth = ctx->f_depth_raw;
+        d_step = (size_t)cols * dpx;
+    }
     float* d_tab = ctx->f_tab;
-    hipLaunchKernelGGL(k_sphere_cloud, grid2d(rows, cols), dim3(256), 0, ctx->stream, ctx->f_depth_raw, (size_t)cols * dpx, depth_type,
-                       rows, cols, convention, d_tab, d_tab + cols, d_tab + 2 * cols, d_tab + 2 * cols + rows, ctx->f_xyz);
+    // four pixels per thread when every row of the depth image and of the cloud starts 16-byte aligned
+    if (cols % 4 == 0 && d_step % 16 == 0 && ((size_t)d_depth & 15) == 0) {
+        hipLaunchKernelGGL(k_sphere_cloud_x4, grid2d(rows, cols / 4), dim3(256), 0, ctx->stream, d_depth, d_step, depth_type, rows, cols,
+                           convention, d_tab, d_tab + cols, d_tab + 2 * cols, d_tab + 2 * cols + rows, ctx->f_xyz);
+    } else {
+        hipLaunchKernelGGL(k_sphere_cloud, grid2d(rows, cols), dim3(256), 0, ctx->stream, d_depth, d_step, depth_type, rows, cols,
+                           convention, d_tab, d_tab + cols, d_tab + 2 * cols, d_tab + 2 * cols + rows, ctx->f_xyz);
+    }
     HIPC(ctx, hipGetLastError());
-    HIPC(ctx, hipStreamSynchronize(ctx->stream));      // `tab` (pageable) must outlive the copy
+    if (!depth_on_device) HIPC(ctx, hipStreamSynchronize(ctx->stream));      // the caller may reuse its host image
     return 0;
 }
 }  // namespace
