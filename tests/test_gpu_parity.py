@@ -395,6 +395,32 @@ def test_plane_regions_match_oracle(hip_lib, oracle_mod, depth_mode, ang):
             assert abs(abs(np.dot(a["normal"], b["normal"])) - 1) < 1e-5 and abs(a["d"] - b["d"]) < 1e-4
 
 
+@pytest.mark.parametrize("W,H", [(250, 101), (700, 37), (65, 70), (24, 15), (513, 129)])
+def test_plane_regions_ragged_sizes(hip_lib, oracle_mod, W, H):
+    """The tiled / hierarchical component passes on sizes that are not multiples of their tiles (256 x 4 link tile, 4 rows per
+    run block, 16-row merge bands, 64-row top level, 512-pixel wave strips): labels, counts and plane roots equal the oracle's."""
+    from rgbd360_amd.register import Frame360Stages
+    (rgbA, dA), _, _ = synth.make_pair(W, H, seed=W + H)
+    d = dA.copy()
+    d[H // 3:H // 3 + 3, W // 4:W // 4 + 9] = 0                        # a hole
+    d[H // 2:, W // 2:W // 2 + W // 8] = (d[H // 2:, W // 2:W // 2 + W // 8] * 0.8).astype(d.dtype)   # a depth step down to the last row
+    xyz = oracle_mod.sphere_cloud(d, 2)
+    nrm, _ = oracle_mod.f360_normals(xyz, H, W, 0.05, 4.0, 1)
+    st = Frame360Stages(_mk(hip_lib, 2))
+    labels, planes = st.plane_fit(xyz, nrm, H, W, 10, 0.08, 0.05, 0.01, 1)
+    labels_ref, planes_ref = oracle_mod.f360_plane_segment(xyz, nrm, H, W, 10, 0.08, 0.05, 0.01, 1)
+    assert np.array_equal(labels, labels_ref)
+    assert (labels_ref >= 0).any()
+    assert [p["root"] for p in planes] == [p["root"] for p in planes_ref]
+    assert [p["count"] for p in planes] == [p["count"] for p in planes_ref]
+    # the device normal map on the same ragged size (32 x 16 tiles, halo 6)
+    nrm_dev = st.normals(xyz, H, W, 0.05, 4.0, 1)
+    assert np.array_equal(np.isnan(nrm_dev[:, 0]), np.isnan(nrm[:, 0]))
+    ok = ~np.isnan(nrm[:, 0])
+    if ok.any():
+        assert np.abs(nrm_dev[ok] - nrm[ok]).max() <= 1.2e-7
+
+
 def test_frame_planes_recovers_the_room_walls(hip_lib, oracle_mod):
     """Functional known answer for the chained device pipeline (range image -> cloud -> normals -> regions): the six walls
     of the synthetic room come out within 1 degree / 1 cm (SURVEY.md 8c bar for the PCL-based rows)."""
