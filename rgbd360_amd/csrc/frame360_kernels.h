@@ -174,7 +174,8 @@ constexpr int kNT_XW = kNT_EW + 2, kNT_XH = kNT_EH + 2;                         
 constexpr int kNT_SW = kNT_EW + 3, kNT_SH = kNT_EH + 1;                                // table: zero column / row in front; odd pitch 47
                                                                                        // (row scans: lane stride 47 doubles = all banks)
 constexpr int kNT_SPLANE = kNT_SW * kNT_SH;                                            // 47 x 29 entries per plane
-constexpr int kNT_THREADS = 256;
+constexpr int kNT_THREADS = 512;                                                         // 8 waves per tile: every phase is a chain of LDS round trips,
+                                                                                       // 256 threads (2 x 4 waves per CU) left them exposed: 87 -> 72 us
 constexpr int kNT_BX = 11, kNT_BY = 14;                                                // scan batch lengths
 static_assert(kNT_EW % kNT_BX == 0 && kNT_EH % kNT_BY == 0, "scan batches");
 static_assert(kNT_HALO * 2 >= kF360R, "window offsets span -rect/2 .. rect-rect/2-1 with rect <= kF360R");
