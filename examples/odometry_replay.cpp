@@ -80,7 +80,8 @@ int main(int argc, char** argv) {
     if (!frame1.load(dir, 0, w, h)) return 3;
     for (int k = 1; k < n; ++k) {
         if (!frame2.load(dir, k, w, h)) return 3;
-        align360.setTargetFrame(frame1.sphereRGB, frame1.sphereDepth);                          // :189
+        if (k == 1) align360.setTargetFrame(frame1.sphereRGB, frame1.sphereDepth);              // :189
+        else align360.promoteSourceToTarget();          // frame1 is last step's frame2: already on the device
         align360.setSourceFrame(frame2.sphereRGB, frame2.sphereDepth);                          // :190
         align360.alignFrames360(rgbd360::Mat4f::Identity(), rgbd360::RegisterPhotoICP::PHOTO_DEPTH);   // :192
         const rgbd360::Mat4f rel = align360.getOptimalPose();                                   // :193

@@ -94,6 +94,13 @@ class RegisterPhotoICP {
     void setTargetFrame(const ImageView& rgb, const ImageView& depth) { set(true, rgb, depth); }
     void setSourceFrame(const ImageView& rgb, const ImageView& depth) { set(false, rgb, depth); }
 
+    // The `setTargetFrame(frame2 ...)` of the next odometry step (OdometryRGBD360.cpp:189) without a second upload: the source
+    // frame's pyramids become the target's (rgbd360_promote_source_to_target); a new source must be set afterwards.
+    void promoteSourceToTarget() {
+        if (rgbd360_promote_source_to_target(ctx()) != 0)
+            throw std::runtime_error(std::string("rgbd360_promote_source_to_target: ") + rgbd360_last_error(ctx_));
+    }
+
     // RPI.h:4519-4784.  void like the reference; `status()` tells ill-posed (1) / no valid pixels (2).
     void alignFrames360(const Mat4f& pose_guess = Mat4f::Identity(), costFuncType method = PHOTO_CONSISTENCY,
                         int occlusion = 0) {
