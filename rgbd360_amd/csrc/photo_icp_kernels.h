@@ -1189,6 +1189,15 @@ __global__ void k_pyrdown_pair(const float* __restrict__ gray_src, const float* 
 }
 
 // calcGradientXY on one plane + seam mask; writes the interleaved {value, gradX, gradY} gather record.
+// n / d and n % d for 0 <= n < 2^24, d >= 1 (images are < 16 Mpx): a float estimate of the quotient, exact after one
+// correction either way -- a runtime-divisor integer division costs ~30 VALU instructions, this one ~8.
+__device__ __forceinline__ void divmod24(int n, int d, int& q, int& rem) {
+    q = (int)((float)n * (1.0f / (float)d));
+    rem = n - q * d;
+    if (rem < 0) { rem += d; --q; }
+    else if (rem >= d) { rem -= d; ++q; }
+}
+
 __device__ __forceinline__ void gradient_rec_px(const float* __restrict__ src, int rows, int cols, int seam_width,
                                                 F3* __restrict__ rec, int r, int c) {
     const float v = src[(size_t)r * cols + c];
@@ -1199,10 +1208,12 @@ __device__ __forceinline__ void gradient_rec_px(const float* __restrict__ src, i
         if ((v > xp && v < xm) || (v < xp && v > xm)) gx = 2.f / (1 / (xp - v) + 1 / (v - xm));
         if ((v > yp && v < ym) || (v < yp && v > ym)) gy = 2.f / (1 / (yp - v) + 1 / (v - ym));
     }
-    if (seam_width > 0) {   // columns s*w-1 and s*w, s = 1..7
-        const int s0 = (c + 1) / seam_width, s1 = c / seam_width;
-        const bool on = ((c + 1) % seam_width == 0 && s0 >= 1 && s0 <= 7) || (c % seam_width == 0 && s1 >= 1 && s1 <= 7);
-        if (on) gx = gy = 0.f;
+    if (seam_width > 1) {   // columns s*w-1 and s*w, s = 1..7: (c + 1) = s*w or s*w + 1
+        int s, rem;
+        divmod24(c + 1, seam_width, s, rem);
+        if (rem <= 1 && s >= 1 && s <= 7) gx = gy = 0.f;
+    } else if (seam_width == 1) {
+        if (c + 1 >= 1 && c <= 7) gx = gy = 0.f;          // every column 0..7 is s*w-1 or s*w for some s in 1..7
     }
     F3 o;
     o.a = v; o.b = gx; o.c = gy;
@@ -1224,7 +1235,8 @@ __global__ void k_gradient_rec_multi(GradJobs jobs) {
     const int p = ((int)blockIdx.x - jobs.first_block[j]) * (int)blockDim.x + (int)threadIdx.x;
     const int cols = jobs.cols[j], rows = jobs.rows[j];
     if (p >= rows * cols) return;
-    const int r = p / cols, c = p - r * cols;
+    int r, c;
+    divmod24(p, cols, r, c);
     gradient_rec_px(jobs.src[j], rows, cols, jobs.seam[j], jobs.rec[j], r, c);
 }
 
@@ -1262,7 +1274,8 @@ __global__ void k_src_rec_multi(SrcJobs jobs) {
     const int p = ((int)blockIdx.x - jobs.first_block[j]) * (int)blockDim.x + (int)threadIdx.x;
     const int cols = jobs.cols[j], rows = jobs.rows[j];
     if (p >= rows * cols) return;
-    const int r = p / cols, c = p - r * cols;
+    int r, c;
+    divmod24(p, cols, r, c);
     src_rec_px(jobs.depth[j], jobs.gray[j], cols, jobs.sin_theta[j], jobs.cos_theta[j], jobs.sin_phi[j], jobs.cos_phi[j],
                jobs.min_depth, jobs.max_depth, jobs.rec[j], r, c);
 }

@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <string>
 #include <thread>
 #include <vector>
@@ -693,8 +694,16 @@ static int align360_batch_impl(rgbd360_ctx* ctx, int n_frames, const uint8_t* co
     {
         std::vector<std::thread> workers;
         workers.reserve(k_ctx - 1);
-        for (int c = 1; c < k_ctx; ++c) workers.emplace_back(run_chunk, c);
+        std::vector<int> inline_chunks;              // sub-chunks whose thread could not be started run on the caller's thread
+        for (int c = 1; c < k_ctx; ++c) {
+            try {
+                workers.emplace_back(run_chunk, c);
+            } catch (const std::exception&) {        // no exception may cross the C boundary
+                inline_chunks.push_back(c);
+            }
+        }
         run_chunk(0);
+        for (int c : inline_chunks) run_chunk(c);
         for (std::thread& w : workers) w.join();
     }
     for (int c = 0; c < k_ctx; ++c)
