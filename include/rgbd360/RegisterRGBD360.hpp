@@ -1,0 +1,158 @@
+// RegisterRGBD360.hpp -- C++ adapter over the C ABI (include/rgbd360_hip.h) with the public surface of the reference's
+// RegisterRGBD360 (include/RegisterRGBD360.h:47-338 of EduFdez/rgbd360) for the PbMap registration that provides the
+// initial guess of the dense alignment: setReference / setTarget / RegisterPbMap / getPose / getCovMat / getInfoMat /
+// calcEntropy / getMatchedPlanes / getAreaMatched, same names, argument meaning and return values, so call sites such as
+// SphereGraphSLAM.cpp:180, KFsphere_SLAM.cpp:182,314-317 keep their shape.  A "frame" is anything that exposes its planar
+// regions as a contiguous `rgbd360_plane` array (what rgbd360_frame_planes[_dev] returns) -- the only member of Frame360
+// this class reads is `planes.vPlanes`.  Header-only; depends on nothing but the C ABI.
+#pragma once
+
+#include <cmath>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "RegisterPhotoICP.hpp"
+
+namespace rgbd360 {
+
+struct PlaneList {                       // view of a frame's planes; the caller keeps ownership
+    const rgbd360_plane* planes = nullptr;
+    int n = 0;
+};
+
+class RegisterRGBD360 {
+   public:
+    enum registrationType { DEFAULT_6DoF, PLANAR_3DoF, ODOMETRY_6DoF, PLANAR_ODOMETRY_3DoF };      // RegisterRGBD360.h:258-264
+
+    float areaSource = 0.f, areaTarget = 0.f;                                                      // :88-92
+
+    // :97-105 loads config_files/configLocaliser_spherical*.ini; here the two parameter sets are built in
+    explicit RegisterRGBD360(bool odometry_config = false) { rgbd360_pbmap_default_params(&params_, odometry_config ? 1 : 0); }
+    explicit RegisterRGBD360(const rgbd360_pbmap_params& p) : params_(p) {}
+
+    rgbd360_pbmap_params& params() { return params_; }
+
+    void setReference(const PlaneList& ref, size_t max_match_planes = 0) {       // :110-157
+        ref_ = ref;
+        max_ref_ = max_match_planes;
+        done_ = false;
+    }
+    void setTarget(const PlaneList& trg, size_t max_match_planes = 0) {          // :163-195
+        trg_ = trg;
+        max_trg_ = max_match_planes;
+        done_ = false;
+    }
+
+    // :276-338.  true = good alignment; false = "Insuficient matching" or an unobservable / inconsistent fit.
+    bool RegisterPbMap(const PlaneList* frame1 = nullptr, const PlaneList* frame2 = nullptr, size_t max_match_planes = 0,
+                       registrationType registMode = DEFAULT_6DoF) {
+        if (frame1) setReference(*frame1, max_match_planes);
+        if (frame2) setTarget(*frame2, max_match_planes);
+        mode_ = registMode;
+        done_ = true;
+        std::vector<int32_t> match(ref_.n > 0 ? ref_.n : 1, -1);
+        int n_matched = 0;
+        float pose[16], info[36];
+        const size_t mmp = max_ref_ > max_trg_ ? max_ref_ : max_trg_;
+        status_ = rgbd360_register_planes(ref_.planes, ref_.n, trg_.planes, trg_.n, (int)mmp, (int)registMode, &params_, pose, info,
+                                          match.data(), &n_matched, &areaMatched_);
+        bestMatch_.clear();
+        for (int i = 0; i < ref_.n; ++i)
+            if (match[i] >= 0) bestMatch_[(unsigned)i] = (unsigned)match[i];
+        if (status_ != 0) return false;
+        std::memcpy(rigidTransf_.m, pose, sizeof(pose));
+        std::memcpy(informationM_.m, info, sizeof(info));
+        areaSource = subgraphArea(ref_);                                                          // :325-333
+        areaTarget = subgraphArea(trg_);
+        return true;
+    }
+
+    Mat4f getPose() {                                                            // :198-204
+        ensure();
+        return rigidTransf_;
+    }
+    Mat6f& getInfoMat() {                                                        // :218-224
+        ensure();
+        return informationM_;
+    }
+    Mat6f getCovMat() {                                                          // :207-215
+        ensure();
+        Mat6f c{};
+        double det;
+        invert6(informationM_, c, det);
+        return c;
+    }
+    float calcEntropy() {                                                        // :229-238
+        ensure();
+        Mat6f c{};
+        double det_info;
+        invert6(informationM_, c, det_info);
+        const double pi = 3.14159265358979323846;
+        return (float)(0.5 * (6 * (1 + std::log(2 * pi)) + std::log(1.0 / det_info)));
+    }
+    std::map<unsigned, unsigned> getMatchedPlanes() {                            // :241-247
+        ensure();
+        return bestMatch_;
+    }
+    float getAreaMatched() {                                                     // :250-256
+        ensure();
+        return areaMatched_;
+    }
+    int status() const { return status_; }      // 0 good, 1 insufficient matching, 2 unobservable / inconsistent
+
+   private:
+    void ensure() {
+        if (!done_) RegisterPbMap(nullptr, nullptr, 0, mode_);
+    }
+    float subgraphArea(const PlaneList& f) const {
+        float a = 0.f;
+        for (int i = 0; i < f.n; ++i)
+            if (f.planes[i].curvature < params_.max_curvature_plane && !(f.planes[i].area < params_.min_area_plane) &&
+                !(f.planes[i].elongation > params_.max_elongation_plane))
+                a += f.planes[i].area;
+        return a;
+    }
+    // Gauss-Jordan with partial pivoting in double; det = determinant of the input
+    static void invert6(const Mat6f& in, Mat6f& out, double& det) {
+        double a[6][12];
+        for (int r = 0; r < 6; ++r)
+            for (int c = 0; c < 6; ++c) {
+                a[r][c] = in(r, c);
+                a[r][6 + c] = r == c;
+            }
+        det = 1;
+        for (int k = 0; k < 6; ++k) {
+            int p = k;
+            for (int r = k + 1; r < 6; ++r)
+                if (std::fabs(a[r][k]) > std::fabs(a[p][k])) p = r;
+            if (p != k) {
+                for (int c = 0; c < 12; ++c) std::swap(a[k][c], a[p][c]);
+                det = -det;
+            }
+            det *= a[k][k];
+            const double inv = 1.0 / a[k][k];
+            for (int c = 0; c < 12; ++c) a[k][c] *= inv;
+            for (int r = 0; r < 6; ++r) {
+                if (r == k) continue;
+                const double f = a[r][k];
+                for (int c = 0; c < 12; ++c) a[r][c] -= f * a[k][c];
+            }
+        }
+        for (int r = 0; r < 6; ++r)
+            for (int c = 0; c < 6; ++c) out.m[c * 6 + r] = (float)a[r][6 + c];
+    }
+
+    rgbd360_pbmap_params params_{};
+    PlaneList ref_{}, trg_{};
+    size_t max_ref_ = 0, max_trg_ = 0;
+    registrationType mode_ = DEFAULT_6DoF;
+    bool done_ = false;
+    int status_ = 1;
+    Mat4f rigidTransf_ = Mat4f::Identity();
+    Mat6f informationM_{};
+    std::map<unsigned, unsigned> bestMatch_;
+    float areaMatched_ = 0.f;
+};
+
+}  // namespace rgbd360

@@ -220,6 +220,13 @@ typedef struct {
     float curvature;
     int   count;        /* inliers */
     int   root;         /* smallest pixel index of the region = its label */
+    /* Extent descriptors from the in-plane second moments of the inliers (eigenvalues l1 <= l2 of the covariance beside
+     * the normal's l0) -- the roles of mrpt::pbmap::Plane::areaHull / elongation / v3PpalDir (Frame360.h:1025-1037), which
+     * MRPT derives from the region's convex hull (third-party, not in the reference tree): area = 12 sqrt(l1 l2) (the
+     * rectangle with these moments), elongation = sqrt(l2 / l1), ppal_dir = eigenvector of l2. */
+    float area;
+    float elongation;
+    float ppal_dir[3];
 } rgbd360_plane;
 
 /* Planar regions of an organised cloud with normals: pcl::OrganizedMultiPlaneSegmentation::segment as configured at
@@ -284,6 +291,58 @@ int rgbd360_load_frame_bin(const char* path, uint8_t* rgb_out, uint16_t* depth_o
 int rgbd360_stitch_sphere(rgbd360_ctx* ctx, const uint8_t* rgb8, const uint16_t* depth8, int sensor_rows, int sensor_cols,
                           const float Rt_inv[128], const float K[4], uint8_t* sphere_rgb_out, uint16_t* sphere_depth_out,
                           int* out_rows, int* out_cols);
+
+/* ---- PbMap plane registration: the initial-guess provider in front of the path -------------- */
+
+/* Thresholds of mrpt::pbmap::SubgraphMatcher (config_files/configLocaliser_spherical.ini / ..._sphericalOdometry.ini,
+ * loaded at RegisterRGBD360.h:97-100) that the geometric constraints below use; colour constraints are not built
+ * (the planes of this library carry no colour). */
+typedef struct {
+    /* [unary] */
+    float dist_d;                 /* odometry modes: |d_ref - d_trg| below this (m) */
+    float angle_deg;              /* odometry modes: angle between the two normals below this (deg) */
+    float elongation_threshold;   /* ratio of elongations below this */
+    float area_threshold;         /* ratio of areas below this */
+    /* [binary] */
+    float dist_threshold;         /* ratio of the two centre distances below this */
+    float angle_threshold_deg;    /* difference of the two inter-normal angles below this (deg) */
+    float height_threshold;       /* difference of the perpendicular offsets of one centre over the other plane (m) */
+    float cos_normal_threshold;   /* after the fit: n_ref . (R n_trg) of every matched pair above this */
+    /* [global] */
+    int   min_planes_recognition; /* fewer matches than this = "Insuficient matching" (RegisterRGBD360.h:312-316) */
+    float max_curvature_plane;    /* planes above it never enter the subgraphs (RegisterRGBD360.h:121-150; Miscellaneous.h:54) */
+    float min_area_plane;         /* Frame360.h:1034 drops smaller planes before they reach the PbMap (Miscellaneous.h:57) */
+    float max_elongation_plane;   /* Frame360.h:1041 drops narrower planes (Miscellaneous.h:60) */
+    /* planar modes: the rig moves on the floor; normals keep their component along this axis (0 = x, up in the sphere
+     * frame of RPI.h:4567-4582) within planar_normal_tol, and horizontal planes keep d within dist_d */
+    int   up_axis;
+    float planar_normal_tol;
+    /* pose fit */
+    float max_conditioning;       /* largest / smallest eigenvalue of sum w n n^T above this = ill-conditioned translation */
+    float sigma_dist, sigma_normal; /* scale of the information matrix: st. dev. of a plane offset (m) / normal (rad) */
+    int   max_nodes;              /* budget of the interpretation-tree search (nodes); 0 = unlimited */
+} rgbd360_pbmap_params;
+
+/* odometry = 0: configLocaliser_spherical.ini, 1: configLocaliser_sphericalOdometry.ini */
+void rgbd360_pbmap_default_params(rgbd360_pbmap_params* p, int odometry);
+
+/* RegisterRGBD360::RegisterPbMap (RegisterRGBD360.h:276-338): subgraph selection (setReference / setTarget :110-195:
+ * planes under max_curvature_plane; if max_match_planes > 0 and there are more, the max_match_planes largest areas),
+ * interpretation-tree matching of the two plane sets under unary + binary geometric constraints
+ * (mrpt::pbmap::SubgraphMatcher::compareSubgraphs -- third-party; restated from the published method, Fernandez-Moral
+ * et al., "Fast place recognition with plane-based maps", ICRA 2013), then the closed-form pose of the matched planes
+ * with its information matrix (mrpt::pbmap::ConsistencyTest::estimatePoseWithCovariance -- third-party, restated:
+ * rotation = SVD of sum w n_ref n_trg^T, translation = least squares on the plane offsets).  Host code, no device work.
+ *   regist_mode: 0 DEFAULT_6DoF, 1 PLANAR_3DoF, 2 ODOMETRY_6DoF, 3 PLANAR_ODOMETRY_3DoF (RegisterRGBD360.h:258-264).
+ *   pose_out: column-major 4x4, pose of the target frame seen from the reference, p_ref = R p_trg + t.
+ *   info_out: column-major 6x6 information matrix in [t; w] order (left perturbation, like RPI.h:4697).
+ *   match_out: n_ref entries, index of the matched target plane or -1.  area_matched_out: matched area in the
+ *   reference frame (calcAreaMatched).  Any output pointer may be NULL.
+ * Returns 0 good alignment, 1 insufficient matching (< min_planes_recognition; pose_out = identity),
+ * 2 ill-conditioned (rotation or translation not observable from the matched normals) or inconsistent fit, -1 bad arguments. */
+int rgbd360_register_planes(const rgbd360_plane* ref, int n_ref, const rgbd360_plane* trg, int n_trg, int max_match_planes,
+                            int regist_mode, const rgbd360_pbmap_params* params, float pose_out[16], float info_out[36],
+                            int32_t* match_out, int* n_matched_out, float* area_matched_out);
 
 #ifdef __cplusplus
 }

@@ -157,10 +157,13 @@ struct oracle_plane {
     float curvature;    // lambda_min / trace(cov)
     int   count;
     int   root;         // smallest pixel index of the region (PCL's label order)
+    float area;         // 12 sqrt(l1 l2), l1 <= l2 the in-plane eigenvalues of the inlier covariance (rgbd360_hip.h)
+    float elongation;   // sqrt(l2 / l1)
+    float ppal_dir[3];  // eigenvector of l2
 };
 
 // smallest eigenpair of a symmetric 3x3 (cyclic Jacobi, double)
-static void smallest_eigen(const double C[3][3], double& eval, double evec[3]) {
+static void smallest_eigen(const double C[3][3], double& eval, double evec[3], double* others = nullptr) {
     double A[3][3], V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
     memcpy(A, C, sizeof(A));
     for (int sweep = 0; sweep < 60; ++sweep) {
@@ -194,6 +197,13 @@ static void smallest_eigen(const double C[3][3], double& eval, double evec[3]) {
         if (A[k][k] < A[m][m]) m = k;
     eval = A[m][m];
     for (int k = 0; k < 3; ++k) evec[k] = V[k][m];
+    if (others) {       // the two in-plane eigenpairs, ascending: others[0..1] = eigenvalues, others[2..4] = eigenvector of the larger
+        const int a = (m + 1) % 3, b = (m + 2) % 3;
+        const int lo = A[a][a] <= A[b][b] ? a : b, hi = lo == a ? b : a;
+        others[0] = A[lo][lo];
+        others[1] = A[hi][hi];
+        for (int k = 0; k < 3; ++k) others[2 + k] = V[k][hi];
+    }
 }
 
 // OrganizedMultiPlaneSegmentation::segment.  labels: n int32 (root pixel index of the region, -1 for non-finite
@@ -260,8 +270,8 @@ int oracle_f360_plane_segment(const float* xyz, const float* normals, int rows, 
         const double C[3][3] = {{m[3] / N - cx * cx, m[4] / N - cx * cy, m[5] / N - cx * cz},
                                 {m[4] / N - cx * cy, m[6] / N - cy * cy, m[7] / N - cy * cz},
                                 {m[5] / N - cx * cz, m[7] / N - cy * cz, m[8] / N - cz * cz}};
-        double ev, v[3];
-        smallest_eigen(C, ev, v);
+        double ev, v[3], inplane[5];
+        smallest_eigen(C, ev, v, inplane);
         double d = -(v[0] * cx + v[1] * cy + v[2] * cz);
         // orient towards the viewpoint (origin): vp - centroid
         if ((-cx) * v[0] + (-cy) * v[1] + (-cz) * v[2] < 0) {
@@ -278,6 +288,10 @@ int oracle_f360_plane_segment(const float* xyz, const float* normals, int rows, 
         P.curvature = (float)curvature;
         P.count = count[roots[k]];
         P.root = roots[k];
+        const double l1 = std::max(inplane[0], 0.0), l2 = std::max(inplane[1], 0.0);
+        P.area = (float)(12.0 * sqrt(l1 * l2));
+        P.elongation = (float)(l1 > 0 ? sqrt(l2 / l1) : INFINITY);
+        for (int k2 = 0; k2 < 3; ++k2) P.ppal_dir[k2] = (float)inplane[2 + k2];
     }
     return n_planes;
 }

@@ -316,7 +316,8 @@ def sphere_cloud(depth: np.ndarray, convention: int) -> np.ndarray:
 
 class OraclePlane(C.Structure):
     _fields_ = [("centroid", C.c_float * 3), ("normal", C.c_float * 3), ("d", C.c_float), ("curvature", C.c_float),
-                ("count", C.c_int), ("root", C.c_int)]
+                ("count", C.c_int), ("root", C.c_int), ("area", C.c_float), ("elongation", C.c_float),
+                ("ppal_dir", C.c_float * 3)]
 
 
 def f360_distance_map(xyz, rows, cols, max_depth_change_factor=0.05, depth_mode=1):
@@ -353,7 +354,9 @@ def f360_plane_segment(xyz, normals, rows, cols, min_inliers=40, angular_thresho
     n = f(_ptr(xyz), _ptr(normals), rows, cols, min_inliers, angular_threshold, distance_threshold, max_curvature, depth_mode,
           _ptr(labels), C.cast(arr, C.c_void_p), max_planes)
     planes = [dict(centroid=np.array(list(arr[i].centroid), np.float32), normal=np.array(list(arr[i].normal), np.float32),
-                   d=float(arr[i].d), curvature=float(arr[i].curvature), count=int(arr[i].count), root=int(arr[i].root))
+                   d=float(arr[i].d), curvature=float(arr[i].curvature), count=int(arr[i].count), root=int(arr[i].root),
+                   area=float(arr[i].area), elongation=float(arr[i].elongation),
+                   ppal_dir=np.array(list(arr[i].ppal_dir), np.float32))
               for i in range(n)]
     return labels.reshape(rows, cols), planes
 

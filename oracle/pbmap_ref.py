@@ -1,0 +1,161 @@
+"""TEST INFRASTRUCTURE ONLY (imported by tests/ and nothing else): numpy restatement of RegisterRGBD360::RegisterPbMap
+(reference include/RegisterRGBD360.h:110-338) -- subgraph selection, plane matching, pose of the matched planes.
+
+The matcher (mrpt::pbmap::SubgraphMatcher::compareSubgraphs) and the pose fit (mrpt::pbmap::ConsistencyTest::
+estimatePoseWithCovariance) are third-party MRPT code that is NOT in the reference tree and not pinned to a version
+(top CMakeLists.txt:11-20: bare FIND_PACKAGE(MRPT ... pbmap)); the reference has no test or recorded result for them.
+PARITY UNPINNED: this file restates the published method (Fernandez-Moral et al., "Fast place recognition with plane-based
+maps", ICRA 2013) with the thresholds of the reference's config_files/configLocaliser_spherical*.ini, written
+independently of rgbd360_amd/csrc/pbmap_register.h: the best interpretation is found by plain enumeration of every
+assignment (no branch and bound), the rotation by numpy's SVD with the determinant fix (no Jacobi / cross products), the
+translation by numpy's least squares.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+DEFAULT_6DoF, PLANAR_3DoF, ODOMETRY_6DoF, PLANAR_ODOMETRY_3DoF = 0, 1, 2, 3      # RegisterRGBD360.h:258-264
+
+
+def default_params(odometry: bool = False) -> dict:
+    """config_files/configLocaliser_spherical.ini / configLocaliser_sphericalOdometry.ini + Miscellaneous.h:54-60."""
+    return dict(dist_d=0.5 if odometry else 0.4, angle_deg=50.0 if odometry else 40.0,
+                elongation_threshold=2.5 if odometry else 3.8, area_threshold=3.0 if odometry else 4.0,
+                dist_threshold=3.0 if odometry else 4.0, angle_threshold_deg=10.0 if odometry else 9.0,
+                height_threshold=0.33, cos_normal_threshold=0.985 if odometry else 0.99, min_planes_recognition=3,
+                max_curvature_plane=0.0013, min_area_plane=0.12, max_elongation_plane=6.0, up_axis=0, planar_normal_tol=0.08,
+                max_conditioning=100.0, sigma_dist=0.02, sigma_normal=0.0398)
+
+
+def _f32(x):
+    return float(np.float32(x))
+
+
+def _ratio(a, b):
+    lo, hi = min(a, b), max(a, b)
+    if lo > 0:
+        return hi / lo
+    return math.inf if hi > 0 else 1.0
+
+
+def select_subgraph(planes, max_match_planes, P):
+    """setReference / setTarget (RegisterRGBD360.h:110-195) after the Frame360.h:1034,1041 size filters."""
+    kept = [i for i, p in enumerate(planes)
+            if not (_f32(p["area"]) < _f32(P["min_area_plane"])) and not (_f32(p["elongation"]) > _f32(P["max_elongation_plane"]))]
+    flat = lambda i: _f32(planes[i]["curvature"]) < _f32(P["max_curvature_plane"])
+    if max_match_planes > 0 and len(kept) > max_match_planes:
+        areas = [_f32(planes[i]["area"]) if flat(i) else 0.0 for i in kept]
+        thr = sorted(areas)[len(kept) - max_match_planes - 1]
+        return [i for i, a in zip(kept, areas) if a > thr]
+    return [i for i in kept if flat(i)]
+
+
+def unary_ok(a, b, mode, P):
+    if not _ratio(_f32(a["area"]), _f32(b["area"])) < _f32(P["area_threshold"]):
+        return False
+    if not _ratio(_f32(a["elongation"]), _f32(b["elongation"])) < _f32(P["elongation_threshold"]):
+        return False
+    na, nb = np.asarray(a["normal"], np.float32).astype(np.float64), np.asarray(b["normal"], np.float32).astype(np.float64)
+    da, db = _f32(a["d"]), _f32(b["d"])
+    if mode in (ODOMETRY_6DoF, PLANAR_ODOMETRY_3DoF):
+        if not float(na @ nb) > math.cos(_f32(P["angle_deg"]) * math.pi / 180):
+            return False
+        if not abs(da - db) < _f32(P["dist_d"]):
+            return False
+    if mode in (PLANAR_3DoF, PLANAR_ODOMETRY_3DoF):
+        ua, ub = na[P["up_axis"]], nb[P["up_axis"]]
+        if not abs(ua - ub) < _f32(P["planar_normal_tol"]):
+            return False
+        if abs(ua) > 0.98 and not abs(da - db) < _f32(P["dist_d"]):
+            return False
+    return True
+
+
+def binary_ok(a1, a2, b1, b2, P):
+    f = lambda v: np.asarray(v, np.float32).astype(np.float64)
+    ang = lambda u, v: math.acos(min(1.0, max(-1.0, float(f(u) @ f(v)))))
+    if not abs(ang(a1["normal"], a2["normal"]) - ang(b1["normal"], b2["normal"])) < _f32(P["angle_threshold_deg"]) * math.pi / 180:
+        return False
+    ca, cb = f(a2["centroid"]) - f(a1["centroid"]), f(b2["centroid"]) - f(b1["centroid"])
+    if not _ratio(math.sqrt(float(ca @ ca)), math.sqrt(float(cb @ cb))) < _f32(P["dist_threshold"]):
+        return False
+    h = _f32(P["height_threshold"])
+    if not abs(float(f(a1["normal"]) @ ca) - float(f(b1["normal"]) @ cb)) < h:
+        return False
+    if not abs(float(f(a2["normal"]) @ ca) - float(f(b2["normal"]) @ cb)) < h:
+        return False
+    return True
+
+
+def best_interpretation(ref, trg, ri, ti, mode, P):
+    """Every consistent assignment is visited; the winner has the most matches, then the largest matched reference area."""
+    best = dict(n=-1, area=-1.0, pairs=[])
+
+    def rec(k, pairs, used, area):
+        if k == len(ri):
+            if len(pairs) > best["n"] or (len(pairs) == best["n"] and area > best["area"]):
+                best.update(n=len(pairs), area=area, pairs=list(pairs))
+            return
+        a = ref[ri[k]]
+        for j in ti:
+            if j in used or not unary_ok(a, trg[j], mode, P):
+                continue
+            if all(binary_ok(ref[i0], a, trg[j0], trg[j], P) for i0, j0 in pairs):
+                pairs.append((ri[k], j))
+                used.add(j)
+                rec(k + 1, pairs, used, area + float(np.float32(a["area"])))
+                used.discard(j)
+                pairs.pop()
+        rec(k + 1, pairs, used, area)
+
+    rec(0, [], set(), 0.0)
+    return best["pairs"], max(best["area"], 0.0)
+
+
+def fit_pose(ref, trg, pairs, P):
+    """(status, T 4x4, info 6x6): status 0 ok, 2 not observable / inconsistent."""
+    f = lambda v: np.asarray(v, np.float32).astype(np.float64)
+    Nr = np.stack([f(ref[i]["normal"]) for i, _ in pairs])
+    Nt = np.stack([f(trg[j]["normal"]) for _, j in pairs])
+    w = np.array([_f32(trg[j]["area"]) for _, j in pairs])
+    M = (Nr * w[:, None]).T @ Nt
+    U, S, Vt = np.linalg.svd(M)
+    if not (S[0] > 0 and S[1] > 1e-6 * S[0]):
+        return 2, np.eye(4), np.zeros((6, 6))
+    D = np.diag([1.0, 1.0, np.sign(np.linalg.det(U @ Vt)) or 1.0])
+    R = U @ D @ Vt
+    e = np.array([_f32(trg[j]["d"]) - _f32(ref[i]["d"]) for i, j in pairs])
+    H = (Nr * w[:, None]).T @ Nr
+    ev = np.linalg.eigvalsh(H)
+    if not (ev[0] > 0 and ev[-1] / ev[0] < _f32(P["max_conditioning"])):
+        return 2, np.eye(4), np.zeros((6, 6))
+    t = np.linalg.solve(H, (Nr * w[:, None]).T @ e)
+    n = Nt @ R.T
+    if not np.all(np.sum(n * Nr, axis=1) > _f32(P["cos_normal_threshold"])):
+        return 2, np.eye(4), np.zeros((6, 6))
+    info = np.zeros((6, 6))
+    sd, sn = _f32(P["sigma_dist"]), _f32(P["sigma_normal"])
+    for k in range(len(pairs)):
+        nn = np.outer(n[k], n[k])
+        info[:3, :3] += w[k] * nn / (sd * sd)
+        info[3:, 3:] += w[k] * (np.eye(3) - nn) / (sn * sn)
+    T = np.eye(4)
+    T[:3, :3], T[:3, 3] = R, t
+    return 0, T, info
+
+
+def register_planes(ref, trg, max_match_planes=0, mode=DEFAULT_6DoF, P=None):
+    P = P or default_params(mode in (ODOMETRY_6DoF, PLANAR_ODOMETRY_3DoF))
+    ri, ti = select_subgraph(ref, max_match_planes, P), select_subgraph(trg, max_match_planes, P)
+    pairs, area = best_interpretation(ref, trg, ri, ti, mode, P)
+    out = dict(status=0, pose=np.eye(4), info=np.zeros((6, 6)), match=dict(pairs), area_matched=area)
+    if len(pairs) < max(P["min_planes_recognition"], 3):
+        out["status"] = 1
+        return out
+    st, T, info = fit_pose(ref, trg, pairs, P)
+    out["status"] = st
+    if st == 0:
+        out["pose"], out["info"] = T, info
+    return out

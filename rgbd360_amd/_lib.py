@@ -16,6 +16,7 @@ SYMBOLS = [
     "rgbd360_sync", "rgbd360_device_count", "rgbd360_sphere_cloud", "rgbd360_selftest_math", "rgbd360_time_solve_kernel", "rgbd360_normals", "rgbd360_distance_map",
     "rgbd360_plane_fit", "rgbd360_frame_planes", "rgbd360_frame_planes_dev", "rgbd360_load_frame_bin", "rgbd360_stitch_sphere",
     "rgbd360_set_camera", "rgbd360_align_pinhole", "rgbd360_eval_pinhole", "rgbd360_warp_indices_pinhole",
+    "rgbd360_pbmap_default_params", "rgbd360_register_planes",
 ]
 
 
@@ -34,7 +35,17 @@ class Result(C.Structure):
 
 class Plane(C.Structure):
     _fields_ = [("centroid", C.c_float * 3), ("normal", C.c_float * 3), ("d", C.c_float), ("curvature", C.c_float),
-                ("count", C.c_int), ("root", C.c_int)]
+                ("count", C.c_int), ("root", C.c_int), ("area", C.c_float), ("elongation", C.c_float),
+                ("ppal_dir", C.c_float * 3)]
+
+
+class PbmapParams(C.Structure):
+    _fields_ = [("dist_d", C.c_float), ("angle_deg", C.c_float), ("elongation_threshold", C.c_float),
+                ("area_threshold", C.c_float), ("dist_threshold", C.c_float), ("angle_threshold_deg", C.c_float),
+                ("height_threshold", C.c_float), ("cos_normal_threshold", C.c_float), ("min_planes_recognition", C.c_int),
+                ("max_curvature_plane", C.c_float), ("min_area_plane", C.c_float), ("max_elongation_plane", C.c_float),
+                ("up_axis", C.c_int), ("planar_normal_tol", C.c_float), ("max_conditioning", C.c_float),
+                ("sigma_dist", C.c_float), ("sigma_normal", C.c_float), ("max_nodes", C.c_int)]
 
 
 _lib = None
@@ -96,5 +107,9 @@ def load() -> C.CDLL:
     L.rgbd360_stitch_sphere.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp, C.POINTER(i32), C.POINTER(i32)]
     L.rgbd360_selftest_math.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
     L.rgbd360_sphere_cloud.argtypes = [vp, vp, C.c_size_t, i32, i32, i32, i32, f32p]
+    L.rgbd360_pbmap_default_params.argtypes = [C.POINTER(PbmapParams), i32]
+    L.rgbd360_pbmap_default_params.restype = None
+    L.rgbd360_register_planes.argtypes = [vp, i32, vp, i32, i32, i32, C.POINTER(PbmapParams), vp, vp, vp, C.POINTER(i32),
+                                          C.POINTER(C.c_float)]
     _lib = L
     return L

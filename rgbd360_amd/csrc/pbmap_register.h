@@ -1,0 +1,318 @@
+// pbmap_register.h -- host side of RegisterRGBD360::RegisterPbMap (RegisterRGBD360.h:110-338 of EduFdez/rgbd360):
+// subgraph selection, interpretation-tree plane matching, closed-form pose + information matrix of the matched planes.
+// The matcher and the pose fit are mrpt::pbmap (SubgraphMatcher::compareSubgraphs, ConsistencyTest::
+// estimatePoseWithCovariance) in the reference -- third-party code that is not in the reference tree; both are restated
+// here from the published method (Fernandez-Moral et al., ICRA 2013) with the thresholds of the reference's own
+// config_files/configLocaliser_spherical*.ini.  Small data (tens of planes): plain C++ on the host, float64 inside.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../include/rgbd360_hip.h"
+
+namespace pbm {
+
+// eigen-decomposition of a symmetric 3x3 by cyclic Jacobi (float64): A -> diag(evals), V columns = eigenvectors
+inline void jacobi3(const double C[3][3], double evals[3], double V[3][3]) {
+    double A[3][3];
+    memcpy(A, C, sizeof(A));
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) V[i][j] = i == j;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        if (fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]) < 1e-300) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (fabs(A[p][q]) < 1e-300) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2 * A[p][q]);
+                const double t = (theta >= 0 ? 1 : -1) / (fabs(theta) + sqrt(theta * theta + 1));
+                const double c = 1 / sqrt(t * t + 1), sn = t * c;
+                for (int k = 0; k < 3; ++k) {
+                    const double akp = A[k][p], akq = A[k][q];
+                    A[k][p] = c * akp - sn * akq;
+                    A[k][q] = sn * akp + c * akq;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double apk = A[p][k], aqk = A[q][k];
+                    A[p][k] = c * apk - sn * aqk;
+                    A[q][k] = sn * apk + c * aqk;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - sn * vkq;
+                    V[k][q] = sn * vkp + c * vkq;
+                }
+            }
+    }
+    for (int k = 0; k < 3; ++k) evals[k] = A[k][k];
+}
+
+struct V3 {
+    double x, y, z;
+};
+inline V3 v3(const float* f) { return {f[0], f[1], f[2]}; }
+inline double dot(const V3& a, const V3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline V3 sub(const V3& a, const V3& b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3 cross(const V3& a, const V3& b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline double norm(const V3& a) { return sqrt(dot(a, a)); }
+inline double clamp1(double c) { return c > 1 ? 1 : (c < -1 ? -1 : c); }
+inline double ratio(double a, double b) {      // max / min of two non-negative numbers, +inf when one vanishes
+    const double lo = std::min(a, b), hi = std::max(a, b);
+    return lo > 0 ? hi / lo : (hi > 0 ? INFINITY : 1.0);
+}
+
+// setReference / setTarget (RegisterRGBD360.h:110-195): indices of the planes that enter the matching
+inline std::vector<int> select_subgraph(const rgbd360_plane* pl_all, int n_all, int max_match_planes, const rgbd360_pbmap_params* P) {
+    std::vector<int> kept;                  // the frame's PbMap: Frame360.h:1034,1041 never store small or narrow planes
+    for (int i = 0; i < n_all; ++i)
+        if (!(pl_all[i].area < P->min_area_plane) && !(pl_all[i].elongation > P->max_elongation_plane)) kept.push_back(i);
+    const int n = (int)kept.size();
+    const float max_curvature = P->max_curvature_plane;
+    std::vector<int> idx;
+    if (max_match_planes > 0 && n > max_match_planes) {
+        std::vector<float> area(n, 0.f);
+        for (int i = 0; i < n; ++i)
+            if (pl_all[kept[i]].curvature < max_curvature) area[i] = pl_all[kept[i]].area;
+        std::vector<float> sorted = area;
+        std::sort(sorted.begin(), sorted.end());
+        const float thr = sorted[n - max_match_planes - 1];      // :136: planes strictly above the (n - max - 1)-th area
+        for (int i = 0; i < n; ++i)
+            if (area[i] > thr) idx.push_back(kept[i]);
+    } else {
+        for (int i = 0; i < n; ++i)
+            if (pl_all[kept[i]].curvature < max_curvature) idx.push_back(kept[i]);
+    }
+    return idx;
+}
+
+struct Matcher {
+    const rgbd360_plane* ref;
+    const rgbd360_plane* trg;
+    std::vector<int> ri, ti;                // subgraph plane indices
+    const rgbd360_pbmap_params* P;
+    int mode;
+    std::vector<signed char> unary;         // [ri.size()][ti.size()]
+    std::vector<int> cur, best;             // per ref subgraph plane: matched trg subgraph position or -1
+    int cur_n = 0, best_n = -1;
+    double best_area = -1;
+    std::vector<char> used;
+    long long nodes = 0;
+    bool out_of_budget = false;
+
+    bool eval_unary(const rgbd360_plane& a, const rgbd360_plane& b) const {
+        if (!(ratio(a.area, b.area) < P->area_threshold)) return false;
+        if (!(ratio(a.elongation, b.elongation) < P->elongation_threshold)) return false;
+        const V3 na = v3(a.normal), nb = v3(b.normal);
+        if (mode == 2 || mode == 3) {           // odometry: small displacement between the two frames
+            if (!(dot(na, nb) > cos(P->angle_deg * M_PI / 180))) return false;
+            if (!(fabs((double)a.d - b.d) < P->dist_d)) return false;
+        }
+        if (mode == 1 || mode == 3) {           // planar movement: rotation about the up axis, no change of height
+            const double ua = a.normal[P->up_axis], ub = b.normal[P->up_axis];
+            if (!(fabs(ua - ub) < P->planar_normal_tol)) return false;
+            if (fabs(ua) > 0.98 && !(fabs((double)a.d - b.d) < P->dist_d)) return false;      // floor / ceiling
+        }
+        return true;
+    }
+    // pair (a1, a2) of the reference against pair (b1, b2) of the target
+    bool eval_binary(const rgbd360_plane& a1, const rgbd360_plane& a2, const rgbd360_plane& b1, const rgbd360_plane& b2) const {
+        const V3 na1 = v3(a1.normal), na2 = v3(a2.normal), nb1 = v3(b1.normal), nb2 = v3(b2.normal);
+        const double ang_a = acos(clamp1(dot(na1, na2))), ang_b = acos(clamp1(dot(nb1, nb2)));
+        if (!(fabs(ang_a - ang_b) < P->angle_threshold_deg * M_PI / 180)) return false;
+        const V3 ca = sub(v3(a2.centroid), v3(a1.centroid)), cb = sub(v3(b2.centroid), v3(b1.centroid));
+        if (!(ratio(norm(ca), norm(cb)) < P->dist_threshold)) return false;
+        if (!(fabs(dot(na1, ca) - dot(nb1, cb)) < P->height_threshold)) return false;         // centre 2 over plane 1
+        if (!(fabs(dot(na2, ca) - dot(nb2, cb)) < P->height_threshold)) return false;         // centre 1 under plane 2
+        return true;
+    }
+    void explore(int k, double area) {      // area = matched reference area so far, summed in matching order
+        if (out_of_budget) return;
+        if (P->max_nodes > 0 && ++nodes > P->max_nodes) {
+            out_of_budget = true;
+            return;
+        }
+        const int nr = (int)ri.size(), nt = (int)ti.size();
+        if (k == nr) {
+            if (cur_n > best_n || (cur_n == best_n && area > best_area)) {
+                best = cur;
+                best_n = cur_n;
+                best_area = area;
+            }
+            return;
+        }
+        if (cur_n + (nr - k) < best_n) return;          // cannot reach the best count any more
+        for (int j = 0; j < nt; ++j) {
+            if (used[j] || unary[(size_t)k * nt + j] <= 0) continue;
+            bool ok = true;
+            for (int m = 0; m < k && ok; ++m)
+                if (cur[m] >= 0) ok = eval_binary(ref[ri[m]], ref[ri[k]], trg[ti[cur[m]]], trg[ti[j]]);
+            if (!ok) continue;
+            used[j] = 1;
+            cur[k] = j;
+            ++cur_n;
+            explore(k + 1, area + (double)ref[ri[k]].area);
+            --cur_n;
+            cur[k] = -1;
+            used[j] = 0;
+        }
+        explore(k + 1, area);                            // plane k stays unmatched
+    }
+    void run() {
+        const int nr = (int)ri.size(), nt = (int)ti.size();
+        unary.assign((size_t)nr * nt, 0);
+        for (int i = 0; i < nr; ++i)
+            for (int j = 0; j < nt; ++j) unary[(size_t)i * nt + j] = eval_unary(ref[ri[i]], trg[ti[j]]) ? 1 : -1;
+        cur.assign(nr, -1);
+        best.assign(nr, -1);
+        used.assign(nt, 0);
+        explore(0, 0.0);
+        if (best_n < 0) best_n = 0;
+        if (best_area < 0) best_area = 0;
+    }
+};
+
+// closed-form pose of matched planes: R = argmax sum w n_ref . (R n_trg), t = argmin sum w (n_ref . t - (d_trg - d_ref))^2.
+// pairs: (ref index, trg index).  Returns 0 ok, 2 not observable / inconsistent.
+inline int fit_pose(const rgbd360_plane* ref, const rgbd360_plane* trg, const std::vector<std::pair<int, int>>& pairs,
+                    const rgbd360_pbmap_params* P, double R[3][3], double t[3], double info[6][6]) {
+    double M[3][3] = {{0}}, MtM[3][3] = {{0}};
+    for (const auto& pr : pairs) {
+        const rgbd360_plane &a = ref[pr.first], &b = trg[pr.second];
+        const double w = b.area;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) M[i][j] += w * (double)a.normal[i] * (double)b.normal[j];
+    }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            for (int k = 0; k < 3; ++k) MtM[i][j] += M[k][i] * M[k][j];
+    double ev[3], V[3][3];
+    jacobi3(MtM, ev, V);
+    int o[3] = {0, 1, 2};
+    std::sort(o, o + 3, [&](int a, int b) { return ev[a] > ev[b]; });
+    const double s1 = sqrt(std::max(ev[o[0]], 0.0)), s2 = sqrt(std::max(ev[o[1]], 0.0));
+    if (!(s1 > 0) || !(s2 > 1e-6 * s1)) return 2;         // all normals parallel: rotation not observable
+    V3 v1 = {V[0][o[0]], V[1][o[0]], V[2][o[0]]}, v2 = {V[0][o[1]], V[1][o[1]], V[2][o[1]]};
+    auto mul = [&](const V3& v) { return V3{M[0][0] * v.x + M[0][1] * v.y + M[0][2] * v.z, M[1][0] * v.x + M[1][1] * v.y + M[1][2] * v.z,
+                                            M[2][0] * v.x + M[2][1] * v.y + M[2][2] * v.z}; };
+    V3 u1 = mul(v1), u2 = mul(v2);
+    const double n1 = norm(u1);
+    u1 = {u1.x / n1, u1.y / n1, u1.z / n1};
+    const double p = dot(u1, u2);
+    u2 = {u2.x - p * u1.x, u2.y - p * u1.y, u2.z - p * u1.z};
+    const double n2 = norm(u2);
+    if (!(n2 > 0)) return 2;
+    u2 = {u2.x / n2, u2.y / n2, u2.z / n2};
+    const V3 u3 = cross(u1, u2), v3c = cross(v1, v2);    // both bases right-handed: det R = +1 (the SVD's reflection fix)
+    const double U[3][3] = {{u1.x, u2.x, u3.x}, {u1.y, u2.y, u3.y}, {u1.z, u2.z, u3.z}};
+    const double W[3][3] = {{v1.x, v2.x, v3c.x}, {v1.y, v2.y, v3c.y}, {v1.z, v2.z, v3c.z}};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            R[i][j] = 0;
+            for (int k = 0; k < 3; ++k) R[i][j] += U[i][k] * W[j][k];
+        }
+    // translation: sum w n n^T t = sum w n (d_trg - d_ref), n = n_ref
+    double H[3][3] = {{0}}, g[3] = {0, 0, 0};
+    for (const auto& pr : pairs) {
+        const rgbd360_plane &a = ref[pr.first], &b = trg[pr.second];
+        const double w = b.area, e = (double)b.d - (double)a.d;
+        for (int i = 0; i < 3; ++i) {
+            g[i] += w * a.normal[i] * e;
+            for (int j = 0; j < 3; ++j) H[i][j] += w * (double)a.normal[i] * (double)a.normal[j];
+        }
+    }
+    double hv[3], HV[3][3];
+    jacobi3(H, hv, HV);
+    const double hmax = std::max(hv[0], std::max(hv[1], hv[2])), hmin = std::min(hv[0], std::min(hv[1], hv[2]));
+    if (!(hmin > 0) || !(hmax / hmin < P->max_conditioning)) return 2;   // "Bad conditioning": < 3 independent normals
+    for (int i = 0; i < 3; ++i) {
+        t[i] = 0;
+        for (int k = 0; k < 3; ++k) {
+            const double proj = (HV[0][k] * g[0] + HV[1][k] * g[1] + HV[2][k] * g[2]) / hv[k];
+            t[i] += HV[i][k] * proj;
+        }
+    }
+    // consistency of the fit + information matrix blockdiag(sum w n n^T / sigma_d^2, sum w (I - n n^T) / sigma_n^2), n = R n_trg
+    memset(info, 0, sizeof(double) * 36);
+    const double wd = 1.0 / ((double)P->sigma_dist * P->sigma_dist), wn = 1.0 / ((double)P->sigma_normal * P->sigma_normal);
+    for (const auto& pr : pairs) {
+        const rgbd360_plane &a = ref[pr.first], &b = trg[pr.second];
+        double n[3];
+        for (int i = 0; i < 3; ++i) n[i] = R[i][0] * b.normal[0] + R[i][1] * b.normal[1] + R[i][2] * b.normal[2];
+        const double c = n[0] * a.normal[0] + n[1] * a.normal[1] + n[2] * a.normal[2];
+        if (!(c > P->cos_normal_threshold)) return 2;
+        const double w = b.area;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) {
+                info[i][j] += w * wd * n[i] * n[j];
+                info[3 + i][3 + j] += w * wn * ((i == j) - n[i] * n[j]);
+            }
+    }
+    return 0;
+}
+
+inline int register_planes(const rgbd360_plane* ref, int n_ref, const rgbd360_plane* trg, int n_trg, int max_match_planes, int mode,
+                           const rgbd360_pbmap_params* P, float pose_out[16], float info_out[36], int32_t* match_out,
+                           int* n_matched_out, float* area_matched_out) {
+    if (n_ref < 0 || n_trg < 0 || (n_ref > 0 && !ref) || (n_trg > 0 && !trg) || mode < 0 || mode > 3 || !P || P->up_axis < 0 ||
+        P->up_axis > 2 || max_match_planes < 0)
+        return -1;
+    if (pose_out)
+        for (int i = 0; i < 16; ++i) pose_out[i] = (i % 5 == 0) ? 1.f : 0.f;
+    if (info_out) memset(info_out, 0, 36 * sizeof(float));
+    if (match_out)
+        for (int i = 0; i < n_ref; ++i) match_out[i] = -1;
+    Matcher m;
+    m.ref = ref;
+    m.trg = trg;
+    m.P = P;
+    m.mode = mode;
+    m.ri = select_subgraph(ref, n_ref, max_match_planes, P);
+    m.ti = select_subgraph(trg, n_trg, max_match_planes, P);
+    m.run();
+    std::vector<std::pair<int, int>> pairs;
+    for (size_t k = 0; k < m.ri.size(); ++k)
+        if (m.best[k] >= 0) pairs.emplace_back(m.ri[k], m.ti[m.best[k]]);
+    if (match_out)
+        for (const auto& pr : pairs) match_out[pr.first] = pr.second;
+    if (n_matched_out) *n_matched_out = (int)pairs.size();
+    if (area_matched_out) *area_matched_out = (float)m.best_area;
+    if ((int)pairs.size() < P->min_planes_recognition || pairs.size() < 3) return 1;     // RegisterRGBD360.h:312
+    double R[3][3], t[3], info[6][6];
+    const int st = fit_pose(ref, trg, pairs, P, R, t, info);
+    if (st != 0) return st;
+    if (pose_out) {
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) pose_out[j * 4 + i] = (float)R[i][j];
+            pose_out[12 + i] = (float)t[i];
+        }
+    }
+    if (info_out)
+        for (int i = 0; i < 6; ++i)
+            for (int j = 0; j < 6; ++j) info_out[j * 6 + i] = (float)info[i][j];
+    return 0;
+}
+
+inline void default_params(rgbd360_pbmap_params* p, int odometry) {
+    // config_files/configLocaliser_spherical.ini (0) / configLocaliser_sphericalOdometry.ini (1)
+    p->dist_d = odometry ? 0.5f : 0.4f;
+    p->angle_deg = odometry ? 50.f : 40.f;
+    p->elongation_threshold = odometry ? 2.5f : 3.8f;
+    p->area_threshold = odometry ? 3.0f : 4.0f;
+    p->dist_threshold = odometry ? 3.0f : 4.0f;
+    p->angle_threshold_deg = odometry ? 10.f : 9.f;
+    p->height_threshold = 0.33f;
+    p->cos_normal_threshold = odometry ? 0.985f : 0.99f;
+    p->min_planes_recognition = 3;
+    p->max_curvature_plane = 0.0013f;     // Miscellaneous.h:54
+    p->min_area_plane = 0.12f;            // Miscellaneous.h:57
+    p->max_elongation_plane = 6.f;        // Miscellaneous.h:60
+    p->up_axis = 0;
+    p->planar_normal_tol = 0.08f;
+    p->max_conditioning = 100.f;
+    p->sigma_dist = 0.02f;                // the segmentation's distance threshold (Frame360.h:960-965)
+    p->sigma_normal = 0.0398f;            // its angular threshold
+    p->max_nodes = 2000000;
+}
+
+}  // namespace pbm

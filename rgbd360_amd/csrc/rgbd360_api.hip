@@ -22,6 +22,7 @@
 #include "occlusion_kernels.h"
 #include "pinhole_kernels.h"
 #include "frame360_kernels.h"
+#include "pbmap_register.h"
 
 using namespace r360;
 
@@ -1255,40 +1256,16 @@ int f360_normals_dev(rgbd360_ctx* ctx, int rows, int cols, float max_depth_chang
     return 0;
 }
 
-// smallest eigenpair of a symmetric 3x3 (cyclic Jacobi, float64) -- pcl::eigen33's role
-void smallest_eigen3(const double C[3][3], double& eval, double evec[3]) {
-    double A[3][3], V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
-    memcpy(A, C, sizeof(A));
-    for (int sweep = 0; sweep < 60; ++sweep) {
-        if (fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]) < 1e-300) break;
-        for (int p = 0; p < 2; ++p)
-            for (int q = p + 1; q < 3; ++q) {
-                if (fabs(A[p][q]) < 1e-300) continue;
-                const double theta = (A[q][q] - A[p][p]) / (2 * A[p][q]);
-                const double t = (theta >= 0 ? 1 : -1) / (fabs(theta) + sqrt(theta * theta + 1));
-                const double c = 1 / sqrt(t * t + 1), sn = t * c;
-                for (int k = 0; k < 3; ++k) {
-                    const double akp = A[k][p], akq = A[k][q];
-                    A[k][p] = c * akp - sn * akq;
-                    A[k][q] = sn * akp + c * akq;
-                }
-                for (int k = 0; k < 3; ++k) {
-                    const double apk = A[p][k], aqk = A[q][k];
-                    A[p][k] = c * apk - sn * aqk;
-                    A[q][k] = sn * apk + c * aqk;
-                }
-                for (int k = 0; k < 3; ++k) {
-                    const double vkp = V[k][p], vkq = V[k][q];
-                    V[k][p] = c * vkp - sn * vkq;
-                    V[k][q] = sn * vkp + c * vkq;
-                }
-            }
+// eigenpairs of a symmetric 3x3 in ascending order (cyclic Jacobi, float64) -- pcl::eigen33's role for the smallest one
+void sorted_eigen3(const double C[3][3], double evals[3], double evecs[3][3]) {    // evecs[k] = eigenvector of evals[k]
+    double ev[3], V[3][3];
+    pbm::jacobi3(C, ev, V);
+    int o[3] = {0, 1, 2};
+    std::stable_sort(o, o + 3, [&](int a, int c) { return ev[a] < ev[c]; });
+    for (int k = 0; k < 3; ++k) {
+        evals[k] = ev[o[k]];
+        for (int i = 0; i < 3; ++i) evecs[k][i] = V[i][o[k]];
     }
-    int m = 0;
-    for (int k = 1; k < 3; ++k)
-        if (A[k][k] < A[m][m]) m = k;
-    eval = A[m][m];
-    for (int k = 0; k < 3; ++k) evec[k] = V[k][m];
 }
 
 // regions of (ctx->f_xyz, ctx->f_normals) -> labels (device ctx->f_label) + plane list (host)
@@ -1366,8 +1343,10 @@ int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float
         const double C[3][3] = {{m[3] / N - cx * cx, m[4] / N - cx * cy, m[5] / N - cx * cz},
                                 {m[4] / N - cx * cy, m[6] / N - cy * cy, m[7] / N - cy * cz},
                                 {m[5] / N - cx * cz, m[7] / N - cy * cz, m[8] / N - cz * cz}};
-        double ev, v[3];
-        smallest_eigen3(C, ev, v);
+        double evs[3], vecs[3][3];
+        sorted_eigen3(C, evs, vecs);
+        const double ev = evs[0];
+        double* v = vecs[0];
         double d = -(v[0] * cx + v[1] * cy + v[2] * cz);
         if ((-cx) * v[0] + (-cy) * v[1] + (-cz) * v[2] < 0) {     // orient towards the viewpoint (origin)
             v[0] = -v[0]; v[1] = -v[1]; v[2] = -v[2];
@@ -1383,6 +1362,10 @@ int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float
         P.curvature = (float)curvature;
         P.count = counts[s];
         P.root = roots[s];
+        const double l1 = std::max(evs[1], 0.0), l2 = std::max(evs[2], 0.0);    // in-plane moments (rgbd360_hip.h)
+        P.area = (float)(12.0 * sqrt(l1 * l2));
+        P.elongation = (float)(l1 > 0 ? sqrt(l2 / l1) : INFINITY);
+        for (int k = 0; k < 3; ++k) P.ppal_dir[k] = (float)vecs[2][k];
     }
     *n_planes = np;
     return 0;
@@ -1686,3 +1669,24 @@ extern "C" int rgbd360_stitch_sphere(rgbd360_ctx* ctx, const uint8_t* rgb8, cons
     return 0;
 }
 
+
+// ---- PbMap plane registration (host only) ---------------------------------------------------
+extern "C" void rgbd360_pbmap_default_params(rgbd360_pbmap_params* p, int odometry) {
+    if (p) pbm::default_params(p, odometry);
+}
+
+extern "C" int rgbd360_register_planes(const rgbd360_plane* ref, int n_ref, const rgbd360_plane* trg, int n_trg, int max_match_planes,
+                                       int regist_mode, const rgbd360_pbmap_params* params, float pose_out[16], float info_out[36],
+                                       int32_t* match_out, int* n_matched_out, float* area_matched_out) {
+    rgbd360_pbmap_params def;
+    if (!params) {
+        pbm::default_params(&def, (regist_mode == 2 || regist_mode == 3) ? 1 : 0);
+        params = &def;
+    }
+    try {
+        return pbm::register_planes(ref, n_ref, trg, n_trg, max_match_planes, regist_mode, params, pose_out, info_out, match_out,
+                                    n_matched_out, area_matched_out);
+    } catch (const std::exception&) {       // allocation failure: nothing may cross the C boundary
+        return -1;
+    }
+}

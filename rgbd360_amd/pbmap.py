@@ -1,0 +1,139 @@
+"""RegisterRGBD360's PbMap side (reference include/RegisterRGBD360.h:47-338) over the C ABI: plane-graph matching of two
+frames' planar regions and the closed-form pose of the matched planes -- the initial-guess provider in front of the dense
+alignment.  Method names follow the reference class; the work is `rgbd360_register_planes` (host C++
+inside the HIP library).  No CPU fallback: `_lib.load()` raises when the library is missing."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib
+
+DEFAULT_6DoF, PLANAR_3DoF, ODOMETRY_6DoF, PLANAR_ODOMETRY_3DoF = 0, 1, 2, 3      # RegisterRGBD360.h:258-264
+DOF = 6                                                                        # RegisterRGBD360.h:42
+
+
+def default_params(odometry: bool = False) -> _lib.PbmapParams:
+    """configLocaliser_spherical.ini (odometry False) / configLocaliser_sphericalOdometry.ini (True)."""
+    p = _lib.PbmapParams()
+    _lib.load().rgbd360_pbmap_default_params(C.byref(p), 1 if odometry else 0)
+    return p
+
+
+def planes_to_array(planes):
+    """list of plane dicts (Frame360Stages.plane_fit / frame_planes) -> ctypes array of rgbd360_plane."""
+    arr = (_lib.Plane * max(len(planes), 1))()
+    for i, pl in enumerate(planes):
+        a = arr[i]
+        for k in range(3):
+            a.centroid[k] = float(pl["centroid"][k])
+            a.normal[k] = float(pl["normal"][k])
+            a.ppal_dir[k] = float(pl.get("ppal_dir", (0, 0, 0))[k])
+        a.d = float(pl["d"])
+        a.curvature = float(pl.get("curvature", 0.0))
+        a.count = int(pl.get("count", 0))
+        a.root = int(pl.get("root", i))
+        a.area = float(pl["area"])
+        a.elongation = float(pl["elongation"])
+    return arr
+
+
+def register_planes(ref_planes, trg_planes, max_match_planes: int = 0, regist_mode: int = DEFAULT_6DoF, params=None):
+    """rgbd360_register_planes.  Returns dict(status, pose [4,4] f32 (p_ref = R p_trg + t), info [6,6] f32, match
+    {ref index: trg index}, area_matched)."""
+    L = _lib.load()
+    ra, ta = planes_to_array(ref_planes), planes_to_array(trg_planes)
+    pose = np.zeros(16, np.float32)
+    info = np.zeros(36, np.float32)
+    match = np.full(max(len(ref_planes), 1), -1, np.int32)
+    nm = C.c_int(0)
+    area = C.c_float(0)
+    st = L.rgbd360_register_planes(C.cast(ra, C.c_void_p), len(ref_planes), C.cast(ta, C.c_void_p), len(trg_planes),
+                                   int(max_match_planes), int(regist_mode), C.byref(params) if params is not None else None,
+                                   pose.ctypes.data_as(C.c_void_p), info.ctypes.data_as(C.c_void_p),
+                                   match.ctypes.data_as(C.c_void_p), C.byref(nm), C.byref(area))
+    if st < 0:
+        raise ValueError("rgbd360_register_planes: bad arguments")
+    m = {i: int(match[i]) for i in range(len(ref_planes)) if match[i] >= 0}
+    assert len(m) == nm.value
+    return dict(status=st, pose=pose.reshape(4, 4).T.copy(), info=info.reshape(6, 6).T.copy(), match=m,
+                area_matched=float(area.value))
+
+
+class RegisterRGBD360:
+    """Mirror of the reference class (RegisterRGBD360.h:47): setReference / setTarget / RegisterPbMap / getPose /
+    getInfoMat / getCovMat / calcEntropy / getMatchedPlanes / getAreaMatched.  A "frame" here is the plane list of a
+    Frame360 (Frame360Stages.frame_planes(...)["planes"]) -- the only part of Frame360 this class reads (`planes.vPlanes`)."""
+
+    def __init__(self, odometry_config: bool = False, params=None):        # :97-105 loads the .ini thresholds
+        self.params = params if params is not None else default_params(odometry_config)
+        self._ref = self._trg = None
+        self._max_ref = self._max_trg = 0
+        self._done = False
+        self.rigidTransf = np.eye(4, dtype=np.float32)
+        self.informationM = np.zeros((6, 6), np.float32)
+        self.bestMatch = {}
+        self.areaMatched = 0.0
+        self.areaSource = self.areaTarget = 0.0
+        self._mode = DEFAULT_6DoF
+        self._good = False
+
+    def setReference(self, ref_planes, max_match_planes: int = 0):          # :110-157
+        self._ref, self._max_ref, self._done = ref_planes, max_match_planes, False
+
+    def setTarget(self, trg_planes, max_match_planes: int = 0):             # :163-195
+        self._trg, self._max_trg, self._done = trg_planes, max_match_planes, False
+
+    def RegisterPbMap(self, frame1=None, frame2=None, max_match_planes: int = 0, registMode: int = DEFAULT_6DoF) -> bool:
+        """:276-338.  True = good alignment."""
+        if frame1 is not None:
+            self.setReference(frame1, max_match_planes)
+        if frame2 is not None:
+            self.setTarget(frame2, max_match_planes)
+        if self._ref is None or self._trg is None:
+            raise RuntimeError("RegisterPbMap: reference and target frames must be set")
+        self._mode = registMode
+        self._done = True
+        r = register_planes(self._ref, self._trg, max(self._max_ref, self._max_trg), registMode, self.params)
+        self.bestMatch, self.areaMatched = r["match"], r["area_matched"]
+        self._good = r["status"] == 0
+        if self._good:
+            self.rigidTransf, self.informationM = r["pose"], r["info"]
+            p = self.params
+
+            def subgraph_area(planes):                                        # :325-333
+                return sum(pl["area"] for pl in planes if pl["curvature"] < p.max_curvature_plane
+                           and not pl["area"] < p.min_area_plane and not pl["elongation"] > p.max_elongation_plane)
+            if max(self._max_ref, self._max_trg) == 0:
+                self.areaSource, self.areaTarget = subgraph_area(self._ref), subgraph_area(self._trg)
+        return self._good
+
+    def _ensure(self):
+        if not self._done:
+            self.RegisterPbMap(registMode=self._mode)
+
+    def getPose(self):                                                        # :198-204
+        self._ensure()
+        return self.rigidTransf
+
+    def getInfoMat(self):                                                     # :218-224
+        self._ensure()
+        return self.informationM
+
+    def getCovMat(self):                                                      # :207-215
+        self._ensure()
+        return np.linalg.inv(self.informationM.astype(np.float64)).astype(np.float32)
+
+    def calcEntropy(self) -> float:                                           # :229-238
+        cov = np.linalg.inv(self.getInfoMat().astype(np.float64))
+        return 0.5 * (DOF * (1 + math.log(2 * math.pi)) + math.log(np.linalg.det(cov)))
+
+    def getMatchedPlanes(self):                                               # :241-247
+        self._ensure()
+        return self.bestMatch
+
+    def getAreaMatched(self) -> float:                                        # :250-256
+        self._ensure()
+        return self.areaMatched

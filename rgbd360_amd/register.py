@@ -393,7 +393,9 @@ class RegisterPhotoICP:
 
 def _planes_to_dicts(arr, n):
     return [dict(centroid=np.array(list(arr[i].centroid), np.float32), normal=np.array(list(arr[i].normal), np.float32),
-                 d=float(arr[i].d), curvature=float(arr[i].curvature), count=int(arr[i].count), root=int(arr[i].root))
+                 d=float(arr[i].d), curvature=float(arr[i].curvature), count=int(arr[i].count), root=int(arr[i].root),
+                 area=float(arr[i].area), elongation=float(arr[i].elongation),
+                 ppal_dir=np.array(list(arr[i].ppal_dir), np.float32))
             for i in range(n)]
 
 

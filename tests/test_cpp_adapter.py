@@ -49,3 +49,39 @@ def test_odometry_replay_matches_python_host(tmp_path, hip_lib):
     pairwise = subprocess.check_output([exe, str(seq), "6", "256", "128"], text=True)
     batched = subprocess.check_output([exe, str(seq), "6", "256", "128", "--sequence"], text=True)
     assert len(pairwise.strip().splitlines()) == 5 and pairwise == batched
+
+
+def test_register_rgbd360_adapter_matches_python_mirror(tmp_path):
+    """include/rgbd360/RegisterRGBD360.hpp (reference RegisterRGBD360.h:47-338 surface) through a small driver: same
+    matches, pose, entropy and matched area as rgbd360_amd.pbmap.RegisterRGBD360.  Host-only code: runs without a GPU."""
+    import math
+    from rgbd360_amd import build, pbmap, synth
+    from tests.test_pbmap_register import room_planes
+    lib = build.build()
+    exe = os.path.join(str(tmp_path), "pbmap_register_demo")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "pbmap_register_demo.cpp"), "-L" + os.path.dirname(lib), "-lrgbd360_hip",
+                           "-Wl,-rpath," + os.path.dirname(lib), "-o", exe])
+    T_wA = synth.make_pose(np.eye(3), np.asarray(synth.CAM_A, float))
+    T_wB = T_wA @ synth.default_motion(21, 0.06, 2.0)
+    rng = np.random.default_rng(3)
+    frames = [room_planes(T_wA, rng, 0.003, 0.003), room_planes(T_wB, rng, 0.003, 0.003)]
+    txt = tmp_path / "planes.txt"
+    with open(txt, "w") as f:
+        for k, planes in enumerate(frames):
+            if k:
+                f.write("--\n")
+            for p in planes:
+                vals = [*p["centroid"], *p["normal"], p["d"], p["curvature"], p["area"], p["elongation"]]
+                f.write(" ".join(repr(float(np.float32(v))) for v in vals) + "\n")
+    out = subprocess.check_output([exe, str(txt), "25", "2", "1"], text=True).strip().splitlines()
+    reg = pbmap.RegisterRGBD360(odometry_config=True)
+    assert reg.RegisterPbMap(frames[0], frames[1], 25, pbmap.ODOMETRY_6DoF)
+    assert out[0] == "status 0 good 1"
+    assert out[1].split()[1:] == [f"{i}:{j}" for i, j in sorted(reg.getMatchedPlanes().items())]
+    pose = np.array([[float(x) for x in l.split()] for l in out[2:6]])
+    assert np.abs(pose - reg.getPose()).max() < 1e-6
+    assert abs(float(out[6].split()[1]) - reg.calcEntropy()) < 1e-3
+    assert abs(float(out[7].split()[1]) - reg.getAreaMatched()) < 1e-3
+    assert synth.pose_error(pose, np.linalg.inv(T_wA) @ T_wB)[0] < math.radians(0.5)
+    assert subprocess.call([exe, str(tmp_path / "missing"), "0", "0", "0"]) == 3

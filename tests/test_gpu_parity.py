@@ -4,6 +4,8 @@ Bars (BASELINE.json north_star): integer / index work bit-exact; float32 planes 
 normal equations within float32 rounding of the float64-accumulated oracle; final SE(3) pose within
 1e-4 rad / 1e-3 m of the oracle.
 """
+import math
+
 import numpy as np
 import pytest
 
@@ -902,3 +904,53 @@ def test_eight_pyramid_levels(hip_lib, oracle_mod):
     assert reg.num_iterations == list(ora.result.iters)[:8]
     rot, trans = synth.pose_error(reg.getOptimalPose(), pose_ref)
     assert rot <= 2e-5 and trans <= 2e-5, (rot, trans)
+
+
+@pytest.mark.parametrize("trans,rot_deg", [(0.06, 2.0), (0.3, 10.0)])
+def test_pbmap_registration_seeds_the_dense_alignment(hip_lib, oracle_mod, trans, rot_deg):
+    """The reference's keyframe check (KFsphere_SLAM.cpp:129-163): planes of both frames -> RegisterPbMap -> the pose seeds
+    alignFrames360 -> the dense pose must agree with the PbMap pose (`isApprox(.., 1e-1)`).  Device planes (chained
+    Frame360 kernels) through the library's host matcher against oracle planes through the numpy restatement: same extent
+    descriptors, same interpretation, same pose; the seeded dense alignment follows the oracle's accept / reject sequence."""
+    from oracle import pbmap_ref
+    from rgbd360_amd import pbmap
+    from rgbd360_amd.register import Frame360Stages
+    W, H = 512, 256
+    pair = synth.make_pair(W, H, seed=5, trans=trans, rot_deg=rot_deg)
+    (rgbA, dA), (rgbB, dB), T = pair
+    st = Frame360Stages(_mk(hip_lib, 3))
+    dev, ora_planes = [], []
+    for d in (dA, dB):
+        dev.append(st.frame_planes(d, convention=2, angular_threshold=0.03)["planes"])
+        xyz = oracle_mod.sphere_cloud(d, 2)
+        nrm, _ = oracle_mod.f360_normals(xyz, H, W, 0.05, 8.0, 1)
+        ora_planes.append(oracle_mod.f360_plane_segment(xyz, nrm, H, W, 40, 0.03, 0.05, 0.001, 1)[1])
+    for got, want in zip(dev, ora_planes):          # the new extent descriptors of the plane records
+        assert [p["root"] for p in got] == [p["root"] for p in want]
+        for a, b in zip(got, want):
+            assert abs(a["area"] - b["area"]) <= 1e-4 * max(1.0, b["area"])
+            if b["area"] > 0.12:                     # (slivers have an ill-defined in-plane aspect)
+                assert abs(a["elongation"] - b["elongation"]) <= 1e-3 * b["elongation"]
+                if b["elongation"] > 1.5:
+                    assert abs(abs(np.dot(a["ppal_dir"], b["ppal_dir"])) - 1) < 1e-4
+    reg360 = pbmap.RegisterRGBD360(odometry_config=True)
+    good = reg360.RegisterPbMap(dev[0], dev[1], 25, pbmap.ODOMETRY_6DoF)
+    want = pbmap_ref.register_planes(ora_planes[0], ora_planes[1], 25, pbmap_ref.ODOMETRY_6DoF)
+    assert good and want["status"] == 0
+    assert reg360.getMatchedPlanes() == want["match"] and len(want["match"]) >= 5
+    rot, tr = synth.pose_error(reg360.getPose(), want["pose"])
+    assert rot < 1e-5 and tr < 1e-5, (rot, tr)
+    rot, tr = synth.pose_error(reg360.getPose(), T)            # planes alone: within 0.1 degree / 1 cm of the truth
+    assert rot < math.radians(0.1) and tr < 0.01, (rot, tr)
+    # dense alignment seeded with the PbMap pose (target = reference frame, source = the other one)
+    reg, ora, _ = _pair_ctx(hip_lib, oracle_mod, pair)
+    guess = reg360.getPose()
+    rc = reg.alignFrames360(guess, 2)
+    st_o, pose_ref = ora.align360(guess, 2)
+    assert rc == st_o == 0
+    assert reg.num_iterations == list(ora.result.iters)[:3]
+    rot, tr = synth.pose_error(reg.getOptimalPose(), pose_ref)
+    assert rot <= POSE_TOL_DEV and tr <= POSE_TOL_DEV, (rot, tr)
+    rot, tr = synth.pose_error(reg.getOptimalPose(), T)
+    assert rot < 2e-3 and tr < 5e-3, (rot, tr)
+    assert np.allclose(reg.getOptimalPose(), guess, atol=1e-1)  # the reference's validity test of the keyframe link

@@ -1,0 +1,215 @@
+"""RegisterRGBD360::RegisterPbMap (reference include/RegisterRGBD360.h:110-338): the host-side plane
+matching + closed-form pose of the HIP library (`rgbd360_register_planes`, pure host C++ -- runs without a GPU) against
+analytic known answers and against the independent numpy restatement oracle/pbmap_ref.py.  PARITY UNPINNED: the matcher
+and the pose fit are MRPT code outside the reference tree (see the oracle's header)."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pbmap_ref as O
+from rgbd360_amd import pbmap, synth
+
+ROOM_LO, ROOM_HI = np.asarray(synth.ROOM_LO, float), np.asarray(synth.ROOM_HI, float)
+# A box is symmetric: without odometry constraints a flipped interpretation explains it equally well (true of the
+# reference too).  The visible part of every second wall is therefore made much smaller, which the unary area
+# constraint (ratio 4 / 3) tells apart.
+VISIBLE = [1.0, 0.2, 1.0, 0.22, 1.0, 0.18]
+
+
+def room_planes(T_wc, rng=None, noise_n=0.0, noise_d=0.0):
+    """The six walls of the synthetic room as seen from camera pose T_wc (camera -> world): analytic plane records."""
+    R, c = T_wc[:3, :3], T_wc[:3, 3]
+    size = ROOM_HI - ROOM_LO
+    planes = []
+    for ax in range(3):
+        for sgn, bound in ((-1.0, ROOM_HI[ax]), (1.0, ROOM_LO[ax])):
+            n_w = np.zeros(3)
+            n_w[ax] = sgn                                   # towards the inside of the room
+            centre_w = 0.5 * (ROOM_LO + ROOM_HI)
+            centre_w[ax] = bound
+            n_c = R.T @ n_w
+            if rng is not None and noise_n > 0:
+                n_c = n_c + rng.normal(size=3) * noise_n
+                n_c /= np.linalg.norm(n_c)
+            cen_c = R.T @ (centre_w - c)
+            d = -float(n_c @ cen_c) + (rng.normal() * noise_d if rng is not None and noise_d > 0 else 0.0)
+            dims = np.delete(size, ax)
+            ppal_w = np.zeros(3)
+            ppal_w[[k for k in range(3) if k != ax][int(np.argmax(dims))]] = 1.0
+            planes.append(dict(centroid=cen_c.astype(np.float32), normal=n_c.astype(np.float32), d=np.float32(d),
+                               curvature=np.float32(1e-5), count=1000, root=len(planes), area=np.float32(dims[0] * dims[1] * VISIBLE[len(planes)]),
+                               elongation=np.float32(dims.max() / dims.min()), ppal_dir=(R.T @ ppal_w).astype(np.float32)))
+    return planes
+
+
+def clutter_plane(rng, root):
+    n = rng.normal(size=3)
+    n /= np.linalg.norm(n)
+    cen = rng.uniform(-2, 2, size=3)
+    if n @ cen > 0:
+        n = -n
+    return dict(centroid=cen.astype(np.float32), normal=n.astype(np.float32), d=np.float32(-n @ cen), curvature=np.float32(2e-4),
+                count=200, root=root, area=np.float32(rng.uniform(0.2, 6.0)), elongation=np.float32(rng.uniform(1.0, 4.0)),
+                ppal_dir=np.array([1, 0, 0], np.float32))
+
+
+def motion(rng, trans, rot_deg):
+    ax = rng.normal(size=3)
+    t = rng.normal(size=3)
+    return synth.make_pose(synth.rodrigues(ax, math.radians(rot_deg)), t / np.linalg.norm(t) * trans)
+
+
+def params_dict(p):
+    return {name: getattr(p, name) for name, _ in p._fields_ if name != "max_nodes"}
+
+
+def test_default_params_are_the_reference_ini_values():
+    for odo, fname in ((False, "configLocaliser_spherical.ini"), (True, "configLocaliser_sphericalOdometry.ini")):
+        p, q = pbmap.default_params(odo), O.default_params(odo)
+        for k, v in q.items():
+            assert abs(getattr(p, k) - v) < 1e-6 * max(1.0, abs(v)), k
+        path = os.path.join("/root/reference/config_files", fname)
+        if not os.path.exists(path):          # the GPU box has no reference tree
+            continue
+        ini = {}
+        for line in open(path):
+            line = line.split("//")[0].strip()
+            if "=" in line and not line.startswith("%"):
+                k, v = line.split("=", 1)
+                ini[k.strip()] = v.strip()
+        for ours, theirs in (("dist_d", "dist_d"), ("angle_deg", "angle"), ("elongation_threshold", "elongation_threshold"),
+                             ("area_threshold", "area_threshold"), ("dist_threshold", "dist_threshold"),
+                             ("angle_threshold_deg", "angle_threshold"), ("height_threshold", "height_threshold"),
+                             ("cos_normal_threshold", "cos_normal_threshold"), ("min_planes_recognition", "min_planes_recognition")):
+            assert abs(getattr(p, ours) - float(ini[theirs])) < 1e-6, (fname, ours)
+
+
+@pytest.mark.parametrize("mode,trans,rot", [(O.DEFAULT_6DoF, 0.8, 35.0), (O.ODOMETRY_6DoF, 0.06, 2.0), (O.DEFAULT_6DoF, 0.0, 0.0)])
+def test_box_room_motion_is_recovered_exactly(mode, trans, rot):
+    """Known answer: noiseless walls seen from two poses, target list shuffled -> all six matched, pose = ground truth."""
+    rng = np.random.default_rng(11)
+    for trial in range(5):
+        T_wA = synth.make_pose(np.eye(3), np.asarray(synth.CAM_A, float))
+        T_wB = T_wA @ motion(rng, trans, rot)
+        ref, trg = room_planes(T_wA), room_planes(T_wB)
+        perm = rng.permutation(6)
+        trg = [trg[k] for k in perm]
+        r = pbmap.register_planes(ref, trg, 0, mode)
+        assert r["status"] == 0
+        assert r["match"] == {i: int(np.where(perm == i)[0][0]) for i in range(6)}
+        rot_err, tr_err = synth.pose_error(r["pose"], np.linalg.inv(T_wA) @ T_wB)
+        assert rot_err < 2e-6 and tr_err < 5e-6, (rot_err, tr_err)
+        assert abs(r["area_matched"] - sum(float(p["area"]) for p in ref)) < 1e-3
+        ev = np.linalg.eigvalsh(r["info"].astype(np.float64))
+        assert ev.min() > 0 and np.allclose(r["info"], r["info"].T)
+
+
+@pytest.mark.parametrize("mode", [O.DEFAULT_6DoF, O.PLANAR_3DoF, O.ODOMETRY_6DoF, O.PLANAR_ODOMETRY_3DoF])
+def test_matches_numpy_restatement_on_noisy_cluttered_scenes(mode):
+    """Branch-and-bound + Jacobi/cross-product pose fit (library) vs plain enumeration + numpy SVD / lstsq (oracle):
+    same status, same interpretation, same pose and information matrix."""
+    rng = np.random.default_rng(100 + mode)
+    odo = mode in (O.ODOMETRY_6DoF, O.PLANAR_ODOMETRY_3DoF)
+    statuses = set()
+    for trial in range(24):
+        T_wA = synth.make_pose(np.eye(3), np.asarray(synth.CAM_A, float))
+        if mode in (O.PLANAR_3DoF, O.PLANAR_ODOMETRY_3DoF):      # rotation about the up axis x, translation on the floor
+            ang = math.radians(3.0 if odo else rng.uniform(-60, 60))
+            t = np.array([0.0, *rng.normal(size=2)])
+            M = synth.make_pose(synth.rodrigues(np.array([1.0, 0, 0]), ang), t / np.linalg.norm(t) * (0.08 if odo else 0.7))
+        else:
+            M = motion(rng, 0.08 if odo else rng.uniform(0.1, 1.0), 3.0 if odo else rng.uniform(0, 50))
+        T_wB = T_wA @ M
+        ref = room_planes(T_wA, rng, 0.004, 0.004)
+        trg = room_planes(T_wB, rng, 0.004, 0.004)
+        if trial % 3 == 1:                                       # a wall not seen in one of the frames
+            ref.pop(int(rng.integers(6)))
+        if trial % 4 == 2:                                       # only two wall directions left: translation unobservable
+            ref = [p for p in ref if abs(p["normal"][0]) < 0.5]
+        for k in range(int(rng.integers(0, 4))):
+            ref.append(clutter_plane(rng, 100 + k))
+        for k in range(int(rng.integers(0, 4))):
+            trg.append(clutter_plane(rng, 200 + k))
+        trg = [trg[k] for k in rng.permutation(len(trg))]
+        p = pbmap.default_params(odo)
+        got = pbmap.register_planes(ref, trg, 0, mode, p)
+        want = O.register_planes(ref, trg, 0, mode, params_dict(p))
+        statuses.add(want["status"])
+        assert got["status"] == want["status"], trial
+        assert got["match"] == want["match"], trial
+        assert abs(got["area_matched"] - want["area_matched"]) < 1e-4 * max(1.0, want["area_matched"])
+        if want["status"] == 0:
+            rot_err, tr_err = synth.pose_error(got["pose"], want["pose"])
+            assert rot_err < 2e-6 and tr_err < 5e-6, (trial, rot_err, tr_err)
+            assert np.abs(got["info"] - want["info"]).max() < 1e-5 * np.abs(want["info"]).max()
+            gt_rot, gt_tr = synth.pose_error(got["pose"], np.linalg.inv(T_wA) @ T_wB)
+            assert gt_rot < math.radians(1.0) and gt_tr < 0.03, (trial, gt_rot, gt_tr)
+        else:
+            assert np.array_equal(got["pose"], np.eye(4, dtype=np.float32))
+    assert 0 in statuses and len(statuses) > 1            # the scenario mix exercises a failure path too
+
+
+def test_insufficient_and_unobservable_cases():
+    T_wA = synth.make_pose(np.eye(3), np.asarray(synth.CAM_A, float))
+    T_wB = T_wA @ synth.default_motion(3, 0.3, 10.0)
+    ref, trg = room_planes(T_wA), room_planes(T_wB)
+    r = pbmap.register_planes(ref[:2], trg, 0, O.DEFAULT_6DoF)              # two planes: "Insuficient matching" (:312)
+    assert r["status"] == 1 and len(r["match"]) == 2 and np.array_equal(r["pose"], np.eye(4, dtype=np.float32))
+    r = pbmap.register_planes([], trg, 0, O.DEFAULT_6DoF)
+    assert r["status"] == 1 and r["match"] == {} and r["area_matched"] == 0.0
+    par = [p for p in ref if abs(p["normal"][0]) < 0.5]                      # four walls, no floor / ceiling
+    r = pbmap.register_planes(par, trg, 0, O.DEFAULT_6DoF)
+    assert r["status"] == 2 and len(r["match"]) == 4                         # matched, but x translation is unobservable
+    with pytest.raises(ValueError):
+        pbmap.register_planes(ref, trg, 0, 7)
+
+
+def test_subgraph_selection_and_filters():
+    """setReference / setTarget (:110-195): curved planes never match; max_match_planes keeps the largest areas; the
+    Frame360.h:1034,1041 filters drop small and narrow planes."""
+    T_wA = synth.make_pose(np.eye(3), np.asarray(synth.CAM_A, float))
+    T_wB = T_wA @ synth.default_motion(4, 0.2, 5.0)
+    ref, trg = room_planes(T_wA), room_planes(T_wB)
+    ref[0]["curvature"] = np.float32(0.01)
+    r = pbmap.register_planes(ref, trg, 0, O.DEFAULT_6DoF)
+    assert r["status"] == 0 and 0 not in r["match"] and len(r["match"]) == 5
+    ref[0]["curvature"] = np.float32(1e-5)
+    r = pbmap.register_planes(ref, trg, 4, O.DEFAULT_6DoF)                  # the four largest areas survive
+    areas = sorted(float(ref[i]["area"]) for i in r["match"])
+    assert r["status"] == 0 and areas == sorted(float(p["area"]) for p in ref)[-4:]
+    assert O.register_planes(ref, trg, 4, O.DEFAULT_6DoF)["match"] == r["match"]
+    ref[2]["area"] = np.float32(0.05)
+    ref[3]["elongation"] = np.float32(9.0)
+    r = pbmap.register_planes(ref, trg, 0, O.DEFAULT_6DoF)
+    assert 2 not in r["match"] and 3 not in r["match"]
+
+
+def test_planar_mode_rejects_a_tilted_interpretation():
+    """PLANAR_3DoF: a motion that tilts the rig cannot be explained; the unconstrained mode recovers it."""
+    T_wA = synth.make_pose(np.eye(3), np.asarray(synth.CAM_A, float))
+    tilt = synth.make_pose(synth.rodrigues(np.array([0, 1.0, 0]), math.radians(25.0)), np.array([0, 0.1, 0.1]))
+    ref, trg = room_planes(T_wA), room_planes(T_wA @ tilt)
+    assert pbmap.register_planes(ref, trg, 0, O.DEFAULT_6DoF)["status"] == 0
+    r = pbmap.register_planes(ref, trg, 0, O.PLANAR_3DoF)
+    assert len(r["match"]) < 6
+    assert r["match"] == O.register_planes(ref, trg, 0, O.PLANAR_3DoF)["match"]
+
+
+def test_reference_class_surface():
+    """The RegisterRGBD360 mirror: lazy registration in the getters (:198-256), entropy formula (:229-238)."""
+    T_wA = synth.make_pose(np.eye(3), np.asarray(synth.CAM_A, float))
+    T_wB = T_wA @ synth.default_motion(9, 0.06, 2.0)
+    reg = pbmap.RegisterRGBD360(odometry_config=True)
+    reg.setReference(room_planes(T_wA))
+    reg.setTarget(room_planes(T_wB))
+    pose = reg.getPose()                                                     # triggers RegisterPbMap
+    assert synth.pose_error(pose, np.linalg.inv(T_wA) @ T_wB)[0] < 2e-6
+    assert len(reg.getMatchedPlanes()) == 6 and reg.getAreaMatched() > 0
+    cov = reg.getCovMat().astype(np.float64)
+    assert np.allclose(cov @ reg.getInfoMat().astype(np.float64), np.eye(6), atol=1e-3)
+    want = 0.5 * (6 * (1 + math.log(2 * math.pi)) + math.log(np.linalg.det(np.linalg.inv(reg.getInfoMat().astype(np.float64)))))
+    assert abs(reg.calcEntropy() - want) < 1e-9
+    assert reg.RegisterPbMap(room_planes(T_wA), room_planes(T_wB), 25, pbmap.PLANAR_ODOMETRY_3DoF) in (True, False)
+    assert reg.areaSource > 0 or reg.areaTarget >= 0
