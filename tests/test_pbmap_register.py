@@ -213,3 +213,27 @@ def test_reference_class_surface():
     assert abs(reg.calcEntropy() - want) < 1e-9
     assert reg.RegisterPbMap(room_planes(T_wA), room_planes(T_wB), 25, pbmap.PLANAR_ODOMETRY_3DoF) in (True, False)
     assert reg.areaSource > 0 or reg.areaTarget >= 0
+
+
+def test_golden_plane_lists():
+    """tests/golden/pbmap_planes.json (planes the oracle extracted from two rendered frames + recorded registrations):
+    the library and the numpy restatement both reproduce every recorded run."""
+    import json
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pbmap_planes.json")))
+    ref, trg = g["frames"]
+    n_good = 0
+    for key, want in g["runs"].items():
+        mode, mmp = int(key[4]), int(key.split("max")[1])
+        for r in (pbmap.register_planes(ref, trg, mmp, mode), O.register_planes(ref, trg, mmp, mode)):
+            assert r["status"] == want["status"], key
+            assert {str(k): v for k, v in r["match"].items()} == want["match"], key
+            assert abs(r["area_matched"] - want["area_matched"]) < 1e-4
+            if want["status"] == 0:
+                rot, tr = synth.pose_error(r["pose"], np.array(want["pose"]))
+                assert rot < 2e-6 and tr < 5e-6, (key, rot, tr)
+                assert np.abs(np.asarray(r["info"]) - np.array(want["info"])).max() < 1e-5 * np.abs(want["info"]).max()
+        if want["status"] == 0:
+            n_good += 1
+            rot, tr = synth.pose_error(np.array(want["pose"]), np.array(g["T_gt"]))
+            assert rot < math.radians(0.1) and tr < 0.01, key        # planes alone land within 0.1 degree / 1 cm
+    assert n_good >= 2
