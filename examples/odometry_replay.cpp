@@ -4,8 +4,11 @@
 //     frame_%03d.rgb  (H*W*3 uint8)   frame_%03d.depth (H*W uint16 mm)
 // Build:  g++ -std=c++17 -O2 -Iinclude examples/odometry_replay.cpp -Lrgbd360_amd/lib -lrgbd360_hip
 //             -Wl,-rpath,$PWD/rgbd360_amd/lib -o odometry_replay
-// Usage:  odometry_replay <dir> <n_frames> <width> <height> [--sequence]
+// Usage:  odometry_replay <dir> <n_frames> <width> <height> [--sequence | --pbmap]
 //         --sequence: all frames are loaded first and the frame loop runs inside the library (alignSequence)
+//         --pbmap:    every pair is first registered from its planes (RegisterRGBD360::RegisterPbMap, ODOMETRY_6DoF, as
+//                     SphereGraphSLAM.cpp:180 / KFsphere_SLAM.cpp:314 do) and that pose seeds alignFrames360
+//                     (KFsphere_SLAM.cpp:149); prints one extra "pbmap" line per pair
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -13,6 +16,7 @@
 #include <vector>
 
 #include "rgbd360/RegisterPhotoICP.hpp"
+#include "rgbd360/RegisterRGBD360.hpp"
 
 struct Frame {   // the two members of Frame360 the dense path reads (Frame360.h:104-111)
     std::vector<uint8_t> rgb;
@@ -49,7 +53,7 @@ static rgbd360::Mat4f mul(const rgbd360::Mat4f& A, const rgbd360::Mat4f& B) {
 
 int main(int argc, char** argv) {
     if (argc < 5) {
-        fprintf(stderr, "usage: %s <dir> <n_frames> <width> <height> [--sequence]\n", argv[0]);
+        fprintf(stderr, "usage: %s <dir> <n_frames> <width> <height> [--sequence | --pbmap]\n", argv[0]);
         return 2;
     }
     const std::string dir = argv[1];
@@ -76,19 +80,38 @@ int main(int argc, char** argv) {
         }
         return 0;
     }
+    const bool use_pbmap = argc > 5 && std::string(argv[5]) == "--pbmap";
+    rgbd360::RegisterRGBD360 registerer(/*odometry_config=*/true);
+    rgbd360::SegmentParams seg;
+    seg.max_depth_change_factor = 0.05f;        // the synthetic frames are full spheres: Frame360_stereo.h:854-882 set-up
+    seg.min_inliers = 40;
+    seg.angular_threshold = 0.03f;
+    seg.distance_threshold = 0.05f;
+    std::vector<rgbd360_plane> planes1, planes2;
     Frame frame1, frame2;
     if (!frame1.load(dir, 0, w, h)) return 3;
+    if (use_pbmap) planes1 = rgbd360::segmentPlanes(align360, frame1.sphereDepth, seg);
     for (int k = 1; k < n; ++k) {
         if (!frame2.load(dir, k, w, h)) return 3;
+        rgbd360::Mat4f guess = rgbd360::Mat4f::Identity();
+        if (use_pbmap) {
+            planes2 = rgbd360::segmentPlanes(align360, frame2.sphereDepth, seg);
+            rgbd360::PlaneList ref{planes1.data(), (int)planes1.size()}, trg{planes2.data(), (int)planes2.size()};
+            const bool good = registerer.RegisterPbMap(&ref, &trg, 25, rgbd360::RegisterRGBD360::ODOMETRY_6DoF);
+            if (good) guess = registerer.getPose();
+            printf("pbmap %d good %d matched %zu t %.5f %.5f %.5f\n", k - 1, good ? 1 : 0, registerer.getMatchedPlanes().size(), guess(0, 3),
+                   guess(1, 3), guess(2, 3));
+        }
         if (k == 1) align360.setTargetFrame(frame1.sphereRGB, frame1.sphereDepth);              // :189
         else align360.promoteSourceToTarget();          // frame1 is last step's frame2: already on the device
         align360.setSourceFrame(frame2.sphereRGB, frame2.sphereDepth);                          // :190
-        align360.alignFrames360(rgbd360::Mat4f::Identity(), rgbd360::RegisterPhotoICP::PHOTO_DEPTH);   // :192
+        align360.alignFrames360(guess, rgbd360::RegisterPhotoICP::PHOTO_DEPTH);                 // :192
         const rgbd360::Mat4f rel = align360.getOptimalPose();                                   // :193
         currentPose = mul(currentPose, rel);                                                    // :257
         printf("pair %d status %d sso %.4f rel_t %.5f %.5f %.5f pose_t %.5f %.5f %.5f\n", k - 1, align360.status(), align360.SSO,
                rel(0, 3), rel(1, 3), rel(2, 3), currentPose(0, 3), currentPose(1, 3), currentPose(2, 3));
         std::swap(frame1, frame2);
+        std::swap(planes1, planes2);
     }
     return 0;
 }

@@ -193,6 +193,10 @@ class RegisterPhotoICP {
     Eigen::Matrix<float, 6, 6> getHessianEigen() const { return Eigen::Map<const Eigen::Matrix<float, 6, 6>>(hessian_.m); }
 #endif
 
+    // The library context behind this object (created on first use) for the calls that have no RegisterPhotoICP counterpart:
+    // the Frame360 stages (rgbd360_frame_planes ...) share its stream and device buffers.
+    rgbd360_ctx* context() { return ctx(); }
+
    private:
     rgbd360_params p_;
     rgbd360_ctx* ctx_ = nullptr;

@@ -9,6 +9,7 @@
 
 #include <cmath>
 #include <map>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -20,6 +21,28 @@ struct PlaneList {                       // view of a frame's planes; the caller
     const rgbd360_plane* planes = nullptr;
     int n = 0;
 };
+
+// Frame360::segmentPlanes / getPlanes (Frame360.h:615-720, 949-1075) for one range panorama: sphere cloud -> normal map ->
+// planar regions on the device (rgbd360_frame_planes), the plane list comes back to the host.  Parameters default to the
+// reference's (PCL set-up of Frame360.h:949-977: depth-change factor 0.02, smoothing 8, min_inliers 80, 0.0398 rad, 0.02 m;
+// max_curvature_plane of Miscellaneous.h:54); convention / depth_mode as in rgbd360_hip.h (2 / 1 = full sphere, range).
+struct SegmentParams {
+    int convention = 2, depth_mode = 1, min_inliers = 80, max_planes = 256;
+    float max_depth_change_factor = 0.02f, normal_smoothing_size = 8.f, angular_threshold = 0.0398f, distance_threshold = 0.02f,
+          max_curvature = 0.0013f;
+};
+inline std::vector<rgbd360_plane> segmentPlanes(RegisterPhotoICP& reg, const ImageView& depth, const SegmentParams& sp = SegmentParams()) {
+    std::vector<rgbd360_plane> planes((size_t)sp.max_planes);
+    int n = 0;
+    const int dt = depth.type == ImageView::U16C1 ? 0 : 1;
+    rgbd360_ctx* ctx = reg.context();
+    const int rc = rgbd360_frame_planes(ctx, depth.data, depth.step, dt, depth.rows, depth.cols, sp.convention, sp.max_depth_change_factor,
+                                        sp.normal_smoothing_size, sp.min_inliers, sp.angular_threshold, sp.distance_threshold,
+                                        sp.max_curvature, sp.depth_mode, nullptr, nullptr, nullptr, planes.data(), sp.max_planes, &n);
+    if (rc != 0) throw std::runtime_error(std::string("rgbd360_frame_planes: ") + rgbd360_last_error(ctx));
+    planes.resize((size_t)n);
+    return planes;
+}
 
 class RegisterRGBD360 {
    public:

@@ -85,3 +85,28 @@ def test_register_rgbd360_adapter_matches_python_mirror(tmp_path):
     assert abs(float(out[7].split()[1]) - reg.getAreaMatched()) < 1e-3
     assert synth.pose_error(pose, np.linalg.inv(T_wA) @ T_wB)[0] < math.radians(0.5)
     assert subprocess.call([exe, str(tmp_path / "missing"), "0", "0", "0"]) == 3
+
+
+@pytest.mark.gpu
+def test_odometry_replay_with_pbmap_initial_guess(tmp_path, hip_lib):
+    """--pbmap: planes of both frames on the device (rgbd360::segmentPlanes), RegisterPbMap in ODOMETRY_6DoF, the pose seeds
+    alignFrames360 (KFsphere_SLAM.cpp:149).  The plane pose is already within a few mm of the motion, and the dense result
+    agrees with the run that starts from the identity."""
+    from rgbd360_amd import synth
+    exe = build_example(tmp_path)
+    seq = tmp_path / "seq"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "dump_sequence.py"), str(seq), "3", "512", "256"])
+    plain = subprocess.check_output([exe, str(seq), "3", "512", "256"], text=True).strip().splitlines()
+    seeded = subprocess.check_output([exe, str(seq), "3", "512", "256", "--pbmap"], text=True).strip().splitlines()
+    pb = [l.split() for l in seeded if l.startswith("pbmap")]
+    pairs = [l.split() for l in seeded if l.startswith("pair")]
+    assert len(pb) == 2 and len(pairs) == 2 and len(plain) == 2
+    for j in range(2):
+        assert pb[j][3] == "1" and int(pb[j][5]) >= 4, pb[j]
+        T_gt = np.linalg.inv(synth.trajectory_pose(j, 7)) @ synth.trajectory_pose(j + 1, 7)
+        t_pb = np.array([float(x) for x in pb[j][7:10]])
+        assert np.linalg.norm(t_pb - T_gt[:3, 3]) < 0.01, (t_pb, T_gt[:3, 3])
+        t_seeded = np.array([float(x) for x in pairs[j][7:10]])
+        t_plain = np.array([float(x) for x in plain[j].split()[7:10]])
+        assert pairs[j][3] == "0" and np.linalg.norm(t_seeded - T_gt[:3, 3]) < 5e-3
+        assert np.linalg.norm(t_seeded - t_plain) < 5e-3
