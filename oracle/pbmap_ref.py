@@ -42,8 +42,13 @@ def _ratio(a, b):
 
 def select_subgraph(planes, max_match_planes, P):
     """setReference / setTarget (RegisterRGBD360.h:110-195) after the Frame360.h:1034,1041 size filters."""
-    kept = [i for i, p in enumerate(planes)
-            if not (_f32(p["area"]) < _f32(P["min_area_plane"])) and not (_f32(p["elongation"]) > _f32(P["max_elongation_plane"]))]
+    def well_formed(p):
+        v = [*np.asarray(p["normal"], np.float32), *np.asarray(p["centroid"], np.float32), _f32(p["d"]), _f32(p["curvature"]),
+             _f32(p["area"]), _f32(p["elongation"])]
+        n = np.asarray(p["normal"], np.float32).astype(np.float64)
+        return bool(np.all(np.isfinite(v))) and _f32(p["area"]) >= 0 and abs(float(n @ n) - 1.0) < 1e-3
+    kept = [i for i, p in enumerate(planes) if well_formed(p)
+            and not (_f32(p["area"]) < _f32(P["min_area_plane"])) and not (_f32(p["elongation"]) > _f32(P["max_elongation_plane"]))]
     flat = lambda i: _f32(planes[i]["curvature"]) < _f32(P["max_curvature_plane"])
     if max_match_planes > 0 and len(kept) > max_match_planes:
         areas = [_f32(planes[i]["area"]) if flat(i) else 0.0 for i in kept]

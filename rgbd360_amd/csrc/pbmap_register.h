@@ -62,11 +62,23 @@ inline double ratio(double a, double b) {      // max / min of two non-negative 
     return lo > 0 ? hi / lo : (hi > 0 ? INFINITY : 1.0);
 }
 
+// a record the matcher can use: finite geometry, a unit-length normal, non-negative extent
+inline bool well_formed(const rgbd360_plane& p) {
+    double nn = 0;
+    for (int k = 0; k < 3; ++k) {
+        if (!std::isfinite(p.normal[k]) || !std::isfinite(p.centroid[k])) return false;
+        nn += (double)p.normal[k] * p.normal[k];
+    }
+    return std::isfinite(p.d) && std::isfinite(p.curvature) && std::isfinite(p.area) && p.area >= 0 && std::isfinite(p.elongation) &&
+           fabs(nn - 1.0) < 1e-3;
+}
+
 // setReference / setTarget (RegisterRGBD360.h:110-195): indices of the planes that enter the matching
 inline std::vector<int> select_subgraph(const rgbd360_plane* pl_all, int n_all, int max_match_planes, const rgbd360_pbmap_params* P) {
     std::vector<int> kept;                  // the frame's PbMap: Frame360.h:1034,1041 never store small or narrow planes
     for (int i = 0; i < n_all; ++i)
-        if (!(pl_all[i].area < P->min_area_plane) && !(pl_all[i].elongation > P->max_elongation_plane)) kept.push_back(i);
+        if (well_formed(pl_all[i]) && !(pl_all[i].area < P->min_area_plane) && !(pl_all[i].elongation > P->max_elongation_plane))
+            kept.push_back(i);
     const int n = (int)kept.size();
     const float max_curvature = P->max_curvature_plane;
     std::vector<int> idx;
@@ -232,6 +244,8 @@ inline int fit_pose(const rgbd360_plane* ref, const rgbd360_plane* trg, const st
             t[i] += HV[i][k] * proj;
         }
     }
+    for (int i = 0; i < 3; ++i)
+        if (!std::isfinite(t[i]) || !std::isfinite(R[i][0]) || !std::isfinite(R[i][1]) || !std::isfinite(R[i][2])) return 2;
     // consistency of the fit + information matrix blockdiag(sum w n n^T / sigma_d^2, sum w (I - n n^T) / sigma_n^2), n = R n_trg
     memset(info, 0, sizeof(double) * 36);
     const double wd = 1.0 / ((double)P->sigma_dist * P->sigma_dist), wn = 1.0 / ((double)P->sigma_normal * P->sigma_normal);

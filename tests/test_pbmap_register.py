@@ -237,3 +237,26 @@ def test_golden_plane_lists():
             rot, tr = synth.pose_error(np.array(want["pose"]), np.array(g["T_gt"]))
             assert rot < math.radians(0.1) and tr < 0.01, key        # planes alone land within 0.1 degree / 1 cm
     assert n_good >= 2
+
+
+def test_hostile_inputs_and_sanitizers(tmp_path):
+    """Records with non-finite or non-unit fields never enter the matching; the host matcher / pose fit (the very header the
+    library compiles) runs seeded random + hostile plane lists clean under AddressSanitizer + UBSan (tools/pbmap_fuzz.cpp)."""
+    import subprocess
+    T_wA = synth.make_pose(np.eye(3), np.asarray(synth.CAM_A, float))
+    T_wB = T_wA @ synth.default_motion(4, 0.06, 2.0)
+    ref, trg = room_planes(T_wA), room_planes(T_wB)
+    ref[1]["d"] = np.float32(np.inf)
+    ref[4]["normal"] = np.array([np.nan, 0, 1], np.float32)
+    trg[2]["normal"] = np.array([0, 0, 3], np.float32)
+    got = pbmap.register_planes(ref, trg, 0, O.ODOMETRY_6DoF)
+    want = O.register_planes(ref, trg, 0, O.ODOMETRY_6DoF)
+    assert got["status"] == want["status"] and got["match"] == want["match"]
+    assert 1 not in got["match"] and 4 not in got["match"] and 2 not in got["match"].values()
+    assert np.isfinite(got["pose"]).all()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "pbmap_fuzz")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-I" + os.path.join(root, "include"), os.path.join(root, "tools", "pbmap_fuzz.cpp"), "-o", exe])
+    out = subprocess.run([exe, "1500"], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("ok 1500 rounds"), out.stdout + out.stderr
