@@ -31,8 +31,16 @@ for d in (dA, dB):
     ptrs.append(p)
 
 
+# PlaneCoefficientComparator links neighbouring pixels whose (window-averaged) normals differ by less than the angular
+# threshold.  Along an image row that crosses a wall / ceiling edge at a shallow angle the blended normal turns by
+# (90 degrees / 8-pixel window) x (slope of the edge in the image) per pixel -- 0.7-1.3 degrees per pixel at 2048x1024 -- so the
+# 0.03 rad that separates the walls at 512x256 merges the whole room into one (curved, rejected) region at full size: the
+# threshold has to shrink with the pixel pitch.
+ANG = float(os.environ.get("PBMAP_ANG", 0.03 * 1024 / W))
+
+
 def planes_of(p):
-    return st.frame_planes_dev(p.value, H, W, 0, convention=2, angular_threshold=0.03, max_curvature=0.0013)["planes"]
+    return st.frame_planes_dev(p.value, H, W, 0, convention=2, angular_threshold=ANG, max_curvature=0.0013, max_planes=2048)["planes"]
 
 
 registerer = pbmap.RegisterRGBD360(odometry_config=True)
@@ -65,8 +73,8 @@ for name, g in (("identity", np.eye(4)), ("pbmap", guess)):
     for _ in range(n):
         rc = reg.alignFrames360(g, 2)
     out[name] = ((time.perf_counter() - t0) / n, rc, list(reg.num_iterations), synth.pose_error(reg.getOptimalPose(), T))
-print("%dx%d, motion %.2f m / %.1f deg: planes of two frames (device, plane lists to the host) %.3f ms; %d / %d planes" % (
-    W, H, trans, rot, t_planes * 1e3, len(pa), len(pb)))
+print("%dx%d, motion %.2f m / %.1f deg, angular threshold %.4f rad: planes of two frames (device, plane lists to the host) %.3f ms; %d / %d planes" % (
+    W, H, trans, rot, ANG, t_planes * 1e3, len(pa), len(pb)))
 print("RegisterPbMap (host, ODOMETRY_6DoF, max 25): %.1f us, status %d, %d matched, pose error vs truth %.2e rad %.2e m; entropy %.2f" % (
     t_match * 1e6, st_pb, nm.value, *synth.pose_error(guess, T), registerer.calcEntropy() if good else float("nan")))
 for name, (t, rc, iters, err) in out.items():
