@@ -37,10 +37,12 @@ for d in (dA, dB):
 # 0.03 rad that separates the walls at 512x256 merges the whole room into one (curved, rejected) region at full size: the
 # threshold has to shrink with the pixel pitch.
 ANG = float(os.environ.get("PBMAP_ANG", 0.03 * 1024 / W))
+MIN_INLIERS = int(os.environ.get("PBMAP_MIN_INLIERS", 40 * (W // 512) ** 2))      # the same solid angle at every resolution
 
 
 def planes_of(p):
-    return st.frame_planes_dev(p.value, H, W, 0, convention=2, angular_threshold=ANG, max_curvature=0.0013, max_planes=2048)["planes"]
+    return st.frame_planes_dev(p.value, H, W, 0, convention=2, angular_threshold=ANG, min_inliers=MIN_INLIERS, max_curvature=0.0013,
+                               max_planes=2048)["planes"]
 
 
 registerer = pbmap.RegisterRGBD360(odometry_config=True)
@@ -73,8 +75,8 @@ for name, g in (("identity", np.eye(4)), ("pbmap", guess)):
     for _ in range(n):
         rc = reg.alignFrames360(g, 2)
     out[name] = ((time.perf_counter() - t0) / n, rc, list(reg.num_iterations), synth.pose_error(reg.getOptimalPose(), T))
-print("%dx%d, motion %.2f m / %.1f deg, angular threshold %.4f rad: planes of two frames (device, plane lists to the host) %.3f ms; %d / %d planes" % (
-    W, H, trans, rot, ANG, t_planes * 1e3, len(pa), len(pb)))
+print("%dx%d, motion %.2f m / %.1f deg, angular threshold %.4f rad, min_inliers %d: planes of two frames (device, plane lists to the host) %.3f ms; %d / %d planes" % (
+    W, H, trans, rot, ANG, MIN_INLIERS, t_planes * 1e3, len(pa), len(pb)))
 print("RegisterPbMap (host, ODOMETRY_6DoF, max 25): %.1f us, status %d, %d matched, pose error vs truth %.2e rad %.2e m; entropy %.2f" % (
     t_match * 1e6, st_pb, nm.value, *synth.pose_error(guess, T), registerer.calcEntropy() if good else float("nan")))
 for name, (t, rc, iters, err) in out.items():
