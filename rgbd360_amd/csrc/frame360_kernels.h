@@ -868,6 +868,124 @@ __global__ __launch_bounds__(kAggThreads) void k_f360_moments(const float* __res
     }
 }
 
+// The same sums with a cost that does not depend on how fragmented the label image is.  k_f360_moments above is built for a
+// few large regions (one wave reduction per region a wave meets: 16 us at 2048 x 1024 with the room as one region, 163 us with
+// 342 regions, where most lanes see several regions and fall back to single-lane LDS atomics).  Here a lane owns 8 CONSECUTIVE
+// pixels, so the slots a wave sees form runs along the lanes: every lane sums its pixels in registers (flushing to the LDS
+// hash only where the slot changes inside its 8 pixels), then ONE segmented scan over the lanes (6 shuffle steps for the nine
+// 64-bit sums, whatever the number of runs) leaves every run's total in its last lane, which adds it to the block's hash.
+// Integer sums: bit-identical to the other kernel and to any other order.
+constexpr int kMomRunHashBits = 8, kMomRunHash = 1 << kMomRunHashBits;
+__device__ __forceinline__ int mom_run_slot(int* keys, int key) {
+    int h = (int)(((unsigned)key * 2654435761u) >> (32 - kMomRunHashBits));
+    for (int probe = 0; probe < 16; ++probe) {
+        const int old = atomicCAS(&keys[h], -1, key);
+        if (old == -1 || old == key) return h;
+        h = (h + 1) & (kMomRunHash - 1);
+    }
+    return -1;
+}
+__global__ __launch_bounds__(kAggThreads) void k_f360_moments_runs(const float* __restrict__ xyz, const int* __restrict__ label,
+                                                                  const int* __restrict__ slot_of_root, int n,
+                                                                  unsigned long long* __restrict__ mom, int max_slots) {
+    __shared__ int keys[kMomRunHash];
+    __shared__ unsigned long long vals[kMomRunHash][9];
+    unsigned long long* mom_rep = mom + (size_t)(blockIdx.x % kMomReplicas) * max_slots * 9;
+    if (threadIdx.x < kMomRunHash) {
+        keys[threadIdx.x] = -1;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) vals[threadIdx.x][k] = 0ull;
+    }
+    __syncthreads();
+    const int lane = (int)threadIdx.x & 63;
+    const int p0 = ((blockIdx.x * (kAggThreads / 64) + ((int)threadIdx.x >> 6)) * 64 + lane) * kMomPerThread;
+    static_assert(kMomPerThread == 8, "two int4 label loads, six float4 point loads per lane");
+    int sl[kMomPerThread];
+    float pt[3 * kMomPerThread];
+    const bool full = p0 + kMomPerThread <= n;
+    if (full) {      // p0 is a multiple of 8: 32-byte aligned labels, 96-byte aligned points
+        const int4 a = *reinterpret_cast<const int4*>(label + p0), b = *reinterpret_cast<const int4*>(label + p0 + 4);
+        sl[0] = a.x; sl[1] = a.y; sl[2] = a.z; sl[3] = a.w; sl[4] = b.x; sl[5] = b.y; sl[6] = b.z; sl[7] = b.w;
+        const float4* q = reinterpret_cast<const float4*>(xyz + 3 * (size_t)p0);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const float4 t = q[k];
+            pt[4 * k] = t.x; pt[4 * k + 1] = t.y; pt[4 * k + 2] = t.z; pt[4 * k + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kMomPerThread; ++j) {
+            const int i = p0 + j;
+            sl[j] = i < n ? label[i] : -1;
+            pt[3 * j] = i < n ? xyz[3 * (size_t)i] : 0.f;
+            pt[3 * j + 1] = i < n ? xyz[3 * (size_t)i + 1] : 0.f;
+            pt[3 * j + 2] = i < n ? xyz[3 * (size_t)i + 2] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kMomPerThread; ++j)
+        if (sl[j] >= 0) sl[j] = slot_of_root[sl[j]];
+    auto d2ll = [](double v) -> long long { return __double_as_longlong(v + 6755399441055744.0) - 0x4338000000000000LL; };
+    auto flush = [&](int k, const long long t[9]) {
+        const int e = mom_run_slot(keys, k);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            if (e >= 0) atomicAdd(&vals[e][q], (unsigned long long)t[q]);
+            else atomicAdd(&mom_rep[(size_t)k * 9 + q], (unsigned long long)t[q]);
+        }
+    };
+    long long v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int key = -1;
+#pragma unroll
+    for (int j = 0; j < kMomPerThread; ++j) {
+        if (sl[j] < 0) continue;
+        if (sl[j] != key) {
+            if (key >= 0) {          // a second run inside the lane's 8 pixels: the first one goes out on its own
+                flush(key, v);
+#pragma unroll
+                for (int q = 0; q < 9; ++q) v[q] = 0;
+            }
+            key = sl[j];
+        }
+        const double x = pt[3 * j], y = pt[3 * j + 1], z = pt[3 * j + 2];
+        v[0] += d2ll(x * kMomScale); v[1] += d2ll(y * kMomScale); v[2] += d2ll(z * kMomScale);
+        v[3] += d2ll(x * x * kMomScale); v[4] += d2ll(x * y * kMomScale); v[5] += d2ll(x * z * kMomScale);
+        v[6] += d2ll(y * y * kMomScale); v[7] += d2ll(y * z * kMomScale); v[8] += d2ll(z * z * kMomScale);
+    }
+    // runs of equal keys along the lanes (key of a lane = the slot of its LAST run; -1 = nothing pending)
+    const int first = __builtin_amdgcn_readfirstlane(key);
+    if (__ballot(key == first) == __ballot(true)) {          // one region (or nothing) in the whole wave
+        if (first >= 0) {
+            long long t[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) t[q] = wave_sum_ll(v[q]);
+            if (lane == 0) flush(first, t);
+        }
+    } else {
+        const int prev = __shfl_up(key, 1);
+        const bool head = lane == 0 || prev != key;
+        const unsigned long long heads = __ballot(head);
+        const int seg = __popcll(heads & (~0ull >> (63 - lane)));          // number of heads at or below this lane
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) {
+            const int oseg = __shfl_up(seg, m);
+            const bool take = lane >= m && oseg == seg;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                const long long o = __shfl_up(v[q], m);
+                v[q] += take ? o : 0ll;
+            }
+        }
+        const bool tail = lane == 63 || ((heads >> (lane + 1)) & 1ull);
+        if (tail && key >= 0) flush(key, v);
+    }
+    __syncthreads();
+    if (threadIdx.x < kMomRunHash && keys[threadIdx.x] >= 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) atomicAdd(&mom_rep[(size_t)keys[threadIdx.x] * 9 + k], vals[threadIdx.x][k]);
+    }
+}
+
 // the 16 copies of the moment table -> copy 0 (integer sums: any order), so that the host fetches n_slots x 9 values once
 __global__ void k_f360_mom_reduce(unsigned long long* __restrict__ mom, const int* __restrict__ n_slots, int max_slots) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
