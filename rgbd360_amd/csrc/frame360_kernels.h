@@ -634,7 +634,6 @@ __global__ void k_f360_ccl_roots(const uint8_t* __restrict__ flags, int n, int* 
 // integer addition is associative, so the results are bitwise reproducible whatever the arrival order.
 constexpr int kAggThreads = 1024;
 constexpr int kMomPerThread = 8;
-constexpr int kAggHash = 64;
 constexpr double kMomScale = 16777216.0;      // 2^24 units per m (linear terms) / per m^2 (quadratic terms)
 constexpr int kMomReplicas = 16;              // copies of the global moment table (block b adds into copy b % 16): a wall is hit by
                                               // every block it spans, and same-address global atomics serialise; the host adds the copies
@@ -643,45 +642,6 @@ __device__ __forceinline__ long long wave_sum_ll(long long v) {
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
     return v;
-}
-
-// find-or-insert `key` (>= 0) in the block's LDS hash; returns the entry index or -1 when the table is full
-__device__ __forceinline__ int agg_slot(int* keys, int key) {
-    int h = (int)(((unsigned)key * 2654435761u) >> 26) & (kAggHash - 1);
-    for (int probe = 0; probe < kAggHash; ++probe) {
-        const int old = atomicCAS(&keys[h], -1, key);
-        if (old == -1 || old == key) return h;
-        h = (h + 1) & (kAggHash - 1);
-    }
-    return -1;
-}
-
-template <int NV>
-__device__ __forceinline__ void agg_add(int* keys, unsigned long long (*vals)[NV], unsigned long long* global_table, int key,
-                                        const long long v[NV], bool active) {
-    const int first = __builtin_amdgcn_readfirstlane(active ? key : -2);
-    const bool uniform = __ballot((active ? key : -2) == first) == __ballot(true);
-    if (uniform) {
-        if (first < 0) return;                                  // whole wave inactive
-        long long t[NV];
-#pragma unroll
-        for (int k = 0; k < NV; ++k) t[k] = wave_sum_ll(v[k]);
-        if ((threadIdx.x & 63) == 0) {
-            const int e = agg_slot(keys, first);
-#pragma unroll
-            for (int k = 0; k < NV; ++k) {
-                if (e >= 0) atomicAdd(&vals[e][k], (unsigned long long)t[k]);
-                else atomicAdd(&global_table[(size_t)first * NV + k], (unsigned long long)t[k]);
-            }
-        }
-    } else if (active) {
-        const int e = agg_slot(keys, key);
-#pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            if (e >= 0) atomicAdd(&vals[e][k], (unsigned long long)v[k]);
-            else atomicAdd(&global_table[(size_t)key * NV + k], (unsigned long long)v[k]);
-        }
-    }
 }
 
 // Pass 5: every remaining pixel takes the root of its run start (exactly one hop), and the region sizes are counted on the
@@ -781,100 +741,15 @@ __global__ void k_f360_assign(const int* __restrict__ label, const unsigned long
     slot_of_root[i] = slot;
 }
 
-// 9 raw moments per selected region (sum x, y, z, xx, xy, xz, yy, yz, zz) in 2^-24 fixed point, two's complement in u64
-__global__ __launch_bounds__(kAggThreads) void k_f360_moments(const float* __restrict__ xyz, const int* __restrict__ label,
-                                                             const int* __restrict__ slot_of_root, int n,
-                                                             unsigned long long* __restrict__ mom, int max_slots) {
-    __shared__ int keys[kAggHash];
-    __shared__ unsigned long long vals[kAggHash][9];
-    unsigned long long* mom_rep = mom + (size_t)(blockIdx.x % kMomReplicas) * max_slots * 9;
-    if (threadIdx.x < kAggHash) {
-        keys[threadIdx.x] = -1;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) vals[threadIdx.x][k] = 0ull;
-    }
-    __syncthreads();
-    // a wave owns kMomPerThread * 64 CONSECUTIVE pixels, lane-interleaved (coalesced rows of 64); inside a plane all of them share
-    // one slot, so every thread sums its pixels in registers and the wave reduction + LDS insert runs once per 512 pixels and
-    // region (the cross-lane shuffles are what this kernel used to spend its time on).  Loads are issued in three batched rounds
-    // (labels, slots, points).
-    const int wave_base = (blockIdx.x * (kAggThreads / 64) + ((int)threadIdx.x >> 6)) * (kMomPerThread * 64) + ((int)threadIdx.x & 63);
-    int sl[kMomPerThread];
-#pragma unroll
-    for (int j = 0; j < kMomPerThread; ++j) {
-        const int i = wave_base + j * 64;
-        sl[j] = i < n ? label[i] : -1;
-    }
-#pragma unroll
-    for (int j = 0; j < kMomPerThread; ++j)
-        if (sl[j] >= 0) sl[j] = slot_of_root[sl[j]];
-    float px[kMomPerThread], py[kMomPerThread], pz[kMomPerThread];
-    int key = -1;
-    bool mixed = false;
-#pragma unroll
-    for (int j = 0; j < kMomPerThread; ++j) {
-        const size_t i = (size_t)(wave_base + j * 64);
-        px[j] = py[j] = pz[j] = 0.f;
-        if (sl[j] >= 0) {
-            px[j] = xyz[3 * i]; py[j] = xyz[3 * i + 1]; pz[j] = xyz[3 * i + 2];
-            if (key < 0) key = sl[j];
-            else if (sl[j] != key) mixed = true;
-        }
-    }
-    // round-to-nearest-even double -> int64 for |v| < 2^51 by the 1.5 * 2^52 trick (one add + one integer subtract instead of
-    // the ~20-instruction conversion sequence; nine of these per pixel dominated the kernel)
-    auto d2ll = [](double v) -> long long { return __double_as_longlong(v + 6755399441055744.0) - 0x4338000000000000LL; };
-    auto moments_of = [&](int j, long long v[9]) {
-        const double x = px[j], y = py[j], z = pz[j];
-        v[0] += d2ll(x * kMomScale); v[1] += d2ll(y * kMomScale); v[2] += d2ll(z * kMomScale);
-        v[3] += d2ll(x * x * kMomScale); v[4] += d2ll(x * y * kMomScale); v[5] += d2ll(x * z * kMomScale);
-        v[6] += d2ll(y * y * kMomScale); v[7] += d2ll(y * z * kMomScale); v[8] += d2ll(z * z * kMomScale);
-    };
-    auto lane_add = [&](int k, const long long t[9]) {            // one lane on its own (a thread that sees a second region)
-        const int e = agg_slot(keys, k);
-#pragma unroll
-        for (int q = 0; q < 9; ++q) {
-            if (e >= 0) atomicAdd(&vals[e][q], (unsigned long long)t[q]);
-            else atomicAdd(&mom_rep[(size_t)k * 9 + q], (unsigned long long)t[q]);
-        }
-    };
-    long long v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int j = 0; j < kMomPerThread; ++j) {
-        if (sl[j] < 0) continue;
-        if (sl[j] == key) moments_of(j, v);
-        else {
-            long long t[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-            moments_of(j, t);
-            lane_add(sl[j], t);
-        }
-    }
-    (void)mixed;
-    // one wave reduction per distinct region among the lanes (one or two almost everywhere)
-    unsigned long long todo = __ballot(key >= 0);
-    while (todo) {
-        const int k = __shfl(key, __ffsll((long long)todo) - 1);
-        const bool mine = key == k;
-        long long t[9];
-#pragma unroll
-        for (int q = 0; q < 9; ++q) t[q] = wave_sum_ll(mine ? v[q] : 0ll);
-        if ((threadIdx.x & 63) == 0) lane_add(k, t);
-        todo &= ~__ballot(mine);
-    }
-    __syncthreads();
-    if (threadIdx.x < kAggHash && keys[threadIdx.x] >= 0) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) atomicAdd(&mom_rep[(size_t)keys[threadIdx.x] * 9 + k], vals[threadIdx.x][k]);
-    }
-}
-
-// The same sums with a cost that does not depend on how fragmented the label image is.  k_f360_moments above is built for a
-// few large regions (one wave reduction per region a wave meets: 16 us at 2048 x 1024 with the room as one region, 163 us with
-// 342 regions, where most lanes see several regions and fall back to single-lane LDS atomics).  Here a lane owns 8 CONSECUTIVE
-// pixels, so the slots a wave sees form runs along the lanes: every lane sums its pixels in registers (flushing to the LDS
-// hash only where the slot changes inside its 8 pixels), then ONE segmented scan over the lanes (6 shuffle steps for the nine
-// 64-bit sums, whatever the number of runs) leaves every run's total in its last lane, which adds it to the block's hash.
-// Integer sums: bit-identical to the other kernel and to any other order.
+// 9 raw moments per selected region (sum x, y, z, xx, xy, xz, yy, yz, zz) in 2^-24 fixed point, two's complement in u64, at a
+// cost that does not depend on how fragmented the label image is.  A lane owns 8 CONSECUTIVE pixels, so the slots a wave sees
+// form runs along the lanes: every lane sums its pixels in registers (flushing to the LDS hash only where the slot changes
+// inside its 8 pixels), then ONE segmented scan over the lanes (6 shuffle steps for the nine 64-bit sums, whatever the number
+// of runs) leaves every run's total in its last lane, which adds it to the block's hash; a wave inside one region takes the
+// plain butterfly sum instead.  (The first version summed lane-interleaved pixels with one wave reduction per region a wave
+// met: 16 us at 2048 x 1024 with the room as one region, but 165 us with 342 regions, where most lanes saw several regions and
+// fell back to single-lane LDS atomics; this one: 16.5 / 17.6 us, and 39 instead of 55 us at 4096 x 2048.)
+// Integer sums: bitwise reproducible whatever the order.
 constexpr int kMomRunHashBits = 8, kMomRunHash = 1 << kMomRunHashBits;
 __device__ __forceinline__ int mom_run_slot(int* keys, int key) {
     int h = (int)(((unsigned)key * 2654435761u) >> (32 - kMomRunHashBits));
@@ -885,7 +760,7 @@ __device__ __forceinline__ int mom_run_slot(int* keys, int key) {
     }
     return -1;
 }
-__global__ __launch_bounds__(kAggThreads) void k_f360_moments_runs(const float* __restrict__ xyz, const int* __restrict__ label,
+__global__ __launch_bounds__(kAggThreads) void k_f360_moments(const float* __restrict__ xyz, const int* __restrict__ label,
                                                                   const int* __restrict__ slot_of_root, int n,
                                                                   unsigned long long* __restrict__ mom, int max_slots) {
     __shared__ int keys[kMomRunHash];
