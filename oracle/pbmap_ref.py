@@ -94,6 +94,18 @@ def binary_ok(a1, a2, b1, b2, P):
     return True
 
 
+def handedness_ok(ref, trg, pairs, i, j):
+    """No mirror images: every triple of matched normals keeps the sign of n1 . (n2 x n3) (near-coplanar triples excepted)."""
+    f = lambda v: np.asarray(v, np.float32).astype(np.float64)
+    for a in range(len(pairs)):
+        for b in range(a + 1, len(pairs)):
+            ta = float(f(ref[pairs[a][0]]["normal"]) @ np.cross(f(ref[pairs[b][0]]["normal"]), f(ref[i]["normal"])))
+            tb = float(f(trg[pairs[a][1]]["normal"]) @ np.cross(f(trg[pairs[b][1]]["normal"]), f(trg[j]["normal"])))
+            if abs(ta) > 0.1 and abs(tb) > 0.1 and (ta > 0) != (tb > 0):
+                return False
+    return True
+
+
 def best_interpretation(ref, trg, ri, ti, mode, P):
     """Every consistent assignment is visited; the winner has the most matches, then the largest matched reference area."""
     best = dict(n=-1, area=-1.0, pairs=[])
@@ -107,7 +119,7 @@ def best_interpretation(ref, trg, ri, ti, mode, P):
         for j in ti:
             if j in used or not unary_ok(a, trg[j], mode, P):
                 continue
-            if all(binary_ok(ref[i0], a, trg[j0], trg[j], P) for i0, j0 in pairs):
+            if all(binary_ok(ref[i0], a, trg[j0], trg[j], P) for i0, j0 in pairs) and handedness_ok(ref, trg, pairs, ri[k], j):
                 pairs.append((ri[k], j))
                 used.add(j)
                 rec(k + 1, pairs, used, area + float(np.float32(a["area"])))

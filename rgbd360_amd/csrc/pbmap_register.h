@@ -138,6 +138,24 @@ struct Matcher {
         if (!(fabs(dot(na2, ca) - dot(nb2, cb)) < P->height_threshold)) return false;         // centre 1 under plane 2
         return true;
     }
+    // A rigid motion keeps the orientation of every triple of normals: n1 . (n2 x n3) has the same sign in both frames.  A set
+    // of matches that violates this is a mirror image of the scene (every angle and distance constraint above is blind to it) and
+    // cannot be fitted by any pose.  Not part of the published matcher: it only discards interpretations the pose fit would
+    // reject anyway, so that a consistent one can win.  Near-coplanar triples (|triple product| < 0.1) say nothing.
+    bool handedness_ok(int k, int j) const {
+        const V3 ak = v3(ref[ri[k]].normal), bk = v3(trg[ti[j]].normal);
+        for (int m1 = 0; m1 < k; ++m1) {
+            if (cur[m1] < 0) continue;
+            const V3 a1 = v3(ref[ri[m1]].normal), b1 = v3(trg[ti[cur[m1]]].normal);
+            for (int m2 = m1 + 1; m2 < k; ++m2) {
+                if (cur[m2] < 0) continue;
+                const double ta = dot(a1, cross(v3(ref[ri[m2]].normal), ak));
+                const double tb = dot(b1, cross(v3(trg[ti[cur[m2]]].normal), bk));
+                if (fabs(ta) > 0.1 && fabs(tb) > 0.1 && (ta > 0) != (tb > 0)) return false;
+            }
+        }
+        return true;
+    }
     void explore(int k, double area) {      // area = matched reference area so far, summed in matching order
         if (out_of_budget) return;
         if (P->max_nodes > 0 && ++nodes > P->max_nodes) {
@@ -159,7 +177,7 @@ struct Matcher {
             bool ok = true;
             for (int m = 0; m < k && ok; ++m)
                 if (cur[m] >= 0) ok = eval_binary(ref[ri[m]], ref[ri[k]], trg[ti[cur[m]]], trg[ti[j]]);
-            if (!ok) continue;
+            if (!ok || !handedness_ok(k, j)) continue;
             used[j] = 1;
             cur[k] = j;
             ++cur_n;

@@ -260,3 +260,23 @@ def test_hostile_inputs_and_sanitizers(tmp_path):
                            "-I" + os.path.join(root, "include"), os.path.join(root, "tools", "pbmap_fuzz.cpp"), "-o", exe])
     out = subprocess.run([exe, "1500"], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.startswith("ok 1500 rounds"), out.stdout + out.stderr
+
+
+def test_mirror_images_are_never_matched():
+    """Three mutually orthogonal planes against their mirror image: every angle / distance constraint holds, but no rigid
+    motion maps one onto the other -- the orientation test of the normal triple leaves one plane unmatched."""
+    def corner(sign_z):
+        planes = []
+        for ax, (a, e) in enumerate(((4.0, 1.5), (6.0, 2.0), (9.0, 1.2))):
+            n = np.zeros(3, np.float32)
+            n[ax] = 1.0 if ax < 2 else sign_z
+            c = np.array([0.3, 0.4, 0.5 * sign_z], np.float32) * 0 + np.float32(-2.0 - ax) * n
+            planes.append(dict(centroid=c, normal=n, d=np.float32(-n @ c), curvature=np.float32(1e-5), count=500, root=ax,
+                               area=np.float32(a), elongation=np.float32(e), ppal_dir=np.array([0, 0, 0], np.float32)))
+        return planes
+    same = pbmap.register_planes(corner(1.0), corner(1.0), 0, O.DEFAULT_6DoF)
+    assert same["status"] == 0 and same["match"] == {0: 0, 1: 1, 2: 2}
+    assert np.allclose(same["pose"], np.eye(4), atol=1e-6)
+    mirrored = pbmap.register_planes(corner(1.0), corner(-1.0), 0, O.DEFAULT_6DoF)
+    assert mirrored["status"] == 1 and len(mirrored["match"]) == 2
+    assert O.register_planes(corner(1.0), corner(-1.0), 0, O.DEFAULT_6DoF)["match"] == mirrored["match"]
