@@ -4,11 +4,13 @@
 //     frame_%03d.rgb  (H*W*3 uint8)   frame_%03d.depth (H*W uint16 mm)
 // Build:  g++ -std=c++17 -O2 -Iinclude examples/odometry_replay.cpp -Lrgbd360_amd/lib -lrgbd360_hip
 //             -Wl,-rpath,$PWD/rgbd360_amd/lib -o odometry_replay
-// Usage:  odometry_replay <dir> <n_frames> <width> <height> [--sequence | --pbmap]
+// Usage:  odometry_replay <dir> <n_frames> <width> <height> [--sequence | --pbmap | --link]
 //         --sequence: all frames are loaded first and the frame loop runs inside the library (alignSequence)
 //         --pbmap:    every pair is first registered from its planes (RegisterRGBD360::RegisterPbMap, ODOMETRY_6DoF, as
 //                     SphereGraphSLAM.cpp:180 / KFsphere_SLAM.cpp:314 do) and that pose seeds alignFrames360
 //                     (KFsphere_SLAM.cpp:149); prints one extra "pbmap" line per pair
+//         --link:     the same per pair through the one-call form rgbd360::RegisterFrames (planes, RegisterPbMap, seeded dense
+//                     alignment, the reference's isApprox(1e-1) validity test); prints "link <pair> <ok> rel_t ..."
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -77,6 +79,26 @@ int main(int argc, char** argv) {
             currentPose = mul(currentPose, rels[j]);
             printf("pair %zu status %d sso %.4f rel_t %.5f %.5f %.5f pose_t %.5f %.5f %.5f\n", j, res[j].status, res[j].sso,
                    rels[j](0, 3), rels[j](1, 3), rels[j](2, 3), currentPose(0, 3), currentPose(1, 3), currentPose(2, 3));
+        }
+        return 0;
+    }
+    if (argc > 5 && std::string(argv[5]) == "--link") {
+        rgbd360::RegisterRGBD360 registerer(/*odometry_config=*/true);
+        rgbd360::SegmentParams seg;
+        seg.max_depth_change_factor = 0.05f;
+        seg.min_inliers = 40;
+        seg.angular_threshold = 0.03f;
+        seg.distance_threshold = 0.05f;
+        Frame a, b;
+        if (!a.load(dir, 0, w, h)) return 3;
+        for (int k = 1; k < n; ++k) {
+            if (!b.load(dir, k, w, h)) return 3;
+            rgbd360::Mat4f rel = rgbd360::Mat4f::Identity();
+            const bool ok = rgbd360::RegisterFrames(a, b, rel, [](const rgbd360::ImageView& v) { return v; }, align360, registerer,
+                                                    rgbd360::RegisterRGBD360::ODOMETRY_6DoF, 25, seg);
+            printf("link %d ok %d matched %zu rel_t %.5f %.5f %.5f\n", k - 1, ok ? 1 : 0, registerer.getMatchedPlanes().size(), rel(0, 3),
+                   rel(1, 3), rel(2, 3));
+            std::swap(a, b);
         }
         return 0;
     }

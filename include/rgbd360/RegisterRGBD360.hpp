@@ -178,4 +178,35 @@ class RegisterRGBD360 {
     float areaMatched_ = 0.f;
 };
 
+// The keyframe link of the reference's SLAM applications as one call (KFsphere_SLAM.cpp:129-163 with :182 / :314 in front):
+// planes of both frames -> RegisterPbMap -> alignFrames360 seeded with the plane pose (with `pose` as passed in when the plane
+// registration fails) -> the reference's validity test `dense.isApprox(pbmap, 1e-1)` when both exist.  `pose` carries the
+// fallback guess in and the dense pose out (p_ref = R p_cur + t).  FrameLike: public `sphereRGB` / `sphereDepth` members.
+template <class FrameLike, class ToView>
+bool RegisterFrames(FrameLike& ref, FrameLike& cur, Mat4f& pose, ToView to_view, RegisterPhotoICP& dense, RegisterRGBD360& registerer,
+                    RegisterRGBD360::registrationType registMode = RegisterRGBD360::ODOMETRY_6DoF, size_t max_match_planes = 25,
+                    const SegmentParams& seg = SegmentParams(),
+                    RegisterPhotoICP::costFuncType method = RegisterPhotoICP::PHOTO_DEPTH) {
+    const std::vector<rgbd360_plane> pr = segmentPlanes(dense, to_view(ref.sphereDepth), seg);
+    const std::vector<rgbd360_plane> pc = segmentPlanes(dense, to_view(cur.sphereDepth), seg);
+    PlaneList lr{pr.data(), (int)pr.size()}, lc{pc.data(), (int)pc.size()};
+    const bool planes_ok = registerer.RegisterPbMap(&lr, &lc, max_match_planes, registMode);
+    const Mat4f guess = planes_ok ? registerer.getPose() : pose;
+    dense.setTargetFrame(to_view(ref.sphereRGB), to_view(ref.sphereDepth));
+    dense.setSourceFrame(to_view(cur.sphereRGB), to_view(cur.sphereDepth));
+    dense.alignFrames360(guess, method);
+    pose = dense.getOptimalPose();
+    if (dense.status() != 0) return false;
+    if (planes_ok) {                                     // Eigen's isApprox(b, p): ||a - b|| <= p min(||a||, ||b||), Frobenius
+        double diff = 0, na = 0, nb = 0;
+        for (int k = 0; k < 16; ++k) {
+            diff += ((double)pose.m[k] - guess.m[k]) * ((double)pose.m[k] - guess.m[k]);
+            na += (double)pose.m[k] * pose.m[k];
+            nb += (double)guess.m[k] * guess.m[k];
+        }
+        if (diff > 1e-2 * (na < nb ? na : nb)) return false;
+    }
+    return true;
+}
+
 }  // namespace rgbd360

@@ -110,3 +110,9 @@ def test_odometry_replay_with_pbmap_initial_guess(tmp_path, hip_lib):
         t_plain = np.array([float(x) for x in plain[j].split()[7:10]])
         assert pairs[j][3] == "0" and np.linalg.norm(t_seeded - T_gt[:3, 3]) < 5e-3
         assert np.linalg.norm(t_seeded - t_plain) < 5e-3
+    # the one-call form (rgbd360::RegisterFrames): same relative translations as the explicit sequence, links valid
+    linked = [l.split() for l in subprocess.check_output([exe, str(seq), "3", "512", "256", "--link"], text=True).strip().splitlines()]
+    assert len(linked) == 2
+    for j in range(2):
+        assert linked[j][3] == "1" and int(linked[j][5]) >= 4, linked[j]
+        assert np.allclose([float(x) for x in linked[j][7:10]], [float(x) for x in pairs[j][7:10]], atol=1e-5)
