@@ -713,8 +713,17 @@ __global__ __launch_bounds__(kAggThreads) void k_f360_finish_count(const uint8_t
                     pend_cnt = c64;
                 }
             }
-        } else if (l >= 0) {
-            add(l, 1u);
+        } else {
+            // several regions among the wave's 64 consecutive pixels: one add per RUN of equal labels (its first lane adds the
+            // run's length, found from the ballot of run starts) instead of one LDS atomic per pixel
+            const int lane = (int)threadIdx.x & 63;
+            const int prev = __shfl_up(l, 1);
+            const bool head = lane == 0 || prev != l;
+            const unsigned long long heads = __ballot(head);
+            if (head && l >= 0) {
+                const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1));
+                add(l, (unsigned int)(above ? __ffsll((long long)above) : 64 - lane));
+            }
         }
     }
     if (pend_cnt && lane0) add(pend_key, pend_cnt);
