@@ -871,14 +871,30 @@ __global__ __launch_bounds__(kAggThreads) void k_f360_moments(const float* __res
 }
 
 // the 16 copies of the moment table -> copy 0 (integer sums: any order), so that the host fetches n_slots x 9 values once
-__global__ void k_f360_mom_reduce(unsigned long long* __restrict__ mom, const int* __restrict__ n_slots, int max_slots) {
+// One record per selected region, as the host reads it back: ONE device-to-host copy of header + records instead of four.
+struct F360SlotRecord {
+    int root, count;
+    unsigned long long mom[9];
+};
+constexpr int kF360PackHeader = 16;            // bytes: int n_slots + padding, the records follow (8-byte aligned)
+__global__ void k_f360_mom_reduce(const unsigned long long* __restrict__ mom, const int* __restrict__ n_slots, int max_slots,
+                                  const int* __restrict__ root_of_slot, const int* __restrict__ count_of_slot,
+                                  unsigned char* __restrict__ pack) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int ns = *n_slots < max_slots ? *n_slots : max_slots;
+    const int ns_all = *n_slots;
+    if (i == 0) *reinterpret_cast<int*>(pack) = ns_all;
+    const int ns = ns_all < max_slots ? ns_all : max_slots;
     if (i >= ns * 9) return;
     unsigned long long acc = mom[i];
 #pragma unroll
     for (int r = 1; r < kMomReplicas; ++r) acc += mom[(size_t)r * max_slots * 9 + i];
-    mom[i] = acc;
+    const int slot = i / 9, q = i - slot * 9;
+    F360SlotRecord* rec = reinterpret_cast<F360SlotRecord*>(pack + kF360PackHeader) + slot;
+    rec->mom[q] = acc;
+    if (q == 0) {
+        rec->root = root_of_slot[slot];
+        rec->count = count_of_slot[slot];
+    }
 }
 
 // Frame360::stitchImage (Frame360.h:1099-1148): one thread per panorama pixel; the sensor is fixed by the column band.
