@@ -661,9 +661,10 @@ __device__ __forceinline__ int cnt_slot(int* keys, int key) {
     return -1;
 }
 __global__ __launch_bounds__(kAggThreads) void k_f360_finish_count(const uint8_t* __restrict__ flags, int n, int* __restrict__ label,
-                                                                  unsigned long long* __restrict__ count) {
+                                                                  unsigned long long* __restrict__ count, int* __restrict__ n_slots) {
     __shared__ int keys[kCntHash];
     __shared__ unsigned int vals[kCntHash];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *n_slots = 0;        // the slot counter of k_f360_assign, the next launch (no memset)
     if (threadIdx.x < kCntHash) {
         keys[threadIdx.x] = -1;
         vals[threadIdx.x] = 0u;
@@ -734,7 +735,7 @@ __global__ __launch_bounds__(kAggThreads) void k_f360_finish_count(const uint8_t
 // compaction: roots of regions with more than min_inliers points get a slot (order fixed later on the host)
 __global__ void k_f360_assign(const int* __restrict__ label, const unsigned long long* __restrict__ count, int n, int min_inliers,
                               int max_slots, int* __restrict__ slot_of_root, int* __restrict__ root_of_slot, int* __restrict__ count_of_slot,
-                              int* __restrict__ n_slots) {
+                              int* __restrict__ n_slots, unsigned long long* __restrict__ mom, int mom_replicas) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (label[i] != i) return;               // slot_of_root is only ever read at roots: no memset of the table
@@ -745,6 +746,9 @@ __global__ void k_f360_assign(const int* __restrict__ label, const unsigned long
             slot = s;
             root_of_slot[s] = i;
             count_of_slot[s] = (int)count[i];
+            // the moment rows of this slot start at zero: no memset of the 16 x 4096 x 9 table, only the slots in use are touched
+            for (int r = 0; r < mom_replicas; ++r)
+                for (int q = 0; q < 9; ++q) mom[((size_t)r * max_slots + s) * 9 + q] = 0ull;
         }
     }
     slot_of_root[i] = slot;
