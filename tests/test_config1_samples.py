@@ -38,3 +38,31 @@ def test_sample_pair_stitches_and_aligns_like_the_committed_record():
     T = np.array(out["PHOTO_DEPTH"]["pose"])
     rot, trans = synth.pose_error(T, np.eye(4))
     assert 0.05 < trans < 0.6 and rot < 0.1
+
+
+@pytest.mark.skipif(not os.path.exists(SAMPLES), reason="reference samples are only present in the build container")
+def test_sample_pair_plane_registration_reports_an_unobservable_translation():
+    """RegisterPairRGBD360.cpp:94-110 runs RegisterPbMap on this very pair.  With the reference's PCL parameters
+    (Frame360.h:949-977: depth-change factor 0.02, smoothing 8, 80 inliers, 0.0398 rad, 0.02 m) but WITHOUT its bilateral
+    pre-filter of the clouds (pcl::FastBilateralFilter, Frame360.h:494-501 -- third-party, not built) only the floor and the
+    ceiling of the raw sensor data survive the segmentation: the matcher pairs a dozen of their pieces, every matched normal is
+    (anti)parallel to the up axis, and the pose fit correctly reports that the translation is not observable (status 2) instead
+    of inventing one -- the dense alignment then has to start from the identity, as tools/config1_samples.py does."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import config1_samples as c1
+    from oracle import oracle as O
+    from rgbd360_amd import pbmap
+    _, pano = c1.run()
+    H, W = pano[0][1].shape
+    frames = []
+    for _, d in pano:
+        xyz = O.sphere_cloud(d, 2)
+        nrm, _w = O.f360_normals(xyz, H, W, 0.02, 8.0, 1)
+        frames.append(O.f360_plane_segment(xyz, nrm, H, W, 80, 0.0398, 0.02, 0.0013, 1, max_planes=1024)[1])
+    assert min(len(f) for f in frames) >= 20
+    for mode in (pbmap.ODOMETRY_6DoF, pbmap.PLANAR_ODOMETRY_3DoF):
+        r = pbmap.register_planes(frames[0], frames[1], 25, mode, pbmap.default_params(True))
+        assert r["status"] == 2 and len(r["match"]) >= 8
+        up = [abs(float(frames[0][i]["normal"][0])) for i in r["match"]]
+        assert min(up) > 0.98                                   # floor / ceiling pieces only
+        assert np.array_equal(r["pose"], np.eye(4, dtype=np.float32))
