@@ -43,9 +43,9 @@ def test_sample_pair_stitches_and_aligns_like_the_committed_record():
 @pytest.mark.skipif(not os.path.exists(SAMPLES), reason="reference samples are only present in the build container")
 def test_sample_pair_plane_registration_reports_an_unobservable_translation():
     """RegisterPairRGBD360.cpp:94-110 runs RegisterPbMap on this very pair.  With the reference's PCL parameters
-    (Frame360.h:949-977: depth-change factor 0.02, smoothing 8, 80 inliers, 0.0398 rad, 0.02 m) but WITHOUT its bilateral
-    pre-filter of the clouds (pcl::FastBilateralFilter, Frame360.h:494-501 -- third-party, not built) only the floor and the
-    ceiling of the raw sensor data survive the segmentation: the matcher pairs a dozen of their pieces, every matched normal is
+    (Frame360.h:949-977: depth-change factor 0.02, smoothing 8, 80 inliers, 0.0398 rad, 0.02 m) applied to the stitched panorama
+    -- the reference segments per sensor, on clouds down-sampled by 2 and smoothed by pcl::FastBilateralFilter (Frame360.h:40-41,
+    479-499; third-party, not built) -- only the floor and the ceiling of the raw sensor data survive the segmentation: the matcher pairs a dozen of their pieces, every matched normal is
     (anti)parallel to the up axis, and the pose fit correctly reports that the translation is not observable (status 2) instead
     of inventing one -- the dense alignment then has to start from the identity, as tools/config1_samples.py does."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
