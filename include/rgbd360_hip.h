@@ -212,6 +212,12 @@ int rgbd360_normals(rgbd360_ctx* ctx, const float* xyz, int rows, int cols, floa
 int rgbd360_distance_map(rgbd360_ctx* ctx, const float* xyz, int rows, int cols, float max_depth_change_factor,
                          int depth_mode, float* dist_out);
 
+/* pcl::FastBilateralFilter<PointXYZRGBA> with setSigmaS(sigma_s) / setSigmaR(sigma_r) on an organised cloud (rows*cols x 3
+ * float32, NaN = invalid): the smoothing Frame360 applies to every sensor cloud before its planes are segmented
+ * (Frame360.h:40, 493-499: sigma_s 10 px, sigma_r 0.05 m).  PCL's bilateral-grid algorithm (third-party; restated, see
+ * oracle/frame360_ref.cpp): only z changes, x and y are copied.  xyz_out may alias xyz. */
+int rgbd360_bilateral_filter(rgbd360_ctx* ctx, const float* xyz, int rows, int cols, float sigma_s, float sigma_r, float* xyz_out);
+
 /* One planar region: n . x + d = 0 with n towards the origin, curvature = lambda_min / trace(cov). */
 typedef struct {
     float centroid[3];

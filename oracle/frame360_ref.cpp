@@ -298,6 +298,101 @@ int oracle_f360_plane_segment(const float* xyz, const float* normals, int rows, 
 
 
 // ------------------------------------------------------------------------------------
+// pcl::FastBilateralFilter<PointXYZRGBA>::applyFilter with setSigmaS(sigma_s) / setSigmaR(sigma_r), the smoothing Frame360
+// applies to every sensor cloud before the planes are segmented (Frame360.h:40, 493-499: sigma_s 10 px, sigma_r 0.05 m).
+// THIRD-PARTY (PCL >= 1.7 filters/impl/fast_bilateral.hpp, not in the reference tree, unpinned): restated from the published
+// bilateral-grid algorithm (Paris & Durand) as PCL implements it -- only z is filtered; non-finite z enter the grid as the
+// largest finite z; grid of (cols-1)/sigma_s + 1 + 4 by (rows-1)/sigma_s + 1 + 4 by (zmax-zmin)/sigma_r + 1 + 4 cells of
+// {sum z, count}; two [1 2 1]/4 passes per axis over the interior cells, ping-ponging two arrays whose border cells are never
+// written (PCL's swap); z = trilinear(sum z) / trilinear(count).  One deliberate difference, shared with the device: the
+// cell sums are accumulated in 2^-20 m fixed point (integers), so they do not depend on the order of the points.
+struct BilateralGrid {
+    int nx, ny, nz;
+    std::vector<float> v;            // {sum z, count} per cell, index ((x * ny) + y) * nz + z
+    size_t idx(int x, int y, int z) const { return (((size_t)x * ny) + y) * nz + z; }
+};
+constexpr double kBilatFixed = 1048576.0;      // 2^20 units per metre
+
+void oracle_fast_bilateral(const float* xyz, int rows, int cols, float sigma_s, float sigma_r, float* out) {
+    const size_t n = (size_t)rows * cols;
+    memcpy(out, xyz, n * 3 * sizeof(float));
+    float base_max = -std::numeric_limits<float>::max(), base_min = std::numeric_limits<float>::max();
+    bool found = false;
+    for (size_t i = 0; i < n; ++i) {
+        const float z = xyz[3 * i + 2];
+        if (std::isfinite(z)) {
+            base_max = std::max(base_max, z);
+            base_min = std::min(base_min, z);
+            found = true;
+        }
+    }
+    if (!found) return;
+    const float base_delta = base_max - base_min;
+    const int pad_xy = 2, pad_z = 2;
+    BilateralGrid g;
+    g.nx = (int)((float)(cols - 1) / sigma_s) + 1 + 2 * pad_xy;
+    g.ny = (int)((float)(rows - 1) / sigma_s) + 1 + 2 * pad_xy;
+    g.nz = (int)(base_delta / sigma_r) + 1 + 2 * pad_z;
+    const size_t cells = (size_t)g.nx * g.ny * g.nz;
+    std::vector<long long> sum(cells, 0);
+    std::vector<int> cnt(cells, 0);
+    for (int y = 0; y < rows; ++y)
+        for (int x = 0; x < cols; ++x) {
+            float pz = xyz[3 * ((size_t)y * cols + x) + 2];
+            if (!std::isfinite(pz)) pz = base_max;
+            const float z = pz - base_min;
+            const int sx = (int)((float)x / sigma_s + 0.5f) + pad_xy, sy = (int)((float)y / sigma_s + 0.5f) + pad_xy;
+            const int sz = (int)(z / sigma_r + 0.5f) + pad_z;
+            const size_t c = g.idx(sx, sy, sz);
+            sum[c] += (long long)llrint((double)pz * kBilatFixed);
+            cnt[c] += 1;
+        }
+    std::vector<float> a(cells * 2), b(cells * 2, 0.f);
+    for (size_t c = 0; c < cells; ++c) {
+        a[2 * c] = (float)((double)sum[c] / kBilatFixed);
+        a[2 * c + 1] = (float)cnt[c];
+    }
+    float *data = a.data(), *buffer = b.data();
+    const size_t offs[3] = {(size_t)g.ny * g.nz, (size_t)g.nz, 1};
+    for (int dim = 0; dim < 3; ++dim)
+        for (int it = 0; it < 2; ++it) {
+            std::swap(data, buffer);
+            const size_t off = offs[dim];
+            for (int x = 1; x < g.nx - 1; ++x)
+                for (int y = 1; y < g.ny - 1; ++y)
+                    for (int z = 1; z < g.nz - 1; ++z) {
+                        const size_t c = g.idx(x, y, z);
+                        for (int k = 0; k < 2; ++k)
+                            data[2 * c + k] = (buffer[2 * (c - off) + k] + buffer[2 * (c + off) + k] + 2.f * buffer[2 * c + k]) / 4.f;
+                    }
+        }
+    auto clampi = [](int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); };
+    for (int y = 0; y < rows; ++y)
+        for (int x = 0; x < cols; ++x) {
+            const size_t i = (size_t)y * cols + x;
+            float pz = xyz[3 * i + 2];
+            if (!std::isfinite(pz)) pz = base_max;
+            const float fx = (float)x / sigma_s + (float)pad_xy, fy = (float)y / sigma_s + (float)pad_xy;
+            const float fz = (pz - base_min) / sigma_r + (float)pad_z;
+            const int x0 = clampi((int)fx, g.nx - 1), x1 = clampi(x0 + 1, g.nx - 1);
+            const int y0 = clampi((int)fy, g.ny - 1), y1 = clampi(y0 + 1, g.ny - 1);
+            const int z0 = clampi((int)fz, g.nz - 1), z1 = clampi(z0 + 1, g.nz - 1);
+            const float xa = fx - (float)x0, ya = fy - (float)y0, za = fz - (float)z0;
+            float D[2];
+            for (int k = 0; k < 2; ++k)
+                D[k] = (1.f - xa) * (1.f - ya) * (1.f - za) * data[2 * g.idx(x0, y0, z0) + k] +
+                       xa * (1.f - ya) * (1.f - za) * data[2 * g.idx(x1, y0, z0) + k] +
+                       (1.f - xa) * ya * (1.f - za) * data[2 * g.idx(x0, y1, z0) + k] +
+                       xa * ya * (1.f - za) * data[2 * g.idx(x1, y1, z0) + k] +
+                       (1.f - xa) * (1.f - ya) * za * data[2 * g.idx(x0, y0, z1) + k] +
+                       xa * (1.f - ya) * za * data[2 * g.idx(x1, y0, z1) + k] +
+                       (1.f - xa) * ya * za * data[2 * g.idx(x0, y1, z1) + k] +
+                       xa * ya * za * data[2 * g.idx(x1, y1, z1) + k];
+            out[3 * i + 2] = D[0] / D[1];
+        }
+}
+
+// ------------------------------------------------------------------------------------
 // Frame360::stitchSphericalImage / stitchImage (Frame360.h:386-405, 1099-1148): the step right before the alignment
 // path.  rgb[s]: sensor_rows x sensor_cols x 3 uint8, depth[s]: uint16 mm; Rt_inv: 8 column-major
 // 4x4 (Calib360::Rt_inv, Calib360.h:129); K = {fx, fy, cx, cy} (Calib360.h:74-77).  Outputs: H x W x 3 and H x W with

@@ -361,6 +361,17 @@ def f360_plane_segment(xyz, normals, rows, cols, min_inliers=40, angular_thresho
     return labels.reshape(rows, cols), planes
 
 
+def fast_bilateral(xyz, rows, cols, sigma_s=10.0, sigma_r=0.05):
+    """pcl::FastBilateralFilter restated (oracle/frame360_ref.cpp): organised cloud in, cloud with filtered z out."""
+    xyz = np.ascontiguousarray(xyz, np.float32).reshape(rows * cols, 3)
+    out = np.empty_like(xyz)
+    f = lib().oracle_fast_bilateral
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]
+    f.restype = None
+    f(_ptr(xyz), rows, cols, sigma_s, sigma_r, _ptr(out))
+    return out
+
+
 def stitch_sphere(rgb8, depth8, Rt_inv, K=(262.5, 262.5, 159.5, 119.5)):
     """Frame360::stitchSphericalImage restated (oracle/frame360_ref.cpp).  Rt_inv: [8,4,4] row-major numpy."""
     rgb8 = np.ascontiguousarray(rgb8, np.uint8)

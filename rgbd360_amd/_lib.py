@@ -16,7 +16,7 @@ SYMBOLS = [
     "rgbd360_sync", "rgbd360_device_count", "rgbd360_sphere_cloud", "rgbd360_selftest_math", "rgbd360_time_solve_kernel", "rgbd360_normals", "rgbd360_distance_map",
     "rgbd360_plane_fit", "rgbd360_frame_planes", "rgbd360_frame_planes_dev", "rgbd360_load_frame_bin", "rgbd360_stitch_sphere",
     "rgbd360_set_camera", "rgbd360_align_pinhole", "rgbd360_eval_pinhole", "rgbd360_warp_indices_pinhole",
-    "rgbd360_pbmap_default_params", "rgbd360_register_planes",
+    "rgbd360_pbmap_default_params", "rgbd360_register_planes", "rgbd360_bilateral_filter",
 ]
 
 
@@ -98,6 +98,7 @@ def load() -> C.CDLL:
     L.rgbd360_time_solve_kernel.argtypes = [vp, i32, i32, i32, C.POINTER(C.c_float)]
     L.rgbd360_normals.argtypes = [vp, vp, i32, i32, C.c_float, C.c_float, i32, vp]
     L.rgbd360_distance_map.argtypes = [vp, vp, i32, i32, C.c_float, i32, vp]
+    L.rgbd360_bilateral_filter.argtypes = [vp, vp, i32, i32, C.c_float, C.c_float, vp]
     L.rgbd360_plane_fit.argtypes = [vp, vp, vp, i32, i32, i32, C.c_float, C.c_float, C.c_float, i32, vp, vp, i32, C.POINTER(i32)]
     L.rgbd360_frame_planes.argtypes = [vp, vp, C.c_size_t, i32, i32, i32, i32, C.c_float, C.c_float, i32, C.c_float, C.c_float, C.c_float,
                                        i32, vp, vp, vp, vp, i32, C.POINTER(i32)]

@@ -939,4 +939,100 @@ __global__ void k_stitch_sphere(StitchArgs a, const uint8_t* __restrict__ rgb /*
     sphereDepth[o] = d;
 }
 
+// ---- pcl::FastBilateralFilter (bilateral grid) -----------------------------------------------------------------------
+// The smoothing Frame360 applies to every sensor cloud before the planes are segmented (Frame360.h:40, 493-499: sigma_s 10 px,
+// sigma_r 0.05 m).  Third-party algorithm (PCL filters/impl/fast_bilateral.hpp), restated in oracle/frame360_ref.cpp; the
+// kernels repeat the oracle's float operations one for one and accumulate the cell sums as integers (2^-20 m), so the filtered
+// cloud is bit-identical to the oracle's whatever the order of the atomics.  Small data (a 160 x 120 sensor cloud has a grid of
+// ~20 x 16 x 100 cells): every kernel here is latency-bound; the point of running them on the device is that the cloud stays there.
+struct BilatGrid {
+    int nx, ny, nz;
+    float sigma_s, sigma_r, base_min, base_max;
+};
+constexpr int kBilatPadXY = 2, kBilatPadZ = 2;
+constexpr double kBilatFixed = 1048576.0;
+
+__device__ __forceinline__ unsigned bilat_encode(float v) {          // order-preserving float -> unsigned
+    const unsigned u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+// mm[0] = min, mm[1] = max of the finite z (encoded); the caller presets {0xffffffff, 0}
+__global__ void k_bilat_minmax(const float* __restrict__ xyz, int n, unsigned* __restrict__ mm) {
+    unsigned lo = 0xffffffffu, hi = 0u;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float z = xyz[3 * (size_t)i + 2];
+        if (isfinite(z)) {
+            const unsigned e = bilat_encode(z);
+            lo = min(lo, e);
+            hi = max(hi, e);
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        lo = min(lo, (unsigned)__shfl_xor((int)lo, m));
+        hi = max(hi, (unsigned)__shfl_xor((int)hi, m));
+    }
+    if ((threadIdx.x & 63) == 0 && lo <= hi) {
+        atomicMin(&mm[0], lo);
+        atomicMax(&mm[1], hi);
+    }
+}
+__device__ __forceinline__ size_t bilat_idx(const BilatGrid& g, int x, int y, int z) { return (((size_t)x * g.ny) + y) * g.nz + z; }
+
+__global__ void k_bilat_scatter(const float* __restrict__ xyz, int rows, int cols, BilatGrid g, unsigned long long* __restrict__ sum,
+                                int* __restrict__ cnt) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    const int y = i / cols, x = i - y * cols;
+    float pz = xyz[3 * (size_t)i + 2];
+    if (!isfinite(pz)) pz = g.base_max;
+    const float z = pz - g.base_min;
+    const int sx = (int)((float)x / g.sigma_s + 0.5f) + kBilatPadXY, sy = (int)((float)y / g.sigma_s + 0.5f) + kBilatPadXY;
+    const int sz = (int)(z / g.sigma_r + 0.5f) + kBilatPadZ;
+    const size_t c = bilat_idx(g, sx, sy, sz);
+    atomicAdd(&sum[c], (unsigned long long)__double2ll_rn((double)pz * kBilatFixed));
+    atomicAdd(&cnt[c], 1);
+}
+// fixed point -> {sum z, count} floats in `a`; `b` (the other ping-pong array) starts at zero
+__global__ void k_bilat_init(const unsigned long long* __restrict__ sum, const int* __restrict__ cnt, size_t cells, float2* __restrict__ a,
+                             float2* __restrict__ b) {
+    const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cells) return;
+    a[c] = make_float2((float)((double)(long long)sum[c] / kBilatFixed), (float)cnt[c]);
+    b[c] = make_float2(0.f, 0.f);
+}
+// one [1 2 1] / 4 pass along one axis over the interior cells: data <- buffer (border cells of `data` keep what they held)
+__global__ void k_bilat_blur(const float2* __restrict__ buffer, float2* __restrict__ data, BilatGrid g, int off) {
+    const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t cells = (size_t)g.nx * g.ny * g.nz;
+    if (c >= cells) return;
+    const int z = (int)(c % g.nz), y = (int)((c / g.nz) % g.ny), x = (int)(c / ((size_t)g.nz * g.ny));
+    if (x < 1 || x >= g.nx - 1 || y < 1 || y >= g.ny - 1 || z < 1 || z >= g.nz - 1) return;
+    const float2 m = buffer[c - off], p = buffer[c + off], q = buffer[c];
+    data[c] = make_float2((m.x + p.x + 2.f * q.x) / 4.f, (m.y + p.y + 2.f * q.y) / 4.f);
+}
+__global__ void k_bilat_interp(float* __restrict__ xyz, int rows, int cols, BilatGrid g, const float2* __restrict__ data) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    const int y = i / cols, x = i - y * cols;
+    float pz = xyz[3 * (size_t)i + 2];
+    if (!isfinite(pz)) pz = g.base_max;
+    const float fx = (float)x / g.sigma_s + (float)kBilatPadXY, fy = (float)y / g.sigma_s + (float)kBilatPadXY;
+    const float fz = (pz - g.base_min) / g.sigma_r + (float)kBilatPadZ;
+    auto clampi = [](int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); };
+    const int x0 = clampi((int)fx, g.nx - 1), x1 = clampi(x0 + 1, g.nx - 1);
+    const int y0 = clampi((int)fy, g.ny - 1), y1 = clampi(y0 + 1, g.ny - 1);
+    const int z0 = clampi((int)fz, g.nz - 1), z1 = clampi(z0 + 1, g.nz - 1);
+    const float xa = fx - (float)x0, ya = fy - (float)y0, za = fz - (float)z0;
+    const float2 c000 = data[bilat_idx(g, x0, y0, z0)], c100 = data[bilat_idx(g, x1, y0, z0)], c010 = data[bilat_idx(g, x0, y1, z0)],
+                 c110 = data[bilat_idx(g, x1, y1, z0)], c001 = data[bilat_idx(g, x0, y0, z1)], c101 = data[bilat_idx(g, x1, y0, z1)],
+                 c011 = data[bilat_idx(g, x0, y1, z1)], c111 = data[bilat_idx(g, x1, y1, z1)];
+    const float w000 = (1.f - xa) * (1.f - ya) * (1.f - za), w100 = xa * (1.f - ya) * (1.f - za), w010 = (1.f - xa) * ya * (1.f - za),
+                w110 = xa * ya * (1.f - za), w001 = (1.f - xa) * (1.f - ya) * za, w101 = xa * (1.f - ya) * za, w011 = (1.f - xa) * ya * za,
+                w111 = xa * ya * za;
+    const float d0 = w000 * c000.x + w100 * c100.x + w010 * c010.x + w110 * c110.x + w001 * c001.x + w101 * c101.x + w011 * c011.x + w111 * c111.x;
+    const float d1 = w000 * c000.y + w100 * c100.y + w010 * c010.y + w110 * c110.y + w001 * c001.y + w101 * c101.y + w011 * c011.y + w111 * c111.y;
+    xyz[3 * (size_t)i + 2] = d0 / d1;
+}
+
 }  // namespace f360

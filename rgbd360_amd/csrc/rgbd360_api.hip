@@ -70,6 +70,11 @@ struct rgbd360_ctx {
     unsigned long long *f_count = nullptr, *f_mom = nullptr;
     int* f_count_of_slot = nullptr;
     unsigned char *f_pack = nullptr, *f_pack_host = nullptr;      // packed region records: device buffer + pinned host mirror
+    unsigned long long* b_sum = nullptr;                          // bilateral grid: fixed-point sums, counts, two float2 ping-pong arrays
+    int* b_cnt = nullptr;
+    float2 *b_a = nullptr, *b_b = nullptr;
+    unsigned* b_mm = nullptr;
+    size_t b_cells = 0;
     float* f_tab = nullptr;
     size_t f_tab_n = 0;
     int f_tab_rows = 0, f_tab_cols = 0, f_tab_conv = -1;      // what the resident angle tables were built for
@@ -492,6 +497,7 @@ void rgbd360_destroy(rgbd360_ctx* ctx) {
     hipFree(ctx->f_root_of_slot); hipFree(ctx->f_nslots); hipFree(ctx->f_window); hipFree(ctx->f_mom);
     hipFree(ctx->f_count_of_slot); hipFree(ctx->f_depth_raw); hipFree(ctx->f_pack);
     if (ctx->f_pack_host) hipHostFree(ctx->f_pack_host);
+    hipFree(ctx->b_sum); hipFree(ctx->b_cnt); hipFree(ctx->b_a); hipFree(ctx->b_b); hipFree(ctx->b_mm);
     hipFree(ctx->occ_head); hipFree(ctx->occ_next); hipFree(ctx->occ_dinv);
     if (ctx->h_state) hipHostFree(ctx->h_state);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
@@ -1266,6 +1272,62 @@ int f360_normals_dev(rgbd360_ctx* ctx, int rows, int cols, float max_depth_chang
     return 0;
 }
 
+// pcl::FastBilateralFilter on the organised cloud in ctx->f_xyz (device), z filtered in place
+int f360_bilateral_dev(rgbd360_ctx* ctx, int rows, int cols, float sigma_s, float sigma_r) {
+    using namespace f360;
+    if (!(sigma_s > 0.f) || !(sigma_r > 0.f)) return fail(ctx, -1, "sigma_s and sigma_r must be positive");
+    const int n = rows * cols;
+    if (!ctx->b_mm) HIPC(ctx, hipMalloc(&ctx->b_mm, 2 * sizeof(unsigned)));
+    HIPC(ctx, hipMemsetAsync(ctx->b_mm, 0xff, sizeof(unsigned), ctx->stream));          // min starts at the largest code,
+    HIPC(ctx, hipMemsetAsync(ctx->b_mm + 1, 0, sizeof(unsigned), ctx->stream));         // max at the smallest
+    hipLaunchKernelGGL(k_bilat_minmax, dim3(std::min(256, (n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->f_xyz, n, ctx->b_mm);
+    unsigned mm[2];
+    HIPC(ctx, hipMemcpyAsync(mm, ctx->b_mm, sizeof(mm), hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    if (mm[0] > mm[1]) return 0;                                   // no finite z: the cloud stays as it is
+    auto decode = [](unsigned e) {
+        const unsigned u = (e & 0x80000000u) ? (e & 0x7fffffffu) : ~e;
+        float v;
+        memcpy(&v, &u, sizeof(v));
+        return v;
+    };
+    BilatGrid g;
+    g.sigma_s = sigma_s; g.sigma_r = sigma_r;
+    g.base_min = decode(mm[0]); g.base_max = decode(mm[1]);
+    const float base_delta = g.base_max - g.base_min;
+    g.nx = (int)((float)(cols - 1) / sigma_s) + 1 + 2 * kBilatPadXY;
+    g.ny = (int)((float)(rows - 1) / sigma_s) + 1 + 2 * kBilatPadXY;
+    const double nz = (double)(base_delta / sigma_r) + 1 + 2 * kBilatPadZ;
+    const double cells_d = (double)g.nx * g.ny * nz;
+    if (!(cells_d < 64e6)) return fail(ctx, -1, "bilateral grid too large (depth range / sigma_r)");
+    g.nz = (int)(base_delta / sigma_r) + 1 + 2 * kBilatPadZ;
+    const size_t cells = (size_t)g.nx * g.ny * g.nz;
+    if (ctx->b_cells < cells) {
+        hipFree(ctx->b_sum); hipFree(ctx->b_cnt); hipFree(ctx->b_a); hipFree(ctx->b_b);
+        ctx->b_sum = nullptr; ctx->b_cnt = nullptr; ctx->b_a = ctx->b_b = nullptr; ctx->b_cells = 0;
+        HIPC(ctx, hipMalloc(&ctx->b_sum, cells * sizeof(unsigned long long)));
+        HIPC(ctx, hipMalloc(&ctx->b_cnt, cells * sizeof(int)));
+        HIPC(ctx, hipMalloc(&ctx->b_a, cells * sizeof(float2)));
+        HIPC(ctx, hipMalloc(&ctx->b_b, cells * sizeof(float2)));
+        ctx->b_cells = cells;
+    }
+    HIPC(ctx, hipMemsetAsync(ctx->b_sum, 0, cells * sizeof(unsigned long long), ctx->stream));
+    HIPC(ctx, hipMemsetAsync(ctx->b_cnt, 0, cells * sizeof(int), ctx->stream));
+    const dim3 gp((n + 255) / 256), gc((unsigned)((cells + 255) / 256)), b(256);
+    hipLaunchKernelGGL(k_bilat_scatter, gp, b, 0, ctx->stream, ctx->f_xyz, rows, cols, g, ctx->b_sum, ctx->b_cnt);
+    hipLaunchKernelGGL(k_bilat_init, gc, b, 0, ctx->stream, ctx->b_sum, ctx->b_cnt, cells, ctx->b_a, ctx->b_b);
+    float2 *data = ctx->b_a, *buffer = ctx->b_b;
+    const int offs[3] = {g.ny * g.nz, g.nz, 1};
+    for (int dim = 0; dim < 3; ++dim)
+        for (int it = 0; it < 2; ++it) {
+            std::swap(data, buffer);
+            hipLaunchKernelGGL(k_bilat_blur, gc, b, 0, ctx->stream, buffer, data, g, offs[dim]);
+        }
+    hipLaunchKernelGGL(k_bilat_interp, gp, b, 0, ctx->stream, ctx->f_xyz, rows, cols, g, data);
+    HIPC(ctx, hipGetLastError());
+    return 0;
+}
+
 // eigenpairs of a symmetric 3x3 in ascending order (cyclic Jacobi, float64) -- pcl::eigen33's role for the smallest one
 void sorted_eigen3(const double C[3][3], double evals[3], double evecs[3][3]) {    // evecs[k] = eigenvector of evals[k]
     double ev[3], V[3][3];
@@ -1506,6 +1568,22 @@ extern "C" int rgbd360_normals(rgbd360_ctx* ctx, const float* xyz, int rows, int
     rc = f360_normals_dev(ctx, rows, cols, max_depth_change_factor, normal_smoothing_size, depth_mode);
     if (rc) return rc;
     HIPC(ctx, hipMemcpyAsync(normals_out, ctx->f_normals, n * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+extern "C" int rgbd360_bilateral_filter(rgbd360_ctx* ctx, const float* xyz, int rows, int cols, float sigma_s, float sigma_r,
+                                       float* xyz_out) {
+    if (!ctx || !xyz || !xyz_out) return -1;
+    if (rows < 1 || cols < 1 || (long long)rows * cols >= (1ll << 30)) return fail(ctx, -1, "bad image size");
+    hipSetDevice(ctx->p.device);
+    const size_t n = (size_t)rows * cols;
+    int rc = f360_ensure(ctx, n);
+    if (rc) return rc;
+    HIPC(ctx, hipMemcpyAsync(ctx->f_xyz, xyz, n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    rc = f360_bilateral_dev(ctx, rows, cols, sigma_s, sigma_r);
+    if (rc) return rc;
+    HIPC(ctx, hipMemcpyAsync(xyz_out, ctx->f_xyz, n * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIPC(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }

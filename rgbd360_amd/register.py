@@ -415,6 +415,13 @@ class Frame360Stages:
                                                  normal_smoothing_size, depth_mode, _ptr(out)))
         return out
 
+    def bilateral_filter(self, xyz, rows, cols, sigma_s=10.0, sigma_r=0.05):
+        """rgbd360_bilateral_filter: pcl::FastBilateralFilter as Frame360.h:493-499 configures it; returns the cloud with filtered z."""
+        xyz = np.ascontiguousarray(xyz, np.float32).reshape(rows * cols, 3)
+        out = np.empty_like(xyz)
+        self._reg._check(self._L.rgbd360_bilateral_filter(self._reg._ctx(), _ptr(xyz), rows, cols, sigma_s, sigma_r, _ptr(out)))
+        return out
+
     def distance_map(self, xyz, rows, cols, max_depth_change_factor=0.05, depth_mode=1):
         xyz = np.ascontiguousarray(xyz, np.float32).reshape(rows * cols, 3)
         out = np.empty((rows, cols), np.float32)

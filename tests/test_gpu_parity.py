@@ -956,3 +956,26 @@ def test_pbmap_registration_seeds_the_dense_alignment(hip_lib, oracle_mod, trans
     rot, tr = synth.pose_error(reg.getOptimalPose(), T)
     assert rot < 2e-3 and tr < 5e-3, (rot, tr)
     assert np.allclose(reg.getOptimalPose(), guess, atol=1e-1)  # the reference's validity test of the keyframe link
+
+
+@pytest.mark.parametrize("rows,cols,sigma_s,sigma_r", [(120, 160, 10.0, 0.05), (97, 131, 7.0, 0.03), (240, 320, 10.0, 0.05)])
+def test_bilateral_filter_bit_exact(hip_lib, oracle_mod, rows, cols, sigma_s, sigma_r):
+    """pcl::FastBilateralFilter (Frame360.h:493-499) on the device against the oracle: same grid, same float operations, integer cell
+    sums -> the filtered cloud is bit-identical; an all-invalid cloud passes through."""
+    from rgbd360_amd.register import Frame360Stages
+    from tests.test_oracle_cpu import _noisy_pinhole_cloud
+    xyz, _ = _noisy_pinhole_cloud(rows, cols, seed=rows + cols)
+    st = Frame360Stages(_mk(hip_lib, 2))
+    got = st.bilateral_filter(xyz, rows, cols, sigma_s, sigma_r)
+    want = oracle_mod.fast_bilateral(xyz, rows, cols, sigma_s, sigma_r)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.array_equal(np.nan_to_num(got), np.nan_to_num(want))
+    assert np.abs(np.nan_to_num(got[:, 2]) - np.nan_to_num(xyz.reshape(-1, 3)[:, 2])).max() > 1e-3      # it did filter
+    allnan = np.full((rows, cols, 3), np.nan, np.float32)
+    assert np.isnan(st.bilateral_filter(allnan, rows, cols, sigma_s, sigma_r)).all()
+    # smoothed cloud -> normals / regions: the wall behind the box comes out as one region with the filter, in pieces without
+    nrm = st.normals(got, rows, cols, 0.02, 8.0, 0)
+    _, planes_f = st.plane_fit(got, nrm, rows, cols, 40, 0.0398, 0.02, 0.0013, 0)
+    nrm0 = st.normals(xyz, rows, cols, 0.02, 8.0, 0)
+    _, planes_0 = st.plane_fit(xyz, nrm0, rows, cols, 40, 0.0398, 0.02, 0.0013, 0)
+    assert max([p["count"] for p in planes_f], default=0) > 2 * max([p["count"] for p in planes_0], default=1)

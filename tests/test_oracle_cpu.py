@@ -504,3 +504,45 @@ def test_numpy_restatement_agrees_on_pinhole_error(oracle_mod):
                 a, b, c, d = NP.pinhole_error(fr, level, pose, K, method)
                 assert abs(c - n_p) <= max(3, 2e-3 * n_p) and abs(d - n_d) <= max(3, 2e-3 * n_d), (level, method, c, n_p, d, n_d)
                 assert abs(a - sp) <= 5e-3 * max(sp, 1.0) and abs(b - sd) <= 5e-3 * max(sd, 1.0)
+
+
+def _noisy_pinhole_cloud(rows=120, cols=160, seed=3, noise=0.01):
+    """A wall 2.5 m in front of a pinhole camera (slanted), a nearer box, holes, Gaussian depth noise."""
+    rng = np.random.default_rng(seed)
+    f, cx, cy = 131.25, cols / 2 - 0.5, rows / 2 - 0.5
+    u, v = np.meshgrid(np.arange(cols, dtype=np.float64), np.arange(rows, dtype=np.float64))
+    z_true = 2.5 + 0.4 * (u - cx) / f
+    z_true[40:70, 50:90] = 1.4                                   # a box in front of the wall: a 1 m depth step
+    z = z_true + rng.normal(size=z_true.shape) * noise
+    z[10:14, 100:130] = np.nan                                   # a hole
+    z[rng.random(z.shape) < 0.02] = np.nan
+    xyz = np.stack([(u - cx) * z / f, (v - cy) * z / f, z], -1).astype(np.float32)
+    xyz[~np.isfinite(xyz[..., 2])] = np.nan
+    return xyz, z_true
+
+
+def test_fast_bilateral_smooths_within_surfaces_and_keeps_depth_steps(oracle_mod):
+    """pcl::FastBilateralFilter restated (Frame360.h:493-499 set-up): noise on a surface shrinks several times, the 1 m step between
+    box and wall stays a step, x / y and invalid points are untouched, a noiseless fronto-parallel plane is a fixed point."""
+    xyz, z_true = _noisy_pinhole_cloud()
+    rows, cols = z_true.shape
+    out = oracle_mod.fast_bilateral(xyz, rows, cols, 10.0, 0.05).reshape(rows, cols, 3)
+    ok = np.isfinite(xyz[..., 2])
+    assert np.array_equal(np.isfinite(out[..., 0]), np.isfinite(xyz[..., 0]))            # x, y copied (NaN stays NaN)
+    assert np.array_equal(out[..., :2][ok], xyz[..., :2][ok])
+    inner = ok.copy()
+    inner[:12] = inner[-12:] = False
+    inner[:, :12] = inner[:, -12:] = False
+    inner[36:74, 46:94] = False                                                          # away from the depth step
+    e_in = (xyz[..., 2] - z_true)[inner].std()
+    e_out = (out[..., 2] - z_true)[inner].std()
+    assert e_out < 0.4 * e_in, (e_in, e_out)
+    box = np.zeros_like(ok)
+    box[44:66, 54:86] = True
+    assert abs(np.nanmedian(out[..., 2][box & ok]) - 1.4) < 0.01                         # the box did not bleed into the wall
+    flat = np.zeros((rows, cols, 3), np.float32)
+    flat[..., 2] = 2.0
+    same = oracle_mod.fast_bilateral(flat, rows, cols, 10.0, 0.05).reshape(rows, cols, 3)
+    assert np.abs(same[..., 2] - 2.0).max() < 1e-6
+    allnan = np.full((8, 9, 3), np.nan, np.float32)
+    assert np.isnan(oracle_mod.fast_bilateral(allnan, 8, 9)).all()
