@@ -66,3 +66,80 @@ def test_sample_pair_plane_registration_reports_an_unobservable_translation():
         up = [abs(float(frames[0][i]["normal"][0])) for i in r["match"]]
         assert min(up) > 0.98                                   # floor / ceiling pieces only
         assert np.array_equal(r["pose"], np.eye(4, dtype=np.float32))
+
+
+def _pinhole_cloud(depth_mm, min_depth=0.3, max_depth=10.0):
+    """CloudRGBD::getPointCloud (OpenNI2_Grabber/FrameRGBD/CloudRGBD.h:107-166): focal 525 * W / 640, centre (W/2 - 0.5, H/2 - 0.5)."""
+    H, W = depth_mm.shape
+    f = np.float32(525.0 * (W / 640.0))
+    z = (np.float32(0.001) * depth_mm.astype(np.float32)).astype(np.float32)
+    u, v = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32))
+    xyz = np.stack([(u - np.float32(W / 2 - 0.5)) * z / f, (v - np.float32(H / 2 - 0.5)) * z / f, z], -1).astype(np.float32)
+    xyz[~((z >= min_depth) & (z <= max_depth))] = np.nan
+    return xyz
+
+
+def _downsample_median(xyz, step=2, min_depth=0.3, max_depth=10.0):
+    """DownsampleRGBD::downsamplePointCloud (OpenNI2_Grabber/FrameRGBD/DownsampleRGBD.h:209-300): per coordinate, element n/2 of the
+    sorted valid values of every step x step block."""
+    H, W, _ = xyz.shape
+    b = xyz.reshape(H // step, step, W // step, step, 3).transpose(0, 2, 1, 3, 4).reshape(H // step, W // step, step * step, 3)
+    ok = np.isfinite(b[..., 0]) & (b[..., 2] > min_depth) & (b[..., 2] < max_depth)
+    n = ok.sum(-1)
+    s = np.sort(np.where(ok[..., None], b, np.inf), axis=2)
+    out = np.take_along_axis(s, np.minimum(n // 2, step * step - 1)[..., None, None].repeat(3, -1), axis=2)[:, :, 0, :]
+    out[n == 0] = np.nan
+    return out.astype(np.float32)
+
+
+@pytest.mark.skipif(not os.path.exists(SAMPLES), reason="reference samples are only present in the build container")
+def test_sample_pair_per_sensor_planes_with_the_bilateral_filter():
+    """The reference's route for the rig's planes (Frame360.h:40-41, 479-499, 949-1075): per sensor, pinhole cloud down-sampled by 2,
+    pcl::FastBilateralFilter (10 px, 0.05 m), normal map, segmentation, planes moved into the rig frame by Rt -- here with the
+    oracle's restatements and the library's matcher.  With the filter the walls of the raw sensor data appear (without it only
+    floor and ceiling do, see the test above); the matcher pairs floor, ceiling and the pieces of one wall direction of frames
+    1 and 10, and the fit reports that the translation along that wall is not observable (two independent normal directions
+    only: conditioning > 100, status 2), as ConsistencyTest's conditioning test would."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import config1_samples as c1
+    from oracle import oracle as O
+    from rgbd360_amd import pbmap
+    Rt = [np.loadtxt("/root/reference/Calibration/Extrinsics/Rt_0%d.txt" % (s + 1)) for s in range(8)]
+    frames = []
+    walls_raw = walls_filtered = 0
+    for idx in (1, 10):
+        planes_rig = []
+        for s, (_, depth) in enumerate(c1.load_frame("/root/reference/samples/sphere_images_%d.bin" % idx)):
+            cloud = _downsample_median(_pinhole_cloud(depth))
+            H, W, _ = cloud.shape
+            for filtered in (False, True):
+                xyz = O.fast_bilateral(cloud, H, W, 10.0, 0.05) if filtered else np.ascontiguousarray(cloud).reshape(-1, 3)
+                nrm, _w = O.f360_normals(xyz, H, W, 0.02, 8.0, 0)
+                planes = O.f360_plane_segment(xyz, nrm, H, W, 40, 0.0398, 0.02, 0.0013, 0, max_planes=512)[1]
+                n_walls = sum(p["count"] for p in planes if abs(p["normal"][2]) > 0.9)     # inliers of planes facing the sensor
+                if filtered:
+                    walls_filtered += n_walls
+                else:
+                    walls_raw += n_walls
+            R, t = Rt[s][:3, :3], Rt[s][:3, 3]
+            for p in planes:                                                  # (filtered planes) sensor frame -> rig frame
+                n, c = R @ p["normal"].astype(np.float64), R @ p["centroid"].astype(np.float64) + t
+                if n @ c > 0:
+                    n = -n
+                q = dict(p)
+                q.update(normal=n.astype(np.float32), centroid=c.astype(np.float32), d=np.float32(-n @ c),
+                         ppal_dir=(R @ p["ppal_dir"].astype(np.float64)).astype(np.float32))
+                planes_rig.append(q)
+        frames.append(planes_rig)
+    print("wall inliers without / with the filter:", walls_raw, walls_filtered)
+    assert walls_filtered >= 20000 and walls_filtered >= 1.5 * walls_raw, (walls_raw, walls_filtered)
+    r = pbmap.register_planes(frames[0], frames[1], 25, pbmap.ODOMETRY_6DoF, pbmap.default_params(True))
+    assert len(r["match"]) >= 12
+    matched = [frames[0][i] for i in r["match"]]
+    horizontal = [p for p in matched if abs(p["normal"][0]) > 0.95]           # x is up in the rig frame: floor / ceiling
+    walls = [p for p in matched if abs(p["normal"][0]) < 0.3]
+    assert len(horizontal) >= 6 and len(walls) >= 3
+    for i, j in r["match"].items():                                           # same planes in both frames: normals within a few degrees,
+        assert float(frames[0][i]["normal"] @ frames[1][j]["normal"]) > 0.99  # offsets within the motion between the frames
+        assert abs(float(frames[0][i]["d"]) - float(frames[1][j]["d"])) < 0.1
+    assert r["status"] == 2
