@@ -253,6 +253,16 @@ int rgbd360_frame_planes(rgbd360_ctx* ctx, const void* depth, size_t depth_step,
                          float* xyz_out, float* normals_out, int32_t* labels_out, rgbd360_plane* planes_out, int max_planes,
                          int* n_planes_out);
 
+/* Frame360::getPlanesSensor for one organised sensor cloud (host, rows*cols x 3 float32, NaN = invalid), with the smoothing
+ * that precedes it: pcl::FastBilateralFilter when sigma_s > 0 (Frame360.h:493-499: 10, 0.05), the normal map (Frame360.h:949-957:
+ * 0.02, 8; depth_mode 0 = PCL's z), the planar regions (Frame360.h:958-996: 80 inliers, 0.0398 rad, 0.02 m) -- the cloud stays on
+ * the device between the three stages -- and, when Rt (column-major 4x4, Calib360::Rt_, sensor -> rig) is not NULL, the
+ * plane.transform(Rt) of Frame360.h:1046.  Planes in PCL's order; n towards the (new) origin, n . x + d = 0. */
+int rgbd360_cloud_planes(rgbd360_ctx* ctx, const float* xyz, int rows, int cols, float sigma_s, float sigma_r,
+                         float max_depth_change_factor, float normal_smoothing_size, int min_inliers, float angular_threshold,
+                         float distance_threshold, float max_curvature, int depth_mode, const float Rt[16],
+                         rgbd360_plane* planes_out, int max_planes, int* n_planes_out);
+
 /* ---- pinhole single-sensor alignment ------------------------------------------------------ */
 
 /* RegisterPhotoICP::setCameraMatrix (RPI.h:254-257): fx, fy, ox, oy of the full-resolution sensor image; the pyramid

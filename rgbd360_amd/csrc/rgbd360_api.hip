@@ -1647,6 +1647,55 @@ static int frame_planes_impl(rgbd360_ctx* ctx, const void* depth, size_t depth_s
     return 0;
 }
 
+extern "C" int rgbd360_cloud_planes(rgbd360_ctx* ctx, const float* xyz, int rows, int cols, float sigma_s, float sigma_r,
+                                   float max_depth_change_factor, float normal_smoothing_size, int min_inliers, float angular_threshold,
+                                   float distance_threshold, float max_curvature, int depth_mode, const float Rt[16],
+                                   rgbd360_plane* planes_out, int max_planes, int* n_planes_out) {
+    if (!ctx || !xyz || !planes_out || !n_planes_out || max_planes < 1) return -1;
+    if (rows < 3 || cols < 3 || (long long)rows * cols >= (1ll << 30)) return fail(ctx, -1, "bad image size");
+    hipSetDevice(ctx->p.device);
+    const size_t n = (size_t)rows * cols;
+    int rc = f360_ensure(ctx, n);
+    if (rc) return rc;
+    HIPC(ctx, hipMemcpyAsync(ctx->f_xyz, xyz, n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    if (sigma_s > 0.f) {                                             // Frame360.h:493-499
+        rc = f360_bilateral_dev(ctx, rows, cols, sigma_s, sigma_r);
+        if (rc) return rc;
+    }
+    rc = f360_normals_dev(ctx, rows, cols, max_depth_change_factor, normal_smoothing_size, depth_mode);      // Frame360.h:949-957
+    if (rc) return rc;
+    rc = f360_planes_dev(ctx, rows, cols, min_inliers, angular_threshold, distance_threshold, max_curvature, depth_mode, planes_out,
+                         max_planes, n_planes_out);                                                         // Frame360.h:958-996
+    if (rc) return rc;
+    if (Rt) {                                                        // plane.transform(Rt), Frame360.h:1046: sensor -> rig frame
+        for (int k = 0; k < *n_planes_out; ++k) {
+            rgbd360_plane& P = planes_out[k];
+            double nn[3], cc[3], pp[3];
+            for (int i = 0; i < 3; ++i) {
+                nn[i] = cc[i] = pp[i] = 0;
+                for (int j = 0; j < 3; ++j) {
+                    nn[i] += (double)Rt[j * 4 + i] * P.normal[j];
+                    cc[i] += (double)Rt[j * 4 + i] * P.centroid[j];
+                    pp[i] += (double)Rt[j * 4 + i] * P.ppal_dir[j];
+                }
+                cc[i] += (double)Rt[12 + i];
+            }
+            double dd = -(nn[0] * cc[0] + nn[1] * cc[1] + nn[2] * cc[2]);
+            if (dd < 0) {                                            // keep the normal towards the new origin (Frame360.h:989-993)
+                for (int i = 0; i < 3; ++i) nn[i] = -nn[i];
+                dd = -dd;
+            }
+            for (int i = 0; i < 3; ++i) {
+                P.normal[i] = (float)nn[i];
+                P.centroid[i] = (float)cc[i];
+                P.ppal_dir[i] = (float)pp[i];
+            }
+            P.d = (float)dd;
+        }
+    }
+    return 0;
+}
+
 extern "C" int rgbd360_frame_planes(rgbd360_ctx* ctx, const void* depth, size_t depth_step, int depth_type, int rows, int cols,
                                     int convention, float max_depth_change_factor, float normal_smoothing_size, int min_inliers,
                                     float angular_threshold, float distance_threshold, float max_curvature, int depth_mode,

@@ -422,6 +422,21 @@ class Frame360Stages:
         self._reg._check(self._L.rgbd360_bilateral_filter(self._reg._ctx(), _ptr(xyz), rows, cols, sigma_s, sigma_r, _ptr(out)))
         return out
 
+    def cloud_planes(self, xyz, rows, cols, sigma_s=10.0, sigma_r=0.05, max_depth_change_factor=0.02, normal_smoothing_size=8.0,
+                     min_inliers=80, angular_threshold=0.0398, distance_threshold=0.02, max_curvature=0.0013, depth_mode=0, Rt=None,
+                     max_planes=512):
+        """rgbd360_cloud_planes: one sensor cloud -> (bilateral filter) -> normal map -> planar regions -> planes in the rig frame
+        (defaults = Frame360.h:493-499, 949-977, Miscellaneous.h:54).  Rt: 4x4 sensor -> rig (row-major numpy) or None."""
+        xyz = np.ascontiguousarray(xyz, np.float32).reshape(rows * cols, 3)
+        arr = (_lib.Plane * max_planes)()
+        n = C.c_int()
+        rt = None if Rt is None else np.ascontiguousarray(np.asarray(Rt, np.float32).T.reshape(16))
+        self._reg._check(self._L.rgbd360_cloud_planes(self._reg._ctx(), _ptr(xyz), rows, cols, sigma_s, sigma_r, max_depth_change_factor,
+                                                      normal_smoothing_size, min_inliers, angular_threshold, distance_threshold,
+                                                      max_curvature, depth_mode, None if rt is None else _ptr(rt),
+                                                      C.cast(arr, C.c_void_p), max_planes, C.byref(n)))
+        return _planes_to_dicts(arr, n.value)
+
     def distance_map(self, xyz, rows, cols, max_depth_change_factor=0.05, depth_mode=1):
         xyz = np.ascontiguousarray(xyz, np.float32).reshape(rows * cols, 3)
         out = np.empty((rows, cols), np.float32)

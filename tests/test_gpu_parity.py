@@ -979,3 +979,34 @@ def test_bilateral_filter_bit_exact(hip_lib, oracle_mod, rows, cols, sigma_s, si
     nrm0 = st.normals(xyz, rows, cols, 0.02, 8.0, 0)
     _, planes_0 = st.plane_fit(xyz, nrm0, rows, cols, 40, 0.0398, 0.02, 0.0013, 0)
     assert max([p["count"] for p in planes_f], default=0) > 2 * max([p["count"] for p in planes_0], default=1)
+
+
+def test_cloud_planes_chain_equals_the_stages(hip_lib, oracle_mod):
+    """rgbd360_cloud_planes (cloud uploaded once: bilateral filter -> normal map -> regions -> plane.transform(Rt)) against the
+    oracle's stages composed on the host: same regions (roots, counts), plane parameters to float32 rounding in the rig frame."""
+    from rgbd360_amd.register import Frame360Stages
+    from tests.test_oracle_cpu import _noisy_pinhole_cloud
+    rows, cols = 120, 160
+    xyz, _ = _noisy_pinhole_cloud(rows, cols, seed=9, noise=0.006)
+    Rt = synth.make_pose(synth.rodrigues(np.array([0.2, 1.0, -0.3]), 0.7), np.array([0.05, -0.02, 0.11]))
+    st = Frame360Stages(_mk(hip_lib, 2))
+    got = st.cloud_planes(xyz, rows, cols, 10.0, 0.05, 0.02, 8.0, 40, 0.0398, 0.02, 0.0013, 0, Rt)
+    filt = oracle_mod.fast_bilateral(xyz, rows, cols, 10.0, 0.05)
+    nrm, _w = oracle_mod.f360_normals(filt, rows, cols, 0.02, 8.0, 0)
+    want = oracle_mod.f360_plane_segment(filt, nrm, rows, cols, 40, 0.0398, 0.02, 0.0013, 0, max_planes=512)[1]
+    assert len(want) >= 2 and [p["root"] for p in got] == [p["root"] for p in want]
+    assert [p["count"] for p in got] == [p["count"] for p in want]
+    R, t = Rt[:3, :3], Rt[:3, 3]
+    for a, b in zip(got, want):
+        n, c = R @ b["normal"].astype(np.float64), R @ b["centroid"].astype(np.float64) + t
+        if n @ c > 0:
+            n = -n
+        assert np.allclose(a["centroid"], c, atol=2e-5) and abs(a["d"] + n @ c) < 1e-4
+        if b["curvature"] > 1e-9:
+            assert float(a["normal"] @ n) > 1 - 1e-5
+        assert abs(a["area"] - b["area"]) <= 1e-3 * max(b["area"], 0.1)
+    # without the filter and without Rt the call is the plain normal map + regions of the sensor cloud
+    plain = st.cloud_planes(xyz, rows, cols, 0.0, 0.0, 0.02, 8.0, 40, 0.0398, 0.02, 0.0013, 0, None)
+    nrm0, _w = oracle_mod.f360_normals(xyz, rows, cols, 0.02, 8.0, 0)
+    want0 = oracle_mod.f360_plane_segment(xyz, nrm0, rows, cols, 40, 0.0398, 0.02, 0.0013, 0, max_planes=512)[1]
+    assert [(p["root"], p["count"]) for p in plain] == [(p["root"], p["count"]) for p in want0]
