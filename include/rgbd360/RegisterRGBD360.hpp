@@ -44,6 +44,30 @@ inline std::vector<rgbd360_plane> segmentPlanes(RegisterPhotoICP& reg, const Ima
     return planes;
 }
 
+// Frame360::getPlanesSensor for one sensor's organised cloud (rows*cols x 3 float32, NaN = invalid; what CloudRGBD::getPointCloud
+// + DownsampleRGBD produce), smoothed by the bilateral filter of Frame360.h:493-499 first, planes moved into the rig frame by
+// Rt (Calib360::Rt_[sensor], column-major 4x4; nullptr = leave them in the sensor frame): rgbd360_cloud_planes.
+struct SensorSegmentParams {
+    float sigma_s = 10.f, sigma_r = 0.05f;                                     // Frame360.h:496-497 (sigma_s <= 0: no filter)
+    float max_depth_change_factor = 0.02f, normal_smoothing_size = 8.f;         // Frame360.h:952-953
+    int min_inliers = 80;                                                        // Frame360.h:960
+    float angular_threshold = 0.0398f, distance_threshold = 0.02f;               // Frame360.h:961-962
+    float max_curvature = 0.0013f;                                               // Miscellaneous.h:54
+    int max_planes = 512;
+};
+inline std::vector<rgbd360_plane> segmentSensorPlanes(RegisterPhotoICP& reg, const float* xyz, int rows, int cols, const float* Rt = nullptr,
+                                                      const SensorSegmentParams& sp = SensorSegmentParams()) {
+    std::vector<rgbd360_plane> planes((size_t)sp.max_planes);
+    int n = 0;
+    rgbd360_ctx* ctx = reg.context();
+    const int rc = rgbd360_cloud_planes(ctx, xyz, rows, cols, sp.sigma_s, sp.sigma_r, sp.max_depth_change_factor, sp.normal_smoothing_size,
+                                        sp.min_inliers, sp.angular_threshold, sp.distance_threshold, sp.max_curvature, /*depth_mode=*/0, Rt,
+                                        planes.data(), sp.max_planes, &n);
+    if (rc != 0) throw std::runtime_error(std::string("rgbd360_cloud_planes: ") + rgbd360_last_error(ctx));
+    planes.resize((size_t)n);
+    return planes;
+}
+
 class RegisterRGBD360 {
    public:
     enum registrationType { DEFAULT_6DoF, PLANAR_3DoF, ODOMETRY_6DoF, PLANAR_ODOMETRY_3DoF };      // RegisterRGBD360.h:258-264
