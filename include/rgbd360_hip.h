@@ -253,6 +253,16 @@ int rgbd360_frame_planes(rgbd360_ctx* ctx, const void* depth, size_t depth_step,
                          float* xyz_out, float* normals_out, int32_t* labels_out, rgbd360_plane* planes_out, int max_planes,
                          int* n_planes_out);
 
+/* One sensor's organised cloud as Frame360::buildSphereCloud_rgbd360 hands it to the plane extraction (Frame360.h:479-481):
+ * CloudRGBD::getPointCloud (OpenNI2_Grabber/FrameRGBD/CloudRGBD.h:107-166: pinhole, focal 525 * cols / 640, centre (cols/2 - 0.5,
+ * rows/2 - 0.5)) followed by DownsampleRGBD::downsamplePointCloud (DownsampleRGBD.h:209-300: per step x step block and per
+ * coordinate the element n/2 of the sorted valid values; step 1 = the plain cloud, DOWNSAMPLE_160 = 2; at most 4).  depth: uint16 mm,
+ * host, depth_step bytes per row; a pixel is valid when it has a depth and min_depth < z < max_depth (metres; DownsampleRGBD's
+ * defaults 0.3 / 10 -- the reference's CloudRGBD.h:133-150 compares metres with millimetre thresholds, which is not reproduced).
+ * xyz_out: (rows/step) * (cols/step) x 3 float32, NaN = invalid. */
+int rgbd360_sensor_cloud(rgbd360_ctx* ctx, const uint16_t* depth, size_t depth_step, int rows, int cols, int step, float min_depth,
+                         float max_depth, float* xyz_out);
+
 /* Frame360::getPlanesSensor for one organised sensor cloud (host, rows*cols x 3 float32, NaN = invalid), with the smoothing
  * that precedes it: pcl::FastBilateralFilter when sigma_s > 0 (Frame360.h:493-499: 10, 0.05), the normal map (Frame360.h:949-957:
  * 0.02, 8; depth_mode 0 = PCL's z), the planar regions (Frame360.h:958-996: 80 inliers, 0.0398 rad, 0.02 m) -- the cloud stays on

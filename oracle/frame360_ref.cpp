@@ -298,6 +298,51 @@ int oracle_f360_plane_segment(const float* xyz, const float* normals, int rows, 
 
 
 // ------------------------------------------------------------------------------------
+// One sensor's organised cloud as Frame360::buildSphereCloud_rgbd360 feeds it to the plane extraction (Frame360.h:479-481):
+// CloudRGBD::getPointCloud (OpenNI2_Grabber/FrameRGBD/CloudRGBD.h:107-166: focal 525 * W / 640, centre (W/2 - 0.5, H/2 - 0.5),
+// x = (c - ox) * z * inv_fx, y = (r - oy) * z * inv_fy, z = 0.001 * depth) followed by DownsampleRGBD::downsamplePointCloud
+// (OpenNI2_Grabber/FrameRGBD/DownsampleRGBD.h:209-300: per step x step block and per coordinate, element n/2 of the sorted
+// valid values; NaN when the block has none).  Validity = DownsampleRGBD's test min_depth < z < max_depth on a measured depth
+// (> 0); the millimetre / metre mix-up of CloudRGBD.h:133-150 (z in metres compared with thresholds scaled by 1000, which
+// no pixel passes) is not reproduced.  out: (rows / step) x (cols / step) x 3.
+void oracle_sensor_cloud(const uint16_t* depth, size_t depth_step_bytes, int rows, int cols, int step, float min_depth, float max_depth,
+                         float* out) {
+    const float res_factor_VGA = cols / 640.0;
+    const float focal_length = 525 * res_factor_VGA;
+    const float inv_fx = 1.f / focal_length, inv_fy = 1.f / focal_length;
+    const float ox = cols / 2 - 0.5, oy = rows / 2 - 0.5;
+    const int orows = rows / step, ocols = cols / step;
+    const float qnan = std::numeric_limits<float>::quiet_NaN();
+    for (int r = 0; r < orows; ++r)
+        for (int c = 0; c < ocols; ++c) {
+            float xs[16], ys[16], zs[16];
+            int n = 0;
+            for (int r2 = r * step; r2 < (r + 1) * step; ++r2)
+                for (int c2 = c * step; c2 < (c + 1) * step; ++c2) {
+                    const uint16_t d = *reinterpret_cast<const uint16_t*>(reinterpret_cast<const uint8_t*>(depth) + (size_t)r2 * depth_step_bytes + 2 * (size_t)c2);
+                    const float z = 0.001 * d;             // double product rounded to float, CloudRGBD.h:147
+                    if (d > 0 && min_depth < z && z < max_depth) {
+                        xs[n] = (c2 - ox) * z * inv_fx;
+                        ys[n] = (r2 - oy) * z * inv_fy;
+                        zs[n] = z;
+                        ++n;
+                    }
+                }
+            float* o = out + 3 * ((size_t)r * ocols + c);
+            if (n == 0) {
+                o[0] = o[1] = o[2] = qnan;
+                continue;
+            }
+            std::sort(xs, xs + n);
+            std::sort(ys, ys + n);
+            std::sort(zs, zs + n);
+            o[0] = xs[n / 2];
+            o[1] = ys[n / 2];
+            o[2] = zs[n / 2];
+        }
+}
+
+// ------------------------------------------------------------------------------------
 // pcl::FastBilateralFilter<PointXYZRGBA>::applyFilter with setSigmaS(sigma_s) / setSigmaR(sigma_r), the smoothing Frame360
 // applies to every sensor cloud before the planes are segmented (Frame360.h:40, 493-499: sigma_s 10 px, sigma_r 0.05 m).
 // THIRD-PARTY (PCL >= 1.7 filters/impl/fast_bilateral.hpp, not in the reference tree, unpinned): restated from the published

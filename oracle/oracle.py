@@ -361,6 +361,18 @@ def f360_plane_segment(xyz, normals, rows, cols, min_inliers=40, angular_thresho
     return labels.reshape(rows, cols), planes
 
 
+def sensor_cloud(depth_mm, step=2, min_depth=0.3, max_depth=10.0):
+    """CloudRGBD::getPointCloud + DownsampleRGBD::downsamplePointCloud restated (oracle/frame360_ref.cpp); depth uint16 mm."""
+    d = np.ascontiguousarray(depth_mm, np.uint16)
+    rows, cols = d.shape
+    out = np.empty((rows // step) * (cols // step) * 3, np.float32)
+    f = lib().oracle_sensor_cloud
+    f.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]
+    f.restype = None
+    f(_ptr(d), d.strides[0], rows, cols, step, min_depth, max_depth, _ptr(out))
+    return out.reshape(rows // step, cols // step, 3)
+
+
 def fast_bilateral(xyz, rows, cols, sigma_s=10.0, sigma_r=0.05):
     """pcl::FastBilateralFilter restated (oracle/frame360_ref.cpp): organised cloud in, cloud with filtered z out."""
     xyz = np.ascontiguousarray(xyz, np.float32).reshape(rows * cols, 3)

@@ -1035,4 +1035,52 @@ __global__ void k_bilat_interp(float* __restrict__ xyz, int rows, int cols, Bila
     xyz[3 * (size_t)i + 2] = d0 / d1;
 }
 
+// ---- one sensor's organised cloud: CloudRGBD::getPointCloud + DownsampleRGBD::downsamplePointCloud ----------------------------
+// (OpenNI2_Grabber/FrameRGBD/CloudRGBD.h:107-166, DownsampleRGBD.h:209-300; restated in oracle/frame360_ref.cpp, whose float
+// operations this kernel repeats: the cloud is bit-identical).  One thread per output point: the step x step block of depths, the
+// pinhole back-projection of its valid pixels, per coordinate the element n/2 of the sorted values.
+struct SensorCloudArgs {
+    int rows, cols, step;
+    float inv_fx, inv_fy, ox, oy, min_depth, max_depth;
+};
+__device__ __forceinline__ float sorted_pick(float* v, int n, int k) {      // k-th smallest of v[0..n), n <= 16 (insertion sort)
+    for (int i = 1; i < n; ++i) {
+        const float x = v[i];
+        int j = i - 1;
+        while (j >= 0 && v[j] > x) {
+            v[j + 1] = v[j];
+            --j;
+        }
+        v[j + 1] = x;
+    }
+    return v[k];
+}
+__global__ void k_sensor_cloud(const uint8_t* __restrict__ depth, size_t depth_step, SensorCloudArgs a, float* __restrict__ out) {
+    const int orows = a.rows / a.step, ocols = a.cols / a.step;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= orows * ocols) return;
+    const int r = i / ocols, c = i - r * ocols;
+    float xs[16], ys[16], zs[16];
+    int n = 0;
+    for (int r2 = r * a.step; r2 < (r + 1) * a.step; ++r2)
+        for (int c2 = c * a.step; c2 < (c + 1) * a.step; ++c2) {
+            const unsigned short d = *reinterpret_cast<const unsigned short*>(depth + (size_t)r2 * depth_step + 2 * (size_t)c2);
+            const float z = (float)(0.001 * (double)d);      // double product rounded to float, CloudRGBD.h:147
+            if (d > 0 && a.min_depth < z && z < a.max_depth) {
+                xs[n] = (c2 - a.ox) * z * a.inv_fx;
+                ys[n] = (r2 - a.oy) * z * a.inv_fy;
+                zs[n] = z;
+                ++n;
+            }
+        }
+    float* o = out + 3 * (size_t)i;
+    if (n == 0) {
+        o[0] = o[1] = o[2] = __builtin_nanf("");
+        return;
+    }
+    o[0] = sorted_pick(xs, n, n / 2);
+    o[1] = sorted_pick(ys, n, n / 2);
+    o[2] = sorted_pick(zs, n, n / 2);
+}
+
 }  // namespace f360

@@ -1647,6 +1647,32 @@ static int frame_planes_impl(rgbd360_ctx* ctx, const void* depth, size_t depth_s
     return 0;
 }
 
+extern "C" int rgbd360_sensor_cloud(rgbd360_ctx* ctx, const uint16_t* depth, size_t depth_step, int rows, int cols, int step, float min_depth,
+                                   float max_depth, float* xyz_out) {
+    if (!ctx || !depth || !xyz_out) return -1;
+    if (rows < 1 || cols < 1 || step < 1 || step > 4 || rows / step < 1 || cols / step < 1 || depth_step < (size_t)cols * 2 ||
+        (long long)rows * cols >= (1ll << 30))
+        return fail(ctx, -1, "bad arguments");
+    hipSetDevice(ctx->p.device);
+    const size_t n = (size_t)rows * cols;
+    int rc = f360_ensure(ctx, n);
+    if (rc) return rc;
+    HIPC(ctx, hipMemcpy2DAsync(ctx->f_depth_raw, (size_t)cols * 2, depth, depth_step, (size_t)cols * 2, rows, hipMemcpyHostToDevice, ctx->stream));
+    f360::SensorCloudArgs a;
+    a.rows = rows; a.cols = cols; a.step = step;
+    const float res_factor_VGA = cols / 640.0;                       // CloudRGBD.h:118-123
+    const float focal_length = 525 * res_factor_VGA;
+    a.inv_fx = 1.f / focal_length; a.inv_fy = 1.f / focal_length;
+    a.ox = cols / 2 - 0.5; a.oy = rows / 2 - 0.5;
+    a.min_depth = min_depth; a.max_depth = max_depth;
+    const int on = (rows / step) * (cols / step);
+    hipLaunchKernelGGL(f360::k_sensor_cloud, dim3((on + 255) / 256), dim3(256), 0, ctx->stream, ctx->f_depth_raw, (size_t)cols * 2, a, ctx->f_xyz);
+    HIPC(ctx, hipGetLastError());
+    HIPC(ctx, hipMemcpyAsync(xyz_out, ctx->f_xyz, (size_t)on * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 extern "C" int rgbd360_cloud_planes(rgbd360_ctx* ctx, const float* xyz, int rows, int cols, float sigma_s, float sigma_r,
                                    float max_depth_change_factor, float normal_smoothing_size, int min_inliers, float angular_threshold,
                                    float distance_threshold, float max_curvature, int depth_mode, const float Rt[16],

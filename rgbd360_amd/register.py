@@ -422,6 +422,16 @@ class Frame360Stages:
         self._reg._check(self._L.rgbd360_bilateral_filter(self._reg._ctx(), _ptr(xyz), rows, cols, sigma_s, sigma_r, _ptr(out)))
         return out
 
+    def sensor_cloud(self, depth_mm, step=2, min_depth=0.3, max_depth=10.0):
+        """rgbd360_sensor_cloud: CloudRGBD::getPointCloud + DownsampleRGBD::downsamplePointCloud of one sensor's uint16 mm depth image."""
+        d = np.asarray(depth_mm)
+        if d.dtype != np.uint16 or d.strides[1] != 2:
+            d = np.ascontiguousarray(d, np.uint16)
+        rows, cols = d.shape
+        out = np.empty(((rows // step) * (cols // step), 3), np.float32)
+        self._reg._check(self._L.rgbd360_sensor_cloud(self._reg._ctx(), _ptr(d), d.strides[0], rows, cols, step, min_depth, max_depth, _ptr(out)))
+        return out.reshape(rows // step, cols // step, 3)
+
     def cloud_planes(self, xyz, rows, cols, sigma_s=10.0, sigma_r=0.05, max_depth_change_factor=0.02, normal_smoothing_size=8.0,
                      min_inliers=80, angular_threshold=0.0398, distance_threshold=0.02, max_curvature=0.0013, depth_mode=0, Rt=None,
                      max_planes=512):

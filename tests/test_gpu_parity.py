@@ -1010,3 +1010,22 @@ def test_cloud_planes_chain_equals_the_stages(hip_lib, oracle_mod):
     nrm0, _w = oracle_mod.f360_normals(xyz, rows, cols, 0.02, 8.0, 0)
     want0 = oracle_mod.f360_plane_segment(xyz, nrm0, rows, cols, 40, 0.0398, 0.02, 0.0013, 0, max_planes=512)[1]
     assert [(p["root"], p["count"]) for p in plain] == [(p["root"], p["count"]) for p in want0]
+
+
+@pytest.mark.parametrize("rows,cols,step", [(240, 320, 2), (240, 320, 1), (121, 163, 2), (96, 128, 4)])
+def test_sensor_cloud_bit_exact(hip_lib, oracle_mod, rows, cols, step):
+    """CloudRGBD::getPointCloud + DownsampleRGBD::downsamplePointCloud on the device against the oracle (bit-exact), including
+    blocks without a valid depth, depths outside (min, max), odd sizes (the last row / column of an odd image is dropped like
+    the reference's integer division does) and a strided depth image."""
+    from rgbd360_amd.register import Frame360Stages
+    rng = np.random.default_rng(rows * 7 + cols + step)
+    big = rng.uniform(200, 11000, (rows, cols + 5)).astype(np.uint16)
+    big[rng.random(big.shape) < 0.25] = 0
+    big[10:14, 20:40] = 0                                            # whole blocks without depth
+    d = big[:, 2:2 + cols]                                           # row stride != 2 * cols
+    st = Frame360Stages(_mk(hip_lib, 2))
+    got = st.sensor_cloud(d, step, 0.3, 10.0)
+    want = oracle_mod.sensor_cloud(np.ascontiguousarray(d), step, 0.3, 10.0)
+    assert got.shape == (rows // step, cols // step, 3)
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and np.isnan(want).any() and np.isfinite(want).any()
+    assert np.array_equal(np.nan_to_num(got), np.nan_to_num(want))
