@@ -1021,7 +1021,7 @@ def test_sensor_cloud_bit_exact(hip_lib, oracle_mod, rows, cols, step):
     rng = np.random.default_rng(rows * 7 + cols + step)
     big = rng.uniform(200, 11000, (rows, cols + 5)).astype(np.uint16)
     big[rng.random(big.shape) < 0.25] = 0
-    big[10:14, 20:40] = 0                                            # whole blocks without depth
+    big[8:16, 16:48] = 0                                             # whole blocks without depth (for every step)
     d = big[:, 2:2 + cols]                                           # row stride != 2 * cols
     st = Frame360Stages(_mk(hip_lib, 2))
     got = st.sensor_cloud(d, step, 0.3, 10.0)
