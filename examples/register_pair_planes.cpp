@@ -1,0 +1,68 @@
+// register_pair_planes.cpp -- the plane side of Registration/RegisterPairRGBD360.cpp:60-110 of the reference on its own file
+// formats: two `sphere_images_%d.bin` frames (Frame360::loadFrame) and the rig extrinsics `Rt_0N.txt` (Calib360::loadExtrinsicCalibration,
+// Calib360.h:122-131: plain 4x4 text) -> per sensor: pinhole cloud down-sampled by 2 (Frame360.h:479-481), bilateral filter
+// (Frame360.h:493-499), normal map + planar regions (Frame360.h:949-996), planes moved into the rig frame (Frame360.h:1046)
+// -> RegisterRGBD360::RegisterPbMap(frame1, frame2, 25, PLANAR_3DoF) (RegisterPairRGBD360.cpp:101).
+// Everything per-pixel runs on the GPU through the C ABI; the matcher and the pose fit are host code inside the library.
+//   usage: register_pair_planes <frame1.bin> <frame2.bin> <extrinsics_dir> [regist_mode 0..3 = 1]
+//   e.g.   register_pair_planes samples/sphere_images_1.bin samples/sphere_images_10.bin Calibration/Extrinsics
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "rgbd360/RegisterRGBD360.hpp"
+
+static bool load_rt(const std::string& dir, int sensor, float Rt_colmajor[16]) {
+    char name[1024];
+    std::snprintf(name, sizeof(name), "%s/Rt_0%d.txt", dir.c_str(), sensor + 1);
+    FILE* f = std::fopen(name, "r");
+    if (!f) return false;
+    bool ok = true;
+    for (int r = 0; r < 4 && ok; ++r)
+        for (int c = 0; c < 4 && ok; ++c) ok = std::fscanf(f, "%f", &Rt_colmajor[c * 4 + r]) == 1;
+    std::fclose(f);
+    return ok;
+}
+
+static bool frame_planes(rgbd360::RegisterPhotoICP& reg, const char* path, const std::string& extr, std::vector<rgbd360_plane>& planes) {
+    int rows = 0, cols = 0;
+    if (rgbd360_load_frame_bin(path, nullptr, nullptr, &rows, &cols) != 0) return false;
+    std::vector<uint8_t> rgb((size_t)8 * rows * cols * 3);
+    std::vector<uint16_t> depth((size_t)8 * rows * cols);
+    if (rgbd360_load_frame_bin(path, rgb.data(), depth.data(), &rows, &cols) != 0) return false;
+    const int step = 2;                                                      // DOWNSAMPLE_160, Frame360.h:41
+    std::vector<float> cloud((size_t)(rows / step) * (cols / step) * 3);
+    rgbd360::SensorSegmentParams sp;
+    sp.min_inliers = 40;                                                      // Frame360.h:960 is for the full 320 x 240 cloud: a quarter of the points
+    for (int s = 0; s < 8; ++s) {
+        float Rt[16];
+        if (!load_rt(extr, s, Rt)) return false;
+        if (rgbd360_sensor_cloud(reg.context(), depth.data() + (size_t)s * rows * cols, (size_t)cols * 2, rows, cols, step, 0.3f, 10.f,
+                                 cloud.data()) != 0)
+            return false;
+        const std::vector<rgbd360_plane> ps = rgbd360::segmentSensorPlanes(reg, cloud.data(), rows / step, cols / step, Rt, sp);
+        planes.insert(planes.end(), ps.begin(), ps.end());
+    }
+    return true;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 4) {
+        std::fprintf(stderr, "usage: %s frame1.bin frame2.bin extrinsics_dir [regist_mode]\n", argv[0]);
+        return 2;
+    }
+    const int mode = argc > 4 ? std::atoi(argv[4]) : 1;
+    rgbd360::RegisterPhotoICP reg;
+    std::vector<rgbd360_plane> p1, p2;
+    if (!frame_planes(reg, argv[1], argv[3], p1) || !frame_planes(reg, argv[2], argv[3], p2)) return 3;
+    std::printf("planes %zu %zu\n", p1.size(), p2.size());
+    rgbd360::RegisterRGBD360 registerer(/*odometry_config=*/false);
+    rgbd360::PlaneList f1{p1.data(), (int)p1.size()}, f2{p2.data(), (int)p2.size()};
+    const bool good = registerer.RegisterPbMap(&f1, &f2, 25, (rgbd360::RegisterRGBD360::registrationType)mode);
+    std::printf("status %d good %d matched %zu area_matched %.3f\n", registerer.status(), good ? 1 : 0, registerer.getMatchedPlanes().size(),
+                registerer.getAreaMatched());
+    const rgbd360::Mat4f T = registerer.getPose();
+    for (int r = 0; r < 4; ++r) std::printf("%.6f %.6f %.6f %.6f\n", T(r, 0), T(r, 1), T(r, 2), T(r, 3));
+    return 0;
+}
