@@ -28,6 +28,5 @@ for rows, cols in ((120, 160), (240, 320), (480, 640), (1024, 2048)):
     for _ in range(20):
         got = st.bilateral_filter(xyz, rows, cols)
     t_dev = (time.perf_counter() - t0) / 20
-    ok = np.isfinite(xyz[..., 2].reshape(-1))
-    print("%4d x %4d: device call %.3f ms (host cloud in / out); noise std %.4f -> %.4f m" % (
-        rows, cols, t_dev * 1e3, np.nanstd(xyz[..., 2].reshape(-1)[ok] - 2.5), np.nanstd(got[ok, 2] - 2.5)))
+    changed = np.nanmax(np.abs(got[:, 2] - xyz[..., 2].reshape(-1)))
+    print("%4d x %4d: device call %.3f ms (host cloud in / out); largest change of a depth %.3f m" % (rows, cols, t_dev * 1e3, changed))
