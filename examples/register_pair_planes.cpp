@@ -32,17 +32,18 @@ static bool frame_planes(rgbd360::RegisterPhotoICP& reg, const char* path, const
     std::vector<uint16_t> depth((size_t)8 * rows * cols);
     if (rgbd360_load_frame_bin(path, rgb.data(), depth.data(), &rows, &cols) != 0) return false;
     const int step = 2;                                                      // DOWNSAMPLE_160, Frame360.h:41
-    std::vector<float> cloud((size_t)(rows / step) * (cols / step) * 3);
     rgbd360::SensorSegmentParams sp;
     sp.min_inliers = 40;                                                      // Frame360.h:960 is for the full 320 x 240 cloud: a quarter of the points
+    std::vector<rgbd360_plane> ps((size_t)sp.max_planes);
     for (int s = 0; s < 8; ++s) {
         float Rt[16];
         if (!load_rt(extr, s, Rt)) return false;
-        if (rgbd360_sensor_cloud(reg.context(), depth.data() + (size_t)s * rows * cols, (size_t)cols * 2, rows, cols, step, 0.3f, 10.f,
-                                 cloud.data()) != 0)
+        int n = 0;                                                            // depth image in, planes in the rig frame out: one call per sensor
+        if (rgbd360_sensor_planes(reg.context(), depth.data() + (size_t)s * rows * cols, (size_t)cols * 2, rows, cols, step, 0.3f, 10.f,
+                                  sp.sigma_s, sp.sigma_r, sp.max_depth_change_factor, sp.normal_smoothing_size, sp.min_inliers,
+                                  sp.angular_threshold, sp.distance_threshold, sp.max_curvature, Rt, ps.data(), sp.max_planes, &n) != 0)
             return false;
-        const std::vector<rgbd360_plane> ps = rgbd360::segmentSensorPlanes(reg, cloud.data(), rows / step, cols / step, Rt, sp);
-        planes.insert(planes.end(), ps.begin(), ps.end());
+        planes.insert(planes.end(), ps.begin(), ps.begin() + n);
     }
     return true;
 }

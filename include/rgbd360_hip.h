@@ -273,6 +273,13 @@ int rgbd360_cloud_planes(rgbd360_ctx* ctx, const float* xyz, int rows, int cols,
                          float distance_threshold, float max_curvature, int depth_mode, const float Rt[16],
                          rgbd360_plane* planes_out, int max_planes, int* n_planes_out);
 
+/* rgbd360_sensor_cloud + rgbd360_cloud_planes (depth_mode 0) as one call: the depth image is uploaded once and the cloud never
+ * leaves the device -- one sensor of Frame360::buildSphereCloud_rgbd360 + getPlanesSensor (Frame360.h:479-499, 949-996, 1046). */
+int rgbd360_sensor_planes(rgbd360_ctx* ctx, const uint16_t* depth, size_t depth_step, int rows, int cols, int step, float min_depth,
+                          float max_depth, float sigma_s, float sigma_r, float max_depth_change_factor, float normal_smoothing_size,
+                          int min_inliers, float angular_threshold, float distance_threshold, float max_curvature, const float Rt[16],
+                          rgbd360_plane* planes_out, int max_planes, int* n_planes_out);
+
 /* ---- pinhole single-sensor alignment ------------------------------------------------------ */
 
 /* RegisterPhotoICP::setCameraMatrix (RPI.h:254-257): fx, fy, ox, oy of the full-resolution sensor image; the pyramid

@@ -1647,9 +1647,9 @@ static int frame_planes_impl(rgbd360_ctx* ctx, const void* depth, size_t depth_s
     return 0;
 }
 
-extern "C" int rgbd360_sensor_cloud(rgbd360_ctx* ctx, const uint16_t* depth, size_t depth_step, int rows, int cols, int step, float min_depth,
-                                   float max_depth, float* xyz_out) {
-    if (!ctx || !depth || !xyz_out) return -1;
+// one sensor's cloud (pinhole + median down-sampling) from a host depth image into ctx->f_xyz (device)
+static int sensor_cloud_upload(rgbd360_ctx* ctx, const uint16_t* depth, size_t depth_step, int rows, int cols, int step, float min_depth,
+                               float max_depth) {
     if (rows < 1 || cols < 1 || step < 1 || step > 4 || rows / step < 1 || cols / step < 1 || depth_step < (size_t)cols * 2 ||
         (long long)rows * cols >= (1ll << 30))
         return fail(ctx, -1, "bad arguments");
@@ -1668,22 +1668,26 @@ extern "C" int rgbd360_sensor_cloud(rgbd360_ctx* ctx, const uint16_t* depth, siz
     const int on = (rows / step) * (cols / step);
     hipLaunchKernelGGL(f360::k_sensor_cloud, dim3((on + 255) / 256), dim3(256), 0, ctx->stream, ctx->f_depth_raw, (size_t)cols * 2, a, ctx->f_xyz);
     HIPC(ctx, hipGetLastError());
-    HIPC(ctx, hipMemcpyAsync(xyz_out, ctx->f_xyz, (size_t)on * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    return 0;
+}
+
+extern "C" int rgbd360_sensor_cloud(rgbd360_ctx* ctx, const uint16_t* depth, size_t depth_step, int rows, int cols, int step, float min_depth,
+                                   float max_depth, float* xyz_out) {
+    if (!ctx || !depth || !xyz_out) return -1;
+    const int rc = sensor_cloud_upload(ctx, depth, depth_step, rows, cols, step, min_depth, max_depth);
+    if (rc) return rc;
+    const size_t on = (size_t)(rows / step) * (cols / step);
+    HIPC(ctx, hipMemcpyAsync(xyz_out, ctx->f_xyz, on * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIPC(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
 
-extern "C" int rgbd360_cloud_planes(rgbd360_ctx* ctx, const float* xyz, int rows, int cols, float sigma_s, float sigma_r,
-                                   float max_depth_change_factor, float normal_smoothing_size, int min_inliers, float angular_threshold,
-                                   float distance_threshold, float max_curvature, int depth_mode, const float Rt[16],
-                                   rgbd360_plane* planes_out, int max_planes, int* n_planes_out) {
-    if (!ctx || !xyz || !planes_out || !n_planes_out || max_planes < 1) return -1;
-    if (rows < 3 || cols < 3 || (long long)rows * cols >= (1ll << 30)) return fail(ctx, -1, "bad image size");
-    hipSetDevice(ctx->p.device);
-    const size_t n = (size_t)rows * cols;
-    int rc = f360_ensure(ctx, n);
-    if (rc) return rc;
-    HIPC(ctx, hipMemcpyAsync(ctx->f_xyz, xyz, n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+// the cloud in ctx->f_xyz -> (filter) -> normal map -> regions -> planes, moved by Rt
+static int cloud_planes_tail(rgbd360_ctx* ctx, int rows, int cols, float sigma_s, float sigma_r, float max_depth_change_factor,
+                             float normal_smoothing_size, int min_inliers, float angular_threshold, float distance_threshold,
+                             float max_curvature, int depth_mode, const float Rt[16], rgbd360_plane* planes_out, int max_planes,
+                             int* n_planes_out) {
+    int rc = 0;
     if (sigma_s > 0.f) {                                             // Frame360.h:493-499
         rc = f360_bilateral_dev(ctx, rows, cols, sigma_s, sigma_r);
         if (rc) return rc;
@@ -1720,6 +1724,33 @@ extern "C" int rgbd360_cloud_planes(rgbd360_ctx* ctx, const float* xyz, int rows
         }
     }
     return 0;
+}
+
+extern "C" int rgbd360_sensor_planes(rgbd360_ctx* ctx, const uint16_t* depth, size_t depth_step, int rows, int cols, int step, float min_depth,
+                                    float max_depth, float sigma_s, float sigma_r, float max_depth_change_factor,
+                                    float normal_smoothing_size, int min_inliers, float angular_threshold, float distance_threshold,
+                                    float max_curvature, const float Rt[16], rgbd360_plane* planes_out, int max_planes, int* n_planes_out) {
+    if (!ctx || !depth || !planes_out || !n_planes_out || max_planes < 1) return -1;
+    if (step < 1 || rows / step < 3 || cols / step < 3) return fail(ctx, -1, "bad image size");
+    const int rc = sensor_cloud_upload(ctx, depth, depth_step, rows, cols, step, min_depth, max_depth);
+    if (rc) return rc;
+    return cloud_planes_tail(ctx, rows / step, cols / step, sigma_s, sigma_r, max_depth_change_factor, normal_smoothing_size, min_inliers,
+                             angular_threshold, distance_threshold, max_curvature, /*depth_mode=*/0, Rt, planes_out, max_planes, n_planes_out);
+}
+
+extern "C" int rgbd360_cloud_planes(rgbd360_ctx* ctx, const float* xyz, int rows, int cols, float sigma_s, float sigma_r,
+                                   float max_depth_change_factor, float normal_smoothing_size, int min_inliers, float angular_threshold,
+                                   float distance_threshold, float max_curvature, int depth_mode, const float Rt[16],
+                                   rgbd360_plane* planes_out, int max_planes, int* n_planes_out) {
+    if (!ctx || !xyz || !planes_out || !n_planes_out || max_planes < 1) return -1;
+    if (rows < 3 || cols < 3 || (long long)rows * cols >= (1ll << 30)) return fail(ctx, -1, "bad image size");
+    hipSetDevice(ctx->p.device);
+    const size_t n = (size_t)rows * cols;
+    const int rc = f360_ensure(ctx, n);
+    if (rc) return rc;
+    HIPC(ctx, hipMemcpyAsync(ctx->f_xyz, xyz, n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    return cloud_planes_tail(ctx, rows, cols, sigma_s, sigma_r, max_depth_change_factor, normal_smoothing_size, min_inliers, angular_threshold,
+                             distance_threshold, max_curvature, depth_mode, Rt, planes_out, max_planes, n_planes_out);
 }
 
 extern "C" int rgbd360_frame_planes(rgbd360_ctx* ctx, const void* depth, size_t depth_step, int depth_type, int rows, int cols,

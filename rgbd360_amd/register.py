@@ -432,6 +432,23 @@ class Frame360Stages:
         self._reg._check(self._L.rgbd360_sensor_cloud(self._reg._ctx(), _ptr(d), d.strides[0], rows, cols, step, min_depth, max_depth, _ptr(out)))
         return out.reshape(rows // step, cols // step, 3)
 
+    def sensor_planes(self, depth_mm, step=2, min_depth=0.3, max_depth=10.0, sigma_s=10.0, sigma_r=0.05, max_depth_change_factor=0.02,
+                      normal_smoothing_size=8.0, min_inliers=80, angular_threshold=0.0398, distance_threshold=0.02, max_curvature=0.0013,
+                      Rt=None, max_planes=512):
+        """rgbd360_sensor_planes: sensor_cloud + cloud_planes in one call (the cloud never leaves the device)."""
+        d = np.asarray(depth_mm)
+        if d.dtype != np.uint16 or d.strides[1] != 2:
+            d = np.ascontiguousarray(d, np.uint16)
+        rows, cols = d.shape
+        arr = (_lib.Plane * max_planes)()
+        n = C.c_int()
+        rt = None if Rt is None else np.ascontiguousarray(np.asarray(Rt, np.float32).T.reshape(16))
+        self._reg._check(self._L.rgbd360_sensor_planes(self._reg._ctx(), _ptr(d), d.strides[0], rows, cols, step, min_depth, max_depth, sigma_s,
+                                                       sigma_r, max_depth_change_factor, normal_smoothing_size, min_inliers, angular_threshold,
+                                                       distance_threshold, max_curvature, None if rt is None else _ptr(rt),
+                                                       C.cast(arr, C.c_void_p), max_planes, C.byref(n)))
+        return _planes_to_dicts(arr, n.value)
+
     def cloud_planes(self, xyz, rows, cols, sigma_s=10.0, sigma_r=0.05, max_depth_change_factor=0.02, normal_smoothing_size=8.0,
                      min_inliers=80, angular_threshold=0.0398, distance_threshold=0.02, max_curvature=0.0013, depth_mode=0, Rt=None,
                      max_planes=512):

@@ -1029,3 +1029,18 @@ def test_sensor_cloud_bit_exact(hip_lib, oracle_mod, rows, cols, step):
     assert got.shape == (rows // step, cols // step, 3)
     assert np.array_equal(np.isnan(got), np.isnan(want)) and np.isnan(want).any() and np.isfinite(want).any()
     assert np.array_equal(np.nan_to_num(got), np.nan_to_num(want))
+
+
+def test_sensor_planes_equals_the_two_calls(hip_lib):
+    """rgbd360_sensor_planes (depth image in, planes out, the cloud never leaves the device) = rgbd360_sensor_cloud + rgbd360_cloud_planes."""
+    from rgbd360_amd.register import Frame360Stages
+    (_, dA), _, _, _ = synth.make_pinhole_pair(320, 240, seed=3)
+    Rt = synth.make_pose(synth.rodrigues(np.array([1.0, 0.2, 0.1]), 0.5), np.array([0.1, 0.2, -0.05]))
+    st = Frame360Stages(_mk(hip_lib, 2))
+    cloud = st.sensor_cloud(dA, 2, 0.3, 10.0)
+    two = st.cloud_planes(cloud, 120, 160, 10.0, 0.05, 0.02, 8.0, 40, 0.0398, 0.02, 0.0013, 0, Rt)
+    one = st.sensor_planes(dA, 2, 0.3, 10.0, 10.0, 0.05, 0.02, 8.0, 40, 0.0398, 0.02, 0.0013, Rt)
+    assert len(one) == len(two) >= 2
+    for a, b in zip(one, two):
+        assert (a["root"], a["count"]) == (b["root"], b["count"])
+        assert np.array_equal(a["normal"], b["normal"]) and np.array_equal(a["centroid"], b["centroid"]) and a["d"] == b["d"]

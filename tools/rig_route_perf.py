@@ -34,7 +34,19 @@ def frame_planes(depths, timing=None):
     return planes
 
 
+def frame_planes_fused(depths):
+    planes = []
+    for s in range(8):
+        planes += st.sensor_planes(depths[s], 2, 0.3, 10.0, 10.0, 0.05, 0.02, 8.0, 40, 0.0398, 0.02, 0.0013, T_rig_sensor[s])
+    return planes
+
+
 p1, p2 = frame_planes(frames[0]), frame_planes(frames[1])
+assert [(p["root"], p["count"]) for p in frame_planes_fused(frames[0])] == [(p["root"], p["count"]) for p in p1]
+t0 = time.perf_counter()
+for _ in range(10):
+    frame_planes_fused(frames[0])
+print("fused rgbd360_sensor_planes, 8 sensors: %.2f ms per frame" % ((time.perf_counter() - t0) / 10 * 1e3))
 n = 10
 tm = [0.0, 0.0]
 t0 = time.perf_counter()
