@@ -174,7 +174,10 @@ constexpr int kNT_XW = kNT_EW + 2, kNT_XH = kNT_EH + 2;                         
 constexpr int kNT_SW = kNT_EW + 3, kNT_SH = kNT_EH + 1;                                // table: zero column / row in front; odd pitch 47
                                                                                        // (row scans: lane stride 47 doubles = all banks)
 constexpr int kNT_SPLANE = kNT_SW * kNT_SH;                                            // 47 x 29 entries per plane
-constexpr int kNT_THREADS = 512;                                                         // 8 waves per tile: every phase is a chain of LDS round trips,
+#ifndef RGBD360_NT_THREADS
+#define RGBD360_NT_THREADS 1024
+#endif
+constexpr int kNT_THREADS = RGBD360_NT_THREADS;                                                         // 16 waves per tile (52 VGPRs: two tiles = 32 waves fit a CU): every phase is a chain of LDS round trips; 512 -> 1024 threads: 71.9 -> 69.5 us, 276 -> 266 us at 4096 x 2048 (same-box A/B);
                                                                                        // 256 threads (2 x 4 waves per CU) left them exposed: 87 -> 72 us
 constexpr int kNT_BX = 11, kNT_BY = 14;                                                // scan batch lengths
 static_assert(kNT_EW % kNT_BX == 0 && kNT_EH % kNT_BY == 0, "scan batches");
@@ -263,14 +266,14 @@ __global__ __launch_bounds__(kNT_THREADS) void k_f360_normals_tiled(const float*
     // this thread's output pixels: their point and distance-map value are fetched now, so that the global round trip runs
     // under the scans
     const int tx = tid % kNT_W, ty = tid / kNT_W;
-    constexpr int kRowsPerThread = kNT_H / (kNT_THREADS / kNT_W);
+    constexpr int kRowsPerThread = (kNT_H * kNT_W + kNT_THREADS - 1) / kNT_THREADS;      // rows ty, ty + kNT_THREADS / kNT_W, ... below kNT_H
     float ppx[kRowsPerThread], ppy[kRowsPerThread], ppz[kRowsPerThread], pdist[kRowsPerThread];
 #pragma unroll
     for (int q = 0; q < kRowsPerThread; ++q) {
         const int ci = c0 + tx, ri = r0 + ty + q * (kNT_THREADS / kNT_W);
         ppx[q] = ppy[q] = ppz[q] = qnan;
         pdist[q] = 0.f;
-        if (ci < cols && ri < rows) {
+        if (ci < cols && ri < rows && ty + q * (kNT_THREADS / kNT_W) < kNT_H) {
             const size_t index = (size_t)ri * cols + ci;
             ppx[q] = xyz[3 * index]; ppy[q] = xyz[3 * index + 1]; ppz[q] = xyz[3 * index + 2];
             pdist[q] = dist[index];
@@ -343,7 +346,7 @@ __global__ __launch_bounds__(kNT_THREADS) void k_f360_normals_tiled(const float*
     for (int q = 0; q < kRowsPerThread; ++q) {
         const int ly = ty + q * (kNT_THREADS / kNT_W);
         const int ci = c0 + tx, ri = r0 + ly;
-        if (ci >= cols || ri >= rows) continue;
+        if (ci >= cols || ri >= rows || ly >= kNT_H) continue;
         const size_t index = (size_t)ri * cols + ci;
         float nx = qnan, ny = qnan, nz = qnan;
         int rect = 0;
