@@ -53,6 +53,27 @@ t0 = time.perf_counter()
 for _ in range(n):
     p1 = frame_planes(frames[0], tm)
 t_frame = (time.perf_counter() - t0) / n
+# one context (stream + buffers) and one host thread per sensor: the per-sensor chains are launch-latency bound, the eight of a
+# frame are independent (Frame360.h:489-503 runs them on 8 OpenMP threads too) -- ctypes releases the GIL during the calls
+from concurrent.futures import ThreadPoolExecutor
+stages = [Frame360Stages(RegisterPhotoICP()) for _ in range(8)]
+pool = ThreadPoolExecutor(8)
+
+
+def frame_planes_threads(depths):
+    def one(s):
+        return stages[s].sensor_planes(depths[s], 2, 0.3, 10.0, 10.0, 0.05, 0.02, 8.0, 40, 0.0398, 0.02, 0.0013, T_rig_sensor[s])
+    out = []
+    for ps in pool.map(one, range(8)):
+        out += ps
+    return out
+
+
+assert [(p["root"], p["count"]) for p in frame_planes_threads(frames[0])] == [(p["root"], p["count"]) for p in p1]
+t0 = time.perf_counter()
+for _ in range(10):
+    frame_planes_threads(frames[0])
+print("8 contexts on 8 host threads (rgbd360_sensor_planes each): %.2f ms per frame" % ((time.perf_counter() - t0) / 10 * 1e3))
 reg = pbmap.RegisterRGBD360(odometry_config=True)
 t0 = time.perf_counter()
 good = reg.RegisterPbMap(p1, p2, 25, pbmap.ODOMETRY_6DoF)
