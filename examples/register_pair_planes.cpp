@@ -6,9 +6,11 @@
 // Everything per-pixel runs on the GPU through the C ABI; the matcher and the pose fit are host code inside the library.
 //   usage: register_pair_planes <frame1.bin> <frame2.bin> <extrinsics_dir> [regist_mode 0..3 = 1]
 //   e.g.   register_pair_planes samples/sphere_images_1.bin samples/sphere_images_10.bin Calibration/Extrinsics
+#include <array>
 #include <cstdio>
 #include <cstdlib>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rgbd360/RegisterRGBD360.hpp"
@@ -25,7 +27,10 @@ static bool load_rt(const std::string& dir, int sensor, float Rt_colmajor[16]) {
     return ok;
 }
 
-static bool frame_planes(rgbd360::RegisterPhotoICP& reg, const char* path, const std::string& extr, std::vector<rgbd360_plane>& planes) {
+// the eight sensors of a frame are independent and each chain is launch-latency bound: one context (stream + device buffers)
+// and one host thread per sensor, like the reference's `#pragma omp parallel num_threads(8)` (Frame360.h:489-503)
+static bool frame_planes(std::array<rgbd360::RegisterPhotoICP, 8>& regs, const char* path, const std::string& extr,
+                         std::vector<rgbd360_plane>& planes) {
     int rows = 0, cols = 0;
     if (rgbd360_load_frame_bin(path, nullptr, nullptr, &rows, &cols) != 0) return false;
     std::vector<uint8_t> rgb((size_t)8 * rows * cols * 3);
@@ -34,16 +39,26 @@ static bool frame_planes(rgbd360::RegisterPhotoICP& reg, const char* path, const
     const int step = 2;                                                      // DOWNSAMPLE_160, Frame360.h:41
     rgbd360::SensorSegmentParams sp;
     sp.min_inliers = 40;                                                      // Frame360.h:960 is for the full 320 x 240 cloud: a quarter of the points
-    std::vector<rgbd360_plane> ps((size_t)sp.max_planes);
+    std::array<std::vector<rgbd360_plane>, 8> per_sensor;
+    std::array<int, 8> rc{};
+    std::vector<std::thread> workers;
+    for (int s = 0; s < 8; ++s)
+        workers.emplace_back([&, s]() {
+            float Rt[16];
+            int n = 0;
+            per_sensor[s].resize((size_t)sp.max_planes);
+            rc[s] = load_rt(extr, s, Rt) ? 0 : 1;                             // depth image in, planes in the rig frame out: one call per sensor
+            if (rc[s] == 0)
+                rc[s] = rgbd360_sensor_planes(regs[s].context(), depth.data() + (size_t)s * rows * cols, (size_t)cols * 2, rows, cols, step, 0.3f,
+                                              10.f, sp.sigma_s, sp.sigma_r, sp.max_depth_change_factor, sp.normal_smoothing_size, sp.min_inliers,
+                                              sp.angular_threshold, sp.distance_threshold, sp.max_curvature, Rt, per_sensor[s].data(),
+                                              sp.max_planes, &n);
+            per_sensor[s].resize((size_t)(rc[s] == 0 ? n : 0));
+        });
+    for (std::thread& w : workers) w.join();
     for (int s = 0; s < 8; ++s) {
-        float Rt[16];
-        if (!load_rt(extr, s, Rt)) return false;
-        int n = 0;                                                            // depth image in, planes in the rig frame out: one call per sensor
-        if (rgbd360_sensor_planes(reg.context(), depth.data() + (size_t)s * rows * cols, (size_t)cols * 2, rows, cols, step, 0.3f, 10.f,
-                                  sp.sigma_s, sp.sigma_r, sp.max_depth_change_factor, sp.normal_smoothing_size, sp.min_inliers,
-                                  sp.angular_threshold, sp.distance_threshold, sp.max_curvature, Rt, ps.data(), sp.max_planes, &n) != 0)
-            return false;
-        planes.insert(planes.end(), ps.begin(), ps.begin() + n);
+        if (rc[s] != 0) return false;
+        planes.insert(planes.end(), per_sensor[s].begin(), per_sensor[s].end());
     }
     return true;
 }
@@ -54,9 +69,9 @@ int main(int argc, char** argv) {
         return 2;
     }
     const int mode = argc > 4 ? std::atoi(argv[4]) : 1;
-    rgbd360::RegisterPhotoICP reg;
+    std::array<rgbd360::RegisterPhotoICP, 8> regs;
     std::vector<rgbd360_plane> p1, p2;
-    if (!frame_planes(reg, argv[1], argv[3], p1) || !frame_planes(reg, argv[2], argv[3], p2)) return 3;
+    if (!frame_planes(regs, argv[1], argv[3], p1) || !frame_planes(regs, argv[2], argv[3], p2)) return 3;
     std::printf("planes %zu %zu\n", p1.size(), p2.size());
     rgbd360::RegisterRGBD360 registerer(/*odometry_config=*/false);
     rgbd360::PlaneList f1{p1.data(), (int)p1.size()}, f2{p2.data(), (int)p2.size()};

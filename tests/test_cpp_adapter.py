@@ -135,7 +135,7 @@ def build_pair_planes(out_dir):
     from rgbd360_amd import build
     lib = build.build()
     exe = os.path.join(str(out_dir), "register_pair_planes")
-    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I" + os.path.join(ROOT, "include"),
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-pthread", "-I" + os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "examples", "register_pair_planes.cpp"), "-L" + os.path.dirname(lib), "-lrgbd360_hip",
                            "-Wl,-rpath," + os.path.dirname(lib), "-o", exe])
     return exe
