@@ -7,6 +7,7 @@
 // this class reads is `planes.vPlanes`.  Header-only; depends on nothing but the C ABI.
 #pragma once
 
+#include <algorithm>
 #include <cmath>
 #include <map>
 #include <stdexcept>
@@ -110,8 +111,8 @@ class RegisterRGBD360 {
         if (status_ != 0) return false;
         std::memcpy(rigidTransf_.m, pose, sizeof(pose));
         std::memcpy(informationM_.m, info, sizeof(info));
-        areaSource = subgraphArea(ref_);                                                          // :325-333
-        areaTarget = subgraphArea(trg_);
+        areaSource = subgraphArea(ref_, mmp);                                                     // :325-333
+        areaTarget = subgraphArea(trg_, mmp);
         return true;
     }
 
@@ -152,12 +153,23 @@ class RegisterRGBD360 {
     void ensure() {
         if (!done_) RegisterPbMap(nullptr, nullptr, 0, mode_);
     }
-    float subgraphArea(const PlaneList& f) const {
+    // area of the planes that entered the matching (:121-150, :325-333): the library's subgraph selection restated
+    float subgraphArea(const PlaneList& f, size_t max_match) const {
+        std::vector<float> areas;
+        for (int i = 0; i < f.n; ++i) {
+            const rgbd360_plane& p = f.planes[i];
+            if (p.area < params_.min_area_plane || p.elongation > params_.max_elongation_plane) continue;
+            areas.push_back(p.curvature < params_.max_curvature_plane ? p.area : 0.f);
+        }
+        float thr = -1.f;
+        if (max_match > 0 && areas.size() > max_match) {
+            std::vector<float> sorted = areas;
+            std::sort(sorted.begin(), sorted.end());
+            thr = sorted[areas.size() - max_match - 1];
+        }
         float a = 0.f;
-        for (int i = 0; i < f.n; ++i)
-            if (f.planes[i].curvature < params_.max_curvature_plane && !(f.planes[i].area < params_.min_area_plane) &&
-                !(f.planes[i].elongation > params_.max_elongation_plane))
-                a += f.planes[i].area;
+        for (float v : areas)
+            if (v > thr && v > 0.f) a += v;
         return a;
     }
     // Gauss-Jordan with partial pivoting in double; det = determinant of the input

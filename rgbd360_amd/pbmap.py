@@ -103,11 +103,15 @@ class RegisterRGBD360:
             self.rigidTransf, self.informationM = r["pose"], r["info"]
             p = self.params
 
-            def subgraph_area(planes):                                        # :325-333
-                return sum(pl["area"] for pl in planes if pl["curvature"] < p.max_curvature_plane
-                           and not pl["area"] < p.min_area_plane and not pl["elongation"] > p.max_elongation_plane)
-            if max(self._max_ref, self._max_trg) == 0:
-                self.areaSource, self.areaTarget = subgraph_area(self._ref), subgraph_area(self._trg)
+            def subgraph_area(planes, max_match):                             # :325-333: area of the planes that entered the matching
+                kept = [pl for pl in planes if not pl["area"] < p.min_area_plane and not pl["elongation"] > p.max_elongation_plane]
+                areas = [float(pl["area"]) if pl["curvature"] < p.max_curvature_plane else 0.0 for pl in kept]
+                if max_match > 0 and len(kept) > max_match:                   # :121-150: the max_match largest areas
+                    thr = sorted(areas)[len(kept) - max_match - 1]
+                    return sum(a for a in areas if a > thr)
+                return sum(a for a, pl in zip(areas, kept) if pl["curvature"] < p.max_curvature_plane)
+            mm = max(self._max_ref, self._max_trg)
+            self.areaSource, self.areaTarget = subgraph_area(self._ref, mm), subgraph_area(self._trg, mm)
         return self._good
 
     def _ensure(self):

@@ -211,8 +211,11 @@ def test_reference_class_surface():
     assert np.allclose(cov @ reg.getInfoMat().astype(np.float64), np.eye(6), atol=1e-3)
     want = 0.5 * (6 * (1 + math.log(2 * math.pi)) + math.log(np.linalg.det(np.linalg.inv(reg.getInfoMat().astype(np.float64)))))
     assert abs(reg.calcEntropy() - want) < 1e-9
-    assert reg.RegisterPbMap(room_planes(T_wA), room_planes(T_wB), 25, pbmap.PLANAR_ODOMETRY_3DoF) in (True, False)
-    assert reg.areaSource > 0 or reg.areaTarget >= 0
+    total = sum(float(p["area"]) for p in room_planes(T_wA))
+    assert abs(reg.areaSource - total) < 1e-3 and abs(reg.areaTarget - total) < 1e-3          # every wall entered the matching
+    assert reg.RegisterPbMap(room_planes(T_wA), room_planes(T_wB), 2, pbmap.ODOMETRY_6DoF) is False      # two planes: insufficient
+    assert reg.RegisterPbMap(room_planes(T_wA), room_planes(T_wB), 4, pbmap.ODOMETRY_6DoF)
+    assert abs(reg.areaSource - sum(sorted(float(p["area"]) for p in room_planes(T_wA))[-4:])) < 1e-3
 
 
 def test_golden_plane_lists():
