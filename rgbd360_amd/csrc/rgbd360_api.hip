@@ -69,7 +69,7 @@ struct rgbd360_ctx {
     int *f_label = nullptr, *f_slot_of_root = nullptr, *f_root_of_slot = nullptr, *f_nslots = nullptr, *f_window = nullptr;
     unsigned long long *f_count = nullptr, *f_mom = nullptr;
     int* f_count_of_slot = nullptr;
-    unsigned char *f_pack = nullptr, *f_pack_host = nullptr;      // packed region records: device buffer + pinned host mirror
+    unsigned char *f_pack = nullptr, *f_pack_host = nullptr;      // packed region records: written by the device straight into pinned host memory (f_pack unused)
     unsigned long long* b_sum = nullptr;                          // bilateral grid: fixed-point sums, counts, two float2 ping-pong arrays
     int* b_cnt = nullptr;
     float2 *b_a = nullptr, *b_b = nullptr;
@@ -1241,7 +1241,6 @@ int f360_ensure(rgbd360_ctx* ctx, size_t n) {
     HIPC(ctx, hipMalloc(&ctx->f_mom, (size_t)f360::kMomReplicas * kF360MaxSlots * 9 * sizeof(unsigned long long)));
     HIPC(ctx, hipMalloc(&ctx->f_count_of_slot, kF360MaxSlots * sizeof(int)));
     const size_t pack_bytes = f360::kF360PackHeader + (size_t)kF360MaxSlots * sizeof(f360::F360SlotRecord);
-    HIPC(ctx, hipMalloc(&ctx->f_pack, pack_bytes));
     HIPC(ctx, hipHostMalloc(&ctx->f_pack_host, pack_bytes));
     HIPC(ctx, hipMalloc(&ctx->f_depth_raw, n * 4));
     ctx->f360_n = n;
@@ -1385,22 +1384,14 @@ int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float
                        ctx->f_slot_of_root, ctx->f_root_of_slot, ctx->f_count_of_slot, ctx->f_nslots, ctx->f_mom, f360::kMomReplicas);
     const dim3 gmom((n + kAggThreads * kMomPerThread - 1) / (kAggThreads * kMomPerThread));
     hipLaunchKernelGGL(k_f360_moments, gmom, bagg, 0, ctx->stream, ctx->f_xyz, ctx->f_label, ctx->f_slot_of_root, n, ctx->f_mom, kF360MaxSlots);
+    // the packing kernel writes the header + records straight into pinned host memory (a few KB over PCIe): no copy to enqueue,
+    // one wait.  (Four copies into pageable vectors with two waits used to cost ~0.1 ms of the 0.45 ms call.)
     hipLaunchKernelGGL(k_f360_mom_reduce, dim3((kF360MaxSlots * 9 + 255) / 256), dim3(256), 0, ctx->stream, ctx->f_mom, ctx->f_nslots, kF360MaxSlots,
-                       ctx->f_root_of_slot, ctx->f_count_of_slot, ctx->f_pack);
+                       ctx->f_root_of_slot, ctx->f_count_of_slot, ctx->f_pack_host);
     HIPC(ctx, hipGetLastError());
-    // one copy into pinned memory + one wait: header and the first kPackFirst records (more regions than that are rare and cost
-    // a second copy); four copies into pageable vectors with two waits used to cost ~0.1 ms of the 0.45 ms call
-    constexpr int kPackFirst = 512;
-    const size_t first_bytes = kF360PackHeader + (size_t)kPackFirst * sizeof(F360SlotRecord);
-    HIPC(ctx, hipMemcpyAsync(ctx->f_pack_host, ctx->f_pack, first_bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPC(ctx, hipStreamSynchronize(ctx->stream));
-    const int nslots = *reinterpret_cast<const int*>(ctx->f_pack_host);
+    const int nslots = *reinterpret_cast<const volatile int*>(ctx->f_pack_host);
     if (nslots > kF360MaxSlots) return fail(ctx, -7, "more than 4096 regions exceed min_inliers");
-    if (nslots > kPackFirst) {
-        HIPC(ctx, hipMemcpyAsync(ctx->f_pack_host + first_bytes, ctx->f_pack + first_bytes, (size_t)(nslots - kPackFirst) * sizeof(F360SlotRecord),
-                                 hipMemcpyDeviceToHost, ctx->stream));
-        HIPC(ctx, hipStreamSynchronize(ctx->stream));
-    }
     const F360SlotRecord* recs = reinterpret_cast<const F360SlotRecord*>(ctx->f_pack_host + kF360PackHeader);
     std::vector<int> roots(nslots), counts(nslots);
     std::vector<double> mom((size_t)nslots * 9);
