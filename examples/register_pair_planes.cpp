@@ -1,7 +1,8 @@
 // register_pair_planes.cpp -- the plane side of Registration/RegisterPairRGBD360.cpp:60-110 of the reference on its own file
 // formats: two `sphere_images_%d.bin` frames (Frame360::loadFrame) and the rig extrinsics `Rt_0N.txt` (Calib360::loadExtrinsicCalibration,
 // Calib360.h:122-131: plain 4x4 text) -> per sensor: pinhole cloud down-sampled by 2 (Frame360.h:479-481), bilateral filter
-// (Frame360.h:493-499), normal map + planar regions (Frame360.h:949-996), planes moved into the rig frame (Frame360.h:1046)
+// (Frame360.h:493-499), normal map + planar regions (Frame360.h:949-996), planes moved into the rig frame (Frame360.h:1046),
+// co-planar pieces of several sensors merged (Frame360.h:655-733)
 // -> RegisterRGBD360::RegisterPbMap(frame1, frame2, 25, PLANAR_3DoF) (RegisterPairRGBD360.cpp:101).
 // Everything per-pixel runs on the GPU through the C ABI; the matcher and the pose fit are host code inside the library.
 //   usage: register_pair_planes <frame1.bin> <frame2.bin> <extrinsics_dir> [regist_mode 0..3 = 1]
@@ -72,7 +73,10 @@ int main(int argc, char** argv) {
     std::array<rgbd360::RegisterPhotoICP, 8> regs;
     std::vector<rgbd360_plane> p1, p2;
     if (!frame_planes(regs, argv[1], argv[3], p1) || !frame_planes(regs, argv[2], argv[3], p2)) return 3;
-    std::printf("planes %zu %zu\n", p1.size(), p2.size());
+    const size_t n1 = p1.size(), n2 = p2.size();
+    p1 = rgbd360::mergePlanes(p1);                                            // Frame360::mergePlanes, Frame360.h:655-733
+    p2 = rgbd360::mergePlanes(p2);
+    std::printf("planes %zu %zu (pieces %zu %zu)\n", p1.size(), p2.size(), n1, n2);
     rgbd360::RegisterRGBD360 registerer(/*odometry_config=*/false);
     rgbd360::PlaneList f1{p1.data(), (int)p1.size()}, f2{p2.data(), (int)p2.size()};
     const bool good = registerer.RegisterPbMap(&f1, &f2, 25, (rgbd360::RegisterRGBD360::registrationType)mode);

@@ -377,6 +377,17 @@ int rgbd360_register_planes(const rgbd360_plane* ref, int n_ref, const rgbd360_p
                             int regist_mode, const rgbd360_pbmap_params* params, float pose_out[16], float info_out[36],
                             int32_t* match_out, int* n_matched_out, float* area_matched_out);
 
+/* Frame360::mergePlanes (Frame360.h:655-733): the pieces several sensors (or several regions) hold of one surface become one
+ * plane.  Same surface = the reference's explicit test: n_j . n_k > cos_normal (0.99), |d_j - d_k| < dist_d (0.45 m), and outline
+ * points closer than proximity (0.3 m) whose difference lies within normal_offset (0.06 m) of plane j -- evaluated on the
+ * rectangle with each plane's in-plane moments instead of mrpt::pbmap's convex hull (corners, edge midpoints, centre; a point of
+ * one outline inside the other stands in for crossing hull edges).  The merged plane is the exact pooled fit of the two
+ * pieces (covariances rebuilt from the records, combined by inlier count -- mrpt's mergePlane2 pools the inliers and refits).
+ * Planes above max_curvature are never merged (Frame360.h:659-661); malformed records are dropped.  Host only.
+ * out may not alias planes; returns -1 when max_out is too small (*n_out = needed). */
+int rgbd360_merge_planes(const rgbd360_plane* planes, int n, float max_curvature, float cos_normal, float dist_d, float proximity,
+                         float normal_offset, rgbd360_plane* out, int max_out, int* n_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -176,3 +176,84 @@ def register_planes(ref, trg, max_match_planes=0, mode=DEFAULT_6DoF, P=None):
     if st == 0:
         out["pose"], out["info"] = T, info
     return out
+
+
+# ---- Frame360::mergePlanes (Frame360.h:655-733) on moment rectangles: independent restatement (numpy eigh, no Jacobi) ------------
+def _axes(p):
+    f = lambda v: np.asarray(v, np.float32).astype(np.float64)
+    n, pp = f(p["normal"]), f(p.get("ppal_dir", (0, 0, 0)))
+    if not np.linalg.norm(pp) > 0.5:
+        pp = np.cross(n, np.array([1.0, 0, 0]) if abs(n[0]) < 0.9 else np.array([0, 1.0, 0]))
+    pp = pp - (pp @ n) * n
+    pp /= np.linalg.norm(pp)
+    return n, pp, np.cross(n, pp)
+
+
+def _moments(p):
+    n, pp, qq = _axes(p)
+    el = _f32(p["elongation"]) if np.isfinite(_f32(p["elongation"])) and _f32(p["elongation"]) > 0 else 1.0
+    area = _f32(p["area"])
+    l1, l2 = area / (12.0 * el), area * el / 12.0
+    cv = min(_f32(p["curvature"]), 0.5)
+    l0 = cv * (l1 + l2) / (1.0 - cv)
+    C = l0 * np.outer(n, n) + l1 * np.outer(qq, qq) + l2 * np.outer(pp, pp)
+    return float(p["count"] if p["count"] > 0 else 1), np.asarray(p["centroid"], np.float32).astype(np.float64), C
+
+
+def _outline(p):
+    n, pp, qq = _axes(p)
+    el = _f32(p["elongation"]) if np.isfinite(_f32(p["elongation"])) and _f32(p["elongation"]) > 0 else 1.0
+    a, b = math.sqrt(3.0 * _f32(p["area"]) * el / 12.0), math.sqrt(3.0 * _f32(p["area"]) / (12.0 * el))
+    c = np.asarray(p["centroid"], np.float32).astype(np.float64)
+    return [c + su * a * pp + sv * b * qq for su in (-1, 0, 1) for sv in (-1, 0, 1)], (n, pp, qq, a, b, c)
+
+
+def _same_surface(pj, pk, cos_normal, dist_d, proximity, normal_offset):
+    nj = np.asarray(pj["normal"], np.float32).astype(np.float64)
+    nk = np.asarray(pk["normal"], np.float32).astype(np.float64)
+    if not nj @ nk > _f32(cos_normal) or not abs(_f32(pj["d"]) - _f32(pk["d"])) < _f32(dist_d):
+        return False
+    Pj, fj = _outline(pj)
+    Pk, fk = _outline(pk)
+    for a in Pj:
+        for b in Pk:
+            if np.linalg.norm(a - b) < _f32(proximity) and abs(nj @ (a - b)) < _f32(normal_offset):
+                return True
+
+    def inside(q, frame):
+        n, pp, qq, a, b, c = frame
+        d = q - c
+        return abs(d @ pp) <= a and abs(d @ qq) <= b and abs(n @ d) < _f32(normal_offset)
+    return any(inside(q, fj) for q in Pk) or any(inside(q, fk) for q in Pj)
+
+
+def merge_planes(planes, max_curvature=0.0013, cos_normal=0.99, dist_d=0.45, proximity=0.3, normal_offset=0.06):
+    v = [dict(p) for p in planes]
+    j = 0
+    while j < len(v):
+        if _f32(v[j]["curvature"]) < _f32(max_curvature):
+            merged = True
+            while merged:
+                merged = False
+                for k in range(j + 1, len(v)):
+                    if not _f32(v[k]["curvature"]) < _f32(max_curvature) or not _same_surface(v[j], v[k], cos_normal, dist_d, proximity, normal_offset):
+                        continue
+                    (na, ca, Ca), (nb, cb, Cb) = _moments(v[j]), _moments(v[k])
+                    n = na + nb
+                    c = (na * ca + nb * cb) / n
+                    Cm = (na * (Ca + np.outer(ca - c, ca - c)) + nb * (Cb + np.outer(cb - c, cb - c))) / n
+                    w, V = np.linalg.eigh(Cm)
+                    nn = V[:, 0]
+                    d = -float(nn @ c)
+                    if d < 0:
+                        nn, d = -nn, -d
+                    l0, l1, l2 = (max(float(x), 0.0) for x in w)
+                    v[j] = dict(centroid=c.astype(np.float32), normal=nn.astype(np.float32), d=np.float32(d),
+                                curvature=np.float32(l0 / (l0 + l1 + l2) if l0 + l1 + l2 > 0 else 0.0), count=int(n),
+                                root=min(v[j]["root"], v[k]["root"]), area=np.float32(12.0 * math.sqrt(l1 * l2)),
+                                elongation=np.float32(math.sqrt(l2 / l1) if l1 > 0 else math.inf), ppal_dir=V[:, 2].astype(np.float32))
+                    del v[k]
+                    merged = True
+                    break
+        j += 1
+    return v

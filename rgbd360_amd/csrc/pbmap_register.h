@@ -325,6 +325,143 @@ inline int register_planes(const rgbd360_plane* ref, int n_ref, const rgbd360_pl
     return 0;
 }
 
+// ---- Frame360::mergePlanes (Frame360.h:655-733): the co-planar pieces several sensors see of one surface become one plane ----
+// The reference's test for "same surface" is explicit -- normals' dot product > 0.99, |d_j - d_k| < 0.45 m, and two contour
+// vertices closer than 0.3 m whose difference is within 0.06 m of plane j (or two contour edges closer than 0.3 m) -- but runs on
+// the convex hulls mrpt::pbmap keeps; here the "contour" of a plane is the rectangle with its in-plane moments (centre c,
+// half-extents sqrt(3 l2) along ppal_dir and sqrt(3 l1) across): its four corners, four edge midpoints and centre stand in for the
+// hull vertices, and a point of one rectangle lying inside the other (within 0.06 m of its plane) stands in for crossing edges.
+// mrpt's mergePlane2 pools the inliers and refits; the pooled fit is exact here: the covariance of every piece is rebuilt from its
+// record (l0 from the curvature, l1 / l2 from area and elongation, axes normal / ppal_dir), the pieces are combined by count.
+struct PlaneMoments {
+    double n, c[3], C[3][3];
+};
+inline PlaneMoments moments_of(const rgbd360_plane& p) {
+    PlaneMoments m;
+    m.n = p.count > 0 ? p.count : 1;
+    V3 nn = v3(p.normal), pp = v3(p.ppal_dir);
+    if (!(norm(pp) > 0.5)) {                              // no principal direction in the record: any unit vector across the normal
+        const V3 e = fabs(nn.x) < 0.9 ? V3{1, 0, 0} : V3{0, 1, 0};
+        pp = cross(nn, e);
+    }
+    const double pn = dot(pp, nn);
+    pp = {pp.x - pn * nn.x, pp.y - pn * nn.y, pp.z - pn * nn.z};
+    const double pl = norm(pp);
+    pp = {pp.x / pl, pp.y / pl, pp.z / pl};
+    const V3 qq = cross(nn, pp);
+    const double el = p.elongation > 0 && std::isfinite(p.elongation) ? p.elongation : 1.0;
+    const double l1 = p.area / (12.0 * el), l2 = p.area * el / 12.0;
+    const double cv = p.curvature < 0.5 ? p.curvature : 0.5;
+    const double l0 = cv * (l1 + l2) / (1.0 - cv);
+    const double a[3][3] = {{nn.x, nn.y, nn.z}, {qq.x, qq.y, qq.z}, {pp.x, pp.y, pp.z}};
+    const double l[3] = {l0, l1, l2};
+    for (int i = 0; i < 3; ++i) {
+        m.c[i] = p.centroid[i];
+        for (int j = 0; j < 3; ++j) {
+            m.C[i][j] = 0;
+            for (int k = 0; k < 3; ++k) m.C[i][j] += l[k] * a[k][i] * a[k][j];
+        }
+    }
+    return m;
+}
+inline rgbd360_plane plane_of(const PlaneMoments& m, int root) {
+    rgbd360_plane P{};
+    double ev[3], V[3][3];
+    jacobi3(m.C, ev, V);
+    int o[3] = {0, 1, 2};
+    std::stable_sort(o, o + 3, [&](int a, int b) { return ev[a] < ev[b]; });
+    double nn[3] = {V[0][o[0]], V[1][o[0]], V[2][o[0]]};
+    double d = -(nn[0] * m.c[0] + nn[1] * m.c[1] + nn[2] * m.c[2]);
+    if (d < 0) {                                           // towards the origin, like the plane fit
+        for (int i = 0; i < 3; ++i) nn[i] = -nn[i];
+        d = -d;
+    }
+    const double l0 = std::max(ev[o[0]], 0.0), l1 = std::max(ev[o[1]], 0.0), l2 = std::max(ev[o[2]], 0.0);
+    for (int i = 0; i < 3; ++i) {
+        P.centroid[i] = (float)m.c[i];
+        P.normal[i] = (float)nn[i];
+        P.ppal_dir[i] = (float)V[i][o[2]];
+    }
+    P.d = (float)d;
+    P.curvature = (float)(l0 + l1 + l2 > 0 ? l0 / (l0 + l1 + l2) : 0.0);
+    P.count = (int)m.n;
+    P.root = root;
+    P.area = (float)(12.0 * sqrt(l1 * l2));
+    P.elongation = (float)(l1 > 0 ? sqrt(l2 / l1) : INFINITY);
+    return P;
+}
+struct MergeParams {
+    float max_curvature, cos_normal, dist_d, proximity, normal_offset;
+};
+inline void contour_points(const rgbd360_plane& p, V3 pts[9], V3& pp, V3& qq, double& a, double& b) {
+    const PlaneMoments m = moments_of(p);                  // (re-derives the axes the same way the merge does)
+    const V3 nn = v3(p.normal);
+    pp = v3(p.ppal_dir);
+    if (!(norm(pp) > 0.5)) pp = cross(nn, fabs(nn.x) < 0.9 ? V3{1, 0, 0} : V3{0, 1, 0});
+    const double pn = dot(pp, nn);
+    pp = {pp.x - pn * nn.x, pp.y - pn * nn.y, pp.z - pn * nn.z};
+    const double pl = norm(pp);
+    pp = {pp.x / pl, pp.y / pl, pp.z / pl};
+    qq = cross(nn, pp);
+    const double el = p.elongation > 0 && std::isfinite(p.elongation) ? p.elongation : 1.0;
+    a = sqrt(3.0 * p.area * el / 12.0);
+    b = sqrt(3.0 * p.area / (12.0 * el));
+    const V3 c = {m.c[0], m.c[1], m.c[2]};
+    int k = 0;
+    for (int su = -1; su <= 1; ++su)
+        for (int sv = -1; sv <= 1; ++sv)
+            pts[k++] = {c.x + su * a * pp.x + sv * b * qq.x, c.y + su * a * pp.y + sv * b * qq.y, c.z + su * a * pp.z + sv * b * qq.z};
+}
+inline bool same_surface(const rgbd360_plane& pj, const rgbd360_plane& pk, const MergeParams& M) {
+    const V3 nj = v3(pj.normal), nk = v3(pk.normal);
+    if (!(dot(nj, nk) > M.cos_normal)) return false;                              // Frame360.h:671
+    if (!(fabs((double)pj.d - pk.d) < M.dist_d)) return false;                    // :672
+    V3 Pj[9], Pk[9], ppj, qqj, ppk, qqk;
+    double aj, bj, ak, bk;
+    contour_points(pj, Pj, ppj, qqj, aj, bj);
+    contour_points(pk, Pk, ppk, qqk, ak, bk);
+    for (int i = 0; i < 9; ++i)
+        for (int ii = 0; ii < 9; ++ii) {                                          // :680-691 vertex against vertex
+            const V3 df = sub(Pj[i], Pk[ii]);
+            if (norm(df) < M.proximity && fabs(dot(nj, df)) < M.normal_offset) return true;
+        }
+    auto inside = [&](const V3& q, const rgbd360_plane& p, const V3& pp, const V3& qq, double a, double b) {
+        const V3 df = sub(q, v3(p.centroid));
+        return fabs(dot(df, pp)) <= a && fabs(dot(df, qq)) <= b && fabs(dot(v3(p.normal), df)) < M.normal_offset;
+    };
+    for (int i = 0; i < 9; ++i)                                                   // :694-711 stand-in: overlapping outlines
+        if (inside(Pk[i], pj, ppj, qqj, aj, bj) || inside(Pj[i], pk, ppk, qqk, ak, bk)) return true;
+    return false;
+}
+inline std::vector<rgbd360_plane> merge_planes(const rgbd360_plane* in, int n, const MergeParams& M) {
+    std::vector<rgbd360_plane> v;
+    for (int i = 0; i < n; ++i)
+        if (well_formed(in[i])) v.push_back(in[i]);
+    for (size_t j = 0; j < v.size(); ++j) {
+        if (!(v[j].curvature < M.max_curvature)) continue;
+        bool merged = true;
+        while (merged) {                                                          // :727-731 re-evaluate plane j after every merge
+            merged = false;
+            for (size_t k = j + 1; k < v.size(); ++k) {
+                if (!(v[k].curvature < M.max_curvature) || !same_surface(v[j], v[k], M)) continue;
+                const PlaneMoments a = moments_of(v[j]), b = moments_of(v[k]);
+                PlaneMoments m;
+                m.n = a.n + b.n;
+                for (int i = 0; i < 3; ++i) m.c[i] = (a.n * a.c[i] + b.n * b.c[i]) / m.n;
+                for (int r = 0; r < 3; ++r)
+                    for (int c = 0; c < 3; ++c)
+                        m.C[r][c] = (a.n * (a.C[r][c] + (a.c[r] - m.c[r]) * (a.c[c] - m.c[c])) +
+                                     b.n * (b.C[r][c] + (b.c[r] - m.c[r]) * (b.c[c] - m.c[c]))) / m.n;
+                v[j] = plane_of(m, std::min(v[j].root, v[k].root));
+                v.erase(v.begin() + (long)k);
+                merged = true;
+                break;
+            }
+        }
+    }
+    return v;
+}
+
 inline void default_params(rgbd360_pbmap_params* p, int odometry) {
     // config_files/configLocaliser_spherical.ini (0) / configLocaliser_sphericalOdometry.ini (1)
     p->dist_d = odometry ? 0.5f : 0.4f;

@@ -1881,3 +1881,18 @@ extern "C" int rgbd360_register_planes(const rgbd360_plane* ref, int n_ref, cons
         return -1;
     }
 }
+
+extern "C" int rgbd360_merge_planes(const rgbd360_plane* planes, int n, float max_curvature, float cos_normal, float dist_d, float proximity,
+                                    float normal_offset, rgbd360_plane* out, int max_out, int* n_out) {
+    if (n < 0 || (n > 0 && !planes) || !out || !n_out || max_out < 0) return -1;
+    try {
+        const pbm::MergeParams M{max_curvature, cos_normal, dist_d, proximity, normal_offset};
+        const std::vector<rgbd360_plane> v = pbm::merge_planes(planes, n, M);
+        *n_out = (int)v.size();
+        if ((int)v.size() > max_out) return -1;
+        for (size_t i = 0; i < v.size(); ++i) out[i] = v[i];
+        return 0;
+    } catch (const std::exception&) {
+        return -1;
+    }
+}

@@ -164,8 +164,9 @@ def test_register_pair_planes_on_a_synthetic_rig(tmp_path, hip_lib):
     for s in range(8):
         np.savetxt(tmp_path / ("Rt_0%d.txt" % (s + 1)), T_rig_sensor[s])
     out = subprocess.check_output([exe, str(tmp_path / "f1.bin"), str(tmp_path / "f2.bin"), str(tmp_path), "2"], text=True).strip().splitlines()
-    n1, n2 = (int(x) for x in out[0].split()[1:])
-    assert n1 >= 8 and n2 >= 8, out[0]
+    n1, n2 = (int(x) for x in out[0].split()[1:3])
+    pieces = [int(x.strip(')')) for x in out[0].split()[4:6]]
+    assert 5 <= n1 <= pieces[0] and 5 <= n2 <= pieces[1] and pieces[0] >= 8, out[0]        # co-planar pieces were merged
     st = out[1].split()
     assert st[1] == "0" and st[3] == "1" and int(st[5]) >= 5, out[1]
     T = np.array([[float(x) for x in l.split()] for l in out[2:6]])

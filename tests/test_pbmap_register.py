@@ -283,3 +283,68 @@ def test_mirror_images_are_never_matched():
     mirrored = pbmap.register_planes(corner(1.0), corner(-1.0), 0, O.DEFAULT_6DoF)
     assert mirrored["status"] == 1 and len(mirrored["match"]) == 2
     assert O.register_planes(corner(1.0), corner(-1.0), 0, O.DEFAULT_6DoF)["match"] == mirrored["match"]
+
+
+def _rect_plane(centre, normal, pdir, a, b, count, root):
+    """Plane record of a uniformly sampled 2a x 2b rectangle."""
+    n = np.asarray(normal, float) / np.linalg.norm(normal)
+    p = np.asarray(pdir, float)
+    p = p - (p @ n) * n
+    p /= np.linalg.norm(p)
+    c = np.asarray(centre, float)
+    if n @ c > 0:
+        n = -n
+    return dict(centroid=c.astype(np.float32), normal=n.astype(np.float32), d=np.float32(-n @ c), curvature=np.float32(1e-6), count=count,
+                root=root, area=np.float32(4 * a * b), elongation=np.float32(max(a, b) / min(a, b)), ppal_dir=(p if a >= b else np.cross(n, p)).astype(np.float32))
+
+
+def test_merge_planes_pools_the_pieces_of_one_surface():
+    """Frame360::mergePlanes (Frame360.h:655-733): two halves of a wall become the wall (exact pooled moments), a parallel wall
+    0.5 m behind and a co-planar patch 1 m away stay separate, curved regions are never merged; library = numpy restatement."""
+    n, pd = np.array([0.0, 0, -1.0]), np.array([1.0, 0, 0])
+    left = _rect_plane([-1.0, 0.2, 2.5], n, pd, 1.0, 0.75, 2000, 10)
+    right = _rect_plane([1.0, 0.2, 2.5], n, pd, 1.0, 0.75, 2000, 20)
+    whole = _rect_plane([0.0, 0.2, 2.5], n, pd, 2.0, 0.75, 4000, 10)
+    behind = _rect_plane([0.0, 0.2, 3.0], n, pd, 2.0, 0.75, 3000, 30)
+    far = _rect_plane([4.5, 0.2, 2.5], n, pd, 0.5, 0.5, 500, 40)            # same plane, 1.5 m beyond the right half's edge
+    curved = dict(_rect_plane([-1.0, 0.2, 2.5], n, pd, 1.0, 0.75, 2000, 50), curvature=np.float32(0.01))
+    got = pbmap.merge_planes([left, right, behind, far, curved])
+    want = O.merge_planes([left, right, behind, far, curved])
+    assert len(got) == len(want) == 4
+    m = got[0]
+    assert m["count"] == 4000 and m["root"] == 10
+    assert np.allclose(m["centroid"], whole["centroid"], atol=1e-5) and abs(m["area"] - whole["area"]) < 1e-3 * whole["area"]
+    assert abs(m["elongation"] - whole["elongation"]) < 1e-3 and abs(abs(m["ppal_dir"] @ pd) - 1) < 1e-5
+    assert float(m["normal"] @ whole["normal"]) > 1 - 1e-6 and abs(m["d"] - whole["d"]) < 1e-5
+    for a, b in zip(got, want):
+        assert (a["count"], a["root"]) == (b["count"], b["root"])
+        assert np.allclose(a["centroid"], b["centroid"], atol=1e-5) and abs(a["area"] - b["area"]) <= 1e-4 * max(b["area"], 1.0)
+        assert float(a["normal"] @ b["normal"]) > 1 - 1e-6
+    # three pieces in a row merge transitively (plane j is re-evaluated after every merge, Frame360.h:727-731), whatever their order
+    third = _rect_plane([3.0, 0.2, 2.5], n, pd, 1.0, 0.75, 2000, 60)
+    for order in ([left, third, right], [third, left, right], [right, left, third]):
+        out = pbmap.merge_planes(order)
+        assert len(out) == 1 and out[0]["count"] == 6000 and abs(out[0]["area"] - 9.0) < 1e-2
+        assert len(O.merge_planes(order)) == 1
+    assert pbmap.merge_planes([]) == []
+
+
+def test_merge_planes_random_sets_match_the_numpy_restatement():
+    rng = np.random.default_rng(8)
+    for trial in range(20):
+        planes = []
+        for w in range(int(rng.integers(1, 4))):                               # a few walls, each cut into 1-4 pieces + noise
+            nrm = rng.normal(size=3)
+            nrm /= np.linalg.norm(nrm)
+            pdv = np.cross(nrm, rng.normal(size=3))
+            dist = rng.uniform(1.5, 4.0)
+            pieces = int(rng.integers(1, 5))
+            for k in range(pieces):
+                centre = -nrm * dist + pdv / np.linalg.norm(pdv) * (k - pieces / 2) * 1.9 + rng.normal(size=3) * 0.005
+                planes.append(_rect_plane(centre, nrm + rng.normal(size=3) * 0.004, pdv, 1.0, rng.uniform(0.4, 1.0), int(rng.integers(200, 3000)),
+                                          len(planes)))
+        planes = [planes[i] for i in rng.permutation(len(planes))]
+        got, want = pbmap.merge_planes(planes), O.merge_planes(planes)
+        assert [(p["count"], p["root"]) for p in got] == [(p["count"], p["root"]) for p in want], trial
+        for a, b in zip(got, want):
+            assert np.allclose(a["centroid"], b["centroid"], atol=2e-5) and abs(a["area"] - b["area"]) <= 2e-4 * max(b["area"], 1.0)

@@ -74,6 +74,14 @@ t0 = time.perf_counter()
 for _ in range(10):
     frame_planes_threads(frames[0])
 print("8 contexts on 8 host threads (rgbd360_sensor_planes each): %.2f ms per frame" % ((time.perf_counter() - t0) / 10 * 1e3))
+t0 = time.perf_counter()
+m1, m2 = pbmap.merge_planes(p1), pbmap.merge_planes(p2)
+t_merge = (time.perf_counter() - t0) / 2
+print("Frame360::mergePlanes: %d -> %d and %d -> %d planes, %.2f ms per frame through the Python mirror" % (len(p1), len(m1), len(p2), len(m2), t_merge * 1e3))
+regm = pbmap.RegisterRGBD360(odometry_config=True)
+goodm = regm.RegisterPbMap(m1, m2, 25, pbmap.ODOMETRY_6DoF)
+print("RegisterPbMap on the merged planes: good %s, %d matched, pose error vs the rig motion %.2e rad %.2e m" % (
+    goodm, len(regm.getMatchedPlanes()), *synth.pose_error(regm.getPose(), M)))
 reg = pbmap.RegisterRGBD360(odometry_config=True)
 t0 = time.perf_counter()
 good = reg.RegisterPbMap(p1, p2, 25, pbmap.ODOMETRY_6DoF)
