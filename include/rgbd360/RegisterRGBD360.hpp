@@ -71,10 +71,11 @@ inline std::vector<rgbd360_plane> segmentSensorPlanes(RegisterPhotoICP& reg, con
 
 // Frame360::mergePlanes (Frame360.h:655-733; defaults = its constants): the pieces several sensors hold of one surface become one plane.
 inline std::vector<rgbd360_plane> mergePlanes(const std::vector<rgbd360_plane>& planes, float max_curvature = 0.0013f, float cos_normal = 0.99f,
-                                              float dist_d = 0.45f, float proximity = 0.3f, float normal_offset = 0.06f) {
+                                              float dist_d = 0.45f, float proximity = 0.3f, float normal_offset = 0.06f, float min_area = 0.12f,
+                                              float max_elongation = 6.f) {
     std::vector<rgbd360_plane> out(planes.size() ? planes.size() : 1);
     int n = 0;
-    if (rgbd360_merge_planes(planes.data(), (int)planes.size(), max_curvature, cos_normal, dist_d, proximity, normal_offset, out.data(),
+    if (rgbd360_merge_planes(planes.data(), (int)planes.size(), max_curvature, min_area, max_elongation, cos_normal, dist_d, proximity, normal_offset, out.data(),
                              (int)out.size(), &n) != 0)
         throw std::runtime_error("rgbd360_merge_planes: bad arguments");
     out.resize((size_t)n);

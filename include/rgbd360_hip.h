@@ -383,10 +383,12 @@ int rgbd360_register_planes(const rgbd360_plane* ref, int n_ref, const rgbd360_p
  * rectangle with each plane's in-plane moments instead of mrpt::pbmap's convex hull (corners, edge midpoints, centre; a point of
  * one outline inside the other stands in for crossing hull edges).  The merged plane is the exact pooled fit of the two
  * pieces (covariances rebuilt from the records, combined by inlier count -- mrpt's mergePlane2 pools the inliers and refits).
- * Planes above max_curvature are never merged (Frame360.h:659-661); malformed records are dropped.  Host only.
+ * Planes above max_curvature are never merged (Frame360.h:659-661).  Regions smaller than min_area (0.12 m2) or narrower than
+ * max_elongation (6) are dropped first: Frame360.h:1034,1041 never stores them, so the reference's merge never sees them (and the
+ * record of a thin strip pins its normal too loosely to be pooled); malformed records are dropped too.  Host only.
  * out may not alias planes; returns -1 when max_out is too small (*n_out = needed). */
-int rgbd360_merge_planes(const rgbd360_plane* planes, int n, float max_curvature, float cos_normal, float dist_d, float proximity,
-                         float normal_offset, rgbd360_plane* out, int max_out, int* n_out);
+int rgbd360_merge_planes(const rgbd360_plane* planes, int n, float max_curvature, float min_area, float max_elongation, float cos_normal,
+                         float dist_d, float proximity, float normal_offset, rgbd360_plane* out, int max_out, int* n_out);
 
 #ifdef __cplusplus
 }

@@ -227,8 +227,9 @@ def _same_surface(pj, pk, cos_normal, dist_d, proximity, normal_offset):
     return any(inside(q, fj) for q in Pk) or any(inside(q, fk) for q in Pj)
 
 
-def merge_planes(planes, max_curvature=0.0013, cos_normal=0.99, dist_d=0.45, proximity=0.3, normal_offset=0.06):
-    v = [dict(p) for p in planes]
+def merge_planes(planes, max_curvature=0.0013, cos_normal=0.99, dist_d=0.45, proximity=0.3, normal_offset=0.06, min_area=0.12,
+                 max_elongation=6.0):
+    v = [dict(p) for p in planes if not _f32(p["area"]) < _f32(min_area) and not _f32(p["elongation"]) > _f32(max_elongation)]
     j = 0
     while j < len(v):
         if _f32(v[j]["curvature"]) < _f32(max_curvature):

@@ -103,7 +103,7 @@ def load() -> C.CDLL:
     L.rgbd360_sensor_cloud.argtypes = [vp, vp, C.c_size_t, i32, i32, i32, C.c_float, C.c_float, vp]
     L.rgbd360_sensor_planes.argtypes = [vp, vp, C.c_size_t, i32, i32, i32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, i32,
                                         C.c_float, C.c_float, C.c_float, vp, vp, i32, C.POINTER(i32)]
-    L.rgbd360_merge_planes.argtypes = [vp, i32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp, i32, C.POINTER(i32)]
+    L.rgbd360_merge_planes.argtypes = [vp, i32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp, i32, C.POINTER(i32)]
     L.rgbd360_cloud_planes.argtypes = [vp, vp, i32, i32, C.c_float, C.c_float, C.c_float, C.c_float, i32, C.c_float, C.c_float, C.c_float, i32, vp,
                                        vp, i32, C.POINTER(i32)]
     L.rgbd360_plane_fit.argtypes = [vp, vp, vp, i32, i32, i32, C.c_float, C.c_float, C.c_float, i32, vp, vp, i32, C.POINTER(i32)]

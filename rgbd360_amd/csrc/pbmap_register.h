@@ -392,6 +392,7 @@ inline rgbd360_plane plane_of(const PlaneMoments& m, int root) {
 }
 struct MergeParams {
     float max_curvature, cos_normal, dist_d, proximity, normal_offset;
+    float min_area, max_elongation;        // Frame360.h:1034,1041: smaller / narrower regions are never stored, so they never reach the merge
 };
 inline void contour_points(const rgbd360_plane& p, V3 pts[9], V3& pp, V3& qq, double& a, double& b) {
     const PlaneMoments m = moments_of(p);                  // (re-derives the axes the same way the merge does)
@@ -436,7 +437,7 @@ inline bool same_surface(const rgbd360_plane& pj, const rgbd360_plane& pk, const
 inline std::vector<rgbd360_plane> merge_planes(const rgbd360_plane* in, int n, const MergeParams& M) {
     std::vector<rgbd360_plane> v;
     for (int i = 0; i < n; ++i)
-        if (well_formed(in[i])) v.push_back(in[i]);
+        if (well_formed(in[i]) && !(in[i].area < M.min_area) && !(in[i].elongation > M.max_elongation)) v.push_back(in[i]);
     for (size_t j = 0; j < v.size(); ++j) {
         if (!(v[j].curvature < M.max_curvature)) continue;
         bool merged = true;

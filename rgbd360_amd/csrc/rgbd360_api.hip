@@ -1882,11 +1882,11 @@ extern "C" int rgbd360_register_planes(const rgbd360_plane* ref, int n_ref, cons
     }
 }
 
-extern "C" int rgbd360_merge_planes(const rgbd360_plane* planes, int n, float max_curvature, float cos_normal, float dist_d, float proximity,
-                                    float normal_offset, rgbd360_plane* out, int max_out, int* n_out) {
+extern "C" int rgbd360_merge_planes(const rgbd360_plane* planes, int n, float max_curvature, float min_area, float max_elongation, float cos_normal,
+                                    float dist_d, float proximity, float normal_offset, rgbd360_plane* out, int max_out, int* n_out) {
     if (n < 0 || (n > 0 && !planes) || !out || !n_out || max_out < 0) return -1;
     try {
-        const pbm::MergeParams M{max_curvature, cos_normal, dist_d, proximity, normal_offset};
+        const pbm::MergeParams M{max_curvature, cos_normal, dist_d, proximity, normal_offset, min_area, max_elongation};
         const std::vector<rgbd360_plane> v = pbm::merge_planes(planes, n, M);
         *n_out = (int)v.size();
         if ((int)v.size() > max_out) return -1;

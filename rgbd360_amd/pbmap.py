@@ -62,14 +62,15 @@ def register_planes(ref_planes, trg_planes, max_match_planes: int = 0, regist_mo
                 area_matched=float(area.value))
 
 
-def merge_planes(planes, max_curvature=0.0013, cos_normal=0.99, dist_d=0.45, proximity=0.3, normal_offset=0.06):
-    """rgbd360_merge_planes (Frame360::mergePlanes, Frame360.h:655-733; defaults = its constants).  Returns the merged plane dicts."""
+def merge_planes(planes, max_curvature=0.0013, cos_normal=0.99, dist_d=0.45, proximity=0.3, normal_offset=0.06, min_area=0.12,
+                 max_elongation=6.0):
+    """rgbd360_merge_planes (Frame360::mergePlanes, Frame360.h:655-733, after the size filters of Frame360.h:1034,1041; defaults = the reference's constants).  Returns the merged plane dicts."""
     from .register import _planes_to_dicts
     L = _lib.load()
     arr = planes_to_array(planes)
     out = (_lib.Plane * max(len(planes), 1))()
     n = C.c_int(0)
-    rc = L.rgbd360_merge_planes(C.cast(arr, C.c_void_p), len(planes), max_curvature, cos_normal, dist_d, proximity, normal_offset,
+    rc = L.rgbd360_merge_planes(C.cast(arr, C.c_void_p), len(planes), max_curvature, min_area, max_elongation, cos_normal, dist_d, proximity, normal_offset,
                                 C.cast(out, C.c_void_p), len(planes), C.byref(n))
     if rc != 0:
         raise ValueError("rgbd360_merge_planes: bad arguments")

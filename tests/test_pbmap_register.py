@@ -327,6 +327,10 @@ def test_merge_planes_pools_the_pieces_of_one_surface():
         assert len(out) == 1 and out[0]["count"] == 6000 and abs(out[0]["area"] - 9.0) < 1e-2
         assert len(O.merge_planes(order)) == 1
     assert pbmap.merge_planes([]) == []
+    sliver = _rect_plane([0.0, 0.2, 2.5], n, pd, 2.0, 0.1, 300, 70)          # elongation 20: never stored by Frame360.h:1041
+    assert len(pbmap.merge_planes([left, sliver])) == 1 and len(O.merge_planes([left, sliver])) == 1
+    assert len(pbmap.merge_planes([left, sliver], max_elongation=100.0)) == 1   # (kept, and merged into the wall it lies on)
+    assert pbmap.merge_planes([left, sliver], max_elongation=100.0)[0]["count"] == 2300
 
 
 def test_merge_planes_random_sets_match_the_numpy_restatement():

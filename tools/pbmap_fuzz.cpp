@@ -84,11 +84,11 @@ int main(int argc, char** argv) {
                 if (!std::isfinite(pose[k])) { std::printf("non-finite pose at %d\n", it); return 1; }
         checksum += st * 1000 + nm + (st == 0 ? pose[12] : 0);
         // Frame360::mergePlanes on the same (hostile) list: never more planes than it was given, every output well formed
-        const pbm::MergeParams M{0.0013f, 0.99f, 0.45f, 0.3f, 0.06f};
+        const pbm::MergeParams M{0.0013f, 0.99f, 0.45f, 0.3f, 0.06f, 0.12f, 6.f};
         const std::vector<rgbd360_plane> merged = pbm::merge_planes(ref.data(), n_ref, M);
         if ((int)merged.size() > n_ref) { std::printf("merge grew the list at %d\n", it); return 1; }
         long long total_in = 0, total_out = 0;
-        for (const auto& p : ref) if (pbm::well_formed(p)) total_in += p.count > 0 ? p.count : 1;
+        for (const auto& p : ref) if (pbm::well_formed(p) && !(p.area < M.min_area) && !(p.elongation > M.max_elongation)) total_in += p.count > 0 ? p.count : 1;
         for (const auto& p : merged) {
             if (!std::isfinite(p.d) || !std::isfinite(p.normal[0]) || !std::isfinite(p.centroid[2])) { std::printf("merge produced a non-finite plane at %d\n", it); return 1; }
             total_out += p.count > 0 ? p.count : 1;
