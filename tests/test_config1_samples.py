@@ -144,3 +144,10 @@ def test_sample_pair_per_sensor_planes_with_the_bilateral_filter():
         assert float(frames[0][i]["normal"] @ frames[1][j]["normal"]) > 0.99  # offsets within the motion between the frames
         assert abs(float(frames[0][i]["d"]) - float(frames[1][j]["d"])) < 0.1
     assert r["status"] == 2
+    # Frame360::mergePlanes on the rig-frame pieces (the floor / ceiling / wall pieces of neighbouring sensors become single planes):
+    # fewer planes, the same verdict
+    merged = [pbmap.merge_planes(f) for f in frames]
+    assert all(3 <= len(m) < len(f) for m, f in zip(merged, frames))
+    rm = pbmap.register_planes(merged[0], merged[1], 25, pbmap.ODOMETRY_6DoF, pbmap.default_params(True))
+    print("planes per frame", [len(f) for f in frames], "merged", [len(m) for m in merged], "matched", len(r["match"]), len(rm["match"]), "status", rm["status"])
+    assert len(rm["match"]) >= 3 and rm["status"] in (0, 2)
