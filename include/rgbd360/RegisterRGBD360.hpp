@@ -26,21 +26,27 @@ struct PlaneList {                       // view of a frame's planes; the caller
 // Frame360::segmentPlanes / getPlanes (Frame360.h:615-720, 949-1075) for one range panorama: sphere cloud -> normal map ->
 // planar regions on the device (rgbd360_frame_planes), the plane list comes back to the host.  Parameters default to the
 // reference's (PCL set-up of Frame360.h:949-977: depth-change factor 0.02, smoothing 8, min_inliers 80, 0.0398 rad, 0.02 m;
-// max_curvature_plane of Miscellaneous.h:54); convention / depth_mode as in rgbd360_hip.h (2 / 1 = full sphere, range).
+// region curvature filter = PCL's default 0.001; max_curvature_plane of Miscellaneous.h:54 only enters at mergePlanes / setReference); convention / depth_mode as in rgbd360_hip.h (2 / 1 = full sphere, range).
 struct SegmentParams {
     int convention = 2, depth_mode = 1, min_inliers = 80, max_planes = 256;
     float max_depth_change_factor = 0.02f, normal_smoothing_size = 8.f, angular_threshold = 0.0398f, distance_threshold = 0.02f,
-          max_curvature = 0.0013f;
+          max_curvature = 0.001f;      // PCL's default region filter: the reference never calls mps.setMaximumCurvature (Frame360.h:958-977)
 };
 inline std::vector<rgbd360_plane> segmentPlanes(RegisterPhotoICP& reg, const ImageView& depth, const SegmentParams& sp = SegmentParams()) {
-    std::vector<rgbd360_plane> planes((size_t)sp.max_planes);
-    int n = 0;
+    std::vector<rgbd360_plane> planes;
+    int n = 0, cap = sp.max_planes;
     const int dt = depth.type == ImageView::U16C1 ? 0 : 1;
     rgbd360_ctx* ctx = reg.context();
-    const int rc = rgbd360_frame_planes(ctx, depth.data, depth.step, dt, depth.rows, depth.cols, sp.convention, sp.max_depth_change_factor,
-                                        sp.normal_smoothing_size, sp.min_inliers, sp.angular_threshold, sp.distance_threshold,
-                                        sp.max_curvature, sp.depth_mode, nullptr, nullptr, nullptr, planes.data(), sp.max_planes, &n);
-    if (rc != 0) throw std::runtime_error(std::string("rgbd360_frame_planes: ") + rgbd360_last_error(ctx));
+    for (int attempt = 0; attempt < 2; ++attempt) {      // the library keeps the largest `cap` regions and reports how many qualified: grow once
+        planes.resize((size_t)cap);
+        const int rc = rgbd360_frame_planes(ctx, depth.data, depth.step, dt, depth.rows, depth.cols, sp.convention, sp.max_depth_change_factor,
+                                            sp.normal_smoothing_size, sp.min_inliers, sp.angular_threshold, sp.distance_threshold,
+                                            sp.max_curvature, sp.depth_mode, nullptr, nullptr, nullptr, planes.data(), cap, &n);
+        if (rc != 0) throw std::runtime_error(std::string("rgbd360_frame_planes: ") + rgbd360_last_error(ctx));
+        const int avail = rgbd360_planes_available(ctx);
+        if (avail <= n) break;
+        cap = avail;
+    }
     planes.resize((size_t)n);
     return planes;
 }
@@ -53,18 +59,24 @@ struct SensorSegmentParams {
     float max_depth_change_factor = 0.02f, normal_smoothing_size = 8.f;         // Frame360.h:952-953
     int min_inliers = 80;                                                        // Frame360.h:960
     float angular_threshold = 0.0398f, distance_threshold = 0.02f;               // Frame360.h:961-962
-    float max_curvature = 0.0013f;                                               // Miscellaneous.h:54
+    float max_curvature = 0.001f;                                                // PCL default (no setMaximumCurvature call); 0.0013 = max_curvature_plane is the merge / subgraph filter
     int max_planes = 512;
 };
 inline std::vector<rgbd360_plane> segmentSensorPlanes(RegisterPhotoICP& reg, const float* xyz, int rows, int cols, const float* Rt = nullptr,
                                                       const SensorSegmentParams& sp = SensorSegmentParams()) {
-    std::vector<rgbd360_plane> planes((size_t)sp.max_planes);
-    int n = 0;
+    std::vector<rgbd360_plane> planes;
+    int n = 0, cap = sp.max_planes;
     rgbd360_ctx* ctx = reg.context();
-    const int rc = rgbd360_cloud_planes(ctx, xyz, rows, cols, sp.sigma_s, sp.sigma_r, sp.max_depth_change_factor, sp.normal_smoothing_size,
-                                        sp.min_inliers, sp.angular_threshold, sp.distance_threshold, sp.max_curvature, /*depth_mode=*/0, Rt,
-                                        planes.data(), sp.max_planes, &n);
-    if (rc != 0) throw std::runtime_error(std::string("rgbd360_cloud_planes: ") + rgbd360_last_error(ctx));
+    for (int attempt = 0; attempt < 2; ++attempt) {      // grow once when more regions qualified than the buffer holds
+        planes.resize((size_t)cap);
+        const int rc = rgbd360_cloud_planes(ctx, xyz, rows, cols, sp.sigma_s, sp.sigma_r, sp.max_depth_change_factor, sp.normal_smoothing_size,
+                                            sp.min_inliers, sp.angular_threshold, sp.distance_threshold, sp.max_curvature, /*depth_mode=*/0, Rt,
+                                            planes.data(), cap, &n);
+        if (rc != 0) throw std::runtime_error(std::string("rgbd360_cloud_planes: ") + rgbd360_last_error(ctx));
+        const int avail = rgbd360_planes_available(ctx);
+        if (avail <= n) break;
+        cap = avail;
+    }
     planes.resize((size_t)n);
     return planes;
 }
@@ -94,13 +106,17 @@ class RegisterRGBD360 {
 
     rgbd360_pbmap_params& params() { return params_; }
 
+    // The planes are COPIED (a few KB): the reference keeps Frame360 pointers whose owners outlive the registration; a view into
+    // a caller's temporary vector would dangle as soon as a later setReference / getPose re-runs the registration.
     void setReference(const PlaneList& ref, size_t max_match_planes = 0) {       // :110-157
-        ref_ = ref;
+        ref_own_.assign(ref.planes, ref.planes + (ref.planes ? ref.n : 0));
+        ref_ = PlaneList{ref_own_.data(), (int)ref_own_.size()};
         max_ref_ = max_match_planes;
         done_ = false;
     }
     void setTarget(const PlaneList& trg, size_t max_match_planes = 0) {          // :163-195
-        trg_ = trg;
+        trg_own_.assign(trg.planes, trg.planes + (trg.planes ? trg.n : 0));
+        trg_ = PlaneList{trg_own_.data(), (int)trg_own_.size()};
         max_trg_ = max_match_planes;
         done_ = false;
     }
@@ -216,6 +232,7 @@ class RegisterRGBD360 {
     }
 
     rgbd360_pbmap_params params_{};
+    std::vector<rgbd360_plane> ref_own_, trg_own_;       // owned copies; ref_ / trg_ view them
     PlaneList ref_{}, trg_{};
     size_t max_ref_ = 0, max_trg_ = 0;
     registrationType mode_ = DEFAULT_6DoF;

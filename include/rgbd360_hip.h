@@ -162,26 +162,8 @@ int rgbd360_warp_indices(rgbd360_ctx* ctx, int level, const float pose[16], int3
 int rgbd360_gn_step(rgbd360_ctx* ctx, const float H[36], const float g[6], float lambda, const float pose[16],
                     float pose_tmp[16], float update[6]);
 
-/* Forced schedule for throughput measurement: n_iters Gauss-Newton iterations on `level`
- * starting at pose0, every step applied regardless of the accept rule, no host round trip.  One iteration =
- * one fused pass + one solve launch.  Enqueued on the context's stream; *elapsed_ms (may be NULL) is the HIP
- * event time around the n_iters iterations. */
-int rgbd360_forced_iters(rgbd360_ctx* ctx, int level, const float pose0[16], int method, int n_iters,
-                         float pose_out[16], double* last_rms, float* elapsed_ms);
-/* Average duration in microseconds of `reps` back-to-back launches of the fused per-pixel kernel alone
- * (HIP events on the stream the kernel is launched on). want_hg = 0 times the error-only variant. */
-int rgbd360_time_eval_kernel(rgbd360_ctx* ctx, int level, const float pose[16], int method, int want_hg, int reps,
-                             float* avg_us);
-
-/* Same for the solve launch (mode 0: reduction + Gauss-Newton step, forced; mode 1: reduction only), re-using the
- * partials of the last pass. */
-int rgbd360_time_solve_kernel(rgbd360_ctx* ctx, int level, int mode, int reps, float* avg_us);
-
-/* Device self-test of the correctly rounded sqrt / reciprocal sequences the warp front end uses: compares them
- * with the compiler's IEEE sqrtf and 1.f/x for the `count` float bit patterns starting at `first_bits`;
- * mismatches[0] = sqrt, mismatches[1] = reciprocal, mismatches[2] = the round-half-up float->int conversion
- * against floor((double)x + 0.5) for |x| < 1e9 (both signs). */
-int rgbd360_selftest_math(rgbd360_ctx* ctx, uint32_t first_bits, uint32_t count, unsigned long long mismatches[3]);
+/* Measurement and self-test entry points (forced iteration schedule, kernel timers, device arithmetic self-test) are not part
+ * of the product ABI: include/rgbd360_hip_diag.h. */
 
 /* The HIP stream all work of this context is enqueued on (hipStream_t as void*). */
 void* rgbd360_stream(rgbd360_ctx* ctx);
@@ -240,10 +222,16 @@ typedef struct {
  * PlaneCoefficientComparator (depth-dependent distance threshold) + organised connected components + per-region
  * centroid / covariance / smallest eigenvector / curvature (the values Frame360.h:984-996 copies into
  * mrpt::pbmap::Plane).  labels_out (may be NULL): per pixel the region's root pixel index, -1 for non-finite points.
- * Planes are returned in PCL's order (by first pixel), at most max_planes. */
+ * Planes are returned in PCL's order (by first pixel), at most max_planes; when more regions pass the filters the
+ * max_planes LARGEST (inlier count) are kept, and rgbd360_planes_available reports how many there were. */
 int rgbd360_plane_fit(rgbd360_ctx* ctx, const float* xyz, const float* normals, int rows, int cols, int min_inliers,
                       float angular_threshold, float distance_threshold, float max_curvature, int depth_mode,
                       int32_t* labels_out, rgbd360_plane* planes_out, int max_planes, int* n_planes_out);
+
+/* Number of regions that passed every filter in the context's last plane call (rgbd360_plane_fit, _frame_planes[_dev],
+ * _cloud_planes, _sensor_planes); larger than the returned n_planes when the caller's max_planes cut the list -- grow the
+ * buffer and call again. */
+int rgbd360_planes_available(rgbd360_ctx* ctx);
 
 /* Range panorama -> sphere cloud -> normals -> planar regions in one call (cloud and normals stay on the device
  * between the stages); xyz_out / normals_out / labels_out may be NULL. */

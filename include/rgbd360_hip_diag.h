@@ -1,0 +1,40 @@
+/* rgbd360_hip_diag.h -- measurement and self-test entry points of librgbd360_hip.so (RGBD360_DIAG).
+ *
+ * Not part of the drop-in boundary (include/rgbd360_hip.h): nothing the reference's RegisterPhotoICP / Frame360 callers would
+ * bind.  bench.py uses the forced schedule and the kernel timers, the GPU test-suite the arithmetic self-test; a deployment
+ * may strip them.
+ */
+#ifndef RGBD360_HIP_DIAG_H
+#define RGBD360_HIP_DIAG_H
+
+#include "rgbd360_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Forced schedule for throughput measurement: n_iters Gauss-Newton iterations on `level`
+ * starting at pose0, every step applied regardless of the accept rule, no host round trip.  One iteration =
+ * one fused pass + one solve launch.  Enqueued on the context's stream; *elapsed_ms (may be NULL) is the HIP
+ * event time around the n_iters iterations. */
+int rgbd360_forced_iters(rgbd360_ctx* ctx, int level, const float pose0[16], int method, int n_iters,
+                         float pose_out[16], double* last_rms, float* elapsed_ms);
+/* Average duration in microseconds of `reps` back-to-back launches of the fused per-pixel kernel alone
+ * (HIP events on the stream the kernel is launched on). want_hg = 0 times the error-only variant. */
+int rgbd360_time_eval_kernel(rgbd360_ctx* ctx, int level, const float pose[16], int method, int want_hg, int reps,
+                             float* avg_us);
+
+/* Same for the solve launch (mode 0: reduction + Gauss-Newton step, forced; mode 1: reduction only), re-using the
+ * partials of the last pass. */
+int rgbd360_time_solve_kernel(rgbd360_ctx* ctx, int level, int mode, int reps, float* avg_us);
+
+/* Device self-test of the correctly rounded sqrt / reciprocal sequences the warp front end uses: compares them
+ * with the compiler's IEEE sqrtf and 1.f/x for the `count` float bit patterns starting at `first_bits`;
+ * mismatches[0] = sqrt, mismatches[1] = reciprocal, mismatches[2] = the round-half-up float->int conversion
+ * against floor((double)x + 0.5) for |x| < 1e9 (both signs). */
+int rgbd360_selftest_math(rgbd360_ctx* ctx, uint32_t first_bits, uint32_t count, unsigned long long mismatches[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RGBD360_HIP_DIAG_H */

@@ -232,9 +232,9 @@ def merge_planes(planes, max_curvature=0.0013, cos_normal=0.99, dist_d=0.45, pro
     v = [dict(p) for p in planes if not _f32(p["area"]) < _f32(min_area) and not _f32(p["elongation"]) > _f32(max_elongation)]
     j = 0
     while j < len(v):
-        if _f32(v[j]["curvature"]) < _f32(max_curvature):
+        if True:
             merged = True
-            while merged:
+            while merged and _f32(v[j]["curvature"]) < _f32(max_curvature):      # Frame360.h:663 re-tested after every merge (`j--`, :727-731)
                 merged = False
                 for k in range(j + 1, len(v)):
                     if not _f32(v[k]["curvature"]) < _f32(max_curvature) or not _same_surface(v[j], v[k], cos_normal, dist_d, proximity, normal_offset):

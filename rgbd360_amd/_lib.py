@@ -17,7 +17,7 @@ SYMBOLS = [
     "rgbd360_plane_fit", "rgbd360_frame_planes", "rgbd360_frame_planes_dev", "rgbd360_load_frame_bin", "rgbd360_stitch_sphere",
     "rgbd360_set_camera", "rgbd360_align_pinhole", "rgbd360_eval_pinhole", "rgbd360_warp_indices_pinhole",
     "rgbd360_pbmap_default_params", "rgbd360_register_planes", "rgbd360_bilateral_filter",
-    "rgbd360_cloud_planes", "rgbd360_sensor_cloud", "rgbd360_sensor_planes", "rgbd360_merge_planes",
+    "rgbd360_cloud_planes", "rgbd360_sensor_cloud", "rgbd360_sensor_planes", "rgbd360_merge_planes", "rgbd360_planes_available",
 ]
 
 
@@ -119,5 +119,6 @@ def load() -> C.CDLL:
     L.rgbd360_pbmap_default_params.restype = None
     L.rgbd360_register_planes.argtypes = [vp, i32, vp, i32, i32, i32, C.POINTER(PbmapParams), vp, vp, vp, C.POINTER(i32),
                                           C.POINTER(C.c_float)]
+    L.rgbd360_planes_available.argtypes = [vp]
     _lib = L
     return L

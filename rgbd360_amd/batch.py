@@ -83,27 +83,41 @@ def align_sequence_native(reg, get_frame, lo: int, hi: int, method: int, guess=N
     return reg.alignSequence(frames, method=method, occlusion=occlusion, pose_guess=guess, n_inflight=n_inflight)
 
 
-def gather_poses(local_poses: np.ndarray, n_total: int, dist=None, device=None):
-    """All-gather of the per-rank pose blocks into the full [n_total,4,4] array on every rank."""
+def gather_poses(local_poses: np.ndarray, n_total: int, dist=None, device=None, status=None, iters=None):
+    """All-gather of the per-rank result blocks into full arrays on every rank: poses [n_total,4,4]; with `status` ([n] int) and
+    `iters` ([n, n_pyr] int) given, the tuple (poses, status, iters) -- a pair's non-zero status must survive the exchange.
+    One collective: every pair travels as a row of 16 + 1 + 8 float32 (status and iteration counts are small integers)."""
+    want_meta = status is not None or iters is not None
+    n_loc = local_poses.shape[0]
+    st = np.zeros(n_loc, np.int32) if status is None else np.asarray(status, np.int32).reshape(n_loc)
+    it = np.zeros((n_loc, 0), np.int32) if iters is None else np.asarray(iters, np.int32).reshape(n_loc, -1)
+    assert it.shape[1] <= 8
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        assert local_poses.shape[0] == n_total
-        return local_poses.copy()
+        assert n_loc == n_total
+        return (local_poses.copy(), st.copy(), it.copy()) if want_meta else local_poses.copy()
     import torch
     world, rank = dist.get_world_size(), dist.get_rank()
     max_chunk = (n_total + world - 1) // world
-    buf = torch.zeros(max_chunk * 16, dtype=torch.float32, device=device)
+    ROW = 25
     lo, hi = shard_range(n_total, rank, world)
-    assert local_poses.shape[0] == hi - lo
-    if hi > lo:
-        buf[: (hi - lo) * 16] = torch.from_numpy(np.ascontiguousarray(local_poses, np.float32).reshape(-1)).to(buf.device)
-    out = torch.empty(world * max_chunk * 16, dtype=torch.float32, device=device)
+    assert n_loc == hi - lo
+    rows = np.zeros((max_chunk, ROW), np.float32)
+    rows[:n_loc, :16] = np.ascontiguousarray(local_poses, np.float32).reshape(n_loc, 16)
+    rows[:n_loc, 16] = st
+    rows[:n_loc, 17:17 + it.shape[1]] = it
+    buf = torch.from_numpy(rows.reshape(-1)).to(device) if device is not None else torch.from_numpy(rows.reshape(-1))
+    out = torch.empty(world * max_chunk * ROW, dtype=torch.float32, device=device)
     dist.all_gather_into_tensor(out, buf)
-    out = out.cpu().numpy().reshape(world, max_chunk, 4, 4)
+    out = out.cpu().numpy().reshape(world, max_chunk, ROW)
     full = np.zeros((n_total, 4, 4), np.float32)
+    full_st = np.zeros(n_total, np.int32)
+    full_it = np.zeros((n_total, it.shape[1]), np.int32)
     for r in range(world):
         a, b = shard_range(n_total, r, world)
-        full[a:b] = out[r, : b - a]
-    return full
+        full[a:b] = out[r, : b - a, :16].reshape(b - a, 4, 4)
+        full_st[a:b] = np.rint(out[r, : b - a, 16]).astype(np.int32)
+        full_it[a:b] = np.rint(out[r, : b - a, 17:17 + it.shape[1]]).astype(np.int32)
+    return (full, full_st, full_it) if want_meta else full
 
 
 def compose_trajectory(rel_poses: np.ndarray, first=None) -> np.ndarray:

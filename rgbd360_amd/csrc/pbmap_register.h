@@ -439,9 +439,10 @@ inline std::vector<rgbd360_plane> merge_planes(const rgbd360_plane* in, int n, c
     for (int i = 0; i < n; ++i)
         if (well_formed(in[i]) && !(in[i].area < M.min_area) && !(in[i].elongation > M.max_elongation)) v.push_back(in[i]);
     for (size_t j = 0; j < v.size(); ++j) {
-        if (!(v[j].curvature < M.max_curvature)) continue;
         bool merged = true;
-        while (merged) {                                                          // :727-731 re-evaluate plane j after every merge
+        // :727-731 re-evaluate plane j after every merge (`j--`): the outer curvature test (:663) runs again on the pooled fit, so a
+        // plane whose curvature has risen above the limit stops absorbing neighbours
+        while (merged && v[j].curvature < M.max_curvature) {
             merged = false;
             for (size_t k = j + 1; k < v.size(); ++k) {
                 if (!(v[k].curvature < M.max_curvature) || !same_surface(v[j], v[k], M)) continue;

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "../../include/rgbd360_hip.h"
+#include "../../include/rgbd360_hip_diag.h"
 #include "photo_icp_kernels.h"
 #include "occlusion_kernels.h"
 #include "pinhole_kernels.h"
@@ -79,6 +80,7 @@ struct rgbd360_ctx {
     size_t f_tab_n = 0;
     int f_tab_rows = 0, f_tab_cols = 0, f_tab_conv = -1;      // what the resident angle tables were built for
     uint8_t* f_depth_raw = nullptr;
+    int f_planes_available = 0;     // regions that passed every filter in the last plane call (may exceed the caller's max_planes)
     float al_guess[16] = {0};     // alignment in flight (rgbd360_align360_begin / _finish)
     int al_method = 0;
     bool al_active = false;
@@ -1403,8 +1405,12 @@ int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float
     std::vector<int> order(nslots);
     for (int s = 0; s < nslots; ++s) order[s] = s;
     std::sort(order.begin(), order.end(), [&](int a, int c) { return roots[a] < roots[c]; });   // PCL's order: by first pixel
-    int np = 0;
-    for (int oi = 0; oi < nslots && np < max_planes; ++oi) {
+    // Planes are built for every region first: when more than max_planes pass the curvature filter the LARGEST ones are kept
+    // (still in PCL's order) instead of the first -- the regions lowest in the image (typically the floor) used to be the ones
+    // cut -- and the total is remembered for rgbd360_planes_available so that an adapter can grow its buffer and call again.
+    std::vector<rgbd360_plane> all;
+    all.reserve(nslots);
+    for (int oi = 0; oi < nslots; ++oi) {
         const int s = order[oi];
         const double* m = &mom[(size_t)s * 9];
         const double N = counts[s];
@@ -1424,7 +1430,8 @@ int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float
         const double tr = C[0][0] + C[1][1] + C[2][2];
         const double curvature = tr != 0 ? fabs(ev / tr) : 0;
         if (!(curvature < max_curvature)) continue;
-        rgbd360_plane& P = planes[np++];
+        all.emplace_back();
+        rgbd360_plane& P = all.back();
         P.centroid[0] = (float)cx; P.centroid[1] = (float)cy; P.centroid[2] = (float)cz;
         P.normal[0] = (float)v[0]; P.normal[1] = (float)v[1]; P.normal[2] = (float)v[2];
         P.d = (float)d;
@@ -1435,6 +1442,19 @@ int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float
         P.area = (float)(12.0 * sqrt(l1 * l2));
         P.elongation = (float)(l1 > 0 ? sqrt(l2 / l1) : INFINITY);
         for (int k = 0; k < 3; ++k) P.ppal_dir[k] = (float)vecs[2][k];
+    }
+    ctx->f_planes_available = (int)all.size();
+    int np = 0;
+    if ((int)all.size() <= max_planes) {
+        for (const rgbd360_plane& P : all) planes[np++] = P;
+    } else {
+        std::vector<int> by_count(all.size());
+        for (size_t k = 0; k < all.size(); ++k) by_count[k] = (int)k;
+        std::stable_sort(by_count.begin(), by_count.end(), [&](int a, int c) { return all[a].count > all[c].count; });
+        std::vector<char> keep(all.size(), 0);
+        for (int k = 0; k < max_planes; ++k) keep[by_count[k]] = 1;
+        for (size_t k = 0; k < all.size(); ++k)
+            if (keep[k]) planes[np++] = all[k];
     }
     *n_planes = np;
     return 0;
@@ -1594,6 +1614,8 @@ extern "C" int rgbd360_distance_map(rgbd360_ctx* ctx, const float* xyz, int rows
     HIPC(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
+
+extern "C" int rgbd360_planes_available(rgbd360_ctx* ctx) { return ctx ? ctx->f_planes_available : -1; }
 
 extern "C" int rgbd360_plane_fit(rgbd360_ctx* ctx, const float* xyz, const float* normals, int rows, int cols, int min_inliers,
                                  float angular_threshold, float distance_threshold, float max_curvature, int depth_mode,

@@ -433,7 +433,7 @@ class Frame360Stages:
         return out.reshape(rows // step, cols // step, 3)
 
     def sensor_planes(self, depth_mm, step=2, min_depth=0.3, max_depth=10.0, sigma_s=10.0, sigma_r=0.05, max_depth_change_factor=0.02,
-                      normal_smoothing_size=8.0, min_inliers=80, angular_threshold=0.0398, distance_threshold=0.02, max_curvature=0.0013,
+                      normal_smoothing_size=8.0, min_inliers=80, angular_threshold=0.0398, distance_threshold=0.02, max_curvature=0.001,
                       Rt=None, max_planes=512):
         """rgbd360_sensor_planes: sensor_cloud + cloud_planes in one call (the cloud never leaves the device)."""
         d = np.asarray(depth_mm)
@@ -450,10 +450,10 @@ class Frame360Stages:
         return _planes_to_dicts(arr, n.value)
 
     def cloud_planes(self, xyz, rows, cols, sigma_s=10.0, sigma_r=0.05, max_depth_change_factor=0.02, normal_smoothing_size=8.0,
-                     min_inliers=80, angular_threshold=0.0398, distance_threshold=0.02, max_curvature=0.0013, depth_mode=0, Rt=None,
+                     min_inliers=80, angular_threshold=0.0398, distance_threshold=0.02, max_curvature=0.001, depth_mode=0, Rt=None,
                      max_planes=512):
         """rgbd360_cloud_planes: one sensor cloud -> (bilateral filter) -> normal map -> planar regions -> planes in the rig frame
-        (defaults = Frame360.h:493-499, 949-977, Miscellaneous.h:54).  Rt: 4x4 sensor -> rig (row-major numpy) or None."""
+        (defaults = Frame360.h:493-499, 949-977; region curvature filter = PCL's default 0.001, the reference never sets it).  Rt: 4x4 sensor -> rig (row-major numpy) or None."""
         xyz = np.ascontiguousarray(xyz, np.float32).reshape(rows * cols, 3)
         arr = (_lib.Plane * max_planes)()
         n = C.c_int()

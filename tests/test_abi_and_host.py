@@ -36,11 +36,19 @@ def test_library_exports_every_declared_symbol(built_lib):
 
 
 def test_no_torch_types_in_the_abi():
-    txt = open(os.path.join(ROOT, "include", "rgbd360_hip.h")).read()
-    assert 'extern "C"' in txt
-    code = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)          # declarations only, comments stripped
-    for banned in ("torch", "at::", "std::", "Tensor", "hipStream_t", "template"):
-        assert banned not in code, banned
+    for hdr in ("rgbd360_hip.h", "rgbd360_hip_diag.h"):
+        txt = open(os.path.join(ROOT, "include", hdr)).read()
+        assert 'extern "C"' in txt
+        code = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)          # declarations only, comments stripped
+        for banned in ("torch", "at::", "std::", "Tensor", "hipStream_t", "template"):
+            assert banned not in code, (hdr, banned)
+
+
+def test_measurement_entry_points_live_in_the_diag_header():
+    """The product ABI (rgbd360_hip.h) carries no timers / self-tests / forced schedules: those are rgbd360_hip_diag.h."""
+    main = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "rgbd360_hip.h")).read(), flags=re.S)
+    for name in ("rgbd360_time_eval_kernel", "rgbd360_time_solve_kernel", "rgbd360_selftest_math", "rgbd360_forced_iters"):
+        assert name not in main, name
 
 
 def test_default_params_match_reference_defaults(built_lib):

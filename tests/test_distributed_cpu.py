@@ -34,9 +34,9 @@ class FakeReg:
 
     def alignFrames360(self, guess, method):
         assert self.cur_src == self.cur_trg + 1
-        self.num_iterations = [1, 2, 3]
+        self.num_iterations = [1, 2, 3 + self.cur_trg]
         self._pose = fake_pose(self.cur_trg)
-        return 0
+        return 1 if self.cur_trg == 5 else 0          # pair 5 reports ILL-POSED: the status must survive the exchange
 
     def getOptimalPose(self):
         return self._pose
@@ -61,7 +61,7 @@ def test_align_sequence_reuses_frames_inside_a_chunk():
     from rgbd360_amd.batch import align_sequence
     reg = FakeReg()
     poses, status, iters = align_sequence(reg, get_frame, 3, 7, 2)
-    assert poses.shape == (4, 4, 4) and (status == 0).all() and iters.shape == (4, 3)
+    assert poses.shape == (4, 4, 4) and list(status) == [0, 0, 1, 0] and iters.shape == (4, 3)
     assert [c for c in reg.calls if c[0] == "T"] == [("T", 3)]          # one target upload per chunk
     assert [c[1] for c in reg.calls if c[0] == "S"] == [4, 5, 6, 7]
     assert [c[1] for c in reg.calls if c[0] == "P"] == [4, 5, 6]
@@ -78,8 +78,11 @@ def _worker(rank, world, port, n_pairs, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lo, hi = shard_range(n_pairs, rank, world)
     poses, status, iters = align_sequence(FakeReg(), get_frame, lo, hi, 2)
-    full = gather_poses(poses, n_pairs, dist)
+    full, full_st, full_it = gather_poses(poses, n_pairs, dist, status=status, iters=iters)
+    assert np.array_equal(gather_poses(poses, n_pairs, dist), full)           # poses-only form: same collective, same result
     np.save(os.path.join(out_dir, "full_%d.npy" % rank), full)
+    np.save(os.path.join(out_dir, "status_%d.npy" % rank), full_st)
+    np.save(os.path.join(out_dir, "iters_%d.npy" % rank), full_it)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -97,6 +100,10 @@ def test_two_rank_gloo_gather_equals_single_process(tmp_path, n_pairs):
     for r in range(2):
         full = np.load(tmp_path / ("full_%d.npy" % r))
         assert np.array_equal(full, ref)                               # every rank holds every pose, in pair order
+        st = np.load(tmp_path / ("status_%d.npy" % r))
+        assert list(st) == [1 if i == 5 else 0 for i in range(n_pairs)]
+        it = np.load(tmp_path / ("iters_%d.npy" % r))
+        assert np.array_equal(it, np.array([[1, 2, 3 + i] for i in range(n_pairs)]))
     traj = compose_trajectory(ref)
     assert traj.shape == (n_pairs + 1, 4, 4)
     assert np.allclose(traj[3], ref[0].astype(np.float64) @ ref[1] @ ref[2])

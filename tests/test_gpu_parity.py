@@ -42,6 +42,20 @@ def _pair_ctx(hip_lib, oracle_mod, pair, n_pyr=3, math_mode=1):
     return reg, ora, T
 
 
+def _assert_libm_oracle_agrees(reg, ora, method, n_pyr):
+    """The reference-faithful oracle (math_mode 0: libm asinf / atan2f / roundf as RPI.h:2674-2680 writes them; reduce_mode 0:
+    the reference's float32 accumulators) against the pose the device has just produced: the north-star tolerance and the
+    same accept / reject sequence (iterations per level)."""
+    pose_gpu, iters_gpu = reg.getOptimalPose(), list(reg.num_iterations)
+    ora.set_modes(0, 0)
+    st, pose_libm = ora.align360(np.eye(4), method)
+    assert st == 0
+    assert iters_gpu == list(ora.result.iters)[:n_pyr], (iters_gpu, list(ora.result.iters)[:n_pyr])
+    rot, trans = synth.pose_error(pose_gpu, pose_libm)
+    assert rot <= ROT_TOL and trans <= TRANS_TOL, (rot, trans)
+    ora.set_modes(1, 1)      # back to the device-arithmetic mode the exact-count checks use
+
+
 def _poses(T_gt):
     rng = np.random.default_rng(5)
     out = [np.eye(4), np.asarray(T_gt)]
@@ -219,10 +233,12 @@ def test_full_size_2048x1024(hip_lib, oracle_mod, method):
     rc = reg.alignFrames360(np.eye(4), method)
     st, pose_ref = ora.align360(np.eye(4), method)
     assert rc == st == 0
+    assert reg.num_iterations == list(ora.result.iters)[:4]
     rot, trans = synth.pose_error(reg.getOptimalPose(), pose_ref)
-    assert rot <= ROT_TOL and trans <= TRANS_TOL, (rot, trans)
+    assert rot <= POSE_TOL_DEV and trans <= POSE_TOL_DEV, (rot, trans)
     rot_gt, trans_gt = synth.pose_error(reg.getOptimalPose(), T)
     assert rot_gt < 5e-4 and trans_gt < 2e-3, (rot_gt, trans_gt)
+    _assert_libm_oracle_agrees(reg, ora, method, 4)
     # size-independent property: re-running is bitwise reproducible (fixed-order reductions, no atomics)
     pose1 = reg.getOptimalPose()
     reg.alignFrames360(np.eye(4), method)
@@ -248,6 +264,7 @@ def test_full_size_4096x2048_with_planes(hip_lib, oracle_mod):
     assert rot <= POSE_TOL_DEV and trans <= POSE_TOL_DEV, (rot, trans)
     rot_gt, trans_gt = synth.pose_error(reg.getOptimalPose(), T)
     assert rot_gt < 2e-4 and trans_gt < 1e-3, (rot_gt, trans_gt)
+    _assert_libm_oracle_agrees(reg, ora, 2, 5)
     e = reg.eval(0, pose_ref, 2)
     _, err2, nvalid = ora.error(0, pose_ref, 2)
     H, g, Hd, gd, nvis = ora.hessgrad(0, pose_ref, 2)
