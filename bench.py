@@ -8,10 +8,19 @@ Step      = one level-0 Gauss-Newton iteration of RegisterPhotoICP::alignFrames3
             spherical pair (BASELINE.json configs[1]: photometric-only), in the forced schedule of BASELINE.md §2
             (accept rule evaluated, step applied regardless): one fused warp+residual+Jacobian pass over every
             source pixel + the 6x6 solve / pose update launch.  Frames are resident in HBM before the timed region.
-N > 1     = every rank aligns its own independent pair (weak scaling) and the solved poses are all-gathered
-            (RCCL) inside the timed region.
+value     = N * K / t, t = the MEDIAN over `--repeats` timed regions of exactly K steps each (every region bracketed by a
+            barrier + device synchronisation on both sides, the maximum over the ranks taken per region): with the driver's
+            K = 20 a single region is 0.4 ms of wall time, far too short to be one sample.
+N > 1     = weak scaling of `value` (every rank iterates on its own pair, the solved poses are all-gathered over RCCL inside
+            every timed region), AND the `sequence` block: BASELINE.json configs[3] itself -- 256 consecutive pairs of an
+            odometry sequence in contiguous shards over the ranks, every rank aligning its shard with the library's sequence
+            entry, one all-gather of poses / status / iteration counts -- as alignments/s of the whole job.
 roofline  = algorithmic bytes of the fused kernel (28 B/px photo, 40 B/px photo+depth, LUT variant)
-            / its average launch duration measured with HIP events on the library's own stream.
+            / its average launch duration measured with HIP events on the library's own stream.  At 2048x1024 the kernel's
+            working set (84 MB) stays in the 256 MiB Infinity Cache between back-to-back launches: `roofline.resident` says so,
+            `roofline_hbm_rotating` repeats the measurement rotating over 5 copies of the pair (420 MB: every launch HBM-fed),
+            and `roofline_4096x2048` (335 MB photo+depth) is the single-pair HBM figure.
+iteration = the same bytes over the whole step (pass + solve launch + gaps).
 cpu_baseline = the CPU oracle (restatement of the reference algorithm, OpenMP) on the same workload, bounded sample.
 """
 from __future__ import annotations
@@ -19,6 +28,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -30,15 +40,42 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0          # measured float4 copy (same guide)
+LLC_BYTES = 256 * 1024 * 1024  # Infinity Cache
 BYTES_PER_PX = {0: 28, 1: 28, 2: 40}   # LUT variant: 16 B source record + 12 B (24 B) gathered target records
+WORKING_SET_PER_PX = {0: 28, 1: 28, 2: 40}
 METHOD_NAMES = {0: "PHOTO_CONSISTENCY", 1: "DEPTH_CONSISTENCY", 2: "PHOTO_DEPTH"}
+SEQ_UNIQUE_FRAMES = 9          # frames rendered per rank for the sequence block (walked back and forth)
 
 
-def avg_kernel_us(reg, level, pose, method, reps, batches=5):
-    """Average launch duration of the fused kernel (HIP events on the library's stream around `reps` back-to-back launches);
-    the median of `batches` such averages, so that one disturbed batch (another process touching the device) cannot skew it."""
-    vals = sorted(reg.time_eval_kernel(level, pose, method, True, reps) for _ in range(batches))
+def avg_kernel_us(fn, batches=5):
+    """Median of `batches` averages (each over back-to-back launches between two HIP events on the library's stream), so
+    that one disturbed batch (another process touching the device) cannot skew it; all batches are reported."""
+    vals = sorted(fn() for _ in range(batches))
     return vals[len(vals) // 2], vals
+
+
+def roofline_entry(us, batches, n_px, method, **extra):
+    alg = BYTES_PER_PX[method] * n_px
+    ach = alg / (us * 1e-6) / 1e9
+    slow = max(batches)
+    d = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+         "kernel": "k_eval<%d,true>" % method, "kernel_avg_us": us, "kernel_avg_us_batches": batches,
+         "frac_slowest_batch": alg / (slow * 1e-6) / 1e9 / HBM_PEAK_GBS,
+         "algorithmic_bytes_per_launch": alg, "bytes_per_pixel": BYTES_PER_PX[method],
+         "frac_of_measured_copy_peak": ach / HBM_COPY_GBS}
+    d.update(extra)
+    return d
+
+
+def pingpong(n_pairs, n_unique):
+    """Frame indices 0,1,..,n_unique-1,n_unique-2,..,0,1,.. : n_pairs + 1 entries, consecutive entries always neighbours."""
+    idx, k, step = [], 0, 1
+    for _ in range(n_pairs + 1):
+        idx.append(k)
+        if k + step < 0 or k + step >= n_unique:
+            step = -step
+        k += step
+    return idx
 
 
 def main():
@@ -46,11 +83,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--repeats", type=int, default=25, help="timed regions of exactly --steps steps; the median is reported")
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--method", type=int, default=0, help="0 photo (configs[1]), 2 photo+depth (configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-4k", action="store_true", help="skip the extra 4096x2048 (configs[4]) kernel measurement")
+    ap.add_argument("--no-sequence", action="store_true", help="skip the configs[3] sequence block")
+    ap.add_argument("--no-native-multi", action="store_true", help="skip the single-process multi-GPU entry (child process)")
+    ap.add_argument("--seq-pairs", type=int, default=256, help="pairs of the configs[3] sequence (whole job)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -81,6 +122,7 @@ def main():
     xdev = "cpu" if share else "cuda"       # where the exchanged tensors live
 
     from rgbd360_amd import synth
+    from rgbd360_amd.batch import gather_poses, shard_range
     from rgbd360_amd.register import RegisterPhotoICP
 
     W, H, method = args.width, args.height, args.method
@@ -95,13 +137,12 @@ def main():
     reg.setSourceFrame(rgbB, dB)
     reg.sync()
 
-    # full coarse-to-fine alignment once (natural accept/reject schedule): pose + the level-0 starting pose
-    t0 = time.time()
-    rc = reg.alignFrames360(np.eye(4), method)
-    t_align = time.time() - t0
-    t0 = time.time()
-    rc = reg.alignFrames360(np.eye(4), method)
-    t_align = min(t_align, time.time() - t0)
+    # full coarse-to-fine alignment (natural accept/reject schedule): pose + per-level iteration counts
+    t_align = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        rc = reg.alignFrames360(np.eye(4), method)
+        t_align.append(time.perf_counter() - t0)
     pose_gpu = reg.getOptimalPose()
     iters_nat = list(reg.num_iterations)
     start_pose = np.eye(4)     # forced schedule starts from the identity guess at level 0
@@ -111,7 +152,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- warmup, then EXACTLY K steps ------------------------------------------------------------------------
+    # ---- warmup, then `repeats` timed regions of EXACTLY K steps ---------------------------------------------
     reg.forced_iters(0, start_pose, method, max(args.warmup, 1))
     if dist is not None:
         # warm the exchange too: the first RCCL all-gather builds channels / loads kernels, which must not be timed
@@ -120,22 +161,27 @@ def main():
         dist.all_gather_into_tensor(w_out, w_in)
         w_t = torch.zeros(1, dtype=torch.float64, device=xdev)
         dist.all_reduce(w_t, op=dist.ReduceOp.MAX)
-    sync_all()
-    t0 = time.perf_counter()
-    out = reg.forced_iters(0, start_pose, method, args.steps)
+    repeats = max(args.repeats, 1)
+    elapsed_all = []
     poses = None
+    for _ in range(repeats):
+        sync_all()
+        t0 = time.perf_counter()
+        out = reg.forced_iters(0, start_pose, method, args.steps)
+        if dist is not None:
+            mine = torch.from_numpy(out["pose"].reshape(16).copy()).to(xdev)
+            gathered = torch.empty(world * 16, dtype=torch.float32, device=xdev)
+            dist.all_gather_into_tensor(gathered, mine)      # RCCL over xGMI: the path's one exchange step
+            poses = gathered
+        sync_all()
+        elapsed_all.append(time.perf_counter() - t0)
     if dist is not None:
-        mine = torch.from_numpy(out["pose"].reshape(16).copy()).to(xdev)
-        gathered = torch.empty(world * 16, dtype=torch.float32, device=xdev)
-        dist.all_gather_into_tensor(gathered, mine)      # RCCL over xGMI: the path's one exchange step
-        poses = gathered
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        tmax = torch.tensor(elapsed_all, dtype=torch.float64, device=xdev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)          # per region: the slowest rank
+        elapsed_all = [float(x) for x in tmax.cpu()]
         assert poses is not None and bool(torch.isfinite(poses).all())
+    srt = sorted(elapsed_all)
+    elapsed = srt[len(srt) // 2]
 
     value = n_gpus * args.steps / elapsed
     result = {
@@ -157,13 +203,30 @@ def main():
             "width": W, "height": H, "method": METHOD_NAMES[method], "n_pyr": 4,
             "pairs_per_gpu": 1, "parallelism": "independent pairs per GPU, RCCL all-gather of poses" if world > 1 else "1 GPU",
         },
+        "timed_regions": {"repeats": repeats, "steps_each": args.steps, "statistic": "median of per-region max over ranks",
+                          "elapsed_s_min": srt[0], "elapsed_s_median": elapsed, "elapsed_s_max": srt[-1],
+                          "value_from_fastest_region": n_gpus * args.steps / srt[0],
+                          "value_from_slowest_region": n_gpus * args.steps / srt[-1]},
     }
+
+    # ---- BASELINE.json configs[3]: the odometry sequence, contiguous shards of pairs over the ranks ----------
+    seq_block = None
+    if not args.no_sequence:
+        seq_block = run_sequence_block(args, torch, dist, synth, reg, rank, world, local_rank, xdev, W, H, gather_poses, shard_range, sync_all)
+        if rank == 0:
+            result["sequence"] = seq_block
+
+    # every collective is behind us: the other ranks leave, rank 0 goes on alone (kernel timers, the child process of the
+    # single-process multi-GPU entry, the CPU baseline) with no rank waiting on it
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+        dist = None
 
     if rank == 0:
         # ---- roofline of the dominant kernel: HIP events on the library's stream -----------------------------
-        kernel_us, kernel_batches = avg_kernel_us(reg, 0, pose_gpu, method, 50)
-        alg_bytes = BYTES_PER_PX[method] * n_px
-        achieved = alg_bytes / (kernel_us * 1e-6) / 1e9
+        ws = WORKING_SET_PER_PX[method] * n_px
+        kernel_us, kernel_batches = avg_kernel_us(lambda: reg.time_eval_kernel(0, pose_gpu, method, True, 50))
         traffic = None
         tr_path = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tr_path):
@@ -173,25 +236,49 @@ def main():
                 traffic = tr.get(key, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        result["roofline"] = {
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "kernel": "k_eval<%d,true>" % method, "kernel_avg_us": kernel_us, "kernel_avg_us_batches": kernel_batches,
-            "algorithmic_bytes_per_launch": alg_bytes, "bytes_per_pixel": BYTES_PER_PX[method],
-            "frac_of_measured_copy_peak": achieved / HBM_COPY_GBS,
-        }
+        result["roofline"] = roofline_entry(
+            kernel_us, kernel_batches, n_px, method, traffic=traffic,
+            resident=("infinity_cache" if ws < LLC_BYTES else "hbm"),
+            note=("back-to-back launches over one pair: the %.0f MB working set stays in the 256 MiB Infinity Cache, which is the "
+                  "regime of the product path (every iteration of a level re-reads the same pair); peak is still the HBM spec "
+                  "figure.  roofline_hbm_rotating / roofline_4096x2048 are the HBM-fed measurements." % (ws / 1e6)) if ws < LLC_BYTES else "")
+        # the same kernel with every launch HBM-fed: rotate over enough copies of the pair to exceed the Infinity Cache
+        n_rot = max(2, int(np.ceil(1.6 * LLC_BYTES / ws)))
+        rot = [reg]
+        for _ in range(n_rot - 1):
+            r2 = RegisterPhotoICP(device=local_rank)
+            r2.setNumPyr(4)
+            r2.setTargetFrame(rgbA, dA)
+            r2.setSourceFrame(rgbB, dB)
+            rot.append(r2)
+        result["roofline_hbm_rotating"] = {}
+        for m in sorted({method, 2}):
+            us, bt = avg_kernel_us(lambda: RegisterPhotoICP.time_eval_kernel_rotating(rot, 0, pose_gpu, m, True, 10 * n_rot))
+            result["roofline_hbm_rotating"][METHOD_NAMES[m]] = roofline_entry(
+                us, bt, n_px, m, resident="hbm", copies=n_rot, rotating_working_set_bytes=n_rot * WORKING_SET_PER_PX[m] * n_px)
+        for r2 in rot[1:]:
+            r2.close()
         # same kernel in photo+depth mode (configs[2]) for reference
         other = 2 if method == 0 else 0
-        k2, _ = avg_kernel_us(reg, 0, pose_gpu, other, 50)
-        result["roofline_other_method"] = {
-            "method": METHOD_NAMES[other], "kernel_avg_us": k2,
-            "achieved": BYTES_PER_PX[other] * n_px / (k2 * 1e-6) / 1e9,
-            "frac": BYTES_PER_PX[other] * n_px / (k2 * 1e-6) / 1e9 / HBM_PEAK_GBS,
-        }
-        result["alignment"] = {"full_pyramid_ms": t_align * 1e3, "iters_per_level": iters_nat, "status": rc,
+        k2, b2 = avg_kernel_us(lambda: reg.time_eval_kernel(0, pose_gpu, other, True, 50))
+        result["roofline_other_method"] = dict(roofline_entry(k2, b2, n_px, other, resident="infinity_cache"), method=METHOD_NAMES[other])
+        # whole-iteration efficiency: the bytes of one pass over the duration of one step (pass + solve launch + gaps)
+        solve_us = reg.time_solve_kernel(0, 0, 50)
+        it_s = elapsed / args.steps
+        result["iteration"] = {
+            "bytes_per_iteration": BYTES_PER_PX[method] * n_px, "us_per_iteration": it_s * 1e6,
+            "pass_us": kernel_us, "solve_us": solve_us, "gap_and_host_us": it_s * 1e6 - kernel_us - solve_us,
+            "achieved": BYTES_PER_PX[method] * n_px / it_s / 1e9, "unit": "GB/s",
+            "frac": BYTES_PER_PX[method] * n_px / it_s / 1e9 / HBM_PEAK_GBS,
+            "note": "value's own step: one k_eval pass + one k_solve launch + launch gaps (+ the K-step call's fixed cost / K)"}
+        srt_a = sorted(t_align)
+        result["alignment"] = {"full_pyramid_ms": srt_a[len(srt_a) // 2] * 1e3, "full_pyramid_ms_min": srt_a[0] * 1e3,
+                               "iters_per_level": iters_nat, "status": rc,
                                "pose_err_vs_ground_truth": dict(zip(("rot_rad", "trans_m"), synth.pose_error(pose_gpu, T_gt)))}
         result["setup_s"] = {"render_pair": t_gen}
 
-        # ---- the same kernel at 4096x2048 (BASELINE.json configs[4]: working set beyond the 256 MiB Infinity Cache) ----
+        # ---- the same kernel at 4096x2048 (BASELINE.json configs[4]); PHOTO_DEPTH (335 MB) exceeds the Infinity Cache,
+        #      PHOTO_CONSISTENCY (235 MB) does not ----
         if n_gpus == 1 and not args.no_4k:
             (a4, d4), (b4, e4), _ = synth.make_pair(4096, 2048, seed=1234)
             reg4 = RegisterPhotoICP(device=local_rank)
@@ -202,13 +289,18 @@ def main():
             p4 = reg4.getOptimalPose()
             result["roofline_4096x2048"] = {}
             for m in (0, 2):
-                us, _ = avg_kernel_us(reg4, 0, p4, m, 30)
-                ach = BYTES_PER_PX[m] * 4096 * 2048 / (us * 1e-6) / 1e9
+                us, bt = avg_kernel_us(lambda: reg4.time_eval_kernel(0, p4, m, True, 30))
                 it = reg4.forced_iters(0, np.eye(4), m, 100)
-                result["roofline_4096x2048"][METHOD_NAMES[m]] = {
-                    "kernel_avg_us": us, "achieved": ach, "frac": ach / HBM_PEAK_GBS, "frac_of_measured_copy_peak": ach / HBM_COPY_GBS,
-                    "gn_iterations_per_s": 100 / (it["elapsed_ms"] * 1e-3)}
+                ws4 = WORKING_SET_PER_PX[m] * 4096 * 2048
+                result["roofline_4096x2048"][METHOD_NAMES[m]] = dict(
+                    roofline_entry(us, bt, 4096 * 2048, m, resident="infinity_cache" if ws4 < LLC_BYTES else "hbm", working_set_bytes=ws4),
+                    gn_iterations_per_s=100 / (it["elapsed_ms"] * 1e-3))
             reg4.close()
+
+        # ---- the single-process multi-GPU entry (rgbd360_multi_*: host thread per device + ncclAllGather), in a child process
+        #      so that nothing it does can cost the bench line ----
+        if not args.no_native_multi and not args.no_sequence and not share:
+            result["native_multi"] = run_native_multi_child(world, args, W, H, seq_block)
 
         # ---- CPU baseline: the oracle on this host's cores, bounded sample (rank 0, N = 1 only) ---------------
         if n_gpus == 1 and not args.no_cpu_baseline:
@@ -217,8 +309,8 @@ def main():
             ora.set_target(rgbA, dA)
             ora.set_source(rgbB, dB)
             st, pose_cpu = ora.align360(np.eye(4), method)
-            rot, trans = synth.pose_error(pose_gpu, pose_cpu)
-            result["alignment"]["pose_err_vs_cpu_ref"] = {"rot_rad": rot, "trans_m": trans}
+            rot_e, trans_e = synth.pose_error(pose_gpu, pose_cpu)
+            result["alignment"]["pose_err_vs_cpu_ref"] = {"rot_rad": rot_e, "trans_m": trans_e}
             result["alignment"]["cpu_iters_per_level"] = list(ora.result.iters)[:4]
             # thread count: the reference uses every OpenMP thread; on many-core hosts that is not the fastest
             # setting for this memory-bound loop, so the baseline is quoted at the best of a short sweep
@@ -246,9 +338,129 @@ def main():
                 "host_cpus": os.cpu_count(),
             }
         print(json.dumps(result), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+
+
+def run_sequence_block(args, torch, dist, synth, reg0, rank, world, local_rank, xdev, W, H, gather_poses, shard_range, sync_all):
+    """configs[3]: args.seq_pairs consecutive pairs, contiguous shards over the ranks (rgbd360_amd.batch.shard_range), every rank
+    aligning its shard through ONE call of the library's sequence entry, then one all-gather of {pose, status, iters}.
+    Each rank renders SEQ_UNIQUE_FRAMES frames of the trajectory (its own stretch) and walks them back and forth -- consecutive
+    entries are always neighbouring frames, i.e. genuine 6 cm / 2 degree odometry pairs -- because rendering 257 full-size frames
+    on the host would take minutes.  Timed: (a) frames resident in HBM, (b) host frames (H2D inside the call)."""
+    from rgbd360_amd.register import RegisterPhotoICP
+    n_total = args.seq_pairs
+    lo, hi = shard_range(n_total, rank, world)
+    n_loc = hi - lo
+    t0 = time.time()
+    uniq = [synth.render(synth.trajectory_pose(rank * (SEQ_UNIQUE_FRAMES - 1) + k, 7), W, H, 7) for k in range(SEQ_UNIQUE_FRAMES)]
+    t_render = time.time() - t0
+    order = pingpong(n_loc, SEQ_UNIQUE_FRAMES)
+    dev = torch.device("cuda", local_rank)
+    rgb_t = [torch.from_numpy(f[0]).to(dev) for f in uniq]
+    dep_t = [torch.from_numpy(f[1].view(np.int16)).to(dev) for f in uniq]       # uint16 bits; torch has no uint16 kernels, none needed
+    torch.cuda.synchronize()
+    rgb_ptrs = [rgb_t[k].data_ptr() for k in order]
+    dep_ptrs = [dep_t[k].data_ptr() for k in order]
+    host_frames = [uniq[k] for k in order]
+    reg = RegisterPhotoICP(device=local_rank)
+    reg.setNumPyr(4)
+    method = 2          # PHOTO_DEPTH, what OdometryRGBD360.cpp:192 runs
+    out = {}
+    for variant in ("resident", "host_frames"):
+        def run():
+            if variant == "resident":
+                return reg.alignSequenceDev(rgb_ptrs, dep_ptrs, H, W, 0, method=method, n_inflight=3)
+            return reg.alignSequence(host_frames, method=method, n_inflight=3)
+        if n_loc > 0:
+            if variant == "resident":
+                reg.alignSequenceDev(rgb_ptrs[:8], dep_ptrs[:8], H, W, 0, method=method, n_inflight=3)      # warm (sibling contexts, buffers)
+            else:
+                reg.alignSequence(host_frames[:8], method=method, n_inflight=3)
+        times, res = [], None
+        for _ in range(3):
+            sync_all()
+            t0 = time.perf_counter()
+            if n_loc > 0:
+                res = run()
+            else:
+                res = (np.zeros((0, 4, 4), np.float32), np.zeros(0, np.int32), np.zeros((0, 4), np.int32))
+            full, st, it = gather_poses(res[0], n_total, dist, device=(None if xdev == "cpu" else dev), status=res[1], iters=res[2])
+            sync_all()
+            times.append(time.perf_counter() - t0)
+        if dist is not None:
+            tm = torch.tensor(times, dtype=torch.float64, device=xdev)
+            dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            times = [float(x) for x in tm.cpu()]
+        srt = sorted(times)
+        med = srt[len(srt) // 2]
+        # size-independent checks: every pair converged; a pair that recurs in the walk gives bit-identical poses every time
+        # (fixed-order reductions, no atomics); forward and backward pass over one pair of frames are inverse motions
+        my = full[lo:hi]
+        first_seen, repeats_equal = {}, True
+        for j in range(n_loc):
+            key = (order[j], order[j + 1])
+            if key in first_seen:
+                repeats_equal &= bool(np.array_equal(my[first_seen[key]], my[j]))
+            else:
+                first_seen[key] = j
+        inv_err = 0.0
+        for (a, b), j in first_seen.items():
+            if (b, a) in first_seen:
+                e = synth.pose_error(my[j].astype(np.float64) @ my[first_seen[(b, a)]].astype(np.float64), np.eye(4))
+                inv_err = max(inv_err, e[0], e[1])
+        gt_err = [0.0, 0.0]
+        for (a, b), j in first_seen.items():
+            base = rank * (SEQ_UNIQUE_FRAMES - 1)
+            T = np.linalg.inv(synth.trajectory_pose(base + a, 7)) @ synth.trajectory_pose(base + b, 7)
+            e = synth.pose_error(my[j], T)
+            gt_err = [max(gt_err[0], e[0]), max(gt_err[1], e[1])]
+        out[variant] = {
+            "alignments_per_s": n_total / med, "elapsed_ms_median": med * 1e3, "elapsed_ms_all": [t * 1e3 for t in times],
+            "ms_per_pair_per_gpu": med * 1e3 / max(1, -(-n_total // world)),
+            "all_status_ok": bool((st == 0).all()), "repeated_pairs_bit_identical": repeats_equal,
+            "max_forward_backward_residual": inv_err, "max_pose_err_vs_ground_truth": {"rot_rad": gt_err[0], "trans_m": gt_err[1]},
+            "mean_iters_per_level": np.round(it.mean(0), 3).tolist() if len(it) else [],
+        }
+    reg.close()
+    out.update({"workload": "configs[3]: %d consecutive %dx%d pairs (PHOTO_DEPTH, 4 levels), contiguous shards over %d rank(s), "
+                            "rgbd360_align360_batch[_dev] per rank (3 sub-chunks in flight), one all-gather of pose/status/iters"
+                            % (n_total, W, H, world),
+                "pairs_total": n_total, "pairs_per_rank": -(-n_total // world), "unique_frames_per_rank": SEQ_UNIQUE_FRAMES,
+                "render_s": t_render, "exchange": "gloo (shared device)" if xdev == "cpu" and world > 1 else ("rccl" if world > 1 else "none")})
+    # the child process of the native multi-GPU entry re-uses rank 0's frames instead of rendering again
+    if rank == 0:
+        try:
+            path = "/tmp/rgbd360_bench_frames_%d.npz" % os.getpid()
+            np.savez(path, rgb=np.stack([f[0] for f in uniq]), depth=np.stack([f[1] for f in uniq]))
+            out["_frames_path"] = path
+        except Exception:
+            pass
+    return out
+
+
+def run_native_multi_child(world, args, W, H, seq_block):
+    """tools/native_multi_bench.py in a child process: the C entry rgbd360_multi_* with n_gpus = the job's GPU count, the same
+    sequence, resident frames.  Run after the ranks' own measurements; a crash or a hang there cannot touch this process."""
+    path = (seq_block or {}).pop("_frames_path", None)
+    if path is None:
+        return {"error": "no frames"}
+    import torch
+    n_dev = min(world, torch.cuda.device_count())
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "native_multi_bench.py"), str(n_dev), str(args.seq_pairs), str(W), str(H), path]
+    try:
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+        line = [l for l in p.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+        if p.returncode != 0 or not line:
+            return {"error": "child rc %d: %s" % (p.returncode, p.stderr.decode(errors="replace")[-400:])}
+        return json.loads(line[-1])
+    except subprocess.TimeoutExpired:
+        return {"error": "timeout"}
+    except Exception as e:       # the bench line must come out whatever happens here
+        return {"error": repr(e)}
+    finally:
+        try:
+            os.remove(path)
+        except OSError:
+            pass
 
 
 if __name__ == "__main__":

@@ -4,8 +4,11 @@
 //     frame_%03d.rgb  (H*W*3 uint8)   frame_%03d.depth (H*W uint16 mm)
 // Build:  g++ -std=c++17 -O2 -Iinclude examples/odometry_replay.cpp -Lrgbd360_amd/lib -lrgbd360_hip
 //             -Wl,-rpath,$PWD/rgbd360_amd/lib -o odometry_replay
-// Usage:  odometry_replay <dir> <n_frames> <width> <height> [--sequence | --pbmap | --link]
+// Usage:  odometry_replay <dir> <n_frames> <width> <height> [--sequence | --multi <n_gpus> | --pbmap | --link]
 //         --sequence: all frames are loaded first and the frame loop runs inside the library (alignSequence)
+//         --multi N:  the same sequence sharded over N GPUs of this node from this one process (rgbd360_multi_*: one host thread
+//                     per device, contiguous shards of pairs, one ncclAllGather of the solved poses over xGMI); prints the
+//                     lines of --sequence
 //         --pbmap:    every pair is first registered from its planes (RegisterRGBD360::RegisterPbMap, ODOMETRY_6DoF, as
 //                     SphereGraphSLAM.cpp:180 / KFsphere_SLAM.cpp:314 do) and that pose seeds alignFrames360
 //                     (KFsphere_SLAM.cpp:149); prints one extra "pbmap" line per pair
@@ -80,6 +83,44 @@ int main(int argc, char** argv) {
             printf("pair %zu status %d sso %.4f rel_t %.5f %.5f %.5f pose_t %.5f %.5f %.5f\n", j, res[j].status, res[j].sso,
                    rels[j](0, 3), rels[j](1, 3), rels[j](2, 3), currentPose(0, 3), currentPose(1, 3), currentPose(2, 3));
         }
+        return 0;
+    }
+    if (argc > 6 && std::string(argv[5]) == "--multi") {
+        const int n_gpus = atoi(argv[6]);
+        std::vector<Frame> frames(n);
+        std::vector<const uint8_t*> rgb(n);
+        std::vector<const void*> depth(n);
+        for (int k = 0; k < n; ++k) {
+            if (!frames[k].load(dir, k, w, h)) return 3;
+            rgb[k] = frames[k].rgb.data();
+            depth[k] = frames[k].depth.data();
+        }
+        rgbd360_params p;
+        rgbd360_default_params(&p);
+        p.n_pyr = 4;
+        rgbd360_multi* m = nullptr;
+        int rc = rgbd360_multi_create(&p, n_gpus, nullptr, &m);
+        if (rc != 0) {
+            fprintf(stderr, "rgbd360_multi_create(%d GPUs) failed: %d\n", n_gpus, rc);
+            return 4;
+        }
+        std::vector<float> poses((size_t)(n - 1) * 16);
+        std::vector<rgbd360_result> res(n - 1);
+        rc = rgbd360_multi_align_sequence(m, n, rgb.data(), (size_t)w * 3, depth.data(), (size_t)w * 2, 0, h, w, nullptr, 2, 0, 3, poses.data(),
+                                          res.data());
+        if (rc != 0) {
+            fprintf(stderr, "rgbd360_multi_align_sequence: %s (%d)\n", rgbd360_multi_last_error(m), rc);
+            rgbd360_multi_destroy(m);
+            return 5;
+        }
+        for (int j = 0; j + 1 < n; ++j) {
+            rgbd360::Mat4f rel{};
+            for (int k = 0; k < 16; ++k) rel.m[k] = poses[(size_t)j * 16 + k];
+            currentPose = mul(currentPose, rel);                                                // OdometryRGBD360.cpp:257
+            printf("pair %d status %d sso %.4f rel_t %.5f %.5f %.5f pose_t %.5f %.5f %.5f\n", j, res[j].status, res[j].sso, rel(0, 3), rel(1, 3),
+                   rel(2, 3), currentPose(0, 3), currentPose(1, 3), currentPose(2, 3));
+        }
+        rgbd360_multi_destroy(m);
         return 0;
     }
     if (argc > 5 && std::string(argv[5]) == "--link") {

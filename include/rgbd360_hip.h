@@ -131,6 +131,44 @@ int rgbd360_align360_batch_dev(rgbd360_ctx* ctx, int n_frames, const uint8_t* co
                                size_t depth_step, int depth_type, int rows, int cols, const float guess[16], int method,
                                int occlusion, int n_inflight, float* poses_out, rgbd360_result* results_out);
 
+/* ---- one process, several GPUs (BASELINE.json configs[3]) ---------------------------------------------------
+ * The sequence path shards by independent frame pairs: device d gets the contiguous pairs rgbd360_shard_range(n_frames-1, d,
+ * n_gpus) and therefore the frames lo..hi (one boundary frame is shared by two neighbours); one host thread per device drives
+ * that device's contexts as rgbd360_align360_batch does, no collective touches the data path, and ONE ncclAllGather (RCCL over
+ * xGMI) of the per-pair result rows {pose[16], rgbd360_result} ends the call, after which every device holds the whole
+ * trajectory (the host reads device 0's copy and checks it against the rows the shards produced).  The caller composes the
+ * relative poses like OdometryRGBD360.cpp:257.  n_gpus == 1 runs without any RCCL call (RGBD360_FORCE_RCCL=1 in the
+ * environment forces the one-rank exchange, for tests).  The handle owns the per-device contexts and the communicators:
+ * create it once, align many sequences.  Replaces the role of the reference's single-threaded odometry loop
+ * (Registration/OdometryRGBD360.cpp:141-297) for a recorded sequence. */
+typedef struct rgbd360_multi rgbd360_multi;
+/* device_ids: n_gpus distinct HIP device indices, NULL = 0..n_gpus-1.  Returns 0, -100 no HIP device, -101 bad device list,
+ * -105 RCCL initialisation failed. */
+int  rgbd360_multi_create(const rgbd360_params* p, int n_gpus, const int* device_ids, rgbd360_multi** out);
+void rgbd360_multi_destroy(rgbd360_multi* m);
+const char* rgbd360_multi_last_error(rgbd360_multi* m);
+int  rgbd360_multi_n_gpus(rgbd360_multi* m);
+int  rgbd360_multi_uses_rccl(rgbd360_multi* m);
+/* Contiguous balanced partition used by the sharding: the first n_items % world ranks get one item more. */
+void rgbd360_shard_range(int n_items, int rank, int world, int* lo, int* hi);
+/* Host frames (as rgbd360_align360_batch: uploaded one frame ahead on each device's copy stream, unchanged until the call
+ * returns).  poses_out: (n_frames-1) x 16 floats; results_out may be NULL.  Returns 0 or the first negative error. */
+int  rgbd360_multi_align_sequence(rgbd360_multi* m, int n_frames, const uint8_t* const* rgb, size_t rgb_step,
+                                  const void* const* depth, size_t depth_step, int depth_type, int rows, int cols,
+                                  const float guess[16], int method, int occlusion, int n_inflight, float* poses_out,
+                                  rgbd360_result* results_out);
+/* Resident variant: _load_sequence copies every device's frames lo..hi into its HBM once (sized for 288 GB per device: a
+ * 2048x1024 frame is 10.5 MB); _align_resident then aligns the whole sequence with no PCIe traffic but the result rows. */
+int  rgbd360_multi_load_sequence(rgbd360_multi* m, int n_frames, const uint8_t* const* rgb, size_t rgb_step,
+                                 const void* const* depth, size_t depth_step, int depth_type, int rows, int cols);
+int  rgbd360_multi_align_resident(rgbd360_multi* m, const float guess[16], int method, int occlusion, int n_inflight,
+                                  float* poses_out, rgbd360_result* results_out);
+/* One-shot form (create + align_sequence + destroy): pays the communicator set-up on every call. */
+int  rgbd360_align360_batch_multi(const rgbd360_params* p, int n_frames, const uint8_t* const* rgb, size_t rgb_step,
+                                  const void* const* depth, size_t depth_step, int depth_type, int rows, int cols,
+                                  const float guess[16], int method, int occlusion, int n_inflight, int n_gpus,
+                                  const int* device_ids, float* poses_out, rgbd360_result* results_out);
+
 /* ---- stage-level entry points (parity tests and measurement) ------------------------------------------------ */
 
 /* Pyramid planes as float32 rows x cols (level dims via rgbd360_level_dims).

@@ -24,6 +24,11 @@ int rgbd360_forced_iters(rgbd360_ctx* ctx, int level, const float pose0[16], int
 int rgbd360_time_eval_kernel(rgbd360_ctx* ctx, int level, const float pose[16], int method, int want_hg, int reps,
                              float* avg_us);
 
+/* The same timer with the launches rotating over n_ctx contexts of one device (each with its own copy of a frame pair) on
+ * ctxs[0]'s stream: once n_ctx x the level's working set exceeds the 256 MiB Infinity Cache every launch is fed from HBM. */
+int rgbd360_time_eval_kernel_rotating(rgbd360_ctx* const* ctxs, int n_ctx, int level, const float pose[16], int method,
+                                      int want_hg, int reps, float* avg_us);
+
 /* Same for the solve launch (mode 0: reduction + Gauss-Newton step, forced; mode 1: reduction only), re-using the
  * partials of the last pass. */
 int rgbd360_time_solve_kernel(rgbd360_ctx* ctx, int level, int mode, int reps, float* avg_us);

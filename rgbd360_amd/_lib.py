@@ -18,6 +18,9 @@ SYMBOLS = [
     "rgbd360_set_camera", "rgbd360_align_pinhole", "rgbd360_eval_pinhole", "rgbd360_warp_indices_pinhole",
     "rgbd360_pbmap_default_params", "rgbd360_register_planes", "rgbd360_bilateral_filter",
     "rgbd360_cloud_planes", "rgbd360_sensor_cloud", "rgbd360_sensor_planes", "rgbd360_merge_planes", "rgbd360_planes_available",
+    "rgbd360_multi_create", "rgbd360_multi_destroy", "rgbd360_multi_last_error", "rgbd360_multi_n_gpus", "rgbd360_multi_uses_rccl",
+    "rgbd360_shard_range", "rgbd360_multi_align_sequence", "rgbd360_multi_load_sequence", "rgbd360_multi_align_resident",
+    "rgbd360_align360_batch_multi", "rgbd360_time_eval_kernel_rotating",
 ]
 
 
@@ -120,5 +123,20 @@ def load() -> C.CDLL:
     L.rgbd360_register_planes.argtypes = [vp, i32, vp, i32, i32, i32, C.POINTER(PbmapParams), vp, vp, vp, C.POINTER(i32),
                                           C.POINTER(C.c_float)]
     L.rgbd360_planes_available.argtypes = [vp]
+    L.rgbd360_time_eval_kernel_rotating.argtypes = [vp, i32, i32, f32p, i32, i32, i32, C.POINTER(C.c_float)]
+    L.rgbd360_multi_create.argtypes = [C.POINTER(Params), i32, vp, C.POINTER(vp)]
+    L.rgbd360_multi_destroy.argtypes = [vp]
+    L.rgbd360_multi_destroy.restype = None
+    L.rgbd360_multi_last_error.argtypes = [vp]
+    L.rgbd360_multi_last_error.restype = C.c_char_p
+    L.rgbd360_multi_n_gpus.argtypes = [vp]
+    L.rgbd360_multi_uses_rccl.argtypes = [vp]
+    L.rgbd360_shard_range.argtypes = [i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]
+    L.rgbd360_shard_range.restype = None
+    L.rgbd360_multi_align_sequence.argtypes = [vp, i32, vp, C.c_size_t, vp, C.c_size_t, i32, i32, i32, f32p, i32, i32, i32, f32p, vp]
+    L.rgbd360_multi_load_sequence.argtypes = [vp, i32, vp, C.c_size_t, vp, C.c_size_t, i32, i32, i32]
+    L.rgbd360_multi_align_resident.argtypes = [vp, f32p, i32, i32, i32, f32p, vp]
+    L.rgbd360_align360_batch_multi.argtypes = [C.POINTER(Params), i32, vp, C.c_size_t, vp, C.c_size_t, i32, i32, i32, f32p, i32, i32, i32,
+                                               i32, vp, f32p, vp]
     _lib = L
     return L

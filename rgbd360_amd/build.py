@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(_HERE, "csrc", "rgbd360_api.hip")
 DEPS = [SRC, os.path.join(_HERE, "csrc", "photo_icp_kernels.h"), os.path.join(_HERE, "csrc", "gn_math.h"),
         os.path.join(_HERE, "csrc", "frame360_kernels.h"), os.path.join(_HERE, "csrc", "occlusion_kernels.h"),
-        os.path.join(_HERE, "csrc", "pinhole_kernels.h"), os.path.join(_HERE, "csrc", "pbmap_register.h"),
+        os.path.join(_HERE, "csrc", "pinhole_kernels.h"), os.path.join(_HERE, "csrc", "pbmap_register.h"), os.path.join(_HERE, "csrc", "multi_gpu.h"),
         os.path.join(_HERE, "..", "include", "rgbd360_hip.h"), os.path.join(_HERE, "..", "include", "rgbd360_hip_diag.h")]
 LIB = os.path.join(_HERE, "lib", "librgbd360_hip.so")
 
@@ -23,6 +23,8 @@ LIB = os.path.join(_HERE, "lib", "librgbd360_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread", "-ffp-contract=off", "-fno-slp-vectorize",
          "-mllvm", "-amdgpu-kernarg-preload-count=16",     # leading scalar kernel arguments arrive in SGPRs (gfx940+): no s_load round trip before the state load
          "-Wno-unused-value"]
+# RCCL (= NCCL on ROCm): the multi-GPU sequence entry all-gathers the solved poses over xGMI (csrc/multi_gpu.h)
+LINK = ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
 
 
 def hipcc() -> str:
@@ -42,7 +44,7 @@ def needs_build() -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     if force or needs_build():
         os.makedirs(os.path.dirname(LIB), exist_ok=True)
-        cmd = [hipcc()] + FLAGS + ["-o", LIB, SRC]
+        cmd = [hipcc()] + FLAGS + ["-o", LIB, SRC] + LINK
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

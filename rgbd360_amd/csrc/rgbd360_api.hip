@@ -898,6 +898,45 @@ int rgbd360_time_eval_kernel(rgbd360_ctx* ctx, int level, const float pose[16], 
     return 0;
 }
 
+// The same timer with the launches ROTATING over n_ctx contexts (all on ctxs[0]'s device, each holding its own copy of a frame
+// pair) on ctxs[0]'s stream: with n_ctx x working set > 256 MiB every launch finds its records evicted from the Infinity Cache,
+// so the average is an HBM-fed launch -- the back-to-back timer above re-reads an Infinity-Cache-resident set at 2048x1024.
+int rgbd360_time_eval_kernel_rotating(rgbd360_ctx* const* ctxs, int n_ctx, int level, const float pose[16], int method, int want_hg,
+                                      int reps, float* avg_us) {
+    if (!ctxs || n_ctx < 1 || !ctxs[0]) return -1;
+    rgbd360_ctx* c0 = ctxs[0];
+    if (!pose || reps < 1 || !avg_us) return fail(c0, -1, "bad arguments");
+    for (int k = 0; k < n_ctx; ++k) {
+        if (!ctxs[k]) return fail(c0, -1, "null context");
+        const int rc = check_args(ctxs[k], level, method);
+        if (rc) return k == 0 ? rc : fail(c0, rc, ctxs[k]->err.c_str());
+        if (ctxs[k]->p.device != c0->p.device) return fail(c0, -1, "all contexts must live on one device");
+    }
+    hipSetDevice(c0->p.device);
+    // every context's kernels go to c0's stream for the duration of the measurement
+    std::vector<hipStream_t> own(n_ctx);
+    for (int k = 0; k < n_ctx; ++k) {
+        HIPC(c0, hipStreamSynchronize(ctxs[k]->stream));
+        own[k] = ctxs[k]->stream;
+        ctxs[k]->stream = c0->stream;
+    }
+    for (int k = 0; k < n_ctx; ++k) {
+        launch_level_init(ctxs[k], level, pose, 1);
+        launch_eval(ctxs[k], level, method, want_hg != 0);      // warm-up
+    }
+    hipError_t e = hipEventRecord(c0->ev0, c0->stream);
+    for (int r = 0; r < reps && e == hipSuccess; ++r) launch_eval(ctxs[r % n_ctx], level, method, want_hg != 0);
+    if (e == hipSuccess) e = hipEventRecord(c0->ev1, c0->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(c0->stream);
+    for (int k = 0; k < n_ctx; ++k) ctxs[k]->stream = own[k];
+    HIPC(c0, e);
+    float ms = 0.f;
+    HIPC(c0, hipEventElapsedTime(&ms, c0->ev0, c0->ev1));
+    *avg_us = ms * 1000.f / reps;
+    return 0;
+}
+
 int rgbd360_time_solve_kernel(rgbd360_ctx* ctx, int level, int mode, int reps, float* avg_us) {
     int rc = check_args(ctx, level, 0);
     if (rc) return rc;
@@ -1918,3 +1957,5 @@ extern "C" int rgbd360_merge_planes(const rgbd360_plane* planes, int n, float ma
         return -1;
     }
 }
+
+#include "multi_gpu.h"

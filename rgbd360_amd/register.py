@@ -367,6 +367,16 @@ class RegisterPhotoICP:
                                                      C.byref(us)))
         return float(us.value)
 
+    @staticmethod
+    def time_eval_kernel_rotating(regs, level: int, pose, method: int, want_hg: bool = True, reps: int = 20) -> float:
+        """Average launch duration with the launches rotating over the contexts `regs` (one device, one pair each): HBM-fed once
+        their working sets together exceed the Infinity Cache (rgbd360_hip_diag.h)."""
+        arr = (C.c_void_p * len(regs))(*[r._ctx() for r in regs])
+        us = C.c_float()
+        regs[0]._check(regs[0]._L.rgbd360_time_eval_kernel_rotating(arr, len(regs), level, _ptr(pose_to_cm(pose)), method, int(want_hg),
+                                                                    reps, C.byref(us)))
+        return float(us.value)
+
     def time_solve_kernel(self, level: int, mode: int = 0, reps: int = 20) -> float:
         us = C.c_float()
         self._check(self._L.rgbd360_time_solve_kernel(self._ctx(), level, mode, reps, C.byref(us)))

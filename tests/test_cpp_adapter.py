@@ -49,6 +49,11 @@ def test_odometry_replay_matches_python_host(tmp_path, hip_lib):
     pairwise = subprocess.check_output([exe, str(seq), "6", "256", "128"], text=True)
     batched = subprocess.check_output([exe, str(seq), "6", "256", "128", "--sequence"], text=True)
     assert len(pairwise.strip().splitlines()) == 5 and pairwise == batched
+    # and sharded over the GPUs of the node from this one C++ process (rgbd360_multi_*; this box has one device)
+    multi = subprocess.check_output([exe, str(seq), "6", "256", "128", "--multi", "1"], text=True)
+    assert multi == batched
+    forced = subprocess.check_output([exe, str(seq), "6", "256", "128", "--multi", "1"], text=True, env=dict(os.environ, RGBD360_FORCE_RCCL="1"))
+    assert forced == batched                        # the rows went through ncclAllGather (one rank) and came back unchanged
 
 
 def test_register_rgbd360_adapter_matches_python_mirror(tmp_path):

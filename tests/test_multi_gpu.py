@@ -1,0 +1,151 @@
+"""BASELINE.json configs[3] (a sequence of pairs sharded over the GPUs of a node, poses all-gathered over RCCL) on what a one-GPU box
+can show: the native single-process entry (rgbd360_multi_*, csrc/multi_gpu.h) with one device -- with and without the RCCL
+exchange -- against the pair-by-pair schedule, and the process-per-GPU path with two ranks running REAL alignments on a shared
+device (gloo for the exchange: RCCL refuses two ranks on one GPU).  The 8-GPU run itself is the driver's.
+"""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from rgbd360_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _frames(n, seed=7, W=256, H=128):
+    return [synth.render(synth.trajectory_pose(k, seed), W, H, seed) for k in range(n)]
+
+
+def _pairwise(frames, n_pyr=3, method=2):
+    from rgbd360_amd.batch import align_sequence
+    from rgbd360_amd.register import RegisterPhotoICP
+    reg = RegisterPhotoICP()
+    reg.setNumPyr(n_pyr)
+    return align_sequence(reg, lambda k: frames[k], 0, len(frames) - 1, method)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("force_rccl", [False, True])
+def test_native_multi_entry_one_gpu_equals_pairwise(hip_lib, force_rccl, monkeypatch):
+    """rgbd360_multi_create(n_gpus = 1) + _align_sequence / _load_sequence + _align_resident == pair-by-pair alignment, bit for
+    bit; with RGBD360_FORCE_RCCL=1 the rows really travel through ncclAllGather (one rank) and come back identical."""
+    from rgbd360_amd.multi import MultiGpuSequence
+    frames = _frames(7)
+    poses, status, iters = _pairwise(frames)
+    if force_rccl:
+        monkeypatch.setenv("RGBD360_FORCE_RCCL", "1")
+    else:
+        monkeypatch.delenv("RGBD360_FORCE_RCCL", raising=False)
+    m = MultiGpuSequence(n_gpus=1, n_pyr=3)
+    assert m.uses_rccl == force_rccl
+    for k in (1, 3):
+        p, s, i = m.align_sequence(frames, method=2, n_inflight=k)
+        assert np.array_equal(p, poses) and np.array_equal(s, status) and np.array_equal(i, iters), k
+    m.load_sequence(frames)
+    p, s, i = m.align_resident(method=2, n_inflight=2)
+    assert np.array_equal(p, poses) and np.array_equal(s, status) and np.array_equal(i, iters)
+    m.close()
+
+
+@pytest.mark.gpu
+def test_one_shot_batch_multi_and_argument_errors(hip_lib):
+    import ctypes as C
+    from rgbd360_amd import _lib
+    from rgbd360_amd.multi import MultiGpuSequence, shard_range
+    from rgbd360_amd.register import Rgbd360Error
+    frames = _frames(4, seed=11)
+    poses, status, iters = _pairwise(frames)
+    L = _lib.load()
+    p = _lib.Params()
+    L.rgbd360_default_params(C.byref(p))
+    p.n_pyr = 3
+    n = len(frames) - 1
+    rp = (C.c_void_p * len(frames))(*[f[0].ctypes.data for f in frames])
+    dp = (C.c_void_p * len(frames))(*[f[1].ctypes.data for f in frames])
+    out = np.zeros(n * 16, np.float32)
+    res = (_lib.Result * n)()
+    rc = L.rgbd360_align360_batch_multi(C.byref(p), len(frames), rp, 256 * 3, dp, 256 * 2, 0, 128, 256, None, 2, 0, 2, 1, None,
+                                        out.ctypes.data_as(C.c_void_p), res)
+    assert rc == 0
+    for j in range(n):
+        assert np.array_equal(out[16 * j:16 * j + 16].reshape(4, 4).T, poses[j]) and res[j].status == status[j]
+    # more devices than the box has, a repeated device, a bad count: refused at creation, nothing half-built
+    ndev = L.rgbd360_device_count()
+    with pytest.raises(Rgbd360Error):
+        MultiGpuSequence(n_gpus=ndev + 1)
+    with pytest.raises(Rgbd360Error):
+        MultiGpuSequence(n_gpus=2, device_ids=[0, 0])
+    with pytest.raises(Rgbd360Error):
+        MultiGpuSequence(n_gpus=0)
+    m = MultiGpuSequence(n_gpus=1, n_pyr=3)
+    with pytest.raises(Rgbd360Error):
+        m.align_resident()
+    assert m.align_sequence(frames[:1])[0].shape == (0, 4, 4)
+    # the library's sharding is the Python one
+    from rgbd360_amd.batch import shard_range as py_shard
+    for n_items in (0, 1, 7, 256, 257):
+        for world in (1, 2, 3, 8):
+            assert [shard_range(n_items, r, world) for r in range(world)] == [py_shard(n_items, r, world) for r in range(world)]
+
+
+_RANK_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import torch.distributed as dist
+from rgbd360_amd import synth
+from rgbd360_amd.batch import align_sequence_native, gather_poses, shard_range
+from rgbd360_amd.register import RegisterPhotoICP
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+n_pairs = %(n_pairs)d
+lo, hi = shard_range(n_pairs, rank, world)
+frames = {k: synth.render(synth.trajectory_pose(k, 7), 256, 128, 7) for k in range(lo, hi + 1)}
+if rank == 1:                                   # one pair of rank 1's shard has a blank source: its status must survive the exchange
+    frames[hi] = (frames[hi][0], np.zeros_like(frames[hi][1]))
+reg = RegisterPhotoICP(device=0)
+reg.setNumPyr(3)
+poses, status, iters = align_sequence_native(reg, lambda k: frames[k], lo, hi, 2, n_inflight=2)
+full, st, it = gather_poses(poses, n_pairs, dist, status=status, iters=iters)
+np.savez(os.path.join(%(out)r, "rank%%d.npz" %% rank), poses=full, status=st, iters=it)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.gpu
+def test_two_ranks_run_real_alignments_and_gather(hip_lib, tmp_path):
+    """Process-per-GPU path with world_size 2, both ranks on this box's one device (the exchange goes through gloo): every rank
+    aligns its contiguous shard with the product library and ends up holding the whole trajectory -- poses, status and iteration
+    counts equal to the single-process pair-by-pair result."""
+    n_pairs = 7
+    frames = _frames(n_pairs + 1)
+    frames[n_pairs] = (frames[n_pairs][0], np.zeros_like(frames[n_pairs][1]))       # as rank 1 does
+    poses, status, iters = _pairwise(frames)
+    assert status[n_pairs - 1] != 0 and (status[:-1] == 0).all()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT % dict(root=ROOT, n_pairs=n_pairs, out=str(tmp_path)))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, _ = p.communicate()
+        outs.append(out.decode(errors="replace"))
+    assert all(p.returncode == 0 for p in procs), outs
+    for r in range(2):
+        z = np.load(tmp_path / ("rank%d.npz" % r))
+        assert np.array_equal(z["poses"], poses) and np.array_equal(z["status"], status) and np.array_equal(z["iters"], iters), r
