@@ -447,10 +447,12 @@ __device__ __forceinline__ void consume_stage(PixW& w, const LevelDev& lv, const
 // Argument order: the scalars the first instructions need (state pointer for the gate / pose loads, source base and span for
 // the first record loads) lead the list so that the kernarg preload (build flag -amdgpu-kernarg-preload-count) delivers
 // them in SGPRs at wave start; the structs follow and are fetched while those first loads are in flight.
+// eval_block is the body of one workgroup; k_eval (one pair per launch) and k_eval_b (blockIdx.y = slot of a lock-step batch of
+// pairs, sequence_engine.h) call it with their own base pointers.
 template <int METHOD, bool HG>
-__global__ __launch_bounds__(kEvalThreads) void k_eval(const GNState* __restrict__ st, const float4* __restrict__ src0, int n_px,
-                                                        int chunk, int level, int nb_arg, double* __restrict__ partials,
-                                                        LevelDev lv, EvalConsts ec) {
+__device__ __forceinline__ void eval_block(const GNState* __restrict__ st, const float4* __restrict__ src0, const int n_px,
+                                           const int chunk, const int level, const int nb_arg, double* __restrict__ partials,
+                                           const LevelDev& lv, const EvalConsts& ec) {
 #ifdef RGBD360_EVAL_STAMPS
     const unsigned long long es0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long es[6] = {0, 0, 0, 0, 0, 0};
@@ -574,6 +576,28 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval(const GNState* __restrict
 #undef ESTAMP
 }
 
+template <int METHOD, bool HG>
+__global__ __launch_bounds__(kEvalThreads) void k_eval(const GNState* __restrict__ st, const float4* __restrict__ src0, int n_px,
+                                                        int chunk, int level, int nb_arg, double* __restrict__ partials,
+                                                        LevelDev lv, EvalConsts ec) {
+    eval_block<METHOD, HG>(st, src0, n_px, chunk, level, nb_arg, partials, lv, ec);
+}
+
+// Lock-step batch of pairs: blockIdx.y = slot.  Every per-slot buffer of a level is one slice of a single allocation, so the
+// slot's pointers are arithmetic on kernel arguments (SGPRs at wave start through the kernarg preload) -- no descriptor table, no
+// dependent load in front of the first record loads.  Work split, partial rows and summation order per slot are exactly those
+// of k_eval, hence bit-identical sums.
+template <int METHOD, bool HG>
+__global__ __launch_bounds__(kEvalThreads) void k_eval_b(const GNState* __restrict__ states, const float4* __restrict__ src0, int n_px,
+                                                          int chunk, int level, int nb_arg, double* __restrict__ partials,
+                                                          int partials_stride, LevelDev lv, EvalConsts ec) {
+    const int slot = blockIdx.y;
+    lv.trgP += (size_t)slot * (size_t)n_px;
+    lv.trgD += (size_t)slot * (size_t)n_px;
+    eval_block<METHOD, HG>(states + slot, src0 + (size_t)slot * (size_t)n_px, n_px, chunk, level, nb_arg,
+                           partials + (size_t)slot * (size_t)partials_stride, lv, ec);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // k_level_init: entering a pyramid level (RPI.h:4590-4604): it = 0, update = (1,..,1), lambda = 1, the first
 // pass is evaluated at the incoming pose.  use_pose != 0 loads `pose` (first level / stage calls).
@@ -581,8 +605,25 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval(const GNState* __restrict
 struct Pose16 {
     float v[16];
 };
+__device__ __forceinline__ void level_init_one(GNState* st, const Pose16& pose, int use_pose, int reset_all, int level);
 __global__ void k_level_init(GNState* st, Pose16 pose, int use_pose, int reset_all, int level) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    level_init_one(st, pose, use_pose, reset_all, level);
+}
+// Lock-step batch: block s initialises slot s; a slot outside live_mask (its span of pairs is exhausted) is parked -- done, and
+// on a level no launch carries -- so that every later launch of the round is a no-op for it.
+__global__ void k_level_init_b(GNState* states, Pose16 pose, int use_pose, int reset_all, int level, unsigned long long live_mask) {
+    if (threadIdx.x != 0) return;
+    GNState* st = states + blockIdx.x;
+    if (!((live_mask >> blockIdx.x) & 1ull)) {
+        st->done = 1;
+        st->level_active = -1;
+        st->status = 0;
+        return;
+    }
+    level_init_one(st, pose, use_pose, reset_all, level);
+}
+__device__ __forceinline__ void level_init_one(GNState* st, const Pose16& pose, int use_pose, int reset_all, int level) {
     if (reset_all) {
         for (int k = 0; k < 36; ++k) st->H[k] = st->Hused[k] = 0.f;
         for (int k = 0; k < 6; ++k) st->g[k] = st->gused[k] = 0.f;
@@ -764,8 +805,7 @@ __device__ __forceinline__ int qr_rank6_lanes(const float* M /*LDS, column-major
 // the rank test and the 6x6 inverse on two waves side by side.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kSolveThreads = 1024;
-__global__ __launch_bounds__(kSolveThreads) void k_solve(GNState* st_g, const double* __restrict__ partials, int nb,
-                                                          SolveCfg cfg) {
+__device__ __forceinline__ void solve_block(GNState* st_g, const double* __restrict__ partials, const int nb, const SolveCfg& cfg) {
     // The state is staged through LDS: one coalesced read while the partials are being reduced, one coalesced
     // write-back at the end; the single-lane bookkeeping below then never waits on global memory.
     __shared__ GNState sst;
@@ -1018,6 +1058,15 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(GNState* st_g, const do
 #endif
     if (tid < kStateWords) reinterpret_cast<int*>(st_g)[tid] = reinterpret_cast<const int*>(&sst)[tid];
 #undef STAMP
+}
+__global__ __launch_bounds__(kSolveThreads) void k_solve(GNState* st_g, const double* __restrict__ partials, int nb,
+                                                          SolveCfg cfg) {
+    solve_block(st_g, partials, nb, cfg);
+}
+// Lock-step batch: one block per slot, each the k_solve of its own pair (same reduction order, same arithmetic).
+__global__ __launch_bounds__(kSolveThreads) void k_solve_b(GNState* states, const double* __restrict__ partials, int partials_stride,
+                                                            int nb, SolveCfg cfg) {
+    solve_block(states + blockIdx.x, partials + (size_t)blockIdx.x * (size_t)partials_stride, nb, cfg);
 }
 
 // Standalone GN step for tests: one thread.
@@ -1278,6 +1327,63 @@ __global__ void k_src_rec_multi(SrcJobs jobs) {
     divmod24(p, cols, r, c);
     src_rec_px(jobs.depth[j], jobs.gray[j], cols, jobs.sin_theta[j], jobs.cos_theta[j], jobs.sin_phi[j], jobs.cos_phi[j],
                jobs.min_depth, jobs.max_depth, jobs.rec[j], r, c);
+}
+
+// ---- lock-step batch forms of the frame set-up kernels (sequence_engine.h): every per-slot plane / record buffer of a level is a
+// slice [slot][n] of one allocation; blockIdx.z (or .y) carries the slot; slots outside live_mask have no frame this round ----
+constexpr int kMaxSlots = 32;
+struct FramePtrs {
+    const uint8_t* rgb[kMaxSlots];
+    const void* depth[kMaxSlots];
+};
+__global__ void k_convert_pair_b(FramePtrs fp, size_t rgb_step, size_t depth_step, int depth_type, int rows, int cols,
+                                 float* __restrict__ gray_out, float* __restrict__ depth_out, unsigned long long live_mask) {
+    const int slot = blockIdx.z >> 1;
+    if (!((live_mask >> slot) & 1ull)) return;
+    const int c4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const int r = blockIdx.y;
+    const size_t off = (size_t)slot * (size_t)rows * (size_t)cols;
+    if ((blockIdx.z & 1) == 0) gray_u8_x4(fp.rgb[slot], rgb_step, rows, cols, gray_out + off, c4, r);
+    else depth_to_f32_x4(fp.depth[slot], depth_step, depth_type, rows, cols, depth_out + off, c4, r);
+}
+__global__ void k_pyrdown_pair_b(const float* __restrict__ gray_src, const float* __restrict__ depth_src, int srows, int scols,
+                                 float* __restrict__ gray_dst, float* __restrict__ depth_dst, int drows, int dcols, float min_depth,
+                                 float max_depth, unsigned long long live_mask) {
+    const int slot = blockIdx.z >> 1;
+    if (!((live_mask >> slot) & 1ull)) return;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= dcols || y >= drows) return;
+    const size_t so = (size_t)slot * (size_t)srows * (size_t)scols, dof = (size_t)slot * (size_t)drows * (size_t)dcols;
+    if ((blockIdx.z & 1) == 0) pyrdown_gray_px(gray_src + so, srows, scols, gray_dst + dof, dcols, x, y);
+    else pyrdown_depth_px(depth_src + so, scols, depth_dst + dof, dcols, min_depth, max_depth, x, y);
+}
+__global__ void k_gradient_rec_multi_b(GradJobs jobs, unsigned long long live_mask) {
+    const int slot = blockIdx.y;
+    if (!((live_mask >> slot) & 1ull)) return;
+    int j = 0;
+    while (j + 1 < jobs.n && (int)blockIdx.x >= jobs.first_block[j + 1]) ++j;
+    const int p = ((int)blockIdx.x - jobs.first_block[j]) * (int)blockDim.x + (int)threadIdx.x;
+    const int cols = jobs.cols[j], rows = jobs.rows[j];
+    if (p >= rows * cols) return;
+    int r, c;
+    divmod24(p, cols, r, c);
+    const size_t off = (size_t)slot * (size_t)rows * (size_t)cols;
+    gradient_rec_px(jobs.src[j] + off, rows, cols, jobs.seam[j], jobs.rec[j] + off, r, c);
+}
+__global__ void k_src_rec_multi_b(SrcJobs jobs, unsigned long long live_mask) {
+    const int slot = blockIdx.y;
+    if (!((live_mask >> slot) & 1ull)) return;
+    int j = 0;
+    while (j + 1 < jobs.n && (int)blockIdx.x >= jobs.first_block[j + 1]) ++j;
+    const int p = ((int)blockIdx.x - jobs.first_block[j]) * (int)blockDim.x + (int)threadIdx.x;
+    const int cols = jobs.cols[j], rows = jobs.rows[j];
+    if (p >= rows * cols) return;
+    int r, c;
+    divmod24(p, cols, r, c);
+    const size_t off = (size_t)slot * (size_t)rows * (size_t)cols;
+    src_rec_px(jobs.depth[j] + off, jobs.gray[j] + off, cols, jobs.sin_theta[j], jobs.cos_theta[j], jobs.sin_phi[j], jobs.cos_phi[j],
+               jobs.min_depth, jobs.max_depth, jobs.rec[j] + off, r, c);
 }
 
 // Frame360 sphere clouds (Frame360.h:555-612, Frame360_stereo.h:454-512) and the RegisterPhotoICP convention.

@@ -42,6 +42,10 @@ struct Level {
 
 }  // namespace
 
+namespace {
+struct SeqEngine;      // sequence_engine.h
+}
+
 struct rgbd360_ctx {
     rgbd360_params p;
     hipStream_t stream = nullptr;
@@ -84,7 +88,8 @@ struct rgbd360_ctx {
     float al_guess[16] = {0};     // alignment in flight (rgbd360_align360_begin / _finish)
     int al_method = 0;
     bool al_active = false;
-    std::vector<rgbd360_ctx*> siblings;                // extra contexts of rgbd360_align360_batch (owned)
+    std::vector<rgbd360_ctx*> siblings;                // extra contexts of rgbd360_align360_batch's per-context route (owned)
+    std::vector<SeqEngine*> engines;                   // lock-step sequence engines of rgbd360_align360_batch (owned)
     int al_occ = 0;
     float cam[4] = {0.f, 0.f, 0.f, 0.f};               // cameraMatrix(0,0), (1,1), (0,2), (1,2)   RPI.h:89, 254-257
     bool have_cam = false;
@@ -417,6 +422,8 @@ int set_frame(rgbd360_ctx* ctx, bool target, const uint8_t* rgb, size_t rgb_step
 
 }  // namespace
 
+#include "sequence_engine.h"
+
 extern "C" {
 
 void rgbd360_default_params(rgbd360_params* p) {
@@ -485,6 +492,8 @@ void rgbd360_destroy(rgbd360_ctx* ctx) {
     hipSetDevice(ctx->p.device);
     for (rgbd360_ctx* sib : ctx->siblings) rgbd360_destroy(sib);
     ctx->siblings.clear();
+    for (SeqEngine* e : ctx->engines) seq_free(e);
+    ctx->engines.clear();
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     free_levels(ctx);
     hipFree(ctx->d_state); hipFree(ctx->d_partials); hipFree(ctx->d_gnio);
@@ -603,20 +612,7 @@ int rgbd360_align360_finish(rgbd360_ctx* ctx, float pose_out[16], rgbd360_result
         HIPC(ctx, hipMemcpyAsync(ctx->h_state, ctx->d_state, sizeof(GNState), hipMemcpyDeviceToHost, ctx->stream));
     }
     rgbd360_result R;
-    memset(&R, 0, sizeof(R));
-    const GNState& S = *ctx->h_state;
-    for (int l = 0; l < ctx->p.n_pyr && l < 8; ++l) R.iters[l] = S.iters[l];
-    memcpy(pose_out, S.pose, sizeof(float) * 16);
-    R.status = S.status;
-    memcpy(R.hessian, S.Hused, sizeof(R.hessian));
-    memcpy(R.gradient, S.gused, sizeof(R.gradient));
-    R.sso = S.used_npix ? (float)S.used_nvis / (float)S.used_npix : 0.f;
-    const double nv = (double)(S.acc_np + S.acc_nd);
-    R.err_final = nv > 0 ? sqrt((S.acc_e2p + S.acc_e2d) / nv) : 0.0;
-    if (ctx->al_occ != 0)       // avPhotoResidual + avDepthResidual (RPI.h:3358-3366, 3848-3855)
-        R.err_final = (S.acc_np > 0 ? sqrt(S.acc_e2p / (double)S.acc_np) : 0.0) + (S.acc_nd > 0 ? sqrt(S.acc_e2d / (double)S.acc_nd) : 0.0);
-    R.rms_photo = S.acc_np > 0 ? sqrt(S.acc_e2p / (double)S.acc_np) : 0.0;
-    R.rms_depth = S.acc_nd > 0 ? sqrt(S.acc_e2d / (double)S.acc_nd) : 0.0;
+    result_from_state(*ctx->h_state, ctx->p.n_pyr, ctx->al_occ, pose_out, &R);
     if (res) *res = R;
     return R.status;
 }
@@ -635,7 +631,7 @@ int rgbd360_align360(rgbd360_ctx* ctx, const float guess[16], int method, int oc
 // n_inflight contiguous sub-chunks, one context (own HIP stream) each; inside a sub-chunk frame j+1 is uploaded once and
 // promoted from source to target; in every step all live contexts are enqueued before any is waited for.
 // ---------------------------------------------------------------------------------------------------------
-static int align360_batch_impl(rgbd360_ctx* ctx, int n_frames, const uint8_t* const* rgb, size_t rgb_step, const void* const* depth,
+static int align360_batch_threads(rgbd360_ctx* ctx, int n_frames, const uint8_t* const* rgb, size_t rgb_step, const void* const* depth,
                                size_t depth_step, int depth_type, int rows, int cols, const float guess[16], int method,
                                int occlusion, int n_inflight, float* poses_out, rgbd360_result* results_out, bool on_device) {
     if (!ctx) return -1;
@@ -720,6 +716,95 @@ static int align360_batch_impl(rgbd360_ctx* ctx, int n_frames, const uint8_t* co
     for (int c = 0; c < k_ctx; ++c)
         if (rcs[c]) return cs[c] == ctx ? rcs[c] : fail(ctx, rcs[c], cs[c]->err.c_str());
     return 0;
+}
+
+// The lock-step route (sequence_engine.h): n_inflight = pairs in flight = slots, spread over one or two engines (own stream and host
+// thread each: while one engine waits for its round's states or enqueues, the other's kernels fill the device).
+static int align360_batch_lockstep(rgbd360_ctx* ctx, int n_frames, const uint8_t* const* rgb, size_t rgb_step, const void* const* depth,
+                                   size_t depth_step, int depth_type, int rows, int cols, const float* g, int method, int n_inflight,
+                                   float* poses_out, rgbd360_result* results_out, bool on_device) {
+    const int n = n_frames - 1;
+    const int S = std::min(n_inflight, n);
+    int n_eng = S >= 4 ? 2 : 1;
+    if (const char* e = getenv("RGBD360_SEQ_ENGINES")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 4) n_eng = std::min(v, S);
+    }
+    while ((S + n_eng - 1) / n_eng > kMaxSlots) ++n_eng;
+    std::vector<int> cnt(n_eng), off(n_eng);
+    for (int e = 0, o = 0; e < n_eng; ++e) {
+        cnt[e] = S / n_eng + (e < S % n_eng ? 1 : 0);
+        off[e] = o;
+        o += cnt[e];
+    }
+    hipSetDevice(ctx->p.device);
+    // engines are kept between calls; geometry or slot count changes rebuild them
+    bool rebuild = (int)ctx->engines.size() != n_eng;
+    for (int e = 0; !rebuild && e < n_eng; ++e)
+        rebuild = ctx->engines[e]->rows != rows || ctx->engines[e]->cols != cols || ctx->engines[e]->P != cnt[0];
+    if (rebuild) {
+        for (SeqEngine* e : ctx->engines) seq_free(e);
+        ctx->engines.clear();
+        for (int e = 0; e < n_eng; ++e) {
+            SeqEngine* E = nullptr;
+            std::string err;
+            const int rc = seq_create(ctx->p, cnt[0], rows, cols, ctx->max_eval_blocks, &E, &err);
+            if (rc) return fail(ctx, rc, err.c_str());
+            ctx->engines.push_back(E);
+        }
+    }
+    std::vector<int> a(S), b(S);      // contiguous balanced spans [a, b) of pairs per slot
+    for (int c = 0; c < S; ++c) {
+        const int base = n / S, extra = n % S;
+        a[c] = c * base + std::min(c, extra);
+        b[c] = a[c] + base + (c < extra ? 1 : 0);
+    }
+    std::vector<int> rcs(n_eng, 0);
+    auto run_engine = [&](int e) {
+        rcs[e] = seq_run(ctx->engines[e], cnt[e], a.data() + off[e], b.data() + off[e], rgb, rgb_step, depth, depth_step, depth_type, g, method,
+                         on_device, poses_out, results_out);
+        if (rcs[e]) hipStreamSynchronize(ctx->engines[e]->stream);
+    };
+    {
+        std::vector<std::thread> workers;
+        std::vector<int> inline_engines;
+        for (int e = 1; e < n_eng; ++e) {
+            try {
+                workers.emplace_back(run_engine, e);
+            } catch (const std::exception&) {        // no exception may cross the C boundary
+                inline_engines.push_back(e);
+            }
+        }
+        run_engine(0);
+        for (int e : inline_engines) run_engine(e);
+        for (std::thread& w : workers) w.join();
+    }
+    for (int e = 0; e < n_eng; ++e)
+        if (rcs[e]) return fail(ctx, rcs[e], ctx->engines[e]->err.c_str());
+    return 0;
+}
+
+static int align360_batch_impl(rgbd360_ctx* ctx, int n_frames, const uint8_t* const* rgb, size_t rgb_step, const void* const* depth,
+                               size_t depth_step, int depth_type, int rows, int cols, const float guess[16], int method,
+                               int occlusion, int n_inflight, float* poses_out, rgbd360_result* results_out, bool on_device) {
+    if (!ctx) return -1;
+    if (!rgb || !depth || !poses_out) return fail(ctx, -1, "null pointer");
+    if (n_frames < 1) return fail(ctx, -1, "n_frames must be >= 1");
+    if (n_inflight < 1 || n_inflight > 64) return fail(ctx, -1, "n_inflight must be in 1..64");
+    if (method < 0 || method > 2) return fail(ctx, -4, "bad method");
+    if (occlusion < 0 || occlusion > 2) return fail(ctx, -5, "occlusion must be 0, 1 or 2");
+    if (depth_type != 0 && depth_type != 1) return fail(ctx, -1, "depth_type must be 0 (u16 mm) or 1 (f32 m)");
+    if (n_frames == 1) return 0;
+    for (int k = 0; k < n_frames; ++k)
+        if (!rgb[k] || !depth[k]) return fail(ctx, -1, "null frame pointer");
+    static const float kIdentity[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    const char* route = getenv("RGBD360_SEQ_ROUTE");          // "contexts": the per-context route for every sequence (A/B measurements)
+    // the occlusion-aware passes have no slot dimension: those sequences run one context per sub-chunk
+    if (occlusion != 0 || (route && strcmp(route, "contexts") == 0))
+        return align360_batch_threads(ctx, n_frames, rgb, rgb_step, depth, depth_step, depth_type, rows, cols, guess, method, occlusion,
+                                      std::min(n_inflight, 16), poses_out, results_out, on_device);
+    return align360_batch_lockstep(ctx, n_frames, rgb, rgb_step, depth, depth_step, depth_type, rows, cols, guess ? guess : kIdentity, method,
+                                   n_inflight, poses_out, results_out, on_device);
 }
 
 int rgbd360_align360_batch(rgbd360_ctx* ctx, int n_frames, const uint8_t* const* rgb, size_t rgb_step, const void* const* depth,

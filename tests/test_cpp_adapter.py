@@ -53,6 +53,7 @@ def test_odometry_replay_matches_python_host(tmp_path, hip_lib):
     multi = subprocess.check_output([exe, str(seq), "6", "256", "128", "--multi", "1"], text=True)
     assert multi == batched
     forced = subprocess.check_output([exe, str(seq), "6", "256", "128", "--multi", "1"], text=True, env=dict(os.environ, RGBD360_FORCE_RCCL="1"))
+    forced = "".join(l + "\n" for l in forced.splitlines() if l.startswith("pair "))      # RCCL prints a version banner on stdout
     assert forced == batched                        # the rows went through ncclAllGather (one rank) and came back unchanged
 
 
