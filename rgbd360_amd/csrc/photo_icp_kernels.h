@@ -1386,6 +1386,202 @@ __global__ void k_src_rec_multi_b(SrcJobs jobs, unsigned long long live_mask) {
                jobs.min_depth, jobs.max_depth, jobs.rec[j] + off, r, c);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Fused frame set-up of the sequence engine: ONE launch per pyramid level takes the level's input (level 0: the raw colour /
+// depth images; level >= 1: the float planes the previous launch left) through an LDS tile and writes everything the alignment
+// reads from this level -- the source records {x,y,z,I} (RPI.h:4554-4587), the target records {v,gx,gy} of intensity and depth
+// (calcGradientXY + seam mask, RPI.h:365-398, 4538-4549) -- plus the next level's two planes (cv::pyrDown / buildPyramidRange,
+// RPI.h:292-354).  The level-0 float planes are never stored: 5 B/px in, 40 B/px of records out, against 8 B/px written and
+// 24 B/px re-read by the four separate kernels.  Every value is produced by the same float operations in the same order as
+// gray_u8_x4 / depth_to_f32_x4 / pyrdown_gray_px / pyrdown_depth_px / gradient_rec_px / src_rec_px: records are bit-identical.
+// Tile = 64 x 16 pixels + a 2-pixel ring (the 5x5 binomial of the next level's pixels reaches 2 pixels out; BORDER_REFLECT_101
+// is applied when the ring is loaded, so the window code has no border case).  blockIdx.z = slot.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kFsTW = 64, kFsTH = 16, kFsRing = 2;
+constexpr int kFsLW = kFsTW + 2 * kFsRing, kFsLH = kFsTH + 2 * kFsRing;      // 68 x 20
+constexpr int kFsRawDw = (kFsLW * 3 + 3 + 3) / 4 + 1;                        // dwords that cover 204 bytes at any byte alignment
+struct FrameLevelArgs {
+    int rows, cols;                 // this level
+    int drows, dcols;               // next level (0: none)
+    int seam;                       // seam-mask width (cols / 8) or 0
+    int depth_type;                 // level 0: 0 = u16 mm, 1 = f32 m
+    size_t rgb_step, depth_step;    // level 0: bytes per row of the raw images
+    const float *gray_in, *depth_in;      // level >= 1: [slot][n] planes
+    float *gray_next, *depth_next;        // [slot][drows * dcols]
+    float4* src_rec;                // [slot][n]
+    F3 *trg_p, *trg_d;              // [slot][n]
+    const float *sin_theta, *cos_theta, *sin_phi, *cos_phi;
+    float min_depth, max_depth;
+    unsigned long long live_mask;   // slots with a frame in this launch
+    unsigned long long src_mask;    // ... whose source records are wanted
+    unsigned long long trg_mask;    // ... whose target records are wanted
+};
+
+__device__ __forceinline__ void store_f3x4(F3* __restrict__ rec, const F3 v[4], bool vec_ok) {
+    if (vec_ok) {
+        float4* o = reinterpret_cast<float4*>(rec);
+        o[0] = make_float4(v[0].a, v[0].b, v[0].c, v[1].a);
+        o[1] = make_float4(v[1].b, v[1].c, v[2].a, v[2].b);
+        o[2] = make_float4(v[2].c, v[3].a, v[3].b, v[3].c);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) rec[k] = v[k];
+    }
+}
+
+template <bool RAW>
+__global__ __launch_bounds__(256) void k_frame_level_b(FrameLevelArgs A, FramePtrs fp) {
+    const int slot = blockIdx.z;
+    if (!((A.live_mask >> slot) & 1ull)) return;
+    __shared__ float sg[kFsLH][kFsLW], sd[kFsLH][kFsLW];
+    __shared__ uint32_t raw[RAW ? kFsLH : 1][RAW ? kFsRawDw : 1];
+    const int tid = threadIdx.x;
+    const int c0 = blockIdx.x * kFsTW, r0 = blockIdx.y * kFsTH;
+    const int rows = A.rows, cols = A.cols;
+    const size_t n = (size_t)rows * (size_t)cols;
+    const bool interior = c0 >= kFsRing && c0 + kFsTW + kFsRing <= cols && r0 >= kFsRing && r0 + kFsTH + kFsRing < rows;
+    if (RAW) {
+        const uint8_t* rgb = fp.rgb[slot];
+        const uint8_t* dep = (const uint8_t*)fp.depth[slot];
+        const float k255 = (float)(1. / 255);
+        auto gray = [](unsigned a, unsigned b, unsigned c) { return (int)((4899u * a + 9617u * b + 1868u * c + 8192u) >> 14); };
+        if (interior) {
+            // colour rows as raw dwords (a 3-byte pixel stream has no natural alignment: the covering dwords are loaded, the bytes
+            // are picked out of LDS), depth as direct 2- / 4-byte loads
+            for (int i = tid; i < kFsLH * kFsRawDw; i += 256) {
+                const int ly = i / kFsRawDw, k = i - ly * kFsRawDw;
+                const size_t addr = (size_t)(rgb + (size_t)(r0 - kFsRing + ly) * A.rgb_step + 3 * (size_t)(c0 - kFsRing));
+                raw[ly][k] = *reinterpret_cast<const uint32_t*>((addr & ~(size_t)3) + 4 * (size_t)k);
+            }
+            __syncthreads();
+            for (int i = tid; i < kFsLH * kFsLW; i += 256) {
+                const int ly = i / kFsLW, lx = i - ly * kFsLW;
+                const int r = r0 - kFsRing + ly, c = c0 - kFsRing + lx;
+                const size_t addr = (size_t)(rgb + (size_t)r * A.rgb_step + 3 * (size_t)(c0 - kFsRing));
+                const uint8_t* q = reinterpret_cast<const uint8_t*>(&raw[ly][0]) + (addr & 3) + 3 * lx;
+                sg[ly][lx] = (float)gray(q[0], q[1], q[2]) * k255;
+                const uint8_t* drow = dep + (size_t)r * A.depth_step;
+                sd[ly][lx] = A.depth_type == 0 ? (float)((const uint16_t*)drow)[c] * 0.001f : ((const float*)drow)[c];
+            }
+        } else {
+            for (int i = tid; i < kFsLH * kFsLW; i += 256) {
+                const int ly = i / kFsLW, lx = i - ly * kFsLW;
+                const int r = reflect101(r0 - kFsRing + ly, rows), c = reflect101(c0 - kFsRing + lx, cols);
+                const uint8_t* q = rgb + (size_t)r * A.rgb_step + 3 * (size_t)c;
+                sg[ly][lx] = (float)gray(q[0], q[1], q[2]) * k255;
+                const uint8_t* drow = dep + (size_t)r * A.depth_step;
+                sd[ly][lx] = A.depth_type == 0 ? (float)((const uint16_t*)drow)[c] * 0.001f : ((const float*)drow)[c];
+            }
+        }
+    } else {
+        const float* gin = A.gray_in + (size_t)slot * n;
+        const float* din = A.depth_in + (size_t)slot * n;
+        for (int i = tid; i < kFsLH * kFsLW; i += 256) {
+            const int ly = i / kFsLW, lx = i - ly * kFsLW;
+            int r = r0 - kFsRing + ly, c = c0 - kFsRing + lx;
+            if (!interior) { r = reflect101(r, rows); c = reflect101(c, cols); }
+            sg[ly][lx] = gin[(size_t)r * cols + c];
+            sd[ly][lx] = din[(size_t)r * cols + c];
+        }
+    }
+    __syncthreads();
+
+    // ---- records of the tile: a thread owns 4 consecutive pixels of a row ----
+    {
+        const int ty = tid >> 4, tx = (tid & 15) * 4;
+        const int r = r0 + ty, cb = c0 + tx;
+        if (r < rows && cb < cols) {
+            const bool want_src = (A.src_mask >> slot) & 1ull, want_trg = (A.trg_mask >> slot) & 1ull;
+            const bool full4 = cb + 4 <= cols;
+            const bool vec_ok = full4 && (cols & 3) == 0;
+            const int ly = ty + kFsRing;
+            if (want_src) {
+                const float sp = A.sin_phi[r], cp = A.cos_phi[r];
+                float4* out = A.src_rec + (size_t)slot * n + (size_t)r * cols + cb;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (cb + k >= cols) break;
+                    const int lx = tx + k + kFsRing;
+                    const float d = sd[ly][lx];
+                    float4 o;
+                    o.w = sg[ly][lx];
+                    if (A.min_depth < d && d < A.max_depth) {
+                        o.x = d * sp;
+                        o.y = -d * cp * A.sin_theta[cb + k];
+                        o.z = -d * cp * A.cos_theta[cb + k];
+                    } else {
+                        o.x = kInvalidPoint;
+                        o.y = 0.f;
+                        o.z = 0.f;
+                    }
+                    out[k] = o;
+                }
+            }
+            if (want_trg) {
+#pragma unroll
+                for (int plane = 0; plane < 2; ++plane) {
+                    const float(*S)[kFsLW] = plane == 0 ? sg : sd;
+                    F3 v4[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int c = cb + k, lx = tx + k + kFsRing;
+                        const float v = S[ly][lx];
+                        float gx = 0.f, gy = 0.f;
+                        if (r >= 1 && r < rows - 1 && c >= 1 && c < cols - 1) {
+                            const float xm = S[ly][lx - 1], xp = S[ly][lx + 1];
+                            const float ym = S[ly - 1][lx], yp = S[ly + 1][lx];
+                            if ((v > xp && v < xm) || (v < xp && v > xm)) gx = 2.f / (1 / (xp - v) + 1 / (v - xm));
+                            if ((v > yp && v < ym) || (v < yp && v > ym)) gy = 2.f / (1 / (yp - v) + 1 / (v - ym));
+                        }
+                        if (A.seam > 1) {
+                            int sidx, rem;
+                            divmod24(c + 1, A.seam, sidx, rem);
+                            if (rem <= 1 && sidx >= 1 && sidx <= 7) gx = gy = 0.f;
+                        } else if (A.seam == 1) {
+                            if (c + 1 >= 1 && c <= 7) gx = gy = 0.f;
+                        }
+                        v4[k].a = v; v4[k].b = gx; v4[k].c = gy;
+                    }
+                    F3* rec = (plane == 0 ? A.trg_p : A.trg_d) + (size_t)slot * n + (size_t)r * cols + cb;
+                    if (full4) store_f3x4(rec, v4, vec_ok);
+                    else
+                        for (int k = 0; k < 4 && cb + k < cols; ++k) rec[k] = v4[k];
+                }
+            }
+        }
+    }
+    // ---- the next level's planes: one output pixel per thread (32 x 8 per tile) ----
+    if (A.drows > 0) {
+        const int oy = tid >> 5, ox = tid & 31;
+        const int x = (c0 >> 1) + ox, y = (r0 >> 1) + oy;
+        if (x < A.dcols && y < A.drows) {
+            const size_t dn = (size_t)A.drows * (size_t)A.dcols;
+            const int ly = 2 * oy, lx = 2 * ox;      // window origin (2y - 2, 2x - 2) in tile coordinates
+            float h[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const float* row = &sg[ly + k][lx];
+                h[k] = row[2] * 6 + (row[1] + row[3]) * 4 + row[0] + row[4];
+            }
+            const float v = h[2] * 6 + (h[1] + h[3]) * 4 + h[0] + h[4];
+            A.gray_next[(size_t)slot * dn + (size_t)y * A.dcols + x] = v * (1.f / 256.f);
+            float av = 0.f;
+            unsigned cnt = 0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float z = sd[ly + kFsRing + i][lx + kFsRing + j];
+                    if (z > A.min_depth && z < A.max_depth) {
+                        av += z;
+                        ++cnt;
+                    }
+                }
+            A.depth_next[(size_t)slot * dn + (size_t)y * A.dcols + x] = cnt > 0 ? av / cnt : 0.f;
+        }
+    }
+}
+
 // Frame360 sphere clouds (Frame360.h:555-612, Frame360_stereo.h:454-512) and the RegisterPhotoICP convention.
 __device__ __forceinline__ void sphere_point(int convention, float d, float sp, float cp, float st, float ct, float& x, float& y, float& z) {
     const float qnan = __builtin_nanf("");

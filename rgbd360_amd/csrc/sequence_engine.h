@@ -18,9 +18,10 @@ namespace {
 struct SeqLevel {
     int rows = 0, cols = 0, n = 0;
     float half_nRows = 0.f, angle_res_inv = 0.f;
-    float *gray[2] = {nullptr, nullptr}, *depth[2] = {nullptr, nullptr};      // [P][n] plane sets; the source / target roles alternate
+    float *gray = nullptr, *depth = nullptr;                                    // [P][n] planes of levels >= 1 (level 0 is never stored)
     float4* srcRec = nullptr;                                                   // [P][n]
-    F3 *trgP = nullptr, *trgD = nullptr;                                        // [P][n]
+    F3 *trgP[2] = {nullptr, nullptr}, *trgD[2] = {nullptr, nullptr};            // [P][n] x 2: the records of a frame are built when it
+                                                                                // arrives as a source, one round before it is the target
     float *sinT = nullptr, *cosT = nullptr, *sinP = nullptr, *cosP = nullptr;
     int nblocks = 0, chunk = 0;
 };
@@ -37,7 +38,7 @@ struct SeqEngine {
     int partials_stride = 0;          // doubles per slot
     uint8_t *stage_rgb[2] = {nullptr, nullptr}, *stage_depth[2] = {nullptr, nullptr};      // [P] frames each (host-frame sequences)
     size_t stage_rgb_frame = 0, stage_depth_frame = 0;
-    int src_set = 0;                  // which plane set holds the SOURCE frames of the round
+    int tb = 0;                       // which target-record buffer holds the TARGETS of the round
     int max_eval_blocks = 256;
     int chunk_top = 8, chunk_mid = 4, chunk_l0 = 4;      // {pass, solve} pairs enqueued ahead per level and visit
     std::string err;
@@ -58,8 +59,8 @@ void seq_free(SeqEngine* E) {
     if (E->stream) hipStreamSynchronize(E->stream);
     if (E->up_stream) hipStreamSynchronize(E->up_stream);
     for (SeqLevel& L : E->levels) {
-        for (int k = 0; k < 2; ++k) { hipFree(L.gray[k]); hipFree(L.depth[k]); }
-        hipFree(L.srcRec); hipFree(L.trgP); hipFree(L.trgD);
+        hipFree(L.gray); hipFree(L.depth); hipFree(L.srcRec);
+        for (int k = 0; k < 2; ++k) { hipFree(L.trgP[k]); hipFree(L.trgD[k]); }
         hipFree(L.sinT); hipFree(L.cosT); hipFree(L.sinP); hipFree(L.cosP);
     }
     hipFree(E->d_states); hipFree(E->d_partials);
@@ -112,10 +113,10 @@ int seq_create(const rgbd360_params& p, int P, int rows, int cols, int max_eval_
         L.half_nRows = 0.5 * r - 0.5;               // RPI.h:2557
         const size_t np = (size_t)P * L.n;
         bool ok = true;
+        if (l > 0) ok = ok && hipMalloc(&L.gray, np * sizeof(float)) == hipSuccess && hipMalloc(&L.depth, np * sizeof(float)) == hipSuccess;
+        ok = ok && hipMalloc(&L.srcRec, np * sizeof(float4)) == hipSuccess;
         for (int k = 0; k < 2; ++k)
-            ok = ok && hipMalloc(&L.gray[k], np * sizeof(float)) == hipSuccess && hipMalloc(&L.depth[k], np * sizeof(float)) == hipSuccess;
-        ok = ok && hipMalloc(&L.srcRec, np * sizeof(float4)) == hipSuccess && hipMalloc(&L.trgP, np * sizeof(F3)) == hipSuccess &&
-             hipMalloc(&L.trgD, np * sizeof(F3)) == hipSuccess;
+            ok = ok && hipMalloc(&L.trgP[k], np * sizeof(F3)) == hipSuccess && hipMalloc(&L.trgD[k], np * sizeof(F3)) == hipSuccess;
         ok = ok && hipMalloc(&L.sinT, c * sizeof(float)) == hipSuccess && hipMalloc(&L.cosT, c * sizeof(float)) == hipSuccess &&
              hipMalloc(&L.sinP, r * sizeof(float)) == hipSuccess && hipMalloc(&L.cosP, r * sizeof(float)) == hipSuccess;
         if (!ok) return bad("out of device memory for the sequence engine");
@@ -152,18 +153,18 @@ int seq_create(const rgbd360_params& p, int P, int rows, int cols, int max_eval_
     return 0;
 }
 
-LevelDev seq_level_dev(const SeqLevel& L) {
+LevelDev seq_level_dev(const SeqLevel& L, int tb) {
     LevelDev d;
     d.rows = L.rows; d.cols = L.cols; d.n = L.n;
     d.half_nRows = L.half_nRows; d.angle_res_inv = L.angle_res_inv;
     d.pi_k = (float)(kPI * (double)L.angle_res_inv);
-    d.src = L.srcRec; d.trgP = L.trgP; d.trgD = L.trgD;
+    d.src = L.srcRec; d.trgP = L.trgP[tb]; d.trgD = L.trgD[tb];
     return d;
 }
 
 void seq_launch_eval(SeqEngine* E, int level, int method) {
     const SeqLevel& L = E->levels[level];
-    const LevelDev lv = seq_level_dev(L);
+    const LevelDev lv = seq_level_dev(L, E->tb);
     const EvalConsts ec = eval_consts(E->p);
     const dim3 g(L.nblocks, E->P), b(kEvalThreads);
 #define LAUNCHB(M) hipLaunchKernelGGL((k_eval_b<M, true>), g, b, 0, E->stream, E->d_states, lv.src, lv.n, L.chunk, level, L.nblocks, E->d_partials, E->partials_stride, lv, ec)
@@ -198,62 +199,31 @@ void seq_enqueue_schedule(SeqEngine* E, int pending, bool pending_started, const
     }
 }
 
-// gradient records of the current TARGET planes of every live slot, all levels x {intensity, depth}, one launch
-void seq_launch_gradient_recs(SeqEngine* E, unsigned long long live) {
-    GradJobs jobs;
-    int nb = 0, n = 0;
-    const int trg = 1 - E->src_set;
+// One frame per live slot through the fused set-up (k_frame_level_b, one launch per pyramid level): source records for the slots
+// of src_mask, target records (into buffer trg_buf) for those of trg_mask, next-level planes for all.
+void seq_frame_setup(SeqEngine* E, const FramePtrs& fp, size_t rgb_step, size_t depth_step, int depth_type, unsigned long long live,
+                     unsigned long long src_mask, unsigned long long trg_mask, int trg_buf) {
     for (int l = 0; l < E->p.n_pyr; ++l) {
         const SeqLevel& L = E->levels[l];
-        const int seam = E->p.mask_seams ? L.cols / 8 : 0;
-        for (int k = 0; k < 2; ++k) {
-            jobs.src[n] = k == 0 ? L.gray[trg] : L.depth[trg];
-            jobs.rec[n] = k == 0 ? L.trgP : L.trgD;
-            jobs.rows[n] = L.rows; jobs.cols[n] = L.cols; jobs.seam[n] = seam;
-            jobs.first_block[n] = nb;
-            nb += (L.n + 255) / 256;
-            ++n;
+        FrameLevelArgs A;
+        memset(&A, 0, sizeof(A));
+        A.rows = L.rows; A.cols = L.cols;
+        if (l + 1 < E->p.n_pyr) {
+            const SeqLevel& N = E->levels[l + 1];
+            A.drows = N.rows; A.dcols = N.cols;
+            A.gray_next = N.gray; A.depth_next = N.depth;
         }
-    }
-    jobs.first_block[n] = nb;
-    jobs.n = n;
-    hipLaunchKernelGGL(k_gradient_rec_multi_b, dim3(nb, E->P), dim3(256), 0, E->stream, jobs, live);
-}
-
-void seq_launch_src_recs(SeqEngine* E, unsigned long long live) {
-    SrcJobs jobs;
-    int nb = 0, n = 0;
-    const int s = E->src_set;
-    for (int l = 0; l < E->p.n_pyr; ++l) {
-        const SeqLevel& L = E->levels[l];
-        jobs.depth[n] = L.depth[s]; jobs.gray[n] = L.gray[s];
-        jobs.sin_theta[n] = L.sinT; jobs.cos_theta[n] = L.cosT; jobs.sin_phi[n] = L.sinP; jobs.cos_phi[n] = L.cosP;
-        jobs.rec[n] = L.srcRec;
-        jobs.rows[n] = L.rows; jobs.cols[n] = L.cols;
-        jobs.first_block[n] = nb;
-        nb += (L.n + 255) / 256;
-        ++n;
-    }
-    jobs.first_block[n] = nb;
-    jobs.n = n;
-    jobs.min_depth = E->p.min_depth; jobs.max_depth = E->p.max_depth;
-    hipLaunchKernelGGL(k_src_rec_multi_b, dim3(nb, E->P), dim3(256), 0, E->stream, jobs, live);
-}
-
-// colour / depth images of the live slots -> float planes of set `set`, all pyramid levels
-void seq_convert_and_reduce(SeqEngine* E, const FramePtrs& fp, size_t rgb_step, size_t depth_step, int depth_type, int set,
-                            unsigned long long live) {
-    SeqLevel& L0 = E->levels[0];
-    {
-        dim3 g((((L0.cols + 3) / 4) + 255) / 256, L0.rows, 2 * E->P);
-        hipLaunchKernelGGL(k_convert_pair_b, g, dim3(256), 0, E->stream, fp, rgb_step, depth_step, depth_type, L0.rows, L0.cols, L0.gray[set],
-                           L0.depth[set], live);
-    }
-    for (int l = 1; l < E->p.n_pyr; ++l) {
-        SeqLevel &Pv = E->levels[l - 1], &C = E->levels[l];
-        dim3 g((C.cols + 255) / 256, C.rows, 2 * E->P);
-        hipLaunchKernelGGL(k_pyrdown_pair_b, g, dim3(256), 0, E->stream, Pv.gray[set], Pv.depth[set], Pv.rows, Pv.cols, C.gray[set], C.depth[set],
-                           C.rows, C.cols, E->p.min_depth, E->p.max_depth, live);
+        A.seam = E->p.mask_seams ? L.cols / 8 : 0;
+        A.depth_type = depth_type;
+        A.rgb_step = rgb_step; A.depth_step = depth_step;
+        A.gray_in = L.gray; A.depth_in = L.depth;
+        A.src_rec = L.srcRec; A.trg_p = L.trgP[trg_buf]; A.trg_d = L.trgD[trg_buf];
+        A.sin_theta = L.sinT; A.cos_theta = L.cosT; A.sin_phi = L.sinP; A.cos_phi = L.cosP;
+        A.min_depth = E->p.min_depth; A.max_depth = E->p.max_depth;
+        A.live_mask = live; A.src_mask = src_mask; A.trg_mask = trg_mask;
+        const dim3 g((L.cols + kFsTW - 1) / kFsTW, (L.rows + kFsTH - 1) / kFsTH, E->P);
+        if (l == 0) hipLaunchKernelGGL((k_frame_level_b<true>), g, dim3(256), 0, E->stream, A, fp);
+        else hipLaunchKernelGGL((k_frame_level_b<false>), g, dim3(256), 0, E->stream, A, fp);
     }
 }
 
@@ -360,24 +330,21 @@ int seq_run(SeqEngine* E, int n_slots, const int* a, const int* b, const uint8_t
         FramePtrs fp;
         size_t rs, ds;
         if (r == 0) {
-            // first targets: frames a[s] into the TARGET plane set
+            // first targets: frames a[s], target records only, into buffer tb
             frame_ptrs(0, 0, par, live, &fp, &rs, &ds);
             if (!on_device) SEQC(E, hipStreamWaitEvent(E->stream, E->up_ev[par], 0));
-            seq_convert_and_reduce(E, fp, rs, ds, depth_type, 1 - E->src_set, live);
+            seq_frame_setup(E, fp, rs, ds, depth_type, live, 0ull, live, E->tb);
             if (!on_device) { SEQC(E, hipEventRecord(E->conv_ev[par], E->stream)); par ^= 1; }
-        } else {
-            E->src_set = 1 - E->src_set;      // last round's sources are this round's targets (promote: the planes change role)
         }
-        seq_launch_gradient_recs(E, live);
-        // sources of this round
+        // sources of this round; they are the targets of the next one in every slot that has another pair: their target
+        // records go into the other buffer now, while the tile is in LDS anyway
         frame_ptrs(r, 1, par, live, &fp, &rs, &ds);
         if (!on_device) SEQC(E, hipStreamWaitEvent(E->stream, E->up_ev[par], 0));
-        seq_convert_and_reduce(E, fp, rs, ds, depth_type, E->src_set, live);
+        seq_frame_setup(E, fp, rs, ds, depth_type, live, live, live & live_of(r + 1), E->tb ^ 1);
         if (!on_device) {
             SEQC(E, hipEventRecord(E->conv_ev[par], E->stream));
             par ^= 1;
         }
-        seq_launch_src_recs(E, live);
         seq_enqueue_schedule(E, E->p.n_pyr - 1, false, guess, method, live);
         SEQC(E, hipGetLastError());
         // next round's sources travel while this round is being aligned (a pageable-memory copy keeps the host in the call, so
@@ -404,6 +371,7 @@ int seq_run(SeqEngine* E, int n_slots, const int* a, const int* b, const uint8_t
             const int j = a[s] + r;
             result_from_state(E->h_states[s], E->p.n_pyr, 0, poses_out + (size_t)16 * j, results_out ? &results_out[j] : nullptr);
         }
+        E->tb ^= 1;      // this round's sources are the next round's targets
     }
     if (E->up_stream) SEQC(E, hipStreamSynchronize(E->up_stream));      // no upload may outlive the caller's buffers
     return 0;

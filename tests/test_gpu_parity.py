@@ -639,6 +639,28 @@ def test_native_batch_threads_blank_frame_and_odd_spans(hip_lib):
         assert np.array_equal(out[16 * j:16 * j + 16].reshape(4, 4).T, p3[j]), j
 
 
+@pytest.mark.parametrize("W,H,n_pyr", [(250, 101, 3), (480, 80, 3), (1000, 37, 2), (66, 18, 1), (130, 34, 2)])
+def test_lockstep_engine_ragged_sizes(hip_lib, W, H, n_pyr):
+    """The sequence engine's fused frame set-up (one tiled launch per level: records + next level's planes) and slot-batched passes
+    on sizes that are no multiple of the 64 x 16 tile, of 4 columns or of 2: the poses of rgbd360_align360_batch are bit-identical
+    to the pair-by-pair path (whose set-up kernels work per pixel), for host frames and for float depth."""
+    from rgbd360_amd.batch import align_sequence
+    frames = [synth.render(synth.trajectory_pose(k, 7), W, H, 7) for k in range(5)]
+    poses, status, iters = align_sequence(_mk(hip_lib, n_pyr), lambda k: frames[k], 0, 4, 2)
+    reg = _mk(hip_lib, n_pyr)
+    for k in (1, 3, 4):
+        p2, s2, i2 = reg.alignSequence(frames, method=2, n_inflight=k)
+        assert np.array_equal(status, s2) and np.array_equal(iters, i2) and np.array_equal(poses, p2), k
+    for m in (0, 1):
+        pm, sm, im = align_sequence(_mk(hip_lib, n_pyr), lambda k: frames[k], 0, 4, m)
+        p3, s3, i3 = reg.alignSequence(frames, method=m, n_inflight=4)
+        assert np.array_equal(sm, s3) and np.array_equal(im, i3) and np.array_equal(pm, p3), m
+    f32 = [(f[0], f[1].astype(np.float32) * np.float32(0.001)) for f in frames]
+    pf, sf, itf = align_sequence(_mk(hip_lib, n_pyr), lambda k: f32[k], 0, 4, 2)
+    p4, s4, i4 = reg.alignSequence(f32, method=2, n_inflight=2)
+    assert np.array_equal(sf, s4) and np.array_equal(itf, i4) and np.array_equal(pf, p4)
+
+
 # ---- occlusion-aware variants (SURVEY.md 8f rank 1; RPI.h:3232-4249, sequential semantics) ---------------------------
 _occluder_pair = synth.add_occluder
 _occ_poses = synth.occlusion_test_poses
