@@ -45,6 +45,7 @@ BYTES_PER_PX = {0: 28, 1: 28, 2: 40}   # LUT variant: 16 B source record + 12 B 
 WORKING_SET_PER_PX = {0: 28, 1: 28, 2: 40}
 METHOD_NAMES = {0: "PHOTO_CONSISTENCY", 1: "DEPTH_CONSISTENCY", 2: "PHOTO_DEPTH"}
 SEQ_UNIQUE_FRAMES = 9          # frames rendered per rank for the sequence block (walked back and forth)
+SEQ_INFLIGHT = 16              # pairs in flight per GPU: slots of the lock-step sequence engine (2 engines x 8)
 
 
 def avg_kernel_us(fn, batches=5):
@@ -368,13 +369,13 @@ def run_sequence_block(args, torch, dist, synth, reg0, rank, world, local_rank, 
     for variant in ("resident", "host_frames"):
         def run():
             if variant == "resident":
-                return reg.alignSequenceDev(rgb_ptrs, dep_ptrs, H, W, 0, method=method, n_inflight=3)
-            return reg.alignSequence(host_frames, method=method, n_inflight=3)
+                return reg.alignSequenceDev(rgb_ptrs, dep_ptrs, H, W, 0, method=method, n_inflight=SEQ_INFLIGHT)
+            return reg.alignSequence(host_frames, method=method, n_inflight=SEQ_INFLIGHT)
         if n_loc > 0:
             if variant == "resident":
-                reg.alignSequenceDev(rgb_ptrs[:8], dep_ptrs[:8], H, W, 0, method=method, n_inflight=3)      # warm (sibling contexts, buffers)
+                reg.alignSequenceDev(rgb_ptrs[:2 * SEQ_INFLIGHT + 1], dep_ptrs[:2 * SEQ_INFLIGHT + 1], H, W, 0, method=method, n_inflight=SEQ_INFLIGHT)      # warm (engines, buffers)
             else:
-                reg.alignSequence(host_frames[:8], method=method, n_inflight=3)
+                reg.alignSequence(host_frames[:2 * SEQ_INFLIGHT + 1], method=method, n_inflight=SEQ_INFLIGHT)
         times, res = [], None
         for _ in range(3):
             sync_all()
@@ -422,8 +423,8 @@ def run_sequence_block(args, torch, dist, synth, reg0, rank, world, local_rank, 
         }
     reg.close()
     out.update({"workload": "configs[3]: %d consecutive %dx%d pairs (PHOTO_DEPTH, 4 levels), contiguous shards over %d rank(s), "
-                            "rgbd360_align360_batch[_dev] per rank (3 sub-chunks in flight), one all-gather of pose/status/iters"
-                            % (n_total, W, H, world),
+                            "rgbd360_align360_batch[_dev] per rank (lock-step engine, %d pairs in flight), one all-gather of pose/status/iters"
+                            % (n_total, W, H, world, SEQ_INFLIGHT),
                 "pairs_total": n_total, "pairs_per_rank": -(-n_total // world), "unique_frames_per_rank": SEQ_UNIQUE_FRAMES,
                 "render_s": t_render, "exchange": "gloo (shared device)" if xdev == "cpu" and world > 1 else ("rccl" if world > 1 else "none")})
     # the child process of the native multi-GPU entry re-uses rank 0's frames instead of rendering again

@@ -132,11 +132,11 @@ class RegisterPhotoICP {
     }
 
     // The frame loop of OdometryRGBD360.cpp:141-297 as one call (rgbd360_align360_batch): pair j aligns frame j+1 (source)
-    // to frame j (target); every frame is uploaded once, n_inflight sub-sequences run concurrently on the GPU.  All
+    // to frame j (target); every frame is uploaded once, n_inflight pairs are in flight on the GPU (lock-step slots of the sequence engine).  All
     // frames must share one size and depth type, and stay untouched until the call returns.  Returns the relative poses;
     // statuses (0 / ILL_POSED / NO_VALID_PIXELS per pair) and full records through the optional outputs.
     std::vector<Mat4f> alignSequence(const std::vector<ImageView>& rgb, const std::vector<ImageView>& depth,
-                                     costFuncType method = PHOTO_DEPTH, int occlusion = 0, int n_inflight = 3,
+                                     costFuncType method = PHOTO_DEPTH, int occlusion = 0, int n_inflight = 16,
                                      const Mat4f& pose_guess = Mat4f::Identity(), std::vector<rgbd360_result>* results = nullptr) {
         if (rgb.size() != depth.size()) throw std::invalid_argument("rgbd360: rgb / depth sequence length mismatch");
         const size_t n_frames = rgb.size();

@@ -113,15 +113,17 @@ int rgbd360_align360_begin(rgbd360_ctx* ctx, const float guess[16], int method, 
 int rgbd360_align360_finish(rgbd360_ctx* ctx, float pose_out[16], rgbd360_result* res);
 
 /* A sequence of n_frames frames = n_frames-1 consecutive pairs (pair j: frame j = target, frame j+1 = source), the way
- * OdometryRGBD360.cpp:141-297 walks a sequence; SURVEY.md 8b/8e's batch entry for ONE GPU (multi-GPU = one process per GPU,
- * each calling this on its contiguous shard; see rgbd360_amd/batch.py).  rgb[k] / depth[k]: host images as in
- * rgbd360_set_target.  The pairs are split into n_inflight (1..16) contiguous sub-chunks that run concurrently, each on its
- * own context, stream and host thread (created by and owned by `ctx`); inside a sub-chunk every frame is uploaded once, one
- * frame ahead of its alignment on a copy stream: the host images must stay unchanged until the call returns.  3 in flight
- * keep the copy engine and the CUs busy.  guess (NULL =
- * identity) is the initial pose of every pair.  poses_out: (n_frames-1) x 16 floats column-major; results_out (may be NULL):
- * n_frames-1 records whose .status carries the per-pair outcome (0 / ILL_POSED / NO_VALID_PIXELS).  Returns 0, or the first
- * negative error. */
+ * OdometryRGBD360.cpp:141-297 walks a sequence; SURVEY.md 8b/8e's batch entry for ONE GPU (several GPUs: rgbd360_multi_* below,
+ * or one process per GPU each calling this on its contiguous shard, rgbd360_amd/batch.py).  rgb[k] / depth[k]: host images as
+ * in rgbd360_set_target.  n_inflight (1..64) pairs are in flight: the sequence is cut into that many contiguous spans ("slots")
+ * which advance in lock step -- every kernel launch of a round (frame set-up, each pass and solve of each pyramid level)
+ * carries a slot dimension, so a round of n_inflight alignments costs the launch count of one (csrc/sequence_engine.h;
+ * 16 = two engines of 8 slots is the measured optimum at 2048x1024).  Inside a span every frame is uploaded once,
+ * one round ahead of its alignment on a copy stream: the host images must stay unchanged until the call returns.  Poses are
+ * bit-identical to rgbd360_align360 pair by pair, whatever n_inflight.  The occlusion-aware variants run one context per span
+ * instead (n_inflight capped at 16).  guess (NULL = identity) is the initial pose of every pair.  poses_out: (n_frames-1) x 16
+ * floats column-major; results_out (may be NULL): n_frames-1 records whose .status carries the per-pair outcome (0 / ILL_POSED
+ * / NO_VALID_PIXELS).  Returns 0, or the first negative error. */
 int rgbd360_align360_batch(rgbd360_ctx* ctx, int n_frames, const uint8_t* const* rgb, size_t rgb_step, const void* const* depth,
                            size_t depth_step, int depth_type, int rows, int cols, const float guess[16], int method,
                            int occlusion, int n_inflight, float* poses_out, rgbd360_result* results_out);

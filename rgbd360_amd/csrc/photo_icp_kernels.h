@@ -1417,17 +1417,16 @@ struct FrameLevelArgs {
     unsigned long long trg_mask;    // ... whose target records are wanted
 };
 
-__device__ __forceinline__ void store_f3x4(F3* __restrict__ rec, const F3 v[4], bool vec_ok) {
-    if (vec_ok) {
-        float4* o = reinterpret_cast<float4*>(rec);
-        o[0] = make_float4(v[0].a, v[0].b, v[0].c, v[1].a);
-        o[1] = make_float4(v[1].b, v[1].c, v[2].a, v[2].b);
-        o[2] = make_float4(v[2].c, v[3].a, v[3].b, v[3].c);
-    } else {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) rec[k] = v[k];
-    }
+// 1.f / x, bit for bit: inside [2^-60, 2^60] the 3-instruction rcp_rn (proven equal to the IEEE quotient over that whole range by
+// rgbd360_selftest_math), the compiler's division sequence (~12 instructions) elsewhere -- a branch no real image takes.
+__device__ __forceinline__ float rcp_ieee(float x) {
+    const float ax = fabsf(x);
+    if (ax >= 0x1p-60f && ax <= 0x1p60f) return rcp_rn(x);
+    return 1.f / x;
 }
+// calcGradientXY's harmonic mean of the two one-sided differences, 2 / (1 / a + 1 / b) (RPI.h:381-390): a and b have the same
+// sign here, 2 * RN(1 / s) == RN(2 / s) (scaling by 2 is exact), so this equals gradient_rec_px's three IEEE divisions bit for bit.
+__device__ __forceinline__ float harmonic2(float a, float b) { return 2.f * rcp_ieee(rcp_ieee(a) + rcp_ieee(b)); }
 
 template <bool RAW>
 __global__ __launch_bounds__(256) void k_frame_level_b(FrameLevelArgs A, FramePtrs fp) {
@@ -1439,36 +1438,66 @@ __global__ __launch_bounds__(256) void k_frame_level_b(FrameLevelArgs A, FramePt
     const int c0 = blockIdx.x * kFsTW, r0 = blockIdx.y * kFsTH;
     const int rows = A.rows, cols = A.cols;
     const size_t n = (size_t)rows * (size_t)cols;
-    const bool interior = c0 >= kFsRing && c0 + kFsTW + kFsRing <= cols && r0 >= kFsRing && r0 + kFsTH + kFsRing < rows;
+    constexpr int kPerThread = (kFsLH * kFsLW + 255) / 256;      // 6 tile pixels per thread in the load phase
     if (RAW) {
         const uint8_t* rgb = fp.rgb[slot];
         const uint8_t* dep = (const uint8_t*)fp.depth[slot];
         const float k255 = (float)(1. / 255);
         auto gray = [](unsigned a, unsigned b, unsigned c) { return (int)((4899u * a + 9617u * b + 1868u * c + 8192u) >> 14); };
-        if (interior) {
-            // colour rows as raw dwords (a 3-byte pixel stream has no natural alignment: the covering dwords are loaded, the bytes
-            // are picked out of LDS), depth as direct 2- / 4-byte loads
-            for (int i = tid; i < kFsLH * kFsRawDw; i += 256) {
-                const int ly = i / kFsRawDw, k = i - ly * kFsRawDw;
-                const size_t addr = (size_t)(rgb + (size_t)(r0 - kFsRing + ly) * A.rgb_step + 3 * (size_t)(c0 - kFsRing));
-                raw[ly][k] = *reinterpret_cast<const uint32_t*>((addr & ~(size_t)3) + 4 * (size_t)k);
+        // Colour rows travel as raw dwords: a 3-byte pixel stream has no natural alignment, so the dwords covering the tile's
+        // 68-pixel column span [cs, cs + 68) are loaded and the bytes are picked out of LDS.  The span is clamped into the image
+        // (at the left / right border the reflected ring columns lie inside it), ring rows are loaded from their reflected row.
+        // Not for tiles that reach the last image row (a covering dword may extend 3 bytes past a row's pixels) or images
+        // narrower than the span: those read byte by byte.
+        const bool fast = cols >= kFsLW && r0 + kFsTH + kFsRing < rows && (r0 > 0 || ((size_t)rgb & 3) == 0);
+        const int cs = min(max(c0 - kFsRing, 0), cols - kFsLW);
+        float dv[kPerThread];
+        if (fast) {
+            uint32_t rw[(kFsLH * kFsRawDw + 255) / 256];
+#pragma unroll
+            for (int q = 0; q < (kFsLH * kFsRawDw + 255) / 256; ++q) {
+                const int i = tid + q * 256;
+                const int ly = min(i / kFsRawDw, kFsLH - 1), k = i - (i / kFsRawDw) * kFsRawDw;
+                const int r = reflect101(r0 - kFsRing + ly, rows);
+                const size_t addr = (size_t)(rgb + (size_t)r * A.rgb_step + 3 * (size_t)cs);
+                rw[q] = *reinterpret_cast<const uint32_t*>((addr & ~(size_t)3) + 4 * (size_t)k);
+            }
+#pragma unroll
+            for (int q = 0; q < kPerThread; ++q) {
+                const int i = min(tid + q * 256, kFsLH * kFsLW - 1);
+                const int ly = i / kFsLW, lx = i - ly * kFsLW;
+                const int r = reflect101(r0 - kFsRing + ly, rows), c = reflect101(c0 - kFsRing + lx, cols);
+                const uint8_t* drow = dep + (size_t)r * A.depth_step;
+                dv[q] = A.depth_type == 0 ? (float)((const uint16_t*)drow)[c] * 0.001f : ((const float*)drow)[c];
+            }
+#pragma unroll
+            for (int q = 0; q < (kFsLH * kFsRawDw + 255) / 256; ++q) {
+                const int i = tid + q * 256;
+                if (i < kFsLH * kFsRawDw) raw[i / kFsRawDw][i - (i / kFsRawDw) * kFsRawDw] = rw[q];
+            }
+#pragma unroll
+            for (int q = 0; q < kPerThread; ++q) {
+                const int i = tid + q * 256;
+                if (i < kFsLH * kFsLW) sd[i / kFsLW][i - (i / kFsLW) * kFsLW] = dv[q];
             }
             __syncthreads();
-            for (int i = tid; i < kFsLH * kFsLW; i += 256) {
-                const int ly = i / kFsLW, lx = i - ly * kFsLW;
-                const int r = r0 - kFsRing + ly, c = c0 - kFsRing + lx;
-                const size_t addr = (size_t)(rgb + (size_t)r * A.rgb_step + 3 * (size_t)(c0 - kFsRing));
-                const uint8_t* q = reinterpret_cast<const uint8_t*>(&raw[ly][0]) + (addr & 3) + 3 * lx;
-                sg[ly][lx] = (float)gray(q[0], q[1], q[2]) * k255;
-                const uint8_t* drow = dep + (size_t)r * A.depth_step;
-                sd[ly][lx] = A.depth_type == 0 ? (float)((const uint16_t*)drow)[c] * 0.001f : ((const float*)drow)[c];
+#pragma unroll
+            for (int q = 0; q < kPerThread; ++q) {
+                const int i = tid + q * 256;
+                if (i < kFsLH * kFsLW) {
+                    const int ly = i / kFsLW, lx = i - ly * kFsLW;
+                    const int r = reflect101(r0 - kFsRing + ly, rows), c = reflect101(c0 - kFsRing + lx, cols);
+                    const size_t addr = (size_t)(rgb + (size_t)r * A.rgb_step + 3 * (size_t)cs);
+                    const uint8_t* px = reinterpret_cast<const uint8_t*>(&raw[ly][0]) + (addr & 3) + 3 * (c - cs);
+                    sg[ly][lx] = (float)gray(px[0], px[1], px[2]) * k255;
+                }
             }
         } else {
             for (int i = tid; i < kFsLH * kFsLW; i += 256) {
                 const int ly = i / kFsLW, lx = i - ly * kFsLW;
                 const int r = reflect101(r0 - kFsRing + ly, rows), c = reflect101(c0 - kFsRing + lx, cols);
-                const uint8_t* q = rgb + (size_t)r * A.rgb_step + 3 * (size_t)c;
-                sg[ly][lx] = (float)gray(q[0], q[1], q[2]) * k255;
+                const uint8_t* px = rgb + (size_t)r * A.rgb_step + 3 * (size_t)c;
+                sg[ly][lx] = (float)gray(px[0], px[1], px[2]) * k255;
                 const uint8_t* drow = dep + (size_t)r * A.depth_step;
                 sd[ly][lx] = A.depth_type == 0 ? (float)((const uint16_t*)drow)[c] * 0.001f : ((const float*)drow)[c];
             }
@@ -1476,76 +1505,93 @@ __global__ __launch_bounds__(256) void k_frame_level_b(FrameLevelArgs A, FramePt
     } else {
         const float* gin = A.gray_in + (size_t)slot * n;
         const float* din = A.depth_in + (size_t)slot * n;
-        for (int i = tid; i < kFsLH * kFsLW; i += 256) {
+        float gv[kPerThread], dv[kPerThread];
+#pragma unroll
+        for (int q = 0; q < kPerThread; ++q) {      // all loads of the tile first, then the LDS writes: one memory round trip
+            const int i = min(tid + q * 256, kFsLH * kFsLW - 1);
             const int ly = i / kFsLW, lx = i - ly * kFsLW;
-            int r = r0 - kFsRing + ly, c = c0 - kFsRing + lx;
-            if (!interior) { r = reflect101(r, rows); c = reflect101(c, cols); }
-            sg[ly][lx] = gin[(size_t)r * cols + c];
-            sd[ly][lx] = din[(size_t)r * cols + c];
+            const int r = reflect101(r0 - kFsRing + ly, rows), c = reflect101(c0 - kFsRing + lx, cols);
+            gv[q] = gin[(size_t)r * cols + c];
+            dv[q] = din[(size_t)r * cols + c];
+        }
+#pragma unroll
+        for (int q = 0; q < kPerThread; ++q) {
+            const int i = tid + q * 256;
+            if (i < kFsLH * kFsLW) {
+                sg[i / kFsLW][i - (i / kFsLW) * kFsLW] = gv[q];
+                sd[i / kFsLW][i - (i / kFsLW) * kFsLW] = dv[q];
+            }
         }
     }
     __syncthreads();
 
-    // ---- records of the tile: a thread owns 4 consecutive pixels of a row ----
+    // ---- records of the tile.  A thread owns the pixels j, j + 16, j + 32, j + 48 of one tile row (16 threads per row): every
+    //      store instruction then writes, per row, 16 consecutive records -- 256 B of source records, 192 B of target records, whole
+    //      64-byte segments -- instead of 64 lanes each dropping 16 bytes into a different segment (which ran at 1.8 TB/s) ----
     {
-        const int ty = tid >> 4, tx = (tid & 15) * 4;
-        const int r = r0 + ty, cb = c0 + tx;
-        if (r < rows && cb < cols) {
+        const int ty = tid >> 4, tj = tid & 15;
+        const int r = r0 + ty;
+        if (r < rows) {
             const bool want_src = (A.src_mask >> slot) & 1ull, want_trg = (A.trg_mask >> slot) & 1ull;
-            const bool full4 = cb + 4 <= cols;
-            const bool vec_ok = full4 && (cols & 3) == 0;
             const int ly = ty + kFsRing;
             if (want_src) {
                 const float sp = A.sin_phi[r], cp = A.cos_phi[r];
-                float4* out = A.src_rec + (size_t)slot * n + (size_t)r * cols + cb;
+                float4* out = A.src_rec + (size_t)slot * n + (size_t)r * cols;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    if (cb + k >= cols) break;
-                    const int lx = tx + k + kFsRing;
-                    const float d = sd[ly][lx];
-                    float4 o;
-                    o.w = sg[ly][lx];
-                    if (A.min_depth < d && d < A.max_depth) {
-                        o.x = d * sp;
-                        o.y = -d * cp * A.sin_theta[cb + k];
-                        o.z = -d * cp * A.cos_theta[cb + k];
-                    } else {
-                        o.x = kInvalidPoint;
-                        o.y = 0.f;
-                        o.z = 0.f;
+                    const int c = c0 + tj + 16 * k;
+                    if (c < cols) {
+                        const int lx = tj + 16 * k + kFsRing;
+                        const float d = sd[ly][lx];
+                        float4 o;
+                        o.w = sg[ly][lx];
+                        if (A.min_depth < d && d < A.max_depth) {
+                            o.x = d * sp;
+                            o.y = -d * cp * A.sin_theta[c];
+                            o.z = -d * cp * A.cos_theta[c];
+                        } else {
+                            o.x = kInvalidPoint;
+                            o.y = 0.f;
+                            o.z = 0.f;
+                        }
+                        out[c] = o;
                     }
-                    out[k] = o;
                 }
             }
             if (want_trg) {
+                F3* recP = A.trg_p + (size_t)slot * n + (size_t)r * cols;
+                F3* recD = A.trg_d + (size_t)slot * n + (size_t)r * cols;
 #pragma unroll
-                for (int plane = 0; plane < 2; ++plane) {
-                    const float(*S)[kFsLW] = plane == 0 ? sg : sd;
-                    F3 v4[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int c = cb + k, lx = tx + k + kFsRing;
-                        const float v = S[ly][lx];
-                        float gx = 0.f, gy = 0.f;
-                        if (r >= 1 && r < rows - 1 && c >= 1 && c < cols - 1) {
-                            const float xm = S[ly][lx - 1], xp = S[ly][lx + 1];
-                            const float ym = S[ly - 1][lx], yp = S[ly + 1][lx];
-                            if ((v > xp && v < xm) || (v < xp && v > xm)) gx = 2.f / (1 / (xp - v) + 1 / (v - xm));
-                            if ((v > yp && v < ym) || (v < yp && v > ym)) gy = 2.f / (1 / (yp - v) + 1 / (v - ym));
-                        }
+                for (int k = 0; k < 4; ++k) {
+                    const int c = c0 + tj + 16 * k;
+                    if (c < cols) {
+                        const int lx = tj + 16 * k + kFsRing;
+                        bool seam = false;      // seam-mask columns (RPI.h:4538-4549), shared by both planes
                         if (A.seam > 1) {
                             int sidx, rem;
                             divmod24(c + 1, A.seam, sidx, rem);
-                            if (rem <= 1 && sidx >= 1 && sidx <= 7) gx = gy = 0.f;
+                            seam = rem <= 1 && sidx >= 1 && sidx <= 7;
                         } else if (A.seam == 1) {
-                            if (c + 1 >= 1 && c <= 7) gx = gy = 0.f;
+                            seam = c + 1 >= 1 && c <= 7;
                         }
-                        v4[k].a = v; v4[k].b = gx; v4[k].c = gy;
+                        const bool inner = r >= 1 && r < rows - 1 && c >= 1 && c < cols - 1;
+#pragma unroll
+                        for (int plane = 0; plane < 2; ++plane) {
+                            const float(*S)[kFsLW] = plane == 0 ? sg : sd;
+                            const float v = S[ly][lx];
+                            float gx = 0.f, gy = 0.f;
+                            if (inner) {
+                                const float xm = S[ly][lx - 1], xp = S[ly][lx + 1];
+                                const float ym = S[ly - 1][lx], yp = S[ly + 1][lx];
+                                if ((v > xp && v < xm) || (v < xp && v > xm)) gx = harmonic2(xp - v, v - xm);
+                                if ((v > yp && v < ym) || (v < yp && v > ym)) gy = harmonic2(yp - v, v - ym);
+                            }
+                            if (seam) gx = gy = 0.f;
+                            F3 o;
+                            o.a = v; o.b = gx; o.c = gy;
+                            (plane == 0 ? recP : recD)[c] = o;
+                        }
                     }
-                    F3* rec = (plane == 0 ? A.trg_p : A.trg_d) + (size_t)slot * n + (size_t)r * cols + cb;
-                    if (full4) store_f3x4(rec, v4, vec_ok);
-                    else
-                        for (int k = 0; k < 4 && cb + k < cols; ++k) rec[k] = v4[k];
                 }
             }
         }
