@@ -300,8 +300,14 @@ def main():
 
         # ---- the single-process multi-GPU entry (rgbd360_multi_*: host thread per device + ncclAllGather), in a child process
         #      so that nothing it does can cost the bench line ----
+        frames_path = (seq_block or {}).pop("_frames_path", None)
         if not args.no_native_multi and not args.no_sequence and not share:
-            result["native_multi"] = run_native_multi_child(world, args, W, H, seq_block)
+            result["native_multi"] = run_native_multi_child(world, args, W, H, frames_path)
+        elif frames_path:
+            try:
+                os.remove(frames_path)
+            except OSError:
+                pass
 
         # ---- CPU baseline: the oracle on this host's cores, bounded sample (rank 0, N = 1 only) ---------------
         if n_gpus == 1 and not args.no_cpu_baseline:
@@ -438,10 +444,9 @@ def run_sequence_block(args, torch, dist, synth, reg0, rank, world, local_rank, 
     return out
 
 
-def run_native_multi_child(world, args, W, H, seq_block):
+def run_native_multi_child(world, args, W, H, path):
     """tools/native_multi_bench.py in a child process: the C entry rgbd360_multi_* with n_gpus = the job's GPU count, the same
     sequence, resident frames.  Run after the ranks' own measurements; a crash or a hang there cannot touch this process."""
-    path = (seq_block or {}).pop("_frames_path", None)
     if path is None:
         return {"error": "no frames"}
     import torch
