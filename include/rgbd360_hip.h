@@ -211,6 +211,37 @@ int   rgbd360_sync(rgbd360_ctx* ctx);
 /* Number of HIP devices visible; does not create a context. */
 int   rgbd360_device_count(void);
 
+/* ---- dense registration of two frames of the 8-sensor rig ---------------------------------------------
+ * RegisterRGBD360::RegisterDensePhotoICP (RegisterRGBD360.h:344-520) over RegisterPhotoICP::calcPhotoICPError_robot
+ * (RPI.h:4905-5076) and calcHessianGradient_robot (RPI.h:5083-5407): the unknown is the RIG's relative pose (p_rig1 = T p_rig2),
+ * every sensor contributes its pinhole photometric / depth rows through its extrinsic Rt_s (sensor -> rig), the 8 sets of normal
+ * equations add up, Levenberg-Marquardt on the sum (lambda 0.001, x / 10, one retry, full SE(3) exponential, tolerances 0.1 on
+ * the summed squared error / 1e-6).  The reference function is broken as written; three defects are FIXED here and in the
+ * oracle (oracle/photo_icp_ref.cpp documents them): new_error is evaluated at the candidate pose (RegisterRGBD360.h:462,488
+ * use the old one), jacobianRt_z is row 2 of the transform Jacobian (RPI.h:5226-5228 leave it uninitialised), and the depth
+ * residual uses the transformed point's depth (RPI.h:5037 uses the untransformed one).
+ * Rt: n_sensors x 16 floats, column-major sensor -> rig poses (Calib360::Rt_); fx, fy, ox, oy: the sensors' level-0 intrinsics
+ * (RegisterRGBD360.h:357-365: 525 * width / 640, centre).  All sensor images of a frame share one size. */
+typedef struct rgbd360_rig rgbd360_rig;
+int  rgbd360_rig_create(const rgbd360_params* p, int n_sensors, const float* Rt, float fx, float fy, float ox, float oy,
+                        rgbd360_rig** out);
+void rgbd360_rig_destroy(rgbd360_rig* rig);
+const char* rgbd360_rig_last_error(rgbd360_rig* rig);
+/* frame1 (target) / frame2 (source): n_sensors host images each, as rgbd360_set_target takes them; copied before return. */
+int  rgbd360_rig_set_target(rgbd360_rig* rig, const uint8_t* const* rgb, size_t rgb_step, const void* const* depth,
+                            size_t depth_step, int depth_type, int rows, int cols);
+int  rgbd360_rig_set_source(rgbd360_rig* rig, const uint8_t* const* rgb, size_t rgb_step, const void* const* depth,
+                            size_t depth_step, int depth_type, int rows, int cols);
+/* One fused pass over all sensors at rig pose `pose`: err2_split = {photo, depth} sums of squared weighted residuals (no
+ * saliency test; their sum is calcPhotoICPError_robot summed over the sensors), n_split the pixel counts, H / g the summed
+ * normal equations (float, per-sensor totals added in sensor order), H64 / g64 the same in double, n_rows the Jacobian rows. */
+int  rgbd360_rig_eval(rgbd360_rig* rig, int level, const float pose[16], int method, double err2_split[2], long long n_split[2],
+                      float H[36], float g[6], double H64[36], double g64[6], long long* n_rows);
+/* The registration.  Returns 0 or RGBD360_ILL_POSED (pose_out = the pose reached).  res->iters = accepted steps per level,
+ * res->hessian = the summed Hessian of the last step (informationM, RegisterRGBD360.h:511), res->err_final = the summed
+ * squared error at pose_out. */
+int  rgbd360_rig_align(rgbd360_rig* rig, const float guess[16], int method, float pose_out[16], rgbd360_result* res);
+
 /* ---- Frame360 per-pixel stages ------------------------------------------------------------------------------ */
 
 /* Spherical point cloud from a range panorama.

@@ -99,6 +99,19 @@ def lib():
         L.oracle_rank6.argtypes = [C.c_void_p]
         L.oracle_inverse6.argtypes = [C.c_void_p, C.c_void_p]
         L.oracle_se3_pseudo_exp.argtypes = [C.c_void_p, C.c_void_p]
+        L.oracle_rig_create.restype = C.c_void_p
+        L.oracle_rig_create.argtypes = [C.POINTER(Params), C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float]
+        L.oracle_rig_destroy.argtypes = [C.c_void_p]
+        L.oracle_rig_set_modes.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.oracle_rig_set_frame.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int]
+        L.oracle_rig_error.restype = C.c_double
+        L.oracle_rig_error.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.oracle_rig_hessgrad.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.POINTER(C.c_long)]
+        L.oracle_rig_align.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_rig_trace_len.argtypes = [C.c_void_p]
+        L.oracle_rig_trace_get.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                           C.POINTER(C.c_double), C.POINTER(C.c_double)]
         _lib = L
     return _lib
 
@@ -410,3 +423,68 @@ def num_threads() -> int:
 
 def set_num_threads(n: int) -> None:
     lib().oracle_set_num_threads(int(n))
+
+
+class RigOracle:
+    """RegisterRGBD360::RegisterDensePhotoICP (RegisterRGBD360.h:344-520) on the CPU restatement, with the three defects of the
+    reference fixed as documented in photo_icp_ref.cpp (new_error at the candidate pose, jacobianRt_z, transformed depth).
+    Rt: list of 4x4 sensor -> rig poses; K = (fx, fy, ox, oy) of level 0."""
+
+    def __init__(self, Rt, K, **params):
+        params.setdefault("mask_seams", 0)
+        self.params = default_params(**params)
+        self.n = len(Rt)
+        rt = np.ascontiguousarray(np.stack([pose_to_cm(T) for T in Rt]))
+        self.h = C.c_void_p(lib().oracle_rig_create(C.byref(self.params), self.n, _ptr(rt), *[float(k) for k in K]))
+        self.iters = []
+        self.hessian = None
+
+    def close(self):
+        if self.h:
+            lib().oracle_rig_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_modes(self, math_mode: int, reduce_mode: int):
+        lib().oracle_rig_set_modes(self.h, math_mode, reduce_mode)
+
+    def set_frame(self, sensor: int, target: bool, rgb, depth):
+        rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+        depth = np.ascontiguousarray(depth)
+        dt = 0 if depth.dtype == np.uint16 else 1
+        lib().oracle_rig_set_frame(self.h, sensor, 1 if target else 0, _ptr(rgb), rgb.strides[0], _ptr(depth), depth.strides[0], dt,
+                                   rgb.shape[0], rgb.shape[1])
+
+    def error(self, level, pose, method):
+        sums = np.zeros(4, np.float64)
+        e = lib().oracle_rig_error(self.h, level, _ptr(pose_to_cm(pose)), method, _ptr(sums))
+        return e, sums
+
+    def hessgrad(self, level, pose, method):
+        H, g = np.zeros(36, np.float32), np.zeros(6, np.float32)
+        Hd, gd = np.zeros(36, np.float64), np.zeros(6, np.float64)
+        n = C.c_long()
+        lib().oracle_rig_hessgrad(self.h, level, _ptr(pose_to_cm(pose)), method, _ptr(H), _ptr(g), _ptr(Hd), _ptr(gd), C.byref(n))
+        return H.reshape(6, 6).T.copy(), g, Hd.reshape(6, 6).T.copy(), gd, n.value
+
+    def align(self, guess, method):
+        out, H = np.zeros(16, np.float32), np.zeros(36, np.float32)
+        it = np.zeros(8, np.int32)
+        st = lib().oracle_rig_align(self.h, _ptr(pose_to_cm(guess)), method, _ptr(out), _ptr(H), _ptr(it))
+        self.iters = [int(x) for x in it[: self.params.n_pyr]]
+        self.hessian = H.reshape(6, 6).T.copy()
+        return st, pose_from_cm(out)
+
+    def trace(self):
+        out = []
+        for i in range(lib().oracle_rig_trace_len(self.h)):
+            lv, it, acc = C.c_int(), C.c_int(), C.c_int()
+            e, ne = C.c_double(), C.c_double()
+            lib().oracle_rig_trace_get(self.h, i, C.byref(lv), C.byref(it), C.byref(acc), C.byref(e), C.byref(ne))
+            out.append((lv.value, it.value, acc.value, e.value, ne.value))
+        return out

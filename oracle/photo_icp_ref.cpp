@@ -1483,6 +1483,337 @@ int alignFrames(Ctx& ctx, const float* pose_guess, int method, float* pose_out, 
     return res->status;
 }
 
+// ====================================================================================
+// 8-sensor rig: RegisterRGBD360::RegisterDensePhotoICP (RegisterRGBD360.h:344-520) over calcPhotoICPError_robot
+// (RPI.h:4905-5076) and calcHessianGradient_robot (RPI.h:5083-5407), bUseSalientPixels false (constructor default).
+// The unknown is the RIG's relative pose (p_rig1 = T p_rig2); sensor s sees it through its extrinsic Rt_s (sensor -> rig) as
+// relPoseCam = Rt_s^-1 T Rt_s.  One RegisterPhotoICP context per sensor (source = frame 2's sensor image, target = frame 1's).
+//
+// SURVEY.md 8f rank 3 asks for this function "with the reference's bugs fixed"; three defects are fixed, each marked FIX below:
+//   A  RegisterRGBD360.h:462, 488 evaluate new_error at pose_estim instead of pose_estim_temp: diff_error is then 0, no step is
+//      ever accepted and the function returns its input.                                   -> new_error at pose_estim_temp.
+//   B  RPI.h:5226-5228, 5372-5374: jacobianRt_z is declared, `jacobianT36.block(2,0,1,6);` is a statement without effect, and the
+//      uninitialised row enters the depth Jacobian.                                         -> jacobianRt_z = jacobianT36.row(2).
+//   C  RPI.h:5037-5040, 5213-5216, 5358-5362: the depth residual compares the target depth with the source pixel's ORIGINAL depth
+//      instead of the transformed point's (what the single-sensor errorPhotoICP / calcHessGrad, RPI.h:722-735, 935-947, and the
+//      Jacobian's -jacobianRt_z term both use): at the true pose a camera that moved along its axis keeps a non-zero residual.
+//                                                                                           -> depth1 = transformedPoint3D(2).
+// Kept as written: the error is the SUM of squared weighted residuals over the 8 sensors (no averaging, no saliency test), the
+// H,g pass applies the saliency `continue`s (a flat depth gradient drops the pixel's photometric row too, RPI.h:5352-5353), LM with
+// lambda 0.001, step 10, one retry, tolerances 0.1 (on the sum) / 1e-6, full SE(3) exponential.
+// THIRD-PARTY: Eigen's general Matrix4f::inverse() of the extrinsic is restated as the rigid inverse [R^T | -R^T t] in float.
+// ====================================================================================
+inline void rigid_inverse_f32(const float* M /*col-major*/, float* Inv) {
+    for (int k = 0; k < 16; ++k) Inv[k] = 0.f;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) Inv[j * 4 + i] = M[i * 4 + j];
+    for (int i = 0; i < 3; ++i) Inv[12 + i] = -((Inv[0 * 4 + i] * M[12] + Inv[1 * 4 + i] * M[13]) + Inv[2 * 4 + i] * M[14]);
+    Inv[15] = 1.f;
+}
+inline void xform_f32(const float* M /*col-major 4x4*/, const float* p, float* q, bool fma_mode) {
+    for (int i = 0; i < 3; ++i)
+        q[i] = fma_mode ? fmaf(M[8 + i], p[2], fmaf(M[4 + i], p[1], fmaf(M[i], p[0], M[12 + i])))
+                        : ((M[i] * p[0] + M[4 + i] * p[1]) + M[8 + i] * p[2]) + M[12 + i];
+}
+struct RobotWarp {
+    float q[3];       // point in the rig frame after the motion: poseGuess * Rt * p   (point3D_robot2)
+    float P[3];       // the same point in the target sensor's frame                    (transformedPoint3D)
+    float inv_z;
+    int r, c;
+    bool visible;
+};
+// which = 0: the chain of calcPhotoICPError_robot (relPoseCam * p, double projection); 1: that of calcHessianGradient_robot
+// (Rt^-1 * (poseGuess * (Rt * p)), double intrinsics).  math_mode 1 = the device definition, one chain for both passes:
+// q = (poseGuess * Rt) p and P = Rt^-1 q with fused multiply-adds, correctly rounded 1/Z, fma projection, round half up.
+inline RobotWarp warp_robot(const float* poseGuess, const float* Rt, const float* Rt_inv, const float* p, int nRows, int nCols,
+                            const PinholeK& K, int math_mode, int which) {
+    RobotWarp w;
+    float tr, tc;
+    if (math_mode == 0) {
+        float pr[3];
+        xform_f32(Rt, p, pr, false);
+        xform_f32(poseGuess, pr, w.q, false);
+        if (which == 0) {
+            float A[16], C[16];
+            mat4_mul_f32(Rt_inv, poseGuess, A);
+            mat4_mul_f32(A, Rt, C);                       // relPoseCam = poseCamRobot_inv * poseGuess * poseCamRobot
+            xform_f32(C, p, w.P, false);
+        } else {
+            xform_f32(Rt_inv, w.q, w.P, false);
+        }
+        const double inv_transformedPz = 1.0 / w.P[2];
+        w.inv_z = (float)inv_transformedPz;
+        const double dc = which == 0 ? (double)(w.P[0] * K.fx) * inv_transformedPz + (double)K.ox
+                                     : ((double)w.P[0] * (double)K.fx) * inv_transformedPz + (double)K.ox;
+        const double dr = which == 0 ? (double)(w.P[1] * K.fy) * inv_transformedPz + (double)K.oy
+                                     : ((double)w.P[1] * (double)K.fy) * inv_transformedPz + (double)K.oy;
+        if (!std::isfinite(dr) || !std::isfinite(dc) || fabs(dr) > 1e9 || fabs(dc) > 1e9) { w.visible = false; w.r = w.c = -1; return w; }
+        w.r = (int)round(dr);
+        w.c = (int)round(dc);
+    } else {
+        float M[16];
+        mat4_mul_f32(poseGuess, Rt, M);
+        xform_f32(M, p, w.q, true);
+        xform_f32(Rt_inv, w.q, w.P, true);
+        w.inv_z = 1.f / w.P[2];
+        tc = fmaf(w.P[0] * K.fx, w.inv_z, K.ox);
+        tr = fmaf(w.P[1] * K.fy, w.inv_z, K.oy);
+        if (!(fabsf(tr) < 1e9f) || !(fabsf(tc) < 1e9f)) { w.visible = false; w.r = w.c = -1; return w; }
+        w.r = round_index(tr);
+        w.c = round_index(tc);
+    }
+    w.visible = (w.r >= 0 && w.r < nRows) && (w.c >= 0 && w.c < nCols);
+    return w;
+}
+
+// RPI.h:4905-5076, else-branch :4990-5072.  Returns error2 (the sum); the per-modality sums and counts go to ctx.last_*.
+double calcPhotoICPError_robot(Ctx& ctx, int level, const float* poseGuess, const float* Rt, int method) {
+    double e2p = 0.0, e2d = 0.0;
+    long nP = 0, nD = 0;
+    const Image& graySrc = ctx.graySrc[level];
+    const int nRows = graySrc.rows, nCols = graySrc.cols;
+    const PinholeK K = level_intrinsics(ctx, level);
+    const float stdDevPhoto = ctx.p.sigma_photo, stdDevDepth = ctx.p.sigma_depth;
+    const double stdDevPhoto_inv = 1. / stdDevPhoto;
+    float Rt_inv[16];
+    rigid_inverse_f32(Rt, Rt_inv);
+    if (ctx.lut_level != 1000 + level) buildLUT_pinhole(ctx, level);
+    const Image &grayTrg = ctx.grayTrg[level], &depthTrg = ctx.depthTrg[level];
+    const long n = (long)nRows * nCols;
+#pragma omp parallel for reduction(+ : e2p, e2d, nP, nD)
+    for (long i = 0; i < n; ++i) {
+        const float* p = &ctx.lut[3 * i];
+        if (p[0] == kInvalidPoint) continue;
+        const RobotWarp w = warp_robot(poseGuess, Rt, Rt_inv, p, nRows, nCols, K, ctx.p.math_mode, 0);
+        if (!w.visible) continue;
+        if (method == METHOD_PHOTO || method == METHOD_PHOTO_DEPTH) {
+            float photoDiff = grayTrg.at(w.r, w.c) - graySrc.d[i];
+            double weight_photo = weightHuber(photoDiff, stdDevPhoto) * stdDevPhoto_inv;
+            float weightedErrorPhoto = weight_photo * photoDiff;
+            e2p += weightedErrorPhoto * weightedErrorPhoto;
+            ++nP;
+        }
+        if (method == METHOD_DEPTH || method == METHOD_PHOTO_DEPTH) {
+            float depth2 = depthTrg.at(w.r, w.c);
+            if (std::isfinite(depth2)) {
+                float depth1 = w.P[2];                                   // FIX C (reference: depthSrcPyr(r, c))
+                float depthDiff = depth2 - depth1;
+                float stdDev_depth1 = stdDevDepth * depth1;
+                double weight_depth = weightHuber(depthDiff, stdDev_depth1) / stdDev_depth1;
+                float weightedErrorDepth = weight_depth * depthDiff;
+                e2d += weightedErrorDepth * weightedErrorDepth;
+                ++nD;
+            }
+        }
+    }
+    ctx.last_err2_photo = e2p; ctx.last_err2_depth = e2d;
+    ctx.last_nvalid_photo = nP; ctx.last_nvalid_depth = nD;
+    ctx.last_nvalid = nP + nD;
+    return e2p + e2d;
+}
+
+// RPI.h:5083-5407, else-branch :5264-5404.  H, g in the rig's left-perturbation coordinates [t; w].
+void calcHessianGradient_robot(Ctx& ctx, int level, const float* poseGuess, const float* Rt, int method) {
+    const Image& graySrc = ctx.graySrc[level];
+    const int nRows = graySrc.rows, nCols = graySrc.cols;
+    const long imgSize = (long)nRows * nCols;
+    const PinholeK K = level_intrinsics(ctx, level);
+    const float stdDevPhoto = ctx.p.sigma_photo, stdDevDepth = ctx.p.sigma_depth;
+    const double stdDevPhoto_inv = 1. / stdDevPhoto;
+    float Rt_inv[16];
+    rigid_inverse_f32(Rt, Rt_inv);
+    if (ctx.lut_level != 1000 + level) buildLUT_pinhole(ctx, level);
+    const Image &grayTrg = ctx.grayTrg[level], &depthTrg = ctx.depthTrg[level];
+    const Image &gx = ctx.gTrgGx[level], &gy = ctx.gTrgGy[level], &dgx = ctx.dTrgGx[level], &dgy = ctx.dTrgGy[level];
+    const float thrI = ctx.p.thres_sal_photo, thrD = ctx.p.thres_sal_depth;
+    float Hf[36] = {0}, gf[6] = {0};
+    double Hd[36] = {0}, gd[6] = {0};
+    long rows_used = 0;
+    auto add_row = [&](const float* J, float res) {
+        for (int a = 0; a < 6; ++a) {
+            for (int b = 0; b < 6; ++b) {
+                const float prod = J[a] * J[b];
+                Hf[b * 6 + a] += prod;
+                Hd[b * 6 + a] += (double)prod;
+            }
+            const float pr = J[a] * res;
+            gf[a] += pr;
+            gd[a] += (double)pr;
+        }
+        ++rows_used;
+    };
+    for (long i = 0; i < imgSize; ++i) {
+        const float* p = &ctx.lut[3 * i];
+        if (p[0] == kInvalidPoint) continue;
+        const RobotWarp w = warp_robot(poseGuess, Rt, Rt_inv, p, nRows, nCols, K, ctx.p.math_mode, 1);
+        if (!w.visible) continue;
+        // jacobianT36 = R_inv [I | -skew(point3D_robot2)]   (RPI.h:5298-5302)
+        const float* q = w.q;
+        const float S[3][3] = {{0, -q[2], q[1]}, {q[2], 0, -q[0]}, {-q[1], q[0], 0}};      // skew(q)
+        float JT[3][6];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) {
+                JT[r][c] = Rt_inv[c * 4 + r];                                                  // R_inv * I
+                JT[r][3 + c] = (Rt_inv[0 * 4 + r] * (-S[0][c]) + Rt_inv[1 * 4 + r] * (-S[1][c])) + Rt_inv[2 * 4 + r] * (-S[2][c]);
+            }
+        // jacobianProj23 (RPI.h:5304-5313)
+        const float iz = w.inv_z;
+        const float P00 = K.fx * iz, P11 = K.fy * iz, P02 = -K.fx * w.P[0] * iz * iz, P12 = -K.fy * w.P[1] * iz * iz;
+        float Jw0[6], Jw1[6];
+        for (int c = 0; c < 6; ++c) {
+            Jw0[c] = P00 * JT[0][c] + P02 * JT[2][c];
+            Jw1[c] = P11 * JT[1][c] + P12 * JT[2][c];
+        }
+        float jacobianPhoto[6] = {0, 0, 0, 0, 0, 0}, jacobianDepth[6] = {0, 0, 0, 0, 0, 0};
+        float weightedErrorPhoto = 0.f, weightedErrorDepth = 0.f;
+        bool have_depth_row = false;
+        if (method == METHOD_PHOTO || method == METHOD_PHOTO_DEPTH) {
+            const float tgx = gx.at(w.r, w.c), tgy = gy.at(w.r, w.c);
+            if (fabsf(tgx) < thrI && fabsf(tgy) < thrI) continue;                              // RPI.h:5331-5332
+            float photoDiff = grayTrg.at(w.r, w.c) - graySrc.d[i];
+            const float weight_photo = (float)(weightHuber(photoDiff, stdDevPhoto) * stdDevPhoto_inv);
+            weightedErrorPhoto = weight_photo * photoDiff;
+            const float wgx = weight_photo * tgx, wgy = weight_photo * tgy;
+            for (int j = 0; j < 6; ++j) jacobianPhoto[j] = wgx * Jw0[j] + wgy * Jw1[j];
+        }
+        if (method == METHOD_DEPTH || method == METHOD_PHOTO_DEPTH) {
+            const float depth2 = depthTrg.at(w.r, w.c);
+            if (std::isfinite(depth2)) {
+                const float tdx = dgx.at(w.r, w.c), tdy = dgy.at(w.r, w.c);
+                if (fabsf(tdx) < thrD && fabsf(tdy) < thrD) continue;                          // RPI.h:5352-5353: drops the photo row too
+                const float depth1 = w.P[2];                                                   // FIX C
+                float depthDiff = depth2 - depth1;
+                float stdDev_depth1 = stdDevDepth * depth1;
+                const float weight_depth = (float)((double)weightHuber(depthDiff, stdDev_depth1) / stdDev_depth1);
+                weightedErrorDepth = weight_depth * depthDiff;
+                for (int j = 0; j < 6; ++j) jacobianDepth[j] = weight_depth * ((tdx * Jw0[j] + tdy * Jw1[j]) - JT[2][j]);      // FIX B
+                have_depth_row = true;
+            }
+        }
+        if (method == METHOD_PHOTO || method == METHOD_PHOTO_DEPTH) add_row(jacobianPhoto, weightedErrorPhoto);
+        if (have_depth_row) add_row(jacobianDepth, weightedErrorDepth);
+    }
+    for (int k = 0; k < 36; ++k) {
+        ctx.H[k] = ctx.p.reduce_mode == 0 ? Hf[k] : (float)Hd[k];
+        ctx.H64[k] = Hd[k];
+    }
+    for (int a = 0; a < 6; ++a) {
+        ctx.g[a] = ctx.p.reduce_mode == 0 ? gf[a] : (float)gd[a];
+        ctx.g64[a] = gd[a];
+    }
+    ctx.n_visible = rows_used;
+}
+
+struct RigTrace {
+    int level, it, accepted;
+    double error, new_error;
+};
+struct Rig {
+    std::vector<Ctx*> sensors;
+    std::vector<float> Rt;          // n x 16, col-major, sensor -> rig
+    std::vector<RigTrace> trace;
+};
+// RegisterRGBD360.h:383-500.  Returns 0 ok / 1 ill-posed (rigidTransf = pose_estim, return false).
+int RegisterDensePhotoICP(Rig& rig, const float* pose_guess, int method, float* pose_out, float* H_out /*36*/, int* iters /*8*/) {
+    const int S = (int)rig.sensors.size();
+    rig.trace.clear();
+    float pose_estim[16], pose_estim_temp[16];
+    memcpy(pose_estim, pose_guess, sizeof(pose_estim));
+    float Hessian[36] = {0}, Gradient[6] = {0};
+    for (int k = 0; k < 8; ++k) iters[k] = 0;
+    auto total_error = [&](int level, const float* pose) {
+        double e = 0.0;
+        for (int s = 0; s < S; ++s) e += calcPhotoICPError_robot(*rig.sensors[s], level, pose, &rig.Rt[16 * s], method);
+        return e;
+    };
+    auto lm_update = [&](float lambda, float* update_pose) -> bool {
+        float M[36];
+        for (int k = 0; k < 36; ++k) M[k] = Hessian[k];
+        for (int i = 0; i < 6; ++i) M[i * 6 + i] = Hessian[i * 6 + i] + lambda * Hessian[i * 6 + i];
+        float inv[36];
+        if (!inverse6_partial_piv_lu(M, inv)) return false;
+        for (int r = 0; r < 6; ++r) {
+            float sacc = 0.f;
+            for (int c = 0; c < 6; ++c) sacc += (-inv[c * 6 + r]) * Gradient[c];
+            update_pose[r] = sacc;
+        }
+        double ud[6], E[16];
+        for (int i = 0; i < 6; ++i) ud[i] = (double)update_pose[i];
+        se3_exp(ud, E);
+        float Ef[16];
+        for (int k = 0; k < 16; ++k) Ef[k] = (float)E[k];
+        mat4_mul_f32(Ef, pose_estim, pose_estim_temp);
+        return true;
+    };
+    const int n_pyr = rig.sensors[0]->p.n_pyr;
+    for (int level = n_pyr - 1; level >= 0; --level) {
+        float lambda = 0.001f;
+        const double step = 10;
+        const unsigned LM_maxIters = 1;
+        int it = 0;
+        const int maxIters = 10;
+        const double tol_residual = pow(10, -1), tol_update = pow(10, -6);
+        float update_pose[6] = {1, 1, 1, 1, 1, 1};
+        double error = total_error(level, pose_estim);
+        double diff_error = error;
+        rig.trace.push_back({level, -1, 1, error, error});
+        auto unorm = [&]() {
+            float sacc = 0;
+            for (int i = 0; i < 6; ++i) sacc += update_pose[i] * update_pose[i];
+            return sqrtf(sacc);
+        };
+        while (it < maxIters && unorm() > tol_update && diff_error > tol_residual) {
+            for (int k = 0; k < 36; ++k) Hessian[k] = 0.f;
+            for (int k = 0; k < 6; ++k) Gradient[k] = 0.f;
+            for (int s = 0; s < S; ++s) {
+                Ctx& c = *rig.sensors[s];
+                calcHessianGradient_robot(c, level, pose_estim, &rig.Rt[16 * s], method);
+                for (int k = 0; k < 36; ++k) Hessian[k] += c.H[k];
+                for (int k = 0; k < 6; ++k) Gradient[k] += c.g[k];
+            }
+            float M[36];
+            for (int k = 0; k < 36; ++k) M[k] = Hessian[k];
+            for (int i = 0; i < 6; ++i) M[i * 6 + i] = Hessian[i * 6 + i] + lambda * Hessian[i * 6 + i];
+            if (rank6_colpiv_qr(M) != 6 || !lm_update(lambda, update_pose)) {
+                memcpy(pose_out, pose_estim, sizeof(pose_estim));
+                memcpy(H_out, Hessian, sizeof(Hessian));
+                return 1;
+            }
+            double new_error = total_error(level, pose_estim_temp);                            // FIX A (reference: pose_estim)
+            diff_error = error - new_error;
+            if (diff_error > 0) {
+                rig.trace.push_back({level, it, 1, error, new_error});
+                lambda /= step;
+                memcpy(pose_estim, pose_estim_temp, sizeof(pose_estim));
+                error = new_error;
+                it = it + 1;
+            } else {
+                rig.trace.push_back({level, it, 0, error, new_error});
+                unsigned LM_it = 0;
+                while (LM_it < LM_maxIters && diff_error < 0) {
+                    lambda = lambda * step;
+                    if (!lm_update(lambda, update_pose)) break;
+                    new_error = total_error(level, pose_estim_temp);                           // FIX A
+                    diff_error = error - new_error;
+                    if (diff_error > 0) {
+                        rig.trace.push_back({level, it, 1, error, new_error});
+                        memcpy(pose_estim, pose_estim_temp, sizeof(pose_estim));
+                        error = new_error;
+                        it = it + 1;
+                    } else {
+                        rig.trace.push_back({level, it, 0, error, new_error});
+                    }
+                    LM_it = LM_it + 1;
+                }
+            }
+        }
+        iters[level] = it;
+    }
+    memcpy(pose_out, pose_estim, sizeof(pose_estim));
+    memcpy(H_out, Hessian, sizeof(Hessian));
+    return 0;
+}
+
 void set_frame(Ctx& ctx, bool target, const uint8_t* rgb, size_t rgb_step, const void* depth, size_t d_step,
                int depth_type, int rows, int cols) {
     Image gray;
@@ -1628,6 +1959,70 @@ void oracle_warp_indices_pinhole(void* h, int level, const float* pose, int* out
         const WarpPin w = warp_pinhole(T, p, nRows, nCols, K, c.p.math_mode);
         if (w.visible) { out_rc[2 * i] = w.r; out_rc[2 * i + 1] = w.c; }
     }
+}
+
+// ---- 8-sensor rig (RegisterDensePhotoICP with the reference's defects fixed, see above) ----
+void* oracle_rig_create(const oracle_params* p, int n_sensors, const float* Rt /*n x 16 col-major*/, float fx, float fy, float ox, float oy) {
+    Rig* r = new Rig();
+    for (int s = 0; s < n_sensors; ++s) {
+        Ctx* c = new Ctx();
+        c->p = *p;
+        c->cam[0] = fx; c->cam[1] = fy; c->cam[2] = ox; c->cam[3] = oy;
+        r->sensors.push_back(c);
+    }
+    r->Rt.assign(Rt, Rt + 16 * (size_t)n_sensors);
+    return r;
+}
+void oracle_rig_destroy(void* h) {
+    Rig* r = (Rig*)h;
+    if (!r) return;
+    for (Ctx* c : r->sensors) delete c;
+    delete r;
+}
+void oracle_rig_set_modes(void* h, int math_mode, int reduce_mode) {
+    for (Ctx* c : ((Rig*)h)->sensors) { c->p.math_mode = math_mode; c->p.reduce_mode = reduce_mode; }
+}
+void oracle_rig_set_frame(void* h, int sensor, int target, const uint8_t* rgb, size_t rgb_step, const void* depth, size_t d_step,
+                          int depth_type, int rows, int cols) {
+    set_frame(*((Rig*)h)->sensors[sensor], target != 0, rgb, rgb_step, depth, d_step, depth_type, rows, cols);
+}
+// error2 of one evaluation at `pose` summed over the sensors; sums[0..1] = photo / depth parts, sums[2..3] = their pixel counts
+double oracle_rig_error(void* h, int level, const float* pose, int method, double* sums) {
+    Rig& r = *(Rig*)h;
+    double e = 0, s4[4] = {0, 0, 0, 0};
+    for (size_t s = 0; s < r.sensors.size(); ++s) {
+        Ctx& c = *r.sensors[s];
+        e += calcPhotoICPError_robot(c, level, pose, &r.Rt[16 * s], method);
+        s4[0] += c.last_err2_photo; s4[1] += c.last_err2_depth; s4[2] += (double)c.last_nvalid_photo; s4[3] += (double)c.last_nvalid_depth;
+    }
+    if (sums) memcpy(sums, s4, sizeof(s4));
+    return e;
+}
+void oracle_rig_hessgrad(void* h, int level, const float* pose, int method, float* H36, float* g6, double* H36d, double* g6d, long* rows_used) {
+    Rig& r = *(Rig*)h;
+    float H[36] = {0}, g[6] = {0};
+    double Hd[36] = {0}, gd[6] = {0};
+    long n = 0;
+    for (size_t s = 0; s < r.sensors.size(); ++s) {
+        Ctx& c = *r.sensors[s];
+        calcHessianGradient_robot(c, level, pose, &r.Rt[16 * s], method);
+        for (int k = 0; k < 36; ++k) { H[k] += c.H[k]; Hd[k] += c.H64[k]; }
+        for (int k = 0; k < 6; ++k) { g[k] += c.g[k]; gd[k] += c.g64[k]; }
+        n += c.n_visible;
+    }
+    if (H36) memcpy(H36, H, sizeof(H));
+    if (g6) memcpy(g6, g, sizeof(g));
+    if (H36d) memcpy(H36d, Hd, sizeof(Hd));
+    if (g6d) memcpy(g6d, gd, sizeof(gd));
+    if (rows_used) *rows_used = n;
+}
+int oracle_rig_align(void* h, const float* guess, int method, float* pose_out, float* H36, int* iters8) {
+    return RegisterDensePhotoICP(*(Rig*)h, guess, method, pose_out, H36, iters8);
+}
+int oracle_rig_trace_len(void* h) { return (int)((Rig*)h)->trace.size(); }
+void oracle_rig_trace_get(void* h, int i, int* level, int* it, int* accepted, double* error, double* new_error) {
+    const RigTrace& t = ((Rig*)h)->trace[i];
+    *level = t.level; *it = t.it; *accepted = t.accepted; *error = t.error; *new_error = t.new_error;
 }
 
 int oracle_trace_len(void* h) { return (int)((Ctx*)h)->trace.size(); }

@@ -21,6 +21,8 @@ SYMBOLS = [
     "rgbd360_multi_create", "rgbd360_multi_destroy", "rgbd360_multi_last_error", "rgbd360_multi_n_gpus", "rgbd360_multi_uses_rccl",
     "rgbd360_shard_range", "rgbd360_multi_align_sequence", "rgbd360_multi_load_sequence", "rgbd360_multi_align_resident",
     "rgbd360_align360_batch_multi", "rgbd360_time_eval_kernel_rotating",
+    "rgbd360_rig_create", "rgbd360_rig_destroy", "rgbd360_rig_last_error", "rgbd360_rig_set_target", "rgbd360_rig_set_source",
+    "rgbd360_rig_eval", "rgbd360_rig_align",
 ]
 
 
@@ -123,6 +125,15 @@ def load() -> C.CDLL:
     L.rgbd360_register_planes.argtypes = [vp, i32, vp, i32, i32, i32, C.POINTER(PbmapParams), vp, vp, vp, C.POINTER(i32),
                                           C.POINTER(C.c_float)]
     L.rgbd360_planes_available.argtypes = [vp]
+    L.rgbd360_rig_create.argtypes = [C.POINTER(Params), i32, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(vp)]
+    L.rgbd360_rig_destroy.argtypes = [vp]
+    L.rgbd360_rig_destroy.restype = None
+    L.rgbd360_rig_last_error.argtypes = [vp]
+    L.rgbd360_rig_last_error.restype = C.c_char_p
+    for f in (L.rgbd360_rig_set_target, L.rgbd360_rig_set_source):
+        f.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, i32, i32, i32]
+    L.rgbd360_rig_eval.argtypes = [vp, i32, f32p, i32, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_longlong)]
+    L.rgbd360_rig_align.argtypes = [vp, f32p, i32, f32p, C.POINTER(Result)]
     L.rgbd360_time_eval_kernel_rotating.argtypes = [vp, i32, i32, f32p, i32, i32, i32, C.POINTER(C.c_float)]
     L.rgbd360_multi_create.argtypes = [C.POINTER(Params), i32, vp, C.POINTER(vp)]
     L.rgbd360_multi_destroy.argtypes = [vp]

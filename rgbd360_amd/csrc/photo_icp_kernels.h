@@ -1415,6 +1415,8 @@ struct FrameLevelArgs {
     unsigned long long live_mask;   // slots with a frame in this launch
     unsigned long long src_mask;    // ... whose source records are wanted
     unsigned long long trg_mask;    // ... whose target records are wanted
+    int pinhole;                    // source records of a pinhole sensor (RPI.h:4277-4300) instead of the spherical LUT
+    float pin_ox, pin_oy, pin_inv_fx, pin_inv_fy;      // intrinsics of THIS level
 };
 
 // 1.f / x, bit for bit: inside [2^-60, 2^60] the 3-instruction rcp_rn (proven equal to the IEEE quotient over that whole range by
@@ -1535,7 +1537,7 @@ __global__ __launch_bounds__(256) void k_frame_level_b(FrameLevelArgs A, FramePt
             const bool want_src = (A.src_mask >> slot) & 1ull, want_trg = (A.trg_mask >> slot) & 1ull;
             const int ly = ty + kFsRing;
             if (want_src) {
-                const float sp = A.sin_phi[r], cp = A.cos_phi[r];
+                const float sp = A.pinhole ? 0.f : A.sin_phi[r], cp = A.pinhole ? 0.f : A.cos_phi[r];
                 float4* out = A.src_rec + (size_t)slot * n + (size_t)r * cols;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -1545,7 +1547,16 @@ __global__ __launch_bounds__(256) void k_frame_level_b(FrameLevelArgs A, FramePt
                         const float d = sd[ly][lx];
                         float4 o;
                         o.w = sg[ly][lx];
-                        if (A.min_depth < d && d < A.max_depth) {
+                        if (A.pinhole) {                   // k_src_rec_pinhole's arithmetic: z is stored for every pixel
+                            o.z = d;
+                            if (A.min_depth < d && d < A.max_depth) {
+                                o.x = ((float)c - A.pin_ox) * d * A.pin_inv_fx;
+                                o.y = ((float)r - A.pin_oy) * d * A.pin_inv_fy;
+                            } else {
+                                o.x = kInvalidPoint;
+                                o.y = 0.f;
+                            }
+                        } else if (A.min_depth < d && d < A.max_depth) {
                             o.x = d * sp;
                             o.y = -d * cp * A.sin_theta[c];
                             o.z = -d * cp * A.cos_theta[c];

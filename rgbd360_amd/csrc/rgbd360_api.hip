@@ -423,6 +423,7 @@ int set_frame(rgbd360_ctx* ctx, bool target, const uint8_t* rgb, size_t rgb_step
 }  // namespace
 
 #include "sequence_engine.h"
+#include "rig_dense.h"
 
 extern "C" {
 

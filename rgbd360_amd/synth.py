@@ -249,3 +249,24 @@ def make_pinhole_pair(width: int = 320, height: int = 240, seed: int = 1234, tra
     rgbA, dA = render_pinhole(T_wA, width, height, seed, depth_f32, K)
     rgbB, dB = render_pinhole(T_wB, width, height, seed, depth_f32, K)
     return (rgbA, dA), (rgbB, dB), np.linalg.inv(T_wA) @ T_wB, K
+
+
+def rig_extrinsics(n_sensors: int = 8):
+    """Sensor -> rig poses of an n-sensor ring: sensor s looks outwards, turned by 360 / n degrees about the rig's up axis (x);
+    image "down" = rig -x (the arrangement of the reference's 8-Asus rig, Calib360.h)."""
+    R0 = np.array([[0.0, -1.0, 0.0], [-1.0, 0.0, 0.0], [0.0, 0.0, -1.0]])
+    return [make_pose(rodrigues(np.array([1.0, 0, 0]), math.radians(360.0 / n_sensors * s)) @ R0, np.zeros(3)) for s in range(n_sensors)]
+
+
+def make_rig_pair(width: int = 320, height: int = 240, seed: int = 1234, trans: float = 0.05, rot_deg: float = 2.0, n_sensors: int = 8,
+                  depth_f32: bool = False):
+    """Two frames of an n-sensor pinhole rig in the room: (frame1, frame2, M, Rt, K); frame_k = list of (rgb, depth) per sensor,
+    M = the rig's motion with p_rig1 = M p_rig2 (the pose RegisterDensePhotoICP estimates), Rt = sensor -> rig poses."""
+    Rt = rig_extrinsics(n_sensors)
+    T_w1 = make_pose(np.eye(3), np.asarray(CAM_A, float))
+    M = default_motion(seed, trans, rot_deg)
+    T_w2 = T_w1 @ M
+    K = pinhole_intrinsics(width, height)
+    f1 = [render_pinhole(T_w1 @ Rt[s], width, height, seed, depth_f32, K) for s in range(n_sensors)]
+    f2 = [render_pinhole(T_w2 @ Rt[s], width, height, seed, depth_f32, K) for s in range(n_sensors)]
+    return f1, f2, M, Rt, K
