@@ -1580,7 +1580,7 @@ double calcPhotoICPError_robot(Ctx& ctx, int level, const float* poseGuess, cons
     if (ctx.lut_level != 1000 + level) buildLUT_pinhole(ctx, level);
     const Image &grayTrg = ctx.grayTrg[level], &depthTrg = ctx.depthTrg[level];
     const long n = (long)nRows * nCols;
-#pragma omp parallel for reduction(+ : e2p, e2d, nP, nD)
+    // (serial: the sensor images are small, and a 256-thread OpenMP team per sensor and evaluation costs more than the loop)
     for (long i = 0; i < n; ++i) {
         const float* p = &ctx.lut[3 * i];
         if (p[0] == kInvalidPoint) continue;

@@ -161,8 +161,18 @@ def test_rig_argument_errors_and_ill_posed(hip_lib, rig_pair):
         reg.align(np.eye(4), 0)                                    # no frames yet
     with pytest.raises(Rgbd360Error):
         reg.setTargetFrame(f1[:5])
+    # no valid pixel anywhere: the error is 0, the loop of RegisterRGBD360.h:414 never runs, the guess comes back as "registered"
     blank = [(np.zeros_like(a), np.zeros_like(d)) for a, d in f1]
     reg.setTargetFrame(blank)
     reg.setSourceFrame(blank)
-    assert not reg.align(np.eye(4), 2) and reg.status == 1          # H = 0: "The problem is ILL-POSED", the guess comes back
+    assert reg.align(np.eye(4), 2) and reg.num_iterations == [0, 0, 0]
     assert np.array_equal(reg.getPose(), np.eye(4, dtype=np.float32))
+    # a residual without any image gradient (two different flat grey levels, photometric only): H = 0 -> "The problem is ILL-POSED",
+    # the pose reached so far (the guess) is returned with status 1 (RegisterRGBD360.h:443-449)
+    flat1 = [(np.full_like(a, 60), d) for a, d in f1]
+    flat2 = [(np.full_like(a, 200), d) for a, d in f1]
+    reg.setTargetFrame(flat1)
+    reg.setSourceFrame(flat2)
+    guess = synth.make_pose(synth.rodrigues(np.array([0.0, 0.0, 1.0]), 0.01), np.array([0.01, 0.0, 0.0])).astype(np.float32)
+    assert not reg.align(guess, 0) and reg.status == 1
+    assert np.array_equal(reg.getPose(), guess)
