@@ -178,6 +178,55 @@ class RegisterRGBD360 {
     }
     int status() const { return status_; }      // 0 good, 1 insufficient matching, 2 unobservable / inconsistent
 
+    // :344-520 RegisterDensePhotoICP(frame1, frame2, pose_estim, method): dense registration of the two frames' 8 sensor image pairs
+    // (frame->frameRGBD_[s].getRGBImage() / getDepthImage()) in the rig frame, rgbd360_rig_* (csrc/rig_dense.h).  Rt: the sensors'
+    // sensor -> rig poses (frame1->calib->Rt_); the intrinsics are the reference's 525 * width / 640, centre (:357-365).  The
+    // reference function is broken as written; the library implements it with the three fixes documented in rgbd360_hip.h.
+    // true: registered (getPose() = rigidTransf, getInfoMat() = the summed Hessian); false: "The problem is ILL-POSED".
+    bool RegisterDensePhotoICP(const std::vector<ImageView>& rgb1, const std::vector<ImageView>& depth1, const std::vector<ImageView>& rgb2,
+                               const std::vector<ImageView>& depth2, const std::vector<Mat4f>& Rt, Mat4f pose_estim = Mat4f::Identity(),
+                               RegisterPhotoICP::costFuncType method = RegisterPhotoICP::PHOTO_CONSISTENCY, int n_pyr = 4) {
+        const size_t S = Rt.size();
+        if (S == 0 || rgb1.size() != S || depth1.size() != S || rgb2.size() != S || depth2.size() != S)
+            throw std::runtime_error("RegisterDensePhotoICP: one image pair and one extrinsic per sensor");
+        const int rows = rgb1[0].rows, cols = rgb1[0].cols;
+        const float focal = 525.f * ((float)cols / 640.f);
+        rgbd360_params p;
+        rgbd360_default_params(&p);
+        p.n_pyr = n_pyr;
+        std::vector<float> rt(16 * S);
+        for (size_t s = 0; s < S; ++s)
+            for (int k = 0; k < 16; ++k) rt[16 * s + k] = Rt[s].m[k];
+        rgbd360_rig* rig = nullptr;
+        if (rgbd360_rig_create(&p, (int)S, rt.data(), focal, focal, cols / 2.f - 0.5f, rows / 2.f - 0.5f, &rig) != 0)
+            throw std::runtime_error("rgbd360_rig_create failed: no usable HIP device (there is no CPU fallback)");
+        auto set = [&](bool target, const std::vector<ImageView>& rgb, const std::vector<ImageView>& depth) {
+            std::vector<const uint8_t*> rp(S);
+            std::vector<const void*> dp(S);
+            for (size_t s = 0; s < S; ++s) {
+                if (rgb[s].rows != rows || rgb[s].cols != cols || depth[s].rows != rows || depth[s].cols != cols || rgb[s].step != rgb[0].step ||
+                    depth[s].step != depth[0].step || depth[s].type != depth[0].type)
+                    throw std::runtime_error("RegisterDensePhotoICP: all sensor images must share one size, stride and depth type");
+                rp[s] = (const uint8_t*)rgb[s].data;
+                dp[s] = depth[s].data;
+            }
+            const int dt = depth[0].type == ImageView::U16C1 ? 0 : 1;
+            return target ? rgbd360_rig_set_target(rig, rp.data(), rgb[0].step, dp.data(), depth[0].step, dt, rows, cols)
+                          : rgbd360_rig_set_source(rig, rp.data(), rgb[0].step, dp.data(), depth[0].step, dt, rows, cols);
+        };
+        int rc = set(true, rgb1, depth1);
+        if (rc == 0) rc = set(false, rgb2, depth2);
+        rgbd360_result res;
+        if (rc == 0) rc = rgbd360_rig_align(rig, pose_estim.m, (int)method, rigidTransf_.m, &res);
+        const std::string err = rc < 0 ? rgbd360_rig_last_error(rig) : "";
+        rgbd360_rig_destroy(rig);
+        if (rc < 0) throw std::runtime_error("RegisterDensePhotoICP: " + err);
+        for (int k = 0; k < 36; ++k) informationM_.m[k] = res.hessian[k];
+        done_ = true;                                   // bRegistrationDone = true   (:506)
+        status_ = rc;
+        return rc == 0;
+    }
+
    private:
     void ensure() {
         if (!done_) RegisterPbMap(nullptr, nullptr, 0, mode_);

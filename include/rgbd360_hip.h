@@ -303,6 +303,15 @@ int rgbd360_plane_fit(rgbd360_ctx* ctx, const float* xyz, const float* normals, 
  * _cloud_planes, _sensor_planes); larger than the returned n_planes when the caller's max_planes cut the list -- grow the
  * buffer and call again. */
 int rgbd360_planes_available(rgbd360_ctx* ctx);
+/* The `refine` half of pcl::OrganizedMultiPlaneSegmentation::segmentAndRefine (what Frame360.h:977 / :868 / Frame360_stereo.h:882
+ * call) for every later plane call of this context: after `segment`, planes grow into neighbouring pixels of regions that did
+ * not become planes when the pixel's point lies within distance_threshold of the plane (PCL's refinement comparator: 0.02 m, not
+ * depth dependent) -- PCL's two raster passes, solved on the device by Jacobi sweeps to the same labels.  labels_out then holds
+ * the refined labels; a plane keeps centroid / normal / d / curvature of `segment` (as PCL's PlanarRegion does), count and the
+ * extent descriptors (area, elongation, ppal_dir) follow the grown inlier set.  Off by default (enabled = 0: plain `segment`). */
+int rgbd360_set_plane_refinement(rgbd360_ctx* ctx, int enabled, float distance_threshold);
+/* Pixels relabelled and Jacobi sweeps of the last plane call with refinement on. */
+int rgbd360_plane_refinement_stats(rgbd360_ctx* ctx, int* pixels_relabelled, int* sweeps);
 
 /* Range panorama -> sphere cloud -> normals -> planar regions in one call (cloud and normals stay on the device
  * between the stages); xyz_out / normals_out / labels_out may be NULL. */

@@ -298,6 +298,97 @@ int oracle_f360_plane_segment(const float* xyz, const float* normals, int rows, 
 
 
 // ------------------------------------------------------------------------------------
+// The `refine` half of pcl::OrganizedMultiPlaneSegmentation::segmentAndRefine (Frame360.h:977, :868; Frame360_stereo.h:882).
+// THIRD-PARTY (PCL >= 1.7, segmentation/organized_multi_plane_segmentation.hpp `refine` + plane_refinement_comparator.h), restated
+// from the published source, parity unpinned.  After `segment`, the regions that became planes ("refine labels") grow into
+// neighbouring pixels of regions that did not: two raster passes with in-place label updates,
+//   pass 1, rows 0 .. H-2 top-down, columns 0 .. W-2 left to right: current -> right neighbour, then current -> lower neighbour;
+//   pass 2, rows H-1 .. 1 bottom-up, columns W-1 .. 0 right to left: current -> left neighbour, then current -> upper neighbour;
+// a neighbour takes the current pixel's label when the current label is a plane's, the neighbour's is not, and the neighbour's
+// point lies within the comparator's distance threshold of that plane (PlaneRefinementComparator::compare: |a x + b y + c z + d|
+// in float against 0.02 m -- the default-constructed refinement comparator is never given mps.setDistanceThreshold's value and is
+// not depth dependent).  An invalid current OR first-neighbour label `continue`s the loop body, which also skips the second check
+// (kept).  One deviation: in pass 2 PCL reads labels[current_row + colIdx - 1] at colIdx == 0, i.e. the LAST pixel of the row
+// above, as "left neighbour" (an out-of-row access); here column 0 has no left neighbour and goes straight to the upper check.
+// The planes keep centroid / normal / d / curvature of `segment` (PCL builds the PlanarRegion from the pre-refinement centroid and
+// covariance); their inlier sets grow, so count and the extent descriptors of the inliers (area, elongation, ppal_dir) are
+// recomputed -- what Frame360.h:1010-1037 derives from the refined inlier cloud.
+// labels: in/out (root index per pixel, -1 invalid); planes: in/out.  Returns the number of pixels relabelled.
+int oracle_f360_plane_refine(const float* xyz, int rows, int cols, int* labels, oracle_plane* planes, int n_planes, float distance_threshold) {
+    const size_t n = (size_t)rows * cols;
+    std::vector<int> model_of(n, -1);          // label (root pixel) -> plane index; >= 0 <=> refine label
+    for (int k = 0; k < n_planes; ++k) model_of[planes[k].root] = k;
+    const std::vector<int> before(labels, labels + n);
+    auto compare = [&](size_t idx1, size_t idx2) {
+        const int current_label = labels[idx1], next_label = labels[idx2];
+        if (!(model_of[current_label] >= 0 && !(model_of[next_label] >= 0))) return false;
+        const oracle_plane& m = planes[model_of[current_label]];
+        const float* pt = xyz + 3 * idx2;
+        const double ptp_dist = fabs(m.normal[0] * pt[0] + m.normal[1] * pt[1] + m.normal[2] * pt[2] + m.d);
+        return ptp_dist < distance_threshold;
+    };
+    // first pass: top to bottom, left to right
+    for (int r = 0; r < rows - 1; ++r)
+        for (int c = 0; c < cols - 1; ++c) {
+            const size_t cur = (size_t)r * cols + c;
+            const int current_label = labels[cur], right_label = labels[cur + 1];
+            if (current_label < 0 || right_label < 0) continue;
+            if (compare(cur, cur + 1)) labels[cur + 1] = current_label;
+            const int lower_label = labels[cur + cols];
+            if (lower_label < 0) continue;
+            if (compare(cur, cur + cols)) labels[cur + cols] = current_label;
+        }
+    // second pass: bottom to top, right to left
+    for (int r = rows - 1; r >= 1; --r)
+        for (int c = cols - 1; c >= 0; --c) {
+            const size_t cur = (size_t)r * cols + c;
+            const int current_label = labels[cur];
+            if (c >= 1) {
+                const int left_label = labels[cur - 1];
+                if (current_label < 0 || left_label < 0) continue;
+                if (compare(cur, cur - 1)) labels[cur - 1] = current_label;
+            } else if (current_label < 0) {
+                continue;
+            }
+            const int upper_label = labels[cur - cols];
+            if (upper_label < 0) continue;
+            if (compare(cur, cur - cols)) labels[cur - cols] = current_label;
+        }
+    // grown inlier sets: count and extent descriptors
+    int changed = 0;
+    std::vector<double> mom((size_t)n_planes * 9, 0.0);
+    std::vector<int> count(n_planes, 0);
+    for (size_t i = 0; i < n; ++i) {
+        if (labels[i] != before[i]) ++changed;
+        if (labels[i] < 0 || model_of[labels[i]] < 0) continue;
+        const int k = model_of[labels[i]];
+        double* m = &mom[(size_t)k * 9];
+        const double x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+        m[0] += x; m[1] += y; m[2] += z;
+        m[3] += x * x; m[4] += x * y; m[5] += x * z; m[6] += y * y; m[7] += y * z; m[8] += z * z;
+        ++count[k];
+    }
+    for (int k = 0; k < n_planes; ++k) {
+        const double* m = &mom[(size_t)k * 9];
+        const double N = count[k];
+        const double cx = m[0] / N, cy = m[1] / N, cz = m[2] / N;
+        const double C[3][3] = {{m[3] / N - cx * cx, m[4] / N - cx * cy, m[5] / N - cx * cz},
+                                {m[4] / N - cx * cy, m[6] / N - cy * cy, m[7] / N - cy * cz},
+                                {m[5] / N - cx * cz, m[7] / N - cy * cz, m[8] / N - cz * cz}};
+        double ev, v[3], inplane[5];
+        smallest_eigen(C, ev, v, inplane);
+        oracle_plane& P = planes[k];
+        P.count = count[k];
+        const double l1 = std::max(inplane[0], 0.0), l2 = std::max(inplane[1], 0.0);
+        P.area = (float)(12.0 * sqrt(l1 * l2));
+        P.elongation = (float)(l1 > 0 ? sqrt(l2 / l1) : INFINITY);
+        for (int k2 = 0; k2 < 3; ++k2) P.ppal_dir[k2] = (float)inplane[2 + k2];
+    }
+    return changed;
+}
+
+
+// ------------------------------------------------------------------------------------
 // One sensor's organised cloud as Frame360::buildSphereCloud_rgbd360 feeds it to the plane extraction (Frame360.h:479-481):
 // CloudRGBD::getPointCloud (OpenNI2_Grabber/FrameRGBD/CloudRGBD.h:107-166: focal 525 * W / 640, centre (W/2 - 0.5, H/2 - 0.5),
 // x = (c - ox) * z * inv_fx, y = (r - oy) * z * inv_fy, z = 0.001 * depth) followed by DownsampleRGBD::downsamplePointCloud

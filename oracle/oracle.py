@@ -374,6 +374,28 @@ def f360_plane_segment(xyz, normals, rows, cols, min_inliers=40, angular_thresho
     return labels.reshape(rows, cols), planes
 
 
+def f360_plane_refine(xyz, rows, cols, labels, planes, distance_threshold=0.02):
+    """The refine half of segmentAndRefine (oracle/frame360_ref.cpp): returns (refined labels, planes with grown inlier sets,
+    number of relabelled pixels).  planes: the dicts f360_plane_segment (or the device) returned."""
+    xyz = np.ascontiguousarray(xyz, np.float32).reshape(rows * cols, 3)
+    lab = np.ascontiguousarray(np.asarray(labels, np.int32).reshape(rows * cols)).copy()
+    arr = (OraclePlane * max(len(planes), 1))()
+    for i, p in enumerate(planes):
+        for k in range(3):
+            arr[i].centroid[k] = float(p["centroid"][k]); arr[i].normal[k] = float(p["normal"][k]); arr[i].ppal_dir[k] = float(p["ppal_dir"][k])
+        arr[i].d = float(p["d"]); arr[i].curvature = float(p["curvature"]); arr[i].count = int(p["count"]); arr[i].root = int(p["root"])
+        arr[i].area = float(p["area"]); arr[i].elongation = float(p["elongation"])
+    f = lib().oracle_f360_plane_refine
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float]
+    f.restype = C.c_int
+    changed = f(_ptr(xyz), rows, cols, _ptr(lab), C.cast(arr, C.c_void_p), len(planes), distance_threshold)
+    out = [dict(centroid=np.array(list(arr[i].centroid), np.float32), normal=np.array(list(arr[i].normal), np.float32),
+                d=float(arr[i].d), curvature=float(arr[i].curvature), count=int(arr[i].count), root=int(arr[i].root),
+                area=float(arr[i].area), elongation=float(arr[i].elongation), ppal_dir=np.array(list(arr[i].ppal_dir), np.float32))
+           for i in range(len(planes))]
+    return lab.reshape(rows, cols), out, changed
+
+
 def sensor_cloud(depth_mm, step=2, min_depth=0.3, max_depth=10.0):
     """CloudRGBD::getPointCloud + DownsampleRGBD::downsamplePointCloud restated (oracle/frame360_ref.cpp); depth uint16 mm."""
     d = np.ascontiguousarray(depth_mm, np.uint16)

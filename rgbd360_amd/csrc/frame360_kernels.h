@@ -904,6 +904,83 @@ __global__ void k_f360_mom_reduce(const unsigned long long* __restrict__ mom, co
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The `refine` half of pcl::OrganizedMultiPlaneSegmentation::segmentAndRefine (Frame360.h:977): plane regions grow into
+// neighbouring non-plane pixels that lie within the refinement comparator's distance of the plane -- in PCL two raster passes
+// with in-place label updates (oracle/frame360_ref.cpp restates them literally).  A raster pass is a recurrence over a DAG: the
+// label a pixel ends a pass with is a function of its own label before the pass and of the END-OF-PASS labels of the two
+// neighbours the raster visits before it (pass 1: upper, then left; pass 2: lower, then right -- the order in which the
+// sequential loop offers them; an accepted offer makes the pixel a plane pixel, which refuses later offers).  The device solves
+// the recurrence by Jacobi sweeps: every sweep recomputes every pixel from the previous sweep's labels of its two neighbours;
+// a pixel is final once its predecessors are, so after (longest growth chain) sweeps nothing changes and the labels are exactly
+// the sequential pass's, whatever the execution order.  models[slot] = {a, b, c, d} of the planes `segment` produced, x = NaN for
+// regions that are no plane (too few inliers, curvature): the "refine labels" are the roots whose slot has a model.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool refine_is_plane(int label, const int* __restrict__ slot_of_root, const float4* __restrict__ models,
+                                                float4& m) {
+    if (label < 0) return false;
+    const int slot = slot_of_root[label];
+    if (slot < 0) return false;
+    m = models[slot];
+    return m.x == m.x;
+}
+template <int PASS>
+__global__ void k_f360_refine_sweep(const float* __restrict__ xyz, const int* __restrict__ lab0, const int* __restrict__ labA,
+                                    int* __restrict__ labB, const int* __restrict__ slot_of_root, const float4* __restrict__ models,
+                                    float thr, int rows, int cols, int* __restrict__ changed) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    if (c >= cols) return;
+    const int i = r * cols + c;
+    const int own = lab0[i];
+    int out = own;
+    float4 m;
+    if (own >= 0 && !refine_is_plane(own, slot_of_root, models, m)) {
+        const float x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
+        auto offer = [&](int from) {        // PlaneRefinementComparator::compare(from, this pixel) with this pixel still no plane
+            const int lf = labA[from];
+            if (!refine_is_plane(lf, slot_of_root, models, m)) return false;
+            const double ptp_dist = fabs(m.x * x + m.y * y + m.z * z + m.w);
+            if (!(ptp_dist < (double)thr)) return false;
+            out = lf;
+            return true;
+        };
+        if (PASS == 1) {
+            // upper pixel (r-1, c) as "current": it is one for c <= W-2, and its body runs only when its right neighbour is valid
+            bool taken = false;
+            if (r >= 1 && c <= cols - 2 && lab0[i - cols + 1] >= 0) taken = offer(i - cols);
+            // left pixel (r, c-1) as "current": rows 0 .. H-2 only
+            if (!taken && c >= 1 && r <= rows - 2) offer(i - 1);
+        } else {
+            // lower pixel (r+1, c) as "current" (rows H-1 .. 1): its upper check runs when its left neighbour is valid (column 0: always)
+            bool taken = false;
+            if (r + 1 <= rows - 1 && (c == 0 || lab0[i + cols - 1] >= 0)) taken = offer(i + cols);
+            // right pixel (r, c+1) as "current": rows 1 .. H-1 only
+            if (!taken && c + 1 <= cols - 1 && r >= 1) offer(i + 1);
+        }
+    }
+    labB[i] = out;
+    if (out != labA[i]) *changed = 1;
+}
+// The grown inliers join their plane's sums: count and the nine integer moments (64-bit atomics, order independent), labels updated.
+__global__ void k_f360_refine_commit(const float* __restrict__ xyz, int* __restrict__ label, const int* __restrict__ refined,
+                                     const int* __restrict__ slot_of_root, int n, int* __restrict__ count_of_slot,
+                                     unsigned long long* __restrict__ mom, int* __restrict__ n_changed) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int nl = refined[i];
+    if (nl == label[i]) return;
+    label[i] = nl;
+    const int slot = slot_of_root[nl];
+    atomicAdd(n_changed, 1);
+    atomicAdd(&count_of_slot[slot], 1);
+    auto d2ll = [](double v) -> long long { return __double_as_longlong(v + 6755399441055744.0) - 0x4338000000000000LL; };
+    const double x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
+    const long long v[9] = {d2ll(x * kMomScale), d2ll(y * kMomScale), d2ll(z * kMomScale), d2ll(x * x * kMomScale), d2ll(x * y * kMomScale),
+                            d2ll(x * z * kMomScale), d2ll(y * y * kMomScale), d2ll(y * z * kMomScale), d2ll(z * z * kMomScale)};
+#pragma unroll
+    for (int q = 0; q < 9; ++q) atomicAdd(&mom[(size_t)slot * 9 + q], (unsigned long long)v[q]);
+}
+
 // Frame360::stitchImage (Frame360.h:1099-1148): one thread per panorama pixel; the sensor is fixed by the column band.
 // sin/cos tables of the row / column angles come from the host's libm (the reference evaluates them per row / pixel).
 struct StitchArgs {

@@ -85,6 +85,11 @@ struct rgbd360_ctx {
     int f_tab_rows = 0, f_tab_cols = 0, f_tab_conv = -1;      // what the resident angle tables were built for
     uint8_t* f_depth_raw = nullptr;
     int f_planes_available = 0;     // regions that passed every filter in the last plane call (may exceed the caller's max_planes)
+    int f_refine = 0;               // segmentAndRefine's refinement after `segment` (rgbd360_set_plane_refinement)
+    float f_refine_dist = 0.02f;    // PlaneRefinementComparator's default distance threshold
+    int f_refine_changed = 0, f_refine_sweeps = 0;      // pixels relabelled / Jacobi sweeps of the last call
+    float4* f_models = nullptr;     // per slot {a, b, c, d} of the planes `segment` produced (x = NaN: no plane)
+    int* f_flags_host = nullptr;    // pinned, device-visible: per-sweep "something changed" flags + the relabelled-pixel counter
     float al_guess[16] = {0};     // alignment in flight (rgbd360_align360_begin / _finish)
     int al_method = 0;
     bool al_active = false;
@@ -509,6 +514,8 @@ void rgbd360_destroy(rgbd360_ctx* ctx) {
     hipFree(ctx->f_root_of_slot); hipFree(ctx->f_nslots); hipFree(ctx->f_window); hipFree(ctx->f_mom);
     hipFree(ctx->f_count_of_slot); hipFree(ctx->f_depth_raw); hipFree(ctx->f_pack);
     if (ctx->f_pack_host) hipHostFree(ctx->f_pack_host);
+    hipFree(ctx->f_models);
+    if (ctx->f_flags_host) hipHostFree(ctx->f_flags_host);
     hipFree(ctx->b_sum); hipFree(ctx->b_cnt); hipFree(ctx->b_a); hipFree(ctx->b_b); hipFree(ctx->b_mm);
     hipFree(ctx->occ_head); hipFree(ctx->occ_next); hipFree(ctx->occ_dinv);
     if (ctx->h_state) hipHostFree(ctx->h_state);
@@ -1467,6 +1474,89 @@ void sorted_eigen3(const double C[3][3], double evals[3], double evecs[3][3]) { 
 }
 
 // regions of (ctx->f_xyz, ctx->f_normals) -> labels (device ctx->f_label) + plane list (host)
+// segmentAndRefine's refinement on the device (frame360_kernels.h k_f360_refine_sweep): Jacobi sweeps of the two raster passes until
+// nothing changes, then the grown inliers are added to their planes' integer sums and the extent descriptors recomputed.
+// Work labels: the two halves of f_count (its counts are spent once the slots are assigned) and f_window.
+int f360_refine_dev(rgbd360_ctx* ctx, int rows, int cols, int nslots, std::vector<rgbd360_plane>& planes, const std::vector<int>& plane_slot) {
+    using namespace f360;
+    const int n = rows * cols;
+    if (!ctx->f_models) HIPC(ctx, hipMalloc(&ctx->f_models, kF360MaxSlots * sizeof(float4)));
+    constexpr int kFlags = 64;
+    if (!ctx->f_flags_host) HIPC(ctx, hipHostMalloc((void**)&ctx->f_flags_host, (kFlags + 1) * sizeof(int), hipHostMallocDefault));
+    std::vector<float4> models(nslots, make_float4(NAN, 0.f, 0.f, 0.f));
+    for (size_t k = 0; k < planes.size(); ++k)
+        models[plane_slot[k]] = make_float4(planes[k].normal[0], planes[k].normal[1], planes[k].normal[2], planes[k].d);
+    HIPC(ctx, hipMemcpyAsync(ctx->f_models, models.data(), (size_t)nslots * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+    int* work[3] = {reinterpret_cast<int*>(ctx->f_count), reinterpret_cast<int*>(ctx->f_count) + n, ctx->f_window};
+    const dim3 g((cols + 255) / 256, rows), b(256);
+    const int* lab0 = ctx->f_label;
+    const int* result = lab0;
+    int sweeps = 0;
+    for (int pass = 1; pass <= 2; ++pass) {
+        // the pass's input must stay intact while two other buffers ping-pong
+        int* pp[2];
+        int q = 0;
+        for (int k = 0; k < 3 && q < 2; ++k)
+            if (work[k] != lab0) pp[q++] = work[k];
+        const int* cur = lab0;
+        int wb = 0;
+        bool converged = false;
+        for (int round = 0; round < 4096 / 4 && !converged; ++round) {
+            volatile int* flags = ctx->f_flags_host;
+            for (int k = 0; k < 4; ++k) flags[k] = 0;
+            for (int k = 0; k < 4; ++k) {        // four sweeps per host check: the check costs a stream synchronisation
+                int* dst = pp[wb];
+                if (pass == 1)
+                    hipLaunchKernelGGL((k_f360_refine_sweep<1>), g, b, 0, ctx->stream, ctx->f_xyz, lab0, cur, dst, ctx->f_slot_of_root, ctx->f_models,
+                                       ctx->f_refine_dist, rows, cols, ctx->f_flags_host + k);
+                else
+                    hipLaunchKernelGGL((k_f360_refine_sweep<2>), g, b, 0, ctx->stream, ctx->f_xyz, lab0, cur, dst, ctx->f_slot_of_root, ctx->f_models,
+                                       ctx->f_refine_dist, rows, cols, ctx->f_flags_host + k);
+                cur = dst;
+                wb ^= 1;
+                ++sweeps;
+            }
+            HIPC(ctx, hipGetLastError());
+            HIPC(ctx, hipStreamSynchronize(ctx->stream));
+            converged = flags[3] == 0;           // a sweep that changes nothing is a fixed point: every later sweep repeats it
+        }
+        if (!converged) return fail(ctx, -7, "plane refinement did not converge");
+        result = cur;
+        lab0 = cur;
+    }
+    ctx->f_flags_host[kFlags] = 0;
+    hipLaunchKernelGGL(k_f360_refine_commit, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->f_xyz, ctx->f_label, result, ctx->f_slot_of_root, n,
+                       ctx->f_count_of_slot, ctx->f_mom, ctx->f_flags_host + kFlags);
+    hipLaunchKernelGGL(k_f360_mom_reduce, dim3((kF360MaxSlots * 9 + 255) / 256), dim3(256), 0, ctx->stream, ctx->f_mom, ctx->f_nslots, kF360MaxSlots,
+                       ctx->f_root_of_slot, ctx->f_count_of_slot, ctx->f_pack_host);
+    HIPC(ctx, hipGetLastError());
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->f_refine_changed = ctx->f_flags_host[kFlags];
+    ctx->f_refine_sweeps = sweeps;
+    // count and the extent descriptors of the grown inlier sets (Frame360.h:1010-1037 derives them from the refined inlier cloud);
+    // centroid / normal / d / curvature stay those of `segment`, as PCL's PlanarRegion keeps them
+    const F360SlotRecord* recs = reinterpret_cast<const F360SlotRecord*>(ctx->f_pack_host + kF360PackHeader);
+    for (size_t k = 0; k < planes.size(); ++k) {
+        const F360SlotRecord& R = recs[plane_slot[k]];
+        double m[9];
+        for (int q = 0; q < 9; ++q) m[q] = (double)(long long)R.mom[q] / kMomScale;
+        const double N = R.count;
+        const double cx = m[0] / N, cy = m[1] / N, cz = m[2] / N;
+        const double C[3][3] = {{m[3] / N - cx * cx, m[4] / N - cx * cy, m[5] / N - cx * cz},
+                                {m[4] / N - cx * cy, m[6] / N - cy * cy, m[7] / N - cy * cz},
+                                {m[5] / N - cx * cz, m[7] / N - cy * cz, m[8] / N - cz * cz}};
+        double evs[3], vecs[3][3];
+        sorted_eigen3(C, evs, vecs);
+        rgbd360_plane& P = planes[k];
+        P.count = R.count;
+        const double l1 = std::max(evs[1], 0.0), l2 = std::max(evs[2], 0.0);
+        P.area = (float)(12.0 * sqrt(l1 * l2));
+        P.elongation = (float)(l1 > 0 ? sqrt(l2 / l1) : INFINITY);
+        for (int q = 0; q < 3; ++q) P.ppal_dir[q] = (float)vecs[2][q];
+    }
+    return 0;
+}
+
 int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float angular_threshold, float distance_threshold,
                     float max_curvature, int depth_mode, rgbd360_plane* planes, int max_planes, int* n_planes) {
     using namespace f360;
@@ -1534,6 +1624,7 @@ int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float
     // (still in PCL's order) instead of the first -- the regions lowest in the image (typically the floor) used to be the ones
     // cut -- and the total is remembered for rgbd360_planes_available so that an adapter can grow its buffer and call again.
     std::vector<rgbd360_plane> all;
+    std::vector<int> all_slot;      // region slot of every plane (its sums live in row `slot` of the moment table)
     all.reserve(nslots);
     for (int oi = 0; oi < nslots; ++oi) {
         const int s = order[oi];
@@ -1556,6 +1647,7 @@ int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float
         const double curvature = tr != 0 ? fabs(ev / tr) : 0;
         if (!(curvature < max_curvature)) continue;
         all.emplace_back();
+        all_slot.push_back(s);
         rgbd360_plane& P = all.back();
         P.centroid[0] = (float)cx; P.centroid[1] = (float)cy; P.centroid[2] = (float)cz;
         P.normal[0] = (float)v[0]; P.normal[1] = (float)v[1]; P.normal[2] = (float)v[2];
@@ -1567,6 +1659,11 @@ int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float
         P.area = (float)(12.0 * sqrt(l1 * l2));
         P.elongation = (float)(l1 > 0 ? sqrt(l2 / l1) : INFINITY);
         for (int k = 0; k < 3; ++k) P.ppal_dir[k] = (float)vecs[2][k];
+    }
+    ctx->f_refine_changed = ctx->f_refine_sweeps = 0;
+    if (ctx->f_refine && !all.empty()) {
+        const int rc = f360_refine_dev(ctx, rows, cols, nslots, all, all_slot);
+        if (rc) return rc;
     }
     ctx->f_planes_available = (int)all.size();
     int np = 0;
@@ -1741,6 +1838,20 @@ extern "C" int rgbd360_distance_map(rgbd360_ctx* ctx, const float* xyz, int rows
 }
 
 extern "C" int rgbd360_planes_available(rgbd360_ctx* ctx) { return ctx ? ctx->f_planes_available : -1; }
+
+extern "C" int rgbd360_set_plane_refinement(rgbd360_ctx* ctx, int enabled, float distance_threshold) {
+    if (!ctx) return -1;
+    if (enabled && !(distance_threshold > 0.f)) return fail(ctx, -1, "the refinement distance threshold must be positive");
+    ctx->f_refine = enabled ? 1 : 0;
+    if (enabled) ctx->f_refine_dist = distance_threshold;
+    return 0;
+}
+extern "C" int rgbd360_plane_refinement_stats(rgbd360_ctx* ctx, int* pixels_relabelled, int* sweeps) {
+    if (!ctx) return -1;
+    if (pixels_relabelled) *pixels_relabelled = ctx->f_refine_changed;
+    if (sweeps) *sweeps = ctx->f_refine_sweeps;
+    return 0;
+}
 
 extern "C" int rgbd360_plane_fit(rgbd360_ctx* ctx, const float* xyz, const float* normals, int rows, int cols, int min_inliers,
                                  float angular_threshold, float distance_threshold, float max_curvature, int depth_mode,

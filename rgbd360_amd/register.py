@@ -418,6 +418,16 @@ class Frame360Stages:
         self._reg = reg or RegisterPhotoICP()
         self._L = self._reg._L
 
+    def set_refinement(self, enabled: bool, distance_threshold: float = 0.02):
+        """rgbd360_set_plane_refinement: segmentAndRefine's refinement (Frame360.h:977) for the later plane calls of this context."""
+        self._refine = (bool(enabled), float(distance_threshold))
+        self._reg._check(self._L.rgbd360_set_plane_refinement(self._reg._ctx(), int(enabled), float(distance_threshold)))
+
+    def refinement_stats(self):
+        a, b = C.c_int(), C.c_int()
+        self._reg._check(self._L.rgbd360_plane_refinement_stats(self._reg._ctx(), C.byref(a), C.byref(b)))
+        return dict(pixels_relabelled=a.value, sweeps=b.value)
+
     def normals(self, xyz, rows, cols, max_depth_change_factor=0.05, normal_smoothing_size=8.0, depth_mode=1):
         xyz = np.ascontiguousarray(xyz, np.float32).reshape(rows * cols, 3)
         out = np.empty_like(xyz)

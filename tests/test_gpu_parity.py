@@ -440,6 +440,59 @@ def test_plane_regions_ragged_sizes(hip_lib, oracle_mod, W, H):
         assert np.abs(nrm_dev[ok] - nrm[ok]).max() <= 1.2e-7
 
 
+def _noisy_scene(oracle_mod, W, H, seed):
+    """A range panorama whose planes have something to grow into: measurement noise on bands of rows / columns (regions there fall
+    under min_inliers or fail the curvature test), a hole and a depth step."""
+    (rgbA, dA), _, _ = synth.make_pair(W, H, seed=seed)
+    rng = np.random.default_rng(seed)
+    d = dA.astype(np.float32)
+    for _ in range(6):
+        r0, c0 = int(rng.integers(0, H - H // 8)), int(rng.integers(0, W - W // 8))
+        hh, ww = int(rng.integers(3, H // 8)), int(rng.integers(3, W // 8))
+        d[r0:r0 + hh, c0:c0 + ww] += rng.normal(0, 12.0, size=(hh, ww)).astype(np.float32)       # 12 mm noise: inside 2 cm of the wall
+    d[H // 3:H // 3 + 3, W // 4:W // 4 + 9] = 0
+    d[H // 2:, W // 2:W // 2 + W // 8] *= 0.8
+    return np.clip(d, 0, 65535).astype(np.uint16)
+
+
+@pytest.mark.parametrize("W,H,seed", [(512, 256, 3), (250, 101, 5), (700, 37, 7), (65, 70, 9)])
+def test_plane_refinement_matches_oracle(hip_lib, oracle_mod, W, H, seed):
+    """segmentAndRefine's refinement (Frame360.h:977): PCL's two sequential raster passes (oracle, literal) against the device's
+    Jacobi sweeps -- refined labels identical pixel for pixel, inlier counts identical, extent descriptors to float rounding; the
+    planes' centroid / normal / d / curvature stay those of `segment`."""
+    from rgbd360_amd.register import Frame360Stages
+    d = _noisy_scene(oracle_mod, W, H, seed)
+    xyz = oracle_mod.sphere_cloud(d, 2)
+    nrm, _ = oracle_mod.f360_normals(xyz, H, W, 0.05, 4.0, 1)
+    st = Frame360Stages(_mk(hip_lib, 2))
+    labels0, planes0 = st.plane_fit(xyz, nrm, H, W, 30, 0.06, 0.05, 0.002, 1)
+    st.set_refinement(True, 0.02)
+    labels1, planes1 = st.plane_fit(xyz, nrm, H, W, 30, 0.06, 0.05, 0.002, 1)
+    stats = st.refinement_stats()
+    # the oracle refines the device's own `segment` result: the test isolates the refinement step
+    labels_ref, planes_ref, changed = oracle_mod.f360_plane_refine(xyz, H, W, labels0, planes0, 0.02)
+    assert changed > 0 and stats["pixels_relabelled"] == changed, (changed, stats)
+    assert np.array_equal(labels1, labels_ref)
+    assert [p["root"] for p in planes1] == [p["root"] for p in planes0] == [p["root"] for p in planes_ref]
+    assert [p["count"] for p in planes1] == [p["count"] for p in planes_ref]
+    assert sum(p["count"] for p in planes1) == sum(p["count"] for p in planes0) + changed
+    for a, b, c in zip(planes1, planes_ref, planes0):
+        assert np.array_equal(a["centroid"], c["centroid"]) and np.array_equal(a["normal"], c["normal"]) and a["d"] == c["d"]
+        assert abs(a["area"] - b["area"]) <= 1e-4 * max(b["area"], 1e-3) and abs(a["elongation"] - b["elongation"]) <= 1e-3 * b["elongation"]
+    # only non-plane pixels change, and every new inlier lies within the threshold of its plane
+    grown = labels1 != labels0
+    plane_roots = {p["root"] for p in planes0}
+    assert not np.isin(labels0[grown], list(plane_roots)).any() and np.isin(labels1[grown], list(plane_roots)).all()
+    model = {p["root"]: (p["normal"], p["d"]) for p in planes0}
+    pts = xyz.reshape(H, W, 3)[grown]
+    dist = np.array([abs(float(np.dot(model[l][0], p) + model[l][1])) for l, p in zip(labels1[grown], pts)])
+    assert (dist < 0.02 + 1e-6).all()
+    # switching it off again restores plain `segment`
+    st.set_refinement(False)
+    labels2, planes2 = st.plane_fit(xyz, nrm, H, W, 30, 0.06, 0.05, 0.002, 1)
+    assert np.array_equal(labels2, labels0) and [p["count"] for p in planes2] == [p["count"] for p in planes0]
+
+
 def test_frame_planes_recovers_the_room_walls(hip_lib, oracle_mod):
     """Functional known answer for the chained device pipeline (range image -> cloud -> normals -> regions): the six walls
     of the synthetic room come out within 1 degree / 1 cm (SURVEY.md 8c bar for the PCL-based rows)."""

@@ -546,3 +546,35 @@ def test_fast_bilateral_smooths_within_surfaces_and_keeps_depth_steps(oracle_mod
     assert np.abs(same[..., 2] - 2.0).max() < 1e-6
     allnan = np.full((8, 9, 3), np.nan, np.float32)
     assert np.isnan(oracle_mod.fast_bilateral(allnan, 8, 9)).all()
+
+
+def test_plane_refinement_grows_planes_into_their_noisy_border(oracle_mod):
+    """oracle_f360_plane_refine (the `refine` half of segmentAndRefine, Frame360.h:977) on a hand-made scene: a wall z = 2 with a
+    noisy patch (no normals there -> the patch is left out by `segment`) and a patch 5 cm in front of the wall.  The plane grows
+    through the noisy patch (within 2 cm) and not into the offset one; the raster passes reach pixels that are several steps away
+    from the original region in every direction; counts and extents follow, the plane model does not move."""
+    H, W = 40, 60
+    xs, ys = np.meshgrid(np.arange(W, dtype=np.float32) * 0.01 - 0.3, np.arange(H, dtype=np.float32) * 0.01 - 0.2)
+    xyz = np.stack([xs, ys, np.full_like(xs, 2.0)], -1)
+    rng = np.random.default_rng(0)
+    xyz[10:20, 15:30, 2] += rng.uniform(-0.015, 0.015, size=(10, 15)).astype(np.float32)        # noisy, but within 2 cm
+    xyz[25:32, 35:50, 2] = 1.95                                                                  # 5 cm off the wall
+    xyz[5:8, 5:8] = np.nan
+    nrm = np.zeros_like(xyz)
+    nrm[..., 2] = -1.0
+    nrm[10:20, 15:30] = np.nan                                                                   # no normals on the noisy patch
+    nrm[25:32, 35:50] = np.nan
+    labels, planes = oracle_mod.f360_plane_segment(xyz, nrm, H, W, 40, 0.05, 0.02, 0.01, 0)
+    assert len(planes) == 1
+    root = planes[0]["root"]
+    assert (labels[10:20, 15:30] != root).all() and (labels[25:32, 35:50] != root).all()
+    ref, planes2, changed = oracle_mod.f360_plane_refine(xyz, H, W, labels, planes, 0.02)
+    assert changed == 10 * 15 and (ref[10:20, 15:30] == root).all()
+    assert (ref[25:32, 35:50] != root).all() and (ref[5:8, 5:8] == -1).all()
+    assert planes2[0]["count"] == planes[0]["count"] + changed
+    assert np.array_equal(planes2[0]["normal"], planes[0]["normal"]) and planes2[0]["d"] == planes[0]["d"]
+    # filling the hole moves mass towards the centre: the moment rectangle shrinks a little, towards the true 0.6 x 0.4 m wall
+    assert 0.22 < planes2[0]["area"] < planes[0]["area"]
+    # idempotent: a second refinement finds nothing left to grow
+    ref2, _, changed2 = oracle_mod.f360_plane_refine(xyz, H, W, ref, planes2, 0.02)
+    assert changed2 == 0 and np.array_equal(ref2, ref)
