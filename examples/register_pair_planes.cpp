@@ -49,6 +49,7 @@ static bool frame_planes(std::array<rgbd360::RegisterPhotoICP, 8>& regs, const c
             int n = 0;
             per_sensor[s].resize((size_t)sp.max_planes);
             rc[s] = load_rt(extr, s, Rt) ? 0 : 1;                             // depth image in, planes in the rig frame out: one call per sensor
+            if (rc[s] == 0) rc[s] = rgbd360_set_plane_refinement(regs[s].context(), sp.refine ? 1 : 0, sp.refine_distance);      // segmentAndRefine, Frame360.h:977
             if (rc[s] == 0)
                 rc[s] = rgbd360_sensor_planes(regs[s].context(), depth.data() + (size_t)s * rows * cols, (size_t)cols * 2, rows, cols, step, 0.3f,
                                               10.f, sp.sigma_s, sp.sigma_r, sp.max_depth_change_factor, sp.normal_smoothing_size, sp.min_inliers,

@@ -31,12 +31,15 @@ struct SegmentParams {
     int convention = 2, depth_mode = 1, min_inliers = 80, max_planes = 256;
     float max_depth_change_factor = 0.02f, normal_smoothing_size = 8.f, angular_threshold = 0.0398f, distance_threshold = 0.02f,
           max_curvature = 0.001f;      // PCL's default region filter: the reference never calls mps.setMaximumCurvature (Frame360.h:958-977)
+    bool refine = true;                // the reference calls segmentAndRefine (Frame360.h:977): planes grow into their noisy borders
+    float refine_distance = 0.02f;     // PlaneRefinementComparator's default threshold (not depth dependent)
 };
 inline std::vector<rgbd360_plane> segmentPlanes(RegisterPhotoICP& reg, const ImageView& depth, const SegmentParams& sp = SegmentParams()) {
     std::vector<rgbd360_plane> planes;
     int n = 0, cap = sp.max_planes;
     const int dt = depth.type == ImageView::U16C1 ? 0 : 1;
     rgbd360_ctx* ctx = reg.context();
+    rgbd360_set_plane_refinement(ctx, sp.refine ? 1 : 0, sp.refine_distance);
     for (int attempt = 0; attempt < 2; ++attempt) {      // the library keeps the largest `cap` regions and reports how many qualified: grow once
         planes.resize((size_t)cap);
         const int rc = rgbd360_frame_planes(ctx, depth.data, depth.step, dt, depth.rows, depth.cols, sp.convention, sp.max_depth_change_factor,
@@ -61,12 +64,15 @@ struct SensorSegmentParams {
     float angular_threshold = 0.0398f, distance_threshold = 0.02f;               // Frame360.h:961-962
     float max_curvature = 0.001f;                                                // PCL default (no setMaximumCurvature call); 0.0013 = max_curvature_plane is the merge / subgraph filter
     int max_planes = 512;
+    bool refine = true;                // segmentAndRefine (Frame360.h:977)
+    float refine_distance = 0.02f;
 };
 inline std::vector<rgbd360_plane> segmentSensorPlanes(RegisterPhotoICP& reg, const float* xyz, int rows, int cols, const float* Rt = nullptr,
                                                       const SensorSegmentParams& sp = SensorSegmentParams()) {
     std::vector<rgbd360_plane> planes;
     int n = 0, cap = sp.max_planes;
     rgbd360_ctx* ctx = reg.context();
+    rgbd360_set_plane_refinement(ctx, sp.refine ? 1 : 0, sp.refine_distance);
     for (int attempt = 0; attempt < 2; ++attempt) {      // grow once when more regions qualified than the buffer holds
         planes.resize((size_t)cap);
         const int rc = rgbd360_cloud_planes(ctx, xyz, rows, cols, sp.sigma_s, sp.sigma_r, sp.max_depth_change_factor, sp.normal_smoothing_size,
