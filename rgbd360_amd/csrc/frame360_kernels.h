@@ -187,7 +187,10 @@ static_assert(3 * kNT_XW * kNT_XH * 4 <= 6 * kNT_SPLANE * 8, "the point tile is 
 
 __global__ __launch_bounds__(kNT_THREADS) void k_f360_normals_tiled(const float* __restrict__ xyz, const float* __restrict__ dist,
                                                                    int rows, int cols, float smoothing_size, int depth_mode,
-                                                                   float* __restrict__ normals, int* __restrict__ window) {
+                                                                   float* __restrict__ normals, int* __restrict__ window,
+                                                                   const unsigned char* __restrict__ tile_flags) {
+    // behind k_f360_normals_sweep only the tiles it marked (pixels with another window size) are left to do
+    if (tile_flags && !tile_flags[blockIdx.y * gridDim.x + blockIdx.x]) return;
     __shared__ double sat[6 * kNT_SPLANE];            // phase 1 also holds the xyz tile (3 x 46 x 30 floats)
     __shared__ int satc[kNT_SPLANE];
     float* pts = reinterpret_cast<float*>(sat);
@@ -384,6 +387,188 @@ __global__ __launch_bounds__(kNT_THREADS) void k_f360_normals_tiled(const float*
         }
         normals[3 * index] = nx; normals[3 * index + 1] = ny; normals[3 * index + 2] = nz;
         if (window) window[index] = rect;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_f360_normals_sweep<R>: the same normal map for the pixels whose window is R x R -- almost every pixel of a frame (rect =
+// int(min(distance map, smoothing_size + depth / 10)) = int(smoothing_size) away from depth edges and below 10 m) -- without any
+// table: a WAVE owns a strip of 64 point columns and sweeps down the rows with everything in registers.
+//   * lane l holds point column (col0 - 1 - R/2 + l); per row one coalesced 12-byte load per lane (three rows prefetched);
+//   * DX(r, c) = p(r, c+1) - p(r, c-1) comes from the neighbouring LANES (DPP wave_shl / wave_shr), DY(r, c) = p(r+1, c) - p(r-1, c)
+//     from the lane's own three-row window;
+//   * the vertical R-sums slide: the row that enters is added, the row that left R steps ago (kept in a register ring, the loop is
+//     unrolled R times so that every ring index is static) is subtracted -- in float64 like the integral images, exact for the same
+//     reason (a handful of float32 terms of similar magnitude);
+//   * the horizontal R-sums are R - 1 lane shifts (DPP) of the vertical sums;
+//   * the output lanes (1 + R/2 .. 63 - R + R/2: their whole window lies inside the wave) finish the pixel: cross product in
+//     double, flip towards the viewpoint.
+// 1.3x the pixels are read (column overlap (R+1)/64, row overlap (R+1)/segment) instead of 2.7x, nothing goes through LDS, and the
+// per-pixel work is a few dozen instructions.  Pixels whose window is NOT R x R are left to k_f360_normals_tiled: the sweep marks
+// their 32 x 16 tile, the tiled kernel then runs on marked tiles only (and rewrites them whole, so a tile is always the product of
+// one kernel).  Exactness is that of the tiled kernel (bit-identical to the oracle up to the rare inexact float64 sum).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wshl1(float v) {      // lane l <- lane l + 1
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float wshr1(float v) {      // lane l <- lane l - 1
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, true));
+}
+__device__ __forceinline__ int wshl1i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xF, 0xF, true); }
+__device__ __forceinline__ int wshr1i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, true); }
+__device__ __forceinline__ double wshl1d(double v) {
+    return __hiloint2double(wshl1i(__double2hiint(v)), wshl1i(__double2loint(v)));
+}
+__device__ __forceinline__ double wshr1d(double v) {
+    return __hiloint2double(wshr1i(__double2hiint(v)), wshr1i(__double2loint(v)));
+}
+struct P3 {
+    float x, y, z;
+};
+constexpr int kSweepWaves = 4;
+template <int R>
+__global__ __launch_bounds__(64 * kSweepWaves) void k_f360_normals_sweep(const float* __restrict__ xyz, const float* __restrict__ dist, int rows,
+                                                                          int cols, float smoothing_size, int depth_mode, int seg_rows,
+                                                                          float* __restrict__ normals, int* __restrict__ window,
+                                                                          unsigned char* __restrict__ tile_flags, int tiles_x) {
+    constexpr int OW = 63 - R;                          // output columns of a strip
+    constexpr int LO = 1 + R / 2;                       // first output lane
+    const int lane = threadIdx.x & 63;
+    const int unit = blockIdx.x * kSweepWaves + (threadIdx.x >> 6);
+    const int strips = (cols + OW - 1) / OW;
+    const int strip = unit % strips, seg = unit / strips;
+    const int y0 = seg * seg_rows;
+    if (y0 >= rows) return;
+    const int y1 = min(rows, y0 + seg_rows);
+    const int col0 = strip * OW;
+    const int c = col0 - LO + lane;                     // this lane's point column
+    const bool col_in = c >= 0 && c < cols;
+    const bool col_inner = c >= 1 && c < cols - 1;
+    const float qnan = __builtin_nanf("");
+    const int e0 = y0 - R / 2, e1 = (y1 - 1) - R / 2 + R - 1;      // difference rows the segment needs
+    auto load_row = [&](int r) {
+        P3 p = {qnan, qnan, qnan};
+        if (col_in && r >= 0 && r < rows) {
+            const float* q = xyz + 3 * ((size_t)r * cols + c);
+            p.x = q[0]; p.y = q[1]; p.z = q[2];
+        }
+        return p;
+    };
+    P3 pm = load_row(e0 - 1), pc = load_row(e0), pn = load_row(e0 + 1);
+    P3 qa = load_row(e0 + 2), qb = load_row(e0 + 3), qc = load_row(e0 + 4);      // in flight
+    float ring[R][6];
+    unsigned vx_bits = 0, vy_bits = 0;
+#pragma unroll
+    for (int k = 0; k < R; ++k)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) ring[k][j] = 0.f;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    int cnt = 0;                                         // count_x | count_y << 16 of the vertical window
+    const int border = (int)smoothing_size;
+    const bool out_lane = lane >= LO && lane < LO + OW && c < cols;
+
+    for (int eb = e0; eb <= e1; eb += R) {
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const int e = eb + k;
+            if (e > e1) continue;                        // wave-uniform (`continue`, not `break`: the unrolled ring indices stay static)
+            // the output pixel this row completes (own point and distance-map value: issued now, used at the end of the step)
+            const int y = e - R + 1 + R / 2;
+            const bool emit = y >= y0 && y < y1;
+            float ox = qnan, oy = qnan, oz = qnan, odist = 0.f;
+            if (emit && out_lane) {
+                const size_t index = (size_t)y * cols + c;
+                ox = xyz[3 * index]; oy = xyz[3 * index + 1]; oz = xyz[3 * index + 2];
+                odist = dist[index];
+            }
+            // differences of row e (initAverage3DGradientMethod: zero, and valid, on the image border)
+            const float lx = wshr1(pc.x), ly = wshr1(pc.y), lz = wshr1(pc.z);      // p(e, c - 1)
+            const float rx = wshl1(pc.x), ry = wshl1(pc.y), rz = wshl1(pc.z);      // p(e, c + 1)
+            float d[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            bool vx = true, vy = true;
+            if (e >= 1 && e < rows - 1 && col_inner) {
+                d[0] = rx - lx; d[1] = ry - ly; d[2] = rz - lz;
+                d[3] = pn.x - pm.x; d[4] = pn.y - pm.y; d[5] = pn.z - pm.z;
+                vx = finite3(d[0], d[1], d[2]);
+                vy = finite3(d[3], d[4], d[5]);
+                if (!vx) d[0] = d[1] = d[2] = 0.f;
+                if (!vy) d[3] = d[4] = d[5] = 0.f;
+            }
+            // vertical sliding sums: row e enters, row e - R (ring slot k) leaves
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                acc[j] += (double)d[j];
+                acc[j] -= (double)ring[k][j];
+                ring[k][j] = d[j];
+            }
+            cnt += (vx ? 1 : 0) + (vy ? 65536 : 0) - (int)((vx_bits >> k) & 1u) - (int)(((vy_bits >> k) & 1u) << 16);
+            vx_bits = (vx_bits & ~(1u << k)) | ((vx ? 1u : 0u) << k);
+            vy_bits = (vy_bits & ~(1u << k)) | ((vy ? 1u : 0u) << k);
+            // next point row
+            pm = pc; pc = pn; pn = qa; qa = qb; qb = qc;
+            qc = load_row(e + 5);
+            if (!emit) continue;                         // wave-uniform
+            // horizontal R-sums: offsets -R/2 .. R-1-R/2 around the lane
+            double s[6];
+            int sc = cnt;
+            {
+                double t[6];
+                int tc = cnt;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) s[j] = t[j] = acc[j];
+#pragma unroll
+                for (int q = 1; q <= R - 1 - R / 2; ++q) {
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        t[j] = wshl1d(t[j]);
+                        s[j] += t[j];
+                    }
+                    tc = wshl1i(tc);
+                    sc += tc;
+                }
+#pragma unroll
+                for (int j = 0; j < 6; ++j) t[j] = acc[j];
+                tc = cnt;
+#pragma unroll
+                for (int q = 1; q <= R / 2; ++q) {
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        t[j] = wshr1d(t[j]);
+                        s[j] += t[j];
+                    }
+                    tc = wshr1i(tc);
+                    sc += tc;
+                }
+            }
+            if (!out_lane) continue;
+            const size_t index = (size_t)y * cols + c;
+            float nx = qnan, ny = qnan, nz = qnan;
+            int rect = 0;
+            if (y >= border && y < rows - border && c >= border && c < cols - border) {
+                const float depth = depth_mode == 0 ? oz : sqrtf(ox * ox + oy * oy + oz * oz);
+                if (isfinite(depth)) {
+                    const float smoothing = fminf(odist, smoothing_size + depth / 10.0f);
+                    if (smoothing > 2.0f) {
+                        rect = (int)smoothing;
+                        if (rect != R) {
+                            tile_flags[(y >> 4) * tiles_x + (c >> 5)] = 1;      // another window size: the tiled kernel owns this tile
+                        } else if ((sc & 65535) > 0 && (sc >> 16) > 0) {
+                            const double v0 = s[4] * s[2] - s[5] * s[1], v1 = s[5] * s[0] - s[3] * s[2], v2 = s[3] * s[1] - s[4] * s[0];
+                            const double len2 = v0 * v0 + v1 * v1 + v2 * v2;
+                            if (len2 != 0.0) {
+                                const double inv = 1.0 / sqrt(len2);
+                                nx = (float)(v0 * inv); ny = (float)(v1 * inv); nz = (float)(v2 * inv);
+                                if ((-ox) * nx + (-oy) * ny + (-oz) * nz < 0.f) {
+                                    nx = -nx; ny = -ny; nz = -nz;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            normals[3 * index] = nx; normals[3 * index + 1] = ny; normals[3 * index + 2] = nz;
+            if (window) window[index] = rect;
+        }
     }
 }
 

@@ -1399,8 +1399,40 @@ int f360_normals_dev(rgbd360_ctx* ctx, int rows, int cols, float max_depth_chang
         return fail(ctx, -1, "normal_smoothing_size out of range (the distance map is truncated at 12 px)");
     launch_distance_map(ctx, rows, cols, max_depth_change_factor, depth_mode);
     const dim3 gt((cols + kNT_W - 1) / kNT_W, (rows + kNT_H - 1) / kNT_H);
+    // Register sweep for the pixels whose window is int(smoothing_size) squared (nearly all of them), the tiled integral-image kernel
+    // for the 32 x 16 tiles the sweep marks (depth edges, far points).  Tile flags: the first bytes of f_change, which the distance
+    // map no longer needs (the plane stage rewrites it).  RGBD360_NORMALS_SWEEP=0 keeps the tiled kernel for everything (A/B).
+    const int R = (int)smoothing_size;
+    static const bool sweep_off = [] { const char* e = getenv("RGBD360_NORMALS_SWEEP"); return e && atoi(e) == 0; }();
+    const bool use_sweep = !sweep_off && R >= 3 && R <= 10 && (size_t)gt.x * gt.y <= (size_t)rows * cols;
+    unsigned char* flags = nullptr;
+    if (use_sweep) {
+        flags = ctx->f_change;
+        HIPC(ctx, hipMemsetAsync(flags, 0, (size_t)gt.x * gt.y, ctx->stream));
+        // rows per wave: the kernel keeps 2 waves per SIMD resident (2048 on the chip) and is issue-bound, so the wave count is made
+        // a whole number of such rounds (2432 waves of 16 rows at 2048 x 1024 would leave a second round for 384 of them: +23 %)
+        const int OW = 63 - R;
+        const int strips = (cols + OW - 1) / OW;
+        const int rounds = std::max(1, (int)lround((double)strips * rows / 32.0 / 2048.0));
+        const int segs = std::max(1, 2048 * rounds / strips);
+        const int seg = std::max(16, (rows + segs - 1) / segs);
+        const int units = strips * ((rows + seg - 1) / seg);
+        const dim3 gs((units + kSweepWaves - 1) / kSweepWaves), bs(64 * kSweepWaves);
+#define SWEEP(RR) hipLaunchKernelGGL((k_f360_normals_sweep<RR>), gs, bs, 0, ctx->stream, ctx->f_xyz, ctx->f_dist, rows, cols, smoothing_size, depth_mode, seg, ctx->f_normals, ctx->f_window, flags, (int)gt.x)
+        switch (R) {
+            case 3: SWEEP(3); break;
+            case 4: SWEEP(4); break;
+            case 5: SWEEP(5); break;
+            case 6: SWEEP(6); break;
+            case 7: SWEEP(7); break;
+            case 8: SWEEP(8); break;
+            case 9: SWEEP(9); break;
+            default: SWEEP(10); break;
+        }
+#undef SWEEP
+    }
     hipLaunchKernelGGL(k_f360_normals_tiled, gt, dim3(kNT_THREADS), 0, ctx->stream, ctx->f_xyz, ctx->f_dist, rows, cols, smoothing_size,
-                       depth_mode, ctx->f_normals, ctx->f_window);
+                       depth_mode, ctx->f_normals, ctx->f_window, (const unsigned char*)flags);
     HIPC(ctx, hipGetLastError());
     return 0;
 }
@@ -1760,12 +1792,13 @@ int sphere_cloud_dev(rgbd360_ctx* ctx, const void* depth, size_t depth_step, int
         d_step = (size_t)cols * dpx;
     }
     float* d_tab = ctx->f_tab;
-    // four pixels per thread when every row of the depth image and of the cloud starts 16-byte aligned
-    if (cols % 4 == 0 && d_step % 16 == 0 && ((size_t)d_depth & 15) == 0) {
+    static const bool cloud_x4 = [] { const char* e = getenv("RGBD360_CLOUD_X4"); return e && atoi(e) != 0; }();      // A/B: the round-1 kernel
+    if (cloud_x4 && cols % 4 == 0 && d_step % 16 == 0 && ((size_t)d_depth & 15) == 0) {
         hipLaunchKernelGGL(k_sphere_cloud_x4, grid2d(rows, cols / 4), dim3(256), 0, ctx->stream, d_depth, d_step, depth_type, rows, cols,
                            convention, d_tab, d_tab + cols, d_tab + 2 * cols, d_tab + 2 * cols + rows, ctx->f_xyz);
     } else {
-        hipLaunchKernelGGL(k_sphere_cloud, grid2d(rows, cols), dim3(256), 0, ctx->stream, d_depth, d_step, depth_type, rows, cols,
+        // consecutive lanes = consecutive pixels, one 12-byte store per lane, four pixels (256 apart) per thread
+        hipLaunchKernelGGL(k_sphere_cloud_s4, dim3((cols + 1023) / 1024, rows), dim3(256), 0, ctx->stream, d_depth, d_step, depth_type, rows, cols,
                            convention, d_tab, d_tab + cols, d_tab + 2 * cols, d_tab + 2 * cols + rows, ctx->f_xyz);
     }
     HIPC(ctx, hipGetLastError());
