@@ -15,9 +15,16 @@
 //                the gated source pixel with the HIGHEST index (last writer); numVisible = distinct target pixels.
 //
 // Implementation: k_occ_build links the candidates of every target pixel into a list (atomicExch on a head array);
-// k_eval_occ walks the (short) list of its own target pixel to decide "prefix maximum / closest / last" exactly, then
-// accumulates the same 32 partial sums per block as k_eval, so k_solve is shared.  dist = sqrt_rn(d2) and
-// 1/dist = rcp_rn(dist) are correctly rounded: every comparison is bit-for-bit the oracle's.
+// k_occ_resolve (round 2) walks the (short) list of every candidate's target pixel and leaves the three decisions "prefix maximum
+// / closest / last" as a flag byte per source pixel; k_eval_occ reads the byte and accumulates the same 32 partial sums per block
+// as k_eval, so k_solve is shared.  dist = sqrt_rn(d2) and 1/dist = rcp_rn(dist) are correctly rounded: every comparison is
+// bit-for-bit the oracle's.
+// Round 1 walked the lists inside k_eval_occ: four to five DEPENDENT global round trips per pixel step (source record -> head ->
+// list element -> target records) in a kernel that keeps one 1024-thread block per CU -- 215-300 us per level-0 pass against 15 us
+// for the plain pass.  The walk now runs one thread per source pixel in 256-thread blocks (latency hidden by occupancy: 54 us, the
+// pass itself 19 us), and the head array needs no memset between passes: its entries carry the pass's generation in their top 8
+// bits.  (Four walks per thread, all their loads issued side by side, was slower -- 0.80 instead of 0.64 ms per alignment: the loop
+// then runs as long as the longest of 256 lists.)
 #pragma once
 #include "photo_icp_kernels.h"
 
@@ -26,9 +33,13 @@ namespace r360 {
 constexpr float kThresDepthOutliers = 0.3f;      // RPI.h:4525
 constexpr int   kOccNotCandidate = -2;
 
+// head entries: generation (top 8 bits) | source pixel index (24 bits; images are < 16 Mpx); an entry of another generation is
+// an empty list
+__device__ __forceinline__ int occ_decode(int tagged, int gen) { return ((unsigned)tagged >> 24) == (unsigned)gen ? (tagged & 0xFFFFFF) : -1; }
+
 template <int OCC>
-__global__ __launch_bounds__(256) void k_occ_build(LevelDev lv, const GNState* __restrict__ st, int level, int* __restrict__ head,
-                                                   int* __restrict__ next, float* __restrict__ dinv) {
+__global__ __launch_bounds__(256) void k_occ_build(LevelDev lv, const GNState* __restrict__ st, int level, int gen, int* __restrict__ head,
+                                                   int* __restrict__ next, float* __restrict__ dinv, int* __restrict__ tgt) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= lv.n) return;
     if (st->done || st->level_active != level) return;
@@ -47,16 +58,39 @@ __global__ __launch_bounds__(256) void k_occ_build(LevelDev lv, const GNState* _
     int nx = kOccNotCandidate;
     if (cand) {
         dinv[i] = rcp_rn(dist);
-        nx = atomicExch(&head[ti], i);
+        tgt[i] = (int)ti;
+        nx = occ_decode(atomicExch(&head[ti], (gen << 24) | i), gen);
     }
     next[i] = nx;
+}
+
+// flag byte per source pixel: 1 candidate, 2 prefix maximum, 4 final owner of the z-buffer cell, 8 last writer
+__global__ __launch_bounds__(256) void k_occ_resolve(int n, const GNState* __restrict__ st, int level, int gen, const int* __restrict__ head,
+                                                     const int* __restrict__ next, const float* __restrict__ dinv,
+                                                     const int* __restrict__ tgt, unsigned char* __restrict__ flags) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (st->done || st->level_active != level) return;
+    unsigned f = 0;
+    if (next[i] != kOccNotCandidate) {
+        bool pm = true, best = true, last = true;
+        const float di = dinv[i];
+        for (int j = occ_decode(head[tgt[i]], gen); j >= 0; j = next[j]) {
+            if (j == i) continue;
+            const float dj = dinv[j];
+            if (j < i && dj > di) pm = false;                            // an earlier pixel was closer: occluded on arrival
+            if (dj > di || (dj == di && j > i)) best = false;            // not the final owner of the z-buffer cell
+            if (j > i) last = false;
+        }
+        f = 1u | (pm ? 2u : 0u) | (best ? 4u : 0u) | (last ? 8u : 0u);
+    }
+    flags[i] = (unsigned char)f;
 }
 
 template <int METHOD, int OCC>
 __global__ __launch_bounds__(kEvalThreads) void k_eval_occ(LevelDev lv, EvalConsts ec, const GNState* __restrict__ st,
                                                             double* __restrict__ partials, int chunk, int level,
-                                                            const int* __restrict__ head, const int* __restrict__ next,
-                                                            const float* __restrict__ dinv) {
+                                                            const unsigned char* __restrict__ flags) {
     const int b = blockIdx.x;
     const int base = b * chunk;
     const int end = min(base + chunk, lv.n);
@@ -79,20 +113,9 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_occ(LevelDev lv, EvalCons
         float X, Y, Z, rho2, d2;
         bool vis;
         unsigned ti = warp_pixel(T, wc, s.x, s.y, s.z, lv, X, Y, Z, rho2, d2, vis);
-        const bool cand = in_range && next[ic] != kOccNotCandidate;          // same pose as k_occ_build => same decision
+        const unsigned fl = in_range ? (unsigned)flags[ic] : 0u;             // k_occ_resolve's decisions at this pose
+        const bool cand = (fl & 1u) != 0, pm = (fl & 2u) != 0, best = (fl & 4u) != 0, last = (fl & 8u) != 0;
         ti = cand ? ti : 0u;
-        // ---- position of this pixel among the candidates of its target pixel ----
-        bool pm = cand, best = cand, last = cand;
-        if (cand) {
-            const float di = dinv[ic];
-            for (int j = head[ti]; j >= 0; j = next[j]) {
-                if (j == ic) continue;
-                const float dj = dinv[j];
-                if (j < ic && dj > di) pm = false;                           // an earlier pixel was closer: occluded on arrival
-                if (dj > di || (dj == di && j > ic)) best = false;           // not the final owner of the z-buffer cell
-                if (j > ic) last = false;
-            }
-        }
         const bool err_on = OCC == 1 ? best : pm;       // whose residual is in the sum
         const bool hg_on = OCC == 1 ? cand : last;      // whose rows reach the normal equations
         A.nVis += ballot_count(hg_on);
