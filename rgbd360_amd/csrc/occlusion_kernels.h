@@ -23,8 +23,9 @@
 // list element -> target records) in a kernel that keeps one 1024-thread block per CU -- 215-300 us per level-0 pass against 15 us
 // for the plain pass.  The walk now runs one thread per source pixel in 256-thread blocks (latency hidden by occupancy: 54 us, the
 // pass itself 19 us), and the head array needs no memset between passes: its entries carry the pass's generation in their top 8
-// bits.  (Four walks per thread, all their loads issued side by side, was slower -- 0.80 instead of 0.64 ms per alignment: the loop
-// then runs as long as the longest of 256 lists.)
+// bits.  (Measured and dropped: four pixels per thread with their loads issued side by side -- 0.80 ms per alignment with one
+// common walk loop, 0.93 ms with only the single-candidate case batched -- instead of 0.64 ms: fewer waves hide less latency than
+// the batching gains.)
 #pragma once
 #include "photo_icp_kernels.h"
 
