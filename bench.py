@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-4k", action="store_true", help="skip the extra 4096x2048 (configs[4]) kernel measurement")
     ap.add_argument("--no-sequence", action="store_true", help="skip the configs[3] sequence block")
+    ap.add_argument("--no-rotating", action="store_true", help="skip the HBM-fed (rotating) kernel measurement, e.g. under rocprofv3 "
+                    "--stats, whose per-kernel average would otherwise mix both regimes")
     ap.add_argument("--no-native-multi", action="store_true", help="skip the single-process multi-GPU entry (child process)")
     ap.add_argument("--seq-pairs", type=int, default=256, help="pairs of the configs[3] sequence (whole job)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -246,14 +248,14 @@ def main():
         # the same kernel with every launch HBM-fed: rotate over enough copies of the pair to exceed the Infinity Cache
         n_rot = max(2, int(np.ceil(1.6 * LLC_BYTES / ws)))
         rot = [reg]
-        for _ in range(n_rot - 1):
+        for _ in range(0 if args.no_rotating else n_rot - 1):
             r2 = RegisterPhotoICP(device=local_rank)
             r2.setNumPyr(4)
             r2.setTargetFrame(rgbA, dA)
             r2.setSourceFrame(rgbB, dB)
             rot.append(r2)
         result["roofline_hbm_rotating"] = {}
-        for m in sorted({method, 2}):
+        for m in ([] if args.no_rotating else sorted({method, 2})):
             us, bt = avg_kernel_us(lambda: RegisterPhotoICP.time_eval_kernel_rotating(rot, 0, pose_gpu, m, True, 10 * n_rot))
             result["roofline_hbm_rotating"][METHOD_NAMES[m]] = roofline_entry(
                 us, bt, n_px, m, resident="hbm", copies=n_rot, rotating_working_set_bytes=n_rot * WORKING_SET_PER_PX[m] * n_px)
