@@ -400,9 +400,12 @@ __global__ __launch_bounds__(kNT_THREADS) void k_f360_normals_tiled(const float*
 //   * the vertical R-sums slide: the row that enters is added, the row that left R steps ago (kept in a register ring, the loop is
 //     unrolled R times so that every ring index is static) is subtracted -- in float64 like the integral images, exact for the same
 //     reason (a handful of float32 terms of similar magnitude);
-//   * the horizontal R-sums are R - 1 lane shifts (DPP) of the vertical sums;
-//   * the output lanes (1 + R/2 .. 63 - R + R/2: their whole window lies inside the wave) finish the pixel: cross product in
-//     double, flip towards the viewpoint.
+//   * the horizontal R-sums of the vertical sums are formed by doubling (S2 = S1 + S1<<1, S4 = S2 + S2<<2, S8 = S4 + S4<<4, then
+//     the binary digits of R): the shift by one is a DPP move, the longer ones go through the LDS crossbar (ds_bpermute), which
+//     runs beside the VALU -- 3 float64 adds per channel instead of R - 1 (the first version shifted R - 1 times by one lane:
+//     165 of its 620 instructions per row);
+//   * lane q = 1 .. 63 - R holds the sums of the window that STARTS at its column, i.e. it finishes the pixel R/2 columns to its
+//     right (cross product in double, flip towards the viewpoint).
 // 1.3x the pixels are read (column overlap (R+1)/64, row overlap (R+1)/segment) instead of 2.7x, nothing goes through LDS, and the
 // per-pixel work is a few dozen instructions.  Pixels whose window is NOT R x R are left to k_f360_normals_tiled: the sweep marks
 // their 32 x 16 tile, the tiled kernel then runs on marked tiles only (and rewrites them whole, so a tile is always the product of
@@ -421,6 +424,48 @@ __device__ __forceinline__ double wshl1d(double v) {
 }
 __device__ __forceinline__ double wshr1d(double v) {
     return __hiloint2double(wshr1i(__double2hiint(v)), wshr1i(__double2loint(v)));
+}
+// lane l <- lane l + K for K >= 2: the LDS crossbar (no LDS memory), which runs beside the VALU
+template <int K>
+__device__ __forceinline__ int wshlk_i(int v, int lane) {
+    return K == 1 ? wshl1i(v) : __builtin_amdgcn_ds_bpermute(((lane + K) & 63) << 2, v);
+}
+template <int K>
+__device__ __forceinline__ double wshlk_d(double v, int lane) {
+    return __hiloint2double(wshlk_i<K>(__double2hiint(v), lane), wshlk_i<K>(__double2loint(v), lane));
+}
+// Sum of the R lanes l .. l + R - 1 by doubling: S2 = S1 + S1<<1, S4 = S2 + S2<<2, S8 = S4 + S4<<4, then the binary digits of R.
+template <int R>
+__device__ __forceinline__ double window_sum_d(double a, int lane) {
+    const double s1 = a;
+    const double s2 = s1 + wshlk_d<1>(s1, lane);
+    if (R == 2) return s2;
+    if (R == 3) return s2 + wshlk_d<2>(s1, lane);
+    const double s4 = s2 + wshlk_d<2>(s2, lane);
+    if (R == 4) return s4;
+    if (R == 5) return s4 + wshlk_d<4>(s1, lane);
+    if (R == 6) return s4 + wshlk_d<4>(s2, lane);
+    if (R == 7) return (s4 + wshlk_d<4>(s2, lane)) + wshlk_d<6>(s1, lane);
+    const double s8 = s4 + wshlk_d<4>(s4, lane);
+    if (R == 8) return s8;
+    if (R == 9) return s8 + wshlk_d<8>(s1, lane);
+    return s8 + wshlk_d<8>(s2, lane);      // R == 10
+}
+template <int R>
+__device__ __forceinline__ int window_sum_i(int a, int lane) {
+    const int s1 = a;
+    const int s2 = s1 + wshlk_i<1>(s1, lane);
+    if (R == 2) return s2;
+    if (R == 3) return s2 + wshlk_i<2>(s1, lane);
+    const int s4 = s2 + wshlk_i<2>(s2, lane);
+    if (R == 4) return s4;
+    if (R == 5) return s4 + wshlk_i<4>(s1, lane);
+    if (R == 6) return s4 + wshlk_i<4>(s2, lane);
+    if (R == 7) return (s4 + wshlk_i<4>(s2, lane)) + wshlk_i<6>(s1, lane);
+    const int s8 = s4 + wshlk_i<4>(s4, lane);
+    if (R == 8) return s8;
+    if (R == 9) return s8 + wshlk_i<8>(s1, lane);
+    return s8 + wshlk_i<8>(s2, lane);
 }
 struct P3 {
     float x, y, z;
@@ -465,7 +510,8 @@ __global__ __launch_bounds__(64 * kSweepWaves) void k_f360_normals_sweep(const f
     double acc[6] = {0, 0, 0, 0, 0, 0};
     int cnt = 0;                                         // count_x | count_y << 16 of the vertical window
     const int border = (int)smoothing_size;
-    const bool out_lane = lane >= LO && lane < LO + OW && c < cols;
+    const int co = c + R / 2;                            // the pixel this lane finishes: its window starts at this lane's column
+    const bool out_lane = lane >= 1 && lane <= OW && co < cols;
 
     for (int eb = e0; eb <= e1; eb += R) {
 #pragma unroll
@@ -477,7 +523,7 @@ __global__ __launch_bounds__(64 * kSweepWaves) void k_f360_normals_sweep(const f
             const bool emit = y >= y0 && y < y1;
             float ox = qnan, oy = qnan, oz = qnan, odist = 0.f;
             if (emit && out_lane) {
-                const size_t index = (size_t)y * cols + c;
+                const size_t index = (size_t)y * cols + co;
                 ox = xyz[3 * index]; oy = xyz[3 * index + 1]; oz = xyz[3 * index + 2];
                 odist = dist[index];
             }
@@ -508,50 +554,23 @@ __global__ __launch_bounds__(64 * kSweepWaves) void k_f360_normals_sweep(const f
             pm = pc; pc = pn; pn = qa; qa = qb; qb = qc;
             qc = load_row(e + 5);
             if (!emit) continue;                         // wave-uniform
-            // horizontal R-sums: offsets -R/2 .. R-1-R/2 around the lane
+            // horizontal R-sums of the window starting at this lane
             double s[6];
-            int sc = cnt;
-            {
-                double t[6];
-                int tc = cnt;
 #pragma unroll
-                for (int j = 0; j < 6; ++j) s[j] = t[j] = acc[j];
-#pragma unroll
-                for (int q = 1; q <= R - 1 - R / 2; ++q) {
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) {
-                        t[j] = wshl1d(t[j]);
-                        s[j] += t[j];
-                    }
-                    tc = wshl1i(tc);
-                    sc += tc;
-                }
-#pragma unroll
-                for (int j = 0; j < 6; ++j) t[j] = acc[j];
-                tc = cnt;
-#pragma unroll
-                for (int q = 1; q <= R / 2; ++q) {
-#pragma unroll
-                    for (int j = 0; j < 6; ++j) {
-                        t[j] = wshr1d(t[j]);
-                        s[j] += t[j];
-                    }
-                    tc = wshr1i(tc);
-                    sc += tc;
-                }
-            }
+            for (int jj = 0; jj < 6; ++jj) s[jj] = window_sum_d<R>(acc[jj], lane);
+            const int sc = window_sum_i<R>(cnt, lane);
             if (!out_lane) continue;
-            const size_t index = (size_t)y * cols + c;
+            const size_t index = (size_t)y * cols + co;
             float nx = qnan, ny = qnan, nz = qnan;
             int rect = 0;
-            if (y >= border && y < rows - border && c >= border && c < cols - border) {
+            if (y >= border && y < rows - border && co >= border && co < cols - border) {
                 const float depth = depth_mode == 0 ? oz : sqrtf(ox * ox + oy * oy + oz * oz);
                 if (isfinite(depth)) {
                     const float smoothing = fminf(odist, smoothing_size + depth / 10.0f);
                     if (smoothing > 2.0f) {
                         rect = (int)smoothing;
                         if (rect != R) {
-                            tile_flags[(y >> 4) * tiles_x + (c >> 5)] = 1;      // another window size: the tiled kernel owns this tile
+                            tile_flags[(y >> 4) * tiles_x + (co >> 5)] = 1;      // another window size: the tiled kernel owns this tile
                         } else if ((sc & 65535) > 0 && (sc >> 16) > 0) {
                             const double v0 = s[4] * s[2] - s[5] * s[1], v1 = s[5] * s[0] - s[3] * s[2], v2 = s[3] * s[1] - s[4] * s[0];
                             const double len2 = v0 * v0 + v1 * v1 + v2 * v2;

@@ -1424,13 +1424,19 @@ int f360_normals_dev(rgbd360_ctx* ctx, int rows, int cols, float max_depth_chang
     if (use_sweep) {
         flags = ctx->f_change;
         HIPC(ctx, hipMemsetAsync(flags, 0, (size_t)gt.x * gt.y, ctx->stream));
-        // rows per wave: the kernel keeps 2 waves per SIMD resident (2048 on the chip) and is issue-bound, so the wave count is made
-        // a whole number of such rounds (2432 waves of 16 rows at 2048 x 1024 would leave a second round for 384 of them: +23 %)
+        // rows per wave: the kernel keeps 3 waves per SIMD resident (149 VGPRs: 3072 on the chip) and is issue-bound, so the wave count
+        // is kept to whole rounds of residency (2432 waves of 16 rows on 2048 slots left a second round for 384 of them: +23 %); longer
+        // segments read fewer warm-up rows, shorter ones hide more latency: 19 rows is the measured optimum at 2048 x 1024 (37.7 us; 16:
+        // 38.8, 22: 41.5, 27: 48.6, 38: 56.6), 28-32 at 4096 x 2048 (117-118 us; 24: 124, 48: 146) -- tools/normals_seg_sweep.sh
         const int OW = 63 - R;
         const int strips = (cols + OW - 1) / OW;
-        const int rounds = std::max(1, (int)lround((double)strips * rows / 32.0 / 2048.0));
-        const int segs = std::max(1, 2048 * rounds / strips);
-        const int seg = std::max(16, (rows + segs - 1) / segs);
+        const int rounds = std::max(1, (int)lround((double)strips * rows / 32.0 / 3072.0));
+        const int segs = std::max(1, 3072 * rounds / strips);
+        int seg = std::max(19, (rows + segs - 1) / segs);
+        if (const char* e = getenv("RGBD360_SWEEP_SEG")) {      // tuning knob
+            const int v = atoi(e);
+            if (v >= 4 && v <= 4096) seg = v;
+        }
         const int units = strips * ((rows + seg - 1) / seg);
         const dim3 gs((units + kSweepWaves - 1) / kSweepWaves), bs(64 * kSweepWaves);
 #define SWEEP(RR) hipLaunchKernelGGL((k_f360_normals_sweep<RR>), gs, bs, 0, ctx->stream, ctx->f_xyz, ctx->f_dist, rows, cols, smoothing_size, depth_mode, seg, ctx->f_normals, ctx->f_window, flags, (int)gt.x)
