@@ -1527,59 +1527,60 @@ void sorted_eigen3(const double C[3][3], double evals[3], double evecs[3][3]) { 
 }
 
 // regions of (ctx->f_xyz, ctx->f_normals) -> labels (device ctx->f_label) + plane list (host)
-// segmentAndRefine's refinement on the device (frame360_kernels.h k_f360_refine_sweep): Jacobi sweeps of the two raster passes until
-// nothing changes, then the grown inliers are added to their planes' integer sums and the extent descriptors recomputed.
-// Work labels: the two halves of f_count (its counts are spent once the slots are assigned) and f_window.
+// segmentAndRefine's refinement on the device (frame360_kernels.h k_f360_refine_tile): block-Jacobi steps of the two raster passes
+// until nothing changes, then the grown inliers are added to their planes' integer sums and the extent descriptors recomputed.
 int f360_refine_dev(rgbd360_ctx* ctx, int rows, int cols, int nslots, std::vector<rgbd360_plane>& planes, const std::vector<int>& plane_slot) {
     using namespace f360;
     const int n = rows * cols;
-    if (!ctx->f_models) HIPC(ctx, hipMalloc(&ctx->f_models, kF360MaxSlots * sizeof(float4)));
+    if (!ctx->f_models) HIPC(ctx, hipMalloc(&ctx->f_models, (kF360MaxSlots + 1) * sizeof(float4)));      // + one slot: the relabelled-pixel counter
+    int* d_changed = reinterpret_cast<int*>(ctx->f_models + kF360MaxSlots);     // (device memory: 166 k atomics into pinned host memory took 8 ms)
     constexpr int kFlags = 64;
     if (!ctx->f_flags_host) HIPC(ctx, hipHostMalloc((void**)&ctx->f_flags_host, (kFlags + 1) * sizeof(int), hipHostMallocDefault));
     std::vector<float4> models(nslots, make_float4(NAN, 0.f, 0.f, 0.f));
     for (size_t k = 0; k < planes.size(); ++k)
         models[plane_slot[k]] = make_float4(planes[k].normal[0], planes[k].normal[1], planes[k].normal[2], planes[k].d);
     HIPC(ctx, hipMemcpyAsync(ctx->f_models, models.data(), (size_t)nslots * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
-    int* work[3] = {reinterpret_cast<int*>(ctx->f_count), reinterpret_cast<int*>(ctx->f_count) + n, ctx->f_window};
-    const dim3 g((cols + 255) / 256, rows), b(256);
-    const int* lab0 = ctx->f_label;
-    const int* result = lab0;
+    // work labels (plane slot / -1 invalid / -2 free): the two halves of f_count (its counts are spent once the slots are assigned) and
+    // f_window (only live during the normal-map stage); tile flags: the first bytes of f_dist (normal-map stage only)
+    int* w[3] = {reinterpret_cast<int*>(ctx->f_count), reinterpret_cast<int*>(ctx->f_count) + n, ctx->f_window};
+    const int tiles_y = (rows + kRefTH - 1) / kRefTH, tiles_x = (cols + 63) / 64;
+    unsigned char* tile_free = reinterpret_cast<unsigned char*>(ctx->f_dist);
+    HIPC(ctx, hipMemsetAsync(tile_free, 0, (size_t)tiles_x * tiles_y, ctx->stream));
+    hipLaunchKernelGGL(k_f360_refine_init, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->f_label, ctx->f_slot_of_root, ctx->f_models, n, cols, tiles_x,
+                       w[0], tile_free);
+    // X (w[1]) starts as the pass labels and is relaxed in place; pass 2 starts from a copy of pass 1's result (w[2])
+    HIPC(ctx, hipMemcpyAsync(w[1], w[0], (size_t)n * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+    const dim3 g(tiles_x, (tiles_y + kRefWaves - 1) / kRefWaves), b(64 * kRefWaves);
     int sweeps = 0;
     for (int pass = 1; pass <= 2; ++pass) {
-        // the pass's input must stay intact while two other buffers ping-pong
-        int* pp[2];
-        int q = 0;
-        for (int k = 0; k < 3 && q < 2; ++k)
-            if (work[k] != lab0) pp[q++] = work[k];
-        const int* cur = lab0;
-        int wb = 0;
+        const int* W0 = pass == 1 ? w[0] : w[2];
+        if (pass == 2) HIPC(ctx, hipMemcpyAsync(w[2], w[1], (size_t)n * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
         bool converged = false;
-        for (int round = 0; round < 4096 / 4 && !converged; ++round) {
+        constexpr int kPerCheck = 8;          // relaxation steps per host check (a check costs a stream synchronisation, a step ~10 us)
+        const int max_rounds = (tiles_x + tiles_y + 8) / kPerCheck + 2;    // a tile is final once its predecessor tiles are
+        for (int round = 0; round < max_rounds && !converged; ++round) {
             volatile int* flags = ctx->f_flags_host;
-            for (int k = 0; k < 4; ++k) flags[k] = 0;
-            for (int k = 0; k < 4; ++k) {        // four sweeps per host check: the check costs a stream synchronisation
-                int* dst = pp[wb];
+            for (int k = 0; k < kPerCheck; ++k) flags[k] = 0;
+            for (int k = 0; k < kPerCheck; ++k) {
                 if (pass == 1)
-                    hipLaunchKernelGGL((k_f360_refine_sweep<1>), g, b, 0, ctx->stream, ctx->f_xyz, lab0, cur, dst, ctx->f_slot_of_root, ctx->f_models,
-                                       ctx->f_refine_dist, rows, cols, ctx->f_flags_host + k);
+                    hipLaunchKernelGGL((k_f360_refine_tile<1>), g, b, 0, ctx->stream, ctx->f_xyz, W0, w[1], w[1], ctx->f_models, ctx->f_refine_dist, rows, cols,
+                                       tiles_y, tile_free, ctx->f_flags_host + k);
                 else
-                    hipLaunchKernelGGL((k_f360_refine_sweep<2>), g, b, 0, ctx->stream, ctx->f_xyz, lab0, cur, dst, ctx->f_slot_of_root, ctx->f_models,
-                                       ctx->f_refine_dist, rows, cols, ctx->f_flags_host + k);
-                cur = dst;
-                wb ^= 1;
+                    hipLaunchKernelGGL((k_f360_refine_tile<2>), g, b, 0, ctx->stream, ctx->f_xyz, W0, w[1], w[1], ctx->f_models, ctx->f_refine_dist, rows, cols,
+                                       tiles_y, tile_free, ctx->f_flags_host + k);
                 ++sweeps;
             }
             HIPC(ctx, hipGetLastError());
             HIPC(ctx, hipStreamSynchronize(ctx->stream));
-            converged = flags[3] == 0;           // a sweep that changes nothing is a fixed point: every later sweep repeats it
+            converged = flags[kPerCheck - 1] == 0;      // a step that changes nothing is a fixed point: every later step repeats it
         }
         if (!converged) return fail(ctx, -7, "plane refinement did not converge");
-        result = cur;
-        lab0 = cur;
     }
-    ctx->f_flags_host[kFlags] = 0;
-    hipLaunchKernelGGL(k_f360_refine_commit, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->f_xyz, ctx->f_label, result, ctx->f_slot_of_root, n,
-                       ctx->f_count_of_slot, ctx->f_mom, ctx->f_flags_host + kFlags);
+    const int* W0 = w[1];
+    HIPC(ctx, hipMemsetAsync(d_changed, 0, sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_f360_refine_commit, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->f_xyz, ctx->f_label, w[0], W0, ctx->f_root_of_slot, n,
+                       ctx->f_count_of_slot, ctx->f_mom, d_changed);
+    HIPC(ctx, hipMemcpyAsync(ctx->f_flags_host + kFlags, d_changed, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     hipLaunchKernelGGL(k_f360_mom_reduce, dim3((kF360MaxSlots * 9 + 255) / 256), dim3(256), 0, ctx->stream, ctx->f_mom, ctx->f_nslots, kF360MaxSlots,
                        ctx->f_root_of_slot, ctx->f_count_of_slot, ctx->f_pack_host);
     HIPC(ctx, hipGetLastError());
