@@ -1045,6 +1045,77 @@ int rgbd360_time_eval_kernel_rotating(rgbd360_ctx* const* ctxs, int n_ctx, int l
     return 0;
 }
 
+// The forced schedule of rgbd360_forced_iters in the lock-step engine's regime: n_pairs copies of ONE pair iterate side by side, every
+// {pass, solve} launch serving all of them (k_eval_b / k_solve_b), n_iters Gauss-Newton iterations each on `level`.  What a GN
+// iteration costs when the solve launch and the launch boundaries are shared by the pairs in flight -- the product's sequence path.
+int rgbd360_forced_iters_batch(rgbd360_ctx* ctx, int n_pairs, const uint8_t* rgb_trg, const void* depth_trg, const uint8_t* rgb_src,
+                               const void* depth_src, size_t rgb_step, size_t depth_step, int depth_type, int rows, int cols, int level,
+                               const float pose0[16], int method, int n_iters, float* poses_out, float* elapsed_ms) {
+    if (!ctx) return -1;
+    if (!rgb_trg || !depth_trg || !rgb_src || !depth_src || !pose0 || n_iters < 1 || n_pairs < 1 || n_pairs > kMaxSlots)
+        return fail(ctx, -1, "bad arguments");
+    if (method < 0 || method > 2) return fail(ctx, -4, "bad method");
+    if (level < 0 || level >= ctx->p.n_pyr) return fail(ctx, -3, "bad pyramid level");
+    if (depth_type != 0 && depth_type != 1) return fail(ctx, -1, "depth_type must be 0 (u16 mm) or 1 (f32 m)");
+    hipSetDevice(ctx->p.device);
+    SeqEngine* E = nullptr;
+    std::string err;
+    int rc = seq_create(ctx->p, n_pairs, rows, cols, ctx->max_eval_blocks, &E, &err);
+    if (rc) return fail(ctx, rc, err.c_str());
+    const size_t dpx = depth_type == 0 ? 2 : 4;
+    const size_t fr = (size_t)rows * cols * 3, fd = (size_t)rows * cols * dpx;
+    uint8_t *d_rgb[2] = {nullptr, nullptr}, *d_dep[2] = {nullptr, nullptr};
+    auto cleanup = [&]() {
+        for (int k = 0; k < 2; ++k) { hipFree(d_rgb[k]); hipFree(d_dep[k]); }
+        seq_free(E);
+    };
+    hipError_t e = hipSuccess;
+    for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+        e = hipMalloc(&d_rgb[k], fr);
+        if (e == hipSuccess) e = hipMalloc(&d_dep[k], fd);
+        if (e == hipSuccess) e = hipMemcpy2D(d_rgb[k], (size_t)cols * 3, k == 0 ? rgb_trg : rgb_src, rgb_step, (size_t)cols * 3, rows, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy2D(d_dep[k], (size_t)cols * dpx, k == 0 ? depth_trg : depth_src, depth_step, (size_t)cols * dpx, rows, hipMemcpyHostToDevice);
+    }
+    if (e != hipSuccess) { cleanup(); return fail(ctx, -(int)e - 1000, hipGetErrorString(e)); }
+    const unsigned long long live = n_pairs >= 64 ? ~0ull : ((1ull << n_pairs) - 1ull);
+    FramePtrs fp;
+    memset(&fp, 0, sizeof(fp));
+    for (int s = 0; s < n_pairs; ++s) { fp.rgb[s] = d_rgb[0]; fp.depth[s] = d_dep[0]; }
+    seq_frame_setup(E, fp, (size_t)cols * 3, (size_t)cols * dpx, depth_type, live, 0ull, live, E->tb);            // targets
+    for (int s = 0; s < n_pairs; ++s) { fp.rgb[s] = d_rgb[1]; fp.depth[s] = d_dep[1]; }
+    seq_frame_setup(E, fp, (size_t)cols * 3, (size_t)cols * dpx, depth_type, live, live, 0ull, E->tb ^ 1);         // sources
+    Pose16 Pz;
+    memcpy(Pz.v, pose0, sizeof(Pz.v));
+    hipLaunchKernelGGL(k_level_init_b, dim3(n_pairs), dim3(64), 0, E->stream, E->d_states, Pz, 1, 1, level, live);
+    for (int k = 0; k < 3; ++k) {        // warm
+        seq_launch_eval(E, level, method);
+        seq_launch_solve(E, level, 1);
+    }
+    hipLaunchKernelGGL(k_level_init_b, dim3(n_pairs), dim3(64), 0, E->stream, E->d_states, Pz, 1, 1, level, live);
+    e = hipEventRecord(ctx->ev0, E->stream);
+    for (int k = 0; k < n_iters; ++k) {
+        seq_launch_eval(E, level, method);
+        seq_launch_solve(E, level, 1);
+    }
+    if (e == hipSuccess) e = hipEventRecord(ctx->ev1, E->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(E->h_states, E->d_states, (size_t)n_pairs * sizeof(GNState), hipMemcpyDeviceToHost, E->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(E->stream);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+    int status = 0;
+    if (e == hipSuccess) {
+        if (elapsed_ms) *elapsed_ms = ms;
+        for (int s = 0; s < n_pairs; ++s) {
+            if (poses_out) memcpy(poses_out + 16 * s, E->h_states[s].pose, sizeof(float) * 16);
+            if (E->h_states[s].status != 0) status = E->h_states[s].status;
+        }
+    }
+    cleanup();
+    if (e != hipSuccess) return fail(ctx, -(int)e - 1000, hipGetErrorString(e));
+    return status;
+}
+
 int rgbd360_time_solve_kernel(rgbd360_ctx* ctx, int level, int mode, int reps, float* avg_us) {
     int rc = check_args(ctx, level, 0);
     if (rc) return rc;

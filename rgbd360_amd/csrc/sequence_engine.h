@@ -174,10 +174,10 @@ void seq_launch_eval(SeqEngine* E, int level, int method) {
 #undef LAUNCHB
 }
 
-void seq_launch_solve(SeqEngine* E, int level) {
+void seq_launch_solve(SeqEngine* E, int level, int forced = 0) {
     const SeqLevel& L = E->levels[level];
     SolveCfg cfg;
-    cfg.level = level; cfg.mode = 0; cfg.forced = 0; cfg.max_iters = E->p.max_iters; cfg.n_pixels = L.n;
+    cfg.level = level; cfg.mode = 0; cfg.forced = forced; cfg.max_iters = E->p.max_iters; cfg.n_pixels = L.n;
     cfg.occ = 0;
     cfg.tol_residual = E->p.tol_residual; cfg.tol_update = E->p.tol_update;
     hipLaunchKernelGGL(k_solve_b, dim3(E->P), dim3(kSolveThreads), 0, E->stream, E->d_states, E->d_partials, E->partials_stride, L.nblocks, cfg);

@@ -361,6 +361,20 @@ class RegisterPhotoICP:
         self._check(rc, allow=(0, 1, 2))
         return dict(status=rc, pose=pose_from_cm(out), rms=rms.value, elapsed_ms=ms.value)
 
+    def forced_iters_batch(self, n_pairs: int, trg, src, level: int, pose0, method: int, n_iters: int):
+        """rgbd360_forced_iters_batch: n_pairs copies of the pair (trg, src) = ((rgb, depth), (rgb, depth)) iterate in lock step."""
+        rgbT, dT = np.ascontiguousarray(trg[0], np.uint8), np.ascontiguousarray(trg[1])
+        rgbS, dS = np.ascontiguousarray(src[0], np.uint8), np.ascontiguousarray(src[1])
+        if dT.dtype not in (np.uint16, np.float32) or dS.dtype != dT.dtype or rgbS.shape != rgbT.shape or dS.shape != dT.shape:
+            raise Rgbd360Error("both frames must share size and depth type (uint16 mm or float32 m)")
+        out = np.zeros(16 * n_pairs, np.float32)
+        ms = C.c_float()
+        rc = self._L.rgbd360_forced_iters_batch(self._ctx(), int(n_pairs), _ptr(rgbT), _ptr(dT), _ptr(rgbS), _ptr(dS), rgbT.strides[0], dT.strides[0],
+                                                0 if dT.dtype == np.uint16 else 1, dT.shape[0], dT.shape[1], level, _ptr(pose_to_cm(pose0)), method,
+                                                n_iters, _ptr(out), C.byref(ms))
+        self._check(rc, allow=(0, 1, 2))
+        return dict(status=rc, poses=np.stack([pose_from_cm(out[16 * k:16 * k + 16]) for k in range(n_pairs)]), elapsed_ms=ms.value)
+
     def time_eval_kernel(self, level: int, pose, method: int, want_hg: bool = True, reps: int = 20) -> float:
         us = C.c_float()
         self._check(self._L.rgbd360_time_eval_kernel(self._ctx(), level, _ptr(pose_to_cm(pose)), method, int(want_hg), reps,

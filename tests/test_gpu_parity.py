@@ -1136,3 +1136,18 @@ def test_sensor_planes_equals_the_two_calls(hip_lib):
     for a, b in zip(one, two):
         assert (a["root"], a["count"]) == (b["root"], b["count"])
         assert np.array_equal(a["normal"], b["normal"]) and np.array_equal(a["centroid"], b["centroid"]) and a["d"] == b["d"]
+
+
+def test_forced_iterations_in_lockstep_equal_single_pair(hip_lib):
+    """rgbd360_forced_iters_batch (bench.py's iteration_lockstep block): P pairs per launch reach the single pair's pose, bit for bit."""
+    (rgbA, dA), (rgbB, dB), _ = synth.make_pair(512, 256, seed=77)
+    reg = _mk(hip_lib, 3)
+    reg.setTargetFrame(rgbA, dA)
+    reg.setSourceFrame(rgbB, dB)
+    for method in (0, 2):
+        one = reg.forced_iters(0, np.eye(4), method, 6)
+        many = reg.forced_iters_batch(5, (rgbA, dA), (rgbB, dB), 0, np.eye(4), method, 6)
+        assert many["status"] == one["status"]
+        for k in range(5):
+            assert np.array_equal(many["poses"][k], one["pose"])
+    reg.close()
