@@ -188,14 +188,18 @@ static_assert(3 * kNT_XW * kNT_XH * 4 <= 6 * kNT_SPLANE * 8, "the point tile is 
 __global__ __launch_bounds__(kNT_THREADS) void k_f360_normals_tiled(const float* __restrict__ xyz, const float* __restrict__ dist,
                                                                    int rows, int cols, float smoothing_size, int depth_mode,
                                                                    float* __restrict__ normals, int* __restrict__ window,
-                                                                   const unsigned char* __restrict__ tile_flags) {
-    // behind k_f360_normals_sweep only the tiles it marked (pixels with another window size) are left to do
-    if (tile_flags && !tile_flags[blockIdx.y * gridDim.x + blockIdx.x]) return;
+                                                                   const unsigned* __restrict__ tile_list, int tiles_x, int tiles_total) {
     __shared__ double sat[6 * kNT_SPLANE];            // phase 1 also holds the xyz tile (3 x 46 x 30 floats)
     __shared__ int satc[kNT_SPLANE];
     float* pts = reinterpret_cast<float*>(sat);
     const int tid = threadIdx.x;
-    const int c0 = blockIdx.x * kNT_W, r0 = blockIdx.y * kNT_H;
+    // Behind k_f360_normals_sweep only the tiles it listed (pixels with another window size) are left to do: tile_list = {count,
+    // tile ids ...}; the grid is a fixed few hundred blocks that walk the list (an empty list costs one load per block, not a wave
+    // launch per tile of the frame).  Without a list (tile_list == nullptr) the blocks walk every tile.
+    const int n_tiles = tile_list ? (int)min(tile_list[0], (unsigned)tiles_total) : tiles_total;
+    for (int ti = blockIdx.x; ti < n_tiles; ti += gridDim.x) {
+    const int tile = tile_list ? (int)tile_list[1 + ti] : ti;
+    const int c0 = (tile % tiles_x) * kNT_W, r0 = (tile / tiles_x) * kNT_H;
     // ---- phase 1: points of the tile + halo 7 (outside the image: NaN, never used by a pixel that produces a normal) ----
     const float qnan = __builtin_nanf("");
     {   // float by float (a tile row is 138 contiguous floats of the cloud), every load of the thread issued before the first
@@ -388,6 +392,8 @@ __global__ __launch_bounds__(kNT_THREADS) void k_f360_normals_tiled(const float*
         normals[3 * index] = nx; normals[3 * index + 1] = ny; normals[3 * index + 2] = nz;
         if (window) window[index] = rect;
     }
+    __syncthreads();                                  // the tables are rebuilt for the block's next tile
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -470,16 +476,21 @@ __device__ __forceinline__ int window_sum_i(int a, int lane) {
 struct P3 {
     float x, y, z;
 };
+typedef float f3v __attribute__((ext_vector_type(3)));
+typedef unsigned u3v __attribute__((ext_vector_type(3)));
 constexpr int kSweepWaves = 4;
 template <int R>
 __global__ __launch_bounds__(64 * kSweepWaves) void k_f360_normals_sweep(const float* __restrict__ xyz, const float* __restrict__ dist, int rows,
                                                                           int cols, float smoothing_size, int depth_mode, int seg_rows,
                                                                           float* __restrict__ normals, int* __restrict__ window,
-                                                                          unsigned char* __restrict__ tile_flags, int tiles_x) {
+                                                                          unsigned* __restrict__ tile_flags, unsigned* __restrict__ tile_list,
+                                                                          int tiles_x) {
     constexpr int OW = 63 - R;                          // output columns of a strip
     constexpr int LO = 1 + R / 2;                       // first output lane
+    constexpr int kPastEnd = (int)0x80000000u;          // a buffer offset beyond any plane (the launcher keeps planes below 2 GiB)
     const int lane = threadIdx.x & 63;
-    const int unit = blockIdx.x * kSweepWaves + (threadIdx.x >> 6);
+    // everything about rows is wave-uniform: keep it in SGPRs (scalar branches, scalar row pointers, 32-bit lane offsets)
+    const int unit = __builtin_amdgcn_readfirstlane(blockIdx.x * kSweepWaves + (threadIdx.x >> 6));
     const int strips = (cols + OW - 1) / OW;
     const int strip = unit % strips, seg = unit / strips;
     const int y0 = seg * seg_rows;
@@ -487,22 +498,27 @@ __global__ __launch_bounds__(64 * kSweepWaves) void k_f360_normals_sweep(const f
     const int y1 = min(rows, y0 + seg_rows);
     const int col0 = strip * OW;
     const int c = col0 - LO + lane;                     // this lane's point column
-    const bool col_in = c >= 0 && c < cols;
     const bool col_inner = c >= 1 && c < cols - 1;
+    // Columns and rows outside the image are loaded CLAMPED, never tested: a difference is formed only where all four neighbours are
+    // inside (col_inner, 1 <= e < rows - 1), and no window of a pixel that gets a normal reaches past the image (border >= R / 2).
+    const int cb = 12 * min(max(c, 0), cols - 1);       // byte offset of this lane's point in a row
+    // buffer addressing: descriptor + row offset in SGPRs, one 32-bit lane offset in a VGPR (no 64-bit per-lane address arithmetic);
+    // the launcher guarantees rows * cols * 12 < 2^31
+    const __amdgpu_buffer_rsrc_t r_xyz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xyz), 0, rows * cols * 12, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_dist = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dist), 0, rows * cols * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_nrm = __builtin_amdgcn_make_buffer_rsrc(normals, 0, rows * cols * 12, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_win = __builtin_amdgcn_make_buffer_rsrc(window, 0, window ? rows * cols * 4 : 0, 0x00020000);
     const float qnan = __builtin_nanf("");
-    const int e0 = y0 - R / 2, e1 = (y1 - 1) - R / 2 + R - 1;      // difference rows the segment needs
+    const int e0 = y0 - R / 2;                          // first difference row the segment needs
     auto load_row = [&](int r) {
-        P3 p = {qnan, qnan, qnan};
-        if (col_in && r >= 0 && r < rows) {
-            const float* q = xyz + 3 * ((size_t)r * cols + c);
-            p.x = q[0]; p.y = q[1]; p.z = q[2];
-        }
+        const f3v w = (f3v)__builtin_amdgcn_raw_buffer_load_b96(r_xyz, cb, min(max(r, 0), rows - 1) * cols * 12, 0);      // row: wave-uniform
+        P3 p = {w.x, w.y, w.z};
         return p;
     };
     P3 pm = load_row(e0 - 1), pc = load_row(e0), pn = load_row(e0 + 1);
     P3 qa = load_row(e0 + 2), qb = load_row(e0 + 3), qc = load_row(e0 + 4);      // in flight
     float ring[R][6];
-    unsigned vx_bits = 0, vy_bits = 0;
+    unsigned vbits = 0;                                  // validity of the R rows in the window: bit k = DX of ring slot k, bit 16 + k = DY
 #pragma unroll
     for (int k = 0; k < R; ++k)
 #pragma unroll
@@ -512,81 +528,99 @@ __global__ __launch_bounds__(64 * kSweepWaves) void k_f360_normals_sweep(const f
     const int border = (int)smoothing_size;
     const int co = c + R / 2;                            // the pixel this lane finishes: its window starts at this lane's column
     const bool out_lane = lane >= 1 && lane <= OW && co < cols;
+    const int co_l = min(max(co, 0), cols - 1), cob = 12 * co_l, cow = 4 * co_l;
+    const bool co_inside = co >= border && co < cols - border;
+    const int lane_past = out_lane ? 0 : kPastEnd;
 
-    for (int eb = e0; eb <= e1; eb += R) {
+    // row e enters the vertical sliding sums, row e - R (ring slot `slot`, a compile-time constant at every call) leaves
+    auto accumulate = [&](int e, int slot) {
+        // differences of row e (initAverage3DGradientMethod: zero, and valid, on the image border)
+        const float lx = wshr1(pc.x), ly = wshr1(pc.y), lz = wshr1(pc.z);      // p(e, c - 1)
+        const float rx = wshl1(pc.x), ry = wshl1(pc.y), rz = wshl1(pc.z);      // p(e, c + 1)
+        const bool inner = col_inner && e >= 1 && e < rows - 1;
+        float d[6];
+        d[0] = rx - lx; d[1] = ry - ly; d[2] = rz - lz;
+        d[3] = pn.x - pm.x; d[4] = pn.y - pm.y; d[5] = pn.z - pm.z;
+        const bool fx = finite3(d[0], d[1], d[2]), fy = finite3(d[3], d[4], d[5]);
+        const bool kx = inner && fx, ky = inner && fy;       // a difference that counts
+        const bool vx = !inner || fx, vy = !inner || fy;     // "valid" (the border's zero differences are)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            d[j] = kx ? d[j] : 0.f;
+            d[3 + j] = ky ? d[3 + j] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            acc[j] += (double)d[j];
+            acc[j] -= (double)ring[slot][j];
+            ring[slot][j] = d[j];
+        }
+        const unsigned vnew = (vx ? 1u : 0u) | (vy ? 65536u : 0u);
+        cnt += (int)vnew - (int)((vbits >> slot) & 0x10001u);
+        vbits = (vbits & ~(0x10001u << slot)) | (vnew << slot);
+        // next point row
+        pm = pc; pc = pn; pn = qa; qa = qb; qb = qc;
+        qc = load_row(e + 5);
+    };
+    // the output pixel's own point and distance-map value, fetched one row ahead of their use
+    auto load_own = [&](int y, float& ox, float& oy, float& oz, float& od) {
+        const int yc = min(y, rows - 1);
+        const f3v w = (f3v)__builtin_amdgcn_raw_buffer_load_b96(r_xyz, cob, yc * cols * 12, 0);
+        ox = w.x; oy = w.y; oz = w.z;
+        od = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_dist, cow, yc * cols * 4, 0));
+    };
+
+    // warm-up: the R - 1 rows above the first output row only enter the sums
+#pragma unroll
+    for (int k = 0; k < R - 1; ++k) accumulate(e0 + k, k);
+    float ox, oy, oz, odist;
+    load_own(y0, ox, oy, oz, odist);
+    // main sweep: every row completes one output row.  Passes of R rows of straight-line code (ring slots static; the finish of
+    // one row overlaps the loads and sums of the next in the scheduler's hands); rows past y1 load clamped and store nothing.
+    for (int yb = y0; yb < y1; yb += R) {
+        bool flagged = false;
 #pragma unroll
         for (int k = 0; k < R; ++k) {
-            const int e = eb + k;
-            if (e > e1) continue;                        // wave-uniform (`continue`, not `break`: the unrolled ring indices stay static)
-            // the output pixel this row completes (own point and distance-map value: issued now, used at the end of the step)
-            const int y = e - R + 1 + R / 2;
-            const bool emit = y >= y0 && y < y1;
-            float ox = qnan, oy = qnan, oz = qnan, odist = 0.f;
-            if (emit && out_lane) {
-                const size_t index = (size_t)y * cols + co;
-                ox = xyz[3 * index]; oy = xyz[3 * index + 1]; oz = xyz[3 * index + 2];
-                odist = dist[index];
-            }
-            // differences of row e (initAverage3DGradientMethod: zero, and valid, on the image border)
-            const float lx = wshr1(pc.x), ly = wshr1(pc.y), lz = wshr1(pc.z);      // p(e, c - 1)
-            const float rx = wshl1(pc.x), ry = wshl1(pc.y), rz = wshl1(pc.z);      // p(e, c + 1)
-            float d[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            bool vx = true, vy = true;
-            if (e >= 1 && e < rows - 1 && col_inner) {
-                d[0] = rx - lx; d[1] = ry - ly; d[2] = rz - lz;
-                d[3] = pn.x - pm.x; d[4] = pn.y - pm.y; d[5] = pn.z - pm.z;
-                vx = finite3(d[0], d[1], d[2]);
-                vy = finite3(d[3], d[4], d[5]);
-                if (!vx) d[0] = d[1] = d[2] = 0.f;
-                if (!vy) d[3] = d[4] = d[5] = 0.f;
-            }
-            // vertical sliding sums: row e enters, row e - R (ring slot k) leaves
-#pragma unroll
-            for (int j = 0; j < 6; ++j) {
-                acc[j] += (double)d[j];
-                acc[j] -= (double)ring[k][j];
-                ring[k][j] = d[j];
-            }
-            cnt += (vx ? 1 : 0) + (vy ? 65536 : 0) - (int)((vx_bits >> k) & 1u) - (int)(((vy_bits >> k) & 1u) << 16);
-            vx_bits = (vx_bits & ~(1u << k)) | ((vx ? 1u : 0u) << k);
-            vy_bits = (vy_bits & ~(1u << k)) | ((vy ? 1u : 0u) << k);
-            // next point row
-            pm = pc; pc = pn; pn = qa; qa = qb; qb = qc;
-            qc = load_row(e + 5);
-            if (!emit) continue;                         // wave-uniform
+            const int y = yb + k;                        // output row; the difference row that completes it is y + R - 1 - R / 2
+            accumulate(y - R / 2 + R - 1, (k + R - 1) % R);
+            const float px = ox, py = oy, pz = oz, pdist = odist;
+            load_own(y + 1, ox, oy, oz, odist);
             // horizontal R-sums of the window starting at this lane
             double s[6];
 #pragma unroll
             for (int jj = 0; jj < 6; ++jj) s[jj] = window_sum_d<R>(acc[jj], lane);
             const int sc = window_sum_i<R>(cnt, lane);
-            if (!out_lane) continue;
-            const size_t index = (size_t)y * cols + co;
-            float nx = qnan, ny = qnan, nz = qnan;
-            int rect = 0;
-            if (y >= border && y < rows - border && co >= border && co < cols - border) {
-                const float depth = depth_mode == 0 ? oz : sqrtf(ox * ox + oy * oy + oz * oz);
-                if (isfinite(depth)) {
-                    const float smoothing = fminf(odist, smoothing_size + depth / 10.0f);
-                    if (smoothing > 2.0f) {
-                        rect = (int)smoothing;
-                        if (rect != R) {
-                            tile_flags[(y >> 4) * tiles_x + (co >> 5)] = 1;      // another window size: the tiled kernel owns this tile
-                        } else if ((sc & 65535) > 0 && (sc >> 16) > 0) {
-                            const double v0 = s[4] * s[2] - s[5] * s[1], v1 = s[5] * s[0] - s[3] * s[2], v2 = s[3] * s[1] - s[4] * s[0];
-                            const double len2 = v0 * v0 + v1 * v1 + v2 * v2;
-                            if (len2 != 0.0) {
-                                const double inv = 1.0 / sqrt(len2);
-                                nx = (float)(v0 * inv); ny = (float)(v1 * inv); nz = (float)(v2 * inv);
-                                if ((-ox) * nx + (-oy) * ny + (-oz) * nz < 0.f) {
-                                    nx = -nx; ny = -ny; nz = -nz;
-                                }
-                            }
-                        }
-                    }
-                }
-            }
-            normals[3 * index] = nx; normals[3 * index + 1] = ny; normals[3 * index + 2] = nz;
-            if (window) window[index] = rect;
+            // straight-line finish: every lane does the arithmetic, predicates select at the end (the nested tests of the tiled
+            // kernel cost a mask save / branch / three NaN moves per level here)
+            const float depth = depth_mode == 0 ? pz : sqrtf(px * px + py * py + pz * pz);
+            const float smoothing = fminf(pdist, smoothing_size + depth / 10.0f);
+            const bool have = co_inside & (y >= border) & (y < rows - border) & (y < y1) & isfinite(depth) & (smoothing > 2.0f);
+            const int rect = have ? (int)smoothing : 0;
+            const double v0 = s[4] * s[2] - s[5] * s[1], v1 = s[5] * s[0] - s[3] * s[2], v2 = s[3] * s[1] - s[4] * s[0];
+            const double len2 = v0 * v0 + v1 * v1 + v2 * v2;
+            const double inv = 1.0 / sqrt(len2);
+            float nx = (float)(v0 * inv), ny = (float)(v1 * inv), nz = (float)(v2 * inv);
+            const bool flip = (-px) * nx + (-py) * ny + (-pz) * nz < 0.f;
+            const bool okn = have & (rect == R) & ((sc & 65535) > 0) & ((sc >> 16) > 0) & (len2 != 0.0);
+            nx = okn ? (flip ? -nx : nx) : qnan;
+            ny = okn ? (flip ? -ny : ny) : qnan;
+            nz = okn ? (flip ? -nz : nz) : qnan;
+            flagged = flagged | (have & (rect != R));    // another window size: the tiled kernel owns this pixel's tile
+            // stores without a branch (the pass stays one basic block): a lane with nothing to write, and every lane of a row past
+            // y1, offers an offset past the buffer -- the hardware range check drops the store (offsets < 2^31: no wrap-around);
+            // without a window plane r_win holds no records at all
+            const int past = lane_past | (y < y1 ? 0 : kPastEnd);      // (an OR, not a select: selects on the offset come back as branches)
+            f3v o;
+            o.x = nx; o.y = ny; o.z = nz;
+            __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(u3v, o), r_nrm, (y * cols * 12 + cob) | past, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32((unsigned)rect, r_win, (y * cols * 4 + cow) | past, 0, 0);
+        }
+        if (flagged && out_lane) {
+            // the pass's rows lie in at most two tile rows (R <= 16); listing a tile that needs no rework only costs time.  The first
+            // lane to claim a tile appends it to the list (tile_list[0] = count).
+            const int ta = (yb >> 4) * tiles_x + (co >> 5), tb = (min(yb + R, y1) - 1 >> 4) * tiles_x + (co >> 5);
+            if (atomicExch(&tile_flags[ta], 1u) == 0u) tile_list[1 + atomicAdd(&tile_list[0], 1u)] = (unsigned)ta;
+            if (tb != ta && atomicExch(&tile_flags[tb], 1u) == 0u) tile_list[1 + atomicAdd(&tile_list[0], 1u)] = (unsigned)tb;
         }
     }
 }

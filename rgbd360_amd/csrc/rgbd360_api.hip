@@ -1486,31 +1486,36 @@ int f360_normals_dev(rgbd360_ctx* ctx, int rows, int cols, float max_depth_chang
     launch_distance_map(ctx, rows, cols, max_depth_change_factor, depth_mode);
     const dim3 gt((cols + kNT_W - 1) / kNT_W, (rows + kNT_H - 1) / kNT_H);
     // Register sweep for the pixels whose window is int(smoothing_size) squared (nearly all of them), the tiled integral-image kernel
-    // for the 32 x 16 tiles the sweep marks (depth edges, far points).  Tile flags: the first bytes of f_change, which the distance
-    // map no longer needs (the plane stage rewrites it).  RGBD360_NORMALS_SWEEP=0 keeps the tiled kernel for everything (A/B).
+    // for the 32 x 16 tiles the sweep lists (depth edges, far points).  Claim flags + tile list: the first bytes of f_change, which the
+    // distance map no longer needs (the plane stage rewrites it).  RGBD360_NORMALS_SWEEP=0 keeps the tiled kernel for everything (A/B).
     const int R = (int)smoothing_size;
     static const bool sweep_off = [] { const char* e = getenv("RGBD360_NORMALS_SWEEP"); return e && atoi(e) == 0; }();
-    const bool use_sweep = !sweep_off && R >= 3 && R <= 10 && (size_t)gt.x * gt.y <= (size_t)rows * cols;
-    unsigned char* flags = nullptr;
+    const bool use_sweep = !sweep_off && R >= 3 && R <= 10 && ((size_t)gt.x * gt.y * 2 + 2) * sizeof(unsigned) <= (size_t)rows * cols &&
+                           (size_t)rows * cols * 12 < ((size_t)1 << 31);      // the sweep addresses its rows with 32-bit buffer offsets
+    const int n_tiles = (int)(gt.x * gt.y);
+    unsigned *flags = nullptr, *list = nullptr;            // {claimed flag per tile}, {count, tile ids ...}
     if (use_sweep) {
-        flags = ctx->f_change;
-        HIPC(ctx, hipMemsetAsync(flags, 0, (size_t)gt.x * gt.y, ctx->stream));
-        // rows per wave: the kernel keeps 3 waves per SIMD resident (149 VGPRs: 3072 on the chip) and is issue-bound, so the wave count
-        // is kept to whole rounds of residency (2432 waves of 16 rows on 2048 slots left a second round for 384 of them: +23 %); longer
-        // segments read fewer warm-up rows, shorter ones hide more latency: 19 rows is the measured optimum at 2048 x 1024 (37.7 us; 16:
-        // 38.8, 22: 41.5, 27: 48.6, 38: 56.6), 28-32 at 4096 x 2048 (117-118 us; 24: 124, 48: 146) -- tools/normals_seg_sweep.sh
+        flags = reinterpret_cast<unsigned*>(ctx->f_change);
+        list = flags + n_tiles;
+        HIPC(ctx, hipMemsetAsync(flags, 0, (size_t)(n_tiles + 1) * sizeof(unsigned), ctx->stream));
+        // rows per wave: 3 waves per SIMD stay resident (146 VGPRs: 3072 on the chip); a wave costs R - 1 warm-up rows + its rows, and
+        // the kernel ends with the most loaded SIMD, so the wave count is kept within one residency round.  16 rows per wave is the
+        // measured optimum at 2048 x 1024 (28.6 us; 8: 28.5, 24: 31.6, 32: 39.4), 16-32 at 4096 x 2048 (85-88 us; 48: 101) --
+        // tools/normals_seg_sweep.sh
         const int OW = 63 - R;
         const int strips = (cols + OW - 1) / OW;
         const int rounds = std::max(1, (int)lround((double)strips * rows / 32.0 / 3072.0));
         const int segs = std::max(1, 3072 * rounds / strips);
-        int seg = std::max(19, (rows + segs - 1) / segs);
+        // after R - 1 warm-up rows a wave sweeps whole passes of R output rows (its unrolled loop body)
+        int seg = std::max(2 * R, (rows + segs - 1) / segs);
+        seg = (seg + R - 1) / R * R;
         if (const char* e = getenv("RGBD360_SWEEP_SEG")) {      // tuning knob
             const int v = atoi(e);
             if (v >= 4 && v <= 4096) seg = v;
         }
         const int units = strips * ((rows + seg - 1) / seg);
         const dim3 gs((units + kSweepWaves - 1) / kSweepWaves), bs(64 * kSweepWaves);
-#define SWEEP(RR) hipLaunchKernelGGL((k_f360_normals_sweep<RR>), gs, bs, 0, ctx->stream, ctx->f_xyz, ctx->f_dist, rows, cols, smoothing_size, depth_mode, seg, ctx->f_normals, ctx->f_window, flags, (int)gt.x)
+#define SWEEP(RR) hipLaunchKernelGGL((k_f360_normals_sweep<RR>), gs, bs, 0, ctx->stream, ctx->f_xyz, ctx->f_dist, rows, cols, smoothing_size, depth_mode, seg, ctx->f_normals, ctx->f_window, flags, list, (int)gt.x)
         switch (R) {
             case 3: SWEEP(3); break;
             case 4: SWEEP(4); break;
@@ -1523,8 +1528,10 @@ int f360_normals_dev(rgbd360_ctx* ctx, int rows, int cols, float max_depth_chang
         }
 #undef SWEEP
     }
-    hipLaunchKernelGGL(k_f360_normals_tiled, gt, dim3(kNT_THREADS), 0, ctx->stream, ctx->f_xyz, ctx->f_dist, rows, cols, smoothing_size,
-                       depth_mode, ctx->f_normals, ctx->f_window, (const unsigned char*)flags);
+    // two tiles fit a CU: 512 blocks walk the sweep's list (every tile of the frame when there was no sweep)
+    hipLaunchKernelGGL(k_f360_normals_tiled, dim3(list ? std::min(n_tiles, 512) : n_tiles), dim3(kNT_THREADS), 0, ctx->stream, ctx->f_xyz,
+                       ctx->f_dist, rows, cols, smoothing_size, depth_mode, ctx->f_normals, ctx->f_window, (const unsigned*)list, (int)gt.x,
+                       n_tiles);
     HIPC(ctx, hipGetLastError());
     return 0;
 }
