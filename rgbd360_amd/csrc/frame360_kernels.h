@@ -618,7 +618,7 @@ __global__ __launch_bounds__(64 * kSweepWaves) void k_f360_normals_sweep(const f
         if (flagged && out_lane) {
             // the pass's rows lie in at most two tile rows (R <= 16); listing a tile that needs no rework only costs time.  The first
             // lane to claim a tile appends it to the list (tile_list[0] = count).
-            const int ta = (yb >> 4) * tiles_x + (co >> 5), tb = (min(yb + R, y1) - 1 >> 4) * tiles_x + (co >> 5);
+            const int ta = (yb >> 4) * tiles_x + (co >> 5), tb = ((min(yb + R, y1) - 1) >> 4) * tiles_x + (co >> 5);
             if (atomicExch(&tile_flags[ta], 1u) == 0u) tile_list[1 + atomicAdd(&tile_list[0], 1u)] = (unsigned)ta;
             if (tb != ta && atomicExch(&tile_flags[tb], 1u) == 0u) tile_list[1 + atomicAdd(&tile_list[0], 1u)] = (unsigned)tb;
         }

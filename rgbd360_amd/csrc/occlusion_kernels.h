@@ -14,84 +14,93 @@
 //                retraction); both averages divide by the number of prefix maxima.  H,g: per target pixel the rows of
 //                the gated source pixel with the HIGHEST index (last writer); numVisible = distinct target pixels.
 //
-// Implementation: k_occ_build links the candidates of every target pixel into a list (atomicExch on a head array);
-// k_occ_resolve (round 2) walks the (short) list of every candidate's target pixel and leaves the three decisions "prefix maximum
-// / closest / last" as a flag byte per source pixel; k_eval_occ reads the byte and accumulates the same 32 partial sums per block
-// as k_eval, so k_solve is shared.  dist = sqrt_rn(d2) and 1/dist = rcp_rn(dist) are correctly rounded: every comparison is
-// bit-for-bit the oracle's.
-// Round 1 walked the lists inside k_eval_occ: four to five DEPENDENT global round trips per pixel step (source record -> head ->
-// list element -> target records) in a kernel that keeps one 1024-thread block per CU -- 215-300 us per level-0 pass against 15 us
-// for the plain pass.  The walk now runs one thread per source pixel in 256-thread blocks (latency hidden by occupancy: 54 us, the
-// pass itself 19 us), and the head array needs no memset between passes: its entries carry the pass's generation in their top 8
-// bits.  (Measured and dropped: four pixels per thread with their loads issued side by side -- 0.80 ms per alignment with one
-// common walk loop, 0.93 ms with only the single-candidate case batched -- instead of 0.64 ms: fewer waves hide less latency than
-// the batching gains.)
+// Implementation (round 2, second form).  Candidates of one target pixel are linked into a list (atomicExch on a generation-tagged
+// head array) -- but a list node is a RUN: consecutive source pixels that land on the same target pixel, summarised by the run's
+// last lane as {max 1/dist and the pixel that has it, first pixel, last pixel = the node's own index}.  k_occ_build (one thread per
+// source pixel, a wave = 64 consecutive pixels) finds the runs with lane shifts, takes a segmented max-scan of (1/dist, index)
+// over each run -- which also tells every member whether an EARLIER member of its run is closer -- and leaves a byte per source
+// pixel {candidate, prefix maximum within its run, offset to the run's first pixel}.  k_eval_occ, which warps its source pixel
+// anyway, reads that byte, gathers its target's list head together with the target records, and decides "prefix maximum / closest /
+// last" against the run nodes: earlier runs (first pixel smaller) that hold something closer, any run with a larger (1/dist, index)
+// key, any run that ends later.  In the common case -- the pixel is a run of one and alone on its target -- the only node is its
+// own, loaded speculatively by index beside everything else: no dependent round trip at all.  dist = sqrt_rn(d2) and 1/dist =
+// rcp_rn(dist) are correctly rounded and identical in both kernels: every comparison is bit-for-bit the oracle's, and nothing
+// depends on the order in which the atomics arrive.
+// Why runs: the long lists are at the poles of the sphere, where a hundred and more pixels of a few neighbouring rows collapse
+// onto one target pixel (2048 x 1024: up to ~240); every design that walks per-pixel lists pays that length as a chain of
+// dependent global loads in some thread: round 1 inside k_eval_occ (one 1024-thread block per CU): 215-300 us per level-0 pass;
+// round 2's first form in a kernel of its own (k_occ_resolve, a flag byte per source pixel): 54 us + 19 us for the pass; an attempt
+// with two inline slots per target and per-pixel overflow lists walked by k_eval_occ: 170-280 us again.  Those pixels arrive as a
+// few long runs, so the run lists are a handful of nodes.
 #pragma once
 #include "photo_icp_kernels.h"
 
 namespace r360 {
 
 constexpr float kThresDepthOutliers = 0.3f;      // RPI.h:4525
-constexpr int   kOccNotCandidate = -2;
 
 // head entries: generation (top 8 bits) | source pixel index (24 bits; images are < 16 Mpx); an entry of another generation is
 // an empty list
 __device__ __forceinline__ int occ_decode(int tagged, int gen) { return ((unsigned)tagged >> 24) == (unsigned)gen ? (tagged & 0xFFFFFF) : -1; }
 
+// runinfo byte of a source pixel: bit 6 candidate, bit 7 no earlier member of its run is closer, bits 0-5 offset to the run's first pixel
+// node (int4, indexed by the run's LAST pixel): x = pixel holding the run's largest (1/dist, index) key, y = bits of that 1/dist,
+// z = first pixel of the run, w = next node of the same target pixel (-1: none)
 template <int OCC>
 __global__ __launch_bounds__(256) void k_occ_build(LevelDev lv, const GNState* __restrict__ st, int level, int gen, int* __restrict__ head,
-                                                   int* __restrict__ next, float* __restrict__ dinv, int* __restrict__ tgt) {
+                                                   int4* __restrict__ nodes, unsigned char* __restrict__ runinfo) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= lv.n) return;
+    const int lane = threadIdx.x & 63;
     if (st->done || st->level_active != level) return;
+    const bool in = i < lv.n;                          // (no early exit: every lane takes part in the shuffles)
+    const int ic = in ? i : lv.n - 1;
     const PoseRT T = load_pose(st->cand);
     const WarpConsts wc = {T.tx, T.ty, T.tz, lv.half_nRows, lv.pi_k};
-    const float4 s = lv.src[i];
+    const float4 s = lv.src[ic];
     float X, Y, Z, rho2, d2;
     bool vis;
     const unsigned ti = warp_pixel(T, wc, s.x, s.y, s.z, lv, X, Y, Z, rho2, d2, vis);
-    bool cand = vis && (s.x != kInvalidPoint);
+    bool cand = in && vis && (s.x != kInvalidPoint);
     const float dist = sqrt_rn(d2);
     if (OCC == 2 && cand) {
         const float depth2 = lv.trgD[ti].a;
         if (fabsf(depth2 - dist) > kThresDepthOutliers) cand = false;          // RPI.h:3788-3791, 3968-3979
     }
-    int nx = kOccNotCandidate;
-    if (cand) {
-        dinv[i] = rcp_rn(dist);
-        tgt[i] = (int)ti;
-        nx = occ_decode(atomicExch(&head[ti], (gen << 24) | i), gen);
+    const float di = rcp_rn(dist);
+    // runs of consecutive lanes with the same target pixel (a non-candidate matches nobody: targets are < 2^24)
+    const unsigned tkey = cand ? ti : (0xFF000000u | (unsigned)lane);
+    const unsigned t_before = __shfl_up(tkey, 1), t_after = __shfl_down(tkey, 1);      // (outside the ||: a shuffle reads active lanes only)
+    const bool run_head = lane == 0 || t_before != tkey;
+    const bool run_tail = lane == 63 || t_after != tkey;
+    int lead = run_head ? lane : 0;                    // lane of the run's first member: inclusive max-scan
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(lead, off);
+        if (lane >= off) lead = max(lead, o);
     }
-    next[i] = nx;
-}
-
-// flag byte per source pixel: 1 candidate, 2 prefix maximum, 4 final owner of the z-buffer cell, 8 last writer
-__global__ __launch_bounds__(256) void k_occ_resolve(int n, const GNState* __restrict__ st, int level, int gen, const int* __restrict__ head,
-                                                     const int* __restrict__ next, const float* __restrict__ dinv,
-                                                     const int* __restrict__ tgt, unsigned char* __restrict__ flags) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (st->done || st->level_active != level) return;
-    unsigned f = 0;
-    if (next[i] != kOccNotCandidate) {
-        bool pm = true, best = true, last = true;
-        const float di = dinv[i];
-        for (int j = occ_decode(head[tgt[i]], gen); j >= 0; j = next[j]) {
-            if (j == i) continue;
-            const float dj = dinv[j];
-            if (j < i && dj > di) pm = false;                            // an earlier pixel was closer: occluded on arrival
-            if (dj > di || (dj == di && j > i)) best = false;            // not the final owner of the z-buffer cell
-            if (j > i) last = false;
-        }
-        f = 1u | (pm ? 2u : 0u) | (best ? 4u : 0u) | (last ? 8u : 0u);
+    // segmented inclusive max-scan of the key (1/dist bits, pixel): positive floats order like their bit patterns
+    unsigned long long key = ((unsigned long long)__float_as_uint(di) << 32) | (unsigned)ic;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long ok = __shfl_up(key, off);
+        const int ol = __shfl_up(lead, off);
+        if (lane >= off && ol == lead && ok > key) key = ok;
     }
-    flags[i] = (unsigned char)f;
+    const unsigned long long kprev = __shfl_up(key, 1);            // the run's maximum BEFORE this member
+    const bool has_prev = lane > lead;
+    const bool pm_run = !(has_prev && __uint_as_float((unsigned)(kprev >> 32)) > di);
+    if (in) runinfo[i] = cand ? (unsigned char)(0x40u | (pm_run ? 0x80u : 0u) | (unsigned)(lane - lead)) : (unsigned char)0;
+    if (cand && run_tail) {
+        const int nx = occ_decode(atomicExch(&head[ti], (gen << 24) | i), gen);
+        nodes[i] = make_int4((int)(unsigned)key, (int)(unsigned)(key >> 32), i - (lane - lead), nx);
+    }
 }
 
 template <int METHOD, int OCC>
 __global__ __launch_bounds__(kEvalThreads) void k_eval_occ(LevelDev lv, EvalConsts ec, const GNState* __restrict__ st,
-                                                            double* __restrict__ partials, int chunk, int level,
-                                                            const unsigned char* __restrict__ flags) {
+                                                            double* __restrict__ partials, int chunk, int level, int gen,
+                                                            const int* __restrict__ head, const int4* __restrict__ nodes,
+                                                            const unsigned char* __restrict__ runinfo) {
     const int b = blockIdx.x;
     const int base = b * chunk;
     const int end = min(base + chunk, lv.n);
@@ -114,15 +123,35 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_occ(LevelDev lv, EvalCons
         float X, Y, Z, rho2, d2;
         bool vis;
         unsigned ti = warp_pixel(T, wc, s.x, s.y, s.z, lv, X, Y, Z, rho2, d2, vis);
-        const unsigned fl = in_range ? (unsigned)flags[ic] : 0u;             // k_occ_resolve's decisions at this pose
-        const bool cand = (fl & 1u) != 0, pm = (fl & 2u) != 0, best = (fl & 4u) != 0, last = (fl & 8u) != 0;
+        const unsigned info = in_range ? (unsigned)runinfo[ic] : 0u;         // k_occ_build's run record at this pose
+        const int4 own = nodes[ic];                                          // this pixel's node if it ends a run (speculative)
+        const bool cand = (info & 0x40u) != 0;
         ti = cand ? ti : 0u;
+        const int hd = occ_decode(head[ti], gen);
+        const float dist = sqrt_rn(d2);
+        const float dist_inv = rcp_rn(dist);
+        F3 tp = {0.f, 0.f, 0.f}, td = {0.f, 0.f, 0.f};
+        if (METHOD != 1) tp = lv.trgP[ti];
+        if (METHOD != 0) td = lv.trgD[ti];
+        // the three decisions against the run nodes of the same target pixel
+        bool pm = cand && (info & 0x80u) != 0, best = cand, last = cand;
+        {
+            const unsigned long long key_i = ((unsigned long long)__float_as_uint(dist_inv) << 32) | (unsigned)ic;
+            const int my_first = ic - (int)(info & 63u);
+            int node = cand ? hd : -1;
+            while (node >= 0) {
+                const int4 nd = node == ic ? own : nodes[node];
+                const unsigned long long k = ((unsigned long long)(unsigned)nd.y << 32) | (unsigned)nd.x;
+                if (nd.z < my_first && __uint_as_float((unsigned)nd.y) > dist_inv) pm = false;      // an earlier run holds something closer
+                if (k > key_i) best = false;                                                        // not the final owner of the z-buffer cell
+                if (node > ic) last = false;                                                        // a run ends later
+                node = nd.w;
+            }
+        }
         const bool err_on = OCC == 1 ? best : pm;       // whose residual is in the sum
         const bool hg_on = OCC == 1 ? cand : last;      // whose rows reach the normal equations
         A.nVis += ballot_count(hg_on);
 
-        const float dist = sqrt_rn(d2);
-        const float dist_inv = rcp_rn(dist);
         float a1, a2, b0, b1, b2;
         {
 #pragma clang fp contract(fast)
@@ -136,9 +165,6 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_occ(LevelDev lv, EvalCons
             b1 = c * Y;
             b2 = c * Z;
         }
-        F3 tp = {0.f, 0.f, 0.f}, td = {0.f, 0.f, 0.f};
-        if (METHOD != 1) tp = lv.trgP[ti];
-        if (METHOD != 0) td = lv.trgD[ti];
         const float depth2 = td.a;
         const bool nonsal_p = METHOD != 1 && fabsf(tp.b) < ec.thr_photo && fabsf(tp.c) < ec.thr_photo;
         const bool nonsal_d = METHOD != 0 && fabsf(td.b) < ec.thr_depth && fabsf(td.c) < ec.thr_depth;

@@ -98,11 +98,10 @@ struct rgbd360_ctx {
     int al_occ = 0;
     float cam[4] = {0.f, 0.f, 0.f, 0.f};               // cameraMatrix(0,0), (1,1), (0,2), (1,2)   RPI.h:89, 254-257
     bool have_cam = false;
-    int *occ_head = nullptr, *occ_next = nullptr;      // occlusion modes: per-target candidate lists
-    int* occ_tgt = nullptr;                            // ... the target pixel of every candidate
-    unsigned char* occ_flags = nullptr;                // ... k_occ_resolve's decisions per source pixel
+    int* occ_head = nullptr;                           // occlusion modes: per-target lists of candidate runs (generation-tagged heads)
+    int4* occ_nodes = nullptr;                         // ... run nodes, indexed by the run's last source pixel
+    unsigned char* occ_runinfo = nullptr;              // ... per source pixel: candidate / prefix maximum within its run / offset to the run's first pixel
     int occ_gen = 0;                                   // generation tag of the head entries (no memset between passes)
-    float* occ_dinv = nullptr;
     size_t occ_n = 0;
     int max_eval_blocks = 256;    // grid cap of the fused pass (tuning knob: RGBD360_EVAL_BLOCKS)
     std::string err;
@@ -215,16 +214,14 @@ dim3 grid2d(int rows, int cols, int bx = 256) { return dim3((cols + bx - 1) / bx
 int occ_ensure(rgbd360_ctx* ctx) {
     const size_t n = ctx->levels.empty() ? 0 : (size_t)ctx->levels[0].n;
     if (ctx->occ_n >= n && n > 0) return 0;
-    hipFree(ctx->occ_head); hipFree(ctx->occ_next); hipFree(ctx->occ_dinv); hipFree(ctx->occ_tgt); hipFree(ctx->occ_flags);
-    ctx->occ_head = ctx->occ_next = ctx->occ_tgt = nullptr;
-    ctx->occ_dinv = nullptr;
-    ctx->occ_flags = nullptr;
+    hipFree(ctx->occ_head); hipFree(ctx->occ_nodes); hipFree(ctx->occ_runinfo);
+    ctx->occ_head = nullptr;
+    ctx->occ_nodes = nullptr;
+    ctx->occ_runinfo = nullptr;
     ctx->occ_n = 0;
     HIPC(ctx, hipMalloc(&ctx->occ_head, n * sizeof(int)));
-    HIPC(ctx, hipMalloc(&ctx->occ_next, n * sizeof(int)));
-    HIPC(ctx, hipMalloc(&ctx->occ_dinv, n * sizeof(float)));
-    HIPC(ctx, hipMalloc(&ctx->occ_tgt, n * sizeof(int)));
-    HIPC(ctx, hipMalloc(&ctx->occ_flags, n));
+    HIPC(ctx, hipMalloc(&ctx->occ_nodes, n * sizeof(int4)));
+    HIPC(ctx, hipMalloc(&ctx->occ_runinfo, n));
     HIPC(ctx, hipMemsetAsync(ctx->occ_head, 0, n * sizeof(int), ctx->stream));      // generation 0 = empty; the passes count from 1
     ctx->occ_gen = 0;
     ctx->occ_n = n;
@@ -237,7 +234,7 @@ void launch_eval(rgbd360_ctx* ctx, int level, int method, bool hg, int occ = 0) 
     const EvalConsts ec = eval_consts(ctx->p);
     dim3 g(L.nblocks), b(kEvalThreads);
     if (occ != 0) {
-        // per-target candidate lists at the pose under evaluation, the per-pixel decisions, then the occlusion-aware fused pass.
+        // per-target lists of candidate RUNS at the pose under evaluation, then the occlusion-aware fused pass, which decides per pixel.
         // The head entries carry the pass's generation (1..255) in their top byte: one memset per 255 passes instead of one per pass.
         if (++ctx->occ_gen > 255) {
             hipMemsetAsync(ctx->occ_head, 0, ctx->occ_n * sizeof(int), ctx->stream);
@@ -245,11 +242,9 @@ void launch_eval(rgbd360_ctx* ctx, int level, int method, bool hg, int occ = 0) 
         }
         const int gen = ctx->occ_gen;
         const dim3 gb((L.n + 255) / 256), bb(256);
-        if (occ == 1) hipLaunchKernelGGL((k_occ_build<1>), gb, bb, 0, ctx->stream, lv, ctx->d_state, level, gen, ctx->occ_head, ctx->occ_next, ctx->occ_dinv, ctx->occ_tgt);
-        else hipLaunchKernelGGL((k_occ_build<2>), gb, bb, 0, ctx->stream, lv, ctx->d_state, level, gen, ctx->occ_head, ctx->occ_next, ctx->occ_dinv, ctx->occ_tgt);
-        hipLaunchKernelGGL(k_occ_resolve, gb, bb, 0, ctx->stream, L.n, ctx->d_state, level, gen, ctx->occ_head, ctx->occ_next, ctx->occ_dinv, ctx->occ_tgt,
-                           ctx->occ_flags);
-#define LAUNCH_OCC(M, O) hipLaunchKernelGGL((k_eval_occ<M, O>), g, b, 0, ctx->stream, lv, ec, ctx->d_state, ctx->d_partials, L.chunk, level, ctx->occ_flags)
+        if (occ == 1) hipLaunchKernelGGL((k_occ_build<1>), gb, bb, 0, ctx->stream, lv, ctx->d_state, level, gen, ctx->occ_head, ctx->occ_nodes, ctx->occ_runinfo);
+        else hipLaunchKernelGGL((k_occ_build<2>), gb, bb, 0, ctx->stream, lv, ctx->d_state, level, gen, ctx->occ_head, ctx->occ_nodes, ctx->occ_runinfo);
+#define LAUNCH_OCC(M, O) hipLaunchKernelGGL((k_eval_occ<M, O>), g, b, 0, ctx->stream, lv, ec, ctx->d_state, ctx->d_partials, L.chunk, level, gen, ctx->occ_head, (const int4*)ctx->occ_nodes, (const unsigned char*)ctx->occ_runinfo)
         if (occ == 1) {
             if (method == 0) LAUNCH_OCC(0, 1);
             else if (method == 1) LAUNCH_OCC(1, 1);
@@ -532,7 +527,7 @@ void rgbd360_destroy(rgbd360_ctx* ctx) {
     hipFree(ctx->f_models);
     if (ctx->f_flags_host) hipHostFree(ctx->f_flags_host);
     hipFree(ctx->b_sum); hipFree(ctx->b_cnt); hipFree(ctx->b_a); hipFree(ctx->b_b); hipFree(ctx->b_mm);
-    hipFree(ctx->occ_head); hipFree(ctx->occ_next); hipFree(ctx->occ_dinv); hipFree(ctx->occ_tgt); hipFree(ctx->occ_flags);
+    hipFree(ctx->occ_head); hipFree(ctx->occ_nodes); hipFree(ctx->occ_runinfo);
     if (ctx->h_state) hipHostFree(ctx->h_state);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
