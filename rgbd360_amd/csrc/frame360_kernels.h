@@ -1190,14 +1190,28 @@ __global__ void k_f360_refine_init(const int* __restrict__ label, const int* __r
 // the 2048 x 1024 test scene with the first version).  The fixed point of the scheme is the unique solution of the raster recurrence,
 // i.e. PCL's sequential pass.
 __device__ __forceinline__ int wave_read_lane(int v, int src_lane) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
+// labels other tiles may be rewriting while this kernel runs: device-coherent accesses (the L2s of the eight XCDs are not coherent
+// with each other for plain loads and stores inside a kernel)
+__device__ __forceinline__ int coherent_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void coherent_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// X is updated IN PLACE: a neighbouring tile's ring pixel may be read while that tile rewrites it -- either value is a valid iterate
+// of this asynchronous relaxation, whose only fixed point is the recurrence's solution.  A wave does not leave after its step: it
+// POLLS its ring (16 + 64 labels) up to n_polls times and repeats the step whenever the ring has changed, so a growth chain crosses
+// many tiles inside one launch (a launch per tile crossed: 56 launches = 1.3 ms on the 2048 x 1024 noisy scene).  Polling is bounded
+// (no wave waits for another: nothing depends on residency) and ends early once `activity` -- a counter every changing step bumps
+// -- has stood still for a few polls.  A launch in which no step changed anything has read nothing but final values (its first step
+// sees everything earlier launches wrote): that is the host's convergence test.  Tiles without free pixels (tile_free) do nothing.
 template <int PASS>
-// X is updated IN PLACE (Xin == Xout): a neighbouring tile's ring pixel may be read while that tile rewrites it -- either value is a
-// valid iterate of this asynchronous relaxation, whose only fixed point is the recurrence's solution; a step in which no tile changed
-// anything has read nothing but final values.  Tiles without free pixels (tile_free) do nothing at all.
-__global__ __launch_bounds__(64 * kRefWaves) void k_f360_refine_tile(const float* __restrict__ xyz, const int* __restrict__ W0, const int* Xin,
-                                                                    int* Xout, const float4* __restrict__ models, float thr, int rows,
-                                                                    int cols, int tiles_y, const unsigned char* __restrict__ tile_free,
-                                                                    int* __restrict__ changed) {
+__global__ __launch_bounds__(64 * kRefWaves) void k_f360_refine_tile(const float* __restrict__ xyz, const int* __restrict__ W0, int* X,
+                                                                    const float4* __restrict__ models, float thr, int rows, int cols,
+                                                                    int tiles_y, const unsigned char* __restrict__ tile_free,
+                                                                    int* __restrict__ changed, int* activity, int n_polls, int n_quiet,
+                                                                    int n_lds_models) {
+    // the plane models in LDS (when they fit): a step looks two of them up per row, each row depends on the one before, and a chain
+    // of 32 L1/L2 round trips per step was what a tile hop cost (~20 us)
+    extern __shared__ float4 s_models[];
+    for (int k = threadIdx.x; k < n_lds_models; k += blockDim.x) s_models[k] = models[k];
+    __syncthreads();
     const int lane = threadIdx.x & 63;
     const int tyi = blockIdx.y * kRefWaves + (threadIdx.x >> 6);
     if (tyi >= tiles_y) return;
@@ -1205,90 +1219,143 @@ __global__ __launch_bounds__(64 * kRefWaves) void k_f360_refine_tile(const float
     const int c0 = blockIdx.x * 64, r0 = tyi * kRefTH;
     const int c = c0 + lane;
     const bool col_in = c < cols;
-    // the whole tile column of this lane into registers (one memory round trip), plus the ring
-    int w0[kRefTH], xin[kRefTH], ringside[kRefTH];
+    // the whole tile column of this lane into registers (one memory round trip)
+    int w0[kRefTH], cur[kRefTH];
     float px[kRefTH], py[kRefTH], pz[kRefTH];
-    const int side_c = PASS == 1 ? c0 - 1 : c0 + 64;          // the ring column the row propagation comes from
 #pragma unroll
     for (int k = 0; k < kRefTH; ++k) {
         const int r = r0 + k;
         const bool in = col_in && r < rows;
         const size_t i = (size_t)(in ? r : 0) * cols + (in ? c : 0);
         w0[k] = in ? W0[i] : kRefInvalid;
-        xin[k] = in ? Xin[i] : kRefInvalid;
+        cur[k] = in ? X[i] : kRefInvalid;
         px[k] = xyz[3 * i]; py[k] = xyz[3 * i + 1]; pz[k] = xyz[3 * i + 2];
-        ringside[k] = (r < rows && side_c >= 0 && side_c < cols) ? Xin[(size_t)r * cols + side_c] : kRefInvalid;      // wave-uniform address
     }
-    const int rprev = PASS == 1 ? r0 - 1 : r0 + kRefTH;       // the ring row the pass comes from
-    int prev = (col_in && rprev >= 0 && rprev < rows) ? Xin[(size_t)rprev * cols + c] : kRefInvalid;
+    // the ring: lane k < 16 holds the label beside row k on the side the row propagation comes from, every lane the label of its
+    // column in the row the pass comes from
+    const int side_c = PASS == 1 ? c0 - 1 : c0 + 64;
+    const int rprev = PASS == 1 ? r0 - 1 : r0 + kRefTH;
+    const bool side_in = lane < kRefTH && r0 + lane < rows && side_c >= 0 && side_c < cols;
+    const bool prev_in = col_in && rprev >= 0 && rprev < rows;
+    const int* side_p = X + (size_t)(side_in ? r0 + lane : 0) * cols + (side_in ? side_c : 0);
+    const int* prev_p = X + (size_t)(prev_in ? rprev : 0) * cols + (prev_in ? c : 0);
     // validity of the previous row's pixel one column further (the coupling of the two checks in PCL's loop body): for the ring row
-    // from memory, afterwards from the lanes
+    // from memory, afterwards from the lanes -- pass labels, static
     const int cc = PASS == 1 ? c + 1 : c - 1;
-    bool prev_side_valid = (cc >= 0 && cc < cols && rprev >= 0 && rprev < rows) ? (W0[(size_t)rprev * cols + cc] != kRefInvalid) : false;
-    bool any_change = false;
+    const bool ring_side_valid = (cc >= 0 && cc < cols && rprev >= 0 && rprev < rows) ? (W0[(size_t)rprev * cols + cc] != kRefInvalid) : false;
+    bool edge_valid[kRefTH];                   // the tile-edge lane's neighbour in the next tile (pass labels, static)
+    {
+        const int edge_c = PASS == 1 ? c0 + 64 : c0 - 1;
 #pragma unroll
-    for (int kk = 0; kk < kRefTH; ++kk) {
-        const int k = PASS == 1 ? kk : kRefTH - 1 - kk;
-        const int r = r0 + k;
-        int state = w0[k];
-        const bool is_free = state == kRefFree;
-        auto within = [&](int label) {        // PlaneRefinementComparator::compare's distance test of this pixel against plane `label`
-            const float4 m = models[label >= 0 ? label : 0];
-            const double ptp_dist = fabs(m.x * px[k] + m.y * py[k] + m.z * pz[k] + m.w);
-            return label >= 0 && ptp_dist < (double)thr;
-        };
-        // offer from the previous row
-        if (PASS == 1) {
-            if (is_free && r >= 1 && c <= cols - 2 && prev_side_valid && within(prev)) state = prev;
-        } else {
-            if (is_free && r + 1 <= rows - 1 && (c == 0 || prev_side_valid) && within(prev)) state = prev;
-        }
-        // propagation along the row
-        const bool still_free = state == kRefFree;
-        const unsigned long long nonfree = __ballot(!still_free);
-        int s;                                 // lane of the nearest non-free pixel on the incoming side, -1 / 64: the ring pixel
-        if (PASS == 1) {
-            const unsigned long long m = nonfree & ((1ull << lane) - 1ull);
-            s = m ? 63 - __builtin_clzll(m) : -1;
-        } else {
-            const unsigned long long m = lane == 63 ? 0ull : (nonfree & ~((2ull << lane) - 1ull));
-            s = m ? __builtin_ctzll(m) : 64;
-        }
-        const int from_lane = wave_read_lane(state, s & 63);
-        const int cand = (s < 0 || s > 63) ? ringside[k] : from_lane;
-        const bool row_ok = PASS == 1 ? (c >= 1 && r <= rows - 2) : (c + 1 <= cols - 1 && r >= 1);
-        const bool ok = still_free && col_in && within(cand);
-        const unsigned long long okm = __ballot(ok);
-        if (still_free && row_ok && cand >= 0) {
-            unsigned long long range;          // the lanes strictly between s and this one, and this one
-            if (PASS == 1) range = ((2ull << lane) - 1ull) & ~(s < 0 ? 0ull : ((2ull << s) - 1ull));
-            else range = (s > 63 ? ~0ull : ((1ull << s) - 1ull)) & ~((1ull << lane) - 1ull);
-            // every pixel of the chain must be allowed to hand the label on: the chain runs inside rows 0 .. H-2 (pass 1) / 1 .. H-1 (pass 2)
-            // for all of them alike, and column limits only bind at the image border, where the chain starts
-            if ((range & ~okm) == 0ull) state = cand;
-        }
-        if (col_in && r < rows && state != xin[k]) {
-            any_change = true;
-            Xout[(size_t)r * cols + c] = state;
-        }
-        // this row is the next one's "previous row"
-        const int nb = PASS == 1 ? wshl1i(w0[k]) : wshr1i(w0[k]);          // pass labels of the neighbouring lane: validity is static
-        const int edge_c = PASS == 1 ? c0 + 64 : c0 - 1;                    // the lane at the tile's edge looks into the ring
-        bool side_valid = nb != kRefInvalid;
-        if ((PASS == 1 && lane == 63) || (PASS == 2 && lane == 0))
-            side_valid = (edge_c >= 0 && edge_c < cols && r < rows) ? (W0[(size_t)r * cols + edge_c] != kRefInvalid) : false;
-        prev_side_valid = side_valid;
-        prev = state;
+        for (int k = 0; k < kRefTH; ++k)
+            edge_valid[k] = (edge_c >= 0 && edge_c < cols && r0 + k < rows) ? (W0[(size_t)(r0 + k) * cols + edge_c] != kRefInvalid) : false;
     }
-    if (__ballot(any_change) != 0ull && lane == 0) *changed = 1;
+    int ring_side = side_in ? coherent_load(side_p) : kRefInvalid;
+    int ring_prev = prev_in ? coherent_load(prev_p) : kRefInvalid;
+    bool any_change = false;
+
+    auto step = [&]() {                        // one exact sweep of the tile against the ring held in ring_side / ring_prev
+        int prev = ring_prev;
+        bool prev_side_valid = ring_side_valid;
+        bool chg = false;
+#pragma unroll
+        for (int kk = 0; kk < kRefTH; ++kk) {
+            const int k = PASS == 1 ? kk : kRefTH - 1 - kk;
+            const int r = r0 + k;
+            int state = w0[k];
+            const bool is_free = state == kRefFree;
+            auto within = [&](int label) {        // PlaneRefinementComparator::compare's distance test of this pixel against plane `label`
+                const int l = label >= 0 ? label : 0;
+                const float4 m = n_lds_models > 0 ? s_models[l] : models[l];
+                const double ptp_dist = fabs(m.x * px[k] + m.y * py[k] + m.z * pz[k] + m.w);
+                return label >= 0 && ptp_dist < (double)thr;
+            };
+            // offer from the previous row
+            if (PASS == 1) {
+                if (is_free && r >= 1 && c <= cols - 2 && prev_side_valid && within(prev)) state = prev;
+            } else {
+                if (is_free && r + 1 <= rows - 1 && (c == 0 || prev_side_valid) && within(prev)) state = prev;
+            }
+            // propagation along the row
+            const bool still_free = state == kRefFree;
+            const unsigned long long nonfree = __ballot(!still_free);
+            int s;                                 // lane of the nearest non-free pixel on the incoming side, -1 / 64: the ring pixel
+            if (PASS == 1) {
+                const unsigned long long m = nonfree & ((1ull << lane) - 1ull);
+                s = m ? 63 - __builtin_clzll(m) : -1;
+            } else {
+                const unsigned long long m = lane == 63 ? 0ull : (nonfree & ~((2ull << lane) - 1ull));
+                s = m ? __builtin_ctzll(m) : 64;
+            }
+            const int from_lane = wave_read_lane(state, s & 63);
+            const int ringside_k = __builtin_amdgcn_readlane(ring_side, k);
+            const int cand = (s < 0 || s > 63) ? ringside_k : from_lane;
+            const bool row_ok = PASS == 1 ? (c >= 1 && r <= rows - 2) : (c + 1 <= cols - 1 && r >= 1);
+            const bool ok = still_free && col_in && within(cand);
+            const unsigned long long okm = __ballot(ok);
+            if (still_free && row_ok && cand >= 0) {
+                unsigned long long range;          // the lanes strictly between s and this one, and this one
+                if (PASS == 1) range = ((2ull << lane) - 1ull) & ~(s < 0 ? 0ull : ((2ull << s) - 1ull));
+                else range = (s > 63 ? ~0ull : ((1ull << s) - 1ull)) & ~((1ull << lane) - 1ull);
+                // every pixel of the chain must be allowed to hand the label on: the chain runs inside rows 0 .. H-2 (pass 1) / 1 .. H-1 (pass 2)
+                // for all of them alike, and column limits only bind at the image border, where the chain starts
+                if ((range & ~okm) == 0ull) state = cand;
+            }
+            if (col_in && r < rows && state != cur[k]) {
+                chg = true;
+                cur[k] = state;
+                coherent_store(X + (size_t)r * cols + c, state);
+            }
+            // this row is the next one's "previous row"
+            const int nb = PASS == 1 ? wshl1i(w0[k]) : wshr1i(w0[k]);          // pass labels of the neighbouring lane: validity is static
+            bool side_valid = nb != kRefInvalid;
+            if ((PASS == 1 && lane == 63) || (PASS == 2 && lane == 0)) side_valid = edge_valid[k];
+            prev_side_valid = side_valid;
+            prev = state;
+        }
+        return __ballot(chg) != 0ull;
+    };
+
+    if (step()) {
+        any_change = true;
+        if (lane == 0) atomicAdd(activity, 1);
+    }
+    int seen = coherent_load(activity), quiet = 0;
+    const int first_seen = seen;
+    for (int p = 0; p < n_polls; ++p) {
+        __builtin_amdgcn_s_sleep(8);
+        const int rs = side_in ? coherent_load(side_p) : kRefInvalid;
+        const int rp = prev_in ? coherent_load(prev_p) : kRefInvalid;
+        const int act = coherent_load(activity);
+        if (__ballot(rs != ring_side || rp != ring_prev) != 0ull) {
+            ring_side = rs; ring_prev = rp;
+            if (step()) {
+                any_change = true;
+                if (lane == 0) atomicAdd(activity, 1);
+            }
+            quiet = 0;
+            seen = coherent_load(activity);
+            continue;
+        }
+        if (act == seen) {
+            // nobody has changed anything for a while: the launch is over for this tile (a launch in which nothing has moved at
+            // all -- the host's verification launch, a frame with nothing to grow -- is given up four times sooner)
+            if (++quiet >= (seen == first_seen && !any_change ? max(n_quiet / 4, 1) : n_quiet)) break;
+        } else {
+            seen = act;
+            quiet = 0;
+        }
+    }
+    if (any_change && lane == 0) *changed = 1;
 }
 // The grown inliers join their plane's sums: count and the nine integer moments (order independent), labels updated.  The sums of a
 // block are collected in an LDS hash first (a noisy patch sends thousands of pixels to ONE plane: 1.7 M same-address global atomics
 // took 5 ms), one global atomic per block, slot and sum follows.
 __global__ __launch_bounds__(256) void k_f360_refine_commit(const float* __restrict__ xyz, int* __restrict__ label, const int* __restrict__ Winit,
                                                             const int* __restrict__ Wfinal, const int* __restrict__ root_of_slot, int n,
-                                                            int* __restrict__ count_of_slot, unsigned long long* __restrict__ mom,
+                                                            int* __restrict__ count_of_slot, unsigned long long* __restrict__ mom, int max_slots,
                                                             int* __restrict__ n_changed) {
+    unsigned long long* mom_rep = mom + (size_t)(blockIdx.x % kMomReplicas) * max_slots * 9;      // any copy will do: k_f360_mom_reduce sums them
     __shared__ int keys[kMomRunHash];
     __shared__ unsigned long long vals[kMomRunHash][10];
     __shared__ int block_changed;
@@ -1298,36 +1365,55 @@ __global__ __launch_bounds__(256) void k_f360_refine_commit(const float* __restr
     if (threadIdx.x == 0) block_changed = 0;
     __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        const int slot = Wfinal[i];
-        if (slot != Winit[i]) {                            // only free pixels change, and only into a plane's slot
-            label[i] = root_of_slot[slot];
-            auto d2ll = [](double v) -> long long { return __double_as_longlong(v + 6755399441055744.0) - 0x4338000000000000LL; };
-            const double x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
-            const long long v[9] = {d2ll(x * kMomScale), d2ll(y * kMomScale), d2ll(z * kMomScale), d2ll(x * x * kMomScale),
-                                    d2ll(x * y * kMomScale), d2ll(x * z * kMomScale), d2ll(y * y * kMomScale), d2ll(y * z * kMomScale),
-                                    d2ll(z * z * kMomScale)};
+    const int lane = threadIdx.x & 63;
+    const int slot = i < n ? Wfinal[i] : kRefInvalid;
+    const bool grown = i < n && slot != Winit[i];          // only free pixels change, and only into a plane's slot
+    unsigned long long v[10] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    if (grown) {
+        label[i] = root_of_slot[slot];
+        auto d2ll = [](double v) -> long long { return __double_as_longlong(v + 6755399441055744.0) - 0x4338000000000000LL; };
+        const double x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
+        v[0] = (unsigned long long)d2ll(x * kMomScale); v[1] = (unsigned long long)d2ll(y * kMomScale); v[2] = (unsigned long long)d2ll(z * kMomScale);
+        v[3] = (unsigned long long)d2ll(x * x * kMomScale); v[4] = (unsigned long long)d2ll(x * y * kMomScale);
+        v[5] = (unsigned long long)d2ll(x * z * kMomScale); v[6] = (unsigned long long)d2ll(y * y * kMomScale);
+        v[7] = (unsigned long long)d2ll(y * z * kMomScale); v[8] = (unsigned long long)d2ll(z * z * kMomScale);
+        v[9] = 1ull;
+    }
+    const unsigned long long gm = __ballot(grown);
+    if (gm != 0ull) {                                      // wave-uniform
+        // a noisy patch sends whole waves to ONE plane: those are summed across the wave first (sums of integers: order free) and
+        // enter the hash once; 64 lanes x 10 atomics on one LDS address each took most of this kernel's 118 us
+        const int first = __builtin_ctzll(gm);
+        const int s0 = __builtin_amdgcn_readlane(slot, first);
+        const bool one_plane = __ballot(grown && slot != s0) == 0ull;
+        if (one_plane) {
+#pragma unroll
+            for (int q = 0; q < 10; ++q) {
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) v[q] += __shfl_xor(v[q], off);
+            }
+        }
+        if (one_plane ? lane == first : grown) {
             const int h = mom_run_slot(keys, slot);
             if (h >= 0) {
 #pragma unroll
-                for (int q = 0; q < 9; ++q) atomicAdd(&vals[h][q], (unsigned long long)v[q]);
-                atomicAdd(&vals[h][9], 1ull);
+                for (int q = 0; q < 10; ++q) atomicAdd(&vals[h][q], v[q]);
             } else {                                       // hash full (more than 256 planes meet in one block): straight to memory
 #pragma unroll
-                for (int q = 0; q < 9; ++q) atomicAdd(&mom[(size_t)slot * 9 + q], (unsigned long long)v[q]);
-                atomicAdd(&count_of_slot[slot], 1);
-                atomicAdd(n_changed, 1);
+                for (int q = 0; q < 9; ++q) atomicAdd(&mom_rep[(size_t)slot * 9 + q], v[q]);
+                atomicAdd(&count_of_slot[slot], (int)v[9]);
+                atomicAdd(n_changed, (int)v[9]);
             }
             block_changed = 1;
         }
     }
     __syncthreads();
     if (!block_changed) return;
-    const int slot = keys[threadIdx.x];
-    if (slot >= 0) {
+    const int hs = keys[threadIdx.x];
+    if (hs >= 0) {
 #pragma unroll
-        for (int q = 0; q < 9; ++q) atomicAdd(&mom[(size_t)slot * 9 + q], vals[threadIdx.x][q]);
-        atomicAdd(&count_of_slot[slot], (int)vals[threadIdx.x][9]);
+        for (int q = 0; q < 9; ++q) atomicAdd(&mom_rep[(size_t)hs * 9 + q], vals[threadIdx.x][q]);
+        atomicAdd(&count_of_slot[hs], (int)vals[threadIdx.x][9]);
         atomicAdd(n_changed, (int)vals[threadIdx.x][9]);
     }
 }

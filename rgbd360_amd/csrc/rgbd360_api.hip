@@ -1607,6 +1607,8 @@ int f360_refine_dev(rgbd360_ctx* ctx, int rows, int cols, int nslots, std::vecto
     const int n = rows * cols;
     if (!ctx->f_models) HIPC(ctx, hipMalloc(&ctx->f_models, (kF360MaxSlots + 1) * sizeof(float4)));      // + one slot: the relabelled-pixel counter
     int* d_changed = reinterpret_cast<int*>(ctx->f_models + kF360MaxSlots);     // (device memory: 166 k atomics into pinned host memory took 8 ms)
+    int* d_activity = d_changed + 1;                                            // bumped by every relaxation step that changed a label
+    HIPC(ctx, hipMemsetAsync(d_activity, 0, sizeof(int), ctx->stream));
     constexpr int kFlags = 64;
     if (!ctx->f_flags_host) HIPC(ctx, hipHostMalloc((void**)&ctx->f_flags_host, (kFlags + 1) * sizeof(int), hipHostMallocDefault));
     std::vector<float4> models(nslots, make_float4(NAN, 0.f, 0.f, 0.f));
@@ -1624,35 +1626,42 @@ int f360_refine_dev(rgbd360_ctx* ctx, int rows, int cols, int nslots, std::vecto
     // X (w[1]) starts as the pass labels and is relaxed in place; pass 2 starts from a copy of pass 1's result (w[2])
     HIPC(ctx, hipMemcpyAsync(w[1], w[0], (size_t)n * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
     const dim3 g(tiles_x, (tiles_y + kRefWaves - 1) / kRefWaves), b(64 * kRefWaves);
+    const int n_lds = nslots <= 2048 ? nslots : 0;         // plane models staged in LDS when they fit 32 KB
+    const size_t lds_bytes = (size_t)n_lds * sizeof(float4);
     int sweeps = 0;
     for (int pass = 1; pass <= 2; ++pass) {
         const int* W0 = pass == 1 ? w[0] : w[2];
         if (pass == 2) HIPC(ctx, hipMemcpyAsync(w[2], w[1], (size_t)n * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
         bool converged = false;
-        constexpr int kPerCheck = 8;          // relaxation steps per host check (a check costs a stream synchronisation, a step ~10 us)
-        const int max_rounds = (tiles_x + tiles_y + 8) / kPerCheck + 2;    // a tile is final once its predecessor tiles are
+        // A launch relaxes until the growth chains stop moving (its waves poll their rings, k_f360_refine_tile); the host looks at the
+        // "something changed" flag of every second launch (a check costs a stream synchronisation): the run ends with a launch that
+        // changed nothing.
+        constexpr int kPerCheck = 2;
+        static const int kPolls = [] { const char* e = getenv("RGBD360_REFINE_POLLS"); return e ? atoi(e) : 512; }();
+        static const int kQuiet = [] { const char* e = getenv("RGBD360_REFINE_QUIET"); return e ? atoi(e) : 64; }();
+        const int max_rounds = tiles_x + tiles_y + 8;      // a tile is final once its predecessor tiles are: one launch per tile at worst
         for (int round = 0; round < max_rounds && !converged; ++round) {
             volatile int* flags = ctx->f_flags_host;
             for (int k = 0; k < kPerCheck; ++k) flags[k] = 0;
             for (int k = 0; k < kPerCheck; ++k) {
                 if (pass == 1)
-                    hipLaunchKernelGGL((k_f360_refine_tile<1>), g, b, 0, ctx->stream, ctx->f_xyz, W0, w[1], w[1], ctx->f_models, ctx->f_refine_dist, rows, cols,
-                                       tiles_y, tile_free, ctx->f_flags_host + k);
+                    hipLaunchKernelGGL((k_f360_refine_tile<1>), g, b, lds_bytes, ctx->stream, ctx->f_xyz, W0, w[1], ctx->f_models, ctx->f_refine_dist, rows, cols,
+                                       tiles_y, tile_free, ctx->f_flags_host + k, d_activity, kPolls, kQuiet, n_lds);
                 else
-                    hipLaunchKernelGGL((k_f360_refine_tile<2>), g, b, 0, ctx->stream, ctx->f_xyz, W0, w[1], w[1], ctx->f_models, ctx->f_refine_dist, rows, cols,
-                                       tiles_y, tile_free, ctx->f_flags_host + k);
+                    hipLaunchKernelGGL((k_f360_refine_tile<2>), g, b, lds_bytes, ctx->stream, ctx->f_xyz, W0, w[1], ctx->f_models, ctx->f_refine_dist, rows, cols,
+                                       tiles_y, tile_free, ctx->f_flags_host + k, d_activity, kPolls, kQuiet, n_lds);
                 ++sweeps;
             }
             HIPC(ctx, hipGetLastError());
             HIPC(ctx, hipStreamSynchronize(ctx->stream));
-            converged = flags[kPerCheck - 1] == 0;      // a step that changes nothing is a fixed point: every later step repeats it
+            converged = flags[kPerCheck - 1] == 0;      // a launch that changes nothing is a fixed point: every later one repeats it
         }
         if (!converged) return fail(ctx, -7, "plane refinement did not converge");
     }
     const int* W0 = w[1];
     HIPC(ctx, hipMemsetAsync(d_changed, 0, sizeof(int), ctx->stream));
     hipLaunchKernelGGL(k_f360_refine_commit, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->f_xyz, ctx->f_label, w[0], W0, ctx->f_root_of_slot, n,
-                       ctx->f_count_of_slot, ctx->f_mom, d_changed);
+                       ctx->f_count_of_slot, ctx->f_mom, kF360MaxSlots, d_changed);
     HIPC(ctx, hipMemcpyAsync(ctx->f_flags_host + kFlags, d_changed, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     hipLaunchKernelGGL(k_f360_mom_reduce, dim3((kF360MaxSlots * 9 + 255) / 256), dim3(256), 0, ctx->stream, ctx->f_mom, ctx->f_nslots, kF360MaxSlots,
                        ctx->f_root_of_slot, ctx->f_count_of_slot, ctx->f_pack_host);
