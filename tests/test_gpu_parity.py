@@ -1151,3 +1151,20 @@ def test_forced_iterations_in_lockstep_equal_single_pair(hip_lib):
         for k in range(5):
             assert np.array_equal(many["poses"][k], one["pose"])
     reg.close()
+
+
+@pytest.mark.parametrize("occlusion", [1, 2])
+def test_eval_occlusion_parity_full_size(hip_lib, oracle_mod, occlusion):
+    """The occlusion-aware pass at 2048x1024, level 0: near the poles a couple of hundred source pixels collapse onto one target
+    pixel -- the case the candidate-run lists of k_occ_build exist for.  Counts and numVisible exact against the sequential oracle
+    at the identity, at the true pose and at a pose that compresses the image."""
+    reg, ora, T = _pair_ctx(hip_lib, oracle_mod, _occluder_pair(synth.make_pair(2048, 1024, seed=77)), n_pyr=4)
+    for pose in (np.eye(4), T, _occ_poses(T)[3]):
+        e = reg.eval(0, pose, 2, occlusion)
+        _, sp, sd, n_p, n_d = ora.error_occ(0, pose, 2, occlusion)
+        H, g, Hd, gd, nvis = ora.hessgrad_occ(0, pose, 2, occlusion)
+        assert list(e["n_split"]) == [n_p, n_d]
+        assert e["n_visible"] == nvis
+        assert abs(e["err2_split"][0] - sp) <= ERR2_RTOL * max(1.0, abs(sp))
+        assert abs(e["err2_split"][1] - sd) <= ERR2_RTOL * max(1.0, abs(sd))
+    reg.close()
