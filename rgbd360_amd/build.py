@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(_HERE, "csrc", "rgbd360_api.hip")
 DEPS = [SRC, os.path.join(_HERE, "csrc", "photo_icp_kernels.h"), os.path.join(_HERE, "csrc", "gn_math.h"),
         os.path.join(_HERE, "csrc", "frame360_kernels.h"), os.path.join(_HERE, "csrc", "occlusion_kernels.h"),
-        os.path.join(_HERE, "csrc", "pinhole_kernels.h"), os.path.join(_HERE, "csrc", "pbmap_register.h"), os.path.join(_HERE, "csrc", "multi_gpu.h"), os.path.join(_HERE, "csrc", "sequence_engine.h"), os.path.join(_HERE, "csrc", "rig_dense.h"),
+        os.path.join(_HERE, "csrc", "pinhole_kernels.h"), os.path.join(_HERE, "csrc", "pbmap_register.h"), os.path.join(_HERE, "csrc", "multi_gpu.h"), os.path.join(_HERE, "csrc", "sequence_engine.h"), os.path.join(_HERE, "csrc", "rig_dense.h"), os.path.join(_HERE, "csrc", "host_wait.h"),
         os.path.join(_HERE, "..", "include", "rgbd360_hip.h"), os.path.join(_HERE, "..", "include", "rgbd360_hip_diag.h")]
 LIB = os.path.join(_HERE, "lib", "librgbd360_hip.so")
 

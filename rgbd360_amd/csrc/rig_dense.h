@@ -176,6 +176,7 @@ struct rgbd360_rig {
     float Rt[r360::kMaxRigSensors][16], Rt_inv[r360::kMaxRigSensors][16];
     SeqEngine* E = nullptr;           // buffers + fused set-up of S "slots" (one per sensor), created at the first frame
     double* h_tot = nullptr;          // pinned, [S][32]
+    hostwait::SpinTag tag;
     bool have_src = false, have_trg = false;
     std::string err;
 };
@@ -299,7 +300,7 @@ int rig_eval(rgbd360_rig* R, int level, const float* T, int method, RigSums* out
 #undef LAUNCHR
     hipLaunchKernelGGL(k_rig_reduce, dim3(R->S), dim3(256), 0, E->stream, E->d_partials, E->partials_stride, L.nblocks, R->h_tot);
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(E->stream);
+    if (e == hipSuccess) e = hostwait::tag_and_wait(R->tag, E->stream);      // (spin on a pinned tag: one round trip per LM evaluation)
     if (e != hipSuccess) return rfail(R, -(int)e - 1000, hipGetErrorString(e));
     RigSums S;
     memset(S.H, 0, sizeof(S.H)); memset(S.g, 0, sizeof(S.g));
@@ -375,7 +376,8 @@ int rgbd360_rig_create(const rgbd360_params* p, int n_sensors, const float* Rt, 
         memcpy(R->Rt[s], Rt + 16 * s, sizeof(float) * 16);
         rigid_inverse(R->Rt[s], R->Rt_inv[s]);
     }
-    if (hipHostMalloc((void**)&R->h_tot, sizeof(double) * kNumPartials * kMaxRigSensors, hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc((void**)&R->h_tot, sizeof(double) * kNumPartials * kMaxRigSensors, hipHostMallocDefault) != hipSuccess ||
+        hostwait::spin_tag_init(&R->tag) != hipSuccess) {
         delete R;
         return -103;
     }
