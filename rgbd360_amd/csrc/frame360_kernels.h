@@ -18,6 +18,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "photo_icp_kernels.h"      // r360::sphere_point for the fused cloud stage of k_f360_edge_bits
+
 namespace f360 {
 
 constexpr int kF360R = 12;          // truncation radius of the distance map (>= smoothing_size + max depth / 10)
@@ -38,8 +40,20 @@ __device__ __forceinline__ bool depth_break(float da, float db, float factor) {
 // into LDS (1.26 per pixel instead of 5), the 64 decisions of a wave row leave through one ballot.
 // History at 2048x1024: byte map + per-row distance + chamfer map as three per-pixel kernels 19.5 + 21 + 27 us.
 constexpr int kEdgeTW = 256, kEdgeTH = 8;
+// CLOUD = true (rgbd360_frame_planes): the kernel is also the sphere-cloud stage -- it forms the points of its tile + ring from the
+// depth image and the angle tables (r360::sphere_point, the arithmetic of k_sphere_cloud) instead of loading them, and writes the
+// tile's own points to xyz.  The cloud as a kernel of its own is a 29 MB write-dominated stream with 5 us of fixed cost (13-14 us at
+// 2048 x 1024, whatever the block shape); here its 2-byte loads replace 12-byte ones and its stores ride along.
+struct EdgeCloudSrc {
+    const void* depth;
+    size_t step;
+    int depth_type, convention;
+    const float *sin_theta, *cos_theta, *sin_phi, *cos_phi;
+};
+template <bool CLOUD>
 __global__ __launch_bounds__(kEdgeTW) void k_f360_edge_bits(const float* __restrict__ xyz, int rows, int cols, float factor, int depth_mode,
-                                                           int pitch_words, unsigned long long* __restrict__ bits) {
+                                                           int pitch_words, unsigned long long* __restrict__ bits, EdgeCloudSrc src,
+                                                           float* __restrict__ xyz_out) {
     __shared__ float dep[kEdgeTH + 2][kEdgeTW + 2];
     const int t = threadIdx.x;
     const int c0 = blockIdx.x * kEdgeTW, r0 = blockIdx.y * kEdgeTH;
@@ -47,14 +61,41 @@ __global__ __launch_bounds__(kEdgeTW) void k_f360_edge_bits(const float* __restr
         constexpr int kN = (kEdgeTH + 2) * (kEdgeTW + 2), kTrips = (kN + kEdgeTW - 1) / kEdgeTW;
         float px[kTrips], py[kTrips], pz[kTrips];
         bool inb[kTrips];
+        if (CLOUD) {
+            float d[kTrips], st[kTrips], ct[kTrips], sp[kTrips], cp[kTrips];
 #pragma unroll
-        for (int k = 0; k < kTrips; ++k) {
-            const int e = t + k * kEdgeTW;
-            const int ey = e / (kEdgeTW + 2), ex = e - ey * (kEdgeTW + 2);
-            const int r = r0 - 1 + ey, c = c0 - 1 + ex;
-            inb[k] = e < kN && r >= 0 && r < rows && c >= 0 && c < cols;
-            const float* p = xyz + 3 * (inb[k] ? (size_t)r * cols + c : (size_t)0);
-            px[k] = p[0]; py[k] = p[1]; pz[k] = p[2];
+            for (int k = 0; k < kTrips; ++k) {
+                const int e = t + k * kEdgeTW;
+                const int ey = e / (kEdgeTW + 2), ex = e - ey * (kEdgeTW + 2);
+                const int r = r0 - 1 + ey, c = c0 - 1 + ex;
+                inb[k] = e < kN && r >= 0 && r < rows && c >= 0 && c < cols;
+                const int rr = inb[k] ? r : 0, cc = inb[k] ? c : 0;
+                const unsigned char* row = (const unsigned char*)src.depth + (size_t)rr * src.step;
+                d[k] = src.depth_type == 0 ? 0.001f * (float)((const unsigned short*)row)[cc] : ((const float*)row)[cc];
+                st[k] = src.sin_theta[cc]; ct[k] = src.cos_theta[cc];
+                sp[k] = src.sin_phi[rr]; cp[k] = src.cos_phi[rr];
+            }
+#pragma unroll
+            for (int k = 0; k < kTrips; ++k) {
+                r360::sphere_point(src.convention, d[k], sp[k], cp[k], st[k], ct[k], px[k], py[k], pz[k]);
+                const int e = t + k * kEdgeTW;
+                const int ey = e / (kEdgeTW + 2), ex = e - ey * (kEdgeTW + 2);
+                // the tile's own pixels (not the ring) leave as the cloud
+                if (inb[k] && ey >= 1 && ey <= kEdgeTH && ex >= 1 && ex <= kEdgeTW) {
+                    float* o = xyz_out + 3 * ((size_t)(r0 - 1 + ey) * cols + (c0 - 1 + ex));
+                    o[0] = px[k]; o[1] = py[k]; o[2] = pz[k];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < kTrips; ++k) {
+                const int e = t + k * kEdgeTW;
+                const int ey = e / (kEdgeTW + 2), ex = e - ey * (kEdgeTW + 2);
+                const int r = r0 - 1 + ey, c = c0 - 1 + ex;
+                inb[k] = e < kN && r >= 0 && r < rows && c >= 0 && c < cols;
+                const float* p = xyz + 3 * (inb[k] ? (size_t)r * cols + c : (size_t)0);
+                px[k] = p[0]; py[k] = p[1]; pz[k] = p[2];
+            }
         }
         float* flat = &dep[0][0];
 #pragma unroll

@@ -73,6 +73,7 @@ struct rgbd360_ctx {
     size_t f360_n = 0;
     float *f_xyz = nullptr, *f_normals = nullptr, *f_dist = nullptr;
     uint8_t *f_change = nullptr, *f_hd = nullptr;
+    f360::EdgeCloudSrc f_cloud_pending = {nullptr, 0, 0, 0, nullptr, nullptr, nullptr, nullptr};      // a sphere cloud the depth-edge kernel is to form (frame_planes)
     int *f_label = nullptr, *f_slot_of_root = nullptr, *f_root_of_slot = nullptr, *f_nslots = nullptr, *f_window = nullptr;
     unsigned long long *f_count = nullptr, *f_mom = nullptr;
     int* f_count_of_slot = nullptr;
@@ -1483,8 +1484,15 @@ static void launch_distance_map(rgbd360_ctx* ctx, int rows, int cols, float max_
     using namespace f360;
     const int pitch = (cols + 63) / 64;
     unsigned long long* bits = reinterpret_cast<unsigned long long*>(ctx->f_hd);
-    hipLaunchKernelGGL(k_f360_edge_bits, dim3((cols + kEdgeTW - 1) / kEdgeTW, (rows + kEdgeTH - 1) / kEdgeTH), dim3(kEdgeTW), 0, ctx->stream,
-                       ctx->f_xyz, rows, cols, max_depth_change_factor, depth_mode, pitch, bits);
+    const dim3 ge((cols + kEdgeTW - 1) / kEdgeTW, (rows + kEdgeTH - 1) / kEdgeTH);
+    if (ctx->f_cloud_pending.depth) {       // rgbd360_frame_planes: the cloud has not been formed yet -- this kernel does it on the way
+        hipLaunchKernelGGL((k_f360_edge_bits<true>), ge, dim3(kEdgeTW), 0, ctx->stream, ctx->f_xyz, rows, cols, max_depth_change_factor, depth_mode,
+                           pitch, bits, ctx->f_cloud_pending, ctx->f_xyz);
+        ctx->f_cloud_pending.depth = nullptr;
+    } else {
+        hipLaunchKernelGGL((k_f360_edge_bits<false>), ge, dim3(kEdgeTW), 0, ctx->stream, ctx->f_xyz, rows, cols, max_depth_change_factor, depth_mode,
+                           pitch, bits, ctx->f_cloud_pending, ctx->f_xyz);
+    }
     hipLaunchKernelGGL(k_f360_distmap, dim3(pitch, (rows + kDistTH - 1) / kDistTH), dim3(kDistThreads), 0, ctx->stream, bits, rows, cols,
                        pitch, ctx->f_dist);
 }
@@ -1835,8 +1843,10 @@ int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float
 }
 // organised cloud of one spherical depth image -> ctx->f_xyz (device); the per-row/column sin/cos tables follow the
 // reference's float expressions and are computed on the host (rows + cols values)
+// defer_to_edge_kernel: tables and depth are put in place, the points themselves are left to k_f360_edge_bits<true> (the next stage
+// of rgbd360_frame_planes), which forms them anyway
 int sphere_cloud_dev(rgbd360_ctx* ctx, const void* depth, size_t depth_step, int depth_type, int rows, int cols, int convention,
-                     bool depth_on_device = false) {
+                     bool depth_on_device = false, bool defer_to_edge_kernel = false) {
     if (convention < 0 || convention > 2 || (depth_type != 0 && depth_type != 1)) return fail(ctx, -1, "bad arguments");
     const bool tables_resident = ctx->f_tab && ctx->f_tab_rows == rows && ctx->f_tab_cols == cols && ctx->f_tab_conv == convention;
     std::vector<float> st(cols), ct(cols), sp(rows), cp(rows);
@@ -1912,6 +1922,12 @@ int sphere_cloud_dev(rgbd360_ctx* ctx, const void* depth, size_t depth_step, int
         d_step = (size_t)cols * dpx;
     }
     float* d_tab = ctx->f_tab;
+    ctx->f_cloud_pending.depth = nullptr;
+    if (defer_to_edge_kernel) {
+        ctx->f_cloud_pending = {d_depth, d_step, depth_type, convention, d_tab, d_tab + cols, d_tab + 2 * cols, d_tab + 2 * cols + rows};
+        if (!depth_on_device) HIPC(ctx, hipStreamSynchronize(ctx->stream));      // the caller may reuse its host image
+        return 0;
+    }
     static const bool cloud_x4 = [] { const char* e = getenv("RGBD360_CLOUD_X4"); return e && atoi(e) != 0; }();      // A/B: the round-1 kernel
     if (cloud_x4 && cols % 4 == 0 && d_step % 16 == 0 && ((size_t)d_depth & 15) == 0) {
         hipLaunchKernelGGL(k_sphere_cloud_x4, grid2d(rows, cols / 4), dim3(256), 0, ctx->stream, d_depth, d_step, depth_type, rows, cols,
@@ -2036,11 +2052,15 @@ static int frame_planes_impl(rgbd360_ctx* ctx, const void* depth, size_t depth_s
     int rc = f360_ensure(ctx, n);
     if (rc) return rc;
     // the cloud stays on the device; a host copy is only made when asked for
-    rc = sphere_cloud_dev(ctx, depth, depth_step, depth_type, rows, cols, convention, depth_on_device);
+    static const bool fuse_cloud = [] { const char* e = getenv("RGBD360_FUSE_CLOUD"); return !e || atoi(e) != 0; }();      // A/B knob
+    rc = sphere_cloud_dev(ctx, depth, depth_step, depth_type, rows, cols, convention, depth_on_device, /*defer_to_edge_kernel=*/fuse_cloud);
     if (rc) return rc;
-    if (xyz_out) HIPC(ctx, hipMemcpyAsync(xyz_out, ctx->f_xyz, n * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     rc = f360_normals_dev(ctx, rows, cols, max_depth_change_factor, normal_smoothing_size, depth_mode);
-    if (rc) return rc;
+    if (rc) {
+        ctx->f_cloud_pending.depth = nullptr;
+        return rc;
+    }
+    if (xyz_out) HIPC(ctx, hipMemcpyAsync(xyz_out, ctx->f_xyz, n * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     rc = f360_planes_dev(ctx, rows, cols, min_inliers, angular_threshold, distance_threshold, max_curvature, depth_mode, planes_out,
                          max_planes, n_planes_out);
     if (rc) return rc;
