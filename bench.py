@@ -37,6 +37,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  Next to PyTorch's and RCCL's own
+# streams that leaves the library's two sequence engines and their copy streams sharing queues (the `sequence` block: 8.5 k
+# alignments/s instead of the 9.9 k of a process that only hosts the library).  Read at runtime initialisation:
+# it has to be in the environment before the first HIP call.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0          # measured float4 copy (same guide)
@@ -200,6 +205,7 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
+        "env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
         "config": {
             "workload": ("configs[1]: single %dx%d synthetic sphere pair per GPU, %s RegisterPhotoICP, level-0 forced "
                          "Gauss-Newton iterations (1 fused pass + 1 solve launch each)" % (W, H, METHOD_NAMES[method])),
