@@ -50,7 +50,7 @@ BYTES_PER_PX = {0: 28, 1: 28, 2: 40}   # LUT variant: 16 B source record + 12 B 
 WORKING_SET_PER_PX = {0: 28, 1: 28, 2: 40}
 METHOD_NAMES = {0: "PHOTO_CONSISTENCY", 1: "DEPTH_CONSISTENCY", 2: "PHOTO_DEPTH"}
 SEQ_UNIQUE_FRAMES = 9          # frames rendered per rank for the sequence block (walked back and forth)
-SEQ_INFLIGHT = 16              # pairs in flight per GPU: slots of the lock-step sequence engine (2 engines x 8)
+SEQ_INFLIGHT = 32              # pairs in flight per GPU: slots of the lock-step sequence engine (2 engines x 16)
 
 
 def avg_kernel_us(fn, batches=5):

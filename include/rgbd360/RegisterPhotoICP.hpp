@@ -136,7 +136,7 @@ class RegisterPhotoICP {
     // frames must share one size and depth type, and stay untouched until the call returns.  Returns the relative poses;
     // statuses (0 / ILL_POSED / NO_VALID_PIXELS per pair) and full records through the optional outputs.
     std::vector<Mat4f> alignSequence(const std::vector<ImageView>& rgb, const std::vector<ImageView>& depth,
-                                     costFuncType method = PHOTO_DEPTH, int occlusion = 0, int n_inflight = 16,
+                                     costFuncType method = PHOTO_DEPTH, int occlusion = 0, int n_inflight = 32,
                                      const Mat4f& pose_guess = Mat4f::Identity(), std::vector<rgbd360_result>* results = nullptr) {
         if (rgb.size() != depth.size()) throw std::invalid_argument("rgbd360: rgb / depth sequence length mismatch");
         const size_t n_frames = rgb.size();

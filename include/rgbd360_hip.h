@@ -118,7 +118,7 @@ int rgbd360_align360_finish(rgbd360_ctx* ctx, float pose_out[16], rgbd360_result
  * in rgbd360_set_target.  n_inflight (1..64) pairs are in flight: the sequence is cut into that many contiguous spans ("slots")
  * which advance in lock step -- every kernel launch of a round (frame set-up, each pass and solve of each pyramid level)
  * carries a slot dimension, so a round of n_inflight alignments costs the launch count of one (csrc/sequence_engine.h;
- * 16 = two engines of 8 slots is the measured optimum at 2048x1024).  Inside a span every frame is uploaded once,
+ * 32 = two engines of 16 slots is the measured optimum at 2048x1024, ~3.6 GB of HBM; 16 costs 5 %; host frames use at most 16).  Inside a span every frame is uploaded once,
  * one round ahead of its alignment on a copy stream: the host images must stay unchanged until the call returns.  Poses are
  * bit-identical to rgbd360_align360 pair by pair, whatever n_inflight.  The occlusion-aware variants run one context per span
  * instead (n_inflight capped at 16).  guess (NULL = identity) is the initial pose of every pair.  poses_out: (n_frames-1) x 16

@@ -73,7 +73,7 @@ def align_sequence_concurrent(regs, get_frame, lo: int, hi: int, method: int, gu
     return poses, status, iters
 
 
-def align_sequence_native(reg, get_frame, lo: int, hi: int, method: int, guess=None, n_inflight: int = 16, occlusion: int = 0):
+def align_sequence_native(reg, get_frame, lo: int, hi: int, method: int, guess=None, n_inflight: int = 32, occlusion: int = 0):
     """Same result as align_sequence through ONE call of the C ABI (rgbd360_align360_batch): the frames lo..hi of the chunk
     are handed over together, the library walks them with n_inflight pairs in flight (lock-step slots) and no Python between the pairs."""
     n = hi - lo

@@ -449,7 +449,12 @@ __device__ __forceinline__ void consume_stage(PixW& w, const LevelDev& lv, const
 // them in SGPRs at wave start; the structs follow and are fetched while those first loads are in flight.
 // eval_block is the body of one workgroup; k_eval (one pair per launch) and k_eval_b (blockIdx.y = slot of a lock-step batch of
 // pairs, sequence_engine.h) call it with their own base pointers.
-template <int METHOD, bool HG>
+// THREADS = 1024 (one pair per launch: the Infinity-Cache-resident regime, one block per CU) or 512 (the lock-step batch, HBM-fed:
+// two blocks of different pairs share a CU, the tail of one overlaps the body of the other -- 9.3 -> 10.0 k alignments/s on one
+// engine).  A 512-thread block computes EXACTLY what the 1024-thread block does: thread t plays the lanes t and t + 512 of the
+// 1024-lane layout with an accumulator set for each (the ping-pong stages of the loop are those two lanes' pixels), its wave w
+// stands for the waves w and w + 8, and the block sum runs over the same 16 wave rows in the same order -- bit-identical sums.
+template <int METHOD, bool HG, int THREADS = kEvalThreads>
 __device__ __forceinline__ void eval_block(const GNState* __restrict__ st, const float4* __restrict__ src0, const int n_px,
                                            const int chunk, const int level, const int nb_arg, double* __restrict__ partials,
                                            const LevelDev& lv, const EvalConsts& ec) {
@@ -473,7 +478,9 @@ __device__ __forceinline__ void eval_block(const GNState* __restrict__ st, const
     int i = base + (int)threadIdx.x;
     // the first two source records do not depend on the state: issue them before the scalar loads of done / pose
     float4 sA = buf_load_f4(bufs.src, (unsigned)i << 4);
-    float4 sB = buf_load_f4(bufs.src, (unsigned)(i + kEvalThreads) << 4);
+    static_assert(THREADS == 1024 || THREADS == 512, "eval_block: 1024-lane layout, played by 1024 or 512 threads");
+    constexpr int NS = kEvalThreads / THREADS;           // accumulator sets (lanes of the 1024-lane layout per thread)
+    float4 sB = buf_load_f4(bufs.src, (unsigned)(i + THREADS) << 4);
     // gate and pose are fetched in ONE batch of scalar loads, in parallel with the two record loads above.  The gate is
     // only TESTED after the first warp stage: an early-exit branch up here makes the compiler sink every load behind it
     // (one dependent memory round trip per sunk batch, ~1 us each); the asm statement that ends warp_stage cannot be moved
@@ -483,52 +490,59 @@ __device__ __forceinline__ void eval_block(const GNState* __restrict__ st, const
     const WarpConsts wc = make_warp_consts(T, lv);
     ESTAMP(0);
 
-    EvalAcc A;
+    EvalAcc A[NS];
 #pragma unroll
-    for (int k = 0; k < 27; ++k) A.acc[k] = 0.f;
-    A.e2p = A.e2d = 0.f;
-    A.nP = A.nD = A.nVis = 0;
+    for (int q = 0; q < NS; ++q) {
+#pragma unroll
+        for (int k = 0; k < 27; ++k) A[q].acc[k] = 0.f;
+        A[q].e2p = A[q].e2d = 0.f;
+        A[q].nP = A[q].nD = A[q].nVis = 0;
+    }
+    EvalAcc& AA = A[0];            // pixels of the even steps (stage A)
+    EvalAcc& AB = A[NS - 1];       // pixels of the odd steps (stage B): the same set at 1024 threads, lane t + 512's at 512
 
     // Wave-uniform trip count (every lane stays active: the ballots count whole waves); lanes past the end of the
     // span process a clamped record with in_range = false.  The loop is unrolled by two with ping-pong register
     // sets (wA / wB) so that no register copy forces an early wait: while the arithmetic of step k runs, the gathers
     // of step k+1 and the source record of step k+2 are in flight.
-    const int n_steps = (end - base + kEvalThreads - 1) / kEvalThreads;
+    const int n_steps = NS * ((end - base + kEvalThreads - 1) / kEvalThreads);
     PixW wA, wB;
     warp_stage<METHOD>(sA, i < end, T, wc, lv, bufs, wA);
     asm volatile("" ::: "memory");                   // the loads issued so far stay above the gate
     if (gate.x | (gate.y != level)) return;          // speculatively enqueued launch of a finished / later level
     ESTAMP(1);
-    sA = buf_load_f4(bufs.src, (unsigned)(i + 2 * kEvalThreads) << 4);
+    sA = buf_load_f4(bufs.src, (unsigned)(i + 2 * THREADS) << 4);
     int k = 0;
     // steady state: straight-line body (no control-flow joins, so the compiler's waits are counted, not vmcnt(0))
-    for (; k + 2 < n_steps; k += 2, i += 2 * kEvalThreads) {
-        warp_stage<METHOD>(sB, (i + kEvalThreads) < end, T, wc, lv, bufs, wB);
-        sB = buf_load_f4(bufs.src, (unsigned)(i + 3 * kEvalThreads) << 4);
-        consume_stage<METHOD, HG>(wA, lv, ec, A);
-        warp_stage<METHOD>(sA, (i + 2 * kEvalThreads) < end, T, wc, lv, bufs, wA);
-        sA = buf_load_f4(bufs.src, (unsigned)(i + 4 * kEvalThreads) << 4);
-        consume_stage<METHOD, HG>(wB, lv, ec, A);
+    for (; k + 2 < n_steps; k += 2, i += 2 * THREADS) {
+        warp_stage<METHOD>(sB, (i + THREADS) < end, T, wc, lv, bufs, wB);
+        sB = buf_load_f4(bufs.src, (unsigned)(i + 3 * THREADS) << 4);
+        consume_stage<METHOD, HG>(wA, lv, ec, AA);
+        warp_stage<METHOD>(sA, (i + 2 * THREADS) < end, T, wc, lv, bufs, wA);
+        sA = buf_load_f4(bufs.src, (unsigned)(i + 4 * THREADS) << 4);
+        consume_stage<METHOD, HG>(wB, lv, ec, AB);
     }
     // tail: one or two steps left, wA holds step k
     if (k + 1 < n_steps) {
-        warp_stage<METHOD>(sB, (i + kEvalThreads) < end, T, wc, lv, bufs, wB);
-        consume_stage<METHOD, HG>(wA, lv, ec, A);
-        consume_stage<METHOD, HG>(wB, lv, ec, A);
+        warp_stage<METHOD>(sB, (i + THREADS) < end, T, wc, lv, bufs, wB);
+        consume_stage<METHOD, HG>(wA, lv, ec, AA);
+        consume_stage<METHOD, HG>(wB, lv, ec, AB);
     } else {
-        consume_stage<METHOD, HG>(wA, lv, ec, A);
+        consume_stage<METHOD, HG>(wA, lv, ec, AA);
     }
 
     ESTAMP(2);
     // ---- reduction: lanes -> wave (halving butterfly, f32) -> block (f64 via LDS) -> one partial row ----
     __shared__ double red[kEvalThreads / 64][kNumPartials];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+        const int wave = (int)(threadIdx.x >> 6) + q * (THREADS / 64);      // the wave of the 1024-lane layout this set belongs to
         float v[32], out[2];
 #pragma unroll
-        for (int k = 0; k < 27; ++k) v[k] = HG ? A.acc[k] : 0.f;
-        v[P_E2P] = A.e2p;
-        v[P_E2D] = A.e2d;
+        for (int k = 0; k < 27; ++k) v[k] = HG ? A[q].acc[k] : 0.f;
+        v[P_E2P] = A[q].e2p;
+        v[P_E2D] = A[q].e2d;
         v[P_NP] = v[P_ND] = v[P_NVIS] = 0.f;        // the counts are wave-uniform scalars, stored below
         wave_reduce32(v, out);
         if ((lane & 3) == 0) {
@@ -538,9 +552,9 @@ __device__ __forceinline__ void eval_block(const GNState* __restrict__ st, const
             if (idx + 1 < P_NP) red[wave][idx + 1] = (double)out[1];
         }
         if (lane == 63) {
-            red[wave][P_NP] = (double)A.nP;
-            red[wave][P_ND] = (double)A.nD;
-            red[wave][P_NVIS] = (double)A.nVis;
+            red[wave][P_NP] = (double)A[q].nP;
+            red[wave][P_ND] = (double)A[q].nD;
+            red[wave][P_NVIS] = (double)A[q].nVis;
         }
     }
     ESTAMP(3);
@@ -587,15 +601,16 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval(const GNState* __restrict
 // slot's pointers are arithmetic on kernel arguments (SGPRs at wave start through the kernarg preload) -- no descriptor table, no
 // dependent load in front of the first record loads.  Work split, partial rows and summation order per slot are exactly those
 // of k_eval, hence bit-identical sums.
+constexpr int kEvalThreadsBatch = 512;
 template <int METHOD, bool HG>
-__global__ __launch_bounds__(kEvalThreads) void k_eval_b(const GNState* __restrict__ states, const float4* __restrict__ src0, int n_px,
+__global__ __launch_bounds__(kEvalThreadsBatch) void k_eval_b(const GNState* __restrict__ states, const float4* __restrict__ src0, int n_px,
                                                           int chunk, int level, int nb_arg, double* __restrict__ partials,
                                                           int partials_stride, LevelDev lv, EvalConsts ec) {
     const int slot = blockIdx.y;
     lv.trgP += (size_t)slot * (size_t)n_px;
     lv.trgD += (size_t)slot * (size_t)n_px;
-    eval_block<METHOD, HG>(states + slot, src0 + (size_t)slot * (size_t)n_px, n_px, chunk, level, nb_arg,
-                           partials + (size_t)slot * (size_t)partials_stride, lv, ec);
+    eval_block<METHOD, HG, kEvalThreadsBatch>(states + slot, src0 + (size_t)slot * (size_t)n_px, n_px, chunk, level, nb_arg,
+                                              partials + (size_t)slot * (size_t)partials_stride, lv, ec);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -166,7 +166,7 @@ void seq_launch_eval(SeqEngine* E, int level, int method) {
     const SeqLevel& L = E->levels[level];
     const LevelDev lv = seq_level_dev(L, E->tb);
     const EvalConsts ec = eval_consts(E->p);
-    const dim3 g(L.nblocks, E->P), b(kEvalThreads);
+    const dim3 g(L.nblocks, E->P), b(kEvalThreadsBatch);
 #define LAUNCHB(M) hipLaunchKernelGGL((k_eval_b<M, true>), g, b, 0, E->stream, E->d_states, lv.src, lv.n, L.chunk, level, L.nblocks, E->d_partials, E->partials_stride, lv, ec)
     if (method == 0) LAUNCHB(0);
     else if (method == 1) LAUNCHB(1);

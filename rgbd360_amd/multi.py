@@ -86,7 +86,7 @@ class MultiGpuSequence:
             iters[j] = [int(res[j].iters[l]) for l in range(self._p.n_pyr)]
         return poses, status, iters
 
-    def align_sequence(self, frames, method: int = 2, occlusion: int = 0, pose_guess=None, n_inflight: int = 16):
+    def align_sequence(self, frames, method: int = 2, occlusion: int = 0, pose_guess=None, n_inflight: int = 32):
         """Host frames [(rgb, depth), ...] -> (poses [n,4,4], status [n], iters [n, n_pyr]) for the n = len(frames)-1 pairs."""
         n = len(frames) - 1
         if n <= 0:
@@ -109,7 +109,7 @@ class MultiGpuSequence:
                                                         0 if dtype == np.uint16 else 1, shape[0], shape[1]))
         self._n_pairs = len(frames) - 1
 
-    def align_resident(self, method: int = 2, occlusion: int = 0, pose_guess=None, n_inflight: int = 16):
+    def align_resident(self, method: int = 2, occlusion: int = 0, pose_guess=None, n_inflight: int = 32):
         n = self._n_pairs
         if n <= 0:
             raise Rgbd360Error("load_sequence must be called first")

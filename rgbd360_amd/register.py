@@ -234,7 +234,7 @@ class RegisterPhotoICP:
         self._check(self._L.rgbd360_warp_indices_pinhole(self._ctx(), level, _ptr(pose_to_cm(pose)), _ptr(out)))
         return out
 
-    def alignSequence(self, frames, method: int = 0, occlusion: int = 0, pose_guess=None, n_inflight: int = 16):
+    def alignSequence(self, frames, method: int = 0, occlusion: int = 0, pose_guess=None, n_inflight: int = 32):
         """rgbd360_align360_batch: the len(frames)-1 consecutive pairs of a sequence (frame j = target, j+1 = source) on this
         context's GPU, n_inflight pairs in flight (slots of the lock-step sequence engine).  frames: list of (rgb HxWx3 uint8, depth HxW uint16 mm | float32 m).
         Returns (poses [n,4,4] float32, status [n] int32, iters [n, n_pyr] int32)."""
@@ -268,7 +268,7 @@ class RegisterPhotoICP:
         return poses, status, iters
 
     def alignSequenceDev(self, rgb_ptrs, depth_ptrs, rows: int, cols: int, depth_type: int, method: int = 0, occlusion: int = 0,
-                         pose_guess=None, n_inflight: int = 16, rgb_step: int = 0, depth_step: int = 0):
+                         pose_guess=None, n_inflight: int = 32, rgb_step: int = 0, depth_step: int = 0):
         """rgbd360_align360_batch_dev: like alignSequence with every frame already in HBM on this context's device.
         rgb_ptrs / depth_ptrs: raw device pointers (e.g. torch_tensor.data_ptr()), row-major, steps in bytes (0 = packed)."""
         from ._lib import Result

@@ -29,8 +29,8 @@ t_create = time.perf_counter() - t0
 out = {"n_gpus": n_gpus, "pairs_total": n_pairs, "uses_rccl": m.uses_rccl, "create_s": t_create,
        "entry": "rgbd360_multi_load_sequence + rgbd360_multi_align_resident / rgbd360_multi_align_sequence (one process, one host thread per device)"}
 m.load_sequence(frames)
-m.align_resident(method=2, n_inflight=16)                  # warm: engines, buffers, RCCL channels
-for name, fn in (("resident", lambda: m.align_resident(method=2, n_inflight=16)), ("host_frames", lambda: m.align_sequence(frames, method=2, n_inflight=16))):
+m.align_resident(method=2, n_inflight=32)                  # warm: engines, buffers, RCCL channels
+for name, fn in (("resident", lambda: m.align_resident(method=2, n_inflight=32)), ("host_frames", lambda: m.align_sequence(frames, method=2, n_inflight=32))):
     if name == "host_frames":
         fn()
     times = []
