@@ -152,7 +152,9 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_rig(const float4* __restr
 }
 
 // Per-sensor totals of the partial rows, fixed order, written straight into pinned host memory: block s -> out[s][32].
-__global__ __launch_bounds__(256) void k_rig_reduce(const double* __restrict__ partials, int partials_stride, int nb, double* __restrict__ out) {
+// The block that finishes last stores the host's sequence tag (host_wait.h): no tag kernel behind this one.
+__global__ __launch_bounds__(256) void k_rig_reduce(const double* __restrict__ partials, int partials_stride, int nb, double* __restrict__ out,
+                                                    unsigned* __restrict__ ticket, unsigned* __restrict__ tag, unsigned seq) {
     __shared__ double red[8][kNumPartials];
     const int s = blockIdx.x, v = threadIdx.x & 31, q = threadIdx.x >> 5;
     double acc = 0.0;
@@ -164,6 +166,12 @@ __global__ __launch_bounds__(256) void k_rig_reduce(const double* __restrict__ p
 #pragma unroll
         for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x];
         out[(size_t)s * kNumPartials + threadIdx.x] = t;
+    }
+    __threadfence_system();            // this block's totals are on their way to the host before it takes its ticket
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(ticket, 1u) == gridDim.x - 1) {
+        *ticket = 0u;
+        __hip_atomic_store(tag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -177,6 +185,7 @@ struct rgbd360_rig {
     SeqEngine* E = nullptr;           // buffers + fused set-up of S "slots" (one per sensor), created at the first frame
     double* h_tot = nullptr;          // pinned, [S][32]
     hostwait::SpinTag tag;
+    unsigned* d_ticket = nullptr;     // device counter of k_rig_reduce's blocks
     bool have_src = false, have_trg = false;
     std::string err;
 };
@@ -298,9 +307,10 @@ int rig_eval(rgbd360_rig* R, int level, const float* T, int method, RigSums* out
     else if (method == 1) LAUNCHR(1);
     else LAUNCHR(2);
 #undef LAUNCHR
-    hipLaunchKernelGGL(k_rig_reduce, dim3(R->S), dim3(256), 0, E->stream, E->d_partials, E->partials_stride, L.nblocks, R->h_tot);
+    hipLaunchKernelGGL(k_rig_reduce, dim3(R->S), dim3(256), 0, E->stream, E->d_partials, E->partials_stride, L.nblocks, R->h_tot, R->d_ticket,
+                       R->tag.h, ++R->tag.seq);
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hostwait::tag_and_wait(R->tag, E->stream);      // (spin on a pinned tag: one round trip per LM evaluation)
+    if (e == hipSuccess) e = hostwait::wait(R->tag, E->stream);      // (spin on a pinned tag: one round trip per LM evaluation)
     if (e != hipSuccess) return rfail(R, -(int)e - 1000, hipGetErrorString(e));
     RigSums S;
     memset(S.H, 0, sizeof(S.H)); memset(S.g, 0, sizeof(S.g));
@@ -355,6 +365,8 @@ void rgbd360_rig_destroy(rgbd360_rig* R) {
     hipSetDevice(R->p.device);
     seq_free(R->E);
     if (R->h_tot) hipHostFree(R->h_tot);
+    hostwait::spin_tag_free(&R->tag);
+    if (R->d_ticket) hipFree(R->d_ticket);
     delete R;
 }
 
@@ -377,7 +389,11 @@ int rgbd360_rig_create(const rgbd360_params* p, int n_sensors, const float* Rt, 
         rigid_inverse(R->Rt[s], R->Rt_inv[s]);
     }
     if (hipHostMalloc((void**)&R->h_tot, sizeof(double) * kNumPartials * kMaxRigSensors, hipHostMallocDefault) != hipSuccess ||
-        hostwait::spin_tag_init(&R->tag) != hipSuccess) {
+        hostwait::spin_tag_init(&R->tag) != hipSuccess || hipMalloc(&R->d_ticket, sizeof(unsigned)) != hipSuccess ||
+        hipMemset(R->d_ticket, 0, sizeof(unsigned)) != hipSuccess) {
+        if (R->h_tot) hipHostFree(R->h_tot);
+        hostwait::spin_tag_free(&R->tag);
+        if (R->d_ticket) hipFree(R->d_ticket);
         delete R;
         return -103;
     }
