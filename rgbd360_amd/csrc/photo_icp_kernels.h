@@ -76,6 +76,11 @@ struct SolveCfg {
     int    n_pixels;
     int    occ;           // 0: error = sqrt(sum / n) (RPI.h:2738); 1/2: avPhotoResidual + avDepthResidual (RPI.h:3358-3366, 3848-3855)
     double tol_residual, tol_update;
+    // when set, the state is also written into this pinned host buffer and host_seq is stored into *host_tag behind it (system
+    // scope): the latency-bound callers read their result without a copy launch and without hipStreamSynchronize (host_wait.h)
+    GNState* host_state = nullptr;
+    unsigned* host_tag = nullptr;
+    unsigned host_seq = 0;
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1072,6 +1077,12 @@ __device__ __forceinline__ void solve_block(GNState* st_g, const double* __restr
     __syncthreads();
 #endif
     if (tid < kStateWords) reinterpret_cast<int*>(st_g)[tid] = reinterpret_cast<const int*>(&sst)[tid];
+    if (cfg.host_state) {                                   // uniform
+        if (tid < kStateWords) reinterpret_cast<int*>(cfg.host_state)[tid] = reinterpret_cast<const int*>(&sst)[tid];
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(cfg.host_tag, cfg.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 #undef STAMP
 }
 __global__ __launch_bounds__(kSolveThreads) void k_solve(GNState* st_g, const double* __restrict__ partials, int nb,

@@ -53,13 +53,14 @@ __device__ __forceinline__ unsigned warp_pinhole(const PoseRT& T, float px, floa
 }
 
 template <int METHOD>
-__global__ __launch_bounds__(kEvalThreads) void k_eval_pinhole(LevelDev lv, PinK K, EvalConsts ec, const GNState* __restrict__ st,
+// The pose of the pass arrives as a kernel argument: the Levenberg-Marquardt loop lives on the host and evaluates one pose per
+// round trip, so there is no device state to gate on and no initialisation launch in front of the pass.
+__global__ __launch_bounds__(kEvalThreads) void k_eval_pinhole(LevelDev lv, PinK K, EvalConsts ec, Pose16 pose,
                                                                 double* __restrict__ partials, int chunk, int level) {
     const int b = blockIdx.x;
     const int base = b * chunk;
     const int end = min(base + chunk, lv.n);
-    if (st->done || st->level_active != level) return;
-    const PoseRT T = load_pose(st->cand);
+    const PoseRT T = load_pose(pose.v);
 
     EvalAcc A;
 #pragma unroll
