@@ -1,6 +1,6 @@
 """BASELINE.json configs[0] (plumbing, CPU only): the reference's own sample frames through the restated .bin reader,
 the restated spherical stitcher and the CPU oracle.  Runs only where /root/reference is mounted (the build container);
-the GPU box never sees the reference.  Expected values: tests/golden/config1_samples.json (tools/config1_samples.py --write)."""
+the GPU box never sees the reference.  Expected values: tests/golden/config1_samples.json (tests/tools/config1_samples.py --write)."""
 import json
 import os
 import sys
@@ -14,7 +14,7 @@ SAMPLES = "/root/reference/samples/sphere_images_1.bin"
 
 @pytest.mark.skipif(not os.path.exists(SAMPLES), reason="reference samples are only present in the build container")
 def test_sample_pair_stitches_and_aligns_like_the_committed_record():
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
     import config1_samples as c1
     from rgbd360_amd import synth
     gold = json.load(open(os.path.join(ROOT, "tests", "golden", "config1_samples.json")))
@@ -47,8 +47,8 @@ def test_sample_pair_plane_registration_reports_an_unobservable_translation():
     -- the reference segments per sensor, on clouds down-sampled by 2 and smoothed by pcl::FastBilateralFilter (Frame360.h:40-41,
     479-499; third-party, not built) -- only the floor and the ceiling of the raw sensor data survive the segmentation: the matcher pairs a dozen of their pieces, every matched normal is
     (anti)parallel to the up axis, and the pose fit correctly reports that the translation is not observable (status 2) instead
-    of inventing one -- the dense alignment then has to start from the identity, as tools/config1_samples.py does."""
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    of inventing one -- the dense alignment then has to start from the identity, as tests/tools/config1_samples.py does."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
     import config1_samples as c1
     from oracle import oracle as O
     from rgbd360_amd import pbmap
@@ -100,7 +100,7 @@ def test_sample_pair_per_sensor_planes_with_the_bilateral_filter():
     floor and ceiling do, see the test above); the matcher pairs floor, ceiling and the pieces of one wall direction of frames
     1 and 10, and the fit reports that the translation along that wall is not observable (two independent normal directions
     only: conditioning > 100, status 2), as ConsistencyTest's conditioning test would."""
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
     import config1_samples as c1
     from oracle import oracle as O
     from rgbd360_amd import pbmap

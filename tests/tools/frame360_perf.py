@@ -1,6 +1,6 @@
 """Timing + parity of the Frame360 stages at full size: python tools/frame360_perf.py [W]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from rgbd360_amd import synth
 from rgbd360_amd.register import RegisterPhotoICP, Frame360Stages

@@ -3,7 +3,7 @@
        -shared -o /tmp/liboracle_asan.so oracle/photo_icp_ref.cpp oracle/frame360_ref.cpp
    ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD=$(gcc -print-file-name=libasan.so) python tools/oracle_sanitize.py"""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import oracle as O
 O._LIB_PATH = "/tmp/liboracle_asan.so"

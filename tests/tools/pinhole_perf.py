@@ -1,6 +1,6 @@
 """Timing of the pinhole single-sensor alignment (320x240 and 640x480): python tools/pinhole_perf.py"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from rgbd360_amd import synth
 from rgbd360_amd.register import RegisterPhotoICP
