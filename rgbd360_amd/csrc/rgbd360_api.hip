@@ -69,6 +69,8 @@ struct rgbd360_ctx {
     int poll_chunk = 3;           // {pass, solve} pairs per level enqueued ahead of the device
     int first_chunk_top = 8;      // ... and for the first visit of the coarsest level (cheap passes, most iterations)
     int chunk_level0 = 3;         // ... and for the finest level (most expensive passes; a second chunk costs a host round trip)
+    bool adaptive_chunks = true;  // RGBD360_ADAPTIVE_CHUNKS=0: fixed chunks only (A/B)
+    int hist_iters[8] = {-1, -1, -1, -1, -1, -1, -1, -1};      // accepted iterations per level of the previous alignment: sizes the first chunks of the next
     // Frame360 stage scratch (normals / plane segmentation), grown on demand
     size_t f360_n = 0;
     float *f_xyz = nullptr, *f_normals = nullptr, *f_dist = nullptr;
@@ -506,6 +508,9 @@ int rgbd360_create(const rgbd360_params* p, rgbd360_ctx** out) {
         const int v = atoi(e);
         if (v >= 1 && v <= 16) ctx->chunk_level0 = v;
     }
+    if (const char* e = getenv("RGBD360_ADAPTIVE_CHUNKS")) {
+        ctx->adaptive_chunks = atoi(e) != 0;
+    }
     bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreate(&ctx->ev0) == hipSuccess && hipEventCreate(&ctx->ev1) == hipSuccess &&
               hipMalloc(&ctx->d_state, sizeof(GNState)) == hipSuccess &&
@@ -607,7 +612,12 @@ static void enqueue_schedule(rgbd360_ctx* ctx, int pending, bool pending_started
     for (int level = pending; level >= 0; --level) {
         if (level == top && !pending_started)        // the finer levels are entered by k_solve itself when a level finishes
             launch_level_init(ctx, level, ctx->al_guess, 1);
-        const int n_pairs = (level == top && !pending_started) ? ctx->first_chunk_top : (level == 0 ? ctx->chunk_level0 : ctx->poll_chunk);
+        int n_pairs = (level == top && !pending_started) ? ctx->first_chunk_top : (level == 0 ? ctx->chunk_level0 : ctx->poll_chunk);
+        // Consecutive alignments of a sequence take much the same number of iterations per level: the first visit of a level is
+        // given what the previous alignment needed there (its accepted iterations + the pass that ends the level + one spare)
+        // instead of the fixed chunk -- fewer no-op launches on the coarse levels (~3 us each), no second round trip on level 0.
+        if (ctx->adaptive_chunks && !(level == pending && pending_started) && ctx->hist_iters[level & 7] >= 0)
+            n_pairs = std::min(std::max(ctx->hist_iters[level & 7] + 2, 2), 12);
         for (int k = 0; k < n_pairs; ++k) {
             launch_eval(ctx, level, ctx->al_method, true, ctx->al_occ);
             launch_solve(ctx, level, 0, 0, ctx->al_occ);
@@ -654,6 +664,7 @@ int rgbd360_align360_finish(rgbd360_ctx* ctx, float pose_out[16], rgbd360_result
     }
     rgbd360_result R;
     result_from_state(*ctx->h_state, ctx->p.n_pyr, ctx->al_occ, pose_out, &R);
+    for (int l = 0; l < 8; ++l) ctx->hist_iters[l] = (R.status == 0 && l < ctx->p.n_pyr) ? ctx->h_state->iters[l] : -1;
     if (res) *res = R;
     return R.status;
 }
