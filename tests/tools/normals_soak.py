@@ -1,0 +1,38 @@
+"""Soak check of the normal map (register sweep + list of reworked tiles) against the CPU checker: random sizes, smoothing sizes
+(= sweep window 3..10), depth modes, scenes with depth steps, holes and far points.  NaN pattern identical, values identical up to the
+rare 1-ulp flip the tiled kernel's test allows.  python tests/tools/normals_soak.py [n_trials]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+from rgbd360_amd import synth
+from rgbd360_amd.register import RegisterPhotoICP, Frame360Stages
+from oracle import oracle as O
+O.set_num_threads(min(16, os.cpu_count() or 1))
+n_trials = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+rng = np.random.default_rng(7)
+st = Frame360Stages(RegisterPhotoICP())
+bad = 0
+for t in range(n_trials):
+    W = int(rng.integers(70, 900)); H = int(rng.integers(40, 420))
+    (rgb, d), _, _ = synth.make_pair(1024, 512, seed=int(rng.integers(0, 99)))
+    d = d[:H, :W].astype(np.float32)
+    for _ in range(int(rng.integers(0, 6))):       # boxes nearer / farther, holes
+        r0, c0 = int(rng.integers(0, H - 8)), int(rng.integers(0, W - 8))
+        hh, ww = int(rng.integers(4, H // 2)), int(rng.integers(4, W // 2))
+        d[r0:r0 + hh, c0:c0 + ww] *= float(rng.choice([0.0, 0.6, 0.8, 1.5, 3.0]))
+    d = np.clip(d, 0, 65535).astype(np.uint16)
+    smoothing = float(rng.choice([3.0, 4.5, 5.0, 6.0, 7.2, 8.0, 9.0]))
+    depth_mode = int(rng.integers(0, 2))
+    xyz = O.sphere_cloud(d, 2).reshape(-1, 3)
+    nrm = st.normals(xyz, H, W, 0.05, smoothing, depth_mode)
+    ref, win = O.f360_normals(xyz, H, W, 0.05, smoothing, depth_mode)
+    nan_same = np.array_equal(np.isnan(nrm[:, 0]), np.isnan(ref[:, 0]))
+    ok = ~np.isnan(ref[:, 0])
+    md = float(np.abs(nrm[ok] - ref[ok]).max()) if ok.any() else 0.0
+    eq = float((nrm[ok] == ref[ok]).mean()) if ok.any() else 1.0
+    good = nan_same and md <= 1.2e-7 and eq > 0.9999
+    bad += 0 if good else 1
+    print("trial %2d: %3dx%-3d smoothing %.1f depth_mode %d: normals at %.0f %% of the pixels, NaN pattern %s, max diff %.1e, equal %.5f -> %s" % (
+        t, W, H, smoothing, depth_mode, 100 * ok.mean(), "same" if nan_same else "DIFFERENT", md, eq, "ok" if good else "FAIL"), flush=True)
+print("normals soak: %d / %d trials ok" % (n_trials - bad, n_trials))
+sys.exit(1 if bad else 0)
