@@ -285,10 +285,10 @@ def main():
             "achieved": BYTES_PER_PX[method] * n_px / it_s / 1e9, "unit": "GB/s",
             "frac": BYTES_PER_PX[method] * n_px / it_s / 1e9 / HBM_PEAK_GBS,
             "note": "value's own step: one k_eval pass + one k_solve launch + launch gaps (+ the K-step call's fixed cost / K)"}
-        # the same forced schedule in the sequence engine's regime: 8 pairs iterate in lock step, one {pass, solve} launch pair
-        # serving all of them (their records are separate allocations: 8 working sets, past the Infinity Cache)
+        # the same forced schedule in the sequence engine's regime: 16 pairs iterate in lock step, one {pass, solve} launch pair
+        # serving all of them (their records are separate allocations: 16 working sets, past the Infinity Cache)
         if not args.no_sequence:
-            P = 8
+            P = 16
             best = None
             for _ in range(5):
                 fb = reg.forced_iters_batch(P, (rgbA, dA), (rgbB, dB), 0, start_pose, method, args.steps)
@@ -301,8 +301,23 @@ def main():
                 "frac": BYTES_PER_PX[method] * n_px / t_it / 1e9 / HBM_PEAK_GBS,
                 "resident": "hbm" if P * ws >= LLC_BYTES else "infinity_cache",
                 "poses_bit_identical_to_single_pair": same,
-                "note": "rgbd360_forced_iters_batch: the step of `value` with 8 pairs per launch (k_eval_b / k_solve_b), HIP events, "
+                # the batch pass alone (k_eval_b, all P slots per launch): HIP events over ten back-to-back launches
+                "pass": {"kernel": "k_eval_b<%d,true>" % method, "pairs_per_launch": P, "avg_launch_us": best["pass_avg_us"],
+                         "algorithmic_bytes_per_launch": P * BYTES_PER_PX[method] * n_px,
+                         "achieved": P * BYTES_PER_PX[method] * n_px / (best["pass_avg_us"] * 1e-6) / 1e9, "unit": "GB/s",
+                         "frac": P * BYTES_PER_PX[method] * n_px / (best["pass_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                         "resident": "hbm" if P * ws >= LLC_BYTES else "infinity_cache"},
+                "pass_photo_depth": None,
+                "note": "rgbd360_forced_iters_batch: the step of `value` with 16 pairs per launch (k_eval_b / k_solve_b), HIP events, "
                         "best of 5; not `value` (configs[1] is a single pair)"}
+        if not args.no_sequence and method != 2:
+            # the same batch pass in the mode of configs[3] (photo + depth, 40 B/px): what the sequence engine's level-0 launches do
+            fb2 = min((reg.forced_iters_batch(P, (rgbA, dA), (rgbB, dB), 0, start_pose, 2, 4) for _ in range(3)), key=lambda r: r["pass_avg_us"])
+            by2 = P * BYTES_PER_PX[2] * n_px
+            result["iteration_lockstep"]["pass_photo_depth"] = {
+                "kernel": "k_eval_b<2,true>", "pairs_per_launch": P, "avg_launch_us": fb2["pass_avg_us"], "algorithmic_bytes_per_launch": by2,
+                "achieved": by2 / (fb2["pass_avg_us"] * 1e-6) / 1e9, "unit": "GB/s", "frac": by2 / (fb2["pass_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                "resident": "hbm"}
         srt_a = sorted(t_align)
         result["alignment"] = {"full_pyramid_ms": srt_a[len(srt_a) // 2] * 1e3, "full_pyramid_ms_min": srt_a[0] * 1e3,
                                "iters_per_level": iters_nat, "status": rc,

@@ -23,10 +23,12 @@ int rgbd360_forced_iters(rgbd360_ctx* ctx, int level, const float pose0[16], int
 /* The same forced schedule in the lock-step sequence engine's regime (csrc/sequence_engine.h): n_pairs (<= 32) copies of ONE pair
  * (host images as in rgbd360_set_target / _set_source, both frames with the same strides) iterate side by side, every {pass, solve}
  * launch serving all of them.  *elapsed_ms = HIP event time around the n_iters iterations of all pairs; poses_out (may be NULL):
- * n_pairs x 16 floats, the pose every pair reached (identical for all of them, and identical to rgbd360_forced_iters'). */
+ * n_pairs x 16 floats, the pose every pair reached (identical for all of them, and identical to rgbd360_forced_iters').
+ * pass_avg_us (may be NULL): average duration of ten back-to-back launches of the batch pass alone (all n_pairs slots) afterwards. */
 int rgbd360_forced_iters_batch(rgbd360_ctx* ctx, int n_pairs, const uint8_t* rgb_trg, const void* depth_trg, const uint8_t* rgb_src,
                                const void* depth_src, size_t rgb_step, size_t depth_step, int depth_type, int rows, int cols,
-                               int level, const float pose0[16], int method, int n_iters, float* poses_out, float* elapsed_ms);
+                               int level, const float pose0[16], int method, int n_iters, float* poses_out, float* elapsed_ms,
+                               float* pass_avg_us);
 /* Average duration in microseconds of `reps` back-to-back launches of the fused per-pixel kernel alone
  * (HIP events on the stream the kernel is launched on). want_hg = 0 times the error-only variant. */
 int rgbd360_time_eval_kernel(rgbd360_ctx* ctx, int level, const float pose[16], int method, int want_hg, int reps,

@@ -129,7 +129,7 @@ def load() -> C.CDLL:
                                           C.POINTER(C.c_float)]
     L.rgbd360_planes_available.argtypes = [vp]
     L.rgbd360_forced_iters_batch.argtypes = [vp, i32, vp, vp, vp, vp, C.c_size_t, C.c_size_t, i32, i32, i32, i32, f32p, i32, i32, f32p,
-                                             C.POINTER(C.c_float)]
+                                             C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.rgbd360_set_plane_refinement.argtypes = [vp, i32, C.c_float]
     L.rgbd360_plane_refinement_stats.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     L.rgbd360_rig_create.argtypes = [C.POINTER(Params), i32, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(vp)]

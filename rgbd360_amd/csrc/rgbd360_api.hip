@@ -1081,7 +1081,7 @@ int rgbd360_time_eval_kernel_rotating(rgbd360_ctx* const* ctxs, int n_ctx, int l
 // iteration costs when the solve launch and the launch boundaries are shared by the pairs in flight -- the product's sequence path.
 int rgbd360_forced_iters_batch(rgbd360_ctx* ctx, int n_pairs, const uint8_t* rgb_trg, const void* depth_trg, const uint8_t* rgb_src,
                                const void* depth_src, size_t rgb_step, size_t depth_step, int depth_type, int rows, int cols, int level,
-                               const float pose0[16], int method, int n_iters, float* poses_out, float* elapsed_ms) {
+                               const float pose0[16], int method, int n_iters, float* poses_out, float* elapsed_ms, float* pass_avg_us) {
     if (!ctx) return -1;
     if (!rgb_trg || !depth_trg || !rgb_src || !depth_src || !pose0 || n_iters < 1 || n_pairs < 1 || n_pairs > kMaxSlots)
         return fail(ctx, -1, "bad arguments");
@@ -1134,6 +1134,16 @@ int rgbd360_forced_iters_batch(rgbd360_ctx* ctx, int n_pairs, const uint8_t* rgb
     if (e == hipSuccess) e = hipStreamSynchronize(E->stream);
     float ms = 0.f;
     if (e == hipSuccess) e = hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+    if (e == hipSuccess && pass_avg_us) {      // the batch pass alone: back-to-back launches at the poses the iterations reached
+        constexpr int kReps = 10;
+        e = hipEventRecord(ctx->ev0, E->stream);
+        for (int k = 0; k < kReps; ++k) seq_launch_eval(E, level, method);
+        if (e == hipSuccess) e = hipEventRecord(ctx->ev1, E->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(E->stream);
+        float pms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&pms, ctx->ev0, ctx->ev1);
+        if (e == hipSuccess) *pass_avg_us = pms * 1e3f / kReps;
+    }
     int status = 0;
     if (e == hipSuccess) {
         if (elapsed_ms) *elapsed_ms = ms;

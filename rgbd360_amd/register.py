@@ -387,12 +387,13 @@ class RegisterPhotoICP:
         if dT.dtype not in (np.uint16, np.float32) or dS.dtype != dT.dtype or rgbS.shape != rgbT.shape or dS.shape != dT.shape:
             raise Rgbd360Error("both frames must share size and depth type (uint16 mm or float32 m)")
         out = np.zeros(16 * n_pairs, np.float32)
-        ms = C.c_float()
+        ms, pus = C.c_float(), C.c_float()
         rc = self._L.rgbd360_forced_iters_batch(self._ctx(), int(n_pairs), _ptr(rgbT), _ptr(dT), _ptr(rgbS), _ptr(dS), rgbT.strides[0], dT.strides[0],
                                                 0 if dT.dtype == np.uint16 else 1, dT.shape[0], dT.shape[1], level, _ptr(pose_to_cm(pose0)), method,
-                                                n_iters, _ptr(out), C.byref(ms))
+                                                n_iters, _ptr(out), C.byref(ms), C.byref(pus))
         self._check(rc, allow=(0, 1, 2))
-        return dict(status=rc, poses=np.stack([pose_from_cm(out[16 * k:16 * k + 16]) for k in range(n_pairs)]), elapsed_ms=ms.value)
+        return dict(status=rc, poses=np.stack([pose_from_cm(out[16 * k:16 * k + 16]) for k in range(n_pairs)]), elapsed_ms=ms.value,
+                    pass_avg_us=pus.value)
 
     def time_eval_kernel(self, level: int, pose, method: int, want_hg: bool = True, reps: int = 20) -> float:
         us = C.c_float()
