@@ -38,9 +38,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 # The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  Next to PyTorch's and RCCL's own
-# streams that leaves the library's two sequence engines and their copy streams sharing queues (the `sequence` block: 8.5 k
-# alignments/s instead of the 9.9 k of a process that only hosts the library).  Read at runtime initialisation:
-# it has to be in the environment before the first HIP call.
+# streams that leaves the library's two sequence engines sharing queues (the `sequence` block: 8.5 k alignments/s instead of the
+# 10.9 k of a process that only hosts the library).  Read at runtime initialisation: it has to be in the environment before the
+# first HIP call.  This process never keeps more than four streams busy at once, which is what makes 8 safe here (INTEGRATION.md §3:
+# with more queues than the four the device runs side by side, a fifth busy stream costs a factor of three).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec

@@ -57,7 +57,6 @@ static rgbd360::Mat4f mul(const rgbd360::Mat4f& A, const rgbd360::Mat4f& B) {
 }
 
 int main(int argc, char** argv) {
-    setenv("GPU_MAX_HW_QUEUES", "8", 0);      // before the first HIP call: queues of their own for the sequence engines
     if (argc < 5) {
         fprintf(stderr, "usage: %s <dir> <n_frames> <width> <height> [--sequence | --pbmap]\n", argv[0]);
         return 2;

@@ -121,7 +121,7 @@ int rgbd360_align360_finish(rgbd360_ctx* ctx, float pose_out[16], rgbd360_result
  * 32 = two engines of 16 slots is the measured optimum at 2048x1024, ~3.6 GB of HBM; 16 costs 5 %; host frames use at most 16).  Inside a span every frame is uploaded once,
  * one round ahead of its alignment on a copy stream: the host images must stay unchanged until the call returns.  Poses are
  * bit-identical to rgbd360_align360 pair by pair, whatever n_inflight.  The occlusion-aware variants run one context per span
- * instead (n_inflight capped at 16).  guess (NULL = identity) is the initial pose of every pair.  poses_out: (n_frames-1) x 16
+ * instead (at most six, three when GPU_MAX_HW_QUEUES > 4: the measured optima of that route).  guess (NULL = identity) is the initial pose of every pair.  poses_out: (n_frames-1) x 16
  * floats column-major; results_out (may be NULL): n_frames-1 records whose .status carries the per-pair outcome (0 / ILL_POSED
  * / NO_VALID_PIXELS).  Returns 0, or the first negative error. */
 int rgbd360_align360_batch(rgbd360_ctx* ctx, int n_frames, const uint8_t* const* rgb, size_t rgb_step, const void* const* depth,

@@ -65,9 +65,6 @@ def load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(rgbd360_amd has no CPU fallback)")
-    # streams -> hardware queues: the runtime's default of 4 is too few once the host application has streams of its own
-    # (INTEGRATION.md); only effective when this is the first use of HIP in the process, harmless otherwise
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     L = C.CDLL(LIB_PATH)
     vp, i32, f32p = C.c_void_p, C.c_int, C.c_void_p
     L.rgbd360_default_params.argtypes = [C.POINTER(Params)]

@@ -8,12 +8,22 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <cstdlib>
 
 #include <immintrin.h>
 
 namespace hostwait {
 
 constexpr double kSpinBudgetUs = 2000.0;
+// RGBD360_HOST_SPIN_US=<microseconds> overrides the budget; 0 = never spin (wait in hipStreamSynchronize, as a deployment that
+// cannot spare a busy core per waiting thread would want)
+inline double spin_budget_us() {
+    static const double v = [] {
+        const char* e = getenv("RGBD360_HOST_SPIN_US");
+        return e ? atof(e) : kSpinBudgetUs;
+    }();
+    return v;
+}
 
 struct SpinTag {
     unsigned* h = nullptr;      // pinned, device-visible
@@ -47,13 +57,12 @@ __global__ __launch_bounds__(256) void k_publish(const unsigned* __restrict__ sr
 
 // host side: returns once the tag shows `seq` (spin), or after hipStreamSynchronize when the budget is spent
 inline hipError_t wait(SpinTag& t, hipStream_t stream) {
+    const double budget = spin_budget_us();
     const auto t0 = std::chrono::steady_clock::now();
-    for (int spins = 0;; ++spins) {
+    for (int spins = 0; budget > 0.0; ++spins) {
         if (__atomic_load_n(t.h, __ATOMIC_ACQUIRE) == t.seq) return hipSuccess;
         _mm_pause();
-        if ((spins & 255) == 255 &&
-            std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > kSpinBudgetUs)
-            break;
+        if ((spins & 255) == 255 && std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > budget) break;
     }
     const hipError_t e = hipStreamSynchronize(stream);
     if (e != hipSuccess) return e;

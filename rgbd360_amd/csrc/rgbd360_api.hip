@@ -772,6 +772,22 @@ static int align360_batch_threads(rgbd360_ctx* ctx, int n_frames, const uint8_t*
 
 // The lock-step route (sequence_engine.h): n_inflight = pairs in flight = slots, spread over one or two engines (own stream and host
 // thread each: while one engine waits for its round's states or enqueues, the other's kernels fill the device).
+// Contexts of the per-context route.  The device runs four hardware queues side by side; a fifth busy queue makes the command
+// processor time-slice them, and throughput collapses (64 pairs at 1024 x 512, host frames: 6.8 k alignments/s with 3 contexts,
+// 2.2 k with 4, when GPU_MAX_HW_QUEUES=8 gives every stream a queue of its own).  With the runtime's default of 4 queues the streams
+// share queues instead and 6 contexts are the optimum (7.6 k; 3: 6.5 k; 16: 6.6 k) -- tools/ctx_threads_perf.py.
+// RGBD360_CTX_ROUTE_CAP overrides (measurements).
+static int ctx_route_cap() {
+    static const int v = [] {
+        const char* q = getenv("GPU_MAX_HW_QUEUES");
+        const int dflt = (q && atoi(q) > 4) ? 3 : 6;
+        const char* e = getenv("RGBD360_CTX_ROUTE_CAP");
+        const int c = e ? atoi(e) : dflt;
+        return c >= 1 && c <= 16 ? c : dflt;
+    }();
+    return v;
+}
+
 static int align360_batch_lockstep(rgbd360_ctx* ctx, int n_frames, const uint8_t* const* rgb, size_t rgb_step, const void* const* depth,
                                    size_t depth_step, int depth_type, int rows, int cols, const float* g, int method, int n_inflight,
                                    float* poses_out, rgbd360_result* results_out, bool on_device) {
@@ -855,8 +871,9 @@ static int align360_batch_impl(rgbd360_ctx* ctx, int n_frames, const uint8_t* co
     const char* route = getenv("RGBD360_SEQ_ROUTE");          // "contexts": the per-context route for every sequence (A/B measurements)
     // the occlusion-aware passes have no slot dimension: those sequences run one context per sub-chunk
     if (occlusion != 0 || (route && strcmp(route, "contexts") == 0))
+        // (capped: more busy streams than hardware queues run side by side costs a factor of three, see ctx_route_cap)
         return align360_batch_threads(ctx, n_frames, rgb, rgb_step, depth, depth_step, depth_type, rows, cols, guess, method, occlusion,
-                                      std::min(n_inflight, 16), poses_out, results_out, on_device);
+                                      std::min(n_inflight, ctx_route_cap()), poses_out, results_out, on_device);
     return align360_batch_lockstep(ctx, n_frames, rgb, rgb_step, depth, depth_step, depth_type, rows, cols, guess ? guess : kIdentity, method,
                                    n_inflight, poses_out, results_out, on_device);
 }
