@@ -860,7 +860,15 @@ __device__ __forceinline__ void solve_block(GNState* st_g, const double* __restr
     red[q][v] = s;
     __syncthreads();
     STAMP(0);
-    if (cfg.mode == 0 && (sst.done || sst.level_active != cfg.level)) return;      // uniform: finished / other level
+    if (cfg.mode == 0 && (sst.done || sst.level_active != cfg.level)) {            // uniform: finished / other level
+        if (cfg.host_state) {                               // the schedule's last launch reports even when it has nothing to do
+            if (tid < kStateWords) reinterpret_cast<int*>(cfg.host_state)[tid] = reinterpret_cast<const int*>(&sst)[tid];
+            __threadfence_system();
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(cfg.host_tag, cfg.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
     if (tid < kNumPartials) {
         double t = 0.0;
 #pragma unroll

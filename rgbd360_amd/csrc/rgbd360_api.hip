@@ -607,6 +607,7 @@ int rgbd360_promote_source_to_target(rgbd360_ctx* ctx) {
 // no-op unless that level is the active, unfinished one (k_level_init of level l only fires once level l+1 has
 // finished).  In the common case -- each level converges within its first chunk -- the host synchronises ONCE per
 // alignment; a level that needs more passes gets another chunk, followed again by the finer levels.
+// The last solve launch of the schedule publishes the state to the host (SolveCfg::host_state): no copy launch behind it.
 static void enqueue_schedule(rgbd360_ctx* ctx, int pending, bool pending_started) {
     const int top = ctx->p.n_pyr - 1;
     for (int level = pending; level >= 0; --level) {
@@ -620,7 +621,7 @@ static void enqueue_schedule(rgbd360_ctx* ctx, int pending, bool pending_started
             n_pairs = std::min(std::max(ctx->hist_iters[level & 7] + 2, 2), 12);
         for (int k = 0; k < n_pairs; ++k) {
             launch_eval(ctx, level, ctx->al_method, true, ctx->al_occ);
-            launch_solve(ctx, level, 0, 0, ctx->al_occ);
+            launch_solve(ctx, level, 0, 0, ctx->al_occ, /*publish=*/level == 0 && k == n_pairs - 1);
         }
     }
 }
@@ -636,10 +637,7 @@ int rgbd360_align360_begin(rgbd360_ctx* ctx, const float guess[16], int method, 
     memcpy(ctx->al_guess, guess, sizeof(ctx->al_guess));
     ctx->al_method = method;
     ctx->al_active = true;
-    enqueue_schedule(ctx, ctx->p.n_pyr - 1, false);
-    HIPC(ctx, hipGetLastError());
-    hipLaunchKernelGGL(hostwait::k_publish, dim3(1), dim3(256), 0, ctx->stream, (const unsigned*)ctx->d_state, (unsigned*)ctx->h_state,
-                       (int)(sizeof(GNState) / 4), ctx->tag.h, ++ctx->tag.seq);
+    enqueue_schedule(ctx, ctx->p.n_pyr - 1, false);      // (its last solve publishes the state and bumps the tag)
     HIPC(ctx, hipGetLastError());
     return 0;
 }
@@ -657,9 +655,6 @@ int rgbd360_align360_finish(rgbd360_ctx* ctx, float pose_out[16], rgbd360_result
         if (S.done) return fail(ctx, -6, "alignment schedule stalled between levels");
         if (round > (ctx->p.max_iters + 4) * ctx->p.n_pyr) return fail(ctx, -6, "alignment loop did not terminate");
         enqueue_schedule(ctx, S.level_active, true);         // the stalled level gets another chunk, then the finer ones
-        HIPC(ctx, hipGetLastError());
-        hipLaunchKernelGGL(hostwait::k_publish, dim3(1), dim3(256), 0, ctx->stream, (const unsigned*)ctx->d_state, (unsigned*)ctx->h_state,
-                           (int)(sizeof(GNState) / 4), ctx->tag.h, ++ctx->tag.seq);
         HIPC(ctx, hipGetLastError());
     }
     rgbd360_result R;
@@ -1023,11 +1018,13 @@ int rgbd360_forced_iters(rgbd360_ctx* ctx, int level, const float pose0[16], int
     if (elapsed_ms) HIPC(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     for (int k = 0; k < n_iters; ++k) {
         launch_eval(ctx, level, method, true);
-        launch_solve(ctx, level, 0, 1);
+        launch_solve(ctx, level, 0, 1, 0, /*publish=*/!elapsed_ms && k == n_iters - 1);
     }
     if (elapsed_ms) HIPC(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     HIPC(ctx, hipGetLastError());
-    rc = elapsed_ms ? read_state_sync(ctx) : read_state(ctx);      // events want the synchronise; without them the host spins (host_wait.h)
+    // events want the synchronise; without them the last solve has published the state and the host spins on its tag (host_wait.h)
+    if (elapsed_ms) rc = read_state_sync(ctx);
+    else HIPC(ctx, hostwait::wait(ctx->tag, ctx->stream));
     if (rc) return rc;
     if (elapsed_ms) HIPC(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev0, ctx->ev1));
     if (pose_out) memcpy(pose_out, ctx->h_state->pose, sizeof(float) * 16);
