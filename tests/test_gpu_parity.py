@@ -1168,3 +1168,19 @@ def test_eval_occlusion_parity_full_size(hip_lib, oracle_mod, occlusion):
         assert abs(e["err2_split"][0] - sp) <= ERR2_RTOL * max(1.0, abs(sp))
         assert abs(e["err2_split"][1] - sd) <= ERR2_RTOL * max(1.0, abs(sd))
     reg.close()
+
+
+def test_occlusion_sequence_with_the_default_inflight_equals_pairwise(hip_lib):
+    """Occlusion-aware sequences take the per-context route, whose number of contexts is capped below n_inflight (a fifth busy
+    hardware queue is time-sliced: DESIGN.md 3.3): with the default n_inflight every pair still gets the pose of the pairwise call."""
+    frames = [synth.render(synth.trajectory_pose(k, 11), 256, 128, 11) for k in range(12)]
+    reg = _mk(hip_lib, 3)
+    for occ in (1, 2):
+        p, s, i = reg.alignSequence(frames, method=2, occlusion=occ)
+        one = _mk(hip_lib, 3)
+        for j in range(len(frames) - 1):
+            one.setTargetFrame(*frames[j]); one.setSourceFrame(*frames[j + 1])
+            assert one.alignFrames360(np.eye(4), 2, occ) == s[j]
+            assert np.array_equal(one.getOptimalPose(), p[j]) and list(one.num_iterations) == list(i[j]), (occ, j)
+        one.close()
+    reg.close()
