@@ -15,7 +15,8 @@ extern "C" {
 
 /* Forced schedule for throughput measurement: n_iters Gauss-Newton iterations on `level`
  * starting at pose0, every step applied regardless of the accept rule, no host round trip.  One iteration =
- * one fused pass + one solve launch.  Enqueued on the context's stream; *elapsed_ms (may be NULL) is the HIP
+ * one launch of k_eval_fs (the solve of the previous pass + the fused pass; the last solve in a one-block launch of its own), or one
+ * fused pass + one solve launch under RGBD360_FUSED_SOLVE=0.  Enqueued on the context's stream; *elapsed_ms (may be NULL) is the HIP
  * event time around the n_iters iterations (NULL: no events are recorded and the call waits for its result the way
  * rgbd360_align360 does, csrc/host_wait.h). */
 int rgbd360_forced_iters(rgbd360_ctx* ctx, int level, const float pose0[16], int method, int n_iters,
@@ -29,8 +30,16 @@ int rgbd360_forced_iters_batch(rgbd360_ctx* ctx, int n_pairs, const uint8_t* rgb
                                const void* depth_src, size_t rgb_step, size_t depth_step, int depth_type, int rows, int cols,
                                int level, const float pose0[16], int method, int n_iters, float* poses_out, float* elapsed_ms,
                                float* pass_avg_us);
+/* One solve on a hand-made partial table (row 0 = `row`: 21 upper-triangle terms of H, 6 of g, the two error sums, the three
+ * counts; every other row zero) at the identity pose on `level`, through the two-launch form (fused = 0: k_solve) or the fused form
+ * (fused = 1: the prologue of k_eval_fs; the state is read as that launch leaves it).  Drives the state-machine paths real images hardly ever reach (ILL-POSED).
+ * out_i: {status, done, level_active, it, n_evals, pend_nb}; cand_out / update_out (may be NULL): the state's candidate pose / update. */
+int rgbd360_debug_solve_partials(rgbd360_ctx* ctx, int level, const double row[32], int method, int fused, int out_i[6],
+                                 float cand_out[16], float update_out[6]);
 /* Average duration in microseconds of `reps` back-to-back launches of the fused per-pixel kernel alone
- * (HIP events on the stream the kernel is launched on). want_hg = 0 times the error-only variant. */
+ * (HIP events on the stream the kernel is launched on). want_hg = 0 times the error-only variant, want_hg = 2 the launch of the
+ * single-pair product schedule: k_eval_fs in the forced schedule, i.e. {solve of the previous pass, pass} = one whole Gauss-Newton
+ * iteration per launch. */
 int rgbd360_time_eval_kernel(rgbd360_ctx* ctx, int level, const float pose[16], int method, int want_hg, int reps,
                              float* avg_us);
 

@@ -22,7 +22,7 @@ SYMBOLS = [
     "rgbd360_shard_range", "rgbd360_multi_align_sequence", "rgbd360_multi_load_sequence", "rgbd360_multi_align_resident",
     "rgbd360_align360_batch_multi", "rgbd360_time_eval_kernel_rotating", "rgbd360_forced_iters_batch",
     "rgbd360_rig_create", "rgbd360_rig_destroy", "rgbd360_rig_last_error", "rgbd360_rig_set_target", "rgbd360_rig_set_source",
-    "rgbd360_rig_eval", "rgbd360_rig_align",
+    "rgbd360_rig_eval", "rgbd360_rig_align", "rgbd360_debug_solve_partials",
 ]
 
 
@@ -127,6 +127,7 @@ def load() -> C.CDLL:
     L.rgbd360_planes_available.argtypes = [vp]
     L.rgbd360_forced_iters_batch.argtypes = [vp, i32, vp, vp, vp, vp, C.c_size_t, C.c_size_t, i32, i32, i32, i32, f32p, i32, i32, f32p,
                                              C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.rgbd360_debug_solve_partials.argtypes = [vp, i32, vp, i32, i32, vp, f32p, f32p]
     L.rgbd360_set_plane_refinement.argtypes = [vp, i32, C.c_float]
     L.rgbd360_plane_refinement_stats.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     L.rgbd360_rig_create.argtypes = [C.POINTER(Params), i32, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(vp)]

@@ -16,6 +16,7 @@
 // whose values only need to agree to float32 rounding.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "gn_math.h"
@@ -54,7 +55,9 @@ struct GNState {
     float  cand[16];     // pose the next / last fused pass is evaluated at (first: read by every k_eval block)
     int    done;         // level finished (or status != 0): later launches of this level exit immediately
     int    level_active; // pyramid level being optimised; launches tagged with another level are no-ops
-    int    it, status, first, n_evals, pad1, pad2;
+    int    it, status, first, n_evals;
+    int    pend_nb, pend_npix;   // fused-solve schedule (k_eval_fs): block rows / pixels of a pass at `cand` on level `level_active`
+                                 // whose partial rows have not been reduced yet (0: nothing pending)
     int    iters[8];     // accepted iterations per level (num_iterations, RPI.h:177)
     float  pose[16];     // accepted pose of the current level
     float  H[36], g[6];  // normal equations at `pose`
@@ -459,42 +462,19 @@ __device__ __forceinline__ void consume_stage(PixW& w, const LevelDev& lv, const
 // engine).  A 512-thread block computes EXACTLY what the 1024-thread block does: thread t plays the lanes t and t + 512 of the
 // 1024-lane layout with an accumulator set for each (the ping-pong stages of the loop are those two lanes' pixels), its wave w
 // stands for the waves w and w + 8, and the block sum runs over the same 16 wave rows in the same order -- bit-identical sums.
-template <int METHOD, bool HG, int THREADS = kEvalThreads>
-__device__ __forceinline__ void eval_block(const GNState* __restrict__ st, const float4* __restrict__ src0, const int n_px,
-                                           const int chunk, const int level, const int nb_arg, double* __restrict__ partials,
-                                           const LevelDev& lv, const EvalConsts& ec) {
 #ifdef RGBD360_EVAL_STAMPS
-    const unsigned long long es0 = __builtin_amdgcn_s_memrealtime();
-    unsigned long long es[6] = {0, 0, 0, 0, 0, 0};
 #define ESTAMP(i) es[i] = __builtin_amdgcn_s_memrealtime() - es0
 #else
 #define ESTAMP(i)
 #endif
-    const int nb = nb_arg;
-    const int b = blockIdx.x;
-    const int cb = ((nb & 7) == 0) ? (b & 7) * (nb >> 3) + (b >> 3) : b;
-    const int base = cb * chunk;
-    const int end = min(base + chunk, n_px);
-    EvalBufs bufs;
-    bufs.src = make_rsrc(src0, (unsigned)n_px * 16u);
-    bufs.trgP = make_rsrc(lv.trgP, (unsigned)lv.n * 12u);
-    bufs.trgD = make_rsrc(lv.trgD, (unsigned)lv.n * 12u);
-    bufs.row_bytes = (unsigned)lv.cols * 12u;
-    int i = base + (int)threadIdx.x;
-    // the first two source records do not depend on the state: issue them before the scalar loads of done / pose
-    float4 sA = buf_load_f4(bufs.src, (unsigned)i << 4);
-    static_assert(THREADS == 1024 || THREADS == 512, "eval_block: 1024-lane layout, played by 1024 or 512 threads");
+// Everything behind the gate: the software-pipelined pixel loop and the block reduction.  On entry the first warp stage (wA, the
+// pixel at i) has been issued and sB holds the source record of the pixel at i + THREADS.
+template <int METHOD, bool HG, int THREADS>
+__device__ __forceinline__ void eval_span(const PoseRT& T, const WarpConsts& wc, const LevelDev& lv, const EvalConsts& ec,
+                                          const EvalBufs& bufs, int i, const int base, const int end, const int b, const int nb,
+                                          PixW& wA, float4 sB, double* __restrict__ partials,
+                                          unsigned long long* es, const unsigned long long es0) {
     constexpr int NS = kEvalThreads / THREADS;           // accumulator sets (lanes of the 1024-lane layout per thread)
-    float4 sB = buf_load_f4(bufs.src, (unsigned)(i + THREADS) << 4);
-    // gate and pose are fetched in ONE batch of scalar loads, in parallel with the two record loads above.  The gate is
-    // only TESTED after the first warp stage: an early-exit branch up here makes the compiler sink every load behind it
-    // (one dependent memory round trip per sunk batch, ~1 us each); the asm statement that ends warp_stage cannot be moved
-    // across the branch, so this order survives.  A no-op launch (finished / other level) costs one warp stage.
-    const int2 gate = *reinterpret_cast<const int2*>(&st->done);            // {done, level_active}
-    const PoseRT T = load_pose(st->cand);
-    const WarpConsts wc = make_warp_consts(T, lv);
-    ESTAMP(0);
-
     EvalAcc A[NS];
 #pragma unroll
     for (int q = 0; q < NS; ++q) {
@@ -511,12 +491,8 @@ __device__ __forceinline__ void eval_block(const GNState* __restrict__ st, const
     // sets (wA / wB) so that no register copy forces an early wait: while the arithmetic of step k runs, the gathers
     // of step k+1 and the source record of step k+2 are in flight.
     const int n_steps = NS * ((end - base + kEvalThreads - 1) / kEvalThreads);
-    PixW wA, wB;
-    warp_stage<METHOD>(sA, i < end, T, wc, lv, bufs, wA);
-    asm volatile("" ::: "memory");                   // the loads issued so far stay above the gate
-    if (gate.x | (gate.y != level)) return;          // speculatively enqueued launch of a finished / later level
-    ESTAMP(1);
-    sA = buf_load_f4(bufs.src, (unsigned)(i + 2 * THREADS) << 4);
+    PixW wB;
+    float4 sA = buf_load_f4(bufs.src, (unsigned)(i + 2 * THREADS) << 4);
     int k = 0;
     // steady state: straight-line body (no control-flow joins, so the compiler's waits are counted, not vmcnt(0))
     for (; k + 2 < n_steps; k += 2, i += 2 * THREADS) {
@@ -592,7 +568,47 @@ __device__ __forceinline__ void eval_block(const GNState* __restrict__ st, const
         }
     }
 #endif
-#undef ESTAMP
+}
+
+template <int METHOD, bool HG, int THREADS = kEvalThreads>
+__device__ __forceinline__ void eval_block(const GNState* __restrict__ st, const float4* __restrict__ src0, const int n_px,
+                                           const int chunk, const int level, const int nb_arg, double* __restrict__ partials,
+                                           const LevelDev& lv, const EvalConsts& ec) {
+    unsigned long long es[6] = {0, 0, 0, 0, 0, 0};
+#ifdef RGBD360_EVAL_STAMPS
+    const unsigned long long es0 = __builtin_amdgcn_s_memrealtime();
+#else
+    const unsigned long long es0 = 0;
+#endif
+    const int nb = nb_arg;
+    const int b = blockIdx.x;
+    const int cb = ((nb & 7) == 0) ? (b & 7) * (nb >> 3) + (b >> 3) : b;
+    const int base = cb * chunk;
+    const int end = min(base + chunk, n_px);
+    EvalBufs bufs;
+    bufs.src = make_rsrc(src0, (unsigned)n_px * 16u);
+    bufs.trgP = make_rsrc(lv.trgP, (unsigned)lv.n * 12u);
+    bufs.trgD = make_rsrc(lv.trgD, (unsigned)lv.n * 12u);
+    bufs.row_bytes = (unsigned)lv.cols * 12u;
+    const int i = base + (int)threadIdx.x;
+    // the first two source records do not depend on the state: issue them before the scalar loads of done / pose
+    const float4 sA = buf_load_f4(bufs.src, (unsigned)i << 4);
+    static_assert(THREADS == 1024 || THREADS == 512, "eval_block: 1024-lane layout, played by 1024 or 512 threads");
+    const float4 sB = buf_load_f4(bufs.src, (unsigned)(i + THREADS) << 4);
+    // gate and pose are fetched in ONE batch of scalar loads, in parallel with the two record loads above.  The gate is
+    // only TESTED after the first warp stage: an early-exit branch up here makes the compiler sink every load behind it
+    // (one dependent memory round trip per sunk batch, ~1 us each); the asm statement that ends warp_stage cannot be moved
+    // across the branch, so this order survives.  A no-op launch (finished / other level) costs one warp stage.
+    const int2 gate = *reinterpret_cast<const int2*>(&st->done);            // {done, level_active}
+    const PoseRT T = load_pose(st->cand);
+    const WarpConsts wc = make_warp_consts(T, lv);
+    ESTAMP(0);
+    PixW wA;
+    warp_stage<METHOD>(sA, i < end, T, wc, lv, bufs, wA);
+    asm volatile("" ::: "memory");                   // the loads issued so far stay above the gate
+    if (gate.x | (gate.y != level)) return;          // speculatively enqueued launch of a finished / later level
+    ESTAMP(1);
+    eval_span<METHOD, HG, THREADS>(T, wc, lv, ec, bufs, i, base, end, b, nb, wA, sB, partials, es, es0);
 }
 
 template <int METHOD, bool HG>
@@ -657,6 +673,7 @@ __device__ __forceinline__ void level_init_one(GNState* st, const Pose16& pose, 
         if (st->status != 0 || !st->done || st->level_active != level + 1) return;
     }
     st->level_active = level;
+    st->pend_nb = 0;
     if (use_pose)
         for (int k = 0; k < 16; ++k) st->pose[k] = pose.v[k];
     for (int k = 0; k < 16; ++k) st->cand[k] = st->pose[k];
@@ -825,88 +842,98 @@ __device__ __forceinline__ int qr_rank6_lanes(const float* M /*LDS, column-major
 // the rank test and the 6x6 inverse on two waves side by side.
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kSolveThreads = 1024;
-__device__ __forceinline__ void solve_block(GNState* st_g, const double* __restrict__ partials, const int nb, const SolveCfg& cfg) {
-    // The state is staged through LDS: one coalesced read while the partials are being reduced, one coalesced
-    // write-back at the end; the single-lane bookkeeping below then never waits on global memory.
-    __shared__ GNState sst;
-    __shared__ double red[kSolveThreads / kNumPartials][kNumPartials];
-    __shared__ float shH[36], shM[36], shInv[36], shE[16], shCand[16], shUpd[6];
-    __shared__ int shGo, shRank, shLuOk;
-    constexpr int kStateWords = sizeof(GNState) / 4;
-    static_assert(sizeof(GNState) % 4 == 0 && kStateWords <= kSolveThreads, "GNState staging");
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// LDS of one solve: the staged state, the per-thread-group partial sums and the hand-over slots of the three working waves.
+struct SolveShared {
+    GNState sst;
+    double red[kSolveThreads / kNumPartials][kNumPartials];
+    float shH[36], shM[36], shInv[36], shE[16], shCand[16], shUpd[6];
+    float prevCand[16], prevUpd[6];           // fused launch: what an ILL-POSED verdict restores
+    int shGo, shRank, shLuOk;
+    unsigned long long stamp0, stamp[8];      // diagnostic build only (RGBD360_SOLVE_STAMPS)
+};
 #ifdef RGBD360_SOLVE_STAMPS
-    unsigned long long stamp0 = __builtin_amdgcn_s_memrealtime(), stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define STAMP(i) if (tid == 0) stamp[i] = __builtin_amdgcn_s_memrealtime() - stamp0
+#define SOLVE_STAMP_T(i, t) if (threadIdx.x == (t)) sh.stamp[i] = __builtin_amdgcn_s_memrealtime() - sh.stamp0
 #else
-#define STAMP(i)
+#define SOLVE_STAMP_T(i, t)
 #endif
-    if (tid < kStateWords) reinterpret_cast<int*>(&sst)[tid] = reinterpret_cast<const int*>(st_g)[tid];
-    const int v = tid % kNumPartials, q = tid / kNumPartials;
+#define SOLVE_STAMP(i) SOLVE_STAMP_T(i, 0)
+
+// The serial part of one loop trip of alignFrames360 on a state staged in LDS (sh.sst) whose partial rows have been summed per
+// thread group into sh.red (a barrier behind both), in three steps so that the fused launch (k_eval_fs) can take the rank test
+// off its critical path: solve_totals -> solve_waves -> (barrier) -> solve_finish.  solve_staged strings them together.
+//
+// solve_totals: column sums of sh.red into sst.tot (fixed order); returns the damping the rank test will use, read while nobody
+// writes the staged state (wave 0 updates first / lambda in solve_waves).  A barrier behind it.
+__device__ __forceinline__ float solve_totals(SolveShared& sh) {
     constexpr int Q = kSolveThreads / kNumPartials;
-    // rows q, q+Q, q+2Q, ... of the partial table: all loads of a batch are issued before the first add (one
-    // memory round trip per 16 rows instead of one per row); the summation order stays fixed.
-    double s = 0.0;
-    for (int b0 = q; b0 < nb; b0 += 16 * Q) {
-        double tmp[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int b = b0 + j * Q;
-            tmp[j] = b < nb ? partials[(size_t)b * kNumPartials + v] : 0.0;
-        }
-#pragma unroll
-        for (int j = 0; j < 16; ++j) s += tmp[j];
-    }
-    red[q][v] = s;
-    __syncthreads();
-    STAMP(0);
-    if (cfg.mode == 0 && (sst.done || sst.level_active != cfg.level)) {            // uniform: finished / other level
-        if (cfg.host_state) {                               // the schedule's last launch reports even when it has nothing to do
-            if (tid < kStateWords) reinterpret_cast<int*>(cfg.host_state)[tid] = reinterpret_cast<const int*>(&sst)[tid];
-            __threadfence_system();
-            __syncthreads();
-            if (tid == 0) __hip_atomic_store(cfg.host_tag, cfg.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-        return;
-    }
+    const int tid = threadIdx.x;
     if (tid < kNumPartials) {
         double t = 0.0;
 #pragma unroll
-        for (int k = 0; k < Q; ++k) t += red[k][tid];
-        sst.tot[tid] = t;
+        for (int k = 0; k < Q; ++k) t += sh.red[k][tid];
+        sh.sst.tot[tid] = t;
     }
-    // the damping the rank test will use, read while nobody writes the staged state (wave 0 updates first / lambda below)
-    const float lam_spec = (float)(sst.first ? sst.lambda : sst.lambda / 5.0);
+    const float lam_spec = (float)(sh.sst.first ? sh.sst.lambda : sh.sst.lambda / 5.0);
     __syncthreads();
-    GNState* st = &sst;
-    const double* tot = sst.tot;
+    SOLVE_STAMP_T(1, 0);       // totals summed
+    return lam_spec;
+}
+
+// (H + lambda diag H).rank() on the calling wave (all 64 lanes), RPI.h:4682.  Returns the rank (wave-uniform) and leaves it in sh.shRank
+// for readers behind a barrier.
+__device__ __forceinline__ int solve_rank_wave(SolveShared& sh, const float lam_spec) {
+    const int lane = threadIdx.x & 63;
+    const double* tot = sh.sst.tot;
+    float hval = 0.f;
+    if (lane < 36) {
+        const int r = lane / 6, c = lane - 6 * r;
+        const int aa = r < c ? r : c, bb = r < c ? c : r;
+        hval = (float)tot[P_H + (aa * (13 - aa)) / 2 + (bb - aa)];
+        sh.shM[lane] = (lane % 7 == 0) ? hval + lam_spec * hval : hval;      // H + lambda diag(H)
+    }
+    const int rk = __builtin_amdgcn_readfirstlane(qr_rank6_lanes(sh.shM, lane));
+    if (lane == 0) sh.shRank = rk;
+    return rk;
+}
+
+// solve_waves: three waves side by side -- wave 0 the bookkeeping, wave 1 the 6x6 inverse, the update, the SE(3) exponential and
+// the candidate pose, wave 2 the rank test (rank_now; the fused launch runs it later, on one block only).  No barrier behind it.
+__device__ __forceinline__ void solve_waves(SolveShared& sh, const SolveCfg& cfg, const float lam_spec, const bool rank_now) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    GNState* st = &sh.sst;
+    const double* tot = sh.sst.tot;
     // ---- waves 1 and 2 start the 6x6 work speculatively, in parallel with the bookkeeping of wave 0: a step is only ever
     //      computed from the H of THIS pass (go implies take, see below), and the damping of the rank test is known from the
     //      state before the decision: lambda on the first pass of a level, lambda / 5 after an accepted step (a rejected
     //      step ends the level, so its result is simply dropped).  RPI.h:4682, 4693, 4718 ----
-    if (cfg.mode == 0 && (wave == 1 || wave == 2)) {
+    if (cfg.mode == 0 && wave == 2 && rank_now) {
+        solve_rank_wave(sh, lam_spec);
+        SOLVE_STAMP_T(7, 128);     // rank done
+    }
+    if (cfg.mode == 0 && wave == 1) {
         float hval = 0.f;
         if (lane < 36) {
             const int r = lane / 6, c = lane - 6 * r;
             const int aa = r < c ? r : c, bb = r < c ? c : r;
             hval = (float)tot[P_H + (aa * (13 - aa)) / 2 + (bb - aa)];
         }
-        if (wave == 1) {
-            if (lane < 36) shH[lane] = hval;
+        {
+            if (lane < 36) sh.shH[lane] = hval;
             float x[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            const bool ok = lu_inverse6_lanes(shH, lane, x);     // hessian.inverse()   RPI.h:4693
+            const bool ok = lu_inverse6_lanes(sh.shH, lane, x);     // hessian.inverse()   RPI.h:4693
             if (lane >= 6 && lane < 12) {
 #pragma unroll
-                for (int r = 0; r < 6; ++r) shInv[(lane - 6) * 6 + r] = x[r];
+                for (int r = 0; r < 6; ++r) sh.shInv[(lane - 6) * 6 + r] = x[r];
             }
-            if (lane == 0) shLuOk = ok ? 1 : 0;
+            if (lane == 0) sh.shLuOk = ok ? 1 : 0;
+            SOLVE_STAMP_T(5, 64);      // inverse done
             // update_pose = (-H^-1) * g, row `lane`, summed in column order; kept aside until wave 0 has decided (its test
             // of the loop condition still reads the previous update)
             float upd = 0.f;
             if (lane < 6) {
 #pragma unroll
-                for (int c = 0; c < 6; ++c) upd += (-shInv[c * 6 + lane]) * (float)tot[P_G + c];
-                shUpd[lane] = upd;
+                for (int c = 0; c < 6; ++c) upd += (-sh.shInv[c * 6 + lane]) * (float)tot[P_G + c];
+                sh.shUpd[lane] = upd;
             }
             // CPose3D::exp(update, true) (RPI.h:4697): every lane evaluates the two scalar coefficients, lane 4*j+i
             // assembles element (i,j) of the 4x4
@@ -942,20 +969,17 @@ __device__ __forceinline__ void solve_block(GNState* st_g, const double* __restr
                 } else if (j == 3 && i < 3) {
                     e = i == 0 ? ux : (i == 1 ? uy : uz);
                 }
-                shE[lane] = (float)e;
+                sh.shE[lane] = (float)e;
             }
             // pose_estim_temp = exp(...).cast<float>() * pose_estim: whenever a step is taken the pose it starts from is the
             // candidate of this pass (accepted: pose := cand; first pass of a level: cand == pose)
             if (lane < 16) {
                 const int c = lane >> 2, r = lane & 3;
-                const float* P = sst.cand;
-                shCand[lane] = ((shE[0 * 4 + r] * P[c * 4 + 0] + shE[1 * 4 + r] * P[c * 4 + 1]) + shE[2 * 4 + r] * P[c * 4 + 2]) +
-                               shE[3 * 4 + r] * P[c * 4 + 3];
+                const float* P = sh.sst.cand;
+                sh.shCand[lane] = ((sh.shE[0 * 4 + r] * P[c * 4 + 0] + sh.shE[1 * 4 + r] * P[c * 4 + 1]) + sh.shE[2 * 4 + r] * P[c * 4 + 2]) +
+                               sh.shE[3 * 4 + r] * P[c * 4 + 3];
             }
-        } else {
-            if (lane < 36) shM[lane] = (lane % 7 == 0) ? hval + lam_spec * hval : hval;      // H + lambda diag(H)   RPI.h:4682
-            const int rk = qr_rank6_lanes(shM, lane);             // (H + lambda diag H).rank()   RPI.h:4682
-            if (lane == 0) shRank = rk;
+            SOLVE_STAMP_T(6, 64);      // update, exponential, candidate pose done
         }
     }
     // ---- bookkeeping on wave 0: lane 0 takes the scalar decisions, lanes 0-41 move the 36 + 6 matrix entries ----
@@ -1024,7 +1048,7 @@ __device__ __forceinline__ void solve_block(GNState* st_g, const double* __restr
                     st->used_npix = cfg.n_pixels;
                 }
             }
-            shGo = go;
+            sh.shGo = go;
         }
         take = __builtin_amdgcn_readfirstlane(take);
         go = __builtin_amdgcn_readfirstlane(go);
@@ -1043,55 +1067,112 @@ __device__ __forceinline__ void solve_block(GNState* st_g, const double* __restr
             }
         }
     }
-    STAMP(1);
-    __syncthreads();            // bookkeeping (wave 0), inverse (wave 1) and rank (wave 2) are all done
-    if (shGo) {
-        STAMP(2);
-        const bool ill = (shRank != 6) || !shLuOk;
+    SOLVE_STAMP(2);
+}
+
+// solve_finish (behind a barrier that follows solve_waves): commits the step or the ILL-POSED status, hands a finished level over to
+// the next finer one.  use_rank = false: the rank test has not run yet -- the step is committed on the inverse's word alone and the
+// values an ILL-POSED verdict restores are kept in sh.prevCand / prevUpd (solve_rank_verdict).
+__device__ __forceinline__ void solve_finish(SolveShared& sh, const SolveCfg& cfg, const bool use_rank) {
+    const int tid = threadIdx.x;
+    GNState* st = &sh.sst;
+    if (sh.shGo) {
+        const bool ill = (use_rank && sh.shRank != 6) || !sh.shLuOk;
+        if (!use_rank && tid < 16) {
+            sh.prevCand[tid] = sh.sst.cand[tid];
+            if (tid < 6) sh.prevUpd[tid] = sh.sst.update[tid];
+        }
         if (ill) {
             if (tid == 0) {
                 st->status = 1;      // "The problem is ILL-POSED": relPose = pose_estim, return   RPI.h:4684-4689
                 st->done = 1;
             }
         } else if (tid < 16) {
-            sst.cand[tid] = shCand[tid];
-            if (tid < 6) sst.update[tid] = shUpd[tid];
+            sh.sst.cand[tid] = sh.shCand[tid];
+            if (tid < 6) sh.sst.update[tid] = sh.shUpd[tid];
         }
-        STAMP(3);
+        SOLVE_STAMP(3);
         __syncthreads();
     }
     // A level that has just finished hands over to the next finer one right here (RPI.h:4590-4604: it = 0, update = (1,..,1),
     // lambda = 1, first pass at the pose reached so far): the next launch in the queue, tagged with that level, finds it
     // active -- no separate initialisation launch between levels.
-    if (cfg.mode == 0 && !cfg.forced && cfg.level > 0 && sst.done && sst.status == 0) {      // uniform
+    if (cfg.mode == 0 && !cfg.forced && cfg.level > 0 && sh.sst.done && sh.sst.status == 0) {      // uniform
         __syncthreads();
-        if (tid < 16) sst.cand[tid] = sst.pose[tid];
-        if (tid < 6) sst.update[tid] = 1.f;
+        if (tid < 16) sh.sst.cand[tid] = sh.sst.pose[tid];
+        if (tid < 6) sh.sst.update[tid] = 1.f;
         if (tid == 0) {
-            sst.level_active = cfg.level - 1;
-            sst.lambda = 1.0;
-            sst.it = 0;
-            sst.first = 1;
-            sst.done = 0;
-            sst.error = sst.new_error = sst.diff_error = 0.0;
+            sh.sst.level_active = cfg.level - 1;
+            sh.sst.lambda = 1.0;
+            sh.sst.it = 0;
+            sh.sst.first = 1;
+            sh.sst.done = 0;
+            sh.sst.error = sh.sst.new_error = sh.sst.diff_error = 0.0;
         }
         __syncthreads();
     }
+}
+
+__device__ __forceinline__ void solve_staged(SolveShared& sh, const SolveCfg& cfg) {
+    const float lam_spec = solve_totals(sh);
+    solve_waves(sh, cfg, lam_spec, true);
+    __syncthreads();            // bookkeeping (wave 0), inverse (wave 1) and rank (wave 2) are all done
+    solve_finish(sh, cfg, true);
+}
+
+__device__ __forceinline__ void solve_block(GNState* st_g, const double* __restrict__ partials, const int nb, const SolveCfg& cfg) {
+    // The state is staged through LDS: one coalesced read while the partials are being reduced, one coalesced
+    // write-back at the end; the single-lane bookkeeping then never waits on global memory.
+    __shared__ SolveShared sh;
+    constexpr int kStateWords = sizeof(GNState) / 4;
+    static_assert(sizeof(GNState) % 4 == 0 && kStateWords <= kSolveThreads, "GNState staging");
+    const int tid = threadIdx.x;
+#ifdef RGBD360_SOLVE_STAMPS
+    if (tid == 0) sh.stamp0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (tid < kStateWords) reinterpret_cast<int*>(&sh.sst)[tid] = reinterpret_cast<const int*>(st_g)[tid];
+    const int v = tid % kNumPartials, q = tid / kNumPartials;
+    constexpr int Q = kSolveThreads / kNumPartials;
+    // rows q, q+Q, q+2Q, ... of the partial table: all loads of a batch are issued before the first add (one
+    // memory round trip per 16 rows instead of one per row); the summation order stays fixed.
+    double s = 0.0;
+    for (int b0 = q; b0 < nb; b0 += 16 * Q) {
+        double tmp[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int b = b0 + j * Q;
+            tmp[j] = b < nb ? partials[(size_t)b * kNumPartials + v] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s += tmp[j];
+    }
+    sh.red[q][v] = s;
+    __syncthreads();
+    SOLVE_STAMP(0);
+    if (cfg.mode == 0 && (sh.sst.done || sh.sst.level_active != cfg.level)) {            // uniform: finished / other level
+        if (cfg.host_state) {                               // the schedule's last launch reports even when it has nothing to do
+            if (tid < kStateWords) reinterpret_cast<int*>(cfg.host_state)[tid] = reinterpret_cast<const int*>(&sh.sst)[tid];
+            __threadfence_system();
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(cfg.host_tag, cfg.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
+    solve_staged(sh, cfg);
 #ifdef RGBD360_SOLVE_STAMPS
     if (tid == 0) {
-        stamp[4] = __builtin_amdgcn_s_memrealtime() - stamp0;
-        for (int i = 0; i < 8; ++i) sst.stamps[i] = stamp[i];
+        sh.stamp[4] = __builtin_amdgcn_s_memrealtime() - sh.stamp0;
+        for (int i = 0; i < 8; ++i) sh.sst.stamps[i] = sh.stamp[i];
     }
     __syncthreads();
 #endif
-    if (tid < kStateWords) reinterpret_cast<int*>(st_g)[tid] = reinterpret_cast<const int*>(&sst)[tid];
+    if (tid < kStateWords) reinterpret_cast<int*>(st_g)[tid] = reinterpret_cast<const int*>(&sh.sst)[tid];
     if (cfg.host_state) {                                   // uniform
-        if (tid < kStateWords) reinterpret_cast<int*>(cfg.host_state)[tid] = reinterpret_cast<const int*>(&sst)[tid];
+        if (tid < kStateWords) reinterpret_cast<int*>(cfg.host_state)[tid] = reinterpret_cast<const int*>(&sh.sst)[tid];
         __threadfence_system();
         __syncthreads();
         if (tid == 0) __hip_atomic_store(cfg.host_tag, cfg.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-#undef STAMP
 }
 __global__ __launch_bounds__(kSolveThreads) void k_solve(GNState* st_g, const double* __restrict__ partials, int nb,
                                                           SolveCfg cfg) {
@@ -1101,6 +1182,173 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve(GNState* st_g, const do
 __global__ __launch_bounds__(kSolveThreads) void k_solve_b(GNState* states, const double* __restrict__ partials, int partials_stride,
                                                             int nb, SolveCfg cfg) {
     solve_block(states + blockIdx.x, partials + (size_t)blockIdx.x * (size_t)partials_stride, nb, cfg);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Fused-solve schedule of the single-pair path (one launch per Gauss-Newton iteration instead of two).
+// The solve of pass k is the PROLOGUE of the launch that runs pass k+1: every block of that launch reduces the partial rows of
+// the previous pass and takes the loop trip of alignFrames360 (RPI.h:4611-4722) itself -- redundantly, in the same fixed order,
+// so all blocks arrive at the same state bit for bit -- and then evaluates its span at the candidate pose it has just computed.
+// One pair keeps the 256 CUs busy for ~9 us per pass and leaves them idle during the ~5 us single-block k_solve launch and
+// both launch boundaries around it; here the serial part runs where the next pass starts, after ONE boundary, while the
+// pose-independent source records of the pass are already in flight.  No cross-block communication inside a launch: the
+// kernel boundary publishes the partial rows, state and partial table are double-buffered (a launch reads buffers A, block 0
+// writes the new state to B, all blocks write their rows to B) so that no block reads what another block of the same launch
+// writes.  What a pass leaves behind is described by the state itself (pend_nb rows, pend_npix pixels, on level
+// level_active, at pose cand).  The arithmetic is solve_staged / eval_span, shared with k_solve / k_eval: poses are
+// bit-identical to the two-launch schedule.  The lock-step sequence engine keeps k_solve_b: there the CUs are never idle and
+// one solve launch already serves all pairs in flight.
+// ---------------------------------------------------------------------------------------------------------
+// Stages the state and sums the pending pass's partial rows.  Everything is requested at once: the partial rows (whole batches of 32
+// rows up to nb_load, the largest table of the context -- the row count of the pending pass is only known with the state, and
+// waiting for it would put two dependent round trips in front of the solve; rows >= pend_nb are dropped from the sum), the state
+// words, and the pending row count itself through the scalar unit.  Returns pend_nb; a barrier behind the LDS writes.
+__device__ __forceinline__ int stage_pending(SolveShared& sh, const GNState* __restrict__ st_in, const double* __restrict__ partials,
+                                             const int nb_load) {
+    constexpr int kStateWords = sizeof(GNState) / 4;
+    constexpr int Q = kSolveThreads / kNumPartials;
+    const int tid = threadIdx.x;
+    const int v = tid % kNumPartials, q = tid / kNumPartials;
+    double tmp[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        tmp[j] = 0.0;
+        if (j * Q < nb_load) tmp[j] = partials[(size_t)(q + j * Q) * kNumPartials + v];      // uniform test: the table is padded to whole batches
+    }
+    int word = 0;
+    if (tid < kStateWords) word = reinterpret_cast<const int*>(st_in)[tid];
+    const int nb = st_in->pend_nb;        // uniform (scalar load)
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s += (q + j * Q < nb) ? tmp[j] : 0.0;      // the order of solve_block's sum
+    sh.red[q][v] = s;
+    if (tid < kStateWords) reinterpret_cast<int*>(&sh.sst)[tid] = word;
+    __syncthreads();
+    return nb;
+}
+constexpr int kMaxPendingRows = 16 * (kSolveThreads / kNumPartials);      // one batch of stage_pending
+
+// wave-uniform pose out of LDS into scalar registers (the pixel loop reads it as SGPR operands, like the scalar loads of k_eval)
+__device__ __forceinline__ float uniform_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+
+template <int METHOD>
+__global__ __launch_bounds__(kEvalThreads) void k_eval_fs(const GNState* __restrict__ st_in, GNState* __restrict__ st_out,
+                                                           const double* __restrict__ partials_in, double* __restrict__ partials_out,
+                                                           const float4* __restrict__ src0, int n_px, int chunk, int level, int nb_arg,
+                                                           int nb_load, LevelDev lv, EvalConsts ec, SolveCfg cfg) {
+    static_assert(kEvalThreads == kSolveThreads, "the fused launch runs the solve on the pass's block");
+    unsigned long long es[6] = {0, 0, 0, 0, 0, 0};
+#ifdef RGBD360_EVAL_STAMPS
+    const unsigned long long es0 = __builtin_amdgcn_s_memrealtime();
+#else
+    const unsigned long long es0 = 0;
+#endif
+    __shared__ SolveShared sh;
+    constexpr int kStateWords = sizeof(GNState) / 4;
+#ifdef RGBD360_SOLVE_STAMPS
+    if (threadIdx.x == 0) sh.stamp0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    // what the solve waits for is requested first (a wave's vector-memory operations complete in issue order) ...
+    const int pend = stage_pending(sh, st_in, partials_in, nb_load);
+    SOLVE_STAMP(0);
+    const int nb = nb_arg;
+    const int b = blockIdx.x;
+    const int cb = ((nb & 7) == 0) ? (b & 7) * (nb >> 3) + (b >> 3) : b;
+    const int base = cb * chunk;
+    const int end = min(base + chunk, n_px);
+    EvalBufs bufs;
+    bufs.src = make_rsrc(src0, (unsigned)n_px * 16u);
+    bufs.trgP = make_rsrc(lv.trgP, (unsigned)lv.n * 12u);
+    bufs.trgD = make_rsrc(lv.trgD, (unsigned)lv.n * 12u);
+    bufs.row_bytes = (unsigned)lv.cols * 12u;
+    const int i = base + (int)threadIdx.x;
+    // ... the first two source records of the span, which depend on nothing, right behind it: in flight during the solve
+    const float4 sA = buf_load_f4(bufs.src, (unsigned)i << 4);
+    const float4 sB = buf_load_f4(bufs.src, (unsigned)(i + kEvalThreads) << 4);
+    float lam_spec = 0.f;
+    if (pend > 0) {                             // uniform: the previous launch ran a pass
+        SolveCfg c = cfg;
+        c.level = sh.sst.level_active;          // the level that pass belongs to (it ran because this level was active)
+        c.n_pixels = sh.sst.pend_npix;
+        lam_spec = solve_totals(sh);
+        solve_waves(sh, c, lam_spec, /*rank_now=*/false);
+        __syncthreads();
+        // the step is committed on the inverse's word; the rank test (the longest of the three chains, and almost never the one that
+        // says no) runs on ONE wave of block 0 while everybody else is already evaluating pixels, see below
+        solve_finish(sh, c, /*use_rank=*/false);
+    }
+    const bool run = !(sh.sst.done | (sh.sst.level_active != level));      // uniform; as k_eval's gate
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        sh.sst.pend_nb = run ? nb : 0;
+        sh.sst.pend_npix = lv.n;
+#ifdef RGBD360_SOLVE_STAMPS
+        sh.stamp[4] = __builtin_amdgcn_s_memrealtime() - sh.stamp0;
+        for (int k = 0; k < 8; ++k) sh.sst.stamps[k] = sh.stamp[k];
+#endif
+    }
+    __syncthreads();
+    if (b == 0 && (threadIdx.x >> 6) == 2) {
+        // block 0, wave 2: the rank verdict on the step just committed, then the new state.  ILL-POSED (RPI.h:4684-4689): status 1,
+        // level done, candidate and update as they were -- and no pending pass: the rows this launch writes are never read.
+        const int lane = threadIdx.x & 63;
+        bool ill_late = false;
+        if (pend > 0 && sh.shGo && sh.shLuOk) {
+            ill_late = solve_rank_wave(sh, lam_spec) != 6;      // (the return value: a lane that did not store shRank may not see it without a barrier)
+        }
+        // one store per word: the staged state, with the words an ILL-POSED verdict changes patched on the way
+        constexpr int kCand = offsetof(GNState, cand) / 4, kUpd = offsetof(GNState, update) / 4;
+        for (int w = lane; w < kStateWords; w += 64) {
+            int val = reinterpret_cast<const int*>(&sh.sst)[w];
+            if (ill_late) {
+                if (w >= kCand && w < kCand + 16) val = __builtin_bit_cast(int, sh.prevCand[w - kCand]);
+                if (w >= kUpd && w < kUpd + 6) val = __builtin_bit_cast(int, sh.prevUpd[w - kUpd]);
+                if (w == offsetof(GNState, status) / 4 || w == offsetof(GNState, done) / 4) val = 1;
+                if (w == offsetof(GNState, pend_nb) / 4) val = 0;
+            }
+            reinterpret_cast<int*>(st_out)[w] = val;
+        }
+    }
+    if (!run) return;
+    const float* P = sh.sst.cand;
+    PoseRT T;
+    T.r00 = uniform_f(P[0]); T.r10 = uniform_f(P[1]); T.r20 = uniform_f(P[2]);
+    T.r01 = uniform_f(P[4]); T.r11 = uniform_f(P[5]); T.r21 = uniform_f(P[6]);
+    T.r02 = uniform_f(P[8]); T.r12 = uniform_f(P[9]); T.r22 = uniform_f(P[10]);
+    T.tx = uniform_f(P[12]); T.ty = uniform_f(P[13]); T.tz = uniform_f(P[14]);
+    const WarpConsts wc = make_warp_consts(T, lv);
+    ESTAMP(0);
+    PixW wA;
+    warp_stage<METHOD>(sA, i < end, T, wc, lv, bufs, wA);
+    ESTAMP(1);
+    eval_span<METHOD, true, kEvalThreads>(T, wc, lv, ec, bufs, i, base, end, b, nb, wA, sB, partials_out, es, es0);
+}
+
+// The tail of a fused-solve schedule: the solve of the last pass enqueued (if one is pending), in place, one block; publishes
+// like k_solve.
+__global__ __launch_bounds__(kSolveThreads) void k_solve_pending(GNState* st_g, const double* __restrict__ partials, int nb_load,
+                                                                  SolveCfg cfg) {
+    __shared__ SolveShared sh;
+    constexpr int kStateWords = sizeof(GNState) / 4;
+    const int tid = threadIdx.x;
+    const int pend = stage_pending(sh, st_g, partials, nb_load);
+    if (pend > 0) {
+        SolveCfg c = cfg;
+        c.level = sh.sst.level_active;
+        c.n_pixels = sh.sst.pend_npix;
+        solve_staged(sh, c);
+        if (tid == 0) sh.sst.pend_nb = 0;
+        __syncthreads();
+    }
+    if (tid < kStateWords) reinterpret_cast<int*>(st_g)[tid] = reinterpret_cast<const int*>(&sh.sst)[tid];
+    if (cfg.host_state) {                                   // uniform
+        if (tid < kStateWords) reinterpret_cast<int*>(cfg.host_state)[tid] = reinterpret_cast<const int*>(&sh.sst)[tid];
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(cfg.host_tag, cfg.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // Standalone GN step for tests: one thread.

@@ -54,10 +54,14 @@ struct rgbd360_ctx {
     std::vector<Level> levels;
     int rows = 0, cols = 0;
     bool have_src = false, have_trg = false;
-    GNState* d_state = nullptr;
+    GNState* d_state = nullptr;       // the CURRENT state buffer: every launch of the stream reads / updates this one ...
+    GNState* d_state_alt = nullptr;   // ... except the fused pass (k_eval_fs), which reads d_state, writes d_state_alt, after which the two swap
     GNState* h_state = nullptr;   // pinned
     hostwait::SpinTag tag;        // pinned sequence number the stream's last kernel stores (host_wait.h)
-    double* d_partials = nullptr;
+    double* d_partials = nullptr;     // partial rows of the last pass enqueued (current) ...
+    double* d_partials_alt = nullptr; // ... and where a fused pass puts its rows while its blocks still read the previous table
+    int max_blocks = 0;               // rows of a partial table = blocks of the largest level
+    bool fused_solve = true;          // single-pair schedule: solve in the prologue of the next pass (RGBD360_FUSED_SOLVE=0: {k_eval, k_solve} pairs, A/B)
     GnIO* d_gnio = nullptr;
     // upload staging: slot 0 serves the single-frame entries (copies on `stream`); the sequence entry alternates both slots,
     // copying on `up_stream` one frame ahead of the alignment (up_ev: upload landed, conv_ev: slot consumed)
@@ -189,9 +193,15 @@ int ensure_levels(rgbd360_ctx* ctx, int rows, int cols) {
         if (L.nblocks > max_blocks) max_blocks = L.nblocks;
         r /= 2; c /= 2;
     }
-    hipFree(ctx->d_partials);
-    ctx->d_partials = nullptr;
-    HIPC(ctx, hipMalloc(&ctx->d_partials, (size_t)(max_blocks + 8 + max_blocks / 16 + 2) * kNumPartials * sizeof(double)));   // + diagnostic rows
+    hipFree(ctx->d_partials); hipFree(ctx->d_partials_alt);
+    ctx->d_partials = ctx->d_partials_alt = nullptr;
+    // whole batches of 32 rows (stage_pending loads whole batches) + diagnostic rows
+    const size_t part_bytes = (size_t)((max_blocks + 31) / 32 * 32 + 8 + max_blocks / 16 + 2) * kNumPartials * sizeof(double);
+    HIPC(ctx, hipMalloc(&ctx->d_partials, part_bytes));
+    HIPC(ctx, hipMalloc(&ctx->d_partials_alt, part_bytes));
+    HIPC(ctx, hipMemset(ctx->d_partials, 0, part_bytes));          // the fused pass loads max_blocks rows whatever the pending count
+    HIPC(ctx, hipMemset(ctx->d_partials_alt, 0, part_bytes));
+    ctx->max_blocks = max_blocks;
     ctx->rows = rows; ctx->cols = cols;
     return 0;
 }
@@ -288,6 +298,44 @@ void launch_solve(rgbd360_ctx* ctx, int level, int mode, int forced, int occ = 0
         cfg.host_seq = ++ctx->tag.seq;
     }
     hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), 0, ctx->stream, ctx->d_state, ctx->d_partials, L.nblocks, cfg);
+}
+
+// Fused-solve schedule (k_eval_fs, photo_icp_kernels.h): the launch solves the pass the previous launch left pending and runs the
+// next pass; state and partial table ping-pong, the host's "current" pointers follow the stream order.
+bool fused_ok(const rgbd360_ctx* ctx, int occ) {
+    return ctx->fused_solve && occ == 0 && ctx->max_blocks <= kMaxPendingRows;
+}
+SolveCfg fused_cfg(const rgbd360_ctx* ctx, int forced) {
+    SolveCfg cfg;
+    cfg.level = -1; cfg.n_pixels = 0;       // taken from the state (level_active / pend_npix of the pending pass)
+    cfg.mode = 0; cfg.forced = forced; cfg.max_iters = ctx->p.max_iters; cfg.occ = 0;
+    cfg.tol_residual = ctx->p.tol_residual; cfg.tol_update = ctx->p.tol_update;
+    return cfg;
+}
+void launch_eval_fused(rgbd360_ctx* ctx, int level, int method, int forced) {
+    const Level& L = ctx->levels[level];
+    const LevelDev lv = level_dev(L);
+    const EvalConsts ec = eval_consts(ctx->p);
+    const SolveCfg cfg = fused_cfg(ctx, forced);
+    dim3 g(L.nblocks), b(kEvalThreads);
+#define LAUNCHF(M) hipLaunchKernelGGL((k_eval_fs<M>), g, b, 0, ctx->stream, (const GNState*)ctx->d_state, ctx->d_state_alt, (const double*)ctx->d_partials, \
+                                      ctx->d_partials_alt, lv.src, lv.n, L.chunk, level, L.nblocks, ctx->max_blocks, lv, ec, cfg)
+    if (method == 0) LAUNCHF(0);
+    else if (method == 1) LAUNCHF(1);
+    else LAUNCHF(2);
+#undef LAUNCHF
+    std::swap(ctx->d_state, ctx->d_state_alt);
+    std::swap(ctx->d_partials, ctx->d_partials_alt);
+}
+// the tail of a fused schedule: solves what the last pass left pending (nothing, if that launch was a no-op) and publishes
+void launch_solve_pending(rgbd360_ctx* ctx, int forced, bool publish) {
+    SolveCfg cfg = fused_cfg(ctx, forced);
+    if (publish) {
+        cfg.host_state = ctx->h_state;
+        cfg.host_tag = ctx->tag.h;
+        cfg.host_seq = ++ctx->tag.seq;
+    }
+    hipLaunchKernelGGL(k_solve_pending, dim3(1), dim3(kSolveThreads), 0, ctx->stream, ctx->d_state, (const double*)ctx->d_partials, ctx->max_blocks, cfg);
 }
 
 void launch_level_init(rgbd360_ctx* ctx, int level, const float* pose, int reset_all) {
@@ -511,10 +559,15 @@ int rgbd360_create(const rgbd360_params* p, rgbd360_ctx** out) {
     if (const char* e = getenv("RGBD360_ADAPTIVE_CHUNKS")) {
         ctx->adaptive_chunks = atoi(e) != 0;
     }
+    if (const char* e = getenv("RGBD360_FUSED_SOLVE")) {
+        ctx->fused_solve = atoi(e) != 0;
+    }
     bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreate(&ctx->ev0) == hipSuccess && hipEventCreate(&ctx->ev1) == hipSuccess &&
               hipMalloc(&ctx->d_state, sizeof(GNState)) == hipSuccess &&
               hipMemset(ctx->d_state, 0, sizeof(GNState)) == hipSuccess &&
+              hipMalloc(&ctx->d_state_alt, sizeof(GNState)) == hipSuccess &&
+              hipMemset(ctx->d_state_alt, 0, sizeof(GNState)) == hipSuccess &&
               hipMalloc(&ctx->d_gnio, sizeof(GnIO)) == hipSuccess &&
               hipHostMalloc((void**)&ctx->h_state, sizeof(GNState), hipHostMallocDefault) == hipSuccess &&
               hostwait::spin_tag_init(&ctx->tag) == hipSuccess;
@@ -535,7 +588,7 @@ void rgbd360_destroy(rgbd360_ctx* ctx) {
     ctx->engines.clear();
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     free_levels(ctx);
-    hipFree(ctx->d_state); hipFree(ctx->d_partials); hipFree(ctx->d_gnio);
+    hipFree(ctx->d_state); hipFree(ctx->d_state_alt); hipFree(ctx->d_partials); hipFree(ctx->d_partials_alt); hipFree(ctx->d_gnio);
     for (int k = 0; k < 2; ++k) {
         hipFree(ctx->d_stage_rgb[k]); hipFree(ctx->d_stage_depth[k]);
         if (ctx->up_ev[k]) hipEventDestroy(ctx->up_ev[k]);
@@ -619,6 +672,13 @@ static void enqueue_schedule(rgbd360_ctx* ctx, int pending, bool pending_started
         // instead of the fixed chunk -- fewer no-op launches on the coarse levels (~3 us each), no second round trip on level 0.
         if (ctx->adaptive_chunks && !(level == pending && pending_started) && ctx->hist_iters[level & 7] >= 0)
             n_pairs = std::min(std::max(ctx->hist_iters[level & 7] + 2, 2), 12);
+        if (fused_ok(ctx, ctx->al_occ)) {
+            // one launch per iteration: n_pairs passes, each carrying the solve of the one before it; the solve of the chunk's last
+            // pass rides in the next level's first launch, the schedule's very last one in a one-block launch that publishes
+            for (int k = 0; k < n_pairs; ++k) launch_eval_fused(ctx, level, ctx->al_method, 0);
+            if (level == 0) launch_solve_pending(ctx, 0, /*publish=*/true);
+            continue;
+        }
         for (int k = 0; k < n_pairs; ++k) {
             launch_eval(ctx, level, ctx->al_method, true, ctx->al_occ);
             launch_solve(ctx, level, 0, 0, ctx->al_occ, /*publish=*/level == 0 && k == n_pairs - 1);
@@ -1016,9 +1076,14 @@ int rgbd360_forced_iters(rgbd360_ctx* ctx, int level, const float pose0[16], int
     hipSetDevice(ctx->p.device);
     launch_level_init(ctx, level, pose0, 1);
     if (elapsed_ms) HIPC(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    for (int k = 0; k < n_iters; ++k) {
-        launch_eval(ctx, level, method, true);
-        launch_solve(ctx, level, 0, 1, 0, /*publish=*/!elapsed_ms && k == n_iters - 1);
+    if (fused_ok(ctx, 0)) {       // n_iters launches {solve of the previous pass, pass} + the last solve
+        for (int k = 0; k < n_iters; ++k) launch_eval_fused(ctx, level, method, 1);
+        launch_solve_pending(ctx, 1, /*publish=*/!elapsed_ms);
+    } else {
+        for (int k = 0; k < n_iters; ++k) {
+            launch_eval(ctx, level, method, true);
+            launch_solve(ctx, level, 0, 1, 0, /*publish=*/!elapsed_ms && k == n_iters - 1);
+        }
     }
     if (elapsed_ms) HIPC(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     HIPC(ctx, hipGetLastError());
@@ -1032,6 +1097,40 @@ int rgbd360_forced_iters(rgbd360_ctx* ctx, int level, const float pose0[16], int
     return ctx->h_state->status;
 }
 
+// One solve on a hand-made partial table (row 0 = `row`, every other row zero) at the identity pose, through the two-launch form
+// (k_solve) or through the fused form (the prologue of k_eval_fs; the state is read as that launch leaves it): the state-machine paths real images hardly
+// ever reach (ILL-POSED by the rank test alone, by a zero pivot, ...) can be driven from a test.  Needs both frames set (the fused
+// form runs a pass afterwards when the step is accepted).  out_i: {status, done, level_active, it, n_evals, pend_nb}.
+int rgbd360_debug_solve_partials(rgbd360_ctx* ctx, int level, const double row[32], int method, int fused, int out_i[6], float cand_out[16],
+                                 float update_out[6]) {
+    int rc = check_args(ctx, level, method);
+    if (rc) return rc;
+    if (!row || !out_i) return fail(ctx, -1, "bad arguments");
+    if (fused && !fused_ok(ctx, 0)) return fail(ctx, -1, "the fused-solve schedule is switched off");
+    hipSetDevice(ctx->p.device);
+    const Level& L = ctx->levels[level];
+    float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    launch_level_init(ctx, level, I, 1);
+    const size_t rows = (size_t)(ctx->max_blocks + 31) / 32 * 32;
+    HIPC(ctx, hipMemsetAsync(ctx->d_partials, 0, rows * kNumPartials * sizeof(double), ctx->stream));
+    HIPC(ctx, hipMemcpyAsync(ctx->d_partials, row, kNumPartials * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    if (fused) {
+        const int pend[2] = {L.nblocks, L.n};       // as if a pass of this level had just written the table
+        HIPC(ctx, hipMemcpyAsync(&ctx->d_state->pend_nb, pend, sizeof(pend), hipMemcpyHostToDevice, ctx->stream));
+        launch_eval_fused(ctx, level, method, 0);      // the state is read as this launch leaves it: its own pass (if it ran one) stays pending
+    } else {
+        launch_solve(ctx, level, 0, 0);
+    }
+    HIPC(ctx, hipGetLastError());
+    rc = read_state_sync(ctx);
+    if (rc) return rc;
+    const GNState& S = *ctx->h_state;
+    out_i[0] = S.status; out_i[1] = S.done; out_i[2] = S.level_active; out_i[3] = S.it; out_i[4] = S.n_evals; out_i[5] = S.pend_nb;
+    if (cand_out) memcpy(cand_out, S.cand, sizeof(float) * 16);
+    if (update_out) memcpy(update_out, S.update, sizeof(float) * 6);
+    return 0;
+}
+
 int rgbd360_time_eval_kernel(rgbd360_ctx* ctx, int level, const float pose[16], int method, int want_hg, int reps,
                              float* avg_us) {
     int rc = check_args(ctx, level, method);
@@ -1039,10 +1138,17 @@ int rgbd360_time_eval_kernel(rgbd360_ctx* ctx, int level, const float pose[16], 
     if (!pose || reps < 1 || !avg_us) return fail(ctx, -1, "bad arguments");
     hipSetDevice(ctx->p.device);
     launch_level_init(ctx, level, pose, 1);
-    launch_eval(ctx, level, method, want_hg != 0);   // warm-up
+    const bool fused = want_hg == 2;      // the product's single-pair launch: solve of the previous pass + pass (forced schedule)
+    if (fused && !fused_ok(ctx, 0)) return fail(ctx, -1, "the fused-solve schedule is switched off");
+    auto one = [&]() {
+        if (fused) launch_eval_fused(ctx, level, method, 1);
+        else launch_eval(ctx, level, method, want_hg != 0);
+    };
+    one();   // warm-up
     HIPC(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    for (int k = 0; k < reps; ++k) launch_eval(ctx, level, method, want_hg != 0);
+    for (int k = 0; k < reps; ++k) one();
     HIPC(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    if (fused) launch_solve_pending(ctx, 1, false);
     HIPC(ctx, hipGetLastError());
     HIPC(ctx, hipStreamSynchronize(ctx->stream));
     float ms = 0.f;
@@ -1064,6 +1170,7 @@ int rgbd360_time_eval_kernel_rotating(rgbd360_ctx* const* ctxs, int n_ctx, int l
         const int rc = check_args(ctxs[k], level, method);
         if (rc) return k == 0 ? rc : fail(c0, rc, ctxs[k]->err.c_str());
         if (ctxs[k]->p.device != c0->p.device) return fail(c0, -1, "all contexts must live on one device");
+        if (want_hg == 2 && !fused_ok(ctxs[k], 0)) return fail(c0, -1, "the fused-solve schedule is switched off");
     }
     hipSetDevice(c0->p.device);
     // every context's kernels go to c0's stream for the duration of the measurement
@@ -1073,13 +1180,19 @@ int rgbd360_time_eval_kernel_rotating(rgbd360_ctx* const* ctxs, int n_ctx, int l
         own[k] = ctxs[k]->stream;
         ctxs[k]->stream = c0->stream;
     }
+    const bool fused = want_hg == 2;      // k_eval_fs, forced schedule (every context iterates on its own pair)
+    auto one = [&](rgbd360_ctx* c) {
+        if (fused) launch_eval_fused(c, level, method, 1);
+        else launch_eval(c, level, method, want_hg != 0);
+    };
     for (int k = 0; k < n_ctx; ++k) {
         launch_level_init(ctxs[k], level, pose, 1);
-        launch_eval(ctxs[k], level, method, want_hg != 0);      // warm-up
+        one(ctxs[k]);      // warm-up
     }
     hipError_t e = hipEventRecord(c0->ev0, c0->stream);
-    for (int r = 0; r < reps && e == hipSuccess; ++r) launch_eval(ctxs[r % n_ctx], level, method, want_hg != 0);
+    for (int r = 0; r < reps && e == hipSuccess; ++r) one(ctxs[r % n_ctx]);
     if (e == hipSuccess) e = hipEventRecord(c0->ev1, c0->stream);
+    if (fused) for (int k = 0; k < n_ctx; ++k) launch_solve_pending(ctxs[k], 1, false);
     if (e == hipSuccess) e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(c0->stream);
     for (int k = 0; k < n_ctx; ++k) ctxs[k]->stream = own[k];

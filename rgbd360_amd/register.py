@@ -362,6 +362,17 @@ class RegisterPhotoICP:
         self._check(rc, allow=(0, 1, 2))
         return dict(status=rc, pose=pose_from_cm(out), rms=rms.value, elapsed_ms=ms.value if want_elapsed else None)
 
+    def debug_solve_partials(self, level: int, row, method: int = 0, fused: bool = True):
+        """rgbd360_debug_solve_partials: one solve on a hand-made partial table (row: 32 float64 -- 21 upper-triangle terms of H, 6 of
+        g, err2 photo / depth, n photo / depth / visible) at the identity pose, through k_solve (fused=False) or the fused launch."""
+        row = np.ascontiguousarray(row, np.float64)
+        assert row.shape == (32,)
+        out_i = np.zeros(6, np.int32)
+        cand, upd = np.zeros(16, np.float32), np.zeros(6, np.float32)
+        self._check(self._L.rgbd360_debug_solve_partials(self._ctx(), level, _ptr(row), method, int(fused), _ptr(out_i), _ptr(cand), _ptr(upd)))
+        return dict(status=int(out_i[0]), done=int(out_i[1]), level_active=int(out_i[2]), it=int(out_i[3]), n_evals=int(out_i[4]),
+                    pend_nb=int(out_i[5]), cand=pose_from_cm(cand), update=upd)
+
     def forced_iters_call(self, level: int, pose0, method: int, n_iters: int):
         """A closure that runs rgbd360_forced_iters with every argument converted ONCE (for timed loops: the numpy / ctypes
         conversions of forced_iters cost 10-15 us per call, as much as a Gauss-Newton iteration).  call() -> status;

@@ -42,14 +42,14 @@ def _pair_ctx(hip_lib, oracle_mod, pair, n_pyr=3, math_mode=1):
     return reg, ora, T
 
 
-def _assert_libm_oracle_agrees(reg, ora, method, n_pyr):
+def _assert_libm_oracle_agrees(reg, ora, method, n_pyr, occlusion=0, status=0):
     """The reference-faithful oracle (math_mode 0: libm asinf / atan2f / roundf as RPI.h:2674-2680 writes them; reduce_mode 0:
     the reference's float32 accumulators) against the pose the device has just produced: the north-star tolerance and the
     same accept / reject sequence (iterations per level)."""
     pose_gpu, iters_gpu = reg.getOptimalPose(), list(reg.num_iterations)
     ora.set_modes(0, 0)
-    st, pose_libm = ora.align360(np.eye(4), method)
-    assert st == 0
+    st, pose_libm = ora.align360(np.eye(4), method, occlusion)
+    assert st == status
     assert iters_gpu == list(ora.result.iters)[:n_pyr], (iters_gpu, list(ora.result.iters)[:n_pyr])
     rot, trans = synth.pose_error(pose_gpu, pose_libm)
     assert rot <= ROT_TOL and trans <= TRANS_TOL, (rot, trans)
@@ -157,6 +157,45 @@ def test_forced_schedule_matches_oracle(hip_lib, oracle_mod, small_pair):
     rot, trans = synth.pose_error(out["pose"], pose_ref)
     assert rot <= POSE_TOL_DEV and trans <= POSE_TOL_DEV, (rot, trans)
     assert abs(out["rms"] - e_ref) <= 1e-5
+
+
+def _partial_row(Hdiag, g, e2=(3.0, 2.0), n=(1000, 800, 1500)):
+    row = np.zeros(32)
+    for a, h in enumerate(Hdiag):
+        row[(a * (13 - a)) // 2] = h          # upper-triangle slot of H(a, a)
+    row[21:27] = g
+    row[27:29] = e2
+    row[29:32] = n
+    return row
+
+
+def test_solve_paths_fused_and_two_launch_agree(hip_lib, oracle_mod, small_pair):
+    """The serial part of a Gauss-Newton iteration (RPI.h:4611-4722) on hand-made normal equations, through k_solve and through the
+    prologue of the fused launch (which commits the step on the inverse's word and lets one wave of block 0 deliver the rank
+    verdict afterwards): an ordinary step, ILL-POSED by the rank test alone ((H + lambda diag H).rank() < 6 with every LU pivot
+    non-zero, RPI.h:4682-4690), ILL-POSED by a zero pivot, and no valid pixels.  Same status / flags / candidate / update, bit for
+    bit, and the ordinary step equals gn::step on the host (through the oracle)."""
+    reg, ora, T = _pair_ctx(hip_lib, oracle_mod, small_pair)
+    g = np.array([0.3, -0.2, 0.1, 0.05, -0.04, 0.02])
+    cases = {"step": (_partial_row([4, 5, 6, 7, 8, 9], g), 0, 0),
+             "rank": (_partial_row([1, 1, 1, 1, 1, 1e-9], g), 1, 1),
+             "pivot": (_partial_row([1, 1, 1, 0, 1, 1], g), 1, 1),
+             "empty": (_partial_row([4, 5, 6, 7, 8, 9], g, n=(0, 0, 0)), 2, 1)}
+    for name, (row, status, done) in cases.items():
+        for level in (0, 2):
+            two = reg.debug_solve_partials(level, row, 2, fused=False)
+            one = reg.debug_solve_partials(level, row, 2, fused=True)
+            assert two["status"] == one["status"] == status, (name, level, two, one)
+            assert two["done"] == one["done"] == done, (name, level, two, one)
+            for key in ("level_active", "it", "n_evals"):
+                assert two[key] == one[key], (name, level, key, two, one)
+            assert np.array_equal(two["cand"], one["cand"]) and np.array_equal(two["update"], one["update"]), (name, level)
+            assert (one["pend_nb"] > 0) == (not done) and two["pend_nb"] == 0, (name, one, two)       # an accepted step's pass stays pending
+            if name == "step":
+                st, pose_o, upd_o = oracle_mod.gn_step(np.diag([4, 5, 6, 7, 8, 9.0]).astype(np.float32), g.astype(np.float32), 1.0, np.eye(4))
+                assert st == 0 and np.allclose(one["update"], upd_o, rtol=1e-5, atol=1e-8) and np.allclose(one["cand"], pose_o, atol=1e-7)
+            else:
+                assert np.array_equal(one["cand"], np.eye(4, dtype=np.float32)) and np.array_equal(one["update"], np.ones(6, np.float32))
 
 
 def test_float_depth_and_strided_inputs(hip_lib, oracle_mod):
@@ -285,6 +324,109 @@ def test_full_size_4096x2048_with_planes(hip_lib, oracle_mod):
     labels, planes = oracle_mod.f360_plane_segment(xyz, out["normals"], 2048, 4096, 40, 0.03, 0.05, 0.001, 1)
     assert np.array_equal(np.asarray(out["labels"]).reshape(-1), np.asarray(labels).reshape(-1))
     assert len(out["planes"]) == len(planes) >= 6
+
+
+def _pingpong(n_pairs, n_unique):
+    idx, k, step = [], 0, 1
+    for _ in range(n_pairs + 1):
+        idx.append(k)
+        if k + step < 0 or k + step >= n_unique:
+            step = -step
+        k += step
+    return idx
+
+
+def _hip_runtime():
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipFree.argtypes = [C.c_void_p]
+
+    def to_device(a):
+        a = np.ascontiguousarray(a)
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), a.nbytes) == 0
+        assert hip.hipMemcpy(p, a.ctypes.data_as(C.c_void_p), a.nbytes, 1) == 0      # hipMemcpyHostToDevice
+        return p.value
+
+    def free(p):
+        hip.hipFree(C.c_void_p(p))
+    return to_device, free
+
+
+def test_full_size_sequence_config3(hip_lib, oracle_mod):
+    """BASELINE.json configs[3] at its stated size: an odometry walk of 33 frames of 2048x1024 (32 consecutive pairs, ping-pong
+    over 5 rendered frames like bench.py) through the lock-step sequence engine -- frames resident in HBM with n_inflight = 32
+    (two engines x 16 slots, the 512-thread batch pass, the fused frame set-up: the configuration the sequence throughput is quoted
+    on) and 8 (four pairs per slot: frame reuse inside a span), and host frames with the default slot count.  Poses, status and
+    iteration counts are BIT-IDENTICAL to pair-by-pair alignFrames360 (OdometryRGBD360.cpp:141-297 calls RPI.h:4519-4784 once per
+    pair); three of the pairs are also held against the reference-faithful oracle (libm asinf / atan2f / roundf, float32
+    accumulators): same iterations per level, pose within the north-star tolerance.  Then the occlusion-aware sequence (per-context
+    route) on one full-size pair, the same two checks."""
+    W, H, n_unique, n_pairs = 2048, 1024, 5, 32
+    uniq = [synth.render(synth.trajectory_pose(k, 7), W, H, 7) for k in range(n_unique)]
+    order = _pingpong(n_pairs, n_unique)
+    assert len(order) == 33
+    # pair by pair, every distinct (target, source) once
+    pairwise = {}
+    one = _mk(hip_lib, 4)
+    for a, b in sorted(set(zip(order[:-1], order[1:]))):
+        one.setTargetFrame(*uniq[a])
+        one.setSourceFrame(*uniq[b])
+        rc = one.alignFrames360(np.eye(4), 2)
+        pairwise[(a, b)] = (one.getOptimalPose().copy(), rc, list(one.num_iterations))
+        assert rc == 0
+    to_device, free = _hip_runtime()
+    rgb_d = [to_device(f[0]) for f in uniq]
+    dep_d = [to_device(f[1]) for f in uniq]
+    reg = _mk(hip_lib, 4)
+    try:
+        runs = [("resident/32", reg.alignSequenceDev([rgb_d[k] for k in order], [dep_d[k] for k in order], H, W, 0, method=2, n_inflight=32)),
+                ("resident/8", reg.alignSequenceDev([rgb_d[k] for k in order], [dep_d[k] for k in order], H, W, 0, method=2, n_inflight=8))]
+    finally:
+        for q in rgb_d + dep_d:
+            free(q)
+    runs.append(("host frames", reg.alignSequence([uniq[k] for k in order], method=2)))
+    for name, (poses, status, iters) in runs:
+        assert poses.shape == (n_pairs, 4, 4)
+        for j in range(n_pairs):
+            p, rc, it = pairwise[(order[j], order[j + 1])]
+            assert status[j] == rc and list(iters[j])[:4] == it, (name, j, status[j], list(iters[j]), it)
+            assert np.array_equal(poses[j], p), (name, j, np.abs(poses[j] - p).max())
+    # the reference-faithful oracle on three of the pairs (forward, backward, another forward)
+    poses = runs[0][1][0]
+    for j in (0, 5, 2):
+        a, b = order[j], order[j + 1]
+        ora = oracle_mod.Oracle(n_pyr=4, math_mode=0, reduce_mode=0)
+        ora.set_target(*uniq[a])
+        ora.set_source(*uniq[b])
+        st, pose_libm = ora.align360(np.eye(4), 2)
+        assert st == 0 and pairwise[(a, b)][2] == list(ora.result.iters)[:4], (j, pairwise[(a, b)][2], list(ora.result.iters)[:4])
+        rot, trans = synth.pose_error(poses[j], pose_libm)
+        assert rot <= ROT_TOL and trans <= TRANS_TOL, (j, rot, trans)
+        T_gt = np.linalg.inv(synth.trajectory_pose(a, 7)) @ synth.trajectory_pose(b, 7)
+        rot, trans = synth.pose_error(poses[j], T_gt)
+        assert rot < 5e-4 and trans < 2e-3, (j, rot, trans)
+    # size-independent property of the walk: a pair and its reverse are inverse motions
+    fwd, bwd = pairwise[(0, 1)][0].astype(np.float64), pairwise[(1, 0)][0].astype(np.float64)
+    rot, trans = synth.pose_error(fwd @ bwd, np.eye(4))
+    assert rot < 2e-4 and trans < 1e-3, (rot, trans)
+    # occlusion-aware sequence at full size, one pair (+ its neighbour so that a frame is reused)
+    po, so, io = reg.alignSequence([uniq[0], uniq[1], uniq[2]], method=2, occlusion=2)
+    for j in range(2):
+        one.setTargetFrame(*uniq[j])
+        one.setSourceFrame(*uniq[j + 1])
+        rc = one.alignFrames360(np.eye(4), 2, 2)
+        assert rc == so[j] == 0 and list(io[j])[:4] == list(one.num_iterations)
+        assert np.array_equal(po[j], one.getOptimalPose()), j
+    ora = oracle_mod.Oracle(n_pyr=4, math_mode=0, reduce_mode=0)
+    ora.set_target(*uniq[0])
+    ora.set_source(*uniq[1])
+    st, pose_libm = ora.align360(np.eye(4), 2, 2)
+    assert st == 0 and list(io[0])[:4] == list(ora.result.iters)[:4], (list(io[0]), list(ora.result.iters)[:4])
+    rot, trans = synth.pose_error(po[0], pose_libm)
+    assert rot <= ROT_TOL and trans <= TRANS_TOL, (rot, trans)
 
 
 def test_sequence_batch_matches_pairwise_alignment(hip_lib, oracle_mod):
@@ -539,6 +681,7 @@ def test_ragged_sizes_match_oracle(hip_lib, oracle_mod, W, H, n_pyr):
     rot, trans = synth.pose_error(reg.getOptimalPose(), pose_ref)
     assert rot <= POSE_TOL_DEV and trans <= POSE_TOL_DEV
     assert reg.num_iterations == list(ora.result.iters)[:n_pyr]
+    _assert_libm_oracle_agrees(reg, ora, 2, n_pyr, status=st)
 
 
 def test_non_default_parameters_match_oracle(hip_lib, oracle_mod, small_pair):
@@ -567,6 +710,7 @@ def test_non_default_parameters_match_oracle(hip_lib, oracle_mod, small_pair):
     st, pose_ref = ora.align360(np.eye(4), 2)
     rot, trans = synth.pose_error(reg.getOptimalPose(), pose_ref)
     assert rc == st == 0 and rot <= POSE_TOL_DEV and trans <= POSE_TOL_DEV
+    _assert_libm_oracle_agrees(reg, ora, 2, 2)
 
 
 def _fake_rig(seed=3, rows=60, cols=80):
@@ -756,6 +900,8 @@ def test_align_occlusion_matches_oracle(hip_lib, oracle_mod, small_pair, occlusi
     # the alignment still lands near the true motion (the billboard is a moving outlier for the room)
     rot, trans = synth.pose_error(reg.getOptimalPose(), T)
     assert rot < 0.02 and trans < 0.05, (rot, trans)
+    # and against the reference-faithful libm oracle (sequential semantics of RPI.h:3232-4249): north-star tolerance
+    _assert_libm_oracle_agrees(reg, ora, method, 3, occlusion)
 
 
 def test_occlusion1_single_modality_returns_guess(hip_lib, oracle_mod, small_pair):
