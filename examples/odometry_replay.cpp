@@ -169,7 +169,7 @@ int main(int argc, char** argv) {
         else align360.promoteSourceToTarget();          // frame1 is last step's frame2: already on the device
         align360.setSourceFrame(frame2.sphereRGB, frame2.sphereDepth);                          // :190
         align360.alignFrames360(guess, rgbd360::RegisterPhotoICP::PHOTO_DEPTH);                 // :192
-        const rgbd360::Mat4f rel = align360.getOptimalPose();                                   // :193
+        const rgbd360::Mat4f rel = align360.getOptimalPosePod();                                  // :193
         currentPose = mul(currentPose, rel);                                                    // :257
         printf("pair %d status %d sso %.4f rel_t %.5f %.5f %.5f pose_t %.5f %.5f %.5f\n", k - 1, align360.status(), align360.SSO,
                rel(0, 3), rel(1, 3), rel(2, 3), currentPose(0, 3), currentPose(1, 3), currentPose(2, 3));

@@ -3,9 +3,14 @@
 // same method names, argument meaning and error behaviour, so call sites such as OdometryRGBD360.cpp:189-193,
 // OdometryKeyFrame360.cpp:244-253, LoopClosure360.h:306-321 compile against it unchanged apart from the include.
 //
-// The adapter is header-only and depends on nothing but the C ABI.  When Eigen / OpenCV headers are present
-// (they are not in the build container) the overloads taking Eigen::Matrix4f / cv::Mat are enabled as well;
-// otherwise the POD Mat4f / ImageView types below are used.
+// The adapter is header-only and depends on nothing but the C ABI.  When Eigen / OpenCV headers are present the class has
+// the reference's own signatures -- setTargetFrame(cv::Mat&, cv::Mat&), alignFrames360(Eigen::Matrix4f, costFuncType, int),
+// Eigen::Matrix4f getOptimalPose(), Eigen::Matrix<float,6,6> getHessian(), Eigen::Matrix<float,6,1> getGradient()
+// (RPI.h:273-288, 480-516, 4519) -- so the reference's call sites compile against it character for character
+// (tests/test_cpp_adapter.py compiles OdometryRGBD360.cpp:189-193, LoopClosure360.h:306-323 and KFsphere_SLAM.cpp:398-402 in
+// place against mock Eigen / OpenCV headers; include/rgbd360/compat/RegisterPhotoICP.h puts the class into the global
+// namespace under the reference's header name).  Without them (the build container has neither) the same names return the
+// POD Mat4f / Mat6f types below; the POD forms are always available as getOptimalPosePod() / getHessianPod() / getGradientPod().
 #pragma once
 
 #include <array>
@@ -58,7 +63,8 @@ class RegisterPhotoICP {
    public:
     enum costFuncType { PHOTO_CONSISTENCY, DEPTH_CONSISTENCY, PHOTO_DEPTH };   // RPI.h:194
 
-    // public fields of the reference (RPI.h:177-189)
+    // public fields of the reference (RPI.h:177-189); num_iterations (RPI.h:177) is filled by every alignment
+    std::vector<int> num_iterations;
     float SSO = 0.f;
     float avResidual = 0.f;
     double avPhotoResidual = 0.0, avDepthResidual = 0.0;
@@ -102,8 +108,12 @@ class RegisterPhotoICP {
     }
 
     // RPI.h:4519-4784.  void like the reference; `status()` tells ill-posed (1) / no valid pixels (2).
+#ifdef RGBD360_HAVE_EIGEN      // (the defaults live on the Eigen overloads below, as in the reference)
+    void alignFrames360(const Mat4f& pose_guess, costFuncType method = PHOTO_CONSISTENCY, int occlusion = 0) {
+#else
     void alignFrames360(const Mat4f& pose_guess = Mat4f::Identity(), costFuncType method = PHOTO_CONSISTENCY,
                         int occlusion = 0) {
+#endif
         rgbd360_result r;
         const int rc = rgbd360_align360(ctx(), pose_guess.m, (int)method, occlusion, relPose_.m, &r);
         if (rc < 0) throw std::runtime_error(std::string("rgbd360_align360: ") + rgbd360_last_error(ctx_));
@@ -114,11 +124,15 @@ class RegisterPhotoICP {
         avResidual = rc == RGBD360_ILL_POSED ? 0.f : (float)r.err_final;      // RPI.h:4688
         avPhotoResidual = r.rms_photo;
         avDepthResidual = r.rms_depth;
-        num_iterations_.assign(r.iters, r.iters + p_.n_pyr);
+        num_iterations.assign(r.iters, r.iters + p_.n_pyr);
     }
 
     // RPI.h:4254-4512: pinhole single-sensor alignment (Levenberg-Marquardt), occlusion 0.
+#ifdef RGBD360_HAVE_EIGEN
+    void alignFrames(const Mat4f& pose_guess, costFuncType method = PHOTO_CONSISTENCY, int occlusion = 0) {
+#else
     void alignFrames(const Mat4f& pose_guess = Mat4f::Identity(), costFuncType method = PHOTO_CONSISTENCY, int occlusion = 0) {
+#endif
         rgbd360_result r;
         const int rc = rgbd360_align_pinhole(ctx(), pose_guess.m, (int)method, occlusion, relPose_.m, &r);
         if (rc < 0) throw std::runtime_error(std::string("rgbd360_align_pinhole: ") + rgbd360_last_error(ctx_));
@@ -128,7 +142,7 @@ class RegisterPhotoICP {
         avResidual = (float)r.err_final;
         avPhotoResidual = r.rms_photo;
         avDepthResidual = r.rms_depth;
-        num_iterations_.assign(r.iters, r.iters + p_.n_pyr);
+        num_iterations.assign(r.iters, r.iters + p_.n_pyr);
     }
 
     // The frame loop of OdometryRGBD360.cpp:141-297 as one call (rgbd360_align360_batch): pair j aligns frame j+1 (source)
@@ -161,10 +175,16 @@ class RegisterPhotoICP {
         return poses;
     }
 
+    // results as PODs (always), and under the reference's names: Eigen types when Eigen is there (below), else the PODs
+    Mat4f getOptimalPosePod() const { return relPose_; }
+    Mat6f getHessianPod() const { return hessian_; }
+    std::array<float, 6> getGradientPod() const { return gradient_; }
+#ifndef RGBD360_HAVE_EIGEN
     Mat4f getOptimalPose() const { return relPose_; }          // RPI.h:273
     Mat6f getHessian() const { return hessian_; }              // RPI.h:279
-    std::array<float, 6> getGradient() const { return gradient_; }
-    const std::vector<int>& numIterations() const { return num_iterations_; }
+    std::array<float, 6> getGradient() const { return gradient_; }     // RPI.h:285
+#endif
+    const std::vector<int>& numIterations() const { return num_iterations; }
     int status() const { return status_; }
 
 #ifdef RGBD360_HAVE_OPENCV
@@ -178,19 +198,65 @@ class RegisterPhotoICP {
     }
 #endif
 #ifdef RGBD360_HAVE_EIGEN
-    void setCameraMatrix(Eigen::Matrix3f& camMat) { setCameraMatrix(camMat(0, 0), camMat(1, 1), camMat(0, 2), camMat(1, 2)); }
-    void alignFrames(const Eigen::Matrix4f pose_guess, costFuncType method = PHOTO_CONSISTENCY, int occlusion = 0) {
+    void setCameraMatrix(Eigen::Matrix3f& camMat) { setCameraMatrix(camMat(0, 0), camMat(1, 1), camMat(0, 2), camMat(1, 2)); }     // RPI.h:254-257
+    // RPI.h:4254 / 4519: by-value Eigen guess with the reference's defaults
+    void alignFrames(const Eigen::Matrix4f pose_guess = Eigen::Matrix4f::Identity(), costFuncType method = PHOTO_CONSISTENCY, int occlusion = 0) {
         Mat4f g;
         std::memcpy(g.m, pose_guess.data(), sizeof(g.m));
         alignFrames(g, method, occlusion);
     }
-    void alignFrames360(const Eigen::Matrix4f pose_guess, costFuncType method = PHOTO_CONSISTENCY, int occlusion = 0) {
+    void alignFrames360(const Eigen::Matrix4f pose_guess = Eigen::Matrix4f::Identity(), costFuncType method = PHOTO_CONSISTENCY, int occlusion = 0) {
         Mat4f g;
         std::memcpy(g.m, pose_guess.data(), sizeof(g.m));
         alignFrames360(g, method, occlusion);
     }
-    Eigen::Matrix4f getOptimalPoseEigen() const { return Eigen::Map<const Eigen::Matrix4f>(relPose_.m); }
-    Eigen::Matrix<float, 6, 6> getHessianEigen() const { return Eigen::Map<const Eigen::Matrix<float, 6, 6>>(hessian_.m); }
+    // RPI.h:273-288: the reference's return types (column-major storage on both sides, hence plain copies)
+    Eigen::Matrix4f getOptimalPose() const {
+        Eigen::Matrix4f T;
+        std::memcpy(T.data(), relPose_.m, sizeof(relPose_.m));
+        return T;
+    }
+    Eigen::Matrix<float, 6, 6> getHessian() const {
+        Eigen::Matrix<float, 6, 6> H;
+        std::memcpy(H.data(), hessian_.m, sizeof(hessian_.m));
+        return H;
+    }
+    Eigen::Matrix<float, 6, 1> getGradient() const {
+        Eigen::Matrix<float, 6, 1> g;
+        std::memcpy(g.data(), gradient_.data(), sizeof(float) * 6);
+        return g;
+    }
+    Eigen::Matrix4f getOptimalPoseEigen() const { return getOptimalPose(); }                 // (round-2 names, kept)
+    Eigen::Matrix<float, 6, 6> getHessianEigen() const { return getHessian(); }
+    // RPI.h:171: LUT_xyz_sphere of pyramid level `level` as the reference keeps it (a download: the alignment itself never needs it on the host)
+    std::vector<Eigen::Vector3f> LUT_xyz_sphere;
+    void downloadLUT(int level) {
+        int rows = 0, cols = 0;
+        if (rgbd360_level_dims(ctx(), level, &rows, &cols) != 0) throw std::runtime_error(std::string("rgbd360_level_dims: ") + rgbd360_last_error(ctx_));
+        std::vector<float> xyz((size_t)rows * cols * 3);
+        if (rgbd360_get_lut(ctx_, level, xyz.data()) != 0) throw std::runtime_error(std::string("rgbd360_get_lut: ") + rgbd360_last_error(ctx_));
+        LUT_xyz_sphere.resize((size_t)rows * cols);
+        for (size_t i = 0; i < LUT_xyz_sphere.size(); ++i) std::memcpy(LUT_xyz_sphere[i].data(), &xyz[3 * i], 3 * sizeof(float));
+    }
+#endif
+#ifdef RGBD360_HAVE_OPENCV
+    // RPI.h:198-199: the public pyramids (CV_32FC1 per level).  They live in HBM; downloadPyramids() fills the vectors for
+    // callers that read them (RegisterRGBD360.h:385-388 does; the alignment itself never needs them on the host).
+    std::vector<cv::Mat> graySrcPyr, grayTrgPyr, depthSrcPyr, depthTrgPyr, grayTrgGradXPyr, grayTrgGradYPyr, depthTrgGradXPyr, depthTrgGradYPyr;
+    void downloadPyramids() {
+        std::vector<cv::Mat>* dst[8] = {&graySrcPyr, &grayTrgPyr, &depthSrcPyr, &depthTrgPyr, &grayTrgGradXPyr, &grayTrgGradYPyr, &depthTrgGradXPyr, &depthTrgGradYPyr};
+        for (int which = 0; which < 8; ++which) {
+            dst[which]->resize((size_t)p_.n_pyr);
+            for (int level = 0; level < p_.n_pyr; ++level) {
+                int rows = 0, cols = 0;
+                if (rgbd360_level_dims(ctx(), level, &rows, &cols) != 0) throw std::runtime_error(std::string("rgbd360_level_dims: ") + rgbd360_last_error(ctx_));
+                cv::Mat& m = (*dst[which])[(size_t)level];
+                m.create(rows, cols, CV_32FC1);
+                if (rgbd360_get_plane(ctx_, which, level, reinterpret_cast<float*>(m.data)) != 0)
+                    throw std::runtime_error(std::string("rgbd360_get_plane: ") + rgbd360_last_error(ctx_));
+            }
+        }
+    }
 #endif
 
     // The library context behind this object (created on first use) for the calls that have no RegisterPhotoICP counterpart:
@@ -203,7 +269,6 @@ class RegisterPhotoICP {
     Mat4f relPose_ = Mat4f::Identity();
     Mat6f hessian_{};
     std::array<float, 6> gradient_{};
-    std::vector<int> num_iterations_;
     int status_ = 0;
     float cam_[4] = {0.f, 0.f, 0.f, 0.f};
     bool have_cam_ = false;
@@ -242,8 +307,23 @@ bool Register(FrameLike& trg, FrameLike& src, Mat4f& pose, ToView to_view,
     r.setTargetFrame(to_view(trg.sphereRGB), to_view(trg.sphereDepth));
     r.setSourceFrame(to_view(src.sphereRGB), to_view(src.sphereDepth));
     r.alignFrames360(pose, method);
+    pose = r.getOptimalPosePod();
+    return r.status() == 0;
+}
+
+#if defined(RGBD360_HAVE_EIGEN) && defined(RGBD360_HAVE_OPENCV)
+// ... and with the reference's own types: frames whose sphereRGB / sphereDepth are cv::Mat (Frame360.h:104-111), an Eigen pose.
+template <class FrameLike>
+bool Register(FrameLike& trg, FrameLike& src, Eigen::Matrix4f& pose,
+              RegisterPhotoICP::costFuncType method = RegisterPhotoICP::PHOTO_DEPTH, RegisterPhotoICP* reg = nullptr) {
+    RegisterPhotoICP local;
+    RegisterPhotoICP& r = reg ? *reg : local;
+    r.setTargetFrame(trg.sphereRGB, trg.sphereDepth);
+    r.setSourceFrame(src.sphereRGB, src.sphereDepth);
+    r.alignFrames360(pose, method);
     pose = r.getOptimalPose();
     return r.status() == 0;
 }
+#endif
 
 }  // namespace rgbd360

@@ -316,7 +316,7 @@ bool RegisterFrames(FrameLike& ref, FrameLike& cur, Mat4f& pose, ToView to_view,
     dense.setTargetFrame(to_view(ref.sphereRGB), to_view(ref.sphereDepth));
     dense.setSourceFrame(to_view(cur.sphereRGB), to_view(cur.sphereDepth));
     dense.alignFrames360(guess, method);
-    pose = dense.getOptimalPose();
+    pose = dense.getOptimalPosePod();
     if (dense.status() != 0) return false;
     if (planes_ok) {                                     // Eigen's isApprox(b, p): ||a - b|| <= p min(||a||, ||b||), Frobenius
         double diff = 0, na = 0, nb = 0;

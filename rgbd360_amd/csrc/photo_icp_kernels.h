@@ -847,7 +847,6 @@ struct SolveShared {
     GNState sst;
     double red[kSolveThreads / kNumPartials][kNumPartials];
     float shH[36], shM[36], shInv[36], shE[16], shCand[16], shUpd[6];
-    float prevCand[16], prevUpd[6];           // fused launch: what an ILL-POSED verdict restores
     int shGo, shRank, shLuOk;
     unsigned long long stamp0, stamp[8];      // diagnostic build only (RGBD360_SOLVE_STAMPS)
 };
@@ -1071,17 +1070,12 @@ __device__ __forceinline__ void solve_waves(SolveShared& sh, const SolveCfg& cfg
 }
 
 // solve_finish (behind a barrier that follows solve_waves): commits the step or the ILL-POSED status, hands a finished level over to
-// the next finer one.  use_rank = false: the rank test has not run yet -- the step is committed on the inverse's word alone and the
-// values an ILL-POSED verdict restores are kept in sh.prevCand / prevUpd (solve_rank_verdict).
-__device__ __forceinline__ void solve_finish(SolveShared& sh, const SolveCfg& cfg, const bool use_rank) {
+// the next finer one.  (k_eval_fs restates these few decisions without barriers: keep the two in step.)
+__device__ __forceinline__ void solve_finish(SolveShared& sh, const SolveCfg& cfg) {
     const int tid = threadIdx.x;
     GNState* st = &sh.sst;
     if (sh.shGo) {
-        const bool ill = (use_rank && sh.shRank != 6) || !sh.shLuOk;
-        if (!use_rank && tid < 16) {
-            sh.prevCand[tid] = sh.sst.cand[tid];
-            if (tid < 6) sh.prevUpd[tid] = sh.sst.update[tid];
-        }
+        const bool ill = (sh.shRank != 6) || !sh.shLuOk;
         if (ill) {
             if (tid == 0) {
                 st->status = 1;      // "The problem is ILL-POSED": relPose = pose_estim, return   RPI.h:4684-4689
@@ -1117,7 +1111,7 @@ __device__ __forceinline__ void solve_staged(SolveShared& sh, const SolveCfg& cf
     const float lam_spec = solve_totals(sh);
     solve_waves(sh, cfg, lam_spec, true);
     __syncthreads();            // bookkeeping (wave 0), inverse (wave 1) and rank (wave 2) are all done
-    solve_finish(sh, cfg, true);
+    solve_finish(sh, cfg);
 }
 
 __device__ __forceinline__ void solve_block(GNState* st_g, const double* __restrict__ partials, const int nb, const SolveCfg& cfg) {
@@ -1268,56 +1262,74 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_fs(const GNState* __restr
     const float4 sA = buf_load_f4(bufs.src, (unsigned)i << 4);
     const float4 sB = buf_load_f4(bufs.src, (unsigned)(i + kEvalThreads) << 4);
     float lam_spec = 0.f;
+    int solved_level = 0;
     if (pend > 0) {                             // uniform: the previous launch ran a pass
         SolveCfg c = cfg;
-        c.level = sh.sst.level_active;          // the level that pass belongs to (it ran because this level was active)
+        c.level = solved_level = sh.sst.level_active;      // the level that pass belongs to (it ran because this level was active)
         c.n_pixels = sh.sst.pend_npix;
         lam_spec = solve_totals(sh);
         solve_waves(sh, c, lam_spec, /*rank_now=*/false);
         __syncthreads();
-        // the step is committed on the inverse's word; the rank test (the longest of the three chains, and almost never the one that
-        // says no) runs on ONE wave of block 0 while everybody else is already evaluating pixels, see below
-        solve_finish(sh, c, /*use_rank=*/false);
     }
-    const bool run = !(sh.sst.done | (sh.sst.level_active != level));      // uniform; as k_eval's gate
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        sh.sst.pend_nb = run ? nb : 0;
-        sh.sst.pend_npix = lv.n;
-#ifdef RGBD360_SOLVE_STAMPS
-        sh.stamp[4] = __builtin_amdgcn_s_memrealtime() - sh.stamp0;
-        for (int k = 0; k < 8; ++k) sh.sst.stamps[k] = sh.stamp[k];
-#endif
-    }
-    __syncthreads();
-    if (b == 0 && (threadIdx.x >> 6) == 2) {
-        // block 0, wave 2: the rank verdict on the step just committed, then the new state.  ILL-POSED (RPI.h:4684-4689): status 1,
-        // level done, candidate and update as they were -- and no pending pass: the rows this launch writes are never read.
-        const int lane = threadIdx.x & 63;
-        bool ill_late = false;
-        if (pend > 0 && sh.shGo && sh.shLuOk) {
-            ill_late = solve_rank_wave(sh, lam_spec) != 6;      // (the return value: a lane that did not store shRank may not see it without a barrier)
-        }
-        // one store per word: the staged state, with the words an ILL-POSED verdict changes patched on the way
-        constexpr int kCand = offsetof(GNState, cand) / 4, kUpd = offsetof(GNState, update) / 4;
-        for (int w = lane; w < kStateWords; w += 64) {
-            int val = reinterpret_cast<const int*>(&sh.sst)[w];
-            if (ill_late) {
-                if (w >= kCand && w < kCand + 16) val = __builtin_bit_cast(int, sh.prevCand[w - kCand]);
-                if (w >= kUpd && w < kUpd + 6) val = __builtin_bit_cast(int, sh.prevUpd[w - kUpd]);
-                if (w == offsetof(GNState, status) / 4 || w == offsetof(GNState, done) / 4) val = 1;
-                if (w == offsetof(GNState, pend_nb) / 4) val = 0;
-            }
-            reinterpret_cast<int*>(st_out)[w] = val;
-        }
-    }
-    if (!run) return;
-    const float* P = sh.sst.cand;
+    // What solve_finish would now do to the state -- commit the step (on the inverse's word: the rank test, the longest of the three
+    // chains and almost never the one that says no, comes later), or ILL-POSED, or hand a finished level over to the next finer
+    // one -- is DECIDED here by every wave from what the three working waves left in LDS, without another barrier; nothing in LDS
+    // is written any more.  Only block 0 needs the new state itself: its wave 2 assembles it word by word on the way to memory.
+    const bool go = pend > 0 && sh.shGo != 0;
+    const bool commit = go && sh.shLuOk != 0;
+    const bool ill = go && !commit;
+    const bool handover = pend > 0 && !go && !cfg.forced && solved_level > 0 && sh.sst.done && sh.sst.status == 0;      // solve_finish's test
+    const int level_now = handover ? solved_level - 1 : sh.sst.level_active;
+    const bool done_now = handover ? false : (ill || sh.sst.done != 0);
+    const bool run = !done_now && level_now == level;      // uniform; k_eval's gate on the new state
+    const float* P = commit ? sh.shCand : (handover ? sh.sst.pose : sh.sst.cand);      // the pose the new state's `cand` holds
     PoseRT T;
     T.r00 = uniform_f(P[0]); T.r10 = uniform_f(P[1]); T.r20 = uniform_f(P[2]);
     T.r01 = uniform_f(P[4]); T.r11 = uniform_f(P[5]); T.r21 = uniform_f(P[6]);
     T.r02 = uniform_f(P[8]); T.r12 = uniform_f(P[9]); T.r22 = uniform_f(P[10]);
     T.tx = uniform_f(P[12]); T.ty = uniform_f(P[13]); T.tz = uniform_f(P[14]);
+    if (b == 0 && (threadIdx.x >> 6) == 2) {
+        // block 0, wave 2: the rank verdict on the step just committed, then the new state.  ILL-POSED (RPI.h:4684-4689): status 1,
+        // level done, candidate and update as they were -- and no pending pass: the rows this launch writes are never read.
+        const int lane = threadIdx.x & 63;
+        bool ill_late = false;
+        if (commit) ill_late = solve_rank_wave(sh, lam_spec) != 6;      // (the return value: a lane that did not store shRank may not see it without a barrier)
+        const bool commit_f = commit && !ill_late, ill_f = ill || ill_late, run_f = run && !ill_late;
+        constexpr int kCand = offsetof(GNState, cand) / 4, kUpd = offsetof(GNState, update) / 4;
+        constexpr int kErr = offsetof(GNState, error) / 4, kLam = offsetof(GNState, lambda) / 4;
+        static_assert(offsetof(GNState, new_error) == offsetof(GNState, error) + 8 && offsetof(GNState, diff_error) == offsetof(GNState, error) + 16, "error block");
+        for (int w = lane; w < kStateWords; w += 64) {      // one store per word
+            int val = reinterpret_cast<const int*>(&sh.sst)[w];
+            if (w >= kCand && w < kCand + 16) {
+                if (commit_f) val = __builtin_bit_cast(int, sh.shCand[w - kCand]);
+                if (handover) val = __builtin_bit_cast(int, sh.sst.pose[w - kCand]);
+            }
+            if (w >= kUpd && w < kUpd + 6) {
+                if (commit_f) val = __builtin_bit_cast(int, sh.shUpd[w - kUpd]);
+                if (handover) val = __builtin_bit_cast(int, 1.f);
+            }
+            if (ill_f && (w == offsetof(GNState, status) / 4 || w == offsetof(GNState, done) / 4)) val = 1;
+            if (handover) {       // RPI.h:4590-4604: it = 0, update = (1,..,1), lambda = 1, first pass at the pose reached
+                if (w == offsetof(GNState, level_active) / 4) val = level_now;
+                if (w == offsetof(GNState, it) / 4 || w == offsetof(GNState, done) / 4) val = 0;
+                if (w == offsetof(GNState, first) / 4) val = 1;
+                if (w >= kErr && w < kErr + 6) val = 0;                  // error = new_error = diff_error = 0.0
+                if (w == kLam) val = 0;                                   // lambda = 1.0 (little endian: low word, high word)
+                if (w == kLam + 1) val = 0x3FF00000;
+            }
+            if (w == offsetof(GNState, pend_nb) / 4) val = run_f ? nb : 0;
+            if (w == offsetof(GNState, pend_npix) / 4) val = lv.n;
+#ifdef RGBD360_SOLVE_STAMPS
+            if (w >= (int)offsetof(GNState, stamps) / 4 && w < (int)offsetof(GNState, stamps) / 4 + 16) {
+                const int si = (w - (int)offsetof(GNState, stamps) / 4) >> 1;      // slot 4 ("end"): now
+                const unsigned long long sv = si == 4 ? __builtin_amdgcn_s_memrealtime() - sh.stamp0 : sh.stamp[si];
+                val = (int)((w & 1) ? (sv >> 32) : (sv & 0xffffffffull));
+            }
+#endif
+            reinterpret_cast<int*>(st_out)[w] = val;
+        }
+    }
+    if (!run) return;
     const WarpConsts wc = make_warp_consts(T, lv);
     ESTAMP(0);
     PixW wA;

@@ -178,3 +178,114 @@ def test_register_pair_planes_on_a_synthetic_rig(tmp_path, hip_lib):
     T = np.array([[float(x) for x in l.split()] for l in out[2:6]])
     rot, tr = synth.pose_error(T, M)
     assert rot < math.radians(0.3) and tr < 0.015, (rot, tr)
+
+
+# ---- the reference's own signatures (Eigen / cv::Mat) on the adapter: compiled against mock headers ------------------------------
+MOCK = os.path.join(ROOT, "tests", "mock_headers")
+REF = "/root/reference"
+
+_HARNESS_HEAD = r'''
+#include <iostream>
+#include <map>
+#include <utility>
+#include <vector>
+#include <RegisterPhotoICP.h>      // include/rgbd360/compat/RegisterPhotoICP.h: the reference's header name, class in the global namespace
+#ifndef RGBD360_HAVE_EIGEN
+#error "the mock Eigen headers were not picked up"
+#endif
+#ifndef RGBD360_HAVE_OPENCV
+#error "the mock OpenCV headers were not picked up"
+#endif
+using namespace std;
+namespace pcl { inline double getTime() { return 0.0; } }
+struct Frame360 { cv::Mat sphereRGB, sphereDepth; };
+struct Map360 {
+    std::vector<Frame360*> vpSpheres;
+    std::map<unsigned, std::map<unsigned, std::pair<Eigen::Matrix4f, Eigen::Matrix<float,6,6> > > > mmConnectionKFs;
+};
+struct Optimizer { void addEdge(int, int, const Eigen::Matrix<double,4,4>&, const Eigen::Matrix<double,6,6>&) {} };
+'''
+
+
+def _compile(tmp_path, name, source, link=False):
+    from rgbd360_amd import build
+    src = tmp_path / (name + ".cpp")
+    src.write_text(source)
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Werror=return-type", "-I" + MOCK, "-I" + os.path.join(ROOT, "include", "rgbd360", "compat"),
+           "-I" + os.path.join(ROOT, "include"), str(src)]
+    if link:
+        lib = build.build()
+        exe = str(tmp_path / name)
+        subprocess.check_call(cmd + ["-L" + os.path.dirname(lib), "-lrgbd360_hip", "-Wl,-rpath," + os.path.dirname(lib), "-o", exe])
+        return exe
+    subprocess.check_call(cmd + ["-c", "-o", str(tmp_path / (name + ".o"))])
+    return None
+
+
+def test_adapter_has_the_reference_signatures_with_eigen_and_opencv(tmp_path):
+    """With Eigen / OpenCV on the include path (here: the mock headers of tests/mock_headers) the adapter's public surface is the
+    reference's (RPI.h:171-199, 273-288, 480-516, 4254, 4519): cv::Mat frames, by-value Eigen::Matrix4f guesses with the reference's
+    defaults, Eigen return types that multiply and convert like the call sites need, public num_iterations / pyramids / LUT.
+    The RGBD360_HAVE_EIGEN / RGBD360_HAVE_OPENCV branches of the header are compiled AND linked here (no GPU needed for that)."""
+    body = _HARNESS_HEAD + r'''
+#include <type_traits>
+static_assert(std::is_same<decltype(std::declval<RegisterPhotoICP&>().getOptimalPose()), Eigen::Matrix4f>::value, "RPI.h:273");
+static_assert(std::is_same<decltype(std::declval<RegisterPhotoICP&>().getHessian()), Eigen::Matrix<float,6,6> >::value, "RPI.h:279");
+static_assert(std::is_same<decltype(std::declval<RegisterPhotoICP&>().getGradient()), Eigen::Matrix<float,6,1> >::value, "RPI.h:285");
+static_assert(std::is_same<decltype(RegisterPhotoICP::num_iterations), std::vector<int> >::value, "RPI.h:177");
+static_assert(std::is_same<decltype(RegisterPhotoICP::graySrcPyr), std::vector<cv::Mat> >::value, "RPI.h:198");
+static_assert(std::is_same<decltype(RegisterPhotoICP::LUT_xyz_sphere), std::vector<Eigen::Vector3f> >::value, "RPI.h:171");
+int main(int argc, char**) {
+    if (argc < 2) return 3;                       // (never run without a GPU: this is a compile + link check)
+    Frame360 a, b;
+    a.sphereRGB.create(8, 16, CV_8UC3); a.sphereDepth.create(8, 16, CV_16UC1);
+    b.sphereRGB.create(8, 16, CV_8UC3); b.sphereDepth.create(8, 16, CV_16UC1);
+    RegisterPhotoICP align360;
+    align360.setNumPyr(1);
+    align360.setTargetFrame(a.sphereRGB, a.sphereDepth);
+    align360.setSourceFrame(b.sphereRGB, b.sphereDepth);
+    align360.alignFrames360();                                            // the reference's defaults (RPI.h:4519)
+    align360.alignFrames360(Eigen::Matrix4f::Identity(), RegisterPhotoICP::PHOTO_DEPTH, 2);
+    Eigen::Matrix3f K = Eigen::Matrix3f::Identity();
+    align360.setCameraMatrix(K);
+    align360.alignFrames(Eigen::Matrix4f::Identity(), RegisterPhotoICP::PHOTO_DEPTH);
+    Eigen::Matrix4f T = align360.getOptimalPose();
+    Eigen::Matrix<double,6,6> info = align360.getHessian().cast<double>();
+    Eigen::Matrix<float,6,1> g = align360.getGradient();
+    align360.downloadPyramids();
+    align360.downloadLUT(0);
+    Eigen::Matrix4f guess = Eigen::Matrix4f::Identity();
+    const bool ok = rgbd360::Register(a, b, guess);                        // bool Register(Frame360&, Frame360&, Eigen::Matrix4f&)
+    std::cout << T << "\n" << info(0, 0) << " " << g(0) << " " << align360.num_iterations.size() << " " << align360.graySrcPyr.size() << " " << ok << std::endl;
+    return 0;
+}
+'''
+    exe = _compile(tmp_path, "eigen_surface", body, link=True)
+    assert subprocess.call([exe]) == 3
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reads the reference's call sites in place (build container only)")
+def test_reference_call_sites_compile_character_for_character(tmp_path):
+    """The north star's "drops into OdometryRGBD360 ... unchanged": the lines of the reference's applications that use
+    RegisterPhotoICP are read IN PLACE from /root/reference (nothing of them is stored in this repository), pasted unmodified into
+    function bodies whose parameters stand for the surrounding variables, and compiled against the adapter with the mock Eigen /
+    OpenCV headers: OdometryRGBD360.cpp:189-193, LoopClosure360.h:306-323, KFsphere_SLAM.cpp:144-153 and :399-402."""
+    def lines(path, lo, hi):
+        with open(os.path.join(REF, path), encoding="latin-1") as f:
+            src = f.read().splitlines()
+        out = "\n".join(src[lo - 1:hi])
+        assert "align360" in out
+        return out
+    body = _HARNESS_HEAD + "\nvoid odometry_site(Frame360* frame360_1, Frame360* frame360_2, RegisterPhotoICP& align360, Eigen::Matrix4f& rigidTransf_dense, const Eigen::Matrix4f& rotOffset) {\n"
+    body += lines("Registration/OdometryRGBD360.cpp", 189, 193)
+    body += "\n}\nvoid loop_closure_site(Map360& Map, Frame360* newKF, unsigned compareLocalIdx, unsigned newFrameID, Eigen::Matrix4f rotOffset, Eigen::Matrix4f relativePose,\n"
+    body += "                       Optimizer& optimizer, std::map<unsigned, std::map<unsigned, float> >& connectionsLC) {\n"
+    body += lines("include/LoopClosure360.h", 306, 323)
+    body += "\n}\nvoid keyframe_site(Map360& Map, unsigned nearestKF, Frame360* candidateKF, std::pair<Eigen::Matrix4f, Eigen::Matrix<float,6,6> > candidateKF_connection,\n"
+    body += "                   RegisterPhotoICP& align360, Eigen::Matrix4f rotOffset) {\n"
+    body += lines("SLAM/KFsphere_SLAM.cpp", 144, 153)
+    body += "\n}\nvoid candidate_site(Frame360*& candidateKF, Frame360* frame360, std::pair<Eigen::Matrix4f, Eigen::Matrix<float,6,6> >& candidateKF_connection,\n"
+    body += "                    float& candidateKF_sso, RegisterPhotoICP& align360, Eigen::Matrix4f rigidTransf_dense) {\n"
+    body += lines("SLAM/KFsphere_SLAM.cpp", 399, 402)
+    body += "\n}\n"
+    _compile(tmp_path, "reference_call_sites", body)
