@@ -7,7 +7,9 @@ with torch.distributed.run, one rank per GPU (RCCL).  Rank 0 prints ONE JSON lin
 Step      = one level-0 Gauss-Newton iteration of RegisterPhotoICP::alignFrames360 on one 2048x1024 synthetic
             spherical pair (BASELINE.json configs[1]: photometric-only), in the forced schedule of BASELINE.md §2
             (accept rule evaluated, step applied regardless): one fused warp+residual+Jacobian pass over every
-            source pixel + the 6x6 solve / pose update launch.  Frames are resident in HBM before the timed region.
+            source pixel + the 6x6 solve / pose update.  Since round 3 that is ONE launch per iteration (k_eval_fs: the solve of
+            the previous pass is the prologue of the next pass's launch; RGBD360_FUSED_SOLVE=0 restores {k_eval, k_solve}).
+            Frames are resident in HBM before the timed region.
 value     = N * K / t, t = the MEDIAN over `--repeats` timed regions of exactly K steps each (every region bracketed by a
             barrier + device synchronisation on both sides, the maximum over the ranks taken per region): with the driver's
             K = 20 a single region is 0.4 ms of wall time, far too short to be one sample.
@@ -15,12 +17,16 @@ N > 1     = weak scaling of `value` (every rank iterates on its own pair, the so
             every timed region), AND the `sequence` block: BASELINE.json configs[3] itself -- 256 consecutive pairs of an
             odometry sequence in contiguous shards over the ranks, every rank aligning its shard with the library's sequence
             entry, one all-gather of poses / status / iteration counts -- as alignments/s of the whole job.
-roofline  = algorithmic bytes of the fused kernel (28 B/px photo, 40 B/px photo+depth, LUT variant)
-            / its average launch duration measured with HIP events on the library's own stream.  At 2048x1024 the kernel's
+roofline  = algorithmic bytes of the dominant kernel (28 B/px photo, 40 B/px photo+depth, LUT variant)
+            / its average launch duration measured with HIP events on the library's own stream.  The dominant kernel of `value` is
+            k_eval_fs (solve prologue + warp/residual/Jacobian pass: a whole Gauss-Newton iteration per launch); `roofline.pass_only`
+            is the per-pixel pass without the prologue (k_eval, the same eval_span body).  At 2048x1024 the kernel's
             working set (84 MB) stays in the 256 MiB Infinity Cache between back-to-back launches: `roofline.resident` says so,
             `roofline_hbm_rotating` repeats the measurement rotating over 5 copies of the pair (420 MB: every launch HBM-fed),
             and `roofline_4096x2048` (335 MB photo+depth) is the single-pair HBM figure.
-iteration = the same bytes over the whole step (pass + solve launch + gaps).
+iteration = the same bytes over the whole step as the host sees it (launch + gaps + the K-step call's fixed cost / K).
+sustained = after the timed regions, one >= 2 s burst of the same forced schedule (not part of `value`): its rate is printed next to
+            `value` as a cross-check, and it is long enough for a utilisation sampler to catch the GPU busy.
 cpu_baseline = the CPU oracle (restatement of the reference algorithm, OpenMP) on the same workload, bounded sample.
 """
 from __future__ import annotations
@@ -61,12 +67,12 @@ def avg_kernel_us(fn, batches=5):
     return vals[len(vals) // 2], vals
 
 
-def roofline_entry(us, batches, n_px, method, **extra):
+def roofline_entry(us, batches, n_px, method, kernel=None, **extra):
     alg = BYTES_PER_PX[method] * n_px
     ach = alg / (us * 1e-6) / 1e9
     slow = max(batches)
     d = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-         "kernel": "k_eval<%d,true>" % method, "kernel_avg_us": us, "kernel_avg_us_batches": batches,
+         "kernel": kernel or "k_eval<%d,true>" % method, "kernel_avg_us": us, "kernel_avg_us_batches": batches,
          "frac_slowest_batch": alg / (slow * 1e-6) / 1e9 / HBM_PEAK_GBS,
          "algorithmic_bytes_per_launch": alg, "bytes_per_pixel": BYTES_PER_PX[method],
          "frac_of_measured_copy_peak": ach / HBM_COPY_GBS}
@@ -194,8 +200,26 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)          # per region: the slowest rank
         elapsed_all = [float(x) for x in tmax.cpu()]
         assert poses is not None and bool(torch.isfinite(poses).all())
+        rccl_ranks_seen = int(poses.numel() // 16)       # rows of the gathered tensor: one 4x4 pose per rank that took part
+    else:
+        rccl_ranks_seen = 1
     srt = sorted(elapsed_all)
     elapsed = srt[len(srt) // 2]
+
+    # ---- sustained burst (NOT part of `value`): the same forced schedule for >= 2 s in few large C calls, so that a utilisation
+    #      sampler sees the GPU busy and the rate cross-checks `value` (which is the median of 25 regions of 0.3 ms) ----
+    burst_steps = max(2000, int(2.2 / max(elapsed / args.steps, 1e-7) / 8))
+    run_burst = reg.forced_iters_call(0, start_pose, method, burst_steps)
+    sync_all()
+    t0 = time.perf_counter()
+    n_burst = 0
+    while time.perf_counter() - t0 < 2.0 or n_burst < 2:
+        run_burst()
+        n_burst += 1
+    torch.cuda.synchronize()
+    burst_s = time.perf_counter() - t0
+    sustained = {"gn_iterations_per_s": n_gpus * n_burst * burst_steps / burst_s, "seconds": burst_s, "steps": n_burst * burst_steps,
+                 "calls": n_burst, "note": "same forced schedule as `value`, one rank's own clock (no barrier inside), not part of `value`"}
 
     value = n_gpus * args.steps / elapsed
     result = {
@@ -211,10 +235,12 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
+        "env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "RGBD360_FUSED_SOLVE": os.environ.get("RGBD360_FUSED_SOLVE", "1 (default)")},
+        "sustained": sustained,
+        "rccl_ranks_seen": rccl_ranks_seen,
         "config": {
             "workload": ("configs[1]: single %dx%d synthetic sphere pair per GPU, %s RegisterPhotoICP, level-0 forced "
-                         "Gauss-Newton iterations (1 fused pass + 1 solve launch each)" % (W, H, METHOD_NAMES[method])),
+                         "Gauss-Newton iterations (one launch each: solve of the previous pass + fused warp/residual/Jacobian pass)" % (W, H, METHOD_NAMES[method])),
             "width": W, "height": H, "method": METHOD_NAMES[method], "n_pyr": 4,
             "pairs_per_gpu": 1, "parallelism": "independent pairs per GPU, RCCL all-gather of poses" if world > 1 else "1 GPU",
         },
@@ -241,22 +267,37 @@ def main():
     if rank == 0:
         # ---- roofline of the dominant kernel: HIP events on the library's stream -----------------------------
         ws = WORKING_SET_PER_PX[method] * n_px
-        kernel_us, kernel_batches = avg_kernel_us(lambda: reg.time_eval_kernel(0, pose_gpu, method, True, 50))
-        traffic = None
+        fused = os.environ.get("RGBD360_FUSED_SOLVE", "1") != "0"
+        kernel_us, kernel_batches = avg_kernel_us(lambda: reg.time_eval_kernel(0, pose_gpu, method, True, 50))       # the pass alone
+        fused_us, fused_batches = (avg_kernel_us(lambda: reg.time_eval_kernel(0, pose_gpu, method, 2, 50)) if fused else (None, None))
+        traffic, traffic_source = None, None
         tr_path = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tr_path):
             try:
                 tr = json.load(open(tr_path))
                 key = "%dx%d_%s" % (W, H, METHOD_NAMES[method])
                 traffic = tr.get(key, {}).get("hbm_bytes_per_launch")
+                if traffic is not None:
+                    traffic_source = ("tracked file profiles/traffic_latest.json (%s): rocprofv3 PMC passes of an earlier run of this workload, "
+                                      "2 x FETCH_SIZE + WRITE_SIZE per launch of the per-pixel pass; NOT collected in this run" % tr.get("collected", "undated"))
             except Exception:
                 traffic = None
-        result["roofline"] = roofline_entry(
-            kernel_us, kernel_batches, n_px, method, traffic=traffic,
-            resident=("infinity_cache" if ws < LLC_BYTES else "hbm"),
-            note=("back-to-back launches over one pair: the %.0f MB working set stays in the 256 MiB Infinity Cache, which is the "
-                  "regime of the product path (every iteration of a level re-reads the same pair); peak is still the HBM spec "
-                  "figure.  roofline_hbm_rotating / roofline_4096x2048 are the HBM-fed measurements." % (ws / 1e6)) if ws < LLC_BYTES else "")
+        res_note = ("back-to-back launches over one pair: the %.0f MB working set stays in the 256 MiB Infinity Cache, which is the "
+                    "regime of the product path (every iteration of a level re-reads the same pair); peak is still the HBM spec "
+                    "figure.  roofline_hbm_rotating / roofline_4096x2048 are the HBM-fed measurements." % (ws / 1e6)) if ws < LLC_BYTES else ""
+        pass_only = roofline_entry(kernel_us, kernel_batches, n_px, method, traffic=traffic, traffic_source=traffic_source,
+                                   resident=("infinity_cache" if ws < LLC_BYTES else "hbm"),
+                                   what="the warp + residual + Jacobian + normal-equation pass alone (k_eval: eval_span without the solve prologue)")
+        if fused:
+            result["roofline"] = roofline_entry(
+                fused_us, fused_batches, n_px, method, kernel="k_eval_fs<%d>" % method, traffic=traffic, traffic_source=traffic_source,
+                resident=("infinity_cache" if ws < LLC_BYTES else "hbm"), note=res_note,
+                what=("the dominant kernel of `value`: ONE launch per Gauss-Newton iteration = solve of the previous pass (reduction of the "
+                      "partial rows, 6x6 inverse, SE(3) exponential; redundantly per block) + the warp/residual/Jacobian pass over every "
+                      "source pixel; back-to-back launches in the forced schedule"),
+                pass_only=pass_only)
+        else:
+            result["roofline"] = dict(pass_only, note=res_note)
         # the same kernel with every launch HBM-fed: rotate over enough copies of the pair to exceed the Infinity Cache
         n_rot = max(2, int(np.ceil(1.6 * LLC_BYTES / ws)))
         rot = [reg]
@@ -269,23 +310,30 @@ def main():
         result["roofline_hbm_rotating"] = {}
         for m in ([] if args.no_rotating else sorted({method, 2})):
             us, bt = avg_kernel_us(lambda: RegisterPhotoICP.time_eval_kernel_rotating(rot, 0, pose_gpu, m, True, 10 * n_rot))
-            result["roofline_hbm_rotating"][METHOD_NAMES[m]] = roofline_entry(
-                us, bt, n_px, m, resident="hbm", copies=n_rot, rotating_working_set_bytes=n_rot * WORKING_SET_PER_PX[m] * n_px)
+            ent = roofline_entry(us, bt, n_px, m, resident="hbm", copies=n_rot, rotating_working_set_bytes=n_rot * WORKING_SET_PER_PX[m] * n_px)
+            if fused:
+                us_f, bt_f = avg_kernel_us(lambda: RegisterPhotoICP.time_eval_kernel_rotating(rot, 0, pose_gpu, m, 2, 10 * n_rot))
+                ent = dict(roofline_entry(us_f, bt_f, n_px, m, kernel="k_eval_fs<%d>" % m, resident="hbm", copies=n_rot,
+                                          rotating_working_set_bytes=n_rot * WORKING_SET_PER_PX[m] * n_px), pass_only=ent)
+            result["roofline_hbm_rotating"][METHOD_NAMES[m]] = ent
         for r2 in rot[1:]:
             r2.close()
         # same kernel in photo+depth mode (configs[2]) for reference
         other = 2 if method == 0 else 0
         k2, b2 = avg_kernel_us(lambda: reg.time_eval_kernel(0, pose_gpu, other, True, 50))
         result["roofline_other_method"] = dict(roofline_entry(k2, b2, n_px, other, resident="infinity_cache"), method=METHOD_NAMES[other])
-        # whole-iteration efficiency: the bytes of one pass over the duration of one step (pass + solve launch + gaps)
+        # whole-iteration efficiency: the bytes of one pass over the duration of one step as the host clock sees it
         solve_us = reg.time_solve_kernel(0, 0, 50)
         it_s = elapsed / args.steps
         result["iteration"] = {
             "bytes_per_iteration": BYTES_PER_PX[method] * n_px, "us_per_iteration": it_s * 1e6,
-            "pass_us": kernel_us, "solve_us": solve_us, "gap_and_host_us": it_s * 1e6 - kernel_us - solve_us,
+            "launch_us": fused_us if fused else kernel_us + solve_us, "pass_only_us": kernel_us, "separate_solve_launch_us": solve_us,
+            "gap_and_host_us": it_s * 1e6 - (fused_us if fused else kernel_us + solve_us),
             "achieved": BYTES_PER_PX[method] * n_px / it_s / 1e9, "unit": "GB/s",
             "frac": BYTES_PER_PX[method] * n_px / it_s / 1e9 / HBM_PEAK_GBS,
-            "note": "value's own step: one k_eval pass + one k_solve launch + launch gaps (+ the K-step call's fixed cost / K)"}
+            "frac_sustained": BYTES_PER_PX[method] * n_px * sustained["gn_iterations_per_s"] / n_gpus / 1e9 / HBM_PEAK_GBS,
+            "note": ("value's own step: one k_eval_fs launch (+ the K-step call's fixed cost / K: the tail solve launch, the host wake-up)" if fused else
+                     "value's own step: one k_eval pass + one k_solve launch + launch gaps (+ the K-step call's fixed cost / K)")}
         # the same forced schedule in the sequence engine's regime: 16 pairs iterate in lock step, one {pass, solve} launch pair
         # serving all of them (their records are separate allocations: 16 working sets, past the Infinity Cache)
         if not args.no_sequence:
@@ -366,19 +414,22 @@ def main():
             rot_e, trans_e = synth.pose_error(pose_gpu, pose_cpu)
             result["alignment"]["pose_err_vs_cpu_ref"] = {"rot_rad": rot_e, "trans_m": trans_e}
             result["alignment"]["cpu_iters_per_level"] = list(ora.result.iters)[:4]
-            # thread count: the reference uses every OpenMP thread; on many-core hosts that is not the fastest
-            # setting for this memory-bound loop, so the baseline is quoted at the best of a short sweep
-            max_thr = O.num_threads()
-            cands = sorted({t for t in (8, 16, 32, 64, 128, max_thr) if t <= max_thr})
-            best_thr, best_per_it = max_thr, None
+            # thread count: the reference uses every OpenMP thread the process may run on.  What this job may use is its CPU AFFINITY
+            # (a 1-GPU lease gets 16 of the node's 256 hardware threads), not os.cpu_count(): the sweep is capped there, and the
+            # baseline is quoted at the best count of the sweep (more threads than cores only lose on this memory-bound loop)
+            allowed = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            max_thr = max(1, min(O.num_threads(), allowed))
+            cands = sorted({t for t in (1, 2, 4, 8, 16, 32, 64, 128, max_thr) if t <= max_thr})
+            per_it_by_thr = {}
             for thr in cands:
                 O.set_num_threads(thr)
                 ora.forced_iters(0, np.eye(4), method, 1)       # warm
+                n_s = 3 if thr > 1 else 2
                 t0 = time.perf_counter()
-                ora.forced_iters(0, np.eye(4), method, 3)
-                per_it = (time.perf_counter() - t0) / 3
-                if best_per_it is None or per_it < best_per_it:
-                    best_thr, best_per_it = thr, per_it
+                ora.forced_iters(0, np.eye(4), method, n_s)
+                per_it_by_thr[thr] = (time.perf_counter() - t0) / n_s
+            best_thr = min(per_it_by_thr, key=per_it_by_thr.get)
+            best_per_it = per_it_by_thr[best_thr]
             O.set_num_threads(best_thr)
             n_cpu = int(max(8, min(5000, args.cpu_seconds / max(best_per_it, 1e-6))))
             t0 = time.perf_counter()
@@ -389,7 +440,11 @@ def main():
                 "sample": "%d level-0 forced GN iterations (H,g pass + solve + error pass, reference structure with its "
                           "per-call Jacobian arrays) on the same %dx%d %s pair, %.1f s, best of OpenMP thread counts %s"
                           % (n_cpu, W, H, METHOD_NAMES[method], dt, cands),
-                "host_cpus": os.cpu_count(),
+                "cores_allowed": allowed, "host_cpus": os.cpu_count(),
+                "single_thread_value": 1.0 / per_it_by_thr[1] if 1 in per_it_by_thr else None,
+                "gn_iterations_per_s_by_threads": {str(k): 1.0 / v for k, v in sorted(per_it_by_thr.items())},
+                "note": "cores = OpenMP threads of the quoted figure; cores_allowed = this process's CPU affinity (what the job may use), "
+                        "the sweep never exceeds it; single_thread_value = the reference-faithful single-thread figure (SURVEY.md 8d)",
             }
         print(json.dumps(result), flush=True)
 
@@ -409,11 +464,14 @@ def run_sequence_block(args, torch, dist, synth, reg0, rank, world, local_rank, 
     t_render = time.time() - t0
     order = pingpong(n_loc, SEQ_UNIQUE_FRAMES)
     dev = torch.device("cuda", local_rank)
-    rgb_t = [torch.from_numpy(f[0]).to(dev) for f in uniq]
-    dep_t = [torch.from_numpy(f[1].view(np.int16)).to(dev) for f in uniq]       # uint16 bits; torch has no uint16 kernels, none needed
+    # every frame of the walk is its OWN copy in HBM (n_loc + 1 distinct buffers, 10.5 MB each), as a recorded sequence would be:
+    # with only the SEQ_UNIQUE_FRAMES rendered images resident (round 2) the raw inputs of the set-up kernels stayed in the Infinity
+    # Cache and `resident` read 6 % high -- the whole of the gap to `native_multi`, whose loader always made distinct copies
+    rgb_t = [torch.from_numpy(uniq[k][0]).to(dev) for k in order]
+    dep_t = [torch.from_numpy(uniq[k][1].view(np.int16)).to(dev) for k in order]       # uint16 bits; torch has no uint16 kernels, none needed
     torch.cuda.synchronize()
-    rgb_ptrs = [rgb_t[k].data_ptr() for k in order]
-    dep_ptrs = [dep_t[k].data_ptr() for k in order]
+    rgb_ptrs = [t.data_ptr() for t in rgb_t]
+    dep_ptrs = [t.data_ptr() for t in dep_t]
     host_frames = [uniq[k] for k in order]
     reg = RegisterPhotoICP(device=local_rank)
     reg.setNumPyr(4)
@@ -467,7 +525,21 @@ def run_sequence_block(args, torch, dist, synth, reg0, rank, world, local_rank, 
             T = np.linalg.inv(synth.trajectory_pose(base + a, 7)) @ synth.trajectory_pose(base + b, 7)
             e = synth.pose_error(my[j], T)
             gt_err = [max(gt_err[0], e[0]), max(gt_err[1], e[1])]
+        # compulsory bytes of one alignment of the sequence (SURVEY.md 8d figures): the set-up of the ONE new frame a pair brings
+        # (level 0 reads 5 B/px of raw colour + depth, levels >= 1 read their 8 B/px of float planes; every level writes 16 + 12 + 12 B/px
+        # of source / target records and the next level's 8 B/px of planes), and per level (accepted iterations + the first pass + the
+        # pass whose rejection ends the level) fused passes of 40 B/px
+        n_l = [(H >> l) * (W >> l) for l in range(4)]
+        setup_b = sum((5 if l == 0 else 8) * n_l[l] + 40 * n_l[l] + (8 * n_l[l + 1] if l + 1 < 4 else 0) for l in range(4))
+        mean_it = it.mean(0) if len(it) else np.zeros(4)
+        pass_b = float(sum(BYTES_PER_PX[method] * n_l[l] * (mean_it[l] + 1 + (1 if mean_it[l] < 10 else 0)) for l in range(4)))
+        pair_b = setup_b + pass_b
+        ach = pair_b * n_total / med / 1e9 / world         # per GPU
         out[variant] = {
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "per": "GPU",
+                         "algorithmic_bytes_per_alignment": pair_b, "setup_bytes": setup_b, "pass_bytes": pass_b,
+                         "model": "frame set-up of one new frame (5 | 8 B/px in, 40 B/px records + 8 B/px next-level planes out, 4 levels) + "
+                                  "sum over levels of (mean accepted iterations + 2) passes x 40 B/px; PCIe bytes of host frames not counted"},
             "alignments_per_s": n_total / med, "elapsed_ms_median": med * 1e3, "elapsed_ms_all": [t * 1e3 for t in times],
             "ms_per_pair_per_gpu": med * 1e3 / max(1, -(-n_total // world)),
             "all_status_ok": bool((st == 0).all()), "repeated_pairs_bit_identical": repeats_equal,
@@ -479,6 +551,7 @@ def run_sequence_block(args, torch, dist, synth, reg0, rank, world, local_rank, 
                             "rgbd360_align360_batch[_dev] per rank (lock-step engine, %d pairs in flight), one all-gather of pose/status/iters"
                             % (n_total, W, H, world, SEQ_INFLIGHT),
                 "pairs_total": n_total, "pairs_per_rank": -(-n_total // world), "unique_frames_per_rank": SEQ_UNIQUE_FRAMES,
+                "resident_frames_are_distinct_copies": True,
                 "render_s": t_render, "exchange": "gloo (shared device)" if xdev == "cpu" and world > 1 else ("rccl" if world > 1 else "none")})
     # the child process of the native multi-GPU entry re-uses rank 0's frames instead of rendering again
     if rank == 0:

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <cmath>
 #include <map>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -203,9 +204,20 @@ class RegisterRGBD360 {
         std::vector<float> rt(16 * S);
         for (size_t s = 0; s < S; ++s)
             for (int k = 0; k < 16; ++k) rt[16 * s + k] = Rt[s].m[k];
-        rgbd360_rig* rig = nullptr;
-        if (rgbd360_rig_create(&p, (int)S, rt.data(), focal, focal, cols / 2.f - 0.5f, rows / 2.f - 0.5f, &rig) != 0)
+        // every view is validated BEFORE the rig exists, and the handle (a sequence engine with its device buffers, pinned memory and
+        // streams) is owned by a unique_ptr from the moment it does: nothing below can leak it
+        for (const std::vector<ImageView>* set_of : {&rgb1, &depth1, &rgb2, &depth2})
+            for (size_t s = 0; s < S; ++s) {
+                const ImageView& v = (*set_of)[s];
+                const ImageView& first = (*set_of)[0];
+                if (v.rows != rows || v.cols != cols || v.step != first.step || v.type != first.type || !v.data)
+                    throw std::runtime_error("RegisterDensePhotoICP: all sensor images must share one size, stride and depth type");
+            }
+        rgbd360_rig* rig_raw = nullptr;
+        if (rgbd360_rig_create(&p, (int)S, rt.data(), focal, focal, cols / 2.f - 0.5f, rows / 2.f - 0.5f, &rig_raw) != 0)
             throw std::runtime_error("rgbd360_rig_create failed: no usable HIP device (there is no CPU fallback)");
+        const std::unique_ptr<rgbd360_rig, void (*)(rgbd360_rig*)> rig_owner(rig_raw, rgbd360_rig_destroy);
+        rgbd360_rig* rig = rig_raw;
         auto set = [&](bool target, const std::vector<ImageView>& rgb, const std::vector<ImageView>& depth) {
             std::vector<const uint8_t*> rp(S);
             std::vector<const void*> dp(S);
@@ -224,9 +236,7 @@ class RegisterRGBD360 {
         if (rc == 0) rc = set(false, rgb2, depth2);
         rgbd360_result res;
         if (rc == 0) rc = rgbd360_rig_align(rig, pose_estim.m, (int)method, rigidTransf_.m, &res);
-        const std::string err = rc < 0 ? rgbd360_rig_last_error(rig) : "";
-        rgbd360_rig_destroy(rig);
-        if (rc < 0) throw std::runtime_error("RegisterDensePhotoICP: " + err);
+        if (rc < 0) throw std::runtime_error(std::string("RegisterDensePhotoICP: ") + rgbd360_rig_last_error(rig));
         for (int k = 0; k < 36; ++k) informationM_.m[k] = res.hessian[k];
         done_ = true;                                   // bRegistrationDone = true   (:506)
         status_ = rc;

@@ -153,6 +153,10 @@ int  rgbd360_multi_n_gpus(rgbd360_multi* m);
 int  rgbd360_multi_uses_rccl(rgbd360_multi* m);
 /* Contiguous balanced partition used by the sharding: the first n_items % world ranks get one item more. */
 void rgbd360_shard_range(int n_items, int rank, int world, int* lo, int* hi);
+/* Layout of the exchange step (ncclAllGather wants equal counts): every rank contributes rows_per_rank = ceil(n_pairs / world) result
+ * rows, the first hi - lo of them its pairs; global pair `pair` is row *row of the gathered table and belongs to rank *rank.
+ * Pure index arithmetic (no device): what rgbd360_multi_* use to scatter the gathered rows back into sequence order. */
+void rgbd360_gather_slot(int n_pairs, int world, int pair, int* rank, int* row, int* rows_per_rank);
 /* Host frames (as rgbd360_align360_batch: uploaded one frame ahead on each device's copy stream, unchanged until the call
  * returns).  poses_out: (n_frames-1) x 16 floats; results_out may be NULL.  Returns 0 or the first negative error. */
 int  rgbd360_multi_align_sequence(rgbd360_multi* m, int n_frames, const uint8_t* const* rgb, size_t rgb_step,

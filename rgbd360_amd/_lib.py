@@ -19,7 +19,7 @@ SYMBOLS = [
     "rgbd360_pbmap_default_params", "rgbd360_register_planes", "rgbd360_bilateral_filter",
     "rgbd360_cloud_planes", "rgbd360_sensor_cloud", "rgbd360_sensor_planes", "rgbd360_merge_planes", "rgbd360_planes_available", "rgbd360_set_plane_refinement", "rgbd360_plane_refinement_stats",
     "rgbd360_multi_create", "rgbd360_multi_destroy", "rgbd360_multi_last_error", "rgbd360_multi_n_gpus", "rgbd360_multi_uses_rccl",
-    "rgbd360_shard_range", "rgbd360_multi_align_sequence", "rgbd360_multi_load_sequence", "rgbd360_multi_align_resident",
+    "rgbd360_shard_range", "rgbd360_gather_slot", "rgbd360_multi_align_sequence", "rgbd360_multi_load_sequence", "rgbd360_multi_align_resident",
     "rgbd360_align360_batch_multi", "rgbd360_time_eval_kernel_rotating", "rgbd360_forced_iters_batch",
     "rgbd360_rig_create", "rgbd360_rig_destroy", "rgbd360_rig_last_error", "rgbd360_rig_set_target", "rgbd360_rig_set_source",
     "rgbd360_rig_eval", "rgbd360_rig_align", "rgbd360_debug_solve_partials",
@@ -149,6 +149,8 @@ def load() -> C.CDLL:
     L.rgbd360_multi_uses_rccl.argtypes = [vp]
     L.rgbd360_shard_range.argtypes = [i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]
     L.rgbd360_shard_range.restype = None
+    L.rgbd360_gather_slot.argtypes = [i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    L.rgbd360_gather_slot.restype = None
     L.rgbd360_multi_align_sequence.argtypes = [vp, i32, vp, C.c_size_t, vp, C.c_size_t, i32, i32, i32, f32p, i32, i32, i32, f32p, vp]
     L.rgbd360_multi_load_sequence.argtypes = [vp, i32, vp, C.c_size_t, vp, C.c_size_t, i32, i32, i32]
     L.rgbd360_multi_align_resident.argtypes = [vp, f32p, i32, i32, i32, f32p, vp]

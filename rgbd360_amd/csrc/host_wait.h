@@ -25,13 +25,19 @@ inline double spin_budget_us() {
     return v;
 }
 
+// flags of every pinned buffer a running kernel publishes into (spin tags, published states / totals / flag words)
+constexpr unsigned kPublishedFlags = hipHostMallocCoherent | hipHostMallocMapped;
+
 struct SpinTag {
     unsigned* h = nullptr;      // pinned, device-visible
     unsigned seq = 0;
 };
 inline hipError_t spin_tag_init(SpinTag* t) {
     if (t->h) return hipSuccess;
-    const hipError_t e = hipHostMalloc((void**)&t->h, 64, hipHostMallocDefault);
+    // coherent (fine-grained) + mapped, explicitly: the host polls this word while the stream is still running, which must not depend
+    // on the process-wide HIP_HOST_COHERENT default (non-coherent pinned memory is only guaranteed visible at synchronisation points:
+    // every wait would burn its whole spin budget first)
+    const hipError_t e = hipHostMalloc((void**)&t->h, 64, kPublishedFlags);
     if (e == hipSuccess) *t->h = 0;
     t->seq = 0;
     return e;

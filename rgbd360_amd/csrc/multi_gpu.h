@@ -21,7 +21,8 @@ struct rgbd360_multi {
     std::vector<uint8_t*> seq_rgb;
     std::vector<uint8_t*> seq_depth;
     std::vector<size_t> seq_rgb_bytes, seq_depth_bytes;
-    int seq_frames = 0, seq_rows = 0, seq_cols = 0, seq_depth_type = 0;
+    std::vector<int> seq_lo, seq_hi;             // ... the pair span [lo_d, hi_d) each device's resident frames were cut for (fixed at load time)
+    int seq_frames = 0, seq_rows = 0, seq_cols = 0, seq_depth_type = 0;      // seq_frames == 0: nothing (valid) is resident
     bool use_rccl = false;
     std::string err;
 };
@@ -42,8 +43,25 @@ void shard_range(int n_items, int rank, int world, int* lo, int* hi) {      // c
     *hi = *lo + base + (rank < extra ? 1 : 0);
 }
 
+// The exchange buffer's layout (pure index arithmetic, exported as rgbd360_gather_slot for the CPU tests): every rank contributes
+// max_chunk = ceil(n_pairs / world) rows -- ncclAllGather wants equal counts -- of which the first hi - lo are its pairs; global pair
+// j therefore sits in row rank_of(j) * max_chunk + (j - lo_rank) of the gathered table, and the rows behind a rank's last pair are
+// padding.
+int gather_chunk(int n_pairs, int world) { return (n_pairs + world - 1) / world; }
+void gather_slot(int n_pairs, int world, int pair, int* rank, int* row) {
+    const int base = n_pairs / world, extra = n_pairs % world;
+    // the first `extra` ranks own base + 1 pairs each: pairs below extra * (base + 1) belong to them
+    int r;
+    if (pair < extra * (base + 1)) r = pair / (base + 1);
+    else r = base > 0 ? extra + (pair - extra * (base + 1)) / base : world - 1;
+    int lo, hi;
+    shard_range(n_pairs, r, world, &lo, &hi);
+    *rank = r;
+    *row = r * gather_chunk(n_pairs, world) + (pair - lo);
+}
+
 int multi_ensure_exchange(rgbd360_multi* m, int n_pairs) {
-    const int max_chunk = (n_pairs + m->n_gpus - 1) / m->n_gpus;
+    const int max_chunk = gather_chunk(n_pairs, m->n_gpus);
     const size_t need_send = (size_t)std::max(max_chunk, 1) * kRowBytes, need_recv = need_send * m->n_gpus;
     if (m->send_cap >= need_send && m->recv_cap >= need_recv) return 0;
     for (int d = 0; d < m->n_gpus; ++d) {
@@ -69,7 +87,7 @@ int multi_run(rgbd360_multi* m, int n_frames, FrameOf frames_of, size_t rgb_step
     int rc = multi_ensure_exchange(m, n_pairs);
     if (rc) return rc;
     const int G = m->n_gpus;
-    const int max_chunk = (n_pairs + G - 1) / G;
+    const int max_chunk = gather_chunk(n_pairs, G);
     std::vector<int> lo(G), hi(G), rcs(G, 0);
     for (int d = 0; d < G; ++d) shard_range(n_pairs, d, G, &lo[d], &hi[d]);
     std::vector<std::vector<unsigned char>> rows_host(G, std::vector<unsigned char>((size_t)max_chunk * kRowBytes, 0));
@@ -137,12 +155,13 @@ int multi_run(rgbd360_multi* m, int n_frames, FrameOf frames_of, size_t rgb_step
     } else {
         for (int d = 0; d < G; ++d) memcpy(all.data() + (size_t)d * max_chunk * kRowBytes, rows_host[d].data(), (size_t)max_chunk * kRowBytes);
     }
-    for (int d = 0; d < G; ++d)
-        for (int j = lo[d]; j < hi[d]; ++j) {
-            const unsigned char* row = all.data() + ((size_t)d * max_chunk + (j - lo[d])) * kRowBytes;
-            memcpy(poses_out + (size_t)16 * j, row, 16 * sizeof(float));
-            if (results_out) memcpy(&results_out[j], row + 16 * sizeof(float), sizeof(rgbd360_result));
-        }
+    for (int j = 0; j < n_pairs; ++j) {
+        int rank, slot;
+        gather_slot(n_pairs, G, j, &rank, &slot);
+        const unsigned char* row = all.data() + (size_t)slot * kRowBytes;
+        memcpy(poses_out + (size_t)16 * j, row, 16 * sizeof(float));
+        if (results_out) memcpy(&results_out[j], row + 16 * sizeof(float), sizeof(rgbd360_result));
+    }
     return 0;
 }
 
@@ -165,6 +184,14 @@ void rgbd360_shard_range(int n_items, int rank, int world, int* lo, int* hi) {
     if (world > 0 && rank >= 0 && rank < world && n_items >= 0) shard_range(n_items, rank, world, &a, &b);
     if (lo) *lo = a;
     if (hi) *hi = b;
+}
+
+void rgbd360_gather_slot(int n_pairs, int world, int pair, int* rank, int* row, int* rows_per_rank) {
+    int r = -1, s = -1;
+    if (world > 0 && n_pairs > 0 && pair >= 0 && pair < n_pairs) gather_slot(n_pairs, world, pair, &r, &s);
+    if (rank) *rank = r;
+    if (row) *row = s;
+    if (rows_per_rank) *rows_per_rank = world > 0 && n_pairs >= 0 ? gather_chunk(n_pairs, world) : 0;
 }
 
 void rgbd360_multi_destroy(rgbd360_multi* m) {
@@ -197,6 +224,7 @@ int rgbd360_multi_create(const rgbd360_params* p, int n_gpus, const int* device_
     m->d_send.assign(n_gpus, nullptr); m->d_recv.assign(n_gpus, nullptr);
     m->seq_rgb.assign(n_gpus, nullptr); m->seq_depth.assign(n_gpus, nullptr);
     m->seq_rgb_bytes.assign(n_gpus, 0); m->seq_depth_bytes.assign(n_gpus, 0);
+    m->seq_lo.assign(n_gpus, 0); m->seq_hi.assign(n_gpus, 0);
     for (int d = 0; d < n_gpus; ++d) {
         rgbd360_params pd = *p;
         pd.device = m->dev[d];
@@ -241,30 +269,41 @@ int rgbd360_multi_load_sequence(rgbd360_multi* m, int n_frames, const uint8_t* c
                                 size_t depth_step, int depth_type, int rows, int cols) {
     if (!m) return -1;
     if (!rgb || !depth || n_frames < 2 || rows < 1 || cols < 1 || (depth_type != 0 && depth_type != 1)) return mfail(m, -1, "bad arguments");
+    for (int k = 0; k < n_frames; ++k)
+        if (!rgb[k] || !depth[k]) return mfail(m, -1, "null frame pointer");      // before anything resident is touched
     const size_t dpx = depth_type == 0 ? 2 : 4;
     const size_t fr = (size_t)rows * cols * 3, fd = (size_t)rows * cols * dpx;
     const int n_pairs = n_frames - 1;
+    // Not failure-atomic by construction (buffers are re-used and overwritten device by device), so the handle says "nothing
+    // resident" from the first touch until EVERY device has its shard: a failed reload can never leave rgbd360_multi_align_resident
+    // with the previous call's geometry over freed or half-overwritten frames.
+    m->seq_frames = 0;
+    auto failed = [&](int code, const char* msg) {
+        multi_free_sequence(m);
+        return mfail(m, code, msg);
+    };
     for (int d = 0; d < m->n_gpus; ++d) {
         int lo, hi;
         shard_range(n_pairs, d, m->n_gpus, &lo, &hi);
         const int nf = hi > lo ? hi - lo + 1 : 0;
-        if (hipSetDevice(m->dev[d]) != hipSuccess) return mfail(m, -102, "hipSetDevice failed");
+        if (hipSetDevice(m->dev[d]) != hipSuccess) return failed(-102, "hipSetDevice failed");
         if (m->seq_rgb_bytes[d] < nf * fr || m->seq_depth_bytes[d] < nf * fd) {
             hipFree(m->seq_rgb[d]); hipFree(m->seq_depth[d]);
             m->seq_rgb[d] = m->seq_depth[d] = nullptr;
             m->seq_rgb_bytes[d] = m->seq_depth_bytes[d] = 0;
             if (nf > 0 && (hipMalloc(&m->seq_rgb[d], nf * fr) != hipSuccess || hipMalloc(&m->seq_depth[d], nf * fd) != hipSuccess))
-                return mfail(m, -103, "cannot allocate the resident sequence");
+                return failed(-103, "cannot allocate the resident sequence");
             m->seq_rgb_bytes[d] = nf * fr; m->seq_depth_bytes[d] = nf * fd;
         }
         for (int k = 0; k < nf; ++k) {
-            if (!rgb[lo + k] || !depth[lo + k]) return mfail(m, -1, "null frame pointer");
             if (hipMemcpy2D(m->seq_rgb[d] + k * fr, (size_t)cols * 3, rgb[lo + k], rgb_step, (size_t)cols * 3, rows, hipMemcpyHostToDevice) != hipSuccess ||
                 hipMemcpy2D(m->seq_depth[d] + k * fd, (size_t)cols * dpx, depth[lo + k], depth_step, (size_t)cols * dpx, rows, hipMemcpyHostToDevice) != hipSuccess)
-                return mfail(m, -104, "upload of the sequence failed");
+                return failed(-104, "upload of the sequence failed");
         }
+        m->seq_lo[d] = lo; m->seq_hi[d] = hi;
     }
-    m->seq_frames = n_frames; m->seq_rows = rows; m->seq_cols = cols; m->seq_depth_type = depth_type;
+    m->seq_rows = rows; m->seq_cols = cols; m->seq_depth_type = depth_type;
+    m->seq_frames = n_frames;          // published last
     return 0;
 }
 
@@ -276,11 +315,15 @@ int rgbd360_multi_align_resident(rgbd360_multi* m, const float guess[16], int me
     const size_t dpx = m->seq_depth_type == 0 ? 2 : 4;
     const size_t fr = (size_t)m->seq_rows * m->seq_cols * 3, fd = (size_t)m->seq_rows * m->seq_cols * dpx;
     const int n_pairs = m->seq_frames - 1;
-    auto frames_of = [&](int d, int k, const uint8_t** r, const void** dpt) {
+    for (int d = 0; d < m->n_gpus; ++d) {       // the shards multi_run will cut must be the ones the frames were loaded for
         int lo, hi;
         shard_range(n_pairs, d, m->n_gpus, &lo, &hi);
-        *r = m->seq_rgb[d] + (size_t)(k - lo) * fr;
-        *dpt = m->seq_depth[d] + (size_t)(k - lo) * fd;
+        if (lo != m->seq_lo[d] || hi != m->seq_hi[d]) return mfail(m, -2, "resident sequence does not match the shard layout");
+        if (hi > lo && (!m->seq_rgb[d] || !m->seq_depth[d])) return mfail(m, -2, "resident sequence is incomplete");
+    }
+    auto frames_of = [&](int d, int k, const uint8_t** r, const void** dpt) {
+        *r = m->seq_rgb[d] + (size_t)(k - m->seq_lo[d]) * fr;
+        *dpt = m->seq_depth[d] + (size_t)(k - m->seq_lo[d]) * fd;
     };
     return multi_run(m, m->seq_frames, frames_of, (size_t)m->seq_cols * 3, (size_t)m->seq_cols * dpx, m->seq_depth_type, m->seq_rows,
                      m->seq_cols, guess, method, occlusion, n_inflight, true, poses_out, results_out);

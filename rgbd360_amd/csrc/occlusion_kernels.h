@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void k_occ_build(LevelDev lv, const GNState* _
     const bool pm_run = !(has_prev && __uint_as_float((unsigned)(kprev >> 32)) > di);
     if (in) runinfo[i] = cand ? (unsigned char)(0x40u | (pm_run ? 0x80u : 0u) | (unsigned)(lane - lead)) : (unsigned char)0;
     if (cand && run_tail) {
-        const int nx = occ_decode(atomicExch(&head[ti], (gen << 24) | i), gen);
+        const int nx = occ_decode(atomicExch(&head[ti], (int)(((unsigned)gen << 24) | (unsigned)i)), gen);      // (unsigned shift: gen reaches 255)
         nodes[i] = make_int4((int)(unsigned)key, (int)(unsigned)(key >> 32), i - (lane - lead), nx);
     }
 }

@@ -569,7 +569,7 @@ int rgbd360_create(const rgbd360_params* p, rgbd360_ctx** out) {
               hipMalloc(&ctx->d_state_alt, sizeof(GNState)) == hipSuccess &&
               hipMemset(ctx->d_state_alt, 0, sizeof(GNState)) == hipSuccess &&
               hipMalloc(&ctx->d_gnio, sizeof(GnIO)) == hipSuccess &&
-              hipHostMalloc((void**)&ctx->h_state, sizeof(GNState), hipHostMallocDefault) == hipSuccess &&
+              hipHostMalloc((void**)&ctx->h_state, sizeof(GNState), hostwait::kPublishedFlags) == hipSuccess &&
               hostwait::spin_tag_init(&ctx->tag) == hipSuccess;
     if (!ok) {
         rgbd360_destroy(ctx);
@@ -1173,10 +1173,11 @@ int rgbd360_time_eval_kernel_rotating(rgbd360_ctx* const* ctxs, int n_ctx, int l
         if (want_hg == 2 && !fused_ok(ctxs[k], 0)) return fail(c0, -1, "the fused-solve schedule is switched off");
     }
     hipSetDevice(c0->p.device);
-    // every context's kernels go to c0's stream for the duration of the measurement
+    // every context's kernels go to c0's stream for the duration of the measurement: all contexts are synchronised first (the
+    // only step that can fail), then the streams are swapped in a loop that cannot, and swapped back on every way out
+    for (int k = 0; k < n_ctx; ++k) HIPC(c0, hipStreamSynchronize(ctxs[k]->stream));
     std::vector<hipStream_t> own(n_ctx);
     for (int k = 0; k < n_ctx; ++k) {
-        HIPC(c0, hipStreamSynchronize(ctxs[k]->stream));
         own[k] = ctxs[k]->stream;
         ctxs[k]->stream = c0->stream;
     }
@@ -1633,7 +1634,7 @@ int f360_ensure(rgbd360_ctx* ctx, size_t n) {
     HIPC(ctx, hipMalloc(&ctx->f_mom, (size_t)f360::kMomReplicas * kF360MaxSlots * 9 * sizeof(unsigned long long)));
     HIPC(ctx, hipMalloc(&ctx->f_count_of_slot, kF360MaxSlots * sizeof(int)));
     const size_t pack_bytes = f360::kF360PackHeader + (size_t)kF360MaxSlots * sizeof(f360::F360SlotRecord);
-    HIPC(ctx, hipHostMalloc(&ctx->f_pack_host, pack_bytes));
+    HIPC(ctx, hipHostMalloc(&ctx->f_pack_host, pack_bytes, hostwait::kPublishedFlags));
     HIPC(ctx, hipMalloc(&ctx->f_depth_raw, n * 4));
     ctx->f360_n = n;
     return 0;
@@ -1794,7 +1795,7 @@ int f360_refine_dev(rgbd360_ctx* ctx, int rows, int cols, int nslots, std::vecto
     int* d_activity = d_changed + 1;                                            // bumped by every relaxation step that changed a label
     HIPC(ctx, hipMemsetAsync(d_activity, 0, sizeof(int), ctx->stream));
     constexpr int kFlags = 64;
-    if (!ctx->f_flags_host) HIPC(ctx, hipHostMalloc((void**)&ctx->f_flags_host, (kFlags + 1) * sizeof(int), hipHostMallocDefault));
+    if (!ctx->f_flags_host) HIPC(ctx, hipHostMalloc((void**)&ctx->f_flags_host, (kFlags + 1) * sizeof(int), hostwait::kPublishedFlags));
     std::vector<float4> models(nslots, make_float4(NAN, 0.f, 0.f, 0.f));
     for (size_t k = 0; k < planes.size(); ++k)
         models[plane_slot[k]] = make_float4(planes[k].normal[0], planes[k].normal[1], planes[k].normal[2], planes[k].d);

@@ -169,7 +169,10 @@ __global__ __launch_bounds__(256) void k_rig_reduce(const double* __restrict__ p
     }
     __threadfence_system();            // this block's totals are on their way to the host before it takes its ticket
     __syncthreads();
-    if (threadIdx.x == 0 && atomicAdd(ticket, 1u) == gridDim.x - 1) {
+    // acq_rel on the ticket: the block that draws the last number synchronises with every earlier block's release, so their host
+    // writes (fenced above) are ordered before the tag it stores next
+    if (threadIdx.x == 0 && __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+        __threadfence_system();
         *ticket = 0u;
         __hip_atomic_store(tag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -388,7 +391,7 @@ int rgbd360_rig_create(const rgbd360_params* p, int n_sensors, const float* Rt, 
         memcpy(R->Rt[s], Rt + 16 * s, sizeof(float) * 16);
         rigid_inverse(R->Rt[s], R->Rt_inv[s]);
     }
-    if (hipHostMalloc((void**)&R->h_tot, sizeof(double) * kNumPartials * kMaxRigSensors, hipHostMallocDefault) != hipSuccess ||
+    if (hipHostMalloc((void**)&R->h_tot, sizeof(double) * kNumPartials * kMaxRigSensors, hostwait::kPublishedFlags) != hipSuccess ||
         hostwait::spin_tag_init(&R->tag) != hipSuccess || hipMalloc(&R->d_ticket, sizeof(unsigned)) != hipSuccess ||
         hipMemset(R->d_ticket, 0, sizeof(unsigned)) != hipSuccess) {
         if (R->h_tot) hipHostFree(R->h_tot);

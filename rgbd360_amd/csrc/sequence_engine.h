@@ -147,7 +147,7 @@ int seq_create(const rgbd360_params& p, int P, int rows, int cols, int max_eval_
     if (hipMalloc(&E->d_partials, (size_t)P * E->partials_stride * sizeof(double)) != hipSuccess ||
         hipMalloc(&E->d_states, (size_t)P * sizeof(GNState)) != hipSuccess ||
         hipMemset(E->d_states, 0, (size_t)P * sizeof(GNState)) != hipSuccess ||
-        hipHostMalloc((void**)&E->h_states, (size_t)P * sizeof(GNState), hipHostMallocDefault) != hipSuccess)
+        hipHostMalloc((void**)&E->h_states, (size_t)P * sizeof(GNState), hostwait::kPublishedFlags) != hipSuccess)
         return bad("out of memory for the engine state");
     *out = E;
     return 0;
@@ -268,7 +268,9 @@ void result_from_state(const GNState& S, int n_pyr, int occ, float pose_out[16],
 }
 
 // Slot s aligns the pairs [a[s], b[s]) of the sequence rgb[] / depth[] (global frame indices; pair j = frames j, j+1).
-int seq_run(SeqEngine* E, int n_slots, const int* a, const int* b, const uint8_t* const* rgb, size_t rgb_step, const void* const* depth,
+// (seq_run below wraps this body with the one exit that matters: whatever the outcome, no copy from the caller's images and no
+// launch of this call is still in flight when the C call returns.)
+int seq_run_body(SeqEngine* E, int n_slots, const int* a, const int* b, const uint8_t* const* rgb, size_t rgb_step, const void* const* depth,
             size_t depth_step, int depth_type, const float* guess, int method, bool on_device, float* poses_out, rgbd360_result* results_out) {
     hipSetDevice(E->p.device);
     const int P = E->P;
@@ -375,6 +377,19 @@ int seq_run(SeqEngine* E, int n_slots, const int* a, const int* b, const uint8_t
     }
     if (E->up_stream) SEQC(E, hipStreamSynchronize(E->up_stream));      // no upload may outlive the caller's buffers
     return 0;
+}
+
+int seq_run(SeqEngine* E, int n_slots, const int* a, const int* b, const uint8_t* const* rgb, size_t rgb_step, const void* const* depth,
+            size_t depth_step, int depth_type, const float* guess, int method, bool on_device, float* poses_out, rgbd360_result* results_out) {
+    const int rc = seq_run_body(E, n_slots, a, b, rgb, rgb_step, depth, depth_step, depth_type, guess, method, on_device, poses_out, results_out);
+    if (rc != 0) {
+        // an error return left the body early: hipMemcpy2DAsync copies from the caller's host images may still be queued on the copy
+        // stream, staged frames unconverted and event waits pending on the engine's stream.  Drain both (errors here change nothing:
+        // the call already failed) so that the caller may free its buffers and the kept engine starts its next call clean.
+        if (E->up_stream) (void)hipStreamSynchronize(E->up_stream);
+        if (E->stream) (void)hipStreamSynchronize(E->stream);
+    }
+    return rc;
 }
 
 }  // namespace

@@ -57,6 +57,39 @@ def test_shard_range_is_a_contiguous_partition():
             assert max(sizes) - min(sizes) <= 1
 
 
+def test_native_gather_layout_for_uneven_shards():
+    """The index arithmetic of the native multi-GPU entry's one exchange step (csrc/multi_gpu.h: every device contributes
+    ceil(n_pairs / G) rows to ncclAllGather, the host scatters the gathered table back into sequence order) for 2, 3 and 8 devices,
+    even and uneven shards, fewer pairs than devices: every pair has exactly one row, inside its owner's block, the owner is the rank
+    whose rgbd360_shard_range holds the pair, rows keep the pair order inside a block, and the library's partition equals the
+    process-per-GPU path's (rgbd360_amd.batch.shard_range).  Pure host code behind the C ABI: no device involved."""
+    import ctypes as C
+    from rgbd360_amd import _lib, batch, multi
+    L = _lib.load()
+    for world in (1, 2, 3, 8):
+        for n in (1, 2, 3, 5, 7, 8, 9, 31, 255, 256, 257):
+            rank, row, chunk = C.c_int(), C.c_int(), C.c_int()
+            spans = [multi.shard_range(n, r, world) for r in range(world)]
+            assert spans == [batch.shard_range(n, r, world) for r in range(world)]
+            seen = set()
+            for j in range(n):
+                L.rgbd360_gather_slot(n, world, j, C.byref(rank), C.byref(row), C.byref(chunk))
+                assert chunk.value == -(-n // world)
+                lo, hi = spans[rank.value]
+                assert lo <= j < hi, (world, n, j, rank.value, spans)
+                assert row.value == rank.value * chunk.value + (j - lo)
+                assert 0 <= row.value < world * chunk.value and row.value not in seen
+                seen.add(row.value)
+            assert len(seen) == n
+            # the rows of a rank's block behind its last pair are padding: never addressed
+            for r, (lo, hi) in enumerate(spans):
+                assert all(r * chunk.value + k not in seen for k in range(hi - lo, chunk.value))
+    # out-of-range queries answer -1 instead of indexing
+    rank, row, chunk = C.c_int(), C.c_int(), C.c_int()
+    L.rgbd360_gather_slot(7, 3, 7, C.byref(rank), C.byref(row), C.byref(chunk))
+    assert (rank.value, row.value) == (-1, -1)
+
+
 def test_align_sequence_reuses_frames_inside_a_chunk():
     from rgbd360_amd.batch import align_sequence
     reg = FakeReg()
