@@ -487,10 +487,11 @@ __device__ __forceinline__ void eval_span(const PoseRT& T, const WarpConsts& wc,
     EvalAcc& AB = A[NS - 1];       // pixels of the odd steps (stage B): the same set at 1024 threads, lane t + 512's at 512
 
     // Wave-uniform trip count (every lane stays active: the ballots count whole waves); lanes past the end of the
-    // span process a clamped record with in_range = false.  The loop is unrolled by two with ping-pong register
+    // span process a clamped record with in_range = false.
+    const int n_steps = NS * ((end - base + kEvalThreads - 1) / kEvalThreads);
+    // The loop is unrolled by two with ping-pong register
     // sets (wA / wB) so that no register copy forces an early wait: while the arithmetic of step k runs, the gathers
     // of step k+1 and the source record of step k+2 are in flight.
-    const int n_steps = NS * ((end - base + kEvalThreads - 1) / kEvalThreads);
     PixW wB;
     float4 sA = buf_load_f4(bufs.src, (unsigned)(i + 2 * THREADS) << 4);
     int k = 0;
@@ -511,6 +512,10 @@ __device__ __forceinline__ void eval_span(const PoseRT& T, const WarpConsts& wc,
     } else {
         consume_stage<METHOD, HG>(wA, lv, ec, AA);
     }
+    // (Round 3, measured and dropped: FOUR register sets, unrolled by four -- gathers three steps ahead, source records six -- to
+    // cover an HBM miss instead of an Infinity-Cache hit: 95 / 111 VGPRs, same sums, and SLOWER everywhere on one box, resident
+    // 12.0 vs 11.7 us, HBM-fed 15.1 vs 13.8 us (photo), 17.5 vs 15.4 / 19.7 vs 17.6 us (photo + depth), 4096 x 2048 58.6 vs 57.1 us:
+    // the loop is not waiting for a deeper queue, tools/ab_libs.py.)
 
     ESTAMP(2);
     // ---- reduction: lanes -> wave (halving butterfly, f32) -> block (f64 via LDS) -> one partial row ----
@@ -1193,34 +1198,44 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve_b(GNState* states, cons
 // bit-identical to the two-launch schedule.  The lock-step sequence engine keeps k_solve_b: there the CUs are never idle and
 // one solve launch already serves all pairs in flight.
 // ---------------------------------------------------------------------------------------------------------
-// Stages the state and sums the pending pass's partial rows.  Everything is requested at once: the partial rows (whole batches of 32
-// rows up to nb_load, the largest table of the context -- the row count of the pending pass is only known with the state, and
-// waiting for it would put two dependent round trips in front of the solve; rows >= pend_nb are dropped from the sum), the state
-// words, and the pending row count itself through the scalar unit.  Returns pend_nb; a barrier behind the LDS writes.
-__device__ __forceinline__ int stage_pending(SolveShared& sh, const GNState* __restrict__ st_in, const double* __restrict__ partials,
-                                             const int nb_load) {
+// Stages the state and sums the pending pass's partial rows.  Everything is requested at once, in the first instructions of the
+// launch: the first kPendingRows rows of the table (always that many: the row count of the pending pass is only known with the state,
+// and waiting for it would put two dependent round trips in front of the solve; rows >= pend_nb are dropped from the sum, the table
+// is allocated with at least kPendingRows rows), the state words, and the pending row count itself through the scalar unit.
+// Straight-line code: a launch's first instruction-cache lines arrive cold (0.7 us passed before the loads were out when each
+// load sat behind its own test).  Returns pend_nb; a barrier behind the LDS writes.
+constexpr int kPendingRows = 256;                 // rows loaded per launch = the grid cap of the single-pair pass
+constexpr int kMaxPendingRows = kPendingRows;     // the fused schedule needs every level's block count <= this
+__device__ __forceinline__ int stage_pending(SolveShared& sh, const GNState* __restrict__ st_in, const double* __restrict__ partials) {
     constexpr int kStateWords = sizeof(GNState) / 4;
     constexpr int Q = kSolveThreads / kNumPartials;
+    constexpr int J = kPendingRows / Q;
+    static_assert(J * Q == kPendingRows && J <= 16, "whole batches");
     const int tid = threadIdx.x;
     const int v = tid % kNumPartials, q = tid / kNumPartials;
-    double tmp[16];
+    double tmp[J];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        tmp[j] = 0.0;
-        if (j * Q < nb_load) tmp[j] = partials[(size_t)(q + j * Q) * kNumPartials + v];      // uniform test: the table is padded to whole batches
-    }
+    for (int j = 0; j < J; ++j) tmp[j] = partials[(size_t)(q + j * Q) * kNumPartials + v];
     int word = 0;
     if (tid < kStateWords) word = reinterpret_cast<const int*>(st_in)[tid];
     const int nb = st_in->pend_nb;        // uniform (scalar load)
+#ifdef RGBD360_SOLVE_STAMPS
+    if (tid == 0) sh.stamp[3] = __builtin_amdgcn_s_memrealtime();      // loads issued (absolute; made relative below)
+#endif
     double s = 0.0;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) s += (q + j * Q < nb) ? tmp[j] : 0.0;      // the order of solve_block's sum
+    for (int j = 0; j < J; ++j) s += (q + j * Q < nb) ? tmp[j] : 0.0;      // the order of solve_block's sum (its zero rows add nothing)
     sh.red[q][v] = s;
     if (tid < kStateWords) reinterpret_cast<int*>(&sh.sst)[tid] = word;
+#ifdef RGBD360_SOLVE_STAMPS
+    if (tid == 0) {
+        sh.stamp[5] = __builtin_amdgcn_s_memrealtime() - sh.stamp0;      // this wave's loads are back, sums in LDS (slot re-used: wave 1 overwrites it later)
+        sh.stamp[3] -= sh.stamp0;
+    }
+#endif
     __syncthreads();
     return nb;
 }
-constexpr int kMaxPendingRows = 16 * (kSolveThreads / kNumPartials);      // one batch of stage_pending
 
 // wave-uniform pose out of LDS into scalar registers (the pixel loop reads it as SGPR operands, like the scalar loads of k_eval)
 __device__ __forceinline__ float uniform_f(float v) {
@@ -1231,7 +1246,7 @@ template <int METHOD>
 __global__ __launch_bounds__(kEvalThreads) void k_eval_fs(const GNState* __restrict__ st_in, GNState* __restrict__ st_out,
                                                            const double* __restrict__ partials_in, double* __restrict__ partials_out,
                                                            const float4* __restrict__ src0, int n_px, int chunk, int level, int nb_arg,
-                                                           int nb_load, LevelDev lv, EvalConsts ec, SolveCfg cfg) {
+                                                           LevelDev lv, EvalConsts ec, SolveCfg cfg) {
     static_assert(kEvalThreads == kSolveThreads, "the fused launch runs the solve on the pass's block");
     unsigned long long es[6] = {0, 0, 0, 0, 0, 0};
 #ifdef RGBD360_EVAL_STAMPS
@@ -1245,7 +1260,7 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_fs(const GNState* __restr
     if (threadIdx.x == 0) sh.stamp0 = __builtin_amdgcn_s_memrealtime();
 #endif
     // what the solve waits for is requested first (a wave's vector-memory operations complete in issue order) ...
-    const int pend = stage_pending(sh, st_in, partials_in, nb_load);
+    const int pend = stage_pending(sh, st_in, partials_in);
     SOLVE_STAMP(0);
     const int nb = nb_arg;
     const int b = blockIdx.x;
@@ -1340,12 +1355,12 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_fs(const GNState* __restr
 
 // The tail of a fused-solve schedule: the solve of the last pass enqueued (if one is pending), in place, one block; publishes
 // like k_solve.
-__global__ __launch_bounds__(kSolveThreads) void k_solve_pending(GNState* st_g, const double* __restrict__ partials, int nb_load,
+__global__ __launch_bounds__(kSolveThreads) void k_solve_pending(GNState* st_g, const double* __restrict__ partials,
                                                                   SolveCfg cfg) {
     __shared__ SolveShared sh;
     constexpr int kStateWords = sizeof(GNState) / 4;
     const int tid = threadIdx.x;
-    const int pend = stage_pending(sh, st_g, partials, nb_load);
+    const int pend = stage_pending(sh, st_g, partials);
     if (pend > 0) {
         SolveCfg c = cfg;
         c.level = sh.sst.level_active;

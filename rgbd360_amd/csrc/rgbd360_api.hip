@@ -113,6 +113,8 @@ struct rgbd360_ctx {
     int occ_gen = 0;                                   // generation tag of the head entries (no memset between passes)
     size_t occ_n = 0;
     int max_eval_blocks = 256;    // grid cap of the fused pass (tuning knob: RGBD360_EVAL_BLOCKS)
+    unsigned char* arena = nullptr;   // ONE allocation behind every per-level buffer of the context (planes, records, angle tables)
+    bool use_arena = true;            // RGBD360_ARENA=0: one hipMalloc per buffer (A/B)
     std::string err;
 };
 
@@ -134,10 +136,15 @@ int fail(rgbd360_ctx* ctx, int code, const char* msg) {
 
 void free_levels(rgbd360_ctx* ctx) {
     for (Level& L : ctx->levels) {
-        hipFree(L.graySrc); hipFree(L.depthSrc); hipFree(L.grayTrg); hipFree(L.depthTrg);
-        hipFree(L.srcRec); hipFree(L.srcRecPin); hipFree(L.trgP); hipFree(L.trgD);
-        hipFree(L.sinT); hipFree(L.cosT); hipFree(L.sinP); hipFree(L.cosP);
+        if (!ctx->arena) {
+            hipFree(L.graySrc); hipFree(L.depthSrc); hipFree(L.grayTrg); hipFree(L.depthTrg);
+            hipFree(L.srcRec); hipFree(L.trgP); hipFree(L.trgD);
+            hipFree(L.sinT); hipFree(L.cosT); hipFree(L.sinP); hipFree(L.cosP);
+        }
+        hipFree(L.srcRecPin);
     }
+    hipFree(ctx->arena);
+    ctx->arena = nullptr;
     ctx->levels.clear();
     ctx->rows = ctx->cols = 0;
     ctx->have_src = ctx->have_trg = false;
@@ -153,6 +160,16 @@ int ensure_levels(rgbd360_ctx* ctx, int rows, int cols) {
     HIPC(ctx, hipStreamSynchronize(ctx->stream));
     free_levels(ctx);
     ctx->levels.resize(ctx->p.n_pyr);
+    size_t arena_off = 0;
+    if (ctx->use_arena) {
+        size_t total = 0;
+        for (int l = 0, rr = rows, cc = cols; l < ctx->p.n_pyr; ++l, rr /= 2, cc /= 2) {
+            const size_t n = (size_t)rr * cc;
+            total += 4 * ((n * 4 + 255) & ~(size_t)255) + ((n * 16 + 255) & ~(size_t)255) + 2 * ((n * 12 + 255) & ~(size_t)255) +
+                     2 * (((size_t)cc * 4 + 255) & ~(size_t)255) + 2 * (((size_t)rr * 4 + 255) & ~(size_t)255);
+        }
+        HIPC(ctx, hipMalloc(&ctx->arena, total));
+    }
     int r = rows, c = cols;
     int max_blocks = 0;
     for (int l = 0; l < ctx->p.n_pyr; ++l) {
@@ -161,14 +178,27 @@ int ensure_levels(rgbd360_ctx* ctx, int rows, int cols) {
         const float angle_res = 2 * kPI / c;        // RPI.h:2554
         L.angle_res_inv = 1 / angle_res;            // RPI.h:2555
         L.half_nRows = 0.5 * r - 0.5;               // RPI.h:2557
+        // every buffer of every level out of ONE allocation (sized below on the first level's visit): a context is ~110 MB at
+        // 2048 x 1024, and one large range keeps its pages' translations together (fewer, larger fragments) instead of scattering
+        // ~45 small allocations over the address space
+        auto take = [&](size_t bytes) -> void* {
+            if (!ctx->use_arena) {
+                void* q = nullptr;
+                return hipMalloc(&q, bytes) == hipSuccess ? q : nullptr;
+            }
+            void* q = ctx->arena + arena_off;
+            arena_off += (bytes + 255) & ~(size_t)255;
+            return q;
+        };
         const size_t nb = (size_t)L.n * sizeof(float);
-        HIPC(ctx, hipMalloc(&L.graySrc, nb)); HIPC(ctx, hipMalloc(&L.depthSrc, nb));
-        HIPC(ctx, hipMalloc(&L.grayTrg, nb)); HIPC(ctx, hipMalloc(&L.depthTrg, nb));
-        HIPC(ctx, hipMalloc(&L.srcRec, (size_t)L.n * sizeof(float4)));
-        HIPC(ctx, hipMalloc(&L.trgP, (size_t)L.n * sizeof(F3)));
-        HIPC(ctx, hipMalloc(&L.trgD, (size_t)L.n * sizeof(F3)));
-        HIPC(ctx, hipMalloc(&L.sinT, c * sizeof(float))); HIPC(ctx, hipMalloc(&L.cosT, c * sizeof(float)));
-        HIPC(ctx, hipMalloc(&L.sinP, r * sizeof(float))); HIPC(ctx, hipMalloc(&L.cosP, r * sizeof(float)));
+        L.graySrc = (float*)take(nb); L.depthSrc = (float*)take(nb); L.grayTrg = (float*)take(nb); L.depthTrg = (float*)take(nb);
+        L.srcRec = (float4*)take((size_t)L.n * sizeof(float4));
+        L.trgP = (F3*)take((size_t)L.n * sizeof(F3));
+        L.trgD = (F3*)take((size_t)L.n * sizeof(F3));
+        L.sinT = (float*)take(c * sizeof(float)); L.cosT = (float*)take(c * sizeof(float));
+        L.sinP = (float*)take(r * sizeof(float)); L.cosP = (float*)take(r * sizeof(float));
+        if (!L.graySrc || !L.depthSrc || !L.grayTrg || !L.depthTrg || !L.srcRec || !L.trgP || !L.trgD || !L.sinT || !L.cosT || !L.sinP || !L.cosP)
+            return fail(ctx, -103, "cannot allocate the pyramid levels");
         // RPI.h:4556-4571: per-column / per-row sin, cos of float arguments (host libm, once per size)
         std::vector<float> st(c), ct(c), sp(r), cp(r);
         for (int j = 0; j < c; ++j) {
@@ -195,8 +225,8 @@ int ensure_levels(rgbd360_ctx* ctx, int rows, int cols) {
     }
     hipFree(ctx->d_partials); hipFree(ctx->d_partials_alt);
     ctx->d_partials = ctx->d_partials_alt = nullptr;
-    // whole batches of 32 rows (stage_pending loads whole batches) + diagnostic rows
-    const size_t part_bytes = (size_t)((max_blocks + 31) / 32 * 32 + 8 + max_blocks / 16 + 2) * kNumPartials * sizeof(double);
+    // at least the kPendingRows rows stage_pending always loads, + diagnostic rows
+    const size_t part_bytes = (size_t)(std::max((max_blocks + 31) / 32 * 32, kPendingRows) + 8 + max_blocks / 16 + 2) * kNumPartials * sizeof(double);
     HIPC(ctx, hipMalloc(&ctx->d_partials, part_bytes));
     HIPC(ctx, hipMalloc(&ctx->d_partials_alt, part_bytes));
     HIPC(ctx, hipMemset(ctx->d_partials, 0, part_bytes));          // the fused pass loads max_blocks rows whatever the pending count
@@ -319,7 +349,7 @@ void launch_eval_fused(rgbd360_ctx* ctx, int level, int method, int forced) {
     const SolveCfg cfg = fused_cfg(ctx, forced);
     dim3 g(L.nblocks), b(kEvalThreads);
 #define LAUNCHF(M) hipLaunchKernelGGL((k_eval_fs<M>), g, b, 0, ctx->stream, (const GNState*)ctx->d_state, ctx->d_state_alt, (const double*)ctx->d_partials, \
-                                      ctx->d_partials_alt, lv.src, lv.n, L.chunk, level, L.nblocks, ctx->max_blocks, lv, ec, cfg)
+                                      ctx->d_partials_alt, lv.src, lv.n, L.chunk, level, L.nblocks, lv, ec, cfg)
     if (method == 0) LAUNCHF(0);
     else if (method == 1) LAUNCHF(1);
     else LAUNCHF(2);
@@ -335,7 +365,7 @@ void launch_solve_pending(rgbd360_ctx* ctx, int forced, bool publish) {
         cfg.host_tag = ctx->tag.h;
         cfg.host_seq = ++ctx->tag.seq;
     }
-    hipLaunchKernelGGL(k_solve_pending, dim3(1), dim3(kSolveThreads), 0, ctx->stream, ctx->d_state, (const double*)ctx->d_partials, ctx->max_blocks, cfg);
+    hipLaunchKernelGGL(k_solve_pending, dim3(1), dim3(kSolveThreads), 0, ctx->stream, ctx->d_state, (const double*)ctx->d_partials, cfg);
 }
 
 void launch_level_init(rgbd360_ctx* ctx, int level, const float* pose, int reset_all) {
@@ -561,6 +591,9 @@ int rgbd360_create(const rgbd360_params* p, rgbd360_ctx** out) {
     }
     if (const char* e = getenv("RGBD360_FUSED_SOLVE")) {
         ctx->fused_solve = atoi(e) != 0;
+    }
+    if (const char* e = getenv("RGBD360_ARENA")) {
+        ctx->use_arena = atoi(e) != 0;
     }
     bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreate(&ctx->ev0) == hipSuccess && hipEventCreate(&ctx->ev1) == hipSuccess &&
@@ -1111,7 +1144,7 @@ int rgbd360_debug_solve_partials(rgbd360_ctx* ctx, int level, const double row[3
     const Level& L = ctx->levels[level];
     float I[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
     launch_level_init(ctx, level, I, 1);
-    const size_t rows = (size_t)(ctx->max_blocks + 31) / 32 * 32;
+    const size_t rows = (size_t)std::max((ctx->max_blocks + 31) / 32 * 32, kPendingRows);
     HIPC(ctx, hipMemsetAsync(ctx->d_partials, 0, rows * kNumPartials * sizeof(double), ctx->stream));
     HIPC(ctx, hipMemcpyAsync(ctx->d_partials, row, kNumPartials * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     if (fused) {

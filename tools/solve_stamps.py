@@ -17,7 +17,7 @@ from rgbd360_amd.register import RegisterPhotoICP
 (rgbA, dA), (rgbB, dB), T = synth.make_pair(2048, 1024, seed=1234)
 reg = RegisterPhotoICP(); reg.setNumPyr(4)
 reg.setTargetFrame(rgbA, dA); reg.setSourceFrame(rgbB, dB)
-names = ["staged+row sums", "totals", "bookkeeping (wave 0)", "commit", "end", "inverse (wave 1)", "update+exp+cand (wave 1)", "rank (wave 2)"]
+names = ["staged+row sums", "totals", "bookkeeping (wave 0)", "loads issued", "end", "inverse (wave 1)", "update+exp+cand (wave 1)", "rank (wave 2)"]
 for level in (0, 3):
     for method in (0, 2):
         reg.forced_iters(level, np.eye(4), method, 20)
