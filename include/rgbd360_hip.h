@@ -283,13 +283,26 @@ typedef struct {
     float curvature;
     int   count;        /* inliers */
     int   root;         /* smallest pixel index of the region = its label */
-    /* Extent descriptors from the in-plane second moments of the inliers (eigenvalues l1 <= l2 of the covariance beside
-     * the normal's l0) -- the roles of mrpt::pbmap::Plane::areaHull / elongation / v3PpalDir (Frame360.h:1025-1037), which
-     * MRPT derives from the region's convex hull (third-party, not in the reference tree): area = 12 sqrt(l1 l2) (the
-     * rectangle with these moments), elongation = sqrt(l2 / l1), ppal_dir = eigenvector of l2. */
+    /* Extent descriptors -- the roles of mrpt::pbmap::Plane::areaHull / elongation / v3PpalDir (Frame360.h:1025-1037; MRPT is
+     * third-party and not in the reference tree):
+     *   area        area of the convex hull of the region's contour projected onto its plane (calcConvexHull +
+     *               computeMassCenterAndArea): metric, whatever the pixel density.  The device reduces the boundary pixels to the
+     *               region's extreme point in each of 256 in-plane directions, the host runs hull + shoelace on those (an inscribed
+     *               polygon: exact for sharp-cornered polygons, 0.01 % low for a disc, a few 0.1 % low where long edges are slightly bowed).  Frame360.h:1031 compares it with min_area_plane (0.12 m2),
+     *               RegisterRGBD360.h:126-136 ranks planes by it.
+     *   elongation  sqrt(l2 / l1), ppal_dir = eigenvector of l2: PCA of the inliers (l1 <= l2 the in-plane eigenvalues of their
+     *               covariance beside the normal's l0), as calcElongationAndPpalDir does on the inlier cloud. */
     float area;
     float elongation;
     float ppal_dir[3];
+    /* area_moment  12 sqrt(l1 l2): the rectangle with the inliers' second moments (rounds 1-2 reported this as `area`; pixel-density
+     *              weighted, it reads a wall seen from a spherical image several times too small).  rgbd360_merge_planes rebuilds a
+     *              piece's covariance from it; 0 in a caller-made record means "take area".
+     * center_hull  mass centre of the hull polygon (what computeMassCenterAndArea leaves in v3center); hull_points = vertices of the
+     *              hull (0: no hull was formed -- caller-made record, or fewer than three extreme points: area = area_moment then). */
+    float area_moment;
+    float center_hull[3];
+    int   hull_points;
 } rgbd360_plane;
 
 /* Planar regions of an organised cloud with normals: pcl::OrganizedMultiPlaneSegmentation::segment as configured at

@@ -374,6 +374,31 @@ def f360_plane_segment(xyz, normals, rows, cols, min_inliers=40, angular_thresho
     return labels.reshape(rows, cols), planes
 
 
+def f360_hull_stats(xyz, labels, plane):
+    """EXACT convex hull of a planar region in its own plane -- the checker of the device's 64-direction hull stage (the roles of
+    mrpt::pbmap::Plane::calcConvexHull / computeMassCenterAndArea, Frame360.h:1025-1031; MRPT itself is not in the reference tree):
+    every pixel labelled plane["root"] is projected onto the plane through plane["centroid"] with normal plane["normal"], the hull
+    comes from scipy (Qhull).  Returns (area, mass centre of the hull polygon as a 3-D point, number of hull vertices)."""
+    from scipy.spatial import ConvexHull
+    lab = np.asarray(labels).reshape(-1)
+    pts = np.asarray(xyz, np.float64).reshape(-1, 3)[lab == int(plane["root"])]
+    n = np.asarray(plane["normal"], np.float64)
+    n = n / np.linalg.norm(n)
+    e1 = np.cross(n, [1.0, 0.0, 0.0] if abs(n[0]) < 0.9 else [0.0, 1.0, 0.0])
+    e1 /= np.linalg.norm(e1)
+    e2 = np.cross(n, e1)
+    c = np.asarray(plane["centroid"], np.float64)
+    uv = np.stack([(pts - c) @ e1, (pts - c) @ e2], axis=1)
+    hull = ConvexHull(uv)
+    poly = uv[hull.vertices]                     # counter-clockwise in 2-D
+    x, y = poly[:, 0], poly[:, 1]
+    xn, yn = np.roll(x, -1), np.roll(y, -1)
+    cr = x * yn - xn * y
+    a2 = cr.sum()
+    cu, cv = ((x + xn) * cr).sum() / (3 * a2), ((y + yn) * cr).sum() / (3 * a2)
+    return abs(a2) / 2, c + cu * e1 + cv * e2, len(hull.vertices)
+
+
 def f360_plane_refine(xyz, rows, cols, labels, planes, distance_threshold=0.02):
     """The refine half of segmentAndRefine (oracle/frame360_ref.cpp): returns (refined labels, planes with grown inlier sets,
     number of relabelled pixels).  planes: the dicts f360_plane_segment (or the device) returned."""

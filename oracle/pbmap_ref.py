@@ -83,7 +83,10 @@ def binary_ok(a1, a2, b1, b2, P):
     ang = lambda u, v: math.acos(min(1.0, max(-1.0, float(f(u) @ f(v)))))
     if not abs(ang(a1["normal"], a2["normal"]) - ang(b1["normal"], b2["normal"])) < _f32(P["angle_threshold_deg"]) * math.pi / 180:
         return False
-    ca, cb = f(a2["centroid"]) - f(a1["centroid"]), f(b2["centroid"]) - f(b1["centroid"])
+    # the point that stands for a plane: the hull polygon's mass centre where the record carries one (what MRPT's
+    # computeMassCenterAndArea leaves in v3center, Frame360.h:1028), else the inlier centroid -- as pbm::center_of in the library
+    ctr = lambda p: f(p["center_hull"]) if int(p.get("hull_points", 0)) > 0 else f(p["centroid"])
+    ca, cb = ctr(a2) - ctr(a1), ctr(b2) - ctr(b1)
     if not _ratio(math.sqrt(float(ca @ ca)), math.sqrt(float(cb @ cb))) < _f32(P["dist_threshold"]):
         return False
     h = _f32(P["height_threshold"])
@@ -192,7 +195,7 @@ def _axes(p):
 def _moments(p):
     n, pp, qq = _axes(p)
     el = _f32(p["elongation"]) if np.isfinite(_f32(p["elongation"])) and _f32(p["elongation"]) > 0 else 1.0
-    area = _f32(p["area"])
+    area = _f32(p["area_moment"]) if _f32(p.get("area_moment", 0.0)) > 0 else _f32(p["area"])      # pbm::moment_area
     l1, l2 = area / (12.0 * el), area * el / 12.0
     cv = min(_f32(p["curvature"]), 0.5)
     l0 = cv * (l1 + l2) / (1.0 - cv)

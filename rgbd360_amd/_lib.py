@@ -42,7 +42,7 @@ class Result(C.Structure):
 class Plane(C.Structure):
     _fields_ = [("centroid", C.c_float * 3), ("normal", C.c_float * 3), ("d", C.c_float), ("curvature", C.c_float),
                 ("count", C.c_int), ("root", C.c_int), ("area", C.c_float), ("elongation", C.c_float),
-                ("ppal_dir", C.c_float * 3)]
+                ("ppal_dir", C.c_float * 3), ("area_moment", C.c_float), ("center_hull", C.c_float * 3), ("hull_points", C.c_int)]
 
 
 class PbmapParams(C.Structure):

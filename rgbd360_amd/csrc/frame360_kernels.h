@@ -1184,6 +1184,241 @@ __global__ void k_f360_mom_reduce(const unsigned long long* __restrict__ mom, co
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Convex hull of a planar region (Frame360.h:1009-1031: regions[i].getContour() -> mrpt::pbmap::Plane::calcConvexHull ->
+// computeMassCenterAndArea; MRPT is not in the reference tree: the hull of the region's contour projected onto its plane, the area
+// and mass centre of that polygon).  The hull of a region's contour is the hull of its pixels, and only pixels on the region's
+// boundary can be hull vertices.  On the device the boundary pixels are reduced to the region's EXTREME point in each of
+// kHullDirs = 256 in-plane directions (a wave holds four directions per lane -- an angle in the first quadrant and its rotations by
+// 90, 180 and 270 degrees, which share two dot products -- and walks the boundary pixels of its 64-pixel stretch through v_readlane;
+// one 64-bit atomicMax per direction and run of equal labels, key = {order-preserving dot product, pixel}): an inscribed polygon
+// that contains every hull vertex whose exterior angle exceeds 2 pi / 256 -- exact for sharp-cornered polygons, 0.01 % low for a
+// disc; what it can lose is a long, slightly bowed edge whose normals all fall between two directions (the margin of a wall's region
+// widens with the range: with 64 directions the 8 m floor of the synthetic room read 0.7 % low at 2048 x 1024, a wall 1.2 % low at
+// 512 x 256).  The extremes arrive in direction order, i.e. already in hull order: the host drops the non-left turns in one linear
+// pass (no sort) and takes the shoelace sums.
+//   k_f360_slot_frames   per region slot: centroid + in-plane basis (eigenvectors of the inlier covariance, float64 Jacobi)
+//   k_f360_hull_extremes per 64-pixel stretch: boundary test, in-plane coordinates, directional maxima
+//   k_f360_hull_pack     winners' coordinates + the frame into the pinned record the host reads
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kHullDirs = 256;       // 4 per lane: a lane's direction and its rotations by 90, 180, 270 degrees share two dot products
+struct SlotFrame {
+    float c[3], e1[3], e2[3], nrm[3];
+};
+struct F360HullRecord {
+    float c[3], e1[3], e2[3];
+    int n;                              // directions that found a pixel
+    float uv[kHullDirs][2];             // in-plane coordinates of the extreme pixel per direction (NaN: none)
+};
+// One WAVE per slot.  Lanes 0-8 sum the moment replicas, lane 0 fits the plane, all lanes clear the slot's row of extremes.  Only the
+// NORMAL has to be accurate (the hull's area does not depend on the in-plane axes): it is the eigenvector of the covariance's smallest
+// eigenvalue l0, found without an iterative diagonalisation -- Newton's method on the (monic) characteristic polynomial started at 0
+// converges to l0 monotonically from the left (the polynomial is increasing and concave below its first root), and an eigenvector of
+// l0 is the largest cross product of two rows of C - l0 I.  (A cyclic Jacobi in one thread per slot took 77 us per frame.)
+__global__ __launch_bounds__(64) void k_f360_slot_frames(const unsigned long long* __restrict__ mom, const int* __restrict__ n_slots, int max_slots,
+                                                         const int* __restrict__ count_of_slot, SlotFrame* __restrict__ frames,
+                                                         unsigned long long* __restrict__ ext) {
+    const int slot = blockIdx.x, lane = threadIdx.x;
+    if (slot >= min(*n_slots, max_slots)) return;
+#pragma unroll
+    for (int k = 0; k < kHullDirs / 64; ++k) ext[(size_t)slot * kHullDirs + 64 * k + lane] = 0ull;
+    double mine = 0.0;
+    if (lane < 9) {
+        unsigned long long acc = 0ull;
+        for (int r = 0; r < kMomReplicas; ++r) acc += mom[((size_t)r * max_slots + slot) * 9 + lane];
+        mine = (double)(long long)acc / kMomScale;
+    }
+    double m[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) m[q] = __shfl(mine, q);
+    if (lane != 0) return;
+    const double N = (double)count_of_slot[slot];
+    const double cx = m[0] / N, cy = m[1] / N, cz = m[2] / N;
+    const double a00 = m[3] / N - cx * cx, a01 = m[4] / N - cx * cy, a02 = m[5] / N - cx * cz;
+    const double a11 = m[6] / N - cy * cy, a12 = m[7] / N - cy * cz, a22 = m[8] / N - cz * cz;
+    // f(l) = l^3 - c2 l^2 + c1 l - c0
+    const double c2 = a00 + a11 + a22;
+    const double c1 = (a00 * a11 - a01 * a01) + (a00 * a22 - a02 * a02) + (a11 * a22 - a12 * a12);
+    const double c0 = a00 * (a11 * a22 - a12 * a12) - a01 * (a01 * a22 - a12 * a02) + a02 * (a01 * a12 - a11 * a02);
+    double l = 0.0;
+    for (int it = 0; it < 12; ++it) {
+        const double f = ((l - c2) * l + c1) * l - c0, df = (3.0 * l - 2.0 * c2) * l + c1;
+        if (!(df > 0.0)) break;
+        const double step = f / df;
+        l -= step;
+        if (fabs(step) <= 1e-15 * c2) break;
+    }
+    const double r0[3] = {a00 - l, a01, a02}, r1[3] = {a01, a11 - l, a12}, r2[3] = {a02, a12, a22 - l};
+    auto cross3 = [](const double* u, const double* v, double* o) {
+        o[0] = u[1] * v[2] - u[2] * v[1]; o[1] = u[2] * v[0] - u[0] * v[2]; o[2] = u[0] * v[1] - u[1] * v[0];
+    };
+    double n01[3], n02[3], n12[3];
+    cross3(r0, r1, n01); cross3(r0, r2, n02); cross3(r1, r2, n12);
+    const double q01 = n01[0] * n01[0] + n01[1] * n01[1] + n01[2] * n01[2], q02 = n02[0] * n02[0] + n02[1] * n02[1] + n02[2] * n02[2];
+    const double q12 = n12[0] * n12[0] + n12[1] * n12[1] + n12[2] * n12[2];
+    double nn[3], qq = q01;
+    nn[0] = n01[0]; nn[1] = n01[1]; nn[2] = n01[2];
+    if (q02 > qq) { qq = q02; nn[0] = n02[0]; nn[1] = n02[1]; nn[2] = n02[2]; }
+    if (q12 > qq) { qq = q12; nn[0] = n12[0]; nn[1] = n12[1]; nn[2] = n12[2]; }
+    if (!(qq > 0.0)) { nn[0] = 0.0; nn[1] = 0.0; nn[2] = 1.0; qq = 1.0; }      // isotropic blob: any frame
+    const double inv = 1.0 / sqrt(qq);
+    nn[0] *= inv; nn[1] *= inv; nn[2] *= inv;
+    // any orthonormal pair across the normal
+    double ax[3] = {1.0, 0.0, 0.0};
+    if (fabs(nn[0]) > 0.9) { ax[0] = 0.0; ax[1] = 1.0; }
+    double e1[3], e2[3];
+    cross3(nn, ax, e1);
+    const double i1 = 1.0 / sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]);
+    e1[0] *= i1; e1[1] *= i1; e1[2] *= i1;
+    cross3(nn, e1, e2);
+    SlotFrame F;
+    F.c[0] = (float)cx; F.c[1] = (float)cy; F.c[2] = (float)cz;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        F.nrm[k] = (float)nn[k];
+        F.e1[k] = (float)e1[k];
+        F.e2[k] = (float)e2[k];
+    }
+    frames[slot] = F;
+}
+__global__ void k_f360_hull_clear(const int* __restrict__ n_slots, int max_slots, unsigned long long* __restrict__ ext) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < min(*n_slots, max_slots) * kHullDirs) ext[i] = 0ull;
+}
+__device__ __forceinline__ unsigned hull_f2ord(float f) {          // order-preserving float -> unsigned
+    const unsigned b = __float_as_uint(f);
+    return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+// A block of 16 waves covers kHullChunks stretches of 1024 pixels and keeps the extremes of the (few) regions it meets in LDS; a region
+// costs a block ONE global atomic per direction, at the end.  The walk over a wave's boundary pixels is serial (every lane updates
+// its four directions per pixel), so the work sits where the long, nearly horizontal edges are: a block's stretches are taken a
+// grid's width apart, which spreads every such edge over all blocks (with eight consecutive stretches per block -- and 64-bit keys
+// in the inner loop -- the kernel took 77 us, the straggler blocks being those along the floor's and ceiling's edges).
+constexpr int kHullBlock = 1024, kHullChunks = 8, kHullHash = 16;
+__global__ __launch_bounds__(kHullBlock) void k_f360_hull_extremes(const float* __restrict__ xyz, const int* __restrict__ label,
+                                                                    const int* __restrict__ slot_of_root, int rows, int cols,
+                                                                    const SlotFrame* __restrict__ frames, unsigned long long* __restrict__ ext) {
+    __shared__ int keys[kHullHash];
+    __shared__ unsigned long long vals[kHullHash][kHullDirs];
+    const int lane = threadIdx.x & 63;
+    for (int k = threadIdx.x; k < kHullHash * kHullDirs; k += kHullBlock) (&vals[0][0])[k] = 0ull;
+    if (threadIdx.x < kHullHash) keys[threadIdx.x] = -1;
+    __syncthreads();
+    const int n = rows * cols;
+    // this lane's direction (cos, sin) at angle 2 pi lane / 256 and its three quarter-turn rotations: direction lane + 64 m, m = 0 .. 3,
+    // has the dot products d0 = u c + v s, d1 = v c - u s, -d0, -d1
+    float sk, ck;
+    sincospif((float)lane * (2.f / kHullDirs), &sk, &ck);
+    for (int chunk = 0; chunk < kHullChunks; ++chunk) {
+        const int first = ((chunk * (int)gridDim.x + (int)blockIdx.x) * (kHullBlock / 64) + (int)(threadIdx.x >> 6)) * 64;      // this wave's first pixel
+        if (first >= n) break;                             // wave-uniform
+        const int i = first + lane;
+        int slot = -1;
+        bool bnd = false;
+        if (i < n) {
+            const int L = label[i];
+            if (L >= 0) {
+                slot = slot_of_root[L];
+                if (slot >= 0) {
+                    const int r = i / cols, c = i - r * cols;
+                    bnd = r == 0 || r == rows - 1 || c == 0 || c == cols - 1 || label[i - 1] != L || label[i + 1] != L ||
+                          label[i - cols] != L || label[i + cols] != L;
+                }
+            }
+        }
+        unsigned long long mask = __ballot(bnd);
+        if (mask == 0ull) continue;
+        float u = 0.f, v = 0.f;
+        if (bnd) {
+            const SlotFrame F = frames[slot];
+            const float dx = xyz[3 * (size_t)i] - F.c[0], dy = xyz[3 * (size_t)i + 1] - F.c[1], dz = xyz[3 * (size_t)i + 2] - F.c[2];
+            u = dx * F.e1[0] + dy * F.e1[1] + dz * F.e1[2];
+            v = dx * F.e2[0] + dy * F.e2[1] + dz * F.e2[2];
+        }
+        // per direction: the largest dot product so far and the wave-lane of the pixel that has it (keys are only formed at a flush)
+        int cur = -1;
+        float bd[4];
+        int bj[4];
+        auto flush = [&]() {
+            // the slot's row of the block's table (wave-uniform linear probe; a full table sends the run straight to memory)
+            int h = -1;
+            for (int q = 0; q < kHullHash && h < 0; ++q) {
+                const int k = (cur + q) & (kHullHash - 1);
+                int seen = keys[k];
+                if (seen == -1) {
+                    if (lane == 0) seen = atomicCAS(&keys[k], -1, cur);
+                    seen = __builtin_amdgcn_readfirstlane(seen);
+                    if (seen == -1) seen = cur;
+                }
+                if (seen == cur) h = k;
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const unsigned long long key = ((unsigned long long)hull_f2ord(bd[m]) << 32) | (unsigned)(first + bj[m]);
+                if (h >= 0) atomicMax(&vals[h][64 * m + lane], key);
+                else atomicMax(&ext[(size_t)cur * kHullDirs + 64 * m + lane], key);
+            }
+        };
+        while (mask != 0ull) {                                 // wave-uniform walk over the boundary pixels, ascending: ties keep the first
+            const int j = __builtin_ctzll(mask);
+            mask &= mask - 1ull;
+            const int sj = __builtin_amdgcn_readlane(slot, j);
+            const float uj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u), j));
+            const float vj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), j));
+            const float d0 = fmaf(uj, ck, vj * sk), d1 = fmaf(vj, ck, -(uj * sk));
+            if (sj != cur) {
+                if (cur >= 0) flush();
+                cur = sj;
+                bd[0] = d0; bd[1] = d1; bd[2] = -d0; bd[3] = -d1;
+                bj[0] = bj[1] = bj[2] = bj[3] = j;
+                continue;
+            }
+            if (d0 > bd[0]) { bd[0] = d0; bj[0] = j; }
+            if (d1 > bd[1]) { bd[1] = d1; bj[1] = j; }
+            if (-d0 > bd[2]) { bd[2] = -d0; bj[2] = j; }
+            if (-d1 > bd[3]) { bd[3] = -d1; bj[3] = j; }
+        }
+        if (cur >= 0) flush();
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < kHullHash * kHullDirs; k += kHullBlock) {
+        const int h = k / kHullDirs, d = k - h * kHullDirs;
+        const int s = keys[h];
+        const unsigned long long val = vals[h][d];
+        if (s >= 0 && val != 0ull) atomicMax(&ext[(size_t)s * kHullDirs + d], val);
+    }
+}
+__global__ __launch_bounds__(kHullDirs) void k_f360_hull_pack(const float* __restrict__ xyz, const SlotFrame* __restrict__ frames,
+                                                               const unsigned long long* __restrict__ ext, const int* __restrict__ n_slots,
+                                                               int max_slots, F360HullRecord* __restrict__ out) {
+    const int slot = blockIdx.x, k = threadIdx.x;
+    if (slot >= min(*n_slots, max_slots)) return;
+    const unsigned long long key = ext[(size_t)slot * kHullDirs + k];
+    const SlotFrame F = frames[slot];
+    float u = __builtin_nanf(""), v = __builtin_nanf("");
+    if (key != 0ull) {
+        const size_t pix = (size_t)(unsigned)(key & 0xFFFFFFFFull);
+        const float dx = xyz[3 * pix] - F.c[0], dy = xyz[3 * pix + 1] - F.c[1], dz = xyz[3 * pix + 2] - F.c[2];
+        u = dx * F.e1[0] + dy * F.e1[1] + dz * F.e1[2];
+        v = dx * F.e2[0] + dy * F.e2[1] + dz * F.e2[2];
+    }
+    out[slot].uv[k][0] = u;
+    out[slot].uv[k][1] = v;
+    __shared__ int cnt_sh;
+    if (k == 0) cnt_sh = 0;
+    __syncthreads();
+    const unsigned long long found = __ballot(key != 0ull);
+    if ((k & 63) == 0) atomicAdd(&cnt_sh, __builtin_popcountll(found));
+    __syncthreads();
+    const int cnt = cnt_sh;
+    if (k < 3) {
+        out[slot].c[k] = F.c[k];
+        out[slot].e1[k] = F.e1[k];
+        out[slot].e2[k] = F.e2[k];
+    }
+    if (k == 0) out[slot].n = cnt;
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // The `refine` half of pcl::OrganizedMultiPlaneSegmentation::segmentAndRefine (Frame360.h:977): plane regions grow into
 // neighbouring non-plane pixels that lie within the refinement comparator's distance of the plane -- in PCL two raster passes
 // with in-place label updates (oracle/frame360_ref.cpp restates them literally).  A raster pass is a recurrence over a DAG: the

@@ -62,6 +62,13 @@ inline double ratio(double a, double b) {      // max / min of two non-negative 
     return lo > 0 ? hi / lo : (hi > 0 ? INFINITY : 1.0);
 }
 
+// The point that stands for a plane in the distance constraints: the mass centre of its hull polygon -- what
+// mrpt::pbmap::Plane::computeMassCenterAndArea leaves in v3center before the plane enters the PbMap (Frame360.h:1028) -- when the
+// record carries one, else the inlier centroid (caller-made records).
+inline V3 center_of(const rgbd360_plane& p) { return p.hull_points > 0 ? v3(p.center_hull) : v3(p.centroid); }
+// the in-plane second moments' rectangle: what a piece's covariance is rebuilt from (area_moment; `area` in records without one)
+inline double moment_area(const rgbd360_plane& p) { return p.area_moment > 0 ? p.area_moment : p.area; }
+
 // a record the matcher can use: finite geometry, a unit-length normal, non-negative extent
 inline bool well_formed(const rgbd360_plane& p) {
     double nn = 0;
@@ -132,7 +139,7 @@ struct Matcher {
         const V3 na1 = v3(a1.normal), na2 = v3(a2.normal), nb1 = v3(b1.normal), nb2 = v3(b2.normal);
         const double ang_a = acos(clamp1(dot(na1, na2))), ang_b = acos(clamp1(dot(nb1, nb2)));
         if (!(fabs(ang_a - ang_b) < P->angle_threshold_deg * M_PI / 180)) return false;
-        const V3 ca = sub(v3(a2.centroid), v3(a1.centroid)), cb = sub(v3(b2.centroid), v3(b1.centroid));
+        const V3 ca = sub(center_of(a2), center_of(a1)), cb = sub(center_of(b2), center_of(b1));
         if (!(ratio(norm(ca), norm(cb)) < P->dist_threshold)) return false;
         if (!(fabs(dot(na1, ca) - dot(nb1, cb)) < P->height_threshold)) return false;         // centre 2 over plane 1
         if (!(fabs(dot(na2, ca) - dot(nb2, cb)) < P->height_threshold)) return false;         // centre 1 under plane 2
@@ -350,7 +357,8 @@ inline PlaneMoments moments_of(const rgbd360_plane& p) {
     pp = {pp.x / pl, pp.y / pl, pp.z / pl};
     const V3 qq = cross(nn, pp);
     const double el = p.elongation > 0 && std::isfinite(p.elongation) ? p.elongation : 1.0;
-    const double l1 = p.area / (12.0 * el), l2 = p.area * el / 12.0;
+    const double am = moment_area(p);
+    const double l1 = am / (12.0 * el), l2 = am * el / 12.0;
     const double cv = p.curvature < 0.5 ? p.curvature : 0.5;
     const double l0 = cv * (l1 + l2) / (1.0 - cv);
     const double a[3][3] = {{nn.x, nn.y, nn.z}, {qq.x, qq.y, qq.z}, {pp.x, pp.y, pp.z}};
@@ -386,8 +394,10 @@ inline rgbd360_plane plane_of(const PlaneMoments& m, int root) {
     P.curvature = (float)(l0 + l1 + l2 > 0 ? l0 / (l0 + l1 + l2) : 0.0);
     P.count = (int)m.n;
     P.root = root;
-    P.area = (float)(12.0 * sqrt(l1 * l2));
+    P.area = P.area_moment = (float)(12.0 * sqrt(l1 * l2));
     P.elongation = (float)(l1 > 0 ? sqrt(l2 / l1) : INFINITY);
+    for (int i = 0; i < 3; ++i) P.center_hull[i] = P.centroid[i];
+    P.hull_points = 0;
     return P;
 }
 struct MergeParams {
@@ -454,7 +464,20 @@ inline std::vector<rgbd360_plane> merge_planes(const rgbd360_plane* in, int n, c
                     for (int c = 0; c < 3; ++c)
                         m.C[r][c] = (a.n * (a.C[r][c] + (a.c[r] - m.c[r]) * (a.c[c] - m.c[c])) +
                                      b.n * (b.C[r][c] + (b.c[r] - m.c[r]) * (b.c[c] - m.c[c]))) / m.n;
+                // pieces that carry hull areas: the merged surface's area is their sum (adjacent views of one surface; mrpt's mergePlane2
+                // re-hulls the union of the two contours, which the records no longer hold), its centre their area-weighted mean
+                const bool hulls = v[j].hull_points > 0 && v[k].hull_points > 0;
+                const double aj = v[j].area, ak = v[k].area;
+                const int hp = v[j].hull_points + v[k].hull_points;
+                const V3 cj = center_of(v[j]), ck = center_of(v[k]);
                 v[j] = plane_of(m, std::min(v[j].root, v[k].root));
+                if (hulls && aj + ak > 0) {
+                    v[j].area = (float)(aj + ak);
+                    v[j].center_hull[0] = (float)((aj * cj.x + ak * ck.x) / (aj + ak));
+                    v[j].center_hull[1] = (float)((aj * cj.y + ak * ck.y) / (aj + ak));
+                    v[j].center_hull[2] = (float)((aj * cj.z + ak * ck.z) / (aj + ak));
+                    v[j].hull_points = hp;
+                }
                 v.erase(v.begin() + (long)k);
                 merged = true;
                 break;

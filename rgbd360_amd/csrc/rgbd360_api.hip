@@ -84,6 +84,8 @@ struct rgbd360_ctx {
     unsigned long long *f_count = nullptr, *f_mom = nullptr;
     int* f_count_of_slot = nullptr;
     unsigned char *f_pack = nullptr, *f_pack_host = nullptr;      // packed region records: written by the device straight into pinned host memory (f_pack unused)
+    f360::SlotFrame* f_frames = nullptr;                          // per region slot: centroid + in-plane basis (hull stage)
+    unsigned long long* f_ext = nullptr;                          // per region slot: 64 directional extremes {ordered dot, pixel}
     unsigned long long* b_sum = nullptr;                          // bilateral grid: fixed-point sums, counts, two float2 ping-pong arrays
     int* b_cnt = nullptr;
     float2 *b_a = nullptr, *b_b = nullptr;
@@ -628,6 +630,7 @@ void rgbd360_destroy(rgbd360_ctx* ctx) {
         if (ctx->conv_ev[k]) hipEventDestroy(ctx->conv_ev[k]);
     }
     if (ctx->up_stream) { hipStreamSynchronize(ctx->up_stream); hipStreamDestroy(ctx->up_stream); }
+    hipFree(ctx->f_frames); hipFree(ctx->f_ext);
     hipFree(ctx->f_xyz); hipFree(ctx->f_normals); hipFree(ctx->f_dist);
     hipFree(ctx->f_change); hipFree(ctx->f_hd); hipFree(ctx->f_label); hipFree(ctx->f_count); hipFree(ctx->f_slot_of_root);
     hipFree(ctx->f_root_of_slot); hipFree(ctx->f_nslots); hipFree(ctx->f_window); hipFree(ctx->f_mom);
@@ -1646,8 +1649,9 @@ int f360_ensure(rgbd360_ctx* ctx, size_t n) {
     hipFree(ctx->f_xyz); hipFree(ctx->f_normals); hipFree(ctx->f_dist);
     hipFree(ctx->f_change); hipFree(ctx->f_hd); hipFree(ctx->f_label); hipFree(ctx->f_count); hipFree(ctx->f_slot_of_root);
     hipFree(ctx->f_root_of_slot); hipFree(ctx->f_nslots); hipFree(ctx->f_window); hipFree(ctx->f_mom);
-    hipFree(ctx->f_count_of_slot); hipFree(ctx->f_depth_raw); hipFree(ctx->f_pack);
+    hipFree(ctx->f_count_of_slot); hipFree(ctx->f_depth_raw); hipFree(ctx->f_pack); hipFree(ctx->f_frames); hipFree(ctx->f_ext);
     if (ctx->f_pack_host) hipHostFree(ctx->f_pack_host);
+    ctx->f_frames = nullptr; ctx->f_ext = nullptr;
     ctx->f_xyz = ctx->f_normals = ctx->f_dist = nullptr;         // a failed allocation below must not leave freed pointers behind
     ctx->f_change = nullptr; ctx->f_hd = nullptr; ctx->f_label = nullptr; ctx->f_count = nullptr; ctx->f_slot_of_root = nullptr;
     ctx->f_root_of_slot = nullptr; ctx->f_nslots = nullptr; ctx->f_window = nullptr; ctx->f_mom = nullptr;
@@ -1666,8 +1670,11 @@ int f360_ensure(rgbd360_ctx* ctx, size_t n) {
     HIPC(ctx, hipMalloc(&ctx->f_nslots, sizeof(int)));
     HIPC(ctx, hipMalloc(&ctx->f_mom, (size_t)f360::kMomReplicas * kF360MaxSlots * 9 * sizeof(unsigned long long)));
     HIPC(ctx, hipMalloc(&ctx->f_count_of_slot, kF360MaxSlots * sizeof(int)));
-    const size_t pack_bytes = f360::kF360PackHeader + (size_t)kF360MaxSlots * sizeof(f360::F360SlotRecord);
+    // pinned: header, one moment record per slot, one hull record per slot behind them
+    const size_t pack_bytes = f360::kF360PackHeader + (size_t)kF360MaxSlots * (sizeof(f360::F360SlotRecord) + sizeof(f360::F360HullRecord));
     HIPC(ctx, hipHostMalloc(&ctx->f_pack_host, pack_bytes, hostwait::kPublishedFlags));
+    HIPC(ctx, hipMalloc(&ctx->f_frames, (size_t)kF360MaxSlots * sizeof(f360::SlotFrame)));
+    HIPC(ctx, hipMalloc(&ctx->f_ext, (size_t)kF360MaxSlots * f360::kHullDirs * sizeof(unsigned long long)));
     HIPC(ctx, hipMalloc(&ctx->f_depth_raw, n * 4));
     ctx->f360_n = n;
     return 0;
@@ -1806,6 +1813,83 @@ int f360_bilateral_dev(rgbd360_ctx* ctx, int rows, int cols, float sigma_s, floa
 }
 
 // eigenpairs of a symmetric 3x3 in ascending order (cyclic Jacobi, float64) -- pcl::eigen33's role for the smallest one
+// Convex hull of the <= 256 directional extremes of a region, its area (shoelace) and mass centre -- the
+// roles of mrpt::pbmap::Plane::calcConvexHull / computeMassCenterAndArea (Frame360.h:1025-1031) in the region's own in-plane frame.
+struct HullStats {
+    int n = 0;                  // hull vertices
+    double area = 0, cu = 0, cv = 0;
+};
+HullStats hull_stats(const float (*uv)[2], int K) {
+    // The K support points arrive in direction order = counter-clockwise boundary order (a point that wins several directions
+    // repeats; ties on a straight edge may put collinear points in either order): no sort -- start at the lowest point (a hull
+    // vertex), then one Graham pass over the sequence drops everything that is not a strict left turn.
+    std::pair<double, double> p[f360::kHullDirs];
+    int n = 0;
+    for (int k = 0; k < K; ++k)
+        if (std::isfinite(uv[k][0]) && std::isfinite(uv[k][1])) {
+            const std::pair<double, double> q(uv[k][0], uv[k][1]);
+            if (n == 0 || q != p[n - 1]) p[n++] = q;
+        }
+    while (n > 1 && p[n - 1] == p[0]) --n;
+    HullStats h;
+    if (n < 3) return h;
+    int start = 0;
+    for (int i = 1; i < n; ++i)
+        if (p[i].second < p[start].second || (p[i].second == p[start].second && p[i].first < p[start].first)) start = i;
+    auto cross = [](const std::pair<double, double>& o, const std::pair<double, double>& a, const std::pair<double, double>& b) {
+        return (a.first - o.first) * (b.second - o.second) - (a.second - o.second) * (b.first - o.first);
+    };
+    std::pair<double, double> H[f360::kHullDirs + 1];
+    int m = 0;
+    for (int i = 0; i < n; ++i) {
+        const std::pair<double, double>& q = p[(start + i) % n];
+        while (m >= 2 && cross(H[m - 2], H[m - 1], q) <= 0) --m;
+        H[m++] = q;
+    }
+    while (m >= 3 && cross(H[m - 2], H[m - 1], H[0]) <= 0) --m;      // close the loop
+    if (m < 3) return h;
+    double a2 = 0, cu = 0, cv = 0;
+    for (int i = 0; i < m; ++i) {
+        const auto &a = H[i], &b = H[(i + 1) % m];
+        const double cr = a.first * b.second - a.second * b.first;
+        a2 += cr;
+        cu += (a.first + b.first) * cr;
+        cv += (a.second + b.second) * cr;
+    }
+    if (!(fabs(a2) > 0)) return h;
+    h.n = m;
+    h.area = fabs(a2) / 2;
+    h.cu = cu / (3 * a2);
+    h.cv = cv / (3 * a2);
+    return h;
+}
+// area / centre of plane P from the hull record of its slot (pinned, written by k_f360_hull_pack); the moment rectangle stays in
+// area_moment, and is the fallback when a region has fewer than three extreme points
+void apply_hull(rgbd360_plane& P, const f360::F360HullRecord& R) {
+    const HullStats h = hull_stats(R.uv, f360::kHullDirs);
+    P.hull_points = h.n;
+    if (h.n >= 3) {
+        P.area = (float)h.area;
+        for (int k = 0; k < 3; ++k) P.center_hull[k] = (float)((double)R.c[k] + h.cu * (double)R.e1[k] + h.cv * (double)R.e2[k]);
+    } else {
+        P.area = P.area_moment;
+        for (int k = 0; k < 3; ++k) P.center_hull[k] = P.centroid[k];
+    }
+}
+const f360::F360HullRecord* hull_records(const rgbd360_ctx* ctx) {
+    return reinterpret_cast<const f360::F360HullRecord*>(ctx->f_pack_host + f360::kF360PackHeader + (size_t)kF360MaxSlots * sizeof(f360::F360SlotRecord));
+}
+// the extremes of the CURRENT labels (ctx->f_label) against the frames of the slots, packed for the host; enqueued on the stream
+void launch_hull(rgbd360_ctx* ctx, int rows, int cols, bool clear_first) {
+    using namespace f360;
+    const int n = rows * cols;
+    if (clear_first) hipLaunchKernelGGL(k_f360_hull_clear, dim3((kF360MaxSlots * kHullDirs + 255) / 256), dim3(256), 0, ctx->stream, ctx->f_nslots, kF360MaxSlots, ctx->f_ext);
+    hipLaunchKernelGGL(k_f360_hull_extremes, dim3((n + kHullBlock * kHullChunks - 1) / (kHullBlock * kHullChunks)), dim3(kHullBlock), 0, ctx->stream, ctx->f_xyz, ctx->f_label, ctx->f_slot_of_root, rows, cols,
+                       ctx->f_frames, ctx->f_ext);
+    hipLaunchKernelGGL(k_f360_hull_pack, dim3(kF360MaxSlots), dim3(kHullDirs), 0, ctx->stream, ctx->f_xyz, ctx->f_frames, ctx->f_ext, ctx->f_nslots, kF360MaxSlots,
+                       const_cast<F360HullRecord*>(hull_records(ctx)));
+}
+
 void sorted_eigen3(const double C[3][3], double evals[3], double evecs[3][3]) {    // evecs[k] = eigenvector of evals[k]
     double ev[3], V[3][3];
     pbm::jacobi3(C, ev, V);
@@ -1883,6 +1967,9 @@ int f360_refine_dev(rgbd360_ctx* ctx, int rows, int cols, int nslots, std::vecto
     HIPC(ctx, hipMemcpyAsync(ctx->f_flags_host + kFlags, d_changed, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     hipLaunchKernelGGL(k_f360_mom_reduce, dim3((kF360MaxSlots * 9 + 255) / 256), dim3(256), 0, ctx->stream, ctx->f_mom, ctx->f_nslots, kF360MaxSlots,
                        ctx->f_root_of_slot, ctx->f_count_of_slot, ctx->f_pack_host);
+    // the contour PCL hands to calcConvexHull is that of the REFINED region, projected with the plane `segment` fitted: extremes of the
+    // committed labels against the frames k_f360_slot_frames left before the refinement
+    launch_hull(ctx, rows, cols, /*clear_first=*/true);
     HIPC(ctx, hipGetLastError());
     HIPC(ctx, hipStreamSynchronize(ctx->stream));
     ctx->f_refine_changed = ctx->f_flags_host[kFlags];
@@ -1904,9 +1991,10 @@ int f360_refine_dev(rgbd360_ctx* ctx, int rows, int cols, int nslots, std::vecto
         rgbd360_plane& P = planes[k];
         P.count = R.count;
         const double l1 = std::max(evs[1], 0.0), l2 = std::max(evs[2], 0.0);
-        P.area = (float)(12.0 * sqrt(l1 * l2));
+        P.area_moment = (float)(12.0 * sqrt(l1 * l2));
         P.elongation = (float)(l1 > 0 ? sqrt(l2 / l1) : INFINITY);
         for (int q = 0; q < 3; ++q) P.ppal_dir[q] = (float)vecs[2][q];
+        apply_hull(P, hull_records(ctx)[plane_slot[k]]);
     }
     return 0;
 }
@@ -1955,6 +2043,11 @@ int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float
                        ctx->f_slot_of_root, ctx->f_root_of_slot, ctx->f_count_of_slot, ctx->f_nslots, ctx->f_mom, f360::kMomReplicas);
     const dim3 gmom((n + kAggThreads * kMomPerThread - 1) / (kAggThreads * kMomPerThread));
     hipLaunchKernelGGL(k_f360_moments, gmom, bagg, 0, ctx->stream, ctx->f_xyz, ctx->f_label, ctx->f_slot_of_root, n, ctx->f_mom, kF360MaxSlots);
+    // hull stage: per slot the in-plane frame (and an empty extremes row); the extremes themselves now, or -- with the refinement
+    // switched on -- once the refined labels are committed (f360_refine_dev)
+    hipLaunchKernelGGL(k_f360_slot_frames, dim3(kF360MaxSlots), dim3(64), 0, ctx->stream, ctx->f_mom, ctx->f_nslots, kF360MaxSlots,
+                       ctx->f_count_of_slot, ctx->f_frames, ctx->f_ext);
+    if (!ctx->f_refine) launch_hull(ctx, rows, cols, /*clear_first=*/false);
     // the packing kernel writes the header + records straight into pinned host memory (a few KB over PCIe): no copy to enqueue,
     // one wait.  (Four copies into pageable vectors with two waits used to cost ~0.1 ms of the 0.45 ms call.)
     hipLaunchKernelGGL(k_f360_mom_reduce, dim3((kF360MaxSlots * 9 + 255) / 256), dim3(256), 0, ctx->stream, ctx->f_mom, ctx->f_nslots, kF360MaxSlots,
@@ -2010,9 +2103,15 @@ int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float
         P.count = counts[s];
         P.root = roots[s];
         const double l1 = std::max(evs[1], 0.0), l2 = std::max(evs[2], 0.0);    // in-plane moments (rgbd360_hip.h)
-        P.area = (float)(12.0 * sqrt(l1 * l2));
+        P.area_moment = (float)(12.0 * sqrt(l1 * l2));
         P.elongation = (float)(l1 > 0 ? sqrt(l2 / l1) : INFINITY);
         for (int k = 0; k < 3; ++k) P.ppal_dir[k] = (float)vecs[2][k];
+        if (!ctx->f_refine) apply_hull(P, hull_records(ctx)[s]);
+        else {                   // filled by f360_refine_dev below
+            P.area = P.area_moment;
+            P.hull_points = 0;
+            for (int k = 0; k < 3; ++k) P.center_hull[k] = P.centroid[k];
+        }
     }
     ctx->f_refine_changed = ctx->f_refine_sweeps = 0;
     if (ctx->f_refine && !all.empty()) {
@@ -2316,15 +2415,17 @@ static int cloud_planes_tail(rgbd360_ctx* ctx, int rows, int cols, float sigma_s
     if (Rt) {                                                        // plane.transform(Rt), Frame360.h:1046: sensor -> rig frame
         for (int k = 0; k < *n_planes_out; ++k) {
             rgbd360_plane& P = planes_out[k];
-            double nn[3], cc[3], pp[3];
+            double nn[3], cc[3], pp[3], hh[3];
             for (int i = 0; i < 3; ++i) {
-                nn[i] = cc[i] = pp[i] = 0;
+                nn[i] = cc[i] = pp[i] = hh[i] = 0;
                 for (int j = 0; j < 3; ++j) {
                     nn[i] += (double)Rt[j * 4 + i] * P.normal[j];
                     cc[i] += (double)Rt[j * 4 + i] * P.centroid[j];
                     pp[i] += (double)Rt[j * 4 + i] * P.ppal_dir[j];
+                    hh[i] += (double)Rt[j * 4 + i] * P.center_hull[j];
                 }
                 cc[i] += (double)Rt[12 + i];
+                hh[i] += (double)Rt[12 + i];
             }
             double dd = -(nn[0] * cc[0] + nn[1] * cc[1] + nn[2] * cc[2]);
             if (dd < 0) {                                            // keep the normal towards the new origin (Frame360.h:989-993)
@@ -2335,6 +2436,7 @@ static int cloud_planes_tail(rgbd360_ctx* ctx, int rows, int cols, float sigma_s
                 P.normal[i] = (float)nn[i];
                 P.centroid[i] = (float)cc[i];
                 P.ppal_dir[i] = (float)pp[i];
+                P.center_hull[i] = (float)hh[i];
             }
             P.d = (float)dd;
         }

@@ -37,6 +37,12 @@ def planes_to_array(planes):
         a.root = int(pl.get("root", i))
         a.area = float(pl["area"])
         a.elongation = float(pl["elongation"])
+        # hull stage (device planes carry these; hand-made records may not: hull_points = 0 makes the library fall back to centroid / area)
+        a.area_moment = float(pl.get("area_moment", 0.0))
+        a.hull_points = int(pl.get("hull_points", 0))
+        ch = pl.get("center_hull", pl["centroid"])
+        for k in range(3):
+            a.center_hull[k] = float(ch[k])
     return arr
 
 

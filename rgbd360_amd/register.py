@@ -450,7 +450,8 @@ def _planes_to_dicts(arr, n):
     return [dict(centroid=np.array(list(arr[i].centroid), np.float32), normal=np.array(list(arr[i].normal), np.float32),
                  d=float(arr[i].d), curvature=float(arr[i].curvature), count=int(arr[i].count), root=int(arr[i].root),
                  area=float(arr[i].area), elongation=float(arr[i].elongation),
-                 ppal_dir=np.array(list(arr[i].ppal_dir), np.float32))
+                 ppal_dir=np.array(list(arr[i].ppal_dir), np.float32), area_moment=float(arr[i].area_moment),
+                 center_hull=np.array(list(arr[i].center_hull), np.float32), hull_points=int(arr[i].hull_points))
             for i in range(n)]
 
 
