@@ -279,7 +279,7 @@ def main():
                 traffic = tr.get(key, {}).get("hbm_bytes_per_launch")
                 if traffic is not None:
                     traffic_source = ("tracked file profiles/traffic_latest.json (%s): rocprofv3 PMC passes of an earlier run of this workload, "
-                                      "2 x FETCH_SIZE + WRITE_SIZE per launch of the per-pixel pass; NOT collected in this run" % tr.get("collected", "undated"))
+                                      "2 x FETCH_SIZE + WRITE_SIZE per launch of %s; NOT collected in this run" % (tr.get("collected", "undated"), tr.get(key, {}).get("kernel", "the per-pixel pass")))
             except Exception:
                 traffic = None
         res_note = ("back-to-back launches over one pair: the %.0f MB working set stays in the 256 MiB Infinity Cache, which is the "

@@ -639,7 +639,15 @@ __global__ __launch_bounds__(64 * kSweepWaves) void k_f360_normals_sweep(const f
             const int rect = have ? (int)smoothing : 0;
             const double v0 = s[4] * s[2] - s[5] * s[1], v1 = s[5] * s[0] - s[3] * s[2], v2 = s[3] * s[1] - s[4] * s[0];
             const double len2 = v0 * v0 + v1 * v1 + v2 * v2;
-            const double inv = 1.0 / sqrt(len2);
+            // 1 / sqrt(len2): hardware estimate + two Newton steps (within an ulp or two of the quotient the tiled kernel and the checker
+            // form with an IEEE sqrt and an IEEE division -- ~25 float64 instructions of the row's ~190; the normal is the product's
+            // float32 rounding, which a last-bit difference of the double changes once in ~1e8 values)
+            double inv = __builtin_amdgcn_rsq(len2);
+            {
+                const double hx = 0.5 * len2;
+                inv = inv * __builtin_fma(-hx * inv, inv, 1.5);
+                inv = inv * __builtin_fma(-hx * inv, inv, 1.5);
+            }
             float nx = (float)(v0 * inv), ny = (float)(v1 * inv), nz = (float)(v2 * inv);
             const bool flip = (-px) * nx + (-py) * ny + (-pz) * nz < 0.f;
             const bool okn = have & (rect == R) & ((sc & 65535) > 0) & ((sc >> 16) > 0) & (len2 != 0.0);
@@ -1217,8 +1225,9 @@ struct F360HullRecord {
 __global__ __launch_bounds__(64) void k_f360_slot_frames(const unsigned long long* __restrict__ mom, const int* __restrict__ n_slots, int max_slots,
                                                          const int* __restrict__ count_of_slot, SlotFrame* __restrict__ frames,
                                                          unsigned long long* __restrict__ ext) {
-    const int slot = blockIdx.x, lane = threadIdx.x;
-    if (slot >= min(*n_slots, max_slots)) return;
+    const int lane = threadIdx.x;
+    const int ns = min(*n_slots, max_slots);
+    for (int slot = blockIdx.x; slot < ns; slot += gridDim.x) {
 #pragma unroll
     for (int k = 0; k < kHullDirs / 64; ++k) ext[(size_t)slot * kHullDirs + 64 * k + lane] = 0ull;
     double mine = 0.0;
@@ -1230,7 +1239,7 @@ __global__ __launch_bounds__(64) void k_f360_slot_frames(const unsigned long lon
     double m[9];
 #pragma unroll
     for (int q = 0; q < 9; ++q) m[q] = __shfl(mine, q);
-    if (lane != 0) return;
+    if (lane != 0) continue;
     const double N = (double)count_of_slot[slot];
     const double cx = m[0] / N, cy = m[1] / N, cz = m[2] / N;
     const double a00 = m[3] / N - cx * cx, a01 = m[4] / N - cx * cy, a02 = m[5] / N - cx * cz;
@@ -1279,6 +1288,7 @@ __global__ __launch_bounds__(64) void k_f360_slot_frames(const unsigned long lon
         F.e2[k] = (float)e2[k];
     }
     frames[slot] = F;
+    }
 }
 __global__ void k_f360_hull_clear(const int* __restrict__ n_slots, int max_slots, unsigned long long* __restrict__ ext) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1293,13 +1303,19 @@ __device__ __forceinline__ unsigned hull_f2ord(float f) {          // order-pres
 // its four directions per pixel), so the work sits where the long, nearly horizontal edges are: a block's stretches are taken a
 // grid's width apart, which spreads every such edge over all blocks (with eight consecutive stretches per block -- and 64-bit keys
 // in the inner loop -- the kernel took 77 us, the straggler blocks being those along the floor's and ceiling's edges).
-constexpr int kHullBlock = 1024, kHullChunks = 8, kHullHash = 16;
+constexpr int kHullBlock = 1024, kHullChunks = 8, kHullHash = 16, kHullFramesLds = 256;
 __global__ __launch_bounds__(kHullBlock) void k_f360_hull_extremes(const float* __restrict__ xyz, const int* __restrict__ label,
                                                                     const int* __restrict__ slot_of_root, int rows, int cols,
-                                                                    const SlotFrame* __restrict__ frames, unsigned long long* __restrict__ ext) {
+                                                                    const SlotFrame* __restrict__ frames, unsigned long long* __restrict__ ext,
+                                                                    int* __restrict__ part_keys, unsigned long long* __restrict__ part_vals, int n_frames_lds) {
     __shared__ int keys[kHullHash];
     __shared__ unsigned long long vals[kHullHash][kHullDirs];
+    __shared__ float fr[kHullFramesLds][9];                // centroid + in-plane axes of the first slots: no dependent gather in front of the walk
     const int lane = threadIdx.x & 63;
+    for (int k = threadIdx.x; k < n_frames_lds * 9; k += kHullBlock) {
+        const int sl = k / 9, q = k - sl * 9;
+        fr[sl][q] = reinterpret_cast<const float*>(frames + sl)[q];      // SlotFrame starts with c[3], e1[3], e2[3]
+    }
     for (int k = threadIdx.x; k < kHullHash * kHullDirs; k += kHullBlock) (&vals[0][0])[k] = 0ull;
     if (threadIdx.x < kHullHash) keys[threadIdx.x] = -1;
     __syncthreads();
@@ -1308,31 +1324,59 @@ __global__ __launch_bounds__(kHullBlock) void k_f360_hull_extremes(const float* 
     // has the dot products d0 = u c + v s, d1 = v c - u s, -d0, -d1
     float sk, ck;
     sincospif((float)lane * (2.f / kHullDirs), &sk, &ck);
+    // The labels of all the wave's stretches are requested first, then all the slot look-ups: two memory round trips for the eight
+    // stretches instead of two per stretch (one after the other they were most of the kernel's 34 us; the serial walk only runs where
+    // there is a boundary).
+    int Lc[kHullChunks];
+    bool differs[kHullChunks];
+#pragma unroll
+    for (int chunk = 0; chunk < kHullChunks; ++chunk) {
+        const int i = ((chunk * (int)gridDim.x + (int)blockIdx.x) * (kHullBlock / 64) + (int)(threadIdx.x >> 6)) * 64 + lane;
+        Lc[chunk] = -1;
+        differs[chunk] = false;
+        if (i < n) {
+            const int r = i / cols, c = i - r * cols;
+            const bool edge = r == 0 || r == rows - 1 || c == 0 || c == cols - 1;
+            // clamped neighbours: on the image border the test below is true anyway
+            const int L = label[i], Ll = label[edge ? i : i - 1], Lr = label[edge ? i : i + 1], Lu = label[edge ? i : i - cols], Ld = label[edge ? i : i + cols];
+            Lc[chunk] = L;
+            differs[chunk] = edge || Ll != L || Lr != L || Lu != L || Ld != L;
+        }
+    }
+    // second round trip, again for all stretches at once: the slot of every pixel whose label differs from a neighbour's, and its point
+    int slots[kHullChunks];
+    float px[kHullChunks], py[kHullChunks], pz[kHullChunks];
+#pragma unroll
+    for (int chunk = 0; chunk < kHullChunks; ++chunk) {
+        const int i = ((chunk * (int)gridDim.x + (int)blockIdx.x) * (kHullBlock / 64) + (int)(threadIdx.x >> 6)) * 64 + lane;
+        slots[chunk] = -1;
+        px[chunk] = py[chunk] = pz[chunk] = 0.f;
+        if (Lc[chunk] >= 0 && differs[chunk]) {
+            slots[chunk] = slot_of_root[Lc[chunk]];
+            px[chunk] = xyz[3 * (size_t)i]; py[chunk] = xyz[3 * (size_t)i + 1]; pz[chunk] = xyz[3 * (size_t)i + 2];
+        }
+    }
+#pragma unroll
     for (int chunk = 0; chunk < kHullChunks; ++chunk) {
         const int first = ((chunk * (int)gridDim.x + (int)blockIdx.x) * (kHullBlock / 64) + (int)(threadIdx.x >> 6)) * 64;      // this wave's first pixel
         if (first >= n) break;                             // wave-uniform
-        const int i = first + lane;
-        int slot = -1;
-        bool bnd = false;
-        if (i < n) {
-            const int L = label[i];
-            if (L >= 0) {
-                slot = slot_of_root[L];
-                if (slot >= 0) {
-                    const int r = i / cols, c = i - r * cols;
-                    bnd = r == 0 || r == rows - 1 || c == 0 || c == cols - 1 || label[i - 1] != L || label[i + 1] != L ||
-                          label[i - cols] != L || label[i + cols] != L;
-                }
-            }
-        }
+        const int slot = slots[chunk];
+        const bool bnd = slot >= 0;
         unsigned long long mask = __ballot(bnd);
         if (mask == 0ull) continue;
         float u = 0.f, v = 0.f;
         if (bnd) {
-            const SlotFrame F = frames[slot];
-            const float dx = xyz[3 * (size_t)i] - F.c[0], dy = xyz[3 * (size_t)i + 1] - F.c[1], dz = xyz[3 * (size_t)i + 2] - F.c[2];
-            u = dx * F.e1[0] + dy * F.e1[1] + dz * F.e1[2];
-            v = dx * F.e2[0] + dy * F.e2[1] + dz * F.e2[2];
+            float f9[9];
+            if (slot < n_frames_lds) {
+#pragma unroll
+                for (int q = 0; q < 9; ++q) f9[q] = fr[slot][q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < 9; ++q) f9[q] = reinterpret_cast<const float*>(frames + slot)[q];
+            }
+            const float dx = px[chunk] - f9[0], dy = py[chunk] - f9[1], dz = pz[chunk] - f9[2];
+            u = dx * f9[3] + dy * f9[4] + dz * f9[5];
+            v = dx * f9[6] + dy * f9[7] + dz * f9[8];
         }
         // per direction: the largest dot product so far and the wave-lane of the pixel that has it (keys are only formed at a flush)
         int cur = -1;
@@ -1380,42 +1424,64 @@ __global__ __launch_bounds__(kHullBlock) void k_f360_hull_extremes(const float* 
         if (cur >= 0) flush();
     }
     __syncthreads();
+    // The block's table goes to memory as it is -- rows of its own, no atomics: 256 blocks x 6 walls x 256 directions of global
+    // atomicMax on 33 rows were 23 of the kernel's 27 us (same-address contention at the memory side).  k_f360_hull_pack takes the
+    // maximum over the blocks' rows of a slot.  (Runs that found the block's table full went to `ext` directly: also read there.)
+    if (threadIdx.x < kHullHash) part_keys[blockIdx.x * kHullHash + threadIdx.x] = keys[threadIdx.x];
     for (int k = threadIdx.x; k < kHullHash * kHullDirs; k += kHullBlock) {
-        const int h = k / kHullDirs, d = k - h * kHullDirs;
-        const int s = keys[h];
-        const unsigned long long val = vals[h][d];
-        if (s >= 0 && val != 0ull) atomicMax(&ext[(size_t)s * kHullDirs + d], val);
+        const int h = k / kHullDirs;
+        if (keys[h] >= 0) part_vals[(size_t)blockIdx.x * kHullHash * kHullDirs + k] = vals[h][k - h * kHullDirs];
     }
 }
 __global__ __launch_bounds__(kHullDirs) void k_f360_hull_pack(const float* __restrict__ xyz, const SlotFrame* __restrict__ frames,
                                                                const unsigned long long* __restrict__ ext, const int* __restrict__ n_slots,
-                                                               int max_slots, F360HullRecord* __restrict__ out) {
-    const int slot = blockIdx.x, k = threadIdx.x;
-    if (slot >= min(*n_slots, max_slots)) return;
-    const unsigned long long key = ext[(size_t)slot * kHullDirs + k];
-    const SlotFrame F = frames[slot];
-    float u = __builtin_nanf(""), v = __builtin_nanf("");
-    if (key != 0ull) {
-        const size_t pix = (size_t)(unsigned)(key & 0xFFFFFFFFull);
-        const float dx = xyz[3 * pix] - F.c[0], dy = xyz[3 * pix + 1] - F.c[1], dz = xyz[3 * pix + 2] - F.c[2];
-        u = dx * F.e1[0] + dy * F.e1[1] + dz * F.e1[2];
-        v = dx * F.e2[0] + dy * F.e2[1] + dz * F.e2[2];
-    }
-    out[slot].uv[k][0] = u;
-    out[slot].uv[k][1] = v;
+                                                               int max_slots, const int* __restrict__ part_keys,
+                                                               const unsigned long long* __restrict__ part_vals, int n_part,
+                                                               F360HullRecord* __restrict__ out) {
+    const int k = threadIdx.x;
+    const int ns = min(*n_slots, max_slots);
     __shared__ int cnt_sh;
-    if (k == 0) cnt_sh = 0;
-    __syncthreads();
-    const unsigned long long found = __ballot(key != 0ull);
-    if ((k & 63) == 0) atomicAdd(&cnt_sh, __builtin_popcountll(found));
-    __syncthreads();
-    const int cnt = cnt_sh;
-    if (k < 3) {
-        out[slot].c[k] = F.c[k];
-        out[slot].e1[k] = F.e1[k];
-        out[slot].e2[k] = F.e2[k];
+    __shared__ int n_match;
+    __shared__ int match[4096];                            // rows of the partial tables that belong to the slot (one per block at most)
+    for (int slot = blockIdx.x; slot < ns; slot += gridDim.x) {      // (a block per slot of the 4096 possible ones cost 9 us of empty launches)
+        if (k == 0) n_match = 0;
+        __syncthreads();
+        for (int e = k; e < n_part; e += kHullDirs)
+            if (part_keys[e] == slot) {
+                const int q = atomicAdd(&n_match, 1);
+                if (q < 4096) match[q] = e;
+            }
+        __syncthreads();
+        unsigned long long key = ext[(size_t)slot * kHullDirs + k];
+        const int nm = min(n_match, 4096);
+        for (int q = 0; q < nm; ++q) {
+            const unsigned long long cand = part_vals[(size_t)match[q] * kHullDirs + k];
+            key = cand > key ? cand : key;
+        }
+        const SlotFrame F = frames[slot];
+        float u = __builtin_nanf(""), v = __builtin_nanf("");
+        if (key != 0ull) {
+            const size_t pix = (size_t)(unsigned)(key & 0xFFFFFFFFull);
+            const float dx = xyz[3 * pix] - F.c[0], dy = xyz[3 * pix + 1] - F.c[1], dz = xyz[3 * pix + 2] - F.c[2];
+            u = dx * F.e1[0] + dy * F.e1[1] + dz * F.e1[2];
+            v = dx * F.e2[0] + dy * F.e2[1] + dz * F.e2[2];
+        }
+        out[slot].uv[k][0] = u;
+        out[slot].uv[k][1] = v;
+        if (k == 0) cnt_sh = 0;
+        __syncthreads();
+        const unsigned long long found = __ballot(key != 0ull);
+        if ((k & 63) == 0) atomicAdd(&cnt_sh, __builtin_popcountll(found));
+        __syncthreads();
+        const int cnt = cnt_sh;
+        if (k < 3) {
+            out[slot].c[k] = F.c[k];
+            out[slot].e1[k] = F.e1[k];
+            out[slot].e2[k] = F.e2[k];
+        }
+        if (k == 0) out[slot].n = cnt;
+        __syncthreads();
     }
-    if (k == 0) out[slot].n = cnt;
 }
 
 // ---------------------------------------------------------------------------------------------------------

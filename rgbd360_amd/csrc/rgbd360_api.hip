@@ -85,7 +85,10 @@ struct rgbd360_ctx {
     int* f_count_of_slot = nullptr;
     unsigned char *f_pack = nullptr, *f_pack_host = nullptr;      // packed region records: written by the device straight into pinned host memory (f_pack unused)
     f360::SlotFrame* f_frames = nullptr;                          // per region slot: centroid + in-plane basis (hull stage)
-    unsigned long long* f_ext = nullptr;                          // per region slot: 64 directional extremes {ordered dot, pixel}
+    unsigned long long* f_ext = nullptr;                          // per region slot: 256 directional extremes {ordered dot, pixel} (overflow path of the block tables)
+    int* f_hull_keys = nullptr;                                   // per block of k_f360_hull_extremes: the slots of its table rows ...
+    unsigned long long* f_hull_vals = nullptr;                    // ... and the rows (256 extremes each)
+    int f_hull_blocks = 0;
     unsigned long long* b_sum = nullptr;                          // bilateral grid: fixed-point sums, counts, two float2 ping-pong arrays
     int* b_cnt = nullptr;
     float2 *b_a = nullptr, *b_b = nullptr;
@@ -630,7 +633,7 @@ void rgbd360_destroy(rgbd360_ctx* ctx) {
         if (ctx->conv_ev[k]) hipEventDestroy(ctx->conv_ev[k]);
     }
     if (ctx->up_stream) { hipStreamSynchronize(ctx->up_stream); hipStreamDestroy(ctx->up_stream); }
-    hipFree(ctx->f_frames); hipFree(ctx->f_ext);
+    hipFree(ctx->f_frames); hipFree(ctx->f_ext); hipFree(ctx->f_hull_keys); hipFree(ctx->f_hull_vals);
     hipFree(ctx->f_xyz); hipFree(ctx->f_normals); hipFree(ctx->f_dist);
     hipFree(ctx->f_change); hipFree(ctx->f_hd); hipFree(ctx->f_label); hipFree(ctx->f_count); hipFree(ctx->f_slot_of_root);
     hipFree(ctx->f_root_of_slot); hipFree(ctx->f_nslots); hipFree(ctx->f_window); hipFree(ctx->f_mom);
@@ -1649,9 +1652,9 @@ int f360_ensure(rgbd360_ctx* ctx, size_t n) {
     hipFree(ctx->f_xyz); hipFree(ctx->f_normals); hipFree(ctx->f_dist);
     hipFree(ctx->f_change); hipFree(ctx->f_hd); hipFree(ctx->f_label); hipFree(ctx->f_count); hipFree(ctx->f_slot_of_root);
     hipFree(ctx->f_root_of_slot); hipFree(ctx->f_nslots); hipFree(ctx->f_window); hipFree(ctx->f_mom);
-    hipFree(ctx->f_count_of_slot); hipFree(ctx->f_depth_raw); hipFree(ctx->f_pack); hipFree(ctx->f_frames); hipFree(ctx->f_ext);
+    hipFree(ctx->f_count_of_slot); hipFree(ctx->f_depth_raw); hipFree(ctx->f_pack); hipFree(ctx->f_frames); hipFree(ctx->f_ext); hipFree(ctx->f_hull_keys); hipFree(ctx->f_hull_vals);
     if (ctx->f_pack_host) hipHostFree(ctx->f_pack_host);
-    ctx->f_frames = nullptr; ctx->f_ext = nullptr;
+    ctx->f_frames = nullptr; ctx->f_ext = nullptr; ctx->f_hull_keys = nullptr; ctx->f_hull_vals = nullptr;
     ctx->f_xyz = ctx->f_normals = ctx->f_dist = nullptr;         // a failed allocation below must not leave freed pointers behind
     ctx->f_change = nullptr; ctx->f_hd = nullptr; ctx->f_label = nullptr; ctx->f_count = nullptr; ctx->f_slot_of_root = nullptr;
     ctx->f_root_of_slot = nullptr; ctx->f_nslots = nullptr; ctx->f_window = nullptr; ctx->f_mom = nullptr;
@@ -1675,6 +1678,9 @@ int f360_ensure(rgbd360_ctx* ctx, size_t n) {
     HIPC(ctx, hipHostMalloc(&ctx->f_pack_host, pack_bytes, hostwait::kPublishedFlags));
     HIPC(ctx, hipMalloc(&ctx->f_frames, (size_t)kF360MaxSlots * sizeof(f360::SlotFrame)));
     HIPC(ctx, hipMalloc(&ctx->f_ext, (size_t)kF360MaxSlots * f360::kHullDirs * sizeof(unsigned long long)));
+    ctx->f_hull_blocks = (int)((n + (size_t)f360::kHullBlock * f360::kHullChunks - 1) / ((size_t)f360::kHullBlock * f360::kHullChunks));
+    HIPC(ctx, hipMalloc(&ctx->f_hull_keys, (size_t)ctx->f_hull_blocks * f360::kHullHash * sizeof(int)));
+    HIPC(ctx, hipMalloc(&ctx->f_hull_vals, (size_t)ctx->f_hull_blocks * f360::kHullHash * f360::kHullDirs * sizeof(unsigned long long)));
     HIPC(ctx, hipMalloc(&ctx->f_depth_raw, n * 4));
     ctx->f360_n = n;
     return 0;
@@ -1884,10 +1890,11 @@ void launch_hull(rgbd360_ctx* ctx, int rows, int cols, bool clear_first) {
     using namespace f360;
     const int n = rows * cols;
     if (clear_first) hipLaunchKernelGGL(k_f360_hull_clear, dim3((kF360MaxSlots * kHullDirs + 255) / 256), dim3(256), 0, ctx->stream, ctx->f_nslots, kF360MaxSlots, ctx->f_ext);
-    hipLaunchKernelGGL(k_f360_hull_extremes, dim3((n + kHullBlock * kHullChunks - 1) / (kHullBlock * kHullChunks)), dim3(kHullBlock), 0, ctx->stream, ctx->f_xyz, ctx->f_label, ctx->f_slot_of_root, rows, cols,
-                       ctx->f_frames, ctx->f_ext);
-    hipLaunchKernelGGL(k_f360_hull_pack, dim3(kF360MaxSlots), dim3(kHullDirs), 0, ctx->stream, ctx->f_xyz, ctx->f_frames, ctx->f_ext, ctx->f_nslots, kF360MaxSlots,
-                       const_cast<F360HullRecord*>(hull_records(ctx)));
+    const int nblk = (n + kHullBlock * kHullChunks - 1) / (kHullBlock * kHullChunks);      // <= ctx->f_hull_blocks (sized for the context's largest frame)
+    hipLaunchKernelGGL(k_f360_hull_extremes, dim3(nblk), dim3(kHullBlock), 0, ctx->stream, ctx->f_xyz, ctx->f_label, ctx->f_slot_of_root, rows, cols,
+                       ctx->f_frames, ctx->f_ext, ctx->f_hull_keys, ctx->f_hull_vals, kHullFramesLds);
+    hipLaunchKernelGGL(k_f360_hull_pack, dim3(256), dim3(kHullDirs), 0, ctx->stream, ctx->f_xyz, ctx->f_frames, ctx->f_ext, ctx->f_nslots, kF360MaxSlots,
+                       ctx->f_hull_keys, ctx->f_hull_vals, nblk * kHullHash, const_cast<F360HullRecord*>(hull_records(ctx)));
 }
 
 void sorted_eigen3(const double C[3][3], double evals[3], double evecs[3][3]) {    // evecs[k] = eigenvector of evals[k]
@@ -2045,7 +2052,7 @@ int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float
     hipLaunchKernelGGL(k_f360_moments, gmom, bagg, 0, ctx->stream, ctx->f_xyz, ctx->f_label, ctx->f_slot_of_root, n, ctx->f_mom, kF360MaxSlots);
     // hull stage: per slot the in-plane frame (and an empty extremes row); the extremes themselves now, or -- with the refinement
     // switched on -- once the refined labels are committed (f360_refine_dev)
-    hipLaunchKernelGGL(k_f360_slot_frames, dim3(kF360MaxSlots), dim3(64), 0, ctx->stream, ctx->f_mom, ctx->f_nslots, kF360MaxSlots,
+    hipLaunchKernelGGL(k_f360_slot_frames, dim3(256), dim3(64), 0, ctx->stream, ctx->f_mom, ctx->f_nslots, kF360MaxSlots,
                        ctx->f_count_of_slot, ctx->f_frames, ctx->f_ext);
     if (!ctx->f_refine) launch_hull(ctx, rows, cols, /*clear_first=*/false);
     // the packing kernel writes the header + records straight into pinned host memory (a few KB over PCIe): no copy to enqueue,

@@ -12,5 +12,10 @@ reps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
 reg = RegisterPhotoICP(); reg.setNumPyr(4)
 reg.setTargetFrame(rgbA, dA); reg.setSourceFrame(rgbB, dB)
 for method in (0, 2):
-    us = reg.time_eval_kernel(0, T, method, True, reps)
-    print("method", method, "avg us", us)
+    us = reg.time_eval_kernel(0, T, method, True, reps)       # k_eval: the per-pixel pass alone
+    print("method", method, "k_eval avg us", us)
+    try:
+        us = reg.time_eval_kernel(0, T, method, 2, reps)      # k_eval_fs: solve prologue + pass (forced schedule)
+        print("method", method, "k_eval_fs avg us", us)
+    except Exception as e:                                    # RGBD360_FUSED_SOLVE=0
+        print("method", method, "k_eval_fs not run:", e)
