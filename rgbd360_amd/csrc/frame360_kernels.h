@@ -1378,12 +1378,37 @@ __global__ __launch_bounds__(kHullBlock) void k_f360_hull_extremes(const float* 
             u = dx * f9[3] + dy * f9[4] + dz * f9[5];
             v = dx * f9[6] + dy * f9[7] + dz * f9[8];
         }
-        // per direction: the largest dot product so far and the wave-lane of the pixel that has it (keys are only formed at a flush)
-        int cur = -1;
-        float bd[4];
-        int bj[4];
-        auto flush = [&]() {
-            // the slot's row of the block's table (wave-uniform linear probe; a full table sends the run straight to memory)
+        // The stretch's boundary pixels are taken slot by slot (a ballot per distinct slot, typically two: the two sides of an edge
+        // alternate along a row, and a flush per RUN of equal slots -- hash probe, four LDS atomics with a wait each -- cost ~1200
+        // cycles); per direction: the largest dot product so far and the lane of the pixel that has it, keys are only formed at the flush.
+        unsigned long long remaining = mask;
+        while (remaining != 0ull) {
+            const int cur = __builtin_amdgcn_readlane(slot, __builtin_ctzll(remaining));
+            unsigned long long todo = __ballot(bnd && slot == cur);
+            remaining &= ~todo;
+            float bd[4];
+            int bj[4];
+            {
+                const int j = __builtin_ctzll(todo);
+                todo &= todo - 1ull;
+                const float uj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u), j));
+                const float vj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), j));
+                const float d0 = fmaf(uj, ck, vj * sk), d1 = fmaf(vj, ck, -(uj * sk));
+                bd[0] = d0; bd[1] = d1; bd[2] = -d0; bd[3] = -d1;
+                bj[0] = bj[1] = bj[2] = bj[3] = j;
+            }
+            while (todo != 0ull) {                         // wave-uniform walk, ascending: ties keep the first
+                const int j = __builtin_ctzll(todo);
+                todo &= todo - 1ull;
+                const float uj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u), j));
+                const float vj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), j));
+                const float d0 = fmaf(uj, ck, vj * sk), d1 = fmaf(vj, ck, -(uj * sk));
+                if (d0 > bd[0]) { bd[0] = d0; bj[0] = j; }
+                if (d1 > bd[1]) { bd[1] = d1; bj[1] = j; }
+                if (-d0 > bd[2]) { bd[2] = -d0; bj[2] = j; }
+                if (-d1 > bd[3]) { bd[3] = -d1; bj[3] = j; }
+            }
+            // the slot's row of the block's table (wave-uniform linear probe; a full table sends the maxima straight to memory)
             int h = -1;
             for (int q = 0; q < kHullHash && h < 0; ++q) {
                 const int k = (cur + q) & (kHullHash - 1);
@@ -1395,37 +1420,22 @@ __global__ __launch_bounds__(kHullBlock) void k_f360_hull_extremes(const float* 
                 }
                 if (seen == cur) h = k;
             }
+            unsigned long long key[4];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const unsigned long long key = ((unsigned long long)hull_f2ord(bd[m]) << 32) | (unsigned)(first + bj[m]);
-                if (h >= 0) atomicMax(&vals[h][64 * m + lane], key);
-                else atomicMax(&ext[(size_t)cur * kHullDirs + 64 * m + lane], key);
+            for (int m = 0; m < 4; ++m) key[m] = ((unsigned long long)hull_f2ord(bd[m]) << 32) | (unsigned)(first + bj[m]);
+            if (h >= 0) {                                  // the four maxima at once, nothing waits for them
+                unsigned long long* row = &vals[h][lane];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) __hip_atomic_fetch_max(row + 64 * m, key[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) atomicMax(&ext[(size_t)cur * kHullDirs + 64 * m + lane], key[m]);
             }
-        };
-        while (mask != 0ull) {                                 // wave-uniform walk over the boundary pixels, ascending: ties keep the first
-            const int j = __builtin_ctzll(mask);
-            mask &= mask - 1ull;
-            const int sj = __builtin_amdgcn_readlane(slot, j);
-            const float uj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u), j));
-            const float vj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), j));
-            const float d0 = fmaf(uj, ck, vj * sk), d1 = fmaf(vj, ck, -(uj * sk));
-            if (sj != cur) {
-                if (cur >= 0) flush();
-                cur = sj;
-                bd[0] = d0; bd[1] = d1; bd[2] = -d0; bd[3] = -d1;
-                bj[0] = bj[1] = bj[2] = bj[3] = j;
-                continue;
-            }
-            if (d0 > bd[0]) { bd[0] = d0; bj[0] = j; }
-            if (d1 > bd[1]) { bd[1] = d1; bj[1] = j; }
-            if (-d0 > bd[2]) { bd[2] = -d0; bj[2] = j; }
-            if (-d1 > bd[3]) { bd[3] = -d1; bj[3] = j; }
         }
-        if (cur >= 0) flush();
     }
     __syncthreads();
     // The block's table goes to memory as it is -- rows of its own, no atomics: 256 blocks x 6 walls x 256 directions of global
-    // atomicMax on 33 rows were 23 of the kernel's 27 us (same-address contention at the memory side).  k_f360_hull_pack takes the
+    // atomicMax on 33 rows were 23 of the kernel's 27 us (same-address contention at the memory side).  k_f360_hull_merge takes the
     // maximum over the blocks' rows of a slot.  (Runs that found the block's table full went to `ext` directly: also read there.)
     if (threadIdx.x < kHullHash) part_keys[blockIdx.x * kHullHash + threadIdx.x] = keys[threadIdx.x];
     for (int k = threadIdx.x; k < kHullHash * kHullDirs; k += kHullBlock) {
@@ -1433,31 +1443,57 @@ __global__ __launch_bounds__(kHullBlock) void k_f360_hull_extremes(const float* 
         if (keys[h] >= 0) part_vals[(size_t)blockIdx.x * kHullHash * kHullDirs + k] = vals[h][k - h * kHullDirs];
     }
 }
-__global__ __launch_bounds__(kHullDirs) void k_f360_hull_pack(const float* __restrict__ xyz, const SlotFrame* __restrict__ frames,
-                                                               const unsigned long long* __restrict__ ext, const int* __restrict__ n_slots,
-                                                               int max_slots, const int* __restrict__ part_keys,
-                                                               const unsigned long long* __restrict__ part_vals, int n_part,
-                                                               F360HullRecord* __restrict__ out) {
-    const int k = threadIdx.x;
+// The blocks' tables -> the global rows of extremes.  A wall met by every block has a 2 KB row in each table (256 at 2048 x 1024, 1024 at
+// 4096 x 2048): ONE block streaming them is bound by what a single block reads (~30-60 GB/s: 19 / 75 us per frame when the packing
+// kernel did it, and anything that put a dependent look-up in front of each row load made every row a full memory round trip:
+// 160 us).  Here kHullMergeSplit blocks share a slot's rows -- block (slot, m) takes the tables of the blocks b = m mod 8 -- and meet
+// in the global row with one atomicMax per direction (8 adders per word).
+constexpr int kHullMergeSplit = 8;
+__global__ __launch_bounds__(kHullDirs) void k_f360_hull_merge(const int* __restrict__ n_slots, int max_slots, const int* __restrict__ part_keys,
+                                                                const unsigned long long* __restrict__ part_vals, int n_blocks,
+                                                                unsigned long long* __restrict__ ext) {
+    const int k = threadIdx.x, m = blockIdx.y;
     const int ns = min(*n_slots, max_slots);
-    __shared__ int cnt_sh;
     __shared__ int n_match;
-    __shared__ int match[4096];                            // rows of the partial tables that belong to the slot (one per block at most)
-    for (int slot = blockIdx.x; slot < ns; slot += gridDim.x) {      // (a block per slot of the 4096 possible ones cost 9 us of empty launches)
+    __shared__ int match[1024];                            // table rows of this block's share that belong to the slot
+    for (int slot = blockIdx.x; slot < ns; slot += gridDim.x) {
         if (k == 0) n_match = 0;
         __syncthreads();
-        for (int e = k; e < n_part; e += kHullDirs)
-            if (part_keys[e] == slot) {
-                const int q = atomicAdd(&n_match, 1);
-                if (q < 4096) match[q] = e;
+        // keys of the tables b = m, m + 8, ...: 16 per table
+        const int n_mine = (n_blocks - m + kHullMergeSplit - 1) / kHullMergeSplit;
+        for (int e = k; e < n_mine * kHullHash; e += kHullDirs) {
+            const int at = (m + (e / kHullHash) * kHullMergeSplit) * kHullHash + (e & (kHullHash - 1));
+            const bool hit = part_keys[at] == slot;
+            const unsigned long long hits = __ballot(hit);
+            if (hits != 0ull) {                            // one LDS atomic per wave with a hit
+                int base = 0;
+                if ((k & 63) == (int)__builtin_ctzll(hits)) base = atomicAdd(&n_match, __builtin_popcountll(hits));
+                base = __builtin_amdgcn_readlane(base, __builtin_ctzll(hits));
+                if (hit) {
+                    const int q = base + __builtin_popcountll(hits & ((1ull << (k & 63)) - 1ull));
+                    if (q < 1024) match[q] = at;
+                }
             }
+        }
         __syncthreads();
-        unsigned long long key = ext[(size_t)slot * kHullDirs + k];
-        const int nm = min(n_match, 4096);
-        for (int q = 0; q < nm; ++q) {
+        const int nm = min(n_match, 1024);
+        unsigned long long key = 0ull;
+        for (int q = 0; q < nm; ++q) {                     // (plain loop: the row loads pipeline)
             const unsigned long long cand = part_vals[(size_t)match[q] * kHullDirs + k];
             key = cand > key ? cand : key;
         }
+        if (key != 0ull) atomicMax(&ext[(size_t)slot * kHullDirs + k], key);
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(kHullDirs) void k_f360_hull_pack(const float* __restrict__ xyz, const SlotFrame* __restrict__ frames,
+                                                               const unsigned long long* __restrict__ ext, const int* __restrict__ n_slots,
+                                                               int max_slots, F360HullRecord* __restrict__ out) {
+    const int k = threadIdx.x;
+    const int ns = min(*n_slots, max_slots);
+    __shared__ int cnt_sh;
+    for (int slot = blockIdx.x; slot < ns; slot += gridDim.x) {      // (a block per slot of the 4096 possible ones cost 9 us of empty launches)
+        const unsigned long long key = ext[(size_t)slot * kHullDirs + k];
         const SlotFrame F = frames[slot];
         float u = __builtin_nanf(""), v = __builtin_nanf("");
         if (key != 0ull) {
