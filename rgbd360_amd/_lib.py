@@ -5,7 +5,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librgbd360_hip.so")
+LIB_PATH = os.environ.get("RGBD360_LIB") or os.path.join(_HERE, "lib", "librgbd360_hip.so")     # RGBD360_LIB: another build of the library (A/B runs)
 
 # Every symbol include/rgbd360_hip.h declares (checked by tests/test_abi.py against the header text).
 SYMBOLS = [

@@ -5,8 +5,10 @@ hipcc cross-compiles without a GPU; the resulting .so travels with the repositor
 from __future__ import annotations
 
 import os
+import re
 import shutil
 import subprocess
+import tempfile
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(_HERE, "csrc", "rgbd360_api.hip")
@@ -41,13 +43,64 @@ def needs_build() -> bool:
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in DEPS)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if force or needs_build():
-        os.makedirs(os.path.dirname(LIB), exist_ok=True)
-        cmd = [hipcc()] + FLAGS + ["-o", LIB, SRC] + LINK
+LLVM_BIN = "/opt/rocm/lib/llvm/bin"
+_SELECT_E32 = re.compile(r"^(\s*)v_cndmask_b32_e32(\s+)(v\d+), ([^,]+), ([^,]+), vcc(\s*(;.*)?)$")
+
+
+def widen_selects(asm_in: str, asm_out: str) -> int:
+    """Rewrites every `v_cndmask_b32_e32 vD, a, b, vcc` of a device-ISA dump into the VOP3 encoding of the same instruction.
+    Measured on gfx950 (tools/ubench/vcc_select.hip, valu_peak2.hip): the VOP2 form costs a SIMD 9.6 ns per wave-instruction
+    whoever wrote VCC (only the select directly behind the v_cmp that produced VCC is exempt), the VOP3 form - naming VCC or any
+    SGPR pair - 2.1-2.4 ns, like every other simple VALU instruction.  The compiler's shrink pass prefers the 4-byte VOP2 form and
+    has no switch; same instruction, same operands, same result: only the encoding (and 4 bytes of code) changes.
+    In the product kernels the selects are never back to back, and the whole-library A/B (tools/ab_libs.py run default plain; Frame360
+    kernel trace of both builds) moved nothing by more than 1 %: the product build stays the one-shot hipcc build, and this path is
+    kept for RGBD360_BUILD_SELECTS_VOP3=1 and for A/B runs."""
+    n = 0
+    out = []
+    with open(asm_in) as f:
+        for line in f:
+            m = _SELECT_E32.match(line.rstrip("\n"))
+            if m:
+                line = "%sv_cndmask_b32_e64%s%s, %s, %s, vcc%s\n" % (m.group(1), m.group(2), m.group(3), m.group(4).strip(), m.group(5).strip(), m.group(6) or "")
+                n += 1
+            out.append(line)
+    with open(asm_out, "w") as f:
+        f.writelines(out)
+    return n
+
+
+def compile_library(out: str, extra_flags=(), verbose: bool = False, selects_vop3: bool = True) -> str:
+    """hipcc in two halves: device code to assembly, the select encoding widened (widen_selects), assembled + linked + bundled with the
+    LLVM tools hipcc itself drives, then the host half compiled with that bundle embedded (`-fcuda-include-gpubinary`, what the driver
+    does internally).  selects_vop3=False is the plain one-shot hipcc build (A/B: tools/ab_libs.py)."""
+    def run(cmd):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+    flags = FLAGS + list(extra_flags)
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    if not selects_vop3:
+        run([hipcc()] + flags + ["-o", out, SRC] + LINK)
+        return out
+    dev_flags = [f for f in flags if f not in ("-shared", "-pthread")]
+    with tempfile.TemporaryDirectory(prefix="rgbd360_build_") as tmp:
+        asm, asm2, obj, hsaco, fb = (os.path.join(tmp, n) for n in ("dev.s", "dev_e64.s", "dev.o", "dev.hsaco", "dev.hipfb"))
+        run([hipcc()] + dev_flags + ["-S", "--cuda-device-only", "-o", asm, SRC])
+        n = widen_selects(asm, asm2)
+        if verbose:
+            print("widen_selects: %d v_cndmask_b32_e32 -> _e64" % n)
+        run([os.path.join(LLVM_BIN, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", asm2, "-o", obj])
+        run([os.path.join(LLVM_BIN, "lld"), "-flavor", "gnu", "-m", "elf64_amdgpu", "--no-undefined", "-shared", "-o", hsaco, obj])
+        run([os.path.join(LLVM_BIN, "clang-offload-bundler"), "-type=o", "-bundle-align=4096",
+             "-targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950", "-input=/dev/null", "-input=" + hsaco, "-output=" + fb])
+        run([hipcc()] + flags + ["--cuda-host-only", "-Xclang", "-fcuda-include-gpubinary", "-Xclang", fb, "-o", out, SRC] + LINK)
+    return out
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if force or needs_build():
+        compile_library(LIB, verbose=verbose, selects_vop3=os.environ.get("RGBD360_BUILD_SELECTS_VOP3", "0") == "1")
     return LIB
 
 

@@ -1298,12 +1298,18 @@ __device__ __forceinline__ unsigned hull_f2ord(float f) {          // order-pres
     const unsigned b = __float_as_uint(f);
     return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
 }
-// A block of 16 waves covers kHullChunks stretches of 1024 pixels and keeps the extremes of the (few) regions it meets in LDS; a region
-// costs a block ONE global atomic per direction, at the end.  The walk over a wave's boundary pixels is serial (every lane updates
-// its four directions per pixel), so the work sits where the long, nearly horizontal edges are: a block's stretches are taken a
-// grid's width apart, which spreads every such edge over all blocks (with eight consecutive stretches per block -- and 64-bit keys
-// in the inner loop -- the kernel took 77 us, the straggler blocks being those along the floor's and ceiling's edges).
-constexpr int kHullBlock = 1024, kHullChunks = 8, kHullHash = 16, kHullFramesLds = 256;
+// A block of 16 waves covers 16 x kHullChunks stretches of 64 pixels, scattered over the image (see hull_stretch below), and keeps the
+// extremes of the regions it meets in LDS (kHullHash rows; a region beyond that goes to memory directly); its table is written to
+// memory as rows of its own at the end.  The walk over a wave's boundary pixels is serial (every lane updates its four directions per
+// pixel), so the work sits where the long, nearly horizontal edges are.  (First version: eight consecutive 1024-pixel stretches per
+// block and 64-bit keys in the inner loop, 77 us, the straggler blocks being those along the floor's and ceiling's edges.)
+constexpr int kHullBlock = 1024, kHullChunks = 8, kHullHash = 32, kHullFramesLds = 256;
+#ifdef RGBD360_HULL_DBG          // diagnostic build (tools/hull_stamps.py): per-wave clock accounting of k_f360_hull_extremes
+__device__ unsigned long long g_hull_dbg[4096][8];
+#define HDBG_T() __builtin_readcyclecounter()
+#else
+#define HDBG_T() 0ull
+#endif
 __global__ __launch_bounds__(kHullBlock) void k_f360_hull_extremes(const float* __restrict__ xyz, const int* __restrict__ label,
                                                                     const int* __restrict__ slot_of_root, int rows, int cols,
                                                                     const SlotFrame* __restrict__ frames, unsigned long long* __restrict__ ext,
@@ -1312,53 +1318,109 @@ __global__ __launch_bounds__(kHullBlock) void k_f360_hull_extremes(const float* 
     __shared__ unsigned long long vals[kHullHash][kHullDirs];
     __shared__ float fr[kHullFramesLds][9];                // centroid + in-plane axes of the first slots: no dependent gather in front of the walk
     const int lane = threadIdx.x & 63;
+    const unsigned long long hd_t0 = HDBG_T();
+    unsigned long long hd_walk = 0, hd_flush = 0, hd_uv = 0, hd_entries = 0, hd_runs = 0;
+    const int n = rows * cols;
+    // Stretch `chunk` of wave w in block b starts at pixel 64 ((chunk 16 + w) gridDim + b): the 64-pixel stretches of an image row go
+    // to CONSECUTIVE BLOCKS.  The walk below is serial per wave (~30 instructions per boundary pixel), and a long horizontal edge
+    // fills every stretch along its row; while a block owned 1024 consecutive pixels those were the 16 waves of two blocks, four
+    // walking waves per SIMD sharing its issue slots: 300 cycles per pixel, 20 k cycles per stretch, on two CUs, with the other 254 idle
+    // (tools/hull_stamps.py).  Spread over 32 (64 at 4096 x 2048) CUs, each such stretch has a SIMD almost to itself.
+    // Shift by the slot index k: with plain interleaving a VERTICAL edge (the same 64-pixel column in every row) would meet the same
+    // gridDim / (stretches per row) blocks in every row; this way all blocks take turns, and a block's share of such an edge falls on
+    // one of its waves.
+    const int wave_u = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // first pixel and first column of the wave's stretches, all wave-uniform, with TWO integer divisions per wave: from one stretch to the
+    // next k grows by 16, the stretch index by 16 G + 16 (minus G where (b + k) mod G wraps), the column by that many pixels modulo the width
+    const int G = (int)gridDim.x;
+    int first_of[kHullChunks], col_of[kHullChunks];
+    {
+        int j = ((int)blockIdx.x + wave_u) % G;
+        int first = (wave_u * G + j) * 64;
+        int c0 = first % cols;
+        const int step_px = ((kHullBlock / 64) * G + (kHullBlock / 64)) * 64;
+        int step_c = step_px, wrap_c = G * 64;
+        if (step_c >= cols) step_c %= cols;
+        if (wrap_c >= cols) wrap_c %= cols;
+#pragma unroll
+        for (int chunk = 0; chunk < kHullChunks; ++chunk) {
+            first_of[chunk] = first;
+            col_of[chunk] = c0;
+            j += kHullBlock / 64;
+            first += step_px;
+            c0 += step_c;
+            while (j >= G) {                               // (more than once only for grids under 16 blocks)
+                j -= G;
+                first -= G * 64;
+                c0 -= wrap_c;
+            }
+            while (c0 < 0) c0 += cols;
+            while (c0 >= cols) c0 -= cols;
+        }
+    }
+    auto hull_stretch = [&](int chunk) { return first_of[chunk]; };
+    // The labels of all the wave's stretches are requested first (before the block's tables are set up: the first memory round trip
+    // of a launch is the long one), then all the slot look-ups: two memory round trips for the eight stretches instead of two per
+    // stretch (one after the other they were most of the kernel's 34 us; the serial walk only runs where there is a boundary).
+    // Range-checked buffer loads with one 32-bit lane offset (a pixel outside the image reads 0 and is masked): with 64-bit addresses
+    // and a division per lane and stretch this part was 770 vector instructions per wave, 5.7 us of issue with four waves per SIMD.
+    const __amdgpu_buffer_rsrc_t r_lab = __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(label), 0, n * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_xyz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xyz), 0, n * 12, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_sor = __builtin_amdgcn_make_buffer_rsrc(const_cast<int*>(slot_of_root), 0, n * 4, 0x00020000);
+    int Lc[kHullChunks];
+    bool differs[kHullChunks];
+    int Lraw[kHullChunks][5];
+    bool edge_of[kHullChunks];
+#pragma unroll
+    for (int chunk = 0; chunk < kHullChunks; ++chunk) {
+        const int i = first_of[chunk] + lane;
+        int c = col_of[chunk] + lane;
+        while (__ballot(c >= cols) != 0ull) c = c >= cols ? c - cols : c;      // once for images at least 64 wide
+        edge_of[chunk] = i < cols || i >= n - cols || c == 0 || c == cols - 1;
+        // a neighbour outside the image reads 0: only border pixels have one, and they count as boundary anyway
+        const int vo = i * 4;
+        Lraw[chunk][0] = __builtin_amdgcn_raw_buffer_load_b32(r_lab, vo, 0, 0);
+        Lraw[chunk][1] = __builtin_amdgcn_raw_buffer_load_b32(r_lab, vo - 4, 0, 0);
+        Lraw[chunk][2] = __builtin_amdgcn_raw_buffer_load_b32(r_lab, vo + 4, 0, 0);
+        Lraw[chunk][3] = __builtin_amdgcn_raw_buffer_load_b32(r_lab, vo - cols * 4, 0, 0);
+        Lraw[chunk][4] = __builtin_amdgcn_raw_buffer_load_b32(r_lab, vo + cols * 4, 0, 0);
+    }
     for (int k = threadIdx.x; k < n_frames_lds * 9; k += kHullBlock) {
         const int sl = k / 9, q = k - sl * 9;
         fr[sl][q] = reinterpret_cast<const float*>(frames + sl)[q];      // SlotFrame starts with c[3], e1[3], e2[3]
     }
     for (int k = threadIdx.x; k < kHullHash * kHullDirs; k += kHullBlock) (&vals[0][0])[k] = 0ull;
     if (threadIdx.x < kHullHash) keys[threadIdx.x] = -1;
-    __syncthreads();
-    const int n = rows * cols;
     // this lane's direction (cos, sin) at angle 2 pi lane / 256 and its three quarter-turn rotations: direction lane + 64 m, m = 0 .. 3,
-    // has the dot products d0 = u c + v s, d1 = v c - u s, -d0, -d1
-    float sk, ck;
-    sincospif((float)lane * (2.f / kHullDirs), &sk, &ck);
-    // The labels of all the wave's stretches are requested first, then all the slot look-ups: two memory round trips for the eight
-    // stretches instead of two per stretch (one after the other they were most of the kernel's 34 us; the serial walk only runs where
-    // there is a boundary).
-    int Lc[kHullChunks];
-    bool differs[kHullChunks];
+    // has the dot products d0 = u c + v s, d1 = v c - u s, -d0, -d1.  (The hardware's sine / cosine take revolutions; any 256 directions
+    // spread over the circle do, they need not be exact.)
+    const float sk = __builtin_amdgcn_sinf((float)lane * (1.f / kHullDirs)), ck = __builtin_amdgcn_cosf((float)lane * (1.f / kHullDirs));
 #pragma unroll
     for (int chunk = 0; chunk < kHullChunks; ++chunk) {
-        const int i = ((chunk * (int)gridDim.x + (int)blockIdx.x) * (kHullBlock / 64) + (int)(threadIdx.x >> 6)) * 64 + lane;
-        Lc[chunk] = -1;
-        differs[chunk] = false;
-        if (i < n) {
-            const int r = i / cols, c = i - r * cols;
-            const bool edge = r == 0 || r == rows - 1 || c == 0 || c == cols - 1;
-            // clamped neighbours: on the image border the test below is true anyway
-            const int L = label[i], Ll = label[edge ? i : i - 1], Lr = label[edge ? i : i + 1], Lu = label[edge ? i : i - cols], Ld = label[edge ? i : i + cols];
-            Lc[chunk] = L;
-            differs[chunk] = edge || Ll != L || Lr != L || Lu != L || Ld != L;
-        }
+        const int L = Lraw[chunk][0];
+        const bool inside = hull_stretch(chunk) + lane < n;
+        Lc[chunk] = inside ? L : -1;
+        differs[chunk] = inside && L >= 0 && (edge_of[chunk] || Lraw[chunk][1] != L || Lraw[chunk][2] != L || Lraw[chunk][3] != L || Lraw[chunk][4] != L);
     }
     // second round trip, again for all stretches at once: the slot of every pixel whose label differs from a neighbour's, and its point
     int slots[kHullChunks];
     float px[kHullChunks], py[kHullChunks], pz[kHullChunks];
 #pragma unroll
     for (int chunk = 0; chunk < kHullChunks; ++chunk) {
-        const int i = ((chunk * (int)gridDim.x + (int)blockIdx.x) * (kHullBlock / 64) + (int)(threadIdx.x >> 6)) * 64 + lane;
+        const int i = hull_stretch(chunk) + lane;
         slots[chunk] = -1;
         px[chunk] = py[chunk] = pz[chunk] = 0.f;
-        if (Lc[chunk] >= 0 && differs[chunk]) {
-            slots[chunk] = slot_of_root[Lc[chunk]];
-            px[chunk] = xyz[3 * (size_t)i]; py[chunk] = xyz[3 * (size_t)i + 1]; pz[chunk] = xyz[3 * (size_t)i + 2];
+        if (differs[chunk]) {
+            slots[chunk] = __builtin_amdgcn_raw_buffer_load_b32(r_sor, Lc[chunk] * 4, 0, 0);
+            const f3v w = (f3v)__builtin_amdgcn_raw_buffer_load_b96(r_xyz, i * 12, 0, 0);
+            px[chunk] = w.x; py[chunk] = w.y; pz[chunk] = w.z;
         }
     }
+    __syncthreads();                                    // the block's tables (set up while the labels were in flight)
+    const unsigned long long hd_t1 = HDBG_T();
 #pragma unroll
     for (int chunk = 0; chunk < kHullChunks; ++chunk) {
-        const int first = ((chunk * (int)gridDim.x + (int)blockIdx.x) * (kHullBlock / 64) + (int)(threadIdx.x >> 6)) * 64;      // this wave's first pixel
+        const int first = hull_stretch(chunk);             // this wave's first pixel
         if (first >= n) break;                             // wave-uniform
         const int slot = slots[chunk];
         const bool bnd = slot >= 0;
@@ -1433,6 +1495,7 @@ __global__ __launch_bounds__(kHullBlock) void k_f360_hull_extremes(const float* 
             }
         }
     }
+    const unsigned long long hd_t2 = HDBG_T();
     __syncthreads();
     // The block's table goes to memory as it is -- rows of its own, no atomics: 256 blocks x 6 walls x 256 directions of global
     // atomicMax on 33 rows were 23 of the kernel's 27 us (same-address contention at the memory side).  k_f360_hull_merge takes the
@@ -1442,6 +1505,12 @@ __global__ __launch_bounds__(kHullBlock) void k_f360_hull_extremes(const float* 
         const int h = k / kHullDirs;
         if (keys[h] >= 0) part_vals[(size_t)blockIdx.x * kHullHash * kHullDirs + k] = vals[h][k - h * kHullDirs];
     }
+#ifdef RGBD360_HULL_DBG
+    if (lane == 0) {
+        unsigned long long* o = g_hull_dbg[(blockIdx.x * (kHullBlock / 64) + (threadIdx.x >> 6)) & 4095];
+        o[0] = hd_t1 - hd_t0; o[1] = hd_t2 - hd_t1; o[2] = HDBG_T() - hd_t2; o[3] = hd_uv; o[4] = hd_walk; o[5] = hd_flush; o[6] = hd_entries; o[7] = hd_runs;
+    }
+#endif
 }
 // The blocks' tables -> the global rows of extremes.  A wall met by every block has a 2 KB row in each table (256 at 2048 x 1024, 1024 at
 // 4096 x 2048): ONE block streaming them is bound by what a single block reads (~30-60 GB/s: 19 / 75 us per frame when the packing

@@ -2634,3 +2634,9 @@ extern "C" int rgbd360_merge_planes(const rgbd360_plane* planes, int n, float ma
 }
 
 #include "multi_gpu.h"
+
+#ifdef RGBD360_HULL_DBG
+extern "C" int rgbd360_debug_hull_stats(unsigned long long* out /* [4096][8] */) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(f360::g_hull_dbg), sizeof(unsigned long long) * 4096 * 8) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -15,7 +15,8 @@ def lib_of(name):
 if sys.argv[1] == "build":
     for spec in sys.argv[2:]:
         name, _, flags = spec.partition("=")
-        subprocess.check_call([B.hipcc()] + B.FLAGS + [f for f in flags.split(",") if f] + ["-o", lib_of(name), B.SRC] + B.LINK)
+        fl = [f for f in flags.split(",") if f]
+        B.compile_library(lib_of(name), [f for f in fl if f != "plain"], selects_vop3="plain" not in fl)     # NAME=plain: one-shot hipcc build (VOP2 selects)
         print(lib_of(name))
     sys.exit(0)
 
