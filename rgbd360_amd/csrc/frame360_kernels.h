@@ -138,7 +138,12 @@ __global__ __launch_bounds__(kEdgeTW) void k_f360_edge_bits(const float* __restr
 constexpr int kDistTW = 64, kDistTH = 32, kDistThreads = 256;
 constexpr int kDistRows = kDistTH + 2 * kF360R;
 __global__ __launch_bounds__(kDistThreads) void k_f360_distmap(const unsigned long long* __restrict__ bits, int rows, int cols, int pitch_words,
-                                                              float* __restrict__ dist) {
+                                                              float* __restrict__ dist, unsigned* __restrict__ clear_words, int n_clear) {
+    // (the normal-map sweep's claim flags + tile count, cleared here: as a memset of their own they were two 5 us fill launches)
+    {
+        const int g = (blockIdx.y * gridDim.x + blockIdx.x) * kDistThreads + threadIdx.x;
+        if (g < n_clear) clear_words[g] = 0u;
+    }
     __shared__ unsigned long long words[kDistRows][3];
     __shared__ uint8_t hd[kDistRows][kDistTW];              // 4 * min(row distance, kF360R + 1): a byte offset into a LUT row
     __shared__ float lut[kF360R + 1][16];                    // lut[|dy|][dx]: chamfer value; dx = kF360R + 1: no change pixel in that row
@@ -1224,9 +1229,13 @@ struct F360HullRecord {
 // l0 is the largest cross product of two rows of C - l0 I.  (A cyclic Jacobi in one thread per slot took 77 us per frame.)
 __global__ __launch_bounds__(64) void k_f360_slot_frames(const unsigned long long* __restrict__ mom, const int* __restrict__ n_slots, int max_slots,
                                                          const int* __restrict__ count_of_slot, SlotFrame* __restrict__ frames,
-                                                         unsigned long long* __restrict__ ext) {
+                                                         unsigned long long* __restrict__ ext, const int* __restrict__ root_of_slot,
+                                                         unsigned char* __restrict__ pack) {
     const int lane = threadIdx.x;
     const int ns = min(*n_slots, max_slots);
+    // pack != nullptr: this kernel also does k_f360_mom_reduce's job (the moment sums it forms anyway, root and count, into the pinned
+    // record the host reads) -- when no refinement will change the sums afterwards
+    if (pack && blockIdx.x == 0 && lane == 0) *reinterpret_cast<int*>(pack) = *n_slots;
     for (int slot = blockIdx.x; slot < ns; slot += gridDim.x) {
 #pragma unroll
     for (int k = 0; k < kHullDirs / 64; ++k) ext[(size_t)slot * kHullDirs + 64 * k + lane] = 0ull;
@@ -1235,6 +1244,14 @@ __global__ __launch_bounds__(64) void k_f360_slot_frames(const unsigned long lon
         unsigned long long acc = 0ull;
         for (int r = 0; r < kMomReplicas; ++r) acc += mom[((size_t)r * max_slots + slot) * 9 + lane];
         mine = (double)(long long)acc / kMomScale;
+        if (pack) {
+            F360SlotRecord* rec = reinterpret_cast<F360SlotRecord*>(pack + kF360PackHeader) + slot;
+            rec->mom[lane] = acc;
+            if (lane == 0) {
+                rec->root = root_of_slot[slot];
+                rec->count = count_of_slot[slot];
+            }
+        }
     }
     double m[9];
 #pragma unroll

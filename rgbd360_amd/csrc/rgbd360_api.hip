@@ -1687,7 +1687,8 @@ int f360_ensure(rgbd360_ctx* ctx, size_t n) {
 }
 
 // distance to the nearest depth change of the organised cloud in ctx->f_xyz -> ctx->f_dist (device); f_hd holds the bit mask
-static void launch_distance_map(rgbd360_ctx* ctx, int rows, int cols, float max_depth_change_factor, int depth_mode) {
+static void launch_distance_map(rgbd360_ctx* ctx, int rows, int cols, float max_depth_change_factor, int depth_mode, unsigned* clear_words = nullptr,
+                                int n_clear = 0) {
     using namespace f360;
     const int pitch = (cols + 63) / 64;
     unsigned long long* bits = reinterpret_cast<unsigned long long*>(ctx->f_hd);
@@ -1701,7 +1702,7 @@ static void launch_distance_map(rgbd360_ctx* ctx, int rows, int cols, float max_
                            pitch, bits, ctx->f_cloud_pending, ctx->f_xyz);
     }
     hipLaunchKernelGGL(k_f360_distmap, dim3(pitch, (rows + kDistTH - 1) / kDistTH), dim3(kDistThreads), 0, ctx->stream, bits, rows, cols,
-                       pitch, ctx->f_dist);
+                       pitch, ctx->f_dist, clear_words, n_clear);
 }
 
 // normals of the organised cloud in ctx->f_xyz -> ctx->f_normals (device)
@@ -1709,11 +1710,11 @@ int f360_normals_dev(rgbd360_ctx* ctx, int rows, int cols, float max_depth_chang
     using namespace f360;
     if (smoothing_size < 1.f || smoothing_size + 2.5f > (float)kF360R)
         return fail(ctx, -1, "normal_smoothing_size out of range (the distance map is truncated at 12 px)");
-    launch_distance_map(ctx, rows, cols, max_depth_change_factor, depth_mode);
     const dim3 gt((cols + kNT_W - 1) / kNT_W, (rows + kNT_H - 1) / kNT_H);
     // Register sweep for the pixels whose window is int(smoothing_size) squared (nearly all of them), the tiled integral-image kernel
     // for the 32 x 16 tiles the sweep lists (depth edges, far points).  Claim flags + tile list: the first bytes of f_change, which the
-    // distance map no longer needs (the plane stage rewrites it).  RGBD360_NORMALS_SWEEP=0 keeps the tiled kernel for everything (A/B).
+    // distance map does not touch (the plane stage rewrites it); the distance-map kernel clears them on its way.
+    // RGBD360_NORMALS_SWEEP=0 keeps the tiled kernel for everything (A/B).
     const int R = (int)smoothing_size;
     static const bool sweep_off = [] { const char* e = getenv("RGBD360_NORMALS_SWEEP"); return e && atoi(e) == 0; }();
     const bool use_sweep = !sweep_off && R >= 3 && R <= 10 && ((size_t)gt.x * gt.y * 2 + 2) * sizeof(unsigned) <= (size_t)rows * cols &&
@@ -1723,7 +1724,9 @@ int f360_normals_dev(rgbd360_ctx* ctx, int rows, int cols, float max_depth_chang
     if (use_sweep) {
         flags = reinterpret_cast<unsigned*>(ctx->f_change);
         list = flags + n_tiles;
-        HIPC(ctx, hipMemsetAsync(flags, 0, (size_t)(n_tiles + 1) * sizeof(unsigned), ctx->stream));
+    }
+    launch_distance_map(ctx, rows, cols, max_depth_change_factor, depth_mode, flags, use_sweep ? n_tiles + 1 : 0);
+    if (use_sweep) {
         // rows per wave: 3 waves per SIMD stay resident (146 VGPRs: 3072 on the chip); a wave costs R - 1 warm-up rows + its rows, and
         // the kernel ends with the most loaded SIMD, so the wave count is kept within one residency round.  16 rows per wave is the
         // measured optimum at 2048 x 1024 (28.6 us; 8: 28.5, 24: 31.6, 32: 39.4), 16-32 at 4096 x 2048 (85-88 us; 48: 101) --
@@ -1818,7 +1821,6 @@ int f360_bilateral_dev(rgbd360_ctx* ctx, int rows, int cols, float sigma_s, floa
     return 0;
 }
 
-// eigenpairs of a symmetric 3x3 in ascending order (cyclic Jacobi, float64) -- pcl::eigen33's role for the smallest one
 // Convex hull of the <= 256 directional extremes of a region, its area (shoelace) and mass centre -- the
 // roles of mrpt::pbmap::Plane::calcConvexHull / computeMassCenterAndArea (Frame360.h:1025-1031) in the region's own in-plane frame.
 struct HullStats {
@@ -1899,6 +1901,7 @@ void launch_hull(rgbd360_ctx* ctx, int rows, int cols, bool clear_first) {
                        const_cast<F360HullRecord*>(hull_records(ctx)));
 }
 
+// eigenpairs of a symmetric 3x3 in ascending order (cyclic Jacobi, float64) -- pcl::eigen33's role for the smallest one
 void sorted_eigen3(const double C[3][3], double evals[3], double evecs[3][3]) {    // evecs[k] = eigenvector of evals[k]
     double ev[3], V[3][3];
     pbm::jacobi3(C, ev, V);
@@ -2054,13 +2057,12 @@ int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float
     hipLaunchKernelGGL(k_f360_moments, gmom, bagg, 0, ctx->stream, ctx->f_xyz, ctx->f_label, ctx->f_slot_of_root, n, ctx->f_mom, kF360MaxSlots);
     // hull stage: per slot the in-plane frame (and an empty extremes row); the extremes themselves now, or -- with the refinement
     // switched on -- once the refined labels are committed (f360_refine_dev)
+    // The header + records go straight into pinned host memory (a few KB over PCIe): no copy to enqueue, one wait.  (Four copies into
+    // pageable vectors with two waits used to cost ~0.1 ms of the 0.45 ms call.)  The frame kernel packs them on its way (it sums the
+    // moment replicas anyway); k_f360_mom_reduce only runs behind the refinement's commit, which changes the sums.
     hipLaunchKernelGGL(k_f360_slot_frames, dim3(256), dim3(64), 0, ctx->stream, ctx->f_mom, ctx->f_nslots, kF360MaxSlots,
-                       ctx->f_count_of_slot, ctx->f_frames, ctx->f_ext);
+                       ctx->f_count_of_slot, ctx->f_frames, ctx->f_ext, ctx->f_root_of_slot, ctx->f_pack_host);
     if (!ctx->f_refine) launch_hull(ctx, rows, cols, /*clear_first=*/false);
-    // the packing kernel writes the header + records straight into pinned host memory (a few KB over PCIe): no copy to enqueue,
-    // one wait.  (Four copies into pageable vectors with two waits used to cost ~0.1 ms of the 0.45 ms call.)
-    hipLaunchKernelGGL(k_f360_mom_reduce, dim3((kF360MaxSlots * 9 + 255) / 256), dim3(256), 0, ctx->stream, ctx->f_mom, ctx->f_nslots, kF360MaxSlots,
-                       ctx->f_root_of_slot, ctx->f_count_of_slot, ctx->f_pack_host);
     HIPC(ctx, hipGetLastError());
     HIPC(ctx, hipStreamSynchronize(ctx->stream));
     const int nslots = *reinterpret_cast<const volatile int*>(ctx->f_pack_host);
