@@ -647,6 +647,10 @@ struct Pose16 {
     float v[16];
 };
 __device__ __forceinline__ void level_init_one(GNState* st, const Pose16& pose, int use_pose, int reset_all, int level);
+struct FsInit {            // k_eval_fs: on != 0 = start a schedule at `pose` on the launch's level (what k_level_init(pose, reset_all) does)
+    Pose16 pose;
+    int on;
+};
 __global__ void k_level_init(GNState* st, Pose16 pose, int use_pose, int reset_all, int level) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     level_init_one(st, pose, use_pose, reset_all, level);
@@ -1246,7 +1250,7 @@ template <int METHOD>
 __global__ __launch_bounds__(kEvalThreads) void k_eval_fs(const GNState* __restrict__ st_in, GNState* __restrict__ st_out,
                                                            const double* __restrict__ partials_in, double* __restrict__ partials_out,
                                                            const float4* __restrict__ src0, int n_px, int chunk, int level, int nb_arg,
-                                                           LevelDev lv, EvalConsts ec, SolveCfg cfg) {
+                                                           LevelDev lv, EvalConsts ec, SolveCfg cfg, FsInit init) {
     static_assert(kEvalThreads == kSolveThreads, "the fused launch runs the solve on the pass's block");
     unsigned long long es[6] = {0, 0, 0, 0, 0, 0};
 #ifdef RGBD360_EVAL_STAMPS
@@ -1260,7 +1264,12 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_fs(const GNState* __restr
     if (threadIdx.x == 0) sh.stamp0 = __builtin_amdgcn_s_memrealtime();
 #endif
     // what the solve waits for is requested first (a wave's vector-memory operations complete in issue order) ...
-    const int pend = stage_pending(sh, st_in, partials_in);
+    int pend = stage_pending(sh, st_in, partials_in);
+    if (init.on) {                              // uniform: the first launch of a schedule is its k_level_init too (every block initialises
+        if (threadIdx.x == 0) level_init_one(&sh.sst, init.pose, 1, 1, level);      // its own LDS copy of the state, block 0 writes it out)
+        __syncthreads();
+        pend = 0;
+    }
     SOLVE_STAMP(0);
     const int nb = nb_arg;
     const int b = blockIdx.x;

@@ -347,14 +347,19 @@ SolveCfg fused_cfg(const rgbd360_ctx* ctx, int forced) {
     cfg.tol_residual = ctx->p.tol_residual; cfg.tol_update = ctx->p.tol_update;
     return cfg;
 }
-void launch_eval_fused(rgbd360_ctx* ctx, int level, int method, int forced) {
+// init_pose != nullptr: the launch starts the schedule itself at that pose (no k_level_init in front of it)
+void launch_eval_fused(rgbd360_ctx* ctx, int level, int method, int forced, const float* init_pose = nullptr) {
+    FsInit init;
+    init.on = init_pose ? 1 : 0;
+    if (init_pose) memcpy(init.pose.v, init_pose, sizeof(init.pose.v));
+    else memset(init.pose.v, 0, sizeof(init.pose.v));
     const Level& L = ctx->levels[level];
     const LevelDev lv = level_dev(L);
     const EvalConsts ec = eval_consts(ctx->p);
     const SolveCfg cfg = fused_cfg(ctx, forced);
     dim3 g(L.nblocks), b(kEvalThreads);
 #define LAUNCHF(M) hipLaunchKernelGGL((k_eval_fs<M>), g, b, 0, ctx->stream, (const GNState*)ctx->d_state, ctx->d_state_alt, (const double*)ctx->d_partials, \
-                                      ctx->d_partials_alt, lv.src, lv.n, L.chunk, level, L.nblocks, lv, ec, cfg)
+                                      ctx->d_partials_alt, lv.src, lv.n, L.chunk, level, L.nblocks, lv, ec, cfg, init)
     if (method == 0) LAUNCHF(0);
     else if (method == 1) LAUNCHF(1);
     else LAUNCHF(2);
@@ -703,18 +708,19 @@ int rgbd360_promote_source_to_target(rgbd360_ctx* ctx) {
 static void enqueue_schedule(rgbd360_ctx* ctx, int pending, bool pending_started) {
     const int top = ctx->p.n_pyr - 1;
     for (int level = pending; level >= 0; --level) {
-        if (level == top && !pending_started)        // the finer levels are entered by k_solve itself when a level finishes
-            launch_level_init(ctx, level, ctx->al_guess, 1);
+        const bool fused = fused_ok(ctx, ctx->al_occ);
+        const bool start = level == top && !pending_started;      // the finer levels are entered by the solve itself when a level finishes
+        if (start && !fused) launch_level_init(ctx, level, ctx->al_guess, 1);      // (the fused schedule's first launch initialises the state itself)
         int n_pairs = (level == top && !pending_started) ? ctx->first_chunk_top : (level == 0 ? ctx->chunk_level0 : ctx->poll_chunk);
         // Consecutive alignments of a sequence take much the same number of iterations per level: the first visit of a level is
         // given what the previous alignment needed there (its accepted iterations + the pass that ends the level + one spare)
         // instead of the fixed chunk -- fewer no-op launches on the coarse levels (~3 us each), no second round trip on level 0.
         if (ctx->adaptive_chunks && !(level == pending && pending_started) && ctx->hist_iters[level & 7] >= 0)
             n_pairs = std::min(std::max(ctx->hist_iters[level & 7] + 2, 2), 12);
-        if (fused_ok(ctx, ctx->al_occ)) {
+        if (fused) {
             // one launch per iteration: n_pairs passes, each carrying the solve of the one before it; the solve of the chunk's last
             // pass rides in the next level's first launch, the schedule's very last one in a one-block launch that publishes
-            for (int k = 0; k < n_pairs; ++k) launch_eval_fused(ctx, level, ctx->al_method, 0);
+            for (int k = 0; k < n_pairs; ++k) launch_eval_fused(ctx, level, ctx->al_method, 0, start && k == 0 ? ctx->al_guess : nullptr);
             if (level == 0) launch_solve_pending(ctx, 0, /*publish=*/true);
             continue;
         }
@@ -1113,10 +1119,11 @@ int rgbd360_forced_iters(rgbd360_ctx* ctx, int level, const float pose0[16], int
     if (rc) return rc;
     if (!pose0 || n_iters < 1) return fail(ctx, -1, "bad arguments");
     hipSetDevice(ctx->p.device);
-    launch_level_init(ctx, level, pose0, 1);
+    const bool fold_init = fused_ok(ctx, 0) && !elapsed_ms;      // the first fused launch initialises the state itself (timed calls keep
+    if (!fold_init) launch_level_init(ctx, level, pose0, 1);      // the initialisation outside the events)
     if (elapsed_ms) HIPC(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     if (fused_ok(ctx, 0)) {       // n_iters launches {solve of the previous pass, pass} + the last solve
-        for (int k = 0; k < n_iters; ++k) launch_eval_fused(ctx, level, method, 1);
+        for (int k = 0; k < n_iters; ++k) launch_eval_fused(ctx, level, method, 1, fold_init && k == 0 ? pose0 : nullptr);
         launch_solve_pending(ctx, 1, /*publish=*/!elapsed_ms);
     } else {
         for (int k = 0; k < n_iters; ++k) {
