@@ -157,3 +157,26 @@ def test_bin_loader_reads_the_boost_archive_layout(tmp_path):
         evil.write_bytes(b"\x00" * 45 + hdr + b"\x00" * 64)
         with pytest.raises(Rgbd360Error):
             load_frame_bin(str(evil))
+
+
+def test_build_select_widening_only_changes_the_encoding(tmp_path):
+    """rgbd360_amd/build.py can re-encode VOP2 selects as VOP3 in the device assembly (an optional build): the rewrite
+    touches exactly the `v_cndmask_b32_e32 ..., vcc` lines, keeps operands and comments, and leaves everything else byte for byte."""
+    from rgbd360_amd import build as B
+    src = tmp_path / "in.s"
+    dst = tmp_path / "out.s"
+    lines = [
+        "\tv_cndmask_b32_e32 v17, 0, v11, vcc\n",
+        "\tv_cndmask_b32_e32 v5, v6, v7, vcc ; select\n",
+        "\tv_cndmask_b32_e64 v1, v2, v3, s[4:5]\n",          # already VOP3
+        "\tv_cndmask_b32_e32 v1, v2, v3, s[4:5]\n",          # not a VCC select: left alone
+        "\tv_fma_f32 v0, v1, v2, v3\n",
+        "\tv_cndmask_b32_sdwa v1, v2, v3, vcc dst_sel:DWORD\n",
+        ".LBB0_1:\n",
+    ]
+    src.write_text("".join(lines))
+    assert B.widen_selects(str(src), str(dst)) == 2
+    out = dst.read_text().splitlines(keepends=True)
+    assert out[0] == "\tv_cndmask_b32_e64 v17, 0, v11, vcc\n"
+    assert out[1].startswith("\tv_cndmask_b32_e64 v5, v6, v7, vcc") and "; select" in out[1]
+    assert out[2:] == lines[2:]
