@@ -1444,6 +1444,7 @@ __global__ __launch_bounds__(kHullBlock) void k_f360_hull_extremes(const float* 
         unsigned long long mask = __ballot(bnd);
         if (mask == 0ull) continue;
         float u = 0.f, v = 0.f;
+        const unsigned long long hd_a = HDBG_T();
         if (bnd) {
             float f9[9];
             if (slot < n_frames_lds) {
@@ -1461,10 +1462,16 @@ __global__ __launch_bounds__(kHullBlock) void k_f360_hull_extremes(const float* 
         // alternate along a row, and a flush per RUN of equal slots -- hash probe, four LDS atomics with a wait each -- cost ~1200
         // cycles); per direction: the largest dot product so far and the lane of the pixel that has it, keys are only formed at the flush.
         unsigned long long remaining = mask;
+#ifdef RGBD360_HULL_DBG
+        asm volatile("" :: "v"(u), "v"(v));
+        hd_uv += HDBG_T() - hd_a;
+#endif
         while (remaining != 0ull) {
             const int cur = __builtin_amdgcn_readlane(slot, __builtin_ctzll(remaining));
             unsigned long long todo = __ballot(bnd && slot == cur);
             remaining &= ~todo;
+            const unsigned long long hd_b = HDBG_T();
+            hd_entries += __builtin_popcountll(todo); hd_runs += 1;
             float bd[4];
             int bj[4];
             {
@@ -1487,6 +1494,11 @@ __global__ __launch_bounds__(kHullBlock) void k_f360_hull_extremes(const float* 
                 if (-d0 > bd[2]) { bd[2] = -d0; bj[2] = j; }
                 if (-d1 > bd[3]) { bd[3] = -d1; bj[3] = j; }
             }
+#ifdef RGBD360_HULL_DBG
+            asm volatile("" :: "v"(bd[0]), "v"(bd[1]), "v"(bd[2]), "v"(bd[3]));
+#endif
+            const unsigned long long hd_c = HDBG_T();
+            hd_walk += hd_c - hd_b;
             // the slot's row of the block's table (wave-uniform linear probe; a full table sends the maxima straight to memory)
             int h = -1;
             for (int q = 0; q < kHullHash && h < 0; ++q) {
@@ -1510,6 +1522,7 @@ __global__ __launch_bounds__(kHullBlock) void k_f360_hull_extremes(const float* 
 #pragma unroll
                 for (int m = 0; m < 4; ++m) atomicMax(&ext[(size_t)cur * kHullDirs + 64 * m + lane], key[m]);
             }
+            hd_flush += HDBG_T() - hd_c;
         }
     }
     const unsigned long long hd_t2 = HDBG_T();

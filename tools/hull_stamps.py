@@ -35,5 +35,9 @@ for w in order[:12]:
     print("  wave %4d  %8.0f | " % (w, tot[w]) + " ".join("%8.0f" % x for x in b[w]))
 for q in (50, 90, 99, 100):
     print("percentile %3d of wave totals: %.0f" % (q, np.percentile(tot, q)))
+bw = int(order[0]) // 16
+print("all waves of the slowest block (%d), by time in the stretches:" % bw)
+for w in sorted(range(bw * 16, bw * 16 + 16), key=lambda w: -b[w, 1]):
+    print("  wave %4d  %8.0f | " % (w, tot[w]) + " ".join("%8.0f" % x for x in b[w]))
 blk = tot.reshape(256, 16).max(1)
 print("block = max of its waves: mean %.0f  max %.0f" % (blk.mean(), blk.max()))
