@@ -1213,14 +1213,20 @@ __global__ void k_f360_mom_reduce(const unsigned long long* __restrict__ mom, co
 //   k_f360_hull_extremes per 64-pixel stretch: boundary test, in-plane coordinates, directional maxima
 //   k_f360_hull_pack     winners' coordinates + the frame into the pinned record the host reads
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kHullDirs = 256;       // 4 per lane: a lane's direction and its rotations by 90, 180, 270 degrees share two dot products
+constexpr int kHullDirs = 256;       // per block, 4 per lane: a lane's direction and its rotations by 90, 180, 270 degrees share two dot products
+// Four direction sets, a quarter of the angular step apart: block b works with set b mod 4.  Thanks to the scattered stretches every
+// block sees a sample of every edge of a region, so the union of the four sets' winners is a polygon of up to 1024 region pixels, still
+// inscribed in the hull -- at no cost in the walk.  One set's 1.4-degree step cannot see the bow of a long, nearly straight edge whose
+// normals all fall between two directions: the 8 m walls of a room lost 0.4-0.6 % of their hull (tests/tools/hull_soak.py).
+constexpr int kHullPhases = 4;
+constexpr int kHullRecPts = kHullPhases * kHullDirs;     // points a record can hold; a point that wins several directions of a set is sent once
 struct SlotFrame {
     float c[3], e1[3], e2[3], nrm[3];
 };
 struct F360HullRecord {
     float c[3], e1[3], e2[3];
-    int n;                              // directions that found a pixel
-    float uv[kHullDirs][2];             // in-plane coordinates of the extreme pixel per direction (NaN: none)
+    int n;                              // points that follow, roughly in direction order (the host sorts them anyway)
+    float uv[kHullRecPts][2];           // in-plane coordinates of the extreme pixels
 };
 // One WAVE per slot.  Lanes 0-8 sum the moment replicas, lane 0 fits the plane, all lanes clear the slot's row of extremes.  Only the
 // NORMAL has to be accurate (the hull's area does not depend on the in-plane axes): it is the eigenvector of the covariance's smallest
@@ -1238,7 +1244,7 @@ __global__ __launch_bounds__(64) void k_f360_slot_frames(const unsigned long lon
     if (pack && blockIdx.x == 0 && lane == 0) *reinterpret_cast<int*>(pack) = *n_slots;
     for (int slot = blockIdx.x; slot < ns; slot += gridDim.x) {
 #pragma unroll
-    for (int k = 0; k < kHullDirs / 64; ++k) ext[(size_t)slot * kHullDirs + 64 * k + lane] = 0ull;
+    for (int k = 0; k < kHullPhases * kHullDirs / 64; ++k) ext[(size_t)slot * kHullPhases * kHullDirs + 64 * k + lane] = 0ull;
     double mine = 0.0;
     if (lane < 9) {
         unsigned long long acc = 0ull;
@@ -1309,7 +1315,7 @@ __global__ __launch_bounds__(64) void k_f360_slot_frames(const unsigned long lon
 }
 __global__ void k_f360_hull_clear(const int* __restrict__ n_slots, int max_slots, unsigned long long* __restrict__ ext) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < min(*n_slots, max_slots) * kHullDirs) ext[i] = 0ull;
+    if (i < min(*n_slots, max_slots) * kHullPhases * kHullDirs) ext[i] = 0ull;
 }
 __device__ __forceinline__ unsigned hull_f2ord(float f) {          // order-preserving float -> unsigned
     const unsigned b = __float_as_uint(f);
@@ -1411,7 +1417,9 @@ __global__ __launch_bounds__(kHullBlock) void k_f360_hull_extremes(const float* 
     // this lane's direction (cos, sin) at angle 2 pi lane / 256 and its three quarter-turn rotations: direction lane + 64 m, m = 0 .. 3,
     // has the dot products d0 = u c + v s, d1 = v c - u s, -d0, -d1.  (The hardware's sine / cosine take revolutions; any 256 directions
     // spread over the circle do, they need not be exact.)
-    const float sk = __builtin_amdgcn_sinf((float)lane * (1.f / kHullDirs)), ck = __builtin_amdgcn_cosf((float)lane * (1.f / kHullDirs));
+    const int phase = (int)blockIdx.x & (kHullPhases - 1);
+    const float rev = (float)(lane * kHullPhases + phase) * (1.f / (kHullDirs * kHullPhases));
+    const float sk = __builtin_amdgcn_sinf(rev), ck = __builtin_amdgcn_cosf(rev);
 #pragma unroll
     for (int chunk = 0; chunk < kHullChunks; ++chunk) {
         const int L = Lraw[chunk][0];
@@ -1520,7 +1528,7 @@ __global__ __launch_bounds__(kHullBlock) void k_f360_hull_extremes(const float* 
                 for (int m = 0; m < 4; ++m) __hip_atomic_fetch_max(row + 64 * m, key[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             } else {
 #pragma unroll
-                for (int m = 0; m < 4; ++m) atomicMax(&ext[(size_t)cur * kHullDirs + 64 * m + lane], key[m]);
+                for (int m = 0; m < 4; ++m) atomicMax(&ext[((size_t)cur * kHullPhases + phase) * kHullDirs + 64 * m + lane], key[m]);
             }
             hd_flush += HDBG_T() - hd_c;
         }
@@ -1581,40 +1589,69 @@ __global__ __launch_bounds__(kHullDirs) void k_f360_hull_merge(const int* __rest
             const unsigned long long cand = part_vals[(size_t)match[q] * kHullDirs + k];
             key = cand > key ? cand : key;
         }
-        if (key != 0ull) atomicMax(&ext[(size_t)slot * kHullDirs + k], key);
+        if (key != 0ull) atomicMax(&ext[((size_t)slot * kHullPhases + (m & (kHullPhases - 1))) * kHullDirs + k], key);      // (tables b = m mod 8 share the set m mod 4)
         __syncthreads();
     }
 }
 __global__ __launch_bounds__(kHullDirs) void k_f360_hull_pack(const float* __restrict__ xyz, const SlotFrame* __restrict__ frames,
                                                                const unsigned long long* __restrict__ ext, const int* __restrict__ n_slots,
                                                                int max_slots, F360HullRecord* __restrict__ out) {
+    static_assert(kHullMergeSplit % kHullPhases == 0, "the merge blocks of a slot pair up with the direction sets");
     const int k = threadIdx.x;
     const int ns = min(*n_slots, max_slots);
-    __shared__ int cnt_sh;
+    __shared__ int pix_sh[kHullDirs * kHullPhases];
+    __shared__ int wave_cnt[kHullDirs / 64];
     for (int slot = blockIdx.x; slot < ns; slot += gridDim.x) {      // (a block per slot of the 4096 possible ones cost 9 us of empty launches)
-        const unsigned long long key = ext[(size_t)slot * kHullDirs + k];
-        const SlotFrame F = frames[slot];
-        float u = __builtin_nanf(""), v = __builtin_nanf("");
-        if (key != 0ull) {
-            const size_t pix = (size_t)(unsigned)(key & 0xFFFFFFFFull);
-            const float dx = xyz[3 * pix] - F.c[0], dy = xyz[3 * pix + 1] - F.c[1], dz = xyz[3 * pix + 2] - F.c[2];
-            u = dx * F.e1[0] + dy * F.e1[1] + dz * F.e1[2];
-            v = dx * F.e2[0] + dy * F.e2[1] + dz * F.e2[2];
+        // thread k owns the directions 4 k + p, p = 0 .. 3 (set p's direction k): consecutive in angle
+        int pix[kHullPhases];
+#pragma unroll
+        for (int p = 0; p < kHullPhases; ++p) {
+            const unsigned long long key = ext[((size_t)slot * kHullPhases + p) * kHullDirs + k];
+            pix[p] = key != 0ull ? (int)(unsigned)(key & 0xFFFFFFFFull) : -1;
+            pix_sh[k * kHullPhases + p] = pix[p];
         }
-        out[slot].uv[k][0] = u;
-        out[slot].uv[k][1] = v;
-        if (k == 0) cnt_sh = 0;
         __syncthreads();
-        const unsigned long long found = __ballot(key != 0ull);
-        if ((k & 63) == 0) atomicAdd(&cnt_sh, __builtin_popcountll(found));
+        // a point is sent once per set: dropped when the set's previous direction found the same pixel (a corner wins hundreds; between
+        // the sets duplicates are rare -- they saw different pixels -- and the host's hull removes them)
+        bool keep[kHullPhases];
+        int mine = 0;
+#pragma unroll
+        for (int p = 0; p < kHullPhases; ++p) {
+            const int prev = k > 0 ? pix_sh[(k - 1) * kHullPhases + p] : -1;
+            keep[p] = pix[p] >= 0 && pix[p] != prev;
+            mine += keep[p] ? 1 : 0;
+        }
+        // exclusive prefix over the block: wave scan + wave totals
+        int incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d *= 2) {
+            const int t = __shfl_up(incl, d);
+            if ((k & 63) >= d) incl += t;
+        }
+        if ((k & 63) == 63) wave_cnt[k >> 6] = incl;
         __syncthreads();
-        const int cnt = cnt_sh;
+        int base = incl - mine, total = 0;
+#pragma unroll
+        for (int w = 0; w < kHullDirs / 64; ++w) {
+            if (w < (k >> 6)) base += wave_cnt[w];
+            total += wave_cnt[w];
+        }
+        const SlotFrame F = frames[slot];
+#pragma unroll
+        for (int p = 0; p < kHullPhases; ++p) {
+            if (!keep[p]) continue;
+            const size_t px = (size_t)pix[p];
+            const float dx = xyz[3 * px] - F.c[0], dy = xyz[3 * px + 1] - F.c[1], dz = xyz[3 * px + 2] - F.c[2];
+            out[slot].uv[base][0] = dx * F.e1[0] + dy * F.e1[1] + dz * F.e1[2];
+            out[slot].uv[base][1] = dx * F.e2[0] + dy * F.e2[1] + dz * F.e2[2];
+            ++base;
+        }
         if (k < 3) {
             out[slot].c[k] = F.c[k];
             out[slot].e1[k] = F.e1[k];
             out[slot].e2[k] = F.e2[k];
         }
-        if (k == 0) out[slot].n = cnt;
+        if (k == 0) out[slot].n = total;
         __syncthreads();
     }
 }

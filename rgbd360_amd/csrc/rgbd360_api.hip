@@ -1684,7 +1684,7 @@ int f360_ensure(rgbd360_ctx* ctx, size_t n) {
     const size_t pack_bytes = f360::kF360PackHeader + (size_t)kF360MaxSlots * (sizeof(f360::F360SlotRecord) + sizeof(f360::F360HullRecord));
     HIPC(ctx, hipHostMalloc(&ctx->f_pack_host, pack_bytes, hostwait::kPublishedFlags));
     HIPC(ctx, hipMalloc(&ctx->f_frames, (size_t)kF360MaxSlots * sizeof(f360::SlotFrame)));
-    HIPC(ctx, hipMalloc(&ctx->f_ext, (size_t)kF360MaxSlots * f360::kHullDirs * sizeof(unsigned long long)));
+    HIPC(ctx, hipMalloc(&ctx->f_ext, (size_t)kF360MaxSlots * f360::kHullPhases * f360::kHullDirs * sizeof(unsigned long long)));
     ctx->f_hull_blocks = (int)((n + (size_t)f360::kHullBlock * f360::kHullChunks - 1) / ((size_t)f360::kHullBlock * f360::kHullChunks));
     HIPC(ctx, hipMalloc(&ctx->f_hull_keys, (size_t)ctx->f_hull_blocks * f360::kHullHash * sizeof(int)));
     HIPC(ctx, hipMalloc(&ctx->f_hull_vals, (size_t)ctx->f_hull_blocks * f360::kHullHash * f360::kHullDirs * sizeof(unsigned long long)));
@@ -1828,40 +1828,37 @@ int f360_bilateral_dev(rgbd360_ctx* ctx, int rows, int cols, float sigma_s, floa
     return 0;
 }
 
-// Convex hull of the <= 256 directional extremes of a region, its area (shoelace) and mass centre -- the
-// roles of mrpt::pbmap::Plane::calcConvexHull / computeMassCenterAndArea (Frame360.h:1025-1031) in the region's own in-plane frame.
+// Convex hull of the directional extremes of a region (<= kHullRecPts points), its area (shoelace) and mass centre -- the roles of
+// mrpt::pbmap::Plane::calcConvexHull / computeMassCenterAndArea (Frame360.h:1025-1031) in the region's own in-plane frame.
 struct HullStats {
     int n = 0;                  // hull vertices
     double area = 0, cu = 0, cv = 0;
 };
 HullStats hull_stats(const float (*uv)[2], int K) {
-    // The K support points arrive in direction order = counter-clockwise boundary order (a point that wins several directions
-    // repeats; ties on a straight edge may put collinear points in either order): no sort -- start at the lowest point (a hull
-    // vertex), then one Graham pass over the sequence drops everything that is not a strict left turn.
-    std::pair<double, double> p[f360::kHullDirs];
+    // The points arrive roughly in boundary order (direction order), but the four direction sets each saw their own sample of the
+    // region's pixels, so neighbours may be swapped along an edge: Andrew's monotone chain on the sorted points, which assumes nothing.
+    std::pair<double, double> p[f360::kHullRecPts];
     int n = 0;
-    for (int k = 0; k < K; ++k)
-        if (std::isfinite(uv[k][0]) && std::isfinite(uv[k][1])) {
-            const std::pair<double, double> q(uv[k][0], uv[k][1]);
-            if (n == 0 || q != p[n - 1]) p[n++] = q;
-        }
-    while (n > 1 && p[n - 1] == p[0]) --n;
+    for (int k = 0; k < K && k < f360::kHullRecPts; ++k)
+        if (std::isfinite(uv[k][0]) && std::isfinite(uv[k][1])) p[n++] = std::pair<double, double>(uv[k][0], uv[k][1]);
+    std::sort(p, p + n);
+    n = (int)(std::unique(p, p + n) - p);
     HullStats h;
     if (n < 3) return h;
-    int start = 0;
-    for (int i = 1; i < n; ++i)
-        if (p[i].second < p[start].second || (p[i].second == p[start].second && p[i].first < p[start].first)) start = i;
     auto cross = [](const std::pair<double, double>& o, const std::pair<double, double>& a, const std::pair<double, double>& b) {
         return (a.first - o.first) * (b.second - o.second) - (a.second - o.second) * (b.first - o.first);
     };
-    std::pair<double, double> H[f360::kHullDirs + 1];
+    std::pair<double, double> H[2 * f360::kHullRecPts + 2];
     int m = 0;
-    for (int i = 0; i < n; ++i) {
-        const std::pair<double, double>& q = p[(start + i) % n];
-        while (m >= 2 && cross(H[m - 2], H[m - 1], q) <= 0) --m;
-        H[m++] = q;
+    for (int i = 0; i < n; ++i) {                          // lower hull
+        while (m >= 2 && cross(H[m - 2], H[m - 1], p[i]) <= 0) --m;
+        H[m++] = p[i];
     }
-    while (m >= 3 && cross(H[m - 2], H[m - 1], H[0]) <= 0) --m;      // close the loop
+    for (int i = n - 2, lo = m + 1; i >= 0; --i) {         // upper hull
+        while (m >= lo && cross(H[m - 2], H[m - 1], p[i]) <= 0) --m;
+        H[m++] = p[i];
+    }
+    --m;                                                   // the first point again
     if (m < 3) return h;
     double a2 = 0, cu = 0, cv = 0;
     for (int i = 0; i < m; ++i) {
@@ -1881,7 +1878,7 @@ HullStats hull_stats(const float (*uv)[2], int K) {
 // area / centre of plane P from the hull record of its slot (pinned, written by k_f360_hull_pack); the moment rectangle stays in
 // area_moment, and is the fallback when a region has fewer than three extreme points
 void apply_hull(rgbd360_plane& P, const f360::F360HullRecord& R) {
-    const HullStats h = hull_stats(R.uv, f360::kHullDirs);
+    const HullStats h = hull_stats(R.uv, std::min(std::max(R.n, 0), f360::kHullRecPts));
     P.hull_points = h.n;
     if (h.n >= 3) {
         P.area = (float)h.area;
@@ -1898,7 +1895,7 @@ const f360::F360HullRecord* hull_records(const rgbd360_ctx* ctx) {
 void launch_hull(rgbd360_ctx* ctx, int rows, int cols, bool clear_first) {
     using namespace f360;
     const int n = rows * cols;
-    if (clear_first) hipLaunchKernelGGL(k_f360_hull_clear, dim3((kF360MaxSlots * kHullDirs + 255) / 256), dim3(256), 0, ctx->stream, ctx->f_nslots, kF360MaxSlots, ctx->f_ext);
+    if (clear_first) hipLaunchKernelGGL(k_f360_hull_clear, dim3((kF360MaxSlots * kHullPhases * kHullDirs + 255) / 256), dim3(256), 0, ctx->stream, ctx->f_nslots, kF360MaxSlots, ctx->f_ext);
     const int nblk = (n + kHullBlock * kHullChunks - 1) / (kHullBlock * kHullChunks);      // <= ctx->f_hull_blocks (sized for the context's largest frame)
     hipLaunchKernelGGL(k_f360_hull_extremes, dim3(nblk), dim3(kHullBlock), 0, ctx->stream, ctx->f_xyz, ctx->f_label, ctx->f_slot_of_root, rows, cols,
                        ctx->f_frames, ctx->f_ext, ctx->f_hull_keys, ctx->f_hull_vals, kHullFramesLds);

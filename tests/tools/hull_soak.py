@@ -1,0 +1,48 @@
+"""Soak check of the hull stage (device: extreme boundary pixel per region in 4 x 256 in-plane directions; host: hull + shoelace)
+against the exact convex hull of every region's inliers (Qhull, the CPU checker): random camera poses in the synthetic room, sizes,
+segmentation thresholds, with and without segmentAndRefine's refinement.  For every plane above 0.12 m2 with elongation <= 6:
+0.998 x exact <= area <= exact (an inscribed polygon is never larger), mass centre within 5 mm; the smallest ratio met is printed
+(30 trials: 0.99883; with ONE set of 256 directions it was 0.99437 -- the bow of the long edges of an 8 m wall falls between two
+directions 1.4 degrees apart).  python tests/tools/hull_soak.py [n_trials]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+from oracle import oracle as oracle_mod
+from rgbd360_amd import synth
+from rgbd360_amd.register import RegisterPhotoICP, Frame360Stages
+n_trials = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+rng = np.random.default_rng(77)
+bad = 0
+overall = 1.0
+for t in range(n_trials):
+    W = int(rng.choice([256, 512, 640, 1024, 2048]))
+    H = W // 2
+    seed = int(rng.integers(0, 1000))
+    which = int(rng.integers(0, 2))
+    pair = synth.make_pair(W, H, seed=seed, trans=float(rng.choice([0.1, 0.3])), rot_deg=float(rng.choice([3.0, 10.0, 25.0])))
+    depth = pair[which][1]
+    ang = float(rng.choice([0.03, 0.05])) * min(1.0, 512.0 / W) * (2.0 if W <= 512 else 1.0)
+    min_inl = int(40 * max(1, (W // 512) ** 2))
+    st = Frame360Stages(RegisterPhotoICP())
+    refine = bool(rng.random() < 0.4)
+    st.set_refinement(refine)
+    out = st.frame_planes(depth, convention=2, angular_threshold=ang, min_inliers=min_inl)
+    xyz = oracle_mod.sphere_cloud(depth, 2)
+    n_ok = n_chk = 0
+    worst = 1.0
+    for p in out["planes"]:
+        if p["area"] <= 0.12 or p["elongation"] > 6.0 or p["hull_points"] < 3:
+            continue
+        exact, center, _nv = oracle_mod.f360_hull_stats(xyz, out["labels"], p)
+        n_chk += 1
+        ratio = p["area"] / exact
+        worst = min(worst, ratio)
+        ok = 0.998 <= ratio <= 1 + 1e-5 and np.abs(p["center_hull"] - center).max() < 5e-3
+        n_ok += 1 if ok else 0
+    good = n_ok == n_chk and n_chk > 0
+    overall = min(overall, worst)
+    bad += 0 if good else 1
+    print("trial %2d: %4dx%-4d frame %d angular %.4f refine %d: %3d planes, %3d checked, smallest area / exact %.5f -> %s" % (
+        t, W, H, which, ang, refine, len(out["planes"]), n_chk, worst, "ok" if good else "FAILED"), flush=True)
+print("hull soak: %d / %d trials ok, smallest area / exact hull area over all checked planes %.5f" % (n_trials - bad, n_trials, overall))
+sys.exit(1 if bad else 0)
