@@ -1326,7 +1326,13 @@ __device__ __forceinline__ unsigned hull_f2ord(float f) {          // order-pres
 // memory as rows of its own at the end.  The walk over a wave's boundary pixels is serial (every lane updates its four directions per
 // pixel), so the work sits where the long, nearly horizontal edges are.  (First version: eight consecutive 1024-pixel stretches per
 // block and 64-bit keys in the inner loop, 77 us, the straggler blocks being those along the floor's and ceiling's edges.)
-constexpr int kHullBlock = 1024, kHullChunks = 8, kHullHash = 32, kHullFramesLds = 256;
+constexpr int kHullBlock = 1024, kHullChunks = 8, kHullHash = 32, kHullFramesLds = 128;
+constexpr int kHullList = 640;        // boundary pixels a block shares out among its waves (more: walked by the wave that found them)
+struct HullEntry {
+    int slot;
+    float u, v;
+    int pix;
+};
 #ifdef RGBD360_HULL_DBG          // diagnostic build (tools/hull_stamps.py): per-wave clock accounting of k_f360_hull_extremes
 __device__ unsigned long long g_hull_dbg[4096][8];
 #define HDBG_T() __builtin_readcyclecounter()
@@ -1340,6 +1346,8 @@ __global__ __launch_bounds__(kHullBlock) void k_f360_hull_extremes(const float* 
     __shared__ int keys[kHullHash];
     __shared__ unsigned long long vals[kHullHash][kHullDirs];
     __shared__ float fr[kHullFramesLds][9];                // centroid + in-plane axes of the first slots: no dependent gather in front of the walk
+    __shared__ HullEntry list[kHullList];
+    __shared__ int cnt[(kHullBlock / 64) * kHullChunks];   // boundary pixels per (wave, stretch)
     const int lane = threadIdx.x & 63;
     const unsigned long long hd_t0 = HDBG_T();
     unsigned long long hd_walk = 0, hd_flush = 0, hd_uv = 0, hd_entries = 0, hd_runs = 0;
@@ -1443,71 +1451,40 @@ __global__ __launch_bounds__(kHullBlock) void k_f360_hull_extremes(const float* 
     }
     __syncthreads();                                    // the block's tables (set up while the labels were in flight)
     const unsigned long long hd_t1 = HDBG_T();
-#pragma unroll
-    for (int chunk = 0; chunk < kHullChunks; ++chunk) {
-        const int first = hull_stretch(chunk);             // this wave's first pixel
-        if (first >= n) break;                             // wave-uniform
-        const int slot = slots[chunk];
-        const bool bnd = slot >= 0;
-        unsigned long long mask = __ballot(bnd);
-        if (mask == 0ull) continue;
-        float u = 0.f, v = 0.f;
-        const unsigned long long hd_a = HDBG_T();
-        if (bnd) {
-            float f9[9];
-            if (slot < n_frames_lds) {
-#pragma unroll
-                for (int q = 0; q < 9; ++q) f9[q] = fr[slot][q];
-            } else {
-#pragma unroll
-                for (int q = 0; q < 9; ++q) f9[q] = reinterpret_cast<const float*>(frames + slot)[q];
-            }
-            const float dx = px[chunk] - f9[0], dy = py[chunk] - f9[1], dz = pz[chunk] - f9[2];
-            u = dx * f9[3] + dy * f9[4] + dz * f9[5];
-            v = dx * f9[6] + dy * f9[7] + dz * f9[8];
-        }
-        // The stretch's boundary pixels are taken slot by slot (a ballot per distinct slot, typically two: the two sides of an edge
-        // alternate along a row, and a flush per RUN of equal slots -- hash probe, four LDS atomics with a wait each -- cost ~1200
-        // cycles); per direction: the largest dot product so far and the lane of the pixel that has it, keys are only formed at the flush.
-        unsigned long long remaining = mask;
-#ifdef RGBD360_HULL_DBG
-        asm volatile("" :: "v"(u), "v"(v));
-        hd_uv += HDBG_T() - hd_a;
-#endif
+    // Walks a wave's worth of boundary pixels -- lane l holds one (slot < 0: none) -- slot by slot (a ballot per distinct slot): every
+    // lane updates the maxima of its four directions per pixel (largest dot product so far and the pixel that has it; ascending, ties
+    // keep the first), then the run's maxima go into the slot's row of the block's table (wave-uniform linear probe, four LDS atomics
+    // nothing waits for; a full table sends them straight to memory).
+    auto walk = [&](int slot, float u, float v, int pix) {
+        unsigned long long remaining = __ballot(slot >= 0);
+        const int ui = __builtin_bit_cast(int, u), vi = __builtin_bit_cast(int, v);
         while (remaining != 0ull) {
             const int cur = __builtin_amdgcn_readlane(slot, __builtin_ctzll(remaining));
-            unsigned long long todo = __ballot(bnd && slot == cur);
+            unsigned long long todo = __ballot(slot == cur);
             remaining &= ~todo;
             const unsigned long long hd_b = HDBG_T();
             hd_entries += __builtin_popcountll(todo); hd_runs += 1;
             float bd[4];
             int bj[4];
-            {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) { bd[m] = -__builtin_inff(); bj[m] = 0; }
+            while (todo != 0ull) {                         // wave-uniform
                 const int j = __builtin_ctzll(todo);
                 todo &= todo - 1ull;
-                const float uj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u), j));
-                const float vj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), j));
+                const float uj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ui, j));
+                const float vj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, j));
+                const int pj = __builtin_amdgcn_readlane(pix, j);
                 const float d0 = fmaf(uj, ck, vj * sk), d1 = fmaf(vj, ck, -(uj * sk));
-                bd[0] = d0; bd[1] = d1; bd[2] = -d0; bd[3] = -d1;
-                bj[0] = bj[1] = bj[2] = bj[3] = j;
-            }
-            while (todo != 0ull) {                         // wave-uniform walk, ascending: ties keep the first
-                const int j = __builtin_ctzll(todo);
-                todo &= todo - 1ull;
-                const float uj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, u), j));
-                const float vj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), j));
-                const float d0 = fmaf(uj, ck, vj * sk), d1 = fmaf(vj, ck, -(uj * sk));
-                if (d0 > bd[0]) { bd[0] = d0; bj[0] = j; }
-                if (d1 > bd[1]) { bd[1] = d1; bj[1] = j; }
-                if (-d0 > bd[2]) { bd[2] = -d0; bj[2] = j; }
-                if (-d1 > bd[3]) { bd[3] = -d1; bj[3] = j; }
+                if (d0 > bd[0]) { bd[0] = d0; bj[0] = pj; }
+                if (d1 > bd[1]) { bd[1] = d1; bj[1] = pj; }
+                if (-d0 > bd[2]) { bd[2] = -d0; bj[2] = pj; }
+                if (-d1 > bd[3]) { bd[3] = -d1; bj[3] = pj; }
             }
 #ifdef RGBD360_HULL_DBG
             asm volatile("" :: "v"(bd[0]), "v"(bd[1]), "v"(bd[2]), "v"(bd[3]));
 #endif
             const unsigned long long hd_c = HDBG_T();
             hd_walk += hd_c - hd_b;
-            // the slot's row of the block's table (wave-uniform linear probe; a full table sends the maxima straight to memory)
             int h = -1;
             for (int q = 0; q < kHullHash && h < 0; ++q) {
                 const int k = (cur + q) & (kHullHash - 1);
@@ -1521,8 +1498,8 @@ __global__ __launch_bounds__(kHullBlock) void k_f360_hull_extremes(const float* 
             }
             unsigned long long key[4];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) key[m] = ((unsigned long long)hull_f2ord(bd[m]) << 32) | (unsigned)(first + bj[m]);
-            if (h >= 0) {                                  // the four maxima at once, nothing waits for them
+            for (int m = 0; m < 4; ++m) key[m] = ((unsigned long long)hull_f2ord(bd[m]) << 32) | (unsigned)bj[m];
+            if (h >= 0) {
                 unsigned long long* row = &vals[h][lane];
 #pragma unroll
                 for (int m = 0; m < 4; ++m) __hip_atomic_fetch_max(row + 64 * m, key[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1531,6 +1508,83 @@ __global__ __launch_bounds__(kHullBlock) void k_f360_hull_extremes(const float* 
                 for (int m = 0; m < 4; ++m) atomicMax(&ext[((size_t)cur * kHullPhases + phase) * kHullDirs + 64 * m + lane], key[m]);
             }
             hd_flush += HDBG_T() - hd_c;
+        }
+    };
+    // in-plane coordinates of the boundary pixels of the wave's stretches, and how many there are
+    float u[kHullChunks], v[kHullChunks];
+    const unsigned long long hd_a = HDBG_T();
+#pragma unroll
+    for (int chunk = 0; chunk < kHullChunks; ++chunk) {
+        const int slot = slots[chunk];
+        const bool bnd = slot >= 0;
+        const unsigned long long mask = __ballot(bnd);
+        u[chunk] = v[chunk] = 0.f;
+        if (lane == 0) cnt[wave_u * kHullChunks + chunk] = __builtin_popcountll(mask);
+        if (mask == 0ull) continue;
+        if (bnd) {
+            float f9[9];
+            if (slot < n_frames_lds) {
+#pragma unroll
+                for (int q = 0; q < 9; ++q) f9[q] = fr[slot][q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < 9; ++q) f9[q] = reinterpret_cast<const float*>(frames + slot)[q];
+            }
+            const float dx = px[chunk] - f9[0], dy = py[chunk] - f9[1], dz = pz[chunk] - f9[2];
+            u[chunk] = dx * f9[3] + dy * f9[4] + dz * f9[5];
+            v[chunk] = dx * f9[6] + dy * f9[7] + dz * f9[8];
+        }
+    }
+#ifdef RGBD360_HULL_DBG
+#pragma unroll
+    for (int chunk = 0; chunk < kHullChunks; ++chunk) asm volatile("" :: "v"(u[chunk]), "v"(v[chunk]));
+    hd_uv += HDBG_T() - hd_a;
+#endif
+    __syncthreads();
+    // The walk is serial per wave, and the boundary pixels are where the edges are: one wave of a block met a fragmented corner (18 regions
+    // for 20 pixels, ~1500 cycles per change of region for a LONE wave) or a 64-pixel stretch of a horizontal edge while its fifteen
+    // neighbours waited at the barrier (tools/hull_stamps.py: 31 k cycles against 5 k).  So the block pools its boundary pixels in LDS --
+    // in the fixed order (wave, stretch, lane): offsets from a prefix sum over the 128 counts, no arrival order anywhere, results stay
+    // reproducible bit for bit -- and every wave walks an equal share of the list.
+    static_assert((kHullBlock / 64) * kHullChunks == 128, "two counts per lane");
+    int c_lo = cnt[lane], c_hi = cnt[64 + lane];
+    int s_lo = c_lo, s_hi = c_hi;
+#pragma unroll
+    for (int d = 1; d < 64; d *= 2) {
+        const int t_lo = __shfl_up(s_lo, d), t_hi = __shfl_up(s_hi, d);
+        if (lane >= d) { s_lo += t_lo; s_hi += t_hi; }
+    }
+    const int tot_lo = __builtin_amdgcn_readlane(s_lo, 63);
+    const int total = tot_lo + __builtin_amdgcn_readlane(s_hi, 63);
+    const int ex_lo = s_lo - c_lo, ex_hi = s_hi - c_hi + tot_lo;       // exclusive prefix of flat index lane / 64 + lane
+#pragma unroll
+    for (int chunk = 0; chunk < kHullChunks; ++chunk) {
+        const int f = wave_u * kHullChunks + chunk;        // wave-uniform
+        const int base = f < 64 ? __builtin_amdgcn_readlane(ex_lo, f & 63) : __builtin_amdgcn_readlane(ex_hi, f & 63);
+        const int slot = slots[chunk];
+        const unsigned long long mask = __ballot(slot >= 0);
+        if (mask == 0ull) continue;
+        const int idx = base + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+        const int pix = first_of[chunk] + lane;
+        if (slot >= 0 && idx < kHullList) {
+            HullEntry e;
+            e.slot = slot; e.u = u[chunk]; e.v = v[chunk]; e.pix = pix;
+            list[idx] = e;
+        }
+        // what the list cannot hold stays with the wave that found it (wave-uniform test)
+        if (base + __builtin_popcountll(mask) > kHullList) walk(slot >= 0 && idx >= kHullList ? slot : -1, u[chunk], v[chunk], pix);
+    }
+    __syncthreads();
+    {
+        const int E = min(total, kHullList);
+        const int per = (E + kHullBlock / 64 - 1) / (kHullBlock / 64);
+        const int begin = wave_u * per, end = min(E, begin + per);
+        for (int b0 = begin; b0 < end; b0 += 64) {          // wave-uniform
+            const int e = b0 + lane;
+            HullEntry en;
+            en.slot = -1; en.u = 0.f; en.v = 0.f; en.pix = 0;
+            if (e < end) en = list[e];
+            walk(en.slot, en.u, en.v, en.pix);
         }
     }
     const unsigned long long hd_t2 = HDBG_T();
