@@ -1327,7 +1327,7 @@ __device__ __forceinline__ unsigned hull_f2ord(float f) {          // order-pres
 // pixel), so the work sits where the long, nearly horizontal edges are.  (First version: eight consecutive 1024-pixel stretches per
 // block and 64-bit keys in the inner loop, 77 us, the straggler blocks being those along the floor's and ceiling's edges.)
 constexpr int kHullBlock = 1024, kHullChunks = 8, kHullHash = 32, kHullFramesLds = 128;
-constexpr int kHullList = 640;        // boundary pixels a block shares out among its waves (more: walked by the wave that found them)
+constexpr int kHullList = 640;        // boundary pixels a block shares out among its waves per round
 struct HullEntry {
     int slot;
     float u, v;
@@ -1545,7 +1545,7 @@ __global__ __launch_bounds__(kHullBlock) void k_f360_hull_extremes(const float* 
     // for 20 pixels, ~1500 cycles per change of region for a LONE wave) or a 64-pixel stretch of a horizontal edge while its fifteen
     // neighbours waited at the barrier (tools/hull_stamps.py: 31 k cycles against 5 k).  So the block pools its boundary pixels in LDS --
     // in the fixed order (wave, stretch, lane): offsets from a prefix sum over the 128 counts, no arrival order anywhere, results stay
-    // reproducible bit for bit -- and every wave walks an equal share of the list.
+    // reproducible bit for bit -- and every wave walks an equal share of the list (in rounds of kHullList entries).
     static_assert((kHullBlock / 64) * kHullChunks == 128, "two counts per lane");
     int c_lo = cnt[lane], c_hi = cnt[64 + lane];
     int s_lo = c_lo, s_hi = c_hi;
@@ -1557,26 +1557,28 @@ __global__ __launch_bounds__(kHullBlock) void k_f360_hull_extremes(const float* 
     const int tot_lo = __builtin_amdgcn_readlane(s_lo, 63);
     const int total = tot_lo + __builtin_amdgcn_readlane(s_hi, 63);
     const int ex_lo = s_lo - c_lo, ex_hi = s_hi - c_hi + tot_lo;       // exclusive prefix of flat index lane / 64 + lane
+    int idx_of[kHullChunks];                               // this lane's place in the block's list (boundary pixels only)
 #pragma unroll
     for (int chunk = 0; chunk < kHullChunks; ++chunk) {
         const int f = wave_u * kHullChunks + chunk;        // wave-uniform
         const int base = f < 64 ? __builtin_amdgcn_readlane(ex_lo, f & 63) : __builtin_amdgcn_readlane(ex_hi, f & 63);
-        const int slot = slots[chunk];
-        const unsigned long long mask = __ballot(slot >= 0);
-        if (mask == 0ull) continue;
-        const int idx = base + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
-        const int pix = first_of[chunk] + lane;
-        if (slot >= 0 && idx < kHullList) {
-            HullEntry e;
-            e.slot = slot; e.u = u[chunk]; e.v = v[chunk]; e.pix = pix;
-            list[idx] = e;
-        }
-        // what the list cannot hold stays with the wave that found it (wave-uniform test)
-        if (base + __builtin_popcountll(mask) > kHullList) walk(slot >= 0 && idx >= kHullList ? slot : -1, u[chunk], v[chunk], pix);
+        const unsigned long long mask = __ballot(slots[chunk] >= 0);
+        idx_of[chunk] = base + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
     }
-    __syncthreads();
-    {
-        const int E = min(total, kHullList);
+    // (a list of kHullList entries per round: one round, unless more than 8 % of the block's 8192 pixels are boundary pixels)
+    for (int lo = 0; lo < total; lo += kHullList) {        // block-uniform
+        if (lo > 0) __syncthreads();                       // the previous round's list has been walked
+#pragma unroll
+        for (int chunk = 0; chunk < kHullChunks; ++chunk) {
+            const int idx = idx_of[chunk] - lo;
+            if (slots[chunk] >= 0 && idx >= 0 && idx < kHullList) {
+                HullEntry e;
+                e.slot = slots[chunk]; e.u = u[chunk]; e.v = v[chunk]; e.pix = first_of[chunk] + lane;
+                list[idx] = e;
+            }
+        }
+        __syncthreads();
+        const int E = min(total - lo, kHullList);
         const int per = (E + kHullBlock / 64 - 1) / (kHullBlock / 64);
         const int begin = wave_u * per, end = min(E, begin + per);
         for (int b0 = begin; b0 < end; b0 += 64) {          // wave-uniform

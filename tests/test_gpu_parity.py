@@ -369,6 +369,31 @@ def test_hull_areas_read_the_room_at_2048x1024(hip_lib, oracle_mod):
     assert all(abs(a - 48.0) <= 2.0 for a in walls[0]), walls[0]          # the floor and the ceiling read 48 +- 2 m2
 
 
+@pytest.mark.gpu
+def test_hull_stage_on_a_striped_image(hip_lib, oracle_mod):
+    """The hull stage where EVERY other pixel is a boundary pixel: a fronto-parallel staircase, 4-pixel-wide stripes alternating between
+    two depths (the plane comparator's distance test separates them), so a block's share of boundary pixels is several times the
+    640 entries its LDS list holds and the kernel walks it in rounds.  Every stripe's hull area and mass centre against the exact hull."""
+    from rgbd360_amd.register import Frame360Stages
+    H, W = 128, 256
+    jj, ii = np.meshgrid(np.arange(W), np.arange(H))
+    z = np.where((jj // 4) % 2 == 0, 2.0, 2.6).astype(np.float32)
+    x = ((jj - W / 2) * 0.004 * z).astype(np.float32)
+    y = ((ii - H / 2) * 0.004 * z).astype(np.float32)
+    xyz = np.stack([x, y, z], axis=-1).reshape(-1, 3).astype(np.float32)
+    nrm = np.tile(np.array([0.0, 0.0, -1.0], np.float32), (H * W, 1))
+    st = Frame360Stages(_mk(hip_lib, 2))
+    labels, planes = st.plane_fit(xyz, nrm, H, W, 40, 0.05, 0.05, 0.01, 0)
+    labels_ref, planes_ref = oracle_mod.f360_plane_segment(xyz, nrm, H, W, 40, 0.05, 0.05, 0.01, 0)
+    assert np.array_equal(labels, labels_ref) and len(planes) == len(planes_ref) == W // 4
+    boundary = (labels[:, 1:] != labels[:, :-1]).sum() * 2 + 2 * H + 2 * (W - 2)
+    assert boundary > 4 * 640 * ((H * W + 8191) // 8192)          # several rounds of the list in every block
+    for p in planes:
+        exact, center, _nv = oracle_mod.f360_hull_stats(xyz, labels, p)
+        assert p["hull_points"] >= 4 and abs(p["area"] - exact) <= 1e-4 * exact, (p["area"], exact)
+        assert np.abs(p["center_hull"] - center).max() < 1e-4
+
+
 def _pingpong(n_pairs, n_unique):
     idx, k, step = [], 0, 1
     for _ in range(n_pairs + 1):
