@@ -713,7 +713,8 @@ static void enqueue_schedule(rgbd360_ctx* ctx, int pending, bool pending_started
         if (start && !fused) launch_level_init(ctx, level, ctx->al_guess, 1);      // (the fused schedule's first launch initialises the state itself)
         int n_pairs = (level == top && !pending_started) ? ctx->first_chunk_top : (level == 0 ? ctx->chunk_level0 : ctx->poll_chunk);
         // Consecutive alignments of a sequence take much the same number of iterations per level: the first visit of a level is
-        // given what the previous alignment needed there (its accepted iterations + the pass that ends the level + one spare)
+        // given what the previous alignment needed there (its accepted iterations + the first pass + the pass that ends the level: one
+        // launch fewer costs a host round trip per level, 173 -> 293 us measured)
         // instead of the fixed chunk -- fewer no-op launches on the coarse levels (~3 us each), no second round trip on level 0.
         if (ctx->adaptive_chunks && !(level == pending && pending_started) && ctx->hist_iters[level & 7] >= 0)
             n_pairs = std::min(std::max(ctx->hist_iters[level & 7] + 2, 2), 12);
