@@ -766,6 +766,19 @@ __global__ __launch_bounds__(kLinkTW) void k_f360_link_flags(const float* __rest
 // pixels (an inclusive max-scan of "column where a run starts"; a lane owns 4 consecutive pixels), so pass 3 only has to
 // join runs vertically.  Invalid pixels get -1.
 constexpr int kRunRowsPerBlock = 4;
+// Inclusive max-scan over the 64 lanes of a wave for values >= -1, on the VALU's data-parallel-primitive paths: shifts by 1, 2, 4, 8 inside
+// the rows of 16 lanes, then lane 15 of a row to the next row and lane 31 to the upper half (lanes without a source take -1).  Twelve vector
+// instructions; six __shfl_up steps are six trips through the LDS crossbar (~100 cycles each for a wave that has the SIMD to itself).
+__device__ __forceinline__ int wave_scan_max(int x) {
+    int t;
+    t = __builtin_amdgcn_update_dpp(-1, x, 0x111, 0xF, 0xF, false); x = t > x ? t : x;      // row_shr:1
+    t = __builtin_amdgcn_update_dpp(-1, x, 0x112, 0xF, 0xF, false); x = t > x ? t : x;      // row_shr:2
+    t = __builtin_amdgcn_update_dpp(-1, x, 0x114, 0xF, 0xF, false); x = t > x ? t : x;      // row_shr:4
+    t = __builtin_amdgcn_update_dpp(-1, x, 0x118, 0xF, 0xF, false); x = t > x ? t : x;      // row_shr:8
+    t = __builtin_amdgcn_update_dpp(-1, x, 0x142, 0xA, 0xF, false); x = t > x ? t : x;      // row_bcast:15 -> rows 1, 3
+    t = __builtin_amdgcn_update_dpp(-1, x, 0x143, 0xC, 0xF, false); x = t > x ? t : x;      // row_bcast:31 -> rows 2, 3
+    return x;
+}
 __global__ __launch_bounds__(64 * kRunRowsPerBlock) void k_f360_ccl_runs(const uint8_t* __restrict__ flags, int rows, int cols,
                                                                         int* __restrict__ label) {
     const int lane = threadIdx.x & 63, r = blockIdx.x * kRunRowsPerBlock + (threadIdx.x >> 6);
@@ -773,35 +786,52 @@ __global__ __launch_bounds__(64 * kRunRowsPerBlock) void k_f360_ccl_runs(const u
     const uint8_t* f = flags + (size_t)r * cols;
     int* L = label + (size_t)r * cols;
     int carry = -1;
-    for (int c0 = 0; c0 < cols; c0 += 256) {
-        const int c = c0 + 4 * lane;
-        int v[4];
-        bool valid[4];
-        int m = -1;
+    // The flags of eight 256-pixel steps are requested before the first step is worked on: one step after the other, every step
+    // waited for its own four bytes -- eight dependent memory round trips per 2048-pixel row, most of the kernel's 9.4 us.
+    constexpr int kBatch = 8;
+    const bool words = ((reinterpret_cast<size_t>(f) | (size_t)cols) & 3) == 0;      // wave-uniform: rows of whole, aligned dwords
+    for (int cb = 0; cb < cols; cb += 256 * kBatch) {
+        unsigned w[kBatch];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int cc = c + k;
-            const int fl = cc < cols ? f[cc] : 0;
-            valid[k] = (fl & 1) != 0;
-            if (cc < cols && !(fl & 2)) m = cc;              // a run starts here
-            v[k] = m;
-        }
-        int s = m;
+        for (int q = 0; q < kBatch; ++q) {
+            const int c = cb + 256 * q + 4 * lane;
+            w[q] = 0u;
+            if (words) {
+                if (c < cols) w[q] = *reinterpret_cast<const unsigned*>(f + c);
+            } else {
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int tt = __shfl_up(s, o);
-            if (lane >= o) s = tt > s ? tt : s;
+                for (int k = 0; k < 4; ++k)
+                    if (c + k < cols) w[q] |= (unsigned)f[c + k] << (8 * k);
+            }
         }
-        int prev = __shfl_up(s, 1);
-        prev = lane == 0 ? carry : (prev > carry ? prev : carry);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int cc = c + k;
-            const int start = v[k] > prev ? v[k] : prev;
-            if (cc < cols) L[cc] = valid[k] ? r * cols + start : -1;
+        for (int q = 0; q < kBatch; ++q) {
+            const int c0 = cb + 256 * q;
+            if (c0 >= cols) break;                           // wave-uniform
+            const int c = c0 + 4 * lane;
+            int v[4];
+            bool valid[4];
+            int m = -1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int cc = c + k;
+                const int fl = cc < cols ? (int)((w[q] >> (8 * k)) & 0xffu) : 0;
+                valid[k] = (fl & 1) != 0;
+                if (cc < cols && !(fl & 2)) m = cc;          // a run starts here
+                v[k] = m;
+            }
+            const int s = wave_scan_max(m);
+            int prev = __builtin_amdgcn_update_dpp(-1, s, 0x138, 0xF, 0xF, false);      // wave_shr:1 (lane 0: -1)
+            prev = prev > carry ? prev : carry;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int cc = c + k;
+                const int start = v[k] > prev ? v[k] : prev;
+                if (cc < cols) L[cc] = valid[k] ? r * cols + start : -1;
+            }
+            const int last = __builtin_amdgcn_readlane(s, 63);
+            carry = last > carry ? last : carry;
         }
-        const int last = __shfl(s, 63);
-        carry = last > carry ? last : carry;
     }
 }
 
