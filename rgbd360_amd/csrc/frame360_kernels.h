@@ -779,13 +779,26 @@ __device__ __forceinline__ int wave_scan_max(int x) {
     t = __builtin_amdgcn_update_dpp(-1, x, 0x143, 0xC, 0xF, false); x = t > x ? t : x;      // row_bcast:31 -> rows 2, 3
     return x;
 }
+// inclusive add-scan over the wave for small non-negative counts, same paths (lanes without a source add 0)
+__device__ __forceinline__ int wave_scan_add(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);
+    return x;
+}
+// starts / nstarts (optional): the row's run starts as a compact list (row r's k-th start at starts[r cols + k]) for k_f360_ccl_roots_list
 __global__ __launch_bounds__(64 * kRunRowsPerBlock) void k_f360_ccl_runs(const uint8_t* __restrict__ flags, int rows, int cols,
-                                                                        int* __restrict__ label) {
+                                                                        int* __restrict__ label, int* __restrict__ starts,
+                                                                        int* __restrict__ nstarts) {
     const int lane = threadIdx.x & 63, r = blockIdx.x * kRunRowsPerBlock + (threadIdx.x >> 6);
     if (r >= rows) return;                                   // whole waves leave; no block-level synchronisation below
     const uint8_t* f = flags + (size_t)r * cols;
     int* L = label + (size_t)r * cols;
     int carry = -1;
+    int n_starts = 0;                                        // wave-uniform
     // The flags of eight 256-pixel steps are requested before the first step is worked on: one step after the other, every step
     // waited for its own four bytes -- eight dependent memory round trips per 2048-pixel row, most of the kernel's 9.4 us.
     constexpr int kBatch = 8;
@@ -812,13 +825,24 @@ __global__ __launch_bounds__(64 * kRunRowsPerBlock) void k_f360_ccl_runs(const u
             int v[4];
             bool valid[4];
             int m = -1;
+            unsigned root_bits = 0;                          // pixels that can be roots: valid and not linked to the left
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int cc = c + k;
                 const int fl = cc < cols ? (int)((w[q] >> (8 * k)) & 0xffu) : 0;
                 valid[k] = (fl & 1) != 0;
                 if (cc < cols && !(fl & 2)) m = cc;          // a run starts here
+                if (cc < cols && (fl & 1) && !(fl & 2)) root_bits |= 1u << k;
                 v[k] = m;
+            }
+            if (starts) {                                    // wave-uniform
+                const int mine = __builtin_popcount(root_bits);
+                const int incl = wave_scan_add(mine);
+                int at = r * cols + n_starts + incl - mine;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (root_bits & (1u << k)) starts[at++] = r * cols + c + k;
+                n_starts += __builtin_amdgcn_readlane(incl, 63);
             }
             const int s = wave_scan_max(m);
             int prev = __builtin_amdgcn_update_dpp(-1, s, 0x138, 0xF, 0xF, false);      // wave_shr:1 (lane 0: -1)
@@ -833,6 +857,7 @@ __global__ __launch_bounds__(64 * kRunRowsPerBlock) void k_f360_ccl_runs(const u
             carry = last > carry ? last : carry;
         }
     }
+    if (nstarts && lane == 0) nstarts[r] = n_starts;
 }
 
 // Parents always have the smaller index (uf_union hangs the larger root under the smaller), so a cell only ever decreases
@@ -946,6 +971,20 @@ __global__ void k_f360_ccl_roots(const uint8_t* __restrict__ flags, int n, int* 
     if (i >= n) return;
     const int fl = flags[i];
     if ((fl & 1) && !(fl & 2)) {
+        label[i] = uf_find(label, i);
+        count[i] = 0ull;
+    }
+}
+// The same over the compact lists k_f360_ccl_runs left: one thread per run start, a block per image row.  (One thread per PIXEL reading
+// its flag byte made 32 k waves whose only load was a 64-byte line, and the chases -- up to nine dependent hops -- started behind it:
+// 17-20 us at 2048 x 1024.)
+constexpr int kRootsThreads = 256;
+__global__ __launch_bounds__(kRootsThreads) void k_f360_ccl_roots_list(const int* __restrict__ starts, const int* __restrict__ nstarts, int cols,
+                                                                         int* __restrict__ label, unsigned long long* __restrict__ count) {
+    const int r = blockIdx.x;
+    const int ns = nstarts[r];
+    for (int k = threadIdx.x; k < ns; k += kRootsThreads) {
+        const int i = starts[(size_t)r * cols + k];
         label[i] = uf_find(label, i);
         count[i] = 0ull;
     }

@@ -2024,8 +2024,13 @@ int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float
     uint8_t* flags = ctx->f_change;
     hipLaunchKernelGGL(k_f360_link_flags, dim3((cols + kLinkTW - 1) / kLinkTW, (rows + kLinkTH - 1) / kLinkTH), dim3(kLinkTW), 0, ctx->stream,
                        ctx->f_xyz, ctx->f_normals, rows, cols, cosf(angular_threshold), distance_threshold, depth_mode, flags);
+    // run starts as compact per-row lists for the root pass: in f_slot_of_root (written by k_f360_assign only after the roots are known)
+    // and, for the counts, in the tail of f_hd (the depth-change mask is spent once the distance map exists); RGBD360_CCL_LISTS=0: A/B
+    static const bool lists_off = [] { const char* e = getenv("RGBD360_CCL_LISTS"); return e && atoi(e) == 0; }();
+    int* run_starts = lists_off ? nullptr : ctx->f_slot_of_root;
+    int* n_run_starts = lists_off ? nullptr : reinterpret_cast<int*>(ctx->f_hd + (((size_t)n + 15) & ~(size_t)15));      // n + 4 rows <= 3 n + 64 bytes
     hipLaunchKernelGGL(k_f360_ccl_runs, dim3((rows + kRunRowsPerBlock - 1) / kRunRowsPerBlock), dim3(64 * kRunRowsPerBlock), 0, ctx->stream,
-                       flags, rows, cols, ctx->f_label);
+                       flags, rows, cols, ctx->f_label, run_starts, n_run_starts);
     hipLaunchKernelGGL(k_f360_ccl_merge_band, dim3((cols + kBandCols - 1) / kBandCols, (rows + kBandRows - 1) / kBandRows),
                        dim3(kBandCols * kBandGroups), 0, ctx->stream, flags, rows, cols, ctx->f_label);
     constexpr int kTopLevel = kBandLevels + 2;
@@ -2043,7 +2048,8 @@ int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float
         fprintf(stderr, "[f360 dbg] after merge: unions %llu find-hops %llu atomicMin %llu longest walk %llu\n", h[0], h[1], h[2], h[3]);
     }
 #endif
-    hipLaunchKernelGGL(k_f360_ccl_roots, g1, b, 0, ctx->stream, flags, n, ctx->f_label, ctx->f_count);
+    if (run_starts) hipLaunchKernelGGL(k_f360_ccl_roots_list, dim3(rows), dim3(kRootsThreads), 0, ctx->stream, run_starts, n_run_starts, cols, ctx->f_label, ctx->f_count);
+    else hipLaunchKernelGGL(k_f360_ccl_roots, g1, b, 0, ctx->stream, flags, n, ctx->f_label, ctx->f_count);
 #ifdef F360_DEBUG_COUNTERS
     {
         unsigned long long h[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
