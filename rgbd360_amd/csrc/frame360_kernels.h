@@ -62,29 +62,50 @@ __global__ __launch_bounds__(kEdgeTW) void k_f360_edge_bits(const float* __restr
         float px[kTrips], py[kTrips], pz[kTrips];
         bool inb[kTrips];
         if (CLOUD) {
-            float d[kTrips], st[kTrips], ct[kTrips], sp[kTrips], cp[kTrips];
-#pragma unroll
-            for (int k = 0; k < kTrips; ++k) {
-                const int e = t + k * kEdgeTW;
-                const int ey = e / (kEdgeTW + 2), ex = e - ey * (kEdgeTW + 2);
-                const int r = r0 - 1 + ey, c = c0 - 1 + ex;
-                inb[k] = e < kN && r >= 0 && r < rows && c >= 0 && c < cols;
-                const int rr = inb[k] ? r : 0, cc = inb[k] ? c : 0;
+            // Row by row: thread t owns column c0 + t of the tile's ten rows (its two angle-table entries are loaded ONCE, a row's
+            // sin / cos of the polar angle are wave-uniform: scalar loads), threads 0-19 own one pixel of the two ring columns
+            // besides.  The flat walk over the 258 x 10 elements (eleven per thread, each with a division by 258, five loads behind
+            // 64-bit addresses and all bounds tests per lane) was 150 vector instructions per output pixel.
+            constexpr int kRows = kEdgeTH + 2;
+            const int c = c0 + t;
+            const bool c_ok = c < cols;
+            const int cc = c_ok ? c : 0;
+            const float st = src.sin_theta[cc], ct = src.cos_theta[cc];
+            const int j_ey = t >> 1, j_c = (t & 1) ? c0 + kEdgeTW : c0 - 1;      // ring pixel of thread t < 2 kRows
+            const int j_r = r0 - 1 + j_ey;
+            const bool j_ok = t < 2 * kRows && j_r >= 0 && j_r < rows && j_c >= 0 && j_c < cols;
+            const int jr = j_ok ? j_r : 0, jc = j_ok ? j_c : 0;
+            auto load_depth = [&](int rr, int col) {
                 const unsigned char* row = (const unsigned char*)src.depth + (size_t)rr * src.step;
-                d[k] = src.depth_type == 0 ? 0.001f * (float)((const unsigned short*)row)[cc] : ((const float*)row)[cc];
-                st[k] = src.sin_theta[cc]; ct[k] = src.cos_theta[cc];
-                sp[k] = src.sin_phi[rr]; cp[k] = src.cos_phi[rr];
-            }
+                return src.depth_type == 0 ? 0.001f * (float)((const unsigned short*)row)[col] : ((const float*)row)[col];
+            };
+            float d[kRows], sp[kRows], cp[kRows];
 #pragma unroll
-            for (int k = 0; k < kTrips; ++k) {
-                r360::sphere_point(src.convention, d[k], sp[k], cp[k], st[k], ct[k], px[k], py[k], pz[k]);
-                const int e = t + k * kEdgeTW;
-                const int ey = e / (kEdgeTW + 2), ex = e - ey * (kEdgeTW + 2);
-                // the tile's own pixels (not the ring) leave as the cloud
-                if (inb[k] && ey >= 1 && ey <= kEdgeTH && ex >= 1 && ex <= kEdgeTW) {
-                    float* o = xyz_out + 3 * ((size_t)(r0 - 1 + ey) * cols + (c0 - 1 + ex));
-                    o[0] = px[k]; o[1] = py[k]; o[2] = pz[k];
+            for (int ey = 0; ey < kRows; ++ey) {
+                const int r = r0 - 1 + ey;                   // wave-uniform
+                const int rr = (r >= 0 && r < rows) ? r : 0;
+                d[ey] = load_depth(rr, cc);
+                sp[ey] = src.sin_phi[rr]; cp[ey] = src.cos_phi[rr];
+            }
+            const float dj = load_depth(jr, jc), stj = src.sin_theta[jc], ctj = src.cos_theta[jc], spj = src.sin_phi[jr], cpj = src.cos_phi[jr];
+#pragma unroll
+            for (int ey = 0; ey < kRows; ++ey) {
+                const int r = r0 - 1 + ey;
+                const bool ok = c_ok && r >= 0 && r < rows;
+                float x, y, z;
+                r360::sphere_point(src.convention, d[ey], sp[ey], cp[ey], st, ct, x, y, z);
+                if (ok && ey >= 1 && ey <= kEdgeTH) {        // the tile's own pixels (not the ring) leave as the cloud
+                    float* o = xyz_out + 3 * ((size_t)r * cols + c);
+                    o[0] = x; o[1] = y; o[2] = z;
                 }
+                const float pt[3] = {x, y, z};
+                dep[ey][t + 1] = ok ? depth_of(pt, depth_mode) : 0.f;
+            }
+            if (t < 2 * kRows) {
+                float x, y, z;
+                r360::sphere_point(src.convention, dj, spj, cpj, stj, ctj, x, y, z);
+                const float pt[3] = {x, y, z};
+                dep[j_ey][(t & 1) ? kEdgeTW + 1 : 0] = j_ok ? depth_of(pt, depth_mode) : 0.f;
             }
         } else {
 #pragma unroll
@@ -97,12 +118,14 @@ __global__ __launch_bounds__(kEdgeTW) void k_f360_edge_bits(const float* __restr
                 px[k] = p[0]; py[k] = p[1]; pz[k] = p[2];
             }
         }
-        float* flat = &dep[0][0];
+        if (!CLOUD) {
+            float* flat = &dep[0][0];
 #pragma unroll
-        for (int k = 0; k < kTrips; ++k) {
-            const int e = t + k * kEdgeTW;
-            const float pt[3] = {px[k], py[k], pz[k]};
-            if (e < kN) flat[e] = inb[k] ? depth_of(pt, depth_mode) : 0.f;
+            for (int k = 0; k < kTrips; ++k) {
+                const int e = t + k * kEdgeTW;
+                const float pt[3] = {px[k], py[k], pz[k]};
+                if (e < kN) flat[e] = inb[k] ? depth_of(pt, depth_mode) : 0.f;
+            }
         }
     }
     __syncthreads();
