@@ -20,8 +20,12 @@ inline void jacobi3(const double C[3][3], double evals[3], double V[3][3]) {
     memcpy(A, C, sizeof(A));
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) V[i][j] = i == j;
+    // Sweeps until the off-diagonal part is below 1e-26 of the diagonal's size: a rotation by less than that changes no double any more.
+    // (Down to 1e-300, i.e. to underflow, it took 9-10 sweeps where 4-5 do: 4.5 us per region, 150 of the 370 us of a frame_planes call.)
+    const double scale = fabs(A[0][0]) + fabs(A[1][1]) + fabs(A[2][2]);
     for (int sweep = 0; sweep < 60; ++sweep) {
-        if (fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]) < 1e-300) break;
+        const double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+        if (off < 1e-300 || off <= 1e-26 * scale) break;
         for (int p = 0; p < 2; ++p)
             for (int q = p + 1; q < 3; ++q) {
                 if (fabs(A[p][q]) < 1e-300) continue;

@@ -1835,21 +1835,26 @@ struct HullStats {
     int n = 0;                  // hull vertices
     double area = 0, cu = 0, cv = 0;
 };
+struct HullPt {
+    double x, y;                // (no constructor: the work arrays below are not cleared -- 48 KB per plane when they were std::pairs)
+    bool operator<(const HullPt& o) const { return x < o.x || (x == o.x && y < o.y); }
+    bool operator==(const HullPt& o) const { return x == o.x && y == o.y; }
+};
 HullStats hull_stats(const float (*uv)[2], int K) {
     // The points arrive roughly in boundary order (direction order), but the four direction sets each saw their own sample of the
     // region's pixels, so neighbours may be swapped along an edge: Andrew's monotone chain on the sorted points, which assumes nothing.
-    std::pair<double, double> p[f360::kHullRecPts];
+    HullPt p[f360::kHullRecPts];
     int n = 0;
-    for (int k = 0; k < K && k < f360::kHullRecPts; ++k)
-        if (std::isfinite(uv[k][0]) && std::isfinite(uv[k][1])) p[n++] = std::pair<double, double>(uv[k][0], uv[k][1]);
+    for (int k = 0; k < K && k < f360::kHullRecPts; ++k) {
+        const float a = uv[k][0], b = uv[k][1];            // (one read each of the pinned record)
+        if (std::isfinite(a) && std::isfinite(b)) { p[n].x = a; p[n].y = b; ++n; }
+    }
     std::sort(p, p + n);
     n = (int)(std::unique(p, p + n) - p);
     HullStats h;
     if (n < 3) return h;
-    auto cross = [](const std::pair<double, double>& o, const std::pair<double, double>& a, const std::pair<double, double>& b) {
-        return (a.first - o.first) * (b.second - o.second) - (a.second - o.second) * (b.first - o.first);
-    };
-    std::pair<double, double> H[2 * f360::kHullRecPts + 2];
+    auto cross = [](const HullPt& o, const HullPt& a, const HullPt& b) { return (a.x - o.x) * (b.y - o.y) - (a.y - o.y) * (b.x - o.x); };
+    HullPt H[2 * f360::kHullRecPts + 2];
     int m = 0;
     for (int i = 0; i < n; ++i) {                          // lower hull
         while (m >= 2 && cross(H[m - 2], H[m - 1], p[i]) <= 0) --m;
@@ -1863,11 +1868,11 @@ HullStats hull_stats(const float (*uv)[2], int K) {
     if (m < 3) return h;
     double a2 = 0, cu = 0, cv = 0;
     for (int i = 0; i < m; ++i) {
-        const auto &a = H[i], &b = H[(i + 1) % m];
-        const double cr = a.first * b.second - a.second * b.first;
+        const HullPt &a = H[i], &b = H[(i + 1) % m];
+        const double cr = a.x * b.y - a.y * b.x;
         a2 += cr;
-        cu += (a.first + b.first) * cr;
-        cv += (a.second + b.second) * cr;
+        cu += (a.x + b.x) * cr;
+        cv += (a.y + b.y) * cr;
     }
     if (!(fabs(a2) > 0)) return h;
     h.n = m;
