@@ -43,6 +43,42 @@ constexpr float kThresDepthOutliers = 0.3f;      // RPI.h:4525
 // an empty list
 __device__ __forceinline__ int occ_decode(int tagged, int gen) { return ((unsigned)tagged >> 24) == (unsigned)gen ? (tagged & 0xFFFFFF) : -1; }
 
+// Wave scans on the VALU's data-parallel-primitive paths (row_shr 1 / 2 / 4 / 8 inside the rows of 16 lanes, then lane 15 of a row to the
+// next row and lane 31 to the upper half) instead of __shfl_up steps through the LDS crossbar: k_occ_build made 27 crossbar trips per wave,
+// 3456 per CU and launch at 2048 x 1024, on the one LDS unit its four SIMDs share.
+#define R360_DPP(old_, src_, ctrl_, rows_) __builtin_amdgcn_update_dpp((int)(old_), (int)(src_), ctrl_, rows_, 0xF, false)
+__device__ __forceinline__ int occ_scan_max(int x) {                 // inclusive max-scan of values >= 0
+    int t;
+    t = R360_DPP(-1, x, 0x111, 0xF); x = t > x ? t : x;
+    t = R360_DPP(-1, x, 0x112, 0xF); x = t > x ? t : x;
+    t = R360_DPP(-1, x, 0x114, 0xF); x = t > x ? t : x;
+    t = R360_DPP(-1, x, 0x118, 0xF); x = t > x ? t : x;
+    t = R360_DPP(-1, x, 0x142, 0xA); x = t > x ? t : x;
+    t = R360_DPP(-1, x, 0x143, 0xC); x = t > x ? t : x;
+    return x;
+}
+// segmented inclusive max-scan of a 64-bit key over the runs `lead` names (lead = lane of the run's first member, constant along a run,
+// increasing from run to run): a source lane counts when it has the same lead (lanes without a source offer lead -1)
+__device__ __forceinline__ unsigned long long occ_seg_scan_max(unsigned long long key, int lead) {
+    unsigned lo = (unsigned)key, hi = (unsigned)(key >> 32);
+#define R360_SEG_STEP(ctrl_, rows_)                                                                              \
+    {                                                                                                            \
+        const int ol = R360_DPP(-1, lead, ctrl_, rows_);                                                         \
+        const unsigned olo = (unsigned)R360_DPP(0, lo, ctrl_, rows_), ohi = (unsigned)R360_DPP(0, hi, ctrl_, rows_); \
+        const bool take = ol == lead && (ohi > hi || (ohi == hi && olo > lo));                                   \
+        lo = take ? olo : lo;                                                                                    \
+        hi = take ? ohi : hi;                                                                                    \
+    }
+    R360_SEG_STEP(0x111, 0xF)
+    R360_SEG_STEP(0x112, 0xF)
+    R360_SEG_STEP(0x114, 0xF)
+    R360_SEG_STEP(0x118, 0xF)
+    R360_SEG_STEP(0x142, 0xA)
+    R360_SEG_STEP(0x143, 0xC)
+#undef R360_SEG_STEP
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 // runinfo byte of a source pixel: bit 6 candidate, bit 7 no earlier member of its run is closer, bits 0-5 offset to the run's first pixel
 // node (int4, indexed by the run's LAST pixel): x = pixel holding the run's largest (1/dist, index) key, y = bits of that 1/dist,
 // z = first pixel of the run, w = next node of the same target pixel (-1: none)
@@ -69,24 +105,15 @@ __global__ __launch_bounds__(256) void k_occ_build(LevelDev lv, const GNState* _
     const float di = rcp_rn(dist);
     // runs of consecutive lanes with the same target pixel (a non-candidate matches nobody: targets are < 2^24)
     const unsigned tkey = cand ? ti : (0xFF000000u | (unsigned)lane);
-    const unsigned t_before = __shfl_up(tkey, 1), t_after = __shfl_down(tkey, 1);      // (outside the ||: a shuffle reads active lanes only)
+    // neighbours' keys by wave shifts (lane 0 / lane 63 take a key nobody has)
+    const unsigned t_before = (unsigned)R360_DPP(0xFE000000u, tkey, 0x138, 0xF), t_after = (unsigned)R360_DPP(0xFE000000u, tkey, 0x130, 0xF);
     const bool run_head = lane == 0 || t_before != tkey;
     const bool run_tail = lane == 63 || t_after != tkey;
-    int lead = run_head ? lane : 0;                    // lane of the run's first member: inclusive max-scan
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int o = __shfl_up(lead, off);
-        if (lane >= off) lead = max(lead, o);
-    }
+    const int lead = occ_scan_max(run_head ? lane : 0);      // lane of the run's first member
     // segmented inclusive max-scan of the key (1/dist bits, pixel): positive floats order like their bit patterns
-    unsigned long long key = ((unsigned long long)__float_as_uint(di) << 32) | (unsigned)ic;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const unsigned long long ok = __shfl_up(key, off);
-        const int ol = __shfl_up(lead, off);
-        if (lane >= off && ol == lead && ok > key) key = ok;
-    }
-    const unsigned long long kprev = __shfl_up(key, 1);            // the run's maximum BEFORE this member
+    const unsigned long long key = occ_seg_scan_max(((unsigned long long)__float_as_uint(di) << 32) | (unsigned)ic, lead);
+    // the run's maximum BEFORE this member
+    const unsigned long long kprev = ((unsigned long long)(unsigned)R360_DPP(0, (unsigned)(key >> 32), 0x138, 0xF) << 32) | (unsigned)R360_DPP(0, (unsigned)key, 0x138, 0xF);
     const bool has_prev = lane > lead;
     const bool pm_run = !(has_prev && __uint_as_float((unsigned)(kprev >> 32)) > di);
     if (in) runinfo[i] = cand ? (unsigned char)(0x40u | (pm_run ? 0x80u : 0u) | (unsigned)(lane - lead)) : (unsigned char)0;
