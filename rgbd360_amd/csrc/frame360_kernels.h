@@ -1025,10 +1025,25 @@ constexpr double kMomScale = 16777216.0;      // 2^24 units per m (linear terms)
 constexpr int kMomReplicas = 16;              // copies of the global moment table (block b adds into copy b % 16): a wall is hit by
                                               // every block it spans, and same-address global atomics serialise; the host adds the copies
 
+// sum over the wave, the same in every lane: an add-scan on the DPP paths (row_shr 1 / 2 / 4 / 8, row_bcast 15 / 31) leaves the total in lane 63.
+// (Six __shfl_xor steps of a 64-bit value are twelve trips through the LDS crossbar; the moment kernel sums nine values per wave.)
 __device__ __forceinline__ long long wave_sum_ll(long long v) {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m);
-    return v;
+#define F360_SUM_STEP(ctrl_, rows_)                                                                                    \
+    {                                                                                                                  \
+        const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(unsigned long long)v, ctrl_, rows_, 0xF, false);          \
+        const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)((unsigned long long)v >> 32), ctrl_, rows_, 0xF, false);  \
+        v += (long long)(((unsigned long long)hi << 32) | lo);                                                         \
+    }
+    F360_SUM_STEP(0x111, 0xF)
+    F360_SUM_STEP(0x112, 0xF)
+    F360_SUM_STEP(0x114, 0xF)
+    F360_SUM_STEP(0x118, 0xF)
+    F360_SUM_STEP(0x142, 0xA)
+    F360_SUM_STEP(0x143, 0xC)
+#undef F360_SUM_STEP
+    const unsigned tlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(unsigned long long)v, 63);
+    const unsigned thi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)v >> 32), 63);
+    return (long long)(((unsigned long long)thi << 32) | tlo);
 }
 
 // Pass 5: every remaining pixel takes the root of its run start (exactly one hop), and the region sizes are counted on the
