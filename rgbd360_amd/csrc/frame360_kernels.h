@@ -1256,16 +1256,24 @@ __global__ __launch_bounds__(kAggThreads) void k_f360_moments(const float* __res
         const bool head = lane == 0 || prev != key;
         const unsigned long long heads = __ballot(head);
         const int seg = __popcll(heads & (~0ull >> (63 - lane)));          // number of heads at or below this lane
-#pragma unroll
-        for (int m = 1; m < 64; m <<= 1) {
-            const int oseg = __shfl_up(seg, m);
-            const bool take = lane >= m && oseg == seg;
-#pragma unroll
-            for (int q = 0; q < 9; ++q) {
-                const long long o = __shfl_up(v[q], m);
-                v[q] += take ? o : 0ll;
-            }
+        // segmented add-scan along the runs, on the DPP paths like wave_sum_ll (a source lane counts when it lies in the same run;
+        // runs are contiguous, so lane 15 / lane 31 of the rows below stand for everything of the run below them)
+#define F360_SEG_STEP(ctrl_, rows_)                                                                                        \
+        {                                                                                                                  \
+            const bool take = __builtin_amdgcn_update_dpp(-1, seg, ctrl_, rows_, 0xF, false) == seg;                       \
+            _Pragma("unroll") for (int q = 0; q < 9; ++q) {                                                                \
+                const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(unsigned long long)v[q], ctrl_, rows_, 0xF, false);          \
+                const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)((unsigned long long)v[q] >> 32), ctrl_, rows_, 0xF, false);  \
+                v[q] += take ? (long long)(((unsigned long long)hi << 32) | lo) : 0ll;                                     \
+            }                                                                                                              \
         }
+        F360_SEG_STEP(0x111, 0xF)
+        F360_SEG_STEP(0x112, 0xF)
+        F360_SEG_STEP(0x114, 0xF)
+        F360_SEG_STEP(0x118, 0xF)
+        F360_SEG_STEP(0x142, 0xA)
+        F360_SEG_STEP(0x143, 0xC)
+#undef F360_SEG_STEP
         const bool tail = lane == 63 || ((heads >> (lane + 1)) & 1ull);
         if (tail && key >= 0) flush(key, v);
     }
