@@ -1663,12 +1663,7 @@ __global__ __launch_bounds__(kHullBlock) void k_f360_hull_extremes(const float* 
     // reproducible bit for bit -- and every wave walks an equal share of the list (in rounds of kHullList entries).
     static_assert((kHullBlock / 64) * kHullChunks == 128, "two counts per lane");
     int c_lo = cnt[lane], c_hi = cnt[64 + lane];
-    int s_lo = c_lo, s_hi = c_hi;
-#pragma unroll
-    for (int d = 1; d < 64; d *= 2) {
-        const int t_lo = __shfl_up(s_lo, d), t_hi = __shfl_up(s_hi, d);
-        if (lane >= d) { s_lo += t_lo; s_hi += t_hi; }
-    }
+    const int s_lo = wave_scan_add(c_lo), s_hi = wave_scan_add(c_hi);
     const int tot_lo = __builtin_amdgcn_readlane(s_lo, 63);
     const int total = tot_lo + __builtin_amdgcn_readlane(s_hi, 63);
     const int ex_lo = s_lo - c_lo, ex_hi = s_hi - c_hi + tot_lo;       // exclusive prefix of flat index lane / 64 + lane
@@ -1793,12 +1788,7 @@ __global__ __launch_bounds__(kHullDirs) void k_f360_hull_pack(const float* __res
             mine += keep[p] ? 1 : 0;
         }
         // exclusive prefix over the block: wave scan + wave totals
-        int incl = mine;
-#pragma unroll
-        for (int d = 1; d < 64; d *= 2) {
-            const int t = __shfl_up(incl, d);
-            if ((k & 63) >= d) incl += t;
-        }
+        const int incl = wave_scan_add(mine);
         if ((k & 63) == 63) wave_cnt[k >> 6] = incl;
         __syncthreads();
         int base = incl - mine, total = 0;
@@ -2073,10 +2063,7 @@ __global__ __launch_bounds__(256) void k_f360_refine_commit(const float* __restr
         const bool one_plane = __ballot(grown && slot != s0) == 0ull;
         if (one_plane) {
 #pragma unroll
-            for (int q = 0; q < 10; ++q) {
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) v[q] += __shfl_xor(v[q], off);
-            }
+            for (int q = 0; q < 10; ++q) v[q] = wave_sum_ll(v[q]);
         }
         if (one_plane ? lane == first : grown) {
             const int h = mom_run_slot(keys, slot);
