@@ -221,6 +221,17 @@ def main():
     sustained = {"gn_iterations_per_s": n_gpus * n_burst * burst_steps / burst_s, "seconds": burst_s, "steps": n_burst * burst_steps,
                  "calls": n_burst, "note": "same forced schedule as `value`, one rank's own clock (no barrier inside), not part of `value`"}
 
+    # "must print the salient fractions" -- the share of the level-0 source pixels that pass every gate of the pass
+    # (valid source point, warped inside the image, target gradient above the saliency threshold, RPI.h:2690 / 2706) and so
+    # contribute a photometric / a depth residual, counted by the device's own pass at the solved pose.  Bytes are counted for
+    # every pixel regardless (the record streams are contiguous).
+    e_pd = reg.eval(0, pose_gpu, 2)
+    e_ph = reg.eval(0, pose_gpu, 0) if method == 0 else e_pd
+    salient_fraction = {"photo": float(e_ph["n_split"][0]) / n_px, "depth": float(e_pd["n_split"][1]) / n_px,
+                        "photo_in_photo_depth_mode": float(e_pd["n_split"][0]) / n_px, "visible": float(e_pd["n_visible"]) / n_px,
+                        "residuals_per_pixel_photo_depth": float(e_pd["n_valid"]) / n_px,
+                        "note": "level 0, at the solved pose; photo / depth = pixels contributing a photometric / depth residual over all %d source pixels" % n_px}
+
     value = n_gpus * args.steps / elapsed
     result = {
         "metric": "Gauss-Newton iters/sec on 2048x1024 spherical pair; SE(3) err vs CPU ref",
@@ -238,6 +249,7 @@ def main():
         "env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "RGBD360_FUSED_SOLVE": os.environ.get("RGBD360_FUSED_SOLVE", "1 (default)")},
         "sustained": sustained,
         "rccl_ranks_seen": rccl_ranks_seen,
+        "salient_fraction": salient_fraction,
         "config": {
             "workload": ("configs[1]: single %dx%d synthetic sphere pair per GPU, %s RegisterPhotoICP, level-0 forced "
                          "Gauss-Newton iterations (one launch each: solve of the previous pass + fused warp/residual/Jacobian pass)" % (W, H, METHOD_NAMES[method])),

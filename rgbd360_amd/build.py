@@ -12,10 +12,15 @@ import tempfile
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(_HERE, "csrc", "rgbd360_api.hip")
-DEPS = [SRC, os.path.join(_HERE, "csrc", "photo_icp_kernels.h"), os.path.join(_HERE, "csrc", "gn_math.h"),
-        os.path.join(_HERE, "csrc", "frame360_kernels.h"), os.path.join(_HERE, "csrc", "occlusion_kernels.h"),
-        os.path.join(_HERE, "csrc", "pinhole_kernels.h"), os.path.join(_HERE, "csrc", "pbmap_register.h"), os.path.join(_HERE, "csrc", "multi_gpu.h"), os.path.join(_HERE, "csrc", "sequence_engine.h"), os.path.join(_HERE, "csrc", "rig_dense.h"), os.path.join(_HERE, "csrc", "host_wait.h"),
-        os.path.join(_HERE, "..", "include", "rgbd360_hip.h"), os.path.join(_HERE, "..", "include", "rgbd360_hip_diag.h")]
+import glob
+
+
+def deps():
+    """Every source the one translation unit can include: csrc/*.h, csrc/*.hip and the public headers (a fixed list went stale twice)."""
+    here = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.h")) + glob.glob(os.path.join(_HERE, "csrc", "*.hip")))
+    return here + sorted(glob.glob(os.path.join(_HERE, "..", "include", "*.h")))
+
+
 LIB = os.path.join(_HERE, "lib", "librgbd360_hip.so")
 
 # -ffp-contract=off: the warp front end must round exactly like the CPU oracle (see photo_icp_kernels.h);
@@ -40,7 +45,7 @@ def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in DEPS)
+    return any(os.path.getmtime(d) > t for d in deps())
 
 
 LLVM_BIN = "/opt/rocm/lib/llvm/bin"

@@ -180,3 +180,13 @@ def test_build_select_widening_only_changes_the_encoding(tmp_path):
     assert out[0] == "\tv_cndmask_b32_e64 v17, 0, v11, vcc\n"
     assert out[1].startswith("\tv_cndmask_b32_e64 v5, v6, v7, vcc") and "; select" in out[1]
     assert out[2:] == lines[2:]
+
+
+def test_build_dependencies_cover_every_source_of_the_library():
+    """needs_build() must see an edit to ANY file the one translation unit includes (a hand-kept list missed rig_dense.h and
+    host_wait.h in round 3): the dependency set is a glob of csrc/ and include/."""
+    from rgbd360_amd import build
+    names = {os.path.basename(d) for d in build.deps()}
+    here = os.path.join(ROOT, "rgbd360_amd", "csrc")
+    assert {f for f in os.listdir(here) if f.endswith((".h", ".hip"))} <= names
+    assert {"rig_dense.h", "host_wait.h", "rgbd360_api.hip", "rgbd360_hip.h", "rgbd360_hip_diag.h"} <= names

@@ -149,3 +149,37 @@ def test_two_ranks_run_real_alignments_and_gather(hip_lib, tmp_path):
     for r in range(2):
         z = np.load(tmp_path / ("rank%d.npz" % r))
         assert np.array_equal(z["poses"], poses) and np.array_equal(z["status"], status) and np.array_equal(z["iters"], iters), r
+
+
+@pytest.mark.gpu
+def test_bench_under_torch_distributed_run_with_two_ranks(hip_lib):
+    """The driver's N > 1 command line -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N --steps K --warmup W` -- with N = 2 on this box's one device (BENCH_SHARE_DEVICE=1: both
+    ranks on device 0, gloo for the exchange because RCCL refuses two ranks on one GPU), started as a child process (the launcher
+    runs before anything in it touches the GPU).  One JSON line from rank 0, n_gpus 2, the gathered pose tensor has one row per
+    rank, and the sharded configs[3] sequence (resident and host frames) converged on both ranks with its size-independent checks."""
+    import json
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--repeats", "5",
+           "--no-cpu-baseline", "--no-4k", "--no-rotating", "--seq-pairs", "24"]
+    env = dict(os.environ, BENCH_SHARE_DEVICE="1", MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="4")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=ROOT)
+    out, err = p.stdout.decode(errors="replace"), p.stderr.decode(errors="replace")
+    assert p.returncode == 0, err[-2000:]
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 5 and r["warmup"] == 2 and r["scaling"] == "weak"
+    assert r["metric"].startswith("Gauss-Newton iters/sec") and r["value"] > 0 and r["rccl_ranks_seen"] == 2
+    assert abs(r["value"] - 2 * 5 / (r["ms_per_step"] * 5e-3)) <= 1e-6 * r["value"]          # whole-job aggregate: N * K / t
+    assert "roofline" in r and 0 < r["roofline"]["frac"] < 1
+    seq = r["sequence"]
+    assert seq["pairs_total"] == 24 and seq["pairs_per_rank"] == 12 and seq["exchange"].startswith("gloo")
+    for variant in ("resident", "host_frames"):
+        v = seq[variant]
+        assert v["all_status_ok"] and v["repeated_pairs_bit_identical"] and v["alignments_per_s"] > 0, (variant, v)
+        assert v["max_forward_backward_residual"] < 1e-3

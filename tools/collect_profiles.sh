@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): bench + rocprofv3 kernel trace of the same command + PMC passes.
 # usage: bash tools/collect_profiles.sh <tag>
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -14,7 +14,15 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/t
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_sq -- python3 $R/tools/prof_eval.py 2048 1024 10 > $OUT/pmc_sq.log 2>&1
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_tcc -- python3 $R/tools/prof_eval.py 2048 1024 10 > $OUT/pmc_tcc.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_4k -- python3 $R/tools/prof_eval.py 4096 2048 10 > $OUT/pmc_fetch_4k.log 2>&1
+# the HBM-fed legs of the bench line, one regime per profiler run (tools/prof_hbm_legs.py): kernel trace + stats, and FETCH_SIZE / WRITE_SIZE
+# on the rotating leg (each counter set in its own run, never together with a trace)
+for leg in rotating 4k batch; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$leg -- python3 $R/tools/prof_hbm_legs.py $leg 10 > $OUT/trace_$leg.log 2>&1
+done
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_rotating -- python3 $R/tools/prof_hbm_legs.py rotating 4 > $OUT/pmc_fetch_rotating.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_rotating -- python3 $R/tools/prof_hbm_legs.py rotating 4 > $OUT/pmc_write_rotating.log 2>&1
 cd $R
 cat $OUT/bench.json
 python3 tools/trace_gaps.py $OUT/trace
-for d in pmc_fetch pmc_write pmc_sq pmc_tcc pmc_fetch_4k; do echo "== $d"; cat $OUT/$d.log | grep "avg us"; python3 tools/pmc_summary.py $OUT/$d; done
+for d in pmc_fetch pmc_write pmc_sq pmc_tcc pmc_fetch_4k pmc_fetch_rotating pmc_write_rotating; do echo "== $d"; cat $OUT/$d.log | grep "avg us"; python3 tools/pmc_summary.py $OUT/$d; done
+for leg in rotating 4k batch; do echo "== trace_$leg"; cat $OUT/trace_$leg.log | grep "HIP events"; python3 tools/trace_gaps.py $OUT/trace_$leg | grep k_eval; cp $(ls $OUT/trace_$leg/*/*kernel_stats.csv | tail -1) $OUT/hbm_${leg}_kernel_stats.csv; done
