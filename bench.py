@@ -54,7 +54,18 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0          # measured float4 copy (same guide)
 LLC_BYTES = 256 * 1024 * 1024  # Infinity Cache
 BYTES_PER_PX = {0: 28, 1: 28, 2: 40}   # LUT variant: 16 B source record + 12 B (24 B) gathered target records
+BYTES_PER_PX_RECOMPUTE = {0: 20, 1: 20, 2: 32}   # recompute variant: 8 B of depth + intensity per source pixel, the point re-formed in the pass
 WORKING_SET_PER_PX = {0: 28, 1: 28, 2: 40}
+# which levels run which form (the library's rules, csrc/rgbd360_api.hip recompute_min_px / sequence_engine.h): the single-pair pass from
+# 4 Mpx up (levels that cannot stay in the Infinity Cache), the lock-step engine (always HBM-fed) from 256 Kpx up
+RECOMPUTE_MIN_PX = int(os.environ.get("RGBD360_RECOMPUTE_MIN_PX", 4 * 1024 * 1024))
+SEQ_RECOMPUTE_MIN_PX = int(os.environ.get("RGBD360_SEQ_RECOMPUTE_MIN_PX", 256 * 1024))
+
+
+def pass_bytes_per_px(method, n_px, engine=False):
+    """Algorithmic bytes per source pixel of one fused pass in the form the library runs at this level size."""
+    rc = n_px >= (SEQ_RECOMPUTE_MIN_PX if engine else RECOMPUTE_MIN_PX)
+    return (BYTES_PER_PX_RECOMPUTE if rc else BYTES_PER_PX)[method]
 METHOD_NAMES = {0: "PHOTO_CONSISTENCY", 1: "DEPTH_CONSISTENCY", 2: "PHOTO_DEPTH"}
 SEQ_UNIQUE_FRAMES = 9          # frames rendered per rank for the sequence block (walked back and forth)
 SEQ_INFLIGHT = 32              # pairs in flight per GPU: slots of the lock-step sequence engine (2 engines x 16)
@@ -67,14 +78,17 @@ def avg_kernel_us(fn, batches=5):
     return vals[len(vals) // 2], vals
 
 
-def roofline_entry(us, batches, n_px, method, kernel=None, **extra):
-    alg = BYTES_PER_PX[method] * n_px
+def roofline_entry(us, batches, n_px, method, kernel=None, engine=False, **extra):
+    bpp = pass_bytes_per_px(method, n_px, engine)
+    alg = bpp * n_px
     ach = alg / (us * 1e-6) / 1e9
     slow = max(batches)
     d = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
          "kernel": kernel or "k_eval<%d,true>" % method, "kernel_avg_us": us, "kernel_avg_us_batches": batches,
          "frac_slowest_batch": alg / (slow * 1e-6) / 1e9 / HBM_PEAK_GBS,
-         "algorithmic_bytes_per_launch": alg, "bytes_per_pixel": BYTES_PER_PX[method],
+         "algorithmic_bytes_per_launch": alg, "bytes_per_pixel": bpp,
+         "source_form": ("recompute: 8 B {depth, intensity} per source pixel + angle tables, point re-formed per pixel" if bpp != BYTES_PER_PX[method]
+                         else "records: 16 B {x, y, z, I} per source pixel (LUT_xyz_sphere precomputed)"),
          "frac_of_measured_copy_peak": ach / HBM_COPY_GBS}
     d.update(extra)
     return d
@@ -338,12 +352,12 @@ def main():
         solve_us = reg.time_solve_kernel(0, 0, 50)
         it_s = elapsed / args.steps
         result["iteration"] = {
-            "bytes_per_iteration": BYTES_PER_PX[method] * n_px, "us_per_iteration": it_s * 1e6,
+            "bytes_per_iteration": pass_bytes_per_px(method, n_px) * n_px, "us_per_iteration": it_s * 1e6,
             "launch_us": fused_us if fused else kernel_us + solve_us, "pass_only_us": kernel_us, "separate_solve_launch_us": solve_us,
             "gap_and_host_us": it_s * 1e6 - (fused_us if fused else kernel_us + solve_us),
-            "achieved": BYTES_PER_PX[method] * n_px / it_s / 1e9, "unit": "GB/s",
-            "frac": BYTES_PER_PX[method] * n_px / it_s / 1e9 / HBM_PEAK_GBS,
-            "frac_sustained": BYTES_PER_PX[method] * n_px * sustained["gn_iterations_per_s"] / n_gpus / 1e9 / HBM_PEAK_GBS,
+            "achieved": pass_bytes_per_px(method, n_px) * n_px / it_s / 1e9, "unit": "GB/s",
+            "frac": pass_bytes_per_px(method, n_px) * n_px / it_s / 1e9 / HBM_PEAK_GBS,
+            "frac_sustained": pass_bytes_per_px(method, n_px) * n_px * sustained["gn_iterations_per_s"] / n_gpus / 1e9 / HBM_PEAK_GBS,
             "note": ("value's own step: one k_eval_fs launch (+ the K-step call's fixed cost / K: the tail solve launch, the host wake-up)" if fused else
                      "value's own step: one k_eval pass + one k_solve launch + launch gaps (+ the K-step call's fixed cost / K)")}
         # the same forced schedule in the sequence engine's regime: 16 pairs iterate in lock step, one {pass, solve} launch pair
@@ -356,17 +370,18 @@ def main():
                 best = fb if best is None or fb["elapsed_ms"] < best["elapsed_ms"] else best
             same = bool(all(np.array_equal(best["poses"][k], out["pose"]) for k in range(P)))
             t_it = best["elapsed_ms"] * 1e-3 / (P * args.steps)
+            bpp_e = pass_bytes_per_px(method, n_px, engine=True)
             result["iteration_lockstep"] = {
                 "pairs_in_flight": P, "gn_iterations_per_s": 1.0 / t_it, "us_per_pair_iteration": t_it * 1e6,
-                "achieved": BYTES_PER_PX[method] * n_px / t_it / 1e9, "unit": "GB/s",
-                "frac": BYTES_PER_PX[method] * n_px / t_it / 1e9 / HBM_PEAK_GBS,
+                "achieved": bpp_e * n_px / t_it / 1e9, "unit": "GB/s", "bytes_per_pixel": bpp_e,
+                "frac": bpp_e * n_px / t_it / 1e9 / HBM_PEAK_GBS,
                 "resident": "hbm" if P * ws >= LLC_BYTES else "infinity_cache",
                 "poses_bit_identical_to_single_pair": same,
                 # the batch pass alone (k_eval_b, all P slots per launch): HIP events over ten back-to-back launches
                 "pass": {"kernel": "k_eval_b<%d,true>" % method, "pairs_per_launch": P, "avg_launch_us": best["pass_avg_us"],
-                         "algorithmic_bytes_per_launch": P * BYTES_PER_PX[method] * n_px,
-                         "achieved": P * BYTES_PER_PX[method] * n_px / (best["pass_avg_us"] * 1e-6) / 1e9, "unit": "GB/s",
-                         "frac": P * BYTES_PER_PX[method] * n_px / (best["pass_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_launch": P * bpp_e * n_px, "bytes_per_pixel": bpp_e,
+                         "achieved": P * bpp_e * n_px / (best["pass_avg_us"] * 1e-6) / 1e9, "unit": "GB/s",
+                         "frac": P * bpp_e * n_px / (best["pass_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
                          "resident": "hbm" if P * ws >= LLC_BYTES else "infinity_cache"},
                 "pass_photo_depth": None,
                 "note": "rgbd360_forced_iters_batch: the step of `value` with 16 pairs per launch (k_eval_b / k_solve_b), HIP events, "
@@ -374,9 +389,10 @@ def main():
         if not args.no_sequence and method != 2:
             # the same batch pass in the mode of configs[3] (photo + depth, 40 B/px): what the sequence engine's level-0 launches do
             fb2 = min((reg.forced_iters_batch(P, (rgbA, dA), (rgbB, dB), 0, start_pose, 2, 4) for _ in range(3)), key=lambda r: r["pass_avg_us"])
-            by2 = P * BYTES_PER_PX[2] * n_px
+            by2 = P * pass_bytes_per_px(2, n_px, engine=True) * n_px
             result["iteration_lockstep"]["pass_photo_depth"] = {
                 "kernel": "k_eval_b<2,true>", "pairs_per_launch": P, "avg_launch_us": fb2["pass_avg_us"], "algorithmic_bytes_per_launch": by2,
+                "bytes_per_pixel": pass_bytes_per_px(2, n_px, engine=True),
                 "achieved": by2 / (fb2["pass_avg_us"] * 1e-6) / 1e9, "unit": "GB/s", "frac": by2 / (fb2["pass_avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
                 "resident": "hbm"}
         srt_a = sorted(t_align)
@@ -542,16 +558,18 @@ def run_sequence_block(args, torch, dist, synth, reg0, rank, world, local_rank, 
         # of source / target records and the next level's 8 B/px of planes), and per level (accepted iterations + the first pass + the
         # pass whose rejection ends the level) fused passes of 40 B/px
         n_l = [(H >> l) * (W >> l) for l in range(4)]
-        setup_b = sum((5 if l == 0 else 8) * n_l[l] + 40 * n_l[l] + (8 * n_l[l + 1] if l + 1 < 4 else 0) for l in range(4))
+        rec_b = [(8 if n_l[l] >= SEQ_RECOMPUTE_MIN_PX else 16) + 24 for l in range(4)]      # source record (compact on the large levels) + both target records
+        setup_b = sum((5 if l == 0 else 8) * n_l[l] + rec_b[l] * n_l[l] + (8 * n_l[l + 1] if l + 1 < 4 else 0) for l in range(4))
         mean_it = it.mean(0) if len(it) else np.zeros(4)
-        pass_b = float(sum(BYTES_PER_PX[method] * n_l[l] * (mean_it[l] + 1 + (1 if mean_it[l] < 10 else 0)) for l in range(4)))
+        pass_b = float(sum(pass_bytes_per_px(method, n_l[l], engine=True) * n_l[l] * (mean_it[l] + 1 + (1 if mean_it[l] < 10 else 0)) for l in range(4)))
         pair_b = setup_b + pass_b
         ach = pair_b * n_total / med / 1e9 / world         # per GPU
         out[variant] = {
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "per": "GPU",
                          "algorithmic_bytes_per_alignment": pair_b, "setup_bytes": setup_b, "pass_bytes": pass_b,
-                         "model": "frame set-up of one new frame (5 | 8 B/px in, 40 B/px records + 8 B/px next-level planes out, 4 levels) + "
-                                  "sum over levels of (mean accepted iterations + 2) passes x 40 B/px; PCIe bytes of host frames not counted"},
+                         "model": "frame set-up of one new frame (5 | 8 B/px in, 32 | 40 B/px records + 8 B/px next-level planes out, 4 levels) + "
+                                  "sum over levels of (mean accepted iterations + 2) passes x 32 | 40 B/px (levels of 256 Kpx and more carry 8-byte {depth, I} source "
+                                  "records and re-form the point in the pass, the small ones the 16-byte record); PCIe bytes of host frames not counted"},
             "alignments_per_s": n_total / med, "elapsed_ms_median": med * 1e3, "elapsed_ms_all": [t * 1e3 for t in times],
             "ms_per_pair_per_gpu": med * 1e3 / max(1, -(-n_total // world)),
             "all_status_ok": bool((st == 0).all()), "repeated_pairs_bit_identical": repeats_equal,

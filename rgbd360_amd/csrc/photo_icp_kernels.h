@@ -42,6 +42,13 @@ struct LevelDev {
     const float4* src;       // {x, y, z, Isrc} per source pixel; x == -10000 marks an invalid point
     const F3* trgP;          // {Itrg, gradX, gradY} per target pixel
     const F3* trgD;          // {Dtrg, dgradX, dgradY} per target pixel
+    // Recompute forms of the source stream (SRC = 1, 2 of the per-pixel pass; SURVEY.md 8d "recompute-from-depth variant": 8 instead of
+    // 16 bytes per source pixel): the point is re-formed per pixel as LUT_xyz_sphere does (RPI.h:4573-4582, bit for bit) from the
+    // pixel's depth and the angle tables.  SRC 1 reads depth / intensity from the level's float planes, SRC 2 from {depth, Isrc} records.
+    const float *depth_src = nullptr, *gray_src = nullptr;
+    const float2* src2 = nullptr;                            // {depth, Isrc} per source pixel (lock-step engine)
+    const float2 *tabT = nullptr, *tabP = nullptr;           // {sin, cos} of theta per column / of phi per row (host libm, RPI.h:4556-4571)
+    float min_depth = 0.f, max_depth = 0.f;
 };
 
 struct EvalConsts {
@@ -96,12 +103,16 @@ struct SolveCfg {
 // exhaustion, not by analysis: rgbd360_selftest_math (and tools/ubench/rn_variants.hip) compare it with the compiler's IEEE
 // sqrtf for every float of that range -- 0 mismatches on gfx950.  (The first version corrected the hardware sqrt with two
 // +-1 ulp residual tests: 9 instructions instead of 6.)
-__device__ __forceinline__ float sqrt_rn(float x) {
-    const float y = __builtin_amdgcn_rsqf(fmaxf(x, 1.17549435e-38f));      // the clamp only matters for x == 0: s = 0 * y = 0
+__device__ __forceinline__ float sqrt_rn(float x, float& y) {           // y: the hardware estimate of 1 / sqrt(x) it starts from (<= 1 ulp)
+    y = __builtin_amdgcn_rsqf(fmaxf(x, 1.17549435e-38f));      // the clamp only matters for x == 0: s = 0 * y = 0
     const float s = x * y;
     const float h = 0.5f * y;
     const float r = fmaf(-s, s, x);
     return fmaf(r, h, s);
+}
+__device__ __forceinline__ float sqrt_rn(float x) {
+    float y;
+    return sqrt_rn(x, y);
 }
 // Correctly rounded 1/x for normal finite |x| in [2^-60, 2^60]: hardware estimate (<= 1 ulp) + one Newton step with an exact
 // fma residual; exhaustively equal to the IEEE quotient 1.f / x on gfx950 (same self-test).
@@ -120,28 +131,39 @@ __device__ __forceinline__ int round_index(float x) {
     return r;
 }
 
-// atan(t) for t in [0, 1(+ulps)]: odd minimax polynomial, 9 coefficients, relative error 1.3e-8.
-__device__ __forceinline__ float atan_unit(float t) {
-    const float q0 = -0.3333333195069166f, q1 = 0.19999765993465415f, q2 = -0.14279110844310372f,
-                q3 = 0.11037993832882714f, q4 = -0.08673169371217875f, q5 = 0.06284358078457526f,
-                q6 = -0.03627014369584507f, q7 = 0.01375026672953864f, q8 = -0.00244702708829393f;
-    const float s = t * t;
-    float p = fmaf(s, q8, q7);
-    p = fmaf(s, p, q6);
-    p = fmaf(s, p, q5);
-    p = fmaf(s, p, q4);
-    p = fmaf(s, p, q3);
-    p = fmaf(s, p, q2);
-    p = fmaf(s, p, q1);
-    p = fmaf(s, p, q0);
-    return fmaf(t * s, p, t);
+// Quadrant angle by table (round 4; rounds 1-3: min / max ratio, a 9-coefficient odd polynomial for atan on [0, 1] and the swap
+// reflection pi/2 - a: 16 vector instructions per angle, 8.5 now).  For a direction (x, y) with x, y >= 0 the "diamond" ratio
+// d = y / (x + y) in [0, 1] grows monotonically with the angle, so T(d) = atan(d / (1 - d)) covers the whole quadrant with no case
+// split.  T is tabulated on kAtanN = 256 intervals as the quadratic through its values at the interval's ends and middle
+// (tools/gen_atan_table.py: float64 libm, rounded to float32; error of the interpolation <= 7.6e-9 rad, i.e. the result is good to
+// float32 rounding like the polynomial was); the table sits in LDS (4 KB per workgroup, staged by atan_tab_stage), one ds_read_b128
+// per angle.  u = d * N arrives from the caller (both angles of a pixel share one correctly rounded reciprocal, and N is folded into
+// it).  Every step is an IEEE-754 basic operation on table constants that the CPU checker computes by the same formula
+// (oracle/photo_icp_ref.cpp, math_mode 1; tests compare the tables bit for bit): indices stay bit-identical CPU <-> GPU.
+constexpr int kAtanN = 256;
+#ifdef RGBD360_ATAN_TABLE
+__device__ const float4 g_atan_tab[kAtanN + 1] = {
+#include "atan_table.inc"
+};
+// every workgroup that warps pixels stages the table once (the caller puts a barrier behind it)
+__device__ __forceinline__ void atan_tab_stage(float4* __restrict__ lds_tab) {
+    for (int k = (int)threadIdx.x; k <= kAtanN; k += (int)blockDim.x) lds_tab[k] = g_atan_tab[k];
 }
-// atan2(y, x) from t = min(|y|,|x|) / max(|y|,|x|) supplied by the caller (both angles share one reciprocal).
-__device__ __forceinline__ float atan2_from_t(float y, float x, float ay, float ax, float t) {
-    float a = atan_unit(t);
-    if (ay > ax) a = 1.57079637f - a;
-    if (__builtin_signbit(x)) a = 3.14159274f - a;
-    return copysignf(a, y);
+#endif
+#ifdef RGBD360_ATAN_TABLE
+#define R360_ATAB_DECL(name) __shared__ float4 name[kAtanN + 1]
+#define R360_ATAB_STAGE(name) atan_tab_stage(name)
+#define R360_ATAB_SYNC() __syncthreads()
+#else
+#define R360_ATAB_DECL(name) const float4* const name = nullptr
+#define R360_ATAB_STAGE(name)
+#define R360_ATAB_SYNC()
+#endif
+__device__ __forceinline__ float atan_diamond(const float4* __restrict__ lds_tab, float u) {
+    const int i = (int)u;                               // u >= 0: truncation = floor (v_cvt_i32_f32; NaN -> 0, like the checker)
+    const float f = __builtin_amdgcn_fractf(u);         // u - floor(u), exact
+    const float4 c = lds_tab[i];
+    return fmaf(f, fmaf(f, c.z, c.y), c.x);
 }
 
 struct PoseRT {
@@ -158,10 +180,11 @@ __device__ __forceinline__ PoseRT load_pose(const float* P) {   // column-major 
 
 // Shared front end of RPI.h:2663-2684 / 2959-2989.  Returns the target pixel index (valid only when `vis`).
 // Device arithmetic definition (the oracle's math_mode 1 repeats it operation for operation):
-//   p' = R p + t with fused multiply-adds;  rho^2 = Y^2 + Z^2,  d^2 = X^2 + rho^2
-//   phi   = atan2(X, rho)      (= asin(X/d) of the reference, RPI.h:2676)      rho = correctly rounded sqrt
-//   theta = atan2(Y, Z);  column = round(theta * k + PI*k)   (RPI.h:2677-2680 with the +PI folded into the scaling)
-//   both quotients min/max come from ONE correctly rounded reciprocal r = 1 / (mx_phi * mx_theta)
+//   p' = R p + t with fused multiply-adds;  rho^2 = Y^2 + Z^2,  d^2 = X^2 + rho^2,  rho = correctly rounded sqrt
+//   phi   = atan2(X, rho)  (= asin(X/d) of the reference, RPI.h:2676):  sign(X) T(|X| / (|X| + rho))
+//   theta = atan2(Y, Z):  a = T(|Y| / (|Y| + |Z|)),  Z < 0: pi - a,  sign(Y);  column = round(theta * k + PI*k)   (RPI.h:2677-2680
+//           with the +PI folded into the scaling)
+//   both ratios come from ONE correctly rounded reciprocal r = 1 / ((|X| + rho) (|Y| + |Z|)), T from the table above
 // Every step is an IEEE-754 basic operation, so x86 and gfx950 agree bit for bit on the pixel index.
 struct WarpConsts {        // per-lane copies (VGPRs) of the wave-uniform addends: a VOP3 fma reads one scalar only
     float tx, ty, tz, half_nRows, pi_k;
@@ -171,34 +194,68 @@ __device__ __forceinline__ WarpConsts make_warp_consts(const PoseRT& T, const Le
     asm volatile("" : "+v"(c.tx), "+v"(c.ty), "+v"(c.tz), "+v"(c.half_nRows), "+v"(c.pi_k));
     return c;
 }
-__device__ __forceinline__ void warp_pixel_rc(const PoseRT& T, const WarpConsts& wc, float px, float py, float pz,
+__device__ __forceinline__ void warp_pixel_rc(const PoseRT& T, const WarpConsts& wc, const float4* __restrict__ atab, float px, float py, float pz,
                                               const LevelDev& lv, float& X, float& Y, float& Z, float& rho2, float& d2,
-                                              int& tr, int& tc, bool& vis) {
+                                              int& tr, int& tc, unsigned long long& vis_mask, float& inv_rho) {
     X = fmaf(T.r02, pz, fmaf(T.r01, py, fmaf(T.r00, px, wc.tx)));
     Y = fmaf(T.r12, pz, fmaf(T.r11, py, fmaf(T.r10, px, wc.ty)));
     Z = fmaf(T.r22, pz, fmaf(T.r21, py, fmaf(T.r20, px, wc.tz)));
     rho2 = fmaf(Z, Z, Y * Y);
     d2 = fmaf(X, X, rho2);
-    const float rho = sqrt_rn(rho2);
-    const float ax = fabsf(X), ay = fabsf(Y), az = fabsf(Z);
-    const float mxp = fmaxf(fmaxf(ax, rho), 1e-9f), mnp = __builtin_amdgcn_fmed3f(ax, rho, 0.f);   // min of two non-negatives
-    const float mxt = fmaxf(fmaxf(ay, az), 1e-9f), mnt = fminf(ay, az);
-    const float r = rcp_rn(mxp * mxt);
-    const float tp = mnp * (r * mxt);
-    const float tt = mnt * (r * mxp);
-    float phi_trg = atan_unit(tp);
-    if (ax > rho) phi_trg = 1.57079637f - phi_trg;
-    phi_trg = copysignf(phi_trg, X);
-    const float theta = atan2_from_t(Y, Z, ay, az, tt);
+    const float rho = sqrt_rn(rho2, inv_rho);       // inv_rho: float32 DATA for the Jacobian (consume_stage), not index work
+    const float ax = fabsf(X), ay = fabsf(Y);
+#ifndef RGBD360_ATAN_TABLE       // the product's angle arithmetic (the checker's math_mode 1 mirrors it); -DRGBD360_ATAN_TABLE: the experimental table form below
+    {
+        const float az = fabsf(Z);
+        const float mxp = fmaxf(fmaxf(ax, rho), 1e-9f), mnp = __builtin_amdgcn_fmed3f(ax, rho, 0.f);
+        const float mxt = fmaxf(fmaxf(ay, az), 1e-9f), mnt = fminf(ay, az);
+        const float r = rcp_rn(mxp * mxt);
+        auto atan_unit = [](float t) {
+            const float q0 = -0.3333333195069166f, q1 = 0.19999765993465415f, q2 = -0.14279110844310372f, q3 = 0.11037993832882714f,
+                        q4 = -0.08673169371217875f, q5 = 0.06284358078457526f, q6 = -0.03627014369584507f, q7 = 0.01375026672953864f,
+                        q8 = -0.00244702708829393f;
+            const float s2 = t * t;
+            float p = fmaf(s2, q8, q7);
+            p = fmaf(s2, p, q6); p = fmaf(s2, p, q5); p = fmaf(s2, p, q4); p = fmaf(s2, p, q3);
+            p = fmaf(s2, p, q2); p = fmaf(s2, p, q1); p = fmaf(s2, p, q0);
+            return fmaf(t * s2, p, t);
+        };
+        float phi_trg = atan_unit(mnp * (r * mxt));
+        if (ax > rho) phi_trg = 1.57079637f - phi_trg;
+        phi_trg = copysignf(phi_trg, X);
+        float a = atan_unit(mnt * (r * mxp));
+        if (ay > az) a = 1.57079637f - a;
+        if (__builtin_signbit(Z)) a = 3.14159274f - a;
+        const float theta_p = copysignf(a, Y);
+        tr = round_index(fmaf(phi_trg, -lv.angle_res_inv, wc.half_nRows));
+        tc = round_index(fmaf(theta_p, lv.angle_res_inv, wc.pi_k));
+        vis_mask = __builtin_amdgcn_ballot_w64((unsigned)tr < (unsigned)lv.rows) & __builtin_amdgcn_ballot_w64((unsigned)tc < (unsigned)lv.cols);
+        return;
+    }
+#endif
+    const float sp = ax + rho;                      // 0 only for p' = 0 (never a valid point: NaN angles, index 0, harmless)
+    const float st = fmaxf(ay + fabsf(Z), 1e-9f);   // the clamp matters on the polar axis (Y = Z = 0: theta = 0, phi = +-pi/2)
+    const float rN = rcp_rn(sp * st) * (float)kAtanN;
+    const float up = ax * (st * rN);                // N |X| / (|X| + rho)
+    const float ut = ay * (sp * rN);                // N |Y| / (|Y| + |Z|)
+    const float phi_trg = copysignf(atan_diamond(atab, up), X);
+    float theta = atan_diamond(atab, ut);
+    if (__builtin_signbit(Z)) theta = 3.14159274f - theta;
+    theta = copysignf(theta, Y);
     tr = round_index(fmaf(phi_trg, -lv.angle_res_inv, wc.half_nRows));
     tc = round_index(fmaf(theta, lv.angle_res_inv, wc.pi_k));
-    vis = ((unsigned)tr < (unsigned)lv.rows) && ((unsigned)tc < (unsigned)lv.cols);
+    // predicates of the per-pixel pass are kept as 64-bit lane masks (the compares' own SGPR results, combined on the scalar unit): the
+    // ballot of a COMBINED bool costs a v_cndmask + v_cmp pair per use with this compiler
+    vis_mask = __builtin_amdgcn_ballot_w64((unsigned)tr < (unsigned)lv.rows) & __builtin_amdgcn_ballot_w64((unsigned)tc < (unsigned)lv.cols);
 }
-__device__ __forceinline__ unsigned warp_pixel(const PoseRT& T, const WarpConsts& wc, float px, float py, float pz,
+__device__ __forceinline__ unsigned warp_pixel(const PoseRT& T, const WarpConsts& wc, const float4* __restrict__ atab, float px, float py, float pz,
                                                const LevelDev& lv, float& X, float& Y, float& Z, float& rho2, float& d2,
                                                bool& vis) {
     int tr, tc;
-    warp_pixel_rc(T, wc, px, py, pz, lv, X, Y, Z, rho2, d2, tr, tc, vis);
+    float inv_rho;
+    unsigned long long vis_mask;
+    warp_pixel_rc(T, wc, atab, px, py, pz, lv, X, Y, Z, rho2, d2, tr, tc, vis_mask, inv_rho);
+    vis = __builtin_amdgcn_inverse_ballot_w64(vis_mask);
     return __umul24(tr, lv.cols) + (unsigned)tc;
 }
 
@@ -292,6 +349,7 @@ __device__ __forceinline__ void wave_reduce32(const float v[32], float out[2]) {
 // past num_records return 0) replaces the index clamps: a lane past the end of its span, or a pixel warped outside
 // the image, may issue its load with whatever offset it has -- the value is never used and the load cannot fault.
 // ---------------------------------------------------------------------------------------------------------
+typedef float float2v __attribute__((ext_vector_type(2)));
 typedef float float3v __attribute__((ext_vector_type(3)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
@@ -310,6 +368,92 @@ __device__ __forceinline__ F3 buf_load_f3(__amdgpu_buffer_rsrc_t r, unsigned byt
 struct EvalBufs {
     __amdgpu_buffer_rsrc_t src, trgP, trgD;
     unsigned row_bytes;      // cols * 12
+    const float4* atab;      // the quadrant-angle table in LDS (atan_tab_stage)
+};
+
+// Source records of one step of a span: the descriptor is rebased on the step's first pixel (wave-uniform: scalar arithmetic), so the
+// per-lane offset is the loop-invariant tid * 16 and no vector instruction goes into the address; records past the end of the buffer
+// read as zero (num_records shrinks with the base, 0 once the step lies behind the buffer).
+__device__ __forceinline__ float4 load_src_step(const float4* __restrict__ src0, const int n_px, const int first_px, const unsigned tid16) {
+    const int left = max(n_px - first_px, 0);
+    return buf_load_f4(make_rsrc(src0 + first_px, (unsigned)left * 16u), tid16);
+}
+
+__device__ __forceinline__ void divmod24(int n, int d, int& q, int& rem);
+// ---------------------------------------------------------------------------------------------------------
+// The source stream of the per-pixel pass, three forms (template parameter SRC):
+//   0  {x, y, z, Isrc} records, 16 B per pixel (LUT_xyz_sphere precomputed per level, like the reference)
+//   1  depth and intensity from the level's float planes (4 + 4 B per pixel) + the angle tables: the point is re-formed per pixel
+//   2  {depth, Isrc} records (8 B per pixel) + the angle tables (the lock-step engine, which keeps no level-0 planes)
+// Forms 1 / 2 move 8 B per source pixel less through the memory system (20 instead of 28 B/px photo, 32 instead of 40
+// photo + depth); the point they form is LUT_xyz_sphere's, operation for operation (src_rec_px), so sums and poses are bit-identical
+// to form 0.  Measured (round 4, tools/ab_libs.py, one box): every HBM-fed regime gains -- 4096 x 2048 photo + depth 56.9 -> 47.0 us,
+// the 2048 x 1024 pass rotating over 8 pairs 13.7 -> 11.8 us -- the Infinity-Cache-resident 2048 x 1024 launch 3 % (14.7 -> 14.3 us
+// fused) and the small levels lose 0.3 us each (more loads and a row / column cursor in a latency-bound launch): the host picks form 1
+// for levels of kRecomputeMinPx pixels and more, the engine (always HBM-fed) form 2 on its large levels.
+// ---------------------------------------------------------------------------------------------------------
+struct SrcRaw { float d, I, st, ct, sp, cp; };
+struct SrcCursor { int r, c, dr, dc; };      // (row, column) of the lane's pixel in the next step to load, and the per-step advance
+__device__ __forceinline__ void cursor_advance(SrcCursor& k, const int cols) {
+    k.c += k.dc; k.r += k.dr;
+    const bool wrap = k.c >= cols;
+    k.c = wrap ? k.c - cols : k.c;
+    k.r = wrap ? k.r + 1 : k.r;
+}
+template <int SRC> struct SrcForm;
+template <> struct SrcForm<0> {
+    typedef float4 T;
+    static __device__ __forceinline__ void cursor_init(SrcCursor&, const LevelDev&, int, int) {}
+    static __device__ __forceinline__ float4 load(const LevelDev&, const float4* __restrict__ src0, const int n_px, const int first_px, const unsigned tid16, SrcCursor&) {
+        return load_src_step(src0, n_px, first_px, tid16);
+    }
+    static __device__ __forceinline__ float4 value(const float4& q, const LevelDev&) { return q; }
+};
+__device__ __forceinline__ void src_tabs(SrcRaw& q, const LevelDev& lv, SrcCursor& k) {
+    const float2v t = (float2v)__builtin_amdgcn_raw_buffer_load_b64(make_rsrc(lv.tabT, (unsigned)lv.cols * 8u), k.c << 3, 0, 0);
+    const float2v p = (float2v)__builtin_amdgcn_raw_buffer_load_b64(make_rsrc(lv.tabP, (unsigned)lv.rows * 8u), k.r << 3, 0, 0);
+    q.st = t.x; q.ct = t.y; q.sp = p.x; q.cp = p.y;
+    cursor_advance(k, lv.cols);
+}
+__device__ __forceinline__ float4 src_point(const SrcRaw& q, const LevelDev& lv) {       // src_rec_px's arithmetic, bit for bit
+    float4 o;
+    o.w = q.I;
+    const bool ok = lv.min_depth < q.d && q.d < lv.max_depth;
+    const float t = -q.d * q.cp;
+    o.x = ok ? q.d * q.sp : kInvalidPoint;
+    o.y = t * q.st;
+    o.z = t * q.ct;
+    return o;
+}
+template <> struct SrcForm<1> {
+    typedef SrcRaw T;
+    static __device__ __forceinline__ void cursor_init(SrcCursor& k, const LevelDev& lv, int first_lane_px, int threads) {
+        divmod24(first_lane_px, lv.cols, k.r, k.c);
+        divmod24(threads, lv.cols, k.dr, k.dc);
+    }
+    static __device__ __forceinline__ SrcRaw load(const LevelDev& lv, const float4* __restrict__, const int n_px, const int first_px, const unsigned tid16, SrcCursor& k) {
+        const int left = max(n_px - first_px, 0);
+        const unsigned tid4 = tid16 >> 2;
+        SrcRaw q;
+        q.d = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(make_rsrc(lv.depth_src + first_px, (unsigned)left * 4u), (int)tid4, 0, 0));
+        q.I = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(make_rsrc(lv.gray_src + first_px, (unsigned)left * 4u), (int)tid4, 0, 0));
+        src_tabs(q, lv, k);
+        return q;
+    }
+    static __device__ __forceinline__ float4 value(const SrcRaw& q, const LevelDev& lv) { return src_point(q, lv); }
+};
+template <> struct SrcForm<2> {
+    typedef SrcRaw T;
+    static __device__ __forceinline__ void cursor_init(SrcCursor& k, const LevelDev& lv, int first_lane_px, int threads) { SrcForm<1>::cursor_init(k, lv, first_lane_px, threads); }
+    static __device__ __forceinline__ SrcRaw load(const LevelDev& lv, const float4* __restrict__, const int n_px, const int first_px, const unsigned tid16, SrcCursor& k) {
+        const int left = max(n_px - first_px, 0);
+        SrcRaw q;
+        const float2v v = (float2v)__builtin_amdgcn_raw_buffer_load_b64(make_rsrc(lv.src2 + first_px, (unsigned)left * 8u), (int)(tid16 >> 1), 0, 0);
+        q.d = v.x; q.I = v.y;
+        src_tabs(q, lv, k);
+        return q;
+    }
+    static __device__ __forceinline__ float4 value(const SrcRaw& q, const LevelDev& lv) { return src_point(q, lv); }
 };
 
 struct EvalAcc {
@@ -320,7 +464,10 @@ struct EvalAcc {
 
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
-__device__ __forceinline__ int ballot_count(bool p) { return __builtin_popcountll(__ballot(p)); }
+// (the wave-mask form of the ballot: HIP's __ballot goes through an integer compare of the predicate, which costs the per-pixel loop a
+// v_cndmask + v_cmp pair per count; this one is the compare's own SGPR mask)
+__device__ __forceinline__ unsigned long long ballot_mask(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ int ballot_count(bool p) { return __builtin_popcountll(ballot_mask(p)); }
 
 // weightHuber (RPI.h:545-554) with the hardware sqrt / rcp approximations (1 ulp): weights are float32 data,
 // not index work.
@@ -356,27 +503,35 @@ __device__ __forceinline__ void accumulate_row(EvalAcc& A, float jx, float jy, f
 // k_eval runs warp_stage of pixel i+1 before consume_stage of pixel i: the gather latency of one pixel hides behind
 // the arithmetic of its neighbour instead of stalling the wave.
 struct PixW {
-    float X, Y, Z, rho2, d2s, isrc;   // d2s = |p'|^2 with the sign bit carrying "not visible" (saves a flag register)
+    float X, Y, Z, rho2, d2, isrc, inv_rho;   // inv_rho: the reciprocal-square-root estimate sqrt_rn(rho2) started from
+    unsigned long long vis;                    // "visible" of the wave's 64 pixels as a lane mask (an SGPR pair: no flag register, no select)
     F3    tp, td;
 };
 
-template <int METHOD>
-__device__ __forceinline__ void warp_stage(const float4 s, const bool in_range, const PoseRT& T, const WarpConsts& wc,
+// CHECK = false: every lane's pixel lies inside the span (all steps but the last of a span): no in_range test.
+template <int METHOD, bool CHECK = true, int SRC = 0>
+__device__ __forceinline__ void warp_stage(const typename SrcForm<SRC>::T sraw, const bool in_range, const PoseRT& T, const WarpConsts& wc,
                                            const LevelDev& lv, const EvalBufs& bufs, PixW& w) {
-    bool vis;
-    float d2;
+    const float4 s = SrcForm<SRC>::value(sraw, lv);
     int tr, tc;
-    warp_pixel_rc(T, wc, s.x, s.y, s.z, lv, w.X, w.Y, w.Z, w.rho2, d2, tr, tc, vis);
-    vis = vis && in_range && (s.x != kInvalidPoint);
-    w.d2s = vis ? d2 : -d2;
+    warp_pixel_rc(T, wc, bufs.atab, s.x, s.y, s.z, lv, w.X, w.Y, w.Z, w.rho2, w.d2, tr, tc, w.vis, w.inv_rho);
+    w.vis &= __builtin_amdgcn_ballot_w64(s.x != kInvalidPoint);
+    if (CHECK) w.vis &= __builtin_amdgcn_ballot_w64(in_range);
     w.isrc = s.w;
     // tie the copy of the source intensity to the end of the warp arithmetic: scheduled earlier it would sit in
     // front of the whole stage and wait for the youngest load (vmcnt(0)) instead of the one this stage needs
-    asm volatile("" : "+v"(w.isrc), "+v"(w.d2s));
+    asm volatile("" : "+v"(w.isrc), "+v"(tc));
     // unconditional gathers, issued as soon as the index is known; an invisible pixel's offset is arbitrary but
     // range-checked by the buffer descriptor
     const unsigned off = __umul24(tr, bufs.row_bytes) + __umul24(tc, 12u);      // byte offset of the 12-byte target record
+#ifdef RGBD360_EXP_GATHER4      // bandwidth-sensitivity experiment (tools/ab_libs.py): 4 instead of 12 bytes per gather, made-up gradients
+    if (METHOD != 1) {
+        const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bufs.trgP, (int)off, 0, 0));
+        w.tp.a = v; w.tp.b = v * 0.37f; w.tp.c = v * -0.21f;
+    }
+#else
     if (METHOD != 1) w.tp = buf_load_f3(bufs.trgP, off);
+#endif
     if (METHOD != 0) w.td = buf_load_f3(bufs.trgD, off);
 }
 
@@ -387,9 +542,8 @@ __device__ __forceinline__ void consume_stage(PixW& w, const LevelDev& lv, const
     if (METHOD != 1) asm volatile("" : "+v"(w.tp.a), "+v"(w.tp.b), "+v"(w.tp.c));
     if (METHOD != 0) asm volatile("" : "+v"(w.td.a), "+v"(w.td.b), "+v"(w.td.c));
     const float X = w.X, Y = w.Y, Z = w.Z;
-    const bool vis = w.d2s > 0.f;
-    const float d2 = fabsf(w.d2s);
-    A.nVis += ballot_count(vis);
+    const float d2 = w.d2;
+    A.nVis += __builtin_popcountll(w.vis);
 
     // rows of jacobianProj23 (RPI.h:3000-3016) in terms of rho^2 = Y^2+Z^2 and d^2 = |p'|^2 (k = angle_res_inv):
     //   d c'/d(y,z) = k (Z, -Y) / rho^2
@@ -397,23 +551,25 @@ __device__ __forceinline__ void consume_stage(PixW& w, const LevelDev& lv, const
     // (algebraically what the reference writes with 1/z, 1/(1+y^2/z^2), 1/sqrt(1-x^2/d^2)); float32 data, so the
     // hardware reciprocal square roots are used.  A weighted gradient (gx, gy) times this 2x3 matrix is, with
     // u = gx k / rho^2 and v = gy k / (rho d^2):   ( -v rho^2,  v X Y + u Z,  v X Z - u Y ).
+    // inv_rho = 1 / rho is the estimate the warp's sqrt_rn(rho^2) started from (the same v_rsq_f32 of the same operand: one
+    // transcendental per pixel less than asking again).
     float k_rho2 = 0.f, k_d2r = 0.f;
     const float dist_inv = fast_rsq(d2);
-    if (HG) {
+    if (HG && METHOD != 0) {            // photo + depth: both rows share the two factors (photo alone folds them into its row, below)
 #pragma clang fp contract(fast)
-        const float inv_rho = fast_rsq(w.rho2);
+        const float inv_rho = w.inv_rho;
         k_rho2 = lv.angle_res_inv * (inv_rho * inv_rho);
         k_d2r = (lv.angle_res_inv * (dist_inv * dist_inv)) * inv_rho;
     }
 
-    bool photo_skip = false;   // `continue` at RPI.h:2690 / 3039 also skips the depth term of the pixel
+    unsigned long long photo_skip = 0ull;   // `continue` at RPI.h:2690 / 3039 also skips the depth term of the pixel
     if (METHOD != 1) {
         const float tgx = w.tp.b, tgy = w.tp.c;
-        const bool nonsal = fabsf(tgx) < ec.thr_photo && fabsf(tgy) < ec.thr_photo;
+        const unsigned long long nonsal = __builtin_amdgcn_ballot_w64(fabsf(tgx) < ec.thr_photo) & __builtin_amdgcn_ballot_w64(fabsf(tgy) < ec.thr_photo);
         photo_skip = nonsal;
-        const bool ok = vis && !nonsal;
-        A.nP += ballot_count(ok);
-        if (ok) {
+        const unsigned long long ok = w.vis & ~nonsal;
+        A.nP += __builtin_popcountll(ok);
+        if (__builtin_amdgcn_inverse_ballot_w64(ok)) {
 #pragma clang fp contract(fast)
             const float photoDiff = w.tp.a - w.isrc;
             const float wpf = weight_huber_fast(photoDiff, ec.sigma_photo) * ec.sigma_photo_inv_f;
@@ -421,7 +577,15 @@ __device__ __forceinline__ void consume_stage(PixW& w, const LevelDev& lv, const
             A.e2p += res * res;
             if (HG) {
                 // (w * grad) * jacobianProj23
-                const float u = (wpf * tgx) * k_rho2, v = (wpf * tgy) * k_d2r;
+                float u, v;
+                if (METHOD == 0) {      // one row per pixel: w k / rho once, two multiplications fewer than through k_rho2 / k_d2r
+                    const float bq = (wpf * lv.angle_res_inv) * w.inv_rho;
+                    u = tgx * (bq * w.inv_rho);
+                    v = tgy * (bq * (dist_inv * dist_inv));
+                } else {
+                    u = (wpf * tgx) * k_rho2;
+                    v = (wpf * tgy) * k_d2r;
+                }
                 const float vX = v * X;
                 accumulate_row(A, -v * w.rho2, vX * Y + u * Z, vX * Z - u * Y, X, Y, Z, res);
             }
@@ -430,10 +594,10 @@ __device__ __forceinline__ void consume_stage(PixW& w, const LevelDev& lv, const
     if (METHOD != 0) {
         const float depth2 = w.td.a;
         const float tdx = w.td.b, tdy = w.td.c;
-        const bool nonsal = fabsf(tdx) < ec.thr_depth && fabsf(tdy) < ec.thr_depth;
-        const bool ok = vis && !photo_skip && isfinite(depth2) && !nonsal;
-        A.nD += ballot_count(ok);
-        if (ok) {
+        const unsigned long long nonsal = __builtin_amdgcn_ballot_w64(fabsf(tdx) < ec.thr_depth) & __builtin_amdgcn_ballot_w64(fabsf(tdy) < ec.thr_depth);
+        const unsigned long long ok = w.vis & ~photo_skip & ~nonsal & __builtin_amdgcn_ballot_w64(fabsf(depth2) < INFINITY);      // isfinite
+        A.nD += __builtin_popcountll(ok);
+        if (__builtin_amdgcn_inverse_ballot_w64(ok)) {
 #pragma clang fp contract(fast)
             float dist = d2 * dist_inv;                                 // |p'|: rsq estimate + one Newton step (< 1 ulp)
             dist = fmaf(0.5f * dist_inv, fmaf(-dist, dist, d2), dist);
@@ -469,10 +633,10 @@ __device__ __forceinline__ void consume_stage(PixW& w, const LevelDev& lv, const
 #endif
 // Everything behind the gate: the software-pipelined pixel loop and the block reduction.  On entry the first warp stage (wA, the
 // pixel at i) has been issued and sB holds the source record of the pixel at i + THREADS.
-template <int METHOD, bool HG, int THREADS>
+template <int METHOD, bool HG, int THREADS, int SRC = 0>
 __device__ __forceinline__ void eval_span(const PoseRT& T, const WarpConsts& wc, const LevelDev& lv, const EvalConsts& ec,
-                                          const EvalBufs& bufs, int i, const int base, const int end, const int b, const int nb,
-                                          PixW& wA, float4 sB, double* __restrict__ partials,
+                                          const EvalBufs& bufs, const float4* __restrict__ src0, const int n_px, const int base, const int end,
+                                          const int b, const int nb, PixW& wA, typename SrcForm<SRC>::T sB, SrcCursor cur, double* __restrict__ partials,
                                           unsigned long long* es, const unsigned long long es0) {
     constexpr int NS = kEvalThreads / THREADS;           // accumulator sets (lanes of the 1024-lane layout per thread)
     EvalAcc A[NS];
@@ -489,24 +653,35 @@ __device__ __forceinline__ void eval_span(const PoseRT& T, const WarpConsts& wc,
     // Wave-uniform trip count (every lane stays active: the ballots count whole waves); lanes past the end of the
     // span process a clamped record with in_range = false.
     const int n_steps = NS * ((end - base + kEvalThreads - 1) / kEvalThreads);
+    const int tid = (int)threadIdx.x;
+    const unsigned tid16 = (unsigned)tid << 4;
     // The loop is unrolled by two with ping-pong register
     // sets (wA / wB) so that no register copy forces an early wait: while the arithmetic of step k runs, the gathers
-    // of step k+1 and the source record of step k+2 are in flight.
+    // of step k+1 and the source record of step k+2 are in flight.  `first` = first pixel of step k (wave-uniform).
     PixW wB;
-    float4 sA = buf_load_f4(bufs.src, (unsigned)(i + 2 * THREADS) << 4);
+    int first = base;
+    typename SrcForm<SRC>::T sA = SrcForm<SRC>::load(lv, src0, n_px, first + 2 * THREADS, tid16, cur);
     int k = 0;
-    // steady state: straight-line body (no control-flow joins, so the compiler's waits are counted, not vmcnt(0))
-    for (; k + 2 < n_steps; k += 2, i += 2 * THREADS) {
-        warp_stage<METHOD>(sB, (i + THREADS) < end, T, wc, lv, bufs, wB);
-        sB = buf_load_f4(bufs.src, (unsigned)(i + 3 * THREADS) << 4);
-        consume_stage<METHOD, HG>(wA, lv, ec, AA);
-        warp_stage<METHOD>(sA, (i + 2 * THREADS) < end, T, wc, lv, bufs, wA);
-        sA = buf_load_f4(bufs.src, (unsigned)(i + 4 * THREADS) << 4);
+#define RGBD360_EVAL_LOOP_BODY(CHECK)                                                                                    \
+        warp_stage<METHOD, CHECK, SRC>(sB, tid < end - (first + THREADS), T, wc, lv, bufs, wB);                         \
+        sB = SrcForm<SRC>::load(lv, src0, n_px, first + 3 * THREADS, tid16, cur);                                       \
+        consume_stage<METHOD, HG>(wA, lv, ec, AA);                                                                      \
+        warp_stage<METHOD, CHECK, SRC>(sA, tid < end - (first + 2 * THREADS), T, wc, lv, bufs, wA);                     \
+        sA = SrcForm<SRC>::load(lv, src0, n_px, first + 4 * THREADS, tid16, cur);                                       \
         consume_stage<METHOD, HG>(wB, lv, ec, AB);
+    // steady state: straight-line body (no control-flow joins, so the compiler's waits are counted, not vmcnt(0)).  Only the last NS
+    // steps of a span can be partial, so the steps this loop warps (k + 1, k + 2 <= n_steps - 1 - NS) need no span test.
+    for (; k + 2 + NS < n_steps; k += 2, first += 2 * THREADS) {
+        RGBD360_EVAL_LOOP_BODY(false)
     }
+    // the same body with the span test for the (at most NS / 2 + 1) trips that touch the span's last steps
+    for (; k + 2 < n_steps; k += 2, first += 2 * THREADS) {
+        RGBD360_EVAL_LOOP_BODY(true)
+    }
+#undef RGBD360_EVAL_LOOP_BODY
     // tail: one or two steps left, wA holds step k
     if (k + 1 < n_steps) {
-        warp_stage<METHOD>(sB, (i + THREADS) < end, T, wc, lv, bufs, wB);
+        warp_stage<METHOD, true, SRC>(sB, tid < end - (first + THREADS), T, wc, lv, bufs, wB);
         consume_stage<METHOD, HG>(wA, lv, ec, AA);
         consume_stage<METHOD, HG>(wB, lv, ec, AB);
     } else {
@@ -575,7 +750,7 @@ __device__ __forceinline__ void eval_span(const PoseRT& T, const WarpConsts& wc,
 #endif
 }
 
-template <int METHOD, bool HG, int THREADS = kEvalThreads>
+template <int METHOD, bool HG, int THREADS = kEvalThreads, int SRC = 0>
 __device__ __forceinline__ void eval_block(const GNState* __restrict__ st, const float4* __restrict__ src0, const int n_px,
                                            const int chunk, const int level, const int nb_arg, double* __restrict__ partials,
                                            const LevelDev& lv, const EvalConsts& ec) {
@@ -595,11 +770,16 @@ __device__ __forceinline__ void eval_block(const GNState* __restrict__ st, const
     bufs.trgP = make_rsrc(lv.trgP, (unsigned)lv.n * 12u);
     bufs.trgD = make_rsrc(lv.trgD, (unsigned)lv.n * 12u);
     bufs.row_bytes = (unsigned)lv.cols * 12u;
+    R360_ATAB_DECL(s_atab);
+    bufs.atab = s_atab;
     const int i = base + (int)threadIdx.x;
     // the first two source records do not depend on the state: issue them before the scalar loads of done / pose
-    const float4 sA = buf_load_f4(bufs.src, (unsigned)i << 4);
     static_assert(THREADS == 1024 || THREADS == 512, "eval_block: 1024-lane layout, played by 1024 or 512 threads");
-    const float4 sB = buf_load_f4(bufs.src, (unsigned)(i + THREADS) << 4);
+    SrcCursor cur = {0, 0, 0, 0};
+    SrcForm<SRC>::cursor_init(cur, lv, i, THREADS);
+    const typename SrcForm<SRC>::T sA = SrcForm<SRC>::load(lv, src0, n_px, base, (unsigned)threadIdx.x << 4, cur);
+    const typename SrcForm<SRC>::T sB = SrcForm<SRC>::load(lv, src0, n_px, base + THREADS, (unsigned)threadIdx.x << 4, cur);
+    R360_ATAB_STAGE(s_atab);                         // (its loads travel with the record loads; the barrier stands below)
     // gate and pose are fetched in ONE batch of scalar loads, in parallel with the two record loads above.  The gate is
     // only TESTED after the first warp stage: an early-exit branch up here makes the compiler sink every load behind it
     // (one dependent memory round trip per sunk batch, ~1 us each); the asm statement that ends warp_stage cannot be moved
@@ -608,19 +788,20 @@ __device__ __forceinline__ void eval_block(const GNState* __restrict__ st, const
     const PoseRT T = load_pose(st->cand);
     const WarpConsts wc = make_warp_consts(T, lv);
     ESTAMP(0);
+    R360_ATAB_SYNC();                                // the angle table is in LDS
     PixW wA;
-    warp_stage<METHOD>(sA, i < end, T, wc, lv, bufs, wA);
+    warp_stage<METHOD, true, SRC>(sA, i < end, T, wc, lv, bufs, wA);
     asm volatile("" ::: "memory");                   // the loads issued so far stay above the gate
     if (gate.x | (gate.y != level)) return;          // speculatively enqueued launch of a finished / later level
     ESTAMP(1);
-    eval_span<METHOD, HG, THREADS>(T, wc, lv, ec, bufs, i, base, end, b, nb, wA, sB, partials, es, es0);
+    eval_span<METHOD, HG, THREADS, SRC>(T, wc, lv, ec, bufs, src0, n_px, base, end, b, nb, wA, sB, cur, partials, es, es0);
 }
 
-template <int METHOD, bool HG>
+template <int METHOD, bool HG, int SRC = 0>
 __global__ __launch_bounds__(kEvalThreads) void k_eval(const GNState* __restrict__ st, const float4* __restrict__ src0, int n_px,
                                                         int chunk, int level, int nb_arg, double* __restrict__ partials,
                                                         LevelDev lv, EvalConsts ec) {
-    eval_block<METHOD, HG>(st, src0, n_px, chunk, level, nb_arg, partials, lv, ec);
+    eval_block<METHOD, HG, kEvalThreads, SRC>(st, src0, n_px, chunk, level, nb_arg, partials, lv, ec);
 }
 
 // Lock-step batch of pairs: blockIdx.y = slot.  Every per-slot buffer of a level is one slice of a single allocation, so the
@@ -628,15 +809,16 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval(const GNState* __restrict
 // dependent load in front of the first record loads.  Work split, partial rows and summation order per slot are exactly those
 // of k_eval, hence bit-identical sums.
 constexpr int kEvalThreadsBatch = 512;
-template <int METHOD, bool HG>
+template <int METHOD, bool HG, int SRC = 0>
 __global__ __launch_bounds__(kEvalThreadsBatch) void k_eval_b(const GNState* __restrict__ states, const float4* __restrict__ src0, int n_px,
                                                           int chunk, int level, int nb_arg, double* __restrict__ partials,
                                                           int partials_stride, LevelDev lv, EvalConsts ec) {
     const int slot = blockIdx.y;
     lv.trgP += (size_t)slot * (size_t)n_px;
     lv.trgD += (size_t)slot * (size_t)n_px;
-    eval_block<METHOD, HG, kEvalThreadsBatch>(states + slot, src0 + (size_t)slot * (size_t)n_px, n_px, chunk, level, nb_arg,
-                                              partials + (size_t)slot * (size_t)partials_stride, lv, ec);
+    if (SRC == 2) lv.src2 += (size_t)slot * (size_t)n_px;
+    eval_block<METHOD, HG, kEvalThreadsBatch, SRC>(states + slot, SRC == 0 ? src0 + (size_t)slot * (size_t)n_px : src0, n_px, chunk, level, nb_arg,
+                                                   partials + (size_t)slot * (size_t)partials_stride, lv, ec);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1246,7 +1428,7 @@ __device__ __forceinline__ float uniform_f(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
 }
 
-template <int METHOD>
+template <int METHOD, int SRC = 0>
 __global__ __launch_bounds__(kEvalThreads) void k_eval_fs(const GNState* __restrict__ st_in, GNState* __restrict__ st_out,
                                                            const double* __restrict__ partials_in, double* __restrict__ partials_out,
                                                            const float4* __restrict__ src0, int n_px, int chunk, int level, int nb_arg,
@@ -1259,11 +1441,14 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_fs(const GNState* __restr
     const unsigned long long es0 = 0;
 #endif
     __shared__ SolveShared sh;
+    R360_ATAB_DECL(s_atab);
     constexpr int kStateWords = sizeof(GNState) / 4;
 #ifdef RGBD360_SOLVE_STAMPS
     if (threadIdx.x == 0) sh.stamp0 = __builtin_amdgcn_s_memrealtime();
 #endif
     // what the solve waits for is requested first (a wave's vector-memory operations complete in issue order) ...
+    // (the angle table of the pixel pass rides along: its barrier is stage_pending's)
+    R360_ATAB_STAGE(s_atab);
     int pend = stage_pending(sh, st_in, partials_in);
     if (init.on) {                              // uniform: the first launch of a schedule is its k_level_init too (every block initialises
         if (threadIdx.x == 0) level_init_one(&sh.sst, init.pose, 1, 1, level);      // its own LDS copy of the state, block 0 writes it out)
@@ -1281,10 +1466,13 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_fs(const GNState* __restr
     bufs.trgP = make_rsrc(lv.trgP, (unsigned)lv.n * 12u);
     bufs.trgD = make_rsrc(lv.trgD, (unsigned)lv.n * 12u);
     bufs.row_bytes = (unsigned)lv.cols * 12u;
+    bufs.atab = s_atab;
     const int i = base + (int)threadIdx.x;
     // ... the first two source records of the span, which depend on nothing, right behind it: in flight during the solve
-    const float4 sA = buf_load_f4(bufs.src, (unsigned)i << 4);
-    const float4 sB = buf_load_f4(bufs.src, (unsigned)(i + kEvalThreads) << 4);
+    SrcCursor cur = {0, 0, 0, 0};
+    SrcForm<SRC>::cursor_init(cur, lv, i, kEvalThreads);
+    const typename SrcForm<SRC>::T sA = SrcForm<SRC>::load(lv, src0, n_px, base, (unsigned)threadIdx.x << 4, cur);
+    const typename SrcForm<SRC>::T sB = SrcForm<SRC>::load(lv, src0, n_px, base + kEvalThreads, (unsigned)threadIdx.x << 4, cur);
     float lam_spec = 0.f;
     int solved_level = 0;
     if (pend > 0) {                             // uniform: the previous launch ran a pass
@@ -1357,9 +1545,9 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_fs(const GNState* __restr
     const WarpConsts wc = make_warp_consts(T, lv);
     ESTAMP(0);
     PixW wA;
-    warp_stage<METHOD>(sA, i < end, T, wc, lv, bufs, wA);
+    warp_stage<METHOD, true, SRC>(sA, i < end, T, wc, lv, bufs, wA);
     ESTAMP(1);
-    eval_span<METHOD, true, kEvalThreads>(T, wc, lv, ec, bufs, i, base, end, b, nb, wA, sB, partials_out, es, es0);
+    eval_span<METHOD, true, kEvalThreads, SRC>(T, wc, lv, ec, bufs, src0, n_px, base, end, b, nb, wA, sB, cur, partials_out, es, es0);
 }
 
 // The tail of a fused-solve schedule: the solve of the last pass enqueued (if one is pending), in place, one block; publishes
@@ -1399,16 +1587,20 @@ __global__ void k_gn_step(GnIO* io) {
 
 // Warp indices of every source pixel (parity diagnostics).
 __global__ void k_warp_indices(LevelDev lv, Pose16 pose, int32_t* __restrict__ out) {
+    R360_ATAB_DECL(s_atab);
+    R360_ATAB_STAGE(s_atab);
+    R360_ATAB_SYNC();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= lv.n) return;
     const PoseRT T = load_pose(pose.v);
     const float4 s = lv.src[i];
     int r = -1, c = -1;
-    if (s.x != kInvalidPoint) {
+    {       // (no branch on the point's validity around the warp: its predicates are whole-wave lane masks)
         float X, Y, Z, rho2, d2;
         bool vis;
         const WarpConsts wc = {T.tx, T.ty, T.tz, lv.half_nRows, lv.pi_k};
-        const unsigned ti = warp_pixel(T, wc, s.x, s.y, s.z, lv, X, Y, Z, rho2, d2, vis);
+        const unsigned ti = warp_pixel(T, wc, s_atab, s.x, s.y, s.z, lv, X, Y, Z, rho2, d2, vis);
+        vis = vis && s.x != kInvalidPoint;
         if (vis) {
             r = (int)(ti / (unsigned)lv.cols);
             c = (int)ti - r * lv.cols;
@@ -1733,6 +1925,7 @@ struct FrameLevelArgs {
     unsigned long long live_mask;   // slots with a frame in this launch
     unsigned long long src_mask;    // ... whose source records are wanted
     unsigned long long trg_mask;    // ... whose target records are wanted
+    int compact_src;                // spherical source records as {depth, Isrc} (8 B: the pass re-forms the point, SrcForm<2>) instead of {x, y, z, Isrc}
     int pinhole;                    // source records of a pinhole sensor (RPI.h:4277-4300) instead of the spherical LUT
     float pin_ox, pin_oy, pin_inv_fx, pin_inv_fy;      // intrinsics of THIS level
 };
@@ -1854,7 +2047,14 @@ __global__ __launch_bounds__(256) void k_frame_level_b(FrameLevelArgs A, FramePt
         if (r < rows) {
             const bool want_src = (A.src_mask >> slot) & 1ull, want_trg = (A.trg_mask >> slot) & 1ull;
             const int ly = ty + kFsRing;
-            if (want_src) {
+            if (want_src && A.compact_src) {       // {depth, Isrc}: validity and direction are the pass's business (src_point)
+                float2* out = reinterpret_cast<float2*>(A.src_rec) + (size_t)slot * n + (size_t)r * cols;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int c = c0 + tj + 16 * k;
+                    if (c < cols) out[c] = make_float2(sd[ly][tj + 16 * k + kFsRing], sg[ly][tj + 16 * k + kFsRing]);
+                }
+            } else if (want_src) {
                 const float sp = A.pinhole ? 0.f : A.sin_phi[r], cp = A.pinhole ? 0.f : A.cos_phi[r];
                 float4* out = A.src_rec + (size_t)slot * n + (size_t)r * cols;
 #pragma unroll

@@ -38,6 +38,7 @@ struct Level {
     float4* srcRecPin = nullptr;     // pinhole LUT record of the source (built per alignment, RPI.h:4277-4300)
     F3 *trgP = nullptr, *trgD = nullptr;
     float *sinT = nullptr, *cosT = nullptr, *sinP = nullptr, *cosP = nullptr;
+    float2 *tabT = nullptr, *tabP = nullptr;      // the same values interleaved {sin, cos}: one 8-byte load per pixel in the recompute form of the pass
     int nblocks = 0, chunk = 0;
 };
 
@@ -144,7 +145,7 @@ void free_levels(rgbd360_ctx* ctx) {
         if (!ctx->arena) {
             hipFree(L.graySrc); hipFree(L.depthSrc); hipFree(L.grayTrg); hipFree(L.depthTrg);
             hipFree(L.srcRec); hipFree(L.trgP); hipFree(L.trgD);
-            hipFree(L.sinT); hipFree(L.cosT); hipFree(L.sinP); hipFree(L.cosP);
+            hipFree(L.sinT); hipFree(L.cosT); hipFree(L.sinP); hipFree(L.cosP); hipFree(L.tabT); hipFree(L.tabP);
         }
         hipFree(L.srcRecPin);
     }
@@ -171,7 +172,8 @@ int ensure_levels(rgbd360_ctx* ctx, int rows, int cols) {
         for (int l = 0, rr = rows, cc = cols; l < ctx->p.n_pyr; ++l, rr /= 2, cc /= 2) {
             const size_t n = (size_t)rr * cc;
             total += 4 * ((n * 4 + 255) & ~(size_t)255) + ((n * 16 + 255) & ~(size_t)255) + 2 * ((n * 12 + 255) & ~(size_t)255) +
-                     2 * (((size_t)cc * 4 + 255) & ~(size_t)255) + 2 * (((size_t)rr * 4 + 255) & ~(size_t)255);
+                     2 * (((size_t)cc * 4 + 255) & ~(size_t)255) + 2 * (((size_t)rr * 4 + 255) & ~(size_t)255) +
+                     (((size_t)cc * 8 + 255) & ~(size_t)255) + (((size_t)rr * 8 + 255) & ~(size_t)255);
         }
         HIPC(ctx, hipMalloc(&ctx->arena, total));
     }
@@ -202,6 +204,8 @@ int ensure_levels(rgbd360_ctx* ctx, int rows, int cols) {
         L.trgD = (F3*)take((size_t)L.n * sizeof(F3));
         L.sinT = (float*)take(c * sizeof(float)); L.cosT = (float*)take(c * sizeof(float));
         L.sinP = (float*)take(r * sizeof(float)); L.cosP = (float*)take(r * sizeof(float));
+        L.tabT = (float2*)take(c * sizeof(float2)); L.tabP = (float2*)take(r * sizeof(float2));
+        if (!L.tabT || !L.tabP) return fail(ctx, -103, "cannot allocate the pyramid levels");
         if (!L.graySrc || !L.depthSrc || !L.grayTrg || !L.depthTrg || !L.srcRec || !L.trgP || !L.trgD || !L.sinT || !L.cosT || !L.sinP || !L.cosP)
             return fail(ctx, -103, "cannot allocate the pyramid levels");
         // RPI.h:4556-4571: per-column / per-row sin, cos of float arguments (host libm, once per size)
@@ -220,6 +224,13 @@ int ensure_levels(rgbd360_ctx* ctx, int rows, int cols) {
         HIPC(ctx, hipMemcpy(L.cosT, ct.data(), c * sizeof(float), hipMemcpyHostToDevice));
         HIPC(ctx, hipMemcpy(L.sinP, sp.data(), r * sizeof(float), hipMemcpyHostToDevice));
         HIPC(ctx, hipMemcpy(L.cosP, cp.data(), r * sizeof(float), hipMemcpyHostToDevice));
+        {
+            std::vector<float2> tt(c), tp(r);
+            for (int j = 0; j < c; ++j) tt[j] = make_float2(st[j], ct[j]);
+            for (int i = 0; i < r; ++i) tp[i] = make_float2(sp[i], cp[i]);
+            HIPC(ctx, hipMemcpy(L.tabT, tt.data(), c * sizeof(float2), hipMemcpyHostToDevice));
+            HIPC(ctx, hipMemcpy(L.tabP, tp.data(), r * sizeof(float2), hipMemcpyHostToDevice));
+        }
         // work split of the fused pass: <= max_eval_blocks blocks, contiguous spans that are multiples of 256 pixels
         int chunk = (L.n + ctx->max_eval_blocks - 1) / ctx->max_eval_blocks;
         chunk = ((chunk + kEvalThreads - 1) / kEvalThreads) * kEvalThreads;
@@ -247,7 +258,16 @@ LevelDev level_dev(const Level& L) {
     d.half_nRows = L.half_nRows; d.angle_res_inv = L.angle_res_inv;
     d.pi_k = (float)(kPI * (double)L.angle_res_inv);
     d.src = L.srcRec; d.trgP = L.trgP; d.trgD = L.trgD;
+    d.depth_src = L.depthSrc; d.gray_src = L.graySrc; d.tabT = L.tabT; d.tabP = L.tabP;
     return d;
+}
+// Levels of this many pixels and more run the per-pixel pass in its recompute form (SRC 1, photo_icp_kernels.h: 8 B per source pixel less;
+// a gain wherever the level is fed from HBM, a small loss on the latency-bound small levels).  Default: levels whose photo + depth
+// working set (40 B/px) does not fit the 256 MiB Infinity Cache next to anything else, i.e. 4096 x 2048 and up; RGBD360_RECOMPUTE_MIN_PX
+// moves the bound (0 = every level, for A/B runs and tests).
+int recompute_min_px() {
+    static const int v = [] { const char* e = getenv("RGBD360_RECOMPUTE_MIN_PX"); return e ? atoi(e) : 4 * 1024 * 1024; }();
+    return v;
 }
 
 EvalConsts eval_consts(const rgbd360_params& p) {
@@ -280,7 +300,8 @@ int occ_ensure(rgbd360_ctx* ctx) {
 
 void launch_eval(rgbd360_ctx* ctx, int level, int method, bool hg, int occ = 0) {
     const Level& L = ctx->levels[level];
-    const LevelDev lv = level_dev(L);
+    LevelDev lv = level_dev(L);
+    lv.min_depth = ctx->p.min_depth; lv.max_depth = ctx->p.max_depth;
     const EvalConsts ec = eval_consts(ctx->p);
     dim3 g(L.nblocks), b(kEvalThreads);
     if (occ != 0) {
@@ -307,15 +328,22 @@ void launch_eval(rgbd360_ctx* ctx, int level, int method, bool hg, int occ = 0) 
 #undef LAUNCH_OCC
         return;
     }
-#define LAUNCH(M, HG) hipLaunchKernelGGL((k_eval<M, HG>), g, b, 0, ctx->stream, ctx->d_state, lv.src, lv.n, L.chunk, level, L.nblocks, ctx->d_partials, lv, ec)
+#define LAUNCH(M, HG, S) hipLaunchKernelGGL((k_eval<M, HG, S>), g, b, 0, ctx->stream, ctx->d_state, lv.src, lv.n, L.chunk, level, L.nblocks, ctx->d_partials, lv, ec)
+    const bool rc = L.n >= recompute_min_px();
     if (hg) {
-        if (method == 0) LAUNCH(0, true);
-        else if (method == 1) LAUNCH(1, true);
-        else LAUNCH(2, true);
+        if (rc) {
+            if (method == 0) LAUNCH(0, true, 1);
+            else if (method == 1) LAUNCH(1, true, 1);
+            else LAUNCH(2, true, 1);
+        } else {
+            if (method == 0) LAUNCH(0, true, 0);
+            else if (method == 1) LAUNCH(1, true, 0);
+            else LAUNCH(2, true, 0);
+        }
     } else {
-        if (method == 0) LAUNCH(0, false);
-        else if (method == 1) LAUNCH(1, false);
-        else LAUNCH(2, false);
+        if (method == 0) LAUNCH(0, false, 0);
+        else if (method == 1) LAUNCH(1, false, 0);
+        else LAUNCH(2, false, 0);
     }
 #undef LAUNCH
 }
@@ -354,15 +382,22 @@ void launch_eval_fused(rgbd360_ctx* ctx, int level, int method, int forced, cons
     if (init_pose) memcpy(init.pose.v, init_pose, sizeof(init.pose.v));
     else memset(init.pose.v, 0, sizeof(init.pose.v));
     const Level& L = ctx->levels[level];
-    const LevelDev lv = level_dev(L);
+    LevelDev lv = level_dev(L);
+    lv.min_depth = ctx->p.min_depth; lv.max_depth = ctx->p.max_depth;
     const EvalConsts ec = eval_consts(ctx->p);
     const SolveCfg cfg = fused_cfg(ctx, forced);
     dim3 g(L.nblocks), b(kEvalThreads);
-#define LAUNCHF(M) hipLaunchKernelGGL((k_eval_fs<M>), g, b, 0, ctx->stream, (const GNState*)ctx->d_state, ctx->d_state_alt, (const double*)ctx->d_partials, \
+#define LAUNCHF(M, S) hipLaunchKernelGGL((k_eval_fs<M, S>), g, b, 0, ctx->stream, (const GNState*)ctx->d_state, ctx->d_state_alt, (const double*)ctx->d_partials, \
                                       ctx->d_partials_alt, lv.src, lv.n, L.chunk, level, L.nblocks, lv, ec, cfg, init)
-    if (method == 0) LAUNCHF(0);
-    else if (method == 1) LAUNCHF(1);
-    else LAUNCHF(2);
+    if (L.n >= recompute_min_px()) {
+        if (method == 0) LAUNCHF(0, 1);
+        else if (method == 1) LAUNCHF(1, 1);
+        else LAUNCHF(2, 1);
+    } else {
+        if (method == 0) LAUNCHF(0, 0);
+        else if (method == 1) LAUNCHF(1, 0);
+        else LAUNCHF(2, 0);
+    }
 #undef LAUNCHF
     std::swap(ctx->d_state, ctx->d_state_alt);
     std::swap(ctx->d_partials, ctx->d_partials_alt);

@@ -23,6 +23,8 @@ struct SeqLevel {
     F3 *trgP[2] = {nullptr, nullptr}, *trgD[2] = {nullptr, nullptr};            // [P][n] x 2: the records of a frame are built when it
                                                                                 // arrives as a source, one round before it is the target
     float *sinT = nullptr, *cosT = nullptr, *sinP = nullptr, *cosP = nullptr;
+    float2 *tabT = nullptr, *tabP = nullptr;      // interleaved {sin, cos} (recompute form of the pass)
+    bool compact = false;                         // source records of this level are {depth, Isrc} (8 B) and k_eval_b re-forms the point
     int nblocks = 0, chunk = 0;
 };
 
@@ -61,7 +63,7 @@ void seq_free(SeqEngine* E) {
     for (SeqLevel& L : E->levels) {
         hipFree(L.gray); hipFree(L.depth); hipFree(L.srcRec);
         for (int k = 0; k < 2; ++k) { hipFree(L.trgP[k]); hipFree(L.trgD[k]); }
-        hipFree(L.sinT); hipFree(L.cosT); hipFree(L.sinP); hipFree(L.cosP);
+        hipFree(L.sinT); hipFree(L.cosT); hipFree(L.sinP); hipFree(L.cosP); hipFree(L.tabT); hipFree(L.tabP);
     }
     hipFree(E->d_states); hipFree(E->d_partials);
     if (E->h_states) hipHostFree(E->h_states);
@@ -136,6 +138,21 @@ int seq_create(const rgbd360_params& p, int P, int rows, int cols, int max_eval_
              hipMemcpy(L.sinP, sp.data(), r * sizeof(float), hipMemcpyHostToDevice) == hipSuccess &&
              hipMemcpy(L.cosP, cp.data(), r * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
         if (!ok) return bad("table upload failed");
+        {
+            std::vector<float2> tt(c), tp(r);
+            for (int j = 0; j < c; ++j) tt[j] = make_float2(st[j], ct[j]);
+            for (int i = 0; i < r; ++i) tp[i] = make_float2(sp[i], cp[i]);
+            ok = hipMalloc(&L.tabT, c * sizeof(float2)) == hipSuccess && hipMalloc(&L.tabP, r * sizeof(float2)) == hipSuccess &&
+                 hipMemcpy(L.tabT, tt.data(), c * sizeof(float2), hipMemcpyHostToDevice) == hipSuccess &&
+                 hipMemcpy(L.tabP, tp.data(), r * sizeof(float2), hipMemcpyHostToDevice) == hipSuccess;
+            if (!ok) return bad("table upload failed");
+        }
+        // The engine's launches serve P pairs at once, so its large levels are fed from HBM whatever the image size: they carry the
+        // 8-byte {depth, Isrc} source record and k_eval_b re-forms the point (SrcForm<2>: 32 instead of 40 B/px per pass, 32 instead of
+        // 40 B/px written by the set-up).  The latency-bound small levels keep the 16-byte record.  RGBD360_SEQ_RECOMPUTE_MIN_PX moves
+        // the bound (0: every level; a huge value: none).  The rig's pinhole records never take this form (rig_dense.h builds its own).
+        static const int seq_min_px = [] { const char* e = getenv("RGBD360_SEQ_RECOMPUTE_MIN_PX"); return e ? atoi(e) : 256 * 1024; }();
+        L.compact = L.n >= seq_min_px;
         int chunk = (L.n + max_eval_blocks - 1) / max_eval_blocks;
         chunk = ((chunk + kEvalThreads - 1) / kEvalThreads) * kEvalThreads;
         L.chunk = chunk;
@@ -159,18 +176,26 @@ LevelDev seq_level_dev(const SeqLevel& L, int tb) {
     d.half_nRows = L.half_nRows; d.angle_res_inv = L.angle_res_inv;
     d.pi_k = (float)(kPI * (double)L.angle_res_inv);
     d.src = L.srcRec; d.trgP = L.trgP[tb]; d.trgD = L.trgD[tb];
+    d.src2 = reinterpret_cast<const float2*>(L.srcRec); d.tabT = L.tabT; d.tabP = L.tabP;
     return d;
 }
 
 void seq_launch_eval(SeqEngine* E, int level, int method) {
     const SeqLevel& L = E->levels[level];
-    const LevelDev lv = seq_level_dev(L, E->tb);
+    LevelDev lv = seq_level_dev(L, E->tb);
+    lv.min_depth = E->p.min_depth; lv.max_depth = E->p.max_depth;
     const EvalConsts ec = eval_consts(E->p);
     const dim3 g(L.nblocks, E->P), b(kEvalThreadsBatch);
-#define LAUNCHB(M) hipLaunchKernelGGL((k_eval_b<M, true>), g, b, 0, E->stream, E->d_states, lv.src, lv.n, L.chunk, level, L.nblocks, E->d_partials, E->partials_stride, lv, ec)
-    if (method == 0) LAUNCHB(0);
-    else if (method == 1) LAUNCHB(1);
-    else LAUNCHB(2);
+#define LAUNCHB(M, S) hipLaunchKernelGGL((k_eval_b<M, true, S>), g, b, 0, E->stream, E->d_states, lv.src, lv.n, L.chunk, level, L.nblocks, E->d_partials, E->partials_stride, lv, ec)
+    if (L.compact) {
+        if (method == 0) LAUNCHB(0, 2);
+        else if (method == 1) LAUNCHB(1, 2);
+        else LAUNCHB(2, 2);
+    } else {
+        if (method == 0) LAUNCHB(0, 0);
+        else if (method == 1) LAUNCHB(1, 0);
+        else LAUNCHB(2, 0);
+    }
 #undef LAUNCHB
 }
 
@@ -220,6 +245,7 @@ void seq_frame_setup(SeqEngine* E, const FramePtrs& fp, size_t rgb_step, size_t 
         A.src_rec = L.srcRec; A.trg_p = L.trgP[trg_buf]; A.trg_d = L.trgD[trg_buf];
         A.sin_theta = L.sinT; A.cos_theta = L.cosT; A.sin_phi = L.sinP; A.cos_phi = L.cosP;
         A.min_depth = E->p.min_depth; A.max_depth = E->p.max_depth;
+        A.compact_src = L.compact ? 1 : 0;
         A.live_mask = live; A.src_mask = src_mask; A.trg_mask = trg_mask;
         const dim3 g((L.cols + kFsTW - 1) / kFsTW, (L.rows + kFsTH - 1) / kFsTH, E->P);
         if (l == 0) hipLaunchKernelGGL((k_frame_level_b<true>), g, dim3(256), 0, E->stream, A, fp);

@@ -1464,3 +1464,50 @@ def test_occlusion_sequence_with_the_default_inflight_equals_pairwise(hip_lib):
             assert np.array_equal(one.getOptimalPose(), p[j]) and list(one.num_iterations) == list(i[j]), (occ, j)
         one.close()
     reg.close()
+
+
+_RECOMPUTE_CHILD = r"""
+import sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+from rgbd360_amd import synth
+from rgbd360_amd.register import RegisterPhotoICP
+out = {}
+for W, H, n_pyr, depth_f32 in ((256, 128, 3, False), (200, 100, 2, False), (328, 164, 2, True), (1024, 512, 4, False)):
+    (rgbA, dA), (rgbB, dB), T = synth.make_pair(W, H, seed=99, depth_f32=depth_f32)
+    reg = RegisterPhotoICP(); reg.setNumPyr(n_pyr)
+    reg.setTargetFrame(rgbA, dA); reg.setSourceFrame(rgbB, dB)
+    for method in (0, 1, 2):
+        for level in range(n_pyr):
+            e = reg.eval(level, T, method)
+            out["e_%%d_%%d_%%d_%%d" %% (W, H, method, level)] = np.concatenate([e["H64"].ravel(), e["g64"], [e["err2"], e["n_valid"], e["n_visible"]]])
+        rc = reg.alignFrames360(np.eye(4), method)
+        out["p_%%d_%%d_%%d" %% (W, H, method)] = np.concatenate([reg.getOptimalPose().ravel(), [rc], reg.num_iterations])
+        f = reg.forced_iters(0, np.eye(4), method, 6)
+        out["f_%%d_%%d_%%d" %% (W, H, method)] = f["pose"].ravel()
+np.savez(sys.argv[1], **out)
+"""
+
+
+def test_recompute_form_of_the_pass_is_bit_identical_to_the_record_form(hip_lib, tmp_path):
+    """The per-pixel pass reads its source points either as {x, y, z, I} records (16 B per pixel: the reference's LUT_xyz_sphere,
+    precomputed) or re-forms them per pixel from depth + angle tables (8 B per pixel; levels of RGBD360_RECOMPUTE_MIN_PX pixels and
+    more, 4 Mpx by default).  Both forms must give the same float64 sums, counts, poses and iteration counts BIT FOR BIT -- the point
+    is formed by the same float operations in the same order -- at power-of-two and ragged sizes (rows of 200 / 328 pixels start
+    inside a wave), u16 and float depth, every method and level, through the two-launch pass (eval), the fused launch (align, forced)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "child.py"
+    script.write_text(_RECOMPUTE_CHILD % dict(root=root))
+    res = {}
+    for tag, min_px in (("records", str(1 << 30)), ("recompute", "0")):
+        path = tmp_path / (tag + ".npz")
+        env = dict(os.environ, RGBD360_RECOMPUTE_MIN_PX=min_px)
+        p = subprocess.run([sys.executable, str(script), str(path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        assert p.returncode == 0, p.stdout.decode(errors="replace")[-2000:]
+        res[tag] = dict(np.load(path))
+    assert set(res["records"]) == set(res["recompute"]) and len(res["records"]) > 40
+    for k in res["records"]:
+        a, b = res["records"][k], res["recompute"][k]
+        assert np.array_equal(a.view(np.uint64) if a.dtype == np.float64 else a, b.view(np.uint64) if b.dtype == np.float64 else b), k
