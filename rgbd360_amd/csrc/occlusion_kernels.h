@@ -88,9 +88,6 @@ __global__ __launch_bounds__(256) void k_occ_build(LevelDev lv, const GNState* _
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     if (st->done || st->level_active != level) return;
-    R360_ATAB_DECL(s_atab);                           // quadrant-angle table of the warp front end (photo_icp_kernels.h; table build only)
-    R360_ATAB_STAGE(s_atab);
-    R360_ATAB_SYNC();
     const bool in = i < lv.n;                          // (no early exit: every lane takes part in the shuffles)
     const int ic = in ? i : lv.n - 1;
     const PoseRT T = load_pose(st->cand);
@@ -98,7 +95,7 @@ __global__ __launch_bounds__(256) void k_occ_build(LevelDev lv, const GNState* _
     const float4 s = lv.src[ic];
     float X, Y, Z, rho2, d2;
     bool vis;
-    const unsigned ti = warp_pixel(T, wc, s_atab, s.x, s.y, s.z, lv, X, Y, Z, rho2, d2, vis);
+    const unsigned ti = warp_pixel(T, wc, s.x, s.y, s.z, lv, X, Y, Z, rho2, d2, vis);
     bool cand = in && vis && (s.x != kInvalidPoint);
     const float dist = sqrt_rn(d2);
     if (OCC == 2 && cand) {
@@ -135,9 +132,6 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_occ(LevelDev lv, EvalCons
     const int base = b * chunk;
     const int end = min(base + chunk, lv.n);
     if (st->done || st->level_active != level) return;
-    R360_ATAB_DECL(s_atab);                           // quadrant-angle table of the warp front end (table build only)
-    R360_ATAB_STAGE(s_atab);
-    R360_ATAB_SYNC();
     const PoseRT T = load_pose(st->cand);
     const WarpConsts wc = make_warp_consts(T, lv);
 
@@ -155,7 +149,7 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_occ(LevelDev lv, EvalCons
         const float4 s = lv.src[ic];
         float X, Y, Z, rho2, d2;
         bool vis;
-        unsigned ti = warp_pixel(T, wc, s_atab, s.x, s.y, s.z, lv, X, Y, Z, rho2, d2, vis);
+        unsigned ti = warp_pixel(T, wc, s.x, s.y, s.z, lv, X, Y, Z, rho2, d2, vis);
         const unsigned info = in_range ? (unsigned)runinfo[ic] : 0u;         // k_occ_build's run record at this pose
         const int4 own = nodes[ic];                                          // this pixel's node if it ends a run (speculative)
         const bool cand = (info & 0x40u) != 0;

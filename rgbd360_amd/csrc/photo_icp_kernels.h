@@ -131,39 +131,31 @@ __device__ __forceinline__ int round_index(float x) {
     return r;
 }
 
-// Quadrant angle by table (round 4; rounds 1-3: min / max ratio, a 9-coefficient odd polynomial for atan on [0, 1] and the swap
-// reflection pi/2 - a: 16 vector instructions per angle, 8.5 now).  For a direction (x, y) with x, y >= 0 the "diamond" ratio
-// d = y / (x + y) in [0, 1] grows monotonically with the angle, so T(d) = atan(d / (1 - d)) covers the whole quadrant with no case
-// split.  T is tabulated on kAtanN = 256 intervals as the quadratic through its values at the interval's ends and middle
-// (tools/gen_atan_table.py: float64 libm, rounded to float32; error of the interpolation <= 7.6e-9 rad, i.e. the result is good to
-// float32 rounding like the polynomial was); the table sits in LDS (4 KB per workgroup, staged by atan_tab_stage), one ds_read_b128
-// per angle.  u = d * N arrives from the caller (both angles of a pixel share one correctly rounded reciprocal, and N is folded into
-// it).  Every step is an IEEE-754 basic operation on table constants that the CPU checker computes by the same formula
-// (oracle/photo_icp_ref.cpp, math_mode 1; tests compare the tables bit for bit): indices stay bit-identical CPU <-> GPU.
-constexpr int kAtanN = 256;
-#ifdef RGBD360_ATAN_TABLE
-__device__ const float4 g_atan_tab[kAtanN + 1] = {
-#include "atan_table.inc"
-};
-// every workgroup that warps pixels stages the table once (the caller puts a barrier behind it)
-__device__ __forceinline__ void atan_tab_stage(float4* __restrict__ lds_tab) {
-    for (int k = (int)threadIdx.x; k <= kAtanN; k += (int)blockDim.x) lds_tab[k] = g_atan_tab[k];
+// atan(t) for t in [0, 1(+ulps)]: odd minimax polynomial, 9 coefficients, relative error 1.3e-8.
+// (Round 4, measured and dropped: the quadrant angle T(|y| / (|y| + |x|)) from a 256-interval quadratic table in LDS instead of min / max
+// ratio + polynomial + reflection -- 8.5 instead of 16 vector instructions per angle, 116 instead of 144 per pixel in all -- changed the
+// launch time by nothing at any size, tools/ab_libs.py: the pass is not bound by vector issue)
+__device__ __forceinline__ float atan_unit(float t) {
+    const float q0 = -0.3333333195069166f, q1 = 0.19999765993465415f, q2 = -0.14279110844310372f,
+                q3 = 0.11037993832882714f, q4 = -0.08673169371217875f, q5 = 0.06284358078457526f,
+                q6 = -0.03627014369584507f, q7 = 0.01375026672953864f, q8 = -0.00244702708829393f;
+    const float s = t * t;
+    float p = fmaf(s, q8, q7);
+    p = fmaf(s, p, q6);
+    p = fmaf(s, p, q5);
+    p = fmaf(s, p, q4);
+    p = fmaf(s, p, q3);
+    p = fmaf(s, p, q2);
+    p = fmaf(s, p, q1);
+    p = fmaf(s, p, q0);
+    return fmaf(t * s, p, t);
 }
-#endif
-#ifdef RGBD360_ATAN_TABLE
-#define R360_ATAB_DECL(name) __shared__ float4 name[kAtanN + 1]
-#define R360_ATAB_STAGE(name) atan_tab_stage(name)
-#define R360_ATAB_SYNC() __syncthreads()
-#else
-#define R360_ATAB_DECL(name) const float4* const name = nullptr
-#define R360_ATAB_STAGE(name)
-#define R360_ATAB_SYNC()
-#endif
-__device__ __forceinline__ float atan_diamond(const float4* __restrict__ lds_tab, float u) {
-    const int i = (int)u;                               // u >= 0: truncation = floor (v_cvt_i32_f32; NaN -> 0, like the checker)
-    const float f = __builtin_amdgcn_fractf(u);         // u - floor(u), exact
-    const float4 c = lds_tab[i];
-    return fmaf(f, fmaf(f, c.z, c.y), c.x);
+// atan2(y, x) from t = min(|y|,|x|) / max(|y|,|x|) supplied by the caller (both angles share one reciprocal).
+__device__ __forceinline__ float atan2_from_t(float y, float x, float ay, float ax, float t) {
+    float a = atan_unit(t);
+    if (ay > ax) a = 1.57079637f - a;
+    if (__builtin_signbit(x)) a = 3.14159274f - a;
+    return copysignf(a, y);
 }
 
 struct PoseRT {
@@ -180,11 +172,10 @@ __device__ __forceinline__ PoseRT load_pose(const float* P) {   // column-major 
 
 // Shared front end of RPI.h:2663-2684 / 2959-2989.  Returns the target pixel index (valid only when `vis`).
 // Device arithmetic definition (the oracle's math_mode 1 repeats it operation for operation):
-//   p' = R p + t with fused multiply-adds;  rho^2 = Y^2 + Z^2,  d^2 = X^2 + rho^2,  rho = correctly rounded sqrt
-//   phi   = atan2(X, rho)  (= asin(X/d) of the reference, RPI.h:2676):  sign(X) T(|X| / (|X| + rho))
-//   theta = atan2(Y, Z):  a = T(|Y| / (|Y| + |Z|)),  Z < 0: pi - a,  sign(Y);  column = round(theta * k + PI*k)   (RPI.h:2677-2680
-//           with the +PI folded into the scaling)
-//   both ratios come from ONE correctly rounded reciprocal r = 1 / ((|X| + rho) (|Y| + |Z|)), T from the table above
+//   p' = R p + t with fused multiply-adds;  rho^2 = Y^2 + Z^2,  d^2 = X^2 + rho^2
+//   phi   = atan2(X, rho)      (= asin(X/d) of the reference, RPI.h:2676)      rho = correctly rounded sqrt
+//   theta = atan2(Y, Z);  column = round(theta * k + PI*k)   (RPI.h:2677-2680 with the +PI folded into the scaling)
+//   both quotients min/max come from ONE correctly rounded reciprocal r = 1 / (mx_phi * mx_theta)
 // Every step is an IEEE-754 basic operation, so x86 and gfx950 agree bit for bit on the pixel index.
 struct WarpConsts {        // per-lane copies (VGPRs) of the wave-uniform addends: a VOP3 fma reads one scalar only
     float tx, ty, tz, half_nRows, pi_k;
@@ -194,7 +185,7 @@ __device__ __forceinline__ WarpConsts make_warp_consts(const PoseRT& T, const Le
     asm volatile("" : "+v"(c.tx), "+v"(c.ty), "+v"(c.tz), "+v"(c.half_nRows), "+v"(c.pi_k));
     return c;
 }
-__device__ __forceinline__ void warp_pixel_rc(const PoseRT& T, const WarpConsts& wc, const float4* __restrict__ atab, float px, float py, float pz,
+__device__ __forceinline__ void warp_pixel_rc(const PoseRT& T, const WarpConsts& wc, float px, float py, float pz,
                                               const LevelDev& lv, float& X, float& Y, float& Z, float& rho2, float& d2,
                                               int& tr, int& tc, unsigned long long& vis_mask, float& inv_rho) {
     X = fmaf(T.r02, pz, fmaf(T.r01, py, fmaf(T.r00, px, wc.tx)));
@@ -203,58 +194,29 @@ __device__ __forceinline__ void warp_pixel_rc(const PoseRT& T, const WarpConsts&
     rho2 = fmaf(Z, Z, Y * Y);
     d2 = fmaf(X, X, rho2);
     const float rho = sqrt_rn(rho2, inv_rho);       // inv_rho: float32 DATA for the Jacobian (consume_stage), not index work
-    const float ax = fabsf(X), ay = fabsf(Y);
-#ifndef RGBD360_ATAN_TABLE       // the product's angle arithmetic (the checker's math_mode 1 mirrors it); -DRGBD360_ATAN_TABLE: the experimental table form below
-    {
-        const float az = fabsf(Z);
-        const float mxp = fmaxf(fmaxf(ax, rho), 1e-9f), mnp = __builtin_amdgcn_fmed3f(ax, rho, 0.f);
-        const float mxt = fmaxf(fmaxf(ay, az), 1e-9f), mnt = fminf(ay, az);
-        const float r = rcp_rn(mxp * mxt);
-        auto atan_unit = [](float t) {
-            const float q0 = -0.3333333195069166f, q1 = 0.19999765993465415f, q2 = -0.14279110844310372f, q3 = 0.11037993832882714f,
-                        q4 = -0.08673169371217875f, q5 = 0.06284358078457526f, q6 = -0.03627014369584507f, q7 = 0.01375026672953864f,
-                        q8 = -0.00244702708829393f;
-            const float s2 = t * t;
-            float p = fmaf(s2, q8, q7);
-            p = fmaf(s2, p, q6); p = fmaf(s2, p, q5); p = fmaf(s2, p, q4); p = fmaf(s2, p, q3);
-            p = fmaf(s2, p, q2); p = fmaf(s2, p, q1); p = fmaf(s2, p, q0);
-            return fmaf(t * s2, p, t);
-        };
-        float phi_trg = atan_unit(mnp * (r * mxt));
-        if (ax > rho) phi_trg = 1.57079637f - phi_trg;
-        phi_trg = copysignf(phi_trg, X);
-        float a = atan_unit(mnt * (r * mxp));
-        if (ay > az) a = 1.57079637f - a;
-        if (__builtin_signbit(Z)) a = 3.14159274f - a;
-        const float theta_p = copysignf(a, Y);
-        tr = round_index(fmaf(phi_trg, -lv.angle_res_inv, wc.half_nRows));
-        tc = round_index(fmaf(theta_p, lv.angle_res_inv, wc.pi_k));
-        vis_mask = __builtin_amdgcn_ballot_w64((unsigned)tr < (unsigned)lv.rows) & __builtin_amdgcn_ballot_w64((unsigned)tc < (unsigned)lv.cols);
-        return;
-    }
-#endif
-    const float sp = ax + rho;                      // 0 only for p' = 0 (never a valid point: NaN angles, index 0, harmless)
-    const float st = fmaxf(ay + fabsf(Z), 1e-9f);   // the clamp matters on the polar axis (Y = Z = 0: theta = 0, phi = +-pi/2)
-    const float rN = rcp_rn(sp * st) * (float)kAtanN;
-    const float up = ax * (st * rN);                // N |X| / (|X| + rho)
-    const float ut = ay * (sp * rN);                // N |Y| / (|Y| + |Z|)
-    const float phi_trg = copysignf(atan_diamond(atab, up), X);
-    float theta = atan_diamond(atab, ut);
-    if (__builtin_signbit(Z)) theta = 3.14159274f - theta;
-    theta = copysignf(theta, Y);
+    const float ax = fabsf(X), ay = fabsf(Y), az = fabsf(Z);
+    const float mxp = fmaxf(fmaxf(ax, rho), 1e-9f), mnp = __builtin_amdgcn_fmed3f(ax, rho, 0.f);   // min of two non-negatives
+    const float mxt = fmaxf(fmaxf(ay, az), 1e-9f), mnt = fminf(ay, az);
+    const float r = rcp_rn(mxp * mxt);
+    const float tp = mnp * (r * mxt);
+    const float tt = mnt * (r * mxp);
+    float phi_trg = atan_unit(tp);
+    if (ax > rho) phi_trg = 1.57079637f - phi_trg;
+    phi_trg = copysignf(phi_trg, X);
+    const float theta = atan2_from_t(Y, Z, ay, az, tt);
     tr = round_index(fmaf(phi_trg, -lv.angle_res_inv, wc.half_nRows));
     tc = round_index(fmaf(theta, lv.angle_res_inv, wc.pi_k));
     // predicates of the per-pixel pass are kept as 64-bit lane masks (the compares' own SGPR results, combined on the scalar unit): the
     // ballot of a COMBINED bool costs a v_cndmask + v_cmp pair per use with this compiler
     vis_mask = __builtin_amdgcn_ballot_w64((unsigned)tr < (unsigned)lv.rows) & __builtin_amdgcn_ballot_w64((unsigned)tc < (unsigned)lv.cols);
 }
-__device__ __forceinline__ unsigned warp_pixel(const PoseRT& T, const WarpConsts& wc, const float4* __restrict__ atab, float px, float py, float pz,
+__device__ __forceinline__ unsigned warp_pixel(const PoseRT& T, const WarpConsts& wc, float px, float py, float pz,
                                                const LevelDev& lv, float& X, float& Y, float& Z, float& rho2, float& d2,
                                                bool& vis) {
     int tr, tc;
     float inv_rho;
     unsigned long long vis_mask;
-    warp_pixel_rc(T, wc, atab, px, py, pz, lv, X, Y, Z, rho2, d2, tr, tc, vis_mask, inv_rho);
+    warp_pixel_rc(T, wc, px, py, pz, lv, X, Y, Z, rho2, d2, tr, tc, vis_mask, inv_rho);
     vis = __builtin_amdgcn_inverse_ballot_w64(vis_mask);
     return __umul24(tr, lv.cols) + (unsigned)tc;
 }
@@ -368,7 +330,6 @@ __device__ __forceinline__ F3 buf_load_f3(__amdgpu_buffer_rsrc_t r, unsigned byt
 struct EvalBufs {
     __amdgpu_buffer_rsrc_t src, trgP, trgD;
     unsigned row_bytes;      // cols * 12
-    const float4* atab;      // the quadrant-angle table in LDS (atan_tab_stage)
 };
 
 // Source records of one step of a span: the descriptor is rebased on the step's first pixel (wave-uniform: scalar arithmetic), so the
@@ -514,7 +475,7 @@ __device__ __forceinline__ void warp_stage(const typename SrcForm<SRC>::T sraw, 
                                            const LevelDev& lv, const EvalBufs& bufs, PixW& w) {
     const float4 s = SrcForm<SRC>::value(sraw, lv);
     int tr, tc;
-    warp_pixel_rc(T, wc, bufs.atab, s.x, s.y, s.z, lv, w.X, w.Y, w.Z, w.rho2, w.d2, tr, tc, w.vis, w.inv_rho);
+    warp_pixel_rc(T, wc, s.x, s.y, s.z, lv, w.X, w.Y, w.Z, w.rho2, w.d2, tr, tc, w.vis, w.inv_rho);
     w.vis &= __builtin_amdgcn_ballot_w64(s.x != kInvalidPoint);
     if (CHECK) w.vis &= __builtin_amdgcn_ballot_w64(in_range);
     w.isrc = s.w;
@@ -524,14 +485,7 @@ __device__ __forceinline__ void warp_stage(const typename SrcForm<SRC>::T sraw, 
     // unconditional gathers, issued as soon as the index is known; an invisible pixel's offset is arbitrary but
     // range-checked by the buffer descriptor
     const unsigned off = __umul24(tr, bufs.row_bytes) + __umul24(tc, 12u);      // byte offset of the 12-byte target record
-#ifdef RGBD360_EXP_GATHER4      // bandwidth-sensitivity experiment (tools/ab_libs.py): 4 instead of 12 bytes per gather, made-up gradients
-    if (METHOD != 1) {
-        const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bufs.trgP, (int)off, 0, 0));
-        w.tp.a = v; w.tp.b = v * 0.37f; w.tp.c = v * -0.21f;
-    }
-#else
     if (METHOD != 1) w.tp = buf_load_f3(bufs.trgP, off);
-#endif
     if (METHOD != 0) w.td = buf_load_f3(bufs.trgD, off);
 }
 
@@ -770,8 +724,6 @@ __device__ __forceinline__ void eval_block(const GNState* __restrict__ st, const
     bufs.trgP = make_rsrc(lv.trgP, (unsigned)lv.n * 12u);
     bufs.trgD = make_rsrc(lv.trgD, (unsigned)lv.n * 12u);
     bufs.row_bytes = (unsigned)lv.cols * 12u;
-    R360_ATAB_DECL(s_atab);
-    bufs.atab = s_atab;
     const int i = base + (int)threadIdx.x;
     // the first two source records do not depend on the state: issue them before the scalar loads of done / pose
     static_assert(THREADS == 1024 || THREADS == 512, "eval_block: 1024-lane layout, played by 1024 or 512 threads");
@@ -779,7 +731,6 @@ __device__ __forceinline__ void eval_block(const GNState* __restrict__ st, const
     SrcForm<SRC>::cursor_init(cur, lv, i, THREADS);
     const typename SrcForm<SRC>::T sA = SrcForm<SRC>::load(lv, src0, n_px, base, (unsigned)threadIdx.x << 4, cur);
     const typename SrcForm<SRC>::T sB = SrcForm<SRC>::load(lv, src0, n_px, base + THREADS, (unsigned)threadIdx.x << 4, cur);
-    R360_ATAB_STAGE(s_atab);                         // (its loads travel with the record loads; the barrier stands below)
     // gate and pose are fetched in ONE batch of scalar loads, in parallel with the two record loads above.  The gate is
     // only TESTED after the first warp stage: an early-exit branch up here makes the compiler sink every load behind it
     // (one dependent memory round trip per sunk batch, ~1 us each); the asm statement that ends warp_stage cannot be moved
@@ -788,7 +739,6 @@ __device__ __forceinline__ void eval_block(const GNState* __restrict__ st, const
     const PoseRT T = load_pose(st->cand);
     const WarpConsts wc = make_warp_consts(T, lv);
     ESTAMP(0);
-    R360_ATAB_SYNC();                                // the angle table is in LDS
     PixW wA;
     warp_stage<METHOD, true, SRC>(sA, i < end, T, wc, lv, bufs, wA);
     asm volatile("" ::: "memory");                   // the loads issued so far stay above the gate
@@ -1392,7 +1342,11 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve_b(GNState* states, cons
 // load sat behind its own test).  Returns pend_nb; a barrier behind the LDS writes.
 constexpr int kPendingRows = 256;                 // rows loaded per launch = the grid cap of the single-pair pass
 constexpr int kMaxPendingRows = kPendingRows;     // the fused schedule needs every level's block count <= this
-__device__ __forceinline__ int stage_pending(SolveShared& sh, const GNState* __restrict__ st_in, const double* __restrict__ partials) {
+// rows_hint (a kernel argument: in an SGPR when the launch starts) = an upper bound of the pending row count the HOST knows when it
+// enqueues the launch -- the block count of the launch in front of it.  The launches of the small pyramid levels leave 8 - 64 rows:
+// with the bound they request one batch of 32 rows (8 KB per workgroup) instead of all 256 (64 KB through one CU's 64 B / clock L1 fill
+// path: 0.5 us of the prologue of a launch that has 1 us of pixel work).  Rows beyond pend_nb add nothing either way: same sums.
+__device__ __forceinline__ int stage_pending(SolveShared& sh, const GNState* __restrict__ st_in, const double* __restrict__ partials, const int rows_hint) {
     constexpr int kStateWords = sizeof(GNState) / 4;
     constexpr int Q = kSolveThreads / kNumPartials;
     constexpr int J = kPendingRows / Q;
@@ -1400,8 +1354,14 @@ __device__ __forceinline__ int stage_pending(SolveShared& sh, const GNState* __r
     const int tid = threadIdx.x;
     const int v = tid % kNumPartials, q = tid / kNumPartials;
     double tmp[J];
+    if (rows_hint <= Q) {                       // uniform (scalar compare on a preloaded argument): two straight-line variants
+        tmp[0] = partials[(size_t)q * kNumPartials + v];
 #pragma unroll
-    for (int j = 0; j < J; ++j) tmp[j] = partials[(size_t)(q + j * Q) * kNumPartials + v];
+        for (int j = 1; j < J; ++j) tmp[j] = 0.0;
+    } else {
+#pragma unroll
+        for (int j = 0; j < J; ++j) tmp[j] = partials[(size_t)(q + j * Q) * kNumPartials + v];
+    }
     int word = 0;
     if (tid < kStateWords) word = reinterpret_cast<const int*>(st_in)[tid];
     const int nb = st_in->pend_nb;        // uniform (scalar load)
@@ -1432,7 +1392,7 @@ template <int METHOD, int SRC = 0>
 __global__ __launch_bounds__(kEvalThreads) void k_eval_fs(const GNState* __restrict__ st_in, GNState* __restrict__ st_out,
                                                            const double* __restrict__ partials_in, double* __restrict__ partials_out,
                                                            const float4* __restrict__ src0, int n_px, int chunk, int level, int nb_arg,
-                                                           LevelDev lv, EvalConsts ec, SolveCfg cfg, FsInit init) {
+                                                           int pend_rows_hint, LevelDev lv, EvalConsts ec, SolveCfg cfg, FsInit init) {
     static_assert(kEvalThreads == kSolveThreads, "the fused launch runs the solve on the pass's block");
     unsigned long long es[6] = {0, 0, 0, 0, 0, 0};
 #ifdef RGBD360_EVAL_STAMPS
@@ -1441,15 +1401,12 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_fs(const GNState* __restr
     const unsigned long long es0 = 0;
 #endif
     __shared__ SolveShared sh;
-    R360_ATAB_DECL(s_atab);
     constexpr int kStateWords = sizeof(GNState) / 4;
 #ifdef RGBD360_SOLVE_STAMPS
     if (threadIdx.x == 0) sh.stamp0 = __builtin_amdgcn_s_memrealtime();
 #endif
     // what the solve waits for is requested first (a wave's vector-memory operations complete in issue order) ...
-    // (the angle table of the pixel pass rides along: its barrier is stage_pending's)
-    R360_ATAB_STAGE(s_atab);
-    int pend = stage_pending(sh, st_in, partials_in);
+    int pend = stage_pending(sh, st_in, partials_in, pend_rows_hint);
     if (init.on) {                              // uniform: the first launch of a schedule is its k_level_init too (every block initialises
         if (threadIdx.x == 0) level_init_one(&sh.sst, init.pose, 1, 1, level);      // its own LDS copy of the state, block 0 writes it out)
         __syncthreads();
@@ -1466,7 +1423,6 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_fs(const GNState* __restr
     bufs.trgP = make_rsrc(lv.trgP, (unsigned)lv.n * 12u);
     bufs.trgD = make_rsrc(lv.trgD, (unsigned)lv.n * 12u);
     bufs.row_bytes = (unsigned)lv.cols * 12u;
-    bufs.atab = s_atab;
     const int i = base + (int)threadIdx.x;
     // ... the first two source records of the span, which depend on nothing, right behind it: in flight during the solve
     SrcCursor cur = {0, 0, 0, 0};
@@ -1552,12 +1508,12 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_fs(const GNState* __restr
 
 // The tail of a fused-solve schedule: the solve of the last pass enqueued (if one is pending), in place, one block; publishes
 // like k_solve.
-__global__ __launch_bounds__(kSolveThreads) void k_solve_pending(GNState* st_g, const double* __restrict__ partials,
+__global__ __launch_bounds__(kSolveThreads) void k_solve_pending(GNState* st_g, const double* __restrict__ partials, int pend_rows_hint,
                                                                   SolveCfg cfg) {
     __shared__ SolveShared sh;
     constexpr int kStateWords = sizeof(GNState) / 4;
     const int tid = threadIdx.x;
-    const int pend = stage_pending(sh, st_g, partials);
+    const int pend = stage_pending(sh, st_g, partials, pend_rows_hint);
     if (pend > 0) {
         SolveCfg c = cfg;
         c.level = sh.sst.level_active;
@@ -1587,9 +1543,6 @@ __global__ void k_gn_step(GnIO* io) {
 
 // Warp indices of every source pixel (parity diagnostics).
 __global__ void k_warp_indices(LevelDev lv, Pose16 pose, int32_t* __restrict__ out) {
-    R360_ATAB_DECL(s_atab);
-    R360_ATAB_STAGE(s_atab);
-    R360_ATAB_SYNC();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= lv.n) return;
     const PoseRT T = load_pose(pose.v);
@@ -1599,7 +1552,7 @@ __global__ void k_warp_indices(LevelDev lv, Pose16 pose, int32_t* __restrict__ o
         float X, Y, Z, rho2, d2;
         bool vis;
         const WarpConsts wc = {T.tx, T.ty, T.tz, lv.half_nRows, lv.pi_k};
-        const unsigned ti = warp_pixel(T, wc, s_atab, s.x, s.y, s.z, lv, X, Y, Z, rho2, d2, vis);
+        const unsigned ti = warp_pixel(T, wc, s.x, s.y, s.z, lv, X, Y, Z, rho2, d2, vis);
         vis = vis && s.x != kInvalidPoint;
         if (vis) {
             r = (int)(ti / (unsigned)lv.cols);

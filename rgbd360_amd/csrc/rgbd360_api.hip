@@ -59,6 +59,7 @@ struct rgbd360_ctx {
     GNState* d_state_alt = nullptr;   // ... except the fused pass (k_eval_fs), which reads d_state, writes d_state_alt, after which the two swap
     GNState* h_state = nullptr;   // pinned
     hostwait::SpinTag tag;        // pinned sequence number the stream's last kernel stores (host_wait.h)
+    int pend_rows_hint = r360::kPendingRows;      // upper bound of the partial rows the next fused launch finds pending (stage_pending)
     double* d_partials = nullptr;     // partial rows of the last pass enqueued (current) ...
     double* d_partials_alt = nullptr; // ... and where a fused pass puts its rows while its blocks still read the previous table
     int max_blocks = 0;               // rows of a partial table = blocks of the largest level
@@ -388,7 +389,7 @@ void launch_eval_fused(rgbd360_ctx* ctx, int level, int method, int forced, cons
     const SolveCfg cfg = fused_cfg(ctx, forced);
     dim3 g(L.nblocks), b(kEvalThreads);
 #define LAUNCHF(M, S) hipLaunchKernelGGL((k_eval_fs<M, S>), g, b, 0, ctx->stream, (const GNState*)ctx->d_state, ctx->d_state_alt, (const double*)ctx->d_partials, \
-                                      ctx->d_partials_alt, lv.src, lv.n, L.chunk, level, L.nblocks, lv, ec, cfg, init)
+                                      ctx->d_partials_alt, lv.src, lv.n, L.chunk, level, L.nblocks, ctx->pend_rows_hint, lv, ec, cfg, init)
     if (L.n >= recompute_min_px()) {
         if (method == 0) LAUNCHF(0, 1);
         else if (method == 1) LAUNCHF(1, 1);
@@ -399,6 +400,7 @@ void launch_eval_fused(rgbd360_ctx* ctx, int level, int method, int forced, cons
         else LAUNCHF(2, 0);
     }
 #undef LAUNCHF
+    ctx->pend_rows_hint = L.nblocks;             // what this launch can leave pending bounds what the next one has to load
     std::swap(ctx->d_state, ctx->d_state_alt);
     std::swap(ctx->d_partials, ctx->d_partials_alt);
 }
@@ -410,7 +412,7 @@ void launch_solve_pending(rgbd360_ctx* ctx, int forced, bool publish) {
         cfg.host_tag = ctx->tag.h;
         cfg.host_seq = ++ctx->tag.seq;
     }
-    hipLaunchKernelGGL(k_solve_pending, dim3(1), dim3(kSolveThreads), 0, ctx->stream, ctx->d_state, (const double*)ctx->d_partials, cfg);
+    hipLaunchKernelGGL(k_solve_pending, dim3(1), dim3(kSolveThreads), 0, ctx->stream, ctx->d_state, (const double*)ctx->d_partials, ctx->pend_rows_hint, cfg);
 }
 
 void launch_level_init(rgbd360_ctx* ctx, int level, const float* pose, int reset_all) {
@@ -418,6 +420,7 @@ void launch_level_init(rgbd360_ctx* ctx, int level, const float* pose, int reset
     if (pose) memcpy(P.v, pose, sizeof(P.v));
     else memset(P.v, 0, sizeof(P.v));
     hipLaunchKernelGGL(k_level_init, dim3(1), dim3(64), 0, ctx->stream, ctx->d_state, P, pose ? 1 : 0, reset_all, level);
+    ctx->pend_rows_hint = kPendingRows;
 }
 
 // the device state into ctx->h_state with memcpy + stream synchronise: for callers that read HIP events afterwards (an event the
@@ -1199,6 +1202,7 @@ int rgbd360_debug_solve_partials(rgbd360_ctx* ctx, int level, const double row[3
     if (fused) {
         const int pend[2] = {L.nblocks, L.n};       // as if a pass of this level had just written the table
         HIPC(ctx, hipMemcpyAsync(&ctx->d_state->pend_nb, pend, sizeof(pend), hipMemcpyHostToDevice, ctx->stream));
+        ctx->pend_rows_hint = kPendingRows;      // a hand-made pending pass: no bound known
         launch_eval_fused(ctx, level, method, 0);      // the state is read as this launch leaves it: its own pass (if it ran one) stays pending
     } else {
         launch_solve(ctx, level, 0, 0);

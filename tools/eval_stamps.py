@@ -39,6 +39,10 @@ def report(tag, r):
     L.rgbd360_debug_eval_stamps(r._ctx(), 0, st.ctypes.data_as(C.c_void_p))
     print("%s: blocks start %.2f..%.2f us after the first, run %.2f (min) %.2f (median) %.2f (max) us, last end %.2f us" % (
         tag, 0.0, (se[:, 0] - t0).max(), (se[:, 1] - se[:, 0]).min(), np.median(se[:, 1] - se[:, 0]), (se[:, 1] - se[:, 0]).max(), (se[:, 1] - t0).max()))
+    run = se[:, 1] - se[:, 0]
+    print("   block run time us: mean %.2f  p10 %.2f  p50 %.2f  p90 %.2f  max %.2f | by position (32 blocks each): %s" % (
+        run.mean(), np.percentile(run, 10), np.percentile(run, 50), np.percentile(run, 90), run.max(),
+        " ".join("%.1f" % run[k:k + 32].mean() for k in range(0, nb, 32))))
     for name, row in (("block 0", st[:6]), ("block nb-1", st[6:])):
         print("   %s: pose %.2f | first stage %.2f | loop %.2f | wave reduce %.2f | end %.2f us" % ((name,) + tuple(row[:5] / 100.0)))
 
