@@ -35,12 +35,21 @@ struct SegmentParams {
     bool refine = true;                // the reference calls segmentAndRefine (Frame360.h:977): planes grow into their noisy borders
     float refine_distance = 0.02f;     // PlaneRefinementComparator's default threshold (not depth dependent)
 };
-inline std::vector<rgbd360_plane> segmentPlanes(RegisterPhotoICP& reg, const ImageView& depth, const SegmentParams& sp = SegmentParams()) {
+// rgb (optional): the frame's colour panorama (8UC3, same size as depth) -- the planes then carry the colour descriptors of
+// Frame360.h:1045-1046 (calcPlaneHistH / calcMainColor2), which RegisterPbMap's unary colour constraint reads.
+inline std::vector<rgbd360_plane> segmentPlanes(RegisterPhotoICP& reg, const ImageView& depth, const SegmentParams& sp = SegmentParams(),
+                                                const ImageView* rgb = nullptr) {
     std::vector<rgbd360_plane> planes;
     int n = 0, cap = sp.max_planes;
     const int dt = depth.type == ImageView::U16C1 ? 0 : 1;
     rgbd360_ctx* ctx = reg.context();
     rgbd360_set_plane_refinement(ctx, sp.refine ? 1 : 0, sp.refine_distance);
+    if (rgb && rgb->data && rgb->type == ImageView::U8C3 && rgb->rows == depth.rows && rgb->cols == depth.cols) {
+        if (rgbd360_set_plane_color_image(ctx, (const uint8_t*)rgb->data, rgb->step, rgb->rows, rgb->cols, 1, 0) != 0)
+            throw std::runtime_error(std::string("rgbd360_set_plane_color_image: ") + rgbd360_last_error(ctx));
+    } else {
+        rgbd360_set_plane_color_image(ctx, nullptr, 0, 0, 0, 1, 0);
+    }
     for (int attempt = 0; attempt < 2; ++attempt) {      // the library keeps the largest `cap` regions and reports how many qualified: grow once
         planes.resize((size_t)cap);
         const int rc = rgbd360_frame_planes(ctx, depth.data, depth.step, dt, depth.rows, depth.cols, sp.convention, sp.max_depth_change_factor,
@@ -318,8 +327,9 @@ bool RegisterFrames(FrameLike& ref, FrameLike& cur, Mat4f& pose, ToView to_view,
                     RegisterRGBD360::registrationType registMode = RegisterRGBD360::ODOMETRY_6DoF, size_t max_match_planes = 25,
                     const SegmentParams& seg = SegmentParams(),
                     RegisterPhotoICP::costFuncType method = RegisterPhotoICP::PHOTO_DEPTH) {
-    const std::vector<rgbd360_plane> pr = segmentPlanes(dense, to_view(ref.sphereDepth), seg);
-    const std::vector<rgbd360_plane> pc = segmentPlanes(dense, to_view(cur.sphereDepth), seg);
+    const ImageView rgb_r = to_view(ref.sphereRGB), rgb_c = to_view(cur.sphereRGB);
+    const std::vector<rgbd360_plane> pr = segmentPlanes(dense, to_view(ref.sphereDepth), seg, &rgb_r);
+    const std::vector<rgbd360_plane> pc = segmentPlanes(dense, to_view(cur.sphereDepth), seg, &rgb_c);
     PlaneList lr{pr.data(), (int)pr.size()}, lc{pc.data(), (int)pc.size()};
     const bool planes_ok = registerer.RegisterPbMap(&lr, &lc, max_match_planes, registMode);
     const Mat4f guess = planes_ok ? registerer.getPose() : pose;

@@ -303,7 +303,30 @@ typedef struct {
     float area_moment;
     float center_hull[3];
     int   hull_points;
+    /* Colour descriptors -- the roles of mrpt::pbmap::Plane::v3colorNrgb / dominantIntensity (calcMainColor2) and hist_H
+     * (calcPlaneHistH), which Frame360.h:1045-1046 / Frame360_stereo.h:949-950 fill for every plane and the PbMap matcher's unary
+     * colour constraint reads (configLocaliser_spherical.ini:19-21).  Filled when a colour image is registered for the plane call
+     * (rgbd360_set_plane_color_image); color_count = 0 otherwise, and the matcher then skips its colour tests.
+     *   color_nrgb   mean of the normalised colour (R, G, B) / (R + G + B) over the inliers with R + G + B > 0 (invariant to a global
+     *                brightness change), color_dev its standard deviation per channel.  MRPT's calcMainColor2 takes the mean-shift
+     *                mode of these values; the mean is what its calcMainColor takes, and the two coincide for a region of one colour.
+     *   intensity    mean R + G + B (0..765) of the same pixels.
+     *   hist_h       normalised histogram over ALL inliers: 72 bins of 5 degrees of hue for saturated pixels, [72] dark pixels
+     *                (V <= 0.2), [73] unsaturated ones (S <= 0.2). */
+    int   color_count;
+    float color_nrgb[3];
+    float color_dev[3];
+    float intensity;
+    float hist_h[74];
 } rgbd360_plane;
+
+/* Registers the colour image that goes with the organised cloud of the context's next plane calls (rgbd360_plane_fit,
+ * _frame_planes[_dev], _cloud_planes, _sensor_planes): rgb is rows x cols x 3 uint8 with rgb_step bytes per row, and cloud pixel
+ * (r, c) takes the colour of image pixel (r * step + step / 2, c * step + step / 2) -- step 1 for a panorama or a full-resolution
+ * sensor cloud, the down-sampling step for a down-sampled one (DownsampleRGBD.h:240, 285-287: the colour of the block's centre
+ * pixel).  on_device = 0: rgb is host memory and is copied at once; 1: device memory that must stay valid through those calls.
+ * The planes of a call whose cloud does not have (rows / step) x (cols / step) points come back without colour.  rgb = NULL clears. */
+int rgbd360_set_plane_color_image(rgbd360_ctx* ctx, const uint8_t* rgb, size_t rgb_step, int rows, int cols, int step, int on_device);
 
 /* Planar regions of an organised cloud with normals: pcl::OrganizedMultiPlaneSegmentation::segment as configured at
  * Frame360.h:958-977 (min_inliers 80, angular 0.0398 rad, distance 0.02) / Frame360_stereo.h:863-882 (40, 0.05, 0.05):
@@ -413,8 +436,7 @@ int rgbd360_stitch_sphere(rgbd360_ctx* ctx, const uint8_t* rgb8, const uint16_t*
 /* ---- PbMap plane registration: the initial-guess provider in front of the path -------------- */
 
 /* Thresholds of mrpt::pbmap::SubgraphMatcher (config_files/configLocaliser_spherical.ini / ..._sphericalOdometry.ini,
- * loaded at RegisterRGBD360.h:97-100) that the geometric constraints below use; colour constraints are not built
- * (the planes of this library carry no colour). */
+ * loaded at RegisterRGBD360.h:97-100) that the geometric and colour constraints below use. */
 typedef struct {
     /* [unary] */
     float dist_d;                 /* odometry modes: |d_ref - d_trg| below this (m) */
@@ -439,6 +461,12 @@ typedef struct {
     float max_conditioning;       /* largest / smallest eigenvalue of sum w n n^T above this = ill-conditioned translation */
     float sigma_dist, sigma_normal; /* scale of the information matrix: st. dev. of a plane offset (m) / normal (rad) */
     int   max_nodes;              /* budget of the interpretation-tree search (nodes); 0 = unlimited */
+    /* [unary], colour (applied to a pair of planes that both carry colour, color_count > 0) */
+    int   use_color;              /* 0: no colour test at all */
+    float color_threshold;        /* |difference| of every channel of color_nrgb below this (ini: 0.07) */
+    float intensity_threshold;    /* |difference| of intensity below this (ini: 150 on the 0..765 scale); <= 0: not tested */
+    float hue_threshold;          /* Bhattacharyya distance sqrt(1 - sum sqrt(h1 h2)) of the two hist_h below this (ini: 0.45); <= 0: not
+                                   * tested -- the default: the reference's own use of it is commented out (Frame360.h:673) */
 } rgbd360_pbmap_params;
 
 /* odometry = 0: configLocaliser_spherical.ini, 1: configLocaliser_sphericalOdometry.ini */

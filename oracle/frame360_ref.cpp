@@ -298,6 +298,62 @@ int oracle_f360_plane_segment(const float* xyz, const float* normals, int rows, 
 
 
 // ------------------------------------------------------------------------------------
+// Colour descriptors of the planar regions: the roles of mrpt::pbmap::Plane::calcMainColor2 / calcPlaneHistH, which
+// Frame360.h:1045-1046 and Frame360_stereo.h:949-950 call for every plane, and whose results the PbMap matcher's unary colour
+// constraint reads (configLocaliser_spherical.ini:19-21).  THIRD-PARTY (MRPT 1.x, src/Plane.cpp), not in the reference tree, version
+// not pinned: PARITY UNPINNED.  Restated from the published method:
+//   * per inlier the normalised colour (R, G, B) / (R + G + B) (pixels with R + G + B = 0 have none), its mean and standard
+//     deviation over the region (calcMainColor's estimate; calcMainColor2 refines it to the mean-shift mode of a 2000-pixel
+//     subsample -- the same value for a region of one colour, not restated) and the mean intensity R + G + B;
+//   * per inlier the hue of the RGB -> HSV conversion in 72 bins of 5 degrees when the pixel is saturated (V > 0.2 and S > 0.2),
+//     else a "dark" (V <= 0.2) or "unsaturated" bin: the 74-bin layout of hist_H, normalised by the inlier count.
+// Integer arithmetic throughout (the device does the same: sums are order independent and comparable bit for bit):
+//   q_c = floor(C * 65536 / (R + G + B));  sums of q_c, q_c^2, R + G + B, pixel counts;
+//   bin = floor((24 k delta + 12 (x - y)) / delta) mod 72 with delta = max - min, (k, x, y) = (0, G, B) when R is the maximum,
+//   (1, B, R) when G is (and R is not), (2, R, G) otherwise.
+// labels: per cloud pixel the region's root pixel index (-1: none); roots: the regions wanted; cloud pixel (r, c) takes image pixel
+// (r step + step / 2, c step + step / 2) (DownsampleRGBD.h:240, 285-287).  out: n_planes x 82 uint64
+// {sum qR, qG, qB, sum qR^2, qG^2, qB^2, sum (R + G + B), pixels with colour, 74 bins}.
+void oracle_f360_plane_colour(const int* labels, int rows, int cols, const uint8_t* rgb, size_t rgb_step, int step, const int* roots,
+                              int n_planes, uint64_t* out) {
+    const size_t n = (size_t)rows * cols;
+    std::vector<int> plane_of(n, -1);
+    for (int k = 0; k < n_planes; ++k) plane_of[roots[k]] = k;
+    std::fill(out, out + (size_t)n_planes * 82, (uint64_t)0);
+    for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < cols; ++c) {
+            const int l = labels[(size_t)r * cols + c];
+            if (l < 0 || plane_of[l] < 0) continue;
+            uint64_t* o = out + (size_t)plane_of[l] * 82;
+            const uint8_t* px = rgb + (size_t)(r * step + step / 2) * rgb_step + 3 * (size_t)(c * step + step / 2);
+            const unsigned R = px[0], G = px[1], B = px[2], S = R + G + B;
+            if (S) {
+                const uint64_t q[3] = {(uint64_t)(R << 16) / S, (uint64_t)(G << 16) / S, (uint64_t)(B << 16) / S};
+                for (int k = 0; k < 3; ++k) {
+                    o[k] += q[k];
+                    o[3 + k] += q[k] * q[k];
+                }
+                o[6] += S;
+                o[7] += 1;
+            }
+            const unsigned mx = std::max(R, std::max(G, B)), mn = std::min(R, std::min(G, B)), delta = mx - mn;
+            int bin;
+            if (mx * 5u <= 255u) bin = 72;
+            else if (delta * 5u <= mx) bin = 73;
+            else {
+                int num;
+                if (mx == R) num = 12 * ((int)G - (int)B);
+                else if (mx == G) num = 24 * (int)delta + 12 * ((int)B - (int)R);
+                else num = 48 * (int)delta + 12 * ((int)R - (int)G);
+                if (num < 0) num += 72 * (int)delta;
+                bin = num / (int)delta;
+                if (bin >= 72) bin -= 72;
+            }
+            o[8 + bin] += 1;
+        }
+}
+
+// ------------------------------------------------------------------------------------
 // The `refine` half of pcl::OrganizedMultiPlaneSegmentation::segmentAndRefine (Frame360.h:977, :868; Frame360_stereo.h:882).
 // THIRD-PARTY (PCL >= 1.7, segmentation/organized_multi_plane_segmentation.hpp `refine` + plane_refinement_comparator.h), restated
 // from the published source, parity unpinned.  After `segment`, the regions that became planes ("refine labels") grow into

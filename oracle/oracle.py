@@ -374,6 +374,38 @@ def f360_plane_segment(xyz, normals, rows, cols, min_inliers=40, angular_thresho
     return labels.reshape(rows, cols), planes
 
 
+def f360_plane_colour(labels, rgb, planes, step=1):
+    """Colour descriptors of planar regions (oracle/frame360_ref.cpp oracle_f360_plane_colour; the roles of
+    mrpt::pbmap::Plane::calcMainColor / calcPlaneHistH, Frame360.h:1045-1046).  labels: rows x cols root indices; rgb: the colour
+    image (cloud pixel (r, c) <- image pixel (r step + step // 2, c step + step // 2)); planes: dicts with "root".
+    Returns (raw uint64 sums [n, 82], list of dicts color_count / color_nrgb / color_dev / intensity / hist_h)."""
+    lab = np.ascontiguousarray(np.asarray(labels, np.int32))
+    rows, cols = lab.shape
+    rgb = np.ascontiguousarray(rgb, np.uint8)
+    roots = np.ascontiguousarray([int(p["root"]) for p in planes], np.int32)
+    out = np.zeros((max(len(planes), 1), 82), np.uint64)
+    f = lib().oracle_f360_plane_colour
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    f.restype = None
+    f(_ptr(lab), rows, cols, _ptr(rgb), rgb.strides[0], int(step), _ptr(roots), len(planes), _ptr(out))
+    desc = []
+    for k in range(len(planes)):
+        w = out[k].astype(np.float64)
+        n, total = w[7], w[8:].sum()
+        d = dict(color_count=int(out[k, 7]), color_nrgb=np.zeros(3, np.float32), color_dev=np.zeros(3, np.float32), intensity=0.0,
+                 hist_h=np.zeros(74, np.float32))
+        if n > 0:
+            m = w[0:3] / n / 65536.0
+            var = w[3:6] / n / 65536.0 ** 2 - m * m
+            d["color_nrgb"] = m.astype(np.float32)
+            d["color_dev"] = np.sqrt(np.maximum(var, 0.0)).astype(np.float32)
+            d["intensity"] = float(np.float32(w[6] / n))
+        if total > 0:
+            d["hist_h"] = (w[8:] / total).astype(np.float32)
+        desc.append(d)
+    return out[:len(planes)], desc
+
+
 def f360_hull_stats(xyz, labels, plane):
     """EXACT convex hull of a planar region in its own plane -- the checker of the device's 64-direction hull stage (the roles of
     mrpt::pbmap::Plane::calcConvexHull / computeMassCenterAndArea, Frame360.h:1025-1031; MRPT itself is not in the reference tree):

@@ -26,7 +26,9 @@ def default_params(odometry: bool = False) -> dict:
                 dist_threshold=3.0 if odometry else 4.0, angle_threshold_deg=10.0 if odometry else 9.0,
                 height_threshold=0.33, cos_normal_threshold=0.985 if odometry else 0.99, min_planes_recognition=3,
                 max_curvature_plane=0.0013, min_area_plane=0.12, max_elongation_plane=6.0, up_axis=0, planar_normal_tol=0.08,
-                max_conditioning=100.0, sigma_dist=0.02, sigma_normal=0.0398)
+                max_conditioning=100.0, sigma_dist=0.02, sigma_normal=0.0398,
+                # [unary] colour (configLocaliser_spherical*.ini:19-21); hue_threshold 0 = not tested (Frame360.h:673 has it commented out)
+                use_color=1, color_threshold=0.07, intensity_threshold=100.0 if odometry else 150.0, hue_threshold=0.0)
 
 
 def _f32(x):
@@ -57,10 +59,30 @@ def select_subgraph(planes, max_match_planes, P):
     return [i for i in kept if flat(i)]
 
 
+def color_ok(a, b, P):
+    """Radiometric unary constraint (mrpt::pbmap::SubgraphMatcher::evalUnaryConstraints, third-party): planes that both carry
+    colour agree in every channel of the normalised colour, in mean intensity, and -- when hue_threshold > 0 -- in the
+    Bhattacharyya distance of their hue histograms."""
+    if not P.get("use_color", 1) or int(a.get("color_count", 0)) <= 0 or int(b.get("color_count", 0)) <= 0:
+        return True
+    ca, cb = np.asarray(a["color_nrgb"], np.float32).astype(np.float64), np.asarray(b["color_nrgb"], np.float32).astype(np.float64)
+    if not np.all(np.abs(ca - cb) < _f32(P["color_threshold"])):
+        return False
+    if _f32(P.get("intensity_threshold", 0)) > 0 and not abs(_f32(a["intensity"]) - _f32(b["intensity"])) < _f32(P["intensity_threshold"]):
+        return False
+    if _f32(P.get("hue_threshold", 0)) > 0:
+        ha, hb = np.asarray(a["hist_h"], np.float32).astype(np.float64), np.asarray(b["hist_h"], np.float32).astype(np.float64)
+        if not math.sqrt(max(0.0, 1.0 - float(np.sqrt(ha * hb).sum()))) < _f32(P["hue_threshold"]):
+            return False
+    return True
+
+
 def unary_ok(a, b, mode, P):
     if not _ratio(_f32(a["area"]), _f32(b["area"])) < _f32(P["area_threshold"]):
         return False
     if not _ratio(_f32(a["elongation"]), _f32(b["elongation"])) < _f32(P["elongation_threshold"]):
+        return False
+    if not color_ok(a, b, P):
         return False
     na, nb = np.asarray(a["normal"], np.float32).astype(np.float64), np.asarray(b["normal"], np.float32).astype(np.float64)
     da, db = _f32(a["d"]), _f32(b["d"])

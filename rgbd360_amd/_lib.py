@@ -17,7 +17,7 @@ SYMBOLS = [
     "rgbd360_plane_fit", "rgbd360_frame_planes", "rgbd360_frame_planes_dev", "rgbd360_load_frame_bin", "rgbd360_stitch_sphere",
     "rgbd360_set_camera", "rgbd360_align_pinhole", "rgbd360_eval_pinhole", "rgbd360_warp_indices_pinhole",
     "rgbd360_pbmap_default_params", "rgbd360_register_planes", "rgbd360_bilateral_filter",
-    "rgbd360_cloud_planes", "rgbd360_sensor_cloud", "rgbd360_sensor_planes", "rgbd360_merge_planes", "rgbd360_planes_available", "rgbd360_set_plane_refinement", "rgbd360_plane_refinement_stats",
+    "rgbd360_cloud_planes", "rgbd360_sensor_cloud", "rgbd360_sensor_planes", "rgbd360_merge_planes", "rgbd360_planes_available", "rgbd360_set_plane_refinement", "rgbd360_plane_refinement_stats", "rgbd360_set_plane_color_image",
     "rgbd360_multi_create", "rgbd360_multi_destroy", "rgbd360_multi_last_error", "rgbd360_multi_n_gpus", "rgbd360_multi_uses_rccl",
     "rgbd360_shard_range", "rgbd360_gather_slot", "rgbd360_multi_align_sequence", "rgbd360_multi_load_sequence", "rgbd360_multi_align_resident",
     "rgbd360_align360_batch_multi", "rgbd360_time_eval_kernel_rotating", "rgbd360_forced_iters_batch",
@@ -42,7 +42,9 @@ class Result(C.Structure):
 class Plane(C.Structure):
     _fields_ = [("centroid", C.c_float * 3), ("normal", C.c_float * 3), ("d", C.c_float), ("curvature", C.c_float),
                 ("count", C.c_int), ("root", C.c_int), ("area", C.c_float), ("elongation", C.c_float),
-                ("ppal_dir", C.c_float * 3), ("area_moment", C.c_float), ("center_hull", C.c_float * 3), ("hull_points", C.c_int)]
+                ("ppal_dir", C.c_float * 3), ("area_moment", C.c_float), ("center_hull", C.c_float * 3), ("hull_points", C.c_int),
+                ("color_count", C.c_int), ("color_nrgb", C.c_float * 3), ("color_dev", C.c_float * 3), ("intensity", C.c_float),
+                ("hist_h", C.c_float * 74)]
 
 
 class PbmapParams(C.Structure):
@@ -51,7 +53,8 @@ class PbmapParams(C.Structure):
                 ("height_threshold", C.c_float), ("cos_normal_threshold", C.c_float), ("min_planes_recognition", C.c_int),
                 ("max_curvature_plane", C.c_float), ("min_area_plane", C.c_float), ("max_elongation_plane", C.c_float),
                 ("up_axis", C.c_int), ("planar_normal_tol", C.c_float), ("max_conditioning", C.c_float),
-                ("sigma_dist", C.c_float), ("sigma_normal", C.c_float), ("max_nodes", C.c_int)]
+                ("sigma_dist", C.c_float), ("sigma_normal", C.c_float), ("max_nodes", C.c_int),
+                ("use_color", C.c_int), ("color_threshold", C.c_float), ("intensity_threshold", C.c_float), ("hue_threshold", C.c_float)]
 
 
 _lib = None
@@ -129,6 +132,7 @@ def load() -> C.CDLL:
                                              C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.rgbd360_debug_solve_partials.argtypes = [vp, i32, vp, i32, i32, vp, f32p, f32p]
     L.rgbd360_set_plane_refinement.argtypes = [vp, i32, C.c_float]
+    L.rgbd360_set_plane_color_image.argtypes = [vp, vp, C.c_size_t, i32, i32, i32, i32]
     L.rgbd360_plane_refinement_stats.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     L.rgbd360_rig_create.argtypes = [C.POINTER(Params), i32, vp, C.c_float, C.c_float, C.c_float, C.c_float, C.POINTER(vp)]
     L.rgbd360_rig_destroy.argtypes = [vp]

@@ -1312,6 +1312,172 @@ __global__ void k_f360_mom_reduce(const unsigned long long* __restrict__ mom, co
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Colour descriptors of the planar regions (Frame360.h:1045-1046 / Frame360_stereo.h:949-950: plane.calcPlaneHistH();
+// plane.calcMainColor2(); -- mrpt::pbmap::Plane, third-party, not in the reference tree; consumed by the PbMap matcher's unary colour
+// constraint, config_files/configLocaliser_spherical.ini:19-21).  Per region, over its inlier pixels:
+//   v3colorNrgb / dominantIntensity   mean and standard deviation of the normalised colour (R, G, B) / (R + G + B) and the mean of
+//                                     R + G + B (the roles calcMainColor[2] fills; the mean stands in for MRPT's mean-shift mode)
+//   hist_H                            normalised histogram of the SATURATED hue: 72 bins of 5 degrees + a bin for dark pixels
+//                                     (V <= 0.2) + a bin for unsaturated ones (S <= 0.2) -- MRPT's 74-bin layout
+// All per-pixel arithmetic is INTEGER (normalised colour in 2^-16 fixed point by integer division, hue bin by integer division of
+// 12 (x - y) by max - min), so the per-region sums are bitwise reproducible and the CPU checker (oracle/frame360_ref.cpp) repeats them
+// exactly; the host turns the sums into floats.  One pass over {label, colour}: 4 + 3 B per pixel.
+// A lane owns 8 pixels 1024 apart (coalesced labels); its sums stay in registers while its region does not change, a wave inside
+// one region adds them up once (the common case), the hue bins go to the block's LDS table by atomics (one table entry per region the
+// block meets, 16 at most -- a pixel of a 17th region adds straight into the global table), the block's table goes out once.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int kColSums = 8;          // sum qR, qG, qB | sum qR^2, qG^2, qB^2 | sum (R + G + B) | pixels with R + G + B > 0
+constexpr int kColBins = 74;
+constexpr int kColWords = kColSums + kColBins;      // 64-bit words per region in the global table
+constexpr int kColPerThread = 8, kColHash = 16;
+struct ColourImage {
+    const uint8_t* rgb;      // device, 3 bytes per pixel
+    size_t step;             // bytes per row
+    int sub;                 // cloud pixel (r, c) takes image pixel (r sub + sub / 2, c sub + sub / 2): DownsampleRGBD.h:240, 285-287 (1: the image itself)
+};
+struct ColourPx {
+    unsigned q[3], S;
+    int bin;
+};
+__device__ __forceinline__ ColourPx colour_px(unsigned R, unsigned G, unsigned B) {
+    ColourPx o;
+    o.S = R + G + B;
+    int rem;
+    int q0 = 0, q1 = 0, q2 = 0;
+    if (o.S) {          // (C << 16) / S, exact: C << 16 < 2^24
+        r360::divmod24((int)(R << 16), (int)o.S, q0, rem);
+        r360::divmod24((int)(G << 16), (int)o.S, q1, rem);
+        r360::divmod24((int)(B << 16), (int)o.S, q2, rem);
+    }
+    o.q[0] = (unsigned)q0; o.q[1] = (unsigned)q1; o.q[2] = (unsigned)q2;
+    const unsigned mx = max(R, max(G, B)), mn = min(R, min(G, B)), delta = mx - mn;
+    if (mx * 5u <= 255u) o.bin = 72;                     // V = max / 255 <= 0.2: dark
+    else if (delta * 5u <= mx) o.bin = 73;               // S = (max - min) / max <= 0.2: unsaturated
+    else {
+        // hue in units of 5 degrees = 12 h6, h6 = sector + (x - y) / delta in [0, 6): floor((24 k delta + 12 (x - y)) / delta), wrapped
+        int num;
+        if (mx == R) num = 12 * ((int)G - (int)B);
+        else if (mx == G) num = 24 * (int)delta + 12 * ((int)B - (int)R);
+        else num = 48 * (int)delta + 12 * ((int)R - (int)G);
+        if (num < 0) num += 72 * (int)delta;
+        int b;
+        r360::divmod24(num, (int)delta, b, rem);
+        o.bin = b >= 72 ? b - 72 : b;
+    }
+    return o;
+}
+__global__ void k_f360_colour_clear(const int* __restrict__ n_slots, int max_slots, unsigned long long* __restrict__ col) {
+    const int ns = min(*n_slots, max_slots);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ns * kColWords; i += gridDim.x * blockDim.x) col[i] = 0ull;
+}
+__global__ __launch_bounds__(kAggThreads) void k_f360_colour(const int* __restrict__ label, const int* __restrict__ slot_of_root, int rows, int cols,
+                                                              ColourImage img, unsigned long long* __restrict__ col) {
+    __shared__ int keys[kColHash];
+    __shared__ unsigned long long sums[kColHash][kColSums];
+    __shared__ unsigned bins[kColHash][kColBins];
+    for (int i = threadIdx.x; i < kColHash * kColBins; i += kAggThreads) (&bins[0][0])[i] = 0u;
+    if (threadIdx.x < kColHash * kColSums) (&sums[0][0])[threadIdx.x] = 0ull;
+    if (threadIdx.x < kColHash) keys[threadIdx.x] = -1;
+    __syncthreads();
+    const int n = rows * cols;
+    auto entry_of = [&](int slot) -> int {               // the block's table entry of a region (-1: table full)
+        int h = slot & (kColHash - 1);
+        for (int probe = 0; probe < kColHash; ++probe) {
+            const int old = atomicCAS(&keys[h], -1, slot);
+            if (old == -1 || old == slot) return h;
+            h = (h + 1) & (kColHash - 1);
+        }
+        return -1;
+    };
+    int key = -1, ent = -1;
+    unsigned a32[5] = {0, 0, 0, 0, 0};                    // sum q (3), sum S, pixels with colour
+    unsigned long long a64[3] = {0, 0, 0};                // sum q^2
+    auto flush_lane = [&]() {                             // this lane's sums to its region's entry (or past a full table)
+        if (key < 0) return;
+        unsigned long long* dst = ent >= 0 ? sums[ent] : col + (size_t)key * kColWords;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) atomicAdd(&dst[k], (unsigned long long)a32[k]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) atomicAdd(&dst[3 + k], a64[k]);
+        atomicAdd(&dst[6], (unsigned long long)a32[3]);
+        atomicAdd(&dst[7], (unsigned long long)a32[4]);
+    };
+#pragma unroll 1
+    for (int j = 0; j < kColPerThread; ++j) {
+        const int p = (blockIdx.x * kColPerThread + j) * kAggThreads + (int)threadIdx.x;
+        int slot = -1;
+        if (p < n) {
+            const int l = label[p];
+            if (l >= 0) slot = slot_of_root[l];
+        }
+        if (slot < 0) continue;
+        int r, c;
+        r360::divmod24(p, cols, r, c);
+        const uint8_t* px = img.rgb + (size_t)(r * img.sub + img.sub / 2) * img.step + 3 * (size_t)(c * img.sub + img.sub / 2);
+        const ColourPx v = colour_px(px[0], px[1], px[2]);
+        if (slot != key) {
+            flush_lane();
+            key = slot;
+            ent = entry_of(slot);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) a32[k] = 0;
+            a64[0] = a64[1] = a64[2] = 0;
+        }
+        if (ent >= 0) atomicAdd(&bins[ent][v.bin], 1u);
+        else atomicAdd(&col[(size_t)slot * kColWords + kColSums + v.bin], 1ull);
+        if (v.S) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                a32[k] += v.q[k];
+                a64[k] += (unsigned long long)v.q[k] * v.q[k];
+            }
+            a32[3] += v.S;
+            a32[4] += 1u;
+        }
+    }
+    // a wave that ended inside ONE region (entry in the block's table) adds its lanes up first; anything else goes lane by lane
+    const int first = __builtin_amdgcn_readfirstlane(key);
+    const int fent = __builtin_amdgcn_readfirstlane(ent);
+    if (__ballot(key == first && ent == fent) == __ballot(true) && first >= 0 && fent >= 0) {
+        unsigned t32[5];
+        long long t64[3];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            unsigned x = a32[k];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) x += __shfl_xor(x, o);
+            t32[k] = x;
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) t64[k] = wave_sum_ll((long long)a64[k]);
+        if ((threadIdx.x & 63) == 0) {
+            unsigned long long* dst = sums[fent];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) atomicAdd(&dst[k], (unsigned long long)t32[k]);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) atomicAdd(&dst[3 + k], (unsigned long long)t64[k]);
+            atomicAdd(&dst[6], (unsigned long long)t32[3]);
+            atomicAdd(&dst[7], (unsigned long long)t32[4]);
+        }
+    } else {
+        flush_lane();
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kColHash * kColWords; i += kAggThreads) {
+        const int e = i / kColWords, w = i - e * kColWords;
+        if (keys[e] < 0) continue;
+        const unsigned long long v = w < kColSums ? sums[e][w] : (unsigned long long)bins[e][w - kColSums];
+        if (v) atomicAdd(&col[(size_t)keys[e] * kColWords + w], v);
+    }
+}
+// the table rows of the slots in use -> pinned host memory, behind the plane list's other records (one wait ends the call)
+__global__ void k_f360_colour_pack(const unsigned long long* __restrict__ col, const int* __restrict__ n_slots, int max_slots,
+                                   unsigned long long* __restrict__ host_out) {
+    const int ns = min(*n_slots, max_slots);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ns * kColWords; i += gridDim.x * blockDim.x) host_out[i] = col[i];
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Convex hull of a planar region (Frame360.h:1009-1031: regions[i].getContour() -> mrpt::pbmap::Plane::calcConvexHull ->
 // computeMassCenterAndArea; MRPT is not in the reference tree: the hull of the region's contour projected onto its plane, the area
 // and mass centre of that polygon).  The hull of a region's contour is the hull of its pixels, and only pixels on the region's

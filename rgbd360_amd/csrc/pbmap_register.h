@@ -123,9 +123,26 @@ struct Matcher {
     long long nodes = 0;
     bool out_of_budget = false;
 
+    // Radiometric part of the unary test (configLocaliser_spherical.ini:19-21: color_threshold, intensity_threshold, hue_threshold;
+    // mrpt::pbmap::SubgraphMatcher::evalUnaryConstraints, third-party): two planes that both carry colour must agree in every channel
+    // of the normalised colour -- invariant to a global brightness change -- in mean intensity (a loose bound), and, when asked for, in
+    // their saturated-hue histograms (Bhattacharyya distance).  Planes without colour (color_count = 0) pass.
+    bool eval_color(const rgbd360_plane& a, const rgbd360_plane& b) const {
+        if (!P->use_color || a.color_count <= 0 || b.color_count <= 0) return true;
+        for (int k = 0; k < 3; ++k)
+            if (!(fabs((double)a.color_nrgb[k] - b.color_nrgb[k]) < P->color_threshold)) return false;
+        if (P->intensity_threshold > 0 && !(fabs((double)a.intensity - b.intensity) < P->intensity_threshold)) return false;
+        if (P->hue_threshold > 0) {
+            double bc = 0;
+            for (int k = 0; k < 74; ++k) bc += sqrt((double)a.hist_h[k] * (double)b.hist_h[k]);
+            if (!(sqrt(std::max(0.0, 1.0 - bc)) < P->hue_threshold)) return false;
+        }
+        return true;
+    }
     bool eval_unary(const rgbd360_plane& a, const rgbd360_plane& b) const {
         if (!(ratio(a.area, b.area) < P->area_threshold)) return false;
         if (!(ratio(a.elongation, b.elongation) < P->elongation_threshold)) return false;
+        if (!eval_color(a, b)) return false;
         const V3 na = v3(a.normal), nb = v3(b.normal);
         if (mode == 2 || mode == 3) {           // odometry: small displacement between the two frames
             if (!(dot(na, nb) > cos(P->angle_deg * M_PI / 180))) return false;
@@ -448,6 +465,25 @@ inline bool same_surface(const rgbd360_plane& pj, const rgbd360_plane& pk, const
         if (inside(Pk[i], pj, ppj, qqj, aj, bj) || inside(Pj[i], pk, ppk, qqk, ak, bk)) return true;
     return false;
 }
+// colour of a merged plane = the pooled statistics of its pieces (mergePlane2 pools the inliers and calls calcMainColor again):
+// means and histogram weighted by the pixel counts they were taken over, the deviation from the pooled second moment
+inline void pool_colour(rgbd360_plane& dst, const rgbd360_plane& a, const rgbd360_plane& b) {
+    const double na = std::max(a.color_count, 0), nb = std::max(b.color_count, 0);
+    dst.color_count = (int)(na + nb);
+    if (na + nb > 0) {
+        for (int k = 0; k < 3; ++k) {
+            const double m = (na * a.color_nrgb[k] + nb * b.color_nrgb[k]) / (na + nb);
+            const double var = (na * ((double)a.color_dev[k] * a.color_dev[k] + (a.color_nrgb[k] - m) * (a.color_nrgb[k] - m)) +
+                                nb * ((double)b.color_dev[k] * b.color_dev[k] + (b.color_nrgb[k] - m) * (b.color_nrgb[k] - m))) / (na + nb);
+            dst.color_nrgb[k] = (float)m;
+            dst.color_dev[k] = (float)sqrt(std::max(var, 0.0));
+        }
+        dst.intensity = (float)((na * a.intensity + nb * b.intensity) / (na + nb));
+    }
+    const double ca = a.color_count > 0 ? std::max(a.count, 0) : 0, cb = b.color_count > 0 ? std::max(b.count, 0) : 0;
+    if (ca + cb > 0)
+        for (int k = 0; k < 74; ++k) dst.hist_h[k] = (float)((ca * a.hist_h[k] + cb * b.hist_h[k]) / (ca + cb));
+}
 inline std::vector<rgbd360_plane> merge_planes(const rgbd360_plane* in, int n, const MergeParams& M) {
     std::vector<rgbd360_plane> v;
     for (int i = 0; i < n; ++i)
@@ -470,6 +506,7 @@ inline std::vector<rgbd360_plane> merge_planes(const rgbd360_plane* in, int n, c
                                      b.n * (b.C[r][c] + (b.c[r] - m.c[r]) * (b.c[c] - m.c[c]))) / m.n;
                 // pieces that carry hull areas: the merged surface's area is their sum (adjacent views of one surface; mrpt's mergePlane2
                 // re-hulls the union of the two contours, which the records no longer hold), its centre their area-weighted mean
+                const rgbd360_plane colour_j = v[j], colour_k = v[k];
                 const bool hulls = v[j].hull_points > 0 && v[k].hull_points > 0;
                 const double aj = v[j].area, ak = v[k].area;
                 const int hp = v[j].hull_points + v[k].hull_points;
@@ -482,6 +519,7 @@ inline std::vector<rgbd360_plane> merge_planes(const rgbd360_plane* in, int n, c
                     v[j].center_hull[2] = (float)((aj * cj.z + ak * ck.z) / (aj + ak));
                     v[j].hull_points = hp;
                 }
+                pool_colour(v[j], colour_j, colour_k);
                 v.erase(v.begin() + (long)k);
                 merged = true;
                 break;
@@ -511,6 +549,10 @@ inline void default_params(rgbd360_pbmap_params* p, int odometry) {
     p->sigma_dist = 0.02f;                // the segmentation's distance threshold (Frame360.h:960-965)
     p->sigma_normal = 0.0398f;            // its angular threshold
     p->max_nodes = 2000000;
+    p->use_color = 1;
+    p->color_threshold = 0.07f;
+    p->intensity_threshold = odometry ? 100.f : 150.f;
+    p->hue_threshold = 0.f;               // ini: 0.35 / 0.45, but the reference's own test of it is commented out (Frame360.h:673): opt-in
 }
 
 }  // namespace pbm

@@ -91,6 +91,13 @@ struct rgbd360_ctx {
     int* f_hull_keys = nullptr;                                   // per block of k_f360_hull_extremes: the slots of its table rows ...
     unsigned long long* f_hull_vals = nullptr;                    // ... and the rows (256 extremes each)
     int f_hull_blocks = 0;
+    // colour image of the next plane calls (rgbd360_set_plane_color_image) and the per-region colour table (k_f360_colour)
+    uint8_t* f_col_owned = nullptr;                               // device copy of a host image
+    size_t f_col_owned_bytes = 0;
+    f360::ColourImage f_col_img = {nullptr, 0, 1};
+    int f_col_rows = 0, f_col_cols = 0;                           // size of the registered image
+    unsigned long long *f_col = nullptr, *f_col_host = nullptr;   // [kF360MaxSlots][kColWords]: device table, pinned copy of the rows in use
+    bool f_col_ran = false;                                       // the last plane call filled f_col_host
     unsigned long long* b_sum = nullptr;                          // bilateral grid: fixed-point sums, counts, two float2 ping-pong arrays
     int* b_cnt = nullptr;
     float2 *b_a = nullptr, *b_b = nullptr;
@@ -682,6 +689,9 @@ void rgbd360_destroy(rgbd360_ctx* ctx) {
     hipFree(ctx->f_root_of_slot); hipFree(ctx->f_nslots); hipFree(ctx->f_window); hipFree(ctx->f_mom);
     hipFree(ctx->f_count_of_slot); hipFree(ctx->f_depth_raw); hipFree(ctx->f_pack);
     if (ctx->f_pack_host) hipHostFree(ctx->f_pack_host);
+    hipFree(ctx->f_col_owned); hipFree(ctx->f_col);
+    if (ctx->f_col_host) hipHostFree(ctx->f_col_host);
+    ctx->f_col_owned = nullptr; ctx->f_col = nullptr; ctx->f_col_host = nullptr; ctx->f_col_owned_bytes = 0;
     hipFree(ctx->f_models);
     if (ctx->f_flags_host) hipHostFree(ctx->f_flags_host);
     hipFree(ctx->b_sum); hipFree(ctx->b_cnt); hipFree(ctx->b_a); hipFree(ctx->b_b); hipFree(ctx->b_mm);
@@ -1962,6 +1972,49 @@ void sorted_eigen3(const double C[3][3], double evals[3], double evecs[3][3]) { 
     }
 }
 
+// Colour descriptors of the regions in their slots (k_f360_colour over the CURRENT labels), enqueued on the stream: the table rows in
+// use land in pinned host memory.  Only when a colour image of this cloud's geometry is registered.
+bool launch_colour(rgbd360_ctx* ctx, int rows, int cols) {
+    using namespace f360;
+    ctx->f_col_ran = false;
+    const ColourImage& im = ctx->f_col_img;
+    if (!im.rgb || im.sub < 1 || ctx->f_col_rows / im.sub != rows || ctx->f_col_cols / im.sub != cols) return false;
+    const size_t bytes = (size_t)kF360MaxSlots * kColWords * sizeof(unsigned long long);
+    if (!ctx->f_col && hipMalloc(&ctx->f_col, bytes) != hipSuccess) return false;
+    if (!ctx->f_col_host && hipHostMalloc((void**)&ctx->f_col_host, bytes, hostwait::kPublishedFlags) != hipSuccess) return false;
+    const int n = rows * cols;
+    hipLaunchKernelGGL(k_f360_colour_clear, dim3(64), dim3(256), 0, ctx->stream, ctx->f_nslots, kF360MaxSlots, ctx->f_col);
+    hipLaunchKernelGGL(k_f360_colour, dim3((n + kAggThreads * kColPerThread - 1) / (kAggThreads * kColPerThread)), dim3(kAggThreads), 0, ctx->stream,
+                       ctx->f_label, ctx->f_slot_of_root, rows, cols, im, ctx->f_col);
+    hipLaunchKernelGGL(k_f360_colour_pack, dim3(64), dim3(256), 0, ctx->stream, ctx->f_col, ctx->f_nslots, kF360MaxSlots, ctx->f_col_host);
+    ctx->f_col_ran = true;
+    return true;
+}
+// sums of a slot's row -> the plane's colour fields (rgbd360_hip.h); the record stays colourless when no colour pass ran
+void apply_colour(const rgbd360_ctx* ctx, rgbd360_plane& P, int slot) {
+    P.color_count = 0;
+    for (int k = 0; k < 3; ++k) P.color_nrgb[k] = P.color_dev[k] = 0.f;
+    P.intensity = 0.f;
+    for (int k = 0; k < 74; ++k) P.hist_h[k] = 0.f;
+    if (!ctx->f_col_ran) return;
+    const volatile unsigned long long* w = ctx->f_col_host + (size_t)slot * f360::kColWords;
+    const double n = (double)w[7];
+    unsigned long long total = 0;
+    for (int k = 0; k < f360::kColBins; ++k) total += w[f360::kColSums + k];
+    if (total == 0) return;
+    P.color_count = (int)w[7];
+    if (n > 0) {
+        for (int k = 0; k < 3; ++k) {
+            const double m = (double)w[k] / n / 65536.0;
+            const double var = (double)w[3 + k] / n / (65536.0 * 65536.0) - m * m;
+            P.color_nrgb[k] = (float)m;
+            P.color_dev[k] = (float)sqrt(std::max(var, 0.0));
+        }
+        P.intensity = (float)((double)w[6] / n);
+    }
+    for (int k = 0; k < f360::kColBins; ++k) P.hist_h[k] = (float)((double)w[f360::kColSums + k] / (double)total);
+}
+
 // regions of (ctx->f_xyz, ctx->f_normals) -> labels (device ctx->f_label) + plane list (host)
 // segmentAndRefine's refinement on the device (frame360_kernels.h k_f360_refine_tile): block-Jacobi steps of the two raster passes
 // until nothing changes, then the grown inliers are added to their planes' integer sums and the extent descriptors recomputed.
@@ -2031,6 +2084,7 @@ int f360_refine_dev(rgbd360_ctx* ctx, int rows, int cols, int nslots, std::vecto
     // the contour PCL hands to calcConvexHull is that of the REFINED region, projected with the plane `segment` fitted: extremes of the
     // committed labels against the frames k_f360_slot_frames left before the refinement
     launch_hull(ctx, rows, cols, /*clear_first=*/true);
+    launch_colour(ctx, rows, cols);          // the colour of the REFINED inlier sets (Frame360.h:1045-1046 run on the refined regions)
     HIPC(ctx, hipGetLastError());
     HIPC(ctx, hipStreamSynchronize(ctx->stream));
     ctx->f_refine_changed = ctx->f_flags_host[kFlags];
@@ -2056,6 +2110,7 @@ int f360_refine_dev(rgbd360_ctx* ctx, int rows, int cols, int nslots, std::vecto
         P.elongation = (float)(l1 > 0 ? sqrt(l2 / l1) : INFINITY);
         for (int q = 0; q < 3; ++q) P.ppal_dir[q] = (float)vecs[2][q];
         apply_hull(P, hull_records(ctx)[plane_slot[k]]);
+        apply_colour(ctx, P, plane_slot[k]);
     }
     return 0;
 }
@@ -2117,7 +2172,11 @@ int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float
     // moment replicas anyway); k_f360_mom_reduce only runs behind the refinement's commit, which changes the sums.
     hipLaunchKernelGGL(k_f360_slot_frames, dim3(256), dim3(64), 0, ctx->stream, ctx->f_mom, ctx->f_nslots, kF360MaxSlots,
                        ctx->f_count_of_slot, ctx->f_frames, ctx->f_ext, ctx->f_root_of_slot, ctx->f_pack_host);
-    if (!ctx->f_refine) launch_hull(ctx, rows, cols, /*clear_first=*/false);
+    ctx->f_col_ran = false;
+    if (!ctx->f_refine) {
+        launch_hull(ctx, rows, cols, /*clear_first=*/false);
+        launch_colour(ctx, rows, cols);
+    }
     HIPC(ctx, hipGetLastError());
     HIPC(ctx, hipStreamSynchronize(ctx->stream));
     const int nslots = *reinterpret_cast<const volatile int*>(ctx->f_pack_host);
@@ -2172,6 +2231,7 @@ int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float
         P.area_moment = (float)(12.0 * sqrt(l1 * l2));
         P.elongation = (float)(l1 > 0 ? sqrt(l2 / l1) : INFINITY);
         for (int k = 0; k < 3; ++k) P.ppal_dir[k] = (float)vecs[2][k];
+        apply_colour(ctx, P, s);      // (with the refinement on: empty here, filled by f360_refine_dev below)
         if (!ctx->f_refine) apply_hull(P, hull_records(ctx)[s]);
         else {                   // filled by f360_refine_dev below
             P.area = P.area_moment;
@@ -2372,6 +2432,33 @@ extern "C" int rgbd360_set_plane_refinement(rgbd360_ctx* ctx, int enabled, float
     if (enabled && !(distance_threshold > 0.f)) return fail(ctx, -1, "the refinement distance threshold must be positive");
     ctx->f_refine = enabled ? 1 : 0;
     if (enabled) ctx->f_refine_dist = distance_threshold;
+    return 0;
+}
+extern "C" int rgbd360_set_plane_color_image(rgbd360_ctx* ctx, const uint8_t* rgb, size_t rgb_step, int rows, int cols, int step, int on_device) {
+    if (!ctx) return -1;
+    hipSetDevice(ctx->p.device);
+    if (!rgb) {
+        ctx->f_col_img = {nullptr, 0, 1};
+        ctx->f_col_rows = ctx->f_col_cols = 0;
+        return 0;
+    }
+    if (rows < 1 || cols < 1 || step < 1 || step > 16 || rgb_step < (size_t)cols * 3) return fail(ctx, -1, "bad colour image geometry");
+    if (on_device) {
+        ctx->f_col_img = {rgb, rgb_step, step};
+    } else {
+        const size_t bytes = (size_t)rows * cols * 3;
+        HIPC(ctx, hipStreamSynchronize(ctx->stream));       // a plane call still reading the previous copy
+        if (ctx->f_col_owned_bytes < bytes) {
+            hipFree(ctx->f_col_owned);
+            ctx->f_col_owned = nullptr;
+            ctx->f_col_owned_bytes = 0;
+            HIPC(ctx, hipMalloc(&ctx->f_col_owned, bytes));
+            ctx->f_col_owned_bytes = bytes;
+        }
+        HIPC(ctx, hipMemcpy2D(ctx->f_col_owned, (size_t)cols * 3, rgb, rgb_step, (size_t)cols * 3, rows, hipMemcpyHostToDevice));
+        ctx->f_col_img = {ctx->f_col_owned, (size_t)cols * 3, step};
+    }
+    ctx->f_col_rows = rows; ctx->f_col_cols = cols;
     return 0;
 }
 extern "C" int rgbd360_plane_refinement_stats(rgbd360_ctx* ctx, int* pixels_relabelled, int* sweeps) {

@@ -43,6 +43,17 @@ def planes_to_array(planes):
         ch = pl.get("center_hull", pl["centroid"])
         for k in range(3):
             a.center_hull[k] = float(ch[k])
+        # colour descriptors (color_count 0 = none: the matcher skips its colour tests for this plane)
+        a.color_count = int(pl.get("color_count", 0))
+        if a.color_count > 0:
+            for k in range(3):
+                a.color_nrgb[k] = float(pl["color_nrgb"][k])
+                a.color_dev[k] = float(pl.get("color_dev", (0, 0, 0))[k])
+            a.intensity = float(pl.get("intensity", 0.0))
+            hh = pl.get("hist_h")
+            if hh is not None:
+                for k in range(74):
+                    a.hist_h[k] = float(hh[k])
     return arr
 
 

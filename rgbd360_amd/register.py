@@ -451,7 +451,10 @@ def _planes_to_dicts(arr, n):
                  d=float(arr[i].d), curvature=float(arr[i].curvature), count=int(arr[i].count), root=int(arr[i].root),
                  area=float(arr[i].area), elongation=float(arr[i].elongation),
                  ppal_dir=np.array(list(arr[i].ppal_dir), np.float32), area_moment=float(arr[i].area_moment),
-                 center_hull=np.array(list(arr[i].center_hull), np.float32), hull_points=int(arr[i].hull_points))
+                 center_hull=np.array(list(arr[i].center_hull), np.float32), hull_points=int(arr[i].hull_points),
+                 color_count=int(arr[i].color_count), color_nrgb=np.array(list(arr[i].color_nrgb), np.float32),
+                 color_dev=np.array(list(arr[i].color_dev), np.float32), intensity=float(arr[i].intensity),
+                 hist_h=np.array(list(arr[i].hist_h), np.float32))
             for i in range(n)]
 
 
@@ -468,6 +471,17 @@ class Frame360Stages:
         """rgbd360_set_plane_refinement: segmentAndRefine's refinement (Frame360.h:977) for the later plane calls of this context."""
         self._refine = (bool(enabled), float(distance_threshold))
         self._reg._check(self._L.rgbd360_set_plane_refinement(self._reg._ctx(), int(enabled), float(distance_threshold)))
+
+    def set_color_image(self, rgb, step: int = 1):
+        """rgbd360_set_plane_color_image: the colour image (H x W x 3 uint8, host) that goes with the clouds of the later plane calls
+        of this context; cloud pixel (r, c) takes image pixel (r step + step // 2, c step + step // 2).  None clears: planes then
+        come back without colour (color_count 0).  Frame360.h:1045-1046 (calcPlaneHistH / calcMainColor2)."""
+        if rgb is None:
+            self._reg._check(self._L.rgbd360_set_plane_color_image(self._reg._ctx(), None, 0, 0, 0, 1, 0))
+            return
+        rgb = np.ascontiguousarray(rgb, np.uint8)
+        assert rgb.ndim == 3 and rgb.shape[2] == 3
+        self._reg._check(self._L.rgbd360_set_plane_color_image(self._reg._ctx(), _ptr(rgb), rgb.strides[0], rgb.shape[0], rgb.shape[1], int(step), 0))
 
     def refinement_stats(self):
         a, b = C.c_int(), C.c_int()

@@ -1511,3 +1511,68 @@ def test_recompute_form_of_the_pass_is_bit_identical_to_the_record_form(hip_lib,
     for k in res["records"]:
         a, b = res["records"][k], res["recompute"][k]
         assert np.array_equal(a.view(np.uint64) if a.dtype == np.float64 else a, b.view(np.uint64) if b.dtype == np.float64 else b), k
+
+
+@pytest.mark.parametrize("W,H,refine", [(512, 256, False), (512, 256, True), (1000, 500, False)])
+def test_plane_colour_descriptors_match_oracle(hip_lib, oracle_mod, W, H, refine):
+    """Frame360.h:1045-1046 (plane.calcPlaneHistH(); plane.calcMainColor2(); mrpt::pbmap, third-party, unpinned): normalised-colour mean
+    / deviation, mean intensity and the 74-bin saturated-hue histogram of every planar region, from the frame's colour panorama.
+    The per-pixel arithmetic is integer on both sides, so the device's sums equal the checker's exactly and the float descriptors agree
+    to their last rounding; with segmentAndRefine's refinement on, the colour is that of the GROWN inlier sets."""
+    from rgbd360_amd.register import Frame360Stages
+    (rgbA, dA), _, _ = synth.make_pair(W, H, seed=31)
+    rgb = rgbA.copy()
+    rgb[: H // 4, :, 0] //= 3                       # tint parts of the frame so that regions differ in colour, and paint a dark
+    rgb[H // 2:, :, 2] = 255 - rgb[H // 2:, :, 2]   # and a grey patch for the two special histogram bins
+    rgb[H // 3: H // 3 + 20, 40:200] = (20, 25, 18)
+    rgb[H // 3 + 30: H // 3 + 50, 40:200] = (128, 126, 131)
+    st = Frame360Stages(_mk(hip_lib, 3))
+    st.set_refinement(refine, 0.02)
+    st.set_color_image(rgb)
+    kw = dict(convention=2, angular_threshold=0.03 if W <= 512 else 0.02, min_inliers=40 if W <= 512 else 120)
+    out = st.frame_planes(dA, **kw)
+    assert len(out["planes"]) >= 5
+    _, want = oracle_mod.f360_plane_colour(out["labels"], rgb, out["planes"])
+    for p, w in zip(out["planes"], want):
+        assert p["color_count"] == w["color_count"] > 0 and p["color_count"] <= p["count"]
+        assert np.abs(p["color_nrgb"] - w["color_nrgb"]).max() <= 1e-7 and abs(p["color_nrgb"].sum() - 1.0) < 1e-3
+        assert np.abs(p["color_dev"] - w["color_dev"]).max() <= 2e-6
+        assert abs(p["intensity"] - w["intensity"]) <= 1e-4 * max(1.0, w["intensity"])
+        assert np.abs(p["hist_h"] - w["hist_h"]).max() <= 1e-7 and abs(p["hist_h"].sum() - 1.0) < 1e-5
+    assert any(p["hist_h"][72] > 0.01 for p in out["planes"]) and any(p["hist_h"][73] > 0.01 for p in out["planes"])
+    if refine:
+        assert st.refinement_stats()["pixels_relabelled"] >= 0
+    # without a colour image (or with one of another geometry) the planes come back colourless, everything else unchanged
+    st.set_color_image(None)
+    bare = st.frame_planes(dA, **kw)
+    assert all(q["color_count"] == 0 and not q["hist_h"].any() for q in bare["planes"])
+    assert [q["root"] for q in bare["planes"]] == [q["root"] for q in out["planes"]]
+    st.set_color_image(rgb[: H // 2])
+    assert all(q["color_count"] == 0 for q in st.frame_planes(dA, **kw)["planes"])
+
+
+def test_plane_colour_of_a_downsampled_sensor_cloud(hip_lib, oracle_mod):
+    """The per-sensor route (Frame360.h:479-503: CloudRGBD::getPointCloud + DownsampleRGBD, step 2): a cloud pixel takes the colour of the
+    CENTRE pixel of its 2 x 2 block (DownsampleRGBD.h:240, 285-287)."""
+    from rgbd360_amd.register import Frame360Stages
+    rows, cols, step = 240, 320, 2
+    (rgb, depth), _, _, _ = synth.make_pinhole_pair(cols, rows, seed=3)       # a pinhole view of the synthetic room
+    rgb = rgb.copy()
+    rgb[:, : cols // 2, 0] = 230                                  # the left half of the view is reddish
+    st = Frame360Stages(_mk(hip_lib, 2))
+    st.set_color_image(rgb, step=step)
+    r2, c2 = rows // step, cols // step
+    xyz = st.sensor_cloud(depth, step, 0.3, 10.0)
+    nrm = st.normals(xyz, r2, c2, 0.02, 8.0, 0)
+    labels, planes = st.plane_fit(xyz, nrm, r2, c2, 40, 0.0398, 0.02, 0.0013, 0)
+    assert len(planes) >= 2
+    _, want = oracle_mod.f360_plane_colour(labels, rgb, planes, step=step)
+    for p, w in zip(planes, want):
+        assert p["color_count"] == w["color_count"] > 0
+        assert np.abs(p["color_nrgb"] - w["color_nrgb"]).max() <= 1e-7 and np.abs(p["hist_h"] - w["hist_h"]).max() <= 1e-7
+    # the centre-of-block rule: a checker that sampled the block's first pixel instead would disagree
+    _, other = oracle_mod.f360_plane_colour(labels, np.roll(rgb, (1, 1), axis=(0, 1)), planes, step=step)
+    assert any(np.abs(p["color_nrgb"] - w["color_nrgb"]).max() > 1e-5 for p, w in zip(planes, other))
+    # the one-call route (no smoothing, same thresholds) reports the same colour records
+    one = st.sensor_planes(depth, step, 0.3, 10.0, 0.0, 0.05, 0.02, 8.0, 40, 0.0398, 0.02, 0.0013)
+    assert [q["color_count"] for q in one] == [q["color_count"] for q in planes]

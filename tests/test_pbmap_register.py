@@ -82,8 +82,10 @@ def test_default_params_are_the_reference_ini_values():
         for ours, theirs in (("dist_d", "dist_d"), ("angle_deg", "angle"), ("elongation_threshold", "elongation_threshold"),
                              ("area_threshold", "area_threshold"), ("dist_threshold", "dist_threshold"),
                              ("angle_threshold_deg", "angle_threshold"), ("height_threshold", "height_threshold"),
-                             ("cos_normal_threshold", "cos_normal_threshold"), ("min_planes_recognition", "min_planes_recognition")):
+                             ("cos_normal_threshold", "cos_normal_threshold"), ("min_planes_recognition", "min_planes_recognition"),
+                             ("color_threshold", "color_threshold"), ("intensity_threshold", "intensity_threshold")):
             assert abs(getattr(p, ours) - float(ini[theirs])) < 1e-6, (fname, ours)
+        assert p.use_color == 1 and p.hue_threshold == 0.0 and 0.3 < float(ini["hue_threshold"]) < 0.5      # the hue test is opt-in (Frame360.h:673)
 
 
 @pytest.mark.parametrize("mode,trans,rot", [(O.DEFAULT_6DoF, 0.8, 35.0), (O.ODOMETRY_6DoF, 0.06, 2.0), (O.DEFAULT_6DoF, 0.0, 0.0)])
@@ -352,3 +354,137 @@ def test_merge_planes_random_sets_match_the_numpy_restatement():
         assert [(p["count"], p["root"]) for p in got] == [(p["count"], p["root"]) for p in want], trial
         for a, b in zip(got, want):
             assert np.allclose(a["centroid"], b["centroid"], atol=2e-5) and abs(a["area"] - b["area"]) <= 2e-4 * max(b["area"], 1.0)
+
+
+# ---- colour descriptors and the radiometric unary constraint (Frame360.h:1045-1046; configLocaliser_spherical.ini:19-21) ----
+WALL_RGB = [(200, 60, 50), (60, 180, 70), (50, 80, 200), (190, 180, 60), (170, 70, 180), (90, 190, 190)]
+
+
+def colour_fields(rgb, brightness=1.0, rng=None, noise=0.0):
+    """The colour record of a region of (nearly) one colour, as the device derives it: normalised colour, intensity, hue histogram."""
+    c = np.clip(np.asarray(rgb, float) * brightness, 0, 255)
+    if rng is not None and noise > 0:
+        c = np.clip(c + rng.normal(size=3) * noise, 1, 255)
+    s = c.sum()
+    mx, mn = c.max(), c.min()
+    hist = np.zeros(74, np.float32)
+    if mx * 5 <= 255:
+        hist[72] = 1
+    elif (mx - mn) * 5 <= mx:
+        hist[73] = 1
+    else:
+        k = int(np.argmax(c))
+        x, y = c[(k + 1) % 3], c[(k + 2) % 3]
+        h12 = (24 * k + 12 * (x - y) / (mx - mn)) % 72
+        hist[int(h12) % 72] = 1
+    return dict(color_count=1000, color_nrgb=(c / s).astype(np.float32), color_dev=np.full(3, 0.004, np.float32),
+                intensity=np.float32(s), hist_h=hist)
+
+
+def coloured(planes, colours, **kw):
+    return [dict(p, **colour_fields(colours[k % len(colours)], **kw)) for k, p in enumerate(planes)]
+
+
+def test_colour_constraint_rejects_same_shape_planes_of_another_colour():
+    """Two frames of the room whose walls differ in nothing but their colour assignment: geometry alone matches all six walls;
+    with the colour records, a wall whose colour changed is left unmatched, and the walls that kept theirs still fix the pose."""
+    rng = np.random.default_rng(3)
+    T_wA = synth.make_pose(np.eye(3), np.asarray(synth.CAM_A, float))
+    T_wB = T_wA @ motion(rng, 0.3, 12.0)
+    ref = coloured(room_planes(T_wA), WALL_RGB)
+    repainted = list(WALL_RGB)
+    repainted[2] = (60, 200, 60)                      # wall 2 was blue, is green now
+    trg = coloured(room_planes(T_wB), repainted)
+    r = pbmap.register_planes(ref, trg, 0, O.DEFAULT_6DoF)
+    assert r["status"] == 0 and r["match"] == {0: 0, 1: 1, 3: 3, 4: 4, 5: 5}
+    rot_err, tr_err = synth.pose_error(r["pose"], np.linalg.inv(T_wA) @ T_wB)
+    assert rot_err < 2e-6 and tr_err < 5e-6
+    p = pbmap.default_params(False)
+    p.use_color = 0                                   # switched off: the repainted wall matches on its shape again
+    assert pbmap.register_planes(ref, trg, 0, O.DEFAULT_6DoF, p)["match"] == {k: k for k in range(6)}
+    # planes WITHOUT colour (color_count 0) are never rejected for it
+    bare = room_planes(T_wB)
+    assert pbmap.register_planes(ref, bare, 0, O.DEFAULT_6DoF)["match"] == {k: k for k in range(6)}
+
+
+def test_colour_constraint_survives_a_global_brightness_change():
+    """The same scene 25 % darker / brighter: the normalised colour does not move, the intensity stays inside its loose bound
+    (150 of 765) -- every wall still matches.  Only a change large enough to break the intensity bound (x 2) unmatches the bright walls."""
+    rng = np.random.default_rng(4)
+    T_wA = synth.make_pose(np.eye(3), np.asarray(synth.CAM_A, float))
+    T_wB = T_wA @ motion(rng, 0.2, 8.0)
+    ref = coloured(room_planes(T_wA), WALL_RGB, brightness=0.6)
+    for b in (0.45, 0.75):
+        trg = coloured(room_planes(T_wB), WALL_RGB, brightness=b, rng=rng, noise=1.0)
+        r = pbmap.register_planes(ref, trg, 0, O.DEFAULT_6DoF)
+        assert r["status"] == 0 and r["match"] == {k: k for k in range(6)}, b
+    p = pbmap.default_params(False)
+    trg = coloured(room_planes(T_wB), WALL_RGB, brightness=1.2)             # twice as bright: sums differ by 180 - 290
+    assert len(pbmap.register_planes(ref, trg, 0, O.DEFAULT_6DoF, p)["match"]) < 6
+    p.intensity_threshold = 0.0                                            # bound off: normalised colour alone
+    assert pbmap.register_planes(ref, trg, 0, O.DEFAULT_6DoF, p)["match"] == {k: k for k in range(6)}
+
+
+def test_hue_histogram_constraint_is_opt_in():
+    rng = np.random.default_rng(5)
+    T_wA = synth.make_pose(np.eye(3), np.asarray(synth.CAM_A, float))
+    T_wB = T_wA @ motion(rng, 0.2, 8.0)
+    ref = coloured(room_planes(T_wA), WALL_RGB)
+    trg = coloured(room_planes(T_wB), WALL_RGB)
+    for q in trg:                                     # same mean colour, but the histogram says "unsaturated"
+        q["hist_h"] = np.zeros(74, np.float32)
+        q["hist_h"][73] = 1
+    p = pbmap.default_params(False)
+    assert pbmap.register_planes(ref, trg, 0, O.DEFAULT_6DoF, p)["match"] == {k: k for k in range(6)}
+    p.hue_threshold = 0.45                            # configLocaliser_spherical.ini:21
+    assert pbmap.register_planes(ref, trg, 0, O.DEFAULT_6DoF, p)["match"] == {}
+    assert O.register_planes(ref, trg, 0, O.DEFAULT_6DoF, params_dict(p))["match"] == {}
+
+
+@pytest.mark.parametrize("mode", [O.DEFAULT_6DoF, O.ODOMETRY_6DoF])
+def test_colour_matches_numpy_restatement_on_random_scenes(mode):
+    """Library vs the independent numpy restatement with colour records on every plane: colours drawn so that some true pairs are
+    within the thresholds, some are not, and clutter planes carry random colours; hue test on in half of the trials."""
+    rng = np.random.default_rng(300 + mode)
+    odo = mode == O.ODOMETRY_6DoF
+    fewer = 0
+    for trial in range(20):
+        T_wA = synth.make_pose(np.eye(3), np.asarray(synth.CAM_A, float))
+        T_wB = T_wA @ motion(rng, 0.08 if odo else rng.uniform(0.1, 0.8), 3.0 if odo else rng.uniform(0, 40))
+        cols_a = [tuple(rng.integers(20, 236, size=3)) for _ in range(6)]
+        cols_b = [tuple(np.clip(np.asarray(c) + rng.normal(size=3) * (4 if rng.random() < 0.7 else 60), 1, 255)) for c in cols_a]
+        ref = coloured(room_planes(T_wA, rng, 0.003, 0.003), cols_a)
+        trg = coloured(room_planes(T_wB, rng, 0.003, 0.003), cols_b, brightness=rng.uniform(0.8, 1.2))
+        for k in range(int(rng.integers(0, 3))):
+            ref.append(dict(clutter_plane(rng, 100 + k), **colour_fields(tuple(rng.integers(0, 256, size=3)))))
+            trg.append(dict(clutter_plane(rng, 200 + k), **colour_fields(tuple(rng.integers(0, 256, size=3)))))
+        trg = [trg[k] for k in rng.permutation(len(trg))]
+        p = pbmap.default_params(odo)
+        if trial % 2:
+            p.hue_threshold = 0.45
+        got = pbmap.register_planes(ref, trg, 0, mode, p)
+        want = O.register_planes(ref, trg, 0, mode, params_dict(p))
+        assert got["status"] == want["status"] and got["match"] == want["match"], trial
+        if want["status"] == 0:
+            rot_err, tr_err = synth.pose_error(got["pose"], want["pose"])
+            assert rot_err < 2e-6 and tr_err < 5e-6
+        p.use_color = 0
+        fewer += len(got["match"]) < len(pbmap.register_planes(ref, trg, 0, mode, p)["match"])
+    assert fewer >= 3          # the colour test really removed matches in some scenes
+
+
+def test_merged_planes_pool_their_colour():
+    """rgbd360_merge_planes (Frame360::mergePlanes -> mergePlane2 + calcMainColor on the pooled inliers): the merged record's colour
+    is the count-weighted pool of its pieces'."""
+    T = synth.make_pose(np.eye(3), np.asarray(synth.CAM_A, float))
+    wall = room_planes(T)[2]
+    a = dict(wall, count=3000, area=np.float32(4.0), **colour_fields((200, 60, 50)))
+    b = dict(wall, count=1000, area=np.float32(2.0), root=7, **colour_fields((180, 80, 50)))
+    b["centroid"] = (np.asarray(wall["centroid"]) + 0.1 * np.asarray(wall["ppal_dir"])).astype(np.float32)
+    a["color_count"], b["color_count"] = 3000, 1000
+    out = pbmap.merge_planes([a, b])
+    assert len(out) == 1 and out[0]["color_count"] == 4000
+    want = (3000 * a["color_nrgb"].astype(np.float64) + 1000 * b["color_nrgb"].astype(np.float64)) / 4000
+    assert np.abs(out[0]["color_nrgb"] - want).max() < 1e-6
+    assert abs(out[0]["intensity"] - (3000 * float(a["intensity"]) + 1000 * float(b["intensity"])) / 4000) < 1e-3
+    assert abs(out[0]["hist_h"].sum() - 1.0) < 1e-5 and (out[0]["color_dev"] >= 0.004 - 1e-6).all()
