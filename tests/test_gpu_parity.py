@@ -1576,3 +1576,38 @@ def test_plane_colour_of_a_downsampled_sensor_cloud(hip_lib, oracle_mod):
     # the one-call route (no smoothing, same thresholds) reports the same colour records
     one = st.sensor_planes(depth, step, 0.3, 10.0, 0.0, 0.05, 0.02, 8.0, 40, 0.0398, 0.02, 0.0013)
     assert [q["color_count"] for q in one] == [q["color_count"] for q in planes]
+
+
+def test_colour_constraint_on_device_planes(hip_lib):
+    """The chain the reference's keyframe link runs (Frame360 planes with their colour -> RegisterPbMap): two views of the synthetic room
+    with their own colour panoramas match as they do without colour (same albedo seen from two poses: the descriptors agree well inside
+    the .ini thresholds); the SAME geometry with the second view's colour channels rotated (every wall another colour) matches nothing
+    -- walls of equal shape and different colour are not paired -- while a 20 % darker second view still matches everything."""
+    from rgbd360_amd import pbmap
+    from rgbd360_amd.register import Frame360Stages
+    W, H = 512, 256
+    (rgbA, dA), (rgbB, dB), T = synth.make_pair(W, H, seed=5, trans=0.06, rot_deg=2.0)
+    rgbA, rgbB = rgbA.copy(), rgbB.copy()
+    for rgb in (rgbA, rgbB):                 # the generator's walls are grey-ish: tint them (a colour per octant of the panorama)
+        for k in range(8):
+            rgb[:, k * W // 8:(k + 1) * W // 8, k % 3] = np.minimum(255, rgb[:, k * W // 8:(k + 1) * W // 8, k % 3].astype(int) + 90).astype(np.uint8)
+    st = Frame360Stages(_mk(hip_lib, 3))
+
+    def planes(depth, rgb):
+        st.set_color_image(rgb)
+        return st.frame_planes(depth, convention=2, angular_threshold=0.03)["planes"]
+    pa, pb = planes(dA, rgbA), planes(dB, rgbB)
+    assert all(p["color_count"] > 0 for p in pa + pb)
+    par = pbmap.default_params(True)
+    with_colour = pbmap.register_planes(pa, pb, 0, pbmap.ODOMETRY_6DoF, par)
+    par.use_color = 0
+    without = pbmap.register_planes(pa, pb, 0, pbmap.ODOMETRY_6DoF, par)
+    assert with_colour["status"] == without["status"] == 0 and with_colour["match"] == without["match"] and len(without["match"]) >= 4
+    par.use_color = 1
+    rot, tr = synth.pose_error(with_colour["pose"], T)
+    assert rot < 2e-3 and tr < 5e-3, (rot, tr)
+    repainted = planes(dB, np.ascontiguousarray(rgbB[:, :, [1, 2, 0]]))
+    r = pbmap.register_planes(pa, repainted, 0, pbmap.ODOMETRY_6DoF, par)
+    assert len(r["match"]) < len(without["match"]) and r["status"] != 0, r["match"]
+    darker = planes(dB, (rgbB * 0.8).astype(np.uint8))
+    assert pbmap.register_planes(pa, darker, 0, pbmap.ODOMETRY_6DoF, par)["match"] == without["match"]
