@@ -259,6 +259,13 @@ __device__ __forceinline__ float swap32_add(float a, float b) {   // lanes 0-31:
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
     return a + b;
 }
+// v(lane) + v(lane ^ 32) in every lane (float64): the two halves of a wave exchanged by v_permlane32_swap on the value's two words
+__device__ __forceinline__ double add_other_half_d(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v), lo2 = lo, hi2 = hi;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(lo2));      // lo: lanes 0-31 own | lanes 32-63 own-32 ... see swap32_add
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(hi), "+v"(hi2));
+    return __hiloint2double(hi, lo) + __hiloint2double(hi2, lo2);
+}
 __device__ __forceinline__ float swap16_add(float a, float b) {   // even rows: a's row pair, odd rows: b's row pair
     asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
     return a + b;
@@ -849,17 +856,21 @@ __device__ __forceinline__ bool lu_inverse6_lanes(const float* M /*LDS, column-m
         float ck[6];
 #pragma unroll
         for (int r = 0; r < 6; ++r) ck[r] = bcast(a[r], k);
+        // Pivot search on the SCALAR unit: the column's six values are wave-uniform (v_readlane results), and for finite values
+        // |x| > |y| is the unsigned comparison of their bit patterns without the sign -- integer compares and selects the scalar ALU
+        // does beside the vector pipe (as float compares they were 15 v_cmp + 30 v_cndmask of the solve's one busy wave).  Same pivot as
+        // gn::inverse6's float comparison for every finite column (first of equal magnitudes wins in both).
         int piv = k;
-        float best = fabsf(ck[k]);
+        unsigned best = __float_as_uint(ck[k]) & 0x7fffffffu;
 #pragma unroll
         for (int r = k + 1; r < 6; ++r) {
-            const float v = fabsf(ck[r]);
+            const unsigned v = __float_as_uint(ck[r]) & 0x7fffffffu;
             if (v > best) {
                 best = v;
                 piv = r;
             }
         }
-        if (best == 0.f) ok = false;
+        if (best == 0u) ok = false;
 #pragma unroll
         for (int r = k + 1; r < 6; ++r)
             if (piv == r) {
@@ -986,7 +997,7 @@ constexpr int kSolveThreads = 1024;
 // LDS of one solve: the staged state, the per-thread-group partial sums and the hand-over slots of the three working waves.
 struct SolveShared {
     GNState sst;
-    double red[kSolveThreads / kNumPartials][kNumPartials];
+    double red[kSolveThreads / 64][kNumPartials];      // per wave: the sum of its two row groups (q = 2 w, 2 w + 1), see reduce_rows_to_lds
     float shH[36], shM[36], shInv[36], shE[16], shCand[16], shUpd[6];
     int shGo, shRank, shLuOk;
     unsigned long long stamp0, stamp[8];      // diagnostic build only (RGBD360_SOLVE_STAMPS)
@@ -1004,8 +1015,14 @@ struct SolveShared {
 //
 // solve_totals: column sums of sh.red into sst.tot (fixed order); returns the damping the rank test will use, read while nobody
 // writes the staged state (wave 0 updates first / lambda in solve_waves).  A barrier behind it.
+// A thread's sum s of its rows (thread = row group q = tid / 32, value v = tid % 32) -> the LDS table of solve_totals: the two row
+// groups a wave holds (lanes v and v + 32) are added in registers first, so the serial chain of solve_totals is 16 adds, not 32.
+__device__ __forceinline__ void reduce_rows_to_lds(SolveShared& sh, double s) {
+    const double pair = add_other_half_d(s);
+    if ((threadIdx.x & 63) < kNumPartials) sh.red[threadIdx.x >> 6][threadIdx.x & 31] = pair;
+}
 __device__ __forceinline__ float solve_totals(SolveShared& sh) {
-    constexpr int Q = kSolveThreads / kNumPartials;
+    constexpr int Q = kSolveThreads / 64;
     const int tid = threadIdx.x;
     if (tid < kNumPartials) {
         double t = 0.0;
@@ -1281,7 +1298,7 @@ __device__ __forceinline__ void solve_block(GNState* st_g, const double* __restr
 #pragma unroll
         for (int j = 0; j < 16; ++j) s += tmp[j];
     }
-    sh.red[q][v] = s;
+    reduce_rows_to_lds(sh, s);
     __syncthreads();
     SOLVE_STAMP(0);
     if (cfg.mode == 0 && (sh.sst.done || sh.sst.level_active != cfg.level)) {            // uniform: finished / other level
@@ -1371,7 +1388,7 @@ __device__ __forceinline__ int stage_pending(SolveShared& sh, const GNState* __r
     double s = 0.0;
 #pragma unroll
     for (int j = 0; j < J; ++j) s += (q + j * Q < nb) ? tmp[j] : 0.0;      // the order of solve_block's sum (its zero rows add nothing)
-    sh.red[q][v] = s;
+    reduce_rows_to_lds(sh, s);
     if (tid < kStateWords) reinterpret_cast<int*>(&sh.sst)[tid] = word;
 #ifdef RGBD360_SOLVE_STAMPS
     if (tid == 0) {
