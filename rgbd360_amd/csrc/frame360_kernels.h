@@ -1156,6 +1156,32 @@ __global__ void k_f360_assign(const int* __restrict__ label, const unsigned long
     slot_of_root[i] = slot;
 }
 
+// The same over the compact run-start lists of k_f360_ccl_runs (a root is a run start): one thread per run start, a block per image row,
+// instead of one thread per PIXEL reading its label to find out that it is not a root (14.5 us at 4096 x 2048 for ~10 k roots).
+__global__ __launch_bounds__(kRootsThreads) void k_f360_assign_list(const int* __restrict__ starts, const int* __restrict__ nstarts, int cols,
+                                                                      const int* __restrict__ label, const unsigned long long* __restrict__ count,
+                                                                      int min_inliers, int max_slots, int* __restrict__ slot_of_root,
+                                                                      int* __restrict__ root_of_slot, int* __restrict__ count_of_slot,
+                                                                      int* __restrict__ n_slots, unsigned long long* __restrict__ mom, int mom_replicas) {
+    const int r = blockIdx.x;
+    const int ns = nstarts[r];
+    for (int k = threadIdx.x; k < ns; k += kRootsThreads) {
+        const int i = starts[(size_t)r * cols + k];
+        if (label[i] != i) continue;
+        int slot = -1;
+        if (count[i] > (unsigned long long)min_inliers) {
+            const int s = atomicAdd(n_slots, 1);
+            if (s < max_slots) {
+                slot = s;
+                root_of_slot[s] = i;
+                count_of_slot[s] = (int)count[i];
+                for (int q = 0; q < mom_replicas * 9; ++q) mom[((size_t)(q / 9) * max_slots + s) * 9 + q % 9] = 0ull;
+            }
+        }
+        slot_of_root[i] = slot;
+    }
+}
+
 // 9 raw moments per selected region (sum x, y, z, xx, xy, xz, yy, yz, zz) in 2^-24 fixed point, two's complement in u64, at a
 // cost that does not depend on how fragmented the label image is.  A lane owns 8 CONSECUTIVE pixels, so the slots a wave sees
 // form runs along the lanes: every lane sums its pixels in registers (flushing to the LDS hash only where the slot changes

@@ -142,16 +142,33 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_occ(LevelDev lv, EvalCons
     A.nP = A.nD = A.nVis = 0;
 
     const int n_steps = (end - base + kEvalThreads - 1) / kEvalThreads;      // wave-uniform: the ballots count whole waves
-    for (int k = 0; k < n_steps; ++k) {
+    // What a step needs that does not depend on its warp -- source record, run byte, own node -- is requested one step ahead: a step
+    // then waits for ONE memory round trip (its gathers) instead of two in a row (round 4: the pass is latency-bound, not issue-bound).
+    auto index_of = [&](int k, bool& in_range) {
         const int i = base + k * kEvalThreads + (int)threadIdx.x;
-        const bool in_range = i < end;
-        const int ic = in_range ? i : lv.n - 1;
-        const float4 s = lv.src[ic];
+        in_range = i < end;
+        return in_range ? i : lv.n - 1;
+    };
+    bool in_next;
+    int ic_next = index_of(0, in_next);
+    float4 s_next = lv.src[ic_next];
+    unsigned info_next = (unsigned)runinfo[ic_next];
+    int4 own_next = nodes[ic_next];
+    for (int k = 0; k < n_steps; ++k) {
+        const bool in_range = in_next;
+        const int ic = ic_next;
+        const float4 s = s_next;
+        const unsigned info = in_range ? info_next : 0u;                     // k_occ_build's run record at this pose
+        const int4 own = own_next;                                           // this pixel's node if it ends a run (speculative)
+        if (k + 1 < n_steps) {                                               // uniform
+            ic_next = index_of(k + 1, in_next);
+            s_next = lv.src[ic_next];
+            info_next = (unsigned)runinfo[ic_next];
+            own_next = nodes[ic_next];
+        }
         float X, Y, Z, rho2, d2;
         bool vis;
         unsigned ti = warp_pixel(T, wc, s.x, s.y, s.z, lv, X, Y, Z, rho2, d2, vis);
-        const unsigned info = in_range ? (unsigned)runinfo[ic] : 0u;         // k_occ_build's run record at this pose
-        const int4 own = nodes[ic];                                          // this pixel's node if it ends a run (speculative)
         const bool cand = (info & 0x40u) != 0;
         ti = cand ? ti : 0u;
         const int hd = occ_decode(head[ti], gen);

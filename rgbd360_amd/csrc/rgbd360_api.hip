@@ -2123,10 +2123,10 @@ int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float
     uint8_t* flags = ctx->f_change;
     hipLaunchKernelGGL(k_f360_link_flags, dim3((cols + kLinkTW - 1) / kLinkTW, (rows + kLinkTH - 1) / kLinkTH), dim3(kLinkTW), 0, ctx->stream,
                        ctx->f_xyz, ctx->f_normals, rows, cols, cosf(angular_threshold), distance_threshold, depth_mode, flags);
-    // run starts as compact per-row lists for the root pass: in f_slot_of_root (written by k_f360_assign only after the roots are known)
-    // and, for the counts, in the tail of f_hd (the depth-change mask is spent once the distance map exists); RGBD360_CCL_LISTS=0: A/B
+    // run starts as compact per-row lists for the root pass and the slot assignment: in f_window (the normal-map stage's window plane,
+    // spent by now; the refinement takes it over later) and, for the counts, in the tail of f_hd (the depth-change mask is spent once the distance map exists); RGBD360_CCL_LISTS=0: A/B
     static const bool lists_off = [] { const char* e = getenv("RGBD360_CCL_LISTS"); return e && atoi(e) == 0; }();
-    int* run_starts = lists_off ? nullptr : ctx->f_slot_of_root;
+    int* run_starts = lists_off ? nullptr : ctx->f_window;        // (the window plane of the normal-map stage is spent; f_slot_of_root stays free for k_f360_assign_list's writes)
     int* n_run_starts = lists_off ? nullptr : reinterpret_cast<int*>(ctx->f_hd + (((size_t)n + 15) & ~(size_t)15));      // n + 4 rows <= 3 n + 64 bytes
     hipLaunchKernelGGL(k_f360_ccl_runs, dim3((rows + kRunRowsPerBlock - 1) / kRunRowsPerBlock), dim3(64 * kRunRowsPerBlock), 0, ctx->stream,
                        flags, rows, cols, ctx->f_label, run_starts, n_run_starts);
@@ -2161,8 +2161,13 @@ int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float
     hipLaunchKernelGGL(k_f360_finish_count, dim3((n + kAggThreads * kCntPerThread - 1) / (kAggThreads * kCntPerThread)), dim3(kAggThreads), 0,
                        ctx->stream, flags, n, ctx->f_label, ctx->f_count, ctx->f_nslots);
     const dim3 bagg(kAggThreads);
-    hipLaunchKernelGGL(k_f360_assign, g1, b, 0, ctx->stream, ctx->f_label, ctx->f_count, n, min_inliers, kF360MaxSlots,
-                       ctx->f_slot_of_root, ctx->f_root_of_slot, ctx->f_count_of_slot, ctx->f_nslots, ctx->f_mom, f360::kMomReplicas);
+    if (run_starts)
+        hipLaunchKernelGGL(k_f360_assign_list, dim3(rows), dim3(kRootsThreads), 0, ctx->stream, run_starts, n_run_starts, cols, ctx->f_label, ctx->f_count,
+                           min_inliers, kF360MaxSlots, ctx->f_slot_of_root, ctx->f_root_of_slot, ctx->f_count_of_slot, ctx->f_nslots, ctx->f_mom,
+                           f360::kMomReplicas);
+    else
+        hipLaunchKernelGGL(k_f360_assign, g1, b, 0, ctx->stream, ctx->f_label, ctx->f_count, n, min_inliers, kF360MaxSlots,
+                           ctx->f_slot_of_root, ctx->f_root_of_slot, ctx->f_count_of_slot, ctx->f_nslots, ctx->f_mom, f360::kMomReplicas);
     const dim3 gmom((n + kAggThreads * kMomPerThread - 1) / (kAggThreads * kMomPerThread));
     hipLaunchKernelGGL(k_f360_moments, gmom, bagg, 0, ctx->stream, ctx->f_xyz, ctx->f_label, ctx->f_slot_of_root, n, ctx->f_mom, kF360MaxSlots);
     // hull stage: per slot the in-plane frame (and an empty extremes row); the extremes themselves now, or -- with the refinement
