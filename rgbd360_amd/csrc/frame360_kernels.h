@@ -1001,7 +1001,7 @@ __global__ void k_f360_ccl_roots(const uint8_t* __restrict__ flags, int n, int* 
 // The same over the compact lists k_f360_ccl_runs left: one thread per run start, a block per image row.  (One thread per PIXEL reading
 // its flag byte made 32 k waves whose only load was a 64-byte line, and the chases -- up to nine dependent hops -- started behind it:
 // 17-20 us at 2048 x 1024.)
-constexpr int kRootsThreads = 256;
+constexpr int kRootsThreads = 1024;     // (256 until round 4: a border row without normals is one run start per pixel, i.e. cols / 256 dependent rounds of pointer chases)
 __global__ __launch_bounds__(kRootsThreads) void k_f360_ccl_roots_list(const int* __restrict__ starts, const int* __restrict__ nstarts, int cols,
                                                                          int* __restrict__ label, unsigned long long* __restrict__ count) {
     const int r = blockIdx.x;
@@ -1158,27 +1158,40 @@ __global__ void k_f360_assign(const int* __restrict__ label, const unsigned long
 
 // The same over the compact run-start lists of k_f360_ccl_runs (a root is a run start): one thread per run start, a block per image row,
 // instead of one thread per PIXEL reading its label to find out that it is not a root (14.5 us at 4096 x 2048 for ~10 k roots).
-__global__ __launch_bounds__(kRootsThreads) void k_f360_assign_list(const int* __restrict__ starts, const int* __restrict__ nstarts, int cols,
+constexpr int kAssignThreads = 1024;      // a border row without normals is one run start per pixel: its list is walked in cols / 1024 dependent rounds
+__global__ __launch_bounds__(kAssignThreads) void k_f360_assign_list(const int* __restrict__ starts, const int* __restrict__ nstarts, int cols,
                                                                       const int* __restrict__ label, const unsigned long long* __restrict__ count,
                                                                       int min_inliers, int max_slots, int* __restrict__ slot_of_root,
                                                                       int* __restrict__ root_of_slot, int* __restrict__ count_of_slot,
                                                                       int* __restrict__ n_slots, unsigned long long* __restrict__ mom, int mom_replicas) {
     const int r = blockIdx.x;
     const int ns = nstarts[r];
-    for (int k = threadIdx.x; k < ns; k += kRootsThreads) {
-        const int i = starts[(size_t)r * cols + k];
-        if (label[i] != i) continue;
-        int slot = -1;
-        if (count[i] > (unsigned long long)min_inliers) {
+    const int lane = threadIdx.x & 63;
+    for (int k0 = 0; k0 < ns; k0 += kAssignThreads) {            // uniform trip count: the waves clear the new slots' moment rows together
+        const int k = k0 + (int)threadIdx.x;
+        int slot = -1, i = -1;
+        if (k < ns) {
+            i = starts[(size_t)r * cols + k];
+            if (label[i] != i) i = -1;
+        }
+        if (i >= 0 && count[i] > (unsigned long long)min_inliers) {
             const int s = atomicAdd(n_slots, 1);
             if (s < max_slots) {
                 slot = s;
                 root_of_slot[s] = i;
                 count_of_slot[s] = (int)count[i];
-                for (int q = 0; q < mom_replicas * 9; ++q) mom[((size_t)(q / 9) * max_slots + s) * 9 + q % 9] = 0ull;
             }
         }
-        slot_of_root[i] = slot;
+        if (i >= 0) slot_of_root[i] = slot;
+        // the moment rows of a new slot start at zero (no memset of the 16 x 4096 x 9 table): 144 words, written by the whole wave (one
+        // thread writing them one after the other is 19 us of a lone wave's issue rate)
+        unsigned long long fresh = __ballot(slot >= 0);
+        while (fresh) {
+            const int src = __builtin_ctzll(fresh);
+            fresh &= fresh - 1;
+            const int s = __builtin_amdgcn_readlane(slot, src);
+            for (int q = lane; q < mom_replicas * 9; q += 64) mom[((size_t)(q / 9) * max_slots + s) * 9 + q % 9] = 0ull;
+        }
     }
 }
 

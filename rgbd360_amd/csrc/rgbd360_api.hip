@@ -2162,7 +2162,7 @@ int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float
                        ctx->stream, flags, n, ctx->f_label, ctx->f_count, ctx->f_nslots);
     const dim3 bagg(kAggThreads);
     if (run_starts)
-        hipLaunchKernelGGL(k_f360_assign_list, dim3(rows), dim3(kRootsThreads), 0, ctx->stream, run_starts, n_run_starts, cols, ctx->f_label, ctx->f_count,
+        hipLaunchKernelGGL(k_f360_assign_list, dim3(rows), dim3(kAssignThreads), 0, ctx->stream, run_starts, n_run_starts, cols, ctx->f_label, ctx->f_count,
                            min_inliers, kF360MaxSlots, ctx->f_slot_of_root, ctx->f_root_of_slot, ctx->f_count_of_slot, ctx->f_nslots, ctx->f_mom,
                            f360::kMomReplicas);
     else
