@@ -616,33 +616,53 @@ __device__ __forceinline__ void eval_span(const PoseRT& T, const WarpConsts& wc,
     const int n_steps = NS * ((end - base + kEvalThreads - 1) / kEvalThreads);
     const int tid = (int)threadIdx.x;
     const unsigned tid16 = (unsigned)tid << 4;
+    // WAVE REBALANCING (round 4).  A SIMD's issue arbiter favours its oldest wave: with one 64-pixel group per wave and step, the four
+    // waves a SIMD holds leave the loop 6.0 / 6.4 / 7.0 / 8.0 us after its start (per-wave stamps, tools/eval_stamps.py: always in
+    // this order), and the block's barrier -- the kernel -- waits for the youngest.  So the layout's four oldest waves (0-3: one per
+    // SIMD) take over the LAST step's groups of its four youngest (12-15): 9 / 8 / 8 / 7 groups per wave at 2048 x 1024 instead of
+    // 8 each.  In the 1024-lane layout: lanes 0-255 get an extra step whose pixels are those of lanes 768-1023 in the span's last
+    // step (first pixel 256 short of a regular step's), lanes 768-1023 stop one step early.  A 512-thread block plays the same layout
+    // (its waves 0-3 = layout waves 0-3 and 8-11, its waves 4-7 = 4-7 and 12-15; the extra half-step is an even one: set A, the
+    // dropped one an odd one: set B), so the sums stay bit-identical between the two block shapes.  Spans of fewer than 4 steps keep
+    // one group per wave and step.
+    const int wave_id = tid >> 6;
+#ifdef RGBD360_NO_REBAL
+    const bool rebal = false;
+#else
+    const bool rebal = n_steps >= 4 * NS;
+#endif
+    const int my_steps = n_steps + (rebal ? ((wave_id < 4 ? 1 : 0) - (wave_id >= THREADS / 64 - 4 ? 1 : 0)) : 0);      // wave-uniform
+    auto fpx = [&](int s) { return base + s * THREADS - ((rebal && s == n_steps) ? 256 : 0); };      // first pixel of (half-)step s
+    auto load_step = [&](int s) {
+        if (SRC != 0 && rebal && s == n_steps) SrcForm<SRC>::cursor_init(cur, lv, fpx(s) + tid, THREADS);      // the extra step breaks the cursor's stride
+        return SrcForm<SRC>::load(lv, src0, n_px, fpx(s), tid16, cur);
+    };
     // The loop is unrolled by two with ping-pong register
     // sets (wA / wB) so that no register copy forces an early wait: while the arithmetic of step k runs, the gathers
-    // of step k+1 and the source record of step k+2 are in flight.  `first` = first pixel of step k (wave-uniform).
+    // of step k+1 and the source record of step k+2 are in flight.
     PixW wB;
-    int first = base;
-    typename SrcForm<SRC>::T sA = SrcForm<SRC>::load(lv, src0, n_px, first + 2 * THREADS, tid16, cur);
+    typename SrcForm<SRC>::T sA = load_step(2);
     int k = 0;
 #define RGBD360_EVAL_LOOP_BODY(CHECK)                                                                                    \
-        warp_stage<METHOD, CHECK, SRC>(sB, tid < end - (first + THREADS), T, wc, lv, bufs, wB);                         \
-        sB = SrcForm<SRC>::load(lv, src0, n_px, first + 3 * THREADS, tid16, cur);                                       \
+        warp_stage<METHOD, CHECK, SRC>(sB, tid < end - fpx(k + 1), T, wc, lv, bufs, wB);                                \
+        sB = load_step(k + 3);                                                                                          \
         consume_stage<METHOD, HG>(wA, lv, ec, AA);                                                                      \
-        warp_stage<METHOD, CHECK, SRC>(sA, tid < end - (first + 2 * THREADS), T, wc, lv, bufs, wA);                     \
-        sA = SrcForm<SRC>::load(lv, src0, n_px, first + 4 * THREADS, tid16, cur);                                       \
+        warp_stage<METHOD, CHECK, SRC>(sA, tid < end - fpx(k + 2), T, wc, lv, bufs, wA);                                \
+        sA = load_step(k + 4);                                                                                          \
         consume_stage<METHOD, HG>(wB, lv, ec, AB);
     // steady state: straight-line body (no control-flow joins, so the compiler's waits are counted, not vmcnt(0)).  Only the last NS
-    // steps of a span can be partial, so the steps this loop warps (k + 1, k + 2 <= n_steps - 1 - NS) need no span test.
-    for (; k + 2 + NS < n_steps; k += 2, first += 2 * THREADS) {
+    // steps of a span (and the extra one) can be partial, so the steps this loop warps (k + 1, k + 2 <= n_steps - 1 - NS) need no span test.
+    for (; k + 2 + NS < n_steps; k += 2) {
         RGBD360_EVAL_LOOP_BODY(false)
     }
-    // the same body with the span test for the (at most NS / 2 + 1) trips that touch the span's last steps
-    for (; k + 2 < n_steps; k += 2, first += 2 * THREADS) {
+    // the same body with the span test for the trips that touch the span's last steps
+    for (; k + 2 < my_steps; k += 2) {
         RGBD360_EVAL_LOOP_BODY(true)
     }
 #undef RGBD360_EVAL_LOOP_BODY
     // tail: one or two steps left, wA holds step k
-    if (k + 1 < n_steps) {
-        warp_stage<METHOD, true, SRC>(sB, tid < end - (first + THREADS), T, wc, lv, bufs, wB);
+    if (k + 1 < my_steps) {
+        warp_stage<METHOD, true, SRC>(sB, tid < end - fpx(k + 1), T, wc, lv, bufs, wB);
         consume_stage<METHOD, HG>(wA, lv, ec, AA);
         consume_stage<METHOD, HG>(wB, lv, ec, AB);
     } else {
@@ -654,6 +674,10 @@ __device__ __forceinline__ void eval_span(const PoseRT& T, const WarpConsts& wc,
     // the loop is not waiting for a deeper queue, tools/ab_libs.py.)
 
     ESTAMP(2);
+#ifdef RGBD360_EVAL_STAMPS
+    if ((threadIdx.x & 63) == 0)      // every wave's own "loop done" (diagnostic rows nb + 32 ...: 16 values per block)
+        partials[(size_t)(nb + 32) * kNumPartials + (size_t)b * 16 + (threadIdx.x >> 6)] = (double)(__builtin_amdgcn_s_memrealtime() - es0);
+#endif
     // ---- reduction: lanes -> wave (halving butterfly, f32) -> block (f64 via LDS) -> one partial row ----
     __shared__ double red[kEvalThreads / 64][kNumPartials];
     const int lane = threadIdx.x & 63;
@@ -1371,13 +1395,14 @@ __device__ __forceinline__ int stage_pending(SolveShared& sh, const GNState* __r
     const int tid = threadIdx.x;
     const int v = tid % kNumPartials, q = tid / kNumPartials;
     double tmp[J];
-    if (rows_hint <= Q) {                       // uniform (scalar compare on a preloaded argument): two straight-line variants
-        tmp[0] = partials[(size_t)q * kNumPartials + v];
+    tmp[0] = partials[(size_t)q * kNumPartials + v];
 #pragma unroll
-        for (int j = 1; j < J; ++j) tmp[j] = 0.0;
-    } else {
+    for (int j = 1; j < J; ++j) tmp[j] = 0.0;
+    // (fall-through = the full table: the level-0 launch runs straight-line code -- as an if / else with the short form first its loads
+    // left 0.2 us later, behind a taken branch into a cold instruction-cache line)
+    if (rows_hint > Q) {                        // uniform: a scalar compare on a preloaded argument
 #pragma unroll
-        for (int j = 0; j < J; ++j) tmp[j] = partials[(size_t)(q + j * Q) * kNumPartials + v];
+        for (int j = 1; j < J; ++j) tmp[j] = partials[(size_t)(q + j * Q) * kNumPartials + v];
     }
     int word = 0;
     if (tid < kStateWords) word = reinterpret_cast<const int*>(st_in)[tid];

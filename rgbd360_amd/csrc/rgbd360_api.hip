@@ -250,7 +250,7 @@ int ensure_levels(rgbd360_ctx* ctx, int rows, int cols) {
     hipFree(ctx->d_partials); hipFree(ctx->d_partials_alt);
     ctx->d_partials = ctx->d_partials_alt = nullptr;
     // at least the kPendingRows rows stage_pending always loads, + diagnostic rows
-    const size_t part_bytes = (size_t)(std::max((max_blocks + 31) / 32 * 32, kPendingRows) + 8 + max_blocks / 16 + 2) * kNumPartials * sizeof(double);
+    const size_t part_bytes = (size_t)(std::max((max_blocks + 31) / 32 * 32, kPendingRows) + 32 + max_blocks / 2 + 2) * kNumPartials * sizeof(double);      // + the diagnostic rows of the stamp builds
     HIPC(ctx, hipMalloc(&ctx->d_partials, part_bytes));
     HIPC(ctx, hipMalloc(&ctx->d_partials_alt, part_bytes));
     HIPC(ctx, hipMemset(ctx->d_partials, 0, part_bytes));          // the fused pass loads max_blocks rows whatever the pending count
@@ -1412,6 +1412,14 @@ int rgbd360_debug_eval_blocks(rgbd360_ctx* ctx, int level, double* out /*2*nbloc
     HIPC(ctx, hipStreamSynchronize(ctx->stream));
     const int nb = ctx->levels[level].nblocks;
     HIPC(ctx, hipMemcpy(out, ctx->d_partials + (size_t)(nb + 8) * kNumPartials, 2 * nb * sizeof(double), hipMemcpyDeviceToHost));
+    return nb;
+}
+
+int rgbd360_debug_eval_waves(rgbd360_ctx* ctx, int level, double* out /*16*nblocks*/) {      // per wave: "loop done", 100 MHz ticks from its block's start
+    if (!ctx || !out || level < 0 || level >= (int)ctx->levels.size()) return -1;
+    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    const int nb = ctx->levels[level].nblocks;
+    HIPC(ctx, hipMemcpy(out, ctx->d_partials + (size_t)(nb + 32) * kNumPartials, 16 * nb * sizeof(double), hipMemcpyDeviceToHost));
     return nb;
 }
 

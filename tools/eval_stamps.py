@@ -43,6 +43,13 @@ def report(tag, r):
     print("   block run time us: mean %.2f  p10 %.2f  p50 %.2f  p90 %.2f  max %.2f | by position (32 blocks each): %s" % (
         run.mean(), np.percentile(run, 10), np.percentile(run, 50), np.percentile(run, 90), run.max(),
         " ".join("%.1f" % run[k:k + 32].mean() for k in range(0, nb, 32))))
+    wv = np.zeros(16 * 256)
+    L.rgbd360_debug_eval_waves.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    nbw = L.rgbd360_debug_eval_waves(r._ctx(), 0, wv.ctypes.data_as(C.c_void_p))
+    wv = wv[:16 * nbw].reshape(nbw, 16) / 100.0
+    print("   per-wave loop end, mean over blocks (us from block start), wave 0..15: " + " ".join("%.2f" % x for x in wv.mean(0)))
+    print("   last wave - first wave per block: mean %.2f us; slowest wave index histogram: %s" % (
+        (wv.max(1) - wv.min(1)).mean(), np.bincount(wv.argmax(1), minlength=16).tolist()))
     for name, row in (("block 0", st[:6]), ("block nb-1", st[6:])):
         print("   %s: pose %.2f | first stage %.2f | loop %.2f | wave reduce %.2f | end %.2f us" % ((name,) + tuple(row[:5] / 100.0)))
 
