@@ -22,8 +22,8 @@
 // pixel {candidate, prefix maximum within its run, offset to the run's first pixel}.  k_eval_occ, which warps its source pixel
 // anyway, reads that byte, gathers its target's list head together with the target records, and decides "prefix maximum / closest /
 // last" against the run nodes: earlier runs (first pixel smaller) that hold something closer, any run with a larger (1/dist, index)
-// key, any run that ends later.  In the common case -- the pixel is a run of one and alone on its target -- the only node is its
-// own, loaded speculatively by index beside everything else: no dependent round trip at all.  dist = sqrt_rn(d2) and 1/dist =
+// key, any run that ends later.  In the common case -- the pixel is a run of one and alone on its target -- the head word says so
+// by itself (no "more than one run" bit, see occ_decode) and no node is read at all.  dist = sqrt_rn(d2) and 1/dist =
 // rcp_rn(dist) are correctly rounded and identical in both kernels: every comparison is bit-for-bit the oracle's, and nothing
 // depends on the order in which the atomics arrive.
 // Why runs: the long lists are at the poles of the sphere, where a hundred and more pixels of a few neighbouring rows collapse
@@ -39,9 +39,14 @@ namespace r360 {
 
 constexpr float kThresDepthOutliers = 0.3f;      // RPI.h:4525
 
-// head entries: generation (top 8 bits) | source pixel index (24 bits; images are < 16 Mpx); an entry of another generation is
-// an empty list
-__device__ __forceinline__ int occ_decode(int tagged, int gen) { return ((unsigned)tagged >> 24) == (unsigned)gen ? (tagged & 0xFFFFFF) : -1; }
+// head entries: "more than one run" (bit 31) | generation (7 bits) | source pixel index (24 bits; images are < 16 Mpx); an entry of
+// another generation is an empty list.  Bit 31 is set by every run that finds the list non-empty when it links itself in (an atomic
+// OR behind its exchange: the last exchange on a list with two or more runs is always followed by one), so a pass that finds its own
+// pixel at the head of a list WITHOUT the bit knows that list is its own node and nothing else -- the common case by far -- and reads
+// no node at all (round 4; until then every pixel loaded its own 16-byte node speculatively: 61 -> 45 B per pixel).
+constexpr int kOccGenMax = 127;
+constexpr unsigned kOccMulti = 0x80000000u;
+__device__ __forceinline__ int occ_decode(int tagged, int gen) { return (((unsigned)tagged >> 24) & 0x7Fu) == (unsigned)gen ? (tagged & 0xFFFFFF) : -1; }
 
 // Wave scans on the VALU's data-parallel-primitive paths (row_shr 1 / 2 / 4 / 8 inside the rows of 16 lanes, then lane 15 of a row to the
 // next row and lane 31 to the upper half) instead of __shfl_up steps through the LDS crossbar: k_occ_build made 27 crossbar trips per wave,
@@ -82,17 +87,26 @@ __device__ __forceinline__ unsigned long long occ_seg_scan_max(unsigned long lon
 // runinfo byte of a source pixel: bit 6 candidate, bit 7 no earlier member of its run is closer, bits 0-5 offset to the run's first pixel
 // node (int4, indexed by the run's LAST pixel): x = pixel holding the run's largest (1/dist, index) key, y = bits of that 1/dist,
 // z = first pixel of the run, w = next node of the same target pixel (-1: none)
+// the node a run's last pixel writes once the exchange on its target's list head has come back (the only thing that waits for it)
+struct OccNodePending {
+    bool on;
+    int i, first, old_head;
+    unsigned ti;
+    unsigned long long key;
+};
+__device__ __forceinline__ void occ_store_node(const OccNodePending& p, const int gen, int4* __restrict__ nodes, int* __restrict__ head) {
+    if (p.on) {
+        const int nx = occ_decode(p.old_head, gen);
+        nodes[p.i] = make_int4((int)(unsigned)p.key, (int)(unsigned)(p.key >> 32), p.first, nx);
+        if (nx >= 0) atomicOr(&head[p.ti], (int)kOccMulti);      // the list held a run already
+    }
+}
+
+// one source pixel of the build (every lane of the wave takes part in the shuffles; `in` = the lane has a pixel, ic = its clamped index)
 template <int OCC>
-__global__ __launch_bounds__(256) void k_occ_build(LevelDev lv, const GNState* __restrict__ st, int level, int gen, int* __restrict__ head,
-                                                   int4* __restrict__ nodes, unsigned char* __restrict__ runinfo) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    if (st->done || st->level_active != level) return;
-    const bool in = i < lv.n;                          // (no early exit: every lane takes part in the shuffles)
-    const int ic = in ? i : lv.n - 1;
-    const PoseRT T = load_pose(st->cand);
-    const WarpConsts wc = {T.tx, T.ty, T.tz, lv.half_nRows, lv.pi_k};
-    const float4 s = lv.src[ic];
+__device__ __forceinline__ void occ_build_px(const LevelDev& lv, const PoseRT& T, const WarpConsts& wc, const int i, const bool in, const int ic,
+                                             const float4 s, const int lane, const int gen, int* __restrict__ head,
+                                             unsigned char* __restrict__ runinfo, OccNodePending& out) {
     float X, Y, Z, rho2, d2;
     bool vis;
     const unsigned ti = warp_pixel(T, wc, s.x, s.y, s.z, lv, X, Y, Z, rho2, d2, vis);
@@ -109,18 +123,104 @@ __global__ __launch_bounds__(256) void k_occ_build(LevelDev lv, const GNState* _
     const unsigned t_before = (unsigned)R360_DPP(0xFE000000u, tkey, 0x138, 0xF), t_after = (unsigned)R360_DPP(0xFE000000u, tkey, 0x130, 0xF);
     const bool run_head = lane == 0 || t_before != tkey;
     const bool run_tail = lane == 63 || t_after != tkey;
-    const int lead = occ_scan_max(run_head ? lane : 0);      // lane of the run's first member
-    // segmented inclusive max-scan of the key (1/dist bits, pixel): positive floats order like their bit patterns
-    const unsigned long long key = occ_seg_scan_max(((unsigned long long)__float_as_uint(di) << 32) | (unsigned)ic, lead);
-    // the run's maximum BEFORE this member
-    const unsigned long long kprev = ((unsigned long long)(unsigned)R360_DPP(0, (unsigned)(key >> 32), 0x138, 0xF) << 32) | (unsigned)R360_DPP(0, (unsigned)key, 0x138, 0xF);
-    const bool has_prev = lane > lead;
-    const bool pm_run = !(has_prev && __uint_as_float((unsigned)(kprev >> 32)) > di);
-    if (in) runinfo[i] = cand ? (unsigned char)(0x40u | (pm_run ? 0x80u : 0u) | (unsigned)(lane - lead)) : (unsigned char)0;
-    if (cand && run_tail) {
-        const int nx = occ_decode(atomicExch(&head[ti], (int)(((unsigned)gen << 24) | (unsigned)i)), gen);      // (unsigned shift: gen reaches 255)
-        nodes[i] = make_int4((int)(unsigned)key, (int)(unsigned)(key >> 32), i - (lane - lead), nx);
+    int lead = lane;
+    unsigned long long key = ((unsigned long long)__float_as_uint(di) << 32) | (unsigned)ic;
+    bool pm_run = true;
+    // Away from the poles and from depth edges no two neighbouring source pixels land on one target pixel: every lane of the wave is a
+    // run of its own, and the scans (a third of the kernel's vector instructions) would return what each lane already holds.
+    if (__builtin_amdgcn_ballot_w64(!run_head) != 0ull) {      // uniform
+        lead = occ_scan_max(run_head ? lane : 0);            // lane of the run's first member
+        // segmented inclusive max-scan of the key (1/dist bits, pixel): positive floats order like their bit patterns
+        key = occ_seg_scan_max(key, lead);
+        // the run's maximum BEFORE this member
+        const unsigned long long kprev = ((unsigned long long)(unsigned)R360_DPP(0, (unsigned)(key >> 32), 0x138, 0xF) << 32) | (unsigned)R360_DPP(0, (unsigned)key, 0x138, 0xF);
+        const bool has_prev = lane > lead;
+        pm_run = !(has_prev && __uint_as_float((unsigned)(kprev >> 32)) > di);
     }
+    if (in) runinfo[i] = cand ? (unsigned char)(0x40u | (pm_run ? 0x80u : 0u) | (unsigned)(lane - lead)) : (unsigned char)0;
+    out.on = cand && run_tail;
+    out.i = i;
+    out.key = key;
+    out.first = i - (lane - lead);
+    out.old_head = 0;
+    out.ti = ti;
+#ifndef RGBD360_OCC_NOATOMIC      // (timing experiment only: wrong lists)
+    if (out.on) out.old_head = atomicExch(&head[ti], (int)(((unsigned)gen << 24) | (unsigned)i));      // (gen <= kOccGenMax)
+#endif
+}
+
+template <int OCC>
+__global__ __launch_bounds__(256) void k_occ_build(LevelDev lv, const GNState* __restrict__ st, int level, int gen, int* __restrict__ head,
+                                                   int4* __restrict__ nodes, unsigned char* __restrict__ runinfo) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    if (st->done || st->level_active != level) return;
+    const bool in = i < lv.n;                          // (no early exit: every lane takes part in the shuffles)
+    const int ic = in ? i : lv.n - 1;
+    const PoseRT T = load_pose(st->cand);
+    const WarpConsts wc = {T.tx, T.ty, T.tz, lv.half_nRows, lv.pi_k};
+    OccNodePending nd;
+    occ_build_px<OCC>(lv, T, wc, i, in, ic, lv.src[ic], lane, gen, head, runinfo, nd);
+    occ_store_node(nd, gen, nodes, head);
+}
+
+// The occlusion-aware schedule with the solve fused in (round 4): k_occ_build_fs is the build on the pass's own grid (blocks of 1024
+// threads that walk a span of `chunk` pixels: a wave still owns 64 consecutive pixels per step, chunk is a multiple of 1024, so the
+// runs -- and every byte the build leaves -- are k_occ_build's) behind the prologue of k_eval_fs: every block first solves the pass the
+// previous k_eval_occ left pending (cfg.occ selects the occlusion modes' error, RPI.h:3232-4249), block 0 writes the new state into
+// st_out, and k_eval_occ -- the next launch on the stream -- reads its gate and its pose from there.  An iteration is two launches
+// (build + pass) instead of three (build, pass, k_solve).
+template <int OCC>
+__global__ __launch_bounds__(kEvalThreads) void k_occ_build_fs(const GNState* __restrict__ st_in, GNState* __restrict__ st_out,
+                                                                const double* __restrict__ partials_in, int chunk, int level, int nb,
+                                                                int pend_rows_hint, LevelDev lv, SolveCfg cfg, FsInit init, int gen,
+                                                                int* __restrict__ head, int4* __restrict__ nodes,
+                                                                unsigned char* __restrict__ runinfo) {
+    __shared__ SolveShared sh;
+#ifdef RGBD360_SOLVE_STAMPS
+    if (threadIdx.x == 0) sh.stamp0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    int pend = stage_pending(sh, st_in, partials_in, pend_rows_hint);
+    if (init.on) {                              // uniform: the first launch of a schedule initialises the state (k_eval_fs does the same)
+        if (threadIdx.x == 0) level_init_one(&sh.sst, init.pose, 1, 1, level);
+        __syncthreads();
+        pend = 0;
+    }
+    SOLVE_STAMP(0);
+    const int base = blockIdx.x * chunk;
+    const int end = min(base + chunk, lv.n);
+    const int lane = threadIdx.x & 63;
+    auto index_of = [&](int k, bool& in_range) {
+        const int i = base + k * kEvalThreads + (int)threadIdx.x;
+        in_range = i < end;
+        return in_range ? i : lv.n - 1;
+    };
+    // the first source records, which depend on nothing, are in flight during the solve
+    bool in_a, in_b;
+    const int ic_a = index_of(0, in_a), ic_b = index_of(1, in_b);
+    float4 s_a = lv.src[ic_a], s_b = lv.src[ic_b];
+    PoseRT T;
+    const bool run = fs_solve_and_publish(sh, pend, cfg, level, nb, lv.n, st_out, T);
+    if (!run) return;
+    const WarpConsts wc = {T.tx, T.ty, T.tz, lv.half_nRows, lv.pi_k};
+    const int n_steps = (end - base + kEvalThreads - 1) / kEvalThreads;      // uniform
+    // a step's node is stored behind the arithmetic of the NEXT step: the exchange's round trip is covered, not waited for
+    OccNodePending prev = {false, 0, 0, 0, 0u, 0ull};
+    for (int k = 0; k < n_steps; ++k) {
+        bool in;
+        const int ic = index_of(k, in);
+        const float4 s = s_a;
+        s_a = s_b;
+        if (k + 2 < n_steps) {                  // uniform
+            bool in_c;
+            s_b = lv.src[index_of(k + 2, in_c)];
+        }
+        OccNodePending cur;
+        occ_build_px<OCC>(lv, T, wc, base + k * kEvalThreads + (int)threadIdx.x, in, ic, s, lane, gen, head, runinfo, cur);
+        occ_store_node(prev, gen, nodes, head);
+        prev = cur;
+    }
+    occ_store_node(prev, gen, nodes, head);
 }
 
 template <int METHOD, int OCC>
@@ -142,49 +242,70 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_occ(LevelDev lv, EvalCons
     A.nP = A.nD = A.nVis = 0;
 
     const int n_steps = (end - base + kEvalThreads - 1) / kEvalThreads;      // wave-uniform: the ballots count whole waves
-    // What a step needs that does not depend on its warp -- source record, run byte, own node -- is requested one step ahead: a step
-    // then waits for ONE memory round trip (its gathers) instead of two in a row (round 4: the pass is latency-bound, not issue-bound).
+    // Two stages, software-pipelined like the plain pass (round 4: the pass is a chain of memory round trips, not issue-bound): while
+    // the arithmetic of step k runs, the gathers of step k + 1 (list head + target records at its warped pixel) and what step k + 2
+    // needs that does not depend on its warp (source record, run byte) are in flight -- a step waits for neither.
     auto index_of = [&](int k, bool& in_range) {
         const int i = base + k * kEvalThreads + (int)threadIdx.x;
         in_range = i < end;
         return in_range ? i : lv.n - 1;
     };
-    bool in_next;
-    int ic_next = index_of(0, in_next);
-    float4 s_next = lv.src[ic_next];
-    unsigned info_next = (unsigned)runinfo[ic_next];
-    int4 own_next = nodes[ic_next];
-    for (int k = 0; k < n_steps; ++k) {
-        const bool in_range = in_next;
-        const int ic = ic_next;
-        const float4 s = s_next;
-        const unsigned info = in_range ? info_next : 0u;                     // k_occ_build's run record at this pose
-        const int4 own = own_next;                                           // this pixel's node if it ends a run (speculative)
-        if (k + 1 < n_steps) {                                               // uniform
-            ic_next = index_of(k + 1, in_next);
-            s_next = lv.src[ic_next];
-            info_next = (unsigned)runinfo[ic_next];
-            own_next = nodes[ic_next];
-        }
-        float X, Y, Z, rho2, d2;
+    struct Pre { float4 s; unsigned info; int ic; bool in; };
+    auto preload = [&](int k) {
+        Pre p;
+        p.ic = index_of(k, p.in);
+        p.s = lv.src[p.ic];
+        p.info = (unsigned)runinfo[p.ic];
+        return p;
+    };
+    struct Stage { float X, Y, Z, rho2, d2, sw; unsigned info; int ic, hd_raw; F3 tp, td; };
+    auto warp_issue = [&](const Pre& p) {
+        Stage w;
         bool vis;
-        unsigned ti = warp_pixel(T, wc, s.x, s.y, s.z, lv, X, Y, Z, rho2, d2, vis);
+        unsigned ti = warp_pixel(T, wc, p.s.x, p.s.y, p.s.z, lv, w.X, w.Y, w.Z, w.rho2, w.d2, vis);
+        w.info = p.in ? p.info : 0u;                                         // k_occ_build's run record at this pose
+        ti = (w.info & 0x40u) != 0 ? ti : 0u;
+        w.hd_raw = head[ti];
+        w.tp = {0.f, 0.f, 0.f};
+        w.td = {0.f, 0.f, 0.f};
+        if (METHOD != 1) w.tp = lv.trgP[ti];
+        if (METHOD != 0) w.td = lv.trgD[ti];
+        w.sw = p.s.w;
+        w.ic = p.ic;
+        return w;
+    };
+    Pre pre = preload(0);
+    Stage nxt = warp_issue(pre);
+    if (n_steps > 1) pre = preload(1);
+    for (int k = 0; k < n_steps; ++k) {
+        const Stage w = nxt;
+        if (k + 1 < n_steps) {                                               // uniform
+            nxt = warp_issue(pre);
+            if (k + 2 < n_steps) pre = preload(k + 2);
+        }
+        const float X = w.X, Y = w.Y, Z = w.Z, rho2 = w.rho2, d2 = w.d2;
+        const unsigned info = w.info;
+        const int ic = w.ic;
+        const F3 tp = w.tp, td = w.td;
+        struct { float w; } s = {w.sw};
         const bool cand = (info & 0x40u) != 0;
-        ti = cand ? ti : 0u;
-        const int hd = occ_decode(head[ti], gen);
+        const int hd = occ_decode(w.hd_raw, gen);
         const float dist = sqrt_rn(d2);
         const float dist_inv = rcp_rn(dist);
-        F3 tp = {0.f, 0.f, 0.f}, td = {0.f, 0.f, 0.f};
-        if (METHOD != 1) tp = lv.trgP[ti];
-        if (METHOD != 0) td = lv.trgD[ti];
         // the three decisions against the run nodes of the same target pixel
         bool pm = cand && (info & 0x80u) != 0, best = cand, last = cand;
         {
             const unsigned long long key_i = ((unsigned long long)__float_as_uint(dist_inv) << 32) | (unsigned)ic;
             const int my_first = ic - (int)(info & 63u);
             int node = cand ? hd : -1;
+            // the head is this pixel, no second run ever linked itself in, and the pixel starts its run: the list is its own node, a
+            // run of one (a head is the LAST pixel of its run) -- nothing to compare with, nothing to load
+            if (w.hd_raw >= 0 && node == ic && (info & 63u) == 0u) node = -1;
+#ifdef RGBD360_OCC_NOWALK      // (timing experiment only)
+            node = -1;
+#endif
             while (node >= 0) {
-                const int4 nd = node == ic ? own : nodes[node];
+                const int4 nd = nodes[node];
                 const unsigned long long k = ((unsigned long long)(unsigned)nd.y << 32) | (unsigned)nd.x;
                 if (nd.z < my_first && __uint_as_float((unsigned)nd.y) > dist_inv) pm = false;      // an earlier run holds something closer
                 if (k > key_i) best = false;                                                        // not the final owner of the z-buffer cell

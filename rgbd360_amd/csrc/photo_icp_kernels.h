@@ -1430,6 +1430,84 @@ __device__ __forceinline__ float uniform_f(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
 }
 
+// The solve half of a fused launch, behind stage_pending (and the schedule's initialisation): solves the pending pass on the block's
+// own LDS copy of the state, decides what the new state is, hands every wave the pose the new state's `cand` holds (scalar registers)
+// and lets block 0 write the new state (pend_nb = nb if the launch's own pass runs).  Returns whether the launch's level is the active,
+// unfinished one.  Shared by k_eval_fs and the occlusion-aware schedule's k_occ_build_fs (occlusion_kernels.h).
+__device__ __forceinline__ bool fs_solve_and_publish(SolveShared& sh, const int pend, const SolveCfg& cfg, const int level, const int nb,
+                                                     const int n_level_px, GNState* __restrict__ st_out, PoseRT& T) {
+    constexpr int kStateWords = sizeof(GNState) / 4;
+    const int b = blockIdx.x;
+    float lam_spec = 0.f;
+    int solved_level = 0;
+    if (pend > 0) {                             // uniform: the previous launch ran a pass
+        SolveCfg c = cfg;
+        c.level = solved_level = sh.sst.level_active;      // the level that pass belongs to (it ran because this level was active)
+        c.n_pixels = sh.sst.pend_npix;
+        lam_spec = solve_totals(sh);
+        solve_waves(sh, c, lam_spec, /*rank_now=*/false);
+        __syncthreads();
+    }
+    // What solve_finish would now do to the state -- commit the step (on the inverse's word: the rank test, the longest of the three
+    // chains and almost never the one that says no, comes later), or ILL-POSED, or hand a finished level over to the next finer
+    // one -- is DECIDED here by every wave from what the three working waves left in LDS, without another barrier; nothing in LDS
+    // is written any more.  Only block 0 needs the new state itself: its wave 2 assembles it word by word on the way to memory.
+    const bool go = pend > 0 && sh.shGo != 0;
+    const bool commit = go && sh.shLuOk != 0;
+    const bool ill = go && !commit;
+    const bool handover = pend > 0 && !go && !cfg.forced && solved_level > 0 && sh.sst.done && sh.sst.status == 0;      // solve_finish's test
+    const int level_now = handover ? solved_level - 1 : sh.sst.level_active;
+    const bool done_now = handover ? false : (ill || sh.sst.done != 0);
+    const bool run = !done_now && level_now == level;      // uniform; k_eval's gate on the new state
+    const float* P = commit ? sh.shCand : (handover ? sh.sst.pose : sh.sst.cand);      // the pose the new state's `cand` holds
+    T.r00 = uniform_f(P[0]); T.r10 = uniform_f(P[1]); T.r20 = uniform_f(P[2]);
+    T.r01 = uniform_f(P[4]); T.r11 = uniform_f(P[5]); T.r21 = uniform_f(P[6]);
+    T.r02 = uniform_f(P[8]); T.r12 = uniform_f(P[9]); T.r22 = uniform_f(P[10]);
+    T.tx = uniform_f(P[12]); T.ty = uniform_f(P[13]); T.tz = uniform_f(P[14]);
+    if (b == 0 && (threadIdx.x >> 6) == 2) {
+        // block 0, wave 2: the rank verdict on the step just committed, then the new state.  ILL-POSED (RPI.h:4684-4689): status 1,
+        // level done, candidate and update as they were -- and no pending pass: the rows this launch writes are never read.
+        const int lane = threadIdx.x & 63;
+        bool ill_late = false;
+        if (commit) ill_late = solve_rank_wave(sh, lam_spec) != 6;      // (the return value: a lane that did not store shRank may not see it without a barrier)
+        const bool commit_f = commit && !ill_late, ill_f = ill || ill_late, run_f = run && !ill_late;
+        constexpr int kCand = offsetof(GNState, cand) / 4, kUpd = offsetof(GNState, update) / 4;
+        constexpr int kErr = offsetof(GNState, error) / 4, kLam = offsetof(GNState, lambda) / 4;
+        static_assert(offsetof(GNState, new_error) == offsetof(GNState, error) + 8 && offsetof(GNState, diff_error) == offsetof(GNState, error) + 16, "error block");
+        for (int w = lane; w < kStateWords; w += 64) {      // one store per word
+            int val = reinterpret_cast<const int*>(&sh.sst)[w];
+            if (w >= kCand && w < kCand + 16) {
+                if (commit_f) val = __builtin_bit_cast(int, sh.shCand[w - kCand]);
+                if (handover) val = __builtin_bit_cast(int, sh.sst.pose[w - kCand]);
+            }
+            if (w >= kUpd && w < kUpd + 6) {
+                if (commit_f) val = __builtin_bit_cast(int, sh.shUpd[w - kUpd]);
+                if (handover) val = __builtin_bit_cast(int, 1.f);
+            }
+            if (ill_f && (w == offsetof(GNState, status) / 4 || w == offsetof(GNState, done) / 4)) val = 1;
+            if (handover) {       // RPI.h:4590-4604: it = 0, update = (1,..,1), lambda = 1, first pass at the pose reached
+                if (w == offsetof(GNState, level_active) / 4) val = level_now;
+                if (w == offsetof(GNState, it) / 4 || w == offsetof(GNState, done) / 4) val = 0;
+                if (w == offsetof(GNState, first) / 4) val = 1;
+                if (w >= kErr && w < kErr + 6) val = 0;                  // error = new_error = diff_error = 0.0
+                if (w == kLam) val = 0;                                   // lambda = 1.0 (little endian: low word, high word)
+                if (w == kLam + 1) val = 0x3FF00000;
+            }
+            if (w == offsetof(GNState, pend_nb) / 4) val = run_f ? nb : 0;
+            if (w == offsetof(GNState, pend_npix) / 4) val = n_level_px;
+#ifdef RGBD360_SOLVE_STAMPS
+            if (w >= (int)offsetof(GNState, stamps) / 4 && w < (int)offsetof(GNState, stamps) / 4 + 16) {
+                const int si = (w - (int)offsetof(GNState, stamps) / 4) >> 1;      // slot 4 ("end"): now
+                const unsigned long long sv = si == 4 ? __builtin_amdgcn_s_memrealtime() - sh.stamp0 : sh.stamp[si];
+                val = (int)((w & 1) ? (sv >> 32) : (sv & 0xffffffffull));
+            }
+#endif
+            reinterpret_cast<int*>(st_out)[w] = val;
+        }
+    }
+    return run;
+}
+
 template <int METHOD, int SRC = 0>
 __global__ __launch_bounds__(kEvalThreads) void k_eval_fs(const GNState* __restrict__ st_in, GNState* __restrict__ st_out,
                                                            const double* __restrict__ partials_in, double* __restrict__ partials_out,
@@ -1471,74 +1549,8 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_fs(const GNState* __restr
     SrcForm<SRC>::cursor_init(cur, lv, i, kEvalThreads);
     const typename SrcForm<SRC>::T sA = SrcForm<SRC>::load(lv, src0, n_px, base, (unsigned)threadIdx.x << 4, cur);
     const typename SrcForm<SRC>::T sB = SrcForm<SRC>::load(lv, src0, n_px, base + kEvalThreads, (unsigned)threadIdx.x << 4, cur);
-    float lam_spec = 0.f;
-    int solved_level = 0;
-    if (pend > 0) {                             // uniform: the previous launch ran a pass
-        SolveCfg c = cfg;
-        c.level = solved_level = sh.sst.level_active;      // the level that pass belongs to (it ran because this level was active)
-        c.n_pixels = sh.sst.pend_npix;
-        lam_spec = solve_totals(sh);
-        solve_waves(sh, c, lam_spec, /*rank_now=*/false);
-        __syncthreads();
-    }
-    // What solve_finish would now do to the state -- commit the step (on the inverse's word: the rank test, the longest of the three
-    // chains and almost never the one that says no, comes later), or ILL-POSED, or hand a finished level over to the next finer
-    // one -- is DECIDED here by every wave from what the three working waves left in LDS, without another barrier; nothing in LDS
-    // is written any more.  Only block 0 needs the new state itself: its wave 2 assembles it word by word on the way to memory.
-    const bool go = pend > 0 && sh.shGo != 0;
-    const bool commit = go && sh.shLuOk != 0;
-    const bool ill = go && !commit;
-    const bool handover = pend > 0 && !go && !cfg.forced && solved_level > 0 && sh.sst.done && sh.sst.status == 0;      // solve_finish's test
-    const int level_now = handover ? solved_level - 1 : sh.sst.level_active;
-    const bool done_now = handover ? false : (ill || sh.sst.done != 0);
-    const bool run = !done_now && level_now == level;      // uniform; k_eval's gate on the new state
-    const float* P = commit ? sh.shCand : (handover ? sh.sst.pose : sh.sst.cand);      // the pose the new state's `cand` holds
     PoseRT T;
-    T.r00 = uniform_f(P[0]); T.r10 = uniform_f(P[1]); T.r20 = uniform_f(P[2]);
-    T.r01 = uniform_f(P[4]); T.r11 = uniform_f(P[5]); T.r21 = uniform_f(P[6]);
-    T.r02 = uniform_f(P[8]); T.r12 = uniform_f(P[9]); T.r22 = uniform_f(P[10]);
-    T.tx = uniform_f(P[12]); T.ty = uniform_f(P[13]); T.tz = uniform_f(P[14]);
-    if (b == 0 && (threadIdx.x >> 6) == 2) {
-        // block 0, wave 2: the rank verdict on the step just committed, then the new state.  ILL-POSED (RPI.h:4684-4689): status 1,
-        // level done, candidate and update as they were -- and no pending pass: the rows this launch writes are never read.
-        const int lane = threadIdx.x & 63;
-        bool ill_late = false;
-        if (commit) ill_late = solve_rank_wave(sh, lam_spec) != 6;      // (the return value: a lane that did not store shRank may not see it without a barrier)
-        const bool commit_f = commit && !ill_late, ill_f = ill || ill_late, run_f = run && !ill_late;
-        constexpr int kCand = offsetof(GNState, cand) / 4, kUpd = offsetof(GNState, update) / 4;
-        constexpr int kErr = offsetof(GNState, error) / 4, kLam = offsetof(GNState, lambda) / 4;
-        static_assert(offsetof(GNState, new_error) == offsetof(GNState, error) + 8 && offsetof(GNState, diff_error) == offsetof(GNState, error) + 16, "error block");
-        for (int w = lane; w < kStateWords; w += 64) {      // one store per word
-            int val = reinterpret_cast<const int*>(&sh.sst)[w];
-            if (w >= kCand && w < kCand + 16) {
-                if (commit_f) val = __builtin_bit_cast(int, sh.shCand[w - kCand]);
-                if (handover) val = __builtin_bit_cast(int, sh.sst.pose[w - kCand]);
-            }
-            if (w >= kUpd && w < kUpd + 6) {
-                if (commit_f) val = __builtin_bit_cast(int, sh.shUpd[w - kUpd]);
-                if (handover) val = __builtin_bit_cast(int, 1.f);
-            }
-            if (ill_f && (w == offsetof(GNState, status) / 4 || w == offsetof(GNState, done) / 4)) val = 1;
-            if (handover) {       // RPI.h:4590-4604: it = 0, update = (1,..,1), lambda = 1, first pass at the pose reached
-                if (w == offsetof(GNState, level_active) / 4) val = level_now;
-                if (w == offsetof(GNState, it) / 4 || w == offsetof(GNState, done) / 4) val = 0;
-                if (w == offsetof(GNState, first) / 4) val = 1;
-                if (w >= kErr && w < kErr + 6) val = 0;                  // error = new_error = diff_error = 0.0
-                if (w == kLam) val = 0;                                   // lambda = 1.0 (little endian: low word, high word)
-                if (w == kLam + 1) val = 0x3FF00000;
-            }
-            if (w == offsetof(GNState, pend_nb) / 4) val = run_f ? nb : 0;
-            if (w == offsetof(GNState, pend_npix) / 4) val = lv.n;
-#ifdef RGBD360_SOLVE_STAMPS
-            if (w >= (int)offsetof(GNState, stamps) / 4 && w < (int)offsetof(GNState, stamps) / 4 + 16) {
-                const int si = (w - (int)offsetof(GNState, stamps) / 4) >> 1;      // slot 4 ("end"): now
-                const unsigned long long sv = si == 4 ? __builtin_amdgcn_s_memrealtime() - sh.stamp0 : sh.stamp[si];
-                val = (int)((w & 1) ? (sv >> 32) : (sv & 0xffffffffull));
-            }
-#endif
-            reinterpret_cast<int*>(st_out)[w] = val;
-        }
-    }
+    const bool run = fs_solve_and_publish(sh, pend, cfg, level, nb, lv.n, st_out, T);
     if (!run) return;
     const WarpConsts wc = make_warp_consts(T, lv);
     ESTAMP(0);

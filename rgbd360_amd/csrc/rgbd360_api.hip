@@ -63,6 +63,7 @@ struct rgbd360_ctx {
     double* d_partials = nullptr;     // partial rows of the last pass enqueued (current) ...
     double* d_partials_alt = nullptr; // ... and where a fused pass puts its rows while its blocks still read the previous table
     int max_blocks = 0;               // rows of a partial table = blocks of the largest level
+    bool fused_occ = true;            // the occlusion-aware alignments on the fused schedule too (RGBD360_FUSED_OCC=0: {build, pass, k_solve} triples, A/B)
     bool fused_solve = true;          // single-pair schedule: solve in the prologue of the next pass (RGBD360_FUSED_SOLVE=0: {k_eval, k_solve} pairs, A/B)
     GnIO* d_gnio = nullptr;
     // upload staging: slot 0 serves the single-frame entries (copies on `stream`); the sequence entry alternates both slots,
@@ -314,8 +315,8 @@ void launch_eval(rgbd360_ctx* ctx, int level, int method, bool hg, int occ = 0) 
     dim3 g(L.nblocks), b(kEvalThreads);
     if (occ != 0) {
         // per-target lists of candidate RUNS at the pose under evaluation, then the occlusion-aware fused pass, which decides per pixel.
-        // The head entries carry the pass's generation (1..255) in their top byte: one memset per 255 passes instead of one per pass.
-        if (++ctx->occ_gen > 255) {
+        // The head entries carry the pass's generation (1..127) in their top byte: one memset per 127 passes instead of one per pass.
+        if (++ctx->occ_gen > kOccGenMax) {
             hipMemsetAsync(ctx->occ_head, 0, ctx->occ_n * sizeof(int), ctx->stream);
             ctx->occ_gen = 1;
         }
@@ -374,12 +375,12 @@ void launch_solve(rgbd360_ctx* ctx, int level, int mode, int forced, int occ = 0
 // Fused-solve schedule (k_eval_fs, photo_icp_kernels.h): the launch solves the pass the previous launch left pending and runs the
 // next pass; state and partial table ping-pong, the host's "current" pointers follow the stream order.
 bool fused_ok(const rgbd360_ctx* ctx, int occ) {
-    return ctx->fused_solve && occ == 0 && ctx->max_blocks <= kMaxPendingRows;
+    return ctx->fused_solve && (occ == 0 || ctx->fused_occ) && ctx->max_blocks <= kMaxPendingRows;
 }
-SolveCfg fused_cfg(const rgbd360_ctx* ctx, int forced) {
+SolveCfg fused_cfg(const rgbd360_ctx* ctx, int forced, int occ = 0) {
     SolveCfg cfg;
     cfg.level = -1; cfg.n_pixels = 0;       // taken from the state (level_active / pend_npix of the pending pass)
-    cfg.mode = 0; cfg.forced = forced; cfg.max_iters = ctx->p.max_iters; cfg.occ = 0;
+    cfg.mode = 0; cfg.forced = forced; cfg.max_iters = ctx->p.max_iters; cfg.occ = occ;
     cfg.tol_residual = ctx->p.tol_residual; cfg.tol_update = ctx->p.tol_update;
     return cfg;
 }
@@ -411,9 +412,48 @@ void launch_eval_fused(rgbd360_ctx* ctx, int level, int method, int forced, cons
     std::swap(ctx->d_state, ctx->d_state_alt);
     std::swap(ctx->d_partials, ctx->d_partials_alt);
 }
+// The occlusion-aware iteration of the fused schedule: k_occ_build_fs (solve of the pending pass + run lists at the new pose; writes
+// the new state) and k_eval_occ (gate and pose from that state; leaves its rows pending) -- two launches instead of three.
+void launch_occ_fused(rgbd360_ctx* ctx, int level, int method, int occ, int forced, const float* init_pose = nullptr) {
+    FsInit init;
+    init.on = init_pose ? 1 : 0;
+    if (init_pose) memcpy(init.pose.v, init_pose, sizeof(init.pose.v));
+    else memset(init.pose.v, 0, sizeof(init.pose.v));
+    const Level& L = ctx->levels[level];
+    LevelDev lv = level_dev(L);
+    lv.min_depth = ctx->p.min_depth; lv.max_depth = ctx->p.max_depth;
+    const EvalConsts ec = eval_consts(ctx->p);
+    const SolveCfg cfg = fused_cfg(ctx, forced, occ);
+    if (++ctx->occ_gen > kOccGenMax) {
+        hipMemsetAsync(ctx->occ_head, 0, ctx->occ_n * sizeof(int), ctx->stream);
+        ctx->occ_gen = 1;
+    }
+    const int gen = ctx->occ_gen;
+    dim3 g(L.nblocks), b(kEvalThreads);
+#define LAUNCH_BUILD(O) hipLaunchKernelGGL((k_occ_build_fs<O>), g, b, 0, ctx->stream, (const GNState*)ctx->d_state, ctx->d_state_alt, (const double*)ctx->d_partials, \
+                                           L.chunk, level, L.nblocks, ctx->pend_rows_hint, lv, cfg, init, gen, ctx->occ_head, ctx->occ_nodes, ctx->occ_runinfo)
+    if (occ == 1) LAUNCH_BUILD(1);
+    else LAUNCH_BUILD(2);
+#undef LAUNCH_BUILD
+#define LAUNCH_OCC(M, O) hipLaunchKernelGGL((k_eval_occ<M, O>), g, b, 0, ctx->stream, lv, ec, (const GNState*)ctx->d_state_alt, ctx->d_partials_alt, L.chunk, level, gen, \
+                                            ctx->occ_head, (const int4*)ctx->occ_nodes, (const unsigned char*)ctx->occ_runinfo)
+    if (occ == 1) {
+        if (method == 0) LAUNCH_OCC(0, 1);
+        else if (method == 1) LAUNCH_OCC(1, 1);
+        else LAUNCH_OCC(2, 1);
+    } else {
+        if (method == 0) LAUNCH_OCC(0, 2);
+        else if (method == 1) LAUNCH_OCC(1, 2);
+        else LAUNCH_OCC(2, 2);
+    }
+#undef LAUNCH_OCC
+    ctx->pend_rows_hint = L.nblocks;
+    std::swap(ctx->d_state, ctx->d_state_alt);
+    std::swap(ctx->d_partials, ctx->d_partials_alt);
+}
 // the tail of a fused schedule: solves what the last pass left pending (nothing, if that launch was a no-op) and publishes
-void launch_solve_pending(rgbd360_ctx* ctx, int forced, bool publish) {
-    SolveCfg cfg = fused_cfg(ctx, forced);
+void launch_solve_pending(rgbd360_ctx* ctx, int forced, bool publish, int occ = 0) {
+    SolveCfg cfg = fused_cfg(ctx, forced, occ);
     if (publish) {
         cfg.host_state = ctx->h_state;
         cfg.host_tag = ctx->tag.h;
@@ -647,6 +687,9 @@ int rgbd360_create(const rgbd360_params* p, rgbd360_ctx** out) {
     if (const char* e = getenv("RGBD360_FUSED_SOLVE")) {
         ctx->fused_solve = atoi(e) != 0;
     }
+    if (const char* e = getenv("RGBD360_FUSED_OCC")) {
+        ctx->fused_occ = atoi(e) != 0;
+    }
     if (const char* e = getenv("RGBD360_ARENA")) {
         ctx->use_arena = atoi(e) != 0;
     }
@@ -769,8 +812,12 @@ static void enqueue_schedule(rgbd360_ctx* ctx, int pending, bool pending_started
         if (fused) {
             // one launch per iteration: n_pairs passes, each carrying the solve of the one before it; the solve of the chunk's last
             // pass rides in the next level's first launch, the schedule's very last one in a one-block launch that publishes
-            for (int k = 0; k < n_pairs; ++k) launch_eval_fused(ctx, level, ctx->al_method, 0, start && k == 0 ? ctx->al_guess : nullptr);
-            if (level == 0) launch_solve_pending(ctx, 0, /*publish=*/true);
+            for (int k = 0; k < n_pairs; ++k) {
+                const float* init_pose = start && k == 0 ? ctx->al_guess : nullptr;
+                if (ctx->al_occ) launch_occ_fused(ctx, level, ctx->al_method, ctx->al_occ, 0, init_pose);
+                else launch_eval_fused(ctx, level, ctx->al_method, 0, init_pose);
+            }
+            if (level == 0) launch_solve_pending(ctx, 0, /*publish=*/true, ctx->al_occ);
             continue;
         }
         for (int k = 0; k < n_pairs; ++k) {

@@ -1023,6 +1023,32 @@ def test_align_occlusion_matches_oracle(hip_lib, oracle_mod, small_pair, occlusi
     _assert_libm_oracle_agrees(reg, ora, method, 3, occlusion)
 
 
+def test_occlusion_fused_schedule_equals_the_three_launch_one(hip_lib, small_pair, monkeypatch):
+    """Round 4: the occlusion-aware alignments run {k_occ_build_fs, k_eval_occ} per iteration (the solve of the previous pass in the
+    prologue of the build, the pass gated by the state the build writes).  Same poses, iteration counts, residuals and status, bit
+    for bit, as {k_occ_build, k_eval_occ, k_solve} (RGBD360_FUSED_OCC=0, read when the context is made) -- from the identity and
+    from a guess, twice in a row on one context (the generation-tagged heads and the double-buffered state carry over)."""
+    (rgbA, dA), (rgbB, dB), T = _occluder_pair(small_pair)
+    out = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("RGBD360_FUSED_OCC", fused)
+        reg = _mk(hip_lib, 3)
+        reg.setTargetFrame(rgbA, dA)
+        reg.setSourceFrame(rgbB, dB)
+        rows = []
+        guess = synth.make_pose(synth.rodrigues(np.array([0.0, 1.0, 0.0]), 0.004), np.array([0.01, 0.0, -0.005]))
+        for occlusion, method in ((1, 2), (2, 0), (2, 1), (2, 2), (1, 0)):
+            for g in (np.eye(4), guess, np.eye(4)):
+                rc = reg.alignFrames360(g, method, occlusion)
+                rows.append((rc, list(reg.num_iterations), reg.getOptimalPose().copy(), reg.avResidual, reg.SSO))
+        out[fused] = rows
+    assert len(out["1"]) == len(out["0"]) == 15
+    for a, b in zip(out["1"], out["0"]):
+        assert a[0] == b[0] and a[1] == b[1], (a, b)
+        assert np.array_equal(a[2], b[2]), (a, b)
+        assert (a[3] == b[3] or (a[3] != a[3] and b[3] != b[3])) and a[4] == b[4], (a, b)
+
+
 def test_occlusion1_single_modality_returns_guess(hip_lib, oracle_mod, small_pair):
     """errorPhotoICP_sphereOcc1 adds avPhotoResidual + avDepthResidual: with PHOTO (or DEPTH) only, the unused term is
     0/0, the error is NaN and the reference's loop never runs -- the guess comes back."""
