@@ -144,9 +144,7 @@ __device__ __forceinline__ void occ_build_px(const LevelDev& lv, const PoseRT& T
     out.first = i - (lane - lead);
     out.old_head = 0;
     out.ti = ti;
-#ifndef RGBD360_OCC_NOATOMIC      // (timing experiment only: wrong lists)
     if (out.on) out.old_head = atomicExch(&head[ti], (int)(((unsigned)gen << 24) | (unsigned)i));      // (gen <= kOccGenMax)
-#endif
 }
 
 template <int OCC>
@@ -301,9 +299,6 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_occ(LevelDev lv, EvalCons
             // the head is this pixel, no second run ever linked itself in, and the pixel starts its run: the list is its own node, a
             // run of one (a head is the LAST pixel of its run) -- nothing to compare with, nothing to load
             if (w.hd_raw >= 0 && node == ic && (info & 63u) == 0u) node = -1;
-#ifdef RGBD360_OCC_NOWALK      // (timing experiment only)
-            node = -1;
-#endif
             while (node >= 0) {
                 const int4 nd = nodes[node];
                 const unsigned long long k = ((unsigned long long)(unsigned)nd.y << 32) | (unsigned)nd.x;
