@@ -940,7 +940,7 @@ __device__ __forceinline__ void uf_union(int* label, int a, int b) {
 // level only starts when the levels below it are complete, so a join always connects two finished blocks of 2^level rows.
 // Launched all at once instead, a wall's thousand runs hook onto each other in one step (run r under run r-1 under ...),
 // and whoever comes late walks the whole chain one dependent L2 round trip at a time: 8 k joins cost 70-90 us at
-// 2048x1024 through a single 75-86 hop walk.  Levels 0..3 (bands of 16 rows) share one launch, levels 4 and 5 get one each, the sparse rest (every 64th row) one together.
+// 2048x1024 through a single 75-86 hop walk.  Levels 0..5 (64 x 64 tiles) share one launch, the sparse rest (every 64th row) one more.
 // fl: flags of (r, c); fl_up: of (r-1, c); fl_left: of (r, c-1)
 __device__ __forceinline__ void ccl_join_up(int cols, int* __restrict__ label, int r, int c, int fl, int fl_up, int fl_left) {
     if (!(fl & 4)) return;
@@ -949,7 +949,12 @@ __device__ __forceinline__ void ccl_join_up(int cols, int* __restrict__ label, i
     uf_union(label, i, i - cols);
 }
 
-constexpr int kBandRows = 16, kBandLevels = 4, kBandCols = 256, kBandGroups = 4;
+#ifndef F360_BAND_ROWS
+#define F360_BAND_ROWS 64
+#endif
+// (round 4: 64 x 64 tiles, six levels per launch -- until then 16-row bands of 256 columns and levels 4 and 5 as launches of their own,
+// 5.6-5.8 us each for a few thousand joins; sixteen row groups keep a thread's joins per level at two)
+constexpr int kBandRows = F360_BAND_ROWS, kBandLevels = kBandRows == 64 ? 6 : 4, kBandCols = kBandRows == 64 ? 64 : 256, kBandGroups = 1024 / kBandCols;
 __global__ __launch_bounds__(kBandCols * kBandGroups) void k_f360_ccl_merge_band(const uint8_t* __restrict__ flags, int rows, int cols,
                                                                                 int* __restrict__ label) {
     __shared__ uint8_t tile[kBandRows][kBandCols + 4];        // flags of the band; column 0 = the column left of the block

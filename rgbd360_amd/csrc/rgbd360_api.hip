@@ -2187,7 +2187,7 @@ int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float
                        flags, rows, cols, ctx->f_label, run_starts, n_run_starts);
     hipLaunchKernelGGL(k_f360_ccl_merge_band, dim3((cols + kBandCols - 1) / kBandCols, (rows + kBandRows - 1) / kBandRows),
                        dim3(kBandCols * kBandGroups), 0, ctx->stream, flags, rows, cols, ctx->f_label);
-    constexpr int kTopLevel = kBandLevels + 2;
+    constexpr int kTopLevel = kBandRows == 64 ? kBandLevels : kBandLevels + 2;      // 64-row bands: every 64th row in one launch behind them
     for (int level = kBandLevels; level <= kTopLevel && (1 << level) < rows; ++level) {
         const bool all_above = level == kTopLevel;
         const int n_rows = all_above ? (rows - 1) / (1 << level) : (rows - 1 - (1 << level)) / (2 << level) + 1;
