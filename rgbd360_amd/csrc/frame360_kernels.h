@@ -173,10 +173,27 @@ __global__ __launch_bounds__(kDistThreads) void k_f360_distmap(const unsigned lo
     const int t = threadIdx.x;
     const int w = blockIdx.x, r0 = blockIdx.y * kDistTH;
     const float far = (float)(cols + rows);
+    bool any_change = false;                               // a depth-change pixel within the radius of the tile
     if (t < kDistRows * 3) {
         const int y = t / 3, k = t - 3 * y;
         const int r = r0 - kF360R + y, ww = w - 1 + k;
-        words[y][k] = (r >= 0 && r < rows && ww >= 0 && ww < pitch_words) ? bits[(size_t)r * pitch_words + ww] : 0ull;
+        const unsigned long long word = (r >= 0 && r < rows && ww >= 0 && ww < pitch_words) ? bits[(size_t)r * pitch_words + ww] : 0ull;
+        words[y][k] = word;
+        // the windows of the tile's columns reach kF360R bits into the neighbouring words
+        const unsigned long long reach = k == 0 ? ~0ull << (64 - kF360R) : (k == 2 ? (1ull << kF360R) - 1ull : ~0ull);
+        any_change = (word & reach) != 0ull;
+    }
+    // Most tiles of a frame see no depth change within the radius (walls, floor): every pixel of such a tile is `far` away (round 4: the
+    // two LDS phases below -- 25 table reads per pixel -- were the whole cost of the kernel, 31 us at 4096 x 2048, for a constant).
+    if (!__syncthreads_or(any_change ? 1 : 0)) {           // uniform
+        const int c = w * 64 + (t & 63);
+        constexpr int kPerE = kDistTH / (kDistThreads / 64);
+#pragma unroll
+        for (int j = 0; j < kPerE; ++j) {
+            const int r = r0 + (t >> 6) * kPerE + j;
+            if (r < rows && c < cols) dist[(size_t)r * cols + c] = far;
+        }
+        return;
     }
     if (t < (kF360R + 1) * 16) {
         const int ady = t >> 4, dx = t & 15;
