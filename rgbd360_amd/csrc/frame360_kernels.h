@@ -887,17 +887,115 @@ __global__ __launch_bounds__(64 * kRunRowsPerBlock) void k_f360_ccl_runs(const u
             const int s = wave_scan_max(m);
             int prev = __builtin_amdgcn_update_dpp(-1, s, 0x138, 0xF, 0xF, false);      // wave_shr:1 (lane 0: -1)
             prev = prev > carry ? prev : carry;
+            int lab[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int cc = c + k;
                 const int start = v[k] > prev ? v[k] : prev;
-                if (cc < cols) L[cc] = valid[k] ? r * cols + start : -1;
+                lab[k] = valid[k] ? r * cols + start : -1;
+            }
+            if (words) {                                     // rows of whole dwords: a lane's four labels leave as ONE 16-byte store (round 4:
+                if (c < cols) *reinterpret_cast<int4*>(L + c) = make_int4(lab[0], lab[1], lab[2], lab[3]);      // four dword stores at a 16-byte stride each filled a quarter of every line they touched: 21 us at 4096 x 2048)
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (c + k < cols) L[c + k] = lab[k];
             }
             const int last = __builtin_amdgcn_readlane(s, 63);
             carry = last > carry ? last : carry;
         }
     }
     if (nstarts && lane == 0) nstarts[r] = n_starts;
+}
+
+// The same with FOUR waves per row (round 4; rows of whole dwords, 1024 <= cols <= 8192): a wave owns a quarter of the columns, holds
+// its flags in registers, and first reports the column of its last run start and its count of run starts; behind one barrier every
+// wave knows the run that reaches into its segment (the latest start to its left) and where its run starts go in the row's list.
+// One wave per row left 2048 waves on 1024 SIMDs at 4096 x 2048: two memory round trips and a serial scan per row, 15-21 us.
+constexpr int kRunSegs = 4, kRunSegSteps = 8;
+__global__ __launch_bounds__(64 * kRunSegs) void k_f360_ccl_runs_seg(const uint8_t* __restrict__ flags, int rows, int cols,
+                                                                   int* __restrict__ label, int* __restrict__ starts,
+                                                                   int* __restrict__ nstarts) {
+    __shared__ int seg_last[kRunSegs], seg_roots[kRunSegs];
+    const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6, r = blockIdx.x;
+    const uint8_t* f = flags + (size_t)r * cols;
+    int* L = label + (size_t)r * cols;
+    const int seg_px = ((cols + kRunSegs * 256 - 1) / (kRunSegs * 256)) * 256;      // <= 256 kRunSegSteps (the launcher checks)
+    const int c_begin = seg * seg_px, c_end = min(cols, c_begin + seg_px);
+    unsigned w[kRunSegSteps];
+#pragma unroll
+    for (int q = 0; q < kRunSegSteps; ++q) {
+        const int c = c_begin + 256 * q + 4 * lane;
+        w[q] = c < c_end ? *reinterpret_cast<const unsigned*>(f + c) : 0u;          // (c_end is a multiple of 4)
+    }
+    {
+        int m_last = -1, roots = 0;
+#pragma unroll
+        for (int q = 0; q < kRunSegSteps; ++q) {
+            const int c = c_begin + 256 * q + 4 * lane;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int fl = (int)((w[q] >> (8 * k)) & 0xffu);
+                if (c + k < c_end && !(fl & 2)) {
+                    m_last = c + k;
+                    roots += fl & 1;
+                }
+            }
+        }
+        const int last = __builtin_amdgcn_readlane(wave_scan_max(m_last), 63), total = __builtin_amdgcn_readlane(wave_scan_add(roots), 63);
+        if (lane == 0) {
+            seg_last[seg] = last;
+            seg_roots[seg] = total;
+        }
+    }
+    __syncthreads();
+    int carry = -1, n_starts = 0;
+#pragma unroll
+    for (int sg = 0; sg < kRunSegs; ++sg)
+        if (sg < seg) {                                      // wave-uniform
+            carry = max(carry, seg_last[sg]);
+            n_starts += seg_roots[sg];
+        }
+#pragma unroll
+    for (int q = 0; q < kRunSegSteps; ++q) {
+        const int c0 = c_begin + 256 * q;
+        if (c0 >= c_end) break;                              // wave-uniform
+        const int c = c0 + 4 * lane;
+        int v[4];
+        bool valid[4];
+        int m = -1;
+        unsigned root_bits = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int cc = c + k;
+            const int fl = cc < c_end ? (int)((w[q] >> (8 * k)) & 0xffu) : 0;
+            valid[k] = (fl & 1) != 0;
+            if (cc < c_end && !(fl & 2)) m = cc;
+            if (cc < c_end && (fl & 1) && !(fl & 2)) root_bits |= 1u << k;
+            v[k] = m;
+        }
+        if (starts) {                                        // uniform
+            const int mine = __builtin_popcount(root_bits);
+            const int incl = wave_scan_add(mine);
+            int at = r * cols + n_starts + incl - mine;
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (root_bits & (1u << k)) starts[at++] = r * cols + c + k;
+            n_starts += __builtin_amdgcn_readlane(incl, 63);
+        }
+        const int sc = wave_scan_max(m);
+        int prev = __builtin_amdgcn_update_dpp(-1, sc, 0x138, 0xF, 0xF, false);      // wave_shr:1 (lane 0: -1)
+        prev = prev > carry ? prev : carry;
+        int lab[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int start = v[k] > prev ? v[k] : prev;
+            lab[k] = valid[k] ? r * cols + start : -1;
+        }
+        if (c < c_end) *reinterpret_cast<int4*>(L + c) = make_int4(lab[0], lab[1], lab[2], lab[3]);
+        const int last = __builtin_amdgcn_readlane(sc, 63);
+        carry = last > carry ? last : carry;
+    }
+    if (nstarts && seg == kRunSegs - 1 && lane == 0) nstarts[r] = n_starts;
 }
 
 // Parents always have the smaller index (uf_union hangs the larger root under the smaller), so a cell only ever decreases

@@ -2183,8 +2183,12 @@ int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float
     static const bool lists_off = [] { const char* e = getenv("RGBD360_CCL_LISTS"); return e && atoi(e) == 0; }();
     int* run_starts = lists_off ? nullptr : ctx->f_window;        // (the window plane of the normal-map stage is spent; f_slot_of_root stays free for k_f360_assign_list's writes)
     int* n_run_starts = lists_off ? nullptr : reinterpret_cast<int*>(ctx->f_hd + (((size_t)n + 15) & ~(size_t)15));      // n + 4 rows <= 3 n + 64 bytes
-    hipLaunchKernelGGL(k_f360_ccl_runs, dim3((rows + kRunRowsPerBlock - 1) / kRunRowsPerBlock), dim3(64 * kRunRowsPerBlock), 0, ctx->stream,
-                       flags, rows, cols, ctx->f_label, run_starts, n_run_starts);
+    const bool seg_rows = cols % 4 == 0 && cols >= 1024 && cols <= kRunSegs * kRunSegSteps * 256;       // (flags and labels are hipMalloc'ed: rows of whole, aligned dwords)
+    if (seg_rows)
+        hipLaunchKernelGGL(k_f360_ccl_runs_seg, dim3(rows), dim3(64 * kRunSegs), 0, ctx->stream, flags, rows, cols, ctx->f_label, run_starts, n_run_starts);
+    else
+        hipLaunchKernelGGL(k_f360_ccl_runs, dim3((rows + kRunRowsPerBlock - 1) / kRunRowsPerBlock), dim3(64 * kRunRowsPerBlock), 0, ctx->stream,
+                           flags, rows, cols, ctx->f_label, run_starts, n_run_starts);
     hipLaunchKernelGGL(k_f360_ccl_merge_band, dim3((cols + kBandCols - 1) / kBandCols, (rows + kBandRows - 1) / kBandRows),
                        dim3(kBandCols * kBandGroups), 0, ctx->stream, flags, rows, cols, ctx->f_label);
     constexpr int kTopLevel = kBandRows == 64 ? kBandLevels : kBandLevels + 2;      // 64-row bands: every 64th row in one launch behind them
