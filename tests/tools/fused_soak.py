@@ -1,6 +1,7 @@
 """Soak check of the fused-solve schedule (one k_eval_fs launch per Gauss-Newton iteration, the library's default) against the two-launch
 schedule (k_eval + k_solve, RGBD360_FUSED_SOLVE=0): random scenes, sizes, pyramid depths, methods, start poses and residual weights; pose,
-status, iteration counts and the result record must agree BIT FOR BIT.  python tests/tools/fused_soak.py [n_trials]"""
+status, iteration counts and the result record must agree BIT FOR BIT.  A third of the trials run an occlusion-aware mode on an occluder scene: there the fused schedule is
+{k_occ_build_fs, k_eval_occ} against {k_occ_build, k_eval_occ, k_solve} (RGBD360_FUSED_OCC=0).  python tests/tools/fused_soak.py [n_trials]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
@@ -23,12 +24,15 @@ for t in range(n_trials):
     if rng.random() < 0.15:
         rgbB = np.zeros_like(rgbB)              # a blank source frame: no salient pixel
     method = int(rng.integers(0, 3))
+    occlusion = int(rng.integers(1, 3)) if rng.random() < 0.34 else 0
+    if occlusion:
+        (rgbA, dA), (rgbB, dB), T = synth.add_occluder(((rgbA, dA), (rgbB, dB), T))
     guess = np.eye(4)
     if rng.random() < 0.3:
         guess = np.linalg.inv(T) if rng.random() < 0.5 else T        # start at the answer / at twice the motion
     res = []
     for fused in ("1", "0"):
-        os.environ["RGBD360_FUSED_SOLVE"] = fused
+        os.environ["RGBD360_FUSED_OCC" if occlusion else "RGBD360_FUSED_SOLVE"] = fused
         reg = RegisterPhotoICP()
         reg.setNumPyr(n_pyr)
         if fused == "1":
@@ -36,14 +40,14 @@ for t in range(n_trials):
         if var is not None:
             reg.setGrayVariance(var[0]); reg.setDepthVariance(var[1])
         reg.setTargetFrame(rgbA, dA); reg.setSourceFrame(rgbB, dB)
-        rc = reg.alignFrames360(guess, method)
+        rc = reg.alignFrames360(guess, method, occlusion)
         res.append((rc, reg.getOptimalPose().copy(), list(reg.num_iterations), reg.getHessian().copy(), reg.getGradient().copy()))
         reg.close()
-    os.environ.pop("RGBD360_FUSED_SOLVE")
+    os.environ.pop("RGBD360_FUSED_OCC" if occlusion else "RGBD360_FUSED_SOLVE")
     a, b = res
     same = a[0] == b[0] and np.array_equal(a[1], b[1]) and a[2] == b[2] and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
     bad += 0 if same else 1
-    print("trial %2d: %4dx%-4d n_pyr %d method %d motion %.2f m / %.0f deg depth %s -> status %d iters %s %s" % (
-        t, W, H, n_pyr, method, trans, rot, dA.dtype, a[0], a[2], "identical" if same else "DIFFERENT"), flush=True)
+    print("trial %2d: %4dx%-4d n_pyr %d method %d occlusion %d motion %.2f m / %.0f deg depth %s -> status %d iters %s %s" % (
+        t, W, H, n_pyr, method, occlusion, trans, rot, dA.dtype, a[0], a[2], "identical" if same else "DIFFERENT"), flush=True)
 print("fused-solve soak: %d / %d trials identical" % (n_trials - bad, n_trials))
 sys.exit(1 if bad else 0)
