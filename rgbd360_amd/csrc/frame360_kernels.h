@@ -50,10 +50,18 @@ struct EdgeCloudSrc {
     int depth_type, convention;
     const float *sin_theta, *cos_theta, *sin_phi, *cos_phi;
 };
-template <bool CLOUD>
-__global__ __launch_bounds__(kEdgeTW) void k_f360_edge_bits(const float* __restrict__ xyz, int rows, int cols, float factor, int depth_mode,
-                                                           int pitch_words, unsigned long long* __restrict__ bits, EdgeCloudSrc src,
+// SPEC >= 0 (CLOUD only): convention, depth type and depth mode as compile-time constants, SPEC = convention * 4 + depth_type * 2 +
+// depth_mode -- the three are tested per row and pixel, 100 scalar branches in the generic kernel's straight-line code
+template <bool CLOUD, int SPEC = -1>
+__global__ __launch_bounds__(kEdgeTW) void k_f360_edge_bits(const float* __restrict__ xyz, int rows, int cols, float factor, int depth_mode_arg,
+                                                           int pitch_words, unsigned long long* __restrict__ bits, EdgeCloudSrc src_arg,
                                                            float* __restrict__ xyz_out) {
+    const int depth_mode = SPEC >= 0 ? (SPEC & 1) : depth_mode_arg;
+    EdgeCloudSrc src = src_arg;
+    if (SPEC >= 0) {
+        src.depth_type = (SPEC >> 1) & 1;
+        src.convention = SPEC >> 2;
+    }
     __shared__ float dep[kEdgeTH + 2][kEdgeTW + 2];
     const int t = threadIdx.x;
     const int c0 = blockIdx.x * kEdgeTW, r0 = blockIdx.y * kEdgeTH;

@@ -1806,8 +1806,26 @@ static void launch_distance_map(rgbd360_ctx* ctx, int rows, int cols, float max_
     unsigned long long* bits = reinterpret_cast<unsigned long long*>(ctx->f_hd);
     const dim3 ge((cols + kEdgeTW - 1) / kEdgeTW, (rows + kEdgeTH - 1) / kEdgeTH);
     if (ctx->f_cloud_pending.depth) {       // rgbd360_frame_planes: the cloud has not been formed yet -- this kernel does it on the way
-        hipLaunchKernelGGL((k_f360_edge_bits<true>), ge, dim3(kEdgeTW), 0, ctx->stream, ctx->f_xyz, rows, cols, max_depth_change_factor, depth_mode,
-                           pitch, bits, ctx->f_cloud_pending, ctx->f_xyz);
+        const EdgeCloudSrc& cs = ctx->f_cloud_pending;
+        const int spec = (cs.convention >= 0 && cs.convention <= 2 && (cs.depth_type | 1) == 1 && (depth_mode | 1) == 1) ? cs.convention * 4 + cs.depth_type * 2 + depth_mode : -1;
+#define EDGE_CLOUD(S) hipLaunchKernelGGL((k_f360_edge_bits<true, S>), ge, dim3(kEdgeTW), 0, ctx->stream, ctx->f_xyz, rows, cols, max_depth_change_factor, depth_mode, \
+                                         pitch, bits, ctx->f_cloud_pending, ctx->f_xyz)
+        switch (spec) {
+            case 0: EDGE_CLOUD(0); break;
+            case 1: EDGE_CLOUD(1); break;
+            case 2: EDGE_CLOUD(2); break;
+            case 3: EDGE_CLOUD(3); break;
+            case 4: EDGE_CLOUD(4); break;
+            case 5: EDGE_CLOUD(5); break;
+            case 6: EDGE_CLOUD(6); break;
+            case 7: EDGE_CLOUD(7); break;
+            case 8: EDGE_CLOUD(8); break;
+            case 9: EDGE_CLOUD(9); break;
+            case 10: EDGE_CLOUD(10); break;
+            case 11: EDGE_CLOUD(11); break;
+            default: EDGE_CLOUD(-1); break;
+        }
+#undef EDGE_CLOUD
         ctx->f_cloud_pending.depth = nullptr;
     } else {
         hipLaunchKernelGGL((k_f360_edge_bits<false>), ge, dim3(kEdgeTW), 0, ctx->stream, ctx->f_xyz, rows, cols, max_depth_change_factor, depth_mode,
