@@ -686,8 +686,13 @@ __global__ __launch_bounds__(64 * kSweepWaves) void k_f360_normals_sweep(const f
             const int sc = window_sum_i<R>(cnt, lane);
             // straight-line finish: every lane does the arithmetic, predicates select at the end (the nested tests of the tiled
             // kernel cost a mask save / branch / three NaN moves per level here)
-            const float depth = depth_mode == 0 ? pz : sqrtf(px * px + py * py + pz * pz);
-            const float smoothing = fminf(pdist, smoothing_size + depth / 10.0f);
+            // sqrtf and the division by 10, bit for bit where they can matter, in 5 + 3 instructions instead of the IEEE sequences' ~22:
+            // r360::sqrt_rn equals sqrtf on [2^-60, 2^60] and the fma form below equals x / 10.0f on [2^-20, 2^60] (exhaustive:
+            // rgbd360_selftest_math, tools/ubench/div10.hip).  Outside: a non-finite depth gives no normal whatever `smoothing` is; a
+            // depth under 2^-20 adds under 2^-23 to a smoothing size that only counts above 2; one over 2^30 leaves `pdist` the minimum.
+            const float depth = depth_mode == 0 ? pz : r360::sqrt_rn(px * px + py * py + pz * pz);
+            const float q10 = depth * 0.1f;
+            const float smoothing = fminf(pdist, smoothing_size + fmaf(fmaf(-q10, 10.0f, depth), 0.1f, q10));
             const bool have = co_inside & (y >= border) & (y < rows - border) & (y < y1) & isfinite(depth) & (smoothing > 2.0f);
             const int rect = have ? (int)smoothing : 0;
             const double v0 = s[4] * s[2] - s[5] * s[1], v1 = s[5] * s[0] - s[3] * s[2], v2 = s[3] * s[1] - s[4] * s[0];
