@@ -25,8 +25,14 @@ namespace f360 {
 constexpr int kF360R = 12;          // truncation radius of the distance map (>= smoothing_size + max depth / 10)
 
 __device__ __forceinline__ bool finite3(float x, float y, float z) { return isfinite(x) && isfinite(y) && isfinite(z); }
+// sqrtf, bit for bit: r360::sqrt_rn (5 instructions, exhaustively equal to the IEEE result on [2^-60, 2^60] and at 0) where it is
+// proven, the compiler's sequence (~15 instructions with its scaling branches) elsewhere -- a branch no real cloud takes
+__device__ __forceinline__ float sqrt_ieee(float x) {
+    if ((x >= 0x1p-60f && x <= 0x1p60f) || x == 0.f) return r360::sqrt_rn(x);
+    return sqrtf(x);
+}
 __device__ __forceinline__ float depth_of(const float* p, int depth_mode) {
-    return depth_mode == 0 ? p[2] : sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+    return depth_mode == 0 ? p[2] : sqrt_ieee(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
 }
 
 // pair test of computeFeature: `a` is the pixel the loop visits, `b` its right / lower neighbour
