@@ -1147,7 +1147,23 @@ __global__ __launch_bounds__(kRootsThreads) void k_f360_ccl_roots_list(const int
     const int ns = nstarts[r];
     for (int k = threadIdx.x; k < ns; k += kRootsThreads) {
         const int i = starts[(size_t)r * cols + k];
+#ifdef F360_ROOTS_WALK
         label[i] = uf_find(label, i);
+#else
+        // Pointer jumping (round 4): every node of the forest is a run start, i.e. has a thread in this launch, and no union runs any
+        // more -- so a thread keeps re-pointing ITS OWN node at its grandparent (device-scope loads: another XCD's compression is only
+        // useful if it is seen) and the reach of every pointer doubles per trip: log2(depth) trips of two loads instead of a hop per
+        // level (the fragmented frame: chains of 30-60 hops, 19-45 us for this launch).  Any value read is an ancestor, so the
+        // result does not depend on the interleaving.
+        int p = __hip_atomic_load(&label[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (;;) {
+            const int g = __hip_atomic_load(&label[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (g == p) break;                               // p is a root
+            __hip_atomic_store(&label[i], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            p = g;
+        }
+        label[i] = p;
+#endif
         count[i] = 0ull;
     }
 }
