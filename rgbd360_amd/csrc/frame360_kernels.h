@@ -1088,7 +1088,12 @@ __device__ __forceinline__ void ccl_join_up(int cols, int* __restrict__ label, i
 #endif
 // (round 4: 64 x 64 tiles, six levels per launch -- until then 16-row bands of 256 columns and levels 4 and 5 as launches of their own,
 // 5.6-5.8 us each for a few thousand joins; sixteen row groups keep a thread's joins per level at two)
-constexpr int kBandRows = F360_BAND_ROWS, kBandLevels = kBandRows == 64 ? 6 : 4, kBandCols = kBandRows == 64 ? 64 : 256, kBandGroups = 1024 / kBandCols;
+constexpr int kBandRows = F360_BAND_ROWS, kBandLevels = kBandRows == 64 ? 6 : 4, kBandCols = kBandRows == 64 ? 64 : 256;
+// row groups per tile (threads = kBandCols x groups): sixteen keep a thread's joins per level at two; with 2048 tiles and more
+// (4096 x 2048) eight are faster -- twice the tiles resident, and the launch is a chain of dependent joins per tile: 41 -> 35 us there,
+// but 17 -> 20 us at 2048 x 1024 and 30 -> 34 us on its fragmented frame, so the launcher picks by the tile count
+constexpr int kBandGroupsMax = 1024 / kBandCols;
+template <int kBandGroups>
 __global__ __launch_bounds__(kBandCols * kBandGroups) void k_f360_ccl_merge_band(const uint8_t* __restrict__ flags, int rows, int cols,
                                                                                 int* __restrict__ label) {
     __shared__ uint8_t tile[kBandRows][kBandCols + 4];        // flags of the band; column 0 = the column left of the block

@@ -2207,8 +2207,13 @@ int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float
     else
         hipLaunchKernelGGL(k_f360_ccl_runs, dim3((rows + kRunRowsPerBlock - 1) / kRunRowsPerBlock), dim3(64 * kRunRowsPerBlock), 0, ctx->stream,
                            flags, rows, cols, ctx->f_label, run_starts, n_run_starts);
-    hipLaunchKernelGGL(k_f360_ccl_merge_band, dim3((cols + kBandCols - 1) / kBandCols, (rows + kBandRows - 1) / kBandRows),
-                       dim3(kBandCols * kBandGroups), 0, ctx->stream, flags, rows, cols, ctx->f_label);
+    {
+        const dim3 gb((cols + kBandCols - 1) / kBandCols, (rows + kBandRows - 1) / kBandRows);
+        if (kBandGroupsMax >= 16 && gb.x * gb.y >= 1536)
+            hipLaunchKernelGGL((k_f360_ccl_merge_band<kBandGroupsMax / 2>), gb, dim3(kBandCols * (kBandGroupsMax / 2)), 0, ctx->stream, flags, rows, cols, ctx->f_label);
+        else
+            hipLaunchKernelGGL((k_f360_ccl_merge_band<kBandGroupsMax>), gb, dim3(kBandCols * kBandGroupsMax), 0, ctx->stream, flags, rows, cols, ctx->f_label);
+    }
     constexpr int kTopLevel = kBandRows == 64 ? kBandLevels : kBandLevels + 2;      // 64-row bands: every 64th row in one launch behind them
     for (int level = kBandLevels; level <= kTopLevel && (1 << level) < rows; ++level) {
         const bool all_above = level == kTopLevel;
