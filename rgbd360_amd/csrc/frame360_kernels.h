@@ -1807,7 +1807,11 @@ __device__ __forceinline__ unsigned hull_f2ord(float f) {          // order-pres
 // pixel), so the work sits where the long, nearly horizontal edges are.  (First version: eight consecutive 1024-pixel stretches per
 // block and 64-bit keys in the inner loop, 77 us, the straggler blocks being those along the floor's and ceiling's edges.)
 constexpr int kHullBlock = 1024, kHullChunks = 8, kHullHash = 32, kHullFramesLds = 128;
-constexpr int kHullList = 640;        // boundary pixels a block shares out among its waves per round
+#ifdef F360_HULL_TWO
+constexpr int kHullList = 512;
+#else
+constexpr int kHullList = 640;
+#endif        // boundary pixels a block shares out among its waves per round
 struct HullEntry {
     int slot;
     float u, v;
@@ -1819,7 +1823,7 @@ __device__ unsigned long long g_hull_dbg[4096][8];
 #else
 #define HDBG_T() 0ull
 #endif
-__global__ __launch_bounds__(kHullBlock) void k_f360_hull_extremes(const float* __restrict__ xyz, const int* __restrict__ label,
+__device__ __forceinline__ void hull_extremes_block(const float* __restrict__ xyz, const int* __restrict__ label,
                                                                     const int* __restrict__ slot_of_root, int rows, int cols,
                                                                     const SlotFrame* __restrict__ frames, unsigned long long* __restrict__ ext,
                                                                     int* __restrict__ part_keys, unsigned long long* __restrict__ part_vals, int n_frames_lds) {
@@ -2080,6 +2084,21 @@ __global__ __launch_bounds__(kHullBlock) void k_f360_hull_extremes(const float* 
         o[0] = hd_t1 - hd_t0; o[1] = hd_t2 - hd_t1; o[2] = HDBG_T() - hd_t2; o[3] = hd_uv; o[4] = hd_walk; o[5] = hd_flush; o[6] = hd_entries; o[7] = hd_runs;
     }
 #endif
+}
+// one block per CU (81 KB of LDS, 95 VGPRs) ...
+__global__ __launch_bounds__(kHullBlock) void k_f360_hull_extremes(const float* __restrict__ xyz, const int* __restrict__ label,
+                                                                    const int* __restrict__ slot_of_root, int rows, int cols,
+                                                                    const SlotFrame* __restrict__ frames, unsigned long long* __restrict__ ext,
+                                                                    int* __restrict__ part_keys, unsigned long long* __restrict__ part_vals, int n_frames_lds) {
+    hull_extremes_block(xyz, label, slot_of_root, rows, cols, frames, ext, part_keys, part_vals, n_frames_lds);
+}
+// ... or two (64 VGPRs, 21 of them spilled): where a frame has more blocks than the chip has CUs (4096 x 2048: four per CU) the second
+// block's round trips run under the first one's walk, 50 -> 40 us; with one block per CU the spills only cost (16.3 -> 17.6 us)
+__global__ __launch_bounds__(kHullBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_f360_hull_extremes_two(const float* __restrict__ xyz, const int* __restrict__ label,
+                                                                    const int* __restrict__ slot_of_root, int rows, int cols,
+                                                                    const SlotFrame* __restrict__ frames, unsigned long long* __restrict__ ext,
+                                                                    int* __restrict__ part_keys, unsigned long long* __restrict__ part_vals, int n_frames_lds) {
+    hull_extremes_block(xyz, label, slot_of_root, rows, cols, frames, ext, part_keys, part_vals, n_frames_lds);
 }
 // The blocks' tables -> the global rows of extremes.  A wall met by every block has a 2 KB row in each table (256 at 2048 x 1024, 1024 at
 // 4096 x 2048): ONE block streaming them is bound by what a single block reads (~30-60 GB/s: 19 / 75 us per frame when the packing

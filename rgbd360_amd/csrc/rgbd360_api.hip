@@ -2025,8 +2025,17 @@ void launch_hull(rgbd360_ctx* ctx, int rows, int cols, bool clear_first) {
     const int n = rows * cols;
     if (clear_first) hipLaunchKernelGGL(k_f360_hull_clear, dim3((kF360MaxSlots * kHullPhases * kHullDirs + 255) / 256), dim3(256), 0, ctx->stream, ctx->f_nslots, kF360MaxSlots, ctx->f_ext);
     const int nblk = (n + kHullBlock * kHullChunks - 1) / (kHullBlock * kHullChunks);      // <= ctx->f_hull_blocks (sized for the context's largest frame)
-    hipLaunchKernelGGL(k_f360_hull_extremes, dim3(nblk), dim3(kHullBlock), 0, ctx->stream, ctx->f_xyz, ctx->f_label, ctx->f_slot_of_root, rows, cols,
-                       ctx->f_frames, ctx->f_ext, ctx->f_hull_keys, ctx->f_hull_vals, kHullFramesLds);
+    static const int n_cus = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
+    if (nblk > n_cus)        // more blocks than CUs: the two-per-CU build of the kernel
+        hipLaunchKernelGGL(k_f360_hull_extremes_two, dim3(nblk), dim3(kHullBlock), 0, ctx->stream, ctx->f_xyz, ctx->f_label, ctx->f_slot_of_root, rows, cols,
+                           ctx->f_frames, ctx->f_ext, ctx->f_hull_keys, ctx->f_hull_vals, kHullFramesLds);
+    else
+        hipLaunchKernelGGL(k_f360_hull_extremes, dim3(nblk), dim3(kHullBlock), 0, ctx->stream, ctx->f_xyz, ctx->f_label, ctx->f_slot_of_root, rows, cols,
+                           ctx->f_frames, ctx->f_ext, ctx->f_hull_keys, ctx->f_hull_vals, kHullFramesLds);
     hipLaunchKernelGGL(k_f360_hull_merge, dim3(64, kHullMergeSplit), dim3(kHullDirs), 0, ctx->stream, ctx->f_nslots, kF360MaxSlots, ctx->f_hull_keys, ctx->f_hull_vals,
                        nblk, ctx->f_ext);
     hipLaunchKernelGGL(k_f360_hull_pack, dim3(256), dim3(kHullDirs), 0, ctx->stream, ctx->f_xyz, ctx->f_frames, ctx->f_ext, ctx->f_nslots, kF360MaxSlots,
