@@ -2218,6 +2218,9 @@ __global__ __launch_bounds__(kHullDirs) void k_f360_hull_pack(const float* __res
 // -2 for valid pixels of regions that did not ("free" pixels: the only ones that can change).
 constexpr int kRefInvalid = -1, kRefFree = -2;
 constexpr int kRefTH = 16, kRefWaves = 4;
+#ifndef F360_REFINE_SLEEP
+#define F360_REFINE_SLEEP 8
+#endif
 __global__ void k_f360_refine_init(const int* __restrict__ label, const int* __restrict__ slot_of_root, const float4* __restrict__ models, int n,
                                    int cols, int tiles_x, int* __restrict__ W, unsigned char* __restrict__ tile_free) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2382,7 +2385,7 @@ __global__ __launch_bounds__(64 * kRefWaves) void k_f360_refine_tile(const float
     int seen = coherent_load(activity), quiet = 0;
     const int first_seen = seen;
     for (int p = 0; p < n_polls; ++p) {
-        __builtin_amdgcn_s_sleep(8);
+        __builtin_amdgcn_s_sleep(F360_REFINE_SLEEP);
         const int rs = side_in ? coherent_load(side_p) : kRefInvalid;
         const int rp = prev_in ? coherent_load(prev_p) : kRefInvalid;
         const int act = coherent_load(activity);
@@ -2391,6 +2394,9 @@ __global__ __launch_bounds__(64 * kRefWaves) void k_f360_refine_tile(const float
             if (step()) {
                 any_change = true;
                 if (lane == 0) atomicAdd(activity, 1);
+#ifdef F360_REFINE_TILE_DBG
+                if (lane == 0) { unsigned char* tf = const_cast<unsigned char*>(tile_free) + tyi * gridDim.x + blockIdx.x; if (*tf < 250) *tf += 1; }
+#endif
             }
             quiet = 0;
             seen = coherent_load(activity);
@@ -2410,67 +2416,81 @@ __global__ __launch_bounds__(64 * kRefWaves) void k_f360_refine_tile(const float
 // The grown inliers join their plane's sums: count and the nine integer moments (order independent), labels updated.  The sums of a
 // block are collected in an LDS hash first (a noisy patch sends thousands of pixels to ONE plane: 1.7 M same-address global atomics
 // took 5 ms), one global atomic per block, slot and sum follows.
-__global__ __launch_bounds__(256) void k_f360_refine_commit(const float* __restrict__ xyz, int* __restrict__ label, const int* __restrict__ Winit,
+constexpr int kCommitThreads = 1024, kCommitPerThread = 8;      // a block owns 8192 consecutive pixels (round 4: 256-pixel blocks flushed their table
+                                                                 // with 11 global atomics per plane each -- 8192 blocks on a handful of words: 50-190 us)
+__global__ __launch_bounds__(kCommitThreads) void k_f360_refine_commit(const float* __restrict__ xyz, int* __restrict__ label, const int* __restrict__ Winit,
                                                             const int* __restrict__ Wfinal, const int* __restrict__ root_of_slot, int n,
                                                             int* __restrict__ count_of_slot, unsigned long long* __restrict__ mom, int max_slots,
                                                             int* __restrict__ n_changed) {
     unsigned long long* mom_rep = mom + (size_t)(blockIdx.x % kMomReplicas) * max_slots * 9;      // any copy will do: k_f360_mom_reduce sums them
     __shared__ int keys[kMomRunHash];
     __shared__ unsigned long long vals[kMomRunHash][10];
-    __shared__ int block_changed;
-    keys[threadIdx.x] = -1;                                // kMomRunHash == blockDim.x == 256
-#pragma unroll
-    for (int q = 0; q < 10; ++q) vals[threadIdx.x][q] = 0ull;
-    if (threadIdx.x == 0) block_changed = 0;
-    __syncthreads();
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    const int slot = i < n ? Wfinal[i] : kRefInvalid;
-    const bool grown = i < n && slot != Winit[i];          // only free pixels change, and only into a plane's slot
-    unsigned long long v[10] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
-    if (grown) {
-        label[i] = root_of_slot[slot];
-        auto d2ll = [](double v) -> long long { return __double_as_longlong(v + 6755399441055744.0) - 0x4338000000000000LL; };
-        const double x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
-        v[0] = (unsigned long long)d2ll(x * kMomScale); v[1] = (unsigned long long)d2ll(y * kMomScale); v[2] = (unsigned long long)d2ll(z * kMomScale);
-        v[3] = (unsigned long long)d2ll(x * x * kMomScale); v[4] = (unsigned long long)d2ll(x * y * kMomScale);
-        v[5] = (unsigned long long)d2ll(x * z * kMomScale); v[6] = (unsigned long long)d2ll(y * y * kMomScale);
-        v[7] = (unsigned long long)d2ll(y * z * kMomScale); v[8] = (unsigned long long)d2ll(z * z * kMomScale);
-        v[9] = 1ull;
+    const int base = blockIdx.x * kCommitThreads * kCommitPerThread;
+    int slot[kCommitPerThread];
+    bool grown[kCommitPerThread];
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < kCommitPerThread; ++j) {
+        const int i = base + j * kCommitThreads + (int)threadIdx.x;
+        slot[j] = i < n ? Wfinal[i] : kRefInvalid;
+        grown[j] = i < n && slot[j] != Winit[i];           // only free pixels change, and only into a plane's slot
+        any |= grown[j];
     }
-    const unsigned long long gm = __ballot(grown);
-    if (gm != 0ull) {                                      // wave-uniform
+    if (!__syncthreads_or(any ? 1 : 0)) return;            // most blocks of a clean frame hold no grown pixel
+    if (threadIdx.x < kMomRunHash) {
+        keys[threadIdx.x] = -1;
+#pragma unroll
+        for (int q = 0; q < 10; ++q) vals[threadIdx.x][q] = 0ull;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kCommitPerThread; ++j) {
+        const unsigned long long gm = __ballot(grown[j]);
+        if (gm == 0ull) continue;                          // wave-uniform
+        const int i = base + j * kCommitThreads + (int)threadIdx.x;
+        unsigned long long v[10] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+        if (grown[j]) {
+            label[i] = root_of_slot[slot[j]];
+            auto d2ll = [](double v) -> long long { return __double_as_longlong(v + 6755399441055744.0) - 0x4338000000000000LL; };
+            const double x = xyz[3 * (size_t)i], y = xyz[3 * (size_t)i + 1], z = xyz[3 * (size_t)i + 2];
+            v[0] = (unsigned long long)d2ll(x * kMomScale); v[1] = (unsigned long long)d2ll(y * kMomScale); v[2] = (unsigned long long)d2ll(z * kMomScale);
+            v[3] = (unsigned long long)d2ll(x * x * kMomScale); v[4] = (unsigned long long)d2ll(x * y * kMomScale);
+            v[5] = (unsigned long long)d2ll(x * z * kMomScale); v[6] = (unsigned long long)d2ll(y * y * kMomScale);
+            v[7] = (unsigned long long)d2ll(y * z * kMomScale); v[8] = (unsigned long long)d2ll(z * z * kMomScale);
+            v[9] = 1ull;
+        }
         // a noisy patch sends whole waves to ONE plane: those are summed across the wave first (sums of integers: order free) and
-        // enter the hash once; 64 lanes x 10 atomics on one LDS address each took most of this kernel's 118 us
+        // enter the hash once; 64 lanes x 10 atomics on one LDS address each took most of the first version's 118 us
         const int first = __builtin_ctzll(gm);
-        const int s0 = __builtin_amdgcn_readlane(slot, first);
-        const bool one_plane = __ballot(grown && slot != s0) == 0ull;
+        const int s0 = __builtin_amdgcn_readlane(slot[j], first);
+        const bool one_plane = __ballot(grown[j] && slot[j] != s0) == 0ull;
         if (one_plane) {
 #pragma unroll
             for (int q = 0; q < 10; ++q) v[q] = wave_sum_ll(v[q]);
         }
-        if (one_plane ? lane == first : grown) {
-            const int h = mom_run_slot(keys, slot);
+        if (one_plane ? lane == first : grown[j]) {
+            const int h = mom_run_slot(keys, slot[j]);
             if (h >= 0) {
 #pragma unroll
                 for (int q = 0; q < 10; ++q) atomicAdd(&vals[h][q], v[q]);
             } else {                                       // hash full (more than 256 planes meet in one block): straight to memory
 #pragma unroll
-                for (int q = 0; q < 9; ++q) atomicAdd(&mom_rep[(size_t)slot * 9 + q], v[q]);
-                atomicAdd(&count_of_slot[slot], (int)v[9]);
+                for (int q = 0; q < 9; ++q) atomicAdd(&mom_rep[(size_t)slot[j] * 9 + q], v[q]);
+                atomicAdd(&count_of_slot[slot[j]], (int)v[9]);
                 atomicAdd(n_changed, (int)v[9]);
             }
-            block_changed = 1;
         }
     }
     __syncthreads();
-    if (!block_changed) return;
-    const int hs = keys[threadIdx.x];
-    if (hs >= 0) {
+    if (threadIdx.x < kMomRunHash) {
+        const int hs = keys[threadIdx.x];
+        if (hs >= 0) {
 #pragma unroll
-        for (int q = 0; q < 9; ++q) atomicAdd(&mom_rep[(size_t)hs * 9 + q], vals[threadIdx.x][q]);
-        atomicAdd(&count_of_slot[hs], (int)vals[threadIdx.x][9]);
-        atomicAdd(n_changed, (int)vals[threadIdx.x][9]);
+            for (int q = 0; q < 9; ++q) atomicAdd(&mom_rep[(size_t)hs * 9 + q], vals[threadIdx.x][q]);
+            atomicAdd(&count_of_slot[hs], (int)vals[threadIdx.x][9]);
+            atomicAdd(n_changed, (int)vals[threadIdx.x][9]);
+        }
     }
 }
 

@@ -2135,8 +2135,8 @@ int f360_refine_dev(rgbd360_ctx* ctx, int rows, int cols, int nslots, std::vecto
         // "something changed" flag of every second launch (a check costs a stream synchronisation): the run ends with a launch that
         // changed nothing.
         constexpr int kPerCheck = 2;
-        static const int kPolls = [] { const char* e = getenv("RGBD360_REFINE_POLLS"); return e ? atoi(e) : 512; }();
-        static const int kQuiet = [] { const char* e = getenv("RGBD360_REFINE_QUIET"); return e ? atoi(e) : 64; }();
+        static const int kPolls = [] { const char* e = getenv("RGBD360_REFINE_POLLS"); return e ? atoi(e) : 4096; }();      // (512 until round 4: a launch whose growth chains were still moving gave up after 0.34 ms and cost a second round of launches + a host synchronisation)
+        static const int kQuiet = [] { const char* e = getenv("RGBD360_REFINE_QUIET"); return e ? atoi(e) : 32; }();
         const int max_rounds = tiles_x + tiles_y + 8;      // a tile is final once its predecessor tiles are: one launch per tile at worst
         for (int round = 0; round < max_rounds && !converged; ++round) {
             volatile int* flags = ctx->f_flags_host;
@@ -2155,10 +2155,24 @@ int f360_refine_dev(rgbd360_ctx* ctx, int rows, int cols, int nslots, std::vecto
             converged = flags[kPerCheck - 1] == 0;      // a launch that changes nothing is a fixed point: every later one repeats it
         }
         if (!converged) return fail(ctx, -7, "plane refinement did not converge");
+        if (getenv("RGBD360_REFINE_DEBUG")) {
+            int act = 0;
+            hipMemcpy(&act, d_activity, sizeof(int), hipMemcpyDeviceToHost);
+            int nfree = 0;
+            std::vector<unsigned char> tf((size_t)tiles_x * tiles_y);
+            hipMemcpy(tf.data(), tile_free, tf.size(), hipMemcpyDeviceToHost);
+            for (unsigned char v : tf) nfree += v ? 1 : 0;
+            for (int ty = 0; ty < tiles_y; ++ty) {
+                std::string line;
+                for (int tx = 0; tx < tiles_x; ++tx) { const int v = tf[(size_t)ty * tiles_x + tx]; line += v == 0 ? '.' : (v == 1 ? 'o' : (v < 11 ? char('0' + v - 1) : '#')); }
+                fprintf(stderr, "%s\n", line.c_str());
+            }
+            fprintf(stderr, "[refine dbg] pass %d: activity (steps that changed a label, cumulative) %d, free tiles %d of %d, sweeps %d\n", pass, act, nfree, tiles_x * tiles_y, sweeps);
+        }
     }
     const int* W0 = w[1];
     HIPC(ctx, hipMemsetAsync(d_changed, 0, sizeof(int), ctx->stream));
-    hipLaunchKernelGGL(k_f360_refine_commit, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->f_xyz, ctx->f_label, w[0], W0, ctx->f_root_of_slot, n,
+    hipLaunchKernelGGL(k_f360_refine_commit, dim3((n + kCommitThreads * kCommitPerThread - 1) / (kCommitThreads * kCommitPerThread)), dim3(kCommitThreads), 0, ctx->stream, ctx->f_xyz, ctx->f_label, w[0], W0, ctx->f_root_of_slot, n,
                        ctx->f_count_of_slot, ctx->f_mom, kF360MaxSlots, d_changed);
     HIPC(ctx, hipMemcpyAsync(ctx->f_flags_host + kFlags, d_changed, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     hipLaunchKernelGGL(k_f360_mom_reduce, dim3((kF360MaxSlots * 9 + 255) / 256), dim3(256), 0, ctx->stream, ctx->f_mom, ctx->f_nslots, kF360MaxSlots,
