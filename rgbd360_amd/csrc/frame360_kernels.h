@@ -2263,7 +2263,11 @@ __device__ __forceinline__ void coherent_store(int* p, int v) { __hip_atomic_sto
 // (no wave waits for another: nothing depends on residency) and ends early once `activity` -- a counter every changing step bumps
 // -- has stood still for a few polls.  A launch in which no step changed anything has read nothing but final values (its first step
 // sees everything earlier launches wrote): that is the host's convergence test.  Tiles without free pixels (tile_free) do nothing.
-template <int PASS>
+// LDS_MODELS: the plane models come out of LDS (n_lds_models = all slots) -- a template argument, not a run-time choice: with
+// `n_lds_models > 0 ? s_models[l] : models[l]` the compiler formed ONE pointer and a FLAT load, whose wait is vmcnt(0) + lgkmcnt(0),
+// i.e. every row of a step also waited for the device-scope stores of the rows before it to be acknowledged by memory: 2.7 us per
+// row that changed a label, 44-90 us per step (per-wave clocks) -- the whole cost of the refinement's launches.
+template <int PASS, bool LDS_MODELS>
 __global__ __launch_bounds__(64 * kRefWaves) void k_f360_refine_tile(const float* __restrict__ xyz, const int* __restrict__ W0, int* X,
                                                                     const float4* __restrict__ models, float thr, int rows, int cols,
                                                                     int tiles_y, const unsigned char* __restrict__ tile_free,
@@ -2307,10 +2311,15 @@ __global__ __launch_bounds__(64 * kRefWaves) void k_f360_refine_tile(const float
     const bool ring_side_valid = (cc >= 0 && cc < cols && rprev >= 0 && rprev < rows) ? (W0[(size_t)rprev * cols + cc] != kRefInvalid) : false;
     bool edge_valid[kRefTH];                   // the tile-edge lane's neighbour in the next tile (pass labels, static)
     {
+        // lane k loads the label beside row k, the rows read it with v_readlane: ONE load (as sixteen conditional loads of a uniform
+        // address the compiler issued them one after the other, each behind its own wait: 15 memory round trips, ~20 us, before a
+        // wave's first step)
         const int edge_c = PASS == 1 ? c0 + 64 : c0 - 1;
+        const bool edge_in = lane < kRefTH && edge_c >= 0 && edge_c < cols && r0 + lane < rows;
+        const int edge_label = W0[(size_t)(edge_in ? r0 + lane : 0) * cols + (edge_in ? edge_c : 0)];
+        const int edge_ok = (edge_in && edge_label != kRefInvalid) ? 1 : 0;
 #pragma unroll
-        for (int k = 0; k < kRefTH; ++k)
-            edge_valid[k] = (edge_c >= 0 && edge_c < cols && r0 + k < rows) ? (W0[(size_t)(r0 + k) * cols + edge_c] != kRefInvalid) : false;
+        for (int k = 0; k < kRefTH; ++k) edge_valid[k] = __builtin_amdgcn_readlane(edge_ok, k) != 0;
     }
     int ring_side = side_in ? coherent_load(side_p) : kRefInvalid;
     int ring_prev = prev_in ? coherent_load(prev_p) : kRefInvalid;
@@ -2328,7 +2337,9 @@ __global__ __launch_bounds__(64 * kRefWaves) void k_f360_refine_tile(const float
             const bool is_free = state == kRefFree;
             auto within = [&](int label) {        // PlaneRefinementComparator::compare's distance test of this pixel against plane `label`
                 const int l = label >= 0 ? label : 0;
-                const float4 m = n_lds_models > 0 ? s_models[l] : models[l];
+                float4 m;
+                if (LDS_MODELS) m = s_models[l];
+                else m = models[l];
                 const double ptp_dist = fabs(m.x * px[k] + m.y * py[k] + m.z * pz[k] + m.w);
                 return label >= 0 && ptp_dist < (double)thr;
             };

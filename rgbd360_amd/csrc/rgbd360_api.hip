@@ -2142,12 +2142,14 @@ int f360_refine_dev(rgbd360_ctx* ctx, int rows, int cols, int nslots, std::vecto
             volatile int* flags = ctx->f_flags_host;
             for (int k = 0; k < kPerCheck; ++k) flags[k] = 0;
             for (int k = 0; k < kPerCheck; ++k) {
-                if (pass == 1)
-                    hipLaunchKernelGGL((k_f360_refine_tile<1>), g, b, lds_bytes, ctx->stream, ctx->f_xyz, W0, w[1], ctx->f_models, ctx->f_refine_dist, rows, cols,
-                                       tiles_y, tile_free, ctx->f_flags_host + k, d_activity, kPolls, kQuiet, n_lds);
-                else
-                    hipLaunchKernelGGL((k_f360_refine_tile<2>), g, b, lds_bytes, ctx->stream, ctx->f_xyz, W0, w[1], ctx->f_models, ctx->f_refine_dist, rows, cols,
-                                       tiles_y, tile_free, ctx->f_flags_host + k, d_activity, kPolls, kQuiet, n_lds);
+#define REFINE_TILE(P, L) hipLaunchKernelGGL((k_f360_refine_tile<P, L>), g, b, lds_bytes, ctx->stream, ctx->f_xyz, W0, w[1], ctx->f_models, ctx->f_refine_dist, rows, cols, \
+                                             tiles_y, tile_free, ctx->f_flags_host + k, d_activity, kPolls, kQuiet, n_lds)
+                if (pass == 1) {
+                    if (n_lds > 0) REFINE_TILE(1, true); else REFINE_TILE(1, false);
+                } else {
+                    if (n_lds > 0) REFINE_TILE(2, true); else REFINE_TILE(2, false);
+                }
+#undef REFINE_TILE
                 ++sweeps;
             }
             HIPC(ctx, hipGetLastError());

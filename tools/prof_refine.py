@@ -1,3 +1,6 @@
+"""frame_planes with the refinement of segmentAndRefine switched on (what the C++ adapter does by default), for rocprofv3:
+   python tools/prof_refine.py [W] [noise_sigma_m]      ANG=<angular threshold> (default 0.015: the walls stay separate planes)
+   tools/prof_refine.sh runs the refinement tests, the kernel trace of a clean and a noisy frame and tools/refine_perf.py."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,6 +1,6 @@
 timeout -k 10 600 python -m pytest tests -m gpu -x -q -k "refine or plane" > gpurun_out/t_ref.log 2>&1; tail -2 gpurun_out/t_ref.log
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for nz in 0 0.01; do rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/rf -- python3 tools/_refine_prof.py 2048 $nz > gpurun_out/rf.log 2>&1; python - <<PY
+for nz in 0 0.01; do rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/rf -- python3 tools/prof_refine.py 2048 $nz > gpurun_out/rf.log 2>&1; python - <<PY
 import csv,glob
 f=glob.glob("gpurun_out/rf/**/*kernel_stats.csv",recursive=True)[0]
 rows=list(csv.DictReader(open(f)))
