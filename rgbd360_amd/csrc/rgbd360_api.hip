@@ -2153,7 +2153,7 @@ int f360_refine_dev(rgbd360_ctx* ctx, int rows, int cols, int nslots, std::vecto
                 ++sweeps;
             }
             HIPC(ctx, hipGetLastError());
-            HIPC(ctx, hipStreamSynchronize(ctx->stream));
+            HIPC(ctx, hostwait::tag_and_wait(ctx->tag, ctx->stream));      // (a tag kernel + host spin: ~10 us less than hipStreamSynchronize, host_wait.h)
             converged = flags[kPerCheck - 1] == 0;      // a launch that changes nothing is a fixed point: every later one repeats it
         }
         if (!converged) return fail(ctx, -7, "plane refinement did not converge");
@@ -2184,7 +2184,7 @@ int f360_refine_dev(rgbd360_ctx* ctx, int rows, int cols, int nslots, std::vecto
     launch_hull(ctx, rows, cols, /*clear_first=*/true);
     launch_colour(ctx, rows, cols);          // the colour of the REFINED inlier sets (Frame360.h:1045-1046 run on the refined regions)
     HIPC(ctx, hipGetLastError());
-    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    HIPC(ctx, hostwait::tag_and_wait(ctx->tag, ctx->stream));      // (a tag kernel + host spin: ~10 us less than hipStreamSynchronize, host_wait.h)
     ctx->f_refine_changed = ctx->f_flags_host[kFlags];
     ctx->f_refine_sweeps = sweeps;
     // count and the extent descriptors of the grown inlier sets (Frame360.h:1010-1037 derives them from the refined inlier cloud);
@@ -2290,7 +2290,7 @@ int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float
         launch_colour(ctx, rows, cols);
     }
     HIPC(ctx, hipGetLastError());
-    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    HIPC(ctx, hostwait::tag_and_wait(ctx->tag, ctx->stream));      // (a tag kernel + host spin: ~10 us less than hipStreamSynchronize, host_wait.h)
     const int nslots = *reinterpret_cast<const volatile int*>(ctx->f_pack_host);
     if (nslots > kF360MaxSlots) return fail(ctx, -7, "more than 4096 regions exceed min_inliers");
     const F360SlotRecord* recs = reinterpret_cast<const F360SlotRecord*>(ctx->f_pack_host + kF360PackHeader);
