@@ -2352,6 +2352,9 @@ __global__ __launch_bounds__(64 * kRefWaves) void k_f360_refine_tile(const float
             // propagation along the row
             const bool still_free = state == kRefFree;
             const unsigned long long nonfree = __ballot(!still_free);
+            // (a row without a free pixel left -- most rows of most tiles, and every row a flood from the previous row has filled -- has
+            // nothing to propagate: the search, the crossbar read and the second test are skipped; wave-uniform)
+            if (nonfree != ~0ull) {
             int s;                                 // lane of the nearest non-free pixel on the incoming side, -1 / 64: the ring pixel
             if (PASS == 1) {
                 const unsigned long long m = nonfree & ((1ull << lane) - 1ull);
@@ -2373,6 +2376,7 @@ __global__ __launch_bounds__(64 * kRefWaves) void k_f360_refine_tile(const float
                 // every pixel of the chain must be allowed to hand the label on: the chain runs inside rows 0 .. H-2 (pass 1) / 1 .. H-1 (pass 2)
                 // for all of them alike, and column limits only bind at the image border, where the chain starts
                 if ((range & ~okm) == 0ull) state = cand;
+            }
             }
             if (col_in && r < rows && state != cur[k]) {
                 chg = true;

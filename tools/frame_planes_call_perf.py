@@ -1,5 +1,5 @@
 """Wall time of the C call rgbd360_frame_planes_dev alone (no Python conversion of the plane list), next to the kernel time the
-rocprofv3 traces give (0.22 ms at 2048x1024): what the host side of the chain costs.  python tools/frame_planes_call_perf.py [W]"""
+rocprofv3 traces give (0.22 ms at 2048x1024): what the host side of the chain costs.  python tools/frame_planes_call_perf.py [W [angular_threshold [refine 0|1]]]"""
 import ctypes as C
 import os
 import sys
@@ -13,10 +13,13 @@ from rgbd360_amd.register import RegisterPhotoICP
 
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 ANG = float(sys.argv[2]) if len(sys.argv) > 2 else 0.03
+REFINE = int(sys.argv[3]) if len(sys.argv) > 3 else 0          # 1: with segmentAndRefine's refinement (rgbd360_set_plane_refinement)
 H = W // 2
 (_, dA), _, _ = synth.make_pair(W, H, seed=5)
 reg = RegisterPhotoICP()
 L = _lib.load()
+if REFINE:
+    assert L.rgbd360_set_plane_refinement(reg._ctx(), 1, C.c_float(0.02)) == 0
 hip = C.CDLL("libamdhip64.so")
 hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
 hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
