@@ -287,7 +287,7 @@ typedef struct {
      * third-party and not in the reference tree):
      *   area        area of the convex hull of the region's contour projected onto its plane (calcConvexHull +
      *               computeMassCenterAndArea): metric, whatever the pixel density.  The device reduces the boundary pixels to the
-     *               region's extreme point in each of 256 in-plane directions, the host runs hull + shoelace on those (an inscribed
+     *               region's extreme point in each of 1024 in-plane directions (eight interleaved sets of 128), the host runs hull + shoelace on those (an inscribed
      *               polygon: exact for sharp-cornered polygons, 0.01 % low for a disc, a few 0.1 % low where long edges are slightly bowed).  Frame360.h:1031 compares it with min_area_plane (0.12 m2),
      *               RegisterRGBD360.h:126-136 ranks planes by it.
      *   elongation  sqrt(l2 / l1), ppal_dir = eigenvector of l2: PCA of the inliers (l1 <= l2 the in-plane eigenvalues of their

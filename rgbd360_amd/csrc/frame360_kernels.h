@@ -1681,24 +1681,26 @@ __global__ void k_f360_colour_pack(const unsigned long long* __restrict__ col, c
 // computeMassCenterAndArea; MRPT is not in the reference tree: the hull of the region's contour projected onto its plane, the area
 // and mass centre of that polygon).  The hull of a region's contour is the hull of its pixels, and only pixels on the region's
 // boundary can be hull vertices.  On the device the boundary pixels are reduced to the region's EXTREME point in each of
-// kHullDirs = 256 in-plane directions (a wave holds four directions per lane -- an angle in the first quadrant and its rotations by
-// 90, 180 and 270 degrees, which share two dot products -- and walks the boundary pixels of its 64-pixel stretch through v_readlane;
-// one 64-bit atomicMax per direction and run of equal labels, key = {order-preserving dot product, pixel}): an inscribed polygon
-// that contains every hull vertex whose exterior angle exceeds 2 pi / 256 -- exact for sharp-cornered polygons, 0.01 % low for a
-// disc; what it can lose is a long, slightly bowed edge whose normals all fall between two directions (the margin of a wall's region
-// widens with the range: with 64 directions the 8 m floor of the synthetic room read 0.7 % low at 2048 x 1024, a wall 1.2 % low at
-// 512 x 256).  The extremes arrive in direction order, i.e. already in hull order: the host drops the non-left turns in one linear
-// pass (no sort) and takes the shoelace sums.
+// kHullDirs = 128 in-plane directions per block (a wave holds two directions per lane -- an angle in the first half turn and the
+// opposite one, which share one dot product -- and walks the boundary pixels of its 64-pixel stretch through v_readlane; one 64-bit
+// atomicMax per direction and run of equal labels, key = {order-preserving dot product, pixel}), kHullPhases = 8 interleaved sets of
+// them, 1024 directions in all: an inscribed polygon that contains every hull vertex whose exterior angle exceeds a few direction
+// steps -- exact for sharp-cornered polygons, 0.01 % low for a disc; what it can lose is a long, slightly bowed edge whose normals all
+// fall between two directions of the set that happens to see it (the margin of a wall's region widens with the range).  The extremes
+// arrive in direction order, i.e. already in hull order: the host drops the non-left turns in one linear pass (no sort) and takes
+// the shoelace sums.
 //   k_f360_slot_frames   per region slot: centroid + in-plane basis (eigenvectors of the inlier covariance, float64 Jacobi)
 //   k_f360_hull_extremes per 64-pixel stretch: boundary test, in-plane coordinates, directional maxima
 //   k_f360_hull_pack     winners' coordinates + the frame into the pinned record the host reads
 // ---------------------------------------------------------------------------------------------------------
-constexpr int kHullDirs = 256;       // per block, 4 per lane: a lane's direction and its rotations by 90, 180, 270 degrees share two dot products
-// Four direction sets, a quarter of the angular step apart: block b works with set b mod 4.  Thanks to the scattered stretches every
-// block sees a sample of every edge of a region, so the union of the four sets' winners is a polygon of up to 1024 region pixels, still
-// inscribed in the hull -- at no cost in the walk.  One set's 1.4-degree step cannot see the bow of a long, nearly straight edge whose
-// normals all fall between two directions: the 8 m walls of a room lost 0.4-0.6 % of their hull (tests/tools/hull_soak.py).
-constexpr int kHullPhases = 4;
+constexpr int kHullDirs = 128;       // per block, 2 per lane: a lane's direction and the opposite one share one dot product (round 4; 256 = quarter turns until then)
+// Eight direction sets, an eighth of the set's angular step apart: block b works with set b mod 8.  Thanks to the scattered stretches every
+// block sees a sample of every edge of a region, so the union of the sets' winners is a polygon of up to 1024 region pixels, still
+// inscribed in the hull.  (Rounds 2-3: four sets of 256 directions, four per lane: 0.9988 x the exact hull at worst over 30 random scenes;
+// eight sets of 128: 0.9979 -- each direction sees an eighth of the boundary instead of a quarter -- for half the walk, 1 KB table rows
+// and 64 of them per block, tests/tools/hull_soak.py.)
+constexpr int kHullPhases = 8;         // direction sets, block b works on set b mod 8 (round 4: 4 sets of 256 -- a table row was 2 KB and a block's
+                                       // 32 rows overflowed into global atomics on frames with many planes: 250 us at 4096 x 2048 with 444 planes)
 constexpr int kHullRecPts = kHullPhases * kHullDirs;     // points a record can hold; a point that wins several directions of a set is sent once
 struct SlotFrame {
     float c[3], e1[3], e2[3], nrm[3];
@@ -1806,7 +1808,9 @@ __device__ __forceinline__ unsigned hull_f2ord(float f) {          // order-pres
 // memory as rows of its own at the end.  The walk over a wave's boundary pixels is serial (every lane updates its four directions per
 // pixel), so the work sits where the long, nearly horizontal edges are.  (First version: eight consecutive 1024-pixel stretches per
 // block and 64-bit keys in the inner loop, 77 us, the straggler blocks being those along the floor's and ceiling's edges.)
-constexpr int kHullBlock = 1024, kHullChunks = 8, kHullHash = 32, kHullFramesLds = 128;
+constexpr int kHullBlock = 1024, kHullChunks = 8, kHullHash = 64, kHullFramesLds = 128;
+constexpr int kHullRot = kHullDirs / 64;      // directions per lane: the lane's own and its rotation(s)
+static_assert(kHullRot == 2, "the walk below pairs a direction with its opposite");
 #ifdef F360_HULL_TWO
 constexpr int kHullList = 512;
 #else
@@ -1906,9 +1910,9 @@ __device__ __forceinline__ void hull_extremes_block(const float* __restrict__ xy
     }
     for (int k = threadIdx.x; k < kHullHash * kHullDirs; k += kHullBlock) (&vals[0][0])[k] = 0ull;
     if (threadIdx.x < kHullHash) keys[threadIdx.x] = -1;
-    // this lane's direction (cos, sin) at angle 2 pi lane / 256 and its three quarter-turn rotations: direction lane + 64 m, m = 0 .. 3,
-    // has the dot products d0 = u c + v s, d1 = v c - u s, -d0, -d1.  (The hardware's sine / cosine take revolutions; any 256 directions
-    // spread over the circle do, they need not be exact.)
+    // this lane's direction (cos, sin) in the first half turn and the opposite one: directions lane + 64 m, m = 0, 1, of the block's set
+    // have the dot products d0 = u c + v s and -d0.  (The hardware's sine / cosine take revolutions; any 1024 directions spread over the
+    // circle do, they need not be exact.)
     const int phase = (int)blockIdx.x & (kHullPhases - 1);
     const float rev = (float)(lane * kHullPhases + phase) * (1.f / (kHullDirs * kHullPhases));
     const float sk = __builtin_amdgcn_sinf(rev), ck = __builtin_amdgcn_cosf(rev);
@@ -1948,24 +1952,22 @@ __device__ __forceinline__ void hull_extremes_block(const float* __restrict__ xy
             remaining &= ~todo;
             const unsigned long long hd_b = HDBG_T();
             hd_entries += __builtin_popcountll(todo); hd_runs += 1;
-            float bd[4];
-            int bj[4];
+            float bd[kHullRot];
+            int bj[kHullRot];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) { bd[m] = -__builtin_inff(); bj[m] = 0; }
+            for (int m = 0; m < kHullRot; ++m) { bd[m] = -__builtin_inff(); bj[m] = 0; }
             while (todo != 0ull) {                         // wave-uniform
                 const int j = __builtin_ctzll(todo);
                 todo &= todo - 1ull;
                 const float uj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ui, j));
                 const float vj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, j));
                 const int pj = __builtin_amdgcn_readlane(pix, j);
-                const float d0 = fmaf(uj, ck, vj * sk), d1 = fmaf(vj, ck, -(uj * sk));
+                const float d0 = fmaf(uj, ck, vj * sk);
                 if (d0 > bd[0]) { bd[0] = d0; bj[0] = pj; }
-                if (d1 > bd[1]) { bd[1] = d1; bj[1] = pj; }
-                if (-d0 > bd[2]) { bd[2] = -d0; bj[2] = pj; }
-                if (-d1 > bd[3]) { bd[3] = -d1; bj[3] = pj; }
+                if (-d0 > bd[1]) { bd[1] = -d0; bj[1] = pj; }
             }
 #ifdef RGBD360_HULL_DBG
-            asm volatile("" :: "v"(bd[0]), "v"(bd[1]), "v"(bd[2]), "v"(bd[3]));
+            asm volatile("" :: "v"(bd[0]), "v"(bd[1]));
 #endif
             const unsigned long long hd_c = HDBG_T();
             hd_walk += hd_c - hd_b;
@@ -1980,16 +1982,16 @@ __device__ __forceinline__ void hull_extremes_block(const float* __restrict__ xy
                 }
                 if (seen == cur) h = k;
             }
-            unsigned long long key[4];
+            unsigned long long key[kHullRot];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) key[m] = ((unsigned long long)hull_f2ord(bd[m]) << 32) | (unsigned)bj[m];
+            for (int m = 0; m < kHullRot; ++m) key[m] = ((unsigned long long)hull_f2ord(bd[m]) << 32) | (unsigned)bj[m];
             if (h >= 0) {
                 unsigned long long* row = &vals[h][lane];
 #pragma unroll
-                for (int m = 0; m < 4; ++m) __hip_atomic_fetch_max(row + 64 * m, key[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                for (int m = 0; m < kHullRot; ++m) __hip_atomic_fetch_max(row + 64 * m, key[m], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             } else {
 #pragma unroll
-                for (int m = 0; m < 4; ++m) atomicMax(&ext[((size_t)cur * kHullPhases + phase) * kHullDirs + 64 * m + lane], key[m]);
+                for (int m = 0; m < kHullRot; ++m) atomicMax(&ext[((size_t)cur * kHullPhases + phase) * kHullDirs + 64 * m + lane], key[m]);
             }
             hd_flush += HDBG_T() - hd_c;
         }
@@ -2139,7 +2141,7 @@ __global__ __launch_bounds__(kHullDirs) void k_f360_hull_merge(const int* __rest
             const unsigned long long cand = part_vals[(size_t)match[q] * kHullDirs + k];
             key = cand > key ? cand : key;
         }
-        if (key != 0ull) atomicMax(&ext[((size_t)slot * kHullPhases + (m & (kHullPhases - 1))) * kHullDirs + k], key);      // (tables b = m mod 8 share the set m mod 4)
+        if (key != 0ull) atomicMax(&ext[((size_t)slot * kHullPhases + (m & (kHullPhases - 1))) * kHullDirs + k], key);      // (the tables of the blocks b = m mod 8 are those of direction set m)
         __syncthreads();
     }
 }
