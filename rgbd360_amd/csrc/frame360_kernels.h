@@ -2107,7 +2107,7 @@ __global__ __launch_bounds__(kHullBlock) __attribute__((amdgpu_waves_per_eu(8, 8
 // kernel did it, and anything that put a dependent look-up in front of each row load made every row a full memory round trip:
 // 160 us).  Here kHullMergeSplit blocks share a slot's rows -- block (slot, m) takes the tables of the blocks b = m mod 8 -- and meet
 // in the global row with one atomicMax per direction (8 adders per word).
-constexpr int kHullMergeSplit = 8;
+constexpr int kHullMergeSplit = 16;     // (8 until the tables had 64 rows: the key scan and the row loop per merge block doubled)
 __global__ __launch_bounds__(kHullDirs) void k_f360_hull_merge(const int* __restrict__ n_slots, int max_slots, const int* __restrict__ part_keys,
                                                                 const unsigned long long* __restrict__ part_vals, int n_blocks,
                                                                 unsigned long long* __restrict__ ext) {
