@@ -2328,6 +2328,10 @@ __global__ __launch_bounds__(64 * kRefWaves) void k_f360_refine_tile(const float
     bool any_change = false;
 
     auto step = [&]() {                        // one exact sweep of the tile against the ring held in ring_side / ring_prev
+        // everything the rows read has ARRIVED before the first row: a row that met the ring's loaded value first inside its
+        // conditional part got a vmcnt(0) there -- which also waits for the label store of the row before (a device-scope store is
+        // acknowledged by memory: ~1 us) -- in every row, since the rows before may have skipped theirs
+        asm volatile("" ::"v"(ring_side), "v"(ring_prev));
         int prev = ring_prev;
         bool prev_side_valid = ring_side_valid;
         bool chg = false;
