@@ -660,10 +660,11 @@ def test_plane_regions_match_oracle(hip_lib, oracle_mod, depth_mode, ang):
             assert abs(abs(np.dot(a["normal"], b["normal"])) - 1) < 1e-5 and abs(a["d"] - b["d"]) < 1e-4
 
 
-@pytest.mark.parametrize("W,H", [(250, 101), (700, 37), (65, 70), (24, 15), (513, 129)])
+@pytest.mark.parametrize("W,H", [(250, 101), (700, 37), (65, 70), (24, 15), (513, 129), (1028, 37), (1500, 70), (1920, 33), (1026, 20), (4100, 18)])
 def test_plane_regions_ragged_sizes(hip_lib, oracle_mod, W, H):
     """The tiled / hierarchical component passes on sizes that are not multiples of their tiles (256 x 4 link tile, 4 rows per
-    run block, 16-row merge bands, 64-row top level, 512-pixel wave strips): labels, counts and plane roots equal the oracle's."""
+    run block, 64 x 64 merge tiles, 512-pixel wave strips; from 1024 columns on -- rows of whole dwords -- four waves share a row of the
+    run pass, 1026 columns take the one-wave kernel again): labels, counts and plane roots equal the oracle's."""
     from rgbd360_amd.register import Frame360Stages
     (rgbA, dA), _, _ = synth.make_pair(W, H, seed=W + H)
     d = dA.copy()
