@@ -1430,6 +1430,35 @@ def test_sensor_cloud_bit_exact(hip_lib, oracle_mod, rows, cols, step):
     assert np.array_equal(np.nan_to_num(got), np.nan_to_num(want))
 
 
+@pytest.mark.parametrize("convention", [0, 1, 2])
+@pytest.mark.parametrize("depth_f32", [False, True])
+@pytest.mark.parametrize("depth_mode", [0, 1])
+def test_frame_planes_equals_the_stages_in_every_mode(hip_lib, convention, depth_f32, depth_mode):
+    """rgbd360_frame_planes forms the cloud inside the depth-edge kernel, which round 4 compiles once per {convention, depth type,
+    depth mode} (k_f360_edge_bits<true, SPEC>): the cloud, the normal map and the labels of every combination equal those of the staged
+    route -- rgbd360_sphere_cloud (k_sphere_cloud), rgbd360_normal_map and rgbd360_plane_fit on that cloud (k_f360_edge_bits<false>) --
+    bit for bit."""
+    from rgbd360_amd.register import Frame360Stages
+    (_, dA), _, _ = synth.make_pair(512, 256, seed=21)
+    d = dA.astype(np.float32) * np.float32(0.001) if depth_f32 else dA
+    if convention == 1:
+        d = d.copy()
+        d[40:60, 100:140] = 16000 if not depth_f32 else 16.0      # beyond the 15 m the second convention accepts: NaN points
+    reg = _mk(hip_lib, 2)
+    st = Frame360Stages(reg)
+    kw = dict(max_depth_change_factor=0.05, normal_smoothing_size=8.0, min_inliers=40, angular_threshold=0.03, distance_threshold=0.05,
+              max_curvature=0.0013, depth_mode=depth_mode)
+    one = st.frame_planes(d, convention=convention, **kw)
+    xyz = reg.sphere_cloud(d, convention)
+    assert np.array_equal(np.isnan(one["xyz"]), np.isnan(xyz)) and np.array_equal(np.nan_to_num(one["xyz"]), np.nan_to_num(xyz))
+    nrm = st.normals(xyz, 256, 512, 0.05, 8.0, depth_mode)
+    assert np.array_equal(np.isnan(one["normals"]), np.isnan(nrm)) and np.array_equal(np.nan_to_num(one["normals"]), np.nan_to_num(nrm))
+    labels, planes = st.plane_fit(xyz, nrm, 256, 512, 40, 0.03, 0.05, 0.0013, depth_mode)
+    assert np.array_equal(one["labels"].reshape(-1), np.asarray(labels).reshape(-1))
+    assert [(p["root"], p["count"]) for p in one["planes"]] == [(p["root"], p["count"]) for p in planes]
+    assert np.isfinite(nrm).any()
+
+
 def test_sensor_planes_equals_the_two_calls(hip_lib):
     """rgbd360_sensor_planes (depth image in, planes out, the cloud never leaves the device) = rgbd360_sensor_cloud + rgbd360_cloud_planes."""
     from rgbd360_amd.register import Frame360Stages
