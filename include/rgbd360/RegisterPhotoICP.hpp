@@ -81,7 +81,12 @@ class RegisterPhotoICP {
     void setMaxDepth(float maxD) { p_.max_depth = maxD; reset(); }
     void setGrayVariance(float stdDev) { p_.sigma_photo = stdDev; reset(); }     // sets the std-dev (RPI.h:242-245)
     void setDepthVariance(float stdDev) { p_.sigma_depth = stdDev; reset(); }
-    void useSaliency(bool) {}             // only feeds code the spherical passes have commented out (RPI.h:2568-2642)
+    // RPI.h:266-269: selects calcGradientXY_saliency's pixel list (RPI.h:401-425), which only the pinhole error pass reads
+    // (RPI.h:590-690); the spherical passes' salient branch is commented out (RPI.h:2568-2642): no effect on alignFrames360.
+    void useSaliency(bool on) {
+        use_saliency_ = on;
+        if (ctx_ && rgbd360_use_saliency(ctx_, on ? 1 : 0, 0.01f) != 0) throw std::runtime_error(std::string("rgbd360_use_saliency: ") + rgbd360_last_error(ctx_));
+    }
     void setVisualization(bool viz) {
         if (viz) throw std::runtime_error("rgbd360: visualisation is not part of the MI355X path");
     }
@@ -127,7 +132,8 @@ class RegisterPhotoICP {
         num_iterations.assign(r.iters, r.iters + p_.n_pyr);
     }
 
-    // RPI.h:4254-4512: pinhole single-sensor alignment (Levenberg-Marquardt), occlusion 0.
+    // RPI.h:4254-4512: pinhole single-sensor alignment (Levenberg-Marquardt); occlusion 1 / 2 = errorPhotoICP_Occ1/2 +
+    // calcHessGrad_Occ1/2 (RPI.h:1107-2030) in their sequential semantics.
 #ifdef RGBD360_HAVE_EIGEN
     void alignFrames(const Mat4f& pose_guess, costFuncType method = PHOTO_CONSISTENCY, int occlusion = 0) {
 #else
@@ -139,6 +145,7 @@ class RegisterPhotoICP {
         status_ = rc;
         std::memcpy(hessian_.m, r.hessian, sizeof(hessian_.m));
         std::memcpy(gradient_.data(), r.gradient, sizeof(float) * 6);
+        if (occlusion == 2) SSO = r.sso;            // only calcHessGrad_Occ2 sets it on this path (RPI.h:2016)
         avResidual = (float)r.err_final;
         avPhotoResidual = r.rms_photo;
         avDepthResidual = r.rms_depth;
@@ -272,6 +279,7 @@ class RegisterPhotoICP {
     int status_ = 0;
     float cam_[4] = {0.f, 0.f, 0.f, 0.f};
     bool have_cam_ = false;
+    bool use_saliency_ = false;
 
     void reset() {
         if (ctx_) rgbd360_destroy(ctx_);
@@ -282,6 +290,7 @@ class RegisterPhotoICP {
             const int rc = rgbd360_create(&p_, &ctx_);
             if (rc != 0) throw std::runtime_error("rgbd360_create failed (" + std::to_string(rc) + "): no usable HIP device; there is no CPU fallback");
             if (have_cam_) rgbd360_set_camera(ctx_, cam_[0], cam_[1], cam_[2], cam_[3]);
+            if (use_saliency_) rgbd360_use_saliency(ctx_, 1, 0.01f);
         }
         return ctx_;
     }

@@ -397,15 +397,30 @@ int rgbd360_set_camera(rgbd360_ctx* ctx, float fx, float fy, float ox, float oy)
  * pinhole RGB-D images (the frames given to rgbd360_set_target / _source of a context created with mask_seams = 0) with
  * the reference's Levenberg-Marquardt schedule (lambda 0.01, x10 / /10, 10 iterations, tolerances 1e-4 hard-coded at
  * RPI.h:4303-4308), errorPhotoICP (RPI.h:560-748) and calcHessGrad (RPI.h:754-1104), CPose3D::exp (full exponential).
- * The per-pixel passes run on the device, the damping loop on the host.  occlusion must be 0.  Reference quirks kept:
- * the error divides both residual sums by the number of depth-valid pixels, so PHOTO_CONSISTENCY alone gives NaN and the
- * guess comes back (status RGBD360_NO_VALID_PIXELS); the error pass applies no saliency test while the H,g pass does. */
+ * The per-pixel passes run on the device, the damping loop on the host.  Reference quirks kept (occlusion 0): the error
+ * divides both residual sums by the number of depth-valid pixels, so PHOTO_CONSISTENCY alone gives NaN and the guess comes
+ * back (status RGBD360_NO_VALID_PIXELS); the error pass applies no saliency test while the H,g pass does.
+ * occlusion 1 / 2 select errorPhotoICP_Occ1 / calcHessGrad_Occ1 (RPI.h:1107-1544) and errorPhotoICP_Occ2 /
+ * calcHessGrad_Occ2 (RPI.h:1547-2030) in the SEQUENTIAL semantics of their source (index order; the OpenMP loops race on the
+ * z-buffer), as written: Occ2's error gate compares the target depth with the point's INVERSE depth, and both H,g variants
+ * sum a pixel's depth row only where its photometric residual is non-zero (DEPTH_CONSISTENCY alone: H = 0, ILL-POSED).
+ * No application of the reference calls them (MethodsRegisterRGBD360.cpp:348 passes 0). */
 int rgbd360_align_pinhole(rgbd360_ctx* ctx, const float guess[16], int method, int occlusion, float pose_out[16],
                           rgbd360_result* res);
+/* RegisterPhotoICP::useSaliency(bool) (RPI.h:266-269) with thresSaliency (RPI.h:217: 0.01): the pinhole error pass
+ * (occlusion 0) sums over vSalientPixels only -- the interior pixels whose TARGET gray gradient exceeds the threshold in x
+ * or y (calcGradientXY_saliency RPI.h:401-425), used as SOURCE pixel indices (RPI.h:590-690, as written); H, g keep every
+ * pixel (their salient branch is commented out, RPI.h:813-870).  No other path of this library reads the list. */
+int rgbd360_use_saliency(rgbd360_ctx* ctx, int on, float thres_saliency);
 /* One fused pinhole pass at `pose` (stage-level, for parity tests): error sums / counts of errorPhotoICP and H, g of
  * calcHessGrad; n_rows = Jacobian rows that entered the normal equations. */
 int rgbd360_eval_pinhole(rgbd360_ctx* ctx, int level, const float pose[16], int method, double err2_split[2],
                          long long n_split[2], float H[36], float g[6], double H64[36], double g64[6], long long* n_rows);
+/* The same with the occlusion mode (0: identical to rgbd360_eval_pinhole): error sums / counts of errorPhotoICP_Occ1/2 and
+ * H, g of calcHessGrad_Occ1/2 at `pose`; n_rows = numVisiblePixels as the reference counts it (a target pixel's first
+ * arrival counts twice, RPI.h:1421-1430). */
+int rgbd360_eval_pinhole_occ(rgbd360_ctx* ctx, int level, const float pose[16], int method, int occlusion, double err2_split[2],
+                             long long n_split[2], float H[36], float g[6], double H64[36], double g64[6], long long* n_rows);
 int rgbd360_warp_indices_pinhole(rgbd360_ctx* ctx, int level, const float pose[16], int32_t* host_out_rc);
 
 /* The same chain with the depth image already in HBM and the maps left there: *xyz_dev, *normals_dev (rows*cols*3 floats) and

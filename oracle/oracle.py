@@ -72,6 +72,15 @@ def lib():
         L.oracle_hessgrad_pinhole.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.POINTER(C.c_long)]
         L.oracle_get_lut_pinhole.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.oracle_align_pinhole_occ.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(Result)]
+        L.oracle_use_saliency.argtypes = [C.c_void_p, C.c_int, C.c_float]
+        L.oracle_salient_pixels.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.oracle_error_pinhole_salient.restype = C.c_double
+        L.oracle_error_pinhole_salient.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.oracle_error_pinhole_occ.restype = C.c_double
+        L.oracle_error_pinhole_occ.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.oracle_hessgrad_pinhole_occ.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                  C.c_void_p, C.POINTER(C.c_long)]
         L.oracle_se3_exp.argtypes = [C.c_void_p, C.c_void_p]
         L.oracle_warp_indices_pinhole.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.oracle_trace_len.argtypes = [C.c_void_p]
@@ -188,11 +197,43 @@ class Oracle:
     def set_camera(self, fx, fy, ox, oy):
         lib().oracle_set_camera(self.h, fx, fy, ox, oy)
 
-    def align_pinhole(self, guess=None, method=PHOTO_DEPTH):
+    def align_pinhole(self, guess=None, method=PHOTO_DEPTH, occlusion=0):
         g = pose_to_cm(np.eye(4) if guess is None else guess)
         out = np.zeros(16, dtype=np.float32)
-        st = lib().oracle_align_pinhole(self.h, _ptr(g), method, _ptr(out), C.byref(self.result))
+        st = lib().oracle_align_pinhole_occ(self.h, _ptr(g), method, occlusion, _ptr(out), C.byref(self.result))
         return st, pose_from_cm(out)
+
+    def use_saliency(self, on=True, thres_saliency=0.01):
+        """useSaliency(bool) RPI.h:266: the pinhole error pass runs over vSalientPixels only."""
+        lib().oracle_use_saliency(self.h, int(bool(on)), thres_saliency)
+
+    def salient_pixels(self, level) -> np.ndarray:
+        n = lib().oracle_salient_pixels(self.h, level, None)
+        out = np.empty(n, np.int32)
+        lib().oracle_salient_pixels(self.h, level, _ptr(out))
+        return out
+
+    def error_pinhole_salient(self, level, pose, method):
+        sums = np.zeros(4, np.float64)
+        e = lib().oracle_error_pinhole_salient(self.h, level, _ptr(pose_to_cm(pose)), method, _ptr(sums))
+        return e, sums[0], sums[1], int(sums[2]), int(sums[3])
+
+    def error_pinhole_occ(self, level, pose, method, occlusion):
+        """errorPhotoICP_Occ1 / _Occ2 -> (avPhoto + avDepth, sum photo, sum depth, n photo, n depth)."""
+        sums = np.zeros(4, np.float64)
+        e = lib().oracle_error_pinhole_occ(self.h, level, _ptr(pose_to_cm(pose)), method, occlusion, _ptr(sums))
+        return e, sums[0], sums[1], int(sums[2]), int(sums[3])
+
+    def hessgrad_pinhole_occ(self, level, pose, method, occlusion):
+        """calcHessGrad_Occ1 / _Occ2 -> (H f32, g f32, H f64, g f64, numVisiblePixels)."""
+        H = np.zeros(36, np.float32)
+        g = np.zeros(6, np.float32)
+        Hd = np.zeros(36, np.float64)
+        gd = np.zeros(6, np.float64)
+        nv = C.c_long()
+        lib().oracle_hessgrad_pinhole_occ(self.h, level, _ptr(pose_to_cm(pose)), method, occlusion, _ptr(H), _ptr(g), _ptr(Hd), _ptr(gd),
+                                          C.byref(nv))
+        return H.reshape(6, 6).T.copy(), g, Hd.reshape(6, 6).T.copy(), gd, nv.value
 
     def error_pinhole(self, level, pose, method):
         sums = np.zeros(4, np.float64)

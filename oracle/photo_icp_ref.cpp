@@ -107,6 +107,9 @@ struct Ctx {
     bool keep_intermediates = true;  // allocate J arrays per call like RPI.h:2761-2767
     float cam[4] = {0, 0, 0, 0};     // cameraMatrix(0,0), (1,1), (0,2), (1,2)   RPI.h:89, 254-257
     bool have_cam = false;
+    bool use_saliency = false;       // bUseSalientPixels (RPI.h:146, 266-269)
+    float thres_saliency = 0.01f;    // thresSaliency (RPI.h:217)
+    std::vector<std::vector<int>> salient;      // vSalientPixels (RPI.h:157): per level, built from the TARGET's gray gradients
 };
 
 // ------------------------------------------------------------------------------------
@@ -1193,6 +1196,250 @@ void calcHessGrad(Ctx& ctx, int level, const float* pose, int method) {
     ctx.sso = 0.f;
 }
 
+// RPI.h:401-425 calcGradientXY_saliency's pixel list: the gradient images are calcGradientXY's (same expressions), the list holds
+// the interior pixels of the TARGET's gray image with |gx| > thresSaliency or |gy| > thresSaliency, in index order.
+void buildSalientPixels(Ctx& ctx, int level) {
+    if ((int)ctx.salient.size() < ctx.p.n_pyr) ctx.salient.resize(ctx.p.n_pyr);
+    const Image &gx = ctx.gTrgGx[level], &gy = ctx.gTrgGy[level];
+    std::vector<int>& v = ctx.salient[level];
+    v.clear();
+    for (int r = 1; r < gx.rows - 1; ++r)
+        for (int c = 1; c < gx.cols - 1; ++c)
+            if (fabsf(gx.at(r, c)) > ctx.thres_saliency || fabsf(gy.at(r, c)) > ctx.thres_saliency) v.push_back(gx.cols * r + c);
+}
+
+// RPI.h:590-690: errorPhotoICP with bUseSalientPixels -- the same residuals over the pixels of vSalientPixels only.  The list was
+// built from the TARGET's gradients (RPI.h:445-446) and is used here to index the SOURCE's LUT and intensities (RPI.h:613-634):
+// restated as written.  calcHessGrad's corresponding branch is commented out (RPI.h:813-870): H, g use every pixel.
+double errorPhotoICP_salient(Ctx& ctx, int level, const float* pose, int method) {
+    double PhotoResidual = 0.0, DepthResidual = 0.0;
+    long nValidPhotoPts = 0, nValidDepthPts = 0;
+    const Image& graySrc = ctx.graySrc[level];
+    const int nRows = graySrc.rows, nCols = graySrc.cols;
+    const PinholeK K = level_intrinsics(ctx, level);
+    const float stdDevPhoto = ctx.p.sigma_photo, stdDevDepth = ctx.p.sigma_depth;
+    const float stdDevPhoto_inv = 1. / stdDevPhoto;
+    const PoseRT T = split_pose(pose);
+    const Image &grayTrg = ctx.grayTrg[level], &depthTrg = ctx.depthTrg[level];
+    buildSalientPixels(ctx, level);
+    for (int i : ctx.salient[level]) {
+        const float* p = &ctx.lut[3 * (size_t)i];
+        if (p[0] == kInvalidPoint) continue;
+        const WarpPin w = warp_pinhole(T, p, nRows, nCols, K, ctx.p.math_mode);
+        if (!w.visible) continue;
+        if (method == METHOD_PHOTO || method == METHOD_PHOTO_DEPTH) {
+            float photoDiff = grayTrg.at(w.r, w.c) - graySrc.d[i];
+            float weight_photo = weightHuber(photoDiff, stdDevPhoto) * stdDevPhoto_inv;
+            float weightedErrorPhoto = weight_photo * photoDiff;
+            PhotoResidual += weightedErrorPhoto * weightedErrorPhoto;
+            ++nValidPhotoPts;
+        }
+        if (method == METHOD_DEPTH || method == METHOD_PHOTO_DEPTH) {
+            float depth2 = depthTrg.at(w.r, w.c);
+            if (std::isfinite(depth2)) {
+                float depth1 = w.Z;
+                float depthDiff = depth2 - depth1;
+                float stdDev_depth1 = stdDevDepth * depth1;
+                float weight_depth = weightHuber(depthDiff, stdDev_depth1) / stdDev_depth1;
+                float weightedErrorDepth = weight_depth * depthDiff;
+                DepthResidual += weightedErrorDepth * weightedErrorDepth;
+                ++nValidDepthPts;
+            }
+        }
+    }
+    ctx.last_err2_photo = PhotoResidual; ctx.last_err2_depth = DepthResidual;
+    ctx.last_nvalid_photo = nValidPhotoPts; ctx.last_nvalid_depth = nValidDepthPts;
+    ctx.last_nvalid = nValidPhotoPts + nValidDepthPts;
+    return sqrt(PhotoResidual / nValidDepthPts) + sqrt(DepthResidual / nValidDepthPts);       // RPI.h:742-744
+}
+
+// ------------------------------------------------------------------------------------
+// Pinhole occlusion-aware variants (RPI.h:1107-2040; no application calls them: MethodsRegisterRGBD360.cpp:348 passes occlusion 0).
+// As for the spherical ones the SEQUENTIAL semantics of the source are restated (pixels in index order; the OpenMP build races on
+// the z-buffer).  Defects of the source, and what is done about each:
+//   * errorPhotoICP_Occ2's outlier gate compares the target DEPTH with the transformed point's INVERSE depth (RPI.h:1687-1690):
+//     restated as written.
+//   * calcHessGrad_Occ1/2 sum a pixel's depth row only where its PHOTOMETRIC residual is non-zero (RPI.h:1530-1535, 2008-2013:
+//     `residualsPhoto(i) != 0` in both loops), so DEPTH_CONSISTENCY alone yields H = 0 (-> ILL-POSED): restated as written.
+//   * calcHessGrad_Occ2 writes mask_dynamic_occlusion, which only exists when visualizeIterations is set (RPI.h:1805, 1872-1876:
+//     an out-of-bounds write otherwise), and asserts on a NaN target depth (RPI.h:1964-1965): neither has an effect on H, g;
+//     the mask is not restated and the NaN case is the no-op it is under NDEBUG.
+//   * numVisiblePixels counts a target pixel's first arrival twice (RPI.h:1421-1430, 1866-1879): restated as written.
+// thresDepthOutliers: alignFrames(occlusion 2) sets it to maxDepthOutliers = 1 m (RPI.h:215, 4256-4260).
+// ------------------------------------------------------------------------------------
+constexpr float kPinThresDepthOutliers = 1.f;
+
+// RPI.h:1107-1325 errorPhotoICP_Occ1 (occ 1), RPI.h:1547-1775 errorPhotoICP_Occ2 (occ 2): z-buffer and residuals indexed by the
+// TARGET pixel; a source pixel at least as close as the z-buffer's entry overwrites the residual, the counters count every write.
+double errorPhotoICP_Occ(Ctx& ctx, int level, const float* pose, int method, int occ, OccSums* out) {
+    const Image& graySrc = ctx.graySrc[level];
+    const int nRows = graySrc.rows, nCols = graySrc.cols;
+    const long imgSize = (long)nRows * nCols;
+    std::vector<float> residualsPhoto(imgSize, 0.f), residualsDepth(imgSize, 0.f), invDepthBuffer(imgSize, 0.f);
+    const PinholeK K = level_intrinsics(ctx, level);
+    const float stdDevPhoto = ctx.p.sigma_photo, stdDevDepth = ctx.p.sigma_depth;
+    const float stdDevPhoto_inv = 1. / stdDevPhoto;
+    const PoseRT T = split_pose(pose);
+    const Image &grayTrg = ctx.grayTrg[level], &depthTrg = ctx.depthTrg[level];
+    const Image &gx = ctx.gTrgGx[level], &gy = ctx.gTrgGy[level], &dgx = ctx.dTrgGx[level], &dgy = ctx.dTrgGy[level];
+    const float thrI = ctx.p.thres_sal_photo, thrD = ctx.p.thres_sal_depth;
+    long nValidPhotoPts = 0, nValidDepthPts = 0;
+    for (long i = 0; i < imgSize; ++i) {
+        const float* p = &ctx.lut[3 * i];
+        if (p[0] == kInvalidPoint) continue;
+        const WarpPin w = warp_pinhole(T, p, nRows, nCols, K, ctx.p.math_mode);
+        if (!w.visible) continue;
+        const float inv_transformedPz = w.inv_z;
+        if (occ == 2) {
+            float depth2 = depthTrg.at(w.r, w.c);
+            float depthDiff = depth2 - inv_transformedPz;                              // RPI.h:1687-1690 (sic)
+            if (fabsf(depthDiff) > kPinThresDepthOutliers) continue;
+        }
+        const long ii = (long)w.r * nCols + w.c;
+        if (invDepthBuffer[ii] > 0 && inv_transformedPz < invDepthBuffer[ii]) continue;    // RPI.h:1248-1250, 1693-1695
+        invDepthBuffer[ii] = inv_transformedPz;
+        if (method == METHOD_PHOTO || method == METHOD_PHOTO_DEPTH) {
+            if (fabsf(gx.at(w.r, w.c)) < thrI && fabsf(gy.at(w.r, w.c)) < thrI) continue;
+            float photoDiff = grayTrg.at(w.r, w.c) - graySrc.d[i];
+            float weight_photo = weightHuber(photoDiff, stdDevPhoto) * stdDevPhoto_inv;
+            float weightedErrorPhoto = weight_photo * photoDiff;
+            residualsPhoto[ii] = weightedErrorPhoto * weightedErrorPhoto;
+            ++nValidPhotoPts;
+        }
+        if (method == METHOD_DEPTH || method == METHOD_PHOTO_DEPTH) {
+            float depth2 = depthTrg.at(w.r, w.c);
+            if (std::isfinite(depth2)) {
+                if (fabsf(dgx.at(w.r, w.c)) < thrD && fabsf(dgy.at(w.r, w.c)) < thrD) continue;
+                float depth1 = w.Z;
+                float depthDiff = depth2 - depth1;
+                float stdDev_depth1 = stdDevDepth * depth1;
+                float weight_depth = weightHuber(depthDiff, stdDev_depth1) / stdDev_depth1;
+                float weightedErrorDepth = weight_depth * depthDiff;
+                residualsDepth[ii] = weightedErrorDepth * weightedErrorDepth;
+                ++nValidDepthPts;
+            }
+        }
+    }
+    double PhotoResidual = 0.0, DepthResidual = 0.0;
+    for (long i = 0; i < imgSize; ++i) {
+        PhotoResidual += residualsPhoto[i];
+        DepthResidual += residualsDepth[i];
+    }
+    if (out) { out->photo = PhotoResidual; out->depth = DepthResidual; out->nPhoto = nValidPhotoPts; out->nDepth = nValidDepthPts; }
+    ctx.last_err2_photo = PhotoResidual; ctx.last_err2_depth = DepthResidual;
+    ctx.last_nvalid_photo = nValidPhotoPts; ctx.last_nvalid_depth = nValidDepthPts;
+    ctx.last_nvalid = nValidPhotoPts + nValidDepthPts;
+    return sqrt(PhotoResidual / nValidPhotoPts) + sqrt(DepthResidual / nValidDepthPts);    // RPI.h:1314-1317, 1765-1768
+}
+
+// RPI.h:1328-1544 calcHessGrad_Occ1 (occ 1), RPI.h:1777-2030 calcHessGrad_Occ2 (occ 2): z-buffer by TARGET pixel, rows stored by
+// SOURCE pixel (an accepted pixel's rows stay when a closer one arrives later); occ 2 adds the depth-outlier gate.
+void calcHessGrad_Occ(Ctx& ctx, int level, const float* pose, int method, int occ) {
+    const Image& graySrc = ctx.graySrc[level];
+    const int nRows = graySrc.rows, nCols = graySrc.cols;
+    const long imgSize = (long)nRows * nCols;
+    const PinholeK K = level_intrinsics(ctx, level);
+    const float fx = K.fx, fy = K.fy;
+    std::vector<float> jacobiansPhoto((size_t)imgSize * 6, 0.f), jacobiansDepth((size_t)imgSize * 6, 0.f);
+    std::vector<float> residualsPhoto(imgSize, 0.f), residualsDepth(imgSize, 0.f), invDepthBuffer(imgSize, 0.f);
+    const float stdDevPhoto = ctx.p.sigma_photo, stdDevDepth = ctx.p.sigma_depth;
+    const float stdDevPhoto_inv = 1. / stdDevPhoto;
+    const PoseRT T = split_pose(pose);
+    const Image &grayTrg = ctx.grayTrg[level], &depthTrg = ctx.depthTrg[level];
+    const Image &gx = ctx.gTrgGx[level], &gy = ctx.gTrgGy[level], &dgx = ctx.dTrgGx[level], &dgy = ctx.dTrgGy[level];
+    const float thrI = ctx.p.thres_sal_photo, thrD = ctx.p.thres_sal_depth;
+    long numVisiblePixels = 0;
+    for (long i = 0; i < imgSize; ++i) {
+        const float* p = &ctx.lut[3 * i];
+        if (p[0] == kInvalidPoint) continue;
+        const WarpPin w = warp_pinhole(T, p, nRows, nCols, K, ctx.p.math_mode);
+        if (!w.visible) continue;
+        const float X = w.X, Y = w.Y, Z = w.Z, inv_transformedPz = w.inv_z;
+        if (occ == 2) {
+            float depth2 = depthTrg.at(w.r, w.c);
+            float depthDiff = depth2 - Z;                                              // RPI.h:1857-1862
+            if (fabsf(depthDiff) > kPinThresDepthOutliers) continue;
+        }
+        const long ii = (long)w.r * nCols + w.c;
+        if (invDepthBuffer[ii] == 0)                                                   // RPI.h:1421-1430, 1866-1879
+            ++numVisiblePixels;
+        else if (inv_transformedPz < invDepthBuffer[ii])
+            continue;
+        ++numVisiblePixels;
+        invDepthBuffer[ii] = inv_transformedPz;
+        float Jw0[6], Jw1[6];                                                          // jacobianWarpRt RPI.h:1435-1452
+        Jw0[0] = fx * inv_transformedPz;
+        Jw1[0] = 0;
+        Jw0[1] = 0;
+        Jw1[1] = fy * inv_transformedPz;
+        const float inv_transformedPz_2 = inv_transformedPz * inv_transformedPz;
+        Jw0[2] = -fx * X * inv_transformedPz_2;
+        Jw1[2] = -fy * Y * inv_transformedPz_2;
+        Jw0[3] = -fx * Y * X * inv_transformedPz_2;
+        Jw1[3] = -fy * (1 + Y * Y * inv_transformedPz_2);
+        Jw0[4] = fx * (1 + X * X * inv_transformedPz_2);
+        Jw1[4] = fy * X * Y * inv_transformedPz_2;
+        Jw0[5] = -fx * Y * inv_transformedPz;
+        Jw1[5] = fy * X * inv_transformedPz;
+        if (method == METHOD_PHOTO || method == METHOD_PHOTO_DEPTH) {
+            const float tgx = gx.at(w.r, w.c), tgy = gy.at(w.r, w.c);
+            if (fabsf(tgx) < thrI && fabsf(tgy) < thrI) continue;
+            float photoDiff = grayTrg.at(w.r, w.c) - graySrc.d[i];
+            float weight_photo = weightHuber(photoDiff, stdDevPhoto) * stdDevPhoto_inv;
+            float weightedErrorPhoto = weight_photo * photoDiff;
+            const float wgx = weight_photo * tgx, wgy = weight_photo * tgy;
+            for (int j = 0; j < 6; ++j) jacobiansPhoto[(size_t)i * 6 + j] = wgx * Jw0[j] + wgy * Jw1[j];
+            residualsPhoto[i] = weightedErrorPhoto;
+        }
+        if (method == METHOD_DEPTH || method == METHOD_PHOTO_DEPTH) {
+            const float tdx = dgx.at(w.r, w.c), tdy = dgy.at(w.r, w.c);
+            if (fabsf(tdx) < thrD && fabsf(tdy) < thrD) continue;
+            float depth2 = depthTrg.at(w.r, w.c);
+            if (std::isfinite(depth2)) {
+                float depthDiff = depth2 - Z;
+                float stdDev_depth1 = stdDevDepth * Z;
+                float weight_depth = weightHuber(depthDiff, stdDev_depth1) / stdDev_depth1;
+                float weightedErrorDepth = weight_depth * depthDiff;
+                const float jacobianRt_z[6] = {0, 0, 1, Y, -X, 0};
+                for (int j = 0; j < 6; ++j) jacobiansDepth[(size_t)i * 6 + j] = weight_depth * ((tdx * Jw0[j] + tdy * Jw1[j]) - jacobianRt_z[j]);
+                residualsDepth[i] = weightedErrorDepth;
+            }
+        }
+    }
+    float Hf[36] = {0}, gf[6] = {0};
+    double Hd[36] = {0}, gd[6] = {0};
+    long rows_used = 0;
+    auto reduce_rows = [&](const std::vector<float>& Jm, const std::vector<float>& res) {
+        for (long i = 0; i < imgSize; ++i)
+            if (residualsPhoto[i] != 0) {                                              // RPI.h:1523, 1531 (both loops test the photo residual)
+                const float* J = &Jm[(size_t)i * 6];
+                for (int a = 0; a < 6; ++a) {
+                    for (int b = 0; b < 6; ++b) {
+                        const float prod = J[a] * J[b];
+                        Hf[b * 6 + a] += prod;
+                        Hd[b * 6 + a] += (double)prod;
+                    }
+                    const float pr = J[a] * res[i];
+                    gf[a] += pr;
+                    gd[a] += (double)pr;
+                }
+                ++rows_used;
+            }
+    };
+    if (method == METHOD_PHOTO || method == METHOD_PHOTO_DEPTH) reduce_rows(jacobiansPhoto, residualsPhoto);
+    if (method == METHOD_DEPTH || method == METHOD_PHOTO_DEPTH) reduce_rows(jacobiansDepth, residualsDepth);
+    for (int k = 0; k < 36; ++k) {
+        ctx.H[k] = ctx.p.reduce_mode == 0 ? Hf[k] : (float)Hd[k];
+        ctx.H64[k] = Hd[k];
+    }
+    for (int a = 0; a < 6; ++a) {
+        ctx.g[a] = ctx.p.reduce_mode == 0 ? gf[a] : (float)gd[a];
+        ctx.g64[a] = gd[a];
+    }
+    ctx.n_visible = numVisiblePixels;
+    if (occ == 2) ctx.sso = (float)numVisiblePixels / imgSize;                         // RPI.h:2016 (Occ1 leaves SSO alone)
+}
+
 // THIRD-PARTY (MRPT 1.x CPose3D::exp(mu, pseudo_exponential = false), RPI.h:4358, 4391): the SE(3) exponential with
 // the translation coupled through V(w): t = u + B (w x u) + C (w x (w x u)); small-angle series below theta^2 < 1e-8 /
 // 1e-6 as in MRPT's (TooN-derived) implementation.
@@ -1356,8 +1603,9 @@ int alignFrames360(Ctx& ctx, const float* pose_guess, int method, float* pose_ou
     return 0;
 }
 
-// RPI.h:4254-4512 alignFrames (pinhole, Levenberg-Marquardt damping, occlusion 0).
-int alignFrames(Ctx& ctx, const float* pose_guess, int method, float* pose_out, Result* res) {
+// RPI.h:4254-4512 alignFrames (pinhole, Levenberg-Marquardt damping); occlusion 0 / 1 / 2 selects the error and H,g functions
+// (RPI.h:4311-4316, 4335-4340, 4362-4367, 4393-4398).
+int alignFrames(Ctx& ctx, const float* pose_guess, int method, float* pose_out, Result* res, int occlusion = 0) {
     ctx.trace.clear();
     memset(res, 0, sizeof(*res));
     float pose_estim[16], pose_estim_temp[16];
@@ -1369,11 +1617,22 @@ int alignFrames(Ctx& ctx, const float* pose_guess, int method, float* pose_out, 
     bool any_iteration = false;
     double final_error = 0;
     auto eval = [&](int level, const float* pose) {
-        const double e = errorPhotoICP(ctx, level, pose, method);
+        double e;
+        if (occlusion == 0) {
+            e = ctx.use_saliency ? errorPhotoICP_salient(ctx, level, pose, method) : errorPhotoICP(ctx, level, pose, method);
+            last_eval_photo = sqrt(ctx.last_err2_photo / ctx.last_nvalid_depth);
+            last_eval_depth = sqrt(ctx.last_err2_depth / ctx.last_nvalid_depth);
+        } else {
+            e = errorPhotoICP_Occ(ctx, level, pose, method, occlusion, nullptr);
+            last_eval_photo = sqrt(ctx.last_err2_photo / ctx.last_nvalid_photo);
+            last_eval_depth = sqrt(ctx.last_err2_depth / ctx.last_nvalid_depth);
+        }
         last_eval = e;
-        last_eval_photo = sqrt(ctx.last_err2_photo / ctx.last_nvalid_depth);
-        last_eval_depth = sqrt(ctx.last_err2_depth / ctx.last_nvalid_depth);
         return e;
+    };
+    auto hessgrad = [&](int level, const float* pose) {
+        if (occlusion == 0) calcHessGrad(ctx, level, pose, method);
+        else calcHessGrad_Occ(ctx, level, pose, method, occlusion);
     };
     auto lm_update = [&](float lambda_or_neg, float* update_pose) -> bool {     // lambda < 0: plain -H^-1 g (RPI.h:4355)
         float M[36];
@@ -1420,7 +1679,7 @@ int alignFrames(Ctx& ctx, const float* pose_guess, int method, float* pose_out, 
         while (it < maxIters && unorm() > tol_update && diff_error > tol_residual) {
             any_iteration = true;
             avResidual_temp = last_eval; avPhoto_temp = last_eval_photo; avDepth_temp = last_eval_depth;
-            calcHessGrad(ctx, level, pose_estim, method);
+            hessgrad(level, pose_estim);
             float M[36];
             for (int k = 0; k < 36; ++k) M[k] = ctx.H[k];
             for (int i = 0; i < 6; ++i) M[i * 6 + i] = ctx.H[i * 6 + i] + lambda * ctx.H[i * 6 + i];
@@ -1476,7 +1735,7 @@ int alignFrames(Ctx& ctx, const float* pose_guess, int method, float* pose_out, 
     res->err_final = any_iteration ? avResidual_temp : last_eval;
     res->rms_photo = any_iteration ? avPhoto_temp : last_eval_photo;
     res->rms_depth = any_iteration ? avDepth_temp : last_eval_depth;
-    res->sso = 0.f;
+    res->sso = (occlusion == 2 && any_iteration) ? ctx.sso : 0.f;      // only calcHessGrad_Occ2 sets SSO on this path (RPI.h:2016)
     for (int k = 0; k < 36; ++k) res->hessian[k] = ctx.H[k];
     for (int k = 0; k < 6; ++k) res->gradient[k] = ctx.g[k];
     res->status = (final_error != final_error) ? 2 : 0;       // NaN error (no depth-valid pixel): nothing was optimised
@@ -1918,6 +2177,49 @@ void oracle_set_camera(void* h, float fx, float fy, float ox, float oy) {
 }
 int oracle_align_pinhole(void* h, const float* guess, int method, float* pose_out, oracle_result* res) {
     return alignFrames(*(Ctx*)h, guess, method, pose_out, res);
+}
+int oracle_align_pinhole_occ(void* h, const float* guess, int method, int occlusion, float* pose_out, oracle_result* res) {
+    return alignFrames(*(Ctx*)h, guess, method, pose_out, res, occlusion);
+}
+// useSaliency(bool) RPI.h:266-269 (+ thresSaliency RPI.h:217)
+void oracle_use_saliency(void* h, int on, float thres_saliency) {
+    Ctx& c = *(Ctx*)h;
+    c.use_saliency = on != 0;
+    c.thres_saliency = thres_saliency;
+}
+// vSalientPixels of a level (out may be null: returns the count)
+int oracle_salient_pixels(void* h, int level, int* out) {
+    Ctx& c = *(Ctx*)h;
+    buildSalientPixels(c, level);
+    if (out) memcpy(out, c.salient[level].data(), c.salient[level].size() * sizeof(int));
+    return (int)c.salient[level].size();
+}
+double oracle_error_pinhole_salient(void* h, int level, const float* pose, int method, double* sums) {
+    Ctx& c = *(Ctx*)h;
+    if (c.lut_level != 1000 + level) buildLUT_pinhole(c, level);
+    const double e = errorPhotoICP_salient(c, level, pose, method);
+    if (sums) { sums[0] = c.last_err2_photo; sums[1] = c.last_err2_depth; sums[2] = (double)c.last_nvalid_photo; sums[3] = (double)c.last_nvalid_depth; }
+    return e;
+}
+// sums[4] = {sum photo, sum depth, n photo, n depth}; returns avPhoto + avDepth
+double oracle_error_pinhole_occ(void* h, int level, const float* pose, int method, int occlusion, double* sums) {
+    Ctx& c = *(Ctx*)h;
+    if (c.lut_level != 1000 + level) buildLUT_pinhole(c, level);
+    OccSums o;
+    const double e = errorPhotoICP_Occ(c, level, pose, method, occlusion, &o);
+    if (sums) { sums[0] = o.photo; sums[1] = o.depth; sums[2] = (double)o.nPhoto; sums[3] = (double)o.nDepth; }
+    return e;
+}
+void oracle_hessgrad_pinhole_occ(void* h, int level, const float* pose, int method, int occlusion, float* H36, float* g6, double* H36d,
+                                 double* g6d, long* n_visible) {
+    Ctx& c = *(Ctx*)h;
+    if (c.lut_level != 1000 + level) buildLUT_pinhole(c, level);
+    calcHessGrad_Occ(c, level, pose, method, occlusion);
+    if (H36) memcpy(H36, c.H, sizeof(c.H));
+    if (g6) memcpy(g6, c.g, sizeof(c.g));
+    if (H36d) memcpy(H36d, c.H64, sizeof(c.H64));
+    if (g6d) memcpy(g6d, c.g64, sizeof(c.g64));
+    if (n_visible) *n_visible = c.n_visible;
 }
 // sums[4] = {sum photo, sum depth, n photo, n depth}; returns avPhoto + avDepth (both / n depth)
 double oracle_error_pinhole(void* h, int level, const float* pose, int method, double* sums) {

@@ -15,7 +15,7 @@ SYMBOLS = [
     "rgbd360_warp_indices", "rgbd360_gn_step", "rgbd360_forced_iters", "rgbd360_time_eval_kernel", "rgbd360_stream",
     "rgbd360_sync", "rgbd360_device_count", "rgbd360_sphere_cloud", "rgbd360_selftest_math", "rgbd360_time_solve_kernel", "rgbd360_normals", "rgbd360_distance_map",
     "rgbd360_plane_fit", "rgbd360_frame_planes", "rgbd360_frame_planes_dev", "rgbd360_load_frame_bin", "rgbd360_stitch_sphere",
-    "rgbd360_set_camera", "rgbd360_align_pinhole", "rgbd360_eval_pinhole", "rgbd360_warp_indices_pinhole",
+    "rgbd360_set_camera", "rgbd360_align_pinhole", "rgbd360_eval_pinhole", "rgbd360_eval_pinhole_occ", "rgbd360_use_saliency", "rgbd360_warp_indices_pinhole",
     "rgbd360_pbmap_default_params", "rgbd360_register_planes", "rgbd360_bilateral_filter",
     "rgbd360_cloud_planes", "rgbd360_sensor_cloud", "rgbd360_sensor_planes", "rgbd360_merge_planes", "rgbd360_planes_available", "rgbd360_set_plane_refinement", "rgbd360_plane_refinement_stats", "rgbd360_set_plane_color_image",
     "rgbd360_multi_create", "rgbd360_multi_destroy", "rgbd360_multi_last_error", "rgbd360_multi_n_gpus", "rgbd360_multi_uses_rccl",
@@ -96,6 +96,8 @@ def load() -> C.CDLL:
     L.rgbd360_set_camera.argtypes = [vp, C.c_float, C.c_float, C.c_float, C.c_float]
     L.rgbd360_align_pinhole.argtypes = [vp, f32p, i32, i32, f32p, C.POINTER(Result)]
     L.rgbd360_eval_pinhole.argtypes = [vp, i32, f32p, i32, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_longlong)]
+    L.rgbd360_eval_pinhole_occ.argtypes = [vp, i32, f32p, i32, i32, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_longlong)]
+    L.rgbd360_use_saliency.argtypes = [vp, i32, C.c_float]
     L.rgbd360_warp_indices_pinhole.argtypes = [vp, i32, f32p, vp]
     L.rgbd360_gn_step.argtypes = [vp, f32p, f32p, C.c_float, f32p, f32p, f32p]
     L.rgbd360_forced_iters.argtypes = [vp, i32, f32p, i32, i32, f32p, C.POINTER(C.c_double), C.POINTER(C.c_float)]

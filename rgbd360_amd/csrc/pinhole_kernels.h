@@ -1,5 +1,6 @@
 // Pinhole single-sensor alignment: RegisterPhotoICP::alignFrames RPI.h:4254-4512 with
-// errorPhotoICP RPI.h:560-748 and calcHessGrad RPI.h:754-1104 (occlusion 0, bUseSalientPixels false).
+// errorPhotoICP RPI.h:560-748 and calcHessGrad RPI.h:754-1104 (occlusion 0; bUseSalientPixels through sal_thr), and the occlusion-aware
+// variants errorPhotoICP_Occ1/2, calcHessGrad_Occ1/2 RPI.h:1107-2030 (second half of this file).
 //
 // The sensor images are small (320x240 per Asus sensor of the rig), so these passes are launch- and latency-bound, not
 // bandwidth-bound; the kernels are the plain form of k_eval (no software pipelining), one fused pass producing
@@ -55,8 +56,12 @@ __device__ __forceinline__ unsigned warp_pinhole(const PoseRT& T, float px, floa
 template <int METHOD>
 // The pose of the pass arrives as a kernel argument: the Levenberg-Marquardt loop lives on the host and evaluates one pose per
 // round trip, so there is no device state to gate on and no initialisation launch in front of the pass.
+// sal_thr >= 0: useSaliency(true) (RPI.h:266, 590-690) -- the ERROR sums run over vSalientPixels only, the interior pixels whose
+// TARGET gray gradient exceeds thresSaliency in x or y (RPI.h:420-424), used as SOURCE pixel indices (RPI.h:613-634: as written);
+// the normal equations keep every pixel (calcHessGrad's salient branch is commented out, RPI.h:813-870).  Border gradients are
+// zero (RPI.h:367-372), so the list's "interior" condition is the threshold test itself.
 __global__ __launch_bounds__(kEvalThreads) void k_eval_pinhole(LevelDev lv, PinK K, EvalConsts ec, Pose16 pose,
-                                                                double* __restrict__ partials, int chunk, int level) {
+                                                                double* __restrict__ partials, int chunk, int level, float sal_thr) {
     const int b = blockIdx.x;
     const int base = b * chunk;
     const int end = min(base + chunk, lv.n);
@@ -78,6 +83,11 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_pinhole(LevelDev lv, PinK
         unsigned ti = warp_pinhole(T, s.x, s.y, s.z, K, lv.rows, lv.cols, X, Y, Z, iz, vis);
         vis = vis && in_range && (s.x != kInvalidPoint);
         ti = vis ? ti : 0u;
+        bool evis = vis;                  // the pixel takes part in the error sums
+        if (sal_thr >= 0.f) {             // uniform
+            const F3 ts = lv.trgP[in_range ? i : 0];
+            evis = vis && (fabsf(ts.b) > sal_thr || fabsf(ts.c) > sal_thr);
+        }
         F3 tp = {0.f, 0.f, 0.f}, td = {0.f, 0.f, 0.f};
         if (METHOD != 1) tp = lv.trgP[ti];
         if (METHOD != 0) td = lv.trgD[ti];
@@ -87,7 +97,7 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_pinhole(LevelDev lv, PinK
         const float iz2 = iz * iz;
 
         if (METHOD != 1) {
-            A.nP += ballot_count(vis);                                            // errorPhotoICP: no saliency test (RPI.h:712-721)
+            A.nP += ballot_count(evis);                                           // errorPhotoICP: no saliency test (RPI.h:712-721)
             const bool row_on = vis && sal_p && (METHOD == 0 || sal_d);           // calcHessGrad: RPI.h:906-907, 929-930
             A.nVis += ballot_count(row_on);
             if (vis) {
@@ -95,7 +105,7 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_pinhole(LevelDev lv, PinK
                 const float photoDiff = tp.a - s.w;
                 const float wpf = weight_huber_fast(photoDiff, ec.sigma_photo) * ec.sigma_photo_inv_f;
                 const float res = wpf * photoDiff;
-                A.e2p += res * res;
+                A.e2p += evis ? res * res : 0.f;
                 if (row_on) {
                     const float wgx = wpf * tp.b * K.fx, wgy = wpf * tp.c * K.fy;
                     accumulate_row(A, wgx * iz, wgy * iz, -(wgx * X + wgy * Y) * iz2, X, Y, Z, res);
@@ -104,7 +114,7 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_pinhole(LevelDev lv, PinK
         }
         if (METHOD != 0) {
             const bool err_on = vis && isfinite(depth2);                          // RPI.h:722-735
-            A.nD += ballot_count(err_on);
+            A.nD += ballot_count(err_on && evis);
             const bool row_on = err_on && sal_d && (METHOD == 1 || sal_p);
             A.nVis += ballot_count(row_on);
             if (err_on) {
@@ -113,7 +123,7 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_pinhole(LevelDev lv, PinK
                 const float sd = ec.sigma_depth * Z;
                 const float wd = weight_huber_fast(depthDiff, sd) * fast_rcp(sd);
                 const float res = wd * depthDiff;
-                A.e2d += res * res;
+                A.e2d += evis ? res * res : 0.f;
                 if (row_on) {
                     const float gx = td.b * K.fx, gy = td.c * K.fy;
                     accumulate_row(A, wd * (gx * iz), wd * (gy * iz), wd * (-(gx * X + gy * Y) * iz2 - 1.f), X, Y, Z, res);
@@ -150,6 +160,165 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_pinhole(LevelDev lv, PinK
 #pragma unroll
         for (int w = 0; w < kEvalThreads / 64; ++w) v += red[w][threadIdx.x];
         partials[(size_t)b * kNumPartials + threadIdx.x] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Occlusion-aware pinhole passes: errorPhotoICP_Occ1 / calcHessGrad_Occ1 (RPI.h:1107-1544), errorPhotoICP_Occ2 /
+// calcHessGrad_Occ2 (RPI.h:1547-2030).  Sequential semantics of the source (its OpenMP loops race on the z-buffer): per TARGET
+// pixel, the source pixels that land on it are visited in index order against a z-buffer entry
+//     error pass   skip if (buf > 0 && 1/Z < buf), else buf = 1/Z; the residual slot of the TARGET pixel is overwritten by every
+//                  accepted pixel that passes the saliency tests, the counters count every such write
+//     H, g pass    first arrival counts twice in numVisiblePixels (as written), later ones are skipped if 1/Z < buf; rows are kept
+//                  per SOURCE pixel (no retraction) and summed where the PHOTOMETRIC residual is non-zero -- the depth rows too
+//                  (as written: DEPTH_CONSISTENCY alone gives H = 0)
+//     Occ2         an outlier gate in front: |Dtrg - 1/Z| > 1 m in the error pass (sic), |Dtrg - Z| > 1 m in the H, g pass
+// That is a state machine along each target pixel's list, so the lists are materialised in index order: k_pin_occ_keys writes
+// (target index, source index + which of the two passes the pixel enters), a stable radix sort by target index (rocPRIM; the
+// images are 320 x 240 -- nothing here is bandwidth-bound) groups them with the source order intact, and k_pin_occ_walk gives each
+// list to the thread that finds its head: one sequential walk, exact whatever the list lengths, no residency or ordering
+// assumption.  One fused walk yields the error sums and the normal equations at the pose, in k_eval's partial-row layout.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr float kPinThresDepthOutliers = 1.f;      // thresDepthOutliers = maxDepthOutliers (RPI.h:215, 4256-4260)
+constexpr unsigned kPinOccErr = 1u << 30, kPinOccHess = 1u << 31, kPinOccIndex = 0xFFFFFFu;
+
+template <int OCC>
+__global__ __launch_bounds__(256) void k_pin_occ_keys(LevelDev lv, PinK K, Pose16 pose, unsigned* __restrict__ keys, unsigned* __restrict__ vals) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= lv.n) return;
+    const PoseRT T = load_pose(pose.v);
+    const float4 s = lv.src[i];
+    float X, Y, Z, iz;
+    bool vis;
+    const unsigned ti = warp_pinhole(T, s.x, s.y, s.z, K, lv.rows, lv.cols, X, Y, Z, iz, vis);
+    const bool cand = vis && (s.x != kInvalidPoint);
+    bool cand_e = cand, cand_h = cand;
+    if (OCC == 2 && cand) {
+        const float depth2 = lv.trgD[ti].a;
+        cand_e = !(fabsf(depth2 - iz) > kPinThresDepthOutliers);       // RPI.h:1687-1690 (depth against inverse depth: as written)
+        cand_h = !(fabsf(depth2 - Z) > kPinThresDepthOutliers);        // RPI.h:1857-1862
+    }
+    keys[i] = (cand_e || cand_h) ? ti : (unsigned)lv.n;                 // non-candidates sort behind every list
+    vals[i] = (unsigned)i | (cand_e ? kPinOccErr : 0u) | (cand_h ? kPinOccHess : 0u);
+}
+
+constexpr int kPinWalkThreads = 256;
+template <int METHOD>
+__global__ __launch_bounds__(kPinWalkThreads) void k_pin_occ_walk(LevelDev lv, PinK K, EvalConsts ec, Pose16 pose, const unsigned* __restrict__ keys,
+                                                                   const unsigned* __restrict__ vals, double* __restrict__ partials) {
+    const int p = blockIdx.x * kPinWalkThreads + (int)threadIdx.x;
+    const PoseRT T = load_pose(pose.v);
+    EvalAcc A;
+#pragma unroll
+    for (int k = 0; k < 27; ++k) A.acc[k] = 0.f;
+    A.e2p = A.e2d = 0.f;
+    int nP = 0, nD = 0, nVis = 0;
+    const unsigned n = (unsigned)lv.n;
+    const unsigned key = p < lv.n ? keys[p] : n;
+    const bool head = key < n && (p == 0 || keys[p - 1] != key);
+    if (head) {
+        const unsigned ti = key;
+        F3 tp = {0.f, 0.f, 0.f};
+        if (METHOD != 1) tp = lv.trgP[ti];
+        const F3 td = lv.trgD[ti];
+        const float depth2 = td.a;
+        const bool sal_p = !(fabsf(tp.b) < ec.thr_photo && fabsf(tp.c) < ec.thr_photo);
+        const bool sal_d = !(fabsf(td.b) < ec.thr_depth && fabsf(td.c) < ec.thr_depth);
+        const bool fin_d = isfinite(depth2);
+        float buf_e = 0.f, buf_h = 0.f;              // invDepthBuffer(ii) of the two passes
+        float res_p = 0.f, res_d = 0.f;              // residualsPhoto(ii), residualsDepth(ii) of the error pass
+        for (int q = p; q < lv.n && keys[q] == key; ++q) {
+            const unsigned v = vals[q];
+            const float4 s = lv.src[v & kPinOccIndex];
+            float X, Y, Z, iz;
+            bool vis;
+            (void)warp_pinhole(T, s.x, s.y, s.z, K, lv.rows, lv.cols, X, Y, Z, iz, vis);
+            // the photometric and depth residuals of this pixel on this target (both passes use the same expressions)
+            float wpf = 0.f, rp = 0.f, wd = 0.f, rd = 0.f;
+            {
+#pragma clang fp contract(fast)
+                if (METHOD != 1) {
+                    const float photoDiff = tp.a - s.w;
+                    wpf = weight_huber_fast(photoDiff, ec.sigma_photo) * ec.sigma_photo_inv_f;
+                    rp = wpf * photoDiff;
+                }
+                if (METHOD != 0) {
+                    const float depthDiff = depth2 - Z;
+                    const float sd = ec.sigma_depth * Z;
+                    wd = weight_huber_fast(depthDiff, sd) * fast_rcp(sd);
+                    rd = wd * depthDiff;
+                }
+            }
+            if (v & kPinOccErr) {                    // errorPhotoICP_Occ1 / _Occ2
+                if (!(buf_e > 0.f && iz < buf_e)) {  // RPI.h:1248-1250
+                    buf_e = iz;
+                    bool on = true;
+                    if (METHOD != 1) {
+                        if (!sal_p) on = false;      // `continue`: skips the depth part too (RPI.h:1254-1256)
+                        else { res_p = rp * rp; ++nP; }
+                    }
+                    if (METHOD != 0 && on && fin_d && sal_d) { res_d = rd * rd; ++nD; }      // RPI.h:1280-1296
+                }
+            }
+            if (v & kPinOccHess) {                   // calcHessGrad_Occ1 / _Occ2
+                bool acc = true;
+                if (buf_h == 0.f) ++nVis;            // RPI.h:1421-1430: the first arrival is counted here and below
+                else if (iz < buf_h) acc = false;
+                if (acc) {
+                    ++nVis;
+                    buf_h = iz;
+                    // rows exist where the photometric residual was stored and is non-zero (RPI.h:1523, 1531: both sums test it)
+                    if (METHOD != 1 && sal_p && rp != 0.f) {
+#pragma clang fp contract(fast)
+                        const float iz2 = iz * iz;
+                        const float wgx = wpf * tp.b * K.fx, wgy = wpf * tp.c * K.fy;
+                        accumulate_row(A, wgx * iz, wgy * iz, -(wgx * X + wgy * Y) * iz2, X, Y, Z, rp);
+                        if (METHOD == 2 && sal_d && fin_d) {
+                            const float gx = td.b * K.fx, gy = td.c * K.fy;
+                            accumulate_row(A, wd * (gx * iz), wd * (gy * iz), wd * (-(gx * X + gy * Y) * iz2 - 1.f), X, Y, Z, rd);
+                        }
+                    }
+                }
+            }
+        }
+        A.e2p = res_p;
+        A.e2d = res_d;
+    }
+    // block reduction into one partial row (k_eval_pinhole's layout); the counts are integers: LDS atomics
+    __shared__ double red[kPinWalkThreads / 64][kNumPartials];
+    __shared__ int cnt[3];
+    if (threadIdx.x < 3) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    if (nP) atomicAdd(&cnt[0], nP);
+    if (nD) atomicAdd(&cnt[1], nD);
+    if (nVis) atomicAdd(&cnt[2], nVis);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    {
+        float v[32], out[2];
+#pragma unroll
+        for (int k = 0; k < 27; ++k) v[k] = A.acc[k];
+        v[P_E2P] = A.e2p;
+        v[P_E2D] = A.e2d;
+        v[P_NP] = v[P_ND] = v[P_NVIS] = 0.f;
+        wave_reduce32(v, out);
+        if ((lane & 3) == 0) {
+            const int row = lane >> 4, quad = (lane >> 2) & 3;
+            const int idx = 2 * (quad & 1) + 4 * (quad >> 1) + 8 * (row & 1) + 16 * (row >> 1);
+            if (idx + 0 < P_NP) red[wave][idx + 0] = (double)out[0];
+            if (idx + 1 < P_NP) red[wave][idx + 1] = (double)out[1];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < kNumPartials) {
+        double v = 0.0;
+        if ((int)threadIdx.x < P_NP) {
+#pragma unroll
+            for (int w = 0; w < kPinWalkThreads / 64; ++w) v += red[w][threadIdx.x];
+        } else {
+            const int k = (int)threadIdx.x - P_NP;      // P_NP, P_ND, P_NVIS are the last three slots, in this order
+            v = k < 3 ? (double)cnt[k] : 0.0;
+        }
+        partials[(size_t)blockIdx.x * kNumPartials + threadIdx.x] = v;
     }
 }
 

@@ -17,6 +17,8 @@
 #include <thread>
 #include <vector>
 
+#include <hipcub/device/device_radix_sort.hpp>      // the pinhole occlusion passes' stable sort by target pixel (pinhole_kernels.h)
+
 #include "../../include/rgbd360_hip.h"
 #include "../../include/rgbd360_hip_diag.h"
 #include "host_wait.h"
@@ -122,6 +124,12 @@ struct rgbd360_ctx {
     int al_occ = 0;
     float cam[4] = {0.f, 0.f, 0.f, 0.f};               // cameraMatrix(0,0), (1,1), (0,2), (1,2)   RPI.h:89, 254-257
     bool have_cam = false;
+    float sal_thr = -1.f;                               // useSaliency(true): thresSaliency (RPI.h:217, 266); < 0 = off
+    // pinhole occlusion passes: (target index, source index) pairs before / after the sort, the sort's scratch, one partial row per walk block
+    unsigned *pin_keys = nullptr, *pin_keys_sorted = nullptr, *pin_vals = nullptr, *pin_vals_sorted = nullptr;
+    void* pin_sort_tmp = nullptr;
+    size_t pin_sort_bytes = 0, pin_occ_n = 0;
+    double* pin_partials = nullptr;
     int* occ_head = nullptr;                           // occlusion modes: per-target lists of candidate runs (generation-tagged heads)
     int4* occ_nodes = nullptr;                         // ... run nodes, indexed by the run's last source pixel
     unsigned char* occ_runinfo = nullptr;              // ... per source pixel: candidate / prefix maximum within its run / offset to the run's first pixel
@@ -158,6 +166,11 @@ void free_levels(rgbd360_ctx* ctx) {
         }
         hipFree(L.srcRecPin);
     }
+    hipFree(ctx->pin_keys); hipFree(ctx->pin_keys_sorted); hipFree(ctx->pin_vals); hipFree(ctx->pin_vals_sorted);
+    hipFree(ctx->pin_sort_tmp); hipFree(ctx->pin_partials);
+    ctx->pin_keys = ctx->pin_keys_sorted = ctx->pin_vals = ctx->pin_vals_sorted = nullptr;
+    ctx->pin_sort_tmp = nullptr; ctx->pin_partials = nullptr;
+    ctx->pin_sort_bytes = ctx->pin_occ_n = 0;
     hipFree(ctx->arena);
     ctx->arena = nullptr;
     ctx->levels.clear();
@@ -1551,10 +1564,68 @@ int pin_eval(rgbd360_ctx* ctx, int level, const float* pose, int method) {
     Pose16 P;
     memcpy(P.v, pose, sizeof(P.v));
     const dim3 g(L.nblocks), b(kEvalThreads);
-    if (method == 0) hipLaunchKernelGGL((k_eval_pinhole<0>), g, b, 0, ctx->stream, lv, K, ec, P, ctx->d_partials, L.chunk, level);
-    else if (method == 1) hipLaunchKernelGGL((k_eval_pinhole<1>), g, b, 0, ctx->stream, lv, K, ec, P, ctx->d_partials, L.chunk, level);
-    else hipLaunchKernelGGL((k_eval_pinhole<2>), g, b, 0, ctx->stream, lv, K, ec, P, ctx->d_partials, L.chunk, level);
+    if (method == 0) hipLaunchKernelGGL((k_eval_pinhole<0>), g, b, 0, ctx->stream, lv, K, ec, P, ctx->d_partials, L.chunk, level, ctx->sal_thr);
+    else if (method == 1) hipLaunchKernelGGL((k_eval_pinhole<1>), g, b, 0, ctx->stream, lv, K, ec, P, ctx->d_partials, L.chunk, level, ctx->sal_thr);
+    else hipLaunchKernelGGL((k_eval_pinhole<2>), g, b, 0, ctx->stream, lv, K, ec, P, ctx->d_partials, L.chunk, level, ctx->sal_thr);
     launch_solve(ctx, level, 1, 0, 0, /*publish=*/true);
+    HIPC(ctx, hipGetLastError());
+    HIPC(ctx, hostwait::wait(ctx->tag, ctx->stream));
+    return 0;
+}
+
+// The occlusion-aware evaluation (pinhole_kernels.h, second half): keys, stable sort by target pixel, one walk per list; the
+// reduce-only solve publishes the sums like pin_eval's.
+int pin_occ_ensure(rgbd360_ctx* ctx, size_t n) {
+    if (ctx->pin_occ_n >= n) return 0;
+    hipFree(ctx->pin_keys); hipFree(ctx->pin_keys_sorted); hipFree(ctx->pin_vals); hipFree(ctx->pin_vals_sorted);
+    hipFree(ctx->pin_sort_tmp); hipFree(ctx->pin_partials);
+    ctx->pin_keys = ctx->pin_keys_sorted = ctx->pin_vals = ctx->pin_vals_sorted = nullptr;
+    ctx->pin_sort_tmp = nullptr; ctx->pin_partials = nullptr;
+    ctx->pin_occ_n = 0;
+    HIPC(ctx, hipMalloc(&ctx->pin_keys, n * sizeof(unsigned)));
+    HIPC(ctx, hipMalloc(&ctx->pin_keys_sorted, n * sizeof(unsigned)));
+    HIPC(ctx, hipMalloc(&ctx->pin_vals, n * sizeof(unsigned)));
+    HIPC(ctx, hipMalloc(&ctx->pin_vals_sorted, n * sizeof(unsigned)));
+    size_t bytes = 0;
+    HIPC(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, ctx->pin_keys, ctx->pin_keys_sorted, ctx->pin_vals, ctx->pin_vals_sorted, (int)n, 0, 32,
+                                                 ctx->stream));
+    HIPC(ctx, hipMalloc(&ctx->pin_sort_tmp, bytes ? bytes : 16));
+    ctx->pin_sort_bytes = bytes;
+    HIPC(ctx, hipMalloc(&ctx->pin_partials, ((n + kPinWalkThreads - 1) / kPinWalkThreads) * kNumPartials * sizeof(double)));
+    ctx->pin_occ_n = n;
+    return 0;
+}
+
+int pin_eval_occ(rgbd360_ctx* ctx, int level, const float* pose, int method, int occ) {
+    const Level& L = ctx->levels[level];
+    int rc = pin_occ_ensure(ctx, (size_t)ctx->levels[0].n);
+    if (rc) return rc;
+    const LevelDev lv = pin_level_dev(L);
+    const PinK K = pin_level_K(ctx, level);
+    const EvalConsts ec = eval_consts(ctx->p);
+    Pose16 P;
+    memcpy(P.v, pose, sizeof(P.v));
+    const dim3 gk((L.n + 255) / 256), bk(256);
+    if (occ == 1) hipLaunchKernelGGL((k_pin_occ_keys<1>), gk, bk, 0, ctx->stream, lv, K, P, ctx->pin_keys, ctx->pin_vals);
+    else hipLaunchKernelGGL((k_pin_occ_keys<2>), gk, bk, 0, ctx->stream, lv, K, P, ctx->pin_keys, ctx->pin_vals);
+    int bits = 1;
+    while ((1ll << bits) <= (long long)L.n) ++bits;          // the keys are target indices < n, and n itself for the non-candidates
+    size_t bytes = ctx->pin_sort_bytes;
+    HIPC(ctx, hipcub::DeviceRadixSort::SortPairs(ctx->pin_sort_tmp, bytes, ctx->pin_keys, ctx->pin_keys_sorted, ctx->pin_vals, ctx->pin_vals_sorted, L.n,
+                                                 0, bits, ctx->stream));
+    const int nblk = (L.n + kPinWalkThreads - 1) / kPinWalkThreads;
+    const dim3 gw(nblk), bw(kPinWalkThreads);
+    if (method == 0) hipLaunchKernelGGL((k_pin_occ_walk<0>), gw, bw, 0, ctx->stream, lv, K, ec, P, ctx->pin_keys_sorted, ctx->pin_vals_sorted, ctx->pin_partials);
+    else if (method == 1) hipLaunchKernelGGL((k_pin_occ_walk<1>), gw, bw, 0, ctx->stream, lv, K, ec, P, ctx->pin_keys_sorted, ctx->pin_vals_sorted, ctx->pin_partials);
+    else hipLaunchKernelGGL((k_pin_occ_walk<2>), gw, bw, 0, ctx->stream, lv, K, ec, P, ctx->pin_keys_sorted, ctx->pin_vals_sorted, ctx->pin_partials);
+    SolveCfg cfg;
+    cfg.level = level; cfg.mode = 1; cfg.forced = 0; cfg.max_iters = ctx->p.max_iters; cfg.n_pixels = L.n;
+    cfg.occ = 0;
+    cfg.tol_residual = ctx->p.tol_residual; cfg.tol_update = ctx->p.tol_update;
+    cfg.host_state = ctx->h_state;
+    cfg.host_tag = ctx->tag.h;
+    cfg.host_seq = ++ctx->tag.seq;
+    hipLaunchKernelGGL(k_solve, dim3(1), dim3(kSolveThreads), 0, ctx->stream, ctx->d_state, (const double*)ctx->pin_partials, nblk, cfg);
     HIPC(ctx, hipGetLastError());
     HIPC(ctx, hostwait::wait(ctx->tag, ctx->stream));
     return 0;
@@ -1564,6 +1635,7 @@ struct PinSums {
     double e2p, e2d, np, nd, rows;
     float H[36], g[6];
     double error() const { return sqrt(e2p / nd) + sqrt(e2d / nd); }     // RPI.h:742-744: both averages / nValidDepthPts
+    double error_occ() const { return sqrt(e2p / np) + sqrt(e2d / nd); } // RPI.h:1314-1317, 1765-1768
 };
 PinSums pin_sums(const GNState& S) {
     PinSums o;
@@ -1605,14 +1677,26 @@ extern "C" int rgbd360_set_camera(rgbd360_ctx* ctx, float fx, float fy, float ox
     return 0;
 }
 
-extern "C" int rgbd360_eval_pinhole(rgbd360_ctx* ctx, int level, const float pose[16], int method, double err2_split[2],
-                                    long long n_split[2], float H[36], float g[6], double H64[36], double g64[6], long long* n_rows) {
+extern "C" int rgbd360_use_saliency(rgbd360_ctx* ctx, int on, float thres_saliency) {
+    if (!ctx) return -1;
+    if (on && !(thres_saliency >= 0.f)) return fail(ctx, -1, "thres_saliency must be >= 0");
+    ctx->sal_thr = on ? thres_saliency : -1.f;
+    return 0;
+}
+
+static int pin_eval_any(rgbd360_ctx* ctx, int level, const float* pose, int method, int occlusion) {
+    return occlusion == 0 ? pin_eval(ctx, level, pose, method) : pin_eval_occ(ctx, level, pose, method, occlusion);
+}
+
+extern "C" int rgbd360_eval_pinhole_occ(rgbd360_ctx* ctx, int level, const float pose[16], int method, int occlusion, double err2_split[2],
+                                        long long n_split[2], float H[36], float g[6], double H64[36], double g64[6], long long* n_rows) {
     int rc = pin_check(ctx, level, method);
     if (rc) return rc;
     if (!pose) return fail(ctx, -1, "null pose pointer");
+    if (occlusion < 0 || occlusion > 2) return fail(ctx, -5, "occlusion must be 0, 1 or 2");
     hipSetDevice(ctx->p.device);
     if ((rc = pin_prepare_level(ctx, level)) != 0) return rc;
-    if ((rc = pin_eval(ctx, level, pose, method)) != 0) return rc;
+    if ((rc = pin_eval_any(ctx, level, pose, method, occlusion)) != 0) return rc;
     const GNState& S = *ctx->h_state;
     const PinSums P = pin_sums(S);
     if (err2_split) { err2_split[0] = P.e2p; err2_split[1] = P.e2d; }
@@ -1629,6 +1713,11 @@ extern "C" int rgbd360_eval_pinhole(rgbd360_ctx* ctx, int level, const float pos
     }
     if (n_rows) *n_rows = (long long)P.rows;
     return 0;
+}
+
+extern "C" int rgbd360_eval_pinhole(rgbd360_ctx* ctx, int level, const float pose[16], int method, double err2_split[2],
+                                    long long n_split[2], float H[36], float g[6], double H64[36], double g64[6], long long* n_rows) {
+    return rgbd360_eval_pinhole_occ(ctx, level, pose, method, 0, err2_split, n_split, H, g, H64, g64, n_rows);
 }
 
 extern "C" int rgbd360_warp_indices_pinhole(rgbd360_ctx* ctx, int level, const float pose[16], int32_t* host_out_rc) {
@@ -1656,7 +1745,7 @@ extern "C" int rgbd360_align_pinhole(rgbd360_ctx* ctx, const float guess[16], in
     int rc = pin_check(ctx, 0, method);
     if (rc) return rc;
     if (!guess || !pose_out) return fail(ctx, -1, "null pose pointer");
-    if (occlusion != 0) return fail(ctx, -5, "the pinhole path implements occlusion 0 only");
+    if (occlusion < 0 || occlusion > 2) return fail(ctx, -5, "occlusion must be 0, 1 or 2");
     hipSetDevice(ctx->p.device);
     rgbd360_result R;
     memset(&R, 0, sizeof(R));
@@ -1667,13 +1756,14 @@ extern "C" int rgbd360_align_pinhole(rgbd360_ctx* ctx, const float guess[16], in
     bool any_iteration = false;
     int status = 0;
     PinSums P;
+    float sso = 0.f;
     auto eval = [&](int level, const float* pose, double& out) -> int {
-        const int e = pin_eval(ctx, level, pose, method);
+        const int e = pin_eval_any(ctx, level, pose, method, occlusion);
         if (e) return e;
         P = pin_sums(*ctx->h_state);
-        out = P.error();
+        out = occlusion ? P.error_occ() : P.error();
         last_eval = out;
-        last_photo = sqrt(P.e2p / P.nd);
+        last_photo = sqrt(P.e2p / (occlusion ? P.np : P.nd));
         last_depth = sqrt(P.e2d / P.nd);
         return 0;
     };
@@ -1701,6 +1791,7 @@ extern "C" int rgbd360_align_pinhole(rgbd360_ctx* ctx, const float guess[16], in
             temp_eval = last_eval; temp_photo = last_photo; temp_depth = last_depth;
             memcpy(H, at_pose.H, sizeof(H));          // calcHessGrad(pose_estim): the fused pass at pose_estim
             memcpy(g, at_pose.g, sizeof(g));
+            if (occlusion == 2) sso = (float)(at_pose.rows / (double)ctx->levels[level].n);      // calcHessGrad_Occ2 sets SSO (RPI.h:2016)
             float M[36];
             for (int k = 0; k < 36; ++k) M[k] = H[k];
             for (int i = 0; i < 6; ++i) M[i * 6 + i] = H[i * 6 + i] + lambda * H[i * 6 + i];
@@ -1747,6 +1838,7 @@ extern "C" int rgbd360_align_pinhole(rgbd360_ctx* ctx, const float guess[16], in
     R.rms_photo = any_iteration ? temp_photo : last_photo;
     R.rms_depth = any_iteration ? temp_depth : last_depth;
     if (status == 1) R.err_final = 0.0;
+    R.sso = status == 1 ? 0.f : sso;
     memcpy(R.hessian, H, sizeof(H));
     memcpy(R.gradient, g, sizeof(g));
     if (res) *res = R;

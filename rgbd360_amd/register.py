@@ -86,10 +86,12 @@ class RegisterPhotoICP:
         self._p.sigma_depth = float(stdDev)
         self._dirty()
 
-    def useSaliency(self, flag: bool):
-        # bUseSalientPixels only selects calcGradientXY_saliency's index list, which the spherical passes
-        # never read (their saliency branch is commented out, RPI.h:2568-2642); accepted and ignored.
-        self._use_saliency = bool(flag)
+    def useSaliency(self, flag: bool, thresSaliency: float = 0.01):
+        # bUseSalientPixels selects calcGradientXY_saliency's index list (RPI.h:401-425), which only the pinhole error pass reads
+        # (RPI.h:590-690); the spherical passes' saliency branch is commented out (RPI.h:2568-2642): no effect there.
+        self._use_saliency = (bool(flag), float(thresSaliency))
+        if self._h is not None:
+            self._check(self._L.rgbd360_use_saliency(self._h, int(bool(flag)), float(thresSaliency)))
 
     def setVisualization(self, viz: bool):
         if viz:
@@ -109,6 +111,8 @@ class RegisterPhotoICP:
             self._h = h
             if getattr(self, "_cam", None) is not None:          # the camera matrix survives the setters that recreate the context
                 self._check(self._L.rgbd360_set_camera(self._h, *self._cam))
+            if getattr(self, "_use_saliency", None):
+                self._check(self._L.rgbd360_use_saliency(self._h, int(self._use_saliency[0]), self._use_saliency[1]))
         return self._h
 
     def close(self):
@@ -207,14 +211,14 @@ class RegisterPhotoICP:
         self.status = rc
         self._pose = pose_from_cm(out)
         r = self._res
-        self.SSO = 0.0
+        self.SSO = float(r.sso)          # only calcHessGrad_Occ2 sets it on this path (RPI.h:2016)
         self.avResidual = float(r.err_final)
         self.avPhotoResidual = float(r.rms_photo)
         self.avDepthResidual = float(r.rms_depth)
         self.num_iterations = [int(r.iters[l]) for l in range(self._p.n_pyr)]
         return rc
 
-    def eval_pinhole(self, level: int, pose, method: int):
+    def eval_pinhole(self, level: int, pose, method: int, occlusion: int = 0):
         p = pose_to_cm(pose)
         nrows = C.c_longlong()
         e2s = np.zeros(2, np.float64)
@@ -223,8 +227,8 @@ class RegisterPhotoICP:
         g = np.zeros(6, np.float32)
         Hd = np.zeros(36, np.float64)
         gd = np.zeros(6, np.float64)
-        self._check(self._L.rgbd360_eval_pinhole(self._ctx(), level, _ptr(p), method, _ptr(e2s), _ptr(ns), _ptr(H), _ptr(g),
-                                                 _ptr(Hd), _ptr(gd), C.byref(nrows)))
+        self._check(self._L.rgbd360_eval_pinhole_occ(self._ctx(), level, _ptr(p), method, int(occlusion), _ptr(e2s), _ptr(ns), _ptr(H), _ptr(g),
+                                                     _ptr(Hd), _ptr(gd), C.byref(nrows)))
         return dict(err2_split=e2s, n_split=ns, H=H.reshape(6, 6).T.copy(), g=g, H64=Hd.reshape(6, 6).T.copy(), g64=gd,
                     n_rows=nrows.value)
 

@@ -324,3 +324,99 @@ def pinhole_error(fr, level, pose, K, method, sigma_p=F(6.0 / 255), sigma_d=F(0.
             we = ((huber(diff, sdev) / sdev).astype(F) * diff).astype(F)
         sd_, n_d = float(sq(we[fin]).sum()), int(fin.sum())
     return sp, sd_, n_p, n_d
+
+
+# ---- pinhole occlusion-aware passes (sequential semantics of RPI.h:1107-2030) --------------------------------------------
+def _pinhole_warp(fr, level, pose, K):
+    d = fr.dep_s[level]
+    rows, cols = d.shape
+    s = F(1.0 / 2 ** level)
+    fx, fy, ox, oy = (F(K[0]) * s, F(K[1]) * s, F(K[2]) * s, F(K[3]) * s)
+    valid = ((fr.dmin < d) & (d < fr.dmax)).ravel()
+    cc, rr = np.meshgrid(np.arange(cols).astype(F), np.arange(rows).astype(F))
+    z = d.ravel()
+    x = ((cc.ravel() - ox) * z * F(1.0 / np.float64(fx))).astype(F)
+    y = ((rr.ravel() - oy) * z * F(1.0 / np.float64(fy))).astype(F)
+    R = np.asarray(pose, F)[:3, :3]
+    t = np.asarray(pose, F)[:3, 3]
+    X = ((R[0, 0] * x + R[0, 1] * y) + R[0, 2] * z) + t[0]
+    Y = ((R[1, 0] * x + R[1, 1] * y) + R[1, 2] * z) + t[1]
+    Z = ((R[2, 0] * x + R[2, 1] * y) + R[2, 2] * z) + t[2]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        iz = (1.0 / Z.astype(np.float64)).astype(F)
+        tc = ((X * fx) * iz + ox).astype(F)
+        tr = ((Y * fy) * iz + oy).astype(F)
+        rnd = lambda v: np.where(np.isfinite(v), np.sign(v) * np.floor(np.abs(v.astype(np.float64)) + 0.5), -1).astype(np.int64)
+        ri, ci = rnd(tr), rnd(tc)
+    vis = valid & (ri >= 0) & (ri < rows) & (ci >= 0) & (ci < cols)
+    return dict(X=X, Y=Y, Z=Z, iz=iz, r=ri, c=ci, vis=vis, rows=rows, cols=cols, fx=fx, fy=fy)
+
+
+def pinhole_occ(fr, level, pose, K, method, occ, sigma_p=F(6.0 / 255), sigma_d=F(0.2), thr_p=F(0.01), thr_d=F(0.01), thr_outlier=F(1.0)):
+    """errorPhotoICP_Occ1/2 and calcHessGrad_Occ1/2 at one pose, grouped by target pixel instead of swept in pixel order (valid while
+    every inverse depth is positive: the z-buffer's accepted pixels are then the prefix maxima of 1/Z).
+    Returns (sum photo, sum depth, n photo, n depth, H f64, g f64, numVisiblePixels)."""
+    w = _pinhole_warp(fr, level, pose, K)
+    idx0 = np.nonzero(w["vis"])[0]
+    assert (w["iz"][idx0] > 0).all()
+    out = []
+    for which in ("error", "hess"):
+        idx = idx0
+        r, c = w["r"][idx], w["c"][idx]
+        d2 = fr.dep_t[level][r, c]
+        if occ == 2:      # the gates: depth against INVERSE depth in the error pass (RPI.h:1687-1690, sic), against depth in H, g (RPI.h:1857-1862)
+            other = w["iz"][idx] if which == "error" else w["Z"][idx]
+            with np.errstate(invalid="ignore"):
+                keep = ~(np.abs((d2 - other).astype(F)) > thr_outlier)
+            idx, r, c, d2 = idx[keep], r[keep], c[keep], d2[keep]
+        X, Y, Z, iz = w["X"][idx], w["Y"][idx], w["Z"][idx], w["iz"][idx]
+        target = r * w["cols"] + c
+        pm, owner = _prefix_maxima(target, iz, idx) if len(idx) else (np.zeros(0, bool), np.zeros(0, bool))
+        gx, gy = fr.gx[level][r, c], fr.gy[level][r, c]
+        sal_p = ~((np.abs(gx) < thr_p) & (np.abs(gy) < thr_p))
+        dgx, dgy = fr.dgx[level][r, c], fr.dgy[level][r, c]
+        sal_d = ~((np.abs(dgx) < thr_d) & (np.abs(dgy) < thr_d))
+        diff_p = (fr.gray_t[level][r, c] - fr.gray_s[level].ravel()[idx]).astype(F)
+        wgt_p = (huber(diff_p, sigma_p) * F(1.0 / np.float64(sigma_p))).astype(F)
+        res_p = (wgt_p * diff_p).astype(F)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            diff_d = (d2 - Z).astype(F)
+            sd = (sigma_d * Z).astype(F)
+            wgt_d = (huber(diff_d, sd) / sd).astype(F)
+            res_d = (wgt_d * diff_d).astype(F)
+        fin = np.isfinite(d2)
+        sq = lambda v: (v * v).astype(F).astype(np.float64)
+        if which == "error":
+            ok_p = sal_p if method in (0, 2) else np.zeros(len(idx), bool)
+            ok_d = (fin & sal_d & (sal_p if method == 2 else True)) if method in (1, 2) else np.zeros(len(idx), bool)
+            out += [float(sq(res_p[owner & ok_p]).sum()), float(sq(res_d[owner & ok_d]).sum()), int((pm & ok_p).sum()), int((pm & ok_d).sum())]
+        else:
+            n_vis = int(pm.sum()) + len(np.unique(target))      # a target's first arrival is counted twice (RPI.h:1421-1430)
+            H = np.zeros((6, 6)); g = np.zeros(6)
+            if method in (0, 2):
+                fx, fy = w["fx"], w["fy"]
+                iz2 = iz * iz
+                Jw0 = np.stack([fx * iz, 0 * iz, -fx * X * iz2, -fx * Y * X * iz2, fx * (1 + X * X * iz2), -fx * Y * iz], 1).astype(F)
+                Jw1 = np.stack([0 * iz, fy * iz, -fy * Y * iz2, -fy * (1 + Y * Y * iz2), fy * X * Y * iz2, fy * X * iz], 1).astype(F)
+                rows_p = pm & sal_p & (res_p != 0)               # rows are kept per SOURCE pixel; both sums test the photo residual
+                Jp = ((wgt_p * gx)[:, None] * Jw0 + (wgt_p * gy)[:, None] * Jw1).astype(F)
+                H += np.einsum("ni,nj->ij", Jp[rows_p], Jp[rows_p], dtype=np.float64)
+                g += Jp[rows_p].astype(np.float64).T @ res_p[rows_p].astype(np.float64)
+                if method == 2:
+                    rows_d = rows_p & sal_d & fin
+                    Jz = np.stack([0 * X, 0 * X, 1 + 0 * X, Y, -X, 0 * X], 1).astype(F)
+                    with np.errstate(invalid="ignore"):
+                        Jd = (wgt_d[:, None] * ((dgx[:, None] * Jw0 + dgy[:, None] * Jw1) - Jz)).astype(F)
+                    H += np.einsum("ni,nj->ij", Jd[rows_d], Jd[rows_d], dtype=np.float64)
+                    g += Jd[rows_d].astype(np.float64).T @ res_d[rows_d].astype(np.float64)
+            out += [H, g, n_vis]
+    return tuple(out)
+
+
+def pinhole_salient_list(fr, level, thr=F(0.01)):
+    """vSalientPixels (RPI.h:420-424): interior pixels of the TARGET whose gray gradient exceeds thr in x or y, index order."""
+    gx, gy = fr.gx[level], fr.gy[level]
+    m = (np.abs(gx) > thr) | (np.abs(gy) > thr)
+    m[0, :] = m[-1, :] = False
+    m[:, 0] = m[:, -1] = False
+    return np.nonzero(m.ravel())[0]

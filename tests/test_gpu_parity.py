@@ -1180,7 +1180,7 @@ def test_pinhole_argument_errors(hip_lib):
         reg.alignFrames(np.eye(4), 2)                 # no camera matrix yet
     reg.setCameraMatrix(np.array([[K[0], 0, K[2]], [0, K[1], K[3]], [0, 0, 1]]))
     with pytest.raises(Rgbd360Error):
-        reg.alignFrames(np.eye(4), 2, occlusion=1)
+        reg.alignFrames(np.eye(4), 2, occlusion=3)
     assert reg.alignFrames(np.eye(4), 2) == 0
     seams = _mk(hip_lib, 3)                           # default params mask the panorama seams: refused for a pinhole image
     seams.setCameraMatrix(K); seams.setTargetFrame(rgbA, dA); seams.setSourceFrame(rgbB, dB)
@@ -1204,6 +1204,138 @@ def test_hip_pinhole_matches_golden_fixture(hip_lib, method):
     e = reg.eval_pinhole(1, T, method)
     assert list(e["n_split"]) == [g["n_photo"], g["n_depth"]] and e["n_rows"] == g["n_rows"]
     assert np.abs(e["H64"] - np.array(g["H64"])).max() <= HG_RTOL * np.abs(np.array(g["H64"])).max()
+
+
+# ---- pinhole occlusion-aware passes + salient-pixel list (RPI.h:1107-2030, 401-425, 590-690) ---------------------------------
+def _pinhole_probe_pose(T):
+    back = np.eye(4)
+    back[2, 3] = 0.6            # the rendered motion pushed 0.6 m along the optical axis: up to four source pixels per target pixel
+    return back @ T
+
+
+@pytest.mark.parametrize("occ", [1, 2])
+@pytest.mark.parametrize("method", [0, 1, 2])
+def test_pinhole_occlusion_eval_parity(hip_lib, oracle_mod, method, occ):
+    """errorPhotoICP_Occ1/2 + calcHessGrad_Occ1/2 at one pose: counts (integer work, the z-buffer's accept chain included) exact,
+    sums within the float tolerances of the plain pass."""
+    reg, ora, T = _pinhole_ctx(hip_lib, oracle_mod)
+    longest = 0
+    for level in range(3):
+        for pose in list(_poses(T)) + [_pinhole_probe_pose(T)]:
+            idx = ora.warp_indices_pinhole(level, pose)
+            v = idx[:, 0] >= 0
+            longest = max(longest, int(np.unique(idx[v, 0] * 4096 + idx[v, 1], return_counts=True)[1].max()))
+            e = reg.eval_pinhole(level, pose, method, occ)
+            _, sp, sd, n_p, n_d = ora.error_pinhole_occ(level, pose, method, occ)
+            H, g, Hd, gd, nvis = ora.hessgrad_pinhole_occ(level, pose, method, occ)
+            assert list(e["n_split"]) == [n_p, n_d] and e["n_rows"] == nvis, (level, list(e["n_split"]), n_p, n_d, e["n_rows"], nvis)
+            assert abs(e["err2_split"][0] - sp) <= ERR2_RTOL * max(1.0, abs(sp))
+            assert abs(e["err2_split"][1] - sd) <= ERR2_RTOL * max(1.0, abs(sd))
+            scale_h = max(np.abs(Hd).max(), 1e-30)
+            assert np.abs(e["H64"] - Hd).max() <= HG_RTOL * scale_h
+            assert np.abs(e["g64"] - gd).max() <= HG_RTOL * max(np.abs(gd).max(), 1e-3 * np.sqrt(scale_h))
+            if method == 1:
+                assert not e["H64"].any()          # as written: both row sums test the photometric residual
+    assert longest >= 3
+
+
+def test_pinhole_occlusion_eval_occlusion_zero_is_the_plain_pass(hip_lib, oracle_mod):
+    reg, ora, T = _pinhole_ctx(hip_lib, oracle_mod)
+    a, b = reg.eval_pinhole(1, T, 2), reg.eval_pinhole(1, T, 2, 0)
+    assert np.array_equal(a["H64"], b["H64"]) and list(a["n_split"]) == list(b["n_split"])
+
+
+@pytest.mark.parametrize("method,occ", [(2, 1), (2, 2), (0, 1), (1, 1)])
+def test_pinhole_occlusion_align_matches_oracle(hip_lib, oracle_mod, method, occ):
+    reg, ora, T = _pinhole_ctx(hip_lib, oracle_mod)
+    rc = reg.alignFrames(np.eye(4), method, occ)
+    st, pose_ref = ora.align_pinhole(np.eye(4), method, occ)
+    assert rc == st
+    # only PHOTO_DEPTH under occlusion 1 optimises anything: a single modality is 0 / 0 in the other average, and occlusion 2's error
+    # gate (target depth against the point's INVERSE depth) leaves no depth residual on the fine levels -- as the source is written
+    assert rc == (0 if (method, occ) == (2, 1) else 2)
+    assert reg.num_iterations == list(ora.result.iters)[:3]
+    rot, trans = synth.pose_error(reg.getOptimalPose(), pose_ref)
+    assert rot <= PINHOLE_ROT_TOL_DEV and trans <= PINHOLE_TRANS_TOL_DEV, (rot, trans)
+    assert abs(reg.SSO - ora.result.sso) <= 1e-6
+    if rc == 0:
+        assert sum(reg.num_iterations) >= 3
+        assert abs(reg.avResidual - ora.result.err_final) <= 1e-3 * max(1.0, ora.result.err_final)
+        assert np.allclose(reg.getHessian(), np.asarray(list(ora.result.hessian)).reshape(6, 6).T, rtol=1e-4, atol=1e-4 * np.abs(reg.getHessian()).max())
+        r0, t0 = synth.pose_error(np.eye(4), T)
+        r1, t1 = synth.pose_error(reg.getOptimalPose(), T)
+        assert r1 < 0.5 * r0 and t1 < 0.5 * t0
+        ora0 = oracle_mod.Oracle(n_pyr=3, math_mode=0, reduce_mode=0, mask_seams=0)       # the reference-faithful libm / roundf oracle
+        (rgbA, dA), (rgbB, dB), _, K = synth.make_pinhole_pair(320, 240, seed=77)
+        ora0.set_camera(*K); ora0.set_target(rgbA, dA); ora0.set_source(rgbB, dB)
+        st0, pose0 = ora0.align_pinhole(np.eye(4), method, occ)
+        rot, trans = synth.pose_error(reg.getOptimalPose(), pose0)
+        assert st0 == 0 and rot <= ROT_TOL and trans <= TRANS_TOL, (rot, trans)
+
+
+def test_hip_pinhole_occlusion_matches_golden_fixture(hip_lib):
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pinhole_occ.json")) as f:
+        G = json.load(f)
+    (rgbA, dA), (rgbB, dB), T, K = synth.make_pinhole_pair(320, 240, seed=77)
+    reg = _mk(hip_lib, 3, setMaskSeams=False)
+    reg.setCameraMatrix(K); reg.setTargetFrame(rgbA, dA); reg.setSourceFrame(rgbB, dB)
+    for occ in (1, 2):
+        for method in (0, 1, 2):
+            ref = G["occ"]["math1/occ%d/method%d" % (occ, method)]
+            rc = reg.alignFrames(np.eye(4), method, occ)
+            assert rc == ref["status"] and reg.num_iterations == ref["iters"]
+            rot, trans = synth.pose_error(reg.getOptimalPose(), np.array(ref["pose"]))
+            assert rot <= PINHOLE_ROT_TOL_DEV and trans <= PINHOLE_TRANS_TOL_DEV
+            for name, pp, level in (("at_gt_level1", T, 1), ("at_probe_level0", _pinhole_probe_pose(T), 0)):
+                g = ref[name]
+                e = reg.eval_pinhole(level, pp, method, occ)
+                assert list(e["n_split"]) == [g["n_photo"], g["n_depth"]] and e["n_rows"] == g["n_visible"]
+                assert np.abs(e["H64"] - np.array(g["H64"])).max() <= HG_RTOL * max(np.abs(np.array(g["H64"])).max(), 1e-30)
+
+
+def test_pinhole_saliency_list_mode(hip_lib, oracle_mod):
+    """useSaliency(true): the error sums run over vSalientPixels (interior pixels with a salient TARGET gradient, used as source indices),
+    the normal equations over every pixel."""
+    reg, ora, T = _pinhole_ctx(hip_lib, oracle_mod)
+    plain = reg.eval_pinhole(1, T, 2)
+    reg.useSaliency(True)
+    ora.use_saliency(True, 0.01)
+    for level in range(3):
+        for pose in _poses(T):
+            for method in (0, 1, 2):
+                e = reg.eval_pinhole(level, pose, method)
+                _, sp, sd, n_p, n_d = ora.error_pinhole_salient(level, pose, method)
+                H, g, Hd, gd, nrows = ora.hessgrad_pinhole(level, pose, method)
+                assert list(e["n_split"]) == [n_p, n_d] and e["n_rows"] == nrows
+                assert abs(e["err2_split"][0] - sp) <= ERR2_RTOL * max(1.0, abs(sp)) and abs(e["err2_split"][1] - sd) <= ERR2_RTOL * max(1.0, abs(sd))
+                assert np.abs(e["H64"] - Hd).max() <= HG_RTOL * np.abs(Hd).max()
+    sal = reg.eval_pinhole(1, T, 2)
+    assert sal["n_split"][0] < plain["n_split"][0] and np.array_equal(sal["H64"], plain["H64"])
+    rc = reg.alignFrames(np.eye(4), 2)
+    st, pose_ref = ora.align_pinhole(np.eye(4), 2)
+    assert rc == st == 0 and reg.num_iterations == list(ora.result.iters)[:3]
+    rot, trans = synth.pose_error(reg.getOptimalPose(), pose_ref)
+    assert rot <= PINHOLE_ROT_TOL_DEV and trans <= PINHOLE_TRANS_TOL_DEV
+    reg.useSaliency(False)
+    back = reg.eval_pinhole(1, T, 2)
+    assert list(back["n_split"]) == list(plain["n_split"])
+
+
+def test_pinhole_occlusion_long_lists_are_walked_exactly(hip_lib, oracle_mod):
+    """A pose that collapses the whole image onto a handful of target pixels (lists of thousands of source pixels): the sorted walk is
+    exact and bounded whatever the list lengths."""
+    reg, ora, T = _pinhole_ctx(hip_lib, oracle_mod)
+    far = np.eye(4)
+    far[2, 3] = 400.0
+    idx = ora.warp_indices_pinhole(0, far)
+    v = idx[:, 0] >= 0
+    assert np.unique(idx[v, 0] * 4096 + idx[v, 1], return_counts=True)[1].max() > 2000
+    for occ in (1, 2):
+        e = reg.eval_pinhole(0, far, 2, occ)
+        _, sp, sd, n_p, n_d = ora.error_pinhole_occ(0, far, 2, occ)
+        nvis = ora.hessgrad_pinhole_occ(0, far, 2, occ)[4]
+        assert list(e["n_split"]) == [n_p, n_d] and e["n_rows"] == nvis
 
 
 @pytest.mark.parametrize("method", [0, 2])

@@ -578,3 +578,116 @@ def test_plane_refinement_grows_planes_into_their_noisy_border(oracle_mod):
     # idempotent: a second refinement finds nothing left to grow
     ref2, _, changed2 = oracle_mod.f360_plane_refine(xyz, H, W, ref, planes2, 0.02)
     assert changed2 == 0 and np.array_equal(ref2, ref)
+
+
+# ---- pinhole occlusion-aware passes and the salient-pixel list (RPI.h:1107-2030, 401-425, 590-690) ----------------------------
+def _pinhole_occ_golden():
+    import json
+    with open(os.path.join(HERE, "golden", "pinhole_occ.json")) as f:
+        return json.load(f)
+
+
+def _probe_pose(T):
+    back = np.eye(4)
+    back[2, 3] = 0.6
+    return back @ T
+
+
+@pytest.mark.parametrize("math_mode", [0, 1])
+def test_oracle_pinhole_occlusion_matches_golden(oracle_mod, math_mode):
+    import zlib
+    G = _pinhole_occ_golden()
+    (rgbA, dA), (rgbB, dB), T, K = synth.make_pinhole_pair(320, 240, seed=77)
+    crc = lambda a: zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF
+    assert [crc(rgbA), crc(dA), crc(rgbB), crc(dB)] == G["crc32_inputs"]
+    ora = oracle_mod.Oracle(n_pyr=3, math_mode=math_mode, reduce_mode=1, mask_seams=0)
+    ora.set_camera(*K); ora.set_target(rgbA, dA); ora.set_source(rgbB, dB)
+    for occ in (1, 2):
+        for method in (0, 1, 2):
+            ref = G["occ"]["math%d/occ%d/method%d" % (math_mode, occ, method)]
+            st, pose = ora.align_pinhole(np.eye(4), method, occ)
+            assert st == ref["status"] and list(ora.result.iters)[:3] == ref["iters"]
+            rot, trans = synth.pose_error(pose, np.array(ref["pose"]))
+            assert rot < 1e-6 and trans < 1e-6
+            assert abs(ora.result.sso - ref["sso"]) < 1e-6
+            for name, pp, level in (("at_gt_level1", T, 1), ("at_probe_level0", _probe_pose(T), 0)):
+                g = ref[name]
+                e = ora.error_pinhole_occ(level, pp, method, occ)
+                assert (e[3], e[4]) == (g["n_photo"], g["n_depth"])
+                assert abs(e[1] - g["sum_photo"]) <= 1e-9 * max(1.0, g["sum_photo"]) and abs(e[2] - g["sum_depth"]) <= 1e-9 * max(1.0, g["sum_depth"])
+                H, gg, Hd, gd, nvis = ora.hessgrad_pinhole_occ(level, pp, method, occ)
+                assert nvis == g["n_visible"] and np.allclose(Hd, np.array(g["H64"]), rtol=1e-9) and np.allclose(gd, np.array(g["g64"]), rtol=1e-9, atol=1e-12)
+    ora.use_saliency(True, 0.01)
+    S = G["salient"]["math%d" % math_mode]
+    for level in range(3):
+        v = ora.salient_pixels(level)
+        assert len(v) == S["list_len"][level] and crc(v.astype(np.int32)) == S["list_crc"][level]
+    for method in (1, 2):
+        g = S["method%d" % method]
+        e = ora.error_pinhole_salient(1, T, method)
+        assert (e[3], e[4]) == (g["n_photo"], g["n_depth"]) and abs(e[1] - g["sum_photo"]) <= 1e-9 * max(1.0, g["sum_photo"])
+        st, pose = ora.align_pinhole(np.eye(4), method, 0)
+        assert st == g["status"] and list(ora.result.iters)[:3] == g["iters"]
+        rot, trans = synth.pose_error(pose, np.array(g["pose"]))
+        assert rot < 1e-6 and trans < 1e-6
+
+
+def test_numpy_restatement_agrees_on_pinhole_occlusion_passes(oracle_mod):
+    """errorPhotoICP_Occ1/2 and calcHessGrad_Occ1/2 against the independent numpy restatement (grouped by target pixel: prefix maxima
+    of 1/Z instead of a z-buffer swept in pixel order), at the rendered motion and at a pose that piles up to four source pixels on a
+    target pixel; counts exact, sums to float accumulation error."""
+    sys.path.insert(0, HERE)
+    import np_restatement as NP
+    (rgbA, dA), (rgbB, dB), T, K = synth.make_pinhole_pair(160, 120, seed=5)
+    ora = oracle_mod.Oracle(n_pyr=2, reduce_mode=1, mask_seams=0)
+    ora.set_camera(*K); ora.set_target(rgbA, dA); ora.set_source(rgbB, dB)
+    fr = NP.Frames(rgbA, dA, rgbB, dB, n_pyr=2, mask=False)
+    longest = 0
+    for level in range(2):
+        for pose in (T, _probe_pose(T)):
+            idx = ora.warp_indices_pinhole(level, pose)
+            v = idx[:, 0] >= 0
+            longest = max(longest, np.unique(idx[v, 0] * 4096 + idx[v, 1], return_counts=True)[1].max())
+            for occ in (1, 2):
+                for method in (0, 1, 2):
+                    _, sp, sd, n_p, n_d = ora.error_pinhole_occ(level, pose, method, occ)
+                    H, g, Hd, gd, nvis = ora.hessgrad_pinhole_occ(level, pose, method, occ)
+                    a = NP.pinhole_occ(fr, level, pose, K, method, occ)
+                    assert (n_p, n_d, nvis) == (a[2], a[3], a[6]), (level, occ, method)
+                    assert abs(a[0] - sp) <= 1e-6 * max(sp, 1.0) and abs(a[1] - sd) <= 1e-6 * max(sd, 1.0)
+                    assert np.abs(Hd - a[4]).max() <= 1e-6 * max(np.abs(Hd).max(), 1e-9) and np.abs(gd - a[5]).max() <= 1e-6 * max(np.abs(gd).max(), 1e-9)
+                    if method == 1:
+                        assert not Hd.any()          # both row sums test the PHOTO residual (RPI.h:1523, 1531): depth alone sums nothing
+        assert np.array_equal(ora.salient_pixels(level), NP.pinhole_salient_list(fr, level))
+    assert longest >= 3
+
+
+def test_pinhole_occlusion_zbuffer_is_sequential(oracle_mod):
+    """Known answers of the index-order sweep.  Pushing every point away along the optical axis shrinks the warped image, so several
+    source pixels share a target pixel.  If the source depth GROWS with the pixel index, a list's later pixels are farther: only the first
+    is accepted.  If it SHRINKS, every later pixel is closer: all are accepted, and each counts.  thres_sal_photo = 0 makes every target
+    pixel salient (`|g| < 0` never holds), so the photo counter counts the accepted pixels; numVisiblePixels counts a target pixel's first
+    arrival twice (RPI.h:1421-1430)."""
+    rows, cols = 24, 32
+    rng = np.random.default_rng(0)
+    rgbA = rng.integers(0, 255, (rows, cols, 3)).astype(np.uint8)
+    rgbB = rng.integers(0, 255, (rows, cols, 3)).astype(np.uint8)
+    dA = np.full((rows, cols), 2000, np.uint16)
+    ramp = np.arange(rows * cols, dtype=np.int64).reshape(rows, cols)
+    K = (30.0, 30.0, 15.5, 11.5)
+    P = np.eye(4)
+    P[2, 3] = 2.5
+    for math_mode in (0, 1):
+        for growing in (True, False):
+            dB = (1500 + ramp if growing else 1500 + ramp[::-1, ::-1]).astype(np.uint16)
+            ora = oracle_mod.Oracle(n_pyr=1, math_mode=math_mode, reduce_mode=1, mask_seams=0, thres_sal_photo=0.0, thres_sal_depth=0.0)
+            ora.set_camera(*K); ora.set_target(rgbA, dA); ora.set_source(rgbB, dB)
+            idx = ora.warp_indices_pinhole(0, P)
+            v = idx[:, 0] >= 0
+            per_target = np.unique(idx[v, 0] * cols + idx[v, 1], return_counts=True)[1]
+            assert per_target.max() >= 3 and v.sum() > 2 * len(per_target)
+            accepted = len(per_target) if growing else int(v.sum())
+            _, sp, sd, n_p, n_d = ora.error_pinhole_occ(0, P, 2, 1)
+            assert n_p == accepted and n_d == accepted
+            nvis = ora.hessgrad_pinhole_occ(0, P, 2, 1)[4]
+            assert nvis == accepted + len(per_target)
