@@ -245,6 +245,11 @@ int  rgbd360_rig_eval(rgbd360_rig* rig, int level, const float pose[16], int met
  * res->hessian = the summed Hessian of the last step (informationM, RegisterRGBD360.h:511), res->err_final = the summed
  * squared error at pose_out. */
 int  rgbd360_rig_align(rgbd360_rig* rig, const float guess[16], int method, float pose_out[16], rgbd360_result* res);
+/* useSaliency(true) on the per-sensor RegisterPhotoICP objects (RPI.h:266-269): calcPhotoICPError_robot and
+ * calcHessianGradient_robot run over vSalientPixels only (RPI.h:4930-5003, 5121-5262: the same loop bodies over the list built by
+ * calcGradientXY_saliency from the TARGET's gray gradients, RPI.h:401-425, used as source pixel indices).  Off by default, as in
+ * every application of the reference. */
+int  rgbd360_rig_use_saliency(rgbd360_rig* rig, int on, float thres_saliency);
 
 /* ---- Frame360 per-pixel stages ------------------------------------------------------------------------------ */
 

@@ -112,6 +112,7 @@ def lib():
         L.oracle_rig_create.argtypes = [C.POINTER(Params), C.c_int, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float]
         L.oracle_rig_destroy.argtypes = [C.c_void_p]
         L.oracle_rig_set_modes.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.oracle_rig_use_saliency.argtypes = [C.c_void_p, C.c_int, C.c_float]
         L.oracle_rig_set_frame.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int]
         L.oracle_rig_error.restype = C.c_double
         L.oracle_rig_error.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
@@ -572,6 +573,10 @@ class RigOracle:
 
     def set_modes(self, math_mode: int, reduce_mode: int):
         lib().oracle_rig_set_modes(self.h, math_mode, reduce_mode)
+
+    def use_saliency(self, on=True, thres_saliency=0.01):
+        """useSaliency(bool) on the per-sensor objects: both passes run over vSalientPixels only (RPI.h:4930-5003, 5121-5262)."""
+        lib().oracle_rig_use_saliency(self.h, int(bool(on)), thres_saliency)
 
     def set_frame(self, sensor: int, target: bool, rgb, depth):
         rgb = np.ascontiguousarray(rgb, dtype=np.uint8)

@@ -1826,6 +1826,15 @@ inline RobotWarp warp_robot(const float* poseGuess, const float* Rt, const float
 }
 
 // RPI.h:4905-5076, else-branch :4990-5072.  Returns error2 (the sum); the per-modality sums and counts go to ctx.last_*.
+// bUseSalientPixels on this path (RPI.h:4930-5003, 5121-5262): the same loop bodies over vSalientPixels -- membership of pixel i
+// in the list calcGradientXY_saliency builds from the TARGET's gray gradients (RPI.h:420-424; border gradients are zero).
+inline bool in_salient_list(const Ctx& ctx, int level, long i) {
+    const Image &gx = ctx.gTrgGx[level], &gy = ctx.gTrgGy[level];
+    const int r = (int)(i / gx.cols), c = (int)(i % gx.cols);
+    if (r < 1 || r >= gx.rows - 1 || c < 1 || c >= gx.cols - 1) return false;
+    return fabsf(gx.d[i]) > ctx.thres_saliency || fabsf(gy.d[i]) > ctx.thres_saliency;
+}
+
 double calcPhotoICPError_robot(Ctx& ctx, int level, const float* poseGuess, const float* Rt, int method) {
     double e2p = 0.0, e2d = 0.0;
     long nP = 0, nD = 0;
@@ -1841,6 +1850,7 @@ double calcPhotoICPError_robot(Ctx& ctx, int level, const float* poseGuess, cons
     const long n = (long)nRows * nCols;
     // (serial: the sensor images are small, and a 256-thread OpenMP team per sensor and evaluation costs more than the loop)
     for (long i = 0; i < n; ++i) {
+        if (ctx.use_saliency && !in_salient_list(ctx, level, i)) continue;
         const float* p = &ctx.lut[3 * i];
         if (p[0] == kInvalidPoint) continue;
         const RobotWarp w = warp_robot(poseGuess, Rt, Rt_inv, p, nRows, nCols, K, ctx.p.math_mode, 0);
@@ -1902,6 +1912,7 @@ void calcHessianGradient_robot(Ctx& ctx, int level, const float* poseGuess, cons
         ++rows_used;
     };
     for (long i = 0; i < imgSize; ++i) {
+        if (ctx.use_saliency && !in_salient_list(ctx, level, i)) continue;
         const float* p = &ctx.lut[3 * i];
         if (p[0] == kInvalidPoint) continue;
         const RobotWarp w = warp_robot(poseGuess, Rt, Rt_inv, p, nRows, nCols, K, ctx.p.math_mode, 1);
@@ -2283,6 +2294,9 @@ void oracle_rig_destroy(void* h) {
 }
 void oracle_rig_set_modes(void* h, int math_mode, int reduce_mode) {
     for (Ctx* c : ((Rig*)h)->sensors) { c->p.math_mode = math_mode; c->p.reduce_mode = reduce_mode; }
+}
+void oracle_rig_use_saliency(void* h, int on, float thres_saliency) {
+    for (Ctx* c : ((Rig*)h)->sensors) { c->use_saliency = on != 0; c->thres_saliency = thres_saliency; }
 }
 void oracle_rig_set_frame(void* h, int sensor, int target, const uint8_t* rgb, size_t rgb_step, const void* depth, size_t d_step,
                           int depth_type, int rows, int cols) {

@@ -34,7 +34,7 @@ __device__ __forceinline__ void xform12(const float* m, float x, float y, float 
 template <int METHOD>
 __global__ __launch_bounds__(kEvalThreads) void k_eval_rig(const float4* __restrict__ src, const F3* __restrict__ trgP,
                                                             const F3* __restrict__ trgD, int rows, int cols, int n, PinK K, EvalConsts ec,
-                                                            RigPoses poses, double* __restrict__ partials, int partials_stride, int chunk) {
+                                                            RigPoses poses, double* __restrict__ partials, int partials_stride, int chunk, float sal_thr) {
     const int b = blockIdx.x, s = blockIdx.y;
     const int base = b * chunk;
     const int end = min(base + chunk, n);
@@ -61,7 +61,11 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_rig(const float4* __restr
         const float tr = fmaf(Y * K.fy, iz, K.oy);
         const bool sane = (fabsf(tr) < 1e9f) && (fabsf(tc) < 1e9f);
         const int ri = round_index(sane ? tr : -1.f), ci = round_index(sane ? tc : -1.f);
-        const bool vis = sane && ((unsigned)ri < (unsigned)rows) && ((unsigned)ci < (unsigned)cols) && in_range && (p.x != kInvalidPoint);
+        bool vis = sane && ((unsigned)ri < (unsigned)rows) && ((unsigned)ci < (unsigned)cols) && in_range && (p.x != kInvalidPoint);
+        if (sal_thr >= 0.f) {      // uniform: bUseSalientPixels (RPI.h:4930-5003, 5121-5262) -- both passes run over vSalientPixels only, the
+            const F3 ts = trgP[in_range ? i : 0];      // interior pixels whose TARGET gray gradient exceeds thresSaliency, used as source indices
+            vis = vis && (fabsf(ts.b) > sal_thr || fabsf(ts.c) > sal_thr);
+        }
         const unsigned ti = vis ? (unsigned)(ri * cols + ci) : 0u;
         F3 tp = {0.f, 0.f, 0.f}, td = {0.f, 0.f, 0.f};
         if (METHOD != 1) tp = trgP[ti];
@@ -190,6 +194,7 @@ struct rgbd360_rig {
     hostwait::SpinTag tag;
     unsigned* d_ticket = nullptr;     // device counter of k_rig_reduce's blocks
     bool have_src = false, have_trg = false;
+    float sal_thr = -1.f;             // useSaliency(true) on the per-sensor objects: thresSaliency (RPI.h:217); < 0 = off
     std::string err;
 };
 
@@ -305,7 +310,7 @@ int rig_eval(rgbd360_rig* R, int level, const float* T, int method, RigSums* out
     const PinK K = rig_level_K(R, level);
     const EvalConsts ec = eval_consts(R->p);
     const dim3 g(L.nblocks, R->S), b(kEvalThreads);
-#define LAUNCHR(Mth) hipLaunchKernelGGL((k_eval_rig<Mth>), g, b, 0, E->stream, L.srcRec, L.trgP[0], L.trgD[0], L.rows, L.cols, L.n, K, ec, P, E->d_partials, E->partials_stride, L.chunk)
+#define LAUNCHR(Mth) hipLaunchKernelGGL((k_eval_rig<Mth>), g, b, 0, E->stream, L.srcRec, L.trgP[0], L.trgD[0], L.rows, L.cols, L.n, K, ec, P, E->d_partials, E->partials_stride, L.chunk, R->sal_thr)
     if (method == 0) LAUNCHR(0);
     else if (method == 1) LAUNCHR(1);
     else LAUNCHR(2);
@@ -405,6 +410,13 @@ int rgbd360_rig_create(const rgbd360_params* p, int n_sensors, const float* Rt, 
 }
 
 const char* rgbd360_rig_last_error(rgbd360_rig* R) { return R ? R->err.c_str() : "null handle"; }
+
+int rgbd360_rig_use_saliency(rgbd360_rig* R, int on, float thres_saliency) {
+    if (!R) return -1;
+    if (on && !(thres_saliency >= 0.f)) return rfail(R, -1, "thres_saliency must be >= 0");
+    R->sal_thr = on ? thres_saliency : -1.f;
+    return 0;
+}
 
 int rgbd360_rig_set_target(rgbd360_rig* R, const uint8_t* const* rgb, size_t rgb_step, const void* const* depth, size_t depth_step,
                            int depth_type, int rows, int cols) {

@@ -74,6 +74,10 @@ class RegisterDensePhotoICP:
     def setSourceFrame(self, frame2):       # frame2->frameRGBD_[s] (RegisterRGBD360.h:375)
         self._set(self._L.rgbd360_rig_set_source, frame2)
 
+    def useSaliency(self, flag: bool, thresSaliency: float = 0.01):
+        """useSaliency(bool) on the per-sensor RegisterPhotoICP objects (RPI.h:266): both passes run over vSalientPixels only."""
+        self._check(self._L.rgbd360_rig_use_saliency(self._h, int(bool(flag)), float(thresSaliency)))
+
     def eval(self, level: int, pose, method: int):
         e2, ns = np.zeros(2, np.float64), np.zeros(2, np.int64)
         H, g = np.zeros(36, np.float32), np.zeros(6, np.float32)

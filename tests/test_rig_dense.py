@@ -128,6 +128,36 @@ def test_rig_align_matches_oracle(hip_lib, oracle_mod, rig_pair, method):
 
 
 @pytest.mark.gpu
+def test_rig_salient_pixel_list_mode(hip_lib, oracle_mod, rig_pair):
+    """useSaliency(true) on the per-sensor objects (RPI.h:4930-5003, 5121-5262): both passes over vSalientPixels only -- counts exact,
+    fewer pixels than the full pass, same accept / reject sequence and pose as the oracle; switching it off restores the full pass."""
+    M = rig_pair[2]
+    reg = _gpu_rig(rig_pair)
+    ora = _oracle(oracle_mod, rig_pair, (1, 1))
+    full = reg.eval(1, M, 2)
+    reg.useSaliency(True)
+    ora.use_saliency(True, 0.01)
+    for level in range(3):
+        for T in (np.eye(4), M):
+            for method in (0, 1, 2):
+                e = reg.eval(level, T, method)
+                err, sums = ora.error(level, T, method)
+                H, g, Hd, gd, n = ora.hessgrad(level, T, method)
+                assert list(e["n_split"]) == [int(sums[2]), int(sums[3])] and e["n_rows"] == n
+                assert abs(e["err2"] - err) <= ERR2_RTOL * max(err, 1.0)
+                assert np.abs(e["H64"] - Hd).max() <= HG_RTOL * np.abs(Hd).max()
+    sal = reg.eval(1, M, 2)
+    assert 0 < sal["n_split"][0] < full["n_split"][0] and sal["n_rows"] < full["n_rows"]
+    assert reg.align(np.eye(4), 2)
+    st, pose_ref = ora.align(np.eye(4), 2)
+    assert st == 0 and reg.num_iterations == ora.iters
+    rot, trans = synth.pose_error(reg.getPose(), pose_ref)
+    assert rot <= POSE_TOL_DEV[0] and trans <= POSE_TOL_DEV[1], (rot, trans)
+    reg.useSaliency(False)
+    assert list(reg.eval(1, M, 2)["n_split"]) == list(full["n_split"])
+
+
+@pytest.mark.gpu
 def test_rig_full_size_sensors_and_float_depth(hip_lib, oracle_mod):
     """The rig's real geometry: eight 320x240 sensors, 4 levels, a 5 cm / 2 degree motion; float32 depth images give the same pose
     as the millimetre ones they were converted from."""
