@@ -1239,18 +1239,17 @@ __global__ __launch_bounds__(kAggThreads) void k_f360_finish_count(const uint8_t
     };
     const int base = blockIdx.x * kAggThreads * kCntPerThread;
     const bool lane0 = (threadIdx.x & 63) == 0;
-    // three batched rounds of loads (flags, labels, the run starts' labels) instead of a dependent triple per pixel
+    // two batched rounds of loads (flags and labels together -- a label is read whether or not its flag says it means anything -- then the
+    // run starts' labels) instead of a dependent triple per pixel
     int fl[kCntPerThread], lab[kCntPerThread];
 #pragma unroll
     for (int j = 0; j < kCntPerThread; ++j) {
         const int i = base + j * kAggThreads + (int)threadIdx.x;
         fl[j] = i < n ? flags[i] : 0;
+        lab[j] = label[i < n ? i : n - 1];
     }
 #pragma unroll
-    for (int j = 0; j < kCntPerThread; ++j) {
-        const int i = base + j * kAggThreads + (int)threadIdx.x;
-        lab[j] = (fl[j] & 1) ? label[i] : -1;
-    }
+    for (int j = 0; j < kCntPerThread; ++j) lab[j] = (fl[j] & 1) ? lab[j] : -1;
 #pragma unroll
     for (int j = 0; j < kCntPerThread; ++j)
         if ((fl[j] & 3) == 3) lab[j] = label[lab[j]];      // not a run start: its label is its run start, whose label is the root by now
