@@ -2144,9 +2144,12 @@ __global__ __launch_bounds__(kHullDirs) void k_f360_hull_merge(const int* __rest
         __syncthreads();
     }
 }
+// host_tag != nullptr: this is the last kernel of a plane call -- the block that finishes last (device ticket) stores host_seq into the pinned
+// word the host spins on (host_wait.h), behind everybody's records: no tag launch behind it (4 us of the stream's time).
 __global__ __launch_bounds__(kHullDirs) void k_f360_hull_pack(const float* __restrict__ xyz, const SlotFrame* __restrict__ frames,
                                                                const unsigned long long* __restrict__ ext, const int* __restrict__ n_slots,
-                                                               int max_slots, F360HullRecord* __restrict__ out) {
+                                                               int max_slots, F360HullRecord* __restrict__ out, unsigned* __restrict__ ticket,
+                                                               unsigned* host_tag, unsigned host_seq) {
     static_assert(kHullMergeSplit % kHullPhases == 0, "the merge blocks of a slot pair up with the direction sets");
     const int k = threadIdx.x;
     const int ns = min(*n_slots, max_slots);
@@ -2199,6 +2202,15 @@ __global__ __launch_bounds__(kHullDirs) void k_f360_hull_pack(const float* __res
         }
         if (k == 0) out[slot].n = total;
         __syncthreads();
+    }
+    if (host_tag) {                                             // uniform
+        __threadfence_system();                                 // this thread's records (pinned host memory) before the ticket
+        __syncthreads();
+        if (k == 0 && __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // for the next call
+            __threadfence_system();
+            __hip_atomic_store(host_tag, host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 

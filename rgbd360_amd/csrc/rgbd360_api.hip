@@ -101,6 +101,7 @@ struct rgbd360_ctx {
     int f_col_rows = 0, f_col_cols = 0;                           // size of the registered image
     unsigned long long *f_col = nullptr, *f_col_host = nullptr;   // [kF360MaxSlots][kColWords]: device table, pinned copy of the rows in use
     bool f_col_ran = false;                                       // the last plane call filled f_col_host
+    unsigned* f_ticket = nullptr;                                 // device counter of k_f360_hull_pack's blocks (the last one publishes the host tag)
     unsigned long long* b_sum = nullptr;                          // bilateral grid: fixed-point sums, counts, two float2 ping-pong arrays
     int* b_cnt = nullptr;
     float2 *b_a = nullptr, *b_b = nullptr;
@@ -742,7 +743,7 @@ void rgbd360_destroy(rgbd360_ctx* ctx) {
     hipFree(ctx->f_frames); hipFree(ctx->f_ext); hipFree(ctx->f_hull_keys); hipFree(ctx->f_hull_vals);
     hipFree(ctx->f_xyz); hipFree(ctx->f_normals); hipFree(ctx->f_dist);
     hipFree(ctx->f_change); hipFree(ctx->f_hd); hipFree(ctx->f_label); hipFree(ctx->f_count); hipFree(ctx->f_slot_of_root);
-    hipFree(ctx->f_root_of_slot); hipFree(ctx->f_nslots); hipFree(ctx->f_window); hipFree(ctx->f_mom);
+    hipFree(ctx->f_root_of_slot); hipFree(ctx->f_nslots); hipFree(ctx->f_window); hipFree(ctx->f_mom); hipFree(ctx->f_ticket);
     hipFree(ctx->f_count_of_slot); hipFree(ctx->f_depth_raw); hipFree(ctx->f_pack);
     if (ctx->f_pack_host) hipHostFree(ctx->f_pack_host);
     hipFree(ctx->f_col_owned); hipFree(ctx->f_col);
@@ -1875,6 +1876,10 @@ int f360_ensure(rgbd360_ctx* ctx, size_t n) {
     HIPC(ctx, hipMalloc(&ctx->f_window, n * sizeof(int)));
     HIPC(ctx, hipMalloc(&ctx->f_root_of_slot, kF360MaxSlots * sizeof(int)));
     HIPC(ctx, hipMalloc(&ctx->f_nslots, sizeof(int)));
+    if (!ctx->f_ticket) {
+        HIPC(ctx, hipMalloc(&ctx->f_ticket, sizeof(unsigned)));
+        HIPC(ctx, hipMemset(ctx->f_ticket, 0, sizeof(unsigned)));
+    }
     HIPC(ctx, hipMalloc(&ctx->f_mom, (size_t)f360::kMomReplicas * kF360MaxSlots * 9 * sizeof(unsigned long long)));
     HIPC(ctx, hipMalloc(&ctx->f_count_of_slot, kF360MaxSlots * sizeof(int)));
     // pinned: header, one moment record per slot, one hull record per slot behind them
@@ -2112,7 +2117,12 @@ const f360::F360HullRecord* hull_records(const rgbd360_ctx* ctx) {
     return reinterpret_cast<const f360::F360HullRecord*>(ctx->f_pack_host + f360::kF360PackHeader + (size_t)kF360MaxSlots * sizeof(f360::F360SlotRecord));
 }
 // the extremes of the CURRENT labels (ctx->f_label) against the frames of the slots, packed for the host; enqueued on the stream
-void launch_hull(rgbd360_ctx* ctx, int rows, int cols, bool clear_first) {
+// tag_behind: the pack kernel is the call's last one and publishes the host tag itself (the caller then waits with hostwait::wait, not tag_and_wait)
+bool colour_can_run(const rgbd360_ctx* ctx, int rows, int cols) {
+    const f360::ColourImage& im = ctx->f_col_img;
+    return im.rgb && im.sub >= 1 && ctx->f_col_rows / im.sub == rows && ctx->f_col_cols / im.sub == cols;
+}
+void launch_hull(rgbd360_ctx* ctx, int rows, int cols, bool clear_first, bool tag_behind = false) {
     using namespace f360;
     const int n = rows * cols;
     if (clear_first) hipLaunchKernelGGL(k_f360_hull_clear, dim3((kF360MaxSlots * kHullPhases * kHullDirs + 255) / 256), dim3(256), 0, ctx->stream, ctx->f_nslots, kF360MaxSlots, ctx->f_ext);
@@ -2131,7 +2141,7 @@ void launch_hull(rgbd360_ctx* ctx, int rows, int cols, bool clear_first) {
     hipLaunchKernelGGL(k_f360_hull_merge, dim3(64, kHullMergeSplit), dim3(kHullDirs), 0, ctx->stream, ctx->f_nslots, kF360MaxSlots, ctx->f_hull_keys, ctx->f_hull_vals,
                        nblk, ctx->f_ext);
     hipLaunchKernelGGL(k_f360_hull_pack, dim3(256), dim3(kHullDirs), 0, ctx->stream, ctx->f_xyz, ctx->f_frames, ctx->f_ext, ctx->f_nslots, kF360MaxSlots,
-                       const_cast<F360HullRecord*>(hull_records(ctx)));
+                       const_cast<F360HullRecord*>(hull_records(ctx)), ctx->f_ticket, tag_behind ? ctx->tag.h : nullptr, tag_behind ? ++ctx->tag.seq : 0u);
 }
 
 // eigenpairs of a symmetric 3x3 in ascending order (cyclic Jacobi, float64) -- pcl::eigen33's role for the smallest one
@@ -2273,10 +2283,13 @@ int f360_refine_dev(rgbd360_ctx* ctx, int rows, int cols, int nslots, std::vecto
                        ctx->f_root_of_slot, ctx->f_count_of_slot, ctx->f_pack_host);
     // the contour PCL hands to calcConvexHull is that of the REFINED region, projected with the plane `segment` fitted: extremes of the
     // committed labels against the frames k_f360_slot_frames left before the refinement
-    launch_hull(ctx, rows, cols, /*clear_first=*/true);
-    launch_colour(ctx, rows, cols);          // the colour of the REFINED inlier sets (Frame360.h:1045-1046 run on the refined regions)
+    const bool pack_tags = !colour_can_run(ctx, rows, cols);       // the hull's pack kernel is the last one: it publishes the host tag itself
+    launch_hull(ctx, rows, cols, /*clear_first=*/true, pack_tags);
+    if (!pack_tags) launch_colour(ctx, rows, cols);          // the colour of the REFINED inlier sets (Frame360.h:1045-1046 run on the refined regions)
+    else ctx->f_col_ran = false;
     HIPC(ctx, hipGetLastError());
-    HIPC(ctx, hostwait::tag_and_wait(ctx->tag, ctx->stream));      // (a tag kernel + host spin: ~10 us less than hipStreamSynchronize, host_wait.h)
+    if (pack_tags) HIPC(ctx, hostwait::wait(ctx->tag, ctx->stream));
+    else HIPC(ctx, hostwait::tag_and_wait(ctx->tag, ctx->stream));      // (a tag kernel + host spin: ~10 us less than hipStreamSynchronize, host_wait.h)
     ctx->f_refine_changed = ctx->f_flags_host[kFlags];
     ctx->f_refine_sweeps = sweeps;
     // count and the extent descriptors of the grown inlier sets (Frame360.h:1010-1037 derives them from the refined inlier cloud);
@@ -2377,12 +2390,15 @@ int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float
     hipLaunchKernelGGL(k_f360_slot_frames, dim3(256), dim3(64), 0, ctx->stream, ctx->f_mom, ctx->f_nslots, kF360MaxSlots,
                        ctx->f_count_of_slot, ctx->f_frames, ctx->f_ext, ctx->f_root_of_slot, ctx->f_pack_host);
     ctx->f_col_ran = false;
+    bool pack_tags = false;
     if (!ctx->f_refine) {
-        launch_hull(ctx, rows, cols, /*clear_first=*/false);
-        launch_colour(ctx, rows, cols);
+        pack_tags = !colour_can_run(ctx, rows, cols);               // the hull's pack kernel is the last one: it publishes the host tag itself
+        launch_hull(ctx, rows, cols, /*clear_first=*/false, pack_tags);
+        if (!pack_tags) launch_colour(ctx, rows, cols);
     }
     HIPC(ctx, hipGetLastError());
-    HIPC(ctx, hostwait::tag_and_wait(ctx->tag, ctx->stream));      // (a tag kernel + host spin: ~10 us less than hipStreamSynchronize, host_wait.h)
+    if (pack_tags) HIPC(ctx, hostwait::wait(ctx->tag, ctx->stream));
+    else HIPC(ctx, hostwait::tag_and_wait(ctx->tag, ctx->stream));      // (a tag kernel + host spin: ~10 us less than hipStreamSynchronize, host_wait.h)
     const int nslots = *reinterpret_cast<const volatile int*>(ctx->f_pack_host);
     if (nslots > kF360MaxSlots) return fail(ctx, -7, "more than 4096 regions exceed min_inliers");
     const F360SlotRecord* recs = reinterpret_cast<const F360SlotRecord*>(ctx->f_pack_host + kF360PackHeader);
