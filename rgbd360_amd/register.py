@@ -172,8 +172,12 @@ class RegisterPhotoICP:
 
     # ---- alignment (RPI.h:4519-4784)
     def alignFrames360(self, pose_guess=None, method: int = 0, occlusion: int = 0):
-        self.alignFrames360_begin(pose_guess, method, occlusion)
-        return self.alignFrames360_finish()
+        # rgbd360_align360 itself (not begin + finish): one alignment at a time on this context, which lets its small pyramid levels run as
+        # resident launches (k_coarse_persist)
+        g = pose_to_cm(np.eye(4) if pose_guess is None else pose_guess)
+        out = np.zeros(16, dtype=np.float32)
+        rc = self._L.rgbd360_align360(self._ctx(), _ptr(g), int(method), int(occlusion), _ptr(out), C.byref(self._res))
+        return self._take_result(rc, out)
 
     def alignFrames360_begin(self, pose_guess=None, method: int = 0, occlusion: int = 0):
         """Enqueue the alignment and return at once (several contexts can then be in flight on one GPU)."""
@@ -183,6 +187,9 @@ class RegisterPhotoICP:
     def alignFrames360_finish(self):
         out = np.zeros(16, dtype=np.float32)
         rc = self._L.rgbd360_align360_finish(self._ctx(), _ptr(out), C.byref(self._res))
+        return self._take_result(rc, out)
+
+    def _take_result(self, rc, out):
         self._check(rc, allow=(0, 1, 2))
         self.status = rc
         self._pose = pose_from_cm(out)

@@ -1206,6 +1206,30 @@ def test_hip_pinhole_matches_golden_fixture(hip_lib, method):
     assert np.abs(e["H64"] - np.array(g["H64"])).max() <= HG_RTOL * np.abs(np.array(g["H64"])).max()
 
 
+def test_resident_coarse_levels_are_bit_identical(hip_lib, monkeypatch):
+    """RGBD360_PERSIST_COARSE=1: the pyramid levels of at most 32 blocks run as ONE resident launch each (k_coarse_persist: the blocks loop
+    {solve, pass} themselves and hand the partial rows round as generation-tagged elements).  Same work split, row sums and solve as the
+    launch-per-iteration schedule: pose, iteration counts, Hessian and status bit for bit -- and the launches did run resident."""
+    import ctypes as C
+    for (W, H, n_pyr, method, seed) in [(2048, 1024, 4, 2, 1234), (512, 256, 5, 0, 7), (640, 320, 4, 1, 11), (256, 128, 3, 2, 3)]:
+        (rgbA, dA), (rgbB, dB), T = synth.make_pair(W, H, seed=seed)
+        out = []
+        for persist in ("1", "0"):
+            monkeypatch.setenv("RGBD360_PERSIST_COARSE", persist)
+            reg = _mk(hip_lib, n_pyr)
+            reg.setTargetFrame(rgbA, dA); reg.setSourceFrame(rgbB, dB)
+            rc = reg.alignFrames360(np.eye(4), method)
+            w = np.zeros(128, np.uint64)
+            assert reg._L.rgbd360_debug_persist(reg._ctx(), w.ctypes.data_as(C.c_void_p)) == 0
+            out.append((rc, reg.getOptimalPose().copy(), list(reg.num_iterations), reg.getHessian().copy(), int(w[0]), int(w[1])))
+            reg.close()
+        a, b = out
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and a[2] == b[2] and np.array_equal(a[3], b[3]), (W, H, n_pyr, a[2], b[2])
+        assert a[4] == 0 and (a[5] & 1) == 0 and (a[5] >> 8) != 0          # nobody gave up, no fall-back, and at least one level ran resident
+        assert b[5] == 0                                                   # the default schedule has no resident launch
+    monkeypatch.delenv("RGBD360_PERSIST_COARSE", raising=False)
+
+
 # ---- pinhole occlusion-aware passes + salient-pixel list (RPI.h:1107-2030, 401-425, 590-690) ---------------------------------
 def _pinhole_probe_pose(T):
     back = np.eye(4)
