@@ -446,12 +446,16 @@ bool persist_level_ok(const rgbd360_ctx* ctx, int level, int occ) {
            L.chunk == kEvalThreads && L.n < recompute_min_px();
 }
 int launch_level_persist(rgbd360_ctx* ctx, int level, int method, const float* init_pose) {
-    if (!ctx->d_rows_tagged) {
+    if (!ctx->d_rows_tagged || !ctx->d_persist_bail) {
         const size_t bytes = (size_t)2 * kPersistMaxBlocks * kNumPartials * sizeof(RowElem);
-        HIPC(ctx, hipMalloc(&ctx->d_rows_tagged, bytes));
-        HIPC(ctx, hipMemset(ctx->d_rows_tagged, 0, bytes));
-        HIPC(ctx, hipMalloc(&ctx->d_persist_bail, 1024));          // the give-up code + (diagnostic builds) per-trip clocks of block 0
-        HIPC(ctx, hipMemset(ctx->d_persist_bail, 0, 1024));
+        if (!ctx->d_rows_tagged) {
+            HIPC(ctx, hipMalloc(&ctx->d_rows_tagged, bytes));
+            HIPC(ctx, hipMemset(ctx->d_rows_tagged, 0, bytes));
+        }
+        if (!ctx->d_persist_bail) {
+            HIPC(ctx, hipMalloc(&ctx->d_persist_bail, 1024));      // the give-up code + (diagnostic builds) per-trip clocks of block 0
+            HIPC(ctx, hipMemset(ctx->d_persist_bail, 0, 1024));
+        }
     }
     FsInit init;
     init.on = init_pose ? 1 : 0;
@@ -882,9 +886,11 @@ static void enqueue_schedule(rgbd360_ctx* ctx, int pending, bool pending_started
             if (start) ctx->pend_zero = true;      // the schedule starts here: nothing is pending by definition
             if (level > 0 && persist_level_ok(ctx, level, ctx->al_occ)) {
                 // the whole level in one resident launch, hand-over to the next finer level included
-                launch_level_persist(ctx, level, ctx->al_method, start ? ctx->al_guess : nullptr);
-                ctx->al_persist_levels |= 1u << level;
-                continue;
+                if (launch_level_persist(ctx, level, ctx->al_method, start ? ctx->al_guess : nullptr) == 0) {
+                    ctx->al_persist_levels |= 1u << level;
+                    continue;
+                }
+                ctx->persist_failed = true;      // (its buffers could not be allocated: the level runs as launches per iteration, below)
             }
         }
         if (fused) {
