@@ -1617,7 +1617,8 @@ constexpr int kPersistSpinCap = 1 << 16;          // polls of ~1 us
 template <int METHOD>
 __global__ __launch_bounds__(kEvalThreads) void k_coarse_persist(const GNState* __restrict__ st_in, GNState* __restrict__ st_out, RowElem* __restrict__ rows,
                                                                   unsigned long long gen0, const float4* __restrict__ src0, int n_px, int chunk, int level,
-                                                                  int nb, LevelDev lv, EvalConsts ec, SolveCfg cfg, FsInit init, int* __restrict__ bail) {
+                                                                  int nb, LevelDev lv, EvalConsts ec, SolveCfg cfg, FsInit init, int* __restrict__ bail,
+                                                                  int test_quit_block) {
     unsigned long long es[6] = {0, 0, 0, 0, 0, 0};
     const unsigned long long es0 = 0;
     __shared__ SolveShared sh;
@@ -1666,6 +1667,7 @@ __global__ __launch_bounds__(kEvalThreads) void k_coarse_persist(const GNState* 
         const typename SrcForm<0>::T sB = SrcForm<0>::load(lv, src0, n_px, base + kEvalThreads, (unsigned)tid << 4, cur);
         int pend = 0;
         PSTAMP(0);
+        if (trip == 1 && b == test_quit_block) return;      // (tests only: a block that is "not running" -- the others must give up and recover)
         if (trip > 0) {
             // the rows of the previous trip's pass (generation gen0 + trip, buffer (trip - 1) & 1): thread group q sums row q -- stage_pending's
             // order for <= 32 rows (one row per group) -- polling until the row's elements carry the generation

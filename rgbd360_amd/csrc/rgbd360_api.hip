@@ -78,6 +78,7 @@ struct rgbd360_ctx {
     unsigned al_persist_levels = 0;            // levels of the running alignment that were enqueued as persistent launches
     unsigned long long persist_gen = 1;        // generation of the next persistent launch's first pass (0 = the buffer's initial state: never matches)
     int* d_persist_bail = nullptr;
+    int persist_test_quit = -1;                // RGBD360_PERSIST_TEST_QUIT=<block>: that block leaves a resident launch after its first pass (tests of the recovery)
     bool pend_zero = false;                    // the host KNOWS the state at the stream's tail has nothing pending (start of a schedule / behind a persistent launch)
     GnIO* d_gnio = nullptr;
     // upload staging: slot 0 serves the single-frame entries (copies on `stream`); the sequence entry alternates both slots,
@@ -468,7 +469,7 @@ int launch_level_persist(rgbd360_ctx* ctx, int level, int method, const float* i
     const SolveCfg cfg = fused_cfg(ctx, 0);
     const dim3 g(L.nblocks), b(kEvalThreads);
 #define LAUNCHP(M) hipLaunchKernelGGL((k_coarse_persist<M>), g, b, 0, ctx->stream, (const GNState*)ctx->d_state, ctx->d_state_alt, ctx->d_rows_tagged, \
-                                      ctx->persist_gen, lv.src, lv.n, L.chunk, level, L.nblocks, lv, ec, cfg, init, ctx->d_persist_bail)
+                                      ctx->persist_gen, lv.src, lv.n, L.chunk, level, L.nblocks, lv, ec, cfg, init, ctx->d_persist_bail, ctx->persist_test_quit)
     if (method == 0) LAUNCHP(0);
     else if (method == 1) LAUNCHP(1);
     else LAUNCHP(2);
@@ -761,6 +762,9 @@ int rgbd360_create(const rgbd360_params* p, rgbd360_ctx** out) {
     }
     if (const char* e = getenv("RGBD360_PERSIST_COARSE")) {
         ctx->persist_coarse = atoi(e) != 0;
+    }
+    if (const char* e = getenv("RGBD360_PERSIST_TEST_QUIT")) {
+        ctx->persist_test_quit = atoi(e);
     }
     if (const char* e = getenv("RGBD360_ARENA")) {
         ctx->use_arena = atoi(e) != 0;

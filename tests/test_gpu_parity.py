@@ -1230,6 +1230,32 @@ def test_resident_coarse_levels_are_bit_identical(hip_lib, monkeypatch):
     monkeypatch.delenv("RGBD360_PERSIST_COARSE", raising=False)
 
 
+def test_resident_launch_recovers_when_a_block_is_missing(hip_lib, monkeypatch):
+    """The resident launch's blocks wait for each other's rows with BOUNDED polls: a block that never delivers (here: made to leave after
+    its first pass; in the field: not resident because another context's grid holds the CUs) makes the others give up, block 0 writes the
+    last solved state with nothing pending, and the host's stall recovery continues the level with a launch per iteration -- same pose,
+    same iteration counts as the default schedule; the context then stays on the default schedule."""
+    import ctypes as C
+    (rgbA, dA), (rgbB, dB), T = synth.make_pair(512, 256, seed=21)
+    ref = _mk(hip_lib, 3)
+    ref.setTargetFrame(rgbA, dA); ref.setSourceFrame(rgbB, dB)
+    rc0 = ref.alignFrames360(np.eye(4), 2)
+    monkeypatch.setenv("RGBD360_PERSIST_COARSE", "1")
+    monkeypatch.setenv("RGBD360_PERSIST_TEST_QUIT", "3")
+    reg = _mk(hip_lib, 3)
+    reg.setTargetFrame(rgbA, dA); reg.setSourceFrame(rgbB, dB)
+    rc = reg.alignFrames360(np.eye(4), 2)
+    w = np.zeros(128, np.uint64)
+    assert reg._L.rgbd360_debug_persist(reg._ctx(), w.ctypes.data_as(C.c_void_p)) == 0
+    assert int(w[0]) == 1 and (int(w[1]) & 1) == 1                      # a block gave up waiting; the context has fallen back
+    assert rc == rc0 and np.array_equal(reg.getOptimalPose(), ref.getOptimalPose()) and reg.num_iterations == ref.num_iterations
+    rc = reg.alignFrames360(np.eye(4), 2)                               # the next alignment: no resident launch any more
+    assert reg._L.rgbd360_debug_persist(reg._ctx(), w.ctypes.data_as(C.c_void_p)) == 0
+    assert (int(w[1]) >> 8) == 0 and np.array_equal(reg.getOptimalPose(), ref.getOptimalPose())
+    monkeypatch.delenv("RGBD360_PERSIST_COARSE", raising=False)
+    monkeypatch.delenv("RGBD360_PERSIST_TEST_QUIT", raising=False)
+
+
 # ---- pinhole occlusion-aware passes + salient-pixel list (RPI.h:1107-2030, 401-425, 590-690) ---------------------------------
 def _pinhole_probe_pose(T):
     back = np.eye(4)
