@@ -71,6 +71,43 @@ SEQ_UNIQUE_FRAMES = 9          # frames rendered per rank for the sequence block
 SEQ_INFLIGHT = 32              # pairs in flight per GPU: slots of the lock-step sequence engine (2 engines x 16)
 
 
+def live_traffic(W, H, method):
+    """roofline.traffic of THIS run: fabric-side bytes per launch of the dominant kernel from two rocprofv3 PMC passes (FETCH_SIZE and
+    WRITE_SIZE, each in its own child process with nothing but --pmc, as /opt/skills/guides/MI355X_MICROARCH.md prescribes) over
+    tools/prof_eval.py, which launches the same kernel on the same synthetic pair; bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB, the guide's
+    gfx950 correction for 16 B / lane streams.  Returns (bytes per launch, source note), or (None, None) when rocprofv3 is unavailable,
+    the passes fail, or bench.py itself runs under a profiler."""
+    import csv, glob, shutil, subprocess, tempfile
+    if "rocprofiler" in os.environ.get("LD_PRELOAD", "") or shutil.which("rocprofv3") is None:
+        return None, None
+    want = "k_eval_fs<%d" % method if os.environ.get("RGBD360_FUSED_SOLVE", "1") != "0" else "k_eval<%d" % method
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="rgbd360_pmc_", dir="/tmp")
+        try:
+            env = dict(os.environ, TMPDIR="/tmp")
+            subprocess.run(["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable,
+                            os.path.join(ROOT, "tools", "prof_eval.py"), str(W), str(H), "6"],
+                           cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180, check=True)
+            v = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r.get("Counter_Name") == counter and want in r.get("Kernel_Name", ""):
+                        v.append(float(r["Counter_Value"]))
+            if not v:
+                return None, None
+            vals[counter] = sum(v) / len(v)
+        except Exception:
+            return None, None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    nbytes = int(round((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0))
+    note = ("collected in THIS run: two rocprofv3 --pmc passes (FETCH_SIZE %.1f KB, WRITE_SIZE %.1f KB per launch of %s>, each counter in its own child "
+            "process over tools/prof_eval.py on the same synthetic pair); bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, the gfx950 correction of "
+            "MI355X_MICROARCH.md for 16 B / lane streams (the 12-byte gathers are an uncalibrated width: +-10 %%)" % (vals["FETCH_SIZE"], vals["WRITE_SIZE"], want))
+    return nbytes, note
+
+
 def avg_kernel_us(fn, batches=5):
     """Median of `batches` averages (each over back-to-back launches between two HIP events on the library's stream), so
     that one disturbed batch (another process touching the device) cannot skew it; all batches are reported."""
@@ -120,6 +157,8 @@ def main():
     ap.add_argument("--no-rotating", action="store_true", help="skip the HBM-fed (rotating) kernel measurement, e.g. under rocprofv3 "
                     "--stats, whose per-kernel average would otherwise mix both regimes")
     ap.add_argument("--no-native-multi", action="store_true", help="skip the single-process multi-GPU entry (child process)")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not collect roofline.traffic with rocprofv3 PMC passes in child "
+                    "processes (then the tracked profiles/traffic_latest.json is quoted); implied when bench.py itself runs under rocprofv3")
     ap.add_argument("--seq-pairs", type=int, default=256, help="pairs of the configs[3] sequence (whole job)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -297,8 +336,10 @@ def main():
         kernel_us, kernel_batches = avg_kernel_us(lambda: reg.time_eval_kernel(0, pose_gpu, method, True, 50))       # the pass alone
         fused_us, fused_batches = (avg_kernel_us(lambda: reg.time_eval_kernel(0, pose_gpu, method, 2, 50)) if fused else (None, None))
         traffic, traffic_source = None, None
+        if not args.no_live_traffic:
+            traffic, traffic_source = live_traffic(W, H, method)
         tr_path = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tr_path):
+        if traffic is None and os.path.exists(tr_path):
             try:
                 tr = json.load(open(tr_path))
                 key = "%dx%d_%s" % (W, H, METHOD_NAMES[method])

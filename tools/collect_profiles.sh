@@ -8,7 +8,7 @@ mkdir -p $OUT
 cd $R
 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-4k --no-native-multi --no-rotating --no-sequence > $OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-4k --no-native-multi --no-rotating --no-sequence --no-live-traffic > $OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/tools/prof_eval.py 2048 1024 10 > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/tools/prof_eval.py 2048 1024 10 > $OUT/pmc_write.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_sq -- python3 $R/tools/prof_eval.py 2048 1024 10 > $OUT/pmc_sq.log 2>&1
