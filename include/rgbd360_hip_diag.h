@@ -36,11 +36,6 @@ int rgbd360_forced_iters_batch(rgbd360_ctx* ctx, int n_pairs, const uint8_t* rgb
  * out_i: {status, done, level_active, it, n_evals, pend_nb}; cand_out / update_out (may be NULL): the state's candidate pose / update. */
 int rgbd360_debug_solve_partials(rgbd360_ctx* ctx, int level, const double row[32], int method, int fused, int out_i[6],
                                  float cand_out[16], float update_out[6]);
-/* The resident coarse-level launches (k_coarse_persist) of this context: words[0] = why the last one that gave up did (0: none did; 1: a
- * block waited for rows that never came -- the grid was not co-resident; 2: called behind a pending pass; 3: the trip backstop), words[1]
- * bit 0 = the context has fallen back to a launch per iteration for good, bits 8.. = the pyramid levels of its last alignment that ran resident; words[2 ...]: per-trip clocks of block 0 in builds with
- * RGBD360_PERSIST_STAMPS (100 MHz ticks since the kernel's start: 8 per trip -- trip start, rows polled, rows summed, -, solve decided, pass done). */
-int rgbd360_debug_persist(rgbd360_ctx* ctx, unsigned long long words[128]);
 /* Average duration in microseconds of `reps` back-to-back launches of the fused per-pixel kernel alone
  * (HIP events on the stream the kernel is launched on). want_hg = 0 times the error-only variant, want_hg = 2 the launch of the
  * single-pair product schedule: k_eval_fs in the forced schedule, i.e. {solve of the previous pass, pass} = one whole Gauss-Newton

@@ -22,7 +22,7 @@ SYMBOLS = [
     "rgbd360_shard_range", "rgbd360_gather_slot", "rgbd360_multi_align_sequence", "rgbd360_multi_load_sequence", "rgbd360_multi_align_resident",
     "rgbd360_align360_batch_multi", "rgbd360_time_eval_kernel_rotating", "rgbd360_forced_iters_batch",
     "rgbd360_rig_create", "rgbd360_rig_destroy", "rgbd360_rig_last_error", "rgbd360_rig_set_target", "rgbd360_rig_set_source",
-    "rgbd360_rig_eval", "rgbd360_rig_align", "rgbd360_rig_use_saliency", "rgbd360_debug_solve_partials", "rgbd360_debug_persist",
+    "rgbd360_rig_eval", "rgbd360_rig_align", "rgbd360_rig_use_saliency", "rgbd360_debug_solve_partials",
 ]
 
 
@@ -146,7 +146,6 @@ def load() -> C.CDLL:
     L.rgbd360_rig_eval.argtypes = [vp, i32, f32p, i32, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_longlong)]
     L.rgbd360_rig_align.argtypes = [vp, f32p, i32, f32p, C.POINTER(Result)]
     L.rgbd360_rig_use_saliency.argtypes = [vp, i32, C.c_float]
-    L.rgbd360_debug_persist.argtypes = [vp, vp]
     L.rgbd360_time_eval_kernel_rotating.argtypes = [vp, i32, i32, f32p, i32, i32, i32, C.POINTER(C.c_float)]
     L.rgbd360_multi_create.argtypes = [C.POINTER(Params), i32, vp, C.POINTER(vp)]
     L.rgbd360_multi_destroy.argtypes = [vp]

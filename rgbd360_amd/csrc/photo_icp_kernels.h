@@ -592,35 +592,13 @@ __device__ __forceinline__ void consume_stage(PixW& w, const LevelDev& lv, const
 #else
 #define ESTAMP(i)
 #endif
-// A partial-row value that travels between the blocks of ONE running kernel (k_coarse_persist): value and generation in one 16-byte
-// device-coherent store / load (one request to one L2 channel: a reader never sees a value without its generation), so the reader of a
-// row polls the row itself -- no counter barrier, no wait for the writer's acknowledgement (tools/ubench/grid_exchange.hip: 1.3 us per
-// exchange among 32 blocks, against 2.1 us with a counter).
-struct alignas(16) RowElem {
-    double v;
-    unsigned long long gen;
-};
-typedef unsigned row_u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void store_row_elem(RowElem* p, double v, unsigned long long gen) {
-    RowElem e;
-    e.v = v; e.gen = gen;
-    const row_u32x4 r = __builtin_bit_cast(row_u32x4, e);
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(r) : "memory");
-}
-__device__ __forceinline__ RowElem load_row_elem(const RowElem* p) {
-    row_u32x4 r;
-    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory");
-    return __builtin_bit_cast(RowElem, r);
-}
-
 // Everything behind the gate: the software-pipelined pixel loop and the block reduction.  On entry the first warp stage (wA, the
 // pixel at i) has been issued and sB holds the source record of the pixel at i + THREADS.
 template <int METHOD, bool HG, int THREADS, int SRC = 0>
 __device__ __forceinline__ void eval_span(const PoseRT& T, const WarpConsts& wc, const LevelDev& lv, const EvalConsts& ec,
                                           const EvalBufs& bufs, const float4* __restrict__ src0, const int n_px, const int base, const int end,
                                           const int b, const int nb, PixW& wA, typename SrcForm<SRC>::T sB, SrcCursor cur, double* __restrict__ partials,
-                                          unsigned long long* es, const unsigned long long es0, RowElem* tagged = nullptr,
-                                          const unsigned long long tag_gen = 0ull) {
+                                          unsigned long long* es, const unsigned long long es0) {
     constexpr int NS = kEvalThreads / THREADS;           // accumulator sets (lanes of the 1024-lane layout per thread)
     EvalAcc A[NS];
 #pragma unroll
@@ -731,8 +709,7 @@ __device__ __forceinline__ void eval_span(const PoseRT& T, const WarpConsts& wc,
         double v = 0.0;
 #pragma unroll
         for (int w = 0; w < kEvalThreads / 64; ++w) v += red[w][threadIdx.x];
-        if (tagged) store_row_elem(&tagged[(size_t)b * kNumPartials + threadIdx.x], v, tag_gen);      // (the persistent coarse-level kernel: value + generation in one 16-byte store)
-        else partials[(size_t)b * kNumPartials + threadIdx.x] = v;
+        partials[(size_t)b * kNumPartials + threadIdx.x] = v;
     }
 #ifdef RGBD360_EVAL_STAMPS
     ESTAMP(4);
@@ -1457,9 +1434,8 @@ __device__ __forceinline__ float uniform_f(float v) {
 // own LDS copy of the state, decides what the new state is, hands every wave the pose the new state's `cand` holds (scalar registers)
 // and lets block 0 write the new state (pend_nb = nb if the launch's own pass runs).  Returns whether the launch's level is the active,
 // unfinished one.  Shared by k_eval_fs and the occlusion-aware schedule's k_occ_build_fs (occlusion_kernels.h).
-// In two halves, so that a caller may put work between them (k_coarse_persist runs its pass first and lets wave 2 write the state while
-// the other waves already wait for the next rows): fs_solve_decide -- the solve and what it means, by every wave -- and fs_write_state --
-// the rank verdict and the new state, by ONE wave (nothing the first half left in LDS may have been overwritten in between).
+// In two halves: fs_solve_decide -- the solve and what it means, by every wave -- and fs_write_state -- the rank verdict and the new
+// state, by ONE wave (nothing the first half left in LDS may have been overwritten in between).
 struct FsDecision {
     bool run, commit, ill, handover;
     int level_now;
@@ -1597,138 +1573,6 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_fs(const GNState* __restr
     warp_stage<METHOD, true, SRC>(sA, i < end, T, wc, lv, bufs, wA);
     ESTAMP(1);
     eval_span<METHOD, true, kEvalThreads, SRC>(T, wc, lv, ec, bufs, src0, n_px, base, end, b, nb, wA, sB, cur, partials_out, es, es0);
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// A whole pyramid level in ONE launch (round 4): the small levels of the pyramid -- at most kPersistMaxBlocks blocks
-// of one 1024-pixel step each -- spend 7.7 us per Gauss-Newton iteration as k_eval_fs launches, of which 1.3 us are the launch boundary
-// and 1.2 us the load of the partial rows behind it.  Here the level's blocks stay resident and loop {solve of the previous pass, pass}
-// themselves; a pass's partial rows travel as generation-tagged 16-byte elements every block polls for (RowElem above), the state lives
-// in every block's LDS (all blocks run the same solve on the same sums: same state, bit for bit, as in k_eval_fs), block 0 writes it out
-// when the level has finished -- INCLUDING the hand-over to the next finer level, so the launches behind it find nothing pending.
-// Work split, row contents, summation order and the solve are k_eval_fs's: poses, iteration counts and status are bit-identical.
-// Residency: the blocks wait for each other, so all nb <= 32 of them must be running -- true on an otherwise idle GPU and whenever 32
-// CUs are free; if they are not (another context's grid holds the CUs), the polls are BOUNDED: a block that waits kPersistSpinCap polls
-// gives up, every other block then runs into its own bound, block 0 writes the last solved state with nothing pending, and the
-// host's ordinary stall recovery (rgbd360_align360_finish) continues the level with k_eval_fs launches.
-// ---------------------------------------------------------------------------------------------------------
-constexpr int kPersistMaxBlocks = 32;
-constexpr int kPersistSpinCap = 1 << 16;          // polls of ~1 us
-template <int METHOD>
-__global__ __launch_bounds__(kEvalThreads) void k_coarse_persist(const GNState* __restrict__ st_in, GNState* __restrict__ st_out, RowElem* __restrict__ rows,
-                                                                  unsigned long long gen0, const float4* __restrict__ src0, int n_px, int chunk, int level,
-                                                                  int nb, LevelDev lv, EvalConsts ec, SolveCfg cfg, FsInit init, int* __restrict__ bail,
-                                                                  int test_quit_block) {
-    unsigned long long es[6] = {0, 0, 0, 0, 0, 0};
-    const unsigned long long es0 = 0;
-    __shared__ SolveShared sh;
-    __shared__ GNState sst_next;
-    __shared__ int gave_up;
-    constexpr int kStateWords = sizeof(GNState) / 4;
-    constexpr int Q = kSolveThreads / kNumPartials;
-    static_assert(kPersistMaxBlocks <= Q, "one row per thread group");
-    const int tid = threadIdx.x;
-    const int b = blockIdx.x;
-    if (tid < kStateWords) reinterpret_cast<int*>(&sh.sst)[tid] = reinterpret_cast<const int*>(st_in)[tid];
-    if (tid == 0) gave_up = 0;
-    __syncthreads();
-    if (init.on) {                              // uniform: the schedule starts here (what k_level_init(pose, reset_all) does)
-        if (tid == 0) level_init_one(&sh.sst, init.pose, 1, 1, level);
-        __syncthreads();
-    }
-    if (sh.sst.pend_nb != 0) {                  // uniform; 0 by the host's contract: rows in the plain format are not this kernel's to read
-        if (b == 0 && tid == 0) *bail = 2;
-        return;
-    }
-    const int cb = ((nb & 7) == 0) ? (b & 7) * (nb >> 3) + (b >> 3) : b;
-    const int base = cb * chunk;
-    const int end = min(base + chunk, n_px);
-    EvalBufs bufs;
-    bufs.src = make_rsrc(src0, (unsigned)n_px * 16u);
-    bufs.trgP = make_rsrc(lv.trgP, (unsigned)lv.n * 12u);
-    bufs.trgD = make_rsrc(lv.trgD, (unsigned)lv.n * 12u);
-    bufs.row_bytes = (unsigned)lv.cols * 12u;
-    const int i = base + tid;
-    const int v = tid % kNumPartials, q = tid / kNumPartials;
-    bool finished = false;
-    const bool state_wave = (tid >> 6) == 2;
-#ifdef RGBD360_PERSIST_STAMPS
-    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(bail) + 2;
-    const unsigned long long t00 = __builtin_amdgcn_s_memrealtime();
-#define PSTAMP(k) if (b == 0 && tid == 0 && trip < 12) dbg[trip * 8 + (k)] = __builtin_amdgcn_s_memrealtime() - t00
-#else
-#define PSTAMP(k)
-#endif
-    for (int trip = 0; trip < cfg.max_iters + 6; ++trip) {       // (the solve ends the level; the bound is a backstop)
-        // the source records of this trip's pass depend on nothing: requested before the wait for the rows
-        SrcCursor cur = {0, 0, 0, 0};
-        SrcForm<0>::cursor_init(cur, lv, i, kEvalThreads);
-        const typename SrcForm<0>::T sA = SrcForm<0>::load(lv, src0, n_px, base, (unsigned)tid << 4, cur);
-        const typename SrcForm<0>::T sB = SrcForm<0>::load(lv, src0, n_px, base + kEvalThreads, (unsigned)tid << 4, cur);
-        int pend = 0;
-        PSTAMP(0);
-        if (trip == 1 && b == test_quit_block) return;      // (tests only: a block that is "not running" -- the others must give up and recover)
-        if (trip > 0) {
-            // the rows of the previous trip's pass (generation gen0 + trip, buffer (trip - 1) & 1): thread group q sums row q -- stage_pending's
-            // order for <= 32 rows (one row per group) -- polling until the row's elements carry the generation
-            const RowElem* R = rows + (size_t)((trip - 1) & 1) * kPersistMaxBlocks * kNumPartials;
-            double sum = 0.0;
-            bool late = false;
-            if (q < nb) {
-                const unsigned long long want = gen0 + (unsigned long long)trip;
-                RowElem e = load_row_elem(&R[(size_t)q * kNumPartials + v]);
-                for (int spins = 0; e.gen != want; ++spins) {
-                    if (spins >= kPersistSpinCap) { late = true; break; }
-                    __builtin_amdgcn_s_sleep(1);
-                    e = load_row_elem(&R[(size_t)q * kNumPartials + v]);
-                }
-                sum = e.v;
-            }
-            if (late) gave_up = 1;
-            PSTAMP(1);
-            reduce_rows_to_lds(sh, sum);
-            __syncthreads();                    // rows summed; sst_next complete (wave 2 wrote it before the pass)
-            PSTAMP(2);
-            if (gave_up) {                      // uniform
-                if (tid == 0) {
-                    sst_next.pend_nb = 0;       // the pending pass is dropped: the next launch repeats it at the same pose
-                    if (b == 0) *bail = 1;
-                }
-                __syncthreads();
-                if (b == 0 && tid < kStateWords) reinterpret_cast<int*>(st_out)[tid] = reinterpret_cast<const int*>(&sst_next)[tid];
-                return;
-            }
-            if (tid < kStateWords) reinterpret_cast<int*>(&sh.sst)[tid] = reinterpret_cast<const int*>(&sst_next)[tid];
-            __syncthreads();
-            pend = sh.sst.pend_nb;              // nb, or 0 when the rank verdict stopped the level behind the pass's back
-        }
-        PoseRT T;
-        PSTAMP(3);
-        const FsDecision dec = fs_solve_decide(sh, pend, cfg, level, T);
-        PSTAMP(4);
-        if (!dec.run) {                         // uniform: the level has finished (or failed)
-            if (state_wave) fs_write_state(sh, dec, nb, lv.n, &sst_next);
-            finished = true;
-            break;
-        }
-        // the rank verdict and the new state: wave 2 joins the pass behind them (as in block 0 of k_eval_fs).  Measured the other way round
-        // -- after the pass, while the other waves already poll -- the trip got LONGER (62.4 vs 57.6 us for the level: wave 2's own polls
-        // then start a verdict late, and a poll that finds its row at once still costs a fabric round trip).
-        if (state_wave) fs_write_state(sh, dec, nb, lv.n, &sst_next);
-        const WarpConsts wc = make_warp_consts(T, lv);
-        PixW wA;
-        warp_stage<METHOD, true, 0>(sA, i < end, T, wc, lv, bufs, wA);
-        eval_span<METHOD, true, kEvalThreads, 0>(T, wc, lv, ec, bufs, src0, n_px, base, end, b, nb, wA, sB, cur, nullptr, es, es0,
-                                                 rows + (size_t)(trip & 1) * kPersistMaxBlocks * kNumPartials, gen0 + (unsigned long long)trip + 1ull);
-        PSTAMP(5);
-    }
-    __syncthreads();                            // wave 2's last state write
-    if (!finished && tid == 0) {                // the backstop fired with a pass pending in the tagged rows: dropped, like a wait that gave up
-        sst_next.pend_nb = 0;
-        if (b == 0) *bail = 3;
-    }
-    __syncthreads();
-    if (b == 0 && tid < kStateWords) reinterpret_cast<int*>(st_out)[tid] = reinterpret_cast<const int*>(&sst_next)[tid];
 }
 
 // The tail of a fused-solve schedule: the solve of the last pass enqueued (if one is pending), in place, one block; publishes

@@ -67,19 +67,6 @@ struct rgbd360_ctx {
     int max_blocks = 0;               // rows of a partial table = blocks of the largest level
     bool fused_occ = true;            // the occlusion-aware alignments on the fused schedule too (RGBD360_FUSED_OCC=0: {build, pass, k_solve} triples, A/B)
     bool fused_solve = true;          // single-pair schedule: solve in the prologue of the next pass (RGBD360_FUSED_SOLVE=0: {k_eval, k_solve} pairs, A/B)
-    // RGBD360_PERSIST_COARSE=1: pyramid levels of at most kPersistMaxBlocks blocks run as ONE resident launch that loops {solve, pass}
-    // itself (k_coarse_persist).  Built for VERDICT r3 item 6, bit-identical, and OFF by default: a resident trip takes 7.2-8.0 us against
-    // 7.7 us per k_eval_fs launch (profiles/r04_persist_coarse.txt) -- the 2.5 us of launch boundary + row loads it saves come back as
-    // 2.7 us of exchange between blocks that finish their passes at different times.  persist_ok: only while this context's alignment is
-    // begun and finished by one call (rgbd360_align360, not the multi-context batch entry); persist_failed: a launch whose blocks were
-    // not all resident gave up once -- the context stays on the per-iteration launches from then on.
-    bool persist_coarse = false, persist_ok = false, persist_failed = false;
-    RowElem* d_rows_tagged = nullptr;          // [2][kPersistMaxBlocks][32]
-    unsigned al_persist_levels = 0;            // levels of the running alignment that were enqueued as persistent launches
-    unsigned long long persist_gen = 1;        // generation of the next persistent launch's first pass (0 = the buffer's initial state: never matches)
-    int* d_persist_bail = nullptr;
-    int persist_test_quit = -1;                // RGBD360_PERSIST_TEST_QUIT=<block>: that block leaves a resident launch after its first pass (tests of the recovery)
-    bool pend_zero = false;                    // the host KNOWS the state at the stream's tail has nothing pending (start of a schedule / behind a persistent launch)
     GnIO* d_gnio = nullptr;
     // upload staging: slot 0 serves the single-frame entries (copies on `stream`); the sequence entry alternates both slots,
     // copying on `up_stream` one frame ahead of the alignment (up_ev: upload landed, conv_ev: slot consumed)
@@ -436,51 +423,9 @@ void launch_eval_fused(rgbd360_ctx* ctx, int level, int method, int forced, cons
     }
 #undef LAUNCHF
     ctx->pend_rows_hint = L.nblocks;             // what this launch can leave pending bounds what the next one has to load
-    ctx->pend_zero = false;
     std::swap(ctx->d_state, ctx->d_state_alt);
     std::swap(ctx->d_partials, ctx->d_partials_alt);
 }
-// A whole level as one resident launch (k_coarse_persist, photo_icp_kernels.h).  Only behind a state with nothing pending.
-bool persist_level_ok(const rgbd360_ctx* ctx, int level, int occ) {
-    const Level& L = ctx->levels[level];
-    return ctx->persist_coarse && ctx->persist_ok && !ctx->persist_failed && occ == 0 && ctx->pend_zero && L.nblocks <= kPersistMaxBlocks &&
-           L.chunk == kEvalThreads && L.n < recompute_min_px();
-}
-int launch_level_persist(rgbd360_ctx* ctx, int level, int method, const float* init_pose) {
-    if (!ctx->d_rows_tagged || !ctx->d_persist_bail) {
-        const size_t bytes = (size_t)2 * kPersistMaxBlocks * kNumPartials * sizeof(RowElem);
-        if (!ctx->d_rows_tagged) {
-            HIPC(ctx, hipMalloc(&ctx->d_rows_tagged, bytes));
-            HIPC(ctx, hipMemset(ctx->d_rows_tagged, 0, bytes));
-        }
-        if (!ctx->d_persist_bail) {
-            HIPC(ctx, hipMalloc(&ctx->d_persist_bail, 1024));      // the give-up code + (diagnostic builds) per-trip clocks of block 0
-            HIPC(ctx, hipMemset(ctx->d_persist_bail, 0, 1024));
-        }
-    }
-    FsInit init;
-    init.on = init_pose ? 1 : 0;
-    if (init_pose) memcpy(init.pose.v, init_pose, sizeof(init.pose.v));
-    else memset(init.pose.v, 0, sizeof(init.pose.v));
-    const Level& L = ctx->levels[level];
-    LevelDev lv = level_dev(L);
-    lv.min_depth = ctx->p.min_depth; lv.max_depth = ctx->p.max_depth;
-    const EvalConsts ec = eval_consts(ctx->p);
-    const SolveCfg cfg = fused_cfg(ctx, 0);
-    const dim3 g(L.nblocks), b(kEvalThreads);
-#define LAUNCHP(M) hipLaunchKernelGGL((k_coarse_persist<M>), g, b, 0, ctx->stream, (const GNState*)ctx->d_state, ctx->d_state_alt, ctx->d_rows_tagged, \
-                                      ctx->persist_gen, lv.src, lv.n, L.chunk, level, L.nblocks, lv, ec, cfg, init, ctx->d_persist_bail, ctx->persist_test_quit)
-    if (method == 0) LAUNCHP(0);
-    else if (method == 1) LAUNCHP(1);
-    else LAUNCHP(2);
-#undef LAUNCHP
-    ctx->persist_gen += (unsigned long long)ctx->p.max_iters + 16ull;
-    ctx->pend_rows_hint = kPendingRows;          // (nothing is pending behind it; the bound only sizes the next launch's speculative row loads)
-    std::swap(ctx->d_state, ctx->d_state_alt);
-    ctx->pend_zero = true;
-    return 0;
-}
-
 // The occlusion-aware iteration of the fused schedule: k_occ_build_fs (solve of the pending pass + run lists at the new pose; writes
 // the new state) and k_eval_occ (gate and pose from that state; leaves its rows pending) -- two launches instead of three.
 void launch_occ_fused(rgbd360_ctx* ctx, int level, int method, int occ, int forced, const float* init_pose = nullptr) {
@@ -517,7 +462,6 @@ void launch_occ_fused(rgbd360_ctx* ctx, int level, int method, int occ, int forc
     }
 #undef LAUNCH_OCC
     ctx->pend_rows_hint = L.nblocks;
-    ctx->pend_zero = false;
     std::swap(ctx->d_state, ctx->d_state_alt);
     std::swap(ctx->d_partials, ctx->d_partials_alt);
 }
@@ -760,12 +704,6 @@ int rgbd360_create(const rgbd360_params* p, rgbd360_ctx** out) {
     if (const char* e = getenv("RGBD360_FUSED_OCC")) {
         ctx->fused_occ = atoi(e) != 0;
     }
-    if (const char* e = getenv("RGBD360_PERSIST_COARSE")) {
-        ctx->persist_coarse = atoi(e) != 0;
-    }
-    if (const char* e = getenv("RGBD360_PERSIST_TEST_QUIT")) {
-        ctx->persist_test_quit = atoi(e);
-    }
     if (const char* e = getenv("RGBD360_ARENA")) {
         ctx->use_arena = atoi(e) != 0;
     }
@@ -796,7 +734,6 @@ void rgbd360_destroy(rgbd360_ctx* ctx) {
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     free_levels(ctx);
     hipFree(ctx->d_state); hipFree(ctx->d_state_alt); hipFree(ctx->d_partials); hipFree(ctx->d_partials_alt); hipFree(ctx->d_gnio);
-    hipFree(ctx->d_rows_tagged); hipFree(ctx->d_persist_bail);
     for (int k = 0; k < 2; ++k) {
         hipFree(ctx->d_stage_rgb[k]); hipFree(ctx->d_stage_depth[k]);
         if (ctx->up_ev[k]) hipEventDestroy(ctx->up_ev[k]);
@@ -886,17 +823,6 @@ static void enqueue_schedule(rgbd360_ctx* ctx, int pending, bool pending_started
         // instead of the fixed chunk -- fewer no-op launches on the coarse levels (~3 us each), no second round trip on level 0.
         if (ctx->adaptive_chunks && !(level == pending && pending_started) && ctx->hist_iters[level & 7] >= 0)
             n_pairs = std::min(std::max(ctx->hist_iters[level & 7] + 2, 2), 12);
-        if (fused && (start || ctx->pend_zero)) {
-            if (start) ctx->pend_zero = true;      // the schedule starts here: nothing is pending by definition
-            if (level > 0 && persist_level_ok(ctx, level, ctx->al_occ)) {
-                // the whole level in one resident launch, hand-over to the next finer level included
-                if (launch_level_persist(ctx, level, ctx->al_method, start ? ctx->al_guess : nullptr) == 0) {
-                    ctx->al_persist_levels |= 1u << level;
-                    continue;
-                }
-                ctx->persist_failed = true;      // (its buffers could not be allocated: the level runs as launches per iteration, below)
-            }
-        }
         if (fused) {
             // one launch per iteration: n_pairs passes, each carrying the solve of the one before it; the solve of the chunk's last
             // pass rides in the next level's first launch, the schedule's very last one in a one-block launch that publishes
@@ -926,7 +852,6 @@ int rgbd360_align360_begin(rgbd360_ctx* ctx, const float guess[16], int method, 
     memcpy(ctx->al_guess, guess, sizeof(ctx->al_guess));
     ctx->al_method = method;
     ctx->al_active = true;
-    ctx->al_persist_levels = 0;
     enqueue_schedule(ctx, ctx->p.n_pyr - 1, false);      // (its last solve publishes the state and bumps the tag)
     HIPC(ctx, hipGetLastError());
     return 0;
@@ -944,9 +869,6 @@ int rgbd360_align360_finish(rgbd360_ctx* ctx, float pose_out[16], rgbd360_result
         if (S.level_active == 0 && S.done) break;
         if (S.done) return fail(ctx, -6, "alignment schedule stalled between levels");
         if (round > (ctx->p.max_iters + 4) * ctx->p.n_pyr) return fail(ctx, -6, "alignment loop did not terminate");
-        // a level that ran as one resident launch never stalls unless its blocks gave up waiting for each other (they were not all
-        // resident): the level continues below with a launch per iteration, and so do this context's later alignments
-        if (ctx->al_persist_levels & (1u << S.level_active)) ctx->persist_failed = true;
         enqueue_schedule(ctx, S.level_active, true);         // the stalled level gets another chunk, then the finer ones
         HIPC(ctx, hipGetLastError());
     }
@@ -960,9 +882,7 @@ int rgbd360_align360_finish(rgbd360_ctx* ctx, float pose_out[16], rgbd360_result
 int rgbd360_align360(rgbd360_ctx* ctx, const float guess[16], int method, int occlusion, float pose_out[16],
                      rgbd360_result* res) {
     if (!pose_out) return ctx ? fail(ctx, -1, "null pose pointer") : -1;
-    if (ctx) ctx->persist_ok = true;          // one alignment at a time on this context, begun and finished here: its small levels may run resident
     const int rc = rgbd360_align360_begin(ctx, guess, method, occlusion);
-    if (ctx) ctx->persist_ok = false;
     if (rc) return rc;
     return rgbd360_align360_finish(ctx, pose_out, res);
 }
@@ -1331,20 +1251,6 @@ int rgbd360_forced_iters(rgbd360_ctx* ctx, int level, const float pose0[16], int
     if (pose_out) memcpy(pose_out, ctx->h_state->pose, sizeof(float) * 16);
     if (last_rms) *last_rms = ctx->h_state->error;
     return ctx->h_state->status;
-}
-
-int rgbd360_debug_persist(rgbd360_ctx* ctx, unsigned long long words[128]) {
-    if (!ctx || !words) return -1;
-    memset(words, 0, 128 * sizeof(unsigned long long));
-    if (ctx->d_persist_bail) {
-        hipSetDevice(ctx->p.device);
-        HIPC(ctx, hipStreamSynchronize(ctx->stream));
-        HIPC(ctx, hipMemcpy(words, ctx->d_persist_bail, 1024, hipMemcpyDeviceToHost));
-        const unsigned long long w0 = words[0];
-        words[0] = w0 & 0xFFFFFFFFull;           // (the device word is an int; the clocks start at word 2)
-    }
-    words[1] = (ctx->persist_failed ? 1ull : 0ull) | ((unsigned long long)ctx->al_persist_levels << 8);
-    return 0;
 }
 
 // One solve on a hand-made partial table (row 0 = `row`, every other row zero) at the identity pose, through the two-launch form

@@ -172,8 +172,6 @@ class RegisterPhotoICP:
 
     # ---- alignment (RPI.h:4519-4784)
     def alignFrames360(self, pose_guess=None, method: int = 0, occlusion: int = 0):
-        # rgbd360_align360 itself (not begin + finish): one alignment at a time on this context, which lets its small pyramid levels run as
-        # resident launches (k_coarse_persist)
         g = pose_to_cm(np.eye(4) if pose_guess is None else pose_guess)
         out = np.zeros(16, dtype=np.float32)
         rc = self._L.rgbd360_align360(self._ctx(), _ptr(g), int(method), int(occlusion), _ptr(out), C.byref(self._res))

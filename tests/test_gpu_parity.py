@@ -303,9 +303,10 @@ def test_promote_source_to_target(hip_lib, oracle_mod, small_pair):
     assert np.array_equal(reg.getOptimalPose(), ref.getOptimalPose())
 
 
-@pytest.mark.parametrize("method", [0, 2])
+@pytest.mark.parametrize("method", [0, 1, 2])
 def test_full_size_2048x1024(hip_lib, oracle_mod, method):
-    """BASELINE.json configs 2/3 at full size: GPU vs oracle pose, and both vs ground truth."""
+    """BASELINE.json configs 2/3 at full size (and DEPTH_CONSISTENCY, the third of the pass's template space): GPU vs oracle pose, and
+    both vs ground truth."""
     pair = synth.make_pair(2048, 1024, seed=1234)
     reg, ora, T = _pair_ctx(hip_lib, oracle_mod, pair, n_pyr=4)
     rc = reg.alignFrames360(np.eye(4), method)
@@ -315,7 +316,8 @@ def test_full_size_2048x1024(hip_lib, oracle_mod, method):
     rot, trans = synth.pose_error(reg.getOptimalPose(), pose_ref)
     assert rot <= POSE_TOL_DEV and trans <= POSE_TOL_DEV, (rot, trans)
     rot_gt, trans_gt = synth.pose_error(reg.getOptimalPose(), T)
-    assert rot_gt < 5e-4 and trans_gt < 2e-3, (rot_gt, trans_gt)
+    # (depth alone, on 1 mm-quantised ranges, recovers the translation to 2.4 mm -- GPU and oracle alike; with the photometric term 0.6 mm)
+    assert rot_gt < 5e-4 and trans_gt < (4e-3 if method == 1 else 2e-3), (rot_gt, trans_gt)
     _assert_libm_oracle_agrees(reg, ora, method, 4)
     # size-independent property: re-running is bitwise reproducible (fixed-order reductions, no atomics)
     pose1 = reg.getOptimalPose()
@@ -1204,56 +1206,6 @@ def test_hip_pinhole_matches_golden_fixture(hip_lib, method):
     e = reg.eval_pinhole(1, T, method)
     assert list(e["n_split"]) == [g["n_photo"], g["n_depth"]] and e["n_rows"] == g["n_rows"]
     assert np.abs(e["H64"] - np.array(g["H64"])).max() <= HG_RTOL * np.abs(np.array(g["H64"])).max()
-
-
-def test_resident_coarse_levels_are_bit_identical(hip_lib, monkeypatch):
-    """RGBD360_PERSIST_COARSE=1: the pyramid levels of at most 32 blocks run as ONE resident launch each (k_coarse_persist: the blocks loop
-    {solve, pass} themselves and hand the partial rows round as generation-tagged elements).  Same work split, row sums and solve as the
-    launch-per-iteration schedule: pose, iteration counts, Hessian and status bit for bit -- and the launches did run resident."""
-    import ctypes as C
-    for (W, H, n_pyr, method, seed) in [(2048, 1024, 4, 2, 1234), (512, 256, 5, 0, 7), (640, 320, 4, 1, 11), (256, 128, 3, 2, 3)]:
-        (rgbA, dA), (rgbB, dB), T = synth.make_pair(W, H, seed=seed)
-        out = []
-        for persist in ("1", "0"):
-            monkeypatch.setenv("RGBD360_PERSIST_COARSE", persist)
-            reg = _mk(hip_lib, n_pyr)
-            reg.setTargetFrame(rgbA, dA); reg.setSourceFrame(rgbB, dB)
-            rc = reg.alignFrames360(np.eye(4), method)
-            w = np.zeros(128, np.uint64)
-            assert reg._L.rgbd360_debug_persist(reg._ctx(), w.ctypes.data_as(C.c_void_p)) == 0
-            out.append((rc, reg.getOptimalPose().copy(), list(reg.num_iterations), reg.getHessian().copy(), int(w[0]), int(w[1])))
-            reg.close()
-        a, b = out
-        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and a[2] == b[2] and np.array_equal(a[3], b[3]), (W, H, n_pyr, a[2], b[2])
-        assert a[4] == 0 and (a[5] & 1) == 0 and (a[5] >> 8) != 0          # nobody gave up, no fall-back, and at least one level ran resident
-        assert b[5] == 0                                                   # the default schedule has no resident launch
-    monkeypatch.delenv("RGBD360_PERSIST_COARSE", raising=False)
-
-
-def test_resident_launch_recovers_when_a_block_is_missing(hip_lib, monkeypatch):
-    """The resident launch's blocks wait for each other's rows with BOUNDED polls: a block that never delivers (here: made to leave after
-    its first pass; in the field: not resident because another context's grid holds the CUs) makes the others give up, block 0 writes the
-    last solved state with nothing pending, and the host's stall recovery continues the level with a launch per iteration -- same pose,
-    same iteration counts as the default schedule; the context then stays on the default schedule."""
-    import ctypes as C
-    (rgbA, dA), (rgbB, dB), T = synth.make_pair(512, 256, seed=21)
-    ref = _mk(hip_lib, 3)
-    ref.setTargetFrame(rgbA, dA); ref.setSourceFrame(rgbB, dB)
-    rc0 = ref.alignFrames360(np.eye(4), 2)
-    monkeypatch.setenv("RGBD360_PERSIST_COARSE", "1")
-    monkeypatch.setenv("RGBD360_PERSIST_TEST_QUIT", "3")
-    reg = _mk(hip_lib, 3)
-    reg.setTargetFrame(rgbA, dA); reg.setSourceFrame(rgbB, dB)
-    rc = reg.alignFrames360(np.eye(4), 2)
-    w = np.zeros(128, np.uint64)
-    assert reg._L.rgbd360_debug_persist(reg._ctx(), w.ctypes.data_as(C.c_void_p)) == 0
-    assert int(w[0]) == 1 and (int(w[1]) & 1) == 1                      # a block gave up waiting; the context has fallen back
-    assert rc == rc0 and np.array_equal(reg.getOptimalPose(), ref.getOptimalPose()) and reg.num_iterations == ref.num_iterations
-    rc = reg.alignFrames360(np.eye(4), 2)                               # the next alignment: no resident launch any more
-    assert reg._L.rgbd360_debug_persist(reg._ctx(), w.ctypes.data_as(C.c_void_p)) == 0
-    assert (int(w[1]) >> 8) == 0 and np.array_equal(reg.getOptimalPose(), ref.getOptimalPose())
-    monkeypatch.delenv("RGBD360_PERSIST_COARSE", raising=False)
-    monkeypatch.delenv("RGBD360_PERSIST_TEST_QUIT", raising=False)
 
 
 # ---- pinhole occlusion-aware passes + salient-pixel list (RPI.h:1107-2030, 401-425, 590-690) ---------------------------------
