@@ -21,8 +21,12 @@ for leg in rotating 4k batch; do
 done
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_rotating -- python3 $R/tools/prof_hbm_legs.py rotating 4 > $OUT/pmc_fetch_rotating.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_rotating -- python3 $R/tools/prof_hbm_legs.py rotating 4 > $OUT/pmc_write_rotating.log 2>&1
+# the 16-slot batch pass k_eval_b (configs[3]'s kernel): bytes and issue counters, each set in its own run
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_batch -- python3 $R/tools/prof_hbm_legs.py batch 4 > $OUT/pmc_fetch_batch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_batch -- python3 $R/tools/prof_hbm_legs.py batch 4 > $OUT/pmc_write_batch.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/pmc_sq_batch -- python3 $R/tools/prof_hbm_legs.py batch 4 > $OUT/pmc_sq_batch.log 2>&1
 cd $R
 cat $OUT/bench.json
 python3 tools/trace_gaps.py $OUT/trace
-for d in pmc_fetch pmc_write pmc_sq pmc_tcc pmc_fetch_4k pmc_fetch_rotating pmc_write_rotating; do echo "== $d"; cat $OUT/$d.log | grep "avg us"; python3 tools/pmc_summary.py $OUT/$d; done
+for d in pmc_fetch pmc_write pmc_sq pmc_tcc pmc_fetch_4k pmc_fetch_rotating pmc_write_rotating pmc_fetch_batch pmc_write_batch pmc_sq_batch; do echo "== $d"; cat $OUT/$d.log | grep "avg us"; python3 tools/pmc_summary.py $OUT/$d; done
 for leg in rotating 4k batch; do echo "== trace_$leg"; cat $OUT/trace_$leg.log | grep "HIP events"; python3 tools/trace_gaps.py $OUT/trace_$leg | grep k_eval; cp $(ls $OUT/trace_$leg/*/*kernel_stats.csv | tail -1) $OUT/hbm_${leg}_kernel_stats.csv; done
