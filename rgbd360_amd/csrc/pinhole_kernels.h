@@ -173,17 +173,27 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_pinhole(LevelDev lv, PinK
 //                  per SOURCE pixel (no retraction) and summed where the PHOTOMETRIC residual is non-zero -- the depth rows too
 //                  (as written: DEPTH_CONSISTENCY alone gives H = 0)
 //     Occ2         an outlier gate in front: |Dtrg - 1/Z| > 1 m in the error pass (sic), |Dtrg - Z| > 1 m in the H, g pass
-// That is a state machine along each target pixel's list, so the lists are materialised in index order: k_pin_occ_keys writes
-// (target index, source index + which of the two passes the pixel enters), a stable radix sort by target index (rocPRIM; the
-// images are 320 x 240 -- nothing here is bandwidth-bound) groups them with the source order intact, and k_pin_occ_walk gives each
-// list to the thread that finds its head: one sequential walk, exact whatever the list lengths, no residency or ordering
-// assumption.  One fused walk yields the error sums and the normal equations at the pose, in k_eval's partial-row layout.
+// That is a state machine along each target pixel's list of source pixels IN INDEX ORDER.  No sort: k_pin_occ_keys counts the arrivals
+// per target pixel (integer atomics: order-independent), keeps the first kPinShort arrivals of a target in its slot row (in arrival
+// order, i.e. unordered) and the lowest / highest source index that landed there; k_pin_occ_walk gives every TARGET pixel to one thread,
+// which visits its list in index order -- a short list by repeated selection of the next larger index among its <= kPinShort slots,
+// a long one (zoom-outs and collapses pile hundreds to tens of thousands of source pixels on one target) by scanning the key array
+// between the two bounds.  Exact sequential semantics whatever the list lengths, no residency or ordering assumption, no library
+// (rounds 3-4 sorted the (target, source) pairs with a library radix sort: 8-10 launches, 44 us per evaluation).  One fused walk
+// yields the error sums and the normal equations at the pose, in k_eval's partial-row layout; it also re-arms the per-target words.
 // ---------------------------------------------------------------------------------------------------------------------------
 constexpr float kPinThresDepthOutliers = 1.f;      // thresDepthOutliers = maxDepthOutliers (RPI.h:215, 4256-4260)
 constexpr unsigned kPinOccErr = 1u << 30, kPinOccHess = 1u << 31, kPinOccIndex = 0xFFFFFFu;
 
+constexpr int kPinShort = 8;                       // arrivals per target pixel kept in its slot row
+struct PinOccLists {                               // per target pixel of the largest level (armed once at allocation, re-armed by the walk)
+    int* cnt;                                      // arrivals (0)
+    int* first;                                    // lowest source index (INT_MAX)
+    int* last;                                     // highest source index (-1)
+    unsigned* slots;                               // [n][kPinShort] source indices, arrival order
+};
 template <int OCC>
-__global__ __launch_bounds__(256) void k_pin_occ_keys(LevelDev lv, PinK K, Pose16 pose, unsigned* __restrict__ keys, unsigned* __restrict__ vals) {
+__global__ __launch_bounds__(256) void k_pin_occ_keys(LevelDev lv, PinK K, Pose16 pose, unsigned* __restrict__ keys, unsigned* __restrict__ vals, PinOccLists Ls) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= lv.n) return;
     const PoseRT T = load_pose(pose.v);
@@ -198,26 +208,38 @@ __global__ __launch_bounds__(256) void k_pin_occ_keys(LevelDev lv, PinK K, Pose1
         cand_e = !(fabsf(depth2 - iz) > kPinThresDepthOutliers);       // RPI.h:1687-1690 (depth against inverse depth: as written)
         cand_h = !(fabsf(depth2 - Z) > kPinThresDepthOutliers);        // RPI.h:1857-1862
     }
-    keys[i] = (cand_e || cand_h) ? ti : (unsigned)lv.n;                 // non-candidates sort behind every list
+    const bool in_list = cand_e || cand_h;
+    keys[i] = in_list ? ti : (unsigned)lv.n;                            // (n: on no list)
     vals[i] = (unsigned)i | (cand_e ? kPinOccErr : 0u) | (cand_h ? kPinOccHess : 0u);
+    if (in_list) {
+        const int slot = atomicAdd(&Ls.cnt[ti], 1);
+        if (slot < kPinShort) Ls.slots[(size_t)ti * kPinShort + slot] = (unsigned)i;
+        atomicMin(&Ls.first[ti], i);
+        atomicMax(&Ls.last[ti], i);
+    }
 }
 
 constexpr int kPinWalkThreads = 256;
 template <int METHOD>
 __global__ __launch_bounds__(kPinWalkThreads) void k_pin_occ_walk(LevelDev lv, PinK K, EvalConsts ec, Pose16 pose, const unsigned* __restrict__ keys,
-                                                                   const unsigned* __restrict__ vals, double* __restrict__ partials) {
-    const int p = blockIdx.x * kPinWalkThreads + (int)threadIdx.x;
+                                                                   const unsigned* __restrict__ vals, PinOccLists Ls, double* __restrict__ partials) {
+    const int p = blockIdx.x * kPinWalkThreads + (int)threadIdx.x;      // the target pixel of this thread
     const PoseRT T = load_pose(pose.v);
     EvalAcc A;
 #pragma unroll
     for (int k = 0; k < 27; ++k) A.acc[k] = 0.f;
     A.e2p = A.e2d = 0.f;
     int nP = 0, nD = 0, nVis = 0;
-    const unsigned n = (unsigned)lv.n;
-    const unsigned key = p < lv.n ? keys[p] : n;
-    const bool head = key < n && (p == 0 || keys[p - 1] != key);
-    if (head) {
-        const unsigned ti = key;
+    int m = 0, lo = 0, hi = -1;
+    if (p < lv.n) {
+        m = Ls.cnt[p];
+        if (m) {
+            lo = Ls.first[p]; hi = Ls.last[p];
+            Ls.cnt[p] = 0; Ls.first[p] = 0x7fffffff; Ls.last[p] = -1;  // re-armed for the next evaluation
+        }
+    }
+    if (m) {
+        const unsigned ti = (unsigned)p;
         F3 tp = {0.f, 0.f, 0.f};
         if (METHOD != 1) tp = lv.trgP[ti];
         const F3 td = lv.trgD[ti];
@@ -227,8 +249,23 @@ __global__ __launch_bounds__(kPinWalkThreads) void k_pin_occ_walk(LevelDev lv, P
         const bool fin_d = isfinite(depth2);
         float buf_e = 0.f, buf_h = 0.f;              // invDepthBuffer(ii) of the two passes
         float res_p = 0.f, res_d = 0.f;              // residualsPhoto(ii), residualsDepth(ii) of the error pass
-        for (int q = p; q < lv.n && keys[q] == key; ++q) {
-            const unsigned v = vals[q];
+        const unsigned* row = Ls.slots + (size_t)ti * kPinShort;
+        int prev = -1, scan = lo;                    // the source index visited last; the scan position of a long list
+        for (int visited = 0; visited < m; ++visited) {
+            int src;
+            if (m <= kPinShort) {                    // the next larger index among the slots
+                unsigned best = 0xffffffffu;
+                for (int k = 0; k < m; ++k) {
+                    const unsigned c = row[k];
+                    if ((int)c > prev && c < best) best = c;
+                }
+                src = (int)best;
+            } else {                                 // the next source pixel with this key, in index order
+                while (scan <= hi && keys[scan] != ti) ++scan;
+                src = scan++;
+            }
+            prev = src;
+            const unsigned v = vals[src];
             const float4 s = lv.src[v & kPinOccIndex];
             float X, Y, Z, iz;
             bool vis;

@@ -17,7 +17,6 @@
 #include <thread>
 #include <vector>
 
-#include <hipcub/device/device_radix_sort.hpp>      // the pinhole occlusion passes' stable sort by target pixel (pinhole_kernels.h)
 
 #include "../../include/rgbd360_hip.h"
 #include "../../include/rgbd360_hip_diag.h"
@@ -127,9 +126,9 @@ struct rgbd360_ctx {
     bool have_cam = false;
     float sal_thr = -1.f;                               // useSaliency(true): thresSaliency (RPI.h:217, 266); < 0 = off
     // pinhole occlusion passes: (target index, source index) pairs before / after the sort, the sort's scratch, one partial row per walk block
-    unsigned *pin_keys = nullptr, *pin_keys_sorted = nullptr, *pin_vals = nullptr, *pin_vals_sorted = nullptr;
-    void* pin_sort_tmp = nullptr;
-    size_t pin_sort_bytes = 0, pin_occ_n = 0;
+    unsigned *pin_keys = nullptr, *pin_vals = nullptr;      // the pinhole occlusion passes: per source pixel its target + pass flags,
+    PinOccLists pin_lists = {nullptr, nullptr, nullptr, nullptr};      // per target pixel its arrivals (pinhole_kernels.h)
+    size_t pin_occ_n = 0;
     double* pin_partials = nullptr;
     int* occ_head = nullptr;                           // occlusion modes: per-target lists of candidate runs (generation-tagged heads)
     int4* occ_nodes = nullptr;                         // ... run nodes, indexed by the run's last source pixel
@@ -158,6 +157,15 @@ int fail(rgbd360_ctx* ctx, int code, const char* msg) {
     return code;
 }
 
+void pin_occ_free(rgbd360_ctx* ctx) {
+    hipFree(ctx->pin_keys); hipFree(ctx->pin_vals); hipFree(ctx->pin_partials);
+    hipFree(ctx->pin_lists.cnt); hipFree(ctx->pin_lists.first); hipFree(ctx->pin_lists.last); hipFree(ctx->pin_lists.slots);
+    ctx->pin_keys = ctx->pin_vals = nullptr;
+    ctx->pin_partials = nullptr;
+    ctx->pin_lists = PinOccLists{nullptr, nullptr, nullptr, nullptr};
+    ctx->pin_occ_n = 0;
+}
+
 void free_levels(rgbd360_ctx* ctx) {
     for (Level& L : ctx->levels) {
         if (!ctx->arena) {
@@ -167,11 +175,7 @@ void free_levels(rgbd360_ctx* ctx) {
         }
         hipFree(L.srcRecPin);
     }
-    hipFree(ctx->pin_keys); hipFree(ctx->pin_keys_sorted); hipFree(ctx->pin_vals); hipFree(ctx->pin_vals_sorted);
-    hipFree(ctx->pin_sort_tmp); hipFree(ctx->pin_partials);
-    ctx->pin_keys = ctx->pin_keys_sorted = ctx->pin_vals = ctx->pin_vals_sorted = nullptr;
-    ctx->pin_sort_tmp = nullptr; ctx->pin_partials = nullptr;
-    ctx->pin_sort_bytes = ctx->pin_occ_n = 0;
+    pin_occ_free(ctx);
     hipFree(ctx->arena);
     ctx->arena = nullptr;
     ctx->levels.clear();
@@ -1574,24 +1578,22 @@ int pin_eval(rgbd360_ctx* ctx, int level, const float* pose, int method) {
     return 0;
 }
 
-// The occlusion-aware evaluation (pinhole_kernels.h, second half): keys, stable sort by target pixel, one walk per list; the
-// reduce-only solve publishes the sums like pin_eval's.
+// The occlusion-aware evaluation (pinhole_kernels.h, second half): per-target arrival lists, one walk per target pixel in source-index
+// order; the reduce-only solve publishes the sums like pin_eval's.
 int pin_occ_ensure(rgbd360_ctx* ctx, size_t n) {
     if (ctx->pin_occ_n >= n) return 0;
-    hipFree(ctx->pin_keys); hipFree(ctx->pin_keys_sorted); hipFree(ctx->pin_vals); hipFree(ctx->pin_vals_sorted);
-    hipFree(ctx->pin_sort_tmp); hipFree(ctx->pin_partials);
-    ctx->pin_keys = ctx->pin_keys_sorted = ctx->pin_vals = ctx->pin_vals_sorted = nullptr;
-    ctx->pin_sort_tmp = nullptr; ctx->pin_partials = nullptr;
-    ctx->pin_occ_n = 0;
+    pin_occ_free(ctx);
+    PinOccLists& Ls = ctx->pin_lists;
     HIPC(ctx, hipMalloc(&ctx->pin_keys, n * sizeof(unsigned)));
-    HIPC(ctx, hipMalloc(&ctx->pin_keys_sorted, n * sizeof(unsigned)));
     HIPC(ctx, hipMalloc(&ctx->pin_vals, n * sizeof(unsigned)));
-    HIPC(ctx, hipMalloc(&ctx->pin_vals_sorted, n * sizeof(unsigned)));
-    size_t bytes = 0;
-    HIPC(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, ctx->pin_keys, ctx->pin_keys_sorted, ctx->pin_vals, ctx->pin_vals_sorted, (int)n, 0, 32,
-                                                 ctx->stream));
-    HIPC(ctx, hipMalloc(&ctx->pin_sort_tmp, bytes ? bytes : 16));
-    ctx->pin_sort_bytes = bytes;
+    HIPC(ctx, hipMalloc(&Ls.cnt, n * sizeof(int)));
+    HIPC(ctx, hipMalloc(&Ls.first, n * sizeof(int)));
+    HIPC(ctx, hipMalloc(&Ls.last, n * sizeof(int)));
+    HIPC(ctx, hipMalloc(&Ls.slots, n * kPinShort * sizeof(unsigned)));
+    // armed once; every walk re-arms the words of the target pixels it visited
+    HIPC(ctx, hipMemsetAsync(Ls.cnt, 0, n * sizeof(int), ctx->stream));
+    HIPC(ctx, hipMemsetAsync(Ls.last, 0xff, n * sizeof(int), ctx->stream));           // -1
+    HIPC(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(Ls.first), 0x7fffffff, n, ctx->stream));
     HIPC(ctx, hipMalloc(&ctx->pin_partials, ((n + kPinWalkThreads - 1) / kPinWalkThreads) * kNumPartials * sizeof(double)));
     ctx->pin_occ_n = n;
     return 0;
@@ -1607,18 +1609,13 @@ int pin_eval_occ(rgbd360_ctx* ctx, int level, const float* pose, int method, int
     Pose16 P;
     memcpy(P.v, pose, sizeof(P.v));
     const dim3 gk((L.n + 255) / 256), bk(256);
-    if (occ == 1) hipLaunchKernelGGL((k_pin_occ_keys<1>), gk, bk, 0, ctx->stream, lv, K, P, ctx->pin_keys, ctx->pin_vals);
-    else hipLaunchKernelGGL((k_pin_occ_keys<2>), gk, bk, 0, ctx->stream, lv, K, P, ctx->pin_keys, ctx->pin_vals);
-    int bits = 1;
-    while ((1ll << bits) <= (long long)L.n) ++bits;          // the keys are target indices < n, and n itself for the non-candidates
-    size_t bytes = ctx->pin_sort_bytes;
-    HIPC(ctx, hipcub::DeviceRadixSort::SortPairs(ctx->pin_sort_tmp, bytes, ctx->pin_keys, ctx->pin_keys_sorted, ctx->pin_vals, ctx->pin_vals_sorted, L.n,
-                                                 0, bits, ctx->stream));
+    if (occ == 1) hipLaunchKernelGGL((k_pin_occ_keys<1>), gk, bk, 0, ctx->stream, lv, K, P, ctx->pin_keys, ctx->pin_vals, ctx->pin_lists);
+    else hipLaunchKernelGGL((k_pin_occ_keys<2>), gk, bk, 0, ctx->stream, lv, K, P, ctx->pin_keys, ctx->pin_vals, ctx->pin_lists);
     const int nblk = (L.n + kPinWalkThreads - 1) / kPinWalkThreads;
     const dim3 gw(nblk), bw(kPinWalkThreads);
-    if (method == 0) hipLaunchKernelGGL((k_pin_occ_walk<0>), gw, bw, 0, ctx->stream, lv, K, ec, P, ctx->pin_keys_sorted, ctx->pin_vals_sorted, ctx->pin_partials);
-    else if (method == 1) hipLaunchKernelGGL((k_pin_occ_walk<1>), gw, bw, 0, ctx->stream, lv, K, ec, P, ctx->pin_keys_sorted, ctx->pin_vals_sorted, ctx->pin_partials);
-    else hipLaunchKernelGGL((k_pin_occ_walk<2>), gw, bw, 0, ctx->stream, lv, K, ec, P, ctx->pin_keys_sorted, ctx->pin_vals_sorted, ctx->pin_partials);
+    if (method == 0) hipLaunchKernelGGL((k_pin_occ_walk<0>), gw, bw, 0, ctx->stream, lv, K, ec, P, ctx->pin_keys, ctx->pin_vals, ctx->pin_lists, ctx->pin_partials);
+    else if (method == 1) hipLaunchKernelGGL((k_pin_occ_walk<1>), gw, bw, 0, ctx->stream, lv, K, ec, P, ctx->pin_keys, ctx->pin_vals, ctx->pin_lists, ctx->pin_partials);
+    else hipLaunchKernelGGL((k_pin_occ_walk<2>), gw, bw, 0, ctx->stream, lv, K, ec, P, ctx->pin_keys, ctx->pin_vals, ctx->pin_lists, ctx->pin_partials);
     SolveCfg cfg;
     cfg.level = level; cfg.mode = 1; cfg.forced = 0; cfg.max_iters = ctx->p.max_iters; cfg.n_pixels = L.n;
     cfg.occ = 0;
