@@ -280,6 +280,7 @@ int rgbd360_distance_map(rgbd360_ctx* ctx, const float* xyz, int rows, int cols,
  * oracle/frame360_ref.cpp): only z changes, x and y are copied.  xyz_out may alias xyz. */
 int rgbd360_bilateral_filter(rgbd360_ctx* ctx, const float* xyz, int rows, int cols, float sigma_s, float sigma_r, float* xyz_out);
 
+#define RGBD360_HULL_MAX 64
 /* One planar region: n . x + d = 0 with n towards the origin, curvature = lambda_min / trace(cov). */
 typedef struct {
     float centroid[3];
@@ -323,6 +324,13 @@ typedef struct {
     float color_dev[3];
     float intensity;
     float hist_h[74];
+    /* The hull POLYGON itself -- mrpt::pbmap::Plane::polygonContourPtr, which Frame360::mergePlanes tests for proximity vertex by vertex and
+     * edge by edge (Frame360.h:680-711) and mergePlane2 re-hulls: hull_n <= RGBD360_HULL_MAX vertices in the frame of the plane record,
+     * counter-clockwise seen from the side the normal points to (the camera's side), on the fitted plane.  A hull of more vertices is
+     * thinned to its extreme points in RGBD360_HULL_MAX evenly spaced in-plane directions (an inscribed polygon: < 0.2 % of the area of a
+     * disc is lost).  hull_n = 0: the record carries no polygon (caller-made record, or no hull was formed). */
+    int   hull_n;
+    float hull[RGBD360_HULL_MAX][3];
 } rgbd360_plane;
 
 /* Registers the colour image that goes with the organised cloud of the context's next plane calls (rgbd360_plane_fit,
@@ -511,11 +519,14 @@ int rgbd360_register_planes(const rgbd360_plane* ref, int n_ref, const rgbd360_p
                             int32_t* match_out, int* n_matched_out, float* area_matched_out);
 
 /* Frame360::mergePlanes (Frame360.h:655-733): the pieces several sensors (or several regions) hold of one surface become one
- * plane.  Same surface = the reference's explicit test: n_j . n_k > cos_normal (0.99), |d_j - d_k| < dist_d (0.45 m), and outline
- * points closer than proximity (0.3 m) whose difference lies within normal_offset (0.06 m) of plane j -- evaluated on the
- * rectangle with each plane's in-plane moments instead of mrpt::pbmap's convex hull (corners, edge midpoints, centre; a point of
- * one outline inside the other stands in for crossing hull edges).  The merged plane is the exact pooled fit of the two
- * pieces (covariances rebuilt from the records, combined by inlier count -- mrpt's mergePlane2 pools the inliers and refits).
+ * plane.  Same surface = the reference's explicit test: n_j . n_k > cos_normal (0.99), |d_j - d_k| < dist_d (0.45 m), and outlines
+ * closer than proximity (0.3 m) at a pair of points whose difference lies within normal_offset (0.06 m) of plane j -- on the HULL
+ * POLYGONS of the two records, as the reference does (Frame360.h:680-691 vertex against vertex, :694-711 edge against edge: the 3-D
+ * segment-to-segment distance; a vertex of one polygon inside the other -- overlapping pieces whose outlines never come close -- counts
+ * too).  Records without a polygon (hull_n = 0: caller-made) are tested on the rectangle with their in-plane moments instead (corners,
+ * edge midpoints, centre).  The merged plane is the exact pooled fit of the two pieces (covariances rebuilt from the records, combined
+ * by inlier count -- mrpt's mergePlane2 pools the inliers and refits); its polygon is the convex hull of the two polygons' vertices
+ * projected onto the pooled plane (mergePlane2 re-hulls the two contours), its area and centre that polygon's.
  * Planes above max_curvature are never merged (Frame360.h:659-661).  Regions smaller than min_area (0.12 m2) or narrower than
  * max_elongation (6) are dropped first: Frame360.h:1034,1041 never stores them, so the reference's merge never sees them (and the
  * record of a thin strip pins its normal too loosely to be pooled); malformed records are dropped too.  Host only.

@@ -419,6 +419,7 @@ inline rgbd360_plane plane_of(const PlaneMoments& m, int root) {
     P.elongation = (float)(l1 > 0 ? sqrt(l2 / l1) : INFINITY);
     for (int i = 0; i < 3; ++i) P.center_hull[i] = P.centroid[i];
     P.hull_points = 0;
+    P.hull_n = 0;
     return P;
 }
 struct MergeParams {
@@ -444,10 +445,86 @@ inline void contour_points(const rgbd360_plane& p, V3 pts[9], V3& pp, V3& qq, do
         for (int sv = -1; sv <= 1; ++sv)
             pts[k++] = {c.x + su * a * pp.x + sv * b * qq.x, c.y + su * a * pp.y + sv * b * qq.y, c.z + su * a * pp.z + sv * b * qq.z};
 }
+// Squared distance between the 3-D segments [p0, p1] and [q0, q1] (mrpt::pbmap::dist3D_Segment_to_Segment2, Frame360.h:697: the classic
+// clamped closest-point solution; MRPT is third-party, restated).
+inline double seg_seg_dist2(const V3& p0, const V3& p1, const V3& q0, const V3& q1) {
+    const V3 u = sub(p1, p0), v = sub(q1, q0), w = sub(p0, q0);
+    const double a = dot(u, u), b = dot(u, v), c = dot(v, v), d = dot(u, w), e = dot(v, w), D = a * c - b * b;
+    double sN, sD = D, tN, tD = D;
+    if (D < 1e-12 * std::max(a * c, 1e-300)) {             // almost parallel: use p0 on the first segment
+        sN = 0.0; sD = 1.0; tN = e; tD = c;
+    } else {
+        sN = b * e - c * d; tN = a * e - b * d;
+        if (sN < 0.0) { sN = 0.0; tN = e; tD = c; }
+        else if (sN > sD) { sN = sD; tN = e + b; tD = c; }
+    }
+    if (tN < 0.0) {
+        tN = 0.0;
+        if (-d < 0.0) sN = 0.0;
+        else if (-d > a) sN = sD;
+        else { sN = -d; sD = a; }
+    } else if (tN > tD) {
+        tN = tD;
+        if (-d + b < 0.0) sN = 0.0;
+        else if (-d + b > a) sN = sD;
+        else { sN = -d + b; sD = a; }
+    }
+    const double sc = fabs(sN) < 1e-300 || !(sD > 0) ? 0.0 : sN / sD, tc = fabs(tN) < 1e-300 || !(tD > 0) ? 0.0 : tN / tD;
+    const V3 dP = {w.x + sc * u.x - tc * v.x, w.y + sc * u.y - tc * v.y, w.z + sc * u.z - tc * v.z};
+    return dot(dP, dP);
+}
+// in-plane frame of a record (unit axes e1, e2 with e1 x e2 = n) and a polygon's vertices in it
+inline void plane_axes(const rgbd360_plane& p, V3& e1, V3& e2) {
+    const V3 nn = v3(p.normal);
+    e1 = v3(p.ppal_dir);
+    if (!(norm(e1) > 0.5)) e1 = cross(nn, fabs(nn.x) < 0.9 ? V3{1, 0, 0} : V3{0, 1, 0});
+    const double pn = dot(e1, nn);
+    e1 = {e1.x - pn * nn.x, e1.y - pn * nn.y, e1.z - pn * nn.z};
+    const double l = norm(e1);
+    e1 = {e1.x / l, e1.y / l, e1.z / l};
+    e2 = cross(nn, e1);
+}
+inline bool point_in_hull(const rgbd360_plane& p, const V3& q, double normal_offset) {      // q within normal_offset of p's plane and inside its polygon
+    const int n = std::min(p.hull_n, (int)RGBD360_HULL_MAX);
+    if (n < 3) return false;
+    const V3 nn = v3(p.normal);
+    if (!(fabs(dot(nn, sub(q, v3(p.hull[0])))) < normal_offset)) return false;
+    double sgn = 0;                                        // the same side of every edge (either sense)
+    for (int i = 0; i < n; ++i) {
+        const V3 a = v3(p.hull[i]), b = v3(p.hull[(i + 1) % n]);
+        const double s = dot(nn, cross(sub(b, a), sub(q, a)));
+        if (s == 0) continue;
+        if (sgn == 0) sgn = s;
+        else if ((s > 0) != (sgn > 0)) return false;
+    }
+    return true;
+}
+inline bool same_surface_hulls(const rgbd360_plane& pj, const rgbd360_plane& pk, const MergeParams& M) {
+    const V3 nj = v3(pj.normal);
+    const int nj_v = std::min(pj.hull_n, (int)RGBD360_HULL_MAX), nk_v = std::min(pk.hull_n, (int)RGBD360_HULL_MAX);
+    for (int i = 0; i < nj_v; ++i)                         // Frame360.h:680-691: vertex against vertex
+        for (int ii = 0; ii < nk_v; ++ii) {
+            const V3 df = sub(v3(pj.hull[i]), v3(pk.hull[ii]));
+            if (norm(df) < M.proximity && fabs(dot(nj, df)) < M.normal_offset) return true;
+        }
+    const double prox2 = (double)M.proximity * M.proximity;
+    for (int i = 0; i < nj_v; ++i)                         // :694-711: edge against edge (the polygons are closed)
+        for (int ii = 0; ii < nk_v; ++ii) {
+            const V3 a0 = v3(pj.hull[i]), a1 = v3(pj.hull[(i + 1) % nj_v]), b0 = v3(pk.hull[ii]), b1 = v3(pk.hull[(ii + 1) % nk_v]);
+            if (seg_seg_dist2(a0, a1, b0, b1) < prox2 && fabs(dot(nj, sub(a1, b1))) < M.normal_offset) return true;
+        }
+    // one piece lying inside the other (no pair of outline points need be close then; a region re-observed through a hole in another)
+    for (int i = 0; i < nk_v; ++i)
+        if (point_in_hull(pj, v3(pk.hull[i]), M.normal_offset)) return true;
+    for (int i = 0; i < nj_v; ++i)
+        if (point_in_hull(pk, v3(pj.hull[i]), M.normal_offset)) return true;
+    return false;
+}
 inline bool same_surface(const rgbd360_plane& pj, const rgbd360_plane& pk, const MergeParams& M) {
     const V3 nj = v3(pj.normal), nk = v3(pk.normal);
     if (!(dot(nj, nk) > M.cos_normal)) return false;                              // Frame360.h:671
     if (!(fabs((double)pj.d - pk.d) < M.dist_d)) return false;                    // :672
+    if (pj.hull_n >= 3 && pk.hull_n >= 3) return same_surface_hulls(pj, pk, M);   // :680-711 on the polygons the records carry
     V3 Pj[9], Pk[9], ppj, qqj, ppk, qqk;
     double aj, bj, ak, bk;
     contour_points(pj, Pj, ppj, qqj, aj, bj);
@@ -464,6 +541,75 @@ inline bool same_surface(const rgbd360_plane& pj, const rgbd360_plane& pk, const
     for (int i = 0; i < 9; ++i)                                                   // :694-711 stand-in: overlapping outlines
         if (inside(Pk[i], pj, ppj, qqj, aj, bj) || inside(Pj[i], pk, ppk, qqk, ak, bk)) return true;
     return false;
+}
+// The polygon of a merged plane: the convex hull, on the pooled plane, of the two pieces' polygon vertices (what mergePlane2 does with
+// the two contours); sets hull / hull_n / area / center_hull of dst.  false: degenerate (fewer than three distinct projected points).
+inline bool rehull(rgbd360_plane& dst, const rgbd360_plane& a, const rgbd360_plane& b, const int hull_points_sum) {
+    V3 e1, e2;
+    plane_axes(dst, e1, e2);
+    const V3 c = v3(dst.centroid);
+    struct P2 { double x, y; };
+    std::vector<P2> pts;
+    for (const rgbd360_plane* p : {&a, &b})
+        for (int i = 0; i < p->hull_n && i < (int)RGBD360_HULL_MAX; ++i) {
+            const V3 d = sub(v3(p->hull[i]), c);
+            pts.push_back({dot(d, e1), dot(d, e2)});
+        }
+    std::sort(pts.begin(), pts.end(), [](const P2& p, const P2& q) { return p.x < q.x || (p.x == q.x && p.y < q.y); });
+    pts.erase(std::unique(pts.begin(), pts.end(), [](const P2& p, const P2& q) { return p.x == q.x && p.y == q.y; }), pts.end());
+    const int n = (int)pts.size();
+    if (n < 3) return false;
+    auto cr = [](const P2& o, const P2& p, const P2& q) { return (p.x - o.x) * (q.y - o.y) - (p.y - o.y) * (q.x - o.x); };
+    std::vector<P2> H(2 * n + 2);
+    int m = 0;
+    for (int i = 0; i < n; ++i) {
+        while (m >= 2 && cr(H[m - 2], H[m - 1], pts[i]) <= 0) --m;
+        H[m++] = pts[i];
+    }
+    for (int i = n - 2, lo = m + 1; i >= 0; --i) {
+        while (m >= lo && cr(H[m - 2], H[m - 1], pts[i]) <= 0) --m;
+        H[m++] = pts[i];
+    }
+    --m;
+    if (m < 3) return false;
+    double a2 = 0, cu = 0, cv = 0;
+    for (int i = 0; i < m; ++i) {
+        const P2 &p = H[i], &q = H[(i + 1) % m];
+        const double w = p.x * q.y - p.y * q.x;
+        a2 += w; cu += (p.x + q.x) * w; cv += (p.y + q.y) * w;
+    }
+    if (!(fabs(a2) > 0)) return false;
+    cu /= 3 * a2; cv /= 3 * a2;
+    // at most 2 x RGBD360_HULL_MAX inputs: thin to the extremes in RGBD360_HULL_MAX directions when the hull is larger (apply_hull's rule)
+    std::vector<int> keep;
+    if (m <= (int)RGBD360_HULL_MAX) {
+        for (int i = 0; i < m; ++i) keep.push_back(i);
+    } else {
+        for (int k = 0; k < (int)RGBD360_HULL_MAX; ++k) {
+            const double th = 2.0 * 3.14159265358979323846 * k / RGBD360_HULL_MAX, cx = cos(th), sy = sin(th);
+            int best = 0;
+            double bd = -1e300;
+            for (int i = 0; i < m; ++i) {
+                const double dd = (H[i].x - cu) * cx + (H[i].y - cv) * sy;
+                if (dd > bd) { bd = dd; best = i; }
+            }
+            if ((!keep.empty() && (keep.back() == best || keep.front() == best))) continue;
+            keep.push_back(best);
+        }
+    }
+    dst.hull_n = (int)keep.size();
+    for (int i = 0; i < dst.hull_n; ++i) {                 // (e1, e2, n) is right-handed: counter-clockwise in (u, v) = counter-clockwise seen from the normal's side
+        const P2& h = H[keep[i]];
+        dst.hull[i][0] = (float)(c.x + h.x * e1.x + h.y * e2.x);
+        dst.hull[i][1] = (float)(c.y + h.x * e1.y + h.y * e2.y);
+        dst.hull[i][2] = (float)(c.z + h.x * e1.z + h.y * e2.z);
+    }
+    dst.area = (float)(fabs(a2) / 2);
+    dst.center_hull[0] = (float)(c.x + cu * e1.x + cv * e2.x);
+    dst.center_hull[1] = (float)(c.y + cu * e1.y + cv * e2.y);
+    dst.center_hull[2] = (float)(c.z + cu * e1.z + cv * e2.z);
+    dst.hull_points = hull_points_sum;
+    return true;
 }
 // colour of a merged plane = the pooled statistics of its pieces (mergePlane2 pools the inliers and calls calcMainColor again):
 // means and histogram weighted by the pixel counts they were taken over, the deviation from the pooled second moment
@@ -511,8 +657,11 @@ inline std::vector<rgbd360_plane> merge_planes(const rgbd360_plane* in, int n, c
                 const double aj = v[j].area, ak = v[k].area;
                 const int hp = v[j].hull_points + v[k].hull_points;
                 const V3 cj = center_of(v[j]), ck = center_of(v[k]);
+                const rgbd360_plane piece_j = v[j], piece_k = v[k];
                 v[j] = plane_of(m, std::min(v[j].root, v[k].root));
-                if (hulls && aj + ak > 0) {
+                if (piece_j.hull_n >= 3 && piece_k.hull_n >= 3 && rehull(v[j], piece_j, piece_k, hp)) {
+                    // mergePlane2: the two contours pooled and hulled again on the merged plane -- area and mass centre are that polygon's
+                } else if (hulls && aj + ak > 0) {
                     v[j].area = (float)(aj + ak);
                     v[j].center_hull[0] = (float)((aj * cj.x + ak * ck.x) / (aj + ak));
                     v[j].center_hull[1] = (float)((aj * cj.y + ak * ck.y) / (aj + ak));

@@ -2050,6 +2050,8 @@ int f360_bilateral_dev(rgbd360_ctx* ctx, int rows, int cols, float sigma_s, floa
 struct HullStats {
     int n = 0;                  // hull vertices
     double area = 0, cu = 0, cv = 0;
+    int np = 0;                 // vertices kept for the plane record (<= RGBD360_HULL_MAX), counter-clockwise in (u, v)
+    double pu[RGBD360_HULL_MAX], pv[RGBD360_HULL_MAX];
 };
 struct HullPt {
     double x, y;                // (no constructor: the work arrays below are not cleared -- 48 KB per plane when they were std::pairs)
@@ -2095,6 +2097,27 @@ HullStats hull_stats(const float (*uv)[2], int K) {
     h.area = fabs(a2) / 2;
     h.cu = cu / (3 * a2);
     h.cv = cv / (3 * a2);
+    // the polygon of the record: the hull itself, or its extreme vertices in RGBD360_HULL_MAX evenly spaced directions (Andrew's chain
+    // leaves the vertices counter-clockwise, so the picks come out in hull order)
+    if (m <= RGBD360_HULL_MAX) {
+        for (int i = 0; i < m; ++i) { h.pu[i] = H[i].x; h.pv[i] = H[i].y; }
+        h.np = m;
+    } else {
+        int last = -1, first = -1;
+        for (int k = 0; k < RGBD360_HULL_MAX; ++k) {
+            const double th = 2.0 * 3.14159265358979323846 * k / RGBD360_HULL_MAX, cx = cos(th), sy = sin(th);
+            int best = 0;
+            double bd = -1e300;
+            for (int i = 0; i < m; ++i) {
+                const double dd = (H[i].x - h.cu) * cx + (H[i].y - h.cv) * sy;
+                if (dd > bd) { bd = dd; best = i; }
+            }
+            if (best == last || best == first) continue;
+            if (first < 0) first = best;
+            last = best;
+            h.pu[h.np] = H[best].x; h.pv[h.np] = H[best].y; ++h.np;
+        }
+    }
     return h;
 }
 // area / centre of plane P from the hull record of its slot (pinned, written by k_f360_hull_pack); the moment rectangle stays in
@@ -2102,9 +2125,20 @@ HullStats hull_stats(const float (*uv)[2], int K) {
 void apply_hull(rgbd360_plane& P, const f360::F360HullRecord& R) {
     const HullStats h = hull_stats(R.uv, std::min(std::max(R.n, 0), f360::kHullRecPts));
     P.hull_points = h.n;
+    P.hull_n = 0;
     if (h.n >= 3) {
         P.area = (float)h.area;
         for (int k = 0; k < 3; ++k) P.center_hull[k] = (float)((double)R.c[k] + h.cu * (double)R.e1[k] + h.cv * (double)R.e2[k]);
+        // counter-clockwise seen from the side the record's normal points to: (e1, e2, e1 x e2) is right-handed, so the (u, v) order is
+        // counter-clockwise about e1 x e2 -- reversed when the normal points the other way
+        const double e3[3] = {(double)R.e1[1] * R.e2[2] - (double)R.e1[2] * R.e2[1], (double)R.e1[2] * R.e2[0] - (double)R.e1[0] * R.e2[2],
+                              (double)R.e1[0] * R.e2[1] - (double)R.e1[1] * R.e2[0]};
+        const bool flip = e3[0] * P.normal[0] + e3[1] * P.normal[1] + e3[2] * P.normal[2] < 0;
+        P.hull_n = h.np;
+        for (int i = 0; i < h.np; ++i) {
+            const int src = flip ? h.np - 1 - i : i;
+            for (int k = 0; k < 3; ++k) P.hull[i][k] = (float)((double)R.c[k] + h.pu[src] * (double)R.e1[k] + h.pv[src] * (double)R.e2[k]);
+        }
     } else {
         P.area = P.area_moment;
         for (int k = 0; k < 3; ++k) P.center_hull[k] = P.centroid[k];
@@ -2453,6 +2487,7 @@ int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float
         else {                   // filled by f360_refine_dev below
             P.area = P.area_moment;
             P.hull_points = 0;
+            P.hull_n = 0;
             for (int k = 0; k < 3; ++k) P.center_hull[k] = P.centroid[k];
         }
     }
@@ -2809,6 +2844,11 @@ static int cloud_planes_tail(rgbd360_ctx* ctx, int rows, int cols, float sigma_s
                 P.center_hull[i] = (float)hh[i];
             }
             P.d = (float)dd;
+            for (int v = 0; v < P.hull_n && v < RGBD360_HULL_MAX; ++v) {      // the polygon travels with the plane (a rigid motion keeps its sense)
+                double q[3];
+                for (int i = 0; i < 3; ++i) q[i] = (double)Rt[0 * 4 + i] * P.hull[v][0] + (double)Rt[1 * 4 + i] * P.hull[v][1] + (double)Rt[2 * 4 + i] * P.hull[v][2] + (double)Rt[12 + i];
+                for (int i = 0; i < 3; ++i) P.hull[v][i] = (float)q[i];
+            }
         }
     }
     return 0;

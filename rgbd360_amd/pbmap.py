@@ -43,6 +43,13 @@ def planes_to_array(planes):
         ch = pl.get("center_hull", pl["centroid"])
         for k in range(3):
             a.center_hull[k] = float(ch[k])
+        hull = pl.get("hull")            # the hull polygon ([n <= 64][3]; rgbd360_merge_planes tests proximity on it)
+        a.hull_n = 0
+        if hull is not None and len(hull) >= 3:
+            a.hull_n = min(len(hull), 64)
+            for v in range(a.hull_n):
+                for k in range(3):
+                    a.hull[v][k] = float(hull[v][k])
         # colour descriptors (color_count 0 = none: the matcher skips its colour tests for this plane)
         a.color_count = int(pl.get("color_count", 0))
         if a.color_count > 0:

@@ -463,7 +463,8 @@ def _planes_to_dicts(arr, n):
                  center_hull=np.array(list(arr[i].center_hull), np.float32), hull_points=int(arr[i].hull_points),
                  color_count=int(arr[i].color_count), color_nrgb=np.array(list(arr[i].color_nrgb), np.float32),
                  color_dev=np.array(list(arr[i].color_dev), np.float32), intensity=float(arr[i].intensity),
-                 hist_h=np.array(list(arr[i].hist_h), np.float32))
+                 hist_h=np.array(list(arr[i].hist_h), np.float32),
+                 hull=np.array([list(arr[i].hull[v]) for v in range(max(0, min(int(arr[i].hull_n), 64)))], np.float32).reshape(-1, 3))
             for i in range(n)]
 
 

@@ -371,6 +371,7 @@ def test_full_size_4096x2048_with_planes(hip_lib, oracle_mod):
         exact, center, _nv = oracle_mod.f360_hull_stats(xyz, labels, p_d)
         assert 0.997 * exact <= p_d["area"] <= exact * (1 + 1e-5), (p_d["area"], exact)
         assert np.abs(p_d["center_hull"] - center).max() < 5e-3 and p_d["hull_points"] >= 3
+        _check_hull_polygon(p_d)
         checked += 1
     assert checked == 6
 
@@ -407,6 +408,20 @@ def test_hull_areas_read_the_room_at_2048x1024(hip_lib, oracle_mod):
     assert all(abs(a - 48.0) <= 2.0 for a in walls[0]), walls[0]          # the floor and the ceiling read 48 +- 2 m2
 
 
+def _check_hull_polygon(p, area_rtol=2e-3):
+    """The polygon a plane record carries (rgbd360_plane::hull, the role of mrpt::pbmap::Plane::polygonContourPtr): at most 64 vertices on the
+    fitted plane, convex, counter-clockwise seen from the side the normal points to, its area the record's (to the thinning of a hull of
+    more than 64 vertices) and its mass centre the record's center_hull."""
+    hv, n, c = p["hull"].astype(np.float64), p["normal"].astype(np.float64), p["centroid"].astype(np.float64)
+    assert 3 <= len(hv) <= 64 and len(hv) <= p["hull_points"]
+    assert np.abs((hv - c) @ n).max() < 1e-4 * max(1.0, np.abs(hv).max())
+    m = len(hv)
+    turns = [n @ np.cross(hv[(i + 1) % m] - hv[i], hv[(i + 2) % m] - hv[(i + 1) % m]) for i in range(m)]
+    assert min(turns) > -1e-9, min(turns)
+    area = 0.5 * abs(sum(n @ np.cross(hv[i] - hv[0], hv[(i + 1) % m] - hv[0]) for i in range(m)))
+    assert area <= p["area"] * (1 + 1e-5) and area >= p["area"] * (1 - (area_rtol if p["hull_points"] > 64 else 1e-5)), (area, p["area"], p["hull_points"])
+
+
 @pytest.mark.gpu
 def test_hull_stage_on_a_striped_image(hip_lib, oracle_mod):
     """The hull stage where EVERY other pixel is a boundary pixel: a fronto-parallel staircase, 4-pixel-wide stripes alternating between
@@ -430,6 +445,7 @@ def test_hull_stage_on_a_striped_image(hip_lib, oracle_mod):
         exact, center, _nv = oracle_mod.f360_hull_stats(xyz, labels, p)
         assert p["hull_points"] >= 4 and abs(p["area"] - exact) <= 1e-4 * exact, (p["area"], exact)
         assert np.abs(p["center_hull"] - center).max() < 1e-4
+        _check_hull_polygon(p)
 
 
 def _pingpong(n_pairs, n_unique):

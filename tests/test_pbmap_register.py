@@ -335,6 +335,76 @@ def test_merge_planes_pools_the_pieces_of_one_surface():
     assert pbmap.merge_planes([left, sliver], max_elongation=100.0)[0]["count"] == 2300
 
 
+def _poly_plane(poly_uv, origin, e1, e2, count, root, with_hull=True):
+    """Plane record of a uniformly sampled CONVEX polygon (vertices counter-clockwise in the (e1, e2) frame of the plane through `origin`):
+    exact-enough moments from a dense grid, the polygon itself as the record's hull."""
+    e1, e2, origin = np.asarray(e1, float), np.asarray(e2, float), np.asarray(origin, float)
+    n = np.cross(e1, e2)
+    P = np.asarray(poly_uv, float)
+    lo, hi = P.min(0), P.max(0)
+    g = np.stack(np.meshgrid(np.linspace(lo[0], hi[0], 601), np.linspace(lo[1], hi[1], 601), indexing="ij"), -1).reshape(-1, 2)
+    inside = np.ones(len(g), bool)
+    for a, b in zip(P, np.roll(P, -1, 0)):
+        inside &= (b[0] - a[0]) * (g[:, 1] - a[1]) - (b[1] - a[1]) * (g[:, 0] - a[0]) >= 0
+    q = g[inside]
+    c2 = q.mean(0)
+    C = np.cov((q - c2).T, bias=True)
+    w, V = np.linalg.eigh(C)
+    l1, l2 = w
+    c = origin + c2[0] * e1 + c2[1] * e2
+    flip = n @ c > 0                                         # the normal points towards the origin
+    nn = -n if flip else n
+    pd = V[0, 1] * e1 + V[1, 1] * e2
+    x, y = P[:, 0], P[:, 1]
+    cr = x * np.roll(y, -1) - np.roll(x, -1) * y
+    area = abs(cr.sum()) / 2
+    cu, cv = ((x + np.roll(x, -1)) * cr).sum() / (3 * cr.sum()), ((y + np.roll(y, -1)) * cr).sum() / (3 * cr.sum())
+    hull = np.array([origin + u * e1 + v * e2 for u, v in (P[::-1] if flip else P)], np.float32)
+    rec = dict(centroid=c.astype(np.float32), normal=nn.astype(np.float32), d=np.float32(-nn @ c), curvature=np.float32(1e-6), count=count, root=root,
+               area=np.float32(area), area_moment=np.float32(12 * np.sqrt(l1 * l2)), elongation=np.float32(np.sqrt(l2 / l1)), ppal_dir=pd.astype(np.float32),
+               center_hull=(origin + cu * e1 + cv * e2).astype(np.float32), hull_points=len(P), hull=hull)
+    if not with_hull:                                        # a caller-made record: moments only
+        rec.update(area=rec["area_moment"], hull_points=0, center_hull=rec["centroid"])
+        del rec["hull"]
+    return rec
+
+
+def test_merge_planes_tests_proximity_on_the_hull_polygons():
+    """Frame360::mergePlanes compares the planes' hull POLYGONS vertex by vertex and edge by edge (Frame360.h:680-711; mergePlane2 then hulls
+    the two contours again).  (1) The two bars of an L-shaped wall merge, and the merged record carries the convex hull of the L;
+    (2) a patch that pokes into the MOMENT rectangle of a large triangular region but stays 0.33 m clear of the triangle itself is
+    merged when the records carry moments only, and kept apart when they carry their polygons; (3) two patches 0.25 m apart along an
+    edge merge through the edge-to-edge distance although no two of their vertices are within 0.3 m."""
+    o, e1, e2 = np.array([-1.0, -1.5, 3.0]), np.array([1.0, 0, 0]), np.array([0, 1.0, 0])
+    bar_a = _poly_plane([(0, 0), (2, 0), (2, 1), (0, 1)], o, e1, e2, 2000, 5)
+    bar_b = _poly_plane([(0, 1), (1, 1), (1, 3), (0, 3)], o, e1, e2, 2000, 9)
+    out = pbmap.merge_planes([bar_a, bar_b])
+    assert len(out) == 1 and out[0]["count"] == 4000 and out[0]["root"] == 5
+    hull_l = np.array([(0, 0), (2, 0), (2, 1), (1, 3), (0, 3)], float)          # the convex hull of the L
+    x, y = hull_l[:, 0], hull_l[:, 1]
+    area_l = abs((x * np.roll(y, -1) - np.roll(x, -1) * y).sum()) / 2
+    assert abs(out[0]["area"] - area_l) < 1e-4 * area_l and len(out[0]["hull"]) == 5
+    got = {tuple(np.round([(v - o) @ e1, (v - o) @ e2], 4)) for v in out[0]["hull"].astype(float)}
+    assert got == {tuple(np.round(v, 4)) for v in hull_l}
+    n_out = out[0]["normal"].astype(float)                                         # counter-clockwise seen from the normal's side
+    hv = out[0]["hull"].astype(float)
+    assert all(n_out @ np.cross(hv[(i + 1) % 5] - hv[i], hv[(i + 2) % 5] - hv[(i + 1) % 5]) > 0 for i in range(5))
+    # (2) moments say "overlap", polygons say "0.33 m apart"
+    tri = [(0, 0), (9, 0), (0, 9)]
+    k = (4.5 + 0.33 / np.sqrt(2) + 0.01)
+    patch = [(k, k), (k + 0.5, k), (k + 0.5, k + 0.5), (k, k + 0.5)]
+    for with_hull, want in ((False, 1), (True, 2)):
+        t = _poly_plane(tri, o, e1, e2, 8000, 1, with_hull)
+        q = _poly_plane(patch, o, e1, e2, 300, 2, with_hull)
+        assert len(pbmap.merge_planes([t, q])) == want, with_hull
+    # (3) edge against edge: 4 m long neighbours, offset so that every vertex pair is > 0.3 m apart
+    long_a = _poly_plane([(0, 0), (4, 0), (4, 1), (0, 1)], o, e1, e2, 3000, 3)
+    long_b = _poly_plane([(1.5, 1.25), (2.5, 1.25), (2.5, 2.25), (1.5, 2.25)], o, e1, e2, 800, 4)
+    assert len(pbmap.merge_planes([long_a, long_b])) == 1
+    far_b = _poly_plane([(1.5, 1.35), (2.5, 1.35), (2.5, 2.35), (1.5, 2.35)], o, e1, e2, 800, 4)      # 0.35 m: stays apart
+    assert len(pbmap.merge_planes([long_a, far_b])) == 2
+
+
 def test_merge_planes_random_sets_match_the_numpy_restatement():
     rng = np.random.default_rng(8)
     for trial in range(20):
