@@ -331,6 +331,17 @@ typedef struct {
      * disc is lost).  hull_n = 0: the record carries no polygon (caller-made record, or no hull was formed). */
     int   hull_n;
     float hull[RGBD360_HULL_MAX][3];
+    /* The DOMINANT colour -- what mrpt::pbmap::Plane::calcMainColor2 leaves in v3colorNrgb / dominantIntensity (Frame360.h:1046): the plane's
+     * pixels thinned to about 2000 samples, then getMultiDimMeanShift_color: samples farther from the running mean than the norm of the
+     * standard deviation are dropped for good, until half the samples are gone or the mean stops moving (third-party; restated in integer
+     * arithmetic, so the CPU checker repeats it exactly).  On a surface of two colours (a poster on a wall) the mean lies between them and
+     * moves with the share of each in view; the dominant colour does not.  color_mode_count = samples it was sought over (0: none --
+     * no colour image, or a caller-made record: the matcher then compares color_nrgb / intensity), color_concentration = the share of the
+     * samples it ended on (MRPT's `concentration`). */
+    int   color_mode_count;
+    float color_mode[3];
+    float intensity_mode;
+    float color_concentration;
 } rgbd360_plane;
 
 /* Registers the colour image that goes with the organised cloud of the context's next plane calls (rgbd360_plane_fit,
@@ -338,7 +349,11 @@ typedef struct {
  * (r, c) takes the colour of image pixel (r * step + step / 2, c * step + step / 2) -- step 1 for a panorama or a full-resolution
  * sensor cloud, the down-sampling step for a down-sampled one (DownsampleRGBD.h:240, 285-287: the colour of the block's centre
  * pixel).  on_device = 0: rgb is host memory and is copied at once; 1: device memory that must stay valid through those calls.
- * The planes of a call whose cloud does not have (rows / step) x (cols / step) points come back without colour.  rgb = NULL clears. */
+ * The planes of a call whose cloud does not have (rows / step) x (cols / step) points come back without colour.  rgb = NULL clears.
+ * Channel order: the three bytes of a pixel are taken as R, G, B.  The descriptors of two planes are only ever compared channel by
+ * channel, so an image in OpenCV's B, G, R order (the reference's panorama, Frame360.h:594-596) gives the same matches -- with
+ * color_nrgb / color_mode channel-swapped and hist_h a mirrored hue circle relative to MRPT's; swap the channels first if the records
+ * are to be exchanged with an MRPT PbMap. */
 int rgbd360_set_plane_color_image(rgbd360_ctx* ctx, const uint8_t* rgb, size_t rgb_step, int rows, int cols, int step, int on_device);
 
 /* Planar regions of an organised cloud with normals: pcl::OrganizedMultiPlaneSegmentation::segment as configured at

@@ -416,6 +416,63 @@ def f360_plane_segment(xyz, normals, rows, cols, min_inliers=40, angular_thresho
     return labels.reshape(rows, cols), planes
 
 
+def f360_plane_colour_mode(labels, rgb, planes, step=1):
+    """The dominant colour of planar regions: mrpt::pbmap::Plane::calcMainColor2 (Frame360.h:1046; MRPT is third-party, restated from its
+    published source) as the library defines it in integer arithmetic (frame360_kernels.h k_f360_colour / k_f360_colour_mode):
+    the region's pixels with R + G + B > 0 on the grid rows r % sr == 0, columns c % sc == 0 (sr = isqrt(step), sc = step // sr,
+    step = max(count // 2000, 1), count = the region's inliers), normalised colour q = (C << 16) // S; then
+    getMultiDimMeanShift_color: mean = floor(sum q / n); threshold^2 = sum_k (floor(sum q_k^2 / N) - mean_k^2); while 2 n > N and the
+    mean moved by more than 0.001: drop the samples farther than the threshold for good, take the mean of the rest.
+    Returns a list of dicts color_mode_count / color_mode / intensity_mode / color_concentration / kept / iterations."""
+    lab = np.asarray(labels, np.int64)
+    rows, cols = lab.shape
+    rgb = np.asarray(rgb, np.uint8)
+    rr, cc = np.meshgrid(np.arange(rows), np.arange(cols), indexing="ij")
+    out = []
+    for p in planes:
+        m = lab == int(p["root"])
+        count = int(m.sum())
+        d = dict(color_mode_count=0, color_mode=np.zeros(3, np.float32), intensity_mode=0.0, color_concentration=0.0, kept=0, iterations=0)
+        st = max(count // 2000, 1)
+        sr = 1
+        while (sr + 1) * (sr + 1) <= st:
+            sr += 1
+        sc = st // sr
+        sel = m & (rr % sr == 0) & (cc % sc == 0)
+        px = rgb[rr[sel] * step + step // 2, cc[sel] * step + step // 2].astype(np.int64)
+        S = px.sum(1)
+        px, S = px[S > 0], S[S > 0]
+        N = len(S)
+        if N == 0 or N > 4096:      # (more than the device's sample capacity: which samples it keeps depends on arrival order -- not comparable)
+            d["color_mode_count"] = -1 if N > 4096 else 0
+            out.append(d)
+            continue
+        q = (px << 16) // S[:, None]
+        mean = q.sum(0) // N
+        thr2 = int(sum(max(int((q[:, k] * q[:, k]).sum() // N) - int(mean[k]) ** 2, 0) for k in range(3)))
+        alive = np.ones(N, bool)
+        n_alive, shift2, iters, sumS = N, None, 0, int(S.sum())
+        while 2 * n_alive > N and (shift2 is None or shift2 > 4294) and iters < 64:
+            d2 = ((q - mean) ** 2).sum(1)
+            alive &= ~(d2 > thr2)
+            iters += 1
+            left = int(alive.sum())
+            if left == 0:
+                n_alive = 0
+                break
+            new = q[alive].sum(0) // left
+            shift2 = int(((new - mean) ** 2).sum())
+            mean, n_alive, sumS = new, left, int(S[alive].sum())
+        if iters == 0 or n_alive == 0:
+            sumS = int(S.sum())
+            if n_alive == 0:
+                n_alive = N
+        d.update(color_mode_count=N, color_mode=(mean / 65536.0).astype(np.float32), intensity_mode=float(np.float32(sumS / n_alive)),
+                 color_concentration=float(np.float32(n_alive / N)), kept=n_alive, iterations=iters)
+        out.append(d)
+    return out
+
+
 def f360_plane_colour(labels, rgb, planes, step=1):
     """Colour descriptors of planar regions (oracle/frame360_ref.cpp oracle_f360_plane_colour; the roles of
     mrpt::pbmap::Plane::calcMainColor / calcPlaneHistH, Frame360.h:1045-1046).  labels: rows x cols root indices; rgb: the colour

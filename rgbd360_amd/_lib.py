@@ -44,7 +44,8 @@ class Plane(C.Structure):
                 ("count", C.c_int), ("root", C.c_int), ("area", C.c_float), ("elongation", C.c_float),
                 ("ppal_dir", C.c_float * 3), ("area_moment", C.c_float), ("center_hull", C.c_float * 3), ("hull_points", C.c_int),
                 ("color_count", C.c_int), ("color_nrgb", C.c_float * 3), ("color_dev", C.c_float * 3), ("intensity", C.c_float),
-                ("hist_h", C.c_float * 74), ("hull_n", C.c_int), ("hull", (C.c_float * 3) * 64)]
+                ("hist_h", C.c_float * 74), ("hull_n", C.c_int), ("hull", (C.c_float * 3) * 64),
+                ("color_mode_count", C.c_int), ("color_mode", C.c_float * 3), ("intensity_mode", C.c_float), ("color_concentration", C.c_float)]
 
 
 class PbmapParams(C.Structure):

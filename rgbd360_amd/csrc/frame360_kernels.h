@@ -1526,7 +1526,20 @@ __global__ void k_f360_mom_reduce(const unsigned long long* __restrict__ mom, co
 // ---------------------------------------------------------------------------------------------------------
 constexpr int kColSums = 8;          // sum qR, qG, qB | sum qR^2, qG^2, qB^2 | sum (R + G + B) | pixels with R + G + B > 0
 constexpr int kColBins = 74;
-constexpr int kColWords = kColSums + kColBins;      // 64-bit words per region in the global table
+constexpr int kColMode = 8;          // the dominant colour (k_f360_colour_mode): samples N | kept | mode qR, qG, qB | sum S over the kept | iterations | threshold^2
+constexpr int kColWords = kColSums + kColBins + kColMode;      // 64-bit words per region in the global table
+// calcMainColor2 (mrpt::pbmap::Plane, third-party; restated from the published source: the plane's points are thinned to about 2000 --
+// `stepColor = size / 2000` -- and getMultiDimMeanShift_color shrinks the sample set around its running mean until half is gone or the
+// mean stops moving).  Here the thinning is a regular grid over the region's pixels, rows r % sr == 0 and columns c % sc == 0 with
+// sr = isqrt(step), sc = step / sr, step = max(count / kModeTarget, 1): a SET of samples that does not depend on any order.
+constexpr int kModeTarget = 2000;
+constexpr int kModeCap = 4096;       // samples a region can hold (a grid over a connected region of `count` pixels yields about count / (sr sc) <= 1.25 kModeTarget)
+__host__ __device__ inline void mode_grid(int count, int& sr, int& sc) {
+    const int step = count / kModeTarget > 1 ? count / kModeTarget : 1;
+    sr = 1;
+    while ((sr + 1) * (sr + 1) <= step) ++sr;
+    sc = step / sr;
+}
 constexpr int kColPerThread = 8, kColHash = 16;
 struct ColourImage {
     const uint8_t* rgb;      // device, 3 bytes per pixel
@@ -1568,8 +1581,36 @@ __global__ void k_f360_colour_clear(const int* __restrict__ n_slots, int max_slo
     const int ns = min(*n_slots, max_slots);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ns * kColWords; i += gridDim.x * blockDim.x) col[i] = 0ull;
 }
+// (one block) where a region's samples start in the pool: exclusive prefix of min(count, kModeCap) over the slots; clears the sample counters
+__global__ __launch_bounds__(1024) void k_f360_colour_offsets(const int* __restrict__ n_slots, int max_slots, const int* __restrict__ count_of_slot,
+                                                               int* __restrict__ samp_off, int* __restrict__ samp_n) {
+    __shared__ int part[1024];
+    const int ns = min(*n_slots, max_slots);
+    const int per = (ns + 1023) / 1024, lo = threadIdx.x * per, hi = min(lo + per, ns);
+    int sum = 0;
+    for (int s2 = lo; s2 < hi; ++s2) sum += min(count_of_slot[s2], kModeCap);
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int t = 0; t < 1024; ++t) { const int v = part[t]; part[t] = run; run += v; }
+    }
+    __syncthreads();
+    int run = part[threadIdx.x];
+    for (int s2 = lo; s2 < hi; ++s2) {
+        samp_off[s2] = run;
+        samp_n[s2] = 0;
+        run += min(count_of_slot[s2], kModeCap);
+    }
+}
+struct ColourSamples {          // nullptr pool: no dominant colour is sought
+    const int* count_of_slot;
+    const int* samp_off;
+    int* samp_n;
+    unsigned* pool;             // R | G << 8 | B << 16 of the sampled pixels, region by region
+};
 __global__ __launch_bounds__(kAggThreads) void k_f360_colour(const int* __restrict__ label, const int* __restrict__ slot_of_root, int rows, int cols,
-                                                              ColourImage img, unsigned long long* __restrict__ col) {
+                                                              ColourImage img, unsigned long long* __restrict__ col, ColourSamples smp) {
     __shared__ int keys[kColHash];
     __shared__ unsigned long long sums[kColHash][kColSums];
     __shared__ unsigned bins[kColHash][kColBins];
@@ -1613,6 +1654,14 @@ __global__ __launch_bounds__(kAggThreads) void k_f360_colour(const int* __restri
         r360::divmod24(p, cols, r, c);
         const uint8_t* px = img.rgb + (size_t)(r * img.sub + img.sub / 2) * img.step + 3 * (size_t)(c * img.sub + img.sub / 2);
         const ColourPx v = colour_px(px[0], px[1], px[2]);
+        if (smp.pool && v.S) {                                // the dominant colour's sample grid (kModeTarget above)
+            int sr, sc;
+            mode_grid(smp.count_of_slot[slot], sr, sc);
+            if (r % sr == 0 && c % sc == 0) {
+                const int pos = atomicAdd(&smp.samp_n[slot], 1);
+                if (pos < kModeCap) smp.pool[smp.samp_off[slot] + pos] = (unsigned)px[0] | ((unsigned)px[1] << 8) | ((unsigned)px[2] << 16);
+            }
+        }
         if (slot != key) {
             flush_lane();
             key = slot;
@@ -1661,11 +1710,103 @@ __global__ __launch_bounds__(kAggThreads) void k_f360_colour(const int* __restri
         flush_lane();
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < kColHash * kColWords; i += kAggThreads) {
-        const int e = i / kColWords, w = i - e * kColWords;
+    constexpr int kColAcc = kColSums + kColBins;          // (the words this pass accumulates; the dominant colour's follow behind them)
+    for (int i = threadIdx.x; i < kColHash * kColAcc; i += kAggThreads) {
+        const int e = i / kColAcc, w = i - e * kColAcc;
         if (keys[e] < 0) continue;
         const unsigned long long v = w < kColSums ? sums[e][w] : (unsigned long long)bins[e][w - kColSums];
         if (v) atomicAdd(&col[(size_t)keys[e] * kColWords + w], v);
+    }
+}
+// The dominant colour of a region: getMultiDimMeanShift_color (MRPT, restated) on its samples, in INTEGER arithmetic so that the CPU checker
+// repeats it exactly whatever the order the samples arrived in: normalised colour q = (C << 16) / S as in colour_px,
+//   mean   = floor(sum q / n) per channel,   threshold^2 = sum over channels of (floor(sum q^2 / N) - mean^2)   (the norm of the std. dev.)
+//   while 2 n > N and |shift|^2 > (0.001 * 65536)^2:  drop the samples farther than the threshold from the mean (for good);
+//                                                     mean = that of the n left; shift = its move
+// One block per region slot; samples in LDS (16 bytes each).  Results into the region's row of the colour table (kColMode words).
+constexpr int kModeThreads = 256;
+__global__ __launch_bounds__(kModeThreads) void k_f360_colour_mode(const int* __restrict__ n_slots, int max_slots, ColourSamples smp,
+                                                                    unsigned long long* __restrict__ col) {
+    __shared__ uint4 sm[kModeCap];                 // {qR, qG, qB, S | alive << 31}
+    __shared__ unsigned long long acc[8];
+    const int ns = min(*n_slots, max_slots);
+    for (int slot = blockIdx.x; slot < ns; slot += gridDim.x) {
+        const int N = min(smp.samp_n[slot], kModeCap);
+        unsigned long long* out = col + (size_t)slot * kColWords + kColSums + kColBins;
+        if (N <= 0) {
+            if (threadIdx.x < kColMode) out[threadIdx.x] = 0ull;
+            continue;
+        }
+        __syncthreads();
+        if (threadIdx.x < 8) acc[threadIdx.x] = 0ull;
+        __syncthreads();
+        unsigned long long s1[3] = {0, 0, 0}, s2[3] = {0, 0, 0};
+        for (int i = threadIdx.x; i < N; i += kModeThreads) {
+            const unsigned w = smp.pool[smp.samp_off[slot] + i];
+            const ColourPx v = colour_px(w & 255u, (w >> 8) & 255u, (w >> 16) & 255u);
+            sm[i] = make_uint4(v.q[0], v.q[1], v.q[2], v.S | 0x80000000u);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { s1[k] += v.q[k]; s2[k] += (unsigned long long)v.q[k] * v.q[k]; }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { atomicAdd(&acc[k], s1[k]); atomicAdd(&acc[3 + k], s2[k]); }
+        __syncthreads();
+        long long m[3];
+        unsigned long long thr2 = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            m[k] = (long long)(acc[k] / (unsigned long long)N);
+            const long long var = (long long)(acc[3 + k] / (unsigned long long)N) - m[k] * m[k];
+            thr2 += (unsigned long long)(var > 0 ? var : 0);
+        }
+        int n_alive = N, iters = 0;
+        unsigned long long shift2 = ~0ull, sumS = 0;
+        const unsigned long long conv2 = 4294ull;          // floor((0.001 * 65536)^2)
+        for (;;) {
+            __syncthreads();                               // everybody has read acc / the loop state is uniform
+            if (!(2 * (long long)n_alive > N && shift2 > conv2) || iters >= 64) break;
+            if (threadIdx.x < 8) acc[threadIdx.x] = 0ull;
+            __syncthreads();
+            unsigned long long t1[3] = {0, 0, 0}, tS = 0, tn = 0;
+            for (int i = threadIdx.x; i < N; i += kModeThreads) {
+                uint4 e = sm[i];
+                if (!(e.w & 0x80000000u)) continue;
+                const long long d0 = (long long)e.x - m[0], d1 = (long long)e.y - m[1], d2 = (long long)e.z - m[2];
+                if ((unsigned long long)(d0 * d0 + d1 * d1 + d2 * d2) > thr2) {
+                    sm[i].w = e.w & 0x7fffffffu;           // erased for good
+                    continue;
+                }
+                t1[0] += e.x; t1[1] += e.y; t1[2] += e.z; tS += e.w & 0x7fffffffu; ++tn;
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) atomicAdd(&acc[k], t1[k]);
+            atomicAdd(&acc[3], tS);
+            atomicAdd(&acc[4], tn);
+            __syncthreads();
+            ++iters;
+            const long long left = (long long)acc[4];
+            if (left == 0) { n_alive = 0; break; }         // (every sample beyond the threshold: the mean stands)
+            shift2 = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const long long mk = (long long)(acc[k] / (unsigned long long)left);
+                shift2 += (unsigned long long)((mk - m[k]) * (mk - m[k]));
+                m[k] = mk;
+            }
+            n_alive = (int)left;
+            sumS = acc[3];
+        }
+        if (iters == 0 || n_alive == 0) {                  // no shrink step ran (N == 1 ...) or it emptied the set: the plain mean over all samples
+            unsigned long long tS = 0;
+            for (int i = 0; i < N; ++i) tS += sm[i].w & 0x7fffffffu;      // (uniform, rare)
+            sumS = tS;
+            if (n_alive == 0) n_alive = N;
+        }
+        if (threadIdx.x == 0) {
+            out[0] = (unsigned long long)N; out[1] = (unsigned long long)n_alive;
+            out[2] = (unsigned long long)m[0]; out[3] = (unsigned long long)m[1]; out[4] = (unsigned long long)m[2];
+            out[5] = sumS; out[6] = (unsigned long long)iters; out[7] = thr2;
+        }
     }
 }
 // the table rows of the slots in use -> pinned host memory, behind the plane list's other records (one wait ends the call)

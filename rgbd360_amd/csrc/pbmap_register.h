@@ -129,9 +129,13 @@ struct Matcher {
     // their saturated-hue histograms (Bhattacharyya distance).  Planes without colour (color_count = 0) pass.
     bool eval_color(const rgbd360_plane& a, const rgbd360_plane& b) const {
         if (!P->use_color || a.color_count <= 0 || b.color_count <= 0) return true;
+        // the DOMINANT colour where both records carry one (what calcMainColor2 leaves in v3colorNrgb / dominantIntensity), else the mean
+        const bool mode = a.color_mode_count > 0 && b.color_mode_count > 0;
+        const float *ca = mode ? a.color_mode : a.color_nrgb, *cb = mode ? b.color_mode : b.color_nrgb;
+        const double ia = mode ? a.intensity_mode : a.intensity, ib = mode ? b.intensity_mode : b.intensity;
         for (int k = 0; k < 3; ++k)
-            if (!(fabs((double)a.color_nrgb[k] - b.color_nrgb[k]) < P->color_threshold)) return false;
-        if (P->intensity_threshold > 0 && !(fabs((double)a.intensity - b.intensity) < P->intensity_threshold)) return false;
+            if (!(fabs((double)ca[k] - cb[k]) < P->color_threshold)) return false;
+        if (P->intensity_threshold > 0 && !(fabs(ia - ib) < P->intensity_threshold)) return false;
         if (P->hue_threshold > 0) {
             double bc = 0;
             for (int k = 0; k < 74; ++k) bc += sqrt((double)a.hist_h[k] * (double)b.hist_h[k]);
@@ -625,6 +629,19 @@ inline void pool_colour(rgbd360_plane& dst, const rgbd360_plane& a, const rgbd36
             dst.color_dev[k] = (float)sqrt(std::max(var, 0.0));
         }
         dst.intensity = (float)((na * a.intensity + nb * b.intensity) / (na + nb));
+    }
+    // the dominant colour of the pooled inliers: mergePlane2 runs calcMainColor2 again on them; the records no longer hold the samples, so
+    // the mode of the piece with more samples on its mode stands for it (two pieces of one surface share their dominant colour)
+    {
+        const double ka = a.color_mode_count > 0 ? (double)a.color_mode_count * a.color_concentration * std::max(a.count, 1) / std::max(a.color_mode_count, 1) : 0;
+        const double kb = b.color_mode_count > 0 ? (double)b.color_mode_count * b.color_concentration * std::max(b.count, 1) / std::max(b.color_mode_count, 1) : 0;
+        const rgbd360_plane* w = ka >= kb ? &a : &b;
+        if (ka > 0 || kb > 0) {
+            dst.color_mode_count = a.color_mode_count + b.color_mode_count;
+            for (int k = 0; k < 3; ++k) dst.color_mode[k] = w->color_mode[k];
+            dst.intensity_mode = w->intensity_mode;
+            dst.color_concentration = (float)(std::max(ka, kb) / std::max((double)std::max(a.count, 0) + std::max(b.count, 0), 1.0));
+        }
     }
     const double ca = a.color_count > 0 ? std::max(a.count, 0) : 0, cb = b.color_count > 0 ? std::max(b.count, 0) : 0;
     if (ca + cb > 0)

@@ -99,6 +99,9 @@ struct rgbd360_ctx {
     f360::ColourImage f_col_img = {nullptr, 0, 1};
     int f_col_rows = 0, f_col_cols = 0;                           // size of the registered image
     unsigned long long *f_col = nullptr, *f_col_host = nullptr;   // [kF360MaxSlots][kColWords]: device table, pinned copy of the rows in use
+    int *f_samp_off = nullptr, *f_samp_n = nullptr;               // the dominant colour's samples: where a slot's start in the pool, how many arrived
+    unsigned* f_samp_pool = nullptr;                              // one entry per pixel of the largest frame seen
+    size_t f_samp_pool_n = 0;
     bool f_col_ran = false;                                       // the last plane call filled f_col_host
     unsigned* f_ticket = nullptr;                                 // device counter of k_f360_hull_pack's blocks (the last one publishes the host tag)
     unsigned long long* b_sum = nullptr;                          // bilateral grid: fixed-point sums, counts, two float2 ping-pong arrays
@@ -750,7 +753,8 @@ void rgbd360_destroy(rgbd360_ctx* ctx) {
     hipFree(ctx->f_root_of_slot); hipFree(ctx->f_nslots); hipFree(ctx->f_window); hipFree(ctx->f_mom); hipFree(ctx->f_ticket);
     hipFree(ctx->f_count_of_slot); hipFree(ctx->f_depth_raw); hipFree(ctx->f_pack);
     if (ctx->f_pack_host) hipHostFree(ctx->f_pack_host);
-    hipFree(ctx->f_col_owned); hipFree(ctx->f_col);
+    hipFree(ctx->f_col_owned); hipFree(ctx->f_col); hipFree(ctx->f_samp_off); hipFree(ctx->f_samp_n); hipFree(ctx->f_samp_pool);
+    ctx->f_samp_off = ctx->f_samp_n = nullptr; ctx->f_samp_pool = nullptr; ctx->f_samp_pool_n = 0;
     if (ctx->f_col_host) hipHostFree(ctx->f_col_host);
     ctx->f_col_owned = nullptr; ctx->f_col = nullptr; ctx->f_col_host = nullptr; ctx->f_col_owned_bytes = 0;
     hipFree(ctx->f_models);
@@ -2198,9 +2202,22 @@ bool launch_colour(rgbd360_ctx* ctx, int rows, int cols) {
     if (!ctx->f_col && hipMalloc(&ctx->f_col, bytes) != hipSuccess) return false;
     if (!ctx->f_col_host && hipHostMalloc((void**)&ctx->f_col_host, bytes, hostwait::kPublishedFlags) != hipSuccess) return false;
     const int n = rows * cols;
+    // the dominant colour's sample pool (one entry per pixel bounds the sum of min(count, kModeCap) over the regions)
+    if (!ctx->f_samp_off && hipMalloc(&ctx->f_samp_off, kF360MaxSlots * sizeof(int)) != hipSuccess) return false;
+    if (!ctx->f_samp_n && hipMalloc(&ctx->f_samp_n, kF360MaxSlots * sizeof(int)) != hipSuccess) return false;
+    if (ctx->f_samp_pool_n < (size_t)n) {
+        hipFree(ctx->f_samp_pool);
+        ctx->f_samp_pool = nullptr;
+        ctx->f_samp_pool_n = 0;
+        if (hipMalloc(&ctx->f_samp_pool, (size_t)n * sizeof(unsigned)) != hipSuccess) return false;
+        ctx->f_samp_pool_n = (size_t)n;
+    }
+    const ColourSamples smp = {ctx->f_count_of_slot, ctx->f_samp_off, ctx->f_samp_n, ctx->f_samp_pool};
     hipLaunchKernelGGL(k_f360_colour_clear, dim3(64), dim3(256), 0, ctx->stream, ctx->f_nslots, kF360MaxSlots, ctx->f_col);
+    hipLaunchKernelGGL(k_f360_colour_offsets, dim3(1), dim3(1024), 0, ctx->stream, ctx->f_nslots, kF360MaxSlots, ctx->f_count_of_slot, ctx->f_samp_off, ctx->f_samp_n);
     hipLaunchKernelGGL(k_f360_colour, dim3((n + kAggThreads * kColPerThread - 1) / (kAggThreads * kColPerThread)), dim3(kAggThreads), 0, ctx->stream,
-                       ctx->f_label, ctx->f_slot_of_root, rows, cols, im, ctx->f_col);
+                       ctx->f_label, ctx->f_slot_of_root, rows, cols, im, ctx->f_col, smp);
+    hipLaunchKernelGGL(k_f360_colour_mode, dim3(256), dim3(kModeThreads), 0, ctx->stream, ctx->f_nslots, kF360MaxSlots, smp, ctx->f_col);
     hipLaunchKernelGGL(k_f360_colour_pack, dim3(64), dim3(256), 0, ctx->stream, ctx->f_col, ctx->f_nslots, kF360MaxSlots, ctx->f_col_host);
     ctx->f_col_ran = true;
     return true;
@@ -2211,6 +2228,9 @@ void apply_colour(const rgbd360_ctx* ctx, rgbd360_plane& P, int slot) {
     for (int k = 0; k < 3; ++k) P.color_nrgb[k] = P.color_dev[k] = 0.f;
     P.intensity = 0.f;
     for (int k = 0; k < 74; ++k) P.hist_h[k] = 0.f;
+    P.color_mode_count = 0;
+    for (int k = 0; k < 3; ++k) P.color_mode[k] = 0.f;
+    P.intensity_mode = P.color_concentration = 0.f;
     if (!ctx->f_col_ran) return;
     const volatile unsigned long long* w = ctx->f_col_host + (size_t)slot * f360::kColWords;
     const double n = (double)w[7];
@@ -2228,6 +2248,13 @@ void apply_colour(const rgbd360_ctx* ctx, rgbd360_plane& P, int slot) {
         P.intensity = (float)((double)w[6] / n);
     }
     for (int k = 0; k < f360::kColBins; ++k) P.hist_h[k] = (float)((double)w[f360::kColSums + k] / (double)total);
+    const volatile unsigned long long* md = w + f360::kColSums + f360::kColBins;      // k_f360_colour_mode: N, kept, mode q (3), sum S, iterations, threshold^2
+    if (md[0] > 0 && md[1] > 0) {
+        P.color_mode_count = (int)md[0];
+        for (int k = 0; k < 3; ++k) P.color_mode[k] = (float)((double)md[2 + k] / 65536.0);
+        P.intensity_mode = (float)((double)md[5] / (double)md[1]);
+        P.color_concentration = (float)((double)md[1] / (double)md[0]);
+    }
 }
 
 // regions of (ctx->f_xyz, ctx->f_normals) -> labels (device ctx->f_label) + plane list (host)

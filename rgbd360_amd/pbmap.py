@@ -61,6 +61,12 @@ def planes_to_array(planes):
             if hh is not None:
                 for k in range(74):
                     a.hist_h[k] = float(hh[k])
+            a.color_mode_count = int(pl.get("color_mode_count", 0))        # the dominant colour (0: the matcher compares the means)
+            if a.color_mode_count > 0:
+                for k in range(3):
+                    a.color_mode[k] = float(pl["color_mode"][k])
+                a.intensity_mode = float(pl.get("intensity_mode", pl.get("intensity", 0.0)))
+                a.color_concentration = float(pl.get("color_concentration", 1.0))
     return arr
 
 

@@ -464,7 +464,9 @@ def _planes_to_dicts(arr, n):
                  color_count=int(arr[i].color_count), color_nrgb=np.array(list(arr[i].color_nrgb), np.float32),
                  color_dev=np.array(list(arr[i].color_dev), np.float32), intensity=float(arr[i].intensity),
                  hist_h=np.array(list(arr[i].hist_h), np.float32),
-                 hull=np.array([list(arr[i].hull[v]) for v in range(max(0, min(int(arr[i].hull_n), 64)))], np.float32).reshape(-1, 3))
+                 hull=np.array([list(arr[i].hull[v]) for v in range(max(0, min(int(arr[i].hull_n), 64)))], np.float32).reshape(-1, 3),
+                 color_mode_count=int(arr[i].color_mode_count), color_mode=np.array(list(arr[i].color_mode), np.float32),
+                 intensity_mode=float(arr[i].intensity_mode), color_concentration=float(arr[i].color_concentration))
             for i in range(n)]
 
 
