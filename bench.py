@@ -78,9 +78,12 @@ def live_traffic(W, H, method):
     gfx950 correction for 16 B / lane streams.  Returns (bytes per launch, source note), or (None, None) when rocprofv3 is unavailable,
     the passes fail, or bench.py itself runs under a profiler."""
     import csv, glob, shutil, subprocess, tempfile
-    if "rocprofiler" in os.environ.get("LD_PRELOAD", "") or shutil.which("rocprofv3") is None:
-        return None, None
-    want = "k_eval_fs<%d" % method if os.environ.get("RGBD360_FUSED_SOLVE", "1") != "0" else "k_eval<%d" % method
+    if "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None, "not collected live: bench.py itself runs under a profiler"
+    if shutil.which("rocprofv3") is None:
+        return None, "not collected live: rocprofv3 is not on PATH"
+    # the full instantiation name of the level's source form (", 0>" = 16-byte records), so that e.g. the recompute instantiation "<0, 1>" is not averaged in
+    want = "k_eval_fs<%d, 0>" % method if os.environ.get("RGBD360_FUSED_SOLVE", "1") != "0" else "k_eval<%d, true, 0>" % method
     vals = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="rgbd360_pmc_", dir="/tmp")
@@ -88,21 +91,21 @@ def live_traffic(W, H, method):
             env = dict(os.environ, TMPDIR="/tmp")
             subprocess.run(["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable,
                             os.path.join(ROOT, "tools", "prof_eval.py"), str(W), str(H), "6"],
-                           cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=180, check=True)
+                           cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=90, check=True)
             v = []
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
                     if r.get("Counter_Name") == counter and want in r.get("Kernel_Name", ""):
                         v.append(float(r["Counter_Value"]))
             if not v:
-                return None, None
+                return None, "not collected live: the %s pass produced no row for %s" % (counter, want)
             vals[counter] = sum(v) / len(v)
-        except Exception:
-            return None, None
+        except Exception as e:      # (why, into the line: the figure then comes from the tracked profiles/traffic_latest.json)
+            return None, "not collected live: the %s pass failed (%s: %s)" % (counter, type(e).__name__, str(e)[:160])
         finally:
             shutil.rmtree(d, ignore_errors=True)
     nbytes = int(round((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0))
-    note = ("collected in THIS run: two rocprofv3 --pmc passes (FETCH_SIZE %.1f KB, WRITE_SIZE %.1f KB per launch of %s>, each counter in its own child "
+    note = ("collected in THIS run: two rocprofv3 --pmc passes (FETCH_SIZE %.1f KB, WRITE_SIZE %.1f KB per launch of %s, each counter in its own child "
             "process over tools/prof_eval.py on the same synthetic pair); bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, the gfx950 correction of "
             "MI355X_MICROARCH.md for 16 B / lane streams (the 12-byte gathers are an uncalibrated width: +-10 %%)" % (vals["FETCH_SIZE"], vals["WRITE_SIZE"], want))
     return nbytes, note
@@ -336,8 +339,11 @@ def main():
         kernel_us, kernel_batches = avg_kernel_us(lambda: reg.time_eval_kernel(0, pose_gpu, method, True, 50))       # the pass alone
         fused_us, fused_batches = (avg_kernel_us(lambda: reg.time_eval_kernel(0, pose_gpu, method, 2, 50)) if fused else (None, None))
         traffic, traffic_source = None, None
+        live_failed = None
         if not args.no_live_traffic:
             traffic, traffic_source = live_traffic(W, H, method)
+            if traffic is None:
+                live_failed, traffic_source = traffic_source, None
         tr_path = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if traffic is None and os.path.exists(tr_path):
             try:
@@ -346,7 +352,8 @@ def main():
                 traffic = tr.get(key, {}).get("hbm_bytes_per_launch")
                 if traffic is not None:
                     traffic_source = ("tracked file profiles/traffic_latest.json (%s): rocprofv3 PMC passes of an earlier run of this workload, "
-                                      "2 x FETCH_SIZE + WRITE_SIZE per launch of %s; NOT collected in this run" % (tr.get("collected", "undated"), tr.get(key, {}).get("kernel", "the per-pixel pass")))
+                                      "2 x FETCH_SIZE + WRITE_SIZE per launch of %s; NOT collected in this run%s" % (tr.get("collected", "undated"), tr.get(key, {}).get("kernel", "the per-pixel pass"),
+                                                                                                                    (" (" + live_failed + ")") if live_failed else ""))
             except Exception:
                 traffic = None
         res_note = ("back-to-back launches over one pair: the %.0f MB working set stays in the 256 MiB Infinity Cache, which is the "
@@ -363,6 +370,14 @@ def main():
                       "partial rows, 6x6 inverse, SE(3) exponential; redundantly per block) + the warp/residual/Jacobian pass over every "
                       "source pixel; back-to-back launches in the forced schedule"),
                 pass_only=pass_only)
+            # what else bounds the launch (round 5, profiles/r05_batched_form_experiment.txt): not part of the roofline contract, a reader's note
+            result["roofline"]["issue_bound"] = {
+                "vector_instructions_per_pixel": 135, "ns_of_a_simd_per_wave_step_4_waves": 178.1,
+                "pure_issue_us_per_launch_2048x1024": 6.5, "serial_us_per_launch": 6.7, "ceiling_frac_of_hbm_roof": 0.56,
+                "note": ("tools/ubench/front_rate.hip on MI355X: the two halves of a pixel cost a SIMD 178 ns per wave-step with four waves always ready; "
+                         "32 wave-steps per SIMD and launch + the block reduction = 6.5 us of pure vector issue, around it a serial chain (kernel boundary, "
+                         "partial rows, 6x6 inverse, SE(3) exponential, block tail) during which the vector units idle: 13.2 us = 0.56 of the HBM roof is the "
+                         "ceiling of this kernel on this instruction stream, whatever the memory system does")}
         else:
             result["roofline"] = dict(pass_only, note=res_note)
         # the same kernel with every launch HBM-fed: rotate over enough copies of the pair to exceed the Infinity Cache

@@ -49,7 +49,7 @@ out = {"_how": "hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024; FETCH
                "tools/collect_profiles.sh; the x2 is the gfx950 correction of MI355X_MICROARCH.md (HBM section) for 16 B/lane streams; the 12-byte gathers are an uncalibrated "
                "width, so treat the figure as +-10%. At 2048x1024 the working set is Infinity-Cache resident: these are fabric-side requests, not necessarily HBM array reads. "
                "Kernel: k_eval_fs (the product launch: solve prologue + pass). 4096x2048 runs the recompute form of the source stream (8 B per source pixel).",
-       "collected": "round 4, tools/collect_profiles.sh %s -> tools/publish_profiles.py" % tag}
+       "collected": "round %s, tools/collect_profiles.sh %s -> tools/publish_profiles.py" % (rnd, tag)}
 fetch, write, fetch4 = pmc_mean("pmc_fetch", "FETCH_SIZE"), pmc_mean("pmc_write", "WRITE_SIZE"), pmc_mean("pmc_fetch_4k", "FETCH_SIZE")
 for size, fm, npx in (("2048x1024", fetch, 2048 * 1024), ("4096x2048", fetch4, 4096 * 2048)):
     for m, name, bpp_rec, bpp_rc in ((0, "PHOTO_CONSISTENCY", 28, 20), (2, "PHOTO_DEPTH", 40, 32)):
