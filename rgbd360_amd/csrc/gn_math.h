@@ -143,10 +143,20 @@ GN_HD inline bool inverse6(const float* M, float* inv) {
 // sin(a)/a and (1-cos(a))/a^2 in float64.  On the device small angles (every Gauss-Newton update is one) use the
 // Maclaurin series to full double accuracy instead of the library's argument-reduction sin/cos; the result is cast
 // to float32 by the caller (RPI.h:4697), far above any difference in the last double bits.
+GN_HD inline void sinc_cosc_sq(double x2, double& a, double& b);
 GN_HD inline void sinc_cosc(double angle, double& a, double& b) {
 #if defined(__HIP_DEVICE_COMPILE__)
     if (angle < 0.5) {
-        const double x2 = angle * angle;
+        sinc_cosc_sq(angle * angle, a, b);
+        return;
+    }
+#endif
+    a = sin(angle) / angle;
+    b = (1 - cos(angle)) / (angle * angle);
+}
+// the same for x2 = angle^2 < 0.25 (Maclaurin series, full double accuracy)
+GN_HD inline void sinc_cosc_sq(double x2, double& a, double& b) {
+    {
         // sin(x)/x = sum (-1)^k x^2k/(2k+1)!,  (1-cos x)/x^2 = sum (-1)^k x^2k/(2k+2)!   (k <= 9: x^18 < 4e-6^... 1e-22 rel)
         double sa = 1.0 / 121645100408832000.0;      // 1/19!
         sa = -sa * x2 + 1.0 / 355687428096000.0;     // 1/17!
@@ -170,11 +180,7 @@ GN_HD inline void sinc_cosc(double angle, double& a, double& b) {
         cb = -cb * x2 + 0.5;
         a = sa;
         b = cb;
-        return;
     }
-#endif
-    a = sin(angle) / angle;
-    b = (1 - cos(angle)) / (angle * angle);
 }
 
 // E = [ Rodrigues(v[3..5])  v[0..2] ; 0 0 0 1 ], float64, column-major.

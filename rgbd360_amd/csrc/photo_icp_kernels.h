@@ -875,11 +875,12 @@ __device__ __forceinline__ bool lu_inverse6_lanes(const float* M /*LDS, column-m
 #pragma unroll
     for (int r = 0; r < 6; ++r) a[r] = lane < 6 ? M[lane * 6 + r] : ((lane - 6) == r ? 1.f : 0.f);
     bool ok = true;
+    float rk[6];                    // reciprocals of the six pivots (wave-uniform): the elimination's multipliers AND the back substitution's divisors
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
         float ck[6];
 #pragma unroll
-        for (int r = 0; r < 6; ++r) ck[r] = bcast(a[r], k);
+        for (int r = k; r < 6; ++r) ck[r] = bcast(a[r], k);      // (rows above k are finished: round 5 stopped broadcasting them)
         // Pivot search on the SCALAR unit: the column's six values are wave-uniform (v_readlane results), and for finite values
         // |x| > |y| is the unsigned comparison of their bit patterns without the sign -- integer compares and selects the scalar ALU
         // does beside the vector pipe (as float compares they were 15 v_cmp + 30 v_cndmask of the solve's one busy wave).  Same pivot as
@@ -895,28 +896,34 @@ __device__ __forceinline__ bool lu_inverse6_lanes(const float* M /*LDS, column-m
             }
         }
         if (best == 0u) ok = false;
+        // the row swap under a SCALAR branch (piv is wave-uniform): plain register swaps in the one arm that runs -- as selects over every
+        // candidate row they were 70 of the inverse's 285 vector instructions, each a link of the launch's longest dependent chain
+        const int pv = __builtin_amdgcn_readfirstlane(piv);
+        if (pv != k) {              // (normal equations: the diagonal entry is the pivot more often than not -- one scalar test then)
 #pragma unroll
-        for (int r = k + 1; r < 6; ++r)
-            if (piv == r) {
-                float t = a[k]; a[k] = a[r]; a[r] = t;
-                t = ck[k]; ck[k] = ck[r]; ck[r] = t;
-            }
+            for (int r = k + 1; r < 6; ++r)
+                if (pv == r) {
+                    asm volatile("v_swap_b32 %0, %1" : "+v"(a[k]), "+v"(a[r]));      // (an asm statement is not if-converted into selects)
+                    const float t = ck[k]; ck[k] = ck[r]; ck[r] = t;
+                }
+        }
         // multipliers l = c_r / c_k through ONE exact reciprocal per step (the five IEEE division sequences were the longest
         // dependent chain of the kernel); l differs from the quotient by at most one rounding
-        const float rk = rcp_rn(ck[k]);
+        rk[k] = rcp_rn(ck[k]);
 #pragma unroll
         for (int r = k + 1; r < 6; ++r) {
-            const float l = ck[r] * rk;
+            const float l = ck[r] * rk[k];
             if (lane > k) a[r] -= l * a[k];
         }
     }
-    // back substitution on the right-hand-side lanes: U[r][c] is row r of lane c
+    // back substitution on the right-hand-side lanes: U[r][c] is row r of lane c; U[r][r] is step r's pivot (row r is final once step r
+    // has run: later steps swap and update rows below it only), so 1 / U[r][r] is the reciprocal that step already formed
 #pragma unroll
     for (int r = 5; r >= 0; --r) {
         float sacc = a[r];
 #pragma unroll
         for (int c = r + 1; c < 6; ++c) sacc -= bcast(a[r], c) * x[c];
-        x[r] = sacc * rcp_rn(bcast(a[r], r));
+        x[r] = sacc * rk[r];
     }
     return ok;
 }
@@ -1120,10 +1127,16 @@ __device__ __forceinline__ void solve_waves(SolveShared& sh, const SolveCfg& cfg
             // assembles element (i,j) of the 4x4
             const double ux = (double)bcast(upd, 0), uy = (double)bcast(upd, 1), uz = (double)bcast(upd, 2);
             const double wx = (double)bcast(upd, 3), wy = (double)bcast(upd, 4), wz = (double)bcast(upd, 5);
-            const double angle = sqrt(wx * wx + wy * wy + wz * wz);
+            // sin(a)/a and (1 - cos a)/a^2 are series in a^2: no square root on the launch's critical path for the angles a Gauss-Newton
+            // update has (round 5; a^2 < 0.25: the Maclaurin branch of gn::sinc_cosc, to which a^2 is handed directly -- it differs from
+            // sqrt(a^2)^2 by an ulp of a double, invisible behind the cast to float32 of RPI.h:4697)
+            const double theta_sq = wx * wx + wy * wy + wz * wz;
             double ca = 0.0, cb = 0.0;
-            const bool rot = angle >= 128 * 2.220446049250313e-16;
-            if (rot) gn::sinc_cosc(angle, ca, cb);
+            const bool rot = theta_sq >= (128 * 2.220446049250313e-16) * (128 * 2.220446049250313e-16);
+            if (rot) {
+                if (theta_sq < 0.25) gn::sinc_cosc_sq(theta_sq, ca, cb);
+                else gn::sinc_cosc(sqrt(theta_sq), ca, cb);
+            }
             if (lane < 16) {
                 const int i = lane & 3, j = lane >> 2;
                 double e = (i == j) ? 1.0 : 0.0;
