@@ -229,10 +229,6 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_occ(LevelDev lv, EvalCons
     const int b = blockIdx.x;
     const int base = b * chunk;
     const int end = min(base + chunk, lv.n);
-    if (st->done || st->level_active != level) return;
-    const PoseRT T = load_pose(st->cand);
-    const WarpConsts wc = make_warp_consts(T, lv);
-
     EvalAcc A;
 #pragma unroll
     for (int k = 0; k < 27; ++k) A.acc[k] = 0.f;
@@ -256,6 +252,12 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_occ(LevelDev lv, EvalCons
         p.info = (unsigned)runinfo[p.ic];
         return p;
     };
+    // the first source records and run bytes do not depend on the pose: requested before the state (gate, pose) is read, so that their
+    // round trip and the state's overlap (a coarse-level pass is one step: a chain of round trips and nothing else)
+    Pre pre = preload(0);
+    if (st->done || st->level_active != level) return;
+    const PoseRT T = load_pose(st->cand);
+    const WarpConsts wc = make_warp_consts(T, lv);
     struct Stage { float X, Y, Z, rho2, d2, sw; unsigned info; int ic, hd_raw; F3 tp, td; };
     auto warp_issue = [&](const Pre& p) {
         Stage w;
@@ -272,7 +274,6 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_occ(LevelDev lv, EvalCons
         w.ic = p.ic;
         return w;
     };
-    Pre pre = preload(0);
     Stage nxt = warp_issue(pre);
     if (n_steps > 1) pre = preload(1);
     for (int k = 0; k < n_steps; ++k) {

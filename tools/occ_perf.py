@@ -13,6 +13,6 @@ reg.setSourceFrame(rgbB, dB)
 for occ, m in ((0, 2), (1, 2), (2, 0), (2, 2)):
     reg.alignFrames360(np.eye(4), m, occ)
     t0 = time.perf_counter()
-    for _ in range(5): rc = reg.alignFrames360(np.eye(4), m, occ)
-    dt = (time.perf_counter() - t0) / 5
-    print("occlusion %d method %d: %.2f ms/alignment, iters %s, rc %d, err vs gt %s" % (occ, m, dt * 1e3, reg.num_iterations, rc, synth.pose_error(reg.getOptimalPose(), T)))
+    for _ in range(20): rc = reg.alignFrames360(np.eye(4), m, occ)
+    dt = (time.perf_counter() - t0) / 20
+    print("occlusion %d method %d: %.4f ms/alignment, iters %s, rc %d, err vs gt %s" % (occ, m, dt * 1e3, reg.num_iterations, rc, synth.pose_error(reg.getOptimalPose(), T)))
