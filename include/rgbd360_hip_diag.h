@@ -32,7 +32,9 @@ int rgbd360_forced_iters_batch(rgbd360_ctx* ctx, int n_pairs, const uint8_t* rgb
                                float* pass_avg_us);
 /* One solve on a hand-made partial table (row 0 = `row`: 21 upper-triangle terms of H, 6 of g, the two error sums, the three
  * counts; every other row zero) at the identity pose on `level`, through the two-launch form (fused = 0: k_solve) or the fused form
- * (fused = 1: the prologue of k_eval_fs; the state is read as that launch leaves it).  Drives the state-machine paths real images hardly ever reach (ILL-POSED).
+ * (fused = 1: the prologue of k_eval_fs; the state is read as that launch leaves it; fused = 2: the same with the row at table row 40
+ * and a launch that was told to expect one pending row -- the device checks the host's bound and fetches the rest, same result; needs
+ * a level of more than 40 block rows).  Drives the state-machine paths real images hardly ever reach (ILL-POSED).
  * out_i: {status, done, level_active, it, n_evals, pend_nb}; cand_out / update_out (may be NULL): the state's candidate pose / update. */
 int rgbd360_debug_solve_partials(rgbd360_ctx* ctx, int level, const double row[32], int method, int fused, int out_i[6],
                                  float cand_out[16], float update_out[6]);

@@ -1420,6 +1420,12 @@ __device__ __forceinline__ int stage_pending(SolveShared& sh, const GNState* __r
     int word = 0;
     if (tid < kStateWords) word = reinterpret_cast<const int*>(st_in)[tid];
     const int nb = st_in->pend_nb;        // uniform (scalar load)
+    // The host's bound is checked, not trusted: a state that holds more pending rows than the short form requested gets the rest now
+    // (a second round trip, never taken by the library's own schedules; without it those rows would silently count as zero).
+    if (nb > Q && rows_hint <= Q) {             // uniform
+#pragma unroll
+        for (int j = 1; j < J; ++j) tmp[j] = partials[(size_t)(q + j * Q) * kNumPartials + v];
+    }
 #ifdef RGBD360_SOLVE_STAMPS
     if (tid == 0) sh.stamp[3] = __builtin_amdgcn_s_memrealtime();      // loads issued (absolute; made relative below)
 #endif

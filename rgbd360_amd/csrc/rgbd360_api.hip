@@ -1277,11 +1277,15 @@ int rgbd360_debug_solve_partials(rgbd360_ctx* ctx, int level, const double row[3
     launch_level_init(ctx, level, I, 1);
     const size_t rows = (size_t)std::max((ctx->max_blocks + 31) / 32 * 32, kPendingRows);
     HIPC(ctx, hipMemsetAsync(ctx->d_partials, 0, rows * kNumPartials * sizeof(double), ctx->stream));
-    HIPC(ctx, hipMemcpyAsync(ctx->d_partials, row, kNumPartials * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    // fused == 2: the row sits beyond the first batch of rows and the launch is given too small a bound -- stage_pending has to notice
+    // that the state holds more rows than the host said and fetch them (the bound is checked on the device, not trusted)
+    const int row_at = fused == 2 ? 40 : 0;
+    if (row_at >= L.nblocks) return fail(ctx, -1, "the level has too few block rows for the late-row form");
+    HIPC(ctx, hipMemcpyAsync(ctx->d_partials + (size_t)row_at * kNumPartials, row, kNumPartials * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     if (fused) {
         const int pend[2] = {L.nblocks, L.n};       // as if a pass of this level had just written the table
         HIPC(ctx, hipMemcpyAsync(&ctx->d_state->pend_nb, pend, sizeof(pend), hipMemcpyHostToDevice, ctx->stream));
-        ctx->pend_rows_hint = kPendingRows;      // a hand-made pending pass: no bound known
+        ctx->pend_rows_hint = fused == 2 ? 1 : kPendingRows;      // a hand-made pending pass: no bound known
         launch_eval_fused(ctx, level, method, 0);      // the state is read as this launch leaves it: its own pass (if it ran one) stays pending
     } else {
         launch_solve(ctx, level, 0, 0);

@@ -373,7 +373,8 @@ class RegisterPhotoICP:
 
     def debug_solve_partials(self, level: int, row, method: int = 0, fused: bool = True):
         """rgbd360_debug_solve_partials: one solve on a hand-made partial table (row: 32 float64 -- 21 upper-triangle terms of H, 6 of
-        g, err2 photo / depth, n photo / depth / visible) at the identity pose, through k_solve (fused=False) or the fused launch."""
+        g, err2 photo / depth, n photo / depth / visible) at the identity pose, through k_solve (fused=False) or the fused launch
+        (fused=2: the row late in the table and too small a host bound on the pending rows, see rgbd360_hip_diag.h)."""
         row = np.ascontiguousarray(row, np.float64)
         assert row.shape == (32,)
         out_i = np.zeros(6, np.int32)

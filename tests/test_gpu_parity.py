@@ -237,6 +237,24 @@ def test_solve_paths_fused_and_two_launch_agree(hip_lib, oracle_mod, small_pair)
                 assert np.array_equal(one["cand"], np.eye(4, dtype=np.float32)) and np.array_equal(one["update"], np.ones(6, np.float32))
 
 
+def test_fused_solve_checks_the_hosts_bound_on_pending_rows(hip_lib):
+    """The fused launch requests the pending pass's partial rows before it knows how many there are; the host passes a bound so that the
+    coarse levels request 32 rows instead of 256.  The device checks that bound against the state: a pending row beyond the first batch
+    behind a launch that was told `one row` is fetched in a second trip -- same step as with the row in place 0, not a silent zero."""
+    if os.environ.get("RGBD360_FUSED_SOLVE") == "0":
+        pytest.skip("the fused-solve schedule is switched off by RGBD360_FUSED_SOLVE=0")
+    from rgbd360_amd.register import RegisterPhotoICP
+    (rgbA, dA), (rgbB, dB), T = synth.make_pair(1024, 512, seed=3)          # level 0: 64 block rows
+    reg = RegisterPhotoICP()
+    reg.setTargetFrame(rgbA, dA); reg.setSourceFrame(rgbB, dB)
+    row = _partial_row([4, 5, 6, 7, 8, 9], np.array([0.3, -0.2, 0.1, 0.05, -0.04, 0.02]))
+    first = reg.debug_solve_partials(0, row, 2, fused=1)
+    late = reg.debug_solve_partials(0, row, 2, fused=2)
+    assert first["status"] == late["status"] == 0 and first["done"] == late["done"] == 0
+    assert np.array_equal(first["update"], late["update"]) and np.array_equal(first["cand"], late["cand"])
+    assert np.abs(first["update"]).max() > 1e-3
+
+
 def test_float_depth_and_strided_inputs(hip_lib, oracle_mod):
     (rgbA, dA), (rgbB, dB), T = synth.make_pair(256, 128, seed=77, depth_f32=True)
     # row-padded (strided) host images, like a cv::Mat ROI
