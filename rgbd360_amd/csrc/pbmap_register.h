@@ -643,9 +643,9 @@ inline void pool_colour(rgbd360_plane& dst, const rgbd360_plane& a, const rgbd36
             dst.color_concentration = (float)(std::max(ka, kb) / std::max((double)std::max(a.count, 0) + std::max(b.count, 0), 1.0));
         }
     }
-    const double ca = a.color_count > 0 ? std::max(a.count, 0) : 0, cb = b.color_count > 0 ? std::max(b.count, 0) : 0;
-    if (ca + cb > 0)
-        for (int k = 0; k < 74; ++k) dst.hist_h[k] = (float)((ca * a.hist_h[k] + cb * b.hist_h[k]) / (ca + cb));
+    // (normalised histograms of the pixels that carry colour: pooled with the weights of the means above)
+    if (na + nb > 0)
+        for (int k = 0; k < 74; ++k) dst.hist_h[k] = (float)((na * a.hist_h[k] + nb * b.hist_h[k]) / (na + nb));
 }
 inline std::vector<rgbd360_plane> merge_planes(const rgbd360_plane* in, int n, const MergeParams& M) {
     std::vector<rgbd360_plane> v;
