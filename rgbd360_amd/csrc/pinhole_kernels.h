@@ -174,13 +174,19 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_pinhole(LevelDev lv, PinK
 //                  (as written: DEPTH_CONSISTENCY alone gives H = 0)
 //     Occ2         an outlier gate in front: |Dtrg - 1/Z| > 1 m in the error pass (sic), |Dtrg - Z| > 1 m in the H, g pass
 // That is a state machine along each target pixel's list of source pixels IN INDEX ORDER.  No sort: k_pin_occ_keys counts the arrivals
-// per target pixel (integer atomics: order-independent), keeps the first kPinShort arrivals of a target in its slot row (in arrival
-// order, i.e. unordered) and the lowest / highest source index that landed there; k_pin_occ_walk gives every TARGET pixel to one thread,
-// which visits its list in index order -- a short list by repeated selection of the next larger index among its <= kPinShort slots,
-// a long one (zoom-outs and collapses pile hundreds to tens of thousands of source pixels on one target) by scanning the key array
-// between the two bounds.  Exact sequential semantics whatever the list lengths, no residency or ordering assumption, no library
-// (rounds 3-4 sorted the (target, source) pairs with a library radix sort: 8-10 launches, 44 us per evaluation).  One fused walk
-// yields the error sums and the normal equations at the pose, in k_eval's partial-row layout; it also re-arms the per-target words.
+// per target pixel (integer atomics: order-independent) and keeps the first kPinShort arrivals of a target in its slot row (in arrival
+// order, i.e. unordered); an arrival beyond those also widens the target's BOX -- lowest / highest source index and lowest / highest
+// source column of the late arrivals (four more atomics, only on the targets that need them).  k_pin_occ_walk gives every TARGET pixel
+// to one thread, which visits its list in index order -- a short list by repeated selection of the next larger index among its
+// <= kPinShort slots, a long one (zoom-outs and collapses pile tens to tens of thousands of source pixels on one target) by scanning the
+// key array over the box of ALL its arrivals (the late ones' box widened by the slots), row by row: the source pixels of one target form
+// a compact patch, so the scan reads about as many keys as the list is long (scanning every key between the lowest and the highest
+// index read whole image rows for a 5 x 5 patch: 0.85 ms instead of 0.08 per 640 x 480 evaluation at a 3 m zoom-out).  Exact sequential
+// semantics whatever the list lengths, no residency or ordering assumption, no library (rounds 3-4 sorted the (target, source) pairs
+// with a library radix sort: 8-10 launches, 44 us per evaluation).  A collapse of the whole image onto a few pixels stays what its
+// semantics make it: one thread per target walking tens of thousands of arrivals (tens of milliseconds; tools/pinhole_occ_longlist_perf.py).
+// One fused walk yields the error sums and the normal equations at the pose, in k_eval's partial-row layout; it also re-arms the
+// per-target words.
 // ---------------------------------------------------------------------------------------------------------------------------
 constexpr float kPinThresDepthOutliers = 1.f;      // thresDepthOutliers = maxDepthOutliers (RPI.h:215, 4256-4260)
 constexpr unsigned kPinOccErr = 1u << 30, kPinOccHess = 1u << 31, kPinOccIndex = 0xFFFFFFu;
@@ -188,10 +194,18 @@ constexpr unsigned kPinOccErr = 1u << 30, kPinOccHess = 1u << 31, kPinOccIndex =
 constexpr int kPinShort = 8;                       // arrivals per target pixel kept in its slot row
 struct PinOccLists {                               // per target pixel of the largest level (armed once at allocation, re-armed by the walk)
     int* cnt;                                      // arrivals (0)
-    int* first;                                    // lowest source index (INT_MAX)
-    int* last;                                     // highest source index (-1)
+    int4* box;                                     // of the arrivals beyond the slot row: {lowest index, highest index, lowest column, highest column}
+                                                   // (armed {INT_MAX, -1, INT_MAX, -1})
     unsigned* slots;                               // [n][kPinShort] source indices, arrival order
 };
+constexpr int4 kPinBoxArmed = {0x7fffffff, -1, 0x7fffffff, -1};
+__global__ void k_pin_occ_arm(int* __restrict__ cnt, int4* __restrict__ box, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        cnt[i] = 0;
+        box[i] = kPinBoxArmed;
+    }
+}
 template <int OCC>
 __global__ __launch_bounds__(256) void k_pin_occ_keys(LevelDev lv, PinK K, Pose16 pose, unsigned* __restrict__ keys, unsigned* __restrict__ vals, PinOccLists Ls) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -214,8 +228,14 @@ __global__ __launch_bounds__(256) void k_pin_occ_keys(LevelDev lv, PinK K, Pose1
     if (in_list) {
         const int slot = atomicAdd(&Ls.cnt[ti], 1);
         if (slot < kPinShort) Ls.slots[(size_t)ti * kPinShort + slot] = (unsigned)i;
-        atomicMin(&Ls.first[ti], i);
-        atomicMax(&Ls.last[ti], i);
+        else {                                                          // a long list: the walk scans the box of its arrivals
+            int* b = reinterpret_cast<int*>(&Ls.box[ti]);
+            const int c = i % lv.cols;
+            atomicMin(&b[0], i);
+            atomicMax(&b[1], i);
+            atomicMin(&b[2], c);
+            atomicMax(&b[3], c);
+        }
     }
 }
 
@@ -230,12 +250,14 @@ __global__ __launch_bounds__(kPinWalkThreads) void k_pin_occ_walk(LevelDev lv, P
     for (int k = 0; k < 27; ++k) A.acc[k] = 0.f;
     A.e2p = A.e2d = 0.f;
     int nP = 0, nD = 0, nVis = 0;
-    int m = 0, lo = 0, hi = -1;
+    int m = 0;
+    int4 box = kPinBoxArmed;
     if (p < lv.n) {
         m = Ls.cnt[p];
-        if (m) {
-            lo = Ls.first[p]; hi = Ls.last[p];
-            Ls.cnt[p] = 0; Ls.first[p] = 0x7fffffff; Ls.last[p] = -1;  // re-armed for the next evaluation
+        if (m) Ls.cnt[p] = 0;                                          // re-armed for the next evaluation
+        if (m > kPinShort) {
+            box = Ls.box[p];
+            Ls.box[p] = kPinBoxArmed;
         }
     }
     if (m) {
@@ -250,7 +272,20 @@ __global__ __launch_bounds__(kPinWalkThreads) void k_pin_occ_walk(LevelDev lv, P
         float buf_e = 0.f, buf_h = 0.f;              // invDepthBuffer(ii) of the two passes
         float res_p = 0.f, res_d = 0.f;              // residualsPhoto(ii), residualsDepth(ii) of the error pass
         const unsigned* row = Ls.slots + (size_t)ti * kPinShort;
-        int prev = -1, scan = lo;                    // the source index visited last; the scan position of a long list
+        int prev = -1;                               // the source index visited last
+        // a long list: the box of the late arrivals, widened by the early ones in the slot row; scanned row by row, in index order
+        int scan_r = 0, scan_c = 0, c_lo = 0, c_hi = -1, hi = -1;
+        if (m > kPinShort) {
+            for (int k = 0; k < kPinShort; ++k) {
+                const int e = (int)row[k], c = e % lv.cols;
+                box.x = min(box.x, e); box.y = max(box.y, e);
+                box.z = min(box.z, c); box.w = max(box.w, c);
+            }
+            hi = box.y;
+            c_lo = box.z; c_hi = box.w;
+            scan_r = box.x / lv.cols;
+            scan_c = c_lo;
+        }
         for (int visited = 0; visited < m; ++visited) {
             int src;
             if (m <= kPinShort) {                    // the next larger index among the slots
@@ -260,9 +295,12 @@ __global__ __launch_bounds__(kPinWalkThreads) void k_pin_occ_walk(LevelDev lv, P
                     if ((int)c > prev && c < best) best = c;
                 }
                 src = (int)best;
-            } else {                                 // the next source pixel with this key, in index order
-                while (scan <= hi && keys[scan] != ti) ++scan;
-                src = scan++;
+            } else {                                 // the next source pixel with this key, in index order (there are m of them in the box)
+                for (;;) {
+                    const int e = scan_r * lv.cols + scan_c;
+                    if (++scan_c > c_hi) { scan_c = c_lo; ++scan_r; }
+                    if (e > hi || keys[e] == ti) { src = min(e, hi); break; }      // (e > hi cannot happen while visited < m: a bound, not a path)
+                }
             }
             prev = src;
             const unsigned v = vals[src];

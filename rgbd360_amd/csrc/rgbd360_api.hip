@@ -130,7 +130,7 @@ struct rgbd360_ctx {
     float sal_thr = -1.f;                               // useSaliency(true): thresSaliency (RPI.h:217, 266); < 0 = off
     // pinhole occlusion passes: (target index, source index) pairs before / after the sort, the sort's scratch, one partial row per walk block
     unsigned *pin_keys = nullptr, *pin_vals = nullptr;      // the pinhole occlusion passes: per source pixel its target + pass flags,
-    PinOccLists pin_lists = {nullptr, nullptr, nullptr, nullptr};      // per target pixel its arrivals (pinhole_kernels.h)
+    PinOccLists pin_lists = {nullptr, nullptr, nullptr};      // per target pixel its arrivals (pinhole_kernels.h)
     size_t pin_occ_n = 0;
     double* pin_partials = nullptr;
     int* occ_head = nullptr;                           // occlusion modes: per-target lists of candidate runs (generation-tagged heads)
@@ -162,10 +162,10 @@ int fail(rgbd360_ctx* ctx, int code, const char* msg) {
 
 void pin_occ_free(rgbd360_ctx* ctx) {
     hipFree(ctx->pin_keys); hipFree(ctx->pin_vals); hipFree(ctx->pin_partials);
-    hipFree(ctx->pin_lists.cnt); hipFree(ctx->pin_lists.first); hipFree(ctx->pin_lists.last); hipFree(ctx->pin_lists.slots);
+    hipFree(ctx->pin_lists.cnt); hipFree(ctx->pin_lists.box); hipFree(ctx->pin_lists.slots);
     ctx->pin_keys = ctx->pin_vals = nullptr;
     ctx->pin_partials = nullptr;
-    ctx->pin_lists = PinOccLists{nullptr, nullptr, nullptr, nullptr};
+    ctx->pin_lists = PinOccLists{nullptr, nullptr, nullptr};
     ctx->pin_occ_n = 0;
 }
 
@@ -1595,13 +1595,11 @@ int pin_occ_ensure(rgbd360_ctx* ctx, size_t n) {
     HIPC(ctx, hipMalloc(&ctx->pin_keys, n * sizeof(unsigned)));
     HIPC(ctx, hipMalloc(&ctx->pin_vals, n * sizeof(unsigned)));
     HIPC(ctx, hipMalloc(&Ls.cnt, n * sizeof(int)));
-    HIPC(ctx, hipMalloc(&Ls.first, n * sizeof(int)));
-    HIPC(ctx, hipMalloc(&Ls.last, n * sizeof(int)));
+    HIPC(ctx, hipMalloc(&Ls.box, n * sizeof(int4)));
     HIPC(ctx, hipMalloc(&Ls.slots, n * kPinShort * sizeof(unsigned)));
     // armed once; every walk re-arms the words of the target pixels it visited
-    HIPC(ctx, hipMemsetAsync(Ls.cnt, 0, n * sizeof(int), ctx->stream));
-    HIPC(ctx, hipMemsetAsync(Ls.last, 0xff, n * sizeof(int), ctx->stream));           // -1
-    HIPC(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(Ls.first), 0x7fffffff, n, ctx->stream));
+    hipLaunchKernelGGL(k_pin_occ_arm, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, Ls.cnt, Ls.box, (int)n);
+    HIPC(ctx, hipGetLastError());
     HIPC(ctx, hipMalloc(&ctx->pin_partials, ((n + kPinWalkThreads - 1) / kPinWalkThreads) * kNumPartials * sizeof(double)));
     ctx->pin_occ_n = n;
     return 0;
