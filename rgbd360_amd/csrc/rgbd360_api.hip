@@ -2109,15 +2109,19 @@ HullStats hull_stats(const float (*uv)[2], int K) {
         for (int i = 0; i < m; ++i) { h.pu[i] = H[i].x; h.pv[i] = H[i].y; }
         h.np = m;
     } else {
+        // (the directions turn counter-clockwise like the vertices: the extreme vertex only ever moves forward -- one full scan for the
+        // first direction, then a walk; with a scan per direction this loop was 4 us per plane, 0.19 ms of a 4096 x 2048 frame's call)
+        static const struct Dirs {
+            double c[RGBD360_HULL_MAX], s[RGBD360_HULL_MAX];
+            Dirs() { for (int k = 0; k < RGBD360_HULL_MAX; ++k) { const double th = 2.0 * 3.14159265358979323846 * k / RGBD360_HULL_MAX; c[k] = cos(th); s[k] = sin(th); } }
+        } D;
+        auto proj = [&](int i, int k) { return ((double)H[i].x - h.cu) * D.c[k] + ((double)H[i].y - h.cv) * D.s[k]; };
+        int best = 0;
+        for (int i = 1; i < m; ++i)
+            if (proj(i, 0) > proj(best, 0)) best = i;
         int last = -1, first = -1;
         for (int k = 0; k < RGBD360_HULL_MAX; ++k) {
-            const double th = 2.0 * 3.14159265358979323846 * k / RGBD360_HULL_MAX, cx = cos(th), sy = sin(th);
-            int best = 0;
-            double bd = -1e300;
-            for (int i = 0; i < m; ++i) {
-                const double dd = (H[i].x - h.cu) * cx + (H[i].y - h.cv) * sy;
-                if (dd > bd) { bd = dd; best = i; }
-            }
+            for (int steps = 0; steps < m && proj((best + 1) % m, k) > proj(best, k); ++steps) best = (best + 1) % m;
             if (best == last || best == first) continue;
             if (first < 0) first = best;
             last = best;
