@@ -1540,7 +1540,7 @@ __host__ __device__ inline void mode_grid(int count, int& sr, int& sc) {
     while ((sr + 1) * (sr + 1) <= step) ++sr;
     sc = step / sr;
 }
-constexpr int kColPerThread = 8, kColHash = 16;
+constexpr int kColPerThread = 8, kColHash = 16, kColListCap = 4096;
 struct ColourImage {
     const uint8_t* rgb;      // device, 3 bytes per pixel
     size_t step;             // bytes per row
@@ -1577,13 +1577,11 @@ __device__ __forceinline__ ColourPx colour_px(unsigned R, unsigned G, unsigned B
     }
     return o;
 }
-__global__ void k_f360_colour_clear(const int* __restrict__ n_slots, int max_slots, unsigned long long* __restrict__ col) {
-    const int ns = min(*n_slots, max_slots);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ns * kColWords; i += gridDim.x * blockDim.x) col[i] = 0ull;
-}
-// (one block) where a region's samples start in the pool: exclusive prefix of min(count, kModeCap) over the slots; clears the sample counters
+// (one block) where a region's samples start in the pool: exclusive prefix of min(count, kModeCap) over the slots; clears the sample
+// counters and the slots' rows of the colour table, and leaves each slot's sample grid (mode_grid: the same for every pixel of a region)
 __global__ __launch_bounds__(1024) void k_f360_colour_offsets(const int* __restrict__ n_slots, int max_slots, const int* __restrict__ count_of_slot,
-                                                               int* __restrict__ samp_off, int* __restrict__ samp_n) {
+                                                               int* __restrict__ samp_off, int* __restrict__ samp_n, int2* __restrict__ samp_grid,
+                                                               unsigned long long* __restrict__ col) {
     __shared__ int part[1024];
     const int ns = min(*n_slots, max_slots);
     const int per = (ns + 1023) / 1024, lo = threadIdx.x * per, hi = min(lo + per, ns);
@@ -1592,21 +1590,28 @@ __global__ __launch_bounds__(1024) void k_f360_colour_offsets(const int* __restr
     part[threadIdx.x] = sum;
     __syncthreads();
     if (threadIdx.x == 0) {
+        const int used = per > 0 ? min(1024, (ns + per - 1) / per) : 0;      // threads that own slots (a frame has tens of regions, not thousands)
         int run = 0;
-        for (int t = 0; t < 1024; ++t) { const int v = part[t]; part[t] = run; run += v; }
+        for (int t = 0; t < used; ++t) { const int v = part[t]; part[t] = run; run += v; }
     }
     __syncthreads();
     int run = part[threadIdx.x];
     for (int s2 = lo; s2 < hi; ++s2) {
+        const int cnt = count_of_slot[s2];
         samp_off[s2] = run;
         samp_n[s2] = 0;
-        run += min(count_of_slot[s2], kModeCap);
+        int sr, sc;
+        mode_grid(cnt, sr, sc);
+        samp_grid[s2] = make_int2(sr, sc);
+        run += min(cnt, kModeCap);
     }
+    for (int i = threadIdx.x; i < ns * kColWords; i += 1024) col[i] = 0ull;
 }
 struct ColourSamples {          // nullptr pool: no dominant colour is sought
     const int* count_of_slot;
     const int* samp_off;
     int* samp_n;
+    const int2* grid;           // {sr, sc} of the slot's sample grid
     unsigned* pool;             // R | G << 8 | B << 16 of the sampled pixels, region by region
 };
 __global__ __launch_bounds__(kAggThreads) void k_f360_colour(const int* __restrict__ label, const int* __restrict__ slot_of_root, int rows, int cols,
@@ -1614,6 +1619,10 @@ __global__ __launch_bounds__(kAggThreads) void k_f360_colour(const int* __restri
     __shared__ int keys[kColHash];
     __shared__ unsigned long long sums[kColHash][kColSums];
     __shared__ unsigned bins[kColHash][kColBins];
+    __shared__ unsigned slist[kColListCap];              // the block's samples: R | G << 8 | B << 16 | table entry << 24
+    __shared__ int slist_n, scount[kColHash], sbase[kColHash];
+    if (threadIdx.x == 0) slist_n = 0;
+    if (threadIdx.x < kColHash) scount[threadIdx.x] = 0;
     for (int i = threadIdx.x; i < kColHash * kColBins; i += kAggThreads) (&bins[0][0])[i] = 0u;
     if (threadIdx.x < kColHash * kColSums) (&sums[0][0])[threadIdx.x] = 0ull;
     if (threadIdx.x < kColHash) keys[threadIdx.x] = -1;
@@ -1641,6 +1650,7 @@ __global__ __launch_bounds__(kAggThreads) void k_f360_colour(const int* __restri
         atomicAdd(&dst[6], (unsigned long long)a32[3]);
         atomicAdd(&dst[7], (unsigned long long)a32[4]);
     };
+    const int lane = (int)threadIdx.x & 63;
 #pragma unroll 1
     for (int j = 0; j < kColPerThread; ++j) {
         const int p = (blockIdx.x * kColPerThread + j) * kAggThreads + (int)threadIdx.x;
@@ -1649,20 +1659,14 @@ __global__ __launch_bounds__(kAggThreads) void k_f360_colour(const int* __restri
             const int l = label[p];
             if (l >= 0) slot = slot_of_root[l];
         }
-        if (slot < 0) continue;
+        const bool on = slot >= 0;
+        if (__ballot(on) == 0ull) continue;                  // uniform: nothing of a region in these 64 pixels
         int r, c;
-        r360::divmod24(p, cols, r, c);
+        r360::divmod24(on ? p : 0, cols, r, c);
         const uint8_t* px = img.rgb + (size_t)(r * img.sub + img.sub / 2) * img.step + 3 * (size_t)(c * img.sub + img.sub / 2);
-        const ColourPx v = colour_px(px[0], px[1], px[2]);
-        if (smp.pool && v.S) {                                // the dominant colour's sample grid (kModeTarget above)
-            int sr, sc;
-            mode_grid(smp.count_of_slot[slot], sr, sc);
-            if (r % sr == 0 && c % sc == 0) {
-                const int pos = atomicAdd(&smp.samp_n[slot], 1);
-                if (pos < kModeCap) smp.pool[smp.samp_off[slot] + pos] = (unsigned)px[0] | ((unsigned)px[1] << 8) | ((unsigned)px[2] << 16);
-            }
-        }
-        if (slot != key) {
+        const unsigned pr = px[0], pg = px[1], pb = px[2];
+        const ColourPx v = colour_px(pr, pg, pb);
+        if (on && slot != key) {
             flush_lane();
             key = slot;
             ent = entry_of(slot);
@@ -1670,9 +1674,53 @@ __global__ __launch_bounds__(kAggThreads) void k_f360_colour(const int* __restri
             for (int k = 0; k < 5; ++k) a32[k] = 0;
             a64[0] = a64[1] = a64[2] = 0;
         }
-        if (ent >= 0) atomicAdd(&bins[ent][v.bin], 1u);
-        else atomicAdd(&col[(size_t)slot * kColWords + kColSums + v.bin], 1ull);
-        if (v.S) {
+        // The dominant colour's sample grid (kModeTarget above).  A sample needs a place in its region's stretch of the pool, i.e. a
+        // counter per region -- bumped once per sample in global memory, the ~2500 samples of a wall queue up on one address (250 of this
+        // kernel's 320 us at 4096 x 2048).  The block collects its samples in LDS and bumps each region's counter once, by its number of
+        // samples in the block (below); only what does not fit the block's table or list goes to the global counter directly.
+        if (smp.pool) {                                       // uniform
+            bool samp = false;
+            if (on && v.S) {
+                const int2 g = smp.grid[slot];
+                int qq, rr = 0, rc = 0;
+                if (g.x > 1) r360::divmod24(r, g.x, qq, rr);
+                if (g.y > 1) r360::divmod24(c, g.y, qq, rc);
+                samp = rr == 0 && rc == 0;
+            }
+            const unsigned rgb = pr | (pg << 8) | (pb << 16);
+            const bool listed = samp && ent >= 0;
+            const unsigned long long m = __ballot(listed);
+            int idx = kColListCap;
+            if (m) {                                          // uniform
+                const int lead = __builtin_ctzll(m);
+                int base = 0;
+                if (lane == lead) base = atomicAdd(&slist_n, (int)__popcll(m));
+                base = __builtin_amdgcn_readlane(base, lead);
+                idx = base + (int)__popcll(m & ((1ull << lane) - 1ull));
+                if (listed && idx < kColListCap) slist[idx] = rgb | ((unsigned)ent << 24);
+            }
+            if (samp && (ent < 0 || idx >= kColListCap)) {
+                const int pos = atomicAdd(&smp.samp_n[slot], 1);
+                if (pos < kModeCap) smp.pool[smp.samp_off[slot] + pos] = rgb;
+            }
+        }
+        // hue bins: one LDS add per (region, bin) the wave's 64 pixels hold, by the group's first lane, with the group's size -- a wall
+        // is one or two bins wide, and 64 lanes adding 1 to the same LDS word are 64 serial read-modify-writes (this was 5/6 of the
+        // kernel: 316 -> 60 us at 4096 x 2048)
+        {
+            const bool in_table = on && ent >= 0;
+            const int kb = (ent << 8) | v.bin;
+            unsigned long long todo = __ballot(in_table);
+            while (todo) {                                    // uniform
+                const int lead = __builtin_ctzll(todo);
+                const int kbl = __builtin_amdgcn_readlane(kb, lead);
+                const unsigned long long same = __ballot(in_table && kb == kbl);
+                if (lane == lead) atomicAdd(&bins[kbl >> 8][kbl & 255], (unsigned)__popcll(same));
+                todo &= ~same;
+            }
+            if (on && ent < 0) atomicAdd(&col[(size_t)slot * kColWords + kColSums + v.bin], 1ull);
+        }
+        if (on && v.S) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 a32[k] += v.q[k];
@@ -1710,6 +1758,23 @@ __global__ __launch_bounds__(kAggThreads) void k_f360_colour(const int* __restri
         flush_lane();
     }
     __syncthreads();
+    if (smp.pool) {                                       // uniform: the block's samples move to their regions' stretches of the pool
+        const int nl = min(slist_n, kColListCap);
+        for (int i = threadIdx.x; i < nl; i += kAggThreads) atomicAdd(&scount[slist[i] >> 24], 1);
+        __syncthreads();
+        if (threadIdx.x < kColHash) {
+            const int cnt = scount[threadIdx.x];
+            sbase[threadIdx.x] = cnt > 0 ? atomicAdd(&smp.samp_n[keys[threadIdx.x]], cnt) : 0;      // one bump per (block, region)
+            scount[threadIdx.x] = 0;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < nl; i += kAggThreads) {
+            const unsigned w = slist[i];
+            const int e = (int)(w >> 24);
+            const int pos = sbase[e] + atomicAdd(&scount[e], 1);
+            if (pos < kModeCap) smp.pool[smp.samp_off[keys[e]] + pos] = w & 0xFFFFFFu;
+        }
+    }
     constexpr int kColAcc = kColSums + kColBins;          // (the words this pass accumulates; the dominant colour's follow behind them)
     for (int i = threadIdx.x; i < kColHash * kColAcc; i += kAggThreads) {
         const int e = i / kColAcc, w = i - e * kColAcc;
@@ -1725,95 +1790,115 @@ __global__ __launch_bounds__(kAggThreads) void k_f360_colour(const int* __restri
 //                                                     mean = that of the n left; shift = its move
 // One block per region slot; samples in LDS (16 bytes each).  Results into the region's row of the colour table (kColMode words).
 constexpr int kModeThreads = 256;
+// Also the stage's last kernel: a block copies the finished row of each of its slots into pinned host memory (behind the plane list's
+// other records: one wait ends the call), and the last block to finish publishes the host tag (host_tag != nullptr; `ticket` as in
+// k_f360_hull_pack).
 __global__ __launch_bounds__(kModeThreads) void k_f360_colour_mode(const int* __restrict__ n_slots, int max_slots, ColourSamples smp,
-                                                                    unsigned long long* __restrict__ col) {
+                                                                    unsigned long long* __restrict__ col, unsigned long long* __restrict__ host_out,
+                                                                    unsigned* __restrict__ ticket, unsigned* host_tag, unsigned host_seq) {
     __shared__ uint4 sm[kModeCap];                 // {qR, qG, qB, S | alive << 31}
     __shared__ unsigned long long acc[8];
     const int ns = min(*n_slots, max_slots);
+    const int lane = (int)threadIdx.x & 63;
+    // a block's five sums of a step: added up inside the waves first (256 threads adding to five LDS words are 1280 serial
+    // read-modify-writes per step, and a region takes up to 64 steps)
+    auto block_add = [&](int k, unsigned long long v) {
+        const unsigned long long t = (unsigned long long)wave_sum_ll((long long)v);
+        if (lane == 0 && t) atomicAdd(&acc[k], t);
+    };
     for (int slot = blockIdx.x; slot < ns; slot += gridDim.x) {
         const int N = min(smp.samp_n[slot], kModeCap);
-        unsigned long long* out = col + (size_t)slot * kColWords + kColSums + kColBins;
+        unsigned long long* row = col + (size_t)slot * kColWords;
+        unsigned long long* out = row + kColSums + kColBins;
+        __syncthreads();                               // (the previous slot's state is no longer read)
         if (N <= 0) {
             if (threadIdx.x < kColMode) out[threadIdx.x] = 0ull;
-            continue;
-        }
-        __syncthreads();
-        if (threadIdx.x < 8) acc[threadIdx.x] = 0ull;
-        __syncthreads();
-        unsigned long long s1[3] = {0, 0, 0}, s2[3] = {0, 0, 0};
-        for (int i = threadIdx.x; i < N; i += kModeThreads) {
-            const unsigned w = smp.pool[smp.samp_off[slot] + i];
-            const ColourPx v = colour_px(w & 255u, (w >> 8) & 255u, (w >> 16) & 255u);
-            sm[i] = make_uint4(v.q[0], v.q[1], v.q[2], v.S | 0x80000000u);
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { s1[k] += v.q[k]; s2[k] += (unsigned long long)v.q[k] * v.q[k]; }
-        }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { atomicAdd(&acc[k], s1[k]); atomicAdd(&acc[3 + k], s2[k]); }
-        __syncthreads();
-        long long m[3];
-        unsigned long long thr2 = 0;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            m[k] = (long long)(acc[k] / (unsigned long long)N);
-            const long long var = (long long)(acc[3 + k] / (unsigned long long)N) - m[k] * m[k];
-            thr2 += (unsigned long long)(var > 0 ? var : 0);
-        }
-        int n_alive = N, iters = 0;
-        unsigned long long shift2 = ~0ull, sumS = 0;
-        const unsigned long long conv2 = 4294ull;          // floor((0.001 * 65536)^2)
-        for (;;) {
-            __syncthreads();                               // everybody has read acc / the loop state is uniform
-            if (!(2 * (long long)n_alive > N && shift2 > conv2) || iters >= 64) break;
+        } else {
             if (threadIdx.x < 8) acc[threadIdx.x] = 0ull;
             __syncthreads();
-            unsigned long long t1[3] = {0, 0, 0}, tS = 0, tn = 0;
+            unsigned long long s1[3] = {0, 0, 0}, s2[3] = {0, 0, 0};
             for (int i = threadIdx.x; i < N; i += kModeThreads) {
-                uint4 e = sm[i];
-                if (!(e.w & 0x80000000u)) continue;
-                const long long d0 = (long long)e.x - m[0], d1 = (long long)e.y - m[1], d2 = (long long)e.z - m[2];
-                if ((unsigned long long)(d0 * d0 + d1 * d1 + d2 * d2) > thr2) {
-                    sm[i].w = e.w & 0x7fffffffu;           // erased for good
-                    continue;
-                }
-                t1[0] += e.x; t1[1] += e.y; t1[2] += e.z; tS += e.w & 0x7fffffffu; ++tn;
+                const unsigned w = smp.pool[smp.samp_off[slot] + i];
+                const ColourPx v = colour_px(w & 255u, (w >> 8) & 255u, (w >> 16) & 255u);
+                sm[i] = make_uint4(v.q[0], v.q[1], v.q[2], v.S | 0x80000000u);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { s1[k] += v.q[k]; s2[k] += (unsigned long long)v.q[k] * v.q[k]; }
             }
 #pragma unroll
-            for (int k = 0; k < 3; ++k) atomicAdd(&acc[k], t1[k]);
-            atomicAdd(&acc[3], tS);
-            atomicAdd(&acc[4], tn);
+            for (int k = 0; k < 3; ++k) { block_add(k, s1[k]); block_add(3 + k, s2[k]); }
             __syncthreads();
-            ++iters;
-            const long long left = (long long)acc[4];
-            if (left == 0) { n_alive = 0; break; }         // (every sample beyond the threshold: the mean stands)
-            shift2 = 0;
+            long long m[3];
+            unsigned long long thr2 = 0;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const long long mk = (long long)(acc[k] / (unsigned long long)left);
-                shift2 += (unsigned long long)((mk - m[k]) * (mk - m[k]));
-                m[k] = mk;
+                m[k] = (long long)(acc[k] / (unsigned long long)N);
+                const long long var = (long long)(acc[3 + k] / (unsigned long long)N) - m[k] * m[k];
+                thr2 += (unsigned long long)(var > 0 ? var : 0);
             }
-            n_alive = (int)left;
-            sumS = acc[3];
+            int n_alive = N, iters = 0;
+            unsigned long long shift2 = ~0ull, sumS = 0;
+            const unsigned long long conv2 = 4294ull;          // floor((0.001 * 65536)^2)
+            for (;;) {
+                __syncthreads();                               // everybody has read acc / the loop state is uniform
+                if (!(2 * (long long)n_alive > N && shift2 > conv2) || iters >= 64) break;
+                if (threadIdx.x < 8) acc[threadIdx.x] = 0ull;
+                __syncthreads();
+                unsigned long long t1[3] = {0, 0, 0}, tS = 0, tn = 0;
+                for (int i = threadIdx.x; i < N; i += kModeThreads) {
+                    uint4 e = sm[i];
+                    if (!(e.w & 0x80000000u)) continue;
+                    const long long d0 = (long long)e.x - m[0], d1 = (long long)e.y - m[1], d2 = (long long)e.z - m[2];
+                    if ((unsigned long long)(d0 * d0 + d1 * d1 + d2 * d2) > thr2) {
+                        sm[i].w = e.w & 0x7fffffffu;           // erased for good
+                        continue;
+                    }
+                    t1[0] += e.x; t1[1] += e.y; t1[2] += e.z; tS += e.w & 0x7fffffffu; ++tn;
+                }
+                // (a block's sums stay below 2^28 -- 4096 samples of 16-bit values -- so two travel in one 64-bit sum)
+                block_add(0, t1[0] | (t1[1] << 32));
+                block_add(1, t1[2] | (tS << 32));
+                block_add(2, tn);
+                __syncthreads();
+                ++iters;
+                const unsigned long long p0 = acc[0], p1 = acc[1];
+                const unsigned long long tot[3] = {p0 & 0xFFFFFFFFull, p0 >> 32, p1 & 0xFFFFFFFFull};
+                const long long left = (long long)acc[2];
+                if (left == 0) { n_alive = 0; break; }         // (every sample beyond the threshold: the mean stands)
+                shift2 = 0;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const long long mk = (long long)(tot[k] / (unsigned long long)left);
+                    shift2 += (unsigned long long)((mk - m[k]) * (mk - m[k]));
+                    m[k] = mk;
+                }
+                n_alive = (int)left;
+                sumS = p1 >> 32;
+            }
+            if (iters == 0 || n_alive == 0) {                  // no shrink step ran (N == 1 ...) or it emptied the set: the plain mean over all samples
+                unsigned long long tS = 0;
+                for (int i = 0; i < N; ++i) tS += sm[i].w & 0x7fffffffu;      // (uniform, rare)
+                sumS = tS;
+                if (n_alive == 0) n_alive = N;
+            }
+            if (threadIdx.x == 0) {
+                out[0] = (unsigned long long)N; out[1] = (unsigned long long)n_alive;
+                out[2] = (unsigned long long)m[0]; out[3] = (unsigned long long)m[1]; out[4] = (unsigned long long)m[2];
+                out[5] = sumS; out[6] = (unsigned long long)iters; out[7] = thr2;
+            }
         }
-        if (iters == 0 || n_alive == 0) {                  // no shrink step ran (N == 1 ...) or it emptied the set: the plain mean over all samples
-            unsigned long long tS = 0;
-            for (int i = 0; i < N; ++i) tS += sm[i].w & 0x7fffffffu;      // (uniform, rare)
-            sumS = tS;
-            if (n_alive == 0) n_alive = N;
-        }
-        if (threadIdx.x == 0) {
-            out[0] = (unsigned long long)N; out[1] = (unsigned long long)n_alive;
-            out[2] = (unsigned long long)m[0]; out[3] = (unsigned long long)m[1]; out[4] = (unsigned long long)m[2];
-            out[5] = sumS; out[6] = (unsigned long long)iters; out[7] = thr2;
+        __syncthreads();                                       // the row is whole (its sums and bins are the previous launch's)
+        if (host_out)
+            for (int i = threadIdx.x; i < kColWords; i += kModeThreads) host_out[(size_t)slot * kColWords + i] = row[i];
+    }
+    if (host_tag) {                                            // uniform
+        __threadfence_system();                                // this thread's words (pinned host memory) before the ticket
+        __syncthreads();
+        if (threadIdx.x == 0 && __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // for the next call
+            __threadfence_system();
+            __hip_atomic_store(host_tag, host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
-}
-// the table rows of the slots in use -> pinned host memory, behind the plane list's other records (one wait ends the call)
-__global__ void k_f360_colour_pack(const unsigned long long* __restrict__ col, const int* __restrict__ n_slots, int max_slots,
-                                   unsigned long long* __restrict__ host_out) {
-    const int ns = min(*n_slots, max_slots);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < ns * kColWords; i += gridDim.x * blockDim.x) host_out[i] = col[i];
 }
 
 // ---------------------------------------------------------------------------------------------------------

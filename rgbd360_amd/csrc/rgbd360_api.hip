@@ -100,6 +100,7 @@ struct rgbd360_ctx {
     int f_col_rows = 0, f_col_cols = 0;                           // size of the registered image
     unsigned long long *f_col = nullptr, *f_col_host = nullptr;   // [kF360MaxSlots][kColWords]: device table, pinned copy of the rows in use
     int *f_samp_off = nullptr, *f_samp_n = nullptr;               // the dominant colour's samples: where a slot's start in the pool, how many arrived
+    int2* f_samp_grid = nullptr;                                  // ... and the slot's sample grid {sr, sc}
     unsigned* f_samp_pool = nullptr;                              // one entry per pixel of the largest frame seen
     size_t f_samp_pool_n = 0;
     bool f_col_ran = false;                                       // the last plane call filled f_col_host
@@ -753,8 +754,8 @@ void rgbd360_destroy(rgbd360_ctx* ctx) {
     hipFree(ctx->f_root_of_slot); hipFree(ctx->f_nslots); hipFree(ctx->f_window); hipFree(ctx->f_mom); hipFree(ctx->f_ticket);
     hipFree(ctx->f_count_of_slot); hipFree(ctx->f_depth_raw); hipFree(ctx->f_pack);
     if (ctx->f_pack_host) hipHostFree(ctx->f_pack_host);
-    hipFree(ctx->f_col_owned); hipFree(ctx->f_col); hipFree(ctx->f_samp_off); hipFree(ctx->f_samp_n); hipFree(ctx->f_samp_pool);
-    ctx->f_samp_off = ctx->f_samp_n = nullptr; ctx->f_samp_pool = nullptr; ctx->f_samp_pool_n = 0;
+    hipFree(ctx->f_col_owned); hipFree(ctx->f_col); hipFree(ctx->f_samp_off); hipFree(ctx->f_samp_n); hipFree(ctx->f_samp_grid); hipFree(ctx->f_samp_pool);
+    ctx->f_samp_off = ctx->f_samp_n = nullptr; ctx->f_samp_grid = nullptr; ctx->f_samp_pool = nullptr; ctx->f_samp_pool_n = 0;
     if (ctx->f_col_host) hipHostFree(ctx->f_col_host);
     ctx->f_col_owned = nullptr; ctx->f_col = nullptr; ctx->f_col_host = nullptr; ctx->f_col_owned_bytes = 0;
     hipFree(ctx->f_models);
@@ -2199,7 +2200,8 @@ void sorted_eigen3(const double C[3][3], double evals[3], double evecs[3][3]) { 
 
 // Colour descriptors of the regions in their slots (k_f360_colour over the CURRENT labels), enqueued on the stream: the table rows in
 // use land in pinned host memory.  Only when a colour image of this cloud's geometry is registered.
-bool launch_colour(rgbd360_ctx* ctx, int rows, int cols) {
+// tag_behind: the stage's last kernel publishes the host tag itself (the caller then waits with hostwait::wait); false when nothing was launched
+bool launch_colour(rgbd360_ctx* ctx, int rows, int cols, bool tag_behind = false) {
     using namespace f360;
     ctx->f_col_ran = false;
     const ColourImage& im = ctx->f_col_img;
@@ -2211,6 +2213,7 @@ bool launch_colour(rgbd360_ctx* ctx, int rows, int cols) {
     // the dominant colour's sample pool (one entry per pixel bounds the sum of min(count, kModeCap) over the regions)
     if (!ctx->f_samp_off && hipMalloc(&ctx->f_samp_off, kF360MaxSlots * sizeof(int)) != hipSuccess) return false;
     if (!ctx->f_samp_n && hipMalloc(&ctx->f_samp_n, kF360MaxSlots * sizeof(int)) != hipSuccess) return false;
+    if (!ctx->f_samp_grid && hipMalloc(&ctx->f_samp_grid, kF360MaxSlots * sizeof(int2)) != hipSuccess) return false;
     if (ctx->f_samp_pool_n < (size_t)n) {
         hipFree(ctx->f_samp_pool);
         ctx->f_samp_pool = nullptr;
@@ -2218,13 +2221,13 @@ bool launch_colour(rgbd360_ctx* ctx, int rows, int cols) {
         if (hipMalloc(&ctx->f_samp_pool, (size_t)n * sizeof(unsigned)) != hipSuccess) return false;
         ctx->f_samp_pool_n = (size_t)n;
     }
-    const ColourSamples smp = {ctx->f_count_of_slot, ctx->f_samp_off, ctx->f_samp_n, ctx->f_samp_pool};
-    hipLaunchKernelGGL(k_f360_colour_clear, dim3(64), dim3(256), 0, ctx->stream, ctx->f_nslots, kF360MaxSlots, ctx->f_col);
-    hipLaunchKernelGGL(k_f360_colour_offsets, dim3(1), dim3(1024), 0, ctx->stream, ctx->f_nslots, kF360MaxSlots, ctx->f_count_of_slot, ctx->f_samp_off, ctx->f_samp_n);
+    const ColourSamples smp = {ctx->f_count_of_slot, ctx->f_samp_off, ctx->f_samp_n, ctx->f_samp_grid, ctx->f_samp_pool};
+    hipLaunchKernelGGL(k_f360_colour_offsets, dim3(1), dim3(1024), 0, ctx->stream, ctx->f_nslots, kF360MaxSlots, ctx->f_count_of_slot, ctx->f_samp_off, ctx->f_samp_n,
+                       ctx->f_samp_grid, ctx->f_col);
     hipLaunchKernelGGL(k_f360_colour, dim3((n + kAggThreads * kColPerThread - 1) / (kAggThreads * kColPerThread)), dim3(kAggThreads), 0, ctx->stream,
                        ctx->f_label, ctx->f_slot_of_root, rows, cols, im, ctx->f_col, smp);
-    hipLaunchKernelGGL(k_f360_colour_mode, dim3(256), dim3(kModeThreads), 0, ctx->stream, ctx->f_nslots, kF360MaxSlots, smp, ctx->f_col);
-    hipLaunchKernelGGL(k_f360_colour_pack, dim3(64), dim3(256), 0, ctx->stream, ctx->f_col, ctx->f_nslots, kF360MaxSlots, ctx->f_col_host);
+    hipLaunchKernelGGL(k_f360_colour_mode, dim3(256), dim3(kModeThreads), 0, ctx->stream, ctx->f_nslots, kF360MaxSlots, smp, ctx->f_col, ctx->f_col_host,
+                       ctx->f_ticket, tag_behind ? ctx->tag.h : nullptr, tag_behind ? ++ctx->tag.seq : 0u);
     ctx->f_col_ran = true;
     return true;
 }
@@ -2347,9 +2350,9 @@ int f360_refine_dev(rgbd360_ctx* ctx, int rows, int cols, int nslots, std::vecto
                        ctx->f_root_of_slot, ctx->f_count_of_slot, ctx->f_pack_host);
     // the contour PCL hands to calcConvexHull is that of the REFINED region, projected with the plane `segment` fitted: extremes of the
     // committed labels against the frames k_f360_slot_frames left before the refinement
-    const bool pack_tags = !colour_can_run(ctx, rows, cols);       // the hull's pack kernel is the last one: it publishes the host tag itself
+    bool pack_tags = !colour_can_run(ctx, rows, cols);             // the hull's pack kernel is the last one: it publishes the host tag itself
     launch_hull(ctx, rows, cols, /*clear_first=*/true, pack_tags);
-    if (!pack_tags) launch_colour(ctx, rows, cols);          // the colour of the REFINED inlier sets (Frame360.h:1045-1046 run on the refined regions)
+    if (!pack_tags) pack_tags = launch_colour(ctx, rows, cols, /*tag_behind=*/true);      // the colour of the REFINED inlier sets (Frame360.h:1045-1046 run on the refined regions); its last kernel tags
     else ctx->f_col_ran = false;
     HIPC(ctx, hipGetLastError());
     if (pack_tags) HIPC(ctx, hostwait::wait(ctx->tag, ctx->stream));
@@ -2458,7 +2461,7 @@ int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float
     if (!ctx->f_refine) {
         pack_tags = !colour_can_run(ctx, rows, cols);               // the hull's pack kernel is the last one: it publishes the host tag itself
         launch_hull(ctx, rows, cols, /*clear_first=*/false, pack_tags);
-        if (!pack_tags) launch_colour(ctx, rows, cols);
+        if (!pack_tags) pack_tags = launch_colour(ctx, rows, cols, /*tag_behind=*/true);      // ... or the colour stage's
     }
     HIPC(ctx, hipGetLastError());
     if (pack_tags) HIPC(ctx, hostwait::wait(ctx->tag, ctx->stream));
