@@ -1550,15 +1550,26 @@ struct ColourPx {
     unsigned q[3], S;
     int bin;
 };
+// n / d for 0 <= n < 2^24, 0 < d, quotients below 2^17 (the colour stage's: (C << 16) / S <= 65536, hue bins, grid steps of rows and columns): the
+// hardware reciprocal (1 ulp) puts the float quotient within 0.02 of the true one, the remainder test settles the last unit -- exact,
+// at a third of the instructions of an IEEE division per quotient (the colour pass makes up to six per pixel)
+__device__ __forceinline__ void divmod_small(int n, float rcp_d, int d, int& q, int& rem) {
+    q = (int)((float)n * rcp_d);
+    rem = n - q * d;
+    if (rem < 0) { rem += d; --q; }
+    else if (rem >= d) { rem -= d; ++q; }
+}
+__device__ __forceinline__ void divmod_small(int n, int d, int& q, int& rem) { divmod_small(n, __builtin_amdgcn_rcpf((float)d), d, q, rem); }
 __device__ __forceinline__ ColourPx colour_px(unsigned R, unsigned G, unsigned B) {
     ColourPx o;
     o.S = R + G + B;
     int rem;
     int q0 = 0, q1 = 0, q2 = 0;
     if (o.S) {          // (C << 16) / S, exact: C << 16 < 2^24
-        r360::divmod24((int)(R << 16), (int)o.S, q0, rem);
-        r360::divmod24((int)(G << 16), (int)o.S, q1, rem);
-        r360::divmod24((int)(B << 16), (int)o.S, q2, rem);
+        const float rS = __builtin_amdgcn_rcpf((float)o.S);
+        divmod_small((int)(R << 16), rS, (int)o.S, q0, rem);
+        divmod_small((int)(G << 16), rS, (int)o.S, q1, rem);
+        divmod_small((int)(B << 16), rS, (int)o.S, q2, rem);
     }
     o.q[0] = (unsigned)q0; o.q[1] = (unsigned)q1; o.q[2] = (unsigned)q2;
     const unsigned mx = max(R, max(G, B)), mn = min(R, min(G, B)), delta = mx - mn;
@@ -1572,7 +1583,7 @@ __device__ __forceinline__ ColourPx colour_px(unsigned R, unsigned G, unsigned B
         else num = 48 * (int)delta + 12 * ((int)R - (int)G);
         if (num < 0) num += 72 * (int)delta;
         int b;
-        r360::divmod24(num, (int)delta, b, rem);
+        divmod_small(num, (int)delta, b, rem);
         o.bin = b >= 72 ? b - 72 : b;
     }
     return o;
@@ -1651,20 +1662,31 @@ __global__ __launch_bounds__(kAggThreads) void k_f360_colour(const int* __restri
         atomicAdd(&dst[7], (unsigned long long)a32[4]);
     };
     const int lane = (int)threadIdx.x & 63;
-#pragma unroll 1
+    // three batched rounds of loads (labels, their slots, the colour bytes of every pixel of the thread) in front of the arithmetic: as
+    // a dependent triple per pixel the kernel was a chain of 8 x 3 memory round trips per thread (81 -> 5x us at 4096 x 2048)
+    int slot_j[kColPerThread], row_j[kColPerThread], col_j[kColPerThread];
+    unsigned rgb_j[kColPerThread];
+#pragma unroll
     for (int j = 0; j < kColPerThread; ++j) {
         const int p = (blockIdx.x * kColPerThread + j) * kAggThreads + (int)threadIdx.x;
-        int slot = -1;
-        if (p < n) {
-            const int l = label[p];
-            if (l >= 0) slot = slot_of_root[l];
-        }
+        slot_j[j] = p < n ? label[p] : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < kColPerThread; ++j) slot_j[j] = slot_j[j] >= 0 ? slot_of_root[slot_j[j]] : -1;
+#pragma unroll
+    for (int j = 0; j < kColPerThread; ++j) {
+        const int p = (blockIdx.x * kColPerThread + j) * kAggThreads + (int)threadIdx.x;
+        r360::divmod24(p < n ? p : 0, cols, row_j[j], col_j[j]);      // (IEEE: the row index is not a small quotient for every geometry)
+        const uint8_t* px = img.rgb + (size_t)(row_j[j] * img.sub + img.sub / 2) * img.step + 3 * (size_t)(col_j[j] * img.sub + img.sub / 2);
+        rgb_j[j] = (unsigned)px[0] | ((unsigned)px[1] << 8) | ((unsigned)px[2] << 16);
+    }
+#pragma unroll
+    for (int j = 0; j < kColPerThread; ++j) {
+        const int slot = slot_j[j];
         const bool on = slot >= 0;
         if (__ballot(on) == 0ull) continue;                  // uniform: nothing of a region in these 64 pixels
-        int r, c;
-        r360::divmod24(on ? p : 0, cols, r, c);
-        const uint8_t* px = img.rgb + (size_t)(r * img.sub + img.sub / 2) * img.step + 3 * (size_t)(c * img.sub + img.sub / 2);
-        const unsigned pr = px[0], pg = px[1], pb = px[2];
+        const int r = row_j[j], c = col_j[j];
+        const unsigned pr = rgb_j[j] & 255u, pg = (rgb_j[j] >> 8) & 255u, pb = rgb_j[j] >> 16;
         const ColourPx v = colour_px(pr, pg, pb);
         if (on && slot != key) {
             flush_lane();
@@ -1683,8 +1705,8 @@ __global__ __launch_bounds__(kAggThreads) void k_f360_colour(const int* __restri
             if (on && v.S) {
                 const int2 g = smp.grid[slot];
                 int qq, rr = 0, rc = 0;
-                if (g.x > 1) r360::divmod24(r, g.x, qq, rr);
-                if (g.y > 1) r360::divmod24(c, g.y, qq, rc);
+                if (g.x > 1) divmod_small(r, g.x, qq, rr);
+                if (g.y > 1 && rr == 0) divmod_small(c, g.y, qq, rc);
                 samp = rr == 0 && rc == 0;
             }
             const unsigned rgb = pr | (pg << 8) | (pb << 16);
