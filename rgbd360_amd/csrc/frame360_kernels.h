@@ -1813,11 +1813,9 @@ __global__ __launch_bounds__(kAggThreads) void k_f360_colour(const int* __restri
 // One block per region slot; samples in LDS (16 bytes each).  Results into the region's row of the colour table (kColMode words).
 constexpr int kModeThreads = 256;
 // Also the stage's last kernel: a block copies the finished row of each of its slots into pinned host memory (behind the plane list's
-// other records: one wait ends the call), and the last block to finish publishes the host tag (host_tag != nullptr; `ticket` as in
-// k_f360_hull_pack).
+// other records: one wait ends the call).
 __global__ __launch_bounds__(kModeThreads) void k_f360_colour_mode(const int* __restrict__ n_slots, int max_slots, ColourSamples smp,
-                                                                    unsigned long long* __restrict__ col, unsigned long long* __restrict__ host_out,
-                                                                    unsigned* __restrict__ ticket, unsigned* host_tag, unsigned host_seq) {
+                                                                    unsigned long long* __restrict__ col, unsigned long long* __restrict__ host_out) {
     __shared__ uint4 sm[kModeCap];                 // {qR, qG, qB, S | alive << 31}
     __shared__ unsigned long long acc[8];
     const int ns = min(*n_slots, max_slots);
@@ -1889,7 +1887,7 @@ __global__ __launch_bounds__(kModeThreads) void k_f360_colour_mode(const int* __
                 shift2 = 0;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    const long long mk = (long long)(tot[k] / (unsigned long long)left);
+                    const long long mk = (long long)((unsigned)tot[k] / (unsigned)left);      // (both below 2^32: a 32-bit division, a quarter of the 64-bit one's instructions)
                     shift2 += (unsigned long long)((mk - m[k]) * (mk - m[k]));
                     m[k] = mk;
                 }
@@ -1911,15 +1909,6 @@ __global__ __launch_bounds__(kModeThreads) void k_f360_colour_mode(const int* __
         __syncthreads();                                       // the row is whole (its sums and bins are the previous launch's)
         if (host_out)
             for (int i = threadIdx.x; i < kColWords; i += kModeThreads) host_out[(size_t)slot * kColWords + i] = row[i];
-    }
-    if (host_tag) {                                            // uniform
-        __threadfence_system();                                // this thread's words (pinned host memory) before the ticket
-        __syncthreads();
-        if (threadIdx.x == 0 && __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
-            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // for the next call
-            __threadfence_system();
-            __hip_atomic_store(host_tag, host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
     }
 }
 
@@ -2392,12 +2381,11 @@ __global__ __launch_bounds__(kHullDirs) void k_f360_hull_merge(const int* __rest
         __syncthreads();
     }
 }
-// host_tag != nullptr: this is the last kernel of a plane call -- the block that finishes last (device ticket) stores host_seq into the pinned
-// word the host spins on (host_wait.h), behind everybody's records: no tag launch behind it (4 us of the stream's time).
+// (Until round 5 the last block of this kernel -- a device ticket -- could publish the host tag itself instead of a tag launch behind it:
+// 256 blocks each running a system-scope fence cost 13 us where the tag kernel costs 4; measured again at both sizes, removed.)
 __global__ __launch_bounds__(kHullDirs) void k_f360_hull_pack(const float* __restrict__ xyz, const SlotFrame* __restrict__ frames,
                                                                const unsigned long long* __restrict__ ext, const int* __restrict__ n_slots,
-                                                               int max_slots, F360HullRecord* __restrict__ out, unsigned* __restrict__ ticket,
-                                                               unsigned* host_tag, unsigned host_seq) {
+                                                               int max_slots, F360HullRecord* __restrict__ out) {
     static_assert(kHullMergeSplit % kHullPhases == 0, "the merge blocks of a slot pair up with the direction sets");
     const int k = threadIdx.x;
     const int ns = min(*n_slots, max_slots);
@@ -2450,15 +2438,6 @@ __global__ __launch_bounds__(kHullDirs) void k_f360_hull_pack(const float* __res
         }
         if (k == 0) out[slot].n = total;
         __syncthreads();
-    }
-    if (host_tag) {                                             // uniform
-        __threadfence_system();                                 // this thread's records (pinned host memory) before the ticket
-        __syncthreads();
-        if (k == 0 && __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
-            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // for the next call
-            __threadfence_system();
-            __hip_atomic_store(host_tag, host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
     }
 }
 

@@ -104,7 +104,6 @@ struct rgbd360_ctx {
     unsigned* f_samp_pool = nullptr;                              // one entry per pixel of the largest frame seen
     size_t f_samp_pool_n = 0;
     bool f_col_ran = false;                                       // the last plane call filled f_col_host
-    unsigned* f_ticket = nullptr;                                 // device counter of k_f360_hull_pack's blocks (the last one publishes the host tag)
     unsigned long long* b_sum = nullptr;                          // bilateral grid: fixed-point sums, counts, two float2 ping-pong arrays
     int* b_cnt = nullptr;
     float2 *b_a = nullptr, *b_b = nullptr;
@@ -751,7 +750,7 @@ void rgbd360_destroy(rgbd360_ctx* ctx) {
     hipFree(ctx->f_frames); hipFree(ctx->f_ext); hipFree(ctx->f_hull_keys); hipFree(ctx->f_hull_vals);
     hipFree(ctx->f_xyz); hipFree(ctx->f_normals); hipFree(ctx->f_dist);
     hipFree(ctx->f_change); hipFree(ctx->f_hd); hipFree(ctx->f_label); hipFree(ctx->f_count); hipFree(ctx->f_slot_of_root);
-    hipFree(ctx->f_root_of_slot); hipFree(ctx->f_nslots); hipFree(ctx->f_window); hipFree(ctx->f_mom); hipFree(ctx->f_ticket);
+    hipFree(ctx->f_root_of_slot); hipFree(ctx->f_nslots); hipFree(ctx->f_window); hipFree(ctx->f_mom);
     hipFree(ctx->f_count_of_slot); hipFree(ctx->f_depth_raw); hipFree(ctx->f_pack);
     if (ctx->f_pack_host) hipHostFree(ctx->f_pack_host);
     hipFree(ctx->f_col_owned); hipFree(ctx->f_col); hipFree(ctx->f_samp_off); hipFree(ctx->f_samp_n); hipFree(ctx->f_samp_grid); hipFree(ctx->f_samp_pool);
@@ -1880,10 +1879,6 @@ int f360_ensure(rgbd360_ctx* ctx, size_t n) {
     HIPC(ctx, hipMalloc(&ctx->f_window, n * sizeof(int)));
     HIPC(ctx, hipMalloc(&ctx->f_root_of_slot, kF360MaxSlots * sizeof(int)));
     HIPC(ctx, hipMalloc(&ctx->f_nslots, sizeof(int)));
-    if (!ctx->f_ticket) {
-        HIPC(ctx, hipMalloc(&ctx->f_ticket, sizeof(unsigned)));
-        HIPC(ctx, hipMemset(ctx->f_ticket, 0, sizeof(unsigned)));
-    }
     HIPC(ctx, hipMalloc(&ctx->f_mom, (size_t)f360::kMomReplicas * kF360MaxSlots * 9 * sizeof(unsigned long long)));
     HIPC(ctx, hipMalloc(&ctx->f_count_of_slot, kF360MaxSlots * sizeof(int)));
     // pinned: header, one moment record per slot, one hull record per slot behind them
@@ -2159,12 +2154,7 @@ const f360::F360HullRecord* hull_records(const rgbd360_ctx* ctx) {
     return reinterpret_cast<const f360::F360HullRecord*>(ctx->f_pack_host + f360::kF360PackHeader + (size_t)kF360MaxSlots * sizeof(f360::F360SlotRecord));
 }
 // the extremes of the CURRENT labels (ctx->f_label) against the frames of the slots, packed for the host; enqueued on the stream
-// tag_behind: the pack kernel is the call's last one and publishes the host tag itself (the caller then waits with hostwait::wait, not tag_and_wait)
-bool colour_can_run(const rgbd360_ctx* ctx, int rows, int cols) {
-    const f360::ColourImage& im = ctx->f_col_img;
-    return im.rgb && im.sub >= 1 && ctx->f_col_rows / im.sub == rows && ctx->f_col_cols / im.sub == cols;
-}
-void launch_hull(rgbd360_ctx* ctx, int rows, int cols, bool clear_first, bool tag_behind = false) {
+void launch_hull(rgbd360_ctx* ctx, int rows, int cols, bool clear_first) {
     using namespace f360;
     const int n = rows * cols;
     if (clear_first) hipLaunchKernelGGL(k_f360_hull_clear, dim3((kF360MaxSlots * kHullPhases * kHullDirs + 255) / 256), dim3(256), 0, ctx->stream, ctx->f_nslots, kF360MaxSlots, ctx->f_ext);
@@ -2183,7 +2173,7 @@ void launch_hull(rgbd360_ctx* ctx, int rows, int cols, bool clear_first, bool ta
     hipLaunchKernelGGL(k_f360_hull_merge, dim3(64, kHullMergeSplit), dim3(kHullDirs), 0, ctx->stream, ctx->f_nslots, kF360MaxSlots, ctx->f_hull_keys, ctx->f_hull_vals,
                        nblk, ctx->f_ext);
     hipLaunchKernelGGL(k_f360_hull_pack, dim3(256), dim3(kHullDirs), 0, ctx->stream, ctx->f_xyz, ctx->f_frames, ctx->f_ext, ctx->f_nslots, kF360MaxSlots,
-                       const_cast<F360HullRecord*>(hull_records(ctx)), ctx->f_ticket, tag_behind ? ctx->tag.h : nullptr, tag_behind ? ++ctx->tag.seq : 0u);
+                       const_cast<F360HullRecord*>(hull_records(ctx)));
 }
 
 // eigenpairs of a symmetric 3x3 in ascending order (cyclic Jacobi, float64) -- pcl::eigen33's role for the smallest one
@@ -2200,8 +2190,7 @@ void sorted_eigen3(const double C[3][3], double evals[3], double evecs[3][3]) { 
 
 // Colour descriptors of the regions in their slots (k_f360_colour over the CURRENT labels), enqueued on the stream: the table rows in
 // use land in pinned host memory.  Only when a colour image of this cloud's geometry is registered.
-// tag_behind: the stage's last kernel publishes the host tag itself (the caller then waits with hostwait::wait); false when nothing was launched
-bool launch_colour(rgbd360_ctx* ctx, int rows, int cols, bool tag_behind = false) {
+bool launch_colour(rgbd360_ctx* ctx, int rows, int cols) {
     using namespace f360;
     ctx->f_col_ran = false;
     const ColourImage& im = ctx->f_col_img;
@@ -2226,8 +2215,7 @@ bool launch_colour(rgbd360_ctx* ctx, int rows, int cols, bool tag_behind = false
                        ctx->f_samp_grid, ctx->f_col);
     hipLaunchKernelGGL(k_f360_colour, dim3((n + kAggThreads * kColPerThread - 1) / (kAggThreads * kColPerThread)), dim3(kAggThreads), 0, ctx->stream,
                        ctx->f_label, ctx->f_slot_of_root, rows, cols, im, ctx->f_col, smp);
-    hipLaunchKernelGGL(k_f360_colour_mode, dim3(256), dim3(kModeThreads), 0, ctx->stream, ctx->f_nslots, kF360MaxSlots, smp, ctx->f_col, ctx->f_col_host,
-                       ctx->f_ticket, tag_behind ? ctx->tag.h : nullptr, tag_behind ? ++ctx->tag.seq : 0u);
+    hipLaunchKernelGGL(k_f360_colour_mode, dim3(256), dim3(kModeThreads), 0, ctx->stream, ctx->f_nslots, kF360MaxSlots, smp, ctx->f_col, ctx->f_col_host);
     ctx->f_col_ran = true;
     return true;
 }
@@ -2350,13 +2338,10 @@ int f360_refine_dev(rgbd360_ctx* ctx, int rows, int cols, int nslots, std::vecto
                        ctx->f_root_of_slot, ctx->f_count_of_slot, ctx->f_pack_host);
     // the contour PCL hands to calcConvexHull is that of the REFINED region, projected with the plane `segment` fitted: extremes of the
     // committed labels against the frames k_f360_slot_frames left before the refinement
-    bool pack_tags = !colour_can_run(ctx, rows, cols);             // the hull's pack kernel is the last one: it publishes the host tag itself
-    launch_hull(ctx, rows, cols, /*clear_first=*/true, pack_tags);
-    if (!pack_tags) pack_tags = launch_colour(ctx, rows, cols, /*tag_behind=*/true);      // the colour of the REFINED inlier sets (Frame360.h:1045-1046 run on the refined regions); its last kernel tags
-    else ctx->f_col_ran = false;
+    launch_hull(ctx, rows, cols, /*clear_first=*/true);
+    launch_colour(ctx, rows, cols);          // the colour of the REFINED inlier sets (Frame360.h:1045-1046 run on the refined regions); a no-op without a colour image
     HIPC(ctx, hipGetLastError());
-    if (pack_tags) HIPC(ctx, hostwait::wait(ctx->tag, ctx->stream));
-    else HIPC(ctx, hostwait::tag_and_wait(ctx->tag, ctx->stream));      // (a tag kernel + host spin: ~10 us less than hipStreamSynchronize, host_wait.h)
+    HIPC(ctx, hostwait::tag_and_wait(ctx->tag, ctx->stream));      // (a tag kernel + host spin: ~10 us less than hipStreamSynchronize, host_wait.h)
     ctx->f_refine_changed = ctx->f_flags_host[kFlags];
     ctx->f_refine_sweeps = sweeps;
     // count and the extent descriptors of the grown inlier sets (Frame360.h:1010-1037 derives them from the refined inlier cloud);
@@ -2457,15 +2442,14 @@ int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float
     hipLaunchKernelGGL(k_f360_slot_frames, dim3(256), dim3(64), 0, ctx->stream, ctx->f_mom, ctx->f_nslots, kF360MaxSlots,
                        ctx->f_count_of_slot, ctx->f_frames, ctx->f_ext, ctx->f_root_of_slot, ctx->f_pack_host);
     ctx->f_col_ran = false;
-    bool pack_tags = false;
     if (!ctx->f_refine) {
-        pack_tags = !colour_can_run(ctx, rows, cols);               // the hull's pack kernel is the last one: it publishes the host tag itself
-        launch_hull(ctx, rows, cols, /*clear_first=*/false, pack_tags);
-        if (!pack_tags) pack_tags = launch_colour(ctx, rows, cols, /*tag_behind=*/true);      // ... or the colour stage's
+        launch_hull(ctx, rows, cols, /*clear_first=*/false);
+        launch_colour(ctx, rows, cols);       // (a no-op without a colour image of this geometry)
     }
     HIPC(ctx, hipGetLastError());
-    if (pack_tags) HIPC(ctx, hostwait::wait(ctx->tag, ctx->stream));
-    else HIPC(ctx, hostwait::tag_and_wait(ctx->tag, ctx->stream));      // (a tag kernel + host spin: ~10 us less than hipStreamSynchronize, host_wait.h)
+    // one tag kernel behind the chain + a host spin (~10 us less than hipStreamSynchronize, host_wait.h).  Until round 5 the chain's last
+    // kernel published the tag from its last block: 256 blocks x a system-scope fence cost 10-22 us more than this launch.
+    HIPC(ctx, hostwait::tag_and_wait(ctx->tag, ctx->stream));
     const int nslots = *reinterpret_cast<const volatile int*>(ctx->f_pack_host);
     if (nslots > kF360MaxSlots) return fail(ctx, -7, "more than 4096 regions exceed min_inliers");
     const F360SlotRecord* recs = reinterpret_cast<const F360SlotRecord*>(ctx->f_pack_host + kF360PackHeader);
