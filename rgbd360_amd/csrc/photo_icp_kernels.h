@@ -1340,8 +1340,10 @@ __device__ __forceinline__ void solve_block(GNState* st_g, const double* __restr
     SOLVE_STAMP(0);
     if (cfg.mode == 0 && (sh.sst.done || sh.sst.level_active != cfg.level)) {            // uniform: finished / other level
         if (cfg.host_state) {                               // the schedule's last launch reports even when it has nothing to do
-            if (tid < kStateWords) reinterpret_cast<int*>(cfg.host_state)[tid] = reinterpret_cast<const int*>(&sh.sst)[tid];
-            __threadfence_system();
+            if (tid < 64) {
+                for (int w = tid; w < kStateWords; w += 64) reinterpret_cast<int*>(cfg.host_state)[w] = reinterpret_cast<const int*>(&sh.sst)[w];
+                __threadfence_system();
+            }
             __syncthreads();
             if (tid == 0) __hip_atomic_store(cfg.host_tag, cfg.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -1357,8 +1359,12 @@ __device__ __forceinline__ void solve_block(GNState* st_g, const double* __restr
 #endif
     if (tid < kStateWords) reinterpret_cast<int*>(st_g)[tid] = reinterpret_cast<const int*>(&sh.sst)[tid];
     if (cfg.host_state) {                                   // uniform
-        if (tid < kStateWords) reinterpret_cast<int*>(cfg.host_state)[tid] = reinterpret_cast<const int*>(&sh.sst)[tid];
-        __threadfence_system();
+        // (one wave writes the state's ~230 words and runs the one system-scope fence: sixteen waves each asking for a write-back cost
+        // the launch 3-4 us)
+        if (tid < 64) {
+            for (int w = tid; w < kStateWords; w += 64) reinterpret_cast<int*>(cfg.host_state)[w] = reinterpret_cast<const int*>(&sh.sst)[w];
+            __threadfence_system();
+        }
         __syncthreads();
         if (tid == 0) __hip_atomic_store(cfg.host_tag, cfg.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -1612,8 +1618,12 @@ __global__ __launch_bounds__(kSolveThreads) void k_solve_pending(GNState* st_g, 
     }
     if (tid < kStateWords) reinterpret_cast<int*>(st_g)[tid] = reinterpret_cast<const int*>(&sh.sst)[tid];
     if (cfg.host_state) {                                   // uniform
-        if (tid < kStateWords) reinterpret_cast<int*>(cfg.host_state)[tid] = reinterpret_cast<const int*>(&sh.sst)[tid];
-        __threadfence_system();
+        // (one wave writes the state's ~230 words and runs the one system-scope fence: sixteen waves each asking for a write-back cost
+        // the launch 3-4 us)
+        if (tid < 64) {
+            for (int w = tid; w < kStateWords; w += 64) reinterpret_cast<int*>(cfg.host_state)[w] = reinterpret_cast<const int*>(&sh.sst)[w];
+            __threadfence_system();
+        }
         __syncthreads();
         if (tid == 0) __hip_atomic_store(cfg.host_tag, cfg.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }

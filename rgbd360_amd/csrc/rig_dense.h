@@ -170,8 +170,8 @@ __global__ __launch_bounds__(256) void k_rig_reduce(const double* __restrict__ p
 #pragma unroll
         for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x];
         out[(size_t)s * kNumPartials + threadIdx.x] = t;
+        __threadfence_system();        // this block's totals (written by this wave alone) are on their way to the host before it takes its ticket
     }
-    __threadfence_system();            // this block's totals are on their way to the host before it takes its ticket
     __syncthreads();
     // acq_rel on the ticket: the block that draws the last number synchronises with every earlier block's release, so their host
     // writes (fenced above) are ordered before the tag it stores next
