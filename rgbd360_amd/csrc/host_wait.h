@@ -53,11 +53,11 @@ __global__ void k_tag(unsigned* tag, unsigned seq) {
     __hip_atomic_store(tag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // n_words 32-bit words from device memory into the pinned host buffer, then the tag
-__global__ __launch_bounds__(256) void k_publish(const unsigned* __restrict__ src, unsigned* __restrict__ dst_host, int n_words, unsigned* tag,
-                                                 unsigned seq) {
+// (one wave: every wave that runs a system-scope fence asks for its own write-back, and a few hundred words do not need four)
+__global__ __launch_bounds__(64) void k_publish(const unsigned* __restrict__ src, unsigned* __restrict__ dst_host, int n_words, unsigned* tag,
+                                                unsigned seq) {
     for (int i = threadIdx.x; i < n_words; i += blockDim.x) dst_host[i] = src[i];
     __threadfence_system();
-    __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(tag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
@@ -82,7 +82,7 @@ inline hipError_t tag_and_wait(SpinTag& t, hipStream_t stream) {
 }
 // copy `bytes` (a multiple of 4) of device memory into a pinned host buffer through the stream and wait for them
 inline hipError_t publish_and_wait(SpinTag& t, hipStream_t stream, const void* src_dev, void* dst_host, size_t bytes) {
-    hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, stream, (const unsigned*)src_dev, (unsigned*)dst_host, (int)(bytes / 4), t.h, ++t.seq);
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, stream, (const unsigned*)src_dev, (unsigned*)dst_host, (int)(bytes / 4), t.h, ++t.seq);
     const hipError_t e = hipGetLastError();
     return e != hipSuccess ? e : wait(t, stream);
 }
