@@ -1837,12 +1837,27 @@ __global__ __launch_bounds__(kModeThreads) void k_f360_colour_mode(const int* __
             if (threadIdx.x < 8) acc[threadIdx.x] = 0ull;
             __syncthreads();
             unsigned long long s1[3] = {0, 0, 0}, s2[3] = {0, 0, 0};
-            for (int i = threadIdx.x; i < N; i += kModeThreads) {
-                const unsigned w = smp.pool[smp.samp_off[slot] + i];
-                const ColourPx v = colour_px(w & 255u, (w >> 8) & 255u, (w >> 16) & 255u);
-                sm[i] = make_uint4(v.q[0], v.q[1], v.q[2], v.S | 0x80000000u);
+            {
+                // every sample of the thread requested before the first is used (a load per trip of a rolled loop was a round trip per trip)
+                constexpr int kPer = kModeCap / kModeThreads;
+                const int off = smp.samp_off[slot];
+                unsigned wv[kPer];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) { s1[k] += v.q[k]; s2[k] += (unsigned long long)v.q[k] * v.q[k]; }
+                for (int u = 0; u < kPer; ++u) {
+                    const int i = (int)threadIdx.x + u * kModeThreads;
+                    wv[u] = i < N ? smp.pool[off + i] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < kPer; ++u) {
+                    const int i = (int)threadIdx.x + u * kModeThreads;
+                    if (i < N) {
+                        const unsigned w = wv[u];
+                        const ColourPx v = colour_px(w & 255u, (w >> 8) & 255u, (w >> 16) & 255u);
+                        sm[i] = make_uint4(v.q[0], v.q[1], v.q[2], v.S | 0x80000000u);
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) { s1[k] += v.q[k]; s2[k] += (unsigned long long)v.q[k] * v.q[k]; }
+                    }
+                }
             }
 #pragma unroll
             for (int k = 0; k < 3; ++k) { block_add(k, s1[k]); block_add(3 + k, s2[k]); }
