@@ -107,7 +107,8 @@ struct rgbd360_ctx {
     unsigned long long* b_sum = nullptr;                          // bilateral grid: fixed-point sums, counts, two float2 ping-pong arrays
     int* b_cnt = nullptr;
     float2 *b_a = nullptr, *b_b = nullptr;
-    unsigned* b_mm = nullptr;
+    unsigned* b_mm = nullptr;                                     // per-block {min, max} codes of the depth range
+    unsigned* b_mm_host = nullptr;                                // ... the pair, published into pinned memory
     size_t b_cells = 0;
     float* f_tab = nullptr;
     size_t f_tab_n = 0;
@@ -759,7 +760,7 @@ void rgbd360_destroy(rgbd360_ctx* ctx) {
     ctx->f_col_owned = nullptr; ctx->f_col = nullptr; ctx->f_col_host = nullptr; ctx->f_col_owned_bytes = 0;
     hipFree(ctx->f_models);
     if (ctx->f_flags_host) hipHostFree(ctx->f_flags_host);
-    hipFree(ctx->b_sum); hipFree(ctx->b_cnt); hipFree(ctx->b_a); hipFree(ctx->b_b); hipFree(ctx->b_mm);
+    hipFree(ctx->b_sum); hipFree(ctx->b_a); hipFree(ctx->b_b); hipFree(ctx->b_mm); if (ctx->b_mm_host) hipHostFree(ctx->b_mm_host);
     hipFree(ctx->occ_head); hipFree(ctx->occ_nodes); hipFree(ctx->occ_runinfo);
     if (ctx->h_state) hipHostFree(ctx->h_state);
     hostwait::spin_tag_free(&ctx->tag);
@@ -1996,13 +1997,16 @@ int f360_bilateral_dev(rgbd360_ctx* ctx, int rows, int cols, float sigma_s, floa
     using namespace f360;
     if (!(sigma_s > 0.f) || !(sigma_r > 0.f)) return fail(ctx, -1, "sigma_s and sigma_r must be positive");
     const int n = rows * cols;
-    if (!ctx->b_mm) HIPC(ctx, hipMalloc(&ctx->b_mm, 2 * sizeof(unsigned)));
-    HIPC(ctx, hipMemsetAsync(ctx->b_mm, 0xff, sizeof(unsigned), ctx->stream));          // min starts at the largest code,
-    HIPC(ctx, hipMemsetAsync(ctx->b_mm + 1, 0, sizeof(unsigned), ctx->stream));         // max at the smallest
-    hipLaunchKernelGGL(k_bilat_minmax, dim3(std::min(256, (n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->f_xyz, n, ctx->b_mm);
-    unsigned mm[2];
-    HIPC(ctx, hipMemcpyAsync(mm, ctx->b_mm, sizeof(mm), hipMemcpyDeviceToHost, ctx->stream));
-    HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    constexpr int kMmBlocks = 64;
+    if (!ctx->b_mm) HIPC(ctx, hipMalloc(&ctx->b_mm, 2 * kMmBlocks * sizeof(unsigned)));
+    if (!ctx->b_mm_host) HIPC(ctx, hipHostMalloc((void**)&ctx->b_mm_host, 2 * sizeof(unsigned), hostwait::kPublishedFlags));
+    // the depth range: per-block pairs, folded and published by a one-wave kernel; the host spins on the tag (no memset, copy or stream synchronise)
+    const int mm_blocks = std::min(kMmBlocks, (n + 4 * kBilatMmThreads - 1) / (4 * kBilatMmThreads));
+    hipLaunchKernelGGL(k_bilat_minmax, dim3(mm_blocks), dim3(kBilatMmThreads), 0, ctx->stream, ctx->f_xyz, n, ctx->b_mm);
+    hipLaunchKernelGGL(k_bilat_minmax_publish, dim3(1), dim3(64), 0, ctx->stream, ctx->b_mm, mm_blocks, ctx->b_mm_host, ctx->tag.h, ++ctx->tag.seq);
+    HIPC(ctx, hipGetLastError());
+    HIPC(ctx, hostwait::wait(ctx->tag, ctx->stream));
+    const unsigned mm[2] = {reinterpret_cast<const volatile unsigned*>(ctx->b_mm_host)[0], reinterpret_cast<const volatile unsigned*>(ctx->b_mm_host)[1]};
     if (mm[0] > mm[1]) return 0;                                   // no finite z: the cloud stays as it is
     auto decode = [](unsigned e) {
         const unsigned u = (e & 0x80000000u) ? (e & 0x7fffffffu) : ~e;
@@ -2022,16 +2026,16 @@ int f360_bilateral_dev(rgbd360_ctx* ctx, int rows, int cols, float sigma_s, floa
     g.nz = (int)(base_delta / sigma_r) + 1 + 2 * kBilatPadZ;
     const size_t cells = (size_t)g.nx * g.ny * g.nz;
     if (ctx->b_cells < cells) {
-        hipFree(ctx->b_sum); hipFree(ctx->b_cnt); hipFree(ctx->b_a); hipFree(ctx->b_b);
+        hipFree(ctx->b_sum); hipFree(ctx->b_a); hipFree(ctx->b_b);
         ctx->b_sum = nullptr; ctx->b_cnt = nullptr; ctx->b_a = ctx->b_b = nullptr; ctx->b_cells = 0;
-        HIPC(ctx, hipMalloc(&ctx->b_sum, cells * sizeof(unsigned long long)));
-        HIPC(ctx, hipMalloc(&ctx->b_cnt, cells * sizeof(int)));
+        HIPC(ctx, hipMalloc(&ctx->b_sum, cells * (sizeof(unsigned long long) + sizeof(int))));      // sums, then counts: one allocation, one memset
+        ctx->b_cnt = reinterpret_cast<int*>(ctx->b_sum + cells);
         HIPC(ctx, hipMalloc(&ctx->b_a, cells * sizeof(float2)));
         HIPC(ctx, hipMalloc(&ctx->b_b, cells * sizeof(float2)));
         ctx->b_cells = cells;
     }
-    HIPC(ctx, hipMemsetAsync(ctx->b_sum, 0, cells * sizeof(unsigned long long), ctx->stream));
-    HIPC(ctx, hipMemsetAsync(ctx->b_cnt, 0, cells * sizeof(int), ctx->stream));
+    ctx->b_cnt = reinterpret_cast<int*>(ctx->b_sum + cells);      // (behind THIS call's cells: the buffer may be larger)
+    HIPC(ctx, hipMemsetAsync(ctx->b_sum, 0, cells * (sizeof(unsigned long long) + sizeof(int)), ctx->stream));
     const dim3 gp((n + 255) / 256), gc((unsigned)((cells + 255) / 256)), b(256);
     hipLaunchKernelGGL(k_bilat_scatter, gp, b, 0, ctx->stream, ctx->f_xyz, rows, cols, g, ctx->b_sum, ctx->b_cnt);
     hipLaunchKernelGGL(k_bilat_init, gc, b, 0, ctx->stream, ctx->b_sum, ctx->b_cnt, cells, ctx->b_a, ctx->b_b);
