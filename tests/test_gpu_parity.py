@@ -1275,6 +1275,32 @@ def test_pinhole_occlusion_eval_parity(hip_lib, oracle_mod, method, occ):
     assert longest >= 3
 
 
+@pytest.mark.parametrize("push", [3.0, 20.0, 200.0])
+def test_pinhole_occlusion_long_arrival_lists(hip_lib, oracle_mod, push):
+    """Poses that pile many source pixels on one target pixel (a zoom-out, a push, a collapse of the image onto a few pixels): lists
+    longer than a target's slot row are visited by scanning the key array over the box of their arrivals -- the same sequential
+    z-buffer semantics, counts exact, whatever the list length.  Both passes of both occlusion modes, every level."""
+    reg, ora, T = _pinhole_ctx(hip_lib, oracle_mod)
+    P = np.eye(4)
+    P[2, 3] = push
+    pose = P @ T
+    longest = 0
+    for level in range(3):
+        idx = ora.warp_indices_pinhole(level, pose)
+        v = idx[:, 0] >= 0
+        longest = max(longest, int(np.unique(idx[v, 0] * 4096 + idx[v, 1], return_counts=True)[1].max()))
+        for method, occ in ((2, 1), (2, 2), (0, 1)):
+            e = reg.eval_pinhole(level, pose, method, occ)
+            _, sp, sd, n_p, n_d = ora.error_pinhole_occ(level, pose, method, occ)
+            H, g, Hd, gd, nvis = ora.hessgrad_pinhole_occ(level, pose, method, occ)
+            assert list(e["n_split"]) == [n_p, n_d] and e["n_rows"] == nvis, (level, method, occ, list(e["n_split"]), n_p, n_d, e["n_rows"], nvis)
+            assert abs(e["err2_split"][0] - sp) <= ERR2_RTOL * max(1.0, abs(sp)) and abs(e["err2_split"][1] - sd) <= ERR2_RTOL * max(1.0, abs(sd))
+            scale_h = max(np.abs(Hd).max(), 1e-30)
+            assert np.abs(e["H64"] - Hd).max() <= HG_RTOL * scale_h
+            assert np.abs(e["g64"] - gd).max() <= HG_RTOL * max(np.abs(gd).max(), 1e-3 * np.sqrt(scale_h))
+    assert longest > 8          # beyond the slot rows: the box scans ran
+
+
 def test_pinhole_occlusion_eval_occlusion_zero_is_the_plain_pass(hip_lib, oracle_mod):
     reg, ora, T = _pinhole_ctx(hip_lib, oracle_mod)
     a, b = reg.eval_pinhole(1, T, 2), reg.eval_pinhole(1, T, 2, 0)
