@@ -441,6 +441,35 @@ def _check_hull_polygon(p, area_rtol=2e-3):
 
 
 @pytest.mark.gpu
+def test_hull_polygon_of_a_disc_is_thinned_to_64_vertices(hip_lib):
+    """A disc on a fronto-parallel plane has an extreme pixel in every one of the hull stage's directions: far more than the 64 vertices a
+    plane record carries, so the record's polygon is the hull's extreme vertex in 64 evenly spaced directions (found by ONE walk round the
+    hull: the extreme vertex only moves forward as the direction turns).  Convex, counter-clockwise, inside the hull, and its area within
+    the inscribed 64-gon's share of the disc (cos-free bound: 1 - (pi / 64)^2 * 2 / 3 > 0.998)."""
+    from rgbd360_amd.register import Frame360Stages
+    H = W = 256
+    jj, ii = np.meshgrid(np.arange(W), np.arange(H))
+    inside = (jj - 127.5) ** 2 + (ii - 127.5) ** 2 <= 100.0 ** 2
+    z = np.where(inside, 2.0, np.nan).astype(np.float32)
+    x = ((jj - W / 2) * 0.004 * 2.0).astype(np.float32)
+    y = ((ii - H / 2) * 0.004 * 2.0).astype(np.float32)
+    xyz = np.stack([np.where(inside, x, np.nan), np.where(inside, y, np.nan), z], axis=-1).reshape(-1, 3).astype(np.float32)
+    nrm = np.tile(np.array([0.0, 0.0, -1.0], np.float32), (H * W, 1))
+    nrm[~inside.reshape(-1)] = np.nan
+    st = Frame360Stages(_mk(hip_lib, 2))
+    labels, planes = st.plane_fit(xyz, nrm, H, W, 40, 0.05, 0.05, 0.01, 0)
+    assert len(planes) == 1
+    p = planes[0]
+    assert p["hull_points"] > 64 and len(p["hull"]) > 48, (p["hull_points"], len(p["hull"]))
+    _check_hull_polygon(p)
+    r = 100.0 * 0.008
+    assert 0.99 * np.pi * r * r < p["area"] < 1.001 * np.pi * r * r
+    ang = np.unwrap(np.arctan2(p["hull"][:, 1] - p["center_hull"][1], p["hull"][:, 0] - p["center_hull"][0]))
+    steps = np.abs(np.diff(np.concatenate([ang, [ang[0] + np.sign(ang[-1] - ang[0]) * 2 * np.pi]])))
+    assert steps.max() < 2.5 * 2 * np.pi / 64, steps.max()          # no gap of several directions: every direction found its vertex
+
+
+@pytest.mark.gpu
 def test_hull_stage_on_a_striped_image(hip_lib, oracle_mod):
     """The hull stage where EVERY other pixel is a boundary pixel: a fronto-parallel staircase, 4-pixel-wide stripes alternating between
     two depths (the plane comparator's distance test separates them), so a block's share of boundary pixels is several times the
