@@ -470,6 +470,38 @@ def test_hull_polygon_of_a_disc_is_thinned_to_64_vertices(hip_lib):
 
 
 @pytest.mark.gpu
+def test_colour_stage_on_a_striped_image(hip_lib, oracle_mod):
+    """The colour stage where a block of 8192 pixels holds 64 small regions, every pixel of which is a sample of the dominant-colour
+    search: more regions than the block's 16-entry table and more samples than its 4096-entry list hold, so sums, hue bins and samples
+    also take their direct routes to the global table / the regions' counters.  Descriptors and dominant colours exact against the
+    numpy restatement, as on a frame of a few large regions."""
+    from rgbd360_amd.register import Frame360Stages
+    H, W = 128, 256
+    jj, ii = np.meshgrid(np.arange(W), np.arange(H))
+    z = np.where((jj // 4) % 2 == 0, 2.0, 2.6).astype(np.float32)
+    x = ((jj - W / 2) * 0.004 * z).astype(np.float32)
+    y = ((ii - H / 2) * 0.004 * z).astype(np.float32)
+    xyz = np.stack([x, y, z], axis=-1).reshape(-1, 3).astype(np.float32)
+    nrm = np.tile(np.array([0.0, 0.0, -1.0], np.float32), (H * W, 1))
+    rng = np.random.default_rng(12)
+    base = rng.integers(30, 226, size=(W // 4, 3))
+    rgb = np.clip(base[jj // 4] + rng.integers(-25, 26, size=(H, W, 3)), 0, 255).astype(np.uint8)
+    rgb[::7, ::5] = 0                                  # black pixels: no normalised colour, the dark hue bin
+    st = Frame360Stages(_mk(hip_lib, 2))
+    st.set_color_image(rgb)
+    labels, planes = st.plane_fit(xyz, nrm, H, W, 40, 0.05, 0.05, 0.01, 0)
+    assert len(planes) == W // 4
+    _, want = oracle_mod.f360_plane_colour(labels.reshape(H, W), rgb, planes)
+    modes = oracle_mod.f360_plane_colour_mode(labels.reshape(H, W), rgb, planes)
+    for p, w, m in zip(planes, want, modes):
+        assert p["color_count"] == w["color_count"] > 0
+        assert np.abs(p["color_nrgb"] - w["color_nrgb"]).max() <= 1e-7 and np.abs(p["color_dev"] - w["color_dev"]).max() <= 2e-6
+        assert np.abs(p["hist_h"] - w["hist_h"]).max() <= 1e-7
+        assert p["color_mode_count"] == m["color_mode_count"] == p["color_count"]          # 512-pixel regions: every coloured pixel is a sample
+        assert np.array_equal(p["color_mode"], m["color_mode"]) and p["intensity_mode"] == m["intensity_mode"] and p["color_concentration"] == m["color_concentration"]
+
+
+@pytest.mark.gpu
 def test_hull_stage_on_a_striped_image(hip_lib, oracle_mod):
     """The hull stage where EVERY other pixel is a boundary pixel: a fronto-parallel staircase, 4-pixel-wide stripes alternating between
     two depths (the plane comparator's distance test separates them), so a block's share of boundary pixels is several times the
