@@ -1491,10 +1491,13 @@ struct F360SlotRecord {
 constexpr int kF360PackHeader = 16;            // bytes: int n_slots + padding, the records follow (8-byte aligned)
 __global__ void k_f360_mom_reduce(const unsigned long long* __restrict__ mom, const int* __restrict__ n_slots, int max_slots,
                                   const int* __restrict__ root_of_slot, const int* __restrict__ count_of_slot,
-                                  unsigned char* __restrict__ pack) {
+                                  unsigned char* __restrict__ pack, const int* __restrict__ relabelled, int* __restrict__ relabelled_host) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int ns_all = *n_slots;
-    if (i == 0) *reinterpret_cast<int*>(pack) = ns_all;
+    if (i == 0) {
+        *reinterpret_cast<int*>(pack) = ns_all;
+        if (relabelled_host) *relabelled_host = *relabelled;      // the commit's counter travels with the records (no copy command of its own)
+    }
     const int ns = ns_all < max_slots ? ns_all : max_slots;
     if (i >= ns * 9) return;
     unsigned long long acc = mom[i];
@@ -2476,9 +2479,13 @@ constexpr int kRefTH = 16, kRefWaves = 4;
 #ifndef F360_REFINE_SLEEP
 #define F360_REFINE_SLEEP 8
 #endif
+// W2: the iterate the tile launches relax in place starts as a copy of the pass labels; counters: {relabelled pixels, activity}, cleared here
+// (the copy and the two clears were commands of their own: ~5 us each on the stream of a call that takes 0.3 ms on a sensor image)
 __global__ void k_f360_refine_init(const int* __restrict__ label, const int* __restrict__ slot_of_root, const float4* __restrict__ models, int n,
-                                   int cols, int tiles_x, int* __restrict__ W, unsigned char* __restrict__ tile_free) {
+                                   int cols, int tiles_x, int* __restrict__ W, int* __restrict__ W2, unsigned char* __restrict__ tile_free,
+                                   int* __restrict__ counters) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) counters[0] = counters[1] = 0;
     if (i >= n) return;
     const int l = label[i];
     int w = kRefInvalid;
@@ -2491,6 +2498,7 @@ __global__ void k_f360_refine_init(const int* __restrict__ label, const int* __r
         }
     }
     W[i] = w;
+    W2[i] = w;
     if (w == kRefFree) {                       // only tiles with free pixels have anything to do
         const int r = i / cols, c = i - r * cols;
         tile_free[(r / kRefTH) * tiles_x + (c >> 6)] = 1;

@@ -107,6 +107,7 @@ struct rgbd360_ctx {
     unsigned long long* b_sum = nullptr;                          // bilateral grid: fixed-point sums, counts, two float2 ping-pong arrays
     int* b_cnt = nullptr;
     float2 *b_a = nullptr, *b_b = nullptr;
+    float4* f_models_host = nullptr;                              // pinned staging of the refinement's plane models
     unsigned* b_mm = nullptr;                                     // per-block {min, max} codes of the depth range
     unsigned* b_mm_host = nullptr;                                // ... the pair, published into pinned memory
     size_t b_cells = 0;
@@ -760,7 +761,7 @@ void rgbd360_destroy(rgbd360_ctx* ctx) {
     ctx->f_col_owned = nullptr; ctx->f_col = nullptr; ctx->f_col_host = nullptr; ctx->f_col_owned_bytes = 0;
     hipFree(ctx->f_models);
     if (ctx->f_flags_host) hipHostFree(ctx->f_flags_host);
-    hipFree(ctx->b_sum); hipFree(ctx->b_a); hipFree(ctx->b_b); hipFree(ctx->b_mm); if (ctx->b_mm_host) hipHostFree(ctx->b_mm_host);
+    hipFree(ctx->b_sum); hipFree(ctx->b_a); hipFree(ctx->b_b); hipFree(ctx->b_mm); if (ctx->b_mm_host) hipHostFree(ctx->b_mm_host); if (ctx->f_models_host) hipHostFree(ctx->f_models_host);
     hipFree(ctx->occ_head); hipFree(ctx->occ_nodes); hipFree(ctx->occ_runinfo);
     if (ctx->h_state) hipHostFree(ctx->h_state);
     hostwait::spin_tag_free(&ctx->tag);
@@ -2267,23 +2268,24 @@ int f360_refine_dev(rgbd360_ctx* ctx, int rows, int cols, int nslots, std::vecto
     if (!ctx->f_models) HIPC(ctx, hipMalloc(&ctx->f_models, (kF360MaxSlots + 1) * sizeof(float4)));      // + one slot: the relabelled-pixel counter
     int* d_changed = reinterpret_cast<int*>(ctx->f_models + kF360MaxSlots);     // (device memory: 166 k atomics into pinned host memory took 8 ms)
     int* d_activity = d_changed + 1;                                            // bumped by every relaxation step that changed a label
-    HIPC(ctx, hipMemsetAsync(d_activity, 0, sizeof(int), ctx->stream));
     constexpr int kFlags = 64;
     if (!ctx->f_flags_host) HIPC(ctx, hipHostMalloc((void**)&ctx->f_flags_host, (kFlags + 1) * sizeof(int), hostwait::kPublishedFlags));
-    std::vector<float4> models(nslots, make_float4(NAN, 0.f, 0.f, 0.f));
+    // (the plane models go up from a pinned buffer: a copy out of pageable memory is staged by the runtime)
+    if (!ctx->f_models_host) HIPC(ctx, hipHostMalloc((void**)&ctx->f_models_host, kF360MaxSlots * sizeof(float4), 0));
+    float4* models = ctx->f_models_host;
+    for (int s2 = 0; s2 < nslots; ++s2) models[s2] = make_float4(NAN, 0.f, 0.f, 0.f);
     for (size_t k = 0; k < planes.size(); ++k)
         models[plane_slot[k]] = make_float4(planes[k].normal[0], planes[k].normal[1], planes[k].normal[2], planes[k].d);
-    HIPC(ctx, hipMemcpyAsync(ctx->f_models, models.data(), (size_t)nslots * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+    HIPC(ctx, hipMemcpyAsync(ctx->f_models, models, (size_t)nslots * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
     // work labels (plane slot / -1 invalid / -2 free): the two halves of f_count (its counts are spent once the slots are assigned) and
     // f_window (only live during the normal-map stage); tile flags: the first bytes of f_dist (normal-map stage only)
     int* w[3] = {reinterpret_cast<int*>(ctx->f_count), reinterpret_cast<int*>(ctx->f_count) + n, ctx->f_window};
     const int tiles_y = (rows + kRefTH - 1) / kRefTH, tiles_x = (cols + 63) / 64;
     unsigned char* tile_free = reinterpret_cast<unsigned char*>(ctx->f_dist);
     HIPC(ctx, hipMemsetAsync(tile_free, 0, (size_t)tiles_x * tiles_y, ctx->stream));
+    // X (w[1]) starts as the pass labels (written by the same launch) and is relaxed in place; pass 2 starts from a copy of pass 1's result (w[2])
     hipLaunchKernelGGL(k_f360_refine_init, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->f_label, ctx->f_slot_of_root, ctx->f_models, n, cols, tiles_x,
-                       w[0], tile_free);
-    // X (w[1]) starts as the pass labels and is relaxed in place; pass 2 starts from a copy of pass 1's result (w[2])
-    HIPC(ctx, hipMemcpyAsync(w[1], w[0], (size_t)n * sizeof(int), hipMemcpyDeviceToDevice, ctx->stream));
+                       w[0], w[1], tile_free, d_changed);
     const dim3 g(tiles_x, (tiles_y + kRefWaves - 1) / kRefWaves), b(64 * kRefWaves);
     const int n_lds = nslots <= 2048 ? nslots : 0;         // plane models staged in LDS when they fit 32 KB
     const size_t lds_bytes = (size_t)n_lds * sizeof(float4);
@@ -2334,12 +2336,10 @@ int f360_refine_dev(rgbd360_ctx* ctx, int rows, int cols, int nslots, std::vecto
         }
     }
     const int* W0 = w[1];
-    HIPC(ctx, hipMemsetAsync(d_changed, 0, sizeof(int), ctx->stream));
     hipLaunchKernelGGL(k_f360_refine_commit, dim3((n + kCommitThreads * kCommitPerThread - 1) / (kCommitThreads * kCommitPerThread)), dim3(kCommitThreads), 0, ctx->stream, ctx->f_xyz, ctx->f_label, w[0], W0, ctx->f_root_of_slot, n,
                        ctx->f_count_of_slot, ctx->f_mom, kF360MaxSlots, d_changed);
-    HIPC(ctx, hipMemcpyAsync(ctx->f_flags_host + kFlags, d_changed, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     hipLaunchKernelGGL(k_f360_mom_reduce, dim3((kF360MaxSlots * 9 + 255) / 256), dim3(256), 0, ctx->stream, ctx->f_mom, ctx->f_nslots, kF360MaxSlots,
-                       ctx->f_root_of_slot, ctx->f_count_of_slot, ctx->f_pack_host);
+                       ctx->f_root_of_slot, ctx->f_count_of_slot, ctx->f_pack_host, (const int*)d_changed, ctx->f_flags_host + kFlags);
     // the contour PCL hands to calcConvexHull is that of the REFINED region, projected with the plane `segment` fitted: extremes of the
     // committed labels against the frames k_f360_slot_frames left before the refinement
     launch_hull(ctx, rows, cols, /*clear_first=*/true);
