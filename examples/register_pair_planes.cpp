@@ -32,7 +32,7 @@ static bool load_rt(const std::string& dir, int sensor, float Rt_colmajor[16]) {
 // the eight sensors of a frame are independent and each chain is launch-latency bound: one context (stream + device buffers)
 // and one host thread per sensor, like the reference's `#pragma omp parallel num_threads(8)` (Frame360.h:489-503)
 static bool frame_planes(std::array<rgbd360::RegisterPhotoICP, 8>& regs, const char* path, const std::string& extr,
-                         std::vector<rgbd360_plane>& planes) {
+                         std::vector<rgbd360_plane>& planes, size_t& n_pieces) {
     int rows = 0, cols = 0;
     if (rgbd360_load_frame_bin(path, nullptr, nullptr, &rows, &cols) != 0) return false;
     std::vector<uint8_t> rgb((size_t)8 * rows * cols * 3);
@@ -62,10 +62,11 @@ static bool frame_planes(std::array<rgbd360::RegisterPhotoICP, 8>& regs, const c
     for (std::thread& w : workers) w.join();
     if (std::getenv("RGBD360_EXAMPLE_TIMING"))
         std::fprintf(stderr, "  8 sensors on 8 threads: %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count());
-    for (int s = 0; s < 8; ++s) {
+    for (int s = 0; s < 8; ++s)
         if (rc[s] != 0) return false;
-        planes.insert(planes.end(), per_sensor[s].begin(), per_sensor[s].end());
-    }
+    n_pieces = 0;
+    for (int s = 0; s < 8; ++s) n_pieces += per_sensor[s].size();
+    planes = rgbd360::groupPlanes(std::vector<std::vector<rgbd360_plane>>(per_sensor.begin(), per_sensor.end()));      // Frame360::groupPlanes, Frame360.h:741-833
     return true;
 }
 
@@ -77,12 +78,12 @@ int main(int argc, char** argv) {
     const int mode = argc > 4 ? std::atoi(argv[4]) : 1;
     std::array<rgbd360::RegisterPhotoICP, 8> regs;
     std::vector<rgbd360_plane> p1, p2;
-    if (!frame_planes(regs, argv[1], argv[3], p1)) return 3;
+    size_t n1 = 0, n2 = 0;
+    if (!frame_planes(regs, argv[1], argv[3], p1, n1)) return 3;
     const auto t0 = std::chrono::steady_clock::now();                        // (the second frame: contexts and buffers exist)
-    if (!frame_planes(regs, argv[2], argv[3], p2)) return 3;
-    std::fprintf(stderr, "planes of one frame (file read + 8 sensors on 8 threads): %.3f ms\n",
+    if (!frame_planes(regs, argv[2], argv[3], p2, n2)) return 3;
+    std::fprintf(stderr, "planes of one frame (file read + 8 sensors on 8 threads + groupPlanes): %.3f ms\n",
                  std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-    const size_t n1 = p1.size(), n2 = p2.size();
     p1 = rgbd360::mergePlanes(p1);                                            // Frame360::mergePlanes, Frame360.h:655-733
     p2 = rgbd360::mergePlanes(p2);
     std::printf("planes %zu %zu (pieces %zu %zu)\n", p1.size(), p2.size(), n1, n2);

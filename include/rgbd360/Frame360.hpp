@@ -1,0 +1,246 @@
+// Frame360.hpp -- C++ adapter over the C ABI (include/rgbd360_hip.h) with the public surface of the reference's Frame360 and
+// Calib360 (include/Frame360.h:93-1148, include/Calib360.h:44-134 of EduFdez/rgbd360) for the stages this library runs on the
+// device: loadFrame, stitchSphericalImage, buildSphereCloud_fromImage, getPlanes (= the eight getPlanesSensor calls, groupPlanes,
+// mergePlanes), getLocalPlanes, segmentPlanes (the one-panorama variant of Frame360_stereo.h:835-980), getPlanarArea,
+// getAverageIntensity -- same member and method names, so call sites such as RegisterPairRGBD360.cpp:95-110 or
+// OdometryRGBD360.cpp:150-176 (`frame.loadFrame(file); frame.stitchSphericalImage(); frame.getPlanes(); ... frame.planes.vPlanes`)
+// keep their shape.  Images are owned byte buffers viewed through ImageView (the adapter has no OpenCV dependency; with OpenCV a
+// cv::Mat header over the same memory is one line).  NOT mirrored: what depends on third-party file formats or models that are not in
+// the reference tree (loadCloud / loadPbMap / save / serialize: PCL and MRPT serialisation; undistort: the CLAMS depth model).
+// Header-only; depends on nothing but the C ABI and the two other adapter headers.
+#pragma once
+
+#include <array>
+#include <cstdint>
+#include <cstdio>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "RegisterRGBD360.hpp"
+
+namespace rgbd360 {
+
+// Calib360.h:44-134: the rig's extrinsics Rt_[8] (sensor -> rig), their inverses and the sensors' pinhole matrix.
+class Calib360 {
+   public:
+    enum Resolution { VGA = 1, QVGA = 2, QQVGA = 4 } resolution;      // Calib360.h:61-66
+    std::array<Mat4f, 8> Rt_, Rt_inv;
+    float cameraMatrix[9];                                            // row-major 3x3, Calib360.h:74-77 (QVGA)
+
+    explicit Calib360(Resolution res = QVGA) : resolution(res) {
+        const float K[9] = {262.5f, 0.f, 159.5f, 0.f, 262.5f, 119.5f, 0.f, 0.f, 1.f};
+        for (int i = 0; i < 9; ++i) cameraMatrix[i] = K[i];
+        for (int s = 0; s < 8; ++s) Rt_[s] = Rt_inv[s] = Mat4f::Identity();
+    }
+    Mat4f getRt_id(int id) const { return Rt_.at((size_t)id); }
+    void setRt_id(int id, const Mat4f& Rt) {
+        Rt_.at((size_t)id) = Rt;
+        Rt_inv.at((size_t)id) = rigid_inverse(Rt);
+    }
+    // Calib360.h:122-131: Rt_0N.txt, N = 1..8, plain text 4x4 (row by row).  Returns false when a file is missing or short
+    // (the reference's loadFromTextFile throws).
+    bool loadExtrinsicCalibration(const std::string& pathToExtrinsicModel) {
+        for (int s = 0; s < 8; ++s) {
+            char name[16];
+            std::snprintf(name, sizeof(name), "/Rt_0%d.txt", s + 1);
+            std::FILE* f = std::fopen((pathToExtrinsicModel + name).c_str(), "r");
+            if (!f) return false;
+            Mat4f M{};
+            bool ok = true;
+            for (int r = 0; r < 4 && ok; ++r)
+                for (int c = 0; c < 4 && ok; ++c) ok = std::fscanf(f, "%f", &M(r, c)) == 1;
+            std::fclose(f);
+            if (!ok) return false;
+            setRt_id(s, M);
+        }
+        return true;
+    }
+    // {fx, fy, cx, cy} as the C ABI takes them
+    std::array<float, 4> K() const { return {cameraMatrix[0], cameraMatrix[4], cameraMatrix[2], cameraMatrix[5]}; }
+
+    // The rig's device side: one context (stream + device buffers) per sensor, created on first use and shared by every Frame360 of this
+    // calibration -- a frame object stays as light as the reference's (creating eight contexts costs tens of milliseconds; a frame's
+    // planes take two).  Like the reference's classes: one thread works with a rig's frames at a time.
+    RegisterPhotoICP& context(int sensor_id) {
+        if (!contexts_) contexts_ = std::make_shared<std::array<RegisterPhotoICP, 8>>();
+        return contexts_->at((size_t)sensor_id);
+    }
+
+   private:
+    std::shared_ptr<std::array<RegisterPhotoICP, 8>> contexts_;
+
+   public:
+    static Mat4f rigid_inverse(const Mat4f& T) {      // [R t; 0 1]^-1 = [R^T  -R^T t; 0 1]
+        Mat4f I = Mat4f::Identity();
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) I(r, c) = T(c, r);
+        for (int r = 0; r < 3; ++r) I(r, 3) = -(I(r, 0) * T(0, 3) + I(r, 1) * T(1, 3) + I(r, 2) * T(2, 3));
+        return I;
+    }
+};
+
+// mrpt::pbmap::PbMap as far as the reference's call sites read it: the plane vector.
+struct PbMap {
+    std::vector<rgbd360_plane> vPlanes;
+};
+
+class Frame360 {
+   public:
+    unsigned id = 0, node = 0;                      // Frame360.h:98-101
+    std::vector<uint8_t> sphereRGB_data;            // the panorama of stitchSphericalImage, 8UC3 ...
+    std::vector<uint16_t> sphereDepth_data;         // ... and its range image, 16UC1 mm
+    ImageView sphereRGB, sphereDepth;               // views of the two (Frame360.h:104-107 holds cv::Mat)
+    std::array<PbMap, 8> local_planes_;             // :110: the planes of each sensor (rig frame)
+    Mat4f pose = Mat4f::Identity();                 // :117
+    std::vector<float> sphereCloud;                 // :120: buildSphereCloud_fromImage's organised cloud, rows*cols x 3 (NaN = invalid)
+    PbMap planes;                                   // :123
+    Calib360* calib;                                // :126
+    uint64_t timeStamp = 0;                         // :131
+    SensorSegmentParams sensor_params;              // getPlanesSensor's PCL set-up (Frame360.h:949-977, min_inliers for the 160x120 clouds below)
+    SegmentParams sphere_params;                    // segmentPlanes' (one panorama)
+
+    explicit Frame360(Calib360* calib360) : calib(calib360) { sensor_params.min_inliers = 40; }      // a quarter of the points of the 320x240 setting
+    Frame360(const Frame360&) = delete;
+    Frame360& operator=(const Frame360&) = delete;
+
+    int sensorRows() const { return srows_; }
+    int sensorCols() const { return scols_; }
+    ImageView sensorRGB(int sensor_id) const {
+        ImageView v;
+        v.data = rgb8_.data() + (size_t)sensor_id * srows_ * scols_ * 3; v.rows = srows_; v.cols = scols_; v.step = (size_t)scols_ * 3; v.type = ImageView::U8C3;
+        return v;
+    }
+    ImageView sensorDepth(int sensor_id) const {
+        ImageView v;
+        v.data = depth8_.data() + (size_t)sensor_id * srows_ * scols_; v.rows = srows_; v.cols = scols_; v.step = (size_t)scols_ * 2; v.type = ImageView::U16C1;
+        return v;
+    }
+
+    void setTimeStamp(uint64_t timestamp) { timeStamp = timestamp; }                                  // :181
+    float getPlanarArea() const {                                                                     // :157-164
+        float planarArea = 0;
+        for (const rgbd360_plane& p : planes.vPlanes) planarArea += p.area;
+        return planarArea;
+    }
+    // :269 (the body is commented out in the source; its intent -- the mean intensity over every sample-th pixel of the 8 sensors, rounded)
+    int getAverageIntensity(int sample = 1) const {
+        if (sample < 1 || rgb8_.empty()) return 0;
+        unsigned long long sum = 0, n = 0;
+        for (size_t i = 0; i + 2 < rgb8_.size(); i += (size_t)3 * sample, ++n)
+            sum += (4899u * rgb8_[i] + 9617u * rgb8_[i + 1] + 1868u * rgb8_[i + 2] + 8192u) >> 14;      // cv::cvtColor's fixed-point grey
+        return n ? (int)((double)sum / (double)n + 0.5) : 0;
+    }
+
+    // :231-266: one binary frame file (8 x {RGB, depth}); throws on an unreadable file (the reference prints and returns)
+    void loadFrame(const std::string& binaryFile) {
+        int rows = 0, cols = 0;
+        if (rgbd360_load_frame_bin(binaryFile.c_str(), nullptr, nullptr, &rows, &cols) != 0) throw std::runtime_error("Frame360::loadFrame: cannot read " + binaryFile);
+        rgb8_.resize((size_t)8 * rows * cols * 3);
+        depth8_.resize((size_t)8 * rows * cols);
+        if (rgbd360_load_frame_bin(binaryFile.c_str(), rgb8_.data(), depth8_.data(), &rows, &cols) != 0)
+            throw std::runtime_error("Frame360::loadFrame: cannot read " + binaryFile);
+        srows_ = rows; scols_ = cols;
+    }
+    // the same from memory: [8][rows][cols][3] uint8 and [8][rows][cols] uint16 mm
+    void setSensorImages(const uint8_t* rgb8, const uint16_t* depth8, int rows, int cols) {
+        rgb8_.assign(rgb8, rgb8 + (size_t)8 * rows * cols * 3);
+        depth8_.assign(depth8, depth8 + (size_t)8 * rows * cols);
+        srows_ = rows; scols_ = cols;
+    }
+
+    // :386-405 (stitchImage :1099-1148): the panorama of the eight sensor images through Rt_inv and K
+    void stitchSphericalImage() {
+        need_images("stitchSphericalImage");
+        const int W = srows_ * 8, H = (int)(W * 0.5 * 60.0 / 180);
+        sphereRGB_data.assign((size_t)H * W * 3, 0);
+        sphereDepth_data.assign((size_t)H * W, 0);
+        float Rinv[128];
+        for (int s = 0; s < 8; ++s)
+            for (int k = 0; k < 16; ++k) Rinv[s * 16 + k] = calib->Rt_inv[(size_t)s].m[k];
+        const std::array<float, 4> K = calib->K();
+        int orow = 0, ocol = 0;
+        if (rgbd360_stitch_sphere(reg(0).context(), rgb8_.data(), depth8_.data(), srows_, scols_, Rinv, K.data(), sphereRGB_data.data(),
+                                  sphereDepth_data.data(), &orow, &ocol) != 0)
+            throw std::runtime_error(std::string("rgbd360_stitch_sphere: ") + rgbd360_last_error(reg(0).context()));
+        sphereRGB.data = sphereRGB_data.data(); sphereRGB.rows = orow; sphereRGB.cols = ocol; sphereRGB.step = (size_t)ocol * 3; sphereRGB.type = ImageView::U8C3;
+        sphereDepth.data = sphereDepth_data.data(); sphereDepth.rows = orow; sphereDepth.cols = ocol; sphereDepth.step = (size_t)ocol * 2; sphereDepth.type = ImageView::U16C1;
+    }
+
+    // :555-612: the organised cloud of the range panorama (convention 0: the rig's 60-degree band; sphereCloud = rows*cols x 3)
+    void buildSphereCloud_fromImage() {
+        if (!sphereDepth.data) throw std::runtime_error("Frame360::buildSphereCloud_fromImage: no panorama (call stitchSphericalImage first)");
+        sphereCloud.resize((size_t)sphereDepth.rows * sphereDepth.cols * 3);
+        if (rgbd360_sphere_cloud(reg(0).context(), sphereDepth.data, sphereDepth.step, 0, sphereDepth.rows, sphereDepth.cols, /*convention=*/0, sphereCloud.data()) != 0)
+            throw std::runtime_error(std::string("rgbd360_sphere_cloud: ") + rgbd360_last_error(reg(0).context()));
+    }
+
+    // :641-655 / :942-1075 (getPlanesSensor): the planes of every sensor's cloud (pinhole cloud down-sampled by 2, bilateral filter, normal map,
+    // regions, refinement), moved into the rig frame by Rt_[sensor] -- one device context and one host thread per sensor, like the source's
+    // `#pragma omp parallel num_threads(8)` (:619-623)
+    void getLocalPlanes() {
+        need_images("getLocalPlanes");
+        std::array<int, 8> rc{};
+        std::array<std::string, 8> err;
+        std::vector<std::thread> workers;
+        for (int s = 0; s < 8; ++s)
+            workers.emplace_back([&, s]() {
+                const SensorSegmentParams& sp = sensor_params;
+                rgbd360_ctx* ctx = reg(s).context();
+                std::vector<rgbd360_plane>& out = local_planes_[(size_t)s].vPlanes;
+                int n = 0, cap = sp.max_planes;
+                rc[(size_t)s] = rgbd360_set_plane_refinement(ctx, sp.refine ? 1 : 0, sp.refine_distance);
+                for (int attempt = 0; attempt < 2 && rc[(size_t)s] == 0; ++attempt) {
+                    out.resize((size_t)cap);
+                    rc[(size_t)s] = rgbd360_sensor_planes(ctx, depth8_.data() + (size_t)s * srows_ * scols_, (size_t)scols_ * 2, srows_, scols_, /*step=*/2, 0.3f, 10.f,
+                                                          sp.sigma_s, sp.sigma_r, sp.max_depth_change_factor, sp.normal_smoothing_size, sp.min_inliers,
+                                                          sp.angular_threshold, sp.distance_threshold, sp.max_curvature, calib->Rt_[(size_t)s].m, out.data(), cap, &n);
+                    const int avail = rgbd360_planes_available(ctx);
+                    if (rc[(size_t)s] != 0 || avail <= n) break;
+                    cap = avail;
+                }
+                if (rc[(size_t)s] != 0) err[(size_t)s] = rgbd360_last_error(ctx);
+                out.resize((size_t)(rc[(size_t)s] == 0 ? n : 0));
+            });
+        for (std::thread& w : workers) w.join();
+        for (int s = 0; s < 8; ++s)
+            if (rc[(size_t)s] != 0) throw std::runtime_error("rgbd360_sensor_planes (sensor " + std::to_string(s) + "): " + err[(size_t)s]);
+    }
+    // :741-833: the sensors' lists -> `planes`, pieces of one surface seen by neighbouring sensors pooled
+    void groupPlanes() {
+        std::vector<std::vector<rgbd360_plane>> per_sensor;
+        for (const PbMap& m : local_planes_) per_sensor.push_back(m.vPlanes);
+        planes.vPlanes = rgbd360::groupPlanes(per_sensor);
+    }
+    // :657-733
+    void mergePlanes() { planes.vPlanes = rgbd360::mergePlanes(planes.vPlanes); }
+    // :615-639
+    void getPlanes() {
+        getLocalPlanes();
+        groupPlanes();
+        mergePlanes();
+    }
+    // Frame360_stereo.h:835-980 (segmentPlanes): planes of the PANORAMA itself (sphere cloud -> normal map -> regions on the device), with
+    // the panorama's colours for the descriptors of Frame360.h:1045-1046
+    void segmentPlanes() {
+        if (!sphereDepth.data) throw std::runtime_error("Frame360::segmentPlanes: no panorama (call stitchSphericalImage first)");
+        SegmentParams sp = sphere_params;
+        sp.convention = 0;
+        planes.vPlanes = rgbd360::segmentPlanes(reg(0), sphereDepth, sp, sphereRGB.data ? &sphereRGB : nullptr);
+    }
+
+    // the context of sensor s (the calibration object's: shared by the rig's frames; sensor 0's also serves the panorama stages)
+    RegisterPhotoICP& reg(int s) { return calib->context(s); }
+
+   private:
+    void need_images(const char* who) const {
+        if (rgb8_.empty() || srows_ <= 0) throw std::runtime_error(std::string("Frame360::") + who + ": no sensor images (loadFrame / setSensorImages first)");
+    }
+    std::vector<uint8_t> rgb8_;
+    std::vector<uint16_t> depth8_;
+    int srows_ = 0, scols_ = 0;
+};
+
+}  // namespace rgbd360

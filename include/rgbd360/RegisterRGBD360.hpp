@@ -13,6 +13,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "RegisterPhotoICP.hpp"
@@ -110,6 +111,25 @@ inline std::vector<rgbd360_plane> mergePlanes(const std::vector<rgbd360_plane>& 
     return out;
 }
 
+// Frame360::groupPlanes (Frame360.h:741-833; defaults = its constants): the eight sensors' plane lists (rig frame, sensor order) -> the
+// frame's list, pieces of one surface seen by neighbouring sensors pooled.  getPlanes (:615-639) = the sensors' planes, this, mergePlanes.
+inline std::vector<rgbd360_plane> groupPlanes(const std::vector<std::vector<rgbd360_plane>>& per_sensor, float max_curvature = 0.0013f, float min_area = 0.5f,
+                                              float cos_normal = 0.99f, float dist_d = 0.45f, float max_dist_hull = 0.5f, float max_dist_parallel_hull = 0.09f) {
+    std::vector<rgbd360_plane> all;
+    std::vector<int> counts;
+    for (const std::vector<rgbd360_plane>& v : per_sensor) {
+        counts.push_back((int)v.size());
+        all.insert(all.end(), v.begin(), v.end());
+    }
+    std::vector<rgbd360_plane> out(all.size() ? all.size() : 1);
+    int n = 0;
+    if (rgbd360_group_planes(all.data(), counts.data(), (int)counts.size(), max_curvature, min_area, cos_normal, dist_d, max_dist_hull, max_dist_parallel_hull,
+                             out.data(), (int)out.size(), &n) != 0)
+        throw std::runtime_error("rgbd360_group_planes: bad arguments");
+    out.resize((size_t)n);
+    return out;
+}
+
 class RegisterRGBD360 {
    public:
     enum registrationType { DEFAULT_6DoF, PLANAR_3DoF, ODOMETRY_6DoF, PLANAR_ODOMETRY_3DoF };      // RegisterRGBD360.h:258-264
@@ -159,6 +179,22 @@ class RegisterRGBD360 {
         areaSource = subgraphArea(ref_, mmp);                                                     // :325-333
         areaTarget = subgraphArea(trg_, mmp);
         return true;
+    }
+
+    // The reference's signatures take Frame360 pointers (RegisterRGBD360.h:110, 163, 276): anything with a `planes.vPlanes` vector of
+    // plane records (rgbd360::Frame360 of Frame360.hpp) goes through the PlaneList forms above.
+    template <class FrameT, class = decltype(std::declval<FrameT&>().planes.vPlanes.data())>
+    void setReference(FrameT* frame, size_t max_match_planes = 0) {
+        setReference(PlaneList{frame->planes.vPlanes.data(), (int)frame->planes.vPlanes.size()}, max_match_planes);
+    }
+    template <class FrameT, class = decltype(std::declval<FrameT&>().planes.vPlanes.data())>
+    void setTarget(FrameT* frame, size_t max_match_planes = 0) {
+        setTarget(PlaneList{frame->planes.vPlanes.data(), (int)frame->planes.vPlanes.size()}, max_match_planes);
+    }
+    template <class FrameT, class = decltype(std::declval<FrameT&>().planes.vPlanes.data())>
+    bool RegisterPbMap(FrameT* frame1, FrameT* frame2, size_t max_match_planes = 0, registrationType registMode = DEFAULT_6DoF) {
+        const PlaneList a{frame1->planes.vPlanes.data(), (int)frame1->planes.vPlanes.size()}, b{frame2->planes.vPlanes.data(), (int)frame2->planes.vPlanes.size()};
+        return RegisterPbMap(&a, &b, max_match_planes, registMode);
     }
 
     Mat4f getPose() {                                                            // :198-204

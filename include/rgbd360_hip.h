@@ -549,6 +549,20 @@ int rgbd360_register_planes(const rgbd360_plane* ref, int n_ref, const rgbd360_p
 int rgbd360_merge_planes(const rgbd360_plane* planes, int n, float max_curvature, float min_area, float max_elongation, float cos_normal,
                          float dist_d, float proximity, float normal_offset, rgbd360_plane* out, int max_out, int* n_out);
 
+/* Frame360::groupPlanes (Frame360.h:741-833), the step of Frame360::getPlanes (:615-639) between the eight getPlanesSensor calls and
+ * mergePlanes: `planes` holds the sensors' plane lists one after the other (n_per_sensor[s] records of sensor s, in the rig frame:
+ * rgbd360_sensor_planes / rgbd360_cloud_planes with that sensor's Rt), the output is the frame's list.  A plane of sensor s is pooled
+ * (mergePlane2, as in rgbd360_merge_planes) into a plane that came from -- or absorbed a piece of -- sensor s - 1 when both are larger
+ * than min_area (0.5 m2) and flatter than max_curvature (0.0013) as the source tests them (:764: area OR curvature for the new piece,
+ * :770: area AND curvature for the absorbing one), n_j . n_k > cos_normal (0.99), |d_j - d_k| < dist_d (0.45 m) and their hull polygons
+ * come within max_dist_hull (0.5 m) at a pair of points / edges whose difference lies within max_dist_parallel_hull (0.09 m) of the
+ * absorbing plane (:788-815); otherwise it is appended.  The last sensor's candidates include the first sensor's planes (the ring of
+ * sensors closes, :827-828).  Nothing is filtered here.  Host only.  out may not alias planes; -1 when max_out is too small
+ * (*n_out = needed) or on bad arguments. */
+int rgbd360_group_planes(const rgbd360_plane* planes, const int* n_per_sensor, int n_sensors, float max_curvature, float min_area,
+                         float cos_normal, float dist_d, float max_dist_hull, float max_dist_parallel_hull, rgbd360_plane* out, int max_out,
+                         int* n_out);
+
 #ifdef __cplusplus
 }
 #endif

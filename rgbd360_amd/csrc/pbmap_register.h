@@ -647,6 +647,34 @@ inline void pool_colour(rgbd360_plane& dst, const rgbd360_plane& a, const rgbd36
     if (na + nb > 0)
         for (int k = 0; k < 74; ++k) dst.hist_h[k] = (float)((na * a.hist_h[k] + nb * b.hist_h[k]) / (na + nb));
 }
+// mrpt::pbmap::Plane::mergePlane2 (third-party; Frame360.h:717, 815): the exact pooled fit of the two pieces' moments, the two contours
+// pooled and hulled again on the merged plane (area and mass centre are that polygon's), the colour descriptors pooled
+inline rgbd360_plane pool_planes(const rgbd360_plane& pj, const rgbd360_plane& pk) {
+    const PlaneMoments a = moments_of(pj), b = moments_of(pk);
+    PlaneMoments m;
+    m.n = a.n + b.n;
+    for (int i = 0; i < 3; ++i) m.c[i] = (a.n * a.c[i] + b.n * b.c[i]) / m.n;
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c)
+            m.C[r][c] = (a.n * (a.C[r][c] + (a.c[r] - m.c[r]) * (a.c[c] - m.c[c])) + b.n * (b.C[r][c] + (b.c[r] - m.c[r]) * (b.c[c] - m.c[c]))) / m.n;
+    const bool hulls = pj.hull_points > 0 && pk.hull_points > 0;
+    const double aj = pj.area, ak = pk.area;
+    const int hp = pj.hull_points + pk.hull_points;
+    const V3 cj = center_of(pj), ck = center_of(pk);
+    rgbd360_plane out = plane_of(m, std::min(pj.root, pk.root));
+    if (pj.hull_n >= 3 && pk.hull_n >= 3 && rehull(out, pj, pk, hp)) {
+        // (the polygon of the merged plane)
+    } else if (hulls && aj + ak > 0) {
+        // records without polygons: the merged surface's area is the pieces' sum, its centre their area-weighted mean
+        out.area = (float)(aj + ak);
+        out.center_hull[0] = (float)((aj * cj.x + ak * ck.x) / (aj + ak));
+        out.center_hull[1] = (float)((aj * cj.y + ak * ck.y) / (aj + ak));
+        out.center_hull[2] = (float)((aj * cj.z + ak * ck.z) / (aj + ak));
+        out.hull_points = hp;
+    }
+    pool_colour(out, pj, pk);
+    return out;
+}
 inline std::vector<rgbd360_plane> merge_planes(const rgbd360_plane* in, int n, const MergeParams& M) {
     std::vector<rgbd360_plane> v;
     for (int i = 0; i < n; ++i)
@@ -659,38 +687,63 @@ inline std::vector<rgbd360_plane> merge_planes(const rgbd360_plane* in, int n, c
             merged = false;
             for (size_t k = j + 1; k < v.size(); ++k) {
                 if (!(v[k].curvature < M.max_curvature) || !same_surface(v[j], v[k], M)) continue;
-                const PlaneMoments a = moments_of(v[j]), b = moments_of(v[k]);
-                PlaneMoments m;
-                m.n = a.n + b.n;
-                for (int i = 0; i < 3; ++i) m.c[i] = (a.n * a.c[i] + b.n * b.c[i]) / m.n;
-                for (int r = 0; r < 3; ++r)
-                    for (int c = 0; c < 3; ++c)
-                        m.C[r][c] = (a.n * (a.C[r][c] + (a.c[r] - m.c[r]) * (a.c[c] - m.c[c])) +
-                                     b.n * (b.C[r][c] + (b.c[r] - m.c[r]) * (b.c[c] - m.c[c]))) / m.n;
-                // pieces that carry hull areas: the merged surface's area is their sum (adjacent views of one surface; mrpt's mergePlane2
-                // re-hulls the union of the two contours, which the records no longer hold), its centre their area-weighted mean
-                const rgbd360_plane colour_j = v[j], colour_k = v[k];
-                const bool hulls = v[j].hull_points > 0 && v[k].hull_points > 0;
-                const double aj = v[j].area, ak = v[k].area;
-                const int hp = v[j].hull_points + v[k].hull_points;
-                const V3 cj = center_of(v[j]), ck = center_of(v[k]);
-                const rgbd360_plane piece_j = v[j], piece_k = v[k];
-                v[j] = plane_of(m, std::min(v[j].root, v[k].root));
-                if (piece_j.hull_n >= 3 && piece_k.hull_n >= 3 && rehull(v[j], piece_j, piece_k, hp)) {
-                    // mergePlane2: the two contours pooled and hulled again on the merged plane -- area and mass centre are that polygon's
-                } else if (hulls && aj + ak > 0) {
-                    v[j].area = (float)(aj + ak);
-                    v[j].center_hull[0] = (float)((aj * cj.x + ak * ck.x) / (aj + ak));
-                    v[j].center_hull[1] = (float)((aj * cj.y + ak * ck.y) / (aj + ak));
-                    v[j].center_hull[2] = (float)((aj * cj.z + ak * ck.z) / (aj + ak));
-                    v[j].hull_points = hp;
-                }
-                pool_colour(v[j], colour_j, colour_k);
+                v[j] = pool_planes(v[j], v[k]);
                 v.erase(v.begin() + (long)k);
                 merged = true;
                 break;
             }
         }
+    }
+    return v;
+}
+
+// Frame360::groupPlanes (Frame360.h:741-833): the planes of the eight sensors, in sensor order, gathered into the frame's plane list --
+// a plane of sensor s is pooled into a plane that came from (or absorbed a piece of) sensor s - 1 when both are large and flat enough
+// (:764, :770) and lie on one surface (|d_j - d_k| < dist_d :775, normals :776, hull polygons within max_dist_hull of each other --
+// vertex against vertex :788-798, edge against edge :800-815 -- with the offset along the absorbing plane's normal below
+// max_dist_parallel_hull), else appended; sensor 7's candidates also include sensor 0's planes (:827-828: the ring closes).
+// Planes are NOT filtered here (small or narrow ones stay in the list: mergePlanes / the registration's subgraph selection drop them).
+struct GroupParams {
+    float max_curvature = 0.0013f;      // max_curvature_plane, Miscellaneous.h:54
+    float min_area = 0.5f;              // :764, :770
+    float cos_normal = 0.99f, dist_d = 0.45f;
+    float max_dist_hull = 0.5f, max_dist_parallel_hull = 0.09f;      // :746-747
+};
+inline std::vector<rgbd360_plane> group_planes(const rgbd360_plane* in, const int* n_per_sensor, int n_sensors, const GroupParams& G) {
+    MergeParams M{};
+    M.cos_normal = G.cos_normal; M.dist_d = G.dist_d; M.proximity = G.max_dist_hull; M.normal_offset = G.max_dist_parallel_hull;
+    std::vector<rgbd360_plane> v;
+    std::vector<int> prev, first;
+    int at = 0;
+    for (int s = 0; s < n_sensors; ++s) {
+        std::vector<int> next_prev;
+        for (int k = 0; k < n_per_sensor[s]; ++k) {
+            const rgbd360_plane& pk = in[at + k];
+            if (!well_formed(pk)) continue;
+            int hit = -1;
+            if (s > 0 && (pk.area > G.min_area || pk.curvature < G.max_curvature))        // :764 (an OR, as written)
+                for (int j : prev) {
+                    if (v[(size_t)j].area < G.min_area || v[(size_t)j].curvature > G.max_curvature) continue;      // :770
+                    if (same_surface(v[(size_t)j], pk, M)) { hit = j; break; }
+                }
+            if (hit >= 0) {
+                v[(size_t)hit] = pool_planes(v[(size_t)hit], pk);
+                next_prev.push_back(hit);
+            } else {
+                next_prev.push_back((int)v.size());
+                v.push_back(pk);
+            }
+        }
+        std::sort(next_prev.begin(), next_prev.end());                                     // (std::set<unsigned>: ascending, unique)
+        next_prev.erase(std::unique(next_prev.begin(), next_prev.end()), next_prev.end());
+        if (s == 0) first = next_prev;
+        prev = next_prev;
+        if (s == n_sensors - 2) {                                                          // :827-828 (sensor_id == 6 of 8)
+            prev.insert(prev.end(), first.begin(), first.end());
+            std::sort(prev.begin(), prev.end());
+            prev.erase(std::unique(prev.begin(), prev.end()), prev.end());
+        }
+        at += n_per_sensor[s];
     }
     return v;
 }

@@ -3058,6 +3058,30 @@ extern "C" int rgbd360_merge_planes(const rgbd360_plane* planes, int n, float ma
     }
 }
 
+extern "C" int rgbd360_group_planes(const rgbd360_plane* planes, const int* n_per_sensor, int n_sensors, float max_curvature, float min_area,
+                                    float cos_normal, float dist_d, float max_dist_hull, float max_dist_parallel_hull, rgbd360_plane* out,
+                                    int max_out, int* n_out) {
+    if (n_sensors < 1 || !n_per_sensor || !out || !n_out || max_out < 0) return -1;
+    long long n = 0;
+    for (int s = 0; s < n_sensors; ++s) {
+        if (n_per_sensor[s] < 0) return -1;
+        n += n_per_sensor[s];
+    }
+    if (n > 0 && !planes) return -1;
+    try {
+        pbm::GroupParams G;
+        G.max_curvature = max_curvature; G.min_area = min_area; G.cos_normal = cos_normal; G.dist_d = dist_d;
+        G.max_dist_hull = max_dist_hull; G.max_dist_parallel_hull = max_dist_parallel_hull;
+        const std::vector<rgbd360_plane> v = pbm::group_planes(planes, n_per_sensor, n_sensors, G);
+        *n_out = (int)v.size();
+        if ((int)v.size() > max_out) return -1;
+        for (size_t i = 0; i < v.size(); ++i) out[i] = v[i];
+        return 0;
+    } catch (const std::exception&) {
+        return -1;
+    }
+}
+
 #include "multi_gpu.h"
 
 #ifdef RGBD360_HULL_DBG

@@ -107,6 +107,23 @@ def merge_planes(planes, max_curvature=0.0013, cos_normal=0.99, dist_d=0.45, pro
     return _planes_to_dicts(out, n.value)
 
 
+def group_planes(planes_per_sensor, max_curvature=0.0013, min_area=0.5, cos_normal=0.99, dist_d=0.45, max_dist_hull=0.5, max_dist_parallel_hull=0.09):
+    """rgbd360_group_planes (Frame360::groupPlanes, Frame360.h:741-833; defaults = the reference's constants): the plane lists of the rig's
+    sensors (in the rig frame, sensor order) -> the frame's plane list, pieces of one surface seen by neighbouring sensors pooled."""
+    from .register import _planes_to_dicts
+    L = _lib.load()
+    flat = [p for lst in planes_per_sensor for p in lst]
+    arr = planes_to_array(flat)
+    counts = (C.c_int32 * len(planes_per_sensor))(*[len(lst) for lst in planes_per_sensor])
+    out = (_lib.Plane * max(len(flat), 1))()
+    n = C.c_int(0)
+    rc = L.rgbd360_group_planes(C.cast(arr, C.c_void_p), counts, len(planes_per_sensor), max_curvature, min_area, cos_normal, dist_d, max_dist_hull,
+                                max_dist_parallel_hull, C.cast(out, C.c_void_p), len(flat), C.byref(n))
+    if rc != 0:
+        raise ValueError("rgbd360_group_planes: bad arguments")
+    return _planes_to_dicts(out, n.value)
+
+
 class RegisterRGBD360:
     """Mirror of the reference class (RegisterRGBD360.h:47): setReference / setTarget / RegisterPbMap / getPose /
     getInfoMat / getCovMat / calcEntropy / getMatchedPlanes / getAreaMatched.  A "frame" here is the plane list of a

@@ -180,6 +180,61 @@ def test_register_pair_planes_on_a_synthetic_rig(tmp_path, hip_lib):
     assert rot < math.radians(0.3) and tr < 0.015, (rot, tr)
 
 
+def build_frame360_pair(out_dir):
+    from rgbd360_amd import build
+    lib = build.build()
+    exe = os.path.join(str(out_dir), "frame360_pair")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-pthread", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "frame360_pair.cpp"), "-L" + os.path.dirname(lib), "-lrgbd360_hip",
+                           "-Wl,-rpath," + os.path.dirname(lib), "-o", exe])
+    return exe
+
+
+def test_frame360_adapter_compiles_and_checks_its_inputs(tmp_path):
+    """include/rgbd360/Frame360.hpp (Frame360 / Calib360 with the reference's member and method names, Frame360.h:93-1148, Calib360.h:44-134)
+    compiles warning-free in the call shape of RegisterPairRGBD360.cpp:60-90; missing calibration files and frames are reported."""
+    exe = build_frame360_pair(tmp_path)
+    assert subprocess.call([exe]) == 2
+    assert subprocess.call([exe, str(tmp_path / "a.bin"), str(tmp_path / "b.bin"), str(tmp_path)]) == 3         # no Rt_0N.txt there
+    for s in range(8):
+        np.savetxt(tmp_path / ("Rt_0%d.txt" % (s + 1)), np.eye(4))
+    assert subprocess.call([exe, str(tmp_path / "a.bin"), str(tmp_path / "b.bin"), str(tmp_path)], stderr=subprocess.DEVNULL) == 3     # no such frames
+
+
+@pytest.mark.gpu
+def test_frame360_adapter_on_a_synthetic_rig(tmp_path, hip_lib):
+    """RegisterPairRGBD360.cpp's sequence through the adapter classes, end to end on the device: loadFrame -> stitchSphericalImage ->
+    getPlanes (eight getPlanesSensor on eight contexts, groupPlanes, mergePlanes) for two frames of the synthetic room, RegisterPbMap on
+    the Frame360 objects, then the dense alignment of the two stitched panoramas from the plane pose.  The rig moved by 8 cm / 3 degrees."""
+    import math
+    from rgbd360_amd import synth
+    exe = build_frame360_pair(tmp_path)
+    R0 = np.array([[0.0, -1.0, 0.0], [-1.0, 0.0, 0.0], [0.0, 0.0, -1.0]])
+    T_rig_sensor = [synth.make_pose(synth.rodrigues(np.array([1.0, 0, 0]), math.radians(45.0 * s)) @ R0, np.zeros(3)) for s in range(8)]
+    T_w1 = synth.make_pose(np.eye(3), np.asarray(synth.CAM_A, float))
+    M = synth.default_motion(17, 0.08, 3.0)
+    _write_rig_frame(tmp_path / "f1.bin", T_w1, T_rig_sensor, 5)
+    _write_rig_frame(tmp_path / "f2.bin", T_w1 @ M, T_rig_sensor, 5)
+    for s in range(8):
+        np.savetxt(tmp_path / ("Rt_0%d.txt" % (s + 1)), T_rig_sensor[s])
+    out = subprocess.check_output([exe, str(tmp_path / "f1.bin"), str(tmp_path / "f2.bin"), str(tmp_path), "2"], text=True).strip().splitlines()
+    w = out[0].split()
+    n1, n2 = int(w[1]), int(w[2])
+    pieces = [int(w[4]), int(w[5].strip(")"))]
+    assert 5 <= n1 < pieces[0] and 5 <= n2 < pieces[1], out[0]                 # pieces of one wall seen by several sensors were pooled
+    assert float(w[8]) > 20.0 and float(w[9]) > 20.0 and 30 < int(w[12]) < 230, out[0]     # planar area (m2) of the room's walls; mean grey level
+    st = out[1].split()
+    assert st[1] == "0" and st[3] == "1" and int(st[5]) >= 4, out[1]
+    Tp = np.array([[float(x) for x in l.split()] for l in out[2:6]])
+    rot, tr = synth.pose_error(Tp, M)
+    assert rot < math.radians(0.5) and tr < 0.02, (rot, tr)
+    assert out[6].split()[2] == "0", out[6]
+    Td = np.array([[float(x) for x in l.split()] for l in out[7:11]])
+    # the stitched panorama lives in the rig frame rotated like the sphere images: the dense pose is compared through its magnitude
+    ang = math.acos(max(-1.0, min(1.0, (np.trace(Td[:3, :3]) - 1) / 2)))
+    assert abs(ang - math.radians(3.0)) < math.radians(0.5) and abs(np.linalg.norm(Td[:3, 3]) - 0.08) < 0.03, (ang, Td[:3, 3])
+
+
 # ---- the reference's own signatures (Eigen / cv::Mat) on the adapter: compiled against mock headers ------------------------------
 MOCK = os.path.join(ROOT, "tests", "mock_headers")
 REF = "/root/reference"

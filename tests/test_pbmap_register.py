@@ -558,3 +558,46 @@ def test_merged_planes_pool_their_colour():
     assert np.abs(out[0]["color_nrgb"] - want).max() < 1e-6
     assert abs(out[0]["intensity"] - (3000 * float(a["intensity"]) + 1000 * float(b["intensity"])) / 4000) < 1e-3
     assert abs(out[0]["hist_h"].sum() - 1.0) < 1e-5 and (out[0]["color_dev"] >= 0.004 - 1e-6).all()
+
+
+def test_group_planes_pools_pieces_of_neighbouring_sensors():
+    """Frame360::groupPlanes (Frame360.h:741-833), the step of getPlanes between the sensors' plane lists and mergePlanes: a plane of
+    sensor s is pooled into a plane of sensor s - 1 (or one that absorbed a piece of it) when the two hull polygons come within 0.5 m on
+    one surface; sensor 7 also sees sensor 0's planes (the ring closes); non-neighbours are left to mergePlanes; the size / curvature
+    gates are the source's (area OR curvature for the new piece, area AND curvature for the absorbing plane); nothing is filtered."""
+    o, e1, e2 = np.array([-1.0, -1.5, 3.0]), np.array([1.0, 0, 0]), np.array([0, 1.0, 0])
+    sq = lambda x0, y0, s, count, root: _poly_plane([(x0, y0), (x0 + s, y0), (x0 + s, y0 + s), (x0, y0 + s)], o, e1, e2, count, root)
+    a = sq(0.0, 0.0, 1.0, 2000, 1)           # sensor 0
+    b = sq(1.4, 0.0, 1.0, 2000, 2)           # 0.4 m to the right of a: inside groupPlanes' 0.5 m, outside mergePlanes' 0.3 m
+    assert len(pbmap.merge_planes([a, b])) == 2
+    empty = []
+    out = pbmap.group_planes([[a], [b]] + [empty] * 6)
+    assert len(out) == 1 and out[0]["count"] == 4000 and abs(out[0]["area"] - 2.4) < 1e-3          # the hull of both squares
+    # not neighbours (sensors 0 and 2): both stay
+    assert len(pbmap.group_planes([[a], empty, [b]] + [empty] * 5)) == 2
+    # a chain: the piece of sensor 2 joins what sensor 1's piece was pooled into
+    c = sq(2.8, 0.0, 1.0, 2000, 3)
+    out = pbmap.group_planes([[a], [b], [c]] + [empty] * 5)
+    assert len(out) == 1 and out[0]["count"] == 6000
+    # the ring closes: sensor 7 against sensor 0 ...
+    assert len(pbmap.group_planes([[a]] + [empty] * 6 + [[b]])) == 1
+    # ... but sensor 6 does not
+    assert len(pbmap.group_planes([[a]] + [empty] * 5 + [[b], empty])) == 2
+    # 0.6 m apart: too far even for groupPlanes; another surface (0.2 m behind): the offset along the normal forbids it
+    assert len(pbmap.group_planes([[a], [sq(1.6, 0.0, 1.0, 2000, 2)]] + [empty] * 6)) == 2
+    behind = _poly_plane([(1.4, 0), (2.4, 0), (2.4, 1), (1.4, 1)], o + np.array([0, 0, 0.2]), e1, e2, 2000, 2)
+    assert len(pbmap.group_planes([[a], [behind]] + [empty] * 6)) == 2
+    # gates: an absorbing plane under 0.5 m2 never absorbs; a small new piece still joins a large plane when it is flat (the source's OR)
+    small_abs = sq(0.0, 0.0, 0.6, 700, 1)    # 0.36 m2
+    assert len(pbmap.group_planes([[small_abs], [sq(0.9, 0.0, 1.0, 2000, 2)]] + [empty] * 6)) == 2
+    small_new = sq(1.3, 0.0, 0.6, 700, 2)
+    assert len(pbmap.group_planes([[a], [small_new]] + [empty] * 6)) == 1
+    curved = dict(small_new)
+    curved["curvature"] = np.float32(0.01)   # neither large nor flat: appended
+    assert len(pbmap.group_planes([[a], [curved]] + [empty] * 6)) == 2
+    # nothing is dropped: a sliver stays in the list (mergePlanes / the subgraph selection filter later)
+    sliver = _poly_plane([(5, 5), (5.05, 5), (5.05, 7), (5, 7)], o, e1, e2, 100, 9)
+    assert len(pbmap.group_planes([[a, sliver]] + [empty] * 7)) == 2
+    # getPlanes = groupPlanes then mergePlanes: the frame's list
+    frame = pbmap.merge_planes(pbmap.group_planes([[a], [b], [c]] + [empty] * 5))
+    assert len(frame) == 1 and frame[0]["count"] == 6000
