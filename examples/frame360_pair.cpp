@@ -28,6 +28,18 @@ int main(int argc, char** argv) {
     try {
         Frame360 frame360_1(&calib);
         frame360_1.loadFrame(file360_1);
+        frame360_1.fastStitchImage360();                      // (the viewer's quick panorama; replaced by the spherical one below)
+        {
+            const int R = frame360_1.sensorRows(), Cn = frame360_1.sensorCols();
+            const uint8_t* pano = (const uint8_t*)frame360_1.sphereRGB.data;
+            const uint8_t* s7 = (const uint8_t*)frame360_1.sensorRGB(7).data;
+            // strip 0 holds sensor 7 transposed and flipped: panorama (r, c) = sensor (c, cols - 1 - r)
+            bool same = frame360_1.sphereRGB.rows == Cn && frame360_1.sphereRGB.cols == 8 * R;
+            for (int r = 0; r < Cn && same; r += 37)
+                for (int c = 0; c < R && same; c += 41)
+                    for (int ch = 0; ch < 3; ++ch) same = same && pano[((size_t)r * 8 * R + c) * 3 + ch] == s7[((size_t)c * Cn + (Cn - 1 - r)) * 3 + ch];
+            if (!same) { std::fprintf(stderr, "fastStitchImage360: unexpected panorama\n"); return 4; }
+        }
         frame360_1.stitchSphericalImage();
         frame360_1.getPlanes();
 

@@ -1,6 +1,6 @@
 // Frame360.hpp -- C++ adapter over the C ABI (include/rgbd360_hip.h) with the public surface of the reference's Frame360 and
 // Calib360 (include/Frame360.h:93-1148, include/Calib360.h:44-134 of EduFdez/rgbd360) for the stages this library runs on the
-// device: loadFrame, stitchSphericalImage, buildSphereCloud_fromImage, getPlanes (= the eight getPlanesSensor calls, groupPlanes,
+// device: loadFrame, fastStitchImage360 (host), stitchSphericalImage, buildSphereCloud_fromImage, getPlanes (= the eight getPlanesSensor calls, groupPlanes,
 // mergePlanes), getLocalPlanes, segmentPlanes (the one-panorama variant of Frame360_stereo.h:835-980), getPlanarArea,
 // getAverageIntensity -- same member and method names, so call sites such as RegisterPairRGBD360.cpp:95-110 or
 // OdometryRGBD360.cpp:150-176 (`frame.loadFrame(file); frame.stitchSphericalImage(); frame.getPlanes(); ... frame.planes.vPlanes`)
@@ -149,6 +149,24 @@ class Frame360 {
         rgb8_.assign(rgb8, rgb8 + (size_t)8 * rows * cols * 3);
         depth8_.assign(depth8, depth8 + (size_t)8 * rows * cols);
         srows_ = rows; scols_ = cols;
+    }
+
+    // :347-383: the eight colour images side by side, each transposed and flipped (sensor 7 - k in the k-th strip) -- no calibration, no
+    // projection, colour only (sphereDepth is left empty: the source's depth half is commented out).  Host code.
+    void fastStitchImage360() {
+        need_images("fastStitchImage360");
+        const int W = srows_ * 8, H = scols_;
+        sphereRGB_data.assign((size_t)H * W * 3, 0);
+        for (int k = 0; k < 8; ++k) {
+            const uint8_t* src = rgb8_.data() + (size_t)(7 - k) * srows_ * scols_ * 3;
+            for (int r = 0; r < H; ++r)
+                for (int c = 0; c < srows_; ++c)      // transpose, then flip about the horizontal axis: out(r, c) = src(c, cols - 1 - r)
+                    for (int ch = 0; ch < 3; ++ch)
+                        sphereRGB_data[((size_t)r * W + (size_t)k * srows_ + c) * 3 + ch] = src[((size_t)c * scols_ + (scols_ - 1 - r)) * 3 + ch];
+        }
+        sphereRGB.data = sphereRGB_data.data(); sphereRGB.rows = H; sphereRGB.cols = W; sphereRGB.step = (size_t)W * 3; sphereRGB.type = ImageView::U8C3;
+        sphereDepth_data.clear();
+        sphereDepth = ImageView();
     }
 
     // :386-405 (stitchImage :1099-1148): the panorama of the eight sensor images through Rt_inv and K
