@@ -1,7 +1,7 @@
 // Frame360.hpp -- C++ adapter over the C ABI (include/rgbd360_hip.h) with the public surface of the reference's Frame360 and
 // Calib360 (include/Frame360.h:93-1148, include/Calib360.h:44-134 of EduFdez/rgbd360) for the stages this library runs on the
 // device: loadFrame, fastStitchImage360 (host), stitchSphericalImage, buildSphereCloud_fromImage, getPlanes (= the eight getPlanesSensor calls, groupPlanes,
-// mergePlanes), getLocalPlanes, segmentPlanes (the one-panorama variant of Frame360_stereo.h:835-980), getPlanarArea,
+// mergePlanes), getPlanesSensor, segmentPlanes (the one-panorama variant of Frame360_stereo.h:835-980), getPlanarArea,
 // getAverageIntensity -- same member and method names, so call sites such as RegisterPairRGBD360.cpp:95-110 or
 // OdometryRGBD360.cpp:150-176 (`frame.loadFrame(file); frame.stitchSphericalImage(); frame.getPlanes(); ... frame.planes.vPlanes`)
 // keep their shape.  Images are owned byte buffers viewed through ImageView (the adapter has no OpenCV dependency; with OpenCV a
@@ -195,36 +195,31 @@ class Frame360 {
             throw std::runtime_error(std::string("rgbd360_sphere_cloud: ") + rgbd360_last_error(reg(0).context()));
     }
 
-    // :641-655 / :942-1075 (getPlanesSensor): the planes of every sensor's cloud (pinhole cloud down-sampled by 2, bilateral filter, normal map,
-    // regions, refinement), moved into the rig frame by Rt_[sensor] -- one device context and one host thread per sensor, like the source's
-    // `#pragma omp parallel num_threads(8)` (:619-623)
-    void getLocalPlanes() {
-        need_images("getLocalPlanes");
-        std::array<int, 8> rc{};
-        std::array<std::string, 8> err;
-        std::vector<std::thread> workers;
-        for (int s = 0; s < 8; ++s)
-            workers.emplace_back([&, s]() {
-                const SensorSegmentParams& sp = sensor_params;
-                rgbd360_ctx* ctx = reg(s).context();
-                std::vector<rgbd360_plane>& out = local_planes_[(size_t)s].vPlanes;
-                int n = 0, cap = sp.max_planes;
-                rc[(size_t)s] = rgbd360_set_plane_refinement(ctx, sp.refine ? 1 : 0, sp.refine_distance);
-                for (int attempt = 0; attempt < 2 && rc[(size_t)s] == 0; ++attempt) {
-                    out.resize((size_t)cap);
-                    rc[(size_t)s] = rgbd360_sensor_planes(ctx, depth8_.data() + (size_t)s * srows_ * scols_, (size_t)scols_ * 2, srows_, scols_, /*step=*/2, 0.3f, 10.f,
-                                                          sp.sigma_s, sp.sigma_r, sp.max_depth_change_factor, sp.normal_smoothing_size, sp.min_inliers,
-                                                          sp.angular_threshold, sp.distance_threshold, sp.max_curvature, calib->Rt_[(size_t)s].m, out.data(), cap, &n);
-                    const int avail = rgbd360_planes_available(ctx);
-                    if (rc[(size_t)s] != 0 || avail <= n) break;
-                    cap = avail;
-                }
-                if (rc[(size_t)s] != 0) err[(size_t)s] = rgbd360_last_error(ctx);
-                out.resize((size_t)(rc[(size_t)s] == 0 ? n : 0));
-            });
-        for (std::thread& w : workers) w.join();
-        for (int s = 0; s < 8; ++s)
-            if (rc[(size_t)s] != 0) throw std::runtime_error("rgbd360_sensor_planes (sensor " + std::to_string(s) + "): " + err[(size_t)s]);
+    // :942-1075: the planes of ONE sensor's cloud (pinhole cloud down-sampled by 2, bilateral filter :493-499, normal map, regions with
+    // refinement, extent and colour-free descriptors), moved into the rig frame by Rt_[sensor] (:1046) -> local_planes_[sensor_id].
+    // (getLocalPlanes / getLocalPlanesInFrame, :641-655 / :839-940, estimate normals with PCL's COVARIANCE_MATRIX method, which this
+    // library does not implement: not mirrored.)
+    void getPlanesSensor(int sensor_id) {
+        need_images("getPlanesSensor");
+        const SensorSegmentParams& sp = sensor_params;
+        rgbd360_ctx* ctx = reg(sensor_id).context();
+        std::vector<rgbd360_plane>& out = local_planes_.at((size_t)sensor_id).vPlanes;
+        int n = 0, cap = sp.max_planes;
+        int rc = rgbd360_set_plane_refinement(ctx, sp.refine ? 1 : 0, sp.refine_distance);
+        for (int attempt = 0; attempt < 2 && rc == 0; ++attempt) {      // grow once when more regions qualified than the buffer holds
+            out.resize((size_t)cap);
+            rc = rgbd360_sensor_planes(ctx, depth8_.data() + (size_t)sensor_id * srows_ * scols_, (size_t)scols_ * 2, srows_, scols_, /*step=*/2, 0.3f, 10.f,
+                                       sp.sigma_s, sp.sigma_r, sp.max_depth_change_factor, sp.normal_smoothing_size, sp.min_inliers, sp.angular_threshold,
+                                       sp.distance_threshold, sp.max_curvature, calib->Rt_[(size_t)sensor_id].m, out.data(), cap, &n);
+            const int avail = rgbd360_planes_available(ctx);
+            if (rc != 0 || avail <= n) break;
+            cap = avail;
+        }
+        if (rc != 0) {
+            out.clear();
+            throw std::runtime_error("rgbd360_sensor_planes (sensor " + std::to_string(sensor_id) + "): " + rgbd360_last_error(ctx));
+        }
+        out.resize((size_t)n);
     }
     // :741-833: the sensors' lists -> `planes`, pieces of one surface seen by neighbouring sensors pooled
     void groupPlanes() {
@@ -236,9 +231,23 @@ class Frame360 {
     void mergePlanes() { planes.vPlanes = rgbd360::mergePlanes(planes.vPlanes); }
     // :615-639
     void getPlanes() {
-        getLocalPlanes();
-        groupPlanes();
-        mergePlanes();
+        need_images("getPlanes");
+        // one host thread per sensor like the source's `#pragma omp parallel num_threads(8)` (:619-623): every sensor has its own context
+        std::array<std::string, 8> err;
+        std::vector<std::thread> workers;
+        for (int s = 0; s < 8; ++s)
+            workers.emplace_back([&, s]() {
+                try {
+                    getPlanesSensor(s);
+                } catch (const std::exception& e) {
+                    err[(size_t)s] = e.what();
+                }
+            });
+        for (std::thread& w : workers) w.join();
+        for (int s = 0; s < 8; ++s)
+            if (!err[(size_t)s].empty()) throw std::runtime_error(err[(size_t)s]);
+        groupPlanes();      // planes detected from adjacent sensors -> `planes`
+        mergePlanes();      // merge big planes
     }
     // Frame360_stereo.h:835-980 (segmentPlanes): planes of the PANORAMA itself (sphere cloud -> normal map -> regions on the device), with
     // the panorama's colours for the descriptors of Frame360.h:1045-1046
