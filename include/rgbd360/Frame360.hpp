@@ -7,7 +7,7 @@
 // keep their shape.  Images are owned byte buffers viewed through ImageView (the adapter has no OpenCV dependency; with OpenCV a
 // cv::Mat header over the same memory is one line).  NOT mirrored: what depends on third-party file formats or models that are not in
 // the reference tree (loadCloud / loadPbMap / save / serialize: PCL and MRPT serialisation; undistort: the CLAMS depth model).
-// Header-only; depends on nothing but the C ABI and the two other adapter headers.
+// Frame360_stereo (include/Frame360_stereo.h) follows at the end.  Header-only; depends on nothing but the C ABI and the two other adapter headers.
 #pragma once
 
 #include <array>
@@ -268,6 +268,74 @@ class Frame360 {
     std::vector<uint8_t> rgb8_;
     std::vector<uint16_t> depth8_;
     int srows_ = 0, scols_ = 0;
+};
+
+// Frame360_stereo.h:90-980: the spherical frame of the stereo omnidirectional camera -- one float32 range panorama in metres (the sensor's
+// band of the sphere: rows start 166 steps of 2 pi / cols above the equator, :470-490) with an optional colour panorama.  loadDepth reads
+// the sensor's raw file (:268-311); loadRGB takes decoded pixels (the reference decodes a PNG through OpenCV, which this header does not
+// depend on); buildSphereCloud :454-512; getPlanesStereo :847-980 with its PCL set-up (0.05 depth-change factor, 40 inliers, 0.05 rad, 0.05 m).
+class Frame360_stereo {
+   public:
+    unsigned id = 0, node = 0;
+    std::vector<float> sphereDepth_data;            // rows x cols float32 metres, row-major
+    std::vector<uint8_t> sphereRGB_data;            // rows x cols x 3 (optional)
+    ImageView sphereRGB, sphereDepth;
+    std::vector<float> sphereCloud;                 // rows*cols x 3 (NaN = invalid)
+    bool bSphereCloudBuilt = false;                 // :143
+    PbMap planes;
+    Mat4f pose = Mat4f::Identity();
+    SegmentParams params;
+
+    Frame360_stereo() {
+        params.convention = 1; params.depth_mode = 1;
+        params.max_depth_change_factor = 0.05f; params.min_inliers = 40; params.angular_threshold = 0.05f; params.distance_threshold = 0.05f;      // :857-866
+    }
+    Frame360_stereo(const Frame360_stereo&) = delete;
+    Frame360_stereo& operator=(const Frame360_stereo&) = delete;
+
+    // :268-311: uint16 height, uint16 width, then width x height float32 (the image stored column by column)
+    void loadDepth(const std::string& binaryDepthFile) {
+        std::FILE* f = std::fopen(binaryDepthFile.c_str(), "rb");
+        if (!f) throw std::runtime_error("Frame360_stereo::loadDepth: " + binaryDepthFile + " does NOT EXIST");
+        uint16_t hw[2] = {0, 0};
+        bool ok = std::fread(hw, 2, 2, f) == 2 && hw[0] > 0 && hw[1] > 0;
+        const int height = hw[0], width = hw[1];
+        std::vector<float> aux;
+        if (ok) {
+            aux.resize((size_t)height * width);
+            ok = std::fread(aux.data(), 4, aux.size(), f) == aux.size();
+        }
+        std::fclose(f);
+        if (!ok) throw std::runtime_error("Frame360_stereo::loadDepth: " + binaryDepthFile + " is short");
+        sphereDepth_data.resize((size_t)height * width);
+        for (int c = 0; c < width; ++c)              // cv::transpose of the width x height block
+            for (int r = 0; r < height; ++r) sphereDepth_data[(size_t)r * width + c] = aux[(size_t)c * height + r];
+        sphereDepth.data = sphereDepth_data.data(); sphereDepth.rows = height; sphereDepth.cols = width; sphereDepth.step = (size_t)width * 4; sphereDepth.type = ImageView::F32C1;
+        bSphereCloudBuilt = false;
+    }
+    // :318-340 with the decoding left to the caller: rows x cols x 3 bytes of the size of the range image
+    void loadRGB(const uint8_t* rgb, int rows, int cols) {
+        sphereRGB_data.assign(rgb, rgb + (size_t)rows * cols * 3);
+        sphereRGB.data = sphereRGB_data.data(); sphereRGB.rows = rows; sphereRGB.cols = cols; sphereRGB.step = (size_t)cols * 3; sphereRGB.type = ImageView::U8C3;
+    }
+    // :454-512
+    void buildSphereCloud() {
+        if (!sphereDepth.data) throw std::runtime_error("Frame360_stereo::buildSphereCloud: no range image (loadDepth first)");
+        sphereCloud.resize((size_t)sphereDepth.rows * sphereDepth.cols * 3);
+        if (rgbd360_sphere_cloud(reg_.context(), sphereDepth.data, sphereDepth.step, 1, sphereDepth.rows, sphereDepth.cols, /*convention=*/1, sphereCloud.data()) != 0)
+            throw std::runtime_error(std::string("rgbd360_sphere_cloud: ") + rgbd360_last_error(reg_.context()));
+        bSphereCloudBuilt = true;
+    }
+    // :847-980 (cloud, normal map, regions with refinement, descriptors: one chain on the device, from the range image)
+    void getPlanesStereo() {
+        if (!sphereDepth.data) throw std::runtime_error("Frame360_stereo::getPlanesStereo: no range image (loadDepth first)");
+        const bool coloured = sphereRGB.data && sphereRGB.rows == sphereDepth.rows && sphereRGB.cols == sphereDepth.cols;
+        planes.vPlanes = rgbd360::segmentPlanes(reg_, sphereDepth, params, coloured ? &sphereRGB : nullptr);
+    }
+    RegisterPhotoICP& reg() { return reg_; }
+
+   private:
+    RegisterPhotoICP reg_;
 };
 
 }  // namespace rgbd360

@@ -235,6 +235,60 @@ def test_frame360_adapter_on_a_synthetic_rig(tmp_path, hip_lib):
     assert abs(ang - math.radians(3.0)) < math.radians(0.5) and abs(np.linalg.norm(Td[:3, 3]) - 0.08) < 0.03, (ang, Td[:3, 3])
 
 
+def build_stereo_planes(out_dir):
+    from rgbd360_amd import build
+    lib = build.build()
+    exe = os.path.join(str(out_dir), "frame360_stereo_planes")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-pthread", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "frame360_stereo_planes.cpp"), "-L" + os.path.dirname(lib), "-lrgbd360_hip",
+                           "-Wl,-rpath," + os.path.dirname(lib), "-o", exe])
+    return exe
+
+
+def test_frame360_stereo_adapter_compiles_and_checks_its_inputs(tmp_path):
+    exe = build_stereo_planes(tmp_path)
+    assert subprocess.call([exe]) == 2
+    assert subprocess.call([exe, str(tmp_path / "none.raw")], stderr=subprocess.DEVNULL) == 3
+    (tmp_path / "short.raw").write_bytes(b"\x10\x00\x20\x00" + b"\x00" * 100)            # 16 x 32 announced, 25 floats present
+    assert subprocess.call([exe, str(tmp_path / "short.raw")], stderr=subprocess.DEVNULL) == 3
+
+
+@pytest.mark.gpu
+def test_frame360_stereo_adapter_finds_the_walls(tmp_path, hip_lib):
+    """Frame360_stereo through its adapter (loadDepth -> buildSphereCloud -> getPlanesStereo, Frame360_stereo.h:268-311, 454-512, 847-980):
+    the range panorama of the synthetic room in the stereo camera's geometry (2048 x 665, rows from -61 to +56 degrees of elevation),
+    written in the sensor's raw layout (uint16 height, width, then the image column by column).  The walls come back as planes with
+    axis-aligned normals at their true distances."""
+    import struct
+    from oracle import oracle as O
+    from rgbd360_amd import synth
+    exe = build_stereo_planes(tmp_path)
+    H, W = 665, 2048
+    rays = O.sphere_cloud(np.ones((H, W), np.float32), 1).astype(np.float64)            # unit rays of every pixel (the oracle's restatement of :470-490)
+    cam = np.asarray(synth.CAM_A, float)
+    lo, hi = np.asarray(synth.ROOM_LO, float), np.asarray(synth.ROOM_HI, float)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t = np.where(rays > 0, (hi - cam) / rays, np.where(rays < 0, (lo - cam) / rays, np.inf))
+    depth = t.min(axis=1).reshape(H, W).astype(np.float32)
+    with open(tmp_path / "room.raw", "wb") as f:
+        f.write(struct.pack("<HH", H, W) + np.ascontiguousarray(depth.T).tobytes())
+    out = subprocess.check_output([exe, str(tmp_path / "room.raw")], text=True).strip().splitlines()
+    head = out[0].replace(",", "").split()
+    assert head[1] == str(H) and head[3] == str(W) and int(head[6]) == H * W and int(head[8]) >= 5, out[0]
+    walls = {}                                   # per wall direction the region with the most inliers
+    for l in out[1:]:
+        v = [float(x) for x in l.split()]
+        n = np.array(v[1:4])
+        ax = int(np.argmax(np.abs(n)))
+        key = (ax, int(np.sign(n[ax])))
+        if abs(n[ax]) > 0.9999 and v[0] > walls.get(key, (0, 0.0))[0]:
+            walls[key] = (v[0], v[4])
+    assert len(walls) >= 4 and sum(c for c, _ in walls.values()) > 0.35 * H * W, (walls, out[:12])
+    for (ax, sgn), (cnt, d) in walls.items():   # normals point at the camera: a wall at hi has normal -e_ax, distance hi - cam
+        want = (hi[ax] - cam[ax]) if sgn < 0 else (cam[ax] - lo[ax])
+        assert abs(d - want) < 0.02, (ax, sgn, cnt, d, want)
+
+
 # ---- the reference's own signatures (Eigen / cv::Mat) on the adapter: compiled against mock headers ------------------------------
 MOCK = os.path.join(ROOT, "tests", "mock_headers")
 REF = "/root/reference"
