@@ -6,6 +6,7 @@
 //   g++ -std=c++17 -O2 -pthread -Iinclude examples/frame360_pair.cpp -Lrgbd360_amd/lib -lrgbd360_hip -o frame360_pair
 //   ./frame360_pair sphere_images_1.bin sphere_images_2.bin Calibration/Extrinsics [regist_mode]
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <map>
@@ -41,6 +42,7 @@ int main(int argc, char** argv) {
             if (!same) { std::fprintf(stderr, "fastStitchImage360: unexpected panorama\n"); return 4; }
         }
         frame360_1.stitchSphericalImage();
+        frame360_1.buildSphereCloud();                        // RegisterPairRGBD360.cpp:70 (the rig-frame cloud of the eight sensors)
         frame360_1.getPlanes();
 
         Frame360 frame360_2(&calib);
@@ -53,6 +55,18 @@ int main(int argc, char** argv) {
         for (int s = 0; s < 8; ++s) {
             pieces1 += frame360_1.local_planes_[(size_t)s].vPlanes.size();
             pieces2 += frame360_2.local_planes_[(size_t)s].vPlanes.size();
+        }
+        {
+            // every plane of the frame lies in the rig frame like the cloud: the points of sensor clouds must sit on some plane of the list
+            size_t finite = 0, on_plane = 0;
+            const std::vector<float>& c = frame360_1.sphereCloud;
+            for (size_t i = 0; i + 2 < c.size(); i += 3 * 97) {
+                if (!(c[i] == c[i])) continue;
+                ++finite;
+                for (const rgbd360_plane& p : frame360_1.planes.vPlanes)
+                    if (std::fabs(p.normal[0] * c[i] + p.normal[1] * c[i + 1] + p.normal[2] * c[i + 2] + p.d) < 0.03f) { ++on_plane; break; }
+            }
+            std::printf("sphere cloud %zu points, sampled %zu finite, %zu within 3 cm of a plane of the frame\n", c.size() / 3, finite, on_plane);
         }
         std::printf("planes %zu %zu (pieces %zu %zu) planar area %.3f %.3f average intensity %d %d\n", frame360_1.planes.vPlanes.size(),
                     frame360_2.planes.vPlanes.size(), pieces1, pieces2, frame360_1.getPlanarArea(), frame360_2.getPlanarArea(),

@@ -1,6 +1,6 @@
 // Frame360.hpp -- C++ adapter over the C ABI (include/rgbd360_hip.h) with the public surface of the reference's Frame360 and
 // Calib360 (include/Frame360.h:93-1148, include/Calib360.h:44-134 of EduFdez/rgbd360) for the stages this library runs on the
-// device: loadFrame, fastStitchImage360 (host), stitchSphericalImage, buildSphereCloud_fromImage, getPlanes (= the eight getPlanesSensor calls, groupPlanes,
+// device: loadFrame, fastStitchImage360 (host), stitchSphericalImage, buildSphereCloud, buildSphereCloud_fromImage, getPlanes (= the eight getPlanesSensor calls, groupPlanes,
 // mergePlanes), getPlanesSensor, segmentPlanes (the one-panorama variant of Frame360_stereo.h:835-980), getPlanarArea,
 // getAverageIntensity -- same member and method names, so call sites such as RegisterPairRGBD360.cpp:95-110 or
 // OdometryRGBD360.cpp:150-176 (`frame.loadFrame(file); frame.stitchSphericalImage(); frame.getPlanes(); ... frame.planes.vPlanes`)
@@ -186,6 +186,34 @@ class Frame360 {
         sphereRGB.data = sphereRGB_data.data(); sphereRGB.rows = orow; sphereRGB.cols = ocol; sphereRGB.step = (size_t)ocol * 3; sphereRGB.type = ImageView::U8C3;
         sphereDepth.data = sphereDepth_data.data(); sphereDepth.rows = orow; sphereDepth.cols = ocol; sphereDepth.step = (size_t)ocol * 2; sphereDepth.type = ImageView::U16C1;
     }
+
+    // :467-520: the eight sensor clouds (pinhole cloud down-sampled by 2 :471-474, bilateral filter :485-491) moved into the rig frame by Rt_
+    // (:493) -> cloud_[sensor] (rows/2 * cols/2 x 3 floats, NaN = invalid) and their concatenation sphereCloud, sensor after sensor.
+    // (getPointCloudUndist's CLAMS undistortion is not part of this library: the clouds are those of the images as loaded.)
+    std::array<std::vector<float>, 8> cloud_;
+    void buildSphereCloud() {
+        need_images("buildSphereCloud");
+        const int orow = srows_ / 2, ocol = scols_ / 2;
+        const size_t np = (size_t)orow * ocol;
+        for (int s = 0; s < 8; ++s) {
+            rgbd360_ctx* ctx = reg(s).context();
+            std::vector<float>& c = cloud_[(size_t)s];
+            c.resize(np * 3);
+            int rc = rgbd360_sensor_cloud(ctx, depth8_.data() + (size_t)s * srows_ * scols_, (size_t)scols_ * 2, srows_, scols_, 2, 0.3f, 10.f, c.data());
+            if (rc == 0 && sensor_params.sigma_s > 0.f) rc = rgbd360_bilateral_filter(ctx, c.data(), orow, ocol, sensor_params.sigma_s, sensor_params.sigma_r, c.data());
+            if (rc != 0) throw std::runtime_error("Frame360::buildSphereCloud (sensor " + std::to_string(s) + "): " + rgbd360_last_error(ctx));
+            const Mat4f& T = calib->Rt_[(size_t)s];
+            for (size_t i = 0; i < np; ++i) {                   // pcl::transformPointCloud; NaN stays NaN
+                const float x = c[3 * i], y = c[3 * i + 1], z = c[3 * i + 2];
+                c[3 * i] = T(0, 0) * x + T(0, 1) * y + T(0, 2) * z + T(0, 3);
+                c[3 * i + 1] = T(1, 0) * x + T(1, 1) * y + T(1, 2) * z + T(1, 3);
+                c[3 * i + 2] = T(2, 0) * x + T(2, 1) * y + T(2, 2) * z + T(2, 3);
+            }
+        }
+        sphereCloud.clear();
+        for (int s = 0; s < 8; ++s) sphereCloud.insert(sphereCloud.end(), cloud_[(size_t)s].begin(), cloud_[(size_t)s].end());
+    }
+    const std::vector<float>& getCloud_id(int id) const { return cloud_.at((size_t)id); }      // :167-171
 
     // :555-612: the organised cloud of the range panorama (convention 0: the rig's 60-degree band; sphereCloud = rows*cols x 3)
     void buildSphereCloud_fromImage() {

@@ -218,6 +218,9 @@ def test_frame360_adapter_on_a_synthetic_rig(tmp_path, hip_lib):
     for s in range(8):
         np.savetxt(tmp_path / ("Rt_0%d.txt" % (s + 1)), T_rig_sensor[s])
     out = subprocess.check_output([exe, str(tmp_path / "f1.bin"), str(tmp_path / "f2.bin"), str(tmp_path), "2"], text=True).strip().splitlines()
+    c = out[0].replace(",", "").split()
+    assert int(c[2]) == 8 * 160 * 120 and int(c[5]) > 1000 and int(c[7]) > 0.9 * int(c[5]), out[0]      # buildSphereCloud: the room's walls, in the planes' frame
+    out = out[1:]
     w = out[0].split()
     n1, n2 = int(w[1]), int(w[2])
     pieces = [int(w[4]), int(w[5].strip(")"))]
