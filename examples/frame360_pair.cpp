@@ -2,9 +2,9 @@
 // adapters (include/rgbd360/Frame360.hpp): two binary 8-sensor frames -> planes of every sensor on the device (getPlanes = the eight
 // getPlanesSensor calls, groupPlanes, mergePlanes) -> RegisterPbMap; then, where the reference runs PCL's GICP on the sphere clouds
 // (:112-142, third-party), the dense spherical alignment this library is built around, seeded with the plane pose
-// (OdometryRGBD360.cpp:176-193's use of the same objects).  undistort() (the CLAMS depth model) is not part of this library.
+// (OdometryRGBD360.cpp:176-193's use of the same objects).  With an intrinsics directory the frames are undistorted first (:69, :76).
 //   g++ -std=c++17 -O2 -pthread -Iinclude examples/frame360_pair.cpp -Lrgbd360_amd/lib -lrgbd360_hip -o frame360_pair
-//   ./frame360_pair sphere_images_1.bin sphere_images_2.bin Calibration/Extrinsics [regist_mode]
+//   ./frame360_pair sphere_images_1.bin sphere_images_2.bin Calibration/Extrinsics [regist_mode [Calibration/Intrinsics]]
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -16,7 +16,7 @@
 
 int main(int argc, char** argv) {
     if (argc < 4) {
-        std::fprintf(stderr, "usage: %s frame1.bin frame2.bin extrinsics_dir [regist_mode]\n", argv[0]);
+        std::fprintf(stderr, "usage: %s frame1.bin frame2.bin extrinsics_dir [regist_mode [intrinsics_dir]]\n", argv[0]);
         return 2;
     }
     using namespace rgbd360;
@@ -25,10 +25,12 @@ int main(int argc, char** argv) {
 
     Calib360 calib;
     if (!calib.loadExtrinsicCalibration(argv[3])) return 3;
+    const bool intrinsics = argc > 5 && calib.loadIntrinsicCalibration(argv[5]);      // Calibration/Intrinsics: frames are then undistorted like the source's
 
     try {
         Frame360 frame360_1(&calib);
         frame360_1.loadFrame(file360_1);
+        if (intrinsics) frame360_1.undistort();               // RegisterPairRGBD360.cpp:69
         frame360_1.fastStitchImage360();                      // (the viewer's quick panorama; replaced by the spherical one below)
         {
             const int R = frame360_1.sensorRows(), Cn = frame360_1.sensorCols();
@@ -47,6 +49,7 @@ int main(int argc, char** argv) {
 
         Frame360 frame360_2(&calib);
         frame360_2.loadFrame(file360_2);
+        if (intrinsics) frame360_2.undistort();
         frame360_2.stitchSphericalImage();
         const auto t0 = std::chrono::steady_clock::now();
         frame360_2.getPlanes();

@@ -1,12 +1,12 @@
 // Frame360.hpp -- C++ adapter over the C ABI (include/rgbd360_hip.h) with the public surface of the reference's Frame360 and
 // Calib360 (include/Frame360.h:93-1148, include/Calib360.h:44-134 of EduFdez/rgbd360) for the stages this library runs on the
-// device: loadFrame, fastStitchImage360 (host), stitchSphericalImage, buildSphereCloud, buildSphereCloud_fromImage, getPlanes (= the eight getPlanesSensor calls, groupPlanes,
+// device: loadFrame, undistort (host), fastStitchImage360 (host), stitchSphericalImage, buildSphereCloud, buildSphereCloud_fromImage, getPlanes (= the eight getPlanesSensor calls, groupPlanes,
 // mergePlanes), getPlanesSensor, segmentPlanes (the one-panorama variant of Frame360_stereo.h:835-980), getPlanarArea,
 // getAverageIntensity -- same member and method names, so call sites such as RegisterPairRGBD360.cpp:95-110 or
 // OdometryRGBD360.cpp:150-176 (`frame.loadFrame(file); frame.stitchSphericalImage(); frame.getPlanes(); ... frame.planes.vPlanes`)
 // keep their shape.  Images are owned byte buffers viewed through ImageView (the adapter has no OpenCV dependency; with OpenCV a
 // cv::Mat header over the same memory is one line).  NOT mirrored: what depends on third-party file formats or models that are not in
-// the reference tree (loadCloud / loadPbMap / save / serialize: PCL and MRPT serialisation; undistort: the CLAMS depth model).
+// the reference tree (loadCloud / loadPbMap / save / serialize: PCL and MRPT serialisation).
 // Frame360_stereo (include/Frame360_stereo.h) follows at the end.  Header-only; depends on nothing but the C ABI and the two other adapter headers.
 #pragma once
 
@@ -58,6 +58,18 @@ class Calib360 {
         }
         return true;
     }
+    // Calib360.h:104-119: the sensors' intrinsic depth models, Calibration/Intrinsics/distortion_model<N> (N = 1..8), prepared for the
+    // half-resolution images the rig delivers (downsampleParams(2)).  false when a file is missing or not a model (the source asserts).
+    bool loadIntrinsicCalibration(const std::string& pathToIntrinsicModel) {
+        for (int s = 0; s < 8; ++s) {
+            rgbd360_depth_model* m = nullptr;
+            if (rgbd360_depth_model_load((pathToIntrinsicModel + "/distortion_model" + std::to_string(s + 1)).c_str(), 2, &m) != 0) return false;
+            intrinsic_model_[(size_t)s] = std::shared_ptr<rgbd360_depth_model>(m, rgbd360_depth_model_free);
+        }
+        return true;
+    }
+    std::array<std::shared_ptr<rgbd360_depth_model>, 8> intrinsic_model_;      // Calib360.h:56
+
     // {fx, fy, cx, cy} as the C ABI takes them
     std::array<float, 4> K() const { return {cameraMatrix[0], cameraMatrix[4], cameraMatrix[2], cameraMatrix[5]}; }
 
@@ -143,12 +155,40 @@ class Frame360 {
         if (rgbd360_load_frame_bin(binaryFile.c_str(), rgb8_.data(), depth8_.data(), &rows, &cols) != 0)
             throw std::runtime_error("Frame360::loadFrame: cannot read " + binaryFile);
         srows_ = rows; scols_ = cols;
+        depth_undist_.clear();
     }
     // the same from memory: [8][rows][cols][3] uint8 and [8][rows][cols] uint16 mm
     void setSensorImages(const uint8_t* rgb8, const uint16_t* depth8, int rows, int cols) {
         rgb8_.assign(rgb8, rgb8 + (size_t)8 * rows * cols * 3);
         depth8_.assign(depth8, depth8 + (size_t)8 * rows * cols);
         srows_ = rows; scols_ = cols;
+        depth_undist_.clear();
+    }
+
+    // :293-311 (undistortDepthSensor :1084-1097): every sensor's depth image in metres (CloudRGBD_Ext.h:64-69: the millimetre image times
+    // 0.001) corrected by its intrinsic model; the clouds and planes of this frame are then built from the corrected float images
+    // (getPointCloudUndist, CloudRGBD_Ext.h:78-131).  The panorama (stitchSphericalImage) keeps using the sensor's own images, as in the source.
+    void undistort() {
+        need_images("undistort");
+        const size_t n = (size_t)srows_ * scols_;
+        depth_undist_.resize(8 * n);
+        for (int s = 0; s < 8; ++s) {
+            if (!calib->intrinsic_model_[(size_t)s]) throw std::runtime_error("Frame360::undistort: no intrinsic model (Calib360::loadIntrinsicCalibration first)");
+            float* z = depth_undist_.data() + (size_t)s * n;
+            const uint16_t* d = depth8_.data() + (size_t)s * n;
+            for (size_t i = 0; i < n; ++i) z[i] = (float)(0.001 * (double)d[i]);
+            if (rgbd360_depth_model_undistort(calib->intrinsic_model_[(size_t)s].get(), z, (size_t)scols_ * 4, srows_, scols_) != 0) {
+                depth_undist_.clear();
+                throw std::runtime_error("Frame360::undistort: the sensor images are not of the model's size");
+            }
+        }
+    }
+    bool undistorted() const { return !depth_undist_.empty(); }
+    ImageView sensorDepthUndistorted(int sensor_id) const {      // float32 metres; empty before undistort()
+        ImageView v;
+        if (depth_undist_.empty()) return v;
+        v.data = depth_undist_.data() + (size_t)sensor_id * srows_ * scols_; v.rows = srows_; v.cols = scols_; v.step = (size_t)scols_ * 4; v.type = ImageView::F32C1;
+        return v;
     }
 
     // :347-383: the eight colour images side by side, each transposed and flipped (sensor 7 - k in the k-th strip) -- no calibration, no
@@ -199,7 +239,8 @@ class Frame360 {
             rgbd360_ctx* ctx = reg(s).context();
             std::vector<float>& c = cloud_[(size_t)s];
             c.resize(np * 3);
-            int rc = rgbd360_sensor_cloud(ctx, depth8_.data() + (size_t)s * srows_ * scols_, (size_t)scols_ * 2, srows_, scols_, 2, 0.3f, 10.f, c.data());
+            const ImageView dv = sensor_depth_in_use(s);
+            int rc = rgbd360_sensor_cloud_ex(ctx, dv.data, dv.step, dv.type == ImageView::F32C1 ? 1 : 0, srows_, scols_, 2, 0.3f, 10.f, c.data());
             if (rc == 0 && sensor_params.sigma_s > 0.f) rc = rgbd360_bilateral_filter(ctx, c.data(), orow, ocol, sensor_params.sigma_s, sensor_params.sigma_r, c.data());
             if (rc != 0) throw std::runtime_error("Frame360::buildSphereCloud (sensor " + std::to_string(s) + "): " + rgbd360_last_error(ctx));
             const Mat4f& T = calib->Rt_[(size_t)s];
@@ -236,9 +277,10 @@ class Frame360 {
         int rc = rgbd360_set_plane_refinement(ctx, sp.refine ? 1 : 0, sp.refine_distance);
         for (int attempt = 0; attempt < 2 && rc == 0; ++attempt) {      // grow once when more regions qualified than the buffer holds
             out.resize((size_t)cap);
-            rc = rgbd360_sensor_planes(ctx, depth8_.data() + (size_t)sensor_id * srows_ * scols_, (size_t)scols_ * 2, srows_, scols_, /*step=*/2, 0.3f, 10.f,
-                                       sp.sigma_s, sp.sigma_r, sp.max_depth_change_factor, sp.normal_smoothing_size, sp.min_inliers, sp.angular_threshold,
-                                       sp.distance_threshold, sp.max_curvature, calib->Rt_[(size_t)sensor_id].m, out.data(), cap, &n);
+            const ImageView dv = sensor_depth_in_use(sensor_id);
+            rc = rgbd360_sensor_planes_ex(ctx, dv.data, dv.step, dv.type == ImageView::F32C1 ? 1 : 0, srows_, scols_, /*step=*/2, 0.3f, 10.f, sp.sigma_s, sp.sigma_r,
+                                          sp.max_depth_change_factor, sp.normal_smoothing_size, sp.min_inliers, sp.angular_threshold, sp.distance_threshold,
+                                          sp.max_curvature, calib->Rt_[(size_t)sensor_id].m, out.data(), cap, &n);
             const int avail = rgbd360_planes_available(ctx);
             if (rc != 0 || avail <= n) break;
             cap = avail;
@@ -290,11 +332,13 @@ class Frame360 {
     RegisterPhotoICP& reg(int s) { return calib->context(s); }
 
    private:
+    ImageView sensor_depth_in_use(int s) const { return depth_undist_.empty() ? sensorDepth(s) : sensorDepthUndistorted(s); }
     void need_images(const char* who) const {
         if (rgb8_.empty() || srows_ <= 0) throw std::runtime_error(std::string("Frame360::") + who + ": no sensor images (loadFrame / setSensorImages first)");
     }
     std::vector<uint8_t> rgb8_;
     std::vector<uint16_t> depth8_;
+    std::vector<float> depth_undist_;      // [8][rows][cols] metres, after undistort()
     int srows_ = 0, scols_ = 0;
 };
 

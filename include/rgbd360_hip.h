@@ -398,6 +398,11 @@ int rgbd360_frame_planes(rgbd360_ctx* ctx, const void* depth, size_t depth_step,
  * xyz_out: (rows/step) * (cols/step) x 3 float32, NaN = invalid. */
 int rgbd360_sensor_cloud(rgbd360_ctx* ctx, const uint16_t* depth, size_t depth_step, int rows, int cols, int step, float min_depth,
                          float max_depth, float* xyz_out);
+/* The same from either kind of sensor image: depth_type 0 = uint16 millimetres (as above), 1 = float32 METRES -- the image
+ * Frame360::undistort leaves (CloudRGBD_Ext.h:61-75, 116-118: m_depthEigUndistort), whose points getPointCloudUndist keeps when
+ * z > 0 && min_depth <= z <= max_depth (inclusive, in metres: :118) before DownsampleRGBD takes the medians. */
+int rgbd360_sensor_cloud_ex(rgbd360_ctx* ctx, const void* depth, size_t depth_step, int depth_type, int rows, int cols, int step,
+                            float min_depth, float max_depth, float* xyz_out);
 
 /* Frame360::getPlanesSensor for one organised sensor cloud (host, rows*cols x 3 float32, NaN = invalid), with the smoothing
  * that precedes it: pcl::FastBilateralFilter when sigma_s > 0 (Frame360.h:493-499: 10, 0.05), the normal map (Frame360.h:949-957:
@@ -415,6 +420,27 @@ int rgbd360_sensor_planes(rgbd360_ctx* ctx, const uint16_t* depth, size_t depth_
                           float max_depth, float sigma_s, float sigma_r, float max_depth_change_factor, float normal_smoothing_size,
                           int min_inliers, float angular_threshold, float distance_threshold, float max_curvature, const float Rt[16],
                           rgbd360_plane* planes_out, int max_planes, int* n_planes_out);
+/* rgbd360_sensor_planes from either kind of sensor image (depth_type as in rgbd360_sensor_cloud_ex). */
+int rgbd360_sensor_planes_ex(rgbd360_ctx* ctx, const void* depth, size_t depth_step, int depth_type, int rows, int cols, int step,
+                             float min_depth, float max_depth, float sigma_s, float sigma_r, float max_depth_change_factor,
+                             float normal_smoothing_size, int min_inliers, float angular_threshold, float distance_threshold,
+                             float max_curvature, const float Rt[16], rgbd360_plane* planes_out, int max_planes, int* n_planes_out);
+
+/* ---- the sensors' intrinsic depth model: Frame360::undistort (Frame360.h:293-311, undistortDepthSensor :1084-1097) ------------
+ * Calib360::loadIntrinsicCalibration (Calib360.h:104-119) loads one clams::DiscreteDepthDistortionModel per sensor from
+ * Calibration/Intrinsics/distortion_model<N> and calls downsampleParams(2); Frame360::undistort applies it to each sensor's depth image
+ * in metres before the clouds are built.  The model (CLAMS, Teichman et al.; vendored by the reference under
+ * OpenNI2_Grabber/third_party/CLAMS) cuts the image into bins of pixels, each with a multiplier per depth slice; z becomes z * m with m
+ * interpolated between the two slices around z when both saw >= 50 training examples (rgbd360_amd/csrc/depth_model.h restates file
+ * layout and arithmetic).  Host only, no context needed.
+ *   load:      0 ok, 1 cannot open, 2 not a model file / truncated / bins not divisible by `downsample`, -1 bad arguments.
+ *   info:      dims = {width, height, bin_width, bin_height, num_bins_x, num_bins_y} after the down-sampling.
+ *   undistort: rows x cols float32 metres, in place (0 = no measurement stays 0); the image must have the model's size (-1 otherwise). */
+typedef struct rgbd360_depth_model rgbd360_depth_model;
+int  rgbd360_depth_model_load(const char* path, int downsample, rgbd360_depth_model** out);
+void rgbd360_depth_model_free(rgbd360_depth_model* model);
+int  rgbd360_depth_model_info(const rgbd360_depth_model* model, int dims[6], double* bin_depth);
+int  rgbd360_depth_model_undistort(const rgbd360_depth_model* model, float* depth_m, size_t depth_step, int rows, int cols);
 
 /* ---- pinhole single-sensor alignment ------------------------------------------------------ */
 

@@ -670,3 +670,60 @@ class RigOracle:
             lib().oracle_rig_trace_get(self.h, i, C.byref(lv), C.byref(it), C.byref(acc), C.byref(e), C.byref(ne))
             out.append((lv.value, it.value, acc.value, e.value, ne.value))
         return out
+
+
+# ---- the sensors' intrinsic depth model (CLAMS DiscreteDepthDistortionModel; Frame360::undistort, Frame360.h:293-311, 1084-1097) ----------
+# Independent numpy restatement of the reference's vendored code (OpenNI2_Grabber/third_party/CLAMS/discrete_depth_distortion_model.cpp:
+# deserialize :82-92, :259-282; index :38-41; interpolatedUndistort :48-69; undistort :175-186; downsampleParams :313-320) and of its
+# serialisation helpers (include/eigen_extensions/eigen_extensions.h:87-113).  Test infrastructure only.
+def depth_model_read(path, downsample=1):
+    import struct
+    b = open(path, "rb").read()
+    nl = b.index(b"\n")
+    assert b[:nl] == b"DiscreteDepthDistortionModel v01"
+    off = nl + 1
+    width, height, bin_w, bin_h = struct.unpack_from("<iiii", b, off); off += 16
+    bin_depth, = struct.unpack_from("<d", b, off); off += 8
+    nbx, nby = struct.unpack_from("<ii", b, off); off += 8
+    counts, mults, depths, nbins = [], [], [], []
+    for _ in range(nbx * nby):
+        _max_dist, = struct.unpack_from("<d", b, off); off += 8
+        nb, = struct.unpack_from("<i", b, off); off += 4
+        bd, = struct.unpack_from("<d", b, off); off += 8
+        vecs = []
+        for _k in range(4):
+            by, r, c = struct.unpack_from("<iii", b, off); off += 12
+            assert by == 4
+            vecs.append(np.frombuffer(b, np.float32, r * c, off).copy()); off += 4 * r * c
+        assert len(vecs[0]) == nb == len(vecs[3])
+        counts.append(vecs[0]); mults.append(vecs[3]); depths.append(bd); nbins.append(nb)
+    assert off == len(b)
+    assert bin_w % downsample == 0 and bin_h % downsample == 0
+    return dict(width=width // downsample, height=height // downsample, bin_width=bin_w // downsample, bin_height=bin_h // downsample, bin_depth=bin_depth,
+                num_bins_x=nbx, num_bins_y=nby, counts=counts, multipliers=mults, frustum_bin_depth=depths, num_bins=nbins)
+
+
+def depth_model_undistort(model, depth_m):
+    """DiscreteDepthDistortionModel::undistort on a float32 image in metres (0 = no measurement): returns the corrected copy."""
+    z = np.ascontiguousarray(depth_m, np.float32).copy()
+    H, W = z.shape
+    assert (H, W) == (model["height"], model["width"])
+    for v in range(H):
+        yb = min(v // model["bin_height"], model["num_bins_y"] - 1)
+        for u in range(W):
+            zz = z[v, u]
+            if not (zz > 0):
+                continue
+            f = yb * model["num_bins_x"] + min(u // model["bin_width"], model["num_bins_x"] - 1)
+            bd, nb, cnt, mul = model["frustum_bin_depth"][f], model["num_bins"][f], model["counts"][f], model["multipliers"][f]
+            idx = min(nb - 1, int(np.floor(np.float64(zz) / bd)))
+            start = np.float32(bd * idx)
+            idx1 = idx if np.float64(np.float32(zz - start)) < bd / 2 else idx + 1
+            idx0 = idx1 - 1
+            if idx0 < 0 or idx1 >= nb or cnt[idx0] < 50 or cnt[idx1] < 50:
+                z[v, u] = np.float32(zz * mul[idx])
+            else:
+                z0 = (idx0 + 1) * bd - bd * 0.5
+                c1 = (np.float64(zz) - z0) / bd
+                z[v, u] = np.float32(np.float64(zz) * ((1.0 - c1) * np.float64(mul[idx0]) + c1 * np.float64(mul[idx1])))
+    return z

@@ -2953,6 +2953,7 @@ __global__ void k_bilat_interp(float* __restrict__ xyz, int rows, int cols, Bila
 struct SensorCloudArgs {
     int rows, cols, step;
     float inv_fx, inv_fy, ox, oy, min_depth, max_depth;
+    int depth_f32;      // 0: uint16 millimetres (the sensor's image); 1: float32 metres (the image Frame360::undistort left: CloudRGBD_Ext.h:116-118)
 };
 __device__ __forceinline__ float sorted_pick(float* v, int n, int k) {      // k-th smallest of v[0..n), n <= 16 (insertion sort)
     for (int i = 1; i < n; ++i) {
@@ -2975,9 +2976,17 @@ __global__ void k_sensor_cloud(const uint8_t* __restrict__ depth, size_t depth_s
     int n = 0;
     for (int r2 = r * a.step; r2 < (r + 1) * a.step; ++r2)
         for (int c2 = c * a.step; c2 < (c + 1) * a.step; ++c2) {
-            const unsigned short d = *reinterpret_cast<const unsigned short*>(depth + (size_t)r2 * depth_step + 2 * (size_t)c2);
-            const float z = (float)(0.001 * (double)d);      // double product rounded to float, CloudRGBD.h:147
-            if (d > 0 && a.min_depth < z && z < a.max_depth) {
+            float z;
+            bool valid;
+            if (a.depth_f32) {                                // getPointCloudUndist: z > 0 && z >= minDepth && z <= maxDepth
+                z = *reinterpret_cast<const float*>(depth + (size_t)r2 * depth_step + 4 * (size_t)c2);
+                valid = z > 0.f && z >= a.min_depth && z <= a.max_depth;
+            } else {
+                const unsigned short d = *reinterpret_cast<const unsigned short*>(depth + (size_t)r2 * depth_step + 2 * (size_t)c2);
+                z = (float)(0.001 * (double)d);               // double product rounded to float, CloudRGBD.h:147
+                valid = d > 0 && a.min_depth < z && z < a.max_depth;
+            }
+            if (valid) {
                 xs[n] = (c2 - a.ox) * z * a.inv_fx;
                 ys[n] = (r2 - a.oy) * z * a.inv_fy;
                 zs[n] = z;

@@ -18,8 +18,11 @@
 #include <vector>
 
 
+#include <memory>
+
 #include "../../include/rgbd360_hip.h"
 #include "../../include/rgbd360_hip_diag.h"
+#include "depth_model.h"
 #include "host_wait.h"
 #include "photo_icp_kernels.h"
 #include "occlusion_kernels.h"
@@ -2792,38 +2795,44 @@ static int frame_planes_impl(rgbd360_ctx* ctx, const void* depth, size_t depth_s
 }
 
 // one sensor's cloud (pinhole + median down-sampling) from a host depth image into ctx->f_xyz (device)
-static int sensor_cloud_upload(rgbd360_ctx* ctx, const uint16_t* depth, size_t depth_step, int rows, int cols, int step, float min_depth,
+static int sensor_cloud_upload(rgbd360_ctx* ctx, const void* depth, size_t depth_step, int depth_type, int rows, int cols, int step, float min_depth,
                                float max_depth) {
-    if (rows < 1 || cols < 1 || step < 1 || step > 4 || rows / step < 1 || cols / step < 1 || depth_step < (size_t)cols * 2 ||
-        (long long)rows * cols >= (1ll << 30))
+    const size_t dpx = depth_type == 0 ? 2 : 4;
+    if (rows < 1 || cols < 1 || step < 1 || step > 4 || rows / step < 1 || cols / step < 1 || depth_step < (size_t)cols * dpx ||
+        (depth_type != 0 && depth_type != 1) || (long long)rows * cols >= (1ll << 30))
         return fail(ctx, -1, "bad arguments");
     hipSetDevice(ctx->p.device);
     const size_t n = (size_t)rows * cols;
     int rc = f360_ensure(ctx, n);
     if (rc) return rc;
-    HIPC(ctx, hipMemcpy2DAsync(ctx->f_depth_raw, (size_t)cols * 2, depth, depth_step, (size_t)cols * 2, rows, hipMemcpyHostToDevice, ctx->stream));
+    HIPC(ctx, hipMemcpy2DAsync(ctx->f_depth_raw, (size_t)cols * dpx, depth, depth_step, (size_t)cols * dpx, rows, hipMemcpyHostToDevice, ctx->stream));
     f360::SensorCloudArgs a;
     a.rows = rows; a.cols = cols; a.step = step;
+    a.depth_f32 = depth_type;
     const float res_factor_VGA = cols / 640.0;                       // CloudRGBD.h:118-123
     const float focal_length = 525 * res_factor_VGA;
     a.inv_fx = 1.f / focal_length; a.inv_fy = 1.f / focal_length;
     a.ox = cols / 2 - 0.5; a.oy = rows / 2 - 0.5;
     a.min_depth = min_depth; a.max_depth = max_depth;
     const int on = (rows / step) * (cols / step);
-    hipLaunchKernelGGL(f360::k_sensor_cloud, dim3((on + 255) / 256), dim3(256), 0, ctx->stream, ctx->f_depth_raw, (size_t)cols * 2, a, ctx->f_xyz);
+    hipLaunchKernelGGL(f360::k_sensor_cloud, dim3((on + 255) / 256), dim3(256), 0, ctx->stream, ctx->f_depth_raw, (size_t)cols * dpx, a, ctx->f_xyz);
     HIPC(ctx, hipGetLastError());
     return 0;
 }
 
-extern "C" int rgbd360_sensor_cloud(rgbd360_ctx* ctx, const uint16_t* depth, size_t depth_step, int rows, int cols, int step, float min_depth,
-                                   float max_depth, float* xyz_out) {
+extern "C" int rgbd360_sensor_cloud_ex(rgbd360_ctx* ctx, const void* depth, size_t depth_step, int depth_type, int rows, int cols, int step,
+                                      float min_depth, float max_depth, float* xyz_out) {
     if (!ctx || !depth || !xyz_out) return -1;
-    const int rc = sensor_cloud_upload(ctx, depth, depth_step, rows, cols, step, min_depth, max_depth);
+    const int rc = sensor_cloud_upload(ctx, depth, depth_step, depth_type, rows, cols, step, min_depth, max_depth);
     if (rc) return rc;
     const size_t on = (size_t)(rows / step) * (cols / step);
     HIPC(ctx, hipMemcpyAsync(xyz_out, ctx->f_xyz, on * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIPC(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
+}
+extern "C" int rgbd360_sensor_cloud(rgbd360_ctx* ctx, const uint16_t* depth, size_t depth_step, int rows, int cols, int step, float min_depth,
+                                   float max_depth, float* xyz_out) {
+    return rgbd360_sensor_cloud_ex(ctx, depth, depth_step, 0, rows, cols, step, min_depth, max_depth, xyz_out);
 }
 
 // the cloud in ctx->f_xyz -> (filter) -> normal map -> regions -> planes, moved by Rt
@@ -2878,16 +2887,55 @@ static int cloud_planes_tail(rgbd360_ctx* ctx, int rows, int cols, float sigma_s
     return 0;
 }
 
+extern "C" int rgbd360_sensor_planes_ex(rgbd360_ctx* ctx, const void* depth, size_t depth_step, int depth_type, int rows, int cols, int step,
+                                       float min_depth, float max_depth, float sigma_s, float sigma_r, float max_depth_change_factor,
+                                       float normal_smoothing_size, int min_inliers, float angular_threshold, float distance_threshold,
+                                       float max_curvature, const float Rt[16], rgbd360_plane* planes_out, int max_planes, int* n_planes_out) {
+    if (!ctx || !depth || !planes_out || !n_planes_out || max_planes < 1) return -1;
+    if (step < 1 || rows / step < 3 || cols / step < 3) return fail(ctx, -1, "bad image size");
+    const int rc = sensor_cloud_upload(ctx, depth, depth_step, depth_type, rows, cols, step, min_depth, max_depth);
+    if (rc) return rc;
+    return cloud_planes_tail(ctx, rows / step, cols / step, sigma_s, sigma_r, max_depth_change_factor, normal_smoothing_size, min_inliers,
+                             angular_threshold, distance_threshold, max_curvature, /*depth_mode=*/0, Rt, planes_out, max_planes, n_planes_out);
+}
 extern "C" int rgbd360_sensor_planes(rgbd360_ctx* ctx, const uint16_t* depth, size_t depth_step, int rows, int cols, int step, float min_depth,
                                     float max_depth, float sigma_s, float sigma_r, float max_depth_change_factor,
                                     float normal_smoothing_size, int min_inliers, float angular_threshold, float distance_threshold,
                                     float max_curvature, const float Rt[16], rgbd360_plane* planes_out, int max_planes, int* n_planes_out) {
-    if (!ctx || !depth || !planes_out || !n_planes_out || max_planes < 1) return -1;
-    if (step < 1 || rows / step < 3 || cols / step < 3) return fail(ctx, -1, "bad image size");
-    const int rc = sensor_cloud_upload(ctx, depth, depth_step, rows, cols, step, min_depth, max_depth);
-    if (rc) return rc;
-    return cloud_planes_tail(ctx, rows / step, cols / step, sigma_s, sigma_r, max_depth_change_factor, normal_smoothing_size, min_inliers,
-                             angular_threshold, distance_threshold, max_curvature, /*depth_mode=*/0, Rt, planes_out, max_planes, n_planes_out);
+    return rgbd360_sensor_planes_ex(ctx, depth, depth_step, 0, rows, cols, step, min_depth, max_depth, sigma_s, sigma_r, max_depth_change_factor,
+                                    normal_smoothing_size, min_inliers, angular_threshold, distance_threshold, max_curvature, Rt, planes_out, max_planes,
+                                    n_planes_out);
+}
+
+// ---- the sensors' intrinsic depth model (depth_model.h): host only ----
+struct rgbd360_depth_model {
+    depthmodel::Model m;
+};
+extern "C" int rgbd360_depth_model_load(const char* path, int downsample, rgbd360_depth_model** out) {
+    if (!path || !out || downsample < 1) return -1;
+    *out = nullptr;
+    try {
+        std::unique_ptr<rgbd360_depth_model> M(new rgbd360_depth_model());
+        const int rc = depthmodel::load(path, M->m);
+        if (rc) return rc;
+        if (!depthmodel::downsample(M->m, downsample)) return 2;
+        *out = M.release();
+        return 0;
+    } catch (const std::exception&) {
+        return -1;
+    }
+}
+extern "C" void rgbd360_depth_model_free(rgbd360_depth_model* model) { delete model; }
+extern "C" int rgbd360_depth_model_info(const rgbd360_depth_model* model, int dims[6], double* bin_depth) {
+    if (!model || !dims) return -1;
+    const depthmodel::Model& m = model->m;
+    dims[0] = m.width; dims[1] = m.height; dims[2] = m.bin_width; dims[3] = m.bin_height; dims[4] = m.num_bins_x; dims[5] = m.num_bins_y;
+    if (bin_depth) *bin_depth = m.bin_depth;
+    return 0;
+}
+extern "C" int rgbd360_depth_model_undistort(const rgbd360_depth_model* model, float* depth_m, size_t depth_step, int rows, int cols) {
+    if (!model || !depth_m || rows < 1 || cols < 1 || depth_step < (size_t)cols * 4) return -1;
+    return depthmodel::undistort(model->m, depth_m, depth_step, rows, cols) ? 0 : -1;
 }
 
 extern "C" int rgbd360_cloud_planes(rgbd360_ctx* ctx, const float* xyz, int rows, int cols, float sigma_s, float sigma_r,

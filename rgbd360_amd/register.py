@@ -456,6 +456,42 @@ class RegisterPhotoICP:
         return out
 
 
+class DepthModel:
+    """rgbd360_depth_model_*: one sensor's intrinsic depth model (clams::DiscreteDepthDistortionModel as Calib360::loadIntrinsicCalibration
+    loads it, Calib360.h:104-119) and Frame360::undistort's use of it (Frame360.h:293-311).  Host only: no device context."""
+
+    def __init__(self, path: str, downsample: int = 2):
+        self._L = _lib.load()
+        h = C.c_void_p()
+        rc = self._L.rgbd360_depth_model_load(str(path).encode(), int(downsample), C.byref(h))
+        if rc != 0:
+            raise Rgbd360Error("rgbd360_depth_model_load(%s): %s" % (path, {1: "cannot open", 2: "not a model file, truncated, or bins not divisible"}.get(rc, "bad arguments")))
+        self._h = h
+        dims = (C.c_int32 * 6)()
+        bd = C.c_double()
+        self._L.rgbd360_depth_model_info(self._h, dims, C.byref(bd))
+        self.width, self.height, self.bin_width, self.bin_height, self.num_bins_x, self.num_bins_y = [int(x) for x in dims]
+        self.bin_depth = float(bd.value)
+
+    def undistort(self, depth_m):
+        """The corrected copy of a float32 depth image in metres (0 = no measurement)."""
+        z = np.ascontiguousarray(depth_m, np.float32).copy()
+        if self._L.rgbd360_depth_model_undistort(self._h, _ptr(z), z.strides[0], z.shape[0], z.shape[1]) != 0:
+            raise Rgbd360Error("rgbd360_depth_model_undistort: the image is not of the model's size (%d x %d)" % (self.height, self.width))
+        return z
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.rgbd360_depth_model_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def _planes_to_dicts(arr, n):
     return [dict(centroid=np.array(list(arr[i].centroid), np.float32), normal=np.array(list(arr[i].normal), np.float32),
                  d=float(arr[i].d), curvature=float(arr[i].curvature), count=int(arr[i].count), root=int(arr[i].root),
@@ -518,6 +554,12 @@ class Frame360Stages:
     def sensor_cloud(self, depth_mm, step=2, min_depth=0.3, max_depth=10.0):
         """rgbd360_sensor_cloud: CloudRGBD::getPointCloud + DownsampleRGBD::downsamplePointCloud of one sensor's uint16 mm depth image."""
         d = np.asarray(depth_mm)
+        if d.dtype == np.float32:            # metres: the image Frame360::undistort leaves (rgbd360_sensor_cloud_ex, depth_type 1)
+            d = np.ascontiguousarray(d)
+            rows, cols = d.shape
+            out = np.empty(((rows // step) * (cols // step), 3), np.float32)
+            self._reg._check(self._L.rgbd360_sensor_cloud_ex(self._reg._ctx(), _ptr(d), d.strides[0], 1, rows, cols, step, min_depth, max_depth, _ptr(out)))
+            return out.reshape(rows // step, cols // step, 3)
         if d.dtype != np.uint16 or d.strides[1] != 2:
             d = np.ascontiguousarray(d, np.uint16)
         rows, cols = d.shape

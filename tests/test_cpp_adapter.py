@@ -217,7 +217,20 @@ def test_frame360_adapter_on_a_synthetic_rig(tmp_path, hip_lib):
     _write_rig_frame(tmp_path / "f2.bin", T_w1 @ M, T_rig_sensor, 5)
     for s in range(8):
         np.savetxt(tmp_path / ("Rt_0%d.txt" % (s + 1)), T_rig_sensor[s])
-    out = subprocess.check_output([exe, str(tmp_path / "f1.bin"), str(tmp_path / "f2.bin"), str(tmp_path), "2"], text=True).strip().splitlines()
+    plain = subprocess.check_output([exe, str(tmp_path / "f1.bin"), str(tmp_path / "f2.bin"), str(tmp_path), "2"], text=True)
+    # with an intrinsics directory the frames go through undistort() first (RegisterPairRGBD360.cpp:69): identity models (multiplier 1 in
+    # every slice of every bin) leave every number of the run unchanged -- the float-metres route of clouds and planes equals the millimetre one
+    import struct
+    one = struct.pack("<d", 10.0) + struct.pack("<i", 5) + struct.pack("<d", 2.0)
+    for vec in (np.full(5, 100.0), np.ones(5), np.ones(5), np.ones(5)):
+        one += struct.pack("<iii", 4, 5, 1) + vec.astype(np.float32).tobytes()
+    os.makedirs(tmp_path / "intr")
+    for s in range(8):
+        with open(tmp_path / "intr" / ("distortion_model%d" % (s + 1)), "wb") as f:
+            f.write(b"DiscreteDepthDistortionModel v01\n" + struct.pack("<iiii", 640, 480, 8, 6) + struct.pack("<d", 2.0) + struct.pack("<ii", 80, 80) + one * 6400)
+    undist = subprocess.check_output([exe, str(tmp_path / "f1.bin"), str(tmp_path / "f2.bin"), str(tmp_path), "2", str(tmp_path / "intr")], text=True)
+    assert undist == plain
+    out = plain.strip().splitlines()
     c = out[0].replace(",", "").split()
     assert int(c[2]) == 8 * 160 * 120 and int(c[5]) > 1000 and int(c[7]) > 0.9 * int(c[5]), out[0]      # buildSphereCloud: the room's walls, in the planes' frame
     out = out[1:]

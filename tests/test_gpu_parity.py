@@ -441,6 +441,33 @@ def _check_hull_polygon(p, area_rtol=2e-3):
 
 
 @pytest.mark.gpu
+def test_sensor_cloud_from_undistorted_float_depth(hip_lib, tmp_path):
+    """The sensor cloud from the float32-metres image Frame360::undistort leaves (rgbd360_sensor_cloud_ex, depth_type 1; getPointCloudUndist,
+    CloudRGBD_Ext.h:78-131): with the millimetre image times 0.001 as that image the cloud is the uint16 path's, bit for bit; corrected by
+    an intrinsic model with one multiplier everywhere every finite point is scaled by it (x, y and z are all proportional to z)."""
+    import struct
+    from rgbd360_amd.register import DepthModel, Frame360Stages
+    (rgb, dep), _, _, K = synth.make_pinhole_pair(320, 240, seed=9)
+    st = Frame360Stages(_mk(hip_lib, 2))
+    want = st.sensor_cloud(dep, 2)
+    as_m = (0.001 * dep.astype(np.float64)).astype(np.float32)
+    got = st.sensor_cloud(as_m, 2)
+    assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(np.nan_to_num(got), np.nan_to_num(want)) and np.isfinite(want).mean() > 0.5
+    path = tmp_path / "model"
+    with open(path, "wb") as f:            # 640 x 480 model of 8 x 6-pixel bins, five 2 m slices, multiplier 1.03 everywhere
+        f.write(b"DiscreteDepthDistortionModel v01\n" + struct.pack("<iiii", 640, 480, 8, 6) + struct.pack("<d", 2.0) + struct.pack("<ii", 80, 80))
+        one = struct.pack("<d", 10.0) + struct.pack("<i", 5) + struct.pack("<d", 2.0)
+        for vec in (np.full(5, 100.0), np.ones(5), np.ones(5), np.full(5, 1.03)):
+            one += struct.pack("<iii", 4, 5, 1) + vec.astype(np.float32).tobytes()
+        f.write(one * 6400)
+    corrected = DepthModel(path, 2).undistort(as_m)
+    assert np.allclose(corrected[as_m > 0], as_m[as_m > 0] * np.float32(1.03), rtol=2e-7)
+    scaled = st.sensor_cloud(corrected, 2)
+    both = np.isfinite(scaled).all(-1) & np.isfinite(want).all(-1)
+    assert both.mean() > 0.5 and np.allclose(scaled[both], want[both] * 1.03, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
 def test_hull_polygon_of_a_disc_is_thinned_to_64_vertices(hip_lib):
     """A disc on a fronto-parallel plane has an extreme pixel in every one of the hull stage's directions: far more than the 64 vertices a
     plane record carries, so the record's polygon is the hull's extreme vertex in 64 evenly spaced directions (found by ONE walk round the
