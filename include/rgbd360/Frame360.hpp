@@ -302,6 +302,7 @@ class Frame360 {
     // :615-639
     void getPlanes() {
         need_images("getPlanes");
+        (void)reg(0);      // the calibration object's context array exists before the threads look at it (each then creates its own element)
         // one host thread per sensor like the source's `#pragma omp parallel num_threads(8)` (:619-623): every sensor has its own context
         std::array<std::string, 8> err;
         std::vector<std::thread> workers;
