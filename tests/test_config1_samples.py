@@ -1,6 +1,8 @@
 """BASELINE.json configs[0] (plumbing, CPU only): the reference's own sample frames through the restated .bin reader,
-the restated spherical stitcher and the CPU oracle.  Runs only where /root/reference is mounted (the build container);
-the GPU box never sees the reference.  Expected values: tests/golden/config1_samples.json (tests/tools/config1_samples.py --write)."""
+the restated spherical stitcher and the CPU oracle.  Where /root/reference is mounted (the build container) the frames are parsed
+from its files in place; elsewhere they come from the committed data fixture tests/golden/sample_pair.npz, which the first test
+below proves equal to those files.  Expected values: tests/golden/config1_samples.json (tests/tools/config1_samples.py --write).
+The same pair on the DEVICE: tests/test_samples_gpu.py."""
 import json
 import os
 import sys
@@ -10,6 +12,38 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SAMPLES = "/root/reference/samples/sphere_images_1.bin"
+
+
+@pytest.mark.skipif(not os.path.exists(SAMPLES), reason="reference samples are only present in the build container")
+def test_data_fixture_holds_the_reference_sample_frames_and_extrinsics():
+    """tests/golden/sample_pair.npz (what the GPU box sees) = the sensor images of samples/sphere_images_{1,10}.bin and the numbers of
+    Calibration/Extrinsics/Rt_0N.txt, value for value; written back in the archive layout it is the reference's file except for the
+    15 version bytes of the Boost header no reader looks at."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+    import config1_samples as c1
+    for idx in (1, 10):
+        ref, fix = c1.frames(idx, "reference"), c1.frames(idx, "fixture")
+        assert all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(ref, fix))
+    assert all(np.array_equal(a, b) for a, b in zip(c1.extrinsics("reference"), c1.extrinsics("fixture")))
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, "s.bin")
+        c1.write_bin(path, c1.frames(1, "fixture"))
+        a, b = open(path, "rb").read(), open(SAMPLES, "rb").read()
+        assert len(a) == len(b) and a[:30] == b[:30] and a[45:] == b[45:]
+
+
+def test_sample_pair_fixture_stitches_to_the_committed_checksums():
+    """Runs everywhere (no reference needed): the oracle's stitcher on the data fixture reproduces the CRCs recorded from the
+    reference's files, and the alignment record carries the iteration counts the device tests expect."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+    import config1_samples as c1
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "config1_samples.json")))
+    pano = c1.panoramas("fixture")
+    got = {"rgb_1": c1.crc(pano[0][0]), "depth_1": c1.crc(pano[0][1]), "rgb_10": c1.crc(pano[1][0]), "depth_10": c1.crc(pano[1][1])}
+    assert got == gold["crc32"]
+    assert gold["alignments"]["m0_o0"]["libm"]["iters"] == gold["alignments"]["m2_o0"]["device"]["iters"] == [10, 10, 10, 7]
+    assert set(gold["alignments"]) == {"m%d_o%d" % mo for mo in c1.ALIGNMENTS}
 
 
 @pytest.mark.skipif(not os.path.exists(SAMPLES), reason="reference samples are only present in the build container")

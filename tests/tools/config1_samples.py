@@ -1,7 +1,8 @@
 """BASELINE.json configs[0] plumbing: RegisterPairRGBD360-style run on the reference's own sample frames, CPU only.
 
-Reads /root/reference/samples/sphere_images_{1,10}.bin and Calibration/Extrinsics/Rt_0N.txt IN PLACE (the 6 MB of
-reference data are never copied into this repository), restates
+Reads /root/reference/samples/sphere_images_{1,10}.bin and Calibration/Extrinsics/Rt_0N.txt IN PLACE where the reference is
+mounted (the build container); elsewhere (the GPU box) the same sensor images and calibration numbers come from the committed data
+fixture tests/golden/sample_pair.npz (tests/golden/make_golden_samples.py; round 6, so that the HIP path sees the pair).  Restates
   * the Boost binary archive layout of Frame360::loadFrame (Frame360.h:231-266 + cvmat_serialization.h:23-55):
     a 45-byte archive header, then 8 x {RGB 8UC3, depth 16UC1 mm} cv::Mat records + a timestamp Mat, each record
     int32 cols, int32 rows, uint64 elemSize, uint64 cvType, raw bytes;
@@ -52,10 +53,51 @@ def load_frame(path):
     return out
 
 
-def load_extrinsics():
+FIXTURE = os.path.join(ROOT, "tests", "golden", "sample_pair.npz")      # the same data as arrays (tests/golden/make_golden_samples.py)
+_fixture = None
+
+
+def have_reference():
+    return os.path.exists(os.path.join(REF, "samples", "sphere_images_1.bin"))
+
+
+def fixture():
+    global _fixture
+    if _fixture is None:
+        _fixture = dict(np.load(FIXTURE))
+    return _fixture
+
+
+def frames(idx, source=None):
+    """The eight (rgb, depth) sensor images of sample frame 1 or 10: parsed from the reference's .bin in place where the reference is
+    mounted (build container), else from the committed data fixture.  source: "reference" | "fixture" | None (= whichever exists)."""
+    if source == "reference" or (source is None and have_reference()):
+        return load_frame(os.path.join(REF, "samples", "sphere_images_%d.bin" % idx))
+    z = fixture()
+    return [(z["rgb_%d" % idx][s], z["depth_%d" % idx][s]) for s in range(8)]
+
+
+def extrinsics(source=None):
+    """Rt [8] (sensor -> rig, float64 as the text files give them)."""
+    if source == "reference" or (source is None and have_reference()):
+        return [np.loadtxt(os.path.join(REF, "Calibration", "Extrinsics", "Rt_0%d.txt" % (s + 1))) for s in range(8)]
+    return list(fixture()["Rt"])
+
+
+def write_bin(path, fr):
+    """Eight (rgb, depth) sensor images in the layout load_frame reads (Frame360::serialize): what the C++ examples load."""
+    with open(path, "wb") as f:
+        f.write(b"\x16\x00\x00\x00\x00\x00\x00\x00serialization::archive" + b"\x00" * 15)
+        for rgb, dep in fr:
+            f.write(struct.pack("<iiQQ", rgb.shape[1], rgb.shape[0], 3, 16) + np.ascontiguousarray(rgb, np.uint8).tobytes())
+            f.write(struct.pack("<iiQQ", dep.shape[1], dep.shape[0], 2, 2) + np.ascontiguousarray(dep, np.uint16).tobytes())
+        f.write(struct.pack("<iiQQ", 0, 0, 0, 0))
+
+
+def load_extrinsics(source=None):
     Rt = []
-    for s in range(8):
-        M = np.loadtxt(os.path.join(REF, "Calibration", "Extrinsics", "Rt_0%d.txt" % (s + 1))).astype(np.float32)
+    for M in extrinsics(source):
+        M = M.astype(np.float32)
         Rt.append(np.linalg.inv(M.astype(np.float32)).astype(np.float32))      # Rt_inv (Calib360.h:129)
     return Rt
 
@@ -102,21 +144,36 @@ def crc(a):
     return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF
 
 
-def run():
+ALIGNMENTS = [(0, 0), (1, 0), (2, 0), (2, 1), (0, 2), (1, 2), (2, 2)]      # (method, occlusion) run on the sample pair; Occ1 sums both modalities only
+
+
+def panoramas(source=None):
+    """The two stitched 1920 x 320 panoramas from the C++ oracle stitcher (oracle/frame360_ref.cpp)."""
+    from oracle import oracle as O
+    Rt_inv = np.stack(load_extrinsics(source))
+    out = []
+    for idx in (1, 10):
+        fr = frames(idx, source)
+        out.append(O.stitch_sphere(np.stack([f[0] for f in fr]), np.stack([f[1] for f in fr]), Rt_inv))
+    return out
+
+
+def run(source=None, all_modes=False):
     """Panoramas from the C++ oracle stitcher (oracle/frame360_ref.cpp); the numpy stitcher above is an independent
     second restatement whose disagreement (numpy float32 sin/cos vs libm: a handful of boundary pixels) is reported."""
     from oracle import oracle as O
-    Rt_inv = load_extrinsics()
+    Rt_inv = load_extrinsics(source)
     pano, mismatch = [], []
     for idx in (1, 10):
-        frames = load_frame(os.path.join(REF, "samples", "sphere_images_%d.bin" % idx))
-        rgb8 = np.stack([f[0] for f in frames])
-        d8 = np.stack([f[1] for f in frames])
+        fr = frames(idx, source)
+        rgb8 = np.stack([f[0] for f in fr])
+        d8 = np.stack([f[1] for f in fr])
         a, b = O.stitch_sphere(rgb8, d8, np.stack(Rt_inv))
-        a2, b2 = stitch(frames, Rt_inv)
+        a2, b2 = stitch(fr, Rt_inv)
         mismatch.append(int((a != a2).any(-1).sum() + (b != b2).sum()))
         pano.append((a, b))
-    out = {"numpy_vs_cpp_stitch_mismatching_pixels": mismatch,"sensor_image_shape": list(frames[0][0].shape), "panorama_shape": list(pano[0][0].shape),
+    frames_ = fr
+    out = {"numpy_vs_cpp_stitch_mismatching_pixels": mismatch,"sensor_image_shape": list(frames_[0][0].shape), "panorama_shape": list(pano[0][0].shape),
            "crc32": {"rgb_1": crc(pano[0][0]), "depth_1": crc(pano[0][1]), "rgb_10": crc(pano[1][0]), "depth_10": crc(pano[1][1])},
            "valid_depth_fraction": [float((p[1] > 0).mean()) for p in pano]}
     for method, name in ((0, "PHOTO_CONSISTENCY"), (2, "PHOTO_DEPTH")):
@@ -126,11 +183,25 @@ def run():
         st, pose = ora.align360(np.eye(4), method)
         out[name] = {"status": st, "iters": list(ora.result.iters)[:4], "pose": pose.astype(np.float64).tolist(),
                      "err_final": ora.result.err_final, "sso": float(ora.result.sso)}
+    if all_modes:
+        # every (method, occlusion) the device tests run on this pair (tests/test_samples_gpu.py), in the reference's arithmetic
+        # ("libm": math_mode 0, float32 accumulators) and in the device's ("device": math_mode 1, float64 accumulation)
+        out["alignments"] = {}
+        for method, occ in ALIGNMENTS:
+            rec = {}
+            for tag, mm, rm in (("libm", 0, 0), ("device", 1, 1)):
+                ora = O.Oracle(n_pyr=4, math_mode=mm, reduce_mode=rm)
+                ora.set_target(*pano[0])
+                ora.set_source(*pano[1])
+                st, pose = ora.align360(np.eye(4), method, occ)
+                rec[tag] = {"status": st, "iters": list(ora.result.iters)[:4], "pose": pose.astype(np.float64).tolist(),
+                            "err_final": ora.result.err_final, "sso": float(ora.result.sso)}
+            out["alignments"]["m%d_o%d" % (method, occ)] = rec
     return out, pano
 
 
 if __name__ == "__main__":
-    out, _ = run()
+    out, _ = run(all_modes=True)
     print(json.dumps(out, indent=1))
     if len(sys.argv) > 1 and sys.argv[1] == "--write":
         json.dump(out, open(os.path.join(ROOT, "tests", "golden", "config1_samples.json"), "w"), indent=1)
