@@ -162,6 +162,32 @@ def make_pair(width: int, height: int | None = None, seed: int = 1234, trans: fl
     return (rgbA, dA), (rgbB, dB), T_rel
 
 
+def spoil_depth(depth_m: np.ndarray, seed: int = 0, ramps: bool = False, isolated: bool = True) -> np.ndarray:
+    """A float32-metres depth image with what a caller's CV_32FC1 image may carry and the reference takes AS IS at level 0
+    (RegisterPhotoICP.h:318-319: `pyramid[0] = img`): patches of NaN, +Inf, negative values, values beyond maxDepth and zeros, plus
+    isolated pixels of each kind.  Patches are constant, so the monotone gradient inside them is zero; with `ramps` two patches hold
+    strictly increasing values instead (negative, and from -1 to +1 through 0): their depth gradient is salient, and the reference's
+    depth residual there is NaN (RPI.h:2721-2723: the Huber weight of a non-positive standard deviation) -- the sums turn NaN.
+    Test input generation only."""
+    d = np.array(depth_m, dtype=np.float32, copy=True)
+    H, W = d.shape
+    rng = np.random.default_rng(seed + 977)
+    ph, pw = max(2, H // 16), max(2, W // 24)
+    kinds = [np.float32(np.nan), np.float32(np.inf), np.float32(-1.5), np.float32(7.5), np.float32(0.0), np.float32(-np.inf), np.float32(25.0)]
+    for k, v in enumerate(kinds):
+        for _ in range(2):
+            r0, c0 = int(rng.integers(1, H - ph - 1)), int(rng.integers(1, W - pw - 1))
+            d[r0:r0 + ph, c0:c0 + pw] = v
+        rr, cc = rng.integers(0, H, size=max(4, H * W // 2048)), rng.integers(0, W, size=max(4, H * W // 2048))
+        if isolated:        # (at 2048 x 1024 some of the 7 x 1024 isolated pixels fall next to each other: -1.5 between -Inf and a valid depth is a ramp)
+            d[rr, cc] = v
+    if ramps:
+        for lo, hi in ((-3.0, -0.5), (-1.0, 1.0)):
+            r0, c0 = int(rng.integers(1, H - ph - 1)), int(rng.integers(1, W - pw - 1))
+            d[r0:r0 + ph, c0:c0 + pw] = np.linspace(lo, hi, pw, dtype=np.float32)[None, :] + np.linspace(0, 0.2, ph, dtype=np.float32)[:, None]
+    return d
+
+
 def trajectory_pose(k: int, seed: int = 1234) -> np.ndarray:
     """Frame k of a smooth closed trajectory (config 4: pair i = frames i, i+1): a 0.6 m-radius loop in the
     y-z plane with ~6 cm steps, 2 degrees of yaw about the up axis per frame and a small seeded wobble."""

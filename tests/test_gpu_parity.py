@@ -2000,3 +2000,127 @@ def test_colour_constraint_on_device_planes(hip_lib):
     # the odometry profile's intensity_threshold of 100 at most)
     darker = planes(dB, (rgbB * 0.85).astype(np.uint8))
     assert pbmap.register_planes(pa, darker, 0, pbmap.ODOMETRY_6DoF, par)["match"] == without["match"]
+
+
+# ---- what the reference's float32 branch lets through: non-finite and out-of-range depth (RPI.h:316-319: level 0 is the caller's image
+#      AS IS; the LUT's range gate :4573 drops such SOURCE pixels; a TARGET pixel reaches isfinite(depth2), :2714 / :3064) -------------------
+def _spoiled_pair(W, H, seed, ramps, isolated=True):
+    (rgbA, dA), (rgbB, dB), T = synth.make_pair(W, H, seed=seed, depth_f32=True)
+    return (rgbA, synth.spoil_depth(dA, 1, ramps, isolated)), (rgbB, synth.spoil_depth(dB, 2, ramps, isolated)), T
+
+
+@pytest.mark.parametrize("ramps", [False, True])
+def test_nonfinite_float_depth_planes_and_counts(hip_lib, oracle_mod, ramps):
+    """A 256 x 128 float32-metres pair whose depth images carry NaN, +Inf, -Inf, negative values, values beyond maxDepth and zeros (patches
+    and isolated pixels) in BOTH frames.  Level 0 keeps them (bit for bit, NaN payloads included), the higher levels average only
+    the valid ones; gradients next to them follow the comparisons of RPI.h:365-398 (NaN: never monotone; Inf: a finite one-sided
+    difference); the LUT's gate invalidates such source pixels; the pass counts exactly the pixels the oracle counts, the target's NaN
+    and Inf pixels failing isfinite(depth2)."""
+    pair = _spoiled_pair(256, 128, 77, ramps)
+    reg, ora, T = _pair_ctx(hip_lib, oracle_mod, pair)
+    assert not np.isfinite(pair[0][1]).all() and (pair[0][1] < 0).any() and (pair[0][1] > 6.0).any()
+    for level in range(3):
+        ora.prepare_level(level)
+        for name in ("depth_src", "depth_trg", "dgx", "dgy", "gx", "gy"):
+            a, b = reg.plane(name, level), ora.plane(name, level)
+            assert np.array_equal(np.isnan(a), np.isnan(b)), (name, level)
+            assert np.array_equal(a[~np.isnan(a)].view(np.uint32), b[~np.isnan(b)].view(np.uint32)), (name, level)
+        if level > 0:
+            assert np.isfinite(reg.plane("depth_trg", level)).all()              # means of valid pixels only (RPI.h:337-346)
+        la, lb = reg.lut(level), ora.lut(level)
+        valid = lb[:, 0] != -10000
+        assert np.array_equal(la[:, 0] != -10000, valid) and np.isfinite(lb[valid]).all()
+        assert np.array_equal(la[valid].view(np.uint32), lb[valid].view(np.uint32))
+    assert (~np.isfinite(reg.plane("depth_trg", 0))).sum() > 100
+    for level in range(3):
+        for pose in _poses(T)[:3]:
+            for method in (0, 1, 2):
+                e = reg.eval(level, pose, method)
+                rms, err2, nvalid = ora.error(level, pose, method)
+                H, g, Hd, gd, nvis = ora.hessgrad(level, pose, method)
+                assert e["n_valid"] == nvalid and e["n_visible"] == nvis, (level, method)
+                if np.isfinite(err2):
+                    assert abs(e["err2"] - err2) <= ERR2_RTOL * max(1.0, abs(err2))
+                    assert np.abs(e["H64"] - Hd).max() <= HG_RTOL * np.abs(Hd).max()
+                else:                       # a salient gradient on non-positive target depth: the reference's residual is NaN (RPI.h:2721-2723)
+                    assert ramps and method != 0 and level == 0 and not np.isfinite(e["err2"])
+            for occ in (1, 2):
+                e = reg.eval(level, pose, 2, occ)
+                _r, sp, sd, n_p, n_d = ora.error_occ(level, pose, 2, occ)
+                assert list(e["n_split"]) == [n_p, n_d], (level, occ, list(e["n_split"]), n_p, n_d)
+                for got, want in zip(e["err2_split"], (sp, sd)):
+                    assert (abs(got - want) <= ERR2_RTOL * max(1.0, abs(want))) if np.isfinite(want) else not np.isfinite(got), (level, occ, got, want)
+
+
+@pytest.mark.parametrize("ramps", [False, True])
+@pytest.mark.parametrize("method,occlusion", [(0, 0), (1, 0), (2, 0), (2, 1), (0, 2), (1, 2), (2, 2)])
+def test_nonfinite_float_depth_alignment(hip_lib, oracle_mod, method, occlusion, ramps):
+    """The same pair through rgbd360_align360: status, iterations per level and pose as the oracle's.  With the ramps the sums of the
+    depth modalities are NaN at level 0: `diff_error > tol_residual` is false (RPI.h:4611), the level ends without a step and the call
+    reports what the reference's NaN error amounts to -- handled like the oracle, not as a silent number."""
+    pair = _spoiled_pair(256, 128, 77, ramps)
+    reg, ora, T = _pair_ctx(hip_lib, oracle_mod, pair)
+    rc = reg.alignFrames360(np.eye(4), method, occlusion)
+    st, pose_ref = ora.align360(np.eye(4), method, occlusion)
+    assert rc == st, (rc, st)
+    assert reg.num_iterations == list(ora.result.iters)[:3], (reg.num_iterations, list(ora.result.iters)[:3])
+    pose = reg.getOptimalPose()
+    assert np.isfinite(pose).all()
+    rot, trans = synth.pose_error(pose, pose_ref)
+    assert rot <= POSE_TOL_DEV and trans <= POSE_TOL_DEV, (rot, trans)
+    _assert_libm_oracle_agrees(reg, ora, method, 3, occlusion, status=st)
+    if st == 0 and method != 1:
+        rot_gt, trans_gt = synth.pose_error(pose, T)
+        assert rot_gt < 3e-3 and trans_gt < 6e-3, (rot_gt, trans_gt)              # the spoiled tenth of the image does not derail it
+
+
+def test_nonfinite_float_depth_full_size_sequence_and_planes(hip_lib, oracle_mod):
+    """2048 x 1024 with the same kinds of values: alignment vs the oracle (iterations, exact counts, pose), the sequence engine on
+    [A, B, A] bit-identical to the pairwise calls, and rgbd360_frame_planes on the spoiled target: cloud, normal map and region labels
+    as the oracle's stages give them (NaN / Inf ranges are points the normal map's finite test drops)."""
+    # with isolated pixels of every kind (7 x 1024 of them) a few fall side by side and form ramps: the depth sums of level 0 are NaN,
+    # the level ends without a step (status 2, iterations [0, 1, 1, 5]) -- the device follows the oracle there too
+    noisy = _spoiled_pair(2048, 1024, 1234, False)
+    reg, ora, T = _pair_ctx(hip_lib, oracle_mod, noisy, n_pyr=4)
+    for method, want in ((0, 0), (2, 2)):
+        rc = reg.alignFrames360(np.eye(4), method)
+        st, pose_ref = ora.align360(np.eye(4), method)
+        assert rc == st == want and reg.num_iterations == list(ora.result.iters)[:4], (method, rc, st)
+        rot, trans = synth.pose_error(reg.getOptimalPose(), pose_ref)
+        assert rot <= POSE_TOL_DEV and trans <= POSE_TOL_DEV, (rot, trans)
+    assert reg.num_iterations[0] == 0
+    pair = _spoiled_pair(2048, 1024, 1234, False, isolated=False)
+    reg, ora, T = _pair_ctx(hip_lib, oracle_mod, pair, n_pyr=4)
+    for method in (0, 2):
+        rc = reg.alignFrames360(np.eye(4), method)
+        st, pose_ref = ora.align360(np.eye(4), method)
+        assert rc == st == 0 and reg.num_iterations == list(ora.result.iters)[:4]
+        rot, trans = synth.pose_error(reg.getOptimalPose(), pose_ref)
+        assert rot <= POSE_TOL_DEV and trans <= POSE_TOL_DEV, (rot, trans)
+        e = reg.eval(0, pose_ref, method)
+        _, err2, nvalid = ora.error(0, pose_ref, method)
+        _H, _g, Hd, gd, nvis = ora.hessgrad(0, pose_ref, method)
+        assert e["n_valid"] == nvalid and e["n_visible"] == nvis
+        assert abs(e["err2"] - err2) <= ERR2_RTOL * err2 and np.abs(e["H64"] - Hd).max() <= HG_RTOL * np.abs(Hd).max()
+        _assert_libm_oracle_agrees(reg, ora, method, 4)
+    pose_pair = reg.getOptimalPose()
+    frames = [pair[0], pair[1], pair[0]]
+    seq = _mk(hip_lib, 4)
+    poses, status, iters = seq.alignSequence(frames, 2)
+    assert status[0] == 0 and np.array_equal(poses[0], pose_pair) and list(iters[0]) == reg.num_iterations
+    back = _mk(hip_lib, 4)
+    back.setTargetFrame(*pair[1]); back.setSourceFrame(*pair[0])
+    assert back.alignFrames360(np.eye(4), 2) == status[1] == 0 and np.array_equal(back.getOptimalPose(), poses[1])
+    # Frame360 stages on the spoiled range image
+    from rgbd360_amd.register import Frame360Stages
+    dA = pair[0][1]
+    out = Frame360Stages(reg).frame_planes(dA, convention=2, angular_threshold=0.03)
+    xyz = oracle_mod.sphere_cloud(dA, 2)
+    assert np.array_equal(np.isnan(xyz), np.isnan(out["xyz"])) and np.array_equal(np.nan_to_num(xyz, posinf=1e30, neginf=-1e30), np.nan_to_num(out["xyz"], posinf=1e30, neginf=-1e30))
+    nrm, _ = oracle_mod.f360_normals(xyz, 1024, 2048, 0.05, 8.0, 1)
+    ok = ~np.isnan(nrm[:, 0])
+    assert np.array_equal(np.isnan(out["normals"][:, 0]), ~ok)
+    assert np.abs(out["normals"][ok] - nrm[ok]).max() <= 1.2e-7
+    labels, planes = oracle_mod.f360_plane_segment(xyz, out["normals"], 1024, 2048, 40, 0.03, 0.05, 0.001, 1)
+    assert np.array_equal(np.asarray(out["labels"]).reshape(-1), np.asarray(labels).reshape(-1))
+    assert [(p["root"], p["count"]) for p in out["planes"]] == [(p["root"], p["count"]) for p in planes] and len(planes) >= 6
