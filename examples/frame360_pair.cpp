@@ -54,11 +54,18 @@ int main(int argc, char** argv) {
         const auto t0 = std::chrono::steady_clock::now();
         frame360_2.getPlanes();
         std::fprintf(stderr, "getPlanes: %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-        size_t pieces1 = 0, pieces2 = 0;
+        size_t pieces1 = 0, pieces2 = 0, coloured = 0;
         for (int s = 0; s < 8; ++s) {
             pieces1 += frame360_1.local_planes_[(size_t)s].vPlanes.size();
             pieces2 += frame360_2.local_planes_[(size_t)s].vPlanes.size();
+            // Frame360.h:1034, :1041, :1045-1046: nothing smaller than min_area_plane or narrower than max_elongation_plane is stored,
+            // and every stored plane carries its colour descriptors
+            for (const rgbd360_plane& p : frame360_1.local_planes_[(size_t)s].vPlanes) {
+                if (p.area < 0.12f || p.elongation > 6.f) { std::fprintf(stderr, "sensor %d stores a plane of %.3f m2, elongation %.1f\n", s, p.area, p.elongation); return 4; }
+                coloured += p.color_count > 0;
+            }
         }
+        if (coloured != pieces1) { std::fprintf(stderr, "%zu of %zu sensor planes carry colour\n", coloured, pieces1); return 4; }
         {
             // every plane of the frame lies in the rig frame like the cloud: the points of sensor clouds must sit on some plane of the list
             size_t finite = 0, on_plane = 0;

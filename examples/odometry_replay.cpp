@@ -173,6 +173,7 @@ int main(int argc, char** argv) {
         currentPose = mul(currentPose, rel);                                                    // :257
         printf("pair %d status %d sso %.4f rel_t %.5f %.5f %.5f pose_t %.5f %.5f %.5f\n", k - 1, align360.status(), align360.SSO,
                rel(0, 3), rel(1, 3), rel(2, 3), currentPose(0, 3), currentPose(1, 3), currentPose(2, 3));
+        fprintf(stderr, "entropy %d %.5f\n", k - 1, align360.calcEntropy());                     // :207 (commented out in the source)
         std::swap(frame1, frame2);
         std::swap(planes1, planes2);
     }

@@ -229,7 +229,7 @@ class Frame360 {
 
     // :467-520: the eight sensor clouds (pinhole cloud down-sampled by 2 :471-474, bilateral filter :485-491) moved into the rig frame by Rt_
     // (:493) -> cloud_[sensor] (rows/2 * cols/2 x 3 floats, NaN = invalid) and their concatenation sphereCloud, sensor after sensor.
-    // (getPointCloudUndist's CLAMS undistortion is not part of this library: the clouds are those of the images as loaded.)
+    // (after undistort() the clouds are those of the corrected float images, as getPointCloudUndist's are in the source.)
     std::array<std::vector<float>, 8> cloud_;
     void buildSphereCloud() {
         need_images("buildSphereCloud");
@@ -265,7 +265,9 @@ class Frame360 {
     }
 
     // :942-1075: the planes of ONE sensor's cloud (pinhole cloud down-sampled by 2, bilateral filter :493-499, normal map, regions with
-    // refinement, extent and colour-free descriptors), moved into the rig frame by Rt_[sensor] (:1046) -> local_planes_[sensor_id].
+    // refinement, hull, extent and the colour descriptors of :1045-1046 from the sensor's own image), moved into the rig frame by
+    // Rt_[sensor] (:1048), then the source's tail (:1034-1068, round 6): regions under min_area_plane / over max_elongation_plane are
+    // never stored, flat regions of one surface are pooled (isSamePlane(0.99, 0.05, 0.2) + mergePlane2) -> local_planes_[sensor_id].
     // (getLocalPlanes / getLocalPlanesInFrame, :641-655 / :839-940, estimate normals with PCL's COVARIANCE_MATRIX method, which this
     // library does not implement: not mirrored.)
     void getPlanesSensor(int sensor_id) {
@@ -275,6 +277,12 @@ class Frame360 {
         std::vector<rgbd360_plane>& out = local_planes_.at((size_t)sensor_id).vPlanes;
         int n = 0, cap = sp.max_planes;
         int rc = rgbd360_set_plane_refinement(ctx, sp.refine ? 1 : 0, sp.refine_distance);
+        // calcPlaneHistH / calcMainColor2 (:1045-1046) read the plane's points' colours: cloud pixel (r, c) of the cloud down-sampled by 2
+        // carries the colour of image pixel (2 r + 1, 2 c + 1) (DownsampleRGBD.h:240, 285-287)
+        if (rc == 0) {
+            const ImageView cv = sensorRGB(sensor_id);
+            rc = rgbd360_set_plane_color_image(ctx, (const uint8_t*)cv.data, cv.step, cv.rows, cv.cols, /*step=*/2, /*on_device=*/0);
+        }
         for (int attempt = 0; attempt < 2 && rc == 0; ++attempt) {      // grow once when more regions qualified than the buffer holds
             out.resize((size_t)cap);
             const ImageView dv = sensor_depth_in_use(sensor_id);
@@ -290,6 +298,7 @@ class Frame360 {
             throw std::runtime_error("rgbd360_sensor_planes (sensor " + std::to_string(sensor_id) + "): " + rgbd360_last_error(ctx));
         }
         out.resize((size_t)n);
+        out = rgbd360::poolSensorPlanes(out, sp.max_curvature_plane, sp.min_area_plane, sp.max_elongation_plane);      // :1034-1068
     }
     // :741-833: the sensors' lists -> `planes`, pieces of one surface seen by neighbouring sensors pooled
     void groupPlanes() {

@@ -14,6 +14,8 @@
 #pragma once
 
 #include <array>
+#include <cmath>
+#include <utility>
 #include <cstdint>
 #include <cstring>
 #include <stdexcept>
@@ -193,6 +195,31 @@ class RegisterPhotoICP {
 #endif
     const std::vector<int>& numIterations() const { return num_iterations; }
     int status() const { return status_; }
+
+    // RPI.h:4789-4797 (call site OdometryRGBD360.cpp:207): differential entropy of the pose estimate, 0.5 (DOF (1 + ln 2 pi) + ln det H^-1)
+    // with DOF = 6 and H the Hessian of the last alignment.  ln det H^-1 = -ln det H from a partial-pivot LU in double: the reference
+    // forms det(H.inverse()) in float, which underflows to 0 (entropy -inf) once det H passes 3e38 -- a 2048 x 1024 Hessian does; the
+    // value here stays finite and equals the reference's wherever that one is finite.  NaN when H is singular or not positive.
+    float calcEntropy() const {
+        double a[6][6], logdet = 0;
+        for (int r = 0; r < 6; ++r)
+            for (int c = 0; c < 6; ++c) a[r][c] = hessian_.m[c * 6 + r];
+        for (int k = 0; k < 6; ++k) {
+            int p = k;
+            for (int r = k + 1; r < 6; ++r)
+                if (std::fabs(a[r][k]) > std::fabs(a[p][k])) p = r;
+            if (p != k)
+                for (int c = 0; c < 6; ++c) std::swap(a[k][c], a[p][c]);
+            logdet += std::log(std::fabs(a[k][k]));          // (a symmetric positive definite H has a positive determinant: the sign is dropped)
+            if (a[k][k] == 0) return std::nanf("");
+            for (int r = k + 1; r < 6; ++r) {
+                const double f = a[r][k] / a[k][k];
+                for (int c = k; c < 6; ++c) a[r][c] -= f * a[k][c];
+            }
+        }
+        const double PI_ = 3.14159265359;                    // the reference's macro (Miscellaneous.h:44)
+        return (float)(0.5 * (6.0 * (1.0 + std::log(2 * PI_)) - logdet));
+    }
 
 #ifdef RGBD360_HAVE_OPENCV
     void setTargetFrame(cv::Mat& imgRGB, cv::Mat& imgDepth) { set(true, view(imgRGB), view(imgDepth)); }

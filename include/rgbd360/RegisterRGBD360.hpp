@@ -77,6 +77,8 @@ struct SensorSegmentParams {
     int max_planes = 512;
     bool refine = true;                // segmentAndRefine (Frame360.h:977)
     float refine_distance = 0.02f;
+    // the tail of getPlanesSensor (Frame360.h:1034-1068; Miscellaneous.h:54,57,60)
+    float max_curvature_plane = 0.0013f, min_area_plane = 0.12f, max_elongation_plane = 6.f;
 };
 inline std::vector<rgbd360_plane> segmentSensorPlanes(RegisterPhotoICP& reg, const float* xyz, int rows, int cols, const float* Rt = nullptr,
                                                       const SensorSegmentParams& sp = SensorSegmentParams()) {
@@ -107,6 +109,19 @@ inline std::vector<rgbd360_plane> mergePlanes(const std::vector<rgbd360_plane>& 
     if (rgbd360_merge_planes(planes.data(), (int)planes.size(), max_curvature, min_area, max_elongation, cos_normal, dist_d, proximity, normal_offset, out.data(),
                              (int)out.size(), &n) != 0)
         throw std::runtime_error("rgbd360_merge_planes: bad arguments");
+    out.resize((size_t)n);
+    return out;
+}
+
+// The tail of Frame360::getPlanesSensor (Frame360.h:1034-1068; defaults = its constants): one sensor's regions -> local_planes_[sensor]:
+// regions under min_area_plane / over max_elongation_plane dropped, flat regions of one surface (isSamePlane(0.99, 0.05, 0.2)) pooled.
+inline std::vector<rgbd360_plane> poolSensorPlanes(const std::vector<rgbd360_plane>& planes, float max_curvature = 0.0013f, float min_area = 0.12f,
+                                                   float max_elongation = 6.f, float cos_normal = 0.99f, float dist_normal = 0.05f, float proximity = 0.2f) {
+    std::vector<rgbd360_plane> out(planes.size() ? planes.size() : 1);
+    int n = 0;
+    if (rgbd360_pool_sensor_planes(planes.data(), (int)planes.size(), max_curvature, min_area, max_elongation, cos_normal, dist_normal, proximity, out.data(),
+                                   (int)out.size(), &n) != 0)
+        throw std::runtime_error("rgbd360_pool_sensor_planes: bad arguments");
     out.resize((size_t)n);
     return out;
 }

@@ -563,8 +563,8 @@ int rgbd360_register_planes(const rgbd360_plane* ref, int n_ref, const rgbd360_p
  * plane.  Same surface = the reference's explicit test: n_j . n_k > cos_normal (0.99), |d_j - d_k| < dist_d (0.45 m), and outlines
  * closer than proximity (0.3 m) at a pair of points whose difference lies within normal_offset (0.06 m) of plane j -- on the HULL
  * POLYGONS of the two records, as the reference does (Frame360.h:680-691 vertex against vertex, :694-711 edge against edge: the 3-D
- * segment-to-segment distance; a vertex of one polygon inside the other -- overlapping pieces whose outlines never come close -- counts
- * too).  Records without a polygon (hull_n = 0: caller-made) are tested on the rectangle with their in-plane moments instead (corners,
+ * segment-to-segment distance; round 6: no containment test -- the reference has none, a panel inside a wall's hull but farther than
+ * `proximity` from its outline stays a plane of its own).  Records without a polygon (hull_n = 0: caller-made) are tested on the rectangle with their in-plane moments instead (corners,
  * edge midpoints, centre).  The merged plane is the exact pooled fit of the two pieces (covariances rebuilt from the records, combined
  * by inlier count -- mrpt's mergePlane2 pools the inliers and refits); its polygon is the convex hull of the two polygons' vertices
  * projected onto the pooled plane (mergePlane2 re-hulls the two contours), its area and centre that polygon's.
@@ -588,6 +588,16 @@ int rgbd360_merge_planes(const rgbd360_plane* planes, int n, float max_curvature
 int rgbd360_group_planes(const rgbd360_plane* planes, const int* n_per_sensor, int n_sensors, float max_curvature, float min_area,
                          float cos_normal, float dist_d, float max_dist_hull, float max_dist_parallel_hull, rgbd360_plane* out, int max_out,
                          int* n_out);
+
+/* The tail of Frame360::getPlanesSensor (Frame360.h:1034-1068), between one sensor's regions (rgbd360_sensor_planes / _cloud_planes, already
+ * in the rig frame) and local_planes_[sensor]: regions smaller than min_area (0.12 m2, :1034) or narrower than max_elongation (6, :1041)
+ * are dropped; each remaining region flatter than max_curvature (0.0013) is pooled (mergePlane2, as in rgbd360_merge_planes) into the
+ * first plane already kept, also flatter, that mrpt::pbmap::Plane::isSamePlane(plane, cos_normal 0.99, dist_normal 0.05 m,
+ * proximity 0.2 m) accepts (:1056-1068) -- normals, the centres' distance along the kept plane's normal, and the outlines nearer than
+ * proximity (centres, vertices, edges; MRPT, third-party: restated, unpinned) -- else appended, in input order.  Host only.
+ * out may not alias planes; -1 when max_out is too small (*n_out = needed) or on bad arguments. */
+int rgbd360_pool_sensor_planes(const rgbd360_plane* planes, int n, float max_curvature, float min_area, float max_elongation, float cos_normal,
+                               float dist_normal, float proximity, rgbd360_plane* out, int max_out, int* n_out);
 
 #ifdef __cplusplus
 }

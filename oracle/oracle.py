@@ -443,8 +443,8 @@ def f360_plane_colour_mode(labels, rgb, planes, step=1):
         S = px.sum(1)
         px, S = px[S > 0], S[S > 0]
         N = len(S)
-        if N == 0 or N > 4096:      # (more than the device's sample capacity: which samples it keeps depends on arrival order -- not comparable)
-            d["color_mode_count"] = -1 if N > 4096 else 0
+        if N == 0 or N > 4096:      # (more than a region slot holds: no dominant colour, by the device's rule -- k_f360_colour_mode)
+            d["color_mode_count"] = 0
             out.append(d)
             continue
         q = (px << 16) // S[:, None]

@@ -78,8 +78,9 @@ inline bool downsample(Model& M, int step) {
 }
 // DiscreteFrustum::index / undistort / interpolatedUndistort, operation for operation (float z, double interpolation weights)
 inline int slice_of(const Frustum& F, float z) {
-    const int i = (int)std::floor((double)z / F.bin_depth);
-    return i < F.num_bins - 1 ? i : F.num_bins - 1;
+    const double q = std::floor((double)z / F.bin_depth);
+    if (!(q < (double)(F.num_bins - 1))) return F.num_bins - 1;      // beyond the last slice, +Inf (and NaN, which undistort() never passes): no float -> int conversion out of range
+    return q < 0 ? -1 : (int)q;
 }
 inline void undistort_px(const Frustum& F, float* z) {
     const int idx = slice_of(F, *z);

@@ -1536,7 +1536,7 @@ constexpr int kColWords = kColSums + kColBins + kColMode;      // 64-bit words p
 // mean stops moving).  Here the thinning is a regular grid over the region's pixels, rows r % sr == 0 and columns c % sc == 0 with
 // sr = isqrt(step), sc = step / sr, step = max(count / kModeTarget, 1): a SET of samples that does not depend on any order.
 constexpr int kModeTarget = 2000;
-constexpr int kModeCap = 4096;       // samples a region can hold (a grid over a connected region of `count` pixels yields about count / (sr sc) <= 1.25 kModeTarget)
+constexpr int kModeCap = 4096;       // samples a region can hold (a grid over a connected region of `count` pixels yields about count / (sr sc) <= 1.25 kModeTarget; a region with more gets no dominant colour: k_f360_colour_mode)
 __host__ __device__ inline void mode_grid(int count, int& sr, int& sc) {
     const int step = count / kModeTarget > 1 ? count / kModeTarget : 1;
     sr = 1;
@@ -1830,7 +1830,11 @@ __global__ __launch_bounds__(kModeThreads) void k_f360_colour_mode(const int* __
         if (lane == 0 && t) atomicAdd(&acc[k], t);
     };
     for (int slot = blockIdx.x; slot < ns; slot += gridDim.x) {
-        const int N = min(smp.samp_n[slot], kModeCap);
+        // A region whose grid yields more samples than a slot holds (samp_n is the exact, order-free COUNT of its grid samples; thin
+        // row-aligned regions can exceed count / (sr sc)) gets NO dominant colour: which samples would have found a place depends on
+        // their arrival order, and a mode of an arbitrary subset is not repeatable.  color_mode_count = 0 then: the matcher compares
+        // the means, the CPU checker says the same.
+        const int N = smp.samp_n[slot] > kModeCap ? 0 : smp.samp_n[slot];
         unsigned long long* row = col + (size_t)slot * kColWords;
         unsigned long long* out = row + kColSums + kColBins;
         __syncthreads();                               // (the previous slot's state is no longer read)

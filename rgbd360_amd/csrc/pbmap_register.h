@@ -517,11 +517,9 @@ inline bool same_surface_hulls(const rgbd360_plane& pj, const rgbd360_plane& pk,
             const V3 a0 = v3(pj.hull[i]), a1 = v3(pj.hull[(i + 1) % nj_v]), b0 = v3(pk.hull[ii]), b1 = v3(pk.hull[(ii + 1) % nk_v]);
             if (seg_seg_dist2(a0, a1, b0, b1) < prox2 && fabs(dot(nj, sub(a1, b1))) < M.normal_offset) return true;
         }
-    // one piece lying inside the other (no pair of outline points need be close then; a region re-observed through a hole in another)
-    for (int i = 0; i < nk_v; ++i)
-        if (point_in_hull(pj, v3(pk.hull[i]), M.normal_offset)) return true;
-    for (int i = 0; i < nj_v; ++i)
-        if (point_in_hull(pk, v3(pj.hull[i]), M.normal_offset)) return true;
+    // (round 5 also accepted a vertex of one polygon INSIDE the other; the reference has no such test -- Frame360.h:680-711, 788-815 are
+    // vertex-vertex and edge-edge proximity only -- and a panel lying inside a wall's hull, farther than `proximity` from its outline,
+    // stays a plane of its own there: removed in round 6.)
     return false;
 }
 inline bool same_surface(const rgbd360_plane& pj, const rgbd360_plane& pk, const MergeParams& M) {
@@ -693,6 +691,68 @@ inline std::vector<rgbd360_plane> merge_planes(const rgbd360_plane* in, int n, c
                 break;
             }
         }
+    }
+    return v;
+}
+
+// Frame360::getPlanesSensor's tail (Frame360.h:1034-1068), the three steps between a sensor's regions and local_planes_[sensor]:
+// regions smaller than min_area (:1034) or narrower than max_elongation (:1041) are never stored; a region flatter than max_curvature
+// is pooled (mergePlane2) into the FIRST stored plane, also flatter, that `isSamePlane(plane, 0.99, 0.05, 0.2)` (:1056-1068), else
+// appended.  mrpt::pbmap::Plane::isSamePlane / isPlaneNearby are third-party (MRPT 1.x pbmap/Plane.cpp, restated, unpinned): normals
+// closer than cos_normal; the other plane's centre within dist_normal of this plane along its normal; the two outlines nearer than
+// proximity -- centre to centre, a vertex of one to the other's centre, vertex to vertex, edge to edge (dist3D_Segment_to_Segment2).
+struct SensorPoolParams {
+    float max_curvature = 0.0013f, min_area = 0.12f, max_elongation = 6.f;      // Miscellaneous.h:54,57,60
+    float cos_normal = 0.99f, dist_normal = 0.05f, proximity = 0.2f;            // Frame360.h:1058
+};
+inline int outline_points(const rgbd360_plane& p, V3 pts[RGBD360_HULL_MAX]) {      // the hull polygon, else the moment rectangle's corners
+    const int n = std::min(p.hull_n, (int)RGBD360_HULL_MAX);
+    if (n >= 3) {
+        for (int i = 0; i < n; ++i) pts[i] = v3(p.hull[i]);
+        return n;
+    }
+    V3 c9[9], pp, qq;
+    double a, b;
+    contour_points(p, c9, pp, qq, a, b);
+    const int corner[4] = {0, 2, 8, 6};                                            // (-,-) (-,+) (+,+) (+,-): a closed outline
+    for (int i = 0; i < 4; ++i) pts[i] = c9[corner[i]];
+    return 4;
+}
+inline bool is_plane_nearby(const rgbd360_plane& a, const rgbd360_plane& b, double prox) {
+    const double p2 = prox * prox;
+    const V3 ca = center_of(a), cb = center_of(b);
+    const V3 dc = sub(ca, cb);
+    if (dot(dc, dc) < p2) return true;
+    V3 A[RGBD360_HULL_MAX], B[RGBD360_HULL_MAX];
+    const int na = outline_points(a, A), nb = outline_points(b, B);
+    for (int i = 0; i < na; ++i) { const V3 d = sub(A[i], cb); if (dot(d, d) < p2) return true; }
+    for (int j = 0; j < nb; ++j) { const V3 d = sub(ca, B[j]); if (dot(d, d) < p2) return true; }
+    for (int i = 0; i < na; ++i)
+        for (int j = 0; j < nb; ++j) { const V3 d = sub(A[i], B[j]); if (dot(d, d) < p2) return true; }
+    for (int i = 0; i < na; ++i)
+        for (int j = 0; j < nb; ++j)
+            if (seg_seg_dist2(A[i], A[(i + 1) % na], B[j], B[(j + 1) % nb]) < p2) return true;
+    return false;
+}
+inline bool is_same_plane(const rgbd360_plane& a, const rgbd360_plane& b, const SensorPoolParams& P) {
+    const V3 na = v3(a.normal);
+    if (dot(na, v3(b.normal)) < P.cos_normal) return false;
+    if (fabs(dot(na, sub(center_of(b), center_of(a)))) > P.dist_normal) return false;
+    return is_plane_nearby(a, b, P.proximity);
+}
+inline std::vector<rgbd360_plane> pool_sensor_planes(const rgbd360_plane* in, int n, const SensorPoolParams& P) {
+    std::vector<rgbd360_plane> v;
+    for (int i = 0; i < n; ++i) {
+        const rgbd360_plane& pl = in[i];
+        if (!well_formed(pl) || pl.area < P.min_area || pl.elongation > P.max_elongation) continue;      // :1034, :1041
+        bool same = false;
+        if (pl.curvature < P.max_curvature)
+            for (size_t j = 0; j < v.size() && !same; ++j)
+                if (v[j].curvature < P.max_curvature && is_same_plane(v[j], pl, P)) {
+                    v[j] = pool_planes(v[j], pl);
+                    same = true;
+                }
+        if (!same) v.push_back(pl);
     }
     return v;
 }

@@ -2866,9 +2866,11 @@ static int cloud_planes_tail(rgbd360_ctx* ctx, int rows, int cols, float sigma_s
                 hh[i] += (double)Rt[12 + i];
             }
             double dd = -(nn[0] * cc[0] + nn[1] * cc[1] + nn[2] * cc[2]);
+            bool flipped = false;
             if (dd < 0) {                                            // keep the normal towards the new origin (Frame360.h:989-993)
                 for (int i = 0; i < 3; ++i) nn[i] = -nn[i];
                 dd = -dd;
+                flipped = true;
             }
             for (int i = 0; i < 3; ++i) {
                 P.normal[i] = (float)nn[i];
@@ -2877,11 +2879,18 @@ static int cloud_planes_tail(rgbd360_ctx* ctx, int rows, int cols, float sigma_s
                 P.center_hull[i] = (float)hh[i];
             }
             P.d = (float)dd;
-            for (int v = 0; v < P.hull_n && v < RGBD360_HULL_MAX; ++v) {      // the polygon travels with the plane (a rigid motion keeps its sense)
+            const int hn = std::min(P.hull_n, (int)RGBD360_HULL_MAX);
+            for (int v = 0; v < hn; ++v) {                           // the polygon travels with the plane
                 double q[3];
                 for (int i = 0; i < 3; ++i) q[i] = (double)Rt[0 * 4 + i] * P.hull[v][0] + (double)Rt[1 * 4 + i] * P.hull[v][1] + (double)Rt[2 * 4 + i] * P.hull[v][2] + (double)Rt[12 + i];
                 for (int i = 0; i < 3; ++i) P.hull[v][i] = (float)q[i];
             }
+            // a rigid motion keeps the polygon's sense about the MOVED normal; where the normal was turned round (the plane lies between the
+            // sensor's origin and the rig's) the header's promise -- counter-clockwise seen from the side the normal points to -- needs the
+            // vertex order reversed
+            if (flipped)
+                for (int a = 0, b = hn - 1; a < b; ++a, --b)
+                    for (int i = 0; i < 3; ++i) std::swap(P.hull[a][i], P.hull[b][i]);
         }
     }
     return 0;
@@ -3121,6 +3130,23 @@ extern "C" int rgbd360_group_planes(const rgbd360_plane* planes, const int* n_pe
         G.max_curvature = max_curvature; G.min_area = min_area; G.cos_normal = cos_normal; G.dist_d = dist_d;
         G.max_dist_hull = max_dist_hull; G.max_dist_parallel_hull = max_dist_parallel_hull;
         const std::vector<rgbd360_plane> v = pbm::group_planes(planes, n_per_sensor, n_sensors, G);
+        *n_out = (int)v.size();
+        if ((int)v.size() > max_out) return -1;
+        for (size_t i = 0; i < v.size(); ++i) out[i] = v[i];
+        return 0;
+    } catch (const std::exception&) {
+        return -1;
+    }
+}
+
+extern "C" int rgbd360_pool_sensor_planes(const rgbd360_plane* planes, int n, float max_curvature, float min_area, float max_elongation, float cos_normal,
+                                         float dist_normal, float proximity, rgbd360_plane* out, int max_out, int* n_out) {
+    if (n < 0 || (n > 0 && !planes) || !out || !n_out || max_out < 0) return -1;
+    try {
+        pbm::SensorPoolParams P;
+        P.max_curvature = max_curvature; P.min_area = min_area; P.max_elongation = max_elongation;
+        P.cos_normal = cos_normal; P.dist_normal = dist_normal; P.proximity = proximity;
+        const std::vector<rgbd360_plane> v = pbm::pool_sensor_planes(planes, n, P);
         *n_out = (int)v.size();
         if ((int)v.size() > max_out) return -1;
         for (size_t i = 0; i < v.size(); ++i) out[i] = v[i];

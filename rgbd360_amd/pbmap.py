@@ -107,6 +107,21 @@ def merge_planes(planes, max_curvature=0.0013, cos_normal=0.99, dist_d=0.45, pro
     return _planes_to_dicts(out, n.value)
 
 
+def pool_sensor_planes(planes, max_curvature=0.0013, min_area=0.12, max_elongation=6.0, cos_normal=0.99, dist_normal=0.05, proximity=0.2):
+    """rgbd360_pool_sensor_planes (the tail of Frame360::getPlanesSensor, Frame360.h:1034-1068): one sensor's regions -> local_planes_[sensor]:
+    small / narrow regions dropped, flat regions of one surface (isSamePlane(0.99, 0.05, 0.2)) pooled in input order."""
+    from .register import _planes_to_dicts
+    L = _lib.load()
+    arr = planes_to_array(planes)
+    out = (_lib.Plane * max(len(planes), 1))()
+    n = C.c_int(0)
+    rc = L.rgbd360_pool_sensor_planes(C.cast(arr, C.c_void_p), len(planes), max_curvature, min_area, max_elongation, cos_normal, dist_normal, proximity,
+                                      C.cast(out, C.c_void_p), len(planes), C.byref(n))
+    if rc != 0:
+        raise ValueError("rgbd360_pool_sensor_planes: bad arguments")
+    return _planes_to_dicts(out, n.value)
+
+
 def group_planes(planes_per_sensor, max_curvature=0.0013, min_area=0.5, cos_normal=0.99, dist_d=0.45, max_dist_hull=0.5, max_dist_parallel_hull=0.09):
     """rgbd360_group_planes (Frame360::groupPlanes, Frame360.h:741-833; defaults = the reference's constants): the plane lists of the rig's
     sensors (in the rig frame, sensor order) -> the frame's plane list, pieces of one surface seen by neighbouring sensors pooled."""

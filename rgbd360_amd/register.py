@@ -312,6 +312,15 @@ class RegisterPhotoICP:
     def getGradient(self) -> np.ndarray:          # RPI.h:285
         return np.asarray(list(self._res.gradient), dtype=np.float32)
 
+    def calcEntropy(self) -> float:               # RPI.h:4789-4797 (OdometryRGBD360.cpp:207)
+        """0.5 (6 (1 + ln 2 pi) + ln det H^-1) of the last alignment's Hessian; float64 log-determinant (the reference's float
+        determinant underflows for full-size Hessians), NaN when H is singular."""
+        import math
+        sign, logdet = np.linalg.slogdet(self.getHessian().astype(np.float64))
+        if sign <= 0:
+            return float("nan")
+        return float(0.5 * (6.0 * (1.0 + math.log(2 * 3.14159265359)) - logdet))      # PI: Miscellaneous.h:44
+
     # ---- stage-level access (tests / measurement)
     def level_dims(self, level: int):
         r, c = C.c_int(), C.c_int()

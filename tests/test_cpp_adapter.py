@@ -34,8 +34,8 @@ def test_odometry_replay_matches_python_host(tmp_path, hip_lib):
     exe = build_example(tmp_path)
     seq = tmp_path / "seq"
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "dump_sequence.py"), str(seq), "3", "256", "128"])
-    out = subprocess.check_output([exe, str(seq), "3", "256", "128"], text=True)
-    rows = [l.split() for l in out.strip().splitlines()]
+    run = subprocess.run([exe, str(seq), "3", "256", "128"], text=True, capture_output=True, check=True)
+    rows = [l.split() for l in run.stdout.strip().splitlines()]
     assert len(rows) == 2 and all(r[3] == "0" for r in rows)
     reg = RegisterPhotoICP()
     reg.setNumPyr(4)
@@ -44,6 +44,11 @@ def test_odometry_replay_matches_python_host(tmp_path, hip_lib):
     for j, r in enumerate(rows):
         rel_t = np.array([float(x) for x in r[7:10]])
         assert np.allclose(rel_t, poses[j][:3, 3], atol=2e-5)
+    # RegisterPhotoICP::calcEntropy (RPI.h:4789-4797) of the last pair, C++ adapter vs the Python mirror vs the formula on the Hessian
+    ent = [float(l.split()[2]) for l in run.stderr.splitlines() if l.startswith("entropy ")]
+    H = reg.getHessian().astype(np.float64)
+    want = 0.5 * (6 * (1 + np.log(2 * 3.14159265359)) + np.log(np.linalg.det(np.linalg.inv(H))))
+    assert len(ent) == 2 and abs(ent[1] - reg.calcEntropy()) < 1e-3 and abs(reg.calcEntropy() - want) < 1e-6 * max(1.0, abs(want)), (ent, reg.calcEntropy(), want)
     # the frame loop inside the library (RegisterPhotoICP::alignSequence -> rgbd360_align360_batch): the same lines
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "dump_sequence.py"), str(seq), "6", "256", "128"])
     pairwise = subprocess.check_output([exe, str(seq), "6", "256", "128"], text=True)
@@ -377,6 +382,8 @@ int main(int argc, char**) {
     Eigen::Matrix4f T = align360.getOptimalPose();
     Eigen::Matrix<double,6,6> info = align360.getHessian().cast<double>();
     Eigen::Matrix<float,6,1> g = align360.getGradient();
+    float entropy = align360.calcEntropy();                                // RPI.h:4789
+    (void)entropy;
     align360.downloadPyramids();
     align360.downloadLUT(0);
     Eigen::Matrix4f guess = Eigen::Matrix4f::Identity();

@@ -55,6 +55,13 @@ def test_depth_model_on_a_written_file(tmp_path):
     out = mo.undistort(z)
     assert np.allclose(out[0], [0.5, 1.0, 2.0 * 1.1, 3.0 * 1.2], rtol=1e-6) and np.allclose(out[1], [3.5 * 1.2, 4.5 * 2.0, 5.5 * 2.0, 9.0 * 2.0], rtol=1e-6)
     assert not out[2:].any()
+    # what is not a measurement passes through: +Inf lands in the last slice without a float -> int conversion out of range and stays
+    # +Inf; NaN, -Inf and negative values are left alone like zeros (`z > 0` is false for them)
+    z[2, :] = (np.inf, np.nan, -np.inf, -2.0)
+    z[3, :] = (1e30, 3.0e38, 0.0, 1.0)
+    out = mo.undistort(z)
+    assert out[2, 0] == np.inf and np.isnan(out[2, 1]) and out[2, 2] == -np.inf and out[2, 3] == -2.0
+    assert out[3, 0] == np.float32(1e30) * np.float32(2.0) and out[3, 1] == np.inf and out[3, 2] == 0.0 and out[3, 3] == 1.0
     # the model of the full-resolution sensor on half-size images (Calib360.h:116: downsampleParams(2))
     half = DepthModel(path, downsample=2)
     assert (half.width, half.height, half.bin_width, half.bin_height) == (W // 2, H // 2, bw // 2, bh // 2)

@@ -2124,3 +2124,24 @@ def test_nonfinite_float_depth_full_size_sequence_and_planes(hip_lib, oracle_mod
     labels, planes = oracle_mod.f360_plane_segment(xyz, out["normals"], 1024, 2048, 40, 0.03, 0.05, 0.001, 1)
     assert np.array_equal(np.asarray(out["labels"]).reshape(-1), np.asarray(labels).reshape(-1))
     assert [(p["root"], p["count"]) for p in out["planes"]] == [(p["root"], p["count"]) for p in planes] and len(planes) >= 6
+
+
+def test_hull_polygon_keeps_its_sense_when_the_rig_origin_lies_behind_the_plane(hip_lib):
+    """rgbd360_sensor_planes with an Rt that puts the rig's origin on the far side of the walls the sensor sees (t = 6 m along the optical
+    axis): every normal is turned round to face the new origin (Frame360.h:989-993) and the record's polygon must still run
+    counter-clockwise seen from the side the normal points to (include/rgbd360_hip.h) -- the vertex order is reversed with the normal."""
+    from rgbd360_amd.register import Frame360Stages
+    (_, dA), _, _, _ = synth.make_pinhole_pair(320, 240, seed=3)
+    st = Frame360Stages(_mk(hip_lib, 2))
+    near = st.sensor_planes(dA, 2, 0.3, 10.0, 10.0, 0.05, 0.02, 8.0, 40, 0.0398, 0.02, 0.0013, np.eye(4))
+    far = st.sensor_planes(dA, 2, 0.3, 10.0, 10.0, 0.05, 0.02, 8.0, 40, 0.0398, 0.02, 0.0013, synth.make_pose(np.eye(3), np.array([0.0, 0.0, -6.0])))
+    assert len(near) == len(far) >= 2
+    flipped = checked = 0
+    for a, b in zip(near, far):
+        assert (a["root"], a["count"]) == (b["root"], b["count"]) and b["d"] >= 0
+        if a["hull_points"] >= 3 and a["area"] > 0.05:      # (a sliver of a few cm2 at 3 m: its area is float32 rounding)
+            _check_hull_polygon(a)
+            _check_hull_polygon(b)
+            checked += 1
+        flipped += int(float(a["normal"] @ b["normal"]) < -0.99)
+    assert flipped >= 1 and checked >= 2

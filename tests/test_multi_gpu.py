@@ -183,3 +183,43 @@ def test_bench_under_torch_distributed_run_with_two_ranks(hip_lib):
         v = seq[variant]
         assert v["all_status_ok"] and v["repeated_pairs_bit_identical"] and v["alignments_per_s"] > 0, (variant, v)
         assert v["max_forward_backward_residual"] < 1e-3
+
+
+@pytest.mark.gpu
+def test_config3_at_its_stated_size_256_pairs_resident(hip_lib):
+    """BASELINE.json configs[3] at the size it names -- 256 consecutive 2048 x 1024 pairs -- through the entry bench.py's `native_multi`
+    block times: rgbd360_multi_load_sequence (257 frames, each its own 10.5 MB copy in HBM, like a recorded sequence) +
+    rgbd360_multi_align_resident (the lock-step engines, 32 pairs in flight, one device here).  The walk goes back and forth over 9
+    rendered frames, so the 256 pairs are 16 distinct (target, source) pairs: EVERY pose, status and iteration count of the run is
+    held against the pair-by-pair rgbd360_align360 of its pair, bit for bit; the walk composes to where it started."""
+    from rgbd360_amd.batch import compose_trajectory
+    from rgbd360_amd.multi import MultiGpuSequence
+    from rgbd360_amd.register import RegisterPhotoICP
+    from tests.test_gpu_parity import _pingpong
+    W, H, n_unique, n_pairs = 2048, 1024, 9, 256
+    uniq = [synth.render(synth.trajectory_pose(k, 7), W, H, 7) for k in range(n_unique)]
+    order = _pingpong(n_pairs, n_unique)
+    assert len(order) == 257 and len(set(zip(order[:-1], order[1:]))) == 16
+    one = RegisterPhotoICP()
+    one.setNumPyr(4)
+    pairwise = {}
+    for a, b in sorted(set(zip(order[:-1], order[1:]))):
+        one.setTargetFrame(*uniq[a])
+        one.setSourceFrame(*uniq[b])
+        rc = one.alignFrames360(np.eye(4), 2)
+        assert rc == 0
+        pairwise[(a, b)] = (one.getOptimalPose().copy(), list(one.num_iterations))
+    m = MultiGpuSequence(n_gpus=1, n_pyr=4)
+    m.load_sequence([uniq[k] for k in order])
+    poses, status, iters = m.align_resident(method=2, n_inflight=32)
+    m.close()
+    assert poses.shape == (256, 4, 4) and not status.any()
+    for j in range(n_pairs):
+        p, it = pairwise[(order[j], order[j + 1])]
+        assert list(iters[j])[:4] == it and np.array_equal(poses[j], p), (j, order[j], order[j + 1])
+    # size-independent property: 256 = 16 x 16 steps of the back-and-forth walk end on frame 0 again
+    assert order[-1] == 0
+    traj = compose_trajectory(poses)
+    rot, trans = synth.pose_error(traj[-1], np.eye(4))
+    print(f"256-pair walk, drift at the end: {rot:.2e} rad {trans:.2e} m")
+    assert rot < 2e-2 and trans < 0.1, (rot, trans)          # (128 there-and-back pairs of <= 2e-4 rad / 1e-3 m each, were they all biased one way)

@@ -601,3 +601,50 @@ def test_group_planes_pools_pieces_of_neighbouring_sensors():
     # getPlanes = groupPlanes then mergePlanes: the frame's list
     frame = pbmap.merge_planes(pbmap.group_planes([[a], [b], [c]] + [empty] * 5))
     assert len(frame) == 1 and frame[0]["count"] == 6000
+
+
+def test_pool_sensor_planes_is_the_tail_of_getPlanesSensor():
+    """rgbd360_pool_sensor_planes = Frame360.h:1034-1068: a region under min_area_plane (0.12 m2) or over max_elongation_plane (6) never
+    reaches local_planes_ (so groupPlanes' `area > 0.5 || curvature < max` gate, :764, never pools such a fragment into a neighbour's wall);
+    flat regions of one surface -- normals within 0.99, centres within 5 cm along the normal, outlines within 0.2 m -- are pooled into
+    the first kept plane in input order (isSamePlane(0.99, 0.05, 0.2) + mergePlane2); a parallel patch 8 cm behind, a co-planar patch
+    0.5 m away and a curved region stay on their own."""
+    e1, e2, org = np.array([1.0, 0, 0]), np.array([0, 1.0, 0]), np.array([0.0, 0, 2.5])
+    sq = lambda x0, y0, w, h: [(x0, y0), (x0 + w, y0), (x0 + w, y0 + h), (x0, y0 + h)]
+    wall_a = _poly_plane(sq(-1.0, -0.5, 1.0, 1.0), org, e1, e2, 2000, 10)
+    wall_b = _poly_plane(sq(0.1, -0.5, 1.0, 1.0), org, e1, e2, 2000, 20)                  # same surface, outlines 0.1 m apart
+    behind = _poly_plane(sq(0.1, -0.5, 1.0, 1.0), org + np.array([0, 0, 0.08]), e1, e2, 2000, 30)      # parallel, 8 cm behind
+    away = _poly_plane(sq(1.6, -0.5, 1.0, 1.0), org, e1, e2, 2000, 40)                    # co-planar, 0.5 m beyond wall_b
+    tiny = _poly_plane(sq(-1.0, 0.6, 0.3, 0.3), org, e1, e2, 90, 50)                      # 0.09 m2
+    strip = _poly_plane(sq(-1.0, -0.9, 2.0, 0.2), org, e1, e2, 400, 60)                   # elongation 10
+    curved = dict(_poly_plane(sq(-1.0, -0.5, 1.0, 1.0), org, e1, e2, 2000, 70), curvature=np.float32(0.01))
+    got = pbmap.pool_sensor_planes([wall_a, tiny, wall_b, strip, behind, away, curved])
+    assert [p["root"] for p in got] == [10, 30, 40, 70]
+    m = got[0]
+    assert m["count"] == 4000 and abs(m["area"] - 2.1) < 0.01                              # the hull of both squares
+    assert float(m["normal"] @ wall_a["normal"]) > 1 - 1e-6 and abs(m["d"] - wall_a["d"]) < 1e-5
+    assert all(p["area"] >= 0.12 and p["elongation"] <= 6.0 for p in got)
+    # order matters as in the source: the incoming region is pooled into the FIRST kept plane that accepts it
+    c = _poly_plane(sq(1.15, -0.5, 0.4, 1.0), org, e1, e2, 800, 80)                       # bridges wall_b and `away` (0.05 m / 0.05 m)
+    got = pbmap.pool_sensor_planes([wall_b, away, c])
+    assert [p["root"] for p in got] == [20, 40] and got[0]["count"] == 2800
+    got = pbmap.pool_sensor_planes([away, wall_b, c])
+    assert [p["root"] for p in got] == [40, 20] and got[0]["count"] == 2800
+    # records without a polygon: the moment rectangle stands in for the outline
+    bare = [_poly_plane(sq(-1.0, -0.5, 1.0, 1.0), org, e1, e2, 2000, 10, with_hull=False), _poly_plane(sq(0.1, -0.5, 1.0, 1.0), org, e1, e2, 2000, 20, with_hull=False)]
+    assert len(pbmap.pool_sensor_planes(bare)) == 1
+    assert pbmap.pool_sensor_planes([]) == []
+
+
+def test_merge_planes_has_no_containment_test():
+    """Frame360::mergePlanes / groupPlanes test proximity vertex against vertex and edge against edge only (Frame360.h:680-711, 788-815): a
+    panel inside a wall's hull, parallel to it and within normal_offset, but farther than `proximity` from the wall's OUTLINE, stays a
+    plane of its own (round 5 merged it through a point-in-polygon test the reference does not have)."""
+    e1, e2, org = np.array([1.0, 0, 0]), np.array([0, 1.0, 0]), np.array([0.0, 0, 2.5])
+    sq = lambda x0, y0, w, h: [(x0, y0), (x0 + w, y0), (x0 + w, y0 + h), (x0, y0 + h)]
+    wall = _poly_plane(sq(-2.0, -1.5, 4.0, 3.0), org, e1, e2, 8000, 10)
+    panel = _poly_plane(sq(-0.4, -0.4, 0.8, 0.8), org + np.array([0, 0, -0.04]), e1, e2, 1500, 20)    # 4 cm in front, 1.1 m from every edge
+    assert len(pbmap.merge_planes([wall, panel])) == 2
+    assert len(pbmap.group_planes([[wall], [panel]])) == 2
+    near = _poly_plane(sq(1.75, -0.4, 0.8, 0.8), org + np.array([0, 0, -0.04]), e1, e2, 1500, 30)      # the same panel at the wall's edge
+    assert len(pbmap.merge_planes([wall, near])) == 1

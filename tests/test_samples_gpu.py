@@ -188,6 +188,7 @@ def test_sample_pair_plane_chain_equals_the_oracle_chain(hip_lib, oracle_mod, sa
     groupPlanes + mergePlanes on the device planes (Frame360.h:615-639) pool the pieces and keep the verdict."""
     from rgbd360_amd import pbmap
     from rgbd360_amd.register import Frame360Stages, RegisterPhotoICP
+    from tests.test_gpu_parity import _check_hull_polygon
     st = Frame360Stages(RegisterPhotoICP())
     dev, ora = [], []
     worst_d, worst_n = {False: 0.0, True: 0.0}, {False: 0.0, True: 0.0}
@@ -208,6 +209,9 @@ def test_sample_pair_plane_chain_equals_the_oracle_chain(hip_lib, oracle_mod, sa
                 if b["curvature"] > 1e-9:
                     worst_n[sliver] = max(worst_n[sliver], 1.0 - float(a["normal"].astype(np.float64) @ b["normal"].astype(np.float64)))
                 assert abs(a["area_moment"] - b["area"]) <= 1e-3 * max(b["area"], 0.1)
+            for a in got:
+                if a["hull_points"] >= 3 and a["area"] > 0.05:
+                    _check_hull_polygon(a)
             per_sensor_dev.append(got)
             flat_ora += want
         dev.append(per_sensor_dev)
@@ -227,8 +231,12 @@ def test_sample_pair_plane_chain_equals_the_oracle_chain(hip_lib, oracle_mod, sa
     matched = [flat_dev[0][i] for i in r_dev["match"]]
     assert len([p for p in matched if abs(p["normal"][0]) > 0.95]) >= 6        # x is up in the rig frame: floor / ceiling pieces
     assert len([p for p in matched if abs(p["normal"][0]) < 0.3]) >= 3         # wall pieces
-    # Frame360::getPlanes = groupPlanes + mergePlanes: pieces of one surface seen by neighbouring sensors become single planes
-    frames = [pbmap.merge_planes(pbmap.group_planes(f)) for f in dev]
+    # Frame360::getPlanes = per sensor the tail of getPlanesSensor (Frame360.h:1034-1068: small / narrow regions never stored, regions of
+    # one surface pooled), then groupPlanes + mergePlanes: pieces of one surface seen by neighbouring sensors become single planes
+    pooled = [[pbmap.pool_sensor_planes(lst) for lst in f] for f in dev]
+    assert all(p["area"] >= 0.12 and p["elongation"] <= 6.0 for f in pooled for lst in f for p in lst)
+    assert sum(len(lst) for f in pooled for lst in f) < sum(len(f) for f in flat_dev)
+    frames = [pbmap.merge_planes(pbmap.group_planes(f)) for f in pooled]
     assert all(3 <= len(m) < len(f) for m, f in zip(frames, flat_dev))
     rm = pbmap.register_planes(frames[0], frames[1], 25, pbmap.ODOMETRY_6DoF, params)
     print("planes per frame", [len(f) for f in flat_dev], "after getPlanes", [len(m) for m in frames], "matched", len(r_dev["match"]), len(rm["match"]),
