@@ -8,7 +8,7 @@ Step      = one level-0 Gauss-Newton iteration of RegisterPhotoICP::alignFrames3
             spherical pair (BASELINE.json configs[1]: photometric-only), in the forced schedule of BASELINE.md §2
             (accept rule evaluated, step applied regardless): one fused warp+residual+Jacobian pass over every
             source pixel + the 6x6 solve / pose update.  Since round 3 that is ONE launch per iteration (k_eval_fs: the solve of
-            the previous pass is the prologue of the next pass's launch; RGBD360_FUSED_SOLVE=0 restores {k_eval, k_solve}).
+            the previous pass is the prologue of the next pass's launch; the two-launch schedule {k_eval, k_solve} is a test hook, rgbd360_debug_set_schedule).
             Frames are resident in HBM before the timed region.
 value     = N * K / t, t = the MEDIAN over `--repeats` timed regions of exactly K steps each (every region bracketed by a
             barrier + device synchronisation on both sides, the maximum over the ranks taken per region): with the driver's
@@ -83,7 +83,7 @@ def live_traffic(W, H, method):
     if shutil.which("rocprofv3") is None:
         return None, "not collected live: rocprofv3 is not on PATH"
     # the full instantiation name of the level's source form (", 0>" = 16-byte records), so that e.g. the recompute instantiation "<0, 1>" is not averaged in
-    want = "k_eval_fs<%d, 0>" % method if os.environ.get("RGBD360_FUSED_SOLVE", "1") != "0" else "k_eval<%d, true, 0>" % method
+    want = "k_eval_fs<%d, 0>" % method
     vals = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="rgbd360_pmc_", dir="/tmp")
@@ -132,6 +132,45 @@ def roofline_entry(us, batches, n_px, method, kernel=None, engine=False, **extra
          "frac_of_measured_copy_peak": ach / HBM_COPY_GBS}
     d.update(extra)
     return d
+
+
+# algorithmic bytes per pixel of the Frame360 stages (one frame, every pixel counted)
+F360_STAGE_BYTES = {"a13_sphere_cloud": 2 + 12,        # u16 range in, xyz out
+                    "a14_normal_map": 12 + 12,         # xyz in, normals out
+                    "a15_plane_stage": 12 + 4}         # xyz + label per pixel of the moment pass
+
+
+def frame360_roofline(torch, Frame360Stages, RegisterPhotoICP, device, depth_u16, reps=12):
+    """HIP-event times of the three Frame360 stages of ONE rgbd360_frame_planes_dev call (depth already in HBM, events on the
+    library's stream at the stage boundaries: rgbd360_frame_planes_stage_timing), median over `reps` calls, against SURVEY.md 8d's bytes."""
+    H, W = depth_u16.shape
+    st = Frame360Stages(RegisterPhotoICP(device=device))
+    d_dev = torch.from_numpy(depth_u16.astype(np.int16)).to("cuda:%d" % device)       # (same bits as the uint16 image)
+    kw = dict(depth_type=0, convention=2, angular_threshold=0.03, min_inliers=40, max_curvature=0.0013, max_planes=4096)      # tools/prof_frame360.py's call
+    out = st.frame_planes_dev(d_dev.data_ptr(), H, W, **kw)                             # warm: allocations, tables
+    st.stage_timing(True)
+    rows, calls = [], []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        out = st.frame_planes_dev(d_dev.data_ptr(), H, W, **kw)
+        calls.append(time.perf_counter() - t0)
+        rows.append(st.stage_times())
+    st.stage_timing(False)
+    med = [sorted(r[k] for r in rows)[len(rows) // 2] for k in range(3)]
+    n = W * H
+    stages = {}
+    for (name, bpp), us in zip(F360_STAGE_BYTES.items(), med):
+        ach = bpp * n / (us * 1e-6) / 1e9
+        stages[name] = {"us": us, "bytes_per_pixel": bpp, "algorithmic_bytes": bpp * n, "achieved": ach, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
+    tot_b = sum(F360_STAGE_BYTES.values()) * n
+    tot_us = sum(med)
+    return {"width": W, "height": H, "planes": len(out["planes"]), "stages": stages,
+            "chain": {"us": tot_us, "algorithmic_bytes": tot_b, "achieved": tot_b / (tot_us * 1e-6) / 1e9, "unit": "GB/s",
+                      "frac": tot_b / (tot_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "peak": HBM_PEAK_GBS},
+            "call_ms_median": sorted(calls)[len(calls) // 2] * 1e3,
+            "kernels": {"a13_sphere_cloud": "k_f360_edge_bits<true> (forms the cloud, writes it and the depth-change mask)",
+                        "a14_normal_map": "k_f360_distmap, k_f360_normals_sweep<8>, k_f360_normals_tiled",
+                        "a15_plane_stage": "k_f360_link_flags ... k_f360_hull_pack (labels, counts, slots, moments, hull extremes; refinement off)"}}
 
 
 def pingpong(n_pairs, n_unique):
@@ -302,7 +341,8 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "RGBD360_FUSED_SOLVE": os.environ.get("RGBD360_FUSED_SOLVE", "1 (default)")},
+        "env": {k: os.environ.get(k) for k in ("GPU_MAX_HW_QUEUES", "RGBD360_HOST_SPIN_US", "RGBD360_RECOMPUTE_MIN_PX", "RGBD360_SEQ_RECOMPUTE_MIN_PX",
+                                                "RGBD360_SEQ_ENGINES", "RGBD360_FORCE_RCCL")},      # the six runtime knobs of a product build (csrc/knobs.h)
         "sustained": sustained,
         "rccl_ranks_seen": rccl_ranks_seen,
         "salient_fraction": salient_fraction,
@@ -335,7 +375,7 @@ def main():
     if rank == 0:
         # ---- roofline of the dominant kernel: HIP events on the library's stream -----------------------------
         ws = WORKING_SET_PER_PX[method] * n_px
-        fused = os.environ.get("RGBD360_FUSED_SOLVE", "1") != "0"
+        fused = True          # (the two-launch schedule is a test hook since round 6: rgbd360_debug_set_schedule)
         kernel_us, kernel_batches = avg_kernel_us(lambda: reg.time_eval_kernel(0, pose_gpu, method, True, 50))       # the pass alone
         fused_us, fused_batches = (avg_kernel_us(lambda: reg.time_eval_kernel(0, pose_gpu, method, 2, 50)) if fused else (None, None))
         traffic, traffic_source = None, None
@@ -476,6 +516,17 @@ def main():
                     roofline_entry(us, bt, 4096 * 2048, m, resident="infinity_cache" if ws4 < LLC_BYTES else "hbm", working_set_bytes=ws4),
                     gn_iterations_per_s=100 / (it["elapsed_ms"] * 1e-3))
             reg4.close()
+            # ---- rows a13-a15 (Frame360 cloud / normal map / plane stage; the other half of configs[4]) at both sizes ----
+            from rgbd360_amd.register import Frame360Stages
+            try:
+                result["roofline_frame360"] = {
+                    "2048x1024": frame360_roofline(torch, Frame360Stages, RegisterPhotoICP, local_rank, dA),
+                    "4096x2048": frame360_roofline(torch, Frame360Stages, RegisterPhotoICP, local_rank, d4),
+                    "note": ("one rgbd360_frame_planes_dev call per repetition on a range panorama resident in HBM (the synthetic room); per stage: "
+                             "SURVEY.md 8d's bytes per pixel x pixels / the stage's time between HIP events on the library's stream / 8 TB/s; "
+                             "kernel-by-kernel times and counters: profiles/r06_frame360_*")}
+            except Exception as e:      # (a measurement block must not cost the line)
+                result["roofline_frame360"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
 
         # ---- the single-process multi-GPU entry (rgbd360_multi_*: host thread per device + ncclAllGather), in a child process
         #      so that nothing it does can cost the bench line ----

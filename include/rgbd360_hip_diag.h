@@ -58,6 +58,24 @@ int rgbd360_time_solve_kernel(rgbd360_ctx* ctx, int level, int mode, int reps, f
  * with the compiler's IEEE sqrtf and 1.f/x for the `count` float bit patterns starting at `first_bits`;
  * mismatches[0] = sqrt, mismatches[1] = reciprocal, mismatches[2] = the round-half-up float->int conversion
  * against floor((double)x + 0.5) for |x| < 1e9 (both signs). */
+/* Test hooks: the alternative schedules the parity tests hold against the default ones (poses, iteration counts and status must be
+ * bit-identical).  fused_solve 0: every Gauss-Newton iteration as a {k_eval, k_solve} launch pair instead of one k_eval_fs launch;
+ * fused_occ 0: the occlusion-aware iterations as {k_occ_build, k_eval_occ, k_solve} triples.  Not while an alignment is in flight. */
+int rgbd360_debug_set_schedule(rgbd360_ctx* ctx, int fused_solve, int fused_occ);
+/* route 1: rgbd360_align360_batch runs every sequence over the per-context route (one context per sub-chunk of pairs; what the
+ * occlusion-aware sequences always use) with at most max_contexts contexts (0: the default cap); route 0: the lock-step engines. */
+int rgbd360_debug_set_sequence_route(rgbd360_ctx* ctx, int route, int max_contexts);
+/* 1 when the library was built with -DRGBD360_DEBUG_KNOBS (csrc/knobs.h: it then reads the A/B environment variables of the measurement tools) */
+int rgbd360_debug_knobs_enabled(void);
+
+/* Stage times of rgbd360_frame_planes[_dev], measured with HIP events ON THE CONTEXT'S STREAM at the stage
+ * boundaries: us[0] the kernel that forms the organised cloud (and the depth-change mask) = a13, us[1] distance map + normal map = a14,
+ * us[2] plane stage (link flags ... hull records, colour when an image is registered) = a15.  _stage_timing(ctx, 1) arms the context's
+ * later calls (four event records per call), _stage_times reads the last call's.  With the refinement on, a15 ends at the last kernel in
+ * front of the refinement (the refinement synchronises with the host).  bench.py's `roofline_frame360` block. */
+int rgbd360_frame_planes_stage_timing(rgbd360_ctx* ctx, int on);
+int rgbd360_frame_planes_stage_times(rgbd360_ctx* ctx, float us[3]);
+
 int rgbd360_selftest_math(rgbd360_ctx* ctx, uint32_t first_bits, uint32_t count, unsigned long long mismatches[3]);
 
 #ifdef __cplusplus

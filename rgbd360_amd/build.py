@@ -103,11 +103,14 @@ def compile_library(out: str, extra_flags=(), verbose: bool = False, selects_vop
     return out
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, debug_knobs: bool = False) -> str:
+    """debug_knobs: -DRGBD360_DEBUG_KNOBS, the library then reads the A/B environment variables of the measurement tools (csrc/knobs.h)."""
     if force or needs_build():
-        compile_library(LIB, verbose=verbose, selects_vop3=os.environ.get("RGBD360_BUILD_SELECTS_VOP3", "0") == "1")
+        compile_library(LIB, extra_flags=["-DRGBD360_DEBUG_KNOBS"] if debug_knobs else (), verbose=verbose,
+                        selects_vop3=os.environ.get("RGBD360_BUILD_SELECTS_VOP3", "0") == "1")
     return LIB
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+    print(build(force=True, verbose=True, debug_knobs="--debug-knobs" in sys.argv))

@@ -1133,16 +1133,7 @@ __global__ void k_f360_ccl_merge_level(const uint8_t* __restrict__ flags, int ro
 // Pass 4: only the first pixel of a run can be (or become) a root, and every other pixel still points at the first pixel of
 // its run: the pointer chase runs over the run starts only (a few per cent of the pixels); their region counters are
 // cleared on the way (no memset of the 8 B/px table).
-__global__ void k_f360_ccl_roots(const uint8_t* __restrict__ flags, int n, int* __restrict__ label, unsigned long long* __restrict__ count) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int fl = flags[i];
-    if ((fl & 1) && !(fl & 2)) {
-        label[i] = uf_find(label, i);
-        count[i] = 0ull;
-    }
-}
-// The same over the compact lists k_f360_ccl_runs left: one thread per run start, a block per image row.  (One thread per PIXEL reading
+// Over the compact lists k_f360_ccl_runs left: one thread per run start, a block per image row.  (One thread per PIXEL reading
 // its flag byte made 32 k waves whose only load was a 64-byte line, and the chases -- up to nine dependent hops -- started behind it:
 // 17-20 us at 2048 x 1024.)
 constexpr int kRootsThreads = 1024;     // (256 until round 4: a border row without normals is one run start per pixel, i.e. cols / 256 dependent rounds of pointer chases)
@@ -1293,29 +1284,8 @@ __global__ __launch_bounds__(kAggThreads) void k_f360_finish_count(const uint8_t
     if (threadIdx.x < kCntHash && keys[threadIdx.x] >= 0) atomicAdd(&count[keys[threadIdx.x]], (unsigned long long)vals[threadIdx.x]);
 }
 
-// compaction: roots of regions with more than min_inliers points get a slot (order fixed later on the host)
-__global__ void k_f360_assign(const int* __restrict__ label, const unsigned long long* __restrict__ count, int n, int min_inliers,
-                              int max_slots, int* __restrict__ slot_of_root, int* __restrict__ root_of_slot, int* __restrict__ count_of_slot,
-                              int* __restrict__ n_slots, unsigned long long* __restrict__ mom, int mom_replicas) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (label[i] != i) return;               // slot_of_root is only ever read at roots: no memset of the table
-    int slot = -1;
-    if (count[i] > (unsigned long long)min_inliers) {
-        const int s = atomicAdd(n_slots, 1);
-        if (s < max_slots) {
-            slot = s;
-            root_of_slot[s] = i;
-            count_of_slot[s] = (int)count[i];
-            // the moment rows of this slot start at zero: no memset of the 16 x 4096 x 9 table, only the slots in use are touched
-            for (int r = 0; r < mom_replicas; ++r)
-                for (int q = 0; q < 9; ++q) mom[((size_t)r * max_slots + s) * 9 + q] = 0ull;
-        }
-    }
-    slot_of_root[i] = slot;
-}
-
-// The same over the compact run-start lists of k_f360_ccl_runs (a root is a run start): one thread per run start, a block per image row,
+// compaction: roots of regions with more than min_inliers points get a slot (order fixed later on the host).
+// Over the compact run-start lists of k_f360_ccl_runs (a root is a run start): one thread per run start, a block per image row,
 // instead of one thread per PIXEL reading its label to find out that it is not a root (14.5 us at 4096 x 2048 for ~10 k roots).
 constexpr int kAssignThreads = 1024;      // a border row without normals is one run start per pixel: its list is walked in cols / 1024 dependent rounds
 __global__ __launch_bounds__(kAssignThreads) void k_f360_assign_list(const int* __restrict__ starts, const int* __restrict__ nstarts, int cols,

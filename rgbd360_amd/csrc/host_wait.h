@@ -5,6 +5,7 @@
 // per Levenberg-Marquardt evaluation of the pinhole and rig registrations, one per alignment of the spherical one).
 // The spin is bounded: after kSpinBudgetUs (2 ms: every alignment of the bench sizes ends sooner) the host falls back to hipStreamSynchronize.
 #pragma once
+#include "knobs.h"
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -19,7 +20,7 @@ constexpr double kSpinBudgetUs = 2000.0;
 // cannot spare a busy core per waiting thread would want)
 inline double spin_budget_us() {
     static const double v = [] {
-        const char* e = getenv("RGBD360_HOST_SPIN_US");
+        const char* e = knobs::product("RGBD360_HOST_SPIN_US");
         return e ? atof(e) : kSpinBudgetUs;
     }();
     return v;

@@ -233,7 +233,7 @@ int rgbd360_multi_create(const rgbd360_params* p, int n_gpus, const int* device_
         if (rc) { rgbd360_multi_destroy(m); return rc; }
         m->ctx.push_back(c);
     }
-    const char* force = getenv("RGBD360_FORCE_RCCL");          // exercise the exchange on a 1-GPU box
+    const char* force = knobs::product("RGBD360_FORCE_RCCL");          // exercise the exchange on a 1-GPU box
     m->use_rccl = n_gpus > 1 || (force && atoi(force) != 0);
     if (m->use_rccl) {
         m->comm.assign(n_gpus, nullptr);

@@ -2233,40 +2233,9 @@ __device__ __forceinline__ void sphere_point(int convention, float d, float sp, 
     }
 }
 
-// A thread owns 4 consecutive pixels of a row: 12 consecutive floats of the cloud leave as three 16-byte stores (12-byte
-// strided dword stores before).  Needs cols % 4 == 0 and 16-byte aligned rows; k_sphere_cloud is the general form.
-__global__ void k_sphere_cloud_x4(const void* __restrict__ depth, size_t step, int depth_type, int rows, int cols,
-                                  int convention, const float* __restrict__ sin_theta, const float* __restrict__ cos_theta,
-                                  const float* __restrict__ sin_phi, const float* __restrict__ cos_phi,
-                                  float* __restrict__ xyz) {
-    const int c = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    const int r = blockIdx.y;
-    if (c >= cols || r >= rows) return;
-    const uint8_t* row = (const uint8_t*)depth + (size_t)r * step;
-    float d[4];
-    if (depth_type == 0) {
-        const uint2 w = *reinterpret_cast<const uint2*>((const uint16_t*)row + c);
-        d[0] = 0.001f * (float)(w.x & 0xFFFFu); d[1] = 0.001f * (float)(w.x >> 16);
-        d[2] = 0.001f * (float)(w.y & 0xFFFFu); d[3] = 0.001f * (float)(w.y >> 16);
-    } else {
-        const float4 w = *reinterpret_cast<const float4*>((const float*)row + c);
-        d[0] = w.x; d[1] = w.y; d[2] = w.z; d[3] = w.w;
-    }
-    const float4 st4 = *reinterpret_cast<const float4*>(sin_theta + c), ct4 = *reinterpret_cast<const float4*>(cos_theta + c);
-    const float st[4] = {st4.x, st4.y, st4.z, st4.w}, ct[4] = {ct4.x, ct4.y, ct4.z, ct4.w};
-    const float sp = sin_phi[r], cp = cos_phi[r];
-    float o[12];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) sphere_point(convention, d[k], sp, cp, st[k], ct[k], o[3 * k], o[3 * k + 1], o[3 * k + 2]);
-    float4* out = reinterpret_cast<float4*>(xyz + 3 * ((size_t)r * cols + c));
-    out[0] = make_float4(o[0], o[1], o[2], o[3]);
-    out[1] = make_float4(o[4], o[5], o[6], o[7]);
-    out[2] = make_float4(o[8], o[9], o[10], o[11]);
-}
-
-// Round 2: consecutive lanes own consecutive pixels and every lane stores its 12-byte point with ONE instruction (768 contiguous
-// bytes per wave instruction); a thread covers four pixels 256 apart.  The x4 form above makes every store instruction drop 16 bytes
-// per lane into a different 64-byte segment (48-byte lane stride): 15 us at 2048 x 1024 = 1.9 TB/s for a pure streaming kernel.
+// Consecutive lanes own consecutive pixels and every lane stores its 12-byte point with ONE instruction (768 contiguous bytes per
+// wave instruction); a thread covers four pixels 256 apart.  (Round 1's form -- a thread owning four consecutive pixels, three 16-byte
+// stores with a 48-byte lane stride, 15 us at 2048 x 1024 = 1.9 TB/s -- and the one-pixel-per-thread form were deleted in round 6.)
 typedef float float3s __attribute__((ext_vector_type(3)));
 __global__ __launch_bounds__(256) void k_sphere_cloud_s4(const void* __restrict__ depth, size_t step, int depth_type, int rows, int cols,
                                                          int convention, const float* __restrict__ sin_theta,
@@ -2296,21 +2265,5 @@ __global__ __launch_bounds__(256) void k_sphere_cloud_s4(const void* __restrict_
     }
 }
 
-__global__ void k_sphere_cloud(const void* __restrict__ depth, size_t step, int depth_type, int rows, int cols,
-                               int convention, const float* __restrict__ sin_theta, const float* __restrict__ cos_theta,
-                               const float* __restrict__ sin_phi, const float* __restrict__ cos_phi,
-                               float* __restrict__ xyz) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    const int r = blockIdx.y;
-    if (c >= cols || r >= rows) return;
-    const uint8_t* row = (const uint8_t*)depth + (size_t)r * step;
-    float d;
-    if (depth_type == 0) d = 0.001f * (float)((const uint16_t*)row)[c];
-    else d = ((const float*)row)[c];
-    float x, y, z;
-    sphere_point(convention, d, sin_phi[r], cos_phi[r], sin_theta[c], cos_theta[c], x, y, z);
-    float* o = xyz + 3 * ((size_t)r * cols + c);
-    o[0] = x; o[1] = y; o[2] = z;
-}
 
 }  // namespace r360

@@ -23,6 +23,7 @@
 #include "../../include/rgbd360_hip.h"
 #include "../../include/rgbd360_hip_diag.h"
 #include "depth_model.h"
+#include "knobs.h"
 #include "host_wait.h"
 #include "photo_icp_kernels.h"
 #include "occlusion_kernels.h"
@@ -68,6 +69,8 @@ struct rgbd360_ctx {
     double* d_partials_alt = nullptr; // ... and where a fused pass puts its rows while its blocks still read the previous table
     int max_blocks = 0;               // rows of a partial table = blocks of the largest level
     bool fused_occ = true;            // the occlusion-aware alignments on the fused schedule too (RGBD360_FUSED_OCC=0: {build, pass, k_solve} triples, A/B)
+    bool seq_route_contexts = false;  // rgbd360_debug_set_sequence_route: every sequence over the per-context route (the occlusion-aware ones always are)
+    int seq_route_cap = 0;            // ... with this many contexts at most (0: ctx_route_cap())
     bool fused_solve = true;          // single-pair schedule: solve in the prologue of the next pass (RGBD360_FUSED_SOLVE=0: {k_eval, k_solve} pairs, A/B)
     GnIO* d_gnio = nullptr;
     // upload staging: slot 0 serves the single-frame entries (copies on `stream`); the sequence entry alternates both slots,
@@ -118,6 +121,10 @@ struct rgbd360_ctx {
     size_t f_tab_n = 0;
     int f_tab_rows = 0, f_tab_cols = 0, f_tab_conv = -1;      // what the resident angle tables were built for
     uint8_t* f_depth_raw = nullptr;
+    // measurement (rgbd360_frame_planes_stage_timing): events on `stream` at the stage boundaries of a frame_planes call -- before the
+    // cloud / depth-edge kernel, behind it (row a13), behind the normal map (a14), behind the last kernel of the plane stage (a15)
+    hipEvent_t f_stage_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool f_stage_timing = false, f_stage_valid = false;
     int f_planes_available = 0;     // regions that passed every filter in the last plane call (may exceed the caller's max_planes)
     int f_refine = 0;               // segmentAndRefine's refinement after `segment` (rgbd360_set_plane_refinement)
     float f_refine_dist = 0.02f;    // PlaneRefinementComparator's default distance threshold
@@ -145,7 +152,6 @@ struct rgbd360_ctx {
     size_t occ_n = 0;
     int max_eval_blocks = 256;    // grid cap of the fused pass (tuning knob: RGBD360_EVAL_BLOCKS)
     unsigned char* arena = nullptr;   // ONE allocation behind every per-level buffer of the context (planes, records, angle tables)
-    bool use_arena = true;            // RGBD360_ARENA=0: one hipMalloc per buffer (A/B)
     std::string err;
 };
 
@@ -176,11 +182,6 @@ void pin_occ_free(rgbd360_ctx* ctx) {
 
 void free_levels(rgbd360_ctx* ctx) {
     for (Level& L : ctx->levels) {
-        if (!ctx->arena) {
-            hipFree(L.graySrc); hipFree(L.depthSrc); hipFree(L.grayTrg); hipFree(L.depthTrg);
-            hipFree(L.srcRec); hipFree(L.trgP); hipFree(L.trgD);
-            hipFree(L.sinT); hipFree(L.cosT); hipFree(L.sinP); hipFree(L.cosP); hipFree(L.tabT); hipFree(L.tabP);
-        }
         hipFree(L.srcRecPin);
     }
     pin_occ_free(ctx);
@@ -202,7 +203,7 @@ int ensure_levels(rgbd360_ctx* ctx, int rows, int cols) {
     free_levels(ctx);
     ctx->levels.resize(ctx->p.n_pyr);
     size_t arena_off = 0;
-    if (ctx->use_arena) {
+    {
         size_t total = 0;
         for (int l = 0, rr = rows, cc = cols; l < ctx->p.n_pyr; ++l, rr /= 2, cc /= 2) {
             const size_t n = (size_t)rr * cc;
@@ -224,10 +225,6 @@ int ensure_levels(rgbd360_ctx* ctx, int rows, int cols) {
         // 2048 x 1024, and one large range keeps its pages' translations together (fewer, larger fragments) instead of scattering
         // ~45 small allocations over the address space
         auto take = [&](size_t bytes) -> void* {
-            if (!ctx->use_arena) {
-                void* q = nullptr;
-                return hipMalloc(&q, bytes) == hipSuccess ? q : nullptr;
-            }
             void* q = ctx->arena + arena_off;
             arena_off += (bytes + 255) & ~(size_t)255;
             return q;
@@ -301,7 +298,7 @@ LevelDev level_dev(const Level& L) {
 // working set (40 B/px) does not fit the 256 MiB Infinity Cache next to anything else, i.e. 4096 x 2048 and up; RGBD360_RECOMPUTE_MIN_PX
 // moves the bound (0 = every level, for A/B runs and tests).
 int recompute_min_px() {
-    static const int v = [] { const char* e = getenv("RGBD360_RECOMPUTE_MIN_PX"); return e ? atoi(e) : 4 * 1024 * 1024; }();
+    static const int v = [] { const char* e = knobs::product("RGBD360_RECOMPUTE_MIN_PX"); return e ? atoi(e) : 4 * 1024 * 1024; }();
     return v;
 }
 
@@ -691,33 +688,30 @@ int rgbd360_create(const rgbd360_params* p, rgbd360_ctx** out) {
     if (hipSetDevice(p->device) != hipSuccess) return -102;
     rgbd360_ctx* ctx = new rgbd360_ctx();
     ctx->p = *p;
-    if (const char* e = getenv("RGBD360_EVAL_BLOCKS")) {
+    if (const char* e = knobs::debug("RGBD360_EVAL_BLOCKS")) {
         const int v = atoi(e);
         if (v >= 8 && v <= 8192) ctx->max_eval_blocks = v;
     }
-    if (const char* e = getenv("RGBD360_POLL_CHUNK")) {
+    if (const char* e = knobs::debug("RGBD360_POLL_CHUNK")) {
         const int v = atoi(e);
         if (v >= 1 && v <= 16) ctx->poll_chunk = v;
     }
-    if (const char* e = getenv("RGBD360_FIRST_CHUNK")) {
+    if (const char* e = knobs::debug("RGBD360_FIRST_CHUNK")) {
         const int v = atoi(e);
         if (v >= 1 && v <= 16) ctx->first_chunk_top = v;
     }
-    if (const char* e = getenv("RGBD360_L0_CHUNK")) {
+    if (const char* e = knobs::debug("RGBD360_L0_CHUNK")) {
         const int v = atoi(e);
         if (v >= 1 && v <= 16) ctx->chunk_level0 = v;
     }
-    if (const char* e = getenv("RGBD360_ADAPTIVE_CHUNKS")) {
+    if (const char* e = knobs::debug("RGBD360_ADAPTIVE_CHUNKS")) {
         ctx->adaptive_chunks = atoi(e) != 0;
     }
-    if (const char* e = getenv("RGBD360_FUSED_SOLVE")) {
+    if (const char* e = knobs::debug("RGBD360_FUSED_SOLVE")) {
         ctx->fused_solve = atoi(e) != 0;
     }
-    if (const char* e = getenv("RGBD360_FUSED_OCC")) {
+    if (const char* e = knobs::debug("RGBD360_FUSED_OCC")) {
         ctx->fused_occ = atoi(e) != 0;
-    }
-    if (const char* e = getenv("RGBD360_ARENA")) {
-        ctx->use_arena = atoi(e) != 0;
     }
     bool ok = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreate(&ctx->ev0) == hipSuccess && hipEventCreate(&ctx->ev1) == hipSuccess &&
@@ -768,6 +762,8 @@ void rgbd360_destroy(rgbd360_ctx* ctx) {
     hipFree(ctx->occ_head); hipFree(ctx->occ_nodes); hipFree(ctx->occ_runinfo);
     if (ctx->h_state) hipHostFree(ctx->h_state);
     hostwait::spin_tag_free(&ctx->tag);
+    for (hipEvent_t e : ctx->f_stage_ev)
+        if (e) hipEventDestroy(e);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
@@ -1002,9 +998,9 @@ static int align360_batch_threads(rgbd360_ctx* ctx, int n_frames, const uint8_t*
 // RGBD360_CTX_ROUTE_CAP overrides (measurements).
 static int ctx_route_cap() {
     static const int v = [] {
-        const char* q = getenv("GPU_MAX_HW_QUEUES");
+        const char* q = knobs::product("GPU_MAX_HW_QUEUES");
         const int dflt = (q && atoi(q) > 4) ? 3 : 6;
-        const char* e = getenv("RGBD360_CTX_ROUTE_CAP");
+        const char* e = knobs::debug("RGBD360_CTX_ROUTE_CAP");
         const int c = e ? atoi(e) : dflt;
         return c >= 1 && c <= 16 ? c : dflt;
     }();
@@ -1019,7 +1015,7 @@ static int align360_batch_lockstep(rgbd360_ctx* ctx, int n_frames, const uint8_t
     // lengthen the first (unoverlapped) upload and the staging buffers (4.37 k alignments/s with 16 slots, 4.12 k with 32)
     const int S = std::min(on_device ? n_inflight : std::min(n_inflight, 16), n);
     int n_eng = S >= 4 ? 2 : 1;
-    if (const char* e = getenv("RGBD360_SEQ_ENGINES")) {
+    if (const char* e = knobs::product("RGBD360_SEQ_ENGINES")) {
         const int v = atoi(e);
         if (v >= 1 && v <= 4) n_eng = std::min(v, S);
     }
@@ -1091,12 +1087,12 @@ static int align360_batch_impl(rgbd360_ctx* ctx, int n_frames, const uint8_t* co
     for (int k = 0; k < n_frames; ++k)
         if (!rgb[k] || !depth[k]) return fail(ctx, -1, "null frame pointer");
     static const float kIdentity[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-    const char* route = getenv("RGBD360_SEQ_ROUTE");          // "contexts": the per-context route for every sequence (A/B measurements)
+    const char* route = knobs::debug("RGBD360_SEQ_ROUTE");          // "contexts": the per-context route for every sequence (A/B measurements)
     // the occlusion-aware passes have no slot dimension: those sequences run one context per sub-chunk
-    if (occlusion != 0 || (route && strcmp(route, "contexts") == 0))
+    if (occlusion != 0 || ctx->seq_route_contexts || (route && strcmp(route, "contexts") == 0))
         // (capped: more busy streams than hardware queues run side by side costs a factor of three, see ctx_route_cap)
         return align360_batch_threads(ctx, n_frames, rgb, rgb_step, depth, depth_step, depth_type, rows, cols, guess, method, occlusion,
-                                      std::min(n_inflight, ctx_route_cap()), poses_out, results_out, on_device);
+                                      std::min(n_inflight, ctx->seq_route_cap > 0 ? ctx->seq_route_cap : ctx_route_cap()), poses_out, results_out, on_device);
     return align360_batch_lockstep(ctx, n_frames, rgb, rgb_step, depth, depth_step, depth_type, rows, cols, guess ? guess : kIdentity, method,
                                    n_inflight, poses_out, results_out, on_device);
 }
@@ -1932,6 +1928,7 @@ static void launch_distance_map(rgbd360_ctx* ctx, int rows, int cols, float max_
         hipLaunchKernelGGL((k_f360_edge_bits<false>), ge, dim3(kEdgeTW), 0, ctx->stream, ctx->f_xyz, rows, cols, max_depth_change_factor, depth_mode,
                            pitch, bits, ctx->f_cloud_pending, ctx->f_xyz);
     }
+    if (ctx->f_stage_timing) hipEventRecord(ctx->f_stage_ev[1], ctx->stream);
     hipLaunchKernelGGL(k_f360_distmap, dim3(pitch, (rows + kDistTH - 1) / kDistTH), dim3(kDistThreads), 0, ctx->stream, bits, rows, cols,
                        pitch, ctx->f_dist, clear_words, n_clear);
 }
@@ -1945,10 +1942,8 @@ int f360_normals_dev(rgbd360_ctx* ctx, int rows, int cols, float max_depth_chang
     // Register sweep for the pixels whose window is int(smoothing_size) squared (nearly all of them), the tiled integral-image kernel
     // for the 32 x 16 tiles the sweep lists (depth edges, far points).  Claim flags + tile list: the first bytes of f_change, which the
     // distance map does not touch (the plane stage rewrites it); the distance-map kernel clears them on its way.
-    // RGBD360_NORMALS_SWEEP=0 keeps the tiled kernel for everything (A/B).
     const int R = (int)smoothing_size;
-    static const bool sweep_off = [] { const char* e = getenv("RGBD360_NORMALS_SWEEP"); return e && atoi(e) == 0; }();
-    const bool use_sweep = !sweep_off && R >= 3 && R <= 10 && ((size_t)gt.x * gt.y * 2 + 2) * sizeof(unsigned) <= (size_t)rows * cols &&
+    const bool use_sweep = R >= 3 && R <= 10 && ((size_t)gt.x * gt.y * 2 + 2) * sizeof(unsigned) <= (size_t)rows * cols &&
                            (size_t)rows * cols * 12 < ((size_t)1 << 31);      // the sweep addresses its rows with 32-bit buffer offsets
     const int n_tiles = (int)(gt.x * gt.y);
     unsigned *flags = nullptr, *list = nullptr;            // {claimed flag per tile}, {count, tile ids ...}
@@ -1969,13 +1964,15 @@ int f360_normals_dev(rgbd360_ctx* ctx, int rows, int cols, float max_depth_chang
         // after R - 1 warm-up rows a wave sweeps whole passes of R output rows (its unrolled loop body)
         int seg = std::max(2 * R, (rows + segs - 1) / segs);
         seg = (seg + R - 1) / R * R;
-        if (const char* e = getenv("RGBD360_SWEEP_SEG")) {      // tuning knob
+        if (const char* e = knobs::debug("RGBD360_SWEEP_SEG")) {      // tuning knob
             const int v = atoi(e);
             if (v >= 4 && v <= 4096) seg = v;
         }
         const int units = strips * ((rows + seg - 1) / seg);
         const dim3 gs((units + kSweepWaves - 1) / kSweepWaves), bs(64 * kSweepWaves);
-#define SWEEP(RR) hipLaunchKernelGGL((k_f360_normals_sweep<RR>), gs, bs, 0, ctx->stream, ctx->f_xyz, ctx->f_dist, rows, cols, smoothing_size, depth_mode, seg, ctx->f_normals, ctx->f_window, flags, list, (int)gt.x)
+        // (no window plane: nothing downstream reads the per-pixel window size -- it was a 4 B/px store of both normal-map kernels,
+        // 33 MB at 4096 x 2048, kept from the days the two kernels were compared through it; round 6)
+#define SWEEP(RR) hipLaunchKernelGGL((k_f360_normals_sweep<RR>), gs, bs, 0, ctx->stream, ctx->f_xyz, ctx->f_dist, rows, cols, smoothing_size, depth_mode, seg, ctx->f_normals, (int*)nullptr, flags, list, (int)gt.x)
         switch (R) {
             case 3: SWEEP(3); break;
             case 4: SWEEP(4); break;
@@ -1990,8 +1987,9 @@ int f360_normals_dev(rgbd360_ctx* ctx, int rows, int cols, float max_depth_chang
     }
     // two tiles fit a CU: 512 blocks walk the sweep's list (every tile of the frame when there was no sweep)
     hipLaunchKernelGGL(k_f360_normals_tiled, dim3(list ? std::min(n_tiles, 512) : n_tiles), dim3(kNT_THREADS), 0, ctx->stream, ctx->f_xyz,
-                       ctx->f_dist, rows, cols, smoothing_size, depth_mode, ctx->f_normals, ctx->f_window, (const unsigned*)list, (int)gt.x,
+                       ctx->f_dist, rows, cols, smoothing_size, depth_mode, ctx->f_normals, (int*)nullptr, (const unsigned*)list, (int)gt.x,
                        n_tiles);
+    if (ctx->f_stage_timing) hipEventRecord(ctx->f_stage_ev[2], ctx->stream);
     HIPC(ctx, hipGetLastError());
     return 0;
 }
@@ -2162,7 +2160,7 @@ const f360::F360HullRecord* hull_records(const rgbd360_ctx* ctx) {
     return reinterpret_cast<const f360::F360HullRecord*>(ctx->f_pack_host + f360::kF360PackHeader + (size_t)kF360MaxSlots * sizeof(f360::F360SlotRecord));
 }
 // the extremes of the CURRENT labels (ctx->f_label) against the frames of the slots, packed for the host; enqueued on the stream
-void launch_hull(rgbd360_ctx* ctx, int rows, int cols, bool clear_first) {
+int launch_hull(rgbd360_ctx* ctx, int rows, int cols, bool clear_first) {
     using namespace f360;
     const int n = rows * cols;
     if (clear_first) hipLaunchKernelGGL(k_f360_hull_clear, dim3((kF360MaxSlots * kHullPhases * kHullDirs + 255) / 256), dim3(256), 0, ctx->stream, ctx->f_nslots, kF360MaxSlots, ctx->f_ext);
@@ -2182,6 +2180,7 @@ void launch_hull(rgbd360_ctx* ctx, int rows, int cols, bool clear_first) {
                        nblk, ctx->f_ext);
     hipLaunchKernelGGL(k_f360_hull_pack, dim3(256), dim3(kHullDirs), 0, ctx->stream, ctx->f_xyz, ctx->f_frames, ctx->f_ext, ctx->f_nslots, kF360MaxSlots,
                        const_cast<F360HullRecord*>(hull_records(ctx)));
+    return 0;
 }
 
 // eigenpairs of a symmetric 3x3 in ascending order (cyclic Jacobi, float64) -- pcl::eigen33's role for the smallest one
@@ -2301,8 +2300,8 @@ int f360_refine_dev(rgbd360_ctx* ctx, int rows, int cols, int nslots, std::vecto
         // "something changed" flag of every second launch (a check costs a stream synchronisation): the run ends with a launch that
         // changed nothing.
         constexpr int kPerCheck = 2;
-        static const int kPolls = [] { const char* e = getenv("RGBD360_REFINE_POLLS"); return e ? atoi(e) : 4096; }();      // (512 until round 4: a launch whose growth chains were still moving gave up after 0.34 ms and cost a second round of launches + a host synchronisation)
-        static const int kQuiet = [] { const char* e = getenv("RGBD360_REFINE_QUIET"); return e ? atoi(e) : 32; }();
+        static const int kPolls = [] { const char* e = knobs::debug("RGBD360_REFINE_POLLS"); return e ? atoi(e) : 4096; }();      // (512 until round 4: a launch whose growth chains were still moving gave up after 0.34 ms and cost a second round of launches + a host synchronisation)
+        static const int kQuiet = [] { const char* e = knobs::debug("RGBD360_REFINE_QUIET"); return e ? atoi(e) : 32; }();
         const int max_rounds = tiles_x + tiles_y + 8;      // a tile is final once its predecessor tiles are: one launch per tile at worst
         for (int round = 0; round < max_rounds && !converged; ++round) {
             volatile int* flags = ctx->f_flags_host;
@@ -2323,7 +2322,7 @@ int f360_refine_dev(rgbd360_ctx* ctx, int rows, int cols, int nslots, std::vecto
             converged = flags[kPerCheck - 1] == 0;      // a launch that changes nothing is a fixed point: every later one repeats it
         }
         if (!converged) return fail(ctx, -7, "plane refinement did not converge");
-        if (getenv("RGBD360_REFINE_DEBUG")) {
+        if (knobs::debug("RGBD360_REFINE_DEBUG")) {
             int act = 0;
             hipMemcpy(&act, d_activity, sizeof(int), hipMemcpyDeviceToHost);
             int nfree = 0;
@@ -2345,7 +2344,7 @@ int f360_refine_dev(rgbd360_ctx* ctx, int rows, int cols, int nslots, std::vecto
                        ctx->f_root_of_slot, ctx->f_count_of_slot, ctx->f_pack_host, (const int*)d_changed, ctx->f_flags_host + kFlags);
     // the contour PCL hands to calcConvexHull is that of the REFINED region, projected with the plane `segment` fitted: extremes of the
     // committed labels against the frames k_f360_slot_frames left before the refinement
-    launch_hull(ctx, rows, cols, /*clear_first=*/true);
+    if (const int rc_h = launch_hull(ctx, rows, cols, /*clear_first=*/true)) return rc_h;
     launch_colour(ctx, rows, cols);          // the colour of the REFINED inlier sets (Frame360.h:1045-1046 run on the refined regions); a no-op without a colour image
     HIPC(ctx, hipGetLastError());
     HIPC(ctx, hostwait::tag_and_wait(ctx->tag, ctx->stream));      // (a tag kernel + host spin: ~10 us less than hipStreamSynchronize, host_wait.h)
@@ -2381,15 +2380,13 @@ int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float
                     float max_curvature, int depth_mode, rgbd360_plane* planes, int max_planes, int* n_planes) {
     using namespace f360;
     const int n = rows * cols;
-    const dim3 g1((n + 255) / 256), b(256);
     uint8_t* flags = ctx->f_change;
     hipLaunchKernelGGL(k_f360_link_flags, dim3((cols + kLinkTW - 1) / kLinkTW, (rows + kLinkTH - 1) / kLinkTH), dim3(kLinkTW), 0, ctx->stream,
                        ctx->f_xyz, ctx->f_normals, rows, cols, cosf(angular_threshold), distance_threshold, depth_mode, flags);
     // run starts as compact per-row lists for the root pass and the slot assignment: in f_window (the normal-map stage's window plane,
-    // spent by now; the refinement takes it over later) and, for the counts, in the tail of f_hd (the depth-change mask is spent once the distance map exists); RGBD360_CCL_LISTS=0: A/B
-    static const bool lists_off = [] { const char* e = getenv("RGBD360_CCL_LISTS"); return e && atoi(e) == 0; }();
-    int* run_starts = lists_off ? nullptr : ctx->f_window;        // (the window plane of the normal-map stage is spent; f_slot_of_root stays free for k_f360_assign_list's writes)
-    int* n_run_starts = lists_off ? nullptr : reinterpret_cast<int*>(ctx->f_hd + (((size_t)n + 15) & ~(size_t)15));      // n + 4 rows <= 3 n + 64 bytes
+    // spent by now; the refinement takes it over later) and, for the counts, in the tail of f_hd (the depth-change mask is spent once the distance map exists)
+    int* run_starts = ctx->f_window;        // (no other use of this plane since round 6; f_slot_of_root stays free for k_f360_assign_list's writes)
+    int* n_run_starts = reinterpret_cast<int*>(ctx->f_hd + (((size_t)n + 15) & ~(size_t)15));      // n + 4 rows <= 3 n + 64 bytes
     const bool seg_rows = cols % 4 == 0 && cols >= 1024 && cols <= kRunSegs * kRunSegSteps * 256;       // (flags and labels are hipMalloc'ed: rows of whole, aligned dwords)
     if (seg_rows)
         hipLaunchKernelGGL(k_f360_ccl_runs_seg, dim3(rows), dim3(64 * kRunSegs), 0, ctx->stream, flags, rows, cols, ctx->f_label, run_starts, n_run_starts);
@@ -2418,8 +2415,7 @@ int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float
         fprintf(stderr, "[f360 dbg] after merge: unions %llu find-hops %llu atomicMin %llu longest walk %llu\n", h[0], h[1], h[2], h[3]);
     }
 #endif
-    if (run_starts) hipLaunchKernelGGL(k_f360_ccl_roots_list, dim3(rows), dim3(kRootsThreads), 0, ctx->stream, run_starts, n_run_starts, cols, ctx->f_label, ctx->f_count);
-    else hipLaunchKernelGGL(k_f360_ccl_roots, g1, b, 0, ctx->stream, flags, n, ctx->f_label, ctx->f_count);
+    hipLaunchKernelGGL(k_f360_ccl_roots_list, dim3(rows), dim3(kRootsThreads), 0, ctx->stream, run_starts, n_run_starts, cols, ctx->f_label, ctx->f_count);
 #ifdef F360_DEBUG_COUNTERS
     {
         unsigned long long h[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -2432,13 +2428,9 @@ int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float
     hipLaunchKernelGGL(k_f360_finish_count, dim3((n + kAggThreads * kCntPerThread - 1) / (kAggThreads * kCntPerThread)), dim3(kAggThreads), 0,
                        ctx->stream, flags, n, ctx->f_label, ctx->f_count, ctx->f_nslots);
     const dim3 bagg(kAggThreads);
-    if (run_starts)
-        hipLaunchKernelGGL(k_f360_assign_list, dim3(rows), dim3(kAssignThreads), 0, ctx->stream, run_starts, n_run_starts, cols, ctx->f_label, ctx->f_count,
-                           min_inliers, kF360MaxSlots, ctx->f_slot_of_root, ctx->f_root_of_slot, ctx->f_count_of_slot, ctx->f_nslots, ctx->f_mom,
-                           f360::kMomReplicas);
-    else
-        hipLaunchKernelGGL(k_f360_assign, g1, b, 0, ctx->stream, ctx->f_label, ctx->f_count, n, min_inliers, kF360MaxSlots,
-                           ctx->f_slot_of_root, ctx->f_root_of_slot, ctx->f_count_of_slot, ctx->f_nslots, ctx->f_mom, f360::kMomReplicas);
+    hipLaunchKernelGGL(k_f360_assign_list, dim3(rows), dim3(kAssignThreads), 0, ctx->stream, run_starts, n_run_starts, cols, ctx->f_label, ctx->f_count,
+                       min_inliers, kF360MaxSlots, ctx->f_slot_of_root, ctx->f_root_of_slot, ctx->f_count_of_slot, ctx->f_nslots, ctx->f_mom,
+                       f360::kMomReplicas);
     const dim3 gmom((n + kAggThreads * kMomPerThread - 1) / (kAggThreads * kMomPerThread));
     hipLaunchKernelGGL(k_f360_moments, gmom, bagg, 0, ctx->stream, ctx->f_xyz, ctx->f_label, ctx->f_slot_of_root, n, ctx->f_mom, kF360MaxSlots);
     // hull stage: per slot the in-plane frame (and an empty extremes row); the extremes themselves now, or -- with the refinement
@@ -2450,8 +2442,12 @@ int f360_planes_dev(rgbd360_ctx* ctx, int rows, int cols, int min_inliers, float
                        ctx->f_count_of_slot, ctx->f_frames, ctx->f_ext, ctx->f_root_of_slot, ctx->f_pack_host);
     ctx->f_col_ran = false;
     if (!ctx->f_refine) {
-        launch_hull(ctx, rows, cols, /*clear_first=*/false);
+        if (const int rc_h = launch_hull(ctx, rows, cols, /*clear_first=*/false)) return rc_h;
         launch_colour(ctx, rows, cols);       // (a no-op without a colour image of this geometry)
+    }
+    if (ctx->f_stage_timing) {
+        hipEventRecord(ctx->f_stage_ev[3], ctx->stream);
+        ctx->f_stage_valid = true;
     }
     HIPC(ctx, hipGetLastError());
     // one tag kernel behind the chain + a host spin (~10 us less than hipStreamSynchronize, host_wait.h).  Until round 5 the chain's last
@@ -2626,15 +2622,9 @@ int sphere_cloud_dev(rgbd360_ctx* ctx, const void* depth, size_t depth_step, int
         if (!depth_on_device) HIPC(ctx, hipStreamSynchronize(ctx->stream));      // the caller may reuse its host image
         return 0;
     }
-    static const bool cloud_x4 = [] { const char* e = getenv("RGBD360_CLOUD_X4"); return e && atoi(e) != 0; }();      // A/B: the round-1 kernel
-    if (cloud_x4 && cols % 4 == 0 && d_step % 16 == 0 && ((size_t)d_depth & 15) == 0) {
-        hipLaunchKernelGGL(k_sphere_cloud_x4, grid2d(rows, cols / 4), dim3(256), 0, ctx->stream, d_depth, d_step, depth_type, rows, cols,
-                           convention, d_tab, d_tab + cols, d_tab + 2 * cols, d_tab + 2 * cols + rows, ctx->f_xyz);
-    } else {
-        // consecutive lanes = consecutive pixels, one 12-byte store per lane, four pixels (256 apart) per thread
-        hipLaunchKernelGGL(k_sphere_cloud_s4, dim3((cols + 1023) / 1024, rows), dim3(256), 0, ctx->stream, d_depth, d_step, depth_type, rows, cols,
-                           convention, d_tab, d_tab + cols, d_tab + 2 * cols, d_tab + 2 * cols + rows, ctx->f_xyz);
-    }
+    // consecutive lanes = consecutive pixels, one 12-byte store per lane, four pixels (256 apart) per thread
+    hipLaunchKernelGGL(k_sphere_cloud_s4, dim3((cols + 1023) / 1024, rows), dim3(256), 0, ctx->stream, d_depth, d_step, depth_type, rows, cols,
+                       convention, d_tab, d_tab + cols, d_tab + 2 * cols, d_tab + 2 * cols + rows, ctx->f_xyz);
     HIPC(ctx, hipGetLastError());
     if (!depth_on_device) HIPC(ctx, hipStreamSynchronize(ctx->stream));      // the caller may reuse its host image
     return 0;
@@ -2701,6 +2691,46 @@ extern "C" int rgbd360_distance_map(rgbd360_ctx* ctx, const float* xyz, int rows
     HIPC(ctx, hipGetLastError());
     HIPC(ctx, hipMemcpyAsync(dist_out, ctx->f_dist, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     HIPC(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// test hooks (rgbd360_hip_diag.h): the schedules the parity tests compare with the default ones
+extern "C" int rgbd360_debug_set_schedule(rgbd360_ctx* ctx, int fused_solve, int fused_occ) {
+    if (!ctx) return -1;
+    if (ctx->al_active) return fail(ctx, -6, "an alignment is in flight");
+    ctx->fused_solve = fused_solve != 0;
+    ctx->fused_occ = fused_occ != 0;
+    return 0;
+}
+extern "C" int rgbd360_debug_set_sequence_route(rgbd360_ctx* ctx, int route, int max_contexts) {
+    if (!ctx || route < 0 || route > 1 || max_contexts < 0 || max_contexts > 16) return -1;
+    ctx->seq_route_contexts = route == 1;
+    ctx->seq_route_cap = max_contexts;
+    return 0;
+}
+extern "C" int rgbd360_debug_knobs_enabled(void) { return knobs::debug_build() ? 1 : 0; }
+
+// measurement: HIP events at the stage boundaries of the context's later frame_planes calls (rgbd360_hip_diag.h)
+extern "C" int rgbd360_frame_planes_stage_timing(rgbd360_ctx* ctx, int on) {
+    if (!ctx) return -1;
+    hipSetDevice(ctx->p.device);
+    if (on)
+        for (hipEvent_t& e : ctx->f_stage_ev)
+            if (!e) HIPC(ctx, hipEventCreate(&e));
+    ctx->f_stage_timing = on != 0;
+    ctx->f_stage_valid = false;
+    return 0;
+}
+extern "C" int rgbd360_frame_planes_stage_times(rgbd360_ctx* ctx, float us[3]) {
+    if (!ctx || !us) return -1;
+    if (!ctx->f_stage_timing || !ctx->f_stage_valid) return fail(ctx, -1, "no timed frame_planes call (rgbd360_frame_planes_stage_timing(ctx, 1) first; the refinement must be off)");
+    hipSetDevice(ctx->p.device);
+    HIPC(ctx, hipEventSynchronize(ctx->f_stage_ev[3]));
+    for (int k = 0; k < 3; ++k) {
+        float ms = 0.f;
+        HIPC(ctx, hipEventElapsedTime(&ms, ctx->f_stage_ev[k], ctx->f_stage_ev[k + 1]));
+        us[k] = ms * 1000.f;
+    }
     return 0;
 }
 
@@ -2777,8 +2807,9 @@ static int frame_planes_impl(rgbd360_ctx* ctx, const void* depth, size_t depth_s
     int rc = f360_ensure(ctx, n);
     if (rc) return rc;
     // the cloud stays on the device; a host copy is only made when asked for
-    static const bool fuse_cloud = [] { const char* e = getenv("RGBD360_FUSE_CLOUD"); return !e || atoi(e) != 0; }();      // A/B knob
-    rc = sphere_cloud_dev(ctx, depth, depth_step, depth_type, rows, cols, convention, depth_on_device, /*defer_to_edge_kernel=*/fuse_cloud);
+    ctx->f_stage_valid = false;
+    if (ctx->f_stage_timing) hipEventRecord(ctx->f_stage_ev[0], ctx->stream);
+    rc = sphere_cloud_dev(ctx, depth, depth_step, depth_type, rows, cols, convention, depth_on_device, /*defer_to_edge_kernel=*/true);
     if (rc) return rc;
     rc = f360_normals_dev(ctx, rows, cols, max_depth_change_factor, normal_smoothing_size, depth_mode);
     if (rc) {

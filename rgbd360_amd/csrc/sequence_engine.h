@@ -93,7 +93,7 @@ int seq_create(const rgbd360_params& p, int P, int rows, int cols, int max_eval_
     if (hipSetDevice(p.device) != hipSuccess) { *err = "hipSetDevice failed"; return -102; }
     SeqEngine* E = new SeqEngine();
     E->p = p; E->P = P; E->rows = rows; E->cols = cols; E->max_eval_blocks = max_eval_blocks;
-    if (const char* e = getenv("RGBD360_SEQ_CHUNKS")) {        // "top,mid,l0" tuning knob
+    if (const char* e = knobs::debug("RGBD360_SEQ_CHUNKS")) {        // "top,mid,l0" tuning knob
         int a = 0, b = 0, c = 0;
         if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3 && a >= 1 && a <= 16 && b >= 1 && b <= 16 && c >= 1 && c <= 16) {
             E->chunk_top = a; E->chunk_mid = b; E->chunk_l0 = c;
@@ -151,7 +151,7 @@ int seq_create(const rgbd360_params& p, int P, int rows, int cols, int max_eval_
         // 8-byte {depth, Isrc} source record and k_eval_b re-forms the point (SrcForm<2>: 32 instead of 40 B/px per pass, 32 instead of
         // 40 B/px written by the set-up).  The latency-bound small levels keep the 16-byte record.  RGBD360_SEQ_RECOMPUTE_MIN_PX moves
         // the bound (0: every level; a huge value: none).  The rig's pinhole records never take this form (rig_dense.h builds its own).
-        static const int seq_min_px = [] { const char* e = getenv("RGBD360_SEQ_RECOMPUTE_MIN_PX"); return e ? atoi(e) : 256 * 1024; }();
+        static const int seq_min_px = [] { const char* e = knobs::product("RGBD360_SEQ_RECOMPUTE_MIN_PX"); return e ? atoi(e) : 256 * 1024; }();
         L.compact = L.n >= seq_min_px;
         int chunk = (L.n + max_eval_blocks - 1) / max_eval_blocks;
         chunk = ((chunk + kEvalThreads - 1) / kEvalThreads) * kEvalThreads;

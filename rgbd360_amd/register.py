@@ -312,6 +312,14 @@ class RegisterPhotoICP:
     def getGradient(self) -> np.ndarray:          # RPI.h:285
         return np.asarray(list(self._res.gradient), dtype=np.float32)
 
+    def debug_set_schedule(self, fused_solve: bool = True, fused_occ: bool = True):
+        """rgbd360_debug_set_schedule (test hook): the two-launch / three-launch schedules the parity tests compare with the fused ones."""
+        self._check(self._L.rgbd360_debug_set_schedule(self._ctx(), int(fused_solve), int(fused_occ)))
+
+    def debug_set_sequence_route(self, contexts: bool, max_contexts: int = 0):
+        """rgbd360_debug_set_sequence_route (test hook): alignSequence over the per-context route instead of the lock-step engines."""
+        self._check(self._L.rgbd360_debug_set_sequence_route(self._ctx(), 1 if contexts else 0, int(max_contexts)))
+
     def calcEntropy(self) -> float:               # RPI.h:4789-4797 (OdometryRGBD360.cpp:207)
         """0.5 (6 (1 + ln 2 pi) + ln det H^-1) of the last alignment's Hessian; float64 log-determinant (the reference's float
         determinant underflows for full-size Hessians), NaN when H is singular."""
@@ -645,6 +653,16 @@ class Frame360Stages:
                                                       C.cast(arr, C.c_void_p), max_planes, C.byref(n)))
         return dict(xyz=xyz, normals=nrm, labels=labels.reshape(rows, cols), planes=_planes_to_dicts(arr, n.value))
 
+
+    def stage_timing(self, on: bool = True):
+        """rgbd360_frame_planes_stage_timing: HIP events at the stage boundaries of the later frame_planes calls (measurement)."""
+        self._reg._check(self._L.rgbd360_frame_planes_stage_timing(self._reg._ctx(), int(on)))
+
+    def stage_times(self):
+        """(a13 cloud + depth-edge mask, a14 distance map + normal map, a15 plane stage) of the last frame_planes call, microseconds."""
+        us = (C.c_float * 3)()
+        self._reg._check(self._L.rgbd360_frame_planes_stage_times(self._reg._ctx(), us))
+        return [float(x) for x in us]
 
     def frame_planes_dev(self, depth_ptr: int, rows: int, cols: int, depth_type: int = 0, convention=2, max_depth_change_factor=0.05,
                          normal_smoothing_size=8.0, min_inliers=40, angular_threshold=0.05, distance_threshold=0.05,

@@ -212,8 +212,6 @@ def test_solve_paths_fused_and_two_launch_agree(hip_lib, oracle_mod, small_pair)
     verdict afterwards): an ordinary step, ILL-POSED by the rank test alone ((H + lambda diag H).rank() < 6 with every LU pivot
     non-zero, RPI.h:4682-4690), ILL-POSED by a zero pivot, and no valid pixels.  Same status / flags / candidate / update, bit for
     bit, and the ordinary step equals gn::step on the host (through the oracle)."""
-    if os.environ.get("RGBD360_FUSED_SOLVE") == "0":
-        pytest.skip("the fused-solve schedule is switched off by RGBD360_FUSED_SOLVE=0")
     reg, ora, T = _pair_ctx(hip_lib, oracle_mod, small_pair)
     g = np.array([0.3, -0.2, 0.1, 0.05, -0.04, 0.02])
     cases = {"step": (_partial_row([4, 5, 6, 7, 8, 9], g), 0, 0),
@@ -241,8 +239,6 @@ def test_fused_solve_checks_the_hosts_bound_on_pending_rows(hip_lib):
     """The fused launch requests the pending pass's partial rows before it knows how many there are; the host passes a bound so that the
     coarse levels request 32 rows instead of 256.  The device checks that bound against the state: a pending row beyond the first batch
     behind a launch that was told `one row` is fetched in a second trip -- same step as with the row in place 0, not a silent zero."""
-    if os.environ.get("RGBD360_FUSED_SOLVE") == "0":
-        pytest.skip("the fused-solve schedule is switched off by RGBD360_FUSED_SOLVE=0")
     from rgbd360_amd.register import RegisterPhotoICP
     (rgbA, dA), (rgbB, dB), T = synth.make_pair(1024, 512, seed=3)          # level 0: 64 block rows
     reg = RegisterPhotoICP()
@@ -1148,16 +1144,16 @@ def test_align_occlusion_matches_oracle(hip_lib, oracle_mod, small_pair, occlusi
     _assert_libm_oracle_agrees(reg, ora, method, 3, occlusion)
 
 
-def test_occlusion_fused_schedule_equals_the_three_launch_one(hip_lib, small_pair, monkeypatch):
+def test_occlusion_fused_schedule_equals_the_three_launch_one(hip_lib, small_pair):
     """Round 4: the occlusion-aware alignments run {k_occ_build_fs, k_eval_occ} per iteration (the solve of the previous pass in the
     prologue of the build, the pass gated by the state the build writes).  Same poses, iteration counts, residuals and status, bit
-    for bit, as {k_occ_build, k_eval_occ, k_solve} (RGBD360_FUSED_OCC=0, read when the context is made) -- from the identity and
+    for bit, as {k_occ_build, k_eval_occ, k_solve} (rgbd360_debug_set_schedule(ctx, 1, 0), rgbd360_hip_diag.h) -- from the identity and
     from a guess, twice in a row on one context (the generation-tagged heads and the double-buffered state carry over)."""
     (rgbA, dA), (rgbB, dB), T = _occluder_pair(small_pair)
     out = {}
     for fused in ("1", "0"):
-        monkeypatch.setenv("RGBD360_FUSED_OCC", fused)
         reg = _mk(hip_lib, 3)
+        reg.debug_set_schedule(fused_solve=True, fused_occ=fused == "1")
         reg.setTargetFrame(rgbA, dA)
         reg.setSourceFrame(rgbB, dB)
         rows = []
@@ -2145,3 +2141,36 @@ def test_hull_polygon_keeps_its_sense_when_the_rig_origin_lies_behind_the_plane(
             checked += 1
         flipped += int(float(a["normal"] @ b["normal"]) < -0.99)
     assert flipped >= 1 and checked >= 2
+
+
+@pytest.mark.parametrize("method", [0, 2])
+def test_two_launch_schedule_equals_the_fused_one_on_alignments(hip_lib, small_pair, method):
+    """rgbd360_debug_set_schedule(ctx, 0, 1): every Gauss-Newton iteration as a {k_eval, k_solve} pair instead of ONE k_eval_fs launch
+    (the library's default, the kernel `value` is made of): poses, iteration counts, Hessians and residuals bit-identical, from the
+    identity and from a guess (until round 6 an environment variable, RGBD360_FUSED_SOLVE, switched this; tests/tools/fused_soak.py is
+    the long version)."""
+    (rgbA, dA), (rgbB, dB), T = small_pair
+    rows = {}
+    for fused in (True, False):
+        reg = _mk(hip_lib, 3)
+        reg.debug_set_schedule(fused_solve=fused, fused_occ=True)
+        reg.setTargetFrame(rgbA, dA)
+        reg.setSourceFrame(rgbB, dB)
+        out = []
+        for g in (np.eye(4), np.asarray(T), np.eye(4)):
+            rc = reg.alignFrames360(g, method)
+            out.append((rc, list(reg.num_iterations), reg.getOptimalPose().copy(), reg.getHessian().copy(), reg.avResidual))
+        rows[fused] = out
+    for a, b in zip(rows[True], rows[False]):
+        assert a[0] == b[0] == 0 and a[1] == b[1] and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and a[4] == b[4], (a, b)
+
+
+def test_per_context_sequence_route_equals_the_lockstep_engines(hip_lib):
+    """rgbd360_debug_set_sequence_route(ctx, 1, 3): a plain sequence over the per-context route (one context per sub-chunk of pairs, what
+    the occlusion-aware sequences always use) gives the lock-step engines' poses bit for bit (tests/tools/engine_soak.py: the long version)."""
+    frames = [synth.render(synth.trajectory_pose(k, 7), 256, 128, 7) for k in range(6)]
+    reg = _mk(hip_lib, 3)
+    p1, s1, i1 = reg.alignSequence(frames, method=2, n_inflight=4)
+    reg.debug_set_sequence_route(True, 3)
+    p0, s0, i0 = reg.alignSequence(frames, method=2, n_inflight=3)
+    assert np.array_equal(p0, p1) and np.array_equal(s0, s1) and np.array_equal(i0, i1) and not s1.any()

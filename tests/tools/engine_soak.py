@@ -23,9 +23,9 @@ for t in range(n_trials):
     slots = int(rng.choice([1, 2, 3, 5, 8, 16, 32]))
     reg = RegisterPhotoICP()
     reg.setNumPyr(n_pyr)
-    os.environ["RGBD360_SEQ_ROUTE"] = "contexts"
+    reg.debug_set_sequence_route(True)
     p0, s0, i0 = reg.alignSequence(frames, method=method, n_inflight=3)
-    os.environ.pop("RGBD360_SEQ_ROUTE")
+    reg.debug_set_sequence_route(False)
     p1, s1, i1 = reg.alignSequence(frames, method=method, n_inflight=slots)
     same = np.array_equal(p0, p1) and np.array_equal(s0, s1) and np.array_equal(i0, i1)
     bad += 0 if same else 1

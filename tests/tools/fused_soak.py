@@ -1,7 +1,7 @@
 """Soak check of the fused-solve schedule (one k_eval_fs launch per Gauss-Newton iteration, the library's default) against the two-launch
-schedule (k_eval + k_solve, RGBD360_FUSED_SOLVE=0): random scenes, sizes, pyramid depths, methods, start poses and residual weights; pose,
+schedule (k_eval + k_solve, rgbd360_debug_set_schedule): random scenes, sizes, pyramid depths, methods, start poses and residual weights; pose,
 status, iteration counts and the result record must agree BIT FOR BIT.  A third of the trials run an occlusion-aware mode on an occluder scene: there the fused schedule is
-{k_occ_build_fs, k_eval_occ} against {k_occ_build, k_eval_occ, k_solve} (RGBD360_FUSED_OCC=0).  python tests/tools/fused_soak.py [n_trials]"""
+{k_occ_build_fs, k_eval_occ} against {k_occ_build, k_eval_occ, k_solve}.  python tests/tools/fused_soak.py [n_trials]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
@@ -32,9 +32,9 @@ for t in range(n_trials):
         guess = np.linalg.inv(T) if rng.random() < 0.5 else T        # start at the answer / at twice the motion
     res = []
     for fused in ("1", "0"):
-        os.environ["RGBD360_FUSED_OCC" if occlusion else "RGBD360_FUSED_SOLVE"] = fused
         reg = RegisterPhotoICP()
         reg.setNumPyr(n_pyr)
+        reg.debug_set_schedule(fused_solve=(fused == "1") or bool(occlusion), fused_occ=(fused == "1") or not occlusion)
         if fused == "1":
             var = (float(rng.choice([3.0, 6.0, 12.0])) / 255.0, float(rng.choice([0.005, 0.01, 0.03]))) if rng.random() < 0.3 else None
         if var is not None:
@@ -43,7 +43,6 @@ for t in range(n_trials):
         rc = reg.alignFrames360(guess, method, occlusion)
         res.append((rc, reg.getOptimalPose().copy(), list(reg.num_iterations), reg.getHessian().copy(), reg.getGradient().copy()))
         reg.close()
-    os.environ.pop("RGBD360_FUSED_OCC" if occlusion else "RGBD360_FUSED_SOLVE")
     a, b = res
     same = a[0] == b[0] and np.array_equal(a[1], b[1]) and a[2] == b[2] and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
     bad += 0 if same else 1
