@@ -18,7 +18,41 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "photo_icp_kernels.h"      // r360::sphere_point for the fused cloud stage of k_f360_edge_bits
+#include "device_math.h"      // r360::sphere_point for the fused cloud stage of k_f360_edge_bits
+
+namespace r360 {
+// Consecutive lanes own consecutive pixels and every lane stores its 12-byte point with ONE instruction (768 contiguous bytes per
+// wave instruction); a thread covers four pixels 256 apart.  (Round 1's form -- a thread owning four consecutive pixels, three 16-byte
+// stores with a 48-byte lane stride, 15 us at 2048 x 1024 = 1.9 TB/s -- and the one-pixel-per-thread form were deleted in round 6.)
+typedef float float3s __attribute__((ext_vector_type(3)));
+__global__ __launch_bounds__(256) void k_sphere_cloud_s4(const void* __restrict__ depth, size_t step, int depth_type, int rows, int cols,
+                                                         int convention, const float* __restrict__ sin_theta,
+                                                         const float* __restrict__ cos_theta, const float* __restrict__ sin_phi,
+                                                         const float* __restrict__ cos_phi, float* __restrict__ xyz) {
+    const int r = blockIdx.y;
+    const uint8_t* row = (const uint8_t*)depth + (size_t)r * step;
+    const float sp = sin_phi[r], cp = cos_phi[r];
+    const int cbase = blockIdx.x * 1024 + threadIdx.x;
+    float d[4], st[4], ct[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {          // all loads first
+        const int c = cbase + 256 * k;
+        const int cc = c < cols ? c : cols - 1;
+        d[k] = depth_type == 0 ? 0.001f * (float)((const uint16_t*)row)[cc] : ((const float*)row)[cc];
+        st[k] = sin_theta[cc];
+        ct[k] = cos_theta[cc];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = cbase + 256 * k;
+        if (c >= cols) continue;
+        float x, y, z;
+        sphere_point(convention, d[k], sp, cp, st[k], ct[k], x, y, z);
+        float3s o = {x, y, z};
+        *reinterpret_cast<float3s*>(xyz + 3 * ((size_t)r * cols + c)) = o;
+    }
+}
+}  // namespace r360
 
 namespace f360 {
 

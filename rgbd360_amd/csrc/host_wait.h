@@ -49,13 +49,13 @@ inline void spin_tag_free(SpinTag* t) {
 }
 
 // the last thing a stream does before the host looks: everything earlier in the stream is complete (stream order)
-__global__ void k_tag(unsigned* tag, unsigned seq) {
+static __global__ void k_tag(unsigned* tag, unsigned seq) {
     __threadfence_system();
     __hip_atomic_store(tag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 // n_words 32-bit words from device memory into the pinned host buffer, then the tag
 // (one wave: every wave that runs a system-scope fence asks for its own write-back, and a few hundred words do not need four)
-__global__ __launch_bounds__(64) void k_publish(const unsigned* __restrict__ src, unsigned* __restrict__ dst_host, int n_words, unsigned* tag,
+static __global__ __launch_bounds__(64) void k_publish(const unsigned* __restrict__ src, unsigned* __restrict__ dst_host, int n_words, unsigned* tag,
                                                 unsigned seq) {
     for (int i = threadIdx.x; i < n_words; i += blockDim.x) dst_host[i] = src[i];
     __threadfence_system();

@@ -19,12 +19,12 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "device_math.h"
 #include "gn_math.h"
 
 namespace r360 {
 
 constexpr float  kInvalidPoint = -10000.f;      // RPI.h:40
-constexpr double kPI = 3.14159265359;           // Miscellaneous.h:44 (truncated literal, double)
 constexpr int    kEvalThreads = 1024;
 constexpr int    kNumPartials = 32;             // doubles per block partial
 // partial slots
@@ -98,30 +98,6 @@ struct SolveCfg {
 // sequence of IEEE-754 basic operations (fma, mul, add, correctly rounded sqrt and reciprocal) that the CPU oracle
 // repeats operation for operation in its math_mode 1, so warped pixel indices agree bit for bit.
 // ---------------------------------------------------------------------------------------------------------
-// Correctly rounded sqrt for x == 0 and normal finite x in [2^-60, 2^60]: reciprocal-square-root estimate (<= 1 ulp) and
-// ONE coupled Newton step, s = x y, s += (x - s s) (y / 2), with the residual taken exactly by an fma.  Proven by
-// exhaustion, not by analysis: rgbd360_selftest_math (and tools/ubench/rn_variants.hip) compare it with the compiler's IEEE
-// sqrtf for every float of that range -- 0 mismatches on gfx950.  (The first version corrected the hardware sqrt with two
-// +-1 ulp residual tests: 9 instructions instead of 6.)
-__device__ __forceinline__ float sqrt_rn(float x, float& y) {           // y: the hardware estimate of 1 / sqrt(x) it starts from (<= 1 ulp)
-    y = __builtin_amdgcn_rsqf(fmaxf(x, 1.17549435e-38f));      // the clamp only matters for x == 0: s = 0 * y = 0
-    const float s = x * y;
-    const float h = 0.5f * y;
-    const float r = fmaf(-s, s, x);
-    return fmaf(r, h, s);
-}
-__device__ __forceinline__ float sqrt_rn(float x) {
-    float y;
-    return sqrt_rn(x, y);
-}
-// Correctly rounded 1/x for normal finite |x| in [2^-60, 2^60]: hardware estimate (<= 1 ulp) + one Newton step with an exact
-// fma residual; exhaustively equal to the IEEE quotient 1.f / x on gfx950 (same self-test).
-__device__ __forceinline__ float rcp_rn(float x) {
-    const float r = __builtin_amdgcn_rcpf(x);
-    const float e = fmaf(-x, r, 1.f);
-    return fmaf(e, r, r);
-}
-
 // round-half-up to the nearest integer, floor(x + 0.5) with the sum taken exactly: one v_cvt_rpi_i32_f32.  Equals
 // C round() except at exact negative ties, which cannot change a visible pixel index (negative rows / columns are
 // dropped).  rgbd360_selftest_math checks the instruction against floor((double)x + 0.5) over the index range.
@@ -347,7 +323,6 @@ __device__ __forceinline__ float4 load_src_step(const float4* __restrict__ src0,
     return buf_load_f4(make_rsrc(src0 + first_px, (unsigned)left * 16u), tid16);
 }
 
-__device__ __forceinline__ void divmod24(int n, int d, int& q, int& rem);
 // ---------------------------------------------------------------------------------------------------------
 // The source stream of the per-pixel pass, three forms (template parameter SRC):
 //   0  {x, y, z, Isrc} records, 16 B per pixel (LUT_xyz_sphere precomputed per level, like the reference)
@@ -1799,15 +1774,6 @@ __global__ void k_pyrdown_pair(const float* __restrict__ gray_src, const float* 
 }
 
 // calcGradientXY on one plane + seam mask; writes the interleaved {value, gradX, gradY} gather record.
-// n / d and n % d for 0 <= n < 2^24, d >= 1 (images are < 16 Mpx): a float estimate of the quotient, exact after one
-// correction either way -- a runtime-divisor integer division costs ~30 VALU instructions, this one ~8.
-__device__ __forceinline__ void divmod24(int n, int d, int& q, int& rem) {
-    q = (int)((float)n * (1.0f / (float)d));
-    rem = n - q * d;
-    if (rem < 0) { rem += d; --q; }
-    else if (rem >= d) { rem -= d; ++q; }
-}
-
 __device__ __forceinline__ void gradient_rec_px(const float* __restrict__ src, int rows, int cols, int seam_width,
                                                 F3* __restrict__ rec, int r, int c) {
     const float v = src[(size_t)r * cols + c];
@@ -2208,62 +2174,7 @@ __global__ __launch_bounds__(256) void k_frame_level_b(FrameLevelArgs A, FramePt
     }
 }
 
-// Frame360 sphere clouds (Frame360.h:555-612, Frame360_stereo.h:454-512) and the RegisterPhotoICP convention.
-__device__ __forceinline__ void sphere_point(int convention, float d, float sp, float cp, float st, float ct, float& x, float& y, float& z) {
-    const float qnan = __builtin_nanf("");
-    x = qnan; y = qnan; z = qnan;
-    if (convention == 0) {
-        if (d != 0) {
-            x = sp * d;
-            y = -cp * st * d;
-            z = -cp * ct * d;
-        }
-    } else if (convention == 1) {
-        if (d > 0.f && d < 15.f) {
-            x = st * cp * d;
-            y = sp * d;
-            z = ct * cp * d;
-        }
-    } else {
-        if (d != 0) {
-            x = d * sp;
-            y = -d * cp * st;
-            z = -d * cp * ct;
-        }
-    }
-}
 
-// Consecutive lanes own consecutive pixels and every lane stores its 12-byte point with ONE instruction (768 contiguous bytes per
-// wave instruction); a thread covers four pixels 256 apart.  (Round 1's form -- a thread owning four consecutive pixels, three 16-byte
-// stores with a 48-byte lane stride, 15 us at 2048 x 1024 = 1.9 TB/s -- and the one-pixel-per-thread form were deleted in round 6.)
-typedef float float3s __attribute__((ext_vector_type(3)));
-__global__ __launch_bounds__(256) void k_sphere_cloud_s4(const void* __restrict__ depth, size_t step, int depth_type, int rows, int cols,
-                                                         int convention, const float* __restrict__ sin_theta,
-                                                         const float* __restrict__ cos_theta, const float* __restrict__ sin_phi,
-                                                         const float* __restrict__ cos_phi, float* __restrict__ xyz) {
-    const int r = blockIdx.y;
-    const uint8_t* row = (const uint8_t*)depth + (size_t)r * step;
-    const float sp = sin_phi[r], cp = cos_phi[r];
-    const int cbase = blockIdx.x * 1024 + threadIdx.x;
-    float d[4], st[4], ct[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {          // all loads first
-        const int c = cbase + 256 * k;
-        const int cc = c < cols ? c : cols - 1;
-        d[k] = depth_type == 0 ? 0.001f * (float)((const uint16_t*)row)[cc] : ((const float*)row)[cc];
-        st[k] = sin_theta[cc];
-        ct[k] = cos_theta[cc];
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int c = cbase + 256 * k;
-        if (c >= cols) continue;
-        float x, y, z;
-        sphere_point(convention, d[k], sp, cp, st[k], ct[k], x, y, z);
-        float3s o = {x, y, z};
-        *reinterpret_cast<float3s*>(xyz + 3 * ((size_t)r * cols + c)) = o;
-    }
-}
 
 
 }  // namespace r360
