@@ -108,9 +108,14 @@ __device__ __forceinline__ int round_index(float x) {
 }
 
 // atan(t) for t in [0, 1(+ulps)]: odd minimax polynomial, 9 coefficients, relative error 1.3e-8.
-// (Round 4, measured and dropped: the quadrant angle T(|y| / (|y| + |x|)) from a 256-interval quadratic table in LDS instead of min / max
-// ratio + polynomial + reflection -- 8.5 instead of 16 vector instructions per angle, 116 instead of 144 per pixel in all -- changed the
-// launch time by nothing at any size, tools/ab_libs.py: the pass is not bound by vector issue)
+// What has been measured against it (none shipped; the pass is bound by vector issue AND the memory round trip of each step together --
+// DESIGN.md 3.1 -- and neither lever moved the launch alone):
+//   round 4: the quadrant angle T(|y| / (|y| + |x|)) from a 256-interval quadratic table in LDS instead of min / max ratio + polynomial +
+//            reflection (8.5 instead of 16 vector instructions per angle, 116 instead of 144 per pixel): no change at any size;
+//   round 6: both angles' Horner chains in lock step on the packed pipe (v_pk_fma_f32, bit-identical results) and the 27 accumulations
+//            as 15 packed ones (115 vector instructions per pixel instead of 135, 26 of them packed): 14.42 -> 14.54 us, the packed
+//            instruction costs 1.47 issue slots (profiles/r03_ubench_valu.txt) and the chains' depth is unchanged
+//            (profiles/r06_headline_kernel_experiment.txt, the diff: profiles/r06_pk_math_experiment.patch).
 __device__ __forceinline__ float atan_unit(float t) {
     const float q0 = -0.3333333195069166f, q1 = 0.19999765993465415f, q2 = -0.14279110844310372f,
                 q3 = 0.11037993832882714f, q4 = -0.08673169371217875f, q5 = 0.06284358078457526f,
