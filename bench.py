@@ -149,11 +149,9 @@ def frame360_roofline(torch, Frame360Stages, RegisterPhotoICP, device, depth_u16
     kw = dict(depth_type=0, convention=2, angular_threshold=0.03, min_inliers=40, max_curvature=0.0013, max_planes=4096)      # tools/prof_frame360.py's call
     out = st.frame_planes_dev(d_dev.data_ptr(), H, W, **kw)                             # warm: allocations, tables
     st.stage_timing(True)
-    rows, calls = [], []
+    rows = []
     for _ in range(reps):
-        t0 = time.perf_counter()
         out = st.frame_planes_dev(d_dev.data_ptr(), H, W, **kw)
-        calls.append(time.perf_counter() - t0)
         rows.append(st.stage_times())
     st.stage_timing(False)
     med = [sorted(r[k] for r in rows)[len(rows) // 2] for k in range(3)]
@@ -167,7 +165,6 @@ def frame360_roofline(torch, Frame360Stages, RegisterPhotoICP, device, depth_u16
     return {"width": W, "height": H, "planes": len(out["planes"]), "stages": stages,
             "chain": {"us": tot_us, "algorithmic_bytes": tot_b, "achieved": tot_b / (tot_us * 1e-6) / 1e9, "unit": "GB/s",
                       "frac": tot_b / (tot_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "peak": HBM_PEAK_GBS},
-            "call_ms_median": sorted(calls)[len(calls) // 2] * 1e3,
             "kernels": {"a13_sphere_cloud": "k_f360_edge_bits<true> (forms the cloud, writes it and the depth-change mask)",
                         "a14_normal_map": "k_f360_distmap, k_f360_normals_sweep<8>, k_f360_normals_tiled",
                         "a15_plane_stage": "k_f360_link_flags ... k_f360_hull_pack (labels, counts, slots, moments, hull extremes; refinement off)"}}
@@ -684,6 +681,30 @@ def run_sequence_block(args, torch, dist, synth, reg0, rank, world, local_rank, 
             "mean_iters_per_level": np.round(it.mean(0), 3).tolist() if len(it) else [],
         }
     reg.close()
+    # The host-frame leg is bound by PCIe, not by HBM: every alignment brings ONE new frame over the link (rows x cols x (3 + 2) bytes).
+    # Its roofline is the host-to-device copy rate of this box, measured here with a pinned buffer (the frames themselves are pageable
+    # numpy arrays the library copies with hipMemcpy2DAsync, as a caller's cv::Mat data would be).
+    if "host_frames" in out and n_loc > 0:
+        try:
+            nb = 64 << 20
+            h_pin = torch.empty(nb, dtype=torch.uint8).pin_memory()
+            d_buf = torch.empty(nb, dtype=torch.uint8, device=dev)
+            d_buf.copy_(h_pin, non_blocking=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(8):
+                d_buf.copy_(h_pin, non_blocking=True)
+            torch.cuda.synchronize()
+            h2d = 8 * nb / (time.perf_counter() - t0) / 1e9
+            frame_b = W * H * 5
+            rate = out["host_frames"]["alignments_per_s"] / world * frame_b / 1e9
+            out["host_frames"]["pcie"] = {
+                "bound": "pcie", "bytes_per_alignment": frame_b, "achieved": rate, "unit": "GB/s", "peak": h2d, "frac": rate / h2d,
+                "peak_source": "8 x 64 MiB pinned host -> device copies on this box, in this run",
+                "note": ("one new %d x %d frame (8UC3 + 16UC1 = %.1f MB) per alignment and GPU; at the measured copy rate the link carries at most %.0f alignments/s per GPU, "
+                         "whatever the kernels do -- PCIe 5.0 x16 is 63 GB/s raw, i.e. 6.0 k/s even on paper" % (W, H, frame_b / 1e6, h2d * 1e9 / frame_b))}
+        except Exception as e:
+            out["host_frames"]["pcie"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:160])}
     out.update({"workload": "configs[3]: %d consecutive %dx%d pairs (PHOTO_DEPTH, 4 levels), contiguous shards over %d rank(s), "
                             "rgbd360_align360_batch[_dev] per rank (lock-step engine, %d pairs in flight), one all-gather of pose/status/iters"
                             % (n_total, W, H, world, SEQ_INFLIGHT),
