@@ -272,3 +272,84 @@ def test_frame360_pair_example_runs_on_the_sample_pair(hip_lib, sample, tmp_path
     assert np.allclose(Td[:3, :3] @ Td[:3, :3].T, np.eye(3), atol=1e-4)
     rot, trans = synth.pose_error(Td, np.eye(4))
     assert 0.02 < trans < 0.6 and rot < 0.1, (rot, trans)
+
+
+QVGA_K = (262.5, 262.5, 159.5, 119.5)       # 525 * 320 / 640 (RegisterRGBD360.h:357-365), Calib360.h:74-77
+
+
+@pytest.mark.parametrize("method", [1, 2])
+def test_sample_pair_pinhole_alignment_per_sensor(hip_lib, oracle_mod, sample, method):
+    """RegisterPhotoICP::alignFrames (RPI.h:4254-4512, the per-sensor use of MethodsRegisterRGBD360.cpp:336-348) on the eight REAL sensor
+    image pairs of frames 1 and 10: a narrow field of view on noisy depth, several sensors facing a bare wall -- poorly conditioned,
+    levels that stop at the iteration limit or never start.  Per sensor: same status and accept / reject sequence as the oracle in
+    device arithmetic, exact per-pass counts at the result, pose within the pinhole tolerance of the synthetic tests scaled by what
+    the problem's conditioning does to a 1e-7 rounding difference (measured and printed)."""
+    from rgbd360_amd.register import RegisterPhotoICP
+    worst = [0.0, 0.0]
+    n_marginal = 0
+    for s in range(8):
+        (rgbA, dA), (rgbB, dB) = sample["frames"][1][s], sample["frames"][10][s]
+        reg = RegisterPhotoICP()
+        reg.setNumPyr(3)
+        reg.setMaskSeams(False)
+        reg.setCameraMatrix(QVGA_K)
+        reg.setTargetFrame(rgbA, dA)
+        reg.setSourceFrame(rgbB, dB)
+        rc = reg.alignFrames(np.eye(4), method)
+        ora = oracle_mod.Oracle(n_pyr=3, math_mode=1, reduce_mode=1, mask_seams=0)
+        ora.set_camera(*QVGA_K)
+        ora.set_target(rgbA, dA)
+        ora.set_source(rgbB, dB)
+        st, pose_ref = ora.align_pinhole(np.eye(4), method)
+        iters = list(reg.num_iterations)
+        rot, trans = synth.pose_error(reg.getOptimalPose(), pose_ref)
+        print(f"sensor {s} method {method}: status {rc}/{st} iters {iters} / {list(ora.result.iters)[:3]} pose diff {rot:.2e} rad {trans:.2e} m")
+        assert rc == st
+        if iters != list(ora.result.iters)[:3]:
+            # A different accept / reject sequence is only tolerated where the oracle's own decision was a coin toss: some step of the
+            # diverging level changed the error by less than float32 rounding of the sums (2e-5 relative).  Met on sensor 6, depth only
+            # (a bare wall in a 60-degree view): the oracle accepts a step that improves 1.2929930 -> 1.2929868 (5e-6) in device arithmetic,
+            # rejects it with float32 accumulators ([10, 7, 0] / [10, 6, 0] / [10, 10, 0] / [10, 7, 0] over its four mode combinations);
+            # the device, whose weights come from the hardware's 1-ulp rsq / rcp, lands on [10, 6, 0].
+            lvl = next(l for l in range(3) if iters[l] != list(ora.result.iters)[l])
+            marginal = [abs(t["error"] - t["new_error"]) / t["error"] for t in ora.trace() if t["level"] == lvl and t["it"] >= 0]
+            print(f"   sensor {s}: sequences differ on level {lvl}; smallest relative error change of a step there {min(marginal):.1e}")
+            assert min(marginal) < 2e-5, (s, iters, list(ora.result.iters)[:3], marginal)
+            n_marginal += 1
+            continue
+        worst = [max(worst[0], rot), max(worst[1], trans)]
+        for level in range(3):
+            e = reg.eval_pinhole(level, pose_ref, method)
+            _, sp, sd, n_p, n_d = ora.error_pinhole(level, pose_ref, method)
+            assert list(e["n_split"]) == [n_p, n_d], (s, level)
+    print(f"worst pose difference over the sensors with the oracle's sequence: {worst[0]:.2e} rad {worst[1]:.2e} m; coin-toss sequences: {n_marginal}")
+    assert worst[0] <= 1e-4 and worst[1] <= 1e-3 and n_marginal <= 1, (worst, n_marginal)
+
+
+@pytest.mark.parametrize("method", [0, 2])
+def test_sample_pair_rig_dense_registration(hip_lib, oracle_mod, sample, method):
+    """RegisterRGBD360::RegisterDensePhotoICP (RegisterRGBD360.h:344-520, the reference's three defects fixed) on the real 8-sensor pair with the
+    reference's extrinsics: every level runs to the iteration limit ([10, 10, 10]); same sequence as the oracle, pose within the rig
+    tolerance of the synthetic tests, and within the north star's of the reference-faithful arithmetic."""
+    from rgbd360_amd.rig import RegisterDensePhotoICP
+    Rt = sample["Rt"]
+    f1, f10 = sample["frames"][1], sample["frames"][10]
+    reg = RegisterDensePhotoICP(Rt, QVGA_K, n_pyr=3)
+    reg.setTargetFrame(f1)
+    reg.setSourceFrame(f10)
+    ok = reg.align(np.eye(4), method)
+    poses = {}
+    for mm in ((1, 1), (0, 0)):
+        rig = oracle_mod.RigOracle(Rt, QVGA_K, n_pyr=3, math_mode=mm[0], reduce_mode=mm[1])
+        for s in range(8):
+            rig.set_frame(s, True, *f1[s])
+            rig.set_frame(s, False, *f10[s])
+        st, pose = rig.align(np.eye(4), method)
+        poses[mm] = (st, pose, list(rig.iters))
+    st, pose_ref, iters_ref = poses[(1, 1)]
+    rot, trans = synth.pose_error(reg.getPose(), pose_ref)
+    rot0, trans0 = synth.pose_error(reg.getPose(), poses[(0, 0)][1])
+    print(f"rig method {method}: ok {ok} iters {reg.num_iterations} / {iters_ref}; vs oracle (device arithmetic) {rot:.2e} rad {trans:.2e} m; vs libm {rot0:.2e} rad {trans0:.2e} m")
+    assert ok and st == 0 and reg.num_iterations == iters_ref == [10, 10, 10]
+    assert rot <= 5e-5 and trans <= 2e-4, (rot, trans)
+    assert rot0 <= ROT_TOL and trans0 <= TRANS_TOL, (rot0, trans0)
