@@ -16,7 +16,7 @@ extern "C" {
 /* Forced schedule for throughput measurement: n_iters Gauss-Newton iterations on `level`
  * starting at pose0, every step applied regardless of the accept rule, no host round trip.  One iteration =
  * one launch of k_eval_fs (the solve of the previous pass + the fused pass; the last solve in a one-block launch of its own), or one
- * fused pass + one solve launch under RGBD360_FUSED_SOLVE=0.  Enqueued on the context's stream; *elapsed_ms (may be NULL) is the HIP
+ * fused pass + one solve launch under rgbd360_debug_set_schedule(ctx, 0, 1).  Enqueued on the context's stream; *elapsed_ms (may be NULL) is the HIP
  * event time around the n_iters iterations (NULL: no events are recorded and the call waits for its result the way
  * rgbd360_align360 does, csrc/host_wait.h). */
 int rgbd360_forced_iters(rgbd360_ctx* ctx, int level, const float pose0[16], int method, int n_iters,

@@ -66,10 +66,10 @@ struct rgbd360_ctx {
     double* d_partials = nullptr;     // partial rows of the last pass enqueued (current) ...
     double* d_partials_alt = nullptr; // ... and where a fused pass puts its rows while its blocks still read the previous table
     int max_blocks = 0;               // rows of a partial table = blocks of the largest level
-    bool fused_occ = true;            // the occlusion-aware alignments on the fused schedule too (RGBD360_FUSED_OCC=0: {build, pass, k_solve} triples, A/B)
+    bool fused_occ = true;            // the occlusion-aware alignments on the fused schedule too (rgbd360_debug_set_schedule: {build, pass, k_solve} triples)
     bool seq_route_contexts = false;  // rgbd360_debug_set_sequence_route: every sequence over the per-context route (the occlusion-aware ones always are)
     int seq_route_cap = 0;            // ... with this many contexts at most (0: ctx_route_cap())
-    bool fused_solve = true;          // single-pair schedule: solve in the prologue of the next pass (RGBD360_FUSED_SOLVE=0: {k_eval, k_solve} pairs, A/B)
+    bool fused_solve = true;          // single-pair schedule: solve in the prologue of the next pass (rgbd360_debug_set_schedule: {k_eval, k_solve} pairs)
     GnIO* d_gnio = nullptr;
     // upload staging: slot 0 serves the single-frame entries (copies on `stream`); the sequence entry alternates both slots,
     // copying on `up_stream` one frame ahead of the alignment (up_ev: upload landed, conv_ev: slot consumed)
@@ -103,7 +103,7 @@ struct rgbd360_ctx {
     unsigned char* occ_runinfo = nullptr;              // ... per source pixel: candidate / prefix maximum within its run / offset to the run's first pixel
     int occ_gen = 0;                                   // generation tag of the head entries (no memset between passes)
     size_t occ_n = 0;
-    int max_eval_blocks = 256;    // grid cap of the fused pass (tuning knob: RGBD360_EVAL_BLOCKS)
+    int max_eval_blocks = 256;    // grid cap of the fused pass (debug knob RGBD360_EVAL_BLOCKS, csrc/knobs.h)
     unsigned char* arena = nullptr;   // ONE allocation behind every per-level buffer of the context (planes, records, angle tables)
     std::string err;
 };

@@ -1,5 +1,6 @@
 """The per-context route (one host thread + context + stream per span) against the number of contexts: python tools/ctx_threads_perf.py
-Runs plain and occlusion-aware sequences through RGBD360_SEQ_ROUTE=contexts with the route's cap lifted (RGBD360_CTX_ROUTE_CAP)."""
+Runs plain and occlusion-aware sequences through RGBD360_SEQ_ROUTE=contexts with the route's cap lifted (RGBD360_CTX_ROUTE_CAP).
+Both are debug knobs since round 6: build the library with `python -m rgbd360_amd.build --debug-knobs` first (csrc/knobs.h)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["RGBD360_SEQ_ROUTE"] = "contexts"

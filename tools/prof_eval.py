@@ -17,5 +17,5 @@ for method in (0, 2):
     try:
         us = reg.time_eval_kernel(0, T, method, 2, reps)      # k_eval_fs: solve prologue + pass (forced schedule)
         print("method", method, "k_eval_fs avg us", us)
-    except Exception as e:                                    # RGBD360_FUSED_SOLVE=0
+    except Exception as e:                                    # (the fused schedule switched off: a debug build with RGBD360_FUSED_SOLVE=0)
         print("method", method, "k_eval_fs not run:", e)

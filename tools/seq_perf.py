@@ -1,4 +1,5 @@
-"""Sequence throughput on one GPU, frames resident in HBM: the lock-step engine (sequence_engine.h) over slot counts / engine counts /
+"""(The RGBD360_SEQ_ROUTE / RGBD360_SEQ_CHUNKS arms need a library built with `python -m rgbd360_amd.build --debug-knobs`, csrc/knobs.h.)
+Sequence throughput on one GPU, frames resident in HBM: the lock-step engine (sequence_engine.h) over slot counts / engine counts /
 speculation depths, next to the per-context route.  python tools/seq_perf.py [n_pairs=256] [W=2048] [quick]"""
 import ctypes as C, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
