@@ -283,3 +283,69 @@ def merge_planes(planes, max_curvature=0.0013, cos_normal=0.99, dist_d=0.45, pro
                     break
         j += 1
     return v
+
+
+# ---- the tail of Frame360::getPlanesSensor (Frame360.h:1034-1068) on records without polygons: independent restatement of
+#      rgbd360_pool_sensor_planes (mrpt's isSamePlane / isPlaneNearby on the moment rectangle's corners; the pooled fit as in merge_planes) ----
+def _seg_seg_dist2(p0, p1, q0, q1):
+    """Squared distance between two 3-D segments by dense sampling of the closed-form minimiser's candidates: the unconstrained optimum
+    clamped, and the four endpoint-to-segment distances (exact for segments: the minimum is at one of them)."""
+    def pt_seg(x, a, b):
+        ab = b - a
+        den = float(ab @ ab)
+        t = 0.0 if den <= 0 else min(1.0, max(0.0, float((x - a) @ ab) / den))
+        d = x - (a + t * ab)
+        return float(d @ d)
+    u, v, w = p1 - p0, q1 - q0, p0 - q0
+    a, b, c, d, e = float(u @ u), float(u @ v), float(v @ v), float(u @ w), float(v @ w)
+    D = a * c - b * b
+    best = min(pt_seg(p0, q0, q1), pt_seg(p1, q0, q1), pt_seg(q0, p0, p1), pt_seg(q1, p0, p1))
+    if D > 1e-12 * max(a * c, 1e-300):
+        sc, tc = (b * e - c * d) / D, (a * e - b * d) / D
+        if 0.0 <= sc <= 1.0 and 0.0 <= tc <= 1.0:
+            dP = w + sc * u - tc * v
+            best = min(best, float(dP @ dP))
+    return best
+
+
+def _corners(p):
+    pts, _ = _outline(p)
+    return [pts[0], pts[2], pts[8], pts[6]]          # (-,-) (-,+) (+,+) (+,-): the rectangle as a closed outline
+
+
+def _is_same_plane(a, b, cos_normal, dist_normal, proximity):
+    f = lambda v: np.asarray(v, np.float32).astype(np.float64)
+    na = f(a["normal"])
+    if na @ f(b["normal"]) < _f32(cos_normal):
+        return False
+    ca, cb = f(a["centroid"]), f(b["centroid"])
+    if abs(na @ (cb - ca)) > _f32(dist_normal):
+        return False
+    p2 = float(_f32(proximity)) ** 2
+    if (ca - cb) @ (ca - cb) < p2:
+        return True
+    A, B = _corners(a), _corners(b)
+    if any((x - cb) @ (x - cb) < p2 for x in A) or any((ca - y) @ (ca - y) < p2 for y in B):
+        return True
+    if any((x - y) @ (x - y) < p2 for x in A for y in B):
+        return True
+    return any(_seg_seg_dist2(A[i], A[(i + 1) % 4], B[j], B[(j + 1) % 4]) < p2 for i in range(4) for j in range(4))
+
+
+def pool_sensor_planes(planes, max_curvature=0.0013, min_area=0.12, max_elongation=6.0, cos_normal=0.99, dist_normal=0.05, proximity=0.2):
+    v = []
+    for p in planes:
+        if _f32(p["area"]) < _f32(min_area) or _f32(p["elongation"]) > _f32(max_elongation):
+            continue
+        hit = None
+        if _f32(p["curvature"]) < _f32(max_curvature):
+            for j, q in enumerate(v):
+                if _f32(q["curvature"]) < _f32(max_curvature) and _is_same_plane(q, p, cos_normal, dist_normal, proximity):
+                    hit = j
+                    break
+        if hit is None:
+            v.append(dict(p))
+        else:
+            v[hit] = merge_planes([v[hit], dict(p)], max_curvature=1e9, cos_normal=-2.0, dist_d=1e9, proximity=1e9, normal_offset=1e9, min_area=-1.0,
+                                  max_elongation=1e9)[0]          # (the pooled fit of exactly these two: every test of merge_planes forced to pass)
+    return v

@@ -636,6 +636,38 @@ def test_pool_sensor_planes_is_the_tail_of_getPlanesSensor():
     assert pbmap.pool_sensor_planes([]) == []
 
 
+def test_pool_sensor_planes_random_sets_match_the_numpy_restatement():
+    """rgbd360_pool_sensor_planes against oracle/pbmap_ref.py's independent restatement (records without polygons: the moment rectangle is
+    the outline) on random sets of wall pieces in random order: which regions survive, which are pooled into which, the pooled fit."""
+    rng = np.random.default_rng(18)
+    pooled_somewhere = dropped_somewhere = 0
+    for trial in range(30):
+        planes = []
+        for w in range(int(rng.integers(1, 4))):
+            nrm = rng.normal(size=3)
+            nrm /= np.linalg.norm(nrm)
+            pdv = np.cross(nrm, rng.normal(size=3))
+            pdv /= np.linalg.norm(pdv)
+            dist = rng.uniform(1.5, 4.0)
+            pieces = int(rng.integers(1, 5))
+            gap = rng.choice([0.05, 0.15, 0.4])                                 # between neighbouring pieces' outlines: under / over the 0.2 m proximity
+            for k in range(pieces):
+                half = rng.uniform(0.25, 0.6)
+                centre = -nrm * dist + pdv * k * (2 * 0.6 + gap) + nrm * rng.choice([0.0, 0.0, 0.08]) + rng.normal(size=3) * 0.002
+                planes.append(_rect_plane(centre, nrm + rng.normal(size=3) * 0.004, pdv, 0.6, half if rng.random() < 0.8 else 0.05,
+                                          int(rng.integers(200, 3000)), len(planes)))
+                if rng.random() < 0.15:
+                    planes[-1]["curvature"] = np.float32(0.01)
+        planes = [planes[i] for i in rng.permutation(len(planes))]
+        got, want = pbmap.pool_sensor_planes(planes), O.pool_sensor_planes(planes)
+        assert [(p["count"], p["root"]) for p in got] == [(p["count"], p["root"]) for p in want], (trial, [(p["count"], p["root"]) for p in got], [(p["count"], p["root"]) for p in want])
+        for a, b in zip(got, want):
+            assert np.allclose(a["centroid"], b["centroid"], atol=2e-5) and abs(a["area"] - b["area"]) <= 2e-4 * max(b["area"], 1.0)
+        pooled_somewhere += int(sum(p["count"] for p in got) == sum(p["count"] for p in planes if p["area"] >= 0.12 and p["elongation"] <= 6.0) and len(got) < sum(1 for p in planes if p["area"] >= 0.12 and p["elongation"] <= 6.0))
+        dropped_somewhere += int(any(p["area"] < 0.12 or p["elongation"] > 6.0 for p in planes))
+    assert pooled_somewhere >= 5 and dropped_somewhere >= 5, (pooled_somewhere, dropped_somewhere)
+
+
 def test_merge_planes_has_no_containment_test():
     """Frame360::mergePlanes / groupPlanes test proximity vertex against vertex and edge against edge only (Frame360.h:680-711, 788-815): a
     panel inside a wall's hull, parallel to it and within normal_offset, but farther than `proximity` from the wall's OUTLINE, stays a
