@@ -183,6 +183,40 @@ def test_bench_under_torch_distributed_run_with_two_ranks(hip_lib):
         v = seq[variant]
         assert v["all_status_ok"] and v["repeated_pairs_bit_identical"] and v["alignments_per_s"] > 0, (variant, v)
         assert v["max_forward_backward_residual"] < 1e-3
+    pcie = seq["host_frames"]["pcie"]          # the host-frame leg against the box's measured host-to-device copy rate
+    assert pcie["bound"] == "pcie" and pcie["bytes_per_alignment"] == 2048 * 1024 * 5 and 0 < pcie["frac"] < 1.5 and pcie["peak"] > 1.0, pcie
+
+
+_F360_BLOCK_SCRIPT = r"""
+import importlib.util, json, os, sys
+sys.path.insert(0, %(root)r)
+import torch                                   # first: bench.py's order (torch brings its own HIP runtime; the library then binds to it)
+torch.cuda.init()
+from rgbd360_amd import synth
+from rgbd360_amd.register import Frame360Stages, RegisterPhotoICP
+spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(%(root)r, "bench.py"))
+bench = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(bench)
+(_, dA), _, _ = synth.make_pair(1024, 512, seed=5)
+print(json.dumps(bench.frame360_roofline(torch, Frame360Stages, RegisterPhotoICP, 0, dA, reps=5)))
+"""
+
+
+@pytest.mark.gpu
+def test_bench_frame360_roofline_block(hip_lib):
+    """bench.py's `roofline_frame360` block (rows a13-a15 from HIP events at the stage boundaries of rgbd360_frame_planes_dev) on a small
+    frame, in a child process that imports torch first like bench.py does: three stages with SURVEY 8d's bytes, positive times that add up
+    to the chain's, fractions consistent with them."""
+    import json
+    out = subprocess.run([sys.executable, "-c", _F360_BLOCK_SCRIPT % dict(root=ROOT)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr.decode(errors="replace")[-2000:]
+    blk = json.loads([l for l in out.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert blk["width"] == 1024 and blk["height"] == 512 and blk["planes"] >= 3
+    st = blk["stages"]
+    assert [st[k]["bytes_per_pixel"] for k in ("a13_sphere_cloud", "a14_normal_map", "a15_plane_stage")] == [14, 24, 16]
+    assert all(v["us"] > 1.0 and 0 < v["frac"] < 1 for v in st.values())
+    assert abs(sum(v["us"] for v in st.values()) - blk["chain"]["us"]) < 1e-3 * blk["chain"]["us"]
+    assert abs(blk["chain"]["frac"] - 54 * 1024 * 512 / (blk["chain"]["us"] * 1e-6) / 8e12) < 1e-9
 
 
 @pytest.mark.gpu
