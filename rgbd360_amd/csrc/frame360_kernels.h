@@ -1960,7 +1960,10 @@ constexpr int kHullDirs = 128;       // per block, 2 per lane: a lane's directio
 // block sees a sample of every edge of a region, so the union of the sets' winners is a polygon of up to 1024 region pixels, still
 // inscribed in the hull.  (Rounds 2-3: four sets of 256 directions, four per lane: 0.9988 x the exact hull at worst over 30 random scenes;
 // eight sets of 128: 0.9979 -- each direction sees an eighth of the boundary instead of a quarter -- for half the walk, 1 KB table rows
-// and 64 of them per block, tests/tools/hull_soak.py.)
+// and 64 of them per block, tests/tools/hull_soak.py.  Round 6, 72 more draws with other seeds: 0.9968 once -- a 6.7 m wall-floor edge along
+// an image row, bowed by one pixel in the plane: its whole bend is 0.7 degrees, i.e. two of the 1024 directions, and along a ROW the stretches
+// of one set lie 512 pixels apart, more than the edge is long, so neither direction had a pixel near the apex; the strip lost is a pixel
+// wide.  tests/tools/hull_case.py prints such a case vertex by vertex.)
 constexpr int kHullPhases = 8;         // direction sets, block b works on set b mod 8 (round 4: 4 sets of 256 -- a table row was 2 KB and a block's
                                        // 32 rows overflowed into global atomics on frames with many planes: 250 us at 4096 x 2048 with 444 planes)
 constexpr int kHullRecPts = kHullPhases * kHullDirs;     // points a record can hold; a point that wins several directions of a set is sent once

@@ -780,6 +780,34 @@ def test_plane_regions_match_oracle(hip_lib, oracle_mod, depth_mode, ang):
             assert abs(abs(np.dot(a["normal"], b["normal"])) - 1) < 1e-5 and abs(a["d"] - b["d"]) < 1e-4
 
 
+@pytest.mark.parametrize("W,seed,trans,rot", [(512, 943, 0.1, 3.0), (512, 840, 0.3, 10.0), (256, 471, 0.1, 25.0)])
+def test_plane_regions_when_a_loose_threshold_links_the_whole_room(hip_lib, oracle_mod, W, seed, trans, rot):
+    """An angular threshold of 0.1 rad on a small frame: the smoothed normals turn the room's corners by less than that per pixel, walls,
+    floor and ceiling become ONE region of ~90 % of the frame (a component every merge level takes part in), which the curvature test
+    refuses; what is left are slivers just above min_inliers.  Labels, planes and their order equal the CPU checker's (the draws are those
+    tests/tools/hull_soak.py met with seed 101: trials 0, 6, 3)."""
+    from rgbd360_amd.register import Frame360Stages
+    H = W // 2
+    depth = synth.make_pair(W, H, seed=seed, trans=trans, rot_deg=rot)[1][1]
+    st = Frame360Stages(_mk(hip_lib, 2))
+    out = st.frame_planes(depth, convention=2, angular_threshold=0.1, min_inliers=40)
+    xyz = oracle_mod.sphere_cloud(depth, 2)
+    assert np.array_equal(np.asarray(out["xyz"]).reshape(-1, 3), np.asarray(xyz).reshape(-1, 3))
+    nrm, _ = oracle_mod.f360_normals(xyz, H, W, 0.05, 8.0, 1)
+    nrm, nrm_dev = np.asarray(nrm).reshape(-1, 3), np.asarray(out["normals"]).reshape(-1, 3)
+    ok = ~np.isnan(nrm[:, 0])
+    assert np.array_equal(np.isnan(nrm_dev[:, 0]), ~ok) and np.abs(nrm_dev[ok] - nrm[ok]).max() <= 1.2e-7
+    # (the segmentation is checked on the device's own normal map: a last-bit difference of a normal may move a comparison)
+    labels_ref, planes_ref = oracle_mod.f360_plane_segment(xyz, nrm_dev, H, W, 40, 0.1, 0.05, 0.001, 1)
+    labels_ref = np.asarray(labels_ref).reshape(-1)
+    assert np.array_equal(np.asarray(out["labels"]).reshape(-1), labels_ref)
+    counts = np.bincount(labels_ref[labels_ref >= 0])
+    assert counts.max() > 0.75 * labels_ref.size                     # the scenario: one region holds the room
+    assert [p["root"] for p in out["planes"]] == [p["root"] for p in planes_ref]
+    assert [p["count"] for p in out["planes"]] == [p["count"] for p in planes_ref]
+    assert all(p["count"] < 64 for p in planes_ref)                  # ... and no plane comes out of it
+
+
 @pytest.mark.parametrize("W,H", [(250, 101), (700, 37), (65, 70), (24, 15), (513, 129), (1028, 37), (1500, 70), (1920, 33), (1026, 20), (4100, 18)])
 def test_plane_regions_ragged_sizes(hip_lib, oracle_mod, W, H):
     """The tiled / hierarchical component passes on sizes that are not multiples of their tiles (256 x 4 link tile, 4 rows per

@@ -1,12 +1,12 @@
 """Soak check of the lock-step sequence engine against the per-context route: random trajectories, sizes, methods, depth types and
-slot counts; poses, status and iteration counts must agree BIT FOR BIT.  python tests/tools/engine_soak.py [n_trials]"""
+slot counts; poses, status and iteration counts must agree BIT FOR BIT.  python tests/tools/engine_soak.py [n_trials [seed]]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from rgbd360_amd import synth
 from rgbd360_amd.register import RegisterPhotoICP
 n_trials = int(sys.argv[1]) if len(sys.argv) > 1 else 12
-rng = np.random.default_rng(2026)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)      # [seed]: another draw of cases
 bad = 0
 for t in range(n_trials):
     W = int(rng.choice([256, 320, 512, 640, 1024]))

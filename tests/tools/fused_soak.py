@@ -1,14 +1,14 @@
 """Soak check of the fused-solve schedule (one k_eval_fs launch per Gauss-Newton iteration, the library's default) against the two-launch
 schedule (k_eval + k_solve, rgbd360_debug_set_schedule): random scenes, sizes, pyramid depths, methods, start poses and residual weights; pose,
 status, iteration counts and the result record must agree BIT FOR BIT.  A third of the trials run an occlusion-aware mode on an occluder scene: there the fused schedule is
-{k_occ_build_fs, k_eval_occ} against {k_occ_build, k_eval_occ, k_solve}.  python tests/tools/fused_soak.py [n_trials]"""
+{k_occ_build_fs, k_eval_occ} against {k_occ_build, k_eval_occ, k_solve}.  python tests/tools/fused_soak.py [n_trials [seed]]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from rgbd360_amd import synth
 from rgbd360_amd.register import RegisterPhotoICP
 n_trials = int(sys.argv[1]) if len(sys.argv) > 1 else 24
-rng = np.random.default_rng(3003)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 3003)      # [seed]: another draw of cases
 bad = 0
 for t in range(n_trials):
     W = int(rng.choice([128, 256, 320, 512, 640, 1024, 2048]))

@@ -1,6 +1,6 @@
 """Soak check of the normal map (register sweep + list of reworked tiles) against the CPU checker: random sizes, smoothing sizes
 (= sweep window 3..10), depth modes, scenes with depth steps, holes and far points.  NaN pattern identical, values identical up to the
-rare 1-ulp flip the tiled kernel's test allows.  python tests/tools/normals_soak.py [n_trials]"""
+rare 1-ulp flip the tiled kernel's test allows.  python tests/tools/normals_soak.py [n_trials [seed]]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
@@ -9,7 +9,7 @@ from rgbd360_amd.register import RegisterPhotoICP, Frame360Stages
 from oracle import oracle as O
 O.set_num_threads(min(16, os.cpu_count() or 1))
 n_trials = int(sys.argv[1]) if len(sys.argv) > 1 else 10
-rng = np.random.default_rng(7)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)      # [seed]: another draw of cases
 st = Frame360Stages(RegisterPhotoICP())
 bad = 0
 for t in range(n_trials):

@@ -2,7 +2,7 @@
 (errorPhotoICP_Occ1/2, calcHessGrad_Occ1/2 in the device-arithmetic mode): random scenes, sizes, levels, methods, occlusion modes and
 poses -- the rendered motion, zoom-outs that pile many source pixels on a target pixel, half-turns that put the points BEHIND the camera
 (negative inverse depths: the z-buffer's `buf > 0` / `buf == 0` tests), collapses onto a few pixels.  Every count must agree exactly
-(the z-buffer's accept chain is integer work), the sums to the plain pass's tolerances.  python tests/tools/pinhole_occ_soak.py [n_trials]"""
+(the z-buffer's accept chain is integer work), the sums to the plain pass's tolerances.  python tests/tools/pinhole_occ_soak.py [n_trials [seed]]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
@@ -10,7 +10,7 @@ from rgbd360_amd import synth
 from rgbd360_amd.register import RegisterPhotoICP
 from oracle import oracle as O
 n_trials = int(sys.argv[1]) if len(sys.argv) > 1 else 24
-rng = np.random.default_rng(515)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 515)      # [seed]: another draw of cases
 bad = 0
 for t in range(n_trials):
     W, H = [(160, 120), (320, 240), (640, 480), (200, 152)][int(rng.integers(0, 4))]
