@@ -362,7 +362,12 @@ int rgbd360_set_plane_color_image(rgbd360_ctx* ctx, const uint8_t* rgb, size_t r
  * centroid / covariance / smallest eigenvector / curvature (the values Frame360.h:984-996 copies into
  * mrpt::pbmap::Plane).  labels_out (may be NULL): per pixel the region's root pixel index, -1 for non-finite points.
  * Planes are returned in PCL's order (by first pixel), at most max_planes; when more regions pass the filters the
- * max_planes LARGEST (inlier count) are kept, and rgbd360_planes_available reports how many there were. */
+ * max_planes LARGEST (inlier count) are kept, and rgbd360_planes_available reports how many there were.
+ * The inlier sums are exact 64-bit integer sums of terms rounded to 2^-28 m (m^2) -- order independent, ~20 x finer than the float
+ * accumulators of PCL 1.7's computeMeanAndCovarianceMatrix; a region a few millimetres across whose smallest eigenvalue lies within
+ * ~1e-8 m^2 of max_curvature x trace may still fall on the other side of the filter than a float64 evaluation puts it.  Errors of the
+ * plane calls: -7 more than 4096 regions exceed min_inliers; -8 the sums left their range (N r^2 >= 3.4e10 m^2: a whole 4096 x 2048
+ * frame that is one region beyond 64 m). */
 int rgbd360_plane_fit(rgbd360_ctx* ctx, const float* xyz, const float* normals, int rows, int cols, int min_inliers,
                       float angular_threshold, float distance_threshold, float max_curvature, int depth_mode,
                       int32_t* labels_out, rgbd360_plane* planes_out, int max_planes, int* n_planes_out);

@@ -1202,11 +1202,16 @@ __global__ __launch_bounds__(kRootsThreads) void k_f360_ccl_roots_list(const int
 // A planar wall owns hundreds of thousands of pixels, so adding per pixel (or even per wave) into one global counter
 // serialises on that address.  Each 1024-thread block therefore sweeps 4096 consecutive pixels, aggregates per label
 // in a small LDS hash (wave-uniform labels -- the common case -- are first reduced inside the wave), and only then
-// issues one global atomic per (block, label, value).  All sums are integers (counts; moments in 2^-24 fixed point):
+// issues one global atomic per (block, label, value).  All sums are integers (counts; moments in 2^-28 fixed point):
 // integer addition is associative, so the results are bitwise reproducible whatever the arrival order.
 constexpr int kAggThreads = 1024;
 constexpr int kMomPerThread = 8;
-constexpr double kMomScale = 16777216.0;      // 2^24 units per m (linear terms) / per m^2 (quadratic terms)
+// 2^28 units per m (linear terms) / per m^2 (quadratic terms).  2^24 until round 6: every term is rounded to the unit once, and in
+// C = sum(x x) / N - (sum(x) / N)^2 that 6e-8 m^2 stands against a smallest eigenvalue of ~1e-7 m^2 for a region of a dozen pixels --
+// curvatures 2 % off the float64 checker's, planes on the other side of max_curvature (tests/tools/planes_soak.py: 2 of 5 k planes).
+// The sums stay inside 64 bits while N r^2 < 2^63 / 2^28 = 3.4e10 m^2: a full 4096 x 2048 frame that is ONE region at 64 m, the whole
+// range of a 16-bit millimetre image; the host checks the decoded sums (f360_planes_dev) and refuses a frame beyond that.
+constexpr double kMomScale = 268435456.0;
 constexpr int kMomReplicas = 16;              // copies of the global moment table (block b adds into copy b % 16): a wall is hit by
                                               // every block it spans, and same-address global atomics serialise; the host adds the copies
 
@@ -1358,7 +1363,7 @@ __global__ __launch_bounds__(kAssignThreads) void k_f360_assign_list(const int* 
     }
 }
 
-// 9 raw moments per selected region (sum x, y, z, xx, xy, xz, yy, yz, zz) in 2^-24 fixed point, two's complement in u64, at a
+// 9 raw moments per selected region (sum x, y, z, xx, xy, xz, yy, yz, zz) in 2^-28 fixed point, two's complement in u64, at a
 // cost that does not depend on how fragmented the label image is.  A lane owns 8 CONSECUTIVE pixels, so the slots a wave sees
 // form runs along the lanes: every lane sums its pixels in registers (flushing to the LDS hash only where the slot changes
 // inside its 8 pixels), then ONE segmented scan over the lanes (6 shuffle steps for the nine 64-bit sums, whatever the number

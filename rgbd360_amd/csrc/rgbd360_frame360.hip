@@ -774,6 +774,10 @@ int f360_planes_dev(F360State* ctx, int rows, int cols, int min_inliers, float a
         const double C[3][3] = {{m[3] / N - cx * cx, m[4] / N - cx * cy, m[5] / N - cx * cz},
                                 {m[4] / N - cx * cy, m[6] / N - cy * cy, m[7] / N - cy * cz},
                                 {m[5] / N - cx * cz, m[7] / N - cy * cz, m[8] / N - cz * cz}};
+        // the fixed-point sums wrap beyond N r^2 = 2^63 / kMomScale (frame360_kernels.h): a wrapped sum of squares is off by
+        // 6.9e10 / N m^2, i.e. negative or absurd -- refused, not returned
+        if (!(m[3] >= 0.0 && m[6] >= 0.0 && m[8] >= 0.0) || C[0][0] < -1e-3 || C[1][1] < -1e-3 || C[2][2] < -1e-3)
+            return fail(ctx, -8, "region moments out of range (points beyond ~60 m over a whole frame)");
         double evs[3], vecs[3][3];
         sorted_eigen3(C, evs, vecs);
         const double ev = evs[0];

@@ -780,6 +780,51 @@ def test_plane_regions_match_oracle(hip_lib, oracle_mod, depth_mode, ang):
             assert abs(abs(np.dot(a["normal"], b["normal"])) - 1) < 1e-5 and abs(a["d"] - b["d"]) < 1e-4
 
 
+def test_small_regions_curvature_against_float64(hip_lib):
+    """The inlier sums are integers of terms rounded to 2^-28 m^2: on patches of 12-24 pixels 2.5 m away with 1 mm of noise (smallest
+    eigenvalue ~1e-6 m^2 under sums of ~6 m^2 per pixel) the curvature is within 0.2 % of numpy's float64 value -- with the 2^-24 of
+    rounds 2-5 it was off by up to several per cent, and tests/tools/planes_soak.py met planes on the other side of max_curvature."""
+    from rgbd360_amd.register import Frame360Stages
+    H, W = 48, 96
+    rng = np.random.default_rng(4)
+    xyz = np.full((H, W, 3), np.nan, np.float32)
+    nrm = np.full((H, W, 3), np.nan, np.float32)
+    want = {}
+    for k in range(18):
+        r0, c0 = 3 + 7 * (k // 6), 3 + 15 * (k % 6)
+        hh, ww = int(rng.integers(3, 5)), int(rng.integers(4, 7))
+        rr, cc = np.meshgrid(np.arange(hh), np.arange(ww), indexing="ij")
+        pts = np.stack([0.3 * k + 0.004 * cc, -0.5 + 0.004 * rr, 2.5 + rng.normal(0, 1e-3, size=rr.shape)], axis=2).astype(np.float32)
+        xyz[r0:r0 + hh, c0:c0 + ww] = pts
+        nrm[r0:r0 + hh, c0:c0 + ww] = (0, 0, -1)
+        ev = np.linalg.eigvalsh(np.cov(pts.reshape(-1, 3).astype(np.float64).T, bias=True))
+        want[r0 * W + c0] = (hh * ww, abs(ev[0]) / ev.sum())
+    st = Frame360Stages(_mk(hip_lib, 2))
+    labels, planes = st.plane_fit(xyz, nrm, H, W, 10, 0.05, 0.05, 0.9, 0)
+    assert sorted(p["root"] for p in planes) == sorted(want)
+    for p in planes:
+        n, curv = want[p["root"]]
+        assert p["count"] == n
+        assert abs(p["curvature"] - curv) < 2e-3 * curv, (p["root"], p["curvature"], curv)
+
+
+def test_plane_fit_refuses_sums_beyond_their_range(hip_lib):
+    """64-bit sums of 2^-28 m^2 terms hold N r^2 < 3.4e10 m^2 (a whole 4096 x 2048 frame as ONE region 64 m away); beyond, a sum wraps.
+    One region of 32768 points 1100 m away (3.96e10): error -8, not a plane with a nonsense covariance."""
+    from rgbd360_amd.register import Frame360Stages, Rgbd360Error
+    H, W = 128, 256
+    rr, cc = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    xyz = np.stack([0.5 * (cc - W / 2), 0.5 * (rr - H / 2), np.full(rr.shape, 1100.0)], axis=2).astype(np.float32)
+    nrm = np.zeros((H, W, 3), np.float32)
+    nrm[..., 2] = -1
+    st = Frame360Stages(_mk(hip_lib, 2))
+    with pytest.raises(Rgbd360Error, match=r"\(-8\).*out of range"):
+        st.plane_fit(xyz, nrm, H, W, 40, 0.05, 0.05, 0.9, 0)
+    xyz[..., 2] = 900.0                                               # 2.65e10: inside
+    labels, planes = st.plane_fit(xyz, nrm, H, W, 40, 0.05, 0.05, 0.9, 0)
+    assert len(planes) == 1 and planes[0]["count"] == H * W and abs(planes[0]["centroid"][2] - 900.0) < 1e-3
+
+
 @pytest.mark.parametrize("W,seed,trans,rot", [(512, 943, 0.1, 3.0), (512, 840, 0.3, 10.0), (256, 471, 0.1, 25.0)])
 def test_plane_regions_when_a_loose_threshold_links_the_whole_room(hip_lib, oracle_mod, W, seed, trans, rot):
     """An angular threshold of 0.1 rad on a small frame: the smoothed normals turn the room's corners by less than that per pixel, walls,
