@@ -18,6 +18,7 @@ n_trials = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 17)      # [seed]: another draw of cases
 bad = 0
 near = 0
+acc = 0          # ... of which the libm warp with float64 sums takes the device's sequence (the float32 accumulators made the difference)
 for t in range(n_trials):
     W = int(rng.choice([128, 192, 256, 320, 512, 640, 1024]))
     H = W // 2
@@ -82,8 +83,15 @@ for t in range(n_trials):
         both = (steps[0].get(lv, []) + steps[1].get(lv, [])) if lv is not None else []
         smallest = min([abs((x["error"] - x["new_error"]) - tol_r) / max(x["error"], 1e-12) for x in both] + [float("inf")])
         upd = min([abs(float(np.linalg.norm(x["update"])) - tol_u) / tol_u for x in both] + [float("inf")])
+        # ... and whose rounding is it: the libm warp with float64 sums (modes 0, 1) tells the index arithmetic from the float32 accumulators
+        ora.set_modes(0, 1)
+        st01, pose01 = ora.align360(guess, method, occlusion)
+        it01 = list(ora.result.iters)[:n_pyr]
+        r01, t01 = synth.pose_error(pose_gpu, pose01)
+        acc += 1 if it01 == it_gpu else 0
         near += 1
-        note = " (libm takes another accept / reject sequence %s: pose %.1e rad %.1e m apart; on the parting level a step came within %.1e (relative to the error) of tol_residual, within %.1e of tol_update)" % (
+        note = " [libm warp + float64 sums: iters %s, %.1e rad %.1e m]" % (it01, r01, t01)
+        note += " (libm takes another accept / reject sequence %s: pose %.1e rad %.1e m apart; on the parting level a step came within %.1e (relative to the error) of tol_residual, within %.1e of tol_update)" % (
             it_libm, r0, t0, smallest, upd)
         # The two arithmetics put ~1e-4 of the pixels on neighbouring target pixels (the device's arctangent polynomial against libm's
         # asinf / atan2f), so their error values differ by a few 1e-4 relative: a step that close to tol_residual is refused
@@ -95,5 +103,6 @@ for t in range(n_trials):
           "libm oracle %.1e rad %.1e m%s -> %s" % (t, W, H, n_pyr, method, occlusion, trans, rot, "float32" if f32 else "uint16", " spoiled" if spoil else "",
                                                   " occluder" if occluder else "", "yes" if not np.array_equal(guess, np.eye(4)) else "no",
                                                   rc, st, it_gpu, it_ora, r1, t1, r0, t0, note, "ok" if good else "FAIL"), flush=True)
-print("align soak: %d / %d trials ok (%d with another accept / reject sequence under libm)" % (n_trials - bad, n_trials, near))
+print("align soak: %d / %d trials ok (%d with another accept / reject sequence under libm + float32 accumulators; in %d of them libm + float64 sums takes the device's)" % (
+    n_trials - bad, n_trials, near, acc))
 sys.exit(1 if bad else 0)
