@@ -1240,7 +1240,16 @@ __device__ __forceinline__ long long wave_sum_ll(long long v) {
 // way: count[root] = number of pixels of the region (unsigned 64-bit).  A block sweeps kCntPerThread x 1024 consecutive
 // pixels; wave-uniform labels (the common case) are accumulated in a wave-scalar (key, count) pair that is only flushed to
 // the block's LDS hash when the key changes, the hash goes to global memory once per (block, label).
-constexpr int kCntPerThread = 8;
+// (round 6 sweep at 4096 x 2048 / 2048 x 1024, tools/f360_ab.sh: 1024 threads x 8 pixels 26.2 / 10.7 us; x 4: 39.0 / 12.1; x 12: 31.8 / 13.9;
+// x 16: 32.1 / 17.0; x 32: 33.8 / 29.8; 512 threads x 8: 34.6 / 12.9; 256 x 8: 59.3 / 19.0; 256 x 16: 40.8 / 16.4 -- fewer pixels per block
+// mean more flushes into the same few counters, more mean a longer chain per block with two blocks resident per CU)
+#ifndef F360_CNT_PER_THREAD
+#define F360_CNT_PER_THREAD 8
+#endif
+#ifndef F360_CNT_THREADS
+#define F360_CNT_THREADS 1024
+#endif
+constexpr int kCntPerThread = F360_CNT_PER_THREAD, kCntThreads = F360_CNT_THREADS;
 constexpr int kCntHashBits = 8, kCntHash = 1 << kCntHashBits;
 __device__ __forceinline__ int cnt_slot(int* keys, int key) {
     int h = (int)(((unsigned)key * 2654435761u) >> (32 - kCntHashBits));
@@ -1252,7 +1261,7 @@ __device__ __forceinline__ int cnt_slot(int* keys, int key) {
     }
     return -1;
 }
-__global__ __launch_bounds__(kAggThreads) void k_f360_finish_count(const uint8_t* __restrict__ flags, int n, int* __restrict__ label,
+__global__ __launch_bounds__(kCntThreads) void k_f360_finish_count(const uint8_t* __restrict__ flags, int n, int* __restrict__ label,
                                                                   unsigned long long* __restrict__ count, int* __restrict__ n_slots) {
     __shared__ int keys[kCntHash];
     __shared__ unsigned int vals[kCntHash];
@@ -1267,14 +1276,14 @@ __global__ __launch_bounds__(kAggThreads) void k_f360_finish_count(const uint8_t
         if (e >= 0) atomicAdd(&vals[e], cnt);
         else atomicAdd(&count[key], (unsigned long long)cnt);
     };
-    const int base = blockIdx.x * kAggThreads * kCntPerThread;
+    const int base = blockIdx.x * kCntThreads * kCntPerThread;
     const bool lane0 = (threadIdx.x & 63) == 0;
     // two batched rounds of loads (flags and labels together -- a label is read whether or not its flag says it means anything -- then the
     // run starts' labels) instead of a dependent triple per pixel
     int fl[kCntPerThread], lab[kCntPerThread];
 #pragma unroll
     for (int j = 0; j < kCntPerThread; ++j) {
-        const int i = base + j * kAggThreads + (int)threadIdx.x;
+        const int i = base + j * kCntThreads + (int)threadIdx.x;
         fl[j] = i < n ? flags[i] : 0;
         lab[j] = label[i < n ? i : n - 1];
     }
@@ -1285,7 +1294,7 @@ __global__ __launch_bounds__(kAggThreads) void k_f360_finish_count(const uint8_t
         if ((fl[j] & 3) == 3) lab[j] = label[lab[j]];      // not a run start: its label is its run start, whose label is the root by now
 #pragma unroll
     for (int j = 0; j < kCntPerThread; ++j) {
-        const int i = base + j * kAggThreads + (int)threadIdx.x;
+        const int i = base + j * kCntThreads + (int)threadIdx.x;
         if ((fl[j] & 3) == 3) label[i] = lab[j];
     }
     int pend_key = -1;

@@ -719,7 +719,7 @@ int f360_planes_dev(F360State* ctx, int rows, int cols, int min_inliers, float a
         hipMemcpyToSymbol(HIP_SYMBOL(f360::g_dbg), z, sizeof(z));
     }
 #endif
-    hipLaunchKernelGGL(k_f360_finish_count, dim3((n + kAggThreads * kCntPerThread - 1) / (kAggThreads * kCntPerThread)), dim3(kAggThreads), 0,
+    hipLaunchKernelGGL(k_f360_finish_count, dim3((n + kCntThreads * kCntPerThread - 1) / (kCntThreads * kCntPerThread)), dim3(kCntThreads), 0,
                        ctx->stream, flags, n, ctx->f_label, ctx->f_count, ctx->f_nslots);
     const dim3 bagg(kAggThreads);
     hipLaunchKernelGGL(k_f360_assign_list, dim3(rows), dim3(kAssignThreads), 0, ctx->stream, run_starts, n_run_starts, cols, ctx->f_label, ctx->f_count,
