@@ -79,7 +79,10 @@ __device__ __forceinline__ bool depth_break(float da, float db, float factor) {
 // the last column are 0).  One block owns 256 columns x 8 rows; the depths of the tile + a one-pixel ring are computed once
 // into LDS (1.26 per pixel instead of 5), the 64 decisions of a wave row leave through one ballot.
 // History at 2048x1024: byte map + per-row distance + chamfer map as three per-pixel kernels 19.5 + 21 + 27 us.
-constexpr int kEdgeTW = 256, kEdgeTH = 8;
+#ifndef F360_EDGE_TH
+#define F360_EDGE_TH 8      // (round 6 sweep, 4096 x 2048 / 2048 x 1024: 4 rows 33.2 / 14.2 us, 8: 32.5 / 14.2, 12: 34.7 / 15.8, 16: 36.4 / 16.9 -- the ring's
+#endif                      // share of the point arithmetic does not matter: with the cloud's 12 B/px of stores the kernel is a write stream)
+constexpr int kEdgeTW = 256, kEdgeTH = F360_EDGE_TH;
 // CLOUD = true (rgbd360_frame_planes): the kernel is also the sphere-cloud stage -- it forms the points of its tile + ring from the
 // depth image and the angle tables (r360::sphere_point, the arithmetic of k_sphere_cloud) instead of loading them, and writes the
 // tile's own points to xyz.  The cloud as a kernel of its own is a 29 MB write-dominated stream with 5 us of fixed cost (13-14 us at
@@ -178,6 +181,7 @@ __global__ __launch_bounds__(kEdgeTW) void k_f360_edge_bits(const float* __restr
     }
     __syncthreads();
     const int c = c0 + t;
+#ifdef F360_EDGE_BRANCHY
 #pragma unroll
     for (int y = 0; y < kEdgeTH; ++y) {
         const int r = r0 + y;
@@ -197,6 +201,35 @@ __global__ __launch_bounds__(kEdgeTW) void k_f360_edge_bits(const float* __restr
         const int w = (c0 >> 6) + (t >> 6);
         if ((t & 63) == 0 && r < rows && w < pitch_words) bits[(size_t)r * pitch_words + w] = m;
     }
+#else
+    // Straight-line form (round 6): a pixel's pair tests are those it makes as the visited pixel -- with its right and its lower
+    // neighbour -- and those its left and upper neighbours made with it.  The lower-neighbour test of row y is the upper-neighbour
+    // test of row y + 1 (carried in a register), the right-neighbour test of column c the left-neighbour test of column c + 1 (the
+    // lane to the left, through the ballot word: bit l of `right` shifted up by one; lane 0 of a wave makes its own).  Every operand
+    // is in the tile's LDS ring, so nothing needs a bounds branch: the image-border conditions mask the results.  (The nested form:
+    // four tests per pixel behind 66 exec branches, 820 scalar instructions beside 846 vector ones.)
+    const bool c_in = c < cols, c_vis = c < cols - 1;                       // column inside / visited as `index`
+    const int lane = t & 63;
+    // the test the row above the tile's first row made with it (row r0 - 1 visited, its lower neighbour r0)
+    bool down_prev = depth_break(dep[0][t + 1], dep[1][t + 1], factor) & (r0 >= 1) & c_vis & (r0 - 1 < rows - 1);
+#pragma unroll
+    for (int y = 0; y < kEdgeTH; ++y) {
+        const int r = r0 + y;                                             // block-uniform
+        const bool r_vis = r < rows - 1;
+        const float d = dep[y + 1][t + 1];
+        const bool right = depth_break(d, dep[y + 1][t + 2], factor) & c_vis & r_vis;      // (r, c) visited, against (r, c + 1)
+        const bool down = depth_break(d, dep[y + 2][t + 1], factor) & c_vis & r_vis;       // ... against (r + 1, c)
+        // the left neighbour's `right`: pixel (r, c - 1) is visited when c - 1 < cols - 1, i.e. always for c < cols
+        const bool left0 = depth_break(dep[y + 1][t], d, factor) & (c >= 1) & r_vis;       // lane 0's own (its left neighbour sits in another wave)
+        const unsigned long long rm = __ballot(right);
+        const unsigned long long from_left = (rm << 1) | (__ballot(left0) & 1ull);
+        const bool edge = (right | down | down_prev | (((from_left >> lane) & 1ull) != 0)) & c_in & (r < rows);
+        down_prev = down;
+        const unsigned long long m = __ballot(edge);
+        const int w = (c0 >> 6) + (t >> 6);
+        if (lane == 0 && r < rows && w < pitch_words) bits[(size_t)r * pitch_words + w] = m;
+    }
+#endif
 }
 
 // Chamfer (1 / 1.4) distance to the nearest depth-change pixel, truncated at kF360R, from the bit mask: one block owns
