@@ -1711,6 +1711,7 @@ extern "C" int rgbd360_align_pinhole(rgbd360_ctx* ctx, const float guess[16], in
         last_depth = sqrt(P.e2d / P.nd);
         return 0;
     };
+    const bool pin_trace = knobs::debug("RGBD360_PIN_TRACE") != nullptr;      // debug builds: every trip's error, update, g and diag(H) on stderr
     for (int level = ctx->p.n_pyr - 1; level >= 0 && status == 0; --level) {
         if ((rc = pin_prepare_level(ctx, level)) != 0) return rc;
         float lambda = 0.01f;                 // RPI.h:4303 (double 0.01 used as a float scalar by Eigen)
@@ -1747,6 +1748,15 @@ extern "C" int rgbd360_align_pinhole(rgbd360_ctx* ctx, const float guess[16], in
             if ((rc = eval(level, pose_estim_temp, new_error)) != 0) return rc;
             cand = P;
             diff_error = error - new_error;
+            if (pin_trace) {
+                fprintf(stderr, "[pin trace] level %d it %d lambda %g: error %.10f -> %.10f, update", level, it, (double)lambda, error, new_error);
+                for (int k = 0; k < 6; ++k) fprintf(stderr, " %.9g", (double)update_pose[k]);
+                fprintf(stderr, "; g");
+                for (int k = 0; k < 6; ++k) fprintf(stderr, " %.9g", (double)g[k]);
+                fprintf(stderr, "; diag H");
+                for (int k = 0; k < 6; ++k) fprintf(stderr, " %.9g", (double)H[k * 6 + k]);
+                fprintf(stderr, "\n");
+            }
             if (diff_error > 0) {
                 lambda /= step;
                 memcpy(pose_estim, pose_estim_temp, sizeof(pose_estim));
