@@ -102,6 +102,13 @@ class RegisterPhotoICP {
         if (ctx_ && rgbd360_set_camera(ctx_, fx, fy, ox, oy) != 0) throw std::runtime_error(std::string("rgbd360_set_camera: ") + rgbd360_last_error(ctx_));
     }
     void setMaskSeams(bool on) { p_.mask_seams = on ? 1 : 0; reset(); }
+    /*! Not in the reference: the spherical warp in the reference's OWN arithmetic (asinf / atan2f / roundf as glibc computes them, Eigen's
+     *  product order) instead of the device definition -- target indices bit-equal to a CPU build of the reference, the pass ~1.8 x
+     *  slower (rgbd360_set_index_arithmetic). */
+    void setReferenceArithmetic(bool on) {
+        index_libm_ = on ? 1 : 0;
+        if (ctx_ && rgbd360_set_index_arithmetic(ctx_, index_libm_) != 0) throw std::runtime_error(std::string("rgbd360_set_index_arithmetic: ") + rgbd360_last_error(ctx_));
+    }
 
     // RPI.h:498-516 / 480-494
     void setTargetFrame(const ImageView& rgb, const ImageView& depth) { set(true, rgb, depth); }
@@ -300,6 +307,7 @@ class RegisterPhotoICP {
    private:
     rgbd360_params p_;
     rgbd360_ctx* ctx_ = nullptr;
+    int index_libm_ = 0;
     Mat4f relPose_ = Mat4f::Identity();
     Mat6f hessian_{};
     std::array<float, 6> gradient_{};
@@ -318,6 +326,7 @@ class RegisterPhotoICP {
             if (rc != 0) throw std::runtime_error("rgbd360_create failed (" + std::to_string(rc) + "): no usable HIP device; there is no CPU fallback");
             if (have_cam_) rgbd360_set_camera(ctx_, cam_[0], cam_[1], cam_[2], cam_[3]);
             if (use_saliency_) rgbd360_use_saliency(ctx_, 1, 0.01f);
+            if (index_libm_) rgbd360_set_index_arithmetic(ctx_, index_libm_);
         }
         return ctx_;
     }

@@ -77,6 +77,10 @@ int rgbd360_frame_planes_stage_timing(rgbd360_ctx* ctx, int on);
 int rgbd360_frame_planes_stage_times(rgbd360_ctx* ctx, float us[3]);
 
 int rgbd360_selftest_math(rgbd360_ctx* ctx, uint32_t first_bits, uint32_t count, unsigned long long mismatches[3]);
+/* csrc/libm_f32.h (asinf / atanf / roundf / atan2f restated operation for operation, what rgbd360_set_index_arithmetic(ctx, 1) computes
+ * with) as the DEVICE evaluates it, against the C library of this process: the floats first_bits .. first_bits + count - 1 through the
+ * one-argument functions (asinf where |x| <= 1.5), `count` drawn pairs through atan2f.  mismatches[4] = {asinf, atanf, roundf, atan2f}. */
+int rgbd360_selftest_libm(rgbd360_ctx* ctx, uint32_t first_bits, uint32_t count, unsigned long long mismatches[4]);
 
 #ifdef __cplusplus
 }

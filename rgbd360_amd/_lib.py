@@ -13,7 +13,7 @@ SYMBOLS = [
     "rgbd360_set_source", "rgbd360_set_target_dev", "rgbd360_set_source_dev", "rgbd360_promote_source_to_target",
     "rgbd360_align360", "rgbd360_align360_begin", "rgbd360_align360_finish", "rgbd360_align360_batch", "rgbd360_align360_batch_dev", "rgbd360_level_dims", "rgbd360_get_plane", "rgbd360_get_lut", "rgbd360_eval", "rgbd360_eval_occ",
     "rgbd360_warp_indices", "rgbd360_gn_step", "rgbd360_forced_iters", "rgbd360_time_eval_kernel", "rgbd360_stream",
-    "rgbd360_sync", "rgbd360_device_count", "rgbd360_sphere_cloud", "rgbd360_selftest_math", "rgbd360_time_solve_kernel", "rgbd360_normals", "rgbd360_distance_map",
+    "rgbd360_sync", "rgbd360_device_count", "rgbd360_sphere_cloud", "rgbd360_selftest_math", "rgbd360_selftest_libm", "rgbd360_set_index_arithmetic", "rgbd360_get_index_arithmetic", "rgbd360_time_solve_kernel", "rgbd360_normals", "rgbd360_distance_map",
     "rgbd360_plane_fit", "rgbd360_frame_planes", "rgbd360_frame_planes_dev", "rgbd360_load_frame_bin", "rgbd360_stitch_sphere",
     "rgbd360_set_camera", "rgbd360_align_pinhole", "rgbd360_eval_pinhole", "rgbd360_eval_pinhole_occ", "rgbd360_use_saliency", "rgbd360_warp_indices_pinhole",
     "rgbd360_pbmap_default_params", "rgbd360_register_planes", "rgbd360_bilateral_filter",
@@ -141,6 +141,9 @@ def load() -> C.CDLL:
     L.rgbd360_load_frame_bin.argtypes = [C.c_char_p, vp, vp, C.POINTER(i32), C.POINTER(i32)]
     L.rgbd360_stitch_sphere.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp, C.POINTER(i32), C.POINTER(i32)]
     L.rgbd360_selftest_math.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
+    L.rgbd360_selftest_libm.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
+    L.rgbd360_set_index_arithmetic.argtypes = [vp, C.c_int]
+    L.rgbd360_get_index_arithmetic.argtypes = [vp]
     L.rgbd360_sphere_cloud.argtypes = [vp, vp, C.c_size_t, i32, i32, i32, i32, f32p]
     L.rgbd360_pbmap_default_params.argtypes = [C.POINTER(PbmapParams), i32]
     L.rgbd360_pbmap_default_params.restype = None

@@ -17,7 +17,7 @@ _CSRC = os.path.join(_HERE, "csrc")
 # not rebuild the Frame360 kernels and vice versa; the units compile in parallel.
 _SHARED = ["knobs.h", "host_wait.h", "device_math.h", "f360_state.h"]
 UNITS = {
-    "rgbd360_api.hip": ["photo_icp_kernels.h", "occlusion_kernels.h", "pinhole_kernels.h", "gn_math.h", "sequence_engine.h", "rig_dense.h", "multi_gpu.h"] + _SHARED,
+    "rgbd360_api.hip": ["photo_icp_kernels.h", "occlusion_kernels.h", "pinhole_kernels.h", "gn_math.h", "sequence_engine.h", "rig_dense.h", "multi_gpu.h", "libm_f32.h"] + _SHARED,
     "rgbd360_frame360.hip": ["frame360_kernels.h", "pbmap_register.h"] + _SHARED,
     "rgbd360_host.cpp": ["depth_model.h", "pbmap_register.h"],
 }

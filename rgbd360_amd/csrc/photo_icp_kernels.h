@@ -21,6 +21,7 @@
 
 #include "device_math.h"
 #include "gn_math.h"
+#include "libm_f32.h"
 
 namespace r360 {
 
@@ -49,6 +50,7 @@ struct LevelDev {
     const float2* src2 = nullptr;                            // {depth, Isrc} per source pixel (lock-step engine)
     const float2 *tabT = nullptr, *tabP = nullptr;           // {sin, cos} of theta per column / of phi per row (host libm, RPI.h:4556-4571)
     float min_depth = 0.f, max_depth = 0.f;
+    int libm = 0;            // 1: the warp in the REFERENCE's arithmetic (libm_f32.h), rgbd360_set_index_arithmetic
 };
 
 struct EvalConsts {
@@ -166,9 +168,39 @@ __device__ __forceinline__ WarpConsts make_warp_consts(const PoseRT& T, const Le
     asm volatile("" : "+v"(c.tx), "+v"(c.ty), "+v"(c.tz), "+v"(c.half_nRows), "+v"(c.pi_k));
     return c;
 }
+// The same front end in the REFERENCE's arithmetic (rgbd360_set_index_arithmetic(ctx, 1); the oracle's math_mode 0 is this sequence on the
+// CPU, with the C library's functions): Eigen's fixed-size product without fused multiply-adds, norm(), 1 / dist, asinf, atan2f + the
+// double PI, roundf -- RPI.h:2663-2684 as compiled on the reference's platform, asinf / atan2f restated operation for operation
+// (libm_f32.h).  Indices, visibility and d^2 are bit-equal to the reference's; ~110 instructions instead of 40, so the fast
+// definition above stays the default.
+__device__ __forceinline__ void warp_pixel_libm(const PoseRT& T, const WarpConsts& wc, float px, float py, float pz, const LevelDev& lv,
+                                             float& X, float& Y, float& Z, float& d2, int& tr, int& tc) {
+    X = ((T.r00 * px + T.r01 * py) + T.r02 * pz) + wc.tx;
+    Y = ((T.r10 * px + T.r11 * py) + T.r12 * pz) + wc.ty;
+    Z = ((T.r20 * px + T.r21 * py) + T.r22 * pz) + wc.tz;
+    d2 = (X * X + Y * Y) + Z * Z;
+    const float dist = libm32::sqrt32(d2);
+    const float dist_inv = libm32::div32(1.f, dist);
+    const float phi = libm32::asinf_(X * dist_inv);
+    const float theta = (float)((double)libm32::atan2f_(Y, Z) + r360::kPI);
+    const float fr = libm32::roundf_(lv.half_nRows - phi * lv.angle_res_inv);
+    const float fc = libm32::roundf_(theta * lv.angle_res_inv);
+    // (int) of a float as x86 converts it: out of range or NaN -> INT_MIN (never a visible index)
+    tr = (fr >= -2147483648.f && fr < 2147483648.f) ? (int)fr : (int)0x80000000;
+    tc = (fc >= -2147483648.f && fc < 2147483648.f) ? (int)fc : (int)0x80000000;
+}
 __device__ __forceinline__ void warp_pixel_rc(const PoseRT& T, const WarpConsts& wc, float px, float py, float pz,
                                               const LevelDev& lv, float& X, float& Y, float& Z, float& rho2, float& d2,
                                               int& tr, int& tc, unsigned long long& vis_mask, float& inv_rho) {
+#ifndef RGBD360_NO_LIBM_WARP                          // (A/B builds of the default path without the branch: tools/ab_libs.py)
+    if (lv.libm) {                                    // uniform (a kernel argument)
+        warp_pixel_libm(T, wc, px, py, pz, lv, X, Y, Z, d2, tr, tc);
+        rho2 = fmaf(Z, Z, Y * Y);                     // float32 data of the Jacobian, like inv_rho
+        (void)sqrt_rn(rho2, inv_rho);
+        vis_mask = __builtin_amdgcn_ballot_w64((unsigned)tr < (unsigned)lv.rows) & __builtin_amdgcn_ballot_w64((unsigned)tc < (unsigned)lv.cols);
+        return;
+    }
+#endif
     X = fmaf(T.r02, pz, fmaf(T.r01, py, fmaf(T.r00, px, wc.tx)));
     Y = fmaf(T.r12, pz, fmaf(T.r11, py, fmaf(T.r10, px, wc.ty)));
     Z = fmaf(T.r22, pz, fmaf(T.r21, py, fmaf(T.r20, px, wc.tz)));
@@ -1663,6 +1695,39 @@ __global__ void k_selftest_math(unsigned first_bits, unsigned count, unsigned lo
     if (bad_s) atomicAdd(&mismatches[0], (unsigned long long)bad_s);
     if (bad_r) atomicAdd(&mismatches[1], (unsigned long long)bad_r);
     if (bad_i) atomicAdd(&mismatches[2], (unsigned long long)bad_i);
+}
+
+// libm_f32.h on the device: asinf_ / atanf_ / roundf_ of the floats first_bits + k, atan2f_ of pairs drawn from k (the host repeats the
+// draw: selftest_libm_pair), written out for the host to compare with the C library's own results
+__host__ __device__ __forceinline__ void selftest_libm_pair(unsigned k, float& y, float& x) {
+    unsigned long long s = 0x9E3779B97F4A7C15ull * (k + 1ull);
+    s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+    const unsigned long long r = s;
+    s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+    const unsigned long long q = s;
+    unsigned a = (unsigned)r, b = (unsigned)q;
+    a = (a & 0x807fffffu) | ((87u + (unsigned)((r >> 32) % 81ull)) << 23);      // binades 2^-40 .. 2^40
+    b = (b & 0x807fffffu) | ((87u + (unsigned)((q >> 32) % 81ull)) << 23);
+    const unsigned kind = (unsigned)(r >> 40) & 63u;
+    if (kind == 0) a &= 0x80000000u;
+    if (kind == 1) b &= 0x80000000u;
+    if (kind == 2) b = 0x3f800000u;
+    if (kind == 3) b = (b & 0x80000000u) | (a & 0x7fffffffu);
+    if (kind == 4) b = (b & 0x807fffffu) | (a & 0x7f800000u);
+    y = libm32::u2f(a);
+    x = libm32::u2f(b);
+}
+__global__ void k_selftest_libm(unsigned first_bits, unsigned count, float* __restrict__ out /*[4][count]*/) {
+    const unsigned stride = gridDim.x * blockDim.x;
+    for (unsigned k = blockIdx.x * blockDim.x + threadIdx.x; k < count; k += stride) {
+        const float v = libm32::u2f(first_bits + k);
+        out[k] = libm32::asinf_(v);
+        out[(size_t)count + k] = libm32::atanf_(v);
+        out[2 * (size_t)count + k] = libm32::roundf_(v);
+        float y, x;
+        selftest_libm_pair(first_bits + k, y, x);
+        out[3 * (size_t)count + k] = libm32::atan2f_(y, x);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -43,6 +43,7 @@ struct Level {
     float *sinT = nullptr, *cosT = nullptr, *sinP = nullptr, *cosP = nullptr;
     float2 *tabT = nullptr, *tabP = nullptr;      // the same values interleaved {sin, cos}: one 8-byte load per pixel in the recompute form of the pass
     int nblocks = 0, chunk = 0;
+    int libm = 0;                    // rgbd360_set_index_arithmetic: the warp in the reference's libm arithmetic
 };
 
 }  // namespace
@@ -104,6 +105,7 @@ struct rgbd360_ctx {
     int occ_gen = 0;                                   // generation tag of the head entries (no memset between passes)
     size_t occ_n = 0;
     int max_eval_blocks = 256;    // grid cap of the fused pass (debug knob RGBD360_EVAL_BLOCKS, csrc/knobs.h)
+    int index_libm = 0;           // rgbd360_set_index_arithmetic: 1 = the spherical warp in the reference's libm arithmetic
     unsigned char* arena = nullptr;   // ONE allocation behind every per-level buffer of the context (planes, records, angle tables)
     std::string err;
 };
@@ -221,6 +223,7 @@ int ensure_levels(rgbd360_ctx* ctx, int rows, int cols) {
         chunk = ((chunk + kEvalThreads - 1) / kEvalThreads) * kEvalThreads;
         L.chunk = chunk;
         L.nblocks = (L.n + chunk - 1) / chunk;
+        L.libm = ctx->index_libm;
         if (L.nblocks > max_blocks) max_blocks = L.nblocks;
         r /= 2; c /= 2;
     }
@@ -244,6 +247,7 @@ LevelDev level_dev(const Level& L) {
     d.pi_k = (float)(kPI * (double)L.angle_res_inv);
     d.src = L.srcRec; d.trgP = L.trgP; d.trgD = L.trgD;
     d.depth_src = L.depthSrc; d.gray_src = L.graySrc; d.tabT = L.tabT; d.tabP = L.tabP;
+    d.libm = L.libm;
     return d;
 }
 // Levels of this many pixels and more run the per-pixel pass in its recompute form (SRC 1, photo_icp_kernels.h: 8 B per source pixel less;
@@ -977,6 +981,7 @@ static int align360_batch_lockstep(rgbd360_ctx* ctx, int n_frames, const uint8_t
             SeqEngine* E = nullptr;
             std::string err;
             const int rc = seq_create(ctx->p, cnt[0], rows, cols, ctx->max_eval_blocks, &E, &err);
+            if (rc == 0) E->libm = ctx->index_libm;
             if (rc) return fail(ctx, rc, err.c_str());
             ctx->engines.push_back(E);
         }
@@ -1329,6 +1334,7 @@ int rgbd360_forced_iters_batch(rgbd360_ctx* ctx, int n_pairs, const uint8_t* rgb
     SeqEngine* E = nullptr;
     std::string err;
     int rc = seq_create(ctx->p, n_pairs, rows, cols, ctx->max_eval_blocks, &E, &err);
+    if (rc == 0) E->libm = ctx->index_libm;
     if (rc) return fail(ctx, rc, err.c_str());
     const size_t dpx = depth_type == 0 ? 2 : 4;
     const size_t fr = (size_t)rows * cols * 3, fd = (size_t)rows * cols * dpx;
@@ -1464,6 +1470,53 @@ int rgbd360_selftest_math(rgbd360_ctx* ctx, uint32_t first_bits, uint32_t count,
         e = hipMemcpyAsync(mismatches, d, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    hipFree(d);
+    HIPC(ctx, e);
+    return 0;
+}
+
+// libm_f32.h as the DEVICE compiles it against the C library this process links (the reference's asinf / atanf / roundf / atan2f): the floats
+// first_bits .. first_bits + count - 1 through the three one-argument functions, `count` drawn pairs through atan2f.  mismatches[4].
+int rgbd360_selftest_libm(rgbd360_ctx* ctx, uint32_t first_bits, uint32_t count, unsigned long long mismatches[4]) {
+    if (!ctx || !mismatches) return -1;
+    hipSetDevice(ctx->p.device);
+    for (int k = 0; k < 4; ++k) mismatches[k] = 0;
+    constexpr uint32_t kChunk = 1u << 22;
+    float* d = nullptr;
+    HIPC(ctx, hipMalloc(&d, 4 * (size_t)kChunk * sizeof(float)));
+    std::vector<float> h(4 * (size_t)kChunk);
+    auto differ = [](float a, float b) {
+        uint32_t x, y;
+        memcpy(&x, &a, 4); memcpy(&y, &b, 4);
+        return x != y && !((x & 0x7fffffffu) > 0x7f800000u && (y & 0x7fffffffu) > 0x7f800000u);      // (any NaN equals any NaN)
+    };
+    hipError_t e = hipSuccess;
+    int shown = 0;
+    for (uint64_t done = 0; done < count && e == hipSuccess; done += kChunk) {
+        const uint32_t n = (uint32_t)std::min<uint64_t>(kChunk, count - done), first = first_bits + (uint32_t)done;
+        hipLaunchKernelGGL(k_selftest_libm, dim3(2048), dim3(256), 0, ctx->stream, first, n, d);
+        e = hipMemcpyAsync(h.data(), d, 4 * (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) break;
+        for (uint32_t k = 0; k < n; ++k) {
+            float v;
+            const uint32_t u = first + k;
+            memcpy(&v, &u, 4);
+            if ((u & 0x7fffffffu) <= 0x3fc00000u) {
+                const bool bad = differ(h[k], asinf(v));
+                mismatches[0] += bad;
+                if (bad && shown < 6 && getenv("RGBD360_SELFTEST_VERBOSE")) {
+                    ++shown;
+                    fprintf(stderr, "[selftest_libm] asinf(%.9g = 0x%08x): device %.9g, library %.9g\n", (double)v, u, (double)h[k], (double)asinf(v));
+                }
+            }
+            mismatches[1] += differ(h[(size_t)n + k], atanf(v));
+            mismatches[2] += differ(h[2 * (size_t)n + k], roundf(v));
+            float y, x;
+            selftest_libm_pair(u, y, x);
+            mismatches[3] += differ(h[3 * (size_t)n + k], atan2f(y, x));
+        }
+    }
     hipFree(d);
     HIPC(ctx, e);
     return 0;
@@ -1620,6 +1673,17 @@ extern "C" int rgbd360_set_camera(rgbd360_ctx* ctx, float fx, float fy, float ox
     ctx->have_cam = true;
     return 0;
 }
+
+extern "C" int rgbd360_set_index_arithmetic(rgbd360_ctx* ctx, int mode) {
+    if (!ctx) return -1;
+    if (mode != 0 && mode != 1) return fail(ctx, -1, "index arithmetic: 0 (device definition) or 1 (the reference's libm)");
+    if (ctx->al_active) return fail(ctx, -6, "an alignment is in flight");
+    ctx->index_libm = mode;
+    for (Level& L : ctx->levels) L.libm = mode;
+    for (SeqEngine* E : ctx->engines) E->libm = mode;
+    return 0;
+}
+extern "C" int rgbd360_get_index_arithmetic(rgbd360_ctx* ctx) { return ctx ? ctx->index_libm : -1; }
 
 extern "C" int rgbd360_use_saliency(rgbd360_ctx* ctx, int on, float thres_saliency) {
     if (!ctx) return -1;

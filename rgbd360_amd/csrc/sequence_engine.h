@@ -42,6 +42,7 @@ struct SeqEngine {
     size_t stage_rgb_frame = 0, stage_depth_frame = 0;
     int tb = 0;                       // which target-record buffer holds the TARGETS of the round
     int max_eval_blocks = 256;
+    int libm = 0;                 // the warp in the reference's libm arithmetic (the owning context's rgbd360_set_index_arithmetic)
     int chunk_top = 8, chunk_mid = 4, chunk_l0 = 4;      // {pass, solve} pairs enqueued ahead per level and visit
     std::string err;
 };
@@ -184,6 +185,7 @@ void seq_launch_eval(SeqEngine* E, int level, int method) {
     const SeqLevel& L = E->levels[level];
     LevelDev lv = seq_level_dev(L, E->tb);
     lv.min_depth = E->p.min_depth; lv.max_depth = E->p.max_depth;
+    lv.libm = E->libm;
     const EvalConsts ec = eval_consts(E->p);
     const dim3 g(L.nblocks, E->P), b(kEvalThreadsBatch);
 #define LAUNCHB(M, S) hipLaunchKernelGGL((k_eval_b<M, true, S>), g, b, 0, E->stream, E->d_states, lv.src, lv.n, L.chunk, level, L.nblocks, E->d_partials, E->partials_stride, lv, ec)

@@ -113,6 +113,8 @@ class RegisterPhotoICP:
                 self._check(self._L.rgbd360_set_camera(self._h, *self._cam))
             if getattr(self, "_use_saliency", None):
                 self._check(self._L.rgbd360_use_saliency(self._h, int(self._use_saliency[0]), self._use_saliency[1]))
+            if getattr(self, "_index_arithmetic", 0):
+                self._check(self._L.rgbd360_set_index_arithmetic(self._h, int(self._index_arithmetic)))
         return self._h
 
     def close(self):
@@ -453,6 +455,19 @@ class RegisterPhotoICP:
         us = C.c_float()
         self._check(self._L.rgbd360_time_solve_kernel(self._ctx(), level, mode, reps, C.byref(us)))
         return float(us.value)
+
+    def set_index_arithmetic(self, mode: int):
+        """rgbd360_set_index_arithmetic: 0 = the device definition of the spherical warp (default), 1 = the reference's libm arithmetic
+        (asinf / atan2f / roundf restated operation for operation: target indices bit-equal to the reference's own)."""
+        self._index_arithmetic = int(mode)
+        if self._h is not None:
+            self._check(self._L.rgbd360_set_index_arithmetic(self._h, int(mode)))
+
+    def selftest_libm(self, first_bits: int, count: int):
+        """(asinf, atanf, roundf, atan2f) mismatches of csrc/libm_f32.h on the device against this process's C library."""
+        out = np.zeros(4, dtype=np.uint64)
+        self._check(self._L.rgbd360_selftest_libm(self._ctx(), first_bits, count, _ptr(out)))
+        return tuple(int(v) for v in out)
 
     def selftest_math(self, first_bits: int, count: int):
         out = np.zeros(3, dtype=np.uint64)

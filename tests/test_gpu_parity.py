@@ -2247,3 +2247,78 @@ def test_per_context_sequence_route_equals_the_lockstep_engines(hip_lib):
     reg.debug_set_sequence_route(True, 3)
     p0, s0, i0 = reg.alignSequence(frames, method=2, n_inflight=3)
     assert np.array_equal(p0, p1) and np.array_equal(s0, s1) and np.array_equal(i0, i1) and not s1.any()
+
+
+# ---- the spherical warp in the reference's own arithmetic (rgbd360_set_index_arithmetic(ctx, 1), csrc/libm_f32.h) ----------------------
+def test_libm_restatement_on_the_device_equals_the_c_library(hip_lib):
+    """asinf / atanf / roundf / atan2f as csrc/libm_f32.h restates them (glibc 2.35's fdlibm float code, operation for operation), evaluated
+    by the DEVICE, against this process's C library: every float of four 2^24-wide windows (around 0.5 and 1 where asinf changes its branch,
+    the arctangent's reduction ranges, the index range of roundf) and 2^26 drawn pairs.  (The host compile of the same header is checked
+    against the library on every float by tools/libm_f32_check.cpp.)"""
+    reg = _mk(hip_lib, 2)
+    for first in (0x3e800000, 0x3f800000 - (1 << 23), 0x40000000, 0xbf000000, 0x44000000, 0x32000000 - (1 << 23)):
+        bad = reg.selftest_libm(first, 1 << 24)
+        assert bad == (0, 0, 0, 0), (hex(first), bad)
+
+
+@pytest.mark.parametrize("W,H", [(256, 128), (2048, 1024)])
+def test_warp_indices_in_the_reference_arithmetic_are_bit_exact(hip_lib, oracle_mod, W, H):
+    """rgbd360_set_index_arithmetic(ctx, 1): every target index and the visibility of every source pixel equal the oracle's math_mode 0
+    (the C library's asinf / atan2f / roundf on the CPU) -- at the identity, the true motion and perturbed poses, on every level.  In the
+    default arithmetic 8e-5 of them differ by one pixel (test_warp_indices_against_the_reference_arithmetic_full_size)."""
+    pair = synth.make_pair(W, H, seed=11)
+    reg, ora, T = _pair_ctx(hip_lib, oracle_mod, pair, n_pyr=3, math_mode=0)
+    reg.set_index_arithmetic(1)
+    flips_default = 0
+    for level in range(3):
+        for P in _poses(T):
+            got = reg.warp_indices(level, P)
+            want = ora.warp_indices(level, P)
+            assert np.array_equal(got, want), (level, int((got != want).any(axis=1).sum()))
+    reg.set_index_arithmetic(0)
+    got = reg.warp_indices(0, T)
+    flips_default = int((got != ora.warp_indices(0, T)).any(axis=1).sum())
+    if W >= 2048:
+        assert 0 < flips_default < 2e-4 * W * H          # what the default definition leaves
+
+
+@pytest.mark.parametrize("method", [0, 1, 2])
+def test_eval_counts_in_the_reference_arithmetic_are_exact(hip_lib, oracle_mod, small_pair, method):
+    """With the reference's warp arithmetic the pass's pixel counts equal the libm oracle's exactly, its sums to float rounding."""
+    reg, ora, T = _pair_ctx(hip_lib, oracle_mod, small_pair, math_mode=0)
+    reg.set_index_arithmetic(1)
+    for level in range(3):
+        for P in _poses(T):
+            e = reg.eval(level, P, method)
+            rms, err2, nvalid = ora.error(level, P, method)
+            H, g, Hd, gd, nvis = ora.hessgrad(level, P, method)
+            assert e["n_valid"] == nvalid and e["n_visible"] == nvis, (level, e["n_valid"], nvalid, e["n_visible"], nvis)
+            assert abs(e["err2"] - err2) <= ERR2_RTOL * max(1.0, abs(err2)), (e["err2"], err2)
+            assert np.abs(e["H64"] - Hd).max() <= HG_RTOL * np.abs(Hd).max()
+
+
+@pytest.mark.parametrize("method,occlusion", [(0, 0), (2, 0), (2, 1), (1, 2)])
+def test_alignment_in_the_reference_arithmetic_follows_the_libm_oracle(hip_lib, oracle_mod, small_pair, method, occlusion):
+    """The whole alignment with the reference's warp arithmetic against the libm oracle with float64 sums (math_mode 0, reduce_mode 1): same
+    status, same accept / reject sequence, pose within the device tolerance -- the comparison that costs 1e-4 rad in the default arithmetic
+    wherever an index flips."""
+    pair = synth.add_occluder(small_pair) if occlusion else small_pair
+    (rgbA, dA), (rgbB, dB), T = pair
+    reg = _mk(hip_lib, 3)
+    reg.set_index_arithmetic(1)
+    reg.setTargetFrame(rgbA, dA)
+    reg.setSourceFrame(rgbB, dB)
+    ora = oracle_mod.Oracle(n_pyr=3, math_mode=0, reduce_mode=1)
+    ora.set_target(rgbA, dA)
+    ora.set_source(rgbB, dB)
+    rc = reg.alignFrames360(np.eye(4), method, occlusion)
+    st, pose_ref = ora.align360(np.eye(4), method, occlusion)
+    assert rc == st == 0
+    assert reg.num_iterations == list(ora.result.iters)[:3]
+    rot, trans = synth.pose_error(reg.getOptimalPose(), pose_ref)
+    assert rot <= POSE_TOL_DEV and trans <= POSE_TOL_DEV, (rot, trans)
+    # the sequence entry follows the context's setting
+    poses, status, iters = reg.alignSequence([(rgbA, dA), (rgbB, dB)], method=method, occlusion=occlusion)
+    assert status[0] == 0 and list(iters[0]) == reg.num_iterations
+    rot, trans = synth.pose_error(poses[0], pose_ref)
+    assert rot <= POSE_TOL_DEV and trans <= POSE_TOL_DEV, (rot, trans)

@@ -112,6 +112,45 @@ def test_sample_pair_alignment_matches_the_oracle(hip_lib, oracle_mod, panos, go
         assert 0.05 < trans0 < 0.6 and rot0 < 0.1
 
 
+@pytest.mark.parametrize("method,occlusion", [(0, 0), (1, 0), (2, 0), (2, 1), (0, 2), (1, 2), (2, 2)])
+def test_sample_pair_alignment_in_the_reference_arithmetic(hip_lib, oracle_mod, panos, gold, method, occlusion):
+    """The same alignments with rgbd360_set_index_arithmetic(ctx, 1) -- the warp in the reference's own arithmetic (csrc/libm_f32.h) --
+    against the COMMITTED record of the reference-faithful oracle (libm, float32 accumulators; generated where the reference's samples
+    are): status, iterations per level, and the pose far inside the north-star tolerance; every warped index of the finest level at the
+    recorded pose equals the live libm oracle's."""
+    from rgbd360_amd.register import RegisterPhotoICP
+    reg = RegisterPhotoICP()
+    reg.setNumPyr(4)
+    reg.set_index_arithmetic(1)
+    reg.setTargetFrame(*panos[0])
+    reg.setSourceFrame(*panos[1])
+    rc = reg.alignFrames360(np.eye(4), method, occlusion)
+    rec = gold["alignments"]["m%d_o%d" % (method, occlusion)]["libm"]
+    iters = list(reg.num_iterations)
+    # live: the libm warp with float64 sums (the device's sums are float64 partials too)
+    ora = oracle_mod.Oracle(n_pyr=4, math_mode=0, reduce_mode=1)
+    ora.set_target(*panos[0])
+    ora.set_source(*panos[1])
+    st, pose_live = ora.align360(np.eye(4), method, occlusion)
+    assert rc == st == rec["status"] == 0
+    assert iters == list(ora.result.iters)[:4], (iters, list(ora.result.iters)[:4])
+    rot, trans = synth.pose_error(reg.getOptimalPose(), pose_live)
+    assert rot <= POSE_TOL_DEV and trans <= 4 * POSE_TOL_DEV, (rot, trans)
+    # committed: libm warp + the reference's float32 accumulators.  Photo + depth with the z-buffer gate (2, 2) ends level 2 after 3 steps
+    # there (and in the device-arithmetic record) and after 10 with the libm warp and float64 sums -- a step the accumulators decide; with
+    # three levels at their iteration limit the two runs then end 9e-3 rad / 6e-2 m apart.  The device follows the float64-sum oracle to
+    # 1e-9; a float32 accumulation in the reference's order is sequential by definition.
+    rot_r, trans_r = synth.pose_error(reg.getOptimalPose(), np.array(rec["pose"]))
+    print(f"sample pair m{method} o{occlusion}, reference arithmetic: iters {iters} (record {rec['iters']}), vs the live libm oracle {rot:.2e} rad {trans:.2e} m, "
+          f"vs the committed libm record {rot_r:.2e} rad {trans_r:.2e} m")
+    if iters == rec["iters"]:
+        assert rot_r <= 2e-5 and trans_r <= 1e-4, (rot_r, trans_r)
+    else:
+        assert (method, occlusion) == (2, 2) and iters == [10, 10, 10, 7] and rec["iters"] == [10, 10, 3, 7], (iters, rec["iters"])
+    P = np.array(rec["pose"])
+    assert np.array_equal(reg.warp_indices(0, P), ora.warp_indices(0, P))
+
+
 def test_sample_pair_occlusion1_single_modality_has_no_valid_pixel(hip_lib, oracle_mod, panos):
     """Occ1 counts a pixel only where BOTH residuals exist (RPI.h:3298-3340): photometric-only and depth-only runs end with status 2
     and the guess, on the device as in the oracle."""

@@ -16,6 +16,10 @@ from oracle import oracle as O
 O.set_num_threads(min(16, os.cpu_count() or 1))
 n_trials = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 17)      # [seed]: another draw of cases
+# [libm]: the device in the reference's warp arithmetic (rgbd360_set_index_arithmetic(ctx, 1)); the device-arithmetic oracle is then the
+# libm warp with float64 sums (modes 0, 1), and the libm + float32-accumulator run should take the same sequence wherever the accumulators
+# do not decide a step
+LIBM = len(sys.argv) > 3 and sys.argv[3] == "libm"
 bad = 0
 near = 0
 acc = 0          # ... of which the libm warp with float64 sums takes the device's sequence (the float32 accumulators made the difference)
@@ -46,9 +50,11 @@ for t in range(n_trials):
         guess = synth.make_pose(synth.rodrigues(rng.normal(size=3), 0.01), rng.normal(size=3) * 0.01)
     reg = RegisterPhotoICP()
     reg.setNumPyr(n_pyr)
+    if LIBM:
+        reg.set_index_arithmetic(1)
     reg.setTargetFrame(rgbA, dA)
     reg.setSourceFrame(rgbB, dB)
-    ora = O.Oracle(n_pyr=n_pyr, math_mode=1, reduce_mode=1)
+    ora = O.Oracle(n_pyr=n_pyr, math_mode=0 if LIBM else 1, reduce_mode=1)
     ora.set_target(rgbA, dA)
     ora.set_source(rgbB, dB)
     rc = reg.alignFrames360(guess, method, occlusion)
@@ -103,6 +109,6 @@ for t in range(n_trials):
           "libm oracle %.1e rad %.1e m%s -> %s" % (t, W, H, n_pyr, method, occlusion, trans, rot, "float32" if f32 else "uint16", " spoiled" if spoil else "",
                                                   " occluder" if occluder else "", "yes" if not np.array_equal(guess, np.eye(4)) else "no",
                                                   rc, st, it_gpu, it_ora, r1, t1, r0, t0, note, "ok" if good else "FAIL"), flush=True)
-print("align soak: %d / %d trials ok (%d with another accept / reject sequence under libm + float32 accumulators; in %d of them libm + float64 sums takes the device's)" % (
+print(("align soak, device in the reference's warp arithmetic: " if LIBM else "align soak: ") + "%d / %d trials ok (%d with another accept / reject sequence under libm + float32 accumulators; in %d of them libm + float64 sums takes the device's)" % (
     n_trials - bad, n_trials, near, acc))
 sys.exit(1 if bad else 0)
