@@ -493,6 +493,29 @@ def main():
                                "iters_per_level": iters_nat, "status": rc,
                                "pose_err_vs_ground_truth": dict(zip(("rot_rad", "trans_m"), synth.pose_error(pose_gpu, T_gt)))}
         result["setup_s"] = {"render_pair": t_gen}
+        # ---- the same step with the warp in the REFERENCE's own arithmetic (rgbd360_set_index_arithmetic(ctx, 1): asinf / atan2f / roundf as
+        #      glibc computes them, target indices bit-equal to a CPU build of the reference).  Information, not `value`: the default is the
+        #      device definition. ----
+        if n_gpus == 1:
+            try:
+                reg.set_index_arithmetic(1)
+                itl = min((reg.forced_iters(0, start_pose, method, 200) for _ in range(3)), key=lambda r: r["elapsed_ms"])
+                pl, _bt = avg_kernel_us(lambda: reg.time_eval_kernel(0, start_pose, method, True, 30))
+                reg.alignFrames360(np.eye(4), method)
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    reg.alignFrames360(np.eye(4), method)
+                al = (time.perf_counter() - t0) / 10
+                result["reference_arithmetic"] = {
+                    "gn_iterations_per_s": 200 / (itl["elapsed_ms"] * 1e-3), "ms_per_step": itl["elapsed_ms"] / 200, "pass_avg_us": pl,
+                    "full_pyramid_ms": al * 1e3, "iters_per_level": list(reg.num_iterations),
+                    "note": ("rgbd360_set_index_arithmetic(ctx, 1): the spherical warp as the reference computes it (csrc/libm_f32.h: glibc's asinf / "
+                             "atan2f / roundf operation for operation) -- target indices bit-exact against the libm oracle "
+                             "(tests: *_in_the_reference_arithmetic_*); opt-in, not the configuration `value` is measured on")}
+            except Exception as e:      # (a measurement block must not cost the line)
+                result["reference_arithmetic"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+            finally:
+                reg.set_index_arithmetic(0)
 
         # ---- the same kernel at 4096x2048 (BASELINE.json configs[4]); PHOTO_DEPTH (335 MB) exceeds the Infinity Cache,
         #      PHOTO_CONSISTENCY (235 MB) does not ----
