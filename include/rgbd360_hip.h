@@ -97,17 +97,18 @@ int rgbd360_set_source_dev(rgbd360_ctx* ctx, const uint8_t* rgb_dev, size_t rgb_
  * (OdometryRGBD360.cpp:189-190 re-sets both frames every step). Builds the target gradients on device. */
 int rgbd360_promote_source_to_target(rgbd360_ctx* ctx);
 
-/* The arithmetic of the spherical warp (RPI.h:2663-2684 / 2959-2989: p' = R p + t, phi = asin(x / |p'|), theta = atan2(y, z) + PI,
- * row / column = round(...)) for every later pass of this context -- rgbd360_align360 and its _begin / _finish, the batch and
- * sequence entries that run on this context, the occlusion-aware passes, rgbd360_eval360, rgbd360_warp_indices:
+/* The arithmetic of the warp -- spherical (RPI.h:2663-2684 / 2959-2989: p' = R p + t, phi = asin(x / |p'|), theta = atan2(y, z) + PI,
+ * row / column = round(...)) and pinhole (RPI.h:701-708: column = round(x fx / z + ox), ...) -- for every later pass of this context:
+ * rgbd360_align360 and its _begin / _finish, the batch and sequence entries that run on this context, the occlusion-aware passes,
+ * rgbd360_eval*, rgbd360_warp_indices*, rgbd360_align_pinhole (the 8-sensor rgbd360_rig_* objects keep the device definition):
  *   0 (default): the device definition -- fused multiply-adds, two correctly rounded arctangent evaluations by one polynomial,
  *      round-half-up; mirrored bit for bit by the CPU checker's math_mode 1.  About 1e-4 of the pixels land on a neighbouring target
  *      pixel compared with the reference built against glibc.
  *   1: the REFERENCE's arithmetic -- Eigen's product order without fused multiply-adds, norm(), 1 / dist, asinf, atan2f + (double) PI,
  *      roundf, the two functions restated operation for operation from glibc 2.35's fdlibm float code (csrc/libm_f32.h; neither is
  *      correctly rounded, so "the same index" means that operation sequence).  Target indices, visibility and |p'|^2 are bit-equal to
- *      the reference's own; the per-pixel pass costs ~1.8 x.  (The pinhole path, RPI.h:701-708, has no transcendental and keeps its one
- *      definition.)
+ *      the reference's own; the spherical per-pixel pass costs ~1.8 x.  The pinhole warp has no transcendental: there the option means
+ *      the reference's operation order, 1.0 / z in double and roundf.
  * Returns -6 while an alignment is in flight. */
 int rgbd360_set_index_arithmetic(rgbd360_ctx* ctx, int mode);
 int rgbd360_get_index_arithmetic(rgbd360_ctx* ctx);

@@ -39,8 +39,25 @@ __global__ void k_src_rec_pinhole(const float* __restrict__ depth, const float* 
 
 // Device arithmetic definition of the pinhole warp (the oracle's math_mode 1 repeats it): fma rotation, correctly rounded
 // 1/Z, column = round(fma(X fx, 1/Z, ox)), row = round(fma(Y fy, 1/Z, oy)), round = floor(x + 0.5).
+// libm != 0 (rgbd360_set_index_arithmetic(ctx, 1)): the REFERENCE's arithmetic instead, RPI.h:701-708 as compiled -- Eigen's product order
+// without fused multiply-adds, inv_z = 1.0 / Z in double stored to float, (X fx) inv_z + ox, roundf, the x86 float -> int conversion; the
+// oracle's math_mode 0.
 __device__ __forceinline__ unsigned warp_pinhole(const PoseRT& T, float px, float py, float pz, const PinK& K, int rows, int cols,
-                                                 float& X, float& Y, float& Z, float& inv_z, bool& vis) {
+                                                 float& X, float& Y, float& Z, float& inv_z, bool& vis, int libm = 0) {
+    if (libm) {                                       // uniform (a kernel argument)
+        X = ((T.r00 * px + T.r01 * py) + T.r02 * pz) + T.tx;
+        Y = ((T.r10 * px + T.r11 * py) + T.r12 * pz) + T.ty;
+        Z = ((T.r20 * px + T.r21 * py) + T.r22 * pz) + T.tz;
+        inv_z = (float)(1.0 / (double)Z);
+        const float tc = (X * K.fx) * inv_z + K.ox;
+        const float tr = (Y * K.fy) * inv_z + K.oy;
+        const bool fin = isfinite(tr) && isfinite(tc);
+        const float fr = libm32::roundf_(fin ? tr : -1.f), fc = libm32::roundf_(fin ? tc : -1.f);
+        const int ri = (fr >= -2147483648.f && fr < 2147483648.f) ? (int)fr : (int)0x80000000;
+        const int ci = (fc >= -2147483648.f && fc < 2147483648.f) ? (int)fc : (int)0x80000000;
+        vis = fin && ((unsigned)ri < (unsigned)rows) && ((unsigned)ci < (unsigned)cols);
+        return (unsigned)(ri * cols + ci);
+    }
     X = fmaf(T.r02, pz, fmaf(T.r01, py, fmaf(T.r00, px, T.tx)));
     Y = fmaf(T.r12, pz, fmaf(T.r11, py, fmaf(T.r10, px, T.ty)));
     Z = fmaf(T.r22, pz, fmaf(T.r21, py, fmaf(T.r20, px, T.tz)));
@@ -80,7 +97,7 @@ __global__ __launch_bounds__(kEvalThreads) void k_eval_pinhole(LevelDev lv, PinK
         const float4 s = lv.src[in_range ? i : lv.n - 1];
         float X, Y, Z, iz;
         bool vis;
-        unsigned ti = warp_pinhole(T, s.x, s.y, s.z, K, lv.rows, lv.cols, X, Y, Z, iz, vis);
+        unsigned ti = warp_pinhole(T, s.x, s.y, s.z, K, lv.rows, lv.cols, X, Y, Z, iz, vis, lv.libm);
         vis = vis && in_range && (s.x != kInvalidPoint);
         ti = vis ? ti : 0u;
         bool evis = vis;                  // the pixel takes part in the error sums
@@ -214,7 +231,7 @@ __global__ __launch_bounds__(256) void k_pin_occ_keys(LevelDev lv, PinK K, Pose1
     const float4 s = lv.src[i];
     float X, Y, Z, iz;
     bool vis;
-    const unsigned ti = warp_pinhole(T, s.x, s.y, s.z, K, lv.rows, lv.cols, X, Y, Z, iz, vis);
+    const unsigned ti = warp_pinhole(T, s.x, s.y, s.z, K, lv.rows, lv.cols, X, Y, Z, iz, vis, lv.libm);
     const bool cand = vis && (s.x != kInvalidPoint);
     bool cand_e = cand, cand_h = cand;
     if (OCC == 2 && cand) {
@@ -307,7 +324,7 @@ __global__ __launch_bounds__(kPinWalkThreads) void k_pin_occ_walk(LevelDev lv, P
             const float4 s = lv.src[v & kPinOccIndex];
             float X, Y, Z, iz;
             bool vis;
-            (void)warp_pinhole(T, s.x, s.y, s.z, K, lv.rows, lv.cols, X, Y, Z, iz, vis);
+            (void)warp_pinhole(T, s.x, s.y, s.z, K, lv.rows, lv.cols, X, Y, Z, iz, vis, lv.libm);
             // the photometric and depth residuals of this pixel on this target (both passes use the same expressions)
             float wpf = 0.f, rp = 0.f, wd = 0.f, rd = 0.f;
             {
@@ -406,7 +423,7 @@ __global__ void k_warp_indices_pinhole(LevelDev lv, PinK K, Pose16 pose, int32_t
     if (s.x != kInvalidPoint) {
         float X, Y, Z, iz;
         bool vis;
-        const unsigned ti = warp_pinhole(T, s.x, s.y, s.z, K, lv.rows, lv.cols, X, Y, Z, iz, vis);
+        const unsigned ti = warp_pinhole(T, s.x, s.y, s.z, K, lv.rows, lv.cols, X, Y, Z, iz, vis, lv.libm);
         if (vis) {
             r = (int)(ti / (unsigned)lv.cols);
             c = (int)ti - r * lv.cols;

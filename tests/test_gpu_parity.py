@@ -2322,3 +2322,30 @@ def test_alignment_in_the_reference_arithmetic_follows_the_libm_oracle(hip_lib, 
     assert status[0] == 0 and list(iters[0]) == reg.num_iterations
     rot, trans = synth.pose_error(poses[0], pose_ref)
     assert rot <= POSE_TOL_DEV and trans <= POSE_TOL_DEV, (rot, trans)
+
+
+@pytest.mark.parametrize("depth_f32", [False, True])
+def test_pinhole_warp_and_alignment_in_the_reference_arithmetic(hip_lib, oracle_mod, depth_f32):
+    """rgbd360_set_index_arithmetic(ctx, 1) on the pinhole path (RPI.h:701-708 as compiled: no fused multiply-adds, 1.0 / Z in double,
+    roundf): target indices bit-equal to the oracle's math_mode 0 on every level, the Levenberg-Marquardt alignment on the libm oracle's
+    accept / reject sequence (float64 sums), plain and occlusion-aware."""
+    (rgbA, dA), (rgbB, dB), T, K = synth.make_pinhole_pair(320, 240, seed=77, depth_f32=depth_f32)
+    reg = _mk(hip_lib, 3, setMaskSeams=False)
+    reg.set_index_arithmetic(1)
+    reg.setCameraMatrix(K)
+    reg.setTargetFrame(rgbA, dA)
+    reg.setSourceFrame(rgbB, dB)
+    ora = oracle_mod.Oracle(n_pyr=3, math_mode=0, reduce_mode=1, mask_seams=0)
+    ora.set_camera(*K)
+    ora.set_target(rgbA, dA)
+    ora.set_source(rgbB, dB)
+    for occlusion in (0, 1, 2):
+        rc = reg.alignFrames(np.eye(4), 2, occlusion)           # (builds the per-alignment source records the index kernel reads)
+        st, pose_ref = ora.align_pinhole(np.eye(4), 2, occlusion)
+        assert rc == st and (occlusion != 0 or rc == 0), (occlusion, rc, st)      # (the occlusion-aware runs of this pair may end without residuals: both sides alike)
+        assert reg.num_iterations == list(ora.result.iters)[:3], (occlusion, reg.num_iterations, list(ora.result.iters)[:3])
+        rot, trans = synth.pose_error(reg.getOptimalPose(), pose_ref)
+        assert rot <= PINHOLE_ROT_TOL_DEV and trans <= PINHOLE_TRANS_TOL_DEV, (occlusion, rot, trans)
+    for level in range(3):
+        for P in _poses(T):
+            assert np.array_equal(reg.warp_indices_pinhole(level, P), ora.warp_indices_pinhole(level, P)), level

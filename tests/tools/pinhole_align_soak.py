@@ -15,6 +15,7 @@ from oracle import oracle as O
 O.set_num_threads(min(16, os.cpu_count() or 1))
 n_trials = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 23)      # [seed]: another draw of cases
+LIBM = len(sys.argv) > 3 and sys.argv[3] == "libm"      # [libm]: the device in the reference's warp arithmetic; its oracle is then modes (0, 1)
 bad = near = n00 = n01 = nseq = 0
 for t in range(n_trials):
     W, H = [(160, 120), (200, 152), (320, 240), (480, 360), (640, 480)][int(rng.integers(0, 5))]
@@ -33,10 +34,12 @@ for t in range(n_trials):
     reg = RegisterPhotoICP()
     reg.setNumPyr(n_pyr)
     reg.setMaskSeams(False)
+    if LIBM:
+        reg.set_index_arithmetic(1)
     reg.setCameraMatrix(np.array([[K[0], 0, K[2]], [0, K[1], K[3]], [0, 0, 1]]))
     reg.setTargetFrame(rgbA, dA)
     reg.setSourceFrame(rgbB, dB)
-    ora = O.Oracle(n_pyr=n_pyr, math_mode=1, reduce_mode=1, mask_seams=0)
+    ora = O.Oracle(n_pyr=n_pyr, math_mode=0 if LIBM else 1, reduce_mode=1, mask_seams=0)
     ora.set_camera(*K)
     ora.set_target(rgbA, dA)
     ora.set_source(rgbB, dB)
@@ -90,6 +93,6 @@ for t in range(n_trials):
           "libm oracle %.1e rad %.1e m%s -> %s" % (t, W, H, n_pyr, method, occlusion, trans, rot, "float32" if f32 else "uint16",
                                                   "yes" if not np.array_equal(guess, np.eye(4)) else "no", rc, st, it_gpu, it_ora, r1, t1, r0, t0, note,
                                                   "ok" if good else "FAIL"), flush=True)
-print("pinhole align soak: %d / %d trials ok against the device-arithmetic oracle (%d of them with a coin-toss step: another sequence); inside 1e-4 rad / 1e-3 m with the same "
+print(("pinhole align soak, device in the reference's warp arithmetic: " if LIBM else "pinhole align soak: ") + "%d / %d trials ok against the device-arithmetic oracle (%d of them with a coin-toss step: another sequence); inside 1e-4 rad / 1e-3 m with the same "
       "sequence against libm + float32 accumulators: %d, against libm + float64 sums: %d; another sequence under libm: %d" % (n_trials - bad, n_trials, near, n00, n01, nseq))
 sys.exit(1 if bad else 0)
