@@ -1505,7 +1505,7 @@ int rgbd360_selftest_libm(rgbd360_ctx* ctx, uint32_t first_bits, uint32_t count,
             if ((u & 0x7fffffffu) <= 0x3fc00000u) {
                 const bool bad = differ(h[k], asinf(v));
                 mismatches[0] += bad;
-                if (bad && shown < 6 && getenv("RGBD360_SELFTEST_VERBOSE")) {
+                if (bad && shown < 6 && knobs::debug("RGBD360_SELFTEST_VERBOSE")) {      // (debug builds: the first mismatches on stderr)
                     ++shown;
                     fprintf(stderr, "[selftest_libm] asinf(%.9g = 0x%08x): device %.9g, library %.9g\n", (double)v, u, (double)h[k], (double)asinf(v));
                 }
