@@ -2261,7 +2261,7 @@ def test_libm_restatement_on_the_device_equals_the_c_library(hip_lib):
         assert bad == (0, 0, 0, 0), (hex(first), bad)
 
 
-@pytest.mark.parametrize("W,H", [(256, 128), (2048, 1024)])
+@pytest.mark.parametrize("W,H", [(256, 128), (2048, 1024), (4096, 2048)])
 def test_warp_indices_in_the_reference_arithmetic_are_bit_exact(hip_lib, oracle_mod, W, H):
     """rgbd360_set_index_arithmetic(ctx, 1): every target index and the visibility of every source pixel equal the oracle's math_mode 0
     (the C library's asinf / atan2f / roundf on the CPU) -- at the identity, the true motion and perturbed poses, on every level.  In the
