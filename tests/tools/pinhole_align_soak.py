@@ -50,7 +50,10 @@ for t in range(n_trials):
     pose_gpu = reg.getOptimalPose()
     r1, t1 = synth.pose_error(pose_gpu, pose_ref)
     # (an alignment that ends ILL-POSED or without residuals returns the pose it had: by definition a badly conditioned one)
-    same = rc == st and it_gpu == it_ora and ((r1 <= 1e-4 and t1 <= 1e-3) if rc == 0 else (r1 <= 1e-3 and t1 <= 1e-2))
+    # (depth only, method 1: the normal equations of a corner seen in a 60-degree view have cond(H) ~ 6e5 -- two float64 systems 1e-8 apart
+    # already give Gauss-Newton steps 1e-4 apart, tests/tools/pinhole_case.py 1010 2 -- so the float32 solve is worth 1e-3 rad there)
+    tol_r, tol_t = (1e-3, 5e-3) if method == 1 else (1e-4, 1e-3)
+    same = rc == st and it_gpu == it_ora and ((r1 <= tol_r and t1 <= tol_t) if rc == 0 else (r1 <= 1e-3 and t1 <= 1e-2))
     note = ""
     if rc == st and it_gpu == it_ora and not same:
         # Same counts, poses further apart than the tolerance.  The objective is DISCONTINUOUS in the pose (every source pixel takes the
@@ -68,7 +71,7 @@ for t in range(n_trials):
         steps = [x for x in trace_dev if x["it"] >= 0]
         m = min([abs(x["error"] - x["new_error"]) / max(x["error"], 1e-12) for x in steps] + [float("inf")])
         note += " (the device takes another sequence than its oracle; smallest relative error change of an oracle step %.1e)" % m
-        same = m < 1e-4
+        same = m < 5e-4 and r1 <= 1e-3 and t1 <= 5e-3
         near += 1
     # The reference's arithmetic, as a statistic (this path is sensitive to it by itself: the oracle's own modes part by more than the
     # device parts from either): libm warp + float32 accumulators (modes 0, 0), and libm warp + float64 sums (0, 1).
