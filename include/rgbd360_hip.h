@@ -100,7 +100,8 @@ int rgbd360_promote_source_to_target(rgbd360_ctx* ctx);
 /* The arithmetic of the warp -- spherical (RPI.h:2663-2684 / 2959-2989: p' = R p + t, phi = asin(x / |p'|), theta = atan2(y, z) + PI,
  * row / column = round(...)) and pinhole (RPI.h:701-708: column = round(x fx / z + ox), ...) -- for every later pass of this context:
  * rgbd360_align360 and its _begin / _finish, the batch and sequence entries that run on this context, the occlusion-aware passes,
- * rgbd360_eval*, rgbd360_warp_indices*, rgbd360_align_pinhole (the 8-sensor rgbd360_rig_* objects keep the device definition):
+ * rgbd360_eval*, rgbd360_warp_indices*, rgbd360_align_pinhole; the sibling contexts and engines a sequence call creates inherit it, a
+ * multi-GPU handle has rgbd360_multi_set_index_arithmetic (the 8-sensor rgbd360_rig_* objects keep the device definition):
  *   0 (default): the device definition -- fused multiply-adds, two correctly rounded arctangent evaluations by one polynomial,
  *      round-half-up; mirrored bit for bit by the CPU checker's math_mode 1.  About 1e-4 of the pixels land on a neighbouring target
  *      pixel compared with the reference built against glibc.
@@ -167,6 +168,8 @@ void rgbd360_multi_destroy(rgbd360_multi* m);
 const char* rgbd360_multi_last_error(rgbd360_multi* m);
 int  rgbd360_multi_n_gpus(rgbd360_multi* m);
 int  rgbd360_multi_uses_rccl(rgbd360_multi* m);
+/* rgbd360_set_index_arithmetic on every device's context of the handle (0: device definition, 1: the reference's libm arithmetic). */
+int  rgbd360_multi_set_index_arithmetic(rgbd360_multi* m, int mode);
 /* Contiguous balanced partition used by the sharding: the first n_items % world ranks get one item more. */
 void rgbd360_shard_range(int n_items, int rank, int world, int* lo, int* hi);
 /* Layout of the exchange step (ncclAllGather wants equal counts): every rank contributes rows_per_rank = ceil(n_pairs / world) result

@@ -18,7 +18,7 @@ SYMBOLS = [
     "rgbd360_set_camera", "rgbd360_align_pinhole", "rgbd360_eval_pinhole", "rgbd360_eval_pinhole_occ", "rgbd360_use_saliency", "rgbd360_warp_indices_pinhole",
     "rgbd360_pbmap_default_params", "rgbd360_register_planes", "rgbd360_bilateral_filter",
     "rgbd360_cloud_planes", "rgbd360_sensor_cloud", "rgbd360_sensor_planes", "rgbd360_sensor_planes_ex", "rgbd360_sensor_cloud_ex", "rgbd360_depth_model_load", "rgbd360_depth_model_free", "rgbd360_depth_model_info", "rgbd360_depth_model_undistort", "rgbd360_merge_planes", "rgbd360_group_planes", "rgbd360_pool_sensor_planes", "rgbd360_debug_set_schedule", "rgbd360_debug_set_sequence_route", "rgbd360_debug_knobs_enabled", "rgbd360_frame_planes_stage_timing", "rgbd360_frame_planes_stage_times", "rgbd360_planes_available", "rgbd360_set_plane_refinement", "rgbd360_plane_refinement_stats", "rgbd360_set_plane_color_image",
-    "rgbd360_multi_create", "rgbd360_multi_destroy", "rgbd360_multi_last_error", "rgbd360_multi_n_gpus", "rgbd360_multi_uses_rccl",
+    "rgbd360_multi_create", "rgbd360_multi_destroy", "rgbd360_multi_last_error", "rgbd360_multi_n_gpus", "rgbd360_multi_uses_rccl", "rgbd360_multi_set_index_arithmetic",
     "rgbd360_shard_range", "rgbd360_gather_slot", "rgbd360_multi_align_sequence", "rgbd360_multi_load_sequence", "rgbd360_multi_align_resident",
     "rgbd360_align360_batch_multi", "rgbd360_time_eval_kernel_rotating", "rgbd360_forced_iters_batch",
     "rgbd360_rig_create", "rgbd360_rig_destroy", "rgbd360_rig_last_error", "rgbd360_rig_set_target", "rgbd360_rig_set_source",
@@ -174,6 +174,7 @@ def load() -> C.CDLL:
     L.rgbd360_multi_last_error.restype = C.c_char_p
     L.rgbd360_multi_n_gpus.argtypes = [vp]
     L.rgbd360_multi_uses_rccl.argtypes = [vp]
+    L.rgbd360_multi_set_index_arithmetic.argtypes = [vp, C.c_int]
     L.rgbd360_shard_range.argtypes = [i32, i32, i32, C.POINTER(i32), C.POINTER(i32)]
     L.rgbd360_shard_range.restype = None
     L.rgbd360_gather_slot.argtypes = [i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]

@@ -252,6 +252,14 @@ int rgbd360_multi_create(const rgbd360_params* p, int n_gpus, const int* device_
 const char* rgbd360_multi_last_error(rgbd360_multi* m) { return m ? m->err.c_str() : "null handle"; }
 int rgbd360_multi_n_gpus(rgbd360_multi* m) { return m ? m->n_gpus : 0; }
 int rgbd360_multi_uses_rccl(rgbd360_multi* m) { return m && m->use_rccl ? 1 : 0; }
+int rgbd360_multi_set_index_arithmetic(rgbd360_multi* m, int mode) {      // every device's context (and its engines / siblings) follows
+    if (!m) return -1;
+    for (rgbd360_ctx* c : m->ctx) {
+        const int rc = rgbd360_set_index_arithmetic(c, mode);
+        if (rc) return mfail(m, rc, rgbd360_last_error(c));
+    }
+    return 0;
+}
 
 int rgbd360_multi_align_sequence(rgbd360_multi* m, int n_frames, const uint8_t* const* rgb, size_t rgb_step, const void* const* depth,
                                  size_t depth_step, int depth_type, int rows, int cols, const float guess[16], int method, int occlusion,

@@ -869,7 +869,10 @@ static int align360_batch_threads(rgbd360_ctx* ctx, int n_frames, const uint8_t*
     }
     std::vector<rgbd360_ctx*> cs(k_ctx);
     cs[0] = ctx;
-    for (int c = 1; c < k_ctx; ++c) cs[c] = ctx->siblings[c - 1];
+    for (int c = 1; c < k_ctx; ++c) {
+        cs[c] = ctx->siblings[c - 1];
+        if (cs[c]->index_libm != ctx->index_libm) rgbd360_set_index_arithmetic(cs[c], ctx->index_libm);      // the siblings follow the context's warp arithmetic
+    }
     // contiguous balanced spans [a, b) of pairs per context
     std::vector<int> a(k_ctx), b(k_ctx);
     for (int c = 0; c < k_ctx; ++c) {
@@ -1681,6 +1684,7 @@ extern "C" int rgbd360_set_index_arithmetic(rgbd360_ctx* ctx, int mode) {
     ctx->index_libm = mode;
     for (Level& L : ctx->levels) L.libm = mode;
     for (SeqEngine* E : ctx->engines) E->libm = mode;
+    for (rgbd360_ctx* sib : ctx->siblings) rgbd360_set_index_arithmetic(sib, mode);
     return 0;
 }
 extern "C" int rgbd360_get_index_arithmetic(rgbd360_ctx* ctx) { return ctx ? ctx->index_libm : -1; }

@@ -46,6 +46,12 @@ class MultiGpuSequence:
     def uses_rccl(self) -> bool:
         return bool(self._L.rgbd360_multi_uses_rccl(self._h))
 
+    def set_index_arithmetic(self, mode: int):
+        """rgbd360_multi_set_index_arithmetic: 1 = the warp in the reference's libm arithmetic on every device (see RegisterPhotoICP)."""
+        rc = self._L.rgbd360_multi_set_index_arithmetic(self._h, int(mode))
+        if rc != 0:
+            raise Rgbd360Error(f"rgbd360_multi_set_index_arithmetic failed ({rc}): {self._L.rgbd360_multi_last_error(self._h).decode()}")
+
     def close(self):
         if getattr(self, "_h", None) is not None:
             self._L.rgbd360_multi_destroy(self._h)

@@ -2349,3 +2349,43 @@ def test_pinhole_warp_and_alignment_in_the_reference_arithmetic(hip_lib, oracle_
     for level in range(3):
         for P in _poses(T):
             assert np.array_equal(reg.warp_indices_pinhole(level, P), ora.warp_indices_pinhole(level, P)), level
+
+
+def test_reference_arithmetic_reaches_sibling_contexts_engines_and_the_multi_handle(hip_lib, oracle_mod):
+    """rgbd360_set_index_arithmetic is a property of the context every route of it inherits: the sibling contexts of the per-context sequence
+    route (occlusion-aware sequences), the lock-step engines, and the devices of a multi-GPU handle -- a 5-frame sequence gives, pair by
+    pair, the poses of single alignments in the same arithmetic (bit for bit), and these differ from the default arithmetic's."""
+    from rgbd360_amd.multi import MultiGpuSequence
+    frames = [synth.render(synth.trajectory_pose(k, 3), 256, 128, 3) for k in range(5)]
+    reg = _mk(hip_lib, 3)
+    out = {}
+    for mode in (0, 1):
+        reg.set_index_arithmetic(mode)
+        single = []
+        for k in range(4):
+            reg.setTargetFrame(*frames[k])
+            reg.setSourceFrame(*frames[k + 1])
+            assert reg.alignFrames360(np.eye(4), 2, 2) == 0
+            single.append(reg.getOptimalPose().copy())
+        poses_occ, st_occ, _ = reg.alignSequence(frames, method=2, occlusion=2, n_inflight=4)        # per-context route: three siblings
+        poses_eng, st_eng, _ = reg.alignSequence(frames, method=2, occlusion=0, n_inflight=4)        # lock-step engines
+        assert list(st_occ) == [0] * 4 and list(st_eng) == [0] * 4
+        for k in range(4):
+            assert np.array_equal(poses_occ[k], single[k]), (mode, k)
+        plain = []
+        for k in range(4):
+            reg.setTargetFrame(*frames[k])
+            reg.setSourceFrame(*frames[k + 1])
+            reg.alignFrames360(np.eye(4), 2, 0)
+            plain.append(reg.getOptimalPose().copy())
+            assert np.array_equal(poses_eng[k], plain[k]), (mode, k)
+        out[mode] = (single, plain)
+    assert any(not np.array_equal(a, b) for a, b in zip(out[0][1], out[1][1]))      # the two arithmetics are not the same function
+    m = MultiGpuSequence(n_gpus=1, n_pyr=3)
+    try:
+        m.set_index_arithmetic(1)
+        poses_m, st_m, _ = m.align_sequence(frames, method=2)
+        for k in range(4):
+            assert np.array_equal(poses_m[k], out[1][1][k]), k
+    finally:
+        m.close()
