@@ -1,7 +1,8 @@
 // Host check of rgbd360_amd/csrc/libm_f32.h against the C library this box links (the reference's asinf / atanf / atan2f / roundf):
 // asinf on every float of [-1, 1] and beyond, atanf and roundf on every float, atan2f on N random pairs (all binades of the warp's operand
 // range, every sign combination, zeros) -- bit for bit.
-//   g++ -O2 -ffp-contract=off -pthread -o /tmp/libm_f32_check tools/libm_f32_check.cpp && /tmp/libm_f32_check [pairs_in_millions]
+//   g++ -O2 -ffp-contract=off -pthread -o /tmp/libm_f32_check tools/libm_f32_check.cpp && /tmp/libm_f32_check [pairs_in_millions [stride]]
+//   (stride > 1: every stride-th float only -- the CPU test suite's quick form, tests/test_libm_restatement.py)
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -17,13 +18,14 @@ static bool same(float a, float b) {
 int main(int argc, char** argv) {
     const unsigned T = std::max(1u, std::thread::hardware_concurrency());
     const long long pairs = (argc > 1 ? atoll(argv[1]) : 2000) * 1000000LL;
+    const uint64_t stride = argc > 2 ? (uint64_t)atoll(argv[2]) : 1;
     std::atomic<unsigned long long> bad_asin{0}, bad_atan{0}, bad_round{0}, bad_atan2{0};
     std::atomic<uint32_t> first_asin{0}, first_atan{0}, first_round{0};
     std::vector<std::thread> th;
     for (unsigned t = 0; t < T; ++t)
         th.emplace_back([&, t] {
             unsigned long long ba = 0, bt = 0, br = 0;
-            for (uint64_t u = t; u < (1ull << 32); u += T) {
+            for (uint64_t u = t * stride; u < (1ull << 32); u += T * stride) {
                 const float x = libm32::u2f((uint32_t)u);
                 const uint32_t ix = (uint32_t)u & 0x7fffffffu;
                 if (ix <= 0x3fc00000u && !same(libm32::asinf_(x), asinf(x))) {      // |x| <= 1.5: the NaN branch too
